@@ -1,0 +1,212 @@
+"""ORACLE tooling (test infrastructure): generate tests/golden/*.npz by running the REAL reference.
+
+Runs only in the build container, where /root/reference exists.  It imports the reference's own
+Python modules (never copies them), drives `TransientTrainer.train(..., is_copy_grad=True)` on seeded
+synthetic batches and stores inputs + expected outputs as data fixtures.  Recipe: SURVEY.md 8(c).
+
+    python oracle/make_golden.py            # F0 (tiny), F1 (small-real)
+    python oracle/make_golden.py --ns       # additionally the north-star-size checksum record (~1 min)
+"""
+import argparse
+import hashlib
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+OUT = os.path.join(ROOT, 'tests', 'golden')
+
+
+def _edit_distance(a, b):
+    prev = list(range(len(b) + 1))
+    for i, ca in enumerate(a, 1):
+        cur = [i]
+        for j, cb in enumerate(b, 1):
+            cur.append(min(prev[j] + 1, cur[-1] + 1, prev[j - 1] + (ca != cb)))
+        prev = cur
+    return prev[-1]
+
+
+def bootstrap_reference():
+    def stub(name, **kw):
+        m = types.ModuleType(name)
+        m.__dict__.update(kw)
+        sys.modules[name] = m
+    stub('Levenshtein', distance=_edit_distance)
+    stub('stanfordcorenlp', StanfordCoreNLP=object)
+    stub('torchaudio')
+    stub('transformers', BertModel=object)
+    sys.path.insert(0, '/root/reference')
+    import torch
+    torch.Tensor.cuda = lambda self, *a, **k: self      # SURVEY Q5 workaround (args.cuda=True on CPU)
+    return torch
+
+
+def tensor_digest(t, full_below=2048, nsample=256):
+    """sum / l2 in fp64, plus the whole tensor when small, else a strided sample."""
+    a = t.detach().cpu().numpy().astype(np.float32).reshape(-1)
+    d = {'sum': np.float64(a.astype(np.float64).sum()), 'l2': np.float64(np.sqrt((a.astype(np.float64) ** 2).sum())),
+         'numel': np.int64(a.size)}
+    if a.size <= full_below:
+        d['full'] = a.copy()
+    else:
+        step = max(a.size // nsample, 1)
+        d['sample'] = a[::step][:nsample].copy()
+        d['step'] = np.int64(step)
+    return d
+
+
+def pack(prefix, named, store):
+    for name, t in named:
+        for k, v in tensor_digest(t).items():
+            store['%s/%s/%s' % (prefix, name, k)] = v
+
+
+FIXTURES = {
+    # tiny: exercises Q2 (length 10 of 64 -> masks on the 16-wide pooled axis) and target padding
+    'F0': dict(cfg=dict(num_enc_layers=1, num_dec_layers=1, num_heads=8, dim_model=128, dim_key=16, dim_value=16,
+                        dim_inner=128, dim_emb=128, src_max_len=500, tgt_max_len=100, r=100, vocab_size=64),
+               k=2, T=64, L=8, n_tasks=3, lr=1e-2, meta_lr=1e-3, iters=2, variable=True),
+    # small-real: the north-star architecture on short inputs
+    'F1': dict(cfg=dict(num_enc_layers=2, num_dec_layers=4, num_heads=8, dim_model=512, dim_key=64, dim_value=64,
+                        dim_inner=512, dim_emb=512, src_max_len=500, tgt_max_len=100, r=100, vocab_size=3765),
+               k=2, T=64, L=8, n_tasks=3, lr=1e-4, meta_lr=1e-4, iters=1, variable=True),
+    # north-star size, checksum-only
+    'NS': dict(cfg=dict(num_enc_layers=2, num_dec_layers=4, num_heads=8, dim_model=512, dim_key=64, dim_value=64,
+                        dim_inner=512, dim_emb=512, src_max_len=5000, tgt_max_len=2500, r=100, vocab_size=3765),
+               k=8, T=1000, L=100, n_tasks=3, lr=1e-4, meta_lr=1e-4, iters=1, variable=False),
+}
+
+
+def run_fixture(name, spec, torch):
+    from utils.data import Vocab
+    from utils.functions import init_transformer_model
+    from trainer.asr.transient_trainer import TransientTrainer
+    sys.path.insert(0, ROOT)
+    from oracle.refimpl import synth_batch
+
+    cfg = spec['cfg']
+    vocab = Vocab()
+    for i in range(cfg['vocab_size'] - 4):
+        ch = chr(0x4e00 + i)
+        vocab.add_token(ch)
+        vocab.add_label(ch)
+    args = argparse.Namespace(
+        feat_extractor='vgg_cnn', sample_rate=16000, window_size=.02, feat='spectrogram', dim_input=161,
+        num_enc_layers=cfg['num_enc_layers'], num_dec_layers=cfg['num_dec_layers'], num_heads=cfg['num_heads'],
+        dim_model=cfg['dim_model'], dim_key=cfg['dim_key'], dim_value=cfg['dim_value'], dim_inner=cfg['dim_inner'],
+        dim_emb=cfg['dim_emb'], src_max_len=cfg['src_max_len'], tgt_max_len=cfg['tgt_max_len'], dropout=0.0,
+        emb_trg_sharing=False, label_smoothing=0.0, name='golden_' + name, lr=spec['lr'], meta_lr=spec['meta_lr'],
+        k_train=spec['k'], k_valid=spec['k'], cuda=True, clip=False, max_norm=400, save_every=10 ** 9,
+        save_folder='/tmp/golden_ckpt')
+    torch.manual_seed(123456)
+    np.random.seed(123456)
+    torch.set_num_threads(8)
+    model = init_transformer_model(args, vocab, is_factorized=False, r=cfg['r'])
+
+    store = {}
+    names = [n for n, _ in model.named_parameters()]
+    h = hashlib.sha256()
+    for _, p in model.named_parameters():
+        h.update(p.detach().numpy().tobytes())
+    store['theta0_sha256'] = np.frombuffer(h.hexdigest().encode(), dtype=np.uint8)
+    pack('theta0', model.named_parameters(), store)
+
+    n, k, T, L = spec['n_tasks'], spec['k'], spec['T'], spec['L']
+
+    class FakeTask:
+        """duck-types SpectrogramDataset.sample (utils/data_loader.py:245-321)"""
+
+        def __init__(self, task):
+            self.task, self.calls = task, 0
+
+        def sample(self, k_train, k_valid, manifest_id):
+            it = self.calls
+            self.calls += 1
+            out = []
+            for part in (0, 1):
+                x, lens, y = synth_batch(1000 * it + 10 * self.task + part, k, T, L, cfg['vocab_size'],
+                                         variable=spec['variable'])
+                tl = (y != 0).sum(1).to(torch.int32)
+                out.append((x, lens, lens.float() / T, y, tl))
+            return tuple(out)
+
+    tasks = [FakeTask(m) for m in range(n)]
+
+    fwd_log = []
+
+    def fwd_hook(mod, inp, outp):
+        pred, gold, hyp = outp
+        import torch.nn.functional as F
+        loss = F.cross_entropy(pred.detach().view(-1, pred.size(2)), gold.view(-1), ignore_index=0, reduction='mean')
+        fwd_log.append((pred.detach().clone(), gold.clone(), hyp.clone(), float(loss)))
+    model.register_forward_hook(fwd_hook)
+
+    G_log, theta_log, cer_log = [], [], []
+    orig_from = model.from_copy_grad
+
+    def from_hook():
+        G_log.append([g.clone() for g in model.copy_grad])
+        orig_from()
+    model.from_copy_grad = from_hook
+
+    trainer = TransientTrainer()
+    orig_fob = trainer.forward_one_batch
+
+    def fob(*a, **kw):
+        loss, cer, nchar = orig_fob(*a, **kw)
+        cer_log.append((int(cer), int(nchar)))
+        return loss, cer, nchar
+    trainer.forward_one_batch = fob
+
+    # one call per iteration so theta can be snapshotted in between (optimizers persist)
+    inner = torch.optim.SGD(model.parameters(), lr=args.lr)
+    outer = torch.optim.Adam(model.parameters(), lr=args.meta_lr)
+    os.makedirs('log', exist_ok=True)
+    for it in range(spec['iters']):
+        trainer.train(model, vocab, tasks, [], 'ce', it, it + 1, args, inner_opt=inner, outer_opt=outer,
+                      evaluate_every=10 ** 9, early_stop='cer,200', is_copy_grad=True)
+        theta_log.append([p.detach().clone() for p in model.parameters()])
+    # the trainer's prefetch thread runs one sample() ahead per train() call; data seeds are keyed on the
+    # per-task call counter, so record which `it` seeds each iteration actually consumed.
+    assert len(G_log) == spec['iters'] and len(fwd_log) == 2 * n * spec['iters']
+
+    store['cfg_keys'] = np.array(sorted(cfg.keys()))
+    store['cfg_vals'] = np.array([cfg[k_] for k_ in sorted(cfg.keys())], dtype=np.int64)
+    store['spec'] = np.array([spec['k'], spec['T'], spec['L'], spec['n_tasks'], spec['iters'], int(spec['variable'])],
+                             dtype=np.int64)
+    store['lr'] = np.float64(spec['lr'])
+    store['meta_lr'] = np.float64(spec['meta_lr'])
+    store['param_names'] = np.array(names)
+    # data-call index consumed by iteration `it`: trainer.train() prefetches once before the loop and once inside,
+    # so each train() call draws 2 samples per task and uses the first.
+    store['data_call_index'] = np.array([2 * it for it in range(spec['iters'])], dtype=np.int64)
+    for it in range(spec['iters']):
+        pack('G/%d' % it, zip(names, G_log[it]), store)
+        pack('theta/%d' % (it + 1), zip(names, theta_log[it]), store)
+        for j in range(2 * n):
+            pred, gold, hyp, loss = fwd_log[it * 2 * n + j]
+            key = 'fwd/%d/%d' % (it, j)
+            store[key + '/gold'] = gold.numpy().astype(np.int64)
+            store[key + '/hyp'] = hyp.numpy().astype(np.int64)
+            store[key + '/loss'] = np.float64(loss)
+            store[key + '/cer'] = np.array(cer_log[it * 2 * n + j], dtype=np.int64)
+            for k_, v in tensor_digest(pred).items():
+                store[key + '/pred/' + k_] = v
+    os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **store)
+    print(name, 'written:', len(store), 'arrays; losses', [round(f[3], 6) for f in fwd_log])
+
+
+if __name__ == '__main__':
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--ns', action='store_true')
+    ap.add_argument('--only', default='')
+    a = ap.parse_args()
+    torch = bootstrap_reference()
+    todo = [a.only] if a.only else (['F0', 'F1'] + (['NS'] if a.ns else []))
+    for name in todo:
+        run_fixture(name, FIXTURES[name], torch)
