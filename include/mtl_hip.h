@@ -1,0 +1,126 @@
+/* mtl_hip.h -- C ABI of libmtl_hip.so: the MI355X (gfx950) kernels of the meta-transfer-learning hot path.
+ *
+ * Drop-in boundary.  The reference (audioku/meta-transfer-learning) has no FFI layer: its
+ * hot path is Python calling stock PyTorch ops.  This library supplies, as hand-written HIP, every op that
+ * path issues; each entry point cites the reference call site(s) it replaces (paths relative to the reference
+ * repository root).  The Python host layer (meta-transfer-learning_amd/) binds these with ctypes and keeps the
+ * reference's own Python signatures (Transformer.forward, TransientTrainer.train, ...).  INTEGRATION.md shows
+ * the ctypes stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer into caller-owned memory unless named `*_host`; the library never
+ *     allocates, frees or retains memory.  Scratch space is passed in (`workspace`, size from *_workspace()).
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  No call synchronises the device.
+ *   - return 0 on success, a negative errno-style code otherwise (-22 bad argument, -5 launch failure);
+ *     nothing throws or aborts.  Re-entrant; one host thread per device.
+ *   - all tensors fp32 row-major unless stated; token ids int64 (`long`), lengths int32.
+ *   - activations inside the conv stack are channels-last with TIME outermost: (B, T, F, C).
+ *   - "accum" outputs are ADDED to (gradient accumulation semantics of .backward()).
+ *   - all reductions are fixed-order (no floating-point atomics): results are run-to-run deterministic.
+ */
+#ifndef MTL_HIP_H
+#define MTL_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int mtl_abi_version(void);
+
+/* ---- GEMM on the fp32 matrix cores (v_mfma_f32_32x32x2_f32) -------------------------------------------
+ * C[z] = epilogue( alpha * opA(A[z]) . opB(B[z]) ),  z = 0..batch-1,  operand z at  base + (z/H)*s?b + (z%H)*s?h
+ *   transA = 0: A is M x K (lda)   | 1: A is stored K x M (lda)
+ *   transB = 0: B is K x N (ldb)   | 1: B is stored N x K (ldb)
+ *   epilogue: + bias[n] (nullable) ; ReLU if flags&MTL_GEMM_RELU ; zero where gate[m*ldg+n] <= 0 (nullable,
+ *             same batch offsets as C) ; += C if flags&MTL_GEMM_ACCUM.
+ * Replaces nn.Linear forward/backward (modules/encoder.py:72; modules/common_layers.py:130,287-289,303;
+ * modules/decoder.py:108-110) and torch.bmm (modules/common_layers.py:321,329) incl. the permute/contiguous
+ * copies at common_layers.py:291-293,301 (heads are addressed by stride instead). */
+#define MTL_GEMM_RELU 1
+#define MTL_GEMM_ACCUM 2
+int mtl_gemm_f32(void* stream, int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
+                 const float* B, int ldb, float* C, int ldc, const float* bias, const float* gate, int ldg, int flags,
+                 int batch, int H, long sAb, long sAh, long sBb, long sBh, long sCb, long sCh);
+
+/* ---- VGG front-end: models/asr/transformer.py:48-59 (Conv2d 3x3 s1 p1 + ReLU [+ MaxPool2d(2,2)]) ------
+ * x_ref is the reference's (B,1,F,T) input; everything downstream is (B,T,F,C). */
+int mtl_conv0_relu_fwd(void* stream, const float* x_ref, const float* w /*(64,1,3,3)*/, const float* bias, float* y,
+                       int B, int T, int F);
+long mtl_conv0_wgrad_workspace(void);
+int mtl_conv0_wgrad(void* stream, const float* x_ref, const float* dy, float* dw /*accum*/, float* db /*accum*/,
+                    float* workspace, int B, int T, int F);
+/* (Cout,Cin,3,3) -> w_fwd [9][Cin][Cout] and w_dgrad [9][Cout][Cin] (taps rotated 180 degrees) */
+int mtl_conv3x3_wprep(void* stream, const float* w_ref, float* w_fwd, float* w_dgrad, int Cout, int Cin);
+int mtl_conv3x3_relu_fwd(void* stream, const float* x, const float* w_fwd, const float* bias, float* y, int B, int T,
+                         int F, int Cin, int Cout);
+/* fused conv + bias + ReLU + 2x2 max-pool (floor mode; first maximum in torch's window order wins):
+ * p_out (B,T/2,F/2,Cout), argmax u8 in {0..3} = 2*(f&1) + (t&1).  The un-pooled activation is never written. */
+int mtl_conv3x3_relu_pool_fwd(void* stream, const float* x, const float* w_fwd, const float* bias, float* p_out,
+                              unsigned char* argmax, int B, int T, int F, int Cin, int Cout);
+/* dx = conv_transpose(dy) gated by ReLU of the forward input activation `act` (same shape as dx).
+ * argmax != NULL: dy is the POOLED gradient (B,T/2,F/2,Cout); un-pooling is fused into the operand load.
+ * T,F,Cin,Cout describe the FORWARD convolution. */
+int mtl_conv3x3_dgrad(void* stream, const float* dy, const unsigned char* argmax, const float* w_dgrad,
+                      const float* act, float* dx, int B, int T, int F, int Cin, int Cout);
+long mtl_conv3x3_wgrad_workspace(int B, int T, int F, int Cin, int Cout, int pooled);
+/* dw_ref (Cout,Cin,3,3) += sum_pixels x (x) dy ; dy dense (B,T,F,Cout) or pooled + argmax as above. */
+int mtl_conv3x3_wgrad(void* stream, const float* x, const float* dy, const unsigned char* argmax, float* dw_ref,
+                      float* workspace, long workspace_bytes, int B, int T, int F, int Cin, int Cout);
+/* wp[o][h*C+c] = w[o][c*Hh+h]  (inverse_accum: dst[o][c*Hh+h] += src[o][h*C+c]); the (C*H) flattening of
+ * models/asr/transformer.py:136-138 folded into encoder.input_linear's weight instead of an activation copy. */
+int mtl_permute_hc(void* stream, const float* src, float* dst, int rows, int C, int Hh, int inverse_accum);
+
+/* ---- LayerNorm(x + residual) * gamma + beta (+ pe[row % T]) then * keep[row] -----------------------------
+ * nn.LayerNorm eps inside the sqrt, biased variance (modules/common_layers.py:131,304; modules/encoder.py:72-73)
+ * with the non_pad_mask multiplies of modules/encoder.py:101,104 and modules/decoder.py:314,318,321 fused.
+ * d in {64,128,256,512,1024}.  Saves xhat (rows x d) and rstd (rows) for the backward. */
+int mtl_layernorm_fwd(void* stream, const float* x, const float* residual, const float* gamma, const float* beta,
+                      const float* pe, const int* keep, float* y, float* xhat, float* rstd, int rows, int d, int T,
+                      float eps);
+long mtl_layernorm_bwd_workspace(int rows, int d);
+int mtl_layernorm_bwd(void* stream, const float* dy, const float* xhat, const float* rstd, const float* gamma,
+                      const int* keep, float* dz, float* dgamma /*accum*/, float* dbeta /*accum*/, float* workspace,
+                      int rows, int d);
+
+/* ---- masked softmax: modules/common_layers.py:322-327.  S is [B][H][Tq][ld], in place.
+ * keys k >= klen[b] (klen nullable) and, if causal, k > q are filled with -inf before the softmax. */
+int mtl_softmax_mask_fwd(void* stream, float* S, const int* klen, int causal, float scale, int B, int H, int Tq, int Tk,
+                         int ld);
+int mtl_softmax_bwd(void* stream, const float* P, float* dP /*in place -> dS*/, float scale, long rows, int Tk, int ld);
+
+/* ---- embedding + positional encoding: modules/decoder.py:96 ------------------------------------------- */
+int mtl_embed_pe_fwd(void* stream, const long* ids, const float* table, const float* pe, float* out, int rows, int T, int d);
+int mtl_embed_bwd(void* stream, const long* ids, const float* dout, float* dtable /*accum*/, int rows, int d, long pad_id);
+
+/* ---- cross-entropy + arg-max: utils/metrics.py:113-126, models/asr/transformer.py:146-147 ----------------
+ * loss_out[0] = sum_rows(gold!=pad ? -log softmax(logits)[gold] : 0) / n_nonpad ; hyp = lowest arg-max index. */
+int mtl_ce_argmax_fwd(void* stream, const float* logits, const long* gold, int rows, int V, int ld, long pad_id,
+                      float smoothing, int n_nonpad, float* lse, long* hyp, float* rowloss, float* loss_out);
+/* dlogits = gscale * (gscale_dev ? *gscale_dev : 1) * (softmax - target) on non-pad rows, 0 elsewhere */
+int mtl_ce_bwd(void* stream, const float* logits, const float* lse, const long* gold, int rows, int V, int ld, long pad_id,
+               float smoothing, float gscale, const float* gscale_dev, float* dlogits, int ldd);
+
+/* ---- out[c] += sum_r X[r*ld + c]  (bias gradients) -------------------------------------------------------- */
+long mtl_colsum_workspace(long rows, int cols);
+int mtl_colsum_accum(void* stream, const float* X, long rows, int cols, long ld, float* out, float* workspace);
+
+/* ---- flat-parameter updates over ONE contiguous fp32 buffer (190 tensors in the reference) ----------------
+ * inner SGD  trainer/asr/transient_trainer.py:106,207 -> theta1 = theta0 - alpha*g (theta0 is never mutated, which
+ *            replaces deepcopy(state_dict)/load_state_dict at :155-160,237)
+ * copy_grad  models/asr/transformer.py:205-240       -> mtl_axpy(G, g, 1)
+ * clip       transient_trainer.py:205-206,253-254     -> mtl_sumsq(mode 2) + mtl_scale(a_dev)
+ * Adam       transient_trainer.py:109,255 (torch defaults) */
+int mtl_sgd_theta_prime(void* stream, const float* theta0, const float* g, float alpha, float* theta1, long n);
+int mtl_axpy(void* stream, float* y, const float* x, float a, long n);
+int mtl_scale(void* stream, float* y, float a, const float* a_dev /*nullable: overrides a*/, long n);
+int mtl_adam_step(void* stream, float* theta, const float* G, float* m, float* v, int step, float lr, float beta1,
+                  float beta2, float eps, long n);
+int mtl_sumsq(void* stream, const float* x, long n, float* out, float* workspace /* >= 4 KiB */, int mode, float arg);
+
+/* ---- host helper: Levenshtein distance on code points (utils/metrics.py:38-44 uses python-Levenshtein) ---- */
+int mtl_levenshtein_u32(const unsigned int* a_host, int na, const unsigned int* b_host, int nb);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MTL_HIP_H */

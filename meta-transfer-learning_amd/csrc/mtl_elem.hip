@@ -1,0 +1,685 @@
+// HBM-bound kernels of the meta-transfer hot path for gfx950 (MI355X): wave64 shuffle reductions,
+// 16-byte-per-lane coalesced accesses, deterministic two-stage reductions (no float atomics).
+//
+// Reference ops replaced (file:line in /root/reference):
+//   nn.LayerNorm + residual + mask multiply   modules/common_layers.py:131,304; modules/encoder.py:72,101,104;
+//                                             modules/decoder.py:314,318,321
+//   masked softmax                            modules/common_layers.py:322-327
+//   nn.Embedding + positional encoding        modules/decoder.py:96
+//   F.cross_entropy + topk(1)                 utils/metrics.py:126; models/asr/transformer.py:146-147
+//   Conv2d(1->64)+ReLU                        models/asr/transformer.py:48-49
+//   SGD / copy_grad / Adam                    trainer/asr/transient_trainer.py:207,229,255; models/asr/transformer.py:205-240
+#include "mtl_common.h"
+#include "../../include/mtl_hip.h"
+
+namespace {
+
+// ------------------------------------------------------------------ flat-vector updates (one fp32 buffer for theta / G / m / v)
+__global__ void sgd_theta_prime_kernel(const float4* __restrict__ t0, const float4* __restrict__ g, float4* __restrict__ t1,
+                                       float alpha, long n4, const float* t0s, const float* gs, float* t1s, long n) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const float4 a = t0[i], b = g[i];
+        t1[i] = make_float4(a.x - alpha * b.x, a.y - alpha * b.y, a.z - alpha * b.z, a.w - alpha * b.w);
+    }
+    if (blockIdx.x == 0)
+        for (long i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) t1s[i] = t0s[i] - alpha * gs[i];
+}
+
+__global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, float a, long n) {
+    const long n4 = n / 4, stride = (long)gridDim.x * blockDim.x;
+    float4* y4 = reinterpret_cast<float4*>(y);
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 u = y4[i];
+        const float4 v = x4[i];
+        u.x += a * v.x;
+        u.y += a * v.y;
+        u.z += a * v.z;
+        u.w += a * v.w;
+        y4[i] = u;
+    }
+    if (blockIdx.x == 0)
+        for (long i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) y[i] += a * x[i];
+}
+
+__global__ void scale_kernel(float* __restrict__ y, float a, const float* a_dev, long n) {
+    if (a_dev) a = *a_dev;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) y[i] *= a;
+}
+
+// torch.optim.Adam (defaults, no amsgrad / weight decay): denom = sqrt(v)/sqrt(bc2) + eps ; theta -= lr/bc1 * m/denom
+__global__ void adam_kernel(float* __restrict__ th, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            float lr, float b1, float b2, float eps, float bc1, float sqrt_bc2, long n) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    const float step = lr / bc1;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float gi = g[i];
+        const float mi = m[i] * b1 + (1.f - b1) * gi;         // m.lerp_(g, 1-b1) == m + (g-m)*(1-b1); see note in DESIGN.md
+        const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / sqrt_bc2 + eps;
+        th[i] -= step * (mi / denom);
+    }
+}
+
+// sum of squares, stage 1: one partial per block; stage 2: single block, fixed order
+__global__ void sumsq_partial_kernel(const float* __restrict__ x, long n, float* __restrict__ part) {
+    __shared__ float sh[4];
+    float s = 0.f;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) s += x[i] * x[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+__global__ void sum_final_kernel(const float* __restrict__ part, int np, float* __restrict__ out, int mode, float arg) {
+    // mode 0: out = sum ; mode 1: out = sum/arg ; mode 2: out = clip coefficient min(1, arg/(sqrt(sum)+1e-6))
+    __shared__ float sh[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < np; i += blockDim.x) s += part[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = sh[0] + sh[1] + sh[2] + sh[3];
+        if (mode == 1) t = t / arg;
+        if (mode == 2) t = fminf(1.f, arg / (sqrtf(t) + 1e-6f));
+        *out = t;
+    }
+}
+
+// ------------------------------------------------------------------ LayerNorm (+residual, +positional table, *row keep)
+// one wave per row; d is a multiple of 64 up to 1024 (NPL = d/64 values per lane, lane-strided so loads coalesce)
+template <int NPL>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            const float* __restrict__ pe, const int* __restrict__ keep,
+                                                            float* __restrict__ y, float* __restrict__ xhat,
+                                                            float* __restrict__ rstd, int rows, int T, float eps) {
+    constexpr int D = NPL * 64;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float v[NPL];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const int c = i * 64 + lane;
+        float t = x[(long)row * D + c];
+        if (res) t += res[(long)row * D + c];
+        v[i] = t;
+        s += t;
+    }
+    const float mean = wave_sum(s) * (1.f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const float dlt = v[i] - mean;
+        q += dlt * dlt;
+    }
+    const float rs = 1.f / sqrtf(wave_sum(q) * (1.f / D) + eps);
+    const float kp = keep ? (float)keep[row] : 1.f;
+    const float* per = pe ? pe + (long)(row % T) * D : nullptr;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const int c = i * 64 + lane;
+        const float h = (v[i] - mean) * rs;
+        xhat[(long)row * D + c] = h;
+        float o = h * gamma[c] + beta[c];
+        if (per) o += per[c];
+        y[(long)row * D + c] = o * kp;
+    }
+    if (lane == 0) rstd[row] = rs;
+}
+
+// dz = rstd * (dxh - mean(dxh) - xhat*mean(dxh*xhat)), dxh = dy*keep*gamma ; per-wave partial dgamma/dbeta rows
+template <int NPL>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ xhat,
+                                                            const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                            const int* __restrict__ keep, float* __restrict__ dz,
+                                                            float* __restrict__ part, int rows, int rows_per_wave) {
+    constexpr int D = NPL * 64;
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    float ag[NPL], ab[NPL], gm[NPL];
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        ag[i] = 0.f;
+        ab[i] = 0.f;
+        gm[i] = gamma[i * 64 + lane];
+    }
+    const int r0 = gw * rows_per_wave;
+    for (int row = r0; row < r0 + rows_per_wave && row < rows; ++row) {
+        const float kp = keep ? (float)keep[row] : 1.f;
+        float g[NPL], h[NPL];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) {
+            const int c = i * 64 + lane;
+            const float d = dy[(long)row * D + c] * kp;
+            h[i] = xhat[(long)row * D + c];
+            ag[i] += d * h[i];
+            ab[i] += d;
+            g[i] = d * gm[i];
+            s1 += g[i];
+            s2 += g[i] * h[i];
+        }
+        s1 = wave_sum(s1) * (1.f / D);
+        s2 = wave_sum(s2) * (1.f / D);
+        const float rs = rstd[row];
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) dz[(long)row * D + i * 64 + lane] = rs * (g[i] - s1 - h[i] * s2);
+    }
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        part[((long)gw * 2) * D + i * 64 + lane] = ag[i];
+        part[((long)gw * 2 + 1) * D + i * 64 + lane] = ab[i];
+    }
+}
+// out_gamma[c] += sum_w part[w][0][c], out_beta[c] += sum_w part[w][1][c]
+__global__ void ln_param_reduce_kernel(const float* __restrict__ part, int nw, int D, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= D) return;
+    float a = 0.f, b = 0.f;
+    for (int w = 0; w < nw; ++w) {
+        a += part[((long)w * 2) * D + c];
+        b += part[((long)w * 2 + 1) * D + c];
+    }
+    dgamma[c] += a;
+    dbeta[c] += b;
+}
+
+// ------------------------------------------------------------------ masked softmax over keys, one wave per (b,h,q) row
+// P = softmax(S*scale) with keys k >= klen[b] (and k > q when causal) filled with -inf.   In place.
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(float* __restrict__ S, const int* __restrict__ klen, int causal,
+                                                          float scale, int H, int Tq, int Tk, int ld, long rows) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int q = (int)(row % Tq);
+    const int b = (int)(row / ((long)Tq * H));
+    int lim = klen ? min(klen[b], Tk) : Tk;
+    if (causal) lim = min(lim, q + 1);
+    float* s = S + row * ld;
+    float mx = -INFINITY;
+    for (int k = lane; k < lim; k += 64) mx = fmaxf(mx, s[k] * scale);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int k = lane; k < lim; k += 64) sum += expf(s[k] * scale - mx);
+    sum = wave_sum(sum);
+    const float inv = 1.f / sum;
+    for (int k = lane; k < Tk; k += 64) s[k] = k < lim ? expf(s[k] * scale - mx) * inv : 0.f;
+}
+// dS = P * (dP - sum_k dP*P) * scale, in place on dP
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ P, float* __restrict__ dP, float scale,
+                                                          int Tk, int ld, long rows) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* p = P + row * ld;
+    float* d = dP + row * ld;
+    float dot = 0.f;
+    for (int k = lane; k < Tk; k += 64) dot += p[k] * d[k];
+    dot = wave_sum(dot);
+    for (int k = lane; k < Tk; k += 64) d[k] = p[k] * (d[k] - dot) * scale;
+}
+
+// ------------------------------------------------------------------ embedding + positional encoding
+__global__ void embed_pe_fwd_kernel(const long* __restrict__ ids, const float* __restrict__ table, const float* __restrict__ pe,
+                                    float* __restrict__ out, int rows, int T, int d) {
+    const long total = (long)rows * d;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(e / d), c = (int)(e - (long)r * d);
+        out[e] = table[ids[r] * d + c] + pe[(long)(r % T) * d + c];
+    }
+}
+// one thread per embedding column, rows walked in order -> deterministic scatter-add (duplicates included)
+__global__ void embed_bwd_kernel(const long* __restrict__ ids, const float* __restrict__ dout, float* __restrict__ dtable,
+                                 int rows, int d, long pad_id) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d) return;
+    for (int r = 0; r < rows; ++r) {
+        const long id = ids[r];
+        if (id != pad_id) dtable[id * d + c] += dout[(long)r * d + c];
+    }
+}
+
+// ------------------------------------------------------------------ cross-entropy (+arg-max), one wave per row
+// lse = max + log(sum exp(x-max)); rowloss = gold!=pad ? lse - x[gold] : 0 ; hyp = lowest index of the max
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ logits, const long* __restrict__ gold, int rows,
+                                                     int V, int ld, long pad_id, float smoothing, float* __restrict__ lse,
+                                                     long* __restrict__ hyp, float* __restrict__ rowloss) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* x = logits + (long)row * ld;
+    float mx = -INFINITY;
+    int arg = 0x7fffffff;
+    for (int j = lane; j < V; j += 64) {
+        const float v = x[j];
+        if (v > mx) {
+            mx = v;
+            arg = j;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float om = __shfl_xor(mx, o, 64);
+        const int oa = __shfl_xor(arg, o, 64);
+        if (om > mx || (om == mx && oa < arg)) {
+            mx = om;
+            arg = oa;
+        }
+    }
+    float s = 0.f, sx = 0.f;
+    for (int j = lane; j < V; j += 64) {
+        s += expf(x[j] - mx);
+        sx += x[j];
+    }
+    s = wave_sum(s);
+    sx = wave_sum(sx);
+    if (lane == 0) {
+        const float l = mx + logf(s);
+        lse[row] = l;
+        hyp[row] = arg;
+        const long g = gold[row];
+        float loss = 0.f;
+        if (g != pad_id) {
+            // label smoothing (utils/metrics.py:113-124): target = (1-eps) one-hot + eps/V elsewhere
+            const float nll_gold = l - x[g];
+            if (smoothing > 0.f) {
+                const float nll_all = l * V - sx;  // sum_j -logp_j
+                loss = (1.f - smoothing) * nll_gold + smoothing / V * (nll_all - nll_gold);
+            } else {
+                loss = nll_gold;
+            }
+        }
+        rowloss[row] = loss;
+    }
+}
+// dlogits = gscale * (softmax - target) on non-pad rows, 0 on pad rows.  gscale = upstream_grad / n_nonpad
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ logits, const float* __restrict__ lse,
+                                                     const long* __restrict__ gold, int rows, int V, int ld, long pad_id,
+                                                     float smoothing, float gscale, const float* gscale_dev,
+                                                     float* __restrict__ dlogits, int ldd) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    if (gscale_dev) gscale *= *gscale_dev;
+    const float* x = logits + (long)row * ld;
+    float* d = dlogits + (long)row * ldd;
+    const long g = gold[row];
+    if (g == pad_id) {
+        for (int j = lane; j < V; j += 64) d[j] = 0.f;
+        return;
+    }
+    const float l = lse[row];
+    const float off = smoothing > 0.f ? smoothing / V : 0.f;
+    const float on = smoothing > 0.f ? 1.f - smoothing : 1.f;
+    for (int j = lane; j < V; j += 64) {
+        const float p = expf(x[j] - l);
+        d[j] = gscale * (p - (j == g ? on : off));
+    }
+}
+
+// ------------------------------------------------------------------ column sums (bias gradients), deterministic two-stage
+// part[blk][c] = sum over this block's row range of X[r][c]; then out[c] += sum_blk part[blk][c]
+__global__ void colsum_partial_kernel(const float* __restrict__ X, long rows, int cols, long ld, long rows_per_block,
+                                      float* __restrict__ part) {
+    const long r0 = (long)blockIdx.y * rows_per_block;
+    long r1 = r0 + rows_per_block;
+    if (r1 > rows) r1 = rows;
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < cols; c += gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (long r = r0; r < r1; ++r) s += X[r * ld + c];
+        part[(long)blockIdx.y * cols + c] = s;
+    }
+}
+__global__ void colsum_final_kernel(const float* __restrict__ part, int nblk, int cols, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += part[(long)b * cols + c];
+    out[c] += s;
+}
+
+// ------------------------------------------------------------------ first conv layer (C_in = 1): direct, HBM-bound
+// x is the reference's (B,1,F,T) tensor (T contiguous); y is (B,T,F,64) channels-last.
+// lane = (pixel, 4-channel group): a wave writes 4 pixels x 64 channels = 1 KiB contiguous.
+__global__ __launch_bounds__(256) void conv0_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float* __restrict__ y, int B, int T,
+                                                        int F) {
+    const int cg = threadIdx.x & 15;  // channels 4cg..4cg+3
+    float wr[4][9], bb[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        bb[c] = bias[cg * 4 + c];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wr[c][k] = w[(cg * 4 + c) * 9 + k];
+    }
+    const long npix = (long)B * T * F;
+    for (long pix = (long)blockIdx.x * 16 + (threadIdx.x >> 4); pix < npix; pix += (long)gridDim.x * 16) {
+        const int f = (int)(pix % F);
+        const long bt = pix / F;
+        const int t = (int)(bt % T), b = (int)(bt / T);
+        const float* xb = x + (long)b * F * T;
+        float acc[4] = {bb[0], bb[1], bb[2], bb[3]};
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int fs = f + kh - 1;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int ts = t + kw - 1;
+                const float xv = ((unsigned)fs < (unsigned)F && (unsigned)ts < (unsigned)T) ? xb[(long)fs * T + ts] : 0.f;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[c] += xv * wr[c][kh * 3 + kw];
+            }
+        }
+        *reinterpret_cast<float4*>(y + pix * 64 + cg * 4) =
+            make_float4(fmaxf(acc[0], 0.f), fmaxf(acc[1], 0.f), fmaxf(acc[2], 0.f), fmaxf(acc[3], 0.f));
+    }
+}
+// dw0[c][tap] = sum_pix x[pix+tap]*dy[pix][c], db0[c] = sum_pix dy[pix][c]: per-block partials [blk][64][10]
+__global__ __launch_bounds__(256) void conv0_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                          float* __restrict__ part, int B, int T, int F) {
+    __shared__ float sh[16][64][10];
+    const int cg = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    float acc[4][10];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int k = 0; k < 10; ++k) acc[c][k] = 0.f;
+    const long npix = (long)B * T * F;
+    for (long pix = (long)blockIdx.x * 16 + pl; pix < npix; pix += (long)gridDim.x * 16) {
+        const int f = (int)(pix % F);
+        const long bt = pix / F;
+        const int t = (int)(bt % T), b = (int)(bt / T);
+        const float* xb = x + (long)b * F * T;
+        const float4 d4 = *reinterpret_cast<const float4*>(dy + pix * 64 + cg * 4);
+        const float d[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int fs = f + kh - 1;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int ts = t + kw - 1;
+                const float xv = ((unsigned)fs < (unsigned)F && (unsigned)ts < (unsigned)T) ? xb[(long)fs * T + ts] : 0.f;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[c][kh * 3 + kw] += xv * d[c];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c][9] += d[c];
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int k = 0; k < 10; ++k) sh[pl][cg * 4 + c][k] = acc[c][k];
+    __syncthreads();
+    for (int e = threadIdx.x; e < 640; e += 256) {
+        float s = 0.f;
+        for (int p = 0; p < 16; ++p) s += (&sh[p][0][0])[e];
+        part[(long)blockIdx.x * 640 + e] = s;
+    }
+}
+__global__ void conv0_wgrad_final_kernel(const float* __restrict__ part, int nblk, float* __restrict__ dw, float* __restrict__ db) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= 640) return;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += part[(long)b * 640 + e];
+    const int c = e / 10, k = e % 10;
+    if (k < 9)
+        dw[c * 9 + k] += s;
+    else
+        db[c] += s;
+}
+
+// ------------------------------------------------------------------ input_linear weight permutation
+// The conv stack emits features as (T', H=F/4, C) per frame; the reference flattens them as c*H + h.
+// wp[o][h*C + c] = w[o][c*H + h]   (and the inverse, accumulating, for the gradient)
+__global__ void permute_hc_kernel(const float* __restrict__ w, float* __restrict__ wp, int rows, int C, int Hh, int inverse_accum) {
+    const long total = (long)rows * C * Hh;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C);
+        const int h = (int)((e / C) % Hh);
+        const long o = e / ((long)C * Hh);
+        const long ref = o * C * Hh + (long)c * Hh + h;
+        if (inverse_accum)
+            wp[ref] += w[e];  // w = gradient in (h,c) order, wp = reference-order gradient
+        else
+            wp[e] = w[ref];
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int mtl_sgd_theta_prime(void* stream, const float* theta0, const float* g, float alpha, float* theta1, long n) {
+    if (!theta0 || !g || !theta1 || n <= 0) return MTL_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(theta0) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(theta1)) & 15)
+        return MTL_EINVAL;
+    const long n4 = n / 4;
+    hipLaunchKernelGGL(sgd_theta_prime_kernel, dim3(grid_for(n4, 256, 2048)), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const float4*>(theta0), reinterpret_cast<const float4*>(g),
+                       reinterpret_cast<float4*>(theta1), alpha, n4, theta0, g, theta1, n);
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}
+
+int mtl_axpy(void* stream, float* y, const float* x, float a, long n) {
+    if (!y || !x || n <= 0) return MTL_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(x)) & 15) return MTL_EINVAL;
+    hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n / 4 + 1, 256, 2048)), dim3(256), 0, as_stream(stream), y, x, a, n);
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}
+
+int mtl_scale(void* stream, float* y, float a, const float* a_dev, long n) {
+    if (!y || n <= 0) return MTL_EINVAL;
+    hipLaunchKernelGGL(scale_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, as_stream(stream), y, a, a_dev, n);
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}
+
+int mtl_adam_step(void* stream, float* theta, const float* G, float* m, float* v, int step, float lr, float beta1,
+                  float beta2, float eps, long n) {
+    if (!theta || !G || !m || !v || n <= 0 || step < 1) return MTL_EINVAL;
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, as_stream(stream), theta, G, m, v, lr, beta1,
+                       beta2, eps, (float)bc1, (float)sqrt(bc2), n);
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}
+
+// out (device scalar) = mode 0: sum x^2 ; mode 2: clip coefficient min(1, arg/(||x||+1e-6)) (torch clip_grad_norm_)
+int mtl_sumsq(void* stream, const float* x, long n, float* out, float* workspace, int mode, float arg) {
+    if (!x || !out || !workspace || n <= 0) return MTL_EINVAL;
+    const int nb = grid_for(n, 256 * 8, 1024);
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb), dim3(256), 0, as_stream(stream), x, n, workspace);
+    hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(256), 0, as_stream(stream), workspace, nb, out, mode, arg);
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}
+
+int mtl_layernorm_fwd(void* stream, const float* x, const float* residual, const float* gamma, const float* beta,
+                      const float* pe, const int* keep, float* y, float* xhat, float* rstd, int rows, int d, int T,
+                      float eps) {
+    if (!x || !gamma || !beta || !y || !xhat || !rstd || rows <= 0) return MTL_EINVAL;
+    dim3 grid((rows + 3) / 4), block(256);
+    hipStream_t s = as_stream(stream);
+#define LN_FWD(N) \
+    hipLaunchKernelGGL(layernorm_fwd_kernel<N>, grid, block, 0, s, x, residual, gamma, beta, pe, keep, y, xhat, rstd, rows, T > 0 ? T : 1, eps)
+    switch (d) {
+        case 64: LN_FWD(1); break;
+        case 128: LN_FWD(2); break;
+        case 256: LN_FWD(4); break;
+        case 512: LN_FWD(8); break;
+        case 1024: LN_FWD(16); break;
+        default: return MTL_EINVAL;
+    }
+#undef LN_FWD
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}
+
+long mtl_layernorm_bwd_workspace(int rows, int d) {
+    const int waves = ((rows + 7) / 8 + 3) / 4 * 4;
+    return (long)waves * 2 * d * 4;
+}
+
+int mtl_layernorm_bwd(void* stream, const float* dy, const float* xhat, const float* rstd, const float* gamma,
+                      const int* keep, float* dz, float* dgamma, float* dbeta, float* workspace, int rows, int d) {
+    if (!dy || !xhat || !rstd || !gamma || !dz || !dgamma || !dbeta || !workspace || rows <= 0) return MTL_EINVAL;
+    const int rpw = 8;
+    const int waves = ((rows + rpw - 1) / rpw + 3) / 4 * 4;
+    dim3 grid(waves / 4), block(256);
+    hipStream_t s = as_stream(stream);
+#define LN_BWD(N) hipLaunchKernelGGL(layernorm_bwd_kernel<N>, grid, block, 0, s, dy, xhat, rstd, gamma, keep, dz, workspace, rows, rpw)
+    switch (d) {
+        case 64: LN_BWD(1); break;
+        case 128: LN_BWD(2); break;
+        case 256: LN_BWD(4); break;
+        case 512: LN_BWD(8); break;
+        case 1024: LN_BWD(16); break;
+        default: return MTL_EINVAL;
+    }
+#undef LN_BWD
+    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((d + 255) / 256), dim3(256), 0, s, workspace, waves, d, dgamma, dbeta);
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}
+
+int mtl_softmax_mask_fwd(void* stream, float* S, const int* klen, int causal, float scale, int B, int H, int Tq, int Tk,
+                         int ld) {
+    if (!S || B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0 || ld < Tk) return MTL_EINVAL;
+    const long rows = (long)B * H * Tq;
+    hipLaunchKernelGGL(softmax_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, as_stream(stream), S, klen, causal,
+                       scale, H, Tq, Tk, ld, rows);
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}
+
+int mtl_softmax_bwd(void* stream, const float* P, float* dP, float scale, long rows, int Tk, int ld) {
+    if (!P || !dP || rows <= 0 || Tk <= 0 || ld < Tk) return MTL_EINVAL;
+    hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, as_stream(stream), P, dP, scale, Tk,
+                       ld, rows);
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}
+
+int mtl_embed_pe_fwd(void* stream, const long* ids, const float* table, const float* pe, float* out, int rows, int T, int d) {
+    if (!ids || !table || !pe || !out || rows <= 0 || T <= 0) return MTL_EINVAL;
+    hipLaunchKernelGGL(embed_pe_fwd_kernel, dim3(grid_for((long)rows * d, 256, 2048)), dim3(256), 0, as_stream(stream), ids,
+                       table, pe, out, rows, T, d);
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}
+
+int mtl_embed_bwd(void* stream, const long* ids, const float* dout, float* dtable, int rows, int d, long pad_id) {
+    if (!ids || !dout || !dtable || rows <= 0) return MTL_EINVAL;
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3((d + 63) / 64), dim3(64), 0, as_stream(stream), ids, dout, dtable, rows, d, pad_id);
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}
+
+int mtl_ce_argmax_fwd(void* stream, const float* logits, const long* gold, int rows, int V, int ld, long pad_id,
+                      float smoothing, int n_nonpad, float* lse, long* hyp, float* rowloss, float* loss_out) {
+    if (!logits || !gold || !lse || !hyp || !rowloss || !loss_out || rows <= 0 || V <= 0 || n_nonpad <= 0) return MTL_EINVAL;
+    hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL(ce_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, logits, gold, rows, V, ld, pad_id, smoothing, lse,
+                       hyp, rowloss);
+    hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(256), 0, s, rowloss, rows, loss_out, 1, (float)n_nonpad);
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}
+
+int mtl_ce_bwd(void* stream, const float* logits, const float* lse, const long* gold, int rows, int V, int ld, long pad_id,
+               float smoothing, float gscale, const float* gscale_dev, float* dlogits, int ldd) {
+    if (!logits || !lse || !gold || !dlogits || rows <= 0) return MTL_EINVAL;
+    hipLaunchKernelGGL(ce_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, as_stream(stream), logits, lse, gold, rows, V, ld,
+                       pad_id, smoothing, gscale, gscale_dev, dlogits, ldd);
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}
+
+long mtl_colsum_workspace(long rows, int cols) {
+    long nblk = (rows + 255) / 256;
+    if (nblk > 512) nblk = 512;
+    return nblk * cols * 4;
+}
+
+int mtl_colsum_accum(void* stream, const float* X, long rows, int cols, long ld, float* out, float* workspace) {
+    if (!X || !out || !workspace || rows <= 0 || cols <= 0) return MTL_EINVAL;
+    long nblk = (rows + 255) / 256;
+    if (nblk > 512) nblk = 512;
+    const long rpb = (rows + nblk - 1) / nblk;
+    hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((cols + 63) / 64, (unsigned)nblk), dim3(64), 0, s, X, rows, cols, ld, rpb,
+                       workspace);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, workspace, (int)nblk, cols, out);
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}
+
+int mtl_conv0_relu_fwd(void* stream, const float* x, const float* w, const float* bias, float* y, int B, int T, int F) {
+    if (!x || !w || !bias || !y) return MTL_EINVAL;
+    hipLaunchKernelGGL(conv0_fwd_kernel, dim3(grid_for((long)B * T * F, 16, 8192)), dim3(256), 0, as_stream(stream), x, w, bias,
+                       y, B, T, F);
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}
+
+long mtl_conv0_wgrad_workspace(void) { return 1024L * 640 * 4; }
+
+int mtl_conv0_wgrad(void* stream, const float* x, const float* dy, float* dw, float* db, float* workspace, int B, int T, int F) {
+    if (!x || !dy || !dw || !db || !workspace) return MTL_EINVAL;
+    const int nb = grid_for((long)B * T * F, 16 * 64, 1024);
+    hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL(conv0_wgrad_kernel, dim3(nb), dim3(256), 0, s, x, dy, workspace, B, T, F);
+    hipLaunchKernelGGL(conv0_wgrad_final_kernel, dim3(3), dim3(256), 0, s, workspace, nb, dw, db);
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}
+
+int mtl_permute_hc(void* stream, const float* src, float* dst, int rows, int C, int Hh, int inverse_accum) {
+    if (!src || !dst) return MTL_EINVAL;
+    hipLaunchKernelGGL(permute_hc_kernel, dim3(grid_for((long)rows * C * Hh, 256, 4096)), dim3(256), 0, as_stream(stream), src,
+                       dst, rows, C, Hh, inverse_accum);
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}
+
+// host-side Levenshtein distance on code points (replaces python-Levenshtein in utils/metrics.py:38-44)
+int mtl_levenshtein_u32(const unsigned int* a, int na, const unsigned int* b, int nb) {
+    if (na < 0 || nb < 0) return MTL_EINVAL;
+    if (na == 0) return nb;
+    if (nb == 0) return na;
+    int stackbuf[1024];
+    int* prev = nb + 1 <= 1024 ? stackbuf : new int[nb + 1];
+    for (int j = 0; j <= nb; ++j) prev[j] = j;
+    for (int i = 1; i <= na; ++i) {
+        int diag = prev[0];
+        prev[0] = i;
+        for (int j = 1; j <= nb; ++j) {
+            const int sub = diag + (a[i - 1] != b[j - 1]);
+            diag = prev[j];
+            int best = prev[j] + 1;
+            if (prev[j - 1] + 1 < best) best = prev[j - 1] + 1;
+            if (sub < best) best = sub;
+            prev[j] = best;
+        }
+    }
+    const int d = prev[nb];
+    if (prev != stackbuf) delete[] prev;
+    return d;
+}
+
+int mtl_abi_version(void) { return 1; }
+
+}  // extern "C"

@@ -1,0 +1,798 @@
+// fp32 MFMA tile engine for gfx950 (MI355X): one engine, many loaders.
+//
+//  * exact-f32 matrix cores: v_mfma_f32_32x32x2_f32 (157.3 TF peak; gfx950 has no TF32/xf32),
+//    bitwise an fmaf chain -> meets the 1e-4 parity bar on meta-gradients without split tricks.
+//  * 256-thread workgroups (4 waves, 2x2), block tiles 128x128 / 128x64 / 64x64, BK = 32,
+//    double-buffered LDS with one barrier per K-tile, register-staged global->LDS copies issued
+//    before the MFMA burst of the current tile (loads fly under 64..256 MFMAs).
+//  * operands are staged in the orientation their HBM layout is contiguous in ("K-major" or
+//    "MN-major"), so every global access is a 16-byte-per-lane coalesced load and no transposed
+//    copies of activations/weights are ever materialised.
+//  * the same engine runs the linears (all four transpose combinations, batched for attention),
+//    the 3x3 convolutions as implicit GEMM (im2col gather in the A loader, fused bias+ReLU(+2x2
+//    max-pool) epilogues, fused un-pool + ReLU-mask for the backward), and the conv weight-gradient
+//    (K = pixels, split-K into a workspace + deterministic reduction).
+//
+// Reference ops replaced (file:line in /root/reference): nn.Linear fwd/bwd (modules/encoder.py:72,
+// modules/common_layers.py:130,287-289,303, modules/decoder.py:109), torch.bmm (common_layers.py:321,329),
+// nn.Conv2d/ReLU/MaxPool2d (models/asr/transformer.py:48-59).
+#include <type_traits>
+
+#include "mtl_common.h"
+#include "../../include/mtl_hip.h"
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int NT = 256;
+
+// ------------------------------------------------------------------ LDS layouts
+template <int ROWS>
+struct LdsK {  // element (row, k) of a [ROWS][BK] tile; stride 33 -> conflict-free ds_read_b32 across 32 rows
+    static constexpr int LD = BK + 1;
+    static constexpr int SIZE = ROWS * LD;
+    static __device__ __forceinline__ int at(int row, int k) { return row * LD + k; }
+};
+template <int ROWS>
+struct LdsMN {  // same tile stored [BK][ROWS+4]: 32 consecutive rows of one k are 32 consecutive banks
+    static constexpr int LD = ROWS + 4;
+    static constexpr int SIZE = BK * LD;
+    static __device__ __forceinline__ int at(int row, int k) { return k * LD + row; }
+};
+
+__device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+// ------------------------------------------------------------------ plain matrix loaders
+// Source is row-major with k contiguous: tile row r, k  ->  base[(r0+r)*ld + k]
+template <int ROWS>
+struct LoadKMajor {
+    using Lds = LdsK<ROWS>;
+    static constexpr int NV = ROWS * BK / 4 / NT;
+    const float* base;
+    long ld;
+    int nrows, K, kq;
+    bool vec;
+    __device__ void init(const float* p, int ld_, int r0, int rows_total, int K_, int tid) {
+        base = p + (long)r0 * ld_;
+        ld = ld_;
+        nrows = rows_total - r0;
+        K = K_;
+        kq = (tid & 7) * 4;
+        vec = ((ld_ & 3) == 0) && ((reinterpret_cast<uintptr_t>(p) & 15) == 0);
+    }
+    __device__ __forceinline__ void fetch(int kt, float4 (&r)[NV], int tid) const {
+        const int k = kt * BK + kq;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int row = (tid >> 3) + i * 32;
+            float4 v = zero4();
+            if (row < nrows) {
+                const float* q = base + row * ld + k;
+                if (vec && k + 3 < K) {
+                    v = *reinterpret_cast<const float4*>(q);
+                } else {
+                    if (k < K) v.x = q[0];
+                    if (k + 1 < K) v.y = q[1];
+                    if (k + 2 < K) v.z = q[2];
+                    if (k + 3 < K) v.w = q[3];
+                }
+            }
+            r[i] = v;
+        }
+    }
+    __device__ __forceinline__ void commit(float* lds, const float4 (&r)[NV], int tid) const {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int o = Lds::at((tid >> 3) + i * 32, kq);
+            lds[o] = r[i].x;
+            lds[o + 1] = r[i].y;
+            lds[o + 2] = r[i].z;
+            lds[o + 3] = r[i].w;
+        }
+    }
+};
+
+// Source is row-major with the tile-row index contiguous: tile row r, k -> base[k*ld + c0 + r]
+template <int ROWS>
+struct LoadMNMajor {
+    using Lds = LdsMN<ROWS>;
+    static constexpr int VPR = ROWS / 4;    // float4 per k-row
+    static constexpr int KPP = NT / VPR;    // k-rows per pass
+    static constexpr int NV = BK / KPP;
+    const float* base;
+    long ld;
+    int ncols, K, m4, k0;
+    bool vec;
+    __device__ void init(const float* p, int ld_, int c0, int cols_total, int K_, int tid) {
+        base = p + c0;
+        ld = ld_;
+        ncols = cols_total - c0;
+        K = K_;
+        m4 = (tid % VPR) * 4;
+        k0 = tid / VPR;
+        vec = ((ld_ & 3) == 0) && ((reinterpret_cast<uintptr_t>(base) & 15) == 0);
+    }
+    __device__ __forceinline__ void fetch(int kt, float4 (&r)[NV], int) const {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int k = kt * BK + k0 + i * KPP;
+            float4 v = zero4();
+            if (k < K) {
+                const float* q = base + k * ld + m4;
+                if (vec && m4 + 3 < ncols) {
+                    v = *reinterpret_cast<const float4*>(q);
+                } else {
+                    if (m4 < ncols) v.x = q[0];
+                    if (m4 + 1 < ncols) v.y = q[1];
+                    if (m4 + 2 < ncols) v.z = q[2];
+                    if (m4 + 3 < ncols) v.w = q[3];
+                }
+            }
+            r[i] = v;
+        }
+    }
+    __device__ __forceinline__ void commit(float* lds, const float4 (&r)[NV], int) const {
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            *reinterpret_cast<float4*>(&lds[(k0 + i * KPP) * Lds::LD + m4]) = r[i];
+    }
+};
+
+// ------------------------------------------------------------------ the engine
+template <int BM, int BN, class LA, class LB>
+struct Engine {
+    static constexpr int WTM = BM / 2, WTN = BN / 2;   // 2 x 2 waves
+    static constexpr int TM = WTM / 32, TN = WTN / 32; // 32x32 MFMA tiles per wave
+    using AL = typename LA::Lds;
+    using BL = typename LB::Lds;
+    static constexpr int SMEM_BYTES = 2 * (AL::SIZE + BL::SIZE) * 4;
+
+    static __device__ __forceinline__ void zero(f32x16 (&acc)[TM][TN]) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    }
+
+    static __device__ __forceinline__ void run(const LA& la, const LB& lb, int nk, float* smem,
+                                               f32x16 (&acc)[TM][TN]) {
+        const int tid = threadIdx.x;
+        const int lane = tid & 63, wave = tid >> 6;
+        const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, hi = lane >> 5;
+        float* As0 = smem;
+        float* As1 = smem + AL::SIZE;
+        float* Bs0 = smem + 2 * AL::SIZE;
+        float* Bs1 = Bs0 + BL::SIZE;
+        float4 ra[LA::NV], rb[LB::NV];
+        la.fetch(0, ra, tid);
+        lb.fetch(0, rb, tid);
+        la.commit(As0, ra, tid);
+        lb.commit(Bs0, rb, tid);
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const float* Ac = (kt & 1) ? As1 : As0;
+            const float* Bc = (kt & 1) ? Bs1 : Bs0;
+            const bool more = kt + 1 < nk;
+            if (more) {
+                la.fetch(kt + 1, ra, tid);
+                lb.fetch(kt + 1, rb, tid);
+            }
+#pragma unroll
+            for (int kk = 0; kk < BK; kk += 2) {
+                float a[TM], b[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = Ac[AL::at(wm * WTM + i * 32 + l31, kk + hi)];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[j] = Bc[BL::at(wn * WTN + j * 32 + l31, kk + hi)];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+            if (more) {
+                la.commit((kt & 1) ? As0 : As1, ra, tid);
+                lb.commit((kt & 1) ? Bs0 : Bs1, rb, tid);
+            }
+            __syncthreads();
+        }
+    }
+
+    // epi.store4(local_row4, local_col, v[4]): rows local_row4..+3 (4-aligned) of column local_col
+    template <class Epi>
+    static __device__ __forceinline__ void finish(const f32x16 (&acc)[TM][TN], const Epi& epi) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, hi = lane >> 5;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float v[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                    epi.store4(wm * WTM + i * 32 + 8 * g + 4 * hi, wn * WTN + j * 32 + l31, v);
+                }
+    }
+};
+
+// ================================================================== generic (batched) GEMM
+struct GemmP {
+    const float* A;
+    const float* B;
+    float* C;
+    const float* bias;
+    const float* gate;
+    int M, N, K, lda, ldb, ldc, ldg;
+    float alpha;
+    int flags, H;
+    long sAb, sAh, sBb, sBh, sCb, sCh;
+};
+
+struct EpiGemm {
+    float* C;
+    const float* bias;
+    const float* gate;
+    int M, N, m0, n0, ldc, ldg, flags;
+    float alpha;
+    __device__ __forceinline__ void store4(int lr, int lc, const float (&v)[4]) const {
+        const int col = n0 + lc;
+        if (col >= N) return;
+        const float bb = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = m0 + lr + j;
+            if (row >= M) continue;
+            float x = alpha * v[j] + bb;
+            if (flags & MTL_GEMM_RELU) x = fmaxf(x, 0.f);
+            if (gate) x = gate[(long)row * ldg + col] > 0.f ? x : 0.f;
+            float* c = C + (long)row * ldc + col;
+            if (flags & MTL_GEMM_ACCUM) x += *c;
+            *c = x;
+        }
+    }
+};
+
+template <int BM, int BN, bool TA, bool TB>
+__global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
+    using LA = typename std::conditional<TA, LoadMNMajor<BM>, LoadKMajor<BM>>::type;
+    using LB = typename std::conditional<TB, LoadKMajor<BN>, LoadMNMajor<BN>>::type;
+    using E = Engine<BM, BN, LA, LB>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int z = blockIdx.z, zb = z / p.H, zh = z % p.H;
+    const float* A = p.A + zb * p.sAb + zh * p.sAh;
+    const float* B = p.B + zb * p.sBb + zh * p.sBh;
+    float* C = p.C + zb * p.sCb + zh * p.sCh;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int tid = threadIdx.x;
+    LA la;
+    LB lb;
+    la.init(A, p.lda, m0, p.M, p.K, tid);
+    lb.init(B, p.ldb, n0, p.N, p.K, tid);
+    f32x16 acc[E::TM][E::TN];
+    E::zero(acc);
+    E::run(la, lb, (p.K + BK - 1) / BK, smem, acc);
+    const float* gate = p.gate ? p.gate + zb * p.sCb + zh * p.sCh : nullptr;
+    EpiGemm epi{C, p.bias, gate, p.M, p.N, m0, n0, p.ldc, p.ldg, p.flags, p.alpha};
+    E::finish(acc, epi);
+}
+
+template <class K>
+int set_smem(K kernel, int bytes) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) ==
+                   hipSuccess
+               ? 0
+               : MTL_ELAUNCH;
+}
+
+template <int BM, int BN, bool TA, bool TB>
+int launch_gemm(const GemmP& p, int batch, hipStream_t s) {
+    using LA = typename std::conditional<TA, LoadMNMajor<BM>, LoadKMajor<BM>>::type;
+    using LB = typename std::conditional<TB, LoadKMajor<BN>, LoadMNMajor<BN>>::type;
+    using E = Engine<BM, BN, LA, LB>;
+    static int attr = set_smem(gemm_kernel<BM, BN, TA, TB>, E::SMEM_BYTES);
+    if (attr) return attr;
+    dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, batch);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, TA, TB>), grid, dim3(NT), E::SMEM_BYTES, s, p);
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}
+
+template <bool TA, bool TB>
+int dispatch_gemm(const GemmP& p, int batch, hipStream_t s) {
+    // big tiles only when they still give >= 1 workgroup per CU
+    const long big = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * batch;
+    if (big >= 256) return launch_gemm<128, 128, TA, TB>(p, batch, s);
+    return launch_gemm<64, 64, TA, TB>(p, batch, s);
+}
+
+// ================================================================== 3x3 convolution, NHWC = (B, T, F, C)
+// Block tile = 128 output pixels in an 8(T) x 16(F) patch x BN output channels.  Tile row m encodes
+// (pool window, position in window) so that MFMA accumulator registers 4g..4g+3 of a lane are one
+// 2x2 pool window: window = (m>>5)*8 + ((m>>2)&7) -> (wt = window>>3, wf = window&7);
+// sub = m&3 -> t = 2*wt + (sub&1), f = 2*wf + (sub>>1)   [torch's window order: freq-major, time-minor]
+struct ConvGeom {
+    int B, T, F, Cin, Cout;  // dense (un-pooled) spatial extent T x F of the conv
+    int Tp, Fp;              // pooled extent (T/2, F/2) when pooling / un-pooling is fused
+};
+
+__device__ __forceinline__ void tile_row_to_tf(int m, int& t, int& f) {
+    const int w = (m >> 5) * 8 + ((m >> 2) & 7);
+    const int sub = m & 3;
+    t = 2 * (w >> 3) + (sub & 1);
+    f = 2 * (w & 7) + (sub >> 1);
+}
+
+// A operand: im2col gather.  k-tile kt -> tap = kt / (C/32), channels (kt % (C/32))*32 .. +31.
+// tap = kh*3 + kw reads source pixel (t + kw - 1, f + kh - 1).   UNPOOL: the source is the pooled
+// gradient dp (B,Tp,Fp,C) with its 2-bit arg-max; the dense gradient is reconstructed on the fly.
+template <bool UNPOOL>
+struct LoadConvA {
+    using Lds = LdsK<128>;
+    static constexpr int NV = 4;
+    const float* x;
+    const uint8_t* am;
+    int T, F, C, Tp, Fp, b, kq, cch;
+    int pt[NV], pf[NV];
+    __device__ void init(const float* x_, const uint8_t* am_, const ConvGeom& g, int C_, int b_, int t0, int f0, int tid) {
+        x = x_;
+        am = am_;
+        T = g.T;
+        F = g.F;
+        Tp = g.Tp;
+        Fp = g.Fp;
+        C = C_;
+        b = b_;
+        cch = C_ / BK;
+        kq = (tid & 7) * 4;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            int t, f;
+            tile_row_to_tf((tid >> 3) + i * 32, t, f);
+            pt[i] = t0 + t;
+            pf[i] = f0 + f;
+        }
+    }
+    __device__ __forceinline__ void fetch(int kt, float4 (&r)[NV], int) const {
+        const int tap = kt / cch;
+        const int c = (kt - tap * cch) * BK + kq;
+        const int kh = tap / 3, kw = tap - kh * 3;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int ts = pt[i] + kw - 1, fs = pf[i] + kh - 1;
+            float4 v = zero4();
+            if ((unsigned)ts < (unsigned)T && (unsigned)fs < (unsigned)F) {
+                if (!UNPOOL) {
+                    v = *reinterpret_cast<const float4*>(x + (((long)b * T + ts) * F + fs) * C + c);
+                } else {
+                    const int tp = ts >> 1, fp = fs >> 1;
+                    if (tp < Tp && fp < Fp) {
+                        const long o = (((long)b * Tp + tp) * Fp + fp) * C + c;
+                        const uchar4 a = *reinterpret_cast<const uchar4*>(am + o);
+                        const float4 d = *reinterpret_cast<const float4*>(x + o);
+                        const int sub = ((fs & 1) << 1) | (ts & 1);
+                        v.x = a.x == sub ? d.x : 0.f;
+                        v.y = a.y == sub ? d.y : 0.f;
+                        v.z = a.z == sub ? d.z : 0.f;
+                        v.w = a.w == sub ? d.w : 0.f;
+                    }
+                }
+            }
+            r[i] = v;
+        }
+    }
+    __device__ __forceinline__ void commit(float* lds, const float4 (&r)[NV], int tid) const {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int o = Lds::at((tid >> 3) + i * 32, kq);
+            lds[o] = r[i].x;
+            lds[o + 1] = r[i].y;
+            lds[o + 2] = r[i].z;
+            lds[o + 3] = r[i].w;
+        }
+    }
+};
+
+struct EpiConvRelu {  // y = relu(acc + bias), dense NHWC
+    float* y;
+    const float* bias;
+    int b, t0, f0, T, F, Cout, n0;
+    __device__ __forceinline__ void store4(int lr, int lc, const float (&v)[4]) const {
+        const int col = n0 + lc;
+        const int w = (lr >> 5) * 8 + ((lr >> 2) & 7);
+        const float bb = bias[col];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int t = t0 + 2 * (w >> 3) + (j & 1), f = f0 + 2 * (w & 7) + (j >> 1);
+            if (t < T && f < F) y[(((long)b * T + t) * F + f) * Cout + col] = fmaxf(v[j] + bb, 0.f);
+        }
+    }
+};
+
+struct EpiConvPool {  // p = maxpool2x2(relu(acc + bias)), first-max arg index (torch tie rule)
+    float* p;
+    uint8_t* am;
+    const float* bias;
+    int b, t0, f0, Tp, Fp, Cout, n0;
+    __device__ __forceinline__ void store4(int lr, int lc, const float (&v)[4]) const {
+        const int col = n0 + lc;
+        const int w = (lr >> 5) * 8 + ((lr >> 2) & 7);
+        const int tp = (t0 >> 1) + (w >> 3), fp = (f0 >> 1) + (w & 7);
+        if (tp >= Tp || fp >= Fp) return;
+        const float bb = bias[col];
+        float best = fmaxf(v[0] + bb, 0.f);
+        int idx = 0;
+#pragma unroll
+        for (int j = 1; j < 4; ++j) {
+            const float xj = fmaxf(v[j] + bb, 0.f);
+            if (xj > best) {
+                best = xj;
+                idx = j;
+            }
+        }
+        const long o = (((long)b * Tp + tp) * Fp + fp) * Cout + col;
+        p[o] = best;
+        am[o] = (uint8_t)idx;
+    }
+};
+
+struct EpiConvDgrad {  // dx = acc masked by the ReLU of the forward activation at the same place
+    float* dx;
+    const float* act;
+    int b, t0, f0, T, F, Cout, n0;
+    __device__ __forceinline__ void store4(int lr, int lc, const float (&v)[4]) const {
+        const int col = n0 + lc;
+        const int w = (lr >> 5) * 8 + ((lr >> 2) & 7);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int t = t0 + 2 * (w >> 3) + (j & 1), f = f0 + 2 * (w & 7) + (j >> 1);
+            if (t < T && f < F) {
+                const long o = (((long)b * T + t) * F + f) * Cout + col;
+                dx[o] = act[o] > 0.f ? v[j] : 0.f;
+            }
+        }
+    }
+};
+
+struct ConvP {
+    const float* x;      // A source: activations (B,T,F,Cin) or pooled gradient (B,Tp,Fp,Cin) when UNPOOL
+    const uint8_t* am_in;
+    const float* w;      // [9][Cin][Cout], already in the tap order the A loader walks
+    const float* bias;
+    const float* act;    // dgrad: forward activation whose ReLU gates the output
+    float* y;
+    uint8_t* am_out;
+    ConvGeom g;
+    int ntile;           // Cout / BN
+};
+
+enum { EPI_RELU = 0, EPI_POOL = 1, EPI_DGRAD = 2 };
+
+template <int BN, bool UNPOOL, int EPI>
+__global__ __launch_bounds__(NT) void conv3x3_kernel(ConvP p) {
+    using LA = LoadConvA<UNPOOL>;
+    using LB = LoadMNMajor<BN>;
+    using E = Engine<128, BN, LA, LB>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.z / p.ntile, n0 = (blockIdx.z % p.ntile) * BN;
+    const int t0 = blockIdx.y * 8, f0 = blockIdx.x * 16;
+    LA la;
+    LB lb;
+    la.init(p.x, p.am_in, p.g, p.g.Cin, b, t0, f0, tid);
+    lb.init(p.w, p.g.Cout, n0, p.g.Cout, 9 * p.g.Cin, tid);
+    f32x16 acc[E::TM][E::TN];
+    E::zero(acc);
+    E::run(la, lb, 9 * p.g.Cin / BK, smem, acc);
+    if (EPI == EPI_RELU) {
+        EpiConvRelu e{p.y, p.bias, b, t0, f0, p.g.T, p.g.F, p.g.Cout, n0};
+        E::finish(acc, e);
+    } else if (EPI == EPI_POOL) {
+        EpiConvPool e{p.y, p.am_out, p.bias, b, t0, f0, p.g.Tp, p.g.Fp, p.g.Cout, n0};
+        E::finish(acc, e);
+    } else {
+        EpiConvDgrad e{p.y, p.act, b, t0, f0, p.g.T, p.g.F, p.g.Cout, n0};
+        E::finish(acc, e);
+    }
+}
+
+template <int BN, bool UNPOOL, int EPI>
+int launch_conv(const ConvP& p, int Te, int Fe, hipStream_t s) {
+    using E = Engine<128, BN, LoadConvA<UNPOOL>, LoadMNMajor<BN>>;
+    static int attr = set_smem(conv3x3_kernel<BN, UNPOOL, EPI>, E::SMEM_BYTES);
+    if (attr) return attr;
+    dim3 grid((Fe + 15) / 16, (Te + 7) / 8, p.g.B * p.ntile);
+    hipLaunchKernelGGL((conv3x3_kernel<BN, UNPOOL, EPI>), grid, dim3(NT), E::SMEM_BYTES, s, p);
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}
+
+template <bool UNPOOL, int EPI>
+int dispatch_conv(ConvP& p, int Te, int Fe, hipStream_t s) {
+    if (p.g.Cin % 32 || p.g.Cout % 64) return MTL_EINVAL;
+    if (p.g.Cout % 128 == 0) {
+        p.ntile = p.g.Cout / 128;
+        return launch_conv<128, UNPOOL, EPI>(p, Te, Fe, s);
+    }
+    p.ntile = p.g.Cout / 64;
+    return launch_conv<64, UNPOOL, EPI>(p, Te, Fe, s);
+}
+
+// ------------------------------------------------------------------ weight gradient
+// dW[tap][cin][cout] = sum over valid output pixels of x[t+kw-1, f+kh-1, cin] * dy[t, f, cout]
+// GEMM view: M = 9*Cin (64-row tiles never straddle a tap), N = Cout, K = pixels (f fastest), split over grid.z.
+struct WgradGeom {
+    int B, T, F;    // activation extent
+    int Ty, Fy;     // extent over which dy can be non-zero (2*Tp, 2*Fp for pooled layers, else T, F)
+    int Tp, Fp;
+    int Cin, Cout;
+    long npix;      // B*Ty*Fy
+    long per_split; // pixels per split (multiple of BK)
+};
+
+struct LoadWgradX {  // A: rows = 64 input channels of one tap, MN-major
+    using Lds = LdsMN<64>;
+    static constexpr int NV = 2;
+    const float* x;
+    WgradGeom g;
+    int dt, df, c0, m4, k0;
+    long pbeg, pend;
+    __device__ void init(const float* x_, const WgradGeom& g_, int m0, long pbeg_, long pend_, int tid) {
+        x = x_;
+        g = g_;
+        const int tap = m0 / g.Cin;
+        c0 = m0 - tap * g.Cin;
+        const int kh = tap / 3, kw = tap - kh * 3;
+        dt = kw - 1;
+        df = kh - 1;
+        m4 = (tid & 15) * 4;
+        k0 = tid >> 4;
+        pbeg = pbeg_;
+        pend = pend_;
+    }
+    __device__ __forceinline__ void fetch(int kt, float4 (&r)[NV], int) const {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const long pix = pbeg + (long)kt * BK + k0 + i * 16;
+            float4 v = zero4();
+            if (pix < pend) {
+                const int plane = g.Ty * g.Fy;
+                const int b = (int)(pix / plane);
+                const int rem = (int)(pix - (long)b * plane);
+                const int t = rem / g.Fy, f = rem - t * g.Fy;
+                const int ts = t + dt, fs = f + df;
+                if ((unsigned)ts < (unsigned)g.T && (unsigned)fs < (unsigned)g.F)
+                    v = *reinterpret_cast<const float4*>(x + (((long)b * g.T + ts) * g.F + fs) * g.Cin + c0 + m4);
+            }
+            r[i] = v;
+        }
+    }
+    __device__ __forceinline__ void commit(float* lds, const float4 (&r)[NV], int) const {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) *reinterpret_cast<float4*>(&lds[(k0 + i * 16) * Lds::LD + m4]) = r[i];
+    }
+};
+
+template <int BN, bool UNPOOL>
+struct LoadWgradDy {  // B: rows = BN output channels, MN-major; dense dy or (dp, argmax)
+    using Lds = LdsMN<BN>;
+    static constexpr int VPR = BN / 4, KPP = NT / VPR, NV = BK / KPP;
+    const float* dy;
+    const uint8_t* am;
+    WgradGeom g;
+    int n0, m4, k0;
+    long pbeg, pend;
+    __device__ void init(const float* dy_, const uint8_t* am_, const WgradGeom& g_, int n0_, long pbeg_, long pend_, int tid) {
+        dy = dy_;
+        am = am_;
+        g = g_;
+        n0 = n0_;
+        m4 = (tid % VPR) * 4;
+        k0 = tid / VPR;
+        pbeg = pbeg_;
+        pend = pend_;
+    }
+    __device__ __forceinline__ void fetch(int kt, float4 (&r)[NV], int) const {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const long pix = pbeg + (long)kt * BK + k0 + i * KPP;
+            float4 v = zero4();
+            if (pix < pend) {
+                if (!UNPOOL) {
+                    v = *reinterpret_cast<const float4*>(dy + pix * g.Cout + n0 + m4);  // Ty==T, Fy==F
+                } else {
+                    const int plane = g.Ty * g.Fy;
+                    const int b = (int)(pix / plane);
+                    const int rem = (int)(pix - (long)b * plane);
+                    const int t = rem / g.Fy, f = rem - t * g.Fy;
+                    const long o = (((long)b * g.Tp + (t >> 1)) * g.Fp + (f >> 1)) * g.Cout + n0 + m4;
+                    const uchar4 a = *reinterpret_cast<const uchar4*>(am + o);
+                    const float4 d = *reinterpret_cast<const float4*>(dy + o);
+                    const int sub = ((f & 1) << 1) | (t & 1);
+                    v.x = a.x == sub ? d.x : 0.f;
+                    v.y = a.y == sub ? d.y : 0.f;
+                    v.z = a.z == sub ? d.z : 0.f;
+                    v.w = a.w == sub ? d.w : 0.f;
+                }
+            }
+            r[i] = v;
+        }
+    }
+    __device__ __forceinline__ void commit(float* lds, const float4 (&r)[NV], int) const {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) *reinterpret_cast<float4*>(&lds[(k0 + i * KPP) * Lds::LD + m4]) = r[i];
+    }
+};
+
+struct EpiPartial {
+    float* out;  // [9*Cin][Cout] slab of this split
+    int m0, n0, Cout;
+    __device__ __forceinline__ void store4(int lr, int lc, const float (&v)[4]) const {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) out[(long)(m0 + lr + j) * Cout + n0 + lc] = v[j];
+    }
+};
+
+struct WgradP {
+    const float* x;
+    const float* dy;
+    const uint8_t* am;
+    float* partial;
+    WgradGeom g;
+};
+
+template <int BN, bool UNPOOL>
+__global__ __launch_bounds__(NT) void conv3x3_wgrad_kernel(WgradP p) {
+    using LA = LoadWgradX;
+    using LB = LoadWgradDy<BN, UNPOOL>;
+    using E = Engine<64, BN, LA, LB>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int m0 = blockIdx.x * 64, n0 = blockIdx.y * BN;
+    const long pbeg = (long)blockIdx.z * p.g.per_split;
+    long pend = pbeg + p.g.per_split;
+    if (pend > p.g.npix) pend = p.g.npix;
+    LA la;
+    LB lb;
+    la.init(p.x, p.g, m0, pbeg, pend, tid);
+    lb.init(p.dy, p.am, p.g, n0, pbeg, pend, tid);
+    f32x16 acc[E::TM][E::TN];
+    E::zero(acc);
+    const int nk = pend > pbeg ? (int)((pend - pbeg + BK - 1) / BK) : 0;
+    if (nk > 0) E::run(la, lb, nk, smem, acc);
+    EpiPartial e{p.partial + (long)blockIdx.z * 9 * p.g.Cin * p.g.Cout, m0, n0, p.g.Cout};
+    E::finish(acc, e);
+}
+
+// dw_ref[cout][cin][kh][kw] += sum_s partial[s][(tap*Cin + cin)][cout]      (fixed order -> deterministic)
+__global__ void wgrad_reduce_kernel(const float* partial, float* dw, int nsplit, int Cin, int Cout) {
+    const int total = 9 * Cin * Cout;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int cout = e % Cout;
+        const int mc = e / Cout;  // tap*Cin + cin
+        const int tap = mc / Cin, cin = mc - tap * Cin;
+        float s = 0.f;
+        for (int k = 0; k < nsplit; ++k) s += partial[(long)k * total + e];
+        dw[((long)cout * Cin + cin) * 9 + tap] += s;
+    }
+}
+
+template <int BN, bool UNPOOL>
+int launch_wgrad(const WgradP& p, int nsplit, hipStream_t s) {
+    using E = Engine<64, BN, LoadWgradX, LoadWgradDy<BN, UNPOOL>>;
+    static int attr = set_smem(conv3x3_wgrad_kernel<BN, UNPOOL>, E::SMEM_BYTES);
+    if (attr) return attr;
+    dim3 grid(9 * p.g.Cin / 64, p.g.Cout / BN, nsplit);
+    hipLaunchKernelGGL((conv3x3_wgrad_kernel<BN, UNPOOL>), grid, dim3(NT), E::SMEM_BYTES, s, p);
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}
+
+// w_ref (Cout,Cin,3,3) -> w_fwd[tap][cin][cout]  and  w_dgrad[tap'][cout][cin] with tap' the 180-degree flipped tap
+__global__ void conv_wprep_kernel(const float* w, float* wf, float* wd, int Cout, int Cin) {
+    const int total = 9 * Cin * Cout;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int tap = e % 9;
+        const int cin = (e / 9) % Cin;
+        const int cout = e / (9 * Cin);
+        const float v = w[e];
+        wf[((long)tap * Cin + cin) * Cout + cout] = v;
+        wd[((long)(8 - tap) * Cout + cout) * Cin + cin] = v;
+    }
+}
+
+}  // namespace
+
+// ================================================================== C ABI
+extern "C" {
+
+int mtl_gemm_f32(void* stream, int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
+                 const float* B, int ldb, float* C, int ldc, const float* bias, const float* gate, int ldg, int flags,
+                 int batch, int H, long sAb, long sAh, long sBb, long sBh, long sCb, long sCh) {
+    if (M <= 0 || N <= 0 || K <= 0 || batch <= 0 || H <= 0 || !A || !B || !C) return MTL_EINVAL;
+    GemmP p{A, B, C, bias, gate, M, N, K, lda, ldb, ldc, ldg, alpha, flags, H, sAb, sAh, sBb, sBh, sCb, sCh};
+    hipStream_t s = as_stream(stream);
+    if (!transA && transB) return dispatch_gemm<false, true>(p, batch, s);
+    if (!transA && !transB) return dispatch_gemm<false, false>(p, batch, s);
+    if (transA && !transB) return dispatch_gemm<true, false>(p, batch, s);
+    return dispatch_gemm<true, true>(p, batch, s);
+}
+
+int mtl_conv3x3_wprep(void* stream, const float* w_ref, float* w_fwd, float* w_dgrad, int Cout, int Cin) {
+    if (!w_ref || !w_fwd || !w_dgrad) return MTL_EINVAL;
+    hipLaunchKernelGGL(conv_wprep_kernel, dim3(grid_for(9L * Cin * Cout, 256)), dim3(256), 0, as_stream(stream), w_ref,
+                       w_fwd, w_dgrad, Cout, Cin);
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}
+
+int mtl_conv3x3_relu_fwd(void* stream, const float* x, const float* w_fwd, const float* bias, float* y, int B, int T,
+                         int F, int Cin, int Cout) {
+    if (!x || !w_fwd || !bias || !y) return MTL_EINVAL;
+    ConvP p{x, nullptr, w_fwd, bias, nullptr, y, nullptr, {B, T, F, Cin, Cout, T / 2, F / 2}, 1};
+    return dispatch_conv<false, EPI_RELU>(p, T, F, as_stream(stream));
+}
+
+int mtl_conv3x3_relu_pool_fwd(void* stream, const float* x, const float* w_fwd, const float* bias, float* p_out,
+                              unsigned char* argmax, int B, int T, int F, int Cin, int Cout) {
+    if (!x || !w_fwd || !bias || !p_out || !argmax) return MTL_EINVAL;
+    ConvP p{x, nullptr, w_fwd, bias, nullptr, p_out, argmax, {B, T, F, Cin, Cout, T / 2, F / 2}, 1};
+    return dispatch_conv<false, EPI_POOL>(p, 2 * (T / 2), 2 * (F / 2), as_stream(stream));
+}
+
+int mtl_conv3x3_dgrad(void* stream, const float* dy, const unsigned char* argmax, const float* w_dgrad,
+                      const float* act, float* dx, int B, int T, int F, int Cin, int Cout) {
+    // Cin/Cout are the FORWARD conv's channel counts: dy has Cout channels, dx has Cin.
+    if (!dy || !w_dgrad || !act || !dx) return MTL_EINVAL;
+    ConvP p{dy, argmax, w_dgrad, nullptr, act, dx, nullptr, {B, T, F, Cout, Cin, T / 2, F / 2}, 1};
+    if (argmax) return dispatch_conv<true, EPI_DGRAD>(p, T, F, as_stream(stream));
+    return dispatch_conv<false, EPI_DGRAD>(p, T, F, as_stream(stream));
+}
+
+long mtl_conv3x3_wgrad_workspace(int B, int T, int F, int Cin, int Cout, int pooled) {
+    const int Ty = pooled ? 2 * (T / 2) : T, Fy = pooled ? 2 * (F / 2) : F;
+    const long npix = (long)B * Ty * Fy;
+    const int tiles = (9 * Cin / 64) * (Cout / (Cout % 128 == 0 ? 128 : 64));
+    long nsplit = (1024 + tiles - 1) / tiles;
+    const long maxsplit = (npix + 1023) / 1024;
+    if (nsplit > maxsplit) nsplit = maxsplit;
+    if (nsplit < 1) nsplit = 1;
+    return nsplit * 9L * Cin * Cout * 4;
+}
+
+int mtl_conv3x3_wgrad(void* stream, const float* x, const float* dy, const unsigned char* argmax, float* dw_ref,
+                      float* workspace, long workspace_bytes, int B, int T, int F, int Cin, int Cout) {
+    if (!x || !dy || !dw_ref || !workspace || Cin % 64 || Cout % 64) return MTL_EINVAL;
+    const int pooled = argmax != nullptr;
+    const long need = mtl_conv3x3_wgrad_workspace(B, T, F, Cin, Cout, pooled);
+    if (workspace_bytes < need) return MTL_EINVAL;
+    const int nsplit = (int)(need / (9L * Cin * Cout * 4));
+    WgradGeom g;
+    g.B = B;
+    g.T = T;
+    g.F = F;
+    g.Ty = pooled ? 2 * (T / 2) : T;
+    g.Fy = pooled ? 2 * (F / 2) : F;
+    g.Tp = T / 2;
+    g.Fp = F / 2;
+    g.Cin = Cin;
+    g.Cout = Cout;
+    g.npix = (long)B * g.Ty * g.Fy;
+    long per = (g.npix + nsplit - 1) / nsplit;
+    g.per_split = (per + BK - 1) / BK * BK;
+    WgradP p{x, dy, argmax, workspace, g};
+    hipStream_t s = as_stream(stream);
+    int rc;
+    if (Cout % 128 == 0)
+        rc = pooled ? launch_wgrad<128, true>(p, nsplit, s) : launch_wgrad<128, false>(p, nsplit, s);
+    else
+        rc = pooled ? launch_wgrad<64, true>(p, nsplit, s) : launch_wgrad<64, false>(p, nsplit, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(9L * Cin * Cout, 256)), dim3(256), 0, s, workspace, dw_ref,
+                       nsplit, Cin, Cout);
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}
+
+}  // extern "C"

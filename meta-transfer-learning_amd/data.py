@@ -1,0 +1,165 @@
+"""Vocabulary, label/manifest loaders and the synthetic task source.
+
+Mirrors: `Vocab` (utils/data.py:1-28), the label-JSON loading of meta_transfer_train.py:151-157, the manifest CSV
+contract of utils/data_loader.py:191-195 and the batch layout returned by `SpectrogramDataset.sample`
+(utils/data_loader.py:245-321).  Audio decoding / STFT (utils/data_loader.py:65-96) is outside the accelerated path
+(SURVEY.md 8(f) f1): datasets here get features from a caller-supplied `feature_fn` or synthesize them.
+"""
+import csv
+import json
+
+import numpy as np
+import torch
+
+
+class Vocab(object):
+    def __init__(self):
+        self.PAD_TOKEN, self.SOS_TOKEN, self.EOS_TOKEN, self.OOV_TOKEN = '<PAD>', '<SOS>', '<EOS>', '<OOV>'
+        self.PAD_ID, self.SOS_ID, self.EOS_ID, self.OOV_ID = 0, 1, 2, 3
+        self.special_token_list = [self.PAD_TOKEN, self.SOS_TOKEN, self.EOS_TOKEN, self.OOV_TOKEN]
+        self.token2id, self.id2token = {}, []
+        self.label2id, self.id2label = {}, []
+        for tok in self.special_token_list:
+            self.add_token(tok)
+            self.add_label(tok)
+
+    def add_token(self, token):
+        if token not in self.token2id:
+            self.token2id[token] = len(self.token2id)
+            self.id2token.append(token)
+
+    def add_label(self, label):
+        if label not in self.label2id:
+            self.label2id[label] = len(self.label2id)
+            self.id2label.append(label)
+
+
+def load_vocab(labels_path):
+    """labels JSON (a list of characters, e.g. data/labels/hkust_seame_labels.json) -> Vocab; specials first."""
+    with open(labels_path, encoding='utf-8') as f:
+        labels = json.load(f)
+    vocab = Vocab()
+    for label in labels:
+        vocab.add_token(label)
+        vocab.add_label(label)
+    return vocab
+
+
+def synthetic_vocab(size):
+    """`size` ids in total (4 specials + size-4 distinct CJK code points), matching the reference's 3765 when size=3765."""
+    vocab = Vocab()
+    for i in range(size - 4):
+        ch = chr(0x4e00 + i)
+        vocab.add_token(ch)
+        vocab.add_label(ch)
+    return vocab
+
+
+def read_manifest(path):
+    """CSV without header, rows `wav_path,txt_path` (data/manifests/*.csv) -> list of [wav, txt]."""
+    with open(path, newline='', encoding='utf-8') as f:
+        return [row[:2] for row in csv.reader(f) if row]
+
+
+def parse_transcript(vocab, transcript_path):
+    """utils/data_loader.py:342-361 (char input): ' ' + lower-cased text -> ids of known labels (unknown chars and id 0 dropped)."""
+    if transcript_path[-4:] == '.txt':
+        with open(transcript_path, 'r', encoding='utf8') as f:
+            text = ' ' + f.read().replace('\n', '').lower()
+    else:
+        text = transcript_path.replace('\n', '').lower()
+    return [i for i in (vocab.label2id.get(ch) for ch in text) if i]
+
+
+def collate(spects, transcripts, pad_id=0):
+    """Zero-pad features to the batch max T and PAD-pad targets: the 5-tuple of utils/data_loader.py:284-297."""
+    k = len(spects)
+    max_t = max(s.size(1) for s in spects)
+    freq = spects[0].size(0)
+    max_l = max(len(t) for t in transcripts)
+    inputs = torch.zeros(k, 1, freq, max_t)
+    input_sizes = torch.zeros(k, dtype=torch.int32)
+    input_percentages = torch.zeros(k, dtype=torch.float32)
+    targets = torch.full((k, max_l), pad_id, dtype=torch.int64)
+    target_sizes = torch.zeros(k, dtype=torch.int32)
+    for i, (s, t) in enumerate(zip(spects, transcripts)):
+        n = s.size(1)
+        inputs[i, 0, :, :n] = s
+        input_sizes[i] = n
+        input_percentages[i] = n / float(max_t)
+        targets[i, :len(t)] = torch.tensor(t, dtype=torch.int64)
+        target_sizes[i] = len(t)
+    return inputs, input_sizes, input_percentages, targets, target_sizes
+
+
+class ManifestTaskDataset:
+    """`.sample(k_train, k_valid, manifest_id)` over manifest CSVs like SpectrogramDataset (utils/data_loader.py:171-321).
+
+    feature_fn(wav_path) -> (F, T) float tensor replaces `parse_audio`; sampling uses np.random.choice with the same
+    per-manifest probabilities (uniform, or uniform over the leading `partitions[i]` fraction)."""
+
+    def __init__(self, vocab, args, manifest_filepath_list, feature_fn, partitions=None):
+        self.vocab, self.args, self.feature_fn = vocab, args, feature_fn
+        self.ids_list = [read_manifest(p) for p in manifest_filepath_list]
+        self.proba = []
+        for i, ids in enumerate(self.ids_list):
+            if partitions is not None:
+                part = max(int(len(ids) * partitions[i]), 1)
+                p = np.zeros(len(ids))
+                p[:part] = 1 / part
+            else:
+                p = np.full(len(ids), 1 / len(ids))
+            self.proba.append(p)
+
+    def _rows(self, ids, picks):
+        spects, trans = [], []
+        for j in picks:
+            wav, txt = ids[j][0], ids[j][1]
+            spects.append(self.feature_fn(wav)[:, :self.args.src_max_len])
+            trans.append(parse_transcript(self.vocab, txt))
+        return spects, trans
+
+    def sample(self, k_train, k_val, manifest_id):
+        ids = self.ids_list[manifest_id]
+        picks = np.random.choice(np.arange(0, len(ids)), k_train + k_val, p=self.proba[manifest_id], replace=True)
+        tr = collate(*self._rows(ids, picks[:k_train]), pad_id=self.vocab.PAD_ID)
+        va = collate(*self._rows(ids, picks[k_train:k_train + k_val]), pad_id=self.vocab.PAD_ID)
+        return tr, va
+
+
+def synth_batch(seed, k, T, L, vocab_size, variable=False, freq_bins=161):
+    """Seeded synthetic batch: N(0,1) 'spectrogram', labels in [4, V); optional ragged lengths."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(k, 1, freq_bins, T, generator=g)
+    y = torch.randint(4, vocab_size, (k, L), generator=g)
+    lens = torch.full((k,), T, dtype=torch.int32)
+    if variable:
+        lens = torch.randint(max(T // 8, 1), T + 1, (k,), generator=g).to(torch.int32)
+        lens[0] = T
+        if k > 1:
+            lens[-1] = max(T // 8, 1)
+        tl = torch.randint(max(L // 2, 1), L + 1, (k,), generator=g)
+        tl[0] = L
+        for i in range(k):
+            x[i, :, :, int(lens[i]):] = 0
+            y[i, int(tl[i]):] = 0
+    return x, lens, y
+
+
+class SyntheticTask:
+    """Duck-types the dataset contract of `TransientTrainer.train`: seeded synthetic (train, valid) batches per call."""
+
+    def __init__(self, task_id, k, T, L, vocab_size, variable=False, pin=False):
+        self.task_id, self.k, self.T, self.L, self.V, self.variable, self.pin = task_id, k, T, L, vocab_size, variable, pin
+        self.calls = 0
+
+    def sample(self, k_train, k_valid, manifest_id):
+        it = self.calls
+        self.calls += 1
+        out = []
+        for part, k in ((0, k_train), (1, k_valid)):
+            x, lens, y = synth_batch(1000 * it + 10 * self.task_id + part, k, self.T, self.L, self.V, self.variable)
+            if self.pin:
+                x = x.pin_memory()
+            out.append((x, lens, lens.float() / self.T, y, (y != 0).sum(1).to(torch.int32)))
+        return tuple(out)

@@ -1,0 +1,63 @@
+"""Multi-GPU plumbing: one process per MI355X, `torch.distributed` backend "nccl" (= RCCL over xGMI on ROCm).
+
+The path shards by meta-task: task m runs on rank m % world; the only data-path collective is one
+SUM all-reduce of the flat fp32 meta-gradient per meta-step.  Everything else (theta0, Adam moments) is replicated and
+updated by identical deterministic kernels, so replicas stay bit-identical without a parameter broadcast.
+Works with backend "gloo" on CPU tensors too (used by the world_size-2 tests).
+"""
+import os
+
+import torch
+import torch.distributed as td
+
+
+def is_on():
+    return td.is_available() and td.is_initialized()
+
+
+def rank():
+    return td.get_rank() if is_on() else 0
+
+
+def world_size():
+    return td.get_world_size() if is_on() else 1
+
+
+def init_from_env(backend=None):
+    """Initialise from torchrun's RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*; no-op for a single process."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world <= 1 or is_on():
+        return int(os.environ.get('LOCAL_RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if backend is None:
+        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+    if backend == 'nccl':
+        torch.cuda.set_device(local)
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    td.init_process_group(backend=backend, rank=int(os.environ['RANK']), world_size=world)
+    return local
+
+
+def shard_tasks(n_tasks, rank_, world):
+    """Task ids owned by `rank_`: m with m % world == rank_ (8 tasks on 8 GPUs = one each)."""
+    return [m for m in range(n_tasks) if m % world == rank_]
+
+
+def allreduce_sum_(flat):
+    """In-place SUM all-reduce of the flat meta-gradient (56 MB at the north-star size): one collective per meta-step."""
+    if is_on() and world_size() > 1:
+        td.all_reduce(flat, op=td.ReduceOp.SUM)
+    return flat
+
+
+def allreduce_scalars(values, device):
+    if not (is_on() and world_size() > 1):
+        return values
+    t = torch.tensor(values, dtype=torch.float64, device=device)
+    td.all_reduce(t, op=td.ReduceOp.SUM)
+    return t.tolist()
+
+
+def barrier():
+    if is_on() and world_size() > 1:
+        td.barrier()

@@ -1,0 +1,465 @@
+"""Pass executor: one forward + hand-written backward of the VGG-CNN + Transformer speech recogniser,
+issued as calls into libmtl_hip.so on the current HIP stream.
+
+PyTorch is used for device memory (a buffer arena of caller-owned tensors) and the stream handle only; every
+arithmetic op of the pass is a kernel from include/mtl_hip.h.  Parameters live in ONE flat fp32 buffer
+(`theta`, layout from `ParamLayout`); a pass reads parameters from any buffer with that layout (theta0 or the
+inner-loop theta') and ACCUMULATES gradients into a second flat buffer (`.backward()` semantics, which the
+reference's meta-gradient definition relies on -- SURVEY.md Q1).
+
+What a pass computes follows the reference line by line:
+  models/asr/transformer.py:120-149 (forward), modules/encoder.py:53-106, modules/decoder.py:71-115,293-323,
+  modules/common_layers.py:110-132,238-331, utils/metrics.py:96-126.
+"""
+import math
+
+import torch
+
+from . import _lib
+from ._lib import check
+
+PAD_ID, SOS_ID, EOS_ID = 0, 1, 2
+RELU, ACCUM = 1, 2
+
+
+class ParamLayout:
+    """name -> (offset, shape) inside the flat fp32 parameter buffer; offsets are 16-byte aligned."""
+
+    def __init__(self, named_shapes):
+        self.entries = {}
+        self.order = []
+        off = 0
+        for name, shape in named_shapes:
+            n = 1
+            for s in shape:
+                n *= int(s)
+            self.entries[name] = (off, tuple(int(s) for s in shape), n)
+            self.order.append(name)
+            off += (n + 3) // 4 * 4
+        self.total = off
+
+    def off(self, name):
+        return self.entries[name][0]
+
+    def view(self, flat, name):
+        off, shape, n = self.entries[name]
+        return flat[off:off + n].view(shape)
+
+
+class Hyper:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def decoder_io(padded_target, pad_id=PAD_ID, sos_id=SOS_ID, eos_id=EOS_ID):
+    """modules/decoder.py:55-69 on the host: seq_in = [SOS, y..] padded with EOS; seq_out = [y.., EOS] padded with PAD."""
+    tgt = padded_target.detach().to('cpu', torch.int64)
+    B = tgt.shape[0]
+    lens = (tgt != pad_id).sum(1)
+    width = int(lens.max()) + 1
+    seq_in = torch.full((B, width), eos_id, dtype=torch.int64)
+    seq_out = torch.full((B, width), pad_id, dtype=torch.int64)
+    for i in range(B):
+        row = tgt[i][tgt[i] != pad_id]
+        n = int(row.numel())
+        seq_in[i, 0] = sos_id
+        seq_in[i, 1:n + 1] = row
+        seq_out[i, :n] = row
+        seq_out[i, n] = eos_id
+    return seq_in, seq_out
+
+
+class PassEngine:
+    def __init__(self, layout, hp, device, pe_enc, pe_dec):
+        self.pe_enc, self.pe_dec = pe_enc, pe_dec   # (max_len, d) fp32 device tables (non-trainable buffers)
+        self.L = layout
+        self.hp = hp
+        self.device = device
+        self.lib = _lib.lib()
+        self.arena = {}     # name -> buffer of the current pass (looked up again by the backward)
+        self.pool = {}      # (name, shape, dtype) -> allocation, so alternating batch shapes do not re-allocate
+        self.saved = None
+        if device.type != 'cuda':
+            raise RuntimeError('PassEngine needs an MI355X device (got %s); there is no CPU product path' % device)
+
+    # ---------------------------------------------------------------- plumbing
+    def buf(self, name, shape, dtype=torch.float32):
+        key = (name, tuple(int(v) for v in shape), dtype)
+        t = self.pool.get(key)
+        if t is None:
+            t = torch.empty(key[1], dtype=dtype, device=self.device)
+            self.pool[key] = t
+        self.arena[name] = t
+        return t
+
+    def scratch(self, nbytes):
+        t = self.arena.get('_scratch')
+        if t is None or t.numel() * 4 < nbytes:
+            t = torch.empty((int(nbytes) + 3) // 4 + 1024, dtype=torch.float32, device=self.device)
+            self.arena['_scratch'] = t
+        return t.data_ptr()
+
+    @property
+    def stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def gemm(self, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias=None, gate=None, ldg=0, flags=0, alpha=1.0,
+             batch=1, H=1, sA=(0, 0), sB=(0, 0), sC=(0, 0)):
+        check(self.lib.mtl_gemm_f32(self.stream, ta, tb, M, N, K, alpha, A, lda, B, ldb, C, ldc, bias, gate, ldg, flags,
+                                    batch, H, sA[0], sA[1], sB[0], sB[1], sC[0], sC[1]), 'mtl_gemm_f32')
+
+    def linear_fwd(self, x, rows, k_in, w, b, y, n_out, relu=False):
+        self.gemm(0, 1, rows, n_out, k_in, x, k_in, w, k_in, y, n_out, bias=b, flags=RELU if relu else 0)
+
+    def linear_bwd(self, x, dy, rows, k_in, n_out, w, dw, db, dx, dx_accum, gate=None):
+        """dw += dy^T x ; db += colsum(dy) ; dx (=|+=) dy.W  (gate: ReLU mask source for dx)"""
+        self.gemm(1, 0, n_out, k_in, rows, dy, n_out, x, k_in, dw, k_in, flags=ACCUM)
+        if db is not None:
+            self.colsum(dy, rows, n_out, db)
+        if dx is not None:
+            self.gemm(0, 0, rows, k_in, n_out, dy, n_out, w, k_in, dx, k_in, gate=gate, ldg=k_in,
+                      flags=ACCUM if dx_accum else 0)
+
+    def colsum(self, x, rows, cols, out):
+        ws = self.scratch(self.lib.mtl_colsum_workspace(rows, cols))
+        check(self.lib.mtl_colsum_accum(self.stream, x, rows, cols, cols, out, ws), 'mtl_colsum_accum')
+
+    def ln_fwd(self, x, res, g, b, pe, keep, y, xhat, rstd, rows, T):
+        check(self.lib.mtl_layernorm_fwd(self.stream, x, res, g, b, pe, keep, y, xhat, rstd, rows, self.hp.d, T, 1e-5),
+              'mtl_layernorm_fwd')
+
+    def ln_bwd(self, dy, xhat, rstd, g, keep, dz, dg, db, rows):
+        ws = self.scratch(self.lib.mtl_layernorm_bwd_workspace(rows, self.hp.d))
+        check(self.lib.mtl_layernorm_bwd(self.stream, dy, xhat, rstd, g, keep, dz, dg, db, ws, rows, self.hp.d),
+              'mtl_layernorm_bwd')
+
+    # ---------------------------------------------------------------- attention / ffn blocks
+    def mha_fwd(self, tag, P, pre, xq, Bn, Tq, xkv, Tk, klen, causal, keep):
+        hp, L = self.hp, self.L
+        d, r, h, dk, dv = hp.d, hp.r, hp.h, hp.dk, hp.dv
+        Mq, Mk = Bn * Tq, Bn * Tk
+        hk, hv = h * dk, h * dv
+        o = lambda n: P + 4 * L.off(pre + n)
+        t = {}
+        for nm, src, rows, width in (('q', xq, Mq, hk), ('k', xkv, Mk, hk), ('v', xkv, Mk, hv)):
+            full = {'q': 'query', 'k': 'key', 'v': 'value'}[nm]
+            a = self.buf(tag + nm + 'a', (rows, r))
+            bfull = self.buf(tag + nm, (rows, width))
+            self.linear_fwd(src, rows, d, o(full + '_linear_a.weight'), None, a.data_ptr(), r)
+            self.linear_fwd(a.data_ptr(), rows, r, o(full + '_linear_b.weight'), o(full + '_linear_b.bias'),
+                            bfull.data_ptr(), width)
+            t[nm + 'a'], t[nm] = a, bfull
+        ldS = (Tk + 3) // 4 * 4
+        S = self.buf(tag + 'P', (Bn, h, Tq, ldS))
+        self.gemm(0, 1, Tq, Tk, dk, t['q'].data_ptr(), hk, t['k'].data_ptr(), hk, S.data_ptr(), ldS, batch=Bn * h, H=h,
+                  sA=(Tq * hk, dk), sB=(Tk * hk, dk), sC=(h * Tq * ldS, Tq * ldS))
+        check(self.lib.mtl_softmax_mask_fwd(self.stream, S.data_ptr(), klen, causal, 1.0 / float(hp.temperature), Bn, h, Tq,
+                                            Tk, ldS), 'mtl_softmax_mask_fwd')
+        O = self.buf(tag + 'O', (Mq, hv))
+        self.gemm(0, 0, Tq, dv, Tk, S.data_ptr(), ldS, t['v'].data_ptr(), hv, O.data_ptr(), hv, batch=Bn * h, H=h,
+                  sA=(h * Tq * ldS, Tq * ldS), sB=(Tk * hv, dv), sC=(Tq * hv, dv))
+        oa = self.buf(tag + 'oa', (Mq, r))
+        ob = self.buf(tag + 'ob', (Mq, d))
+        self.linear_fwd(O.data_ptr(), Mq, hv, o('output_linear_a.weight'), None, oa.data_ptr(), r)
+        self.linear_fwd(oa.data_ptr(), Mq, r, o('output_linear_b.weight'), o('output_linear_b.bias'), ob.data_ptr(), d)
+        y = self.buf(tag + 'y', (Mq, d))
+        xhat = self.buf(tag + 'xhat', (Mq, d))
+        rstd = self.buf(tag + 'rstd', (Mq,))
+        self.ln_fwd(ob.data_ptr(), xq, o('layer_norm.weight'), o('layer_norm.bias'), None, keep, y.data_ptr(),
+                    xhat.data_ptr(), rstd.data_ptr(), Mq, Tq)
+        return y
+
+    def mha_bwd(self, tag, P, G, pre, dy, xq, Bn, Tq, xkv, Tk, keep, dxq, dxkv, dxkv_accum):
+        """dy: grad of the block output.  Writes dxq (overwrite) and dxkv (accumulate when dxkv is dxq or flagged)."""
+        hp, L, A = self.hp, self.L, self.arena
+        d, r, h, dk, dv = hp.d, hp.r, hp.h, hp.dk, hp.dv
+        Mq, Mk = Bn * Tq, Bn * Tk
+        hk, hv = h * dk, h * dv
+        o = lambda n: P + 4 * L.off(pre + n)
+        g = lambda n: G + 4 * L.off(pre + n)
+        ldS = (Tk + 3) // 4 * 4
+        Pm, O, oa = A[tag + 'P'], A[tag + 'O'], A[tag + 'oa']
+        # LayerNorm(o + residual) * keep
+        self.ln_bwd(dy, A[tag + 'xhat'].data_ptr(), A[tag + 'rstd'].data_ptr(), o('layer_norm.weight'), keep, dxq,
+                    g('layer_norm.weight'), g('layer_norm.bias'), Mq)
+        dz = dxq  # residual path: dxq starts as dz, projections accumulate on top
+        doa = self.buf('_doa', (Mq, r))
+        self.linear_bwd(oa.data_ptr(), dz, Mq, r, d, o('output_linear_b.weight'), g('output_linear_b.weight'),
+                        g('output_linear_b.bias'), doa.data_ptr(), False)
+        dO = self.buf('_dO', (Mq, hv))
+        self.linear_bwd(O.data_ptr(), doa.data_ptr(), Mq, hv, r, o('output_linear_a.weight'), g('output_linear_a.weight'),
+                        None, dO.data_ptr(), False)
+        q, k, v = A[tag + 'q'], A[tag + 'k'], A[tag + 'v']
+        dq = self.buf('_dq', (Mq, hk))
+        dkk = self.buf('_dk', (Mk, hk))
+        dvv = self.buf('_dv', (Mk, hv))
+        dP = self.buf('_dP', (Bn, h, Tq, ldS))
+        sP = (h * Tq * ldS, Tq * ldS)
+        # dV = P^T dO ; dP = dO V^T ; dS = softmax'(P, dP)/temp ; dQ = dS K ; dK = dS^T Q
+        self.gemm(1, 0, Tk, dv, Tq, Pm.data_ptr(), ldS, dO.data_ptr(), hv, dvv.data_ptr(), hv, batch=Bn * h, H=h,
+                  sA=sP, sB=(Tq * hv, dv), sC=(Tk * hv, dv))
+        self.gemm(0, 1, Tq, Tk, dv, dO.data_ptr(), hv, v.data_ptr(), hv, dP.data_ptr(), ldS, batch=Bn * h, H=h,
+                  sA=(Tq * hv, dv), sB=(Tk * hv, dv), sC=sP)
+        check(self.lib.mtl_softmax_bwd(self.stream, Pm.data_ptr(), dP.data_ptr(), 1.0 / float(hp.temperature),
+                                       Bn * h * Tq, Tk, ldS), 'mtl_softmax_bwd')
+        self.gemm(0, 0, Tq, dk, Tk, dP.data_ptr(), ldS, k.data_ptr(), hk, dq.data_ptr(), hk, batch=Bn * h, H=h,
+                  sA=sP, sB=(Tk * hk, dk), sC=(Tq * hk, dk))
+        self.gemm(1, 0, Tk, dk, Tq, dP.data_ptr(), ldS, q.data_ptr(), hk, dkk.data_ptr(), hk, batch=Bn * h, H=h,
+                  sA=sP, sB=(Tq * hk, dk), sC=(Tk * hk, dk))
+        da = self.buf('_da', (max(Mq, Mk), r))
+        first_kv = True
+        for nm, full, dfull, src, rows, width, dst in (('q', 'query', dq, xq, Mq, hk, dxq), ('k', 'key', dkk, xkv, Mk, hk, dxkv),
+                                                       ('v', 'value', dvv, xkv, Mk, hv, dxkv)):
+            a = A[tag + nm + 'a']
+            self.linear_bwd(a.data_ptr(), dfull.data_ptr(), rows, r, width, o(full + '_linear_b.weight'),
+                            g(full + '_linear_b.weight'), g(full + '_linear_b.bias'), da.data_ptr(), False)
+            if nm == 'q':
+                accum = True
+            else:
+                accum = dxkv_accum or (dxkv == dxq) or not first_kv
+                first_kv = False
+            self.linear_bwd(src, da.data_ptr(), rows, d, r, o(full + '_linear_a.weight'), g(full + '_linear_a.weight'), None,
+                            dst, accum)
+
+    def ffn_fwd(self, tag, P, pre, x, rows, T, keep):
+        hp, L = self.hp, self.L
+        o = lambda n: P + 4 * L.off(pre + n)
+        h1 = self.buf(tag + 'h1', (rows, hp.inner))
+        h2 = self.buf(tag + 'h2', (rows, hp.d))
+        self.linear_fwd(x, rows, hp.d, o('linear_1.weight'), o('linear_1.bias'), h1.data_ptr(), hp.inner, relu=True)
+        self.linear_fwd(h1.data_ptr(), rows, hp.inner, o('linear_2.weight'), o('linear_2.bias'), h2.data_ptr(), hp.d)
+        y = self.buf(tag + 'y', (rows, hp.d))
+        xhat = self.buf(tag + 'xhat', (rows, hp.d))
+        rstd = self.buf(tag + 'rstd', (rows,))
+        self.ln_fwd(h2.data_ptr(), x, o('layer_norm.weight'), o('layer_norm.bias'), None, keep, y.data_ptr(), xhat.data_ptr(),
+                    rstd.data_ptr(), rows, T)
+        return y
+
+    def ffn_bwd(self, tag, P, G, pre, dy, x, rows, keep, dx):
+        hp, L, A = self.hp, self.L, self.arena
+        o = lambda n: P + 4 * L.off(pre + n)
+        g = lambda n: G + 4 * L.off(pre + n)
+        self.ln_bwd(dy, A[tag + 'xhat'].data_ptr(), A[tag + 'rstd'].data_ptr(), o('layer_norm.weight'), keep, dx,
+                    g('layer_norm.weight'), g('layer_norm.bias'), rows)
+        h1 = A[tag + 'h1']
+        dh1 = self.buf('_dh1', (rows, hp.inner))
+        self.linear_bwd(h1.data_ptr(), dx, rows, hp.inner, hp.d, o('linear_2.weight'), g('linear_2.weight'),
+                        g('linear_2.bias'), dh1.data_ptr(), False, gate=h1.data_ptr())
+        self.linear_bwd(x, dh1.data_ptr(), rows, hp.d, hp.inner, o('linear_1.weight'), g('linear_1.weight'),
+                        g('linear_1.bias'), dx, True)
+
+    # ---------------------------------------------------------------- the pass
+    def forward(self, theta, x, lengths, target, smoothing=0.0):
+        """x (B,1,F,T) fp32 on device; lengths (B) int; target (B,L) int64 PAD-padded.  Returns a dict with device
+        tensors pred (B,Td,V), gold, hyp (B,Td) int64 and `loss` (1,) fp32; keeps what the backward needs."""
+        hp, L, lib, st = self.hp, self.L, self.lib, self.stream
+        assert theta.numel() == L.total and theta.dtype == torch.float32 and theta.is_contiguous()
+        if x.dim() != 4 or x.shape[1] != 1:
+            raise ValueError('expected (B,1,F,T) input')
+        x = x.contiguous()
+        if x.dtype != torch.float32 or x.device != self.device:
+            raise ValueError('input must be fp32 on %s' % self.device)
+        B, _, F, T = x.shape
+        T2, F2 = T // 2, F // 2
+        T4, F4 = T2 // 2, F2 // 2
+        if F4 * 128 != hp.d_in:
+            raise ValueError('dim_input %d does not match %d frequency bins' % (hp.d_in, F))
+        P = theta.data_ptr()
+        o = lambda n: P + 4 * L.off(n)
+        d, V = hp.d, hp.V
+
+        # ---- host-side integer prep (masks are derived from lengths inside the kernels) ----
+        seq_in, seq_out = decoder_io(target)
+        Td = seq_in.shape[1]
+        if T4 > hp.src_max_len or Td > hp.tgt_max_len:
+            raise ValueError('sequence longer than the positional tables')
+        lens = lengths.detach().to('cpu', torch.int64)
+        is_pad = seq_in.eq(EOS_ID)
+        dec_len = (~is_pad).sum(1)
+        if not bool((is_pad == (torch.arange(Td).unsqueeze(0) >= dec_len.unsqueeze(1))).all()):
+            raise ValueError('EOS inside a target sequence is not supported')
+        pos = torch.arange(T4).unsqueeze(0)
+        meta_i32 = torch.cat([
+            torch.clamp(lens, max=T4).to(torch.int32),                        # klen_enc (B)      (raw lengths)
+            dec_len.to(torch.int32),                                           # klen_dec (B)
+            (pos < lens.unsqueeze(1)).to(torch.int32).reshape(-1),             # keep_enc (B*T4)
+            (~is_pad).to(torch.int32).reshape(-1)])                            # keep_dec (B*Td)
+        dev_i32 = self.buf('meta_i32', (meta_i32.numel(),), torch.int32)
+        dev_i32.copy_(meta_i32, non_blocking=True)
+        ids = self.buf('ids', (2, B, Td), torch.int64)
+        ids.copy_(torch.stack([seq_in, seq_out]), non_blocking=True)
+        klen_enc = dev_i32.data_ptr()
+        klen_dec = klen_enc + 4 * B
+        keep_enc = klen_dec + 4 * B
+        keep_dec = keep_enc + 4 * B * T4
+        n_nonpad = int((seq_out != PAD_ID).sum())
+        Me, Md = B * T4, B * Td
+
+        # ---- VGG front-end ----
+        y1 = self.buf('y1', (B, T, F, 64))
+        check(lib.mtl_conv0_relu_fwd(st, x.data_ptr(), o('conv.0.weight'), o('conv.0.bias'), y1.data_ptr(), B, T, F), 'conv0')
+        wf, wd = {}, {}
+        for idx, cin, cout in ((2, 64, 64), (5, 64, 128), (7, 128, 128)):
+            wf[idx] = self.buf('wf%d' % idx, (9, cin, cout))
+            wd[idx] = self.buf('wd%d' % idx, (9, cout, cin))
+            check(lib.mtl_conv3x3_wprep(st, o('conv.%d.weight' % idx), wf[idx].data_ptr(), wd[idx].data_ptr(), cout, cin), 'wprep')
+        p1 = self.buf('p1', (B, T2, F2, 64))
+        am1 = self.buf('am1', (B, T2, F2, 64), torch.uint8)
+        check(lib.mtl_conv3x3_relu_pool_fwd(st, y1.data_ptr(), wf[2].data_ptr(), o('conv.2.bias'), p1.data_ptr(), am1.data_ptr(),
+                                            B, T, F, 64, 64), 'conv2')
+        y5 = self.buf('y5', (B, T2, F2, 128))
+        check(lib.mtl_conv3x3_relu_fwd(st, p1.data_ptr(), wf[5].data_ptr(), o('conv.5.bias'), y5.data_ptr(), B, T2, F2, 64, 128),
+              'conv5')
+        p2 = self.buf('p2', (B, T4, F4, 128))
+        am2 = self.buf('am2', (B, T4, F4, 128), torch.uint8)
+        check(lib.mtl_conv3x3_relu_pool_fwd(st, y5.data_ptr(), wf[7].data_ptr(), o('conv.7.bias'), p2.data_ptr(), am2.data_ptr(),
+                                            B, T2, F2, 128, 128), 'conv7')
+
+        # ---- encoder ----
+        wp = self.buf('wp_in', (d, hp.d_in))
+        check(lib.mtl_permute_hc(st, o('encoder.input_linear.weight'), wp.data_ptr(), d, 128, F4, 0), 'permute')
+        e0 = self.buf('e0', (Me, d))
+        self.linear_fwd(p2.data_ptr(), Me, hp.d_in, wp.data_ptr(), o('encoder.input_linear.bias'), e0.data_ptr(), d)
+        ex = self.buf('enc_in.y', (Me, d))
+        self.ln_fwd(e0.data_ptr(), None, o('encoder.layer_norm_input.weight'), o('encoder.layer_norm_input.bias'),
+                    self.pe_enc.data_ptr(), None, ex.data_ptr(), self.buf('enc_in.xhat', (Me, d)).data_ptr(),
+                    self.buf('enc_in.rstd', (Me,)).data_ptr(), Me, T4)
+        cur = ex
+        enc_inputs = []
+        for i in range(hp.n_enc):
+            pre = 'encoder.layers.%d.' % i
+            enc_inputs.append(cur)
+            a = self.mha_fwd('e%d.sa.' % i, P, pre + 'self_attn.', cur.data_ptr(), B, T4, cur.data_ptr(), T4, klen_enc, 0, keep_enc)
+            cur = self.ffn_fwd('e%d.ff.' % i, P, pre + 'pos_ffn.', a.data_ptr(), Me, T4, keep_enc)
+        mem = cur
+
+        # ---- decoder ----
+        d0 = self.buf('dec_in.y', (Md, d))
+        check(lib.mtl_embed_pe_fwd(st, ids.data_ptr(), o('decoder.trg_embedding.weight'), self.pe_dec.data_ptr(), d0.data_ptr(),
+                                   Md, Td, d), 'embed')
+        cur = d0
+        for i in range(hp.n_dec):
+            pre = 'decoder.layers.%d.' % i
+            a = self.mha_fwd('d%d.sa.' % i, P, pre + 'self_attn.', cur.data_ptr(), B, Td, cur.data_ptr(), Td, klen_dec, 1, keep_dec)
+            c = self.mha_fwd('d%d.ca.' % i, P, pre + 'encoder_attn.', a.data_ptr(), B, Td, mem.data_ptr(), T4, klen_enc, 0, keep_dec)
+            cur = self.ffn_fwd('d%d.ff.' % i, P, pre + 'pos_ffn.', c.data_ptr(), Md, Td, keep_dec)
+        pred = self.buf('pred', (B, Td, V))
+        self.gemm(0, 1, Md, V, d, cur.data_ptr(), d, o('decoder.output_linear.weight'), d, pred.data_ptr(), V)
+
+        # ---- loss + arg-max ----
+        lse = self.buf('lse', (Md,))
+        hyp = self.buf('hyp', (B, Td), torch.int64)
+        rowloss = self.buf('rowloss', (Md,))
+        loss = self.buf('loss', (1,))
+        gold_ptr = ids.data_ptr() + 8 * Md
+        check(lib.mtl_ce_argmax_fwd(st, pred.data_ptr(), gold_ptr, Md, V, V, PAD_ID, float(smoothing), n_nonpad, lse.data_ptr(),
+                                    hyp.data_ptr(), rowloss.data_ptr(), loss.data_ptr()), 'ce_fwd')
+        self.saved = dict(theta=theta, x=x, B=B, T=T, F=F, Td=Td, n_nonpad=n_nonpad, smoothing=float(smoothing),
+                          klen_enc=klen_enc, klen_dec=klen_dec, keep_enc=keep_enc, keep_dec=keep_dec, dec_last=cur,
+                          enc_inputs=enc_inputs)
+        return dict(pred=pred, gold=ids[1], hyp=hyp, loss=loss, gold_host=seq_out, n_nonpad=n_nonpad)
+
+    def backward(self, grad, scale=1.0, dpred=None):
+        """Accumulate `scale` * dLoss/dtheta of the LAST forward into the flat buffer `grad` (+=).
+        dpred: optional externally supplied gradient w.r.t. pred (B,Td,V) instead of the fused CE backward."""
+        S = self.saved
+        if S is None:
+            raise RuntimeError('backward() without a preceding forward()')
+        hp, L, lib, st, A = self.hp, self.L, self.lib, self.stream, self.arena
+        assert grad.numel() == L.total and grad.is_contiguous()
+        theta = S['theta']
+        P, G = theta.data_ptr(), grad.data_ptr()
+        o = lambda n: P + 4 * L.off(n)
+        g = lambda n: G + 4 * L.off(n)
+        B, T, F, Td = S['B'], S['T'], S['F'], S['Td']
+        T2, F2 = T // 2, F // 2
+        T4, F4 = T2 // 2, F2 // 2
+        Me, Md, d, V = B * T4, B * Td, hp.d, hp.V
+        keep_enc, keep_dec = S['keep_enc'], S['keep_dec']
+
+        if dpred is None:
+            ldd = (V + 3) // 4 * 4        # padded leading dimension -> 16-byte operand loads in the two GEMMs below
+            dlog = self.buf('_dpred', (Md, ldd))
+            gold_ptr = A['ids'].data_ptr() + 8 * Md
+            check(lib.mtl_ce_bwd(st, A['pred'].data_ptr(), A['lse'].data_ptr(), gold_ptr, Md, V, V, PAD_ID, S['smoothing'],
+                                 float(scale) / S['n_nonpad'], None, dlog.data_ptr(), ldd), 'ce_bwd')
+            dlog_ptr = dlog.data_ptr()
+        else:
+            ldd = V
+            dlog = dpred.contiguous()
+            if scale != 1.0:
+                dlog = dlog * scale
+            dlog_ptr = dlog.data_ptr()
+        dA = self.buf('_dxA', (Md, d))
+        dB = self.buf('_dxB', (Md, d))
+        dmem = self.buf('_dmem', (Me, d))
+        last = S['dec_last']
+        # vocab projection (no bias)
+        self.gemm(1, 0, V, d, Md, dlog_ptr, ldd, last.data_ptr(), d, g('decoder.output_linear.weight'), d, flags=ACCUM)
+        self.gemm(0, 0, Md, d, V, dlog_ptr, ldd, o('decoder.output_linear.weight'), d, dA.data_ptr(), d)
+        dcur, dnext = dA, dB
+        for i in reversed(range(hp.n_dec)):
+            pre = 'decoder.layers.%d.' % i
+            x_in = A['dec_in.y'] if i == 0 else A['d%d.ff.y' % (i - 1)]
+            sa_y, ca_y = A['d%d.sa.y' % i], A['d%d.ca.y' % i]
+            self.ffn_bwd('d%d.ff.' % i, P, G, pre + 'pos_ffn.', dcur.data_ptr(), ca_y.data_ptr(), Md, keep_dec, dnext.data_ptr())
+            dcur, dnext = dnext, dcur
+            self.mha_bwd('d%d.ca.' % i, P, G, pre + 'encoder_attn.', dcur.data_ptr(), sa_y.data_ptr(), B, Td,
+                         A['e%d.ff.y' % (hp.n_enc - 1)].data_ptr() if hp.n_enc else A['enc_in.y'].data_ptr(), T4, keep_dec,
+                         dnext.data_ptr(), dmem.data_ptr(), i != hp.n_dec - 1)
+            dcur, dnext = dnext, dcur
+            self.mha_bwd('d%d.sa.' % i, P, G, pre + 'self_attn.', dcur.data_ptr(), x_in.data_ptr(), B, Td, x_in.data_ptr(), Td,
+                         keep_dec, dnext.data_ptr(), dnext.data_ptr(), True)
+            dcur, dnext = dnext, dcur
+        check(lib.mtl_embed_bwd(st, A['ids'].data_ptr(), dcur.data_ptr(), g('decoder.trg_embedding.weight'), Md, d, PAD_ID),
+              'embed_bwd')
+
+        # ---- encoder ----
+        eA = self.buf('_deA', (Me, d))
+        dcur, dnext = dmem, eA
+        for i in reversed(range(hp.n_enc)):
+            pre = 'encoder.layers.%d.' % i
+            x_in = A['enc_in.y'] if i == 0 else A['e%d.ff.y' % (i - 1)]
+            self.ffn_bwd('e%d.ff.' % i, P, G, pre + 'pos_ffn.', dcur.data_ptr(), A['e%d.sa.y' % i].data_ptr(), Me, keep_enc,
+                         dnext.data_ptr())
+            dcur, dnext = dnext, dcur
+            self.mha_bwd('e%d.sa.' % i, P, G, pre + 'self_attn.', dcur.data_ptr(), x_in.data_ptr(), B, T4, x_in.data_ptr(), T4,
+                         keep_enc, dnext.data_ptr(), dnext.data_ptr(), True)
+            dcur, dnext = dnext, dcur
+        # input LayerNorm (+PE: no grad) and input_linear
+        de0 = dnext
+        self.ln_bwd(dcur.data_ptr(), A['enc_in.xhat'].data_ptr(), A['enc_in.rstd'].data_ptr(), o('encoder.layer_norm_input.weight'),
+                    None, de0.data_ptr(), g('encoder.layer_norm_input.weight'), g('encoder.layer_norm_input.bias'), Me)
+        p2, y5, p1, y1 = A['p2'], A['y5'], A['p1'], A['y1']
+        dwp = self.buf('_dwp', (d, hp.d_in))
+        dp2 = self.buf('_dp2', (B, T4, F4, 128))
+        self.gemm(1, 0, d, hp.d_in, Me, de0.data_ptr(), d, p2.data_ptr(), hp.d_in, dwp.data_ptr(), hp.d_in)
+        check(lib.mtl_permute_hc(st, dwp.data_ptr(), g('encoder.input_linear.weight'), d, 128, F4, 1), 'permute_inv')
+        self.colsum(de0.data_ptr(), Me, d, g('encoder.input_linear.bias'))
+        self.gemm(0, 0, Me, hp.d_in, d, de0.data_ptr(), d, A['wp_in'].data_ptr(), hp.d_in, dp2.data_ptr(), hp.d_in,
+                  gate=p2.data_ptr(), ldg=hp.d_in)
+
+        # ---- VGG front-end ----
+        def wgrad(xa, dy, am, idx, Bq, Tq, Fq, cin, cout):
+            need = lib.mtl_conv3x3_wgrad_workspace(Bq, Tq, Fq, cin, cout, 1 if am else 0)
+            ws = self.scratch(need)
+            check(lib.mtl_conv3x3_wgrad(st, xa, dy, am, g('conv.%d.weight' % idx), ws, need, Bq, Tq, Fq, cin, cout), 'wgrad')
+
+        self.colsum(dp2.data_ptr(), B * T4 * F4, 128, g('conv.7.bias'))
+        wgrad(y5.data_ptr(), dp2.data_ptr(), A['am2'].data_ptr(), 7, B, T2, F2, 128, 128)
+        dy5 = self.buf('_dy5', (B, T2, F2, 128))
+        check(lib.mtl_conv3x3_dgrad(st, dp2.data_ptr(), A['am2'].data_ptr(), A['wd7'].data_ptr(), y5.data_ptr(), dy5.data_ptr(),
+                                    B, T2, F2, 128, 128), 'dgrad7')
+        self.colsum(dy5.data_ptr(), B * T2 * F2, 128, g('conv.5.bias'))
+        wgrad(p1.data_ptr(), dy5.data_ptr(), None, 5, B, T2, F2, 64, 128)
+        dp1 = self.buf('_dp1', (B, T2, F2, 64))
+        check(lib.mtl_conv3x3_dgrad(st, dy5.data_ptr(), None, A['wd5'].data_ptr(), p1.data_ptr(), dp1.data_ptr(), B, T2, F2, 64,
+                                    128), 'dgrad5')
+        self.colsum(dp1.data_ptr(), B * T2 * F2, 64, g('conv.2.bias'))
+        wgrad(y1.data_ptr(), dp1.data_ptr(), A['am1'].data_ptr(), 2, B, T, F, 64, 64)
+        dy1 = self.buf('_dy1', (B, T, F, 64))
+        check(lib.mtl_conv3x3_dgrad(st, dp1.data_ptr(), A['am1'].data_ptr(), A['wd2'].data_ptr(), y1.data_ptr(), dy1.data_ptr(),
+                                    B, T, F, 64, 64), 'dgrad2')
+        ws = self.scratch(lib.mtl_conv0_wgrad_workspace())
+        check(lib.mtl_conv0_wgrad(st, S['x'].data_ptr(), dy1.data_ptr(), g('conv.0.weight'), g('conv.0.bias'), ws, B, T, F),
+              'wgrad0')

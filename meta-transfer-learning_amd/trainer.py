@@ -1,0 +1,336 @@
+"""`TransientTrainer`: drop-in for trainer/asr/transient_trainer.py (the `--copy-grad` meta-transfer loop).
+
+Same `train(...)` / `forward_one_batch(...)` signatures, log lines and meta-gradient definition
+    G = sum_m [ grad L_tr,m(theta0) + (1/n) grad L_val(theta0 - alpha grad L_tr,m(theta0)) ]      
+but the iteration is restructured for the device:
+  * theta0 is never mutated inside an iteration (theta' is materialised by one fused kernel into a second flat
+    buffer), which removes deepcopy(state_dict) / n x load_state_dict (transient_trainer.py:155-160,237);
+  * gradients, copy_grad, Adam moments are single flat fp32 buffers updated by one kernel each;
+  * label/loss read-backs are asynchronous copies resolved once per iteration instead of ~1600 `int(x)` device
+    syncs per forward (transient_trainer.py:29-35,46);
+  * with torch.distributed initialised, tasks are sharded round-robin over ranks and the flat G is summed with ONE
+    all-reduce (RCCL over xGMI) before the (replicated, deterministic) Adam step.
+"""
+import logging
+import threading
+import time
+from collections import deque
+
+import torch
+
+from . import _lib, dist as mdist
+from .functions import post_process, save_meta_model
+from .metrics import calculate_cer
+
+check = _lib.check
+
+
+class FlatAdam:
+    """torch.optim.Adam(lr, betas=(0.9,0.999), eps=1e-8) over the model's flat parameter buffer."""
+
+    def __init__(self, model, lr, betas=(0.9, 0.999), eps=1e-8):
+        self.model, self.lr, self.betas, self.eps = model, lr, betas, eps
+        self.m = torch.zeros_like(model.flat_parameters)
+        self.v = torch.zeros_like(model.flat_parameters)
+        self.step_count = 0
+        self.param_groups = [{'lr': lr, 'betas': betas, 'eps': eps}]
+
+    @classmethod
+    def from_torch(cls, model, opt):
+        """Import the state of a torch.optim.Adam built over model.parameters() (reference checkpoints pickle those)."""
+        g = opt.param_groups[0]
+        self = cls(model, g['lr'], tuple(g['betas']), g['eps'])
+        lay = model._layout
+        for name, p in zip(lay.order, opt.param_groups[0]['params']):
+            st = opt.state.get(p, None)
+            if st:
+                lay.view(self.m, name).copy_(st['exp_avg'])
+                lay.view(self.v, name).copy_(st['exp_avg_sq'])
+                self.step_count = int(st['step'])
+        return self
+
+    def to_torch(self):
+        opt = torch.optim.Adam(self.model.parameters(), lr=self.param_groups[0]['lr'], betas=self.betas, eps=self.eps)
+        if self.step_count:
+            lay = self.model._layout
+            for name, p in zip(lay.order, self.model.parameters()):
+                opt.state[p] = {'step': torch.tensor(float(self.step_count)), 'exp_avg': lay.view(self.m, name).clone(),
+                                'exp_avg_sq': lay.view(self.v, name).clone()}
+        return opt
+
+    def zero_grad(self):
+        self.model.zero_grad()
+
+    def step(self, grad=None):
+        m = self.model
+        g = m.flat_grad if grad is None else grad
+        self.step_count += 1
+        th = m.flat_parameters
+        check(_lib.lib().mtl_adam_step(torch.cuda.current_stream(th.device).cuda_stream, th.data_ptr(), g.data_ptr(),
+                                       self.m.data_ptr(), self.v.data_ptr(), self.step_count, float(self.param_groups[0]['lr']),
+                                       self.betas[0], self.betas[1], self.eps, th.numel()), 'mtl_adam_step')
+
+
+class FlatSGD:
+    """torch.optim.SGD(lr) (no momentum / weight decay) as theta' = theta0 - lr*g into a separate buffer."""
+
+    def __init__(self, model, lr):
+        self.model = model
+        self.param_groups = [{'lr': lr}]
+        self.theta_prime = torch.empty_like(model.flat_parameters)
+
+    @classmethod
+    def from_torch(cls, model, opt):
+        return cls(model, opt.param_groups[0]['lr'])
+
+    def to_torch(self):
+        return torch.optim.SGD(self.model.parameters(), lr=self.param_groups[0]['lr'])
+
+    def zero_grad(self):
+        self.model.zero_grad()
+
+    def theta_prime_from(self, theta0, grad):
+        check(_lib.lib().mtl_sgd_theta_prime(torch.cuda.current_stream(theta0.device).cuda_stream, theta0.data_ptr(),
+                                             grad.data_ptr(), float(self.param_groups[0]['lr']), self.theta_prime.data_ptr(),
+                                             theta0.numel()), 'mtl_sgd_theta_prime')
+        return self.theta_prime
+
+
+def clip_flat_grad_(model, grad, max_norm):
+    """torch.nn.utils.clip_grad_norm_ on the flat buffer: grad *= min(1, max_norm / (||grad|| + 1e-6)), no host sync."""
+    eng = model._need_engine()
+    ws = eng.scratch(8192)
+    coef = eng.buf('_clip_coef', (1,))
+    st = eng.stream
+    check(eng.lib.mtl_sumsq(st, grad.data_ptr(), grad.numel(), coef.data_ptr(), ws, 2, float(max_norm)), 'mtl_sumsq')
+    check(eng.lib.mtl_scale(st, grad.data_ptr(), 1.0, coef.data_ptr(), grad.numel()), 'mtl_scale')
+
+
+class _Readback:
+    """Asynchronous D2H of (gold, hyp, loss) of one forward; resolved after the iteration's single sync."""
+
+    def __init__(self, out, stream_device):
+        self.gold_host = out['gold_host']
+        self.hyp = torch.empty(out['hyp'].shape, dtype=torch.int64).pin_memory()
+        self.loss = torch.empty(1, dtype=torch.float32).pin_memory()
+        self.hyp.copy_(out['hyp'], non_blocking=True)
+        self.loss.copy_(out['loss'], non_blocking=True)
+
+
+def _strings(vocab, rows):
+    return [''.join(vocab.id2label[int(t)] for t in row) for row in rows.tolist()]
+
+
+def cer_counts(vocab, gold, hyp):
+    """total edit distance / reference length over a batch, exactly as transient_trainer.py:29-35,52-64."""
+    total_cer, total_char = 0, 0
+    for g, h in zip(_strings(vocab, gold), _strings(vocab, hyp)):
+        h = post_process(h, vocab.special_token_list).replace(' ', '')
+        g = post_process(g, vocab.special_token_list).replace(' ', '')
+        total_cer += calculate_cer(h, g)
+        total_char += len(g)
+    return total_cer, total_char
+
+
+class TransientTrainer():
+    def __init__(self):
+        logging.info('Transient Trainer is initialized')
+
+    # ------------------------------------------------------------------ drop-in single-batch API
+    def forward_one_batch(self, model, vocab, src, trg, src_percentages, src_lengths, trg_lengths, smoothing, loss_type,
+                          verbose=False):
+        """-> (loss tensor, total_cer, total_char); `loss.backward()` runs the HIP backward (transient_trainer.py:25-73)."""
+        if loss_type != 'ce':
+            raise NotImplementedError("only loss_type='ce' is on the accelerated path")
+        pred, gold, hyp = model(src, src_lengths, trg, verbose=False)
+        if smoothing and smoothing > 0:
+            raise NotImplementedError('label smoothing is available through train() (fused pass), not this compatibility call')
+        src_percentages.mul_(int(pred.size(1)))     # the reference scales the caller's tensor in place
+        loss = model.loss_from_last_forward(pred)
+        total_cer, total_char = cer_counts(vocab, gold.cpu(), hyp.cpu())
+        if verbose:
+            print('Total CER', total_cer)
+            print('Total char', total_char)
+        return loss, total_cer, total_char
+
+    def get_lr(self, optimizer):
+        for param_group in optimizer.param_groups:
+            return param_group['lr']
+
+    # ------------------------------------------------------------------ one meta-iteration on the device
+    def meta_iteration(self, model, vocab, task_batches, val_batch, n_tasks, inner, outer, args, task_ids=None):
+        """task_batches: this rank's [(inputs, input_sizes, percentages, targets, target_sizes)], val_batch: same 5-tuple.
+        n_tasks is the GLOBAL task count (the 1/n of the validation loss).  Returns (sum val loss, cer, chars) local."""
+        dev = model.flat_parameters.device
+        theta0, g, G = model.flat_parameters, model.flat_grad, model._G
+        smoothing = float(getattr(args, 'label_smoothing', 0.0) or 0.0)
+        reads = []
+        G.zero_()
+        vx = val_batch[0].to(dev, non_blocking=True)
+        for (tx, tsz, _tp, ty, _tl) in task_batches:
+            tx = tx.to(dev, non_blocking=True)
+            g.zero_()                                                            # inner_opt.zero_grad()   (:198)
+            out = model.pass_forward(tx, tsz, ty, theta=theta0, smoothing=smoothing)   # meta-train forward (:188)
+            tr_read = _Readback(out, dev)
+            model.pass_backward(g, 1.0)                                          # tr_loss.backward()      (:199)
+            if args.clip:
+                clip_flat_grad_(model, g, args.max_norm)                         # (:205-206)
+            theta1 = inner.theta_prime_from(theta0, g)                           # inner_opt.step()        (:207)
+            out = model.pass_forward(vx, val_batch[1], val_batch[3], theta=theta1, smoothing=smoothing)   # (:215)
+            va_read = _Readback(out, dev)
+            model.pass_backward(g, 1.0 / n_tasks)                                # (val_loss/n).backward(): g += g_val/n (:226-227, Q1)
+            model._axpy(G, g, 1.0)                                               # add_copy_grad()         (:229)
+            reads.append((tr_read, va_read))
+        return reads
+
+    def train(self, model, vocab, train_data_list, valid_loader_list, loss_type, start_it, num_it, args, inner_opt=None,
+              outer_opt=None, evaluate_every=1000, window_size=100, last_summary_every=1000, last_metrics=None, early_stop=10,
+              cpu_state_dict=False, is_copy_grad=False):
+        if loss_type != 'ce':
+            raise NotImplementedError("only loss_type='ce' is on the accelerated path")
+        if not is_copy_grad:
+            raise NotImplementedError('the accelerated path is the --copy-grad loop (is_copy_grad=True)')
+        history = []
+        best_valid_val = 1000000000
+        early_stop_criteria, early_stop_val = early_stop.split(',')[0], int(early_stop.split(',')[1])
+        count_stop = 0
+        logging.info('name ' + args.name)
+        total_time = 0
+        logging.info('TRAIN')
+        rank, world = mdist.rank(), mdist.world_size()
+        if rank == 0:
+            print('TRAIN')
+        model.train()
+
+        if inner_opt is None:
+            inner_opt = FlatSGD(model, args.lr)
+        elif not isinstance(inner_opt, FlatSGD):
+            inner_opt = FlatSGD.from_torch(model, inner_opt)
+        if outer_opt is None:
+            outer_opt = FlatAdam(model, args.meta_lr)
+        elif not isinstance(outer_opt, FlatAdam):
+            outer_opt = FlatAdam.from_torch(model, outer_opt)
+        self.inner_opt, self.outer_opt = inner_opt, outer_opt
+        model.zero_copy_grad()
+
+        last_sum_loss, last_sum_cer, last_sum_char = deque(maxlen=window_size), deque(maxlen=window_size), deque(maxlen=window_size)
+        k_train, k_valid = args.k_train, args.k_valid
+        n_tasks = len(train_data_list)
+        train_data_buffer = [[] for _ in range(n_tasks)]
+        my_tasks = mdist.shard_tasks(n_tasks, rank, world)
+
+        def fetch_train_batch(buf):
+            for manifest_id in range(n_tasks):                       # every rank draws every task: RNG streams stay in lock-step
+                buf[manifest_id].insert(0, train_data_list[manifest_id].sample(k_train, k_valid, manifest_id))
+
+        prefetch = threading.Thread(target=fetch_train_batch, args=(train_data_buffer,))
+        prefetch.start()
+        dev = model.flat_parameters.device
+        it = start_it
+        while it < num_it:
+            prefetch.join()
+            prefetch = threading.Thread(target=fetch_train_batch, args=(train_data_buffer,))
+            prefetch.start()
+
+            start_time = time.time()
+            _, val_data = train_data_buffer[-1][-1]                  # the LAST task's validation batch, shared by all (:168)
+            popped = [train_data_buffer[m].pop() for m in range(n_tasks)]
+            task_batches = [popped[m][0] for m in my_tasks]
+            outer_opt.zero_grad()
+            reads = self.meta_iteration(model, vocab, task_batches, val_data, n_tasks, inner_opt, outer_opt, args)
+            G = model._G
+            mdist.allreduce_sum_(G)                                  # the one collective of the path
+            if args.clip:
+                clip_flat_grad_(model, G, args.max_norm)             # (:253-254) on the summed meta-gradient
+            outer_opt.step(G)                                        # from_copy_grad() + outer_opt.step()  (:248-255)
+            torch.cuda.synchronize(dev)
+
+            total_loss, total_cer, total_char = 0.0, 0, 0
+            for tr_read, va_read in reads:
+                c, n = cer_counts(vocab, tr_read.gold_host, tr_read.hyp)    # the reference reports the TRAIN batches' CER
+                total_cer += c
+                total_char += n
+                total_loss += float(va_read.loss[0])
+            total_loss, total_cer, total_char = mdist.allreduce_scalars([total_loss, total_cer, total_char], dev)
+            last_sum_cer.append(total_cer)
+            last_sum_char.append(total_char)
+            last_sum_loss.append(total_loss / n_tasks)
+            diff_time = time.time() - start_time
+            total_time += diff_time
+            self.last_iteration_seconds = diff_time
+
+            msg = '(Iteration {}) TRAIN LOSS:{:.4f} CER:{:.2f}% LR:{:.7f} TOTAL TIME:{:.7f}'.format(
+                (it + 1), total_loss / n_tasks, total_cer * 100 / max(total_char, 1), self.get_lr(outer_opt), total_time)
+            if rank == 0:
+                print(msg)
+            logging.info(msg)
+            if (it + 1) % last_summary_every == 0:
+                msg = '(Summary Iteration {} | MA {}) TRAIN LOSS:{:.4f} CER:{:.2f}%'.format(
+                    (it + 1), window_size, sum(last_sum_loss) / len(last_sum_loss), sum(last_sum_cer) * 100 / sum(last_sum_char))
+                if rank == 0:
+                    print(msg, flush=True)
+                logging.info(msg)
+
+            if (it + 1) % evaluate_every == 0:
+                stop, best_valid_val, count_stop = self._validate(model, vocab, valid_loader_list, it, args, history, inner_opt,
+                                                                  outer_opt, early_stop_criteria, early_stop_val, best_valid_val,
+                                                                  count_stop, rank)
+                if stop:
+                    break
+            it += 1
+        prefetch.join()
+
+    # ------------------------------------------------------------------ validation + checkpoints (transient_trainer.py:280-360)
+    def _validate(self, model, vocab, valid_loader_list, it, args, history, inner_opt, outer_opt, criteria, stop_val, best, count_stop,
+                  rank):
+        if rank == 0:
+            print('')
+        logging.info('VALID')
+        model.eval()
+        final_losses, final_cers = [], []
+        dev = model.flat_parameters.device
+        for ind, loader in enumerate(valid_loader_list):
+            tot_loss, tot_cer, tot_char, nb = 0.0, 0, 0, 0
+            for data in loader:
+                src, trg, _pct, src_lengths, _tl = data
+                out = model.pass_forward(src.to(dev), src_lengths, trg)
+                c, n = cer_counts(vocab, out['gold_host'], out['hyp'].cpu())
+                tot_cer += c
+                tot_char += n
+                tot_loss += float(out['loss'].item())
+                nb += 1
+            final_losses.append(tot_loss / max(nb, 1))
+            final_cers.append(tot_cer * 100 / max(tot_char, 1))
+            msg = '(Iteration {}) VALID SET {} LOSS:{:.4f} CER:{:.2f}%'.format((it + 1), ind, final_losses[-1], final_cers[-1])
+            if rank == 0:
+                print(msg)
+            logging.info(msg)
+        model.train()
+        if not final_losses:
+            return False, best, count_stop
+        metrics = {'avg_valid_loss': sum(final_losses) / len(final_losses), 'avg_valid_cer': sum(final_cers) / len(final_cers),
+                   'valid_loss': final_losses, 'valid_cer': final_cers, 'history': history}
+        history.append(metrics)
+        msg = '(Iteration {}) AVG VALID LOSS:{:.4f} AVG CER:{:.2f}%'.format((it + 1), metrics['avg_valid_loss'], metrics['avg_valid_cer'])
+        if rank == 0:
+            print(msg)
+        logging.info(msg)
+        if rank == 0 and (it + 1) % args.save_every == 0:
+            save_meta_model(model, vocab, (it + 1), inner_opt, outer_opt, metrics, args, best_model=False)
+        cur = metrics['avg_valid_cer'] if criteria == 'cer' else metrics['avg_valid_loss']
+        if rank == 0:
+            print('CRITERIA: CER' if criteria == 'cer' else 'CRITERIA: LOSS')
+        if best > cur:
+            count_stop, best = 0, cur
+            if rank == 0:
+                save_meta_model(model, vocab, (it + 1), inner_opt, outer_opt, metrics, args, best_model=True)
+        else:
+            count_stop += 1
+            if rank == 0:
+                print('count_stop:', count_stop)
+        if count_stop >= stop_val:
+            logging.info('EARLY STOP')
+            if rank == 0:
+                print('EARLY STOP\n')
+            return True, best, count_stop
+        return False, best, count_stop

@@ -1,0 +1,114 @@
+"""CPU: host-side logic of the drop-in layer (parameter tree / init order, vocabulary and loaders, decoder I/O prep,
+checkpoint format, loud failure without a GPU)."""
+import argparse
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests import golden_util as gu
+
+
+def make_args(cfg, **kw):
+    base = dict(feat_extractor='vgg_cnn', sample_rate=16000, window_size=.02, feat='spectrogram', dim_input=161, dropout=0.0,
+                emb_trg_sharing=False, label_smoothing=0.0, name='t', lr=1e-2, meta_lr=1e-3, k_train=2, k_valid=2, clip=False,
+                max_norm=400, save_every=1, save_folder='/tmp/mtl_ckpt_test', cuda=False, is_factorized=False, r=cfg.get('r', 100))
+    base.update({k: v for k, v in cfg.items() if k not in ('vocab_size', 'r')})
+    base.update(kw)
+    return argparse.Namespace(**base)
+
+
+@pytest.mark.parametrize('name', ['F0', 'F1'])
+def test_product_init_matches_reference_bit_for_bit(name):
+    import mtl_amd
+    z, cfg, spec = gu.load(name)
+    torch.manual_seed(123456)
+    m = mtl_amd.init_transformer_model(make_args(cfg), mtl_amd.synthetic_vocab(cfg['vocab_size']), r=cfg['r'])
+    assert [n for n, _ in m.named_parameters()] == [str(s) for s in z['param_names']]
+    h = hashlib.sha256()
+    for _, p in m.named_parameters():
+        h.update(p.detach().numpy().tobytes())
+    assert h.hexdigest() == bytes(z['theta0_sha256']).decode()
+    sd = m.state_dict()
+    assert 'encoder.positional_encoding.pe' in sd and 'decoder.positional_encoding.pe' in sd and 'conv.7.bias' in sd
+    # parameters are views into ONE flat buffer, gradients likewise
+    p0 = next(m.parameters())
+    assert p0.data_ptr() == m.flat_parameters.data_ptr() and p0.grad.data_ptr() == m.flat_grad.data_ptr()
+    assert m.flat_parameters.numel() == sum(p.numel() for p in m.parameters())
+
+
+def test_no_cpu_fallback():
+    import mtl_amd
+    z, cfg, spec = gu.load('F0')
+    m = mtl_amd.init_transformer_model(make_args(cfg), mtl_amd.synthetic_vocab(64))
+    x, lens, y = mtl_amd.synth_batch(0, 2, 64, 8, 64)
+    with pytest.raises(RuntimeError, match='no CPU'):
+        m(x, lens, y)
+
+
+def test_decoder_io_matches_oracle():
+    from oracle import refimpl as R
+    import importlib
+    eng = importlib.import_module('mtl_amd.engine')
+    y = torch.tensor([[5, 6, 7, 0, 0], [9, 8, 7, 6, 5], [4, 0, 0, 0, 0]])
+    a, b = eng.decoder_io(y)
+    ra, rb = R.decoder_io(y)
+    assert torch.equal(a, ra) and torch.equal(b, rb)
+    assert a.tolist()[0] == [1, 5, 6, 7, 2, 2] and b.tolist()[0] == [5, 6, 7, 2, 0, 0]
+
+
+def test_vocab_manifest_and_sampling(tmp_path):
+    import mtl_amd
+    labels = ['_', "'", 'a', 'b', 'c', ' ', '你']
+    lp = tmp_path / 'labels.json'
+    lp.write_text(json.dumps(labels), encoding='utf-8')
+    vocab = mtl_amd.load_vocab(str(lp))
+    assert vocab.label2id['<PAD>'] == 0 and vocab.label2id['<SOS>'] == 1 and vocab.label2id['<EOS>'] == 2 and vocab.label2id['<OOV>'] == 3
+    assert vocab.label2id['_'] == 4 and vocab.id2label[10] == '你' and len(vocab.label2id) == 11
+    rows = []
+    for i in range(5):
+        t = tmp_path / ('u%d.txt' % i)
+        t.write_text('ab c你\n' if i % 2 else 'CAB', encoding='utf8')
+        rows.append('%s,%s' % (tmp_path / ('u%d.wav' % i), t))
+    mp = tmp_path / 'm.csv'
+    mp.write_text('\n'.join(rows) + '\n')
+    args = argparse.Namespace(src_max_len=50)
+    feats = lambda wav: torch.randn(161, 30 + 7 * int(os.path.basename(wav)[1]))
+    ds = mtl_amd.ManifestTaskDataset(vocab, args, [str(mp)], feats, partitions=None)
+    np.random.seed(0)
+    tr, va = ds.sample(3, 2, 0)
+    x, sizes, pct, tgt, tsz = tr
+    assert x.shape[0] == 3 and x.shape[1] == 1 and x.shape[2] == 161 and x.shape[3] == int(sizes.max()) <= 50
+    assert tgt.dtype == torch.int64 and sizes.dtype == torch.int32 and abs(float(pct.max()) - 1.0) < 1e-6
+    assert va[0].shape[0] == 2
+    # leading ' ' + lower-casing as the reference's parse_transcript
+    assert mtl_amd.data.parse_transcript(vocab, 'AB') == [vocab.label2id['a'], vocab.label2id['b']]
+    assert (x[0, 0, :, int(sizes[0]):] == 0).all()
+
+
+def test_checkpoint_roundtrip_reference_format(tmp_path):
+    import mtl_amd
+    z, cfg, spec = gu.load('F0')
+    args = make_args(cfg, save_folder=str(tmp_path), name='ck')
+    vocab = mtl_amd.synthetic_vocab(64)
+    m = mtl_amd.init_transformer_model(args, vocab)
+    inner = torch.optim.SGD(m.parameters(), lr=args.lr)
+    outer = torch.optim.Adam(m.parameters(), lr=args.meta_lr)
+    path = mtl_amd.save_meta_model(m, vocab, 7, inner, outer, {'avg_valid_cer': 1.0}, args, best_model=False)
+    ck = torch.load(path, weights_only=False)
+    assert sorted(ck.keys()) == ['args', 'epoch', 'inner_opt', 'metrics', 'model_state_dict', 'outer_opt', 'vocab']
+    m2, v2, i2, o2, ep, met, a2 = mtl_amd.load_meta_model(path)
+    assert ep == 7 and met['avg_valid_cer'] == 1.0 and len(v2.label2id) == 64
+    for (n1, p1), (n2, p2) in zip(m.named_parameters(), m2.named_parameters()):
+        assert n1 == n2 and torch.equal(p1, p2)
+    assert o2.param_groups[0]['lr'] == args.meta_lr
+
+
+def test_task_sharding():
+    import mtl_amd
+    assert mtl_amd.dist.shard_tasks(8, 3, 8) == [3]
+    assert mtl_amd.dist.shard_tasks(8, 1, 2) == [1, 3, 5, 7]
+    assert sorted(sum((mtl_amd.dist.shard_tasks(3, r, 2) for r in range(2)), [])) == [0, 1, 2]

@@ -1,0 +1,301 @@
+"""Per-kernel parity: every C-ABI entry point of libmtl_hip.so against the same op in plain PyTorch fp32 on the CPU.
+Floating-point kernels -> tolerance stated per test (relative L2); integer outputs (arg-max, pool indices) bit-exact."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def L():
+    import mtl_amd
+    assert torch.cuda.is_available()
+    return mtl_amd._lib.lib()
+
+
+def st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def dev(t):
+    return t.cuda().contiguous()
+
+
+@pytest.mark.parametrize('ta,tb', [(0, 1), (0, 0), (1, 0), (1, 1)])
+@pytest.mark.parametrize('M,N,K', [(101, 250, 64), (808, 3765, 512), (2000, 100, 512), (512, 5120, 300), (64, 64, 32)])
+def test_gemm_transposes(L, ta, tb, M, N, K):
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K + ta * 2 + tb)
+    A = torch.randn((K, M) if ta else (M, K), generator=g)
+    B = torch.randn((N, K) if tb else (K, N), generator=g)
+    bias = torch.randn(N, generator=g)
+    C0 = torch.randn(M, N, generator=g)
+    ref = (A.t() if ta else A) @ (B.t() if tb else B)
+    dA, dB, dbias = dev(A), dev(B), dev(bias)
+    C = dev(C0.clone())
+    assert L.mtl_gemm_f32(st(), ta, tb, M, N, K, 1.0, dA.data_ptr(), A.shape[1], dB.data_ptr(), B.shape[1], C.data_ptr(), N,
+                          None, None, 0, 0, 1, 1, 0, 0, 0, 0, 0, 0) == 0
+    assert rel(C, ref) < 2e-6
+    C = dev(C0.clone())           # bias + relu + accumulate
+    assert L.mtl_gemm_f32(st(), ta, tb, M, N, K, 0.5, dA.data_ptr(), A.shape[1], dB.data_ptr(), B.shape[1], C.data_ptr(), N,
+                          dbias.data_ptr(), None, 0, 3, 1, 1, 0, 0, 0, 0, 0, 0) == 0
+    assert rel(C, torch.relu(0.5 * ref + bias) + C0) < 2e-6
+
+
+def test_gemm_gate_and_batched_heads(L):
+    g = torch.Generator().manual_seed(5)
+    Bn, H, Tq, Tk, dk = 3, 8, 101, 250, 16
+    q = torch.randn(Bn, Tq, H * dk, generator=g)
+    k = torch.randn(Bn, Tk, H * dk, generator=g)
+    ld = (Tk + 3) // 4 * 4
+    S = torch.full((Bn, H, Tq, ld), float('nan')).cuda()
+    dq, dk_ = dev(q), dev(k)
+    assert L.mtl_gemm_f32(st(), 0, 1, Tq, Tk, dk, 1.0, dq.data_ptr(), H * dk, dk_.data_ptr(), H * dk, S.data_ptr(), ld, None, None,
+                          0, 0, Bn * H, H, Tq * H * dk, dk, Tk * H * dk, dk, H * Tq * ld, Tq * ld) == 0
+    ref = torch.einsum('bqhd,bkhd->bhqk', q.view(Bn, Tq, H, dk), k.view(Bn, Tk, H, dk))
+    assert rel(S[..., :Tk], ref) < 2e-6
+    M, N, K = 300, 200, 96
+    A, Bm, gate = torch.randn(M, K, generator=g), torch.randn(K, N, generator=g), torch.randn(M, N, generator=g)
+    C = torch.empty(M, N).cuda()
+    dA, dB, dg = dev(A), dev(Bm), dev(gate)
+    assert L.mtl_gemm_f32(st(), 0, 0, M, N, K, 1.0, dA.data_ptr(), K, dB.data_ptr(), N, C.data_ptr(), N, None, dg.data_ptr(), N, 0,
+                          1, 1, 0, 0, 0, 0, 0, 0) == 0
+    assert rel(C, (A @ Bm) * (gate > 0)) < 2e-6
+
+
+def nhwc(t):   # reference (B,C,F,T) -> ours (B,T,F,C)
+    return t.permute(0, 3, 2, 1).contiguous()
+
+
+def from_nhwc(t):
+    return t.permute(0, 3, 2, 1).contiguous()
+
+
+@pytest.mark.parametrize('B,T,Fq', [(2, 37, 161), (1, 16, 21)])
+def test_conv0(L, B, T, Fq):
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B, 1, Fq, T, generator=g)
+    w, b = torch.randn(64, 1, 3, 3, generator=g) * 0.3, torch.randn(64, generator=g)
+    ref = torch.relu(F.conv2d(x, w, b, padding=1))
+    dx, dw, db = dev(x), dev(w), dev(b)
+    y = torch.empty(B, T, Fq, 64).cuda()
+    assert L.mtl_conv0_relu_fwd(st(), dx.data_ptr(), dw.data_ptr(), db.data_ptr(), y.data_ptr(), B, T, Fq) == 0
+    assert rel(from_nhwc(y), ref) < 2e-6
+    dy = torch.randn(B, 64, Fq, T, generator=g)
+    wg = torch.zeros(64, 1, 3, 3).cuda()
+    bg = torch.zeros(64).cuda()
+    ws = torch.empty(L.mtl_conv0_wgrad_workspace() // 4).cuda()
+    d_dy = dev(nhwc(dy))
+    assert L.mtl_conv0_wgrad(st(), dx.data_ptr(), d_dy.data_ptr(), wg.data_ptr(), bg.data_ptr(), ws.data_ptr(), B, T, Fq) == 0
+    wref = torch.nn.grad.conv2d_weight(x, w.shape, dy, padding=1)
+    assert rel(wg, wref) < 1e-5 and rel(bg, dy.sum((0, 2, 3))) < 1e-5
+
+
+@pytest.mark.parametrize('Cin,Cout,B,T,Fq', [(64, 64, 2, 21, 161), (64, 128, 2, 18, 80), (128, 128, 1, 9, 19)])
+def test_conv3x3_all(L, Cin, Cout, B, T, Fq):
+    g = torch.Generator().manual_seed(Cin + Cout + T)
+    x = torch.relu(torch.randn(B, Cin, Fq, T, generator=g))
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * (1.0 / np.sqrt(9 * Cin))
+    b = torch.randn(Cout, generator=g) * 0.1
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    yr = torch.relu(F.conv2d(xr, wr, b, padding=1))
+    pr, idx = F.max_pool2d(yr, 2, stride=2, return_indices=True)
+    dxn, dw, db = dev(nhwc(x)), dev(w), dev(b)
+    wf, wd = torch.empty(9, Cin, Cout).cuda(), torch.empty(9, Cout, Cin).cuda()
+    assert L.mtl_conv3x3_wprep(st(), dw.data_ptr(), wf.data_ptr(), wd.data_ptr(), Cout, Cin) == 0
+    # plain conv + relu
+    y = torch.empty(B, T, Fq, Cout).cuda()
+    assert L.mtl_conv3x3_relu_fwd(st(), dxn.data_ptr(), wf.data_ptr(), db.data_ptr(), y.data_ptr(), B, T, Fq, Cin, Cout) == 0
+    assert rel(from_nhwc(y), yr) < 3e-6
+    # fused pool
+    Tp, Fp = T // 2, Fq // 2
+    p = torch.empty(B, Tp, Fp, Cout).cuda()
+    am = torch.empty(B, Tp, Fp, Cout, dtype=torch.uint8).cuda()
+    assert L.mtl_conv3x3_relu_pool_fwd(st(), dxn.data_ptr(), wf.data_ptr(), db.data_ptr(), p.data_ptr(), am.data_ptr(), B, T, Fq,
+                                       Cin, Cout) == 0
+    assert rel(from_nhwc(p), pr) < 3e-6
+    # arg-max: torch index = f*T + t inside the (F,T) plane
+    amc = from_nhwc(am).long()
+    fgrid = torch.arange(Fp).view(1, 1, Fp, 1) * 2 + (amc >> 1)
+    tgrid = torch.arange(Tp).view(1, 1, 1, Tp) * 2 + (amc & 1)
+    mism = (fgrid * T + tgrid) != idx
+    # ties (e.g. all-zero windows after ReLU) must pick torch's first element; values must agree wherever indices differ
+    assert int(mism.sum()) == 0
+    # backward of the pooled layer: dgrad (fused un-pool + ReLU gate of the INPUT activation) and wgrad
+    dp = torch.randn(pr.shape, generator=g)
+    pr.backward(dp)
+    dpn = dev(nhwc(dp * (pr.detach() > 0)))           # the engine hands over ReLU-gated pooled grads
+    dx = torch.empty(B, T, Fq, Cin).cuda()
+    assert L.mtl_conv3x3_dgrad(st(), dpn.data_ptr(), am.data_ptr(), wd.data_ptr(), dxn.data_ptr(), dx.data_ptr(), B, T, Fq, Cin,
+                               Cout) == 0
+    assert rel(from_nhwc(dx), xr.grad * (x > 0)) < 1e-5
+    need = L.mtl_conv3x3_wgrad_workspace(B, T, Fq, Cin, Cout, 1)
+    ws = torch.empty(need // 4 + 16).cuda()
+    wg = torch.zeros(Cout, Cin, 3, 3).cuda()
+    assert L.mtl_conv3x3_wgrad(st(), dxn.data_ptr(), dpn.data_ptr(), am.data_ptr(), wg.data_ptr(), ws.data_ptr(), need, B, T, Fq,
+                               Cin, Cout) == 0
+    assert rel(wg, wr.grad) < 1e-5
+    # dense (un-pooled) backward
+    xr2 = x.clone().requires_grad_(True)
+    wr2 = w.clone().requires_grad_(True)
+    y2 = torch.relu(F.conv2d(xr2, wr2, b, padding=1))
+    dy = torch.randn(y2.shape, generator=g)
+    y2.backward(dy)
+    dyn = dev(nhwc(dy * (y2.detach() > 0)))
+    assert L.mtl_conv3x3_dgrad(st(), dyn.data_ptr(), None, wd.data_ptr(), dxn.data_ptr(), dx.data_ptr(), B, T, Fq, Cin, Cout) == 0
+    assert rel(from_nhwc(dx), xr2.grad * (x > 0)) < 1e-5
+    need = L.mtl_conv3x3_wgrad_workspace(B, T, Fq, Cin, Cout, 0)
+    ws = torch.empty(need // 4 + 16).cuda()
+    wg.zero_()
+    assert L.mtl_conv3x3_wgrad(st(), dxn.data_ptr(), dyn.data_ptr(), None, wg.data_ptr(), ws.data_ptr(), need, B, T, Fq, Cin,
+                               Cout) == 0
+    assert rel(wg, wr2.grad) < 1e-5
+
+
+@pytest.mark.parametrize('d', [128, 512])
+def test_layernorm(L, d):
+    g = torch.Generator().manual_seed(d)
+    rows, T = 77, 11
+    x, res = torch.randn(rows, d, generator=g), torch.randn(rows, d, generator=g)
+    gam, bet, pe = torch.randn(d, generator=g), torch.randn(d, generator=g), torch.randn(T, d, generator=g)
+    keep = (torch.rand(rows, generator=g) > 0.3).int()
+    xr, rr, gr, br = [t.clone().requires_grad_(True) for t in (x, res, gam, bet)]
+    yr = (F.layer_norm(xr + rr, (d,), gr, br, 1e-5) + pe[torch.arange(rows) % T]) * keep.unsqueeze(1)
+    dy = torch.randn(rows, d, generator=g)
+    yr.backward(dy)
+    y, xhat, rstd = torch.empty(rows, d).cuda(), torch.empty(rows, d).cuda(), torch.empty(rows).cuda()
+    a = [dev(t) for t in (x, res, gam, bet, pe)]
+    kd = keep.cuda()
+    assert L.mtl_layernorm_fwd(st(), a[0].data_ptr(), a[1].data_ptr(), a[2].data_ptr(), a[3].data_ptr(), a[4].data_ptr(),
+                               kd.data_ptr(), y.data_ptr(), xhat.data_ptr(), rstd.data_ptr(), rows, d, T, 1e-5) == 0
+    assert rel(y, yr) < 2e-6
+    dz, dg, db = torch.empty(rows, d).cuda(), torch.zeros(d).cuda(), torch.zeros(d).cuda()
+    ws = torch.empty(L.mtl_layernorm_bwd_workspace(rows, d) // 4).cuda()
+    ddy = dev(dy)
+    assert L.mtl_layernorm_bwd(st(), ddy.data_ptr(), xhat.data_ptr(), rstd.data_ptr(), a[2].data_ptr(), kd.data_ptr(),
+                               dz.data_ptr(), dg.data_ptr(), db.data_ptr(), ws.data_ptr(), rows, d) == 0
+    assert rel(dz, xr.grad) < 1e-5 and rel(dg, gr.grad) < 1e-5 and rel(db, br.grad) < 1e-5
+
+
+@pytest.mark.parametrize('causal', [0, 1])
+def test_softmax(L, causal):
+    g = torch.Generator().manual_seed(causal)
+    Bn, H, Tq, Tk = 3, 4, 9, 13 if not causal else 9
+    ld = (Tk + 3) // 4 * 4
+    s = torch.randn(Bn, H, Tq, Tk, generator=g) * 3
+    klen = torch.tensor([Tk, 5, 1], dtype=torch.int32)
+    blocked = torch.arange(Tk).view(1, 1, 1, Tk) >= klen.view(Bn, 1, 1, 1)
+    if causal:
+        blocked = blocked | torch.triu(torch.ones(Tq, Tk, dtype=torch.bool), 1)
+    sr = s.clone().requires_grad_(True)
+    pr = torch.softmax((sr / 4.0).masked_fill(blocked, -np.inf), -1)
+    dp = torch.randn(pr.shape, generator=g)
+    pr.backward(dp)
+    S = torch.zeros(Bn, H, Tq, ld)
+    S[..., :Tk] = s
+    S = S.cuda()
+    kd = klen.cuda()
+    assert L.mtl_softmax_mask_fwd(st(), S.data_ptr(), kd.data_ptr(), causal, 0.25, Bn, H, Tq, Tk, ld) == 0
+    assert rel(S[..., :Tk], pr) < 2e-6
+    D = torch.zeros(Bn, H, Tq, ld)
+    D[..., :Tk] = dp
+    D = D.cuda()
+    assert L.mtl_softmax_bwd(st(), S.data_ptr(), D.data_ptr(), 0.25, Bn * H * Tq, Tk, ld) == 0
+    assert rel(D[..., :Tk], sr.grad) < 1e-5
+
+
+def test_embed_and_ce(L):
+    g = torch.Generator().manual_seed(3)
+    V, d, B, T = 3765, 128, 3, 7
+    table, pe = torch.randn(V, d, generator=g), torch.randn(T, d, generator=g)
+    ids = torch.randint(1, V, (B, T), generator=g)
+    ids[0, 1] = ids[0, 0]
+    out = torch.empty(B * T, d).cuda()
+    dt, dpe, dids = dev(table), dev(pe), ids.cuda()
+    assert L.mtl_embed_pe_fwd(st(), dids.data_ptr(), dt.data_ptr(), dpe.data_ptr(), out.data_ptr(), B * T, T, d) == 0
+    assert rel(out, (table[ids] + pe.unsqueeze(0)).view(B * T, d)) == 0
+    dout = torch.randn(B * T, d, generator=g)
+    tg = torch.zeros(V, d).cuda()
+    ddo = dev(dout)
+    assert L.mtl_embed_bwd(st(), dids.data_ptr(), ddo.data_ptr(), tg.data_ptr(), B * T, d, 0) == 0
+    ref = torch.zeros(V, d).index_add_(0, ids.view(-1), dout)
+    assert rel(tg, ref) < 1e-6
+    # cross entropy + arg-max (ties -> lowest index; padded rows are all-zero logits)
+    rows = 40
+    logits = torch.randn(rows, V, generator=g)
+    logits[5] = 0
+    logits[6, 50] = logits[6, 100] = logits[6, 3000] = 9.0
+    gold = torch.randint(4, V, (rows,), generator=g)
+    gold[5] = 0
+    gold[9] = 0
+    lr_ = logits.clone().requires_grad_(True)
+    loss_ref = F.cross_entropy(lr_, gold, ignore_index=0, reduction='mean')
+    (loss_ref / 3).backward()
+    dl, dgold = dev(logits), gold.cuda()
+    lse, hyp = torch.empty(rows).cuda(), torch.empty(rows, dtype=torch.int64).cuda()
+    rowloss, loss = torch.empty(rows).cuda(), torch.empty(1).cuda()
+    nn_ = int((gold != 0).sum())
+    assert L.mtl_ce_argmax_fwd(st(), dl.data_ptr(), dgold.data_ptr(), rows, V, V, 0, 0.0, nn_, lse.data_ptr(), hyp.data_ptr(),
+                               rowloss.data_ptr(), loss.data_ptr()) == 0
+    assert abs(float(loss) - float(loss_ref)) < 2e-6 * float(loss_ref)
+    assert torch.equal(hyp.cpu(), torch.topk(logits, 1, dim=1)[1].squeeze(1))
+    assert int(hyp[5]) == 0 and int(hyp[6]) == 50
+    ldd = (V + 3) // 4 * 4
+    dlog = torch.empty(rows, ldd).cuda()
+    assert L.mtl_ce_bwd(st(), dl.data_ptr(), lse.data_ptr(), dgold.data_ptr(), rows, V, V, 0, 0.0, (1.0 / 3) / nn_, None,
+                        dlog.data_ptr(), ldd) == 0
+    assert rel(dlog[:, :V], lr_.grad) < 1e-5
+
+
+def test_flat_updates_colsum_permute(L):
+    g = torch.Generator().manual_seed(9)
+    n = 100003
+    n4 = n // 4 * 4
+    th, gr = torch.randn(n4, generator=g), torch.randn(n4, generator=g)
+    dth, dgr, t1 = dev(th), dev(gr), torch.empty(n4).cuda()
+    assert L.mtl_sgd_theta_prime(st(), dth.data_ptr(), dgr.data_ptr(), 0.01, t1.data_ptr(), n4) == 0
+    assert torch.equal(t1.cpu(), th - 0.01 * gr) or rel(t1, th - 0.01 * gr) < 1e-7
+    y = dev(th.clone())
+    assert L.mtl_axpy(st(), y.data_ptr(), dgr.data_ptr(), 1.0, n4) == 0
+    assert torch.equal(y.cpu(), th + gr)
+    # Adam, 3 steps, against torch.optim.Adam
+    p = th.clone().requires_grad_(True)
+    opt = torch.optim.Adam([p], lr=1e-3)
+    m, v, w = torch.zeros(n4).cuda(), torch.zeros(n4).cuda(), dev(th.clone())
+    for step in range(1, 4):
+        gg = torch.randn(n4, generator=g)
+        p.grad = gg.clone()
+        opt.step()
+        dg = dev(gg)
+        assert L.mtl_adam_step(st(), w.data_ptr(), dg.data_ptr(), m.data_ptr(), v.data_ptr(), step, 1e-3, 0.9, 0.999, 1e-8, n4) == 0
+    assert rel(w, p.detach()) < 1e-6
+    # clip coefficient
+    ws, coef = torch.empty(2048).cuda(), torch.empty(1).cuda()
+    assert L.mtl_sumsq(st(), dgr.data_ptr(), n4, coef.data_ptr(), ws.data_ptr(), 2, 5.0) == 0
+    assert abs(float(coef) - min(1.0, 5.0 / (float(gr.norm()) + 1e-6))) < 1e-6
+    # column sums
+    X = torch.randn(5000, 100, generator=g)
+    out = torch.ones(100).cuda()
+    ws = torch.empty(L.mtl_colsum_workspace(5000, 100) // 4).cuda()
+    dX = dev(X)
+    assert L.mtl_colsum_accum(st(), dX.data_ptr(), 5000, 100, 100, out.data_ptr(), ws.data_ptr()) == 0
+    assert rel(out, X.sum(0) + 1) < 1e-5
+    # (c,h) <-> (h,c) permutation of input_linear columns
+    rows, C, H = 7, 128, 5
+    wt = torch.randn(rows, C * H, generator=g)
+    wp = torch.empty(rows, C * H).cuda()
+    dwt = dev(wt)
+    assert L.mtl_permute_hc(st(), dwt.data_ptr(), wp.data_ptr(), rows, C, H, 0) == 0
+    assert torch.equal(wp.cpu(), wt.view(rows, C, H).transpose(1, 2).reshape(rows, -1))
+    back = torch.zeros(rows, C * H).cuda()
+    assert L.mtl_permute_hc(st(), wp.data_ptr(), back.data_ptr(), rows, C, H, 1) == 0
+    assert torch.equal(back.cpu(), wt)

@@ -1,0 +1,157 @@
+"""Whole-path parity on the MI355X, through the drop-in Python API over the C ABI:
+  * against the committed goldens produced by the real reference (tests/golden/F0,F1,NS.npz);
+  * against the CPU oracle run live on the same seeded inputs (full tensors, small sizes).
+Bars (BASELINE.json north_star): label indices bit-exact; fp32 loss and meta-gradients within 1e-4 relative."""
+import argparse
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+from tests import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+
+
+def make(cfg, spec, name='parity'):
+    import mtl_amd
+    args = argparse.Namespace(feat_extractor='vgg_cnn', sample_rate=16000, window_size=.02, feat='spectrogram', dim_input=161,
+                              dropout=0.0, emb_trg_sharing=False, label_smoothing=0.0, name=name, lr=spec['lr'],
+                              meta_lr=spec['meta_lr'], k_train=spec['k'], k_valid=spec['k'], clip=False, max_norm=400,
+                              save_every=10 ** 9, save_folder='/tmp/mtl_ckpt', cuda=True,
+                              **{k: v for k, v in cfg.items() if k not in ('vocab_size', 'r')})
+    vocab = mtl_amd.synthetic_vocab(cfg['vocab_size'])
+    torch.manual_seed(123456)
+    model = mtl_amd.init_transformer_model(args, vocab, r=cfg['r'])
+    return mtl_amd, args, vocab, model
+
+
+@pytest.mark.parametrize('name', ['F0', 'F1', 'NS'])
+def test_meta_iterations_match_reference_goldens(name):
+    z, cfg, spec = gu.load(name)
+    mtl_amd, args, vocab, model = make(cfg, spec)
+    names = [str(s) for s in z['param_names']]
+    assert [n for n, _ in model.named_parameters()] == names
+    h = hashlib.sha256()
+    for _, p in model.named_parameters():
+        h.update(p.detach().numpy().tobytes())
+    assert h.hexdigest() == bytes(z['theta0_sha256']).decode()          # init draw order (Q4), bit-exact
+    model = model.cuda()
+    n = spec['n_tasks']
+    tasks = [mtl_amd.SyntheticTask(m, spec['k'], spec['T'], spec['L'], cfg['vocab_size'], variable=spec['variable'])
+             for m in range(n)]
+    trainer = mtl_amd.TransientTrainer()
+    worst = 0.0
+    for it in range(spec['iters']):
+        captured = {}
+        orig = trainer.meta_iteration
+
+        def spy(*a, **kw):
+            reads = orig(*a, **kw)
+            captured['reads'] = reads
+            return reads
+        trainer.meta_iteration = spy
+        trainer.train(model, vocab, tasks, [], 'ce', it, it + 1, args, inner_opt=getattr(trainer, 'inner_opt', None),
+                      outer_opt=getattr(trainer, 'outer_opt', None), evaluate_every=10 ** 9, early_stop='cer,200',
+                      is_copy_grad=True)
+        trainer.meta_iteration = orig
+        for m, (tr, va) in enumerate(captured['reads']):
+            for j, rd in ((2 * m, tr), (2 * m + 1, va)):
+                key = 'fwd/%d/%d' % (it, j)
+                assert np.array_equal(rd.gold_host.numpy(), z[key + '/gold']), key
+                assert np.array_equal(rd.hyp.numpy(), z[key + '/hyp']), key + ' hyp'        # label indices: bit-exact
+                ref = float(z[key + '/loss'])
+                assert abs(float(rd.loss[0]) - ref) <= RTOL * abs(ref), key
+        floor = 1e-4 * gu.global_l2(z, 'G/%d' % it, names)
+        for nm in names:
+            worst = max(worst, gu.check_digest(z, 'G/%d' % it, nm, model._layout.view(model._G, nm), rtol=RTOL, what=name,
+                                               floor=floor))
+        for nm, p in model.named_parameters():
+            if float(z['G/%d/%s/l2' % (it, nm)]) < floor * 1e-2:
+                continue        # Adam on an exactly-zero gradient: sign of rounding noise (see tests/test_oracle_golden.py)
+            gu.check_digest(z, 'theta/%d' % (it + 1), nm, p, rtol=RTOL, what=name)
+    print('%s worst per-tensor meta-gradient rel err: %.3e' % (name, worst))
+
+
+def test_full_tensors_against_live_oracle():
+    from oracle import refimpl as R
+    z, cfg, spec = gu.load('F0')
+    mtl_amd, args, vocab, model = make(cfg, spec)
+    model = model.cuda()
+    oracle = R.build_model(cfg)
+    tr, val = gu.batches_for(cfg, spec, 0, z['data_call_index'])
+    # forward: pred / hyp / loss
+    x, lens, y = tr[0]
+    out = model.pass_forward(x.cuda(), lens, y)
+    pred_r, gold_r, hyp_r = oracle(x, lens, y)
+    assert torch.equal(out['hyp'].cpu(), hyp_r) and torch.equal(out['gold'].cpu(), gold_r)
+    assert float((out['pred'].cpu() - pred_r).norm() / pred_r.norm()) < RTOL
+    assert abs(float(out['loss']) - float(R.ce_loss(pred_r, gold_r))) < RTOL * float(R.ce_loss(pred_r, gold_r))
+    # one whole meta-gradient
+    G_r, _, _, _ = R.meta_gradient(oracle, tr, val, spec['lr'])
+    trainer = mtl_amd.TransientTrainer()
+    inner = mtl_amd.FlatSGD(model, spec['lr'])
+    model.zero_copy_grad()
+    as5 = lambda b: (b[0], b[1], None, b[2], None)
+    trainer.meta_iteration(model, vocab, [as5(b) for b in tr], as5(val), len(tr), inner, None, args)
+    gn = float(torch.sqrt(sum((g.double() ** 2).sum() for g in G_r)))
+    for (nm, _), g_r in zip(oracle.named_parameters(), G_r):
+        g_h = model._layout.view(model._G, nm).cpu()
+        err = float((g_h - g_r).norm() / max(float(g_r.norm()), 1e-4 * gn))
+        assert err < RTOL, (nm, err)
+
+
+def test_dropin_autograd_api_matches_oracle():
+    """pred,gold,hyp = model(...); loss,_ = calculate_metrics(...); loss.backward() -- the reference's own call pattern."""
+    from oracle import refimpl as R
+    z, cfg, spec = gu.load('F0')
+    mtl_amd, args, vocab, model = make(cfg, spec)
+    model = model.cuda()
+    oracle = R.build_model(cfg)
+    (x, lens, y), _ = gu.batches_for(cfg, spec, 0, z['data_call_index'])[0][0], None
+    opt = torch.optim.SGD(model.parameters(), lr=0.0)
+    opt.zero_grad()
+    pred, gold, hyp = model(x.cuda(), lens, y)
+    loss, ncorrect = mtl_amd.calculate_metrics(pred, gold, 0, smoothing=0.0, loss_type='ce')
+    (loss / 3).backward()
+    pr, gr, hr = oracle(x, lens, y)
+    lref = R.ce_loss(pr, gr)
+    (lref / 3).backward()
+    assert abs(float(loss) - float(lref)) < RTOL * float(lref)
+    assert ncorrect == int(((hr == gr) & (gr != 0)).sum())
+    gn = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in oracle.parameters())))
+    for (nm, p), (_, q) in zip(model.named_parameters(), oracle.named_parameters()):
+        err = float((p.grad.cpu() - q.grad).norm() / max(float(q.grad.norm()), 1e-4 * gn))
+        assert err < RTOL, (nm, err)
+    # a second backward accumulates (torch .grad semantics, which SURVEY Q1 depends on)
+    pred, gold, hyp = model(x.cuda(), lens, y)
+    loss, _ = mtl_amd.calculate_metrics(pred, gold, 0)
+    loss.backward()
+    for (nm, p), (_, q) in zip(model.named_parameters(), oracle.named_parameters()):
+        err = float((p.grad.cpu() - q.grad * 4).norm() / max(float(q.grad.norm() * 4), 4e-4 * gn))
+        assert err < RTOL, (nm, err)
+
+
+def test_round_trip_properties_full_size():
+    """Size-independent properties at the north-star shapes: linearity of the backward in the loss scale and
+    accumulate semantics, determinism (bitwise) of two identical passes."""
+    z, cfg, spec = gu.load('NS')
+    mtl_amd, args, vocab, model = make(cfg, spec)
+    model = model.cuda()
+    x, lens, y = mtl_amd.synth_batch(7, spec['k'], spec['T'], spec['L'], cfg['vocab_size'])
+    g1, g2 = torch.zeros_like(model.flat_grad), torch.zeros_like(model.flat_grad)
+    out = model.pass_forward(x.cuda(), lens, y)
+    l1 = float(out['loss'])
+    model.pass_backward(g1, 1.0)
+    out = model.pass_forward(x.cuda(), lens, y)
+    model.pass_backward(g2, 0.5)
+    model.pass_backward(g2, 0.5)
+    assert float(out['loss']) == l1                                   # deterministic forward
+    assert float((g1 - g2).norm() / g1.norm()) < 1e-6                 # linear + accumulating backward
+    g3 = torch.zeros_like(g1)
+    model.pass_forward(x.cuda(), lens, y)
+    model.pass_backward(g3, 1.0)
+    assert torch.equal(g1, g3)                                        # fixed-order reductions: bitwise reproducible
+    assert abs(l1 - np.log(cfg['vocab_size'])) < 0.5                  # CE at init ~ ln V
