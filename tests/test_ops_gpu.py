@@ -124,7 +124,7 @@ def test_conv3x3_all(L, Cin, Cout, B, T, Fq):
                                        Cin, Cout) == 0
     assert rel(from_nhwc(p), pr) < 3e-6
     # arg-max: torch index = f*T + t inside the (F,T) plane
-    amc = from_nhwc(am).long()
+    amc = from_nhwc(am).long().cpu()
     fgrid = torch.arange(Fp).view(1, 1, Fp, 1) * 2 + (amc >> 1)
     tgrid = torch.arange(Tp).view(1, 1, 1, Tp) * 2 + (amc & 1)
     mism = (fgrid * T + tgrid) != idx
