@@ -33,6 +33,8 @@ int mtl_abi_version(void);
  *   transB = 0: B is K x N (ldb)   | 1: B is stored N x K (ldb)
  *   epilogue: + bias[n] (nullable) ; ReLU if flags&MTL_GEMM_RELU ; zero where gate[m*ldg+n] <= 0 (nullable,
  *             same batch offsets as C) ; += C if flags&MTL_GEMM_ACCUM.
+ *   workspace (nullable): when batch == 1 and the output has too few tiles to fill the 256 CUs, K is split over the grid
+ *             into workspace slabs that a second kernel sums in fixed order (deterministic split-K).
  * Replaces nn.Linear forward/backward (modules/encoder.py:72; modules/common_layers.py:130,287-289,303;
  * modules/decoder.py:108-110) and torch.bmm (modules/common_layers.py:321,329) incl. the permute/contiguous
  * copies at common_layers.py:291-293,301 (heads are addressed by stride instead). */
@@ -40,7 +42,8 @@ int mtl_abi_version(void);
 #define MTL_GEMM_ACCUM 2
 int mtl_gemm_f32(void* stream, int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
                  const float* B, int ldb, float* C, int ldc, const float* bias, const float* gate, int ldg, int flags,
-                 int batch, int H, long sAb, long sAh, long sBb, long sBh, long sCb, long sCh);
+                 int batch, int H, long sAb, long sAh, long sBb, long sBh, long sCb, long sCh, float* workspace,
+                 long workspace_bytes);
 
 /* ---- VGG front-end: models/asr/transformer.py:48-59 (Conv2d 3x3 s1 p1 + ReLU [+ MaxPool2d(2,2)]) ------
  * x_ref is the reference's (B,1,F,T) input; everything downstream is (B,T,F,C). */
@@ -79,8 +82,9 @@ int mtl_layernorm_fwd(void* stream, const float* x, const float* residual, const
                       float eps);
 long mtl_layernorm_bwd_workspace(int rows, int d);
 int mtl_layernorm_bwd(void* stream, const float* dy, const float* xhat, const float* rstd, const float* gamma,
-                      const int* keep, float* dz, float* dgamma /*accum*/, float* dbeta /*accum*/, float* workspace,
-                      int rows, int d);
+                      const int* keep, float* dz, float* dgamma /*accum*/, float* dbeta /*accum*/,
+                      float* dsum /*nullable, accum: += column sums of dz (bias gradient of the producing linear)*/,
+                      float* workspace, int rows, int d);
 
 /* ---- masked softmax: modules/common_layers.py:322-327.  S is [B][H][Tq][ld], in place.
  * keys k >= klen[b] (klen nullable) and, if causal, k > q are filled with -inf before the softmax. */

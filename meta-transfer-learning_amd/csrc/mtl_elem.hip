@@ -145,11 +145,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     constexpr int D = NPL * 64;
     const int lane = threadIdx.x & 63;
     const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
-    float ag[NPL], ab[NPL], gm[NPL];
+    float ag[NPL], ab[NPL], az[NPL], gm[NPL];
 #pragma unroll
     for (int i = 0; i < NPL; ++i) {
         ag[i] = 0.f;
         ab[i] = 0.f;
+        az[i] = 0.f;
         gm[i] = gamma[i * 64 + lane];
     }
     const int r0 = gw * rows_per_wave;
@@ -172,26 +173,36 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         s2 = wave_sum(s2) * (1.f / D);
         const float rs = rstd[row];
 #pragma unroll
-        for (int i = 0; i < NPL; ++i) dz[(long)row * D + i * 64 + lane] = rs * (g[i] - s1 - h[i] * s2);
+        for (int i = 0; i < NPL; ++i) {
+            const float o = rs * (g[i] - s1 - h[i] * s2);
+            dz[(long)row * D + i * 64 + lane] = o;
+            az[i] += o;
+        }
     }
 #pragma unroll
     for (int i = 0; i < NPL; ++i) {
-        part[((long)gw * 2) * D + i * 64 + lane] = ag[i];
-        part[((long)gw * 2 + 1) * D + i * 64 + lane] = ab[i];
+        part[((long)gw * 3) * D + i * 64 + lane] = ag[i];
+        part[((long)gw * 3 + 1) * D + i * 64 + lane] = ab[i];
+        part[((long)gw * 3 + 2) * D + i * 64 + lane] = az[i];
     }
 }
-// out_gamma[c] += sum_w part[w][0][c], out_beta[c] += sum_w part[w][1][c]
-__global__ void ln_param_reduce_kernel(const float* __restrict__ part, int nw, int D, float* __restrict__ dgamma,
-                                       float* __restrict__ dbeta) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= D) return;
-    float a = 0.f, b = 0.f;
-    for (int w = 0; w < nw; ++w) {
-        a += part[((long)w * 2) * D + c];
-        b += part[((long)w * 2 + 1) * D + c];
-    }
-    dgamma[c] += a;
-    dbeta[c] += b;
+// out[which][c] += sum_w part[w][which][c]  for which = gamma, beta, colsum(dz); one block per (which, 64 columns),
+// 4 waves stride the partial rows and combine through LDS in a fixed order
+__global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __restrict__ part, int nw, int D,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                              float* __restrict__ dsum) {
+    __shared__ float sh[4][64];
+    const int which = blockIdx.y;
+    float* out = which == 0 ? dgamma : (which == 1 ? dbeta : dsum);
+    if (!out) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    float a = 0.f;
+    if (c < D)
+        for (int w = wv; w < nw; w += 4) a += part[((long)w * 3 + which) * D + c];
+    sh[wv][lane] = a;
+    __syncthreads();
+    if (wv == 0 && c < D) out[c] += (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
 }
 
 // ------------------------------------------------------------------ masked softmax over keys, one wave per (b,h,q) row
@@ -328,24 +339,39 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ l
 }
 
 // ------------------------------------------------------------------ column sums (bias gradients), deterministic two-stage
-// part[blk][c] = sum over this block's row range of X[r][c]; then out[c] += sum_blk part[blk][c]
-__global__ void colsum_partial_kernel(const float* __restrict__ X, long rows, int cols, long ld, long rows_per_block,
-                                      float* __restrict__ part) {
+// stage 1: block (64 columns, row chunk): 4 waves stride the rows of the chunk, lanes = columns (256-B coalesced rows),
+// combined through LDS -> part[chunk][c];  stage 2: out[c] += sum_chunk part[chunk][c] in fixed order.
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ X, long rows, int cols, long ld,
+                                                             long rows_per_block, float* __restrict__ part) {
+    __shared__ float sh[4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
     const long r0 = (long)blockIdx.y * rows_per_block;
     long r1 = r0 + rows_per_block;
     if (r1 > rows) r1 = rows;
-    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < cols; c += gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (long r = r0; r < r1; ++r) s += X[r * ld + c];
-        part[(long)blockIdx.y * cols + c] = s;
+    float s0 = 0.f, s1 = 0.f;
+    if (c < cols) {
+        long r = r0 + wv;
+        for (; r + 4 < r1; r += 8) {
+            s0 += X[r * ld + c];
+            s1 += X[(r + 4) * ld + c];
+        }
+        if (r < r1) s0 += X[r * ld + c];
     }
+    sh[wv][lane] = s0 + s1;
+    __syncthreads();
+    if (wv == 0 && c < cols) part[(long)blockIdx.y * cols + c] = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
 }
-__global__ void colsum_final_kernel(const float* __restrict__ part, int nblk, int cols, float* __restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= cols) return;
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int nblk, int cols, float* __restrict__ out) {
+    __shared__ float sh[4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
     float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += part[(long)b * cols + c];
-    out[c] += s;
+    if (c < cols)
+        for (int b = wv; b < nblk; b += 4) s += part[(long)b * cols + c];
+    sh[wv][lane] = s;
+    __syncthreads();
+    if (wv == 0 && c < cols) out[c] += (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
 }
 
 // ------------------------------------------------------------------ first conv layer (C_in = 1): direct, HBM-bound
@@ -530,11 +556,11 @@ int mtl_layernorm_fwd(void* stream, const float* x, const float* residual, const
 
 long mtl_layernorm_bwd_workspace(int rows, int d) {
     const int waves = ((rows + 7) / 8 + 3) / 4 * 4;
-    return (long)waves * 2 * d * 4;
+    return (long)waves * 3 * d * 4;
 }
 
 int mtl_layernorm_bwd(void* stream, const float* dy, const float* xhat, const float* rstd, const float* gamma,
-                      const int* keep, float* dz, float* dgamma, float* dbeta, float* workspace, int rows, int d) {
+                      const int* keep, float* dz, float* dgamma, float* dbeta, float* dsum, float* workspace, int rows, int d) {
     if (!dy || !xhat || !rstd || !gamma || !dz || !dgamma || !dbeta || !workspace || rows <= 0) return MTL_EINVAL;
     const int rpw = 8;
     const int waves = ((rows + rpw - 1) / rpw + 3) / 4 * 4;
@@ -550,7 +576,7 @@ int mtl_layernorm_bwd(void* stream, const float* dy, const float* xhat, const fl
         default: return MTL_EINVAL;
     }
 #undef LN_BWD
-    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((d + 255) / 256), dim3(256), 0, s, workspace, waves, d, dgamma, dbeta);
+    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((d + 63) / 64, 3), dim3(256), 0, s, workspace, waves, d, dgamma, dbeta, dsum);
     MTL_CHECK_LAUNCH();
     return MTL_OK;
 }
@@ -608,21 +634,25 @@ int mtl_ce_bwd(void* stream, const float* logits, const float* lse, const long* 
     return MTL_OK;
 }
 
-long mtl_colsum_workspace(long rows, int cols) {
-    long nblk = (rows + 255) / 256;
-    if (nblk > 512) nblk = 512;
-    return nblk * cols * 4;
+static long colsum_chunks(long rows, int cols) {
+    const long colblocks = (cols + 63) / 64;
+    long nblk = (rows + 31) / 32;                 // >= 32 rows per block
+    const long want = (2048 + colblocks - 1) / colblocks;
+    if (nblk > want) nblk = want;
+    if (nblk < 1) nblk = 1;
+    return nblk;
 }
+long mtl_colsum_workspace(long rows, int cols) { return colsum_chunks(rows, cols) * cols * 4; }
 
 int mtl_colsum_accum(void* stream, const float* X, long rows, int cols, long ld, float* out, float* workspace) {
     if (!X || !out || !workspace || rows <= 0 || cols <= 0) return MTL_EINVAL;
-    long nblk = (rows + 255) / 256;
-    if (nblk > 512) nblk = 512;
+    long nblk = colsum_chunks(rows, cols);
     const long rpb = (rows + nblk - 1) / nblk;
+    nblk = (rows + rpb - 1) / rpb;
     hipStream_t s = as_stream(stream);
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3((cols + 63) / 64, (unsigned)nblk), dim3(64), 0, s, X, rows, cols, ld, rpb,
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((cols + 63) / 64, (unsigned)nblk), dim3(256), 0, s, X, rows, cols, ld, rpb,
                        workspace);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, workspace, (int)nblk, cols, out);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((cols + 63) / 64), dim3(256), 0, s, workspace, (int)nblk, cols, out);
     MTL_CHECK_LAUNCH();
     return MTL_OK;
 }

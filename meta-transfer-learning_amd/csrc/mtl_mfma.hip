@@ -228,6 +228,8 @@ struct GemmP {
     float alpha;
     int flags, H;
     long sAb, sAh, sBb, sBh, sCb, sCh;
+    int ksplit, kchunk;   // ksplit > 1: grid.z indexes K-chunks (batch must be 1); raw partial tiles go to `partial`
+    float* partial;       // [ksplit][M][N]
 };
 
 struct EpiGemm {
@@ -260,22 +262,49 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
     using LB = typename std::conditional<TB, LoadKMajor<BN>, LoadMNMajor<BN>>::type;
     using E = Engine<BM, BN, LA, LB>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int z = blockIdx.z, zb = z / p.H, zh = z % p.H;
-    const float* A = p.A + zb * p.sAb + zh * p.sAh;
-    const float* B = p.B + zb * p.sBb + zh * p.sBh;
-    float* C = p.C + zb * p.sCb + zh * p.sCh;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int tid = threadIdx.x;
     LA la;
     LB lb;
-    la.init(A, p.lda, m0, p.M, p.K, tid);
-    lb.init(B, p.ldb, n0, p.N, p.K, tid);
     f32x16 acc[E::TM][E::TN];
     E::zero(acc);
+    if (p.ksplit > 1) {
+        // split-K: this block owns k in [k0, k0+Kc); partial sums are combined in fixed order by splitk_reduce_kernel
+        const int k0 = blockIdx.z * p.kchunk;
+        const int Kc = min(p.kchunk, p.K - k0);
+        la.init(p.A + (TA ? (long)k0 * p.lda : (long)k0), p.lda, m0, p.M, Kc, tid);
+        lb.init(p.B + (TB ? (long)k0 : (long)k0 * p.ldb), p.ldb, n0, p.N, Kc, tid);
+        E::run(la, lb, (Kc + BK - 1) / BK, smem, acc);
+        EpiGemm epi{p.partial + (long)blockIdx.z * p.M * p.N, nullptr, nullptr, p.M, p.N, m0, n0, p.N, 0, 0, 1.f};
+        E::finish(acc, epi);
+        return;
+    }
+    const int z = blockIdx.z, zb = z / p.H, zh = z % p.H;
+    const float* A = p.A + zb * p.sAb + zh * p.sAh;
+    const float* B = p.B + zb * p.sBb + zh * p.sBh;
+    float* C = p.C + zb * p.sCb + zh * p.sCh;
+    la.init(A, p.lda, m0, p.M, p.K, tid);
+    lb.init(B, p.ldb, n0, p.N, p.K, tid);
     E::run(la, lb, (p.K + BK - 1) / BK, smem, acc);
     const float* gate = p.gate ? p.gate + zb * p.sCb + zh * p.sCh : nullptr;
     EpiGemm epi{C, p.bias, gate, p.M, p.N, m0, n0, p.ldc, p.ldg, p.flags, p.alpha};
     E::finish(acc, epi);
+}
+
+// C = epilogue(sum_z partial[z]) -- fixed summation order, so split-K stays run-to-run deterministic
+__global__ void splitk_reduce_kernel(GemmP p) {
+    const long total = (long)p.M * p.N;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int row = (int)(e / p.N), col = (int)(e - (long)row * p.N);
+        float s = 0.f;
+        for (int z = 0; z < p.ksplit; ++z) s += p.partial[(long)z * total + e];
+        float x = p.alpha * s + (p.bias ? p.bias[col] : 0.f);
+        if (p.flags & MTL_GEMM_RELU) x = fmaxf(x, 0.f);
+        if (p.gate) x = p.gate[(long)row * p.ldg + col] > 0.f ? x : 0.f;
+        float* c = p.C + (long)row * p.ldc + col;
+        if (p.flags & MTL_GEMM_ACCUM) x += *c;
+        *c = x;
+    }
 }
 
 template <class K>
@@ -300,10 +329,32 @@ int launch_gemm(const GemmP& p, int batch, hipStream_t s) {
 }
 
 template <bool TA, bool TB>
-int dispatch_gemm(const GemmP& p, int batch, hipStream_t s) {
+int dispatch_gemm(GemmP& p, int batch, hipStream_t s, float* workspace, long workspace_bytes) {
     // big tiles only when they still give >= 1 workgroup per CU
     const long big = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * batch;
     if (big >= 256) return launch_gemm<128, 128, TA, TB>(p, batch, s);
+    const long tiles = (long)((p.M + 63) / 64) * ((p.N + 63) / 64);
+    if (batch == 1 && workspace && tiles < 192 && p.K >= 128) {
+        // too few output tiles to fill 256 CUs: split K over grid.z into a workspace, then a fixed-order reduction
+        long S = (512 + tiles - 1) / tiles;
+        if (S > p.K / 64) S = p.K / 64;
+        const long fit = workspace_bytes / ((long)p.M * p.N * 4);
+        if (S > fit) S = fit;
+        if (S > 32) S = 32;
+        if (S >= 2) {
+            p.kchunk = (int)(((p.K + S - 1) / S + BK - 1) / BK * BK);
+            p.ksplit = (p.K + p.kchunk - 1) / p.kchunk;
+            p.partial = workspace;
+            if (p.ksplit >= 2) {
+                int rc = launch_gemm<64, 64, TA, TB>(p, p.ksplit, s);
+                if (rc) return rc;
+                hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for((long)p.M * p.N, 256, 1024)), dim3(256), 0, s, p);
+                MTL_CHECK_LAUNCH();
+                return MTL_OK;
+            }
+            p.ksplit = 1;
+        }
+    }
     return launch_gemm<64, 64, TA, TB>(p, batch, s);
 }
 
@@ -709,14 +760,15 @@ extern "C" {
 
 int mtl_gemm_f32(void* stream, int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
                  const float* B, int ldb, float* C, int ldc, const float* bias, const float* gate, int ldg, int flags,
-                 int batch, int H, long sAb, long sAh, long sBb, long sBh, long sCb, long sCh) {
+                 int batch, int H, long sAb, long sAh, long sBb, long sBh, long sCb, long sCh, float* workspace,
+                 long workspace_bytes) {
     if (M <= 0 || N <= 0 || K <= 0 || batch <= 0 || H <= 0 || !A || !B || !C) return MTL_EINVAL;
-    GemmP p{A, B, C, bias, gate, M, N, K, lda, ldb, ldc, ldg, alpha, flags, H, sAb, sAh, sBb, sBh, sCb, sCh};
+    GemmP p{A, B, C, bias, gate, M, N, K, lda, ldb, ldc, ldg, alpha, flags, H, sAb, sAh, sBb, sBh, sCb, sCh, 1, 0, nullptr};
     hipStream_t s = as_stream(stream);
-    if (!transA && transB) return dispatch_gemm<false, true>(p, batch, s);
-    if (!transA && !transB) return dispatch_gemm<false, false>(p, batch, s);
-    if (transA && !transB) return dispatch_gemm<true, false>(p, batch, s);
-    return dispatch_gemm<true, true>(p, batch, s);
+    if (!transA && transB) return dispatch_gemm<false, true>(p, batch, s, workspace, workspace_bytes);
+    if (!transA && !transB) return dispatch_gemm<false, false>(p, batch, s, workspace, workspace_bytes);
+    if (transA && !transB) return dispatch_gemm<true, false>(p, batch, s, workspace, workspace_bytes);
+    return dispatch_gemm<true, true>(p, batch, s, workspace, workspace_bytes);
 }
 
 int mtl_conv3x3_wprep(void* stream, const float* w_ref, float* w_fwd, float* w_dgrad, int Cout, int Cin) {

@@ -79,6 +79,8 @@ class PassEngine:
         self.arena = {}     # name -> buffer of the current pass (looked up again by the backward)
         self.pool = {}      # (name, shape, dtype) -> allocation, so alternating batch shapes do not re-allocate
         self.saved = None
+        self.gemm_ws = torch.empty(8 << 20, dtype=torch.float32, device=device) if device.type == 'cuda' else None  # split-K slabs
+        self.prof = None    # optional {name: [flops, [(start_event, end_event), ...]]}: HIP events around the conv launches
         if device.type != 'cuda':
             raise RuntimeError('PassEngine needs an MI355X device (got %s); there is no CPU product path' % device)
 
@@ -99,20 +101,33 @@ class PassEngine:
             self.arena['_scratch'] = t
         return t.data_ptr()
 
+    def timed(self, name, flops, fn, *args):
+        """Run one library call; when profiling is on, bracket it with events on the launch stream (bench.py roofline)."""
+        if self.prof is None:
+            return fn(*args)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(torch.cuda.current_stream(self.device))
+        rc = fn(*args)
+        b.record(torch.cuda.current_stream(self.device))
+        self.prof.setdefault(name, [flops, []])[1].append((a, b))
+        return rc
+
     @property
     def stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
 
     def gemm(self, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias=None, gate=None, ldg=0, flags=0, alpha=1.0,
              batch=1, H=1, sA=(0, 0), sB=(0, 0), sC=(0, 0)):
+        ws, wsb = (self.gemm_ws.data_ptr(), self.gemm_ws.numel() * 4) if batch == 1 else (None, 0)
         check(self.lib.mtl_gemm_f32(self.stream, ta, tb, M, N, K, alpha, A, lda, B, ldb, C, ldc, bias, gate, ldg, flags,
-                                    batch, H, sA[0], sA[1], sB[0], sB[1], sC[0], sC[1]), 'mtl_gemm_f32')
+                                    batch, H, sA[0], sA[1], sB[0], sB[1], sC[0], sC[1], ws, wsb), 'mtl_gemm_f32')
 
     def linear_fwd(self, x, rows, k_in, w, b, y, n_out, relu=False):
         self.gemm(0, 1, rows, n_out, k_in, x, k_in, w, k_in, y, n_out, bias=b, flags=RELU if relu else 0)
 
     def linear_bwd(self, x, dy, rows, k_in, n_out, w, dw, db, dx, dx_accum, gate=None):
-        """dw += dy^T x ; db += colsum(dy) ; dx (=|+=) dy.W  (gate: ReLU mask source for dx)"""
+        """dw += dy^T x ; db += colsum(dy) (db None: no bias, or already produced by the LayerNorm backward) ;
+        dx (=|+=) dy.W  (gate: ReLU mask source for dx)"""
         self.gemm(1, 0, n_out, k_in, rows, dy, n_out, x, k_in, dw, k_in, flags=ACCUM)
         if db is not None:
             self.colsum(dy, rows, n_out, db)
@@ -128,9 +143,9 @@ class PassEngine:
         check(self.lib.mtl_layernorm_fwd(self.stream, x, res, g, b, pe, keep, y, xhat, rstd, rows, self.hp.d, T, 1e-5),
               'mtl_layernorm_fwd')
 
-    def ln_bwd(self, dy, xhat, rstd, g, keep, dz, dg, db, rows):
+    def ln_bwd(self, dy, xhat, rstd, g, keep, dz, dg, db, rows, dsum=None):
         ws = self.scratch(self.lib.mtl_layernorm_bwd_workspace(rows, self.hp.d))
-        check(self.lib.mtl_layernorm_bwd(self.stream, dy, xhat, rstd, g, keep, dz, dg, db, ws, rows, self.hp.d),
+        check(self.lib.mtl_layernorm_bwd(self.stream, dy, xhat, rstd, g, keep, dz, dg, db, dsum, ws, rows, self.hp.d),
               'mtl_layernorm_bwd')
 
     # ---------------------------------------------------------------- attention / ffn blocks
@@ -181,11 +196,11 @@ class PassEngine:
         Pm, O, oa = A[tag + 'P'], A[tag + 'O'], A[tag + 'oa']
         # LayerNorm(o + residual) * keep
         self.ln_bwd(dy, A[tag + 'xhat'].data_ptr(), A[tag + 'rstd'].data_ptr(), o('layer_norm.weight'), keep, dxq,
-                    g('layer_norm.weight'), g('layer_norm.bias'), Mq)
+                    g('layer_norm.weight'), g('layer_norm.bias'), Mq, dsum=g('output_linear_b.bias'))
         dz = dxq  # residual path: dxq starts as dz, projections accumulate on top
         doa = self.buf('_doa', (Mq, r))
         self.linear_bwd(oa.data_ptr(), dz, Mq, r, d, o('output_linear_b.weight'), g('output_linear_b.weight'),
-                        g('output_linear_b.bias'), doa.data_ptr(), False)
+                        None, doa.data_ptr(), False)
         dO = self.buf('_dO', (Mq, hv))
         self.linear_bwd(O.data_ptr(), doa.data_ptr(), Mq, hv, r, o('output_linear_a.weight'), g('output_linear_a.weight'),
                         None, dO.data_ptr(), False)
@@ -240,11 +255,11 @@ class PassEngine:
         o = lambda n: P + 4 * L.off(pre + n)
         g = lambda n: G + 4 * L.off(pre + n)
         self.ln_bwd(dy, A[tag + 'xhat'].data_ptr(), A[tag + 'rstd'].data_ptr(), o('layer_norm.weight'), keep, dx,
-                    g('layer_norm.weight'), g('layer_norm.bias'), rows)
+                    g('layer_norm.weight'), g('layer_norm.bias'), rows, dsum=g('linear_2.bias'))
         h1 = A[tag + 'h1']
         dh1 = self.buf('_dh1', (rows, hp.inner))
         self.linear_bwd(h1.data_ptr(), dx, rows, hp.inner, hp.d, o('linear_2.weight'), g('linear_2.weight'),
-                        g('linear_2.bias'), dh1.data_ptr(), False, gate=h1.data_ptr())
+                        None, dh1.data_ptr(), False, gate=h1.data_ptr())
         self.linear_bwd(x, dh1.data_ptr(), rows, hp.d, hp.inner, o('linear_1.weight'), g('linear_1.weight'),
                         g('linear_1.bias'), dx, True)
 
@@ -297,7 +312,9 @@ class PassEngine:
 
         # ---- VGG front-end ----
         y1 = self.buf('y1', (B, T, F, 64))
-        check(lib.mtl_conv0_relu_fwd(st, x.data_ptr(), o('conv.0.weight'), o('conv.0.bias'), y1.data_ptr(), B, T, F), 'conv0')
+        cf = lambda t_, f_, ci, co: 2.0 * B * t_ * f_ * 9 * ci * co     # algorithmic FLOPs of one 3x3 conv launch
+        check(self.timed('conv0_fwd', cf(T, F, 1, 64), lib.mtl_conv0_relu_fwd, st, x.data_ptr(), o('conv.0.weight'),
+                         o('conv.0.bias'), y1.data_ptr(), B, T, F), 'conv0')
         wf, wd = {}, {}
         for idx, cin, cout in ((2, 64, 64), (5, 64, 128), (7, 128, 128)):
             wf[idx] = self.buf('wf%d' % idx, (9, cin, cout))
@@ -305,15 +322,15 @@ class PassEngine:
             check(lib.mtl_conv3x3_wprep(st, o('conv.%d.weight' % idx), wf[idx].data_ptr(), wd[idx].data_ptr(), cout, cin), 'wprep')
         p1 = self.buf('p1', (B, T2, F2, 64))
         am1 = self.buf('am1', (B, T2, F2, 64), torch.uint8)
-        check(lib.mtl_conv3x3_relu_pool_fwd(st, y1.data_ptr(), wf[2].data_ptr(), o('conv.2.bias'), p1.data_ptr(), am1.data_ptr(),
-                                            B, T, F, 64, 64), 'conv2')
+        check(self.timed('conv2_fwd_pool', cf(T, F, 64, 64), lib.mtl_conv3x3_relu_pool_fwd, st, y1.data_ptr(), wf[2].data_ptr(),
+                         o('conv.2.bias'), p1.data_ptr(), am1.data_ptr(), B, T, F, 64, 64), 'conv2')
         y5 = self.buf('y5', (B, T2, F2, 128))
-        check(lib.mtl_conv3x3_relu_fwd(st, p1.data_ptr(), wf[5].data_ptr(), o('conv.5.bias'), y5.data_ptr(), B, T2, F2, 64, 128),
-              'conv5')
+        check(self.timed('conv5_fwd', cf(T2, F2, 64, 128), lib.mtl_conv3x3_relu_fwd, st, p1.data_ptr(), wf[5].data_ptr(),
+                         o('conv.5.bias'), y5.data_ptr(), B, T2, F2, 64, 128), 'conv5')
         p2 = self.buf('p2', (B, T4, F4, 128))
         am2 = self.buf('am2', (B, T4, F4, 128), torch.uint8)
-        check(lib.mtl_conv3x3_relu_pool_fwd(st, y5.data_ptr(), wf[7].data_ptr(), o('conv.7.bias'), p2.data_ptr(), am2.data_ptr(),
-                                            B, T2, F2, 128, 128), 'conv7')
+        check(self.timed('conv7_fwd_pool', cf(T2, F2, 128, 128), lib.mtl_conv3x3_relu_pool_fwd, st, y5.data_ptr(), wf[7].data_ptr(),
+                         o('conv.7.bias'), p2.data_ptr(), am2.data_ptr(), B, T2, F2, 128, 128), 'conv7')
 
         # ---- encoder ----
         wp = self.buf('wp_in', (d, hp.d_in))
@@ -429,37 +446,40 @@ class PassEngine:
         # input LayerNorm (+PE: no grad) and input_linear
         de0 = dnext
         self.ln_bwd(dcur.data_ptr(), A['enc_in.xhat'].data_ptr(), A['enc_in.rstd'].data_ptr(), o('encoder.layer_norm_input.weight'),
-                    None, de0.data_ptr(), g('encoder.layer_norm_input.weight'), g('encoder.layer_norm_input.bias'), Me)
+                    None, de0.data_ptr(), g('encoder.layer_norm_input.weight'), g('encoder.layer_norm_input.bias'), Me,
+                    dsum=g('encoder.input_linear.bias'))
         p2, y5, p1, y1 = A['p2'], A['y5'], A['p1'], A['y1']
         dwp = self.buf('_dwp', (d, hp.d_in))
         dp2 = self.buf('_dp2', (B, T4, F4, 128))
         self.gemm(1, 0, d, hp.d_in, Me, de0.data_ptr(), d, p2.data_ptr(), hp.d_in, dwp.data_ptr(), hp.d_in)
         check(lib.mtl_permute_hc(st, dwp.data_ptr(), g('encoder.input_linear.weight'), d, 128, F4, 1), 'permute_inv')
-        self.colsum(de0.data_ptr(), Me, d, g('encoder.input_linear.bias'))
         self.gemm(0, 0, Me, hp.d_in, d, de0.data_ptr(), d, A['wp_in'].data_ptr(), hp.d_in, dp2.data_ptr(), hp.d_in,
                   gate=p2.data_ptr(), ldg=hp.d_in)
 
         # ---- VGG front-end ----
+        cf = lambda t_, f_, ci, co: 2.0 * B * t_ * f_ * 9 * ci * co
+
         def wgrad(xa, dy, am, idx, Bq, Tq, Fq, cin, cout):
             need = lib.mtl_conv3x3_wgrad_workspace(Bq, Tq, Fq, cin, cout, 1 if am else 0)
             ws = self.scratch(need)
-            check(lib.mtl_conv3x3_wgrad(st, xa, dy, am, g('conv.%d.weight' % idx), ws, need, Bq, Tq, Fq, cin, cout), 'wgrad')
+            check(self.timed('conv%d_wgrad' % idx, cf(Tq, Fq, cin, cout), lib.mtl_conv3x3_wgrad, st, xa, dy, am,
+                             g('conv.%d.weight' % idx), ws, need, Bq, Tq, Fq, cin, cout), 'wgrad')
 
         self.colsum(dp2.data_ptr(), B * T4 * F4, 128, g('conv.7.bias'))
         wgrad(y5.data_ptr(), dp2.data_ptr(), A['am2'].data_ptr(), 7, B, T2, F2, 128, 128)
         dy5 = self.buf('_dy5', (B, T2, F2, 128))
-        check(lib.mtl_conv3x3_dgrad(st, dp2.data_ptr(), A['am2'].data_ptr(), A['wd7'].data_ptr(), y5.data_ptr(), dy5.data_ptr(),
-                                    B, T2, F2, 128, 128), 'dgrad7')
+        check(self.timed('conv7_dgrad', cf(T2, F2, 128, 128), lib.mtl_conv3x3_dgrad, st, dp2.data_ptr(), A['am2'].data_ptr(),
+                         A['wd7'].data_ptr(), y5.data_ptr(), dy5.data_ptr(), B, T2, F2, 128, 128), 'dgrad7')
         self.colsum(dy5.data_ptr(), B * T2 * F2, 128, g('conv.5.bias'))
         wgrad(p1.data_ptr(), dy5.data_ptr(), None, 5, B, T2, F2, 64, 128)
         dp1 = self.buf('_dp1', (B, T2, F2, 64))
-        check(lib.mtl_conv3x3_dgrad(st, dy5.data_ptr(), None, A['wd5'].data_ptr(), p1.data_ptr(), dp1.data_ptr(), B, T2, F2, 64,
-                                    128), 'dgrad5')
+        check(self.timed('conv5_dgrad', cf(T2, F2, 64, 128), lib.mtl_conv3x3_dgrad, st, dy5.data_ptr(), None, A['wd5'].data_ptr(),
+                         p1.data_ptr(), dp1.data_ptr(), B, T2, F2, 64, 128), 'dgrad5')
         self.colsum(dp1.data_ptr(), B * T2 * F2, 64, g('conv.2.bias'))
         wgrad(y1.data_ptr(), dp1.data_ptr(), A['am1'].data_ptr(), 2, B, T, F, 64, 64)
         dy1 = self.buf('_dy1', (B, T, F, 64))
-        check(lib.mtl_conv3x3_dgrad(st, dp1.data_ptr(), A['am1'].data_ptr(), A['wd2'].data_ptr(), y1.data_ptr(), dy1.data_ptr(),
-                                    B, T, F, 64, 64), 'dgrad2')
+        check(self.timed('conv2_dgrad', cf(T, F, 64, 64), lib.mtl_conv3x3_dgrad, st, dp1.data_ptr(), A['am1'].data_ptr(),
+                         A['wd2'].data_ptr(), y1.data_ptr(), dy1.data_ptr(), B, T, F, 64, 64), 'dgrad2')
         ws = self.scratch(lib.mtl_conv0_wgrad_workspace())
-        check(lib.mtl_conv0_wgrad(st, S['x'].data_ptr(), dy1.data_ptr(), g('conv.0.weight'), g('conv.0.bias'), ws, B, T, F),
-              'wgrad0')
+        check(self.timed('conv0_wgrad', cf(T, F, 1, 64), lib.mtl_conv0_wgrad, st, S['x'].data_ptr(), dy1.data_ptr(),
+                         g('conv.0.weight'), g('conv.0.bias'), ws, B, T, F), 'wgrad0')

@@ -183,6 +183,26 @@ class TransientTrainer():
             reads.append((tr_read, va_read))
         return reads
 
+    def run_iteration(self, model, vocab, task_batches, val_data, n_tasks, inner_opt, outer_opt, args):
+        """The timed body of one meta-iteration (transient_trainer.py:152-264): local tasks, ONE all-reduce of G, Adam,
+        then a single device sync to resolve the loss / label read-backs.  -> (sum val loss, CER edits, chars), global."""
+        dev = model.flat_parameters.device
+        outer_opt.zero_grad()
+        reads = self.meta_iteration(model, vocab, task_batches, val_data, n_tasks, inner_opt, outer_opt, args)
+        G = model._G
+        mdist.allreduce_sum_(G)                                  # the one collective of the path
+        if args.clip:
+            clip_flat_grad_(model, G, args.max_norm)             # (:253-254) on the summed meta-gradient
+        outer_opt.step(G)                                        # from_copy_grad() + outer_opt.step()  (:248-255)
+        torch.cuda.synchronize(dev)
+        total_loss, total_cer, total_char = 0.0, 0, 0
+        for tr_read, va_read in reads:
+            c, n = cer_counts(vocab, tr_read.gold_host, tr_read.hyp)    # the reference reports the TRAIN batches' CER
+            total_cer += c
+            total_char += n
+            total_loss += float(va_read.loss[0])
+        return mdist.allreduce_scalars([total_loss, total_cer, total_char], dev)
+
     def train(self, model, vocab, train_data_list, valid_loader_list, loss_type, start_it, num_it, args, inner_opt=None,
               outer_opt=None, evaluate_every=1000, window_size=100, last_summary_every=1000, last_metrics=None, early_stop=10,
               cpu_state_dict=False, is_copy_grad=False):
@@ -236,22 +256,8 @@ class TransientTrainer():
             _, val_data = train_data_buffer[-1][-1]                  # the LAST task's validation batch, shared by all (:168)
             popped = [train_data_buffer[m].pop() for m in range(n_tasks)]
             task_batches = [popped[m][0] for m in my_tasks]
-            outer_opt.zero_grad()
-            reads = self.meta_iteration(model, vocab, task_batches, val_data, n_tasks, inner_opt, outer_opt, args)
-            G = model._G
-            mdist.allreduce_sum_(G)                                  # the one collective of the path
-            if args.clip:
-                clip_flat_grad_(model, G, args.max_norm)             # (:253-254) on the summed meta-gradient
-            outer_opt.step(G)                                        # from_copy_grad() + outer_opt.step()  (:248-255)
-            torch.cuda.synchronize(dev)
-
-            total_loss, total_cer, total_char = 0.0, 0, 0
-            for tr_read, va_read in reads:
-                c, n = cer_counts(vocab, tr_read.gold_host, tr_read.hyp)    # the reference reports the TRAIN batches' CER
-                total_cer += c
-                total_char += n
-                total_loss += float(va_read.loss[0])
-            total_loss, total_cer, total_char = mdist.allreduce_scalars([total_loss, total_cer, total_char], dev)
+            total_loss, total_cer, total_char = self.run_iteration(model, vocab, task_batches, val_data, n_tasks, inner_opt,
+                                                                   outer_opt, args)
             last_sum_cer.append(total_cer)
             last_sum_char.append(total_char)
             last_sum_loss.append(total_loss / n_tasks)

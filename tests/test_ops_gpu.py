@@ -42,12 +42,33 @@ def test_gemm_transposes(L, ta, tb, M, N, K):
     dA, dB, dbias = dev(A), dev(B), dev(bias)
     C = dev(C0.clone())
     assert L.mtl_gemm_f32(st(), ta, tb, M, N, K, 1.0, dA.data_ptr(), A.shape[1], dB.data_ptr(), B.shape[1], C.data_ptr(), N,
-                          None, None, 0, 0, 1, 1, 0, 0, 0, 0, 0, 0) == 0
+                          None, None, 0, 0, 1, 1, 0, 0, 0, 0, 0, 0, None, 0) == 0
     assert rel(C, ref) < 2e-6
     C = dev(C0.clone())           # bias + relu + accumulate
     assert L.mtl_gemm_f32(st(), ta, tb, M, N, K, 0.5, dA.data_ptr(), A.shape[1], dB.data_ptr(), B.shape[1], C.data_ptr(), N,
-                          dbias.data_ptr(), None, 0, 3, 1, 1, 0, 0, 0, 0, 0, 0) == 0
+                          dbias.data_ptr(), None, 0, 3, 1, 1, 0, 0, 0, 0, 0, 0, None, 0) == 0
     assert rel(C, torch.relu(0.5 * ref + bias) + C0) < 2e-6
+
+
+@pytest.mark.parametrize('ta,tb', [(0, 1), (0, 0), (1, 0), (1, 1)])
+def test_gemm_split_k_deterministic(L, ta, tb):
+    """few output tiles + long K -> split-K through the workspace; same epilogue semantics, bitwise repeatable"""
+    g = torch.Generator().manual_seed(11 + ta * 2 + tb)
+    M, N, K = 100, 512, 2000
+    A = torch.randn((K, M) if ta else (M, K), generator=g)
+    B = torch.randn((N, K) if tb else (K, N), generator=g)
+    bias, C0, gate = torch.randn(N, generator=g), torch.randn(M, N, generator=g), torch.randn(M, N, generator=g)
+    ref = (torch.relu((A.t() if ta else A) @ (B.t() if tb else B) + bias)) * (gate > 0) + C0
+    dA, dB, dbias, dgate = dev(A), dev(B), dev(bias), dev(gate)
+    ws = torch.empty(4 << 20).cuda()
+    outs = []
+    for _ in range(2):
+        C = dev(C0.clone())
+        assert L.mtl_gemm_f32(st(), ta, tb, M, N, K, 1.0, dA.data_ptr(), A.shape[1], dB.data_ptr(), B.shape[1], C.data_ptr(), N,
+                              dbias.data_ptr(), dgate.data_ptr(), N, 3, 1, 1, 0, 0, 0, 0, 0, 0, ws.data_ptr(), ws.numel() * 4) == 0
+        outs.append(C.cpu())
+    assert rel(outs[0], ref) < 3e-6
+    assert torch.equal(outs[0], outs[1])
 
 
 def test_gemm_gate_and_batched_heads(L):
@@ -59,7 +80,7 @@ def test_gemm_gate_and_batched_heads(L):
     S = torch.full((Bn, H, Tq, ld), float('nan')).cuda()
     dq, dk_ = dev(q), dev(k)
     assert L.mtl_gemm_f32(st(), 0, 1, Tq, Tk, dk, 1.0, dq.data_ptr(), H * dk, dk_.data_ptr(), H * dk, S.data_ptr(), ld, None, None,
-                          0, 0, Bn * H, H, Tq * H * dk, dk, Tk * H * dk, dk, H * Tq * ld, Tq * ld) == 0
+                          0, 0, Bn * H, H, Tq * H * dk, dk, Tk * H * dk, dk, H * Tq * ld, Tq * ld, None, 0) == 0
     ref = torch.einsum('bqhd,bkhd->bhqk', q.view(Bn, Tq, H, dk), k.view(Bn, Tk, H, dk))
     assert rel(S[..., :Tk], ref) < 2e-6
     M, N, K = 300, 200, 96
@@ -67,7 +88,7 @@ def test_gemm_gate_and_batched_heads(L):
     C = torch.empty(M, N).cuda()
     dA, dB, dg = dev(A), dev(Bm), dev(gate)
     assert L.mtl_gemm_f32(st(), 0, 0, M, N, K, 1.0, dA.data_ptr(), K, dB.data_ptr(), N, C.data_ptr(), N, None, dg.data_ptr(), N, 0,
-                          1, 1, 0, 0, 0, 0, 0, 0) == 0
+                          1, 1, 0, 0, 0, 0, 0, 0, None, 0) == 0
     assert rel(C, (A @ Bm) * (gate > 0)) < 2e-6
 
 
@@ -181,9 +202,11 @@ def test_layernorm(L, d):
     dz, dg, db = torch.empty(rows, d).cuda(), torch.zeros(d).cuda(), torch.zeros(d).cuda()
     ws = torch.empty(L.mtl_layernorm_bwd_workspace(rows, d) // 4).cuda()
     ddy = dev(dy)
+    dsum = torch.ones(d).cuda()
     assert L.mtl_layernorm_bwd(st(), ddy.data_ptr(), xhat.data_ptr(), rstd.data_ptr(), a[2].data_ptr(), kd.data_ptr(),
-                               dz.data_ptr(), dg.data_ptr(), db.data_ptr(), ws.data_ptr(), rows, d) == 0
+                               dz.data_ptr(), dg.data_ptr(), db.data_ptr(), dsum.data_ptr(), ws.data_ptr(), rows, d) == 0
     assert rel(dz, xr.grad) < 1e-5 and rel(dg, gr.grad) < 1e-5 and rel(db, br.grad) < 1e-5
+    assert rel(dsum, xr.grad.sum(0) + 1) < 1e-5
 
 
 @pytest.mark.parametrize('causal', [0, 1])

@@ -137,7 +137,7 @@ def test_every_pass_of_a_meta_step_against_live_oracle(name):
         g_tr, _ = _pass_parity(model, oracle, batch, model.flat_parameters, '%s task %d train' % (name, m))
         theta1 = inner.theta_prime_from(model.flat_parameters, g_tr).clone()
         ref_t1 = model.flat_parameters - spec['lr'] * g_tr                      # inner SGD step
-        assert float((theta1 - ref_t1).abs().max()) <= 1e-7 * float(ref_t1.abs().max())
+        assert float((theta1 - ref_t1).abs().max()) <= 2.5e-7 * float(ref_t1.abs().max())   # fma vs mul+sub: 2 ulp
         g_val, _ = _pass_parity(model, oracle, val, theta1, '%s task %d valid' % (name, m))
         G_sum += g_tr + g_val / n
     trainer = mtl_amd.TransientTrainer()
