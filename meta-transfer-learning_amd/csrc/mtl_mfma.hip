@@ -43,98 +43,105 @@ struct LdsMN {  // same tile stored [BK][ROWS+4]: 32 consecutive rows of one k a
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
 // ------------------------------------------------------------------ plain matrix loaders
+// All loaders are BRANCH-FREE: fetch() issues unconditional loads from clamped (always valid) addresses and records a
+// 4-bit validity mask; the zero-fill happens in commit(), i.e. AFTER the MFMA burst of the current tile.  With bounds
+// checks as branches hipcc parks an `s_waitcnt vmcnt(0)` in front of the MFMAs and the HBM latency of every K-tile is
+// exposed; this way the loads stay in flight under 64..256 MFMAs.
+__device__ __forceinline__ float4 mask4(float4 v, unsigned m) {
+    v.x = (m & 1u) ? v.x : 0.f;
+    v.y = (m & 2u) ? v.y : 0.f;
+    v.z = (m & 4u) ? v.z : 0.f;
+    v.w = (m & 8u) ? v.w : 0.f;
+    return v;
+}
+template <bool VEC>
+__device__ __forceinline__ float4 load4(const float* q, unsigned m) {
+    if (VEC) return *reinterpret_cast<const float4*>(q);
+    // unaligned source: four dword loads, each from an in-range element
+    return make_float4(q[0], q[(m & 2u) ? 1 : 0], q[(m & 4u) ? 2 : 0], q[(m & 8u) ? 3 : 0]);
+}
+
 // Source is row-major with k contiguous: tile row r, k  ->  base[(r0+r)*ld + k]
-template <int ROWS>
+template <int ROWS, bool VEC>
 struct LoadKMajor {
     using Lds = LdsK<ROWS>;
     static constexpr int NV = ROWS * BK / 4 / NT;
+    struct Regs {
+        float4 v[NV];
+        unsigned m[NV];
+    };
     const float* base;
     long ld;
     int nrows, K, kq;
-    bool vec;
     __device__ void init(const float* p, int ld_, int r0, int rows_total, int K_, int tid) {
         base = p + (long)r0 * ld_;
         ld = ld_;
         nrows = rows_total - r0;
         K = K_;
         kq = (tid & 7) * 4;
-        vec = ((ld_ & 3) == 0) && ((reinterpret_cast<uintptr_t>(p) & 15) == 0);
     }
-    __device__ __forceinline__ void fetch(int kt, float4 (&r)[NV], int tid) const {
+    __device__ __forceinline__ void fetch(int kt, Regs& r, int tid) const {
         const int k = kt * BK + kq;
+        const unsigned km = (k < K ? 1u : 0u) | (k + 1 < K ? 2u : 0u) | (k + 2 < K ? 4u : 0u) | (k + 3 < K ? 8u : 0u);
+        const int kc = k < K ? k : 0;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int row = (tid >> 3) + i * 32;
-            float4 v = zero4();
-            if (row < nrows) {
-                const float* q = base + row * ld + k;
-                if (vec && k + 3 < K) {
-                    v = *reinterpret_cast<const float4*>(q);
-                } else {
-                    if (k < K) v.x = q[0];
-                    if (k + 1 < K) v.y = q[1];
-                    if (k + 2 < K) v.z = q[2];
-                    if (k + 3 < K) v.w = q[3];
-                }
-            }
-            r[i] = v;
+            const bool ok = row < nrows;
+            r.m[i] = ok ? km : 0u;
+            r.v[i] = load4<VEC>(base + (ok ? row : 0) * ld + kc, km);
         }
     }
-    __device__ __forceinline__ void commit(float* lds, const float4 (&r)[NV], int tid) const {
+    __device__ __forceinline__ void commit(float* lds, const Regs& r, int tid) const {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
+            const float4 v = mask4(r.v[i], r.m[i]);
             const int o = Lds::at((tid >> 3) + i * 32, kq);
-            lds[o] = r[i].x;
-            lds[o + 1] = r[i].y;
-            lds[o + 2] = r[i].z;
-            lds[o + 3] = r[i].w;
+            lds[o] = v.x;
+            lds[o + 1] = v.y;
+            lds[o + 2] = v.z;
+            lds[o + 3] = v.w;
         }
     }
 };
 
 // Source is row-major with the tile-row index contiguous: tile row r, k -> base[k*ld + c0 + r]
-template <int ROWS>
+template <int ROWS, bool VEC>
 struct LoadMNMajor {
     using Lds = LdsMN<ROWS>;
     static constexpr int VPR = ROWS / 4;    // float4 per k-row
     static constexpr int KPP = NT / VPR;    // k-rows per pass
     static constexpr int NV = BK / KPP;
+    struct Regs {
+        float4 v[NV];
+        unsigned m[NV];
+    };
     const float* base;
     long ld;
-    int ncols, K, m4, k0;
-    bool vec;
+    int K, m4, k0;
+    unsigned mm;
     __device__ void init(const float* p, int ld_, int c0, int cols_total, int K_, int tid) {
-        base = p + c0;
+        const int ncols = cols_total - c0;
         ld = ld_;
-        ncols = cols_total - c0;
         K = K_;
         m4 = (tid % VPR) * 4;
         k0 = tid / VPR;
-        vec = ((ld_ & 3) == 0) && ((reinterpret_cast<uintptr_t>(base) & 15) == 0);
+        mm = (m4 < ncols ? 1u : 0u) | (m4 + 1 < ncols ? 2u : 0u) | (m4 + 2 < ncols ? 4u : 0u) | (m4 + 3 < ncols ? 8u : 0u);
+        base = p + c0 + (m4 < ncols ? m4 : 0);
     }
-    __device__ __forceinline__ void fetch(int kt, float4 (&r)[NV], int) const {
+    __device__ __forceinline__ void fetch(int kt, Regs& r, int) const {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int k = kt * BK + k0 + i * KPP;
-            float4 v = zero4();
-            if (k < K) {
-                const float* q = base + k * ld + m4;
-                if (vec && m4 + 3 < ncols) {
-                    v = *reinterpret_cast<const float4*>(q);
-                } else {
-                    if (m4 < ncols) v.x = q[0];
-                    if (m4 + 1 < ncols) v.y = q[1];
-                    if (m4 + 2 < ncols) v.z = q[2];
-                    if (m4 + 3 < ncols) v.w = q[3];
-                }
-            }
-            r[i] = v;
+            const bool ok = k < K;
+            r.m[i] = ok ? mm : 0u;
+            r.v[i] = load4<VEC>(base + (ok ? k : 0) * ld, mm);
         }
     }
-    __device__ __forceinline__ void commit(float* lds, const float4 (&r)[NV], int) const {
+    __device__ __forceinline__ void commit(float* lds, const Regs& r, int) const {
 #pragma unroll
         for (int i = 0; i < NV; ++i)
-            *reinterpret_cast<float4*>(&lds[(k0 + i * KPP) * Lds::LD + m4]) = r[i];
+            *reinterpret_cast<float4*>(&lds[(k0 + i * KPP) * Lds::LD + m4]) = mask4(r.v[i], r.m[i]);
     }
 };
 
@@ -165,7 +172,8 @@ struct Engine {
         float* As1 = smem + AL::SIZE;
         float* Bs0 = smem + 2 * AL::SIZE;
         float* Bs1 = Bs0 + BL::SIZE;
-        float4 ra[LA::NV], rb[LB::NV];
+        typename LA::Regs ra;
+        typename LB::Regs rb;
         la.fetch(0, ra, tid);
         lb.fetch(0, rb, tid);
         la.commit(As0, ra, tid);
@@ -179,18 +187,29 @@ struct Engine {
                 la.fetch(kt + 1, ra, tid);
                 lb.fetch(kt + 1, rb, tid);
             }
+            // LDS -> register fragments are double-buffered across the 16 k-steps of the tile: step s+1's operands are
+            // requested before step s's MFMAs issue, so a 32x32x2 MFMA group (64 cycles each) never waits on a ds_read
+            float a[2][TM], b[2][TN];
 #pragma unroll
-            for (int kk = 0; kk < BK; kk += 2) {
-                float a[TM], b[TN];
+            for (int i = 0; i < TM; ++i) a[0][i] = Ac[AL::at(wm * WTM + i * 32 + l31, hi)];
 #pragma unroll
-                for (int i = 0; i < TM; ++i) a[i] = Ac[AL::at(wm * WTM + i * 32 + l31, kk + hi)];
+            for (int j = 0; j < TN; ++j) b[0][j] = Bc[BL::at(wn * WTN + j * 32 + l31, hi)];
 #pragma unroll
-                for (int j = 0; j < TN; ++j) b[j] = Bc[BL::at(wn * WTN + j * 32 + l31, kk + hi)];
+            for (int st = 0; st < BK / 2; ++st) {
+                const int cur = st & 1, nxt = cur ^ 1;
+                if (st + 1 < BK / 2) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) a[nxt][i] = Ac[AL::at(wm * WTM + i * 32 + l31, 2 * (st + 1) + hi)];
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) b[nxt][j] = Bc[BL::at(wn * WTN + j * 32 + l31, 2 * (st + 1) + hi)];
+                }
+                __builtin_amdgcn_sched_barrier(0);   // pin: next step's ds_reads are issued BEFORE this step's MFMAs
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
             if (more) {
                 la.commit((kt & 1) ? As0 : As1, ra, tid);
@@ -256,10 +275,10 @@ struct EpiGemm {
     }
 };
 
-template <int BM, int BN, bool TA, bool TB>
+template <int BM, int BN, bool TA, bool TB, bool VEC>
 __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
-    using LA = typename std::conditional<TA, LoadMNMajor<BM>, LoadKMajor<BM>>::type;
-    using LB = typename std::conditional<TB, LoadKMajor<BN>, LoadMNMajor<BN>>::type;
+    using LA = typename std::conditional<TA, LoadMNMajor<BM, VEC>, LoadKMajor<BM, VEC>>::type;
+    using LB = typename std::conditional<TB, LoadKMajor<BN, VEC>, LoadMNMajor<BN, VEC>>::type;
     using E = Engine<BM, BN, LA, LB>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
@@ -315,17 +334,27 @@ int set_smem(K kernel, int bytes) {
                : MTL_ELAUNCH;
 }
 
-template <int BM, int BN, bool TA, bool TB>
-int launch_gemm(const GemmP& p, int batch, hipStream_t s) {
-    using LA = typename std::conditional<TA, LoadMNMajor<BM>, LoadKMajor<BM>>::type;
-    using LB = typename std::conditional<TB, LoadKMajor<BN>, LoadMNMajor<BN>>::type;
+template <int BM, int BN, bool TA, bool TB, bool VEC>
+int launch_gemm_v(const GemmP& p, int batch, hipStream_t s) {
+    using LA = typename std::conditional<TA, LoadMNMajor<BM, VEC>, LoadKMajor<BM, VEC>>::type;
+    using LB = typename std::conditional<TB, LoadKMajor<BN, VEC>, LoadMNMajor<BN, VEC>>::type;
     using E = Engine<BM, BN, LA, LB>;
-    static int attr = set_smem(gemm_kernel<BM, BN, TA, TB>, E::SMEM_BYTES);
+    static int attr = set_smem(gemm_kernel<BM, BN, TA, TB, VEC>, E::SMEM_BYTES);
     if (attr) return attr;
     dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, batch);
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, TA, TB>), grid, dim3(NT), E::SMEM_BYTES, s, p);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, TA, TB, VEC>), grid, dim3(NT), E::SMEM_BYTES, s, p);
     MTL_CHECK_LAUNCH();
     return MTL_OK;
+}
+
+inline bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+
+template <int BM, int BN, bool TA, bool TB>
+int launch_gemm(const GemmP& p, int batch, hipStream_t s) {
+    // 16-byte operand loads need 16-byte aligned bases/strides (true for every call of the pass except an
+    // odd-width logits matrix); everything else takes the dword-load instantiation
+    const bool vec = aligned16(p.A) && aligned16(p.B) && (p.lda & 3) == 0 && (p.ldb & 3) == 0 && ((p.sAb | p.sAh | p.sBb | p.sBh) & 3) == 0;
+    return vec ? launch_gemm_v<BM, BN, TA, TB, true>(p, batch, s) : launch_gemm_v<BM, BN, TA, TB, false>(p, batch, s);
 }
 
 template <bool TA, bool TB>
@@ -382,6 +411,11 @@ template <bool UNPOOL>
 struct LoadConvA {
     using Lds = LdsK<128>;
     static constexpr int NV = 4;
+    struct Regs {
+        float4 v[NV];
+        uchar4 a[NV];
+        unsigned m[NV];   // bit 0: source pixel valid; bits 1..2: position of the source pixel in its pool window
+    };
     const float* x;
     const uint8_t* am;
     int T, F, C, Tp, Fp, b, kq, cch;
@@ -405,42 +439,47 @@ struct LoadConvA {
             pf[i] = f0 + f;
         }
     }
-    __device__ __forceinline__ void fetch(int kt, float4 (&r)[NV], int) const {
+    __device__ __forceinline__ void fetch(int kt, Regs& r, int) const {
         const int tap = kt / cch;
         const int c = (kt - tap * cch) * BK + kq;
         const int kh = tap / 3, kw = tap - kh * 3;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int ts = pt[i] + kw - 1, fs = pf[i] + kh - 1;
-            float4 v = zero4();
-            if ((unsigned)ts < (unsigned)T && (unsigned)fs < (unsigned)F) {
-                if (!UNPOOL) {
-                    v = *reinterpret_cast<const float4*>(x + (((long)b * T + ts) * F + fs) * C + c);
-                } else {
-                    const int tp = ts >> 1, fp = fs >> 1;
-                    if (tp < Tp && fp < Fp) {
-                        const long o = (((long)b * Tp + tp) * Fp + fp) * C + c;
-                        const uchar4 a = *reinterpret_cast<const uchar4*>(am + o);
-                        const float4 d = *reinterpret_cast<const float4*>(x + o);
-                        const int sub = ((fs & 1) << 1) | (ts & 1);
-                        v.x = a.x == sub ? d.x : 0.f;
-                        v.y = a.y == sub ? d.y : 0.f;
-                        v.z = a.z == sub ? d.z : 0.f;
-                        v.w = a.w == sub ? d.w : 0.f;
-                    }
-                }
+            bool ok = (unsigned)ts < (unsigned)T && (unsigned)fs < (unsigned)F;
+            const int tc = min(max(ts, 0), T - 1), fc = min(max(fs, 0), F - 1);
+            if (!UNPOOL) {
+                r.v[i] = *reinterpret_cast<const float4*>(x + (((long)b * T + tc) * F + fc) * C + c);
+                r.m[i] = ok ? 1u : 0u;
+            } else {
+                const int tp = tc >> 1, fp = fc >> 1;
+                ok = ok && tp < Tp && fp < Fp;
+                const long o = (((long)b * Tp + min(tp, Tp - 1)) * Fp + min(fp, Fp - 1)) * C + c;
+                r.a[i] = *reinterpret_cast<const uchar4*>(am + o);
+                r.v[i] = *reinterpret_cast<const float4*>(x + o);
+                r.m[i] = (ok ? 1u : 0u) | ((unsigned)(((fs & 1) << 1) | (ts & 1)) << 1);
             }
-            r[i] = v;
         }
     }
-    __device__ __forceinline__ void commit(float* lds, const float4 (&r)[NV], int tid) const {
+    __device__ __forceinline__ void commit(float* lds, const Regs& r, int tid) const {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
+            float4 v = r.v[i];
+            const bool ok = r.m[i] & 1u;
+            if (!UNPOOL) {
+                v = mask4(v, ok ? 15u : 0u);
+            } else {
+                const unsigned sub = r.m[i] >> 1;
+                v.x = (ok && r.a[i].x == sub) ? v.x : 0.f;
+                v.y = (ok && r.a[i].y == sub) ? v.y : 0.f;
+                v.z = (ok && r.a[i].z == sub) ? v.z : 0.f;
+                v.w = (ok && r.a[i].w == sub) ? v.w : 0.f;
+            }
             const int o = Lds::at((tid >> 3) + i * 32, kq);
-            lds[o] = r[i].x;
-            lds[o + 1] = r[i].y;
-            lds[o + 2] = r[i].z;
-            lds[o + 3] = r[i].w;
+            lds[o] = v.x;
+            lds[o + 1] = v.y;
+            lds[o + 2] = v.z;
+            lds[o + 3] = v.w;
         }
     }
 };
@@ -523,7 +562,7 @@ enum { EPI_RELU = 0, EPI_POOL = 1, EPI_DGRAD = 2 };
 template <int BN, bool UNPOOL, int EPI>
 __global__ __launch_bounds__(NT) void conv3x3_kernel(ConvP p) {
     using LA = LoadConvA<UNPOOL>;
-    using LB = LoadMNMajor<BN>;
+    using LB = LoadMNMajor<BN, true>;
     using E = Engine<128, BN, LA, LB>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
@@ -550,7 +589,7 @@ __global__ __launch_bounds__(NT) void conv3x3_kernel(ConvP p) {
 
 template <int BN, bool UNPOOL, int EPI>
 int launch_conv(const ConvP& p, int Te, int Fe, hipStream_t s) {
-    using E = Engine<128, BN, LoadConvA<UNPOOL>, LoadMNMajor<BN>>;
+    using E = Engine<128, BN, LoadConvA<UNPOOL>, LoadMNMajor<BN, true>>;
     static int attr = set_smem(conv3x3_kernel<BN, UNPOOL, EPI>, E::SMEM_BYTES);
     if (attr) return attr;
     dim3 grid((Fe + 15) / 16, (Te + 7) / 8, p.g.B * p.ntile);
@@ -585,6 +624,10 @@ struct WgradGeom {
 struct LoadWgradX {  // A: rows = 64 input channels of one tap, MN-major
     using Lds = LdsMN<64>;
     static constexpr int NV = 2;
+    struct Regs {
+        float4 v[NV];
+        unsigned m[NV];
+    };
     const float* x;
     WgradGeom g;
     int dt, df, c0, m4, k0;
@@ -602,26 +645,27 @@ struct LoadWgradX {  // A: rows = 64 input channels of one tap, MN-major
         pbeg = pbeg_;
         pend = pend_;
     }
-    __device__ __forceinline__ void fetch(int kt, float4 (&r)[NV], int) const {
+    __device__ __forceinline__ void fetch(int kt, Regs& r, int) const {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const long pix = pbeg + (long)kt * BK + k0 + i * 16;
-            float4 v = zero4();
-            if (pix < pend) {
-                const int plane = g.Ty * g.Fy;
-                const int b = (int)(pix / plane);
-                const int rem = (int)(pix - (long)b * plane);
-                const int t = rem / g.Fy, f = rem - t * g.Fy;
-                const int ts = t + dt, fs = f + df;
-                if ((unsigned)ts < (unsigned)g.T && (unsigned)fs < (unsigned)g.F)
-                    v = *reinterpret_cast<const float4*>(x + (((long)b * g.T + ts) * g.F + fs) * g.Cin + c0 + m4);
-            }
-            r[i] = v;
+            long pix = pbeg + (long)kt * BK + k0 + i * 16;
+            bool ok = pix < pend;
+            pix = ok ? pix : pbeg;
+            const int plane = g.Ty * g.Fy;
+            const int b = (int)(pix / plane);
+            const int rem = (int)(pix - (long)b * plane);
+            const int t = rem / g.Fy, f = rem - t * g.Fy;
+            const int ts = t + dt, fs = f + df;
+            ok = ok && (unsigned)ts < (unsigned)g.T && (unsigned)fs < (unsigned)g.F;
+            const int tc = min(max(ts, 0), g.T - 1), fc = min(max(fs, 0), g.F - 1);
+            r.v[i] = *reinterpret_cast<const float4*>(x + (((long)b * g.T + tc) * g.F + fc) * g.Cin + c0 + m4);
+            r.m[i] = ok ? 15u : 0u;
         }
     }
-    __device__ __forceinline__ void commit(float* lds, const float4 (&r)[NV], int) const {
+    __device__ __forceinline__ void commit(float* lds, const Regs& r, int) const {
 #pragma unroll
-        for (int i = 0; i < NV; ++i) *reinterpret_cast<float4*>(&lds[(k0 + i * 16) * Lds::LD + m4]) = r[i];
+        for (int i = 0; i < NV; ++i)
+            *reinterpret_cast<float4*>(&lds[(k0 + i * 16) * Lds::LD + m4]) = mask4(r.v[i], r.m[i]);
     }
 };
 
@@ -629,6 +673,11 @@ template <int BN, bool UNPOOL>
 struct LoadWgradDy {  // B: rows = BN output channels, MN-major; dense dy or (dp, argmax)
     using Lds = LdsMN<BN>;
     static constexpr int VPR = BN / 4, KPP = NT / VPR, NV = BK / KPP;
+    struct Regs {
+        float4 v[NV];
+        uchar4 a[NV];
+        unsigned m[NV];
+    };
     const float* dy;
     const uint8_t* am;
     WgradGeom g;
@@ -644,35 +693,43 @@ struct LoadWgradDy {  // B: rows = BN output channels, MN-major; dense dy or (dp
         pbeg = pbeg_;
         pend = pend_;
     }
-    __device__ __forceinline__ void fetch(int kt, float4 (&r)[NV], int) const {
+    __device__ __forceinline__ void fetch(int kt, Regs& r, int) const {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const long pix = pbeg + (long)kt * BK + k0 + i * KPP;
-            float4 v = zero4();
-            if (pix < pend) {
-                if (!UNPOOL) {
-                    v = *reinterpret_cast<const float4*>(dy + pix * g.Cout + n0 + m4);  // Ty==T, Fy==F
-                } else {
-                    const int plane = g.Ty * g.Fy;
-                    const int b = (int)(pix / plane);
-                    const int rem = (int)(pix - (long)b * plane);
-                    const int t = rem / g.Fy, f = rem - t * g.Fy;
-                    const long o = (((long)b * g.Tp + (t >> 1)) * g.Fp + (f >> 1)) * g.Cout + n0 + m4;
-                    const uchar4 a = *reinterpret_cast<const uchar4*>(am + o);
-                    const float4 d = *reinterpret_cast<const float4*>(dy + o);
-                    const int sub = ((f & 1) << 1) | (t & 1);
-                    v.x = a.x == sub ? d.x : 0.f;
-                    v.y = a.y == sub ? d.y : 0.f;
-                    v.z = a.z == sub ? d.z : 0.f;
-                    v.w = a.w == sub ? d.w : 0.f;
-                }
+            long pix = pbeg + (long)kt * BK + k0 + i * KPP;
+            const bool ok = pix < pend;
+            pix = ok ? pix : pbeg;
+            if (!UNPOOL) {
+                r.v[i] = *reinterpret_cast<const float4*>(dy + pix * g.Cout + n0 + m4);  // Ty==T, Fy==F
+                r.m[i] = ok ? 1u : 0u;
+            } else {
+                const int plane = g.Ty * g.Fy;
+                const int b = (int)(pix / plane);
+                const int rem = (int)(pix - (long)b * plane);
+                const int t = rem / g.Fy, f = rem - t * g.Fy;
+                const long o = (((long)b * g.Tp + (t >> 1)) * g.Fp + (f >> 1)) * g.Cout + n0 + m4;
+                r.a[i] = *reinterpret_cast<const uchar4*>(am + o);
+                r.v[i] = *reinterpret_cast<const float4*>(dy + o);
+                r.m[i] = (ok ? 1u : 0u) | ((unsigned)(((f & 1) << 1) | (t & 1)) << 1);
             }
-            r[i] = v;
         }
     }
-    __device__ __forceinline__ void commit(float* lds, const float4 (&r)[NV], int) const {
+    __device__ __forceinline__ void commit(float* lds, const Regs& r, int) const {
 #pragma unroll
-        for (int i = 0; i < NV; ++i) *reinterpret_cast<float4*>(&lds[(k0 + i * KPP) * Lds::LD + m4]) = r[i];
+        for (int i = 0; i < NV; ++i) {
+            float4 v = r.v[i];
+            const bool ok = r.m[i] & 1u;
+            if (!UNPOOL) {
+                v = mask4(v, ok ? 15u : 0u);
+            } else {
+                const unsigned sub = r.m[i] >> 1;
+                v.x = (ok && r.a[i].x == sub) ? v.x : 0.f;
+                v.y = (ok && r.a[i].y == sub) ? v.y : 0.f;
+                v.z = (ok && r.a[i].z == sub) ? v.z : 0.f;
+                v.w = (ok && r.a[i].w == sub) ? v.w : 0.f;
+            }
+            *reinterpret_cast<float4*>(&lds[(k0 + i * KPP) * Lds::LD + m4]) = v;
+        }
     }
 };
 
