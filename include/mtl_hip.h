@@ -94,7 +94,10 @@ int mtl_softmax_bwd(void* stream, const float* P, float* dP /*in place -> dS*/, 
 
 /* ---- embedding + positional encoding: modules/decoder.py:96 ------------------------------------------- */
 int mtl_embed_pe_fwd(void* stream, const long* ids, const float* table, const float* pe, float* out, int rows, int T, int d);
-int mtl_embed_bwd(void* stream, const long* ids, const float* dout, float* dtable /*accum*/, int rows, int d, long pad_id);
+/* rank[r] = number of rows r' < r with ids[r'] == ids[r] (host-computed), n_pass = 1 + max rank: duplicates are added in
+ * row order, pass by pass, so the scatter-add is parallel AND deterministic. */
+int mtl_embed_bwd(void* stream, const long* ids, const int* rank, int n_pass, const float* dout, float* dtable /*accum*/,
+                  int rows, int d, long pad_id);
 
 /* ---- cross-entropy + arg-max: utils/metrics.py:113-126, models/asr/transformer.py:146-147 ----------------
  * loss_out[0] = sum_rows(gold!=pad ? -log softmax(logits)[gold] : 0) / n_nonpad ; hyp = lowest arg-max index. */

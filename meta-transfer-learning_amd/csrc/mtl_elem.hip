@@ -249,14 +249,15 @@ __global__ void embed_pe_fwd_kernel(const long* __restrict__ ids, const float* _
         out[e] = table[ids[r] * d + c] + pe[(long)(r % T) * d + c];
     }
 }
-// one thread per embedding column, rows walked in order -> deterministic scatter-add (duplicates included)
-__global__ void embed_bwd_kernel(const long* __restrict__ ids, const float* __restrict__ dout, float* __restrict__ dtable,
-                                 int rows, int d, long pad_id) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= d) return;
-    for (int r = 0; r < rows; ++r) {
+// Scatter-add with duplicate ids, deterministic and parallel: `rank[r]` (host-computed) is the number of earlier rows
+// with the same id; pass j adds the rows of rank j (all distinct ids -> conflict-free), passes run in order.
+__global__ void embed_bwd_kernel(const long* __restrict__ ids, const int* __restrict__ rank, const float* __restrict__ dout,
+                                 float* __restrict__ dtable, int rows, int d, long pad_id, int pass) {
+    const long total = (long)rows * d;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(e / d), c = (int)(e - (long)r * d);
         const long id = ids[r];
-        if (id != pad_id) dtable[id * d + c] += dout[(long)r * d + c];
+        if (id != pad_id && rank[r] == pass) dtable[id * d + c] += dout[e];
     }
 }
 
@@ -453,16 +454,22 @@ __global__ __launch_bounds__(256) void conv0_wgrad_kernel(const float* __restric
         part[(long)blockIdx.x * 640 + e] = s;
     }
 }
-__global__ void conv0_wgrad_final_kernel(const float* __restrict__ part, int nblk, float* __restrict__ dw, float* __restrict__ db) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+// one wave per output element: lanes stride the per-block partials, fixed-order shuffle tree
+__global__ __launch_bounds__(256) void conv0_wgrad_final_kernel(const float* __restrict__ part, int nblk, float* __restrict__ dw,
+                                                                float* __restrict__ db) {
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     if (e >= 640) return;
     float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += part[(long)b * 640 + e];
-    const int c = e / 10, k = e % 10;
-    if (k < 9)
-        dw[c * 9 + k] += s;
-    else
-        db[c] += s;
+    for (int b = lane; b < nblk; b += 64) s += part[(long)b * 640 + e];
+    s = wave_sum(s);
+    if (lane == 0) {
+        const int c = e / 10, k = e % 10;
+        if (k < 9)
+            dw[c * 9 + k] += s;
+        else
+            db[c] += s;
+    }
 }
 
 // ------------------------------------------------------------------ input_linear weight permutation
@@ -607,9 +614,12 @@ int mtl_embed_pe_fwd(void* stream, const long* ids, const float* table, const fl
     return MTL_OK;
 }
 
-int mtl_embed_bwd(void* stream, const long* ids, const float* dout, float* dtable, int rows, int d, long pad_id) {
-    if (!ids || !dout || !dtable || rows <= 0) return MTL_EINVAL;
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3((d + 63) / 64), dim3(64), 0, as_stream(stream), ids, dout, dtable, rows, d, pad_id);
+int mtl_embed_bwd(void* stream, const long* ids, const int* rank, int n_pass, const float* dout, float* dtable, int rows, int d,
+                  long pad_id) {
+    if (!ids || !rank || !dout || !dtable || rows <= 0 || n_pass < 1) return MTL_EINVAL;
+    for (int j = 0; j < n_pass; ++j)
+        hipLaunchKernelGGL(embed_bwd_kernel, dim3(grid_for((long)rows * d, 256, 2048)), dim3(256), 0, as_stream(stream), ids, rank,
+                           dout, dtable, rows, d, pad_id, j);
     MTL_CHECK_LAUNCH();
     return MTL_OK;
 }
@@ -672,7 +682,7 @@ int mtl_conv0_wgrad(void* stream, const float* x, const float* dy, float* dw, fl
     const int nb = grid_for((long)B * T * F, 16 * 64, 1024);
     hipStream_t s = as_stream(stream);
     hipLaunchKernelGGL(conv0_wgrad_kernel, dim3(nb), dim3(256), 0, s, x, dy, workspace, B, T, F);
-    hipLaunchKernelGGL(conv0_wgrad_final_kernel, dim3(3), dim3(256), 0, s, workspace, nb, dw, db);
+    hipLaunchKernelGGL(conv0_wgrad_final_kernel, dim3(160), dim3(256), 0, s, workspace, nb, dw, db);
     MTL_CHECK_LAUNCH();
     return MTL_OK;
 }

@@ -294,11 +294,21 @@ class PassEngine:
         if not bool((is_pad == (torch.arange(Td).unsqueeze(0) >= dec_len.unsqueeze(1))).all()):
             raise ValueError('EOS inside a target sequence is not supported')
         pos = torch.arange(T4).unsqueeze(0)
+        flat_in = seq_in.reshape(-1)
+        order = torch.argsort(flat_in, stable=True)                           # occurrence rank of every decoder input id
+        srt = flat_in[order]
+        start = torch.ones_like(srt, dtype=torch.bool)
+        start[1:] = srt[1:] != srt[:-1]
+        idx = torch.arange(srt.numel())
+        first = torch.cummax(torch.where(start, idx, torch.zeros_like(idx)), 0)[0]
+        rank = torch.empty_like(idx)
+        rank[order] = idx - first
         meta_i32 = torch.cat([
             torch.clamp(lens, max=T4).to(torch.int32),                        # klen_enc (B)      (raw lengths)
             dec_len.to(torch.int32),                                           # klen_dec (B)
             (pos < lens.unsqueeze(1)).to(torch.int32).reshape(-1),             # keep_enc (B*T4)
-            (~is_pad).to(torch.int32).reshape(-1)])                            # keep_dec (B*Td)
+            (~is_pad).to(torch.int32).reshape(-1),                             # keep_dec (B*Td)
+            rank.to(torch.int32)])                                             # embed_rank (B*Td)
         dev_i32 = self.buf('meta_i32', (meta_i32.numel(),), torch.int32)
         dev_i32.copy_(meta_i32, non_blocking=True)
         ids = self.buf('ids', (2, B, Td), torch.int64)
@@ -307,6 +317,7 @@ class PassEngine:
         klen_dec = klen_enc + 4 * B
         keep_enc = klen_dec + 4 * B
         keep_dec = keep_enc + 4 * B * T4
+        embed_rank = keep_dec + 4 * B * Td
         n_nonpad = int((seq_out != PAD_ID).sum())
         Me, Md = B * T4, B * Td
 
@@ -373,6 +384,7 @@ class PassEngine:
                                     hyp.data_ptr(), rowloss.data_ptr(), loss.data_ptr()), 'ce_fwd')
         self.saved = dict(theta=theta, x=x, B=B, T=T, F=F, Td=Td, n_nonpad=n_nonpad, smoothing=float(smoothing),
                           klen_enc=klen_enc, klen_dec=klen_dec, keep_enc=keep_enc, keep_dec=keep_dec, dec_last=cur,
+                          embed_rank=embed_rank, embed_passes=int(rank.max()) + 1,
                           enc_inputs=enc_inputs)
         return dict(pred=pred, gold=ids[1], hyp=hyp, loss=loss, gold_host=seq_out, n_nonpad=n_nonpad)
 
@@ -428,8 +440,8 @@ class PassEngine:
             self.mha_bwd('d%d.sa.' % i, P, G, pre + 'self_attn.', dcur.data_ptr(), x_in.data_ptr(), B, Td, x_in.data_ptr(), Td,
                          keep_dec, dnext.data_ptr(), dnext.data_ptr(), True)
             dcur, dnext = dnext, dcur
-        check(lib.mtl_embed_bwd(st, A['ids'].data_ptr(), dcur.data_ptr(), g('decoder.trg_embedding.weight'), Md, d, PAD_ID),
-              'embed_bwd')
+        check(lib.mtl_embed_bwd(st, A['ids'].data_ptr(), S['embed_rank'], S['embed_passes'], dcur.data_ptr(),
+                                g('decoder.trg_embedding.weight'), Md, d, PAD_ID), 'embed_bwd')
 
         # ---- encoder ----
         eA = self.buf('_deA', (Me, d))

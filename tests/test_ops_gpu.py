@@ -249,7 +249,13 @@ def test_embed_and_ce(L):
     dout = torch.randn(B * T, d, generator=g)
     tg = torch.zeros(V, d).cuda()
     ddo = dev(dout)
-    assert L.mtl_embed_bwd(st(), dids.data_ptr(), ddo.data_ptr(), tg.data_ptr(), B * T, d, 0) == 0
+    flat = ids.view(-1).tolist()
+    seen, rk = {}, []
+    for v in flat:
+        rk.append(seen.get(v, 0))
+        seen[v] = seen.get(v, 0) + 1
+    drk = torch.tensor(rk, dtype=torch.int32).cuda()
+    assert L.mtl_embed_bwd(st(), dids.data_ptr(), drk.data_ptr(), max(rk) + 1, ddo.data_ptr(), tg.data_ptr(), B * T, d, 0) == 0
     ref = torch.zeros(V, d).index_add_(0, ids.view(-1), dout)
     assert rel(tg, ref) < 1e-6
     # cross entropy + arg-max (ties -> lowest index; padded rows are all-zero logits)
