@@ -163,7 +163,7 @@ struct Engine {
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     }
 
-    static __device__ __forceinline__ void run(const LA& la, const LB& lb, int nk, float* smem,
+    static __device__ __forceinline__ void run(LA& la, LB& lb, int nk, float* smem,
                                                f32x16 (&acc)[TM][TN]) {
         const int tid = threadIdx.x;
         const int lane = tid & 63, wave = tid >> 6;
@@ -621,51 +621,77 @@ struct WgradGeom {
     long per_split; // pixels per split (multiple of BK)
 };
 
-struct LoadWgradX {  // A: rows = 64 input channels of one tap, MN-major
-    using Lds = LdsMN<64>;
-    static constexpr int NV = 2;
+// pixel cursor: (b, t, f) of a flattened pixel index over the Ty x Fy extent, advanced by BK per K-tile without divisions
+struct PixCursor {
+    int b, t, f;
+    __device__ __forceinline__ void set(long pix, int Ty, int Fy) {
+        const int plane = Ty * Fy;
+        b = (int)(pix / plane);
+        const int rem = (int)(pix - (long)b * plane);
+        t = rem / Fy;
+        f = rem - t * Fy;
+    }
+    __device__ __forceinline__ void advance(int n, int Ty, int Fy) {
+        f += n;
+        while (f >= Fy) {   // at most one iteration for the real layer shapes (Fy >= 80 > BK)
+            f -= Fy;
+            if (++t >= Ty) {
+                t = 0;
+                ++b;
+            }
+        }
+    }
+};
+
+template <int ROWS>
+struct LoadWgradX {  // A: rows = ROWS consecutive (tap, cin) indices, MN-major; a thread's 4 channels never straddle a tap
+    using Lds = LdsMN<ROWS>;
+    static constexpr int VPR = ROWS / 4, KPP = NT / VPR, NV = BK / KPP;
     struct Regs {
         float4 v[NV];
         unsigned m[NV];
     };
     const float* x;
     WgradGeom g;
-    int dt, df, c0, m4, k0;
+    int dt, df, cofs, m4, k0;
+    bool row_ok;
     long pbeg, pend;
+    PixCursor cur[NV];
     __device__ void init(const float* x_, const WgradGeom& g_, int m0, long pbeg_, long pend_, int tid) {
         x = x_;
         g = g_;
-        const int tap = m0 / g.Cin;
-        c0 = m0 - tap * g.Cin;
+        m4 = (tid % VPR) * 4;
+        k0 = tid / VPR;
+        const int m = m0 + m4;
+        row_ok = m < 9 * g.Cin;
+        const int tap = row_ok ? m / g.Cin : 0;
+        cofs = row_ok ? m - tap * g.Cin : 0;
         const int kh = tap / 3, kw = tap - kh * 3;
         dt = kw - 1;
         df = kh - 1;
-        m4 = (tid & 15) * 4;
-        k0 = tid >> 4;
         pbeg = pbeg_;
         pend = pend_;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) cur[i].set(min(pbeg + k0 + i * KPP, g.npix - 1), g.Ty, g.Fy);
     }
-    __device__ __forceinline__ void fetch(int kt, Regs& r, int) const {
+    __device__ __forceinline__ void fetch(int kt, Regs& r, int) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            long pix = pbeg + (long)kt * BK + k0 + i * 16;
-            bool ok = pix < pend;
-            pix = ok ? pix : pbeg;
-            const int plane = g.Ty * g.Fy;
-            const int b = (int)(pix / plane);
-            const int rem = (int)(pix - (long)b * plane);
-            const int t = rem / g.Fy, f = rem - t * g.Fy;
-            const int ts = t + dt, fs = f + df;
+            const long pix = pbeg + (long)kt * BK + k0 + i * KPP;
+            bool ok = row_ok && pix < pend;
+            const int ts = cur[i].t + dt, fs = cur[i].f + df;
             ok = ok && (unsigned)ts < (unsigned)g.T && (unsigned)fs < (unsigned)g.F;
             const int tc = min(max(ts, 0), g.T - 1), fc = min(max(fs, 0), g.F - 1);
-            r.v[i] = *reinterpret_cast<const float4*>(x + (((long)b * g.T + tc) * g.F + fc) * g.Cin + c0 + m4);
+            const int bc = min(cur[i].b, g.B - 1);
+            r.v[i] = *reinterpret_cast<const float4*>(x + (((long)bc * g.T + tc) * g.F + fc) * g.Cin + cofs);
             r.m[i] = ok ? 15u : 0u;
+            cur[i].advance(BK, g.Ty, g.Fy);
         }
     }
     __device__ __forceinline__ void commit(float* lds, const Regs& r, int) const {
 #pragma unroll
         for (int i = 0; i < NV; ++i)
-            *reinterpret_cast<float4*>(&lds[(k0 + i * 16) * Lds::LD + m4]) = mask4(r.v[i], r.m[i]);
+            *reinterpret_cast<float4*>(&lds[(k0 + i * KPP) * Lds::LD + m4]) = mask4(r.v[i], r.m[i]);
     }
 };
 
@@ -683,6 +709,7 @@ struct LoadWgradDy {  // B: rows = BN output channels, MN-major; dense dy or (dp
     WgradGeom g;
     int n0, m4, k0;
     long pbeg, pend;
+    PixCursor cur[NV];
     __device__ void init(const float* dy_, const uint8_t* am_, const WgradGeom& g_, int n0_, long pbeg_, long pend_, int tid) {
         dy = dy_;
         am = am_;
@@ -692,25 +719,26 @@ struct LoadWgradDy {  // B: rows = BN output channels, MN-major; dense dy or (dp
         k0 = tid / VPR;
         pbeg = pbeg_;
         pend = pend_;
+        if (UNPOOL) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) cur[i].set(min(pbeg + k0 + i * KPP, g.npix - 1), g.Ty, g.Fy);
+        }
     }
-    __device__ __forceinline__ void fetch(int kt, Regs& r, int) const {
+    __device__ __forceinline__ void fetch(int kt, Regs& r, int) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            long pix = pbeg + (long)kt * BK + k0 + i * KPP;
+            const long pix = pbeg + (long)kt * BK + k0 + i * KPP;
             const bool ok = pix < pend;
-            pix = ok ? pix : pbeg;
             if (!UNPOOL) {
-                r.v[i] = *reinterpret_cast<const float4*>(dy + pix * g.Cout + n0 + m4);  // Ty==T, Fy==F
+                r.v[i] = *reinterpret_cast<const float4*>(dy + (ok ? pix : pbeg) * g.Cout + n0 + m4);  // Ty==T, Fy==F
                 r.m[i] = ok ? 1u : 0u;
             } else {
-                const int plane = g.Ty * g.Fy;
-                const int b = (int)(pix / plane);
-                const int rem = (int)(pix - (long)b * plane);
-                const int t = rem / g.Fy, f = rem - t * g.Fy;
-                const long o = (((long)b * g.Tp + (t >> 1)) * g.Fp + (f >> 1)) * g.Cout + n0 + m4;
+                const int t = cur[i].t, f = cur[i].f, bc = min(cur[i].b, g.B - 1);
+                const long o = (((long)bc * g.Tp + (t >> 1)) * g.Fp + (f >> 1)) * g.Cout + n0 + m4;
                 r.a[i] = *reinterpret_cast<const uchar4*>(am + o);
                 r.v[i] = *reinterpret_cast<const float4*>(dy + o);
                 r.m[i] = (ok ? 1u : 0u) | ((unsigned)(((f & 1) << 1) | (t & 1)) << 1);
+                cur[i].advance(BK, g.Ty, g.Fy);
             }
         }
     }
@@ -735,10 +763,11 @@ struct LoadWgradDy {  // B: rows = BN output channels, MN-major; dense dy or (dp
 
 struct EpiPartial {
     float* out;  // [9*Cin][Cout] slab of this split
-    int m0, n0, Cout;
+    int m0, n0, Cout, M;
     __device__ __forceinline__ void store4(int lr, int lc, const float (&v)[4]) const {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) out[(long)(m0 + lr + j) * Cout + n0 + lc] = v[j];
+        for (int j = 0; j < 4; ++j)
+            if (m0 + lr + j < M) out[(long)(m0 + lr + j) * Cout + n0 + lc] = v[j];
     }
 };
 
@@ -752,12 +781,12 @@ struct WgradP {
 
 template <int BN, bool UNPOOL>
 __global__ __launch_bounds__(NT) void conv3x3_wgrad_kernel(WgradP p) {
-    using LA = LoadWgradX;
+    using LA = LoadWgradX<128>;
     using LB = LoadWgradDy<BN, UNPOOL>;
-    using E = Engine<64, BN, LA, LB>;
+    using E = Engine<128, BN, LA, LB>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
-    const int m0 = blockIdx.x * 64, n0 = blockIdx.y * BN;
+    const int m0 = blockIdx.x * 128, n0 = blockIdx.y * BN;
     const long pbeg = (long)blockIdx.z * p.g.per_split;
     long pend = pbeg + p.g.per_split;
     if (pend > p.g.npix) pend = p.g.npix;
@@ -769,7 +798,7 @@ __global__ __launch_bounds__(NT) void conv3x3_wgrad_kernel(WgradP p) {
     E::zero(acc);
     const int nk = pend > pbeg ? (int)((pend - pbeg + BK - 1) / BK) : 0;
     if (nk > 0) E::run(la, lb, nk, smem, acc);
-    EpiPartial e{p.partial + (long)blockIdx.z * 9 * p.g.Cin * p.g.Cout, m0, n0, p.g.Cout};
+    EpiPartial e{p.partial + (long)blockIdx.z * 9 * p.g.Cin * p.g.Cout, m0, n0, p.g.Cout, 9 * p.g.Cin};
     E::finish(acc, e);
 }
 
@@ -788,10 +817,10 @@ __global__ void wgrad_reduce_kernel(const float* partial, float* dw, int nsplit,
 
 template <int BN, bool UNPOOL>
 int launch_wgrad(const WgradP& p, int nsplit, hipStream_t s) {
-    using E = Engine<64, BN, LoadWgradX, LoadWgradDy<BN, UNPOOL>>;
+    using E = Engine<128, BN, LoadWgradX<128>, LoadWgradDy<BN, UNPOOL>>;
     static int attr = set_smem(conv3x3_wgrad_kernel<BN, UNPOOL>, E::SMEM_BYTES);
     if (attr) return attr;
-    dim3 grid(9 * p.g.Cin / 64, p.g.Cout / BN, nsplit);
+    dim3 grid((9 * p.g.Cin + 127) / 128, p.g.Cout / BN, nsplit);
     hipLaunchKernelGGL((conv3x3_wgrad_kernel<BN, UNPOOL>), grid, dim3(NT), E::SMEM_BYTES, s, p);
     MTL_CHECK_LAUNCH();
     return MTL_OK;
@@ -862,7 +891,7 @@ int mtl_conv3x3_dgrad(void* stream, const float* dy, const unsigned char* argmax
 long mtl_conv3x3_wgrad_workspace(int B, int T, int F, int Cin, int Cout, int pooled) {
     const int Ty = pooled ? 2 * (T / 2) : T, Fy = pooled ? 2 * (F / 2) : F;
     const long npix = (long)B * Ty * Fy;
-    const int tiles = (9 * Cin / 64) * (Cout / (Cout % 128 == 0 ? 128 : 64));
+    const int tiles = ((9 * Cin + 127) / 128) * (Cout / (Cout % 128 == 0 ? 128 : 64));
     long nsplit = (1024 + tiles - 1) / tiles;
     const long maxsplit = (npix + 1023) / 1024;
     if (nsplit > maxsplit) nsplit = maxsplit;
