@@ -119,6 +119,7 @@ int mtl_colsum_accum(void* stream, const float* X, long rows, int cols, long ld,
  * Adam       transient_trainer.py:109,255 (torch defaults) */
 int mtl_sgd_theta_prime(void* stream, const float* theta0, const float* g, float alpha, float* theta1, long n);
 int mtl_axpy(void* stream, float* y, const float* x, float a, long n);
+int mtl_copy_f32(void* stream, float* dst, const float* src, long n); /* device-to-device, asynchronous on `stream` */
 int mtl_scale(void* stream, float* y, float a, const float* a_dev /*nullable: overrides a*/, long n);
 int mtl_adam_step(void* stream, float* theta, const float* G, float* m, float* v, int step, float lr, float beta1,
                   float beta2, float eps, long n);

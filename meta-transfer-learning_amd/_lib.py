@@ -40,6 +40,7 @@ SIGNATURES = {
     'mtl_colsum_accum': (I, [P, P, L, I, L, P, P]),
     'mtl_sgd_theta_prime': (I, [P, P, P, F, P, L]),
     'mtl_axpy': (I, [P, P, P, F, L]),
+    'mtl_copy_f32': (I, [P, P, P, L]),
     'mtl_scale': (I, [P, P, F, P, L]),
     'mtl_adam_step': (I, [P, P, P, P, P, I, F, F, F, F, L]),
     'mtl_sumsq': (I, [P, P, L, P, P, I, F]),

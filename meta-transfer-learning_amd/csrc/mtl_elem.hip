@@ -513,6 +513,11 @@ int mtl_axpy(void* stream, float* y, const float* x, float a, long n) {
     return MTL_OK;
 }
 
+int mtl_copy_f32(void* stream, float* dst, const float* src, long n) {
+    if (!dst || !src || n <= 0) return MTL_EINVAL;
+    return hipMemcpyAsync(dst, src, (size_t)n * 4, hipMemcpyDeviceToDevice, as_stream(stream)) == hipSuccess ? MTL_OK : MTL_ELAUNCH;
+}
+
 int mtl_scale(void* stream, float* y, float a, const float* a_dev, long n) {
     if (!y || n <= 0) return MTL_EINVAL;
     hipLaunchKernelGGL(scale_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, as_stream(stream), y, a, a_dev, n);

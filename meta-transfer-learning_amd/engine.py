@@ -80,6 +80,14 @@ class PassEngine:
         self.pool = {}      # (name, shape, dtype) -> allocation, so alternating batch shapes do not re-allocate
         self.saved = None
         self.gemm_ws = torch.empty(8 << 20, dtype=torch.float32, device=device) if device.type == 'cuda' else None  # split-K slabs
+        # weight/bias-gradient kernels are off the critical path (nothing downstream in the backward reads them): they run
+        # on a second HIP stream with their own workspaces, forked once per block and joined at the end of the backward
+        self.side = torch.cuda.Stream(device) if device.type == 'cuda' else None
+        self.gemm_ws_side = torch.empty(8 << 20, dtype=torch.float32, device=device) if device.type == 'cuda' else None
+        self.scratch_side = torch.empty(4 << 20, dtype=torch.float32, device=device) if device.type == 'cuda' else None
+        self.on_side = False
+        self.deferred = []
+        self.use_side_stream = True
         self.prof = None    # optional {name: [flops, [(start_event, end_event), ...]]}: HIP events around the conv launches
         if device.type != 'cuda':
             raise RuntimeError('PassEngine needs an MI355X device (got %s); there is no CPU product path' % device)
@@ -95,6 +103,10 @@ class PassEngine:
         return t
 
     def scratch(self, nbytes):
+        if self.on_side:
+            if nbytes > self.scratch_side.numel() * 4:
+                raise RuntimeError('side-stream scratch too small for %d bytes' % nbytes)
+            return self.scratch_side.data_ptr()
         t = self.arena.get('_scratch')
         if t is None or t.numel() * 4 < nbytes:
             t = torch.empty((int(nbytes) + 3) // 4 + 1024, dtype=torch.float32, device=self.device)
@@ -118,9 +130,42 @@ class PassEngine:
 
     def gemm(self, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias=None, gate=None, ldg=0, flags=0, alpha=1.0,
              batch=1, H=1, sA=(0, 0), sB=(0, 0), sC=(0, 0)):
-        ws, wsb = (self.gemm_ws.data_ptr(), self.gemm_ws.numel() * 4) if batch == 1 else (None, 0)
+        wst = self.gemm_ws_side if self.on_side else self.gemm_ws
+        ws, wsb = (wst.data_ptr(), wst.numel() * 4) if batch == 1 else (None, 0)
         check(self.lib.mtl_gemm_f32(self.stream, ta, tb, M, N, K, alpha, A, lda, B, ldb, C, ldc, bias, gate, ldg, flags,
                                     batch, H, sA[0], sA[1], sB[0], sB[1], sC[0], sC[1], ws, wsb), 'mtl_gemm_f32')
+
+    # ---- side stream: deferred parameter-gradient work
+    def defer(self, fn):
+        if self.use_side_stream:
+            self.deferred.append(fn)
+        else:
+            fn()
+
+    def flush_side(self):
+        """Everything enqueued on the main stream so far is visible to the deferred jobs, which are now issued on the side
+        stream.  Their inputs are per-block buffers that the main stream never rewrites within this backward."""
+        if not self.deferred:
+            return
+        main = torch.cuda.current_stream(self.device)
+        ev = torch.cuda.Event()
+        ev.record(main)
+        self.side.wait_event(ev)
+        jobs, self.deferred = self.deferred, []
+        with torch.cuda.stream(self.side):
+            self.on_side = True
+            try:
+                for fn in jobs:
+                    fn()
+            finally:
+                self.on_side = False
+
+    def join_side(self):
+        self.flush_side()
+        if self.use_side_stream:
+            ev = torch.cuda.Event()
+            ev.record(self.side)
+            torch.cuda.current_stream(self.device).wait_event(ev)
 
     def linear_fwd(self, x, rows, k_in, w, b, y, n_out, relu=False):
         self.gemm(0, 1, rows, n_out, k_in, x, k_in, w, k_in, y, n_out, bias=b, flags=RELU if relu else 0)
@@ -128,9 +173,11 @@ class PassEngine:
     def linear_bwd(self, x, dy, rows, k_in, n_out, w, dw, db, dx, dx_accum, gate=None):
         """dw += dy^T x ; db += colsum(dy) (db None: no bias, or already produced by the LayerNorm backward) ;
         dx (=|+=) dy.W  (gate: ReLU mask source for dx)"""
-        self.gemm(1, 0, n_out, k_in, rows, dy, n_out, x, k_in, dw, k_in, flags=ACCUM)
-        if db is not None:
-            self.colsum(dy, rows, n_out, db)
+        def param_grads():
+            self.gemm(1, 0, n_out, k_in, rows, dy, n_out, x, k_in, dw, k_in, flags=ACCUM)
+            if db is not None:
+                self.colsum(dy, rows, n_out, db)
+        self.defer(param_grads)
         if dx is not None:
             self.gemm(0, 0, rows, k_in, n_out, dy, n_out, w, k_in, dx, k_in, gate=gate, ldg=k_in,
                       flags=ACCUM if dx_accum else 0)
@@ -195,19 +242,21 @@ class PassEngine:
         ldS = (Tk + 3) // 4 * 4
         Pm, O, oa = A[tag + 'P'], A[tag + 'O'], A[tag + 'oa']
         # LayerNorm(o + residual) * keep
-        self.ln_bwd(dy, A[tag + 'xhat'].data_ptr(), A[tag + 'rstd'].data_ptr(), o('layer_norm.weight'), keep, dxq,
+        dzb = self.buf(tag + '_dz', (Mq, d))       # kept intact for the deferred dW GEMM; dxq = dz + projections
+        self.ln_bwd(dy, A[tag + 'xhat'].data_ptr(), A[tag + 'rstd'].data_ptr(), o('layer_norm.weight'), keep, dzb.data_ptr(),
                     g('layer_norm.weight'), g('layer_norm.bias'), Mq, dsum=g('output_linear_b.bias'))
-        dz = dxq  # residual path: dxq starts as dz, projections accumulate on top
-        doa = self.buf('_doa', (Mq, r))
+        dz = dzb.data_ptr()
+        check(self.lib.mtl_copy_f32(self.stream, dxq, dz, Mq * d), 'mtl_copy_f32')   # residual path
+        doa = self.buf(tag + '_doa', (Mq, r))
         self.linear_bwd(oa.data_ptr(), dz, Mq, r, d, o('output_linear_b.weight'), g('output_linear_b.weight'),
                         None, doa.data_ptr(), False)
-        dO = self.buf('_dO', (Mq, hv))
+        dO = self.buf(tag + '_dO', (Mq, hv))
         self.linear_bwd(O.data_ptr(), doa.data_ptr(), Mq, hv, r, o('output_linear_a.weight'), g('output_linear_a.weight'),
                         None, dO.data_ptr(), False)
         q, k, v = A[tag + 'q'], A[tag + 'k'], A[tag + 'v']
-        dq = self.buf('_dq', (Mq, hk))
-        dkk = self.buf('_dk', (Mk, hk))
-        dvv = self.buf('_dv', (Mk, hv))
+        dq = self.buf(tag + '_dq', (Mq, hk))
+        dkk = self.buf(tag + '_dk', (Mk, hk))
+        dvv = self.buf(tag + '_dv', (Mk, hv))
         dP = self.buf('_dP', (Bn, h, Tq, ldS))
         sP = (h * Tq * ldS, Tq * ldS)
         # dV = P^T dO ; dP = dO V^T ; dS = softmax'(P, dP)/temp ; dQ = dS K ; dK = dS^T Q
@@ -221,11 +270,11 @@ class PassEngine:
                   sA=sP, sB=(Tk * hk, dk), sC=(Tq * hk, dk))
         self.gemm(1, 0, Tk, dk, Tq, dP.data_ptr(), ldS, q.data_ptr(), hk, dkk.data_ptr(), hk, batch=Bn * h, H=h,
                   sA=sP, sB=(Tq * hk, dk), sC=(Tk * hk, dk))
-        da = self.buf('_da', (max(Mq, Mk), r))
         first_kv = True
         for nm, full, dfull, src, rows, width, dst in (('q', 'query', dq, xq, Mq, hk, dxq), ('k', 'key', dkk, xkv, Mk, hk, dxkv),
                                                        ('v', 'value', dvv, xkv, Mk, hv, dxkv)):
             a = A[tag + nm + 'a']
+            da = self.buf(tag + '_da' + nm, (rows, r))
             self.linear_bwd(a.data_ptr(), dfull.data_ptr(), rows, r, width, o(full + '_linear_b.weight'),
                             g(full + '_linear_b.weight'), g(full + '_linear_b.bias'), da.data_ptr(), False)
             if nm == 'q':
@@ -235,6 +284,7 @@ class PassEngine:
                 first_kv = False
             self.linear_bwd(src, da.data_ptr(), rows, d, r, o(full + '_linear_a.weight'), g(full + '_linear_a.weight'), None,
                             dst, accum)
+        self.flush_side()
 
     def ffn_fwd(self, tag, P, pre, x, rows, T, keep):
         hp, L = self.hp, self.L
@@ -254,14 +304,17 @@ class PassEngine:
         hp, L, A = self.hp, self.L, self.arena
         o = lambda n: P + 4 * L.off(pre + n)
         g = lambda n: G + 4 * L.off(pre + n)
-        self.ln_bwd(dy, A[tag + 'xhat'].data_ptr(), A[tag + 'rstd'].data_ptr(), o('layer_norm.weight'), keep, dx,
+        dzb = self.buf(tag + '_dz', (rows, hp.d))
+        self.ln_bwd(dy, A[tag + 'xhat'].data_ptr(), A[tag + 'rstd'].data_ptr(), o('layer_norm.weight'), keep, dzb.data_ptr(),
                     g('layer_norm.weight'), g('layer_norm.bias'), rows, dsum=g('linear_2.bias'))
+        check(self.lib.mtl_copy_f32(self.stream, dx, dzb.data_ptr(), rows * hp.d), 'mtl_copy_f32')   # residual path
         h1 = A[tag + 'h1']
-        dh1 = self.buf('_dh1', (rows, hp.inner))
-        self.linear_bwd(h1.data_ptr(), dx, rows, hp.inner, hp.d, o('linear_2.weight'), g('linear_2.weight'),
+        dh1 = self.buf(tag + '_dh1', (rows, hp.inner))
+        self.linear_bwd(h1.data_ptr(), dzb.data_ptr(), rows, hp.inner, hp.d, o('linear_2.weight'), g('linear_2.weight'),
                         None, dh1.data_ptr(), False, gate=h1.data_ptr())
         self.linear_bwd(x, dh1.data_ptr(), rows, hp.d, hp.inner, o('linear_1.weight'), g('linear_1.weight'),
                         g('linear_1.bias'), dx, True)
+        self.flush_side()
 
     # ---------------------------------------------------------------- the pass
     def forward(self, theta, x, lengths, target, smoothing=0.0):
@@ -424,8 +477,10 @@ class PassEngine:
         dmem = self.buf('_dmem', (Me, d))
         last = S['dec_last']
         # vocab projection (no bias)
-        self.gemm(1, 0, V, d, Md, dlog_ptr, ldd, last.data_ptr(), d, g('decoder.output_linear.weight'), d, flags=ACCUM)
+        self.defer(lambda: self.gemm(1, 0, V, d, Md, dlog_ptr, ldd, last.data_ptr(), d, g('decoder.output_linear.weight'), d,
+                                     flags=ACCUM))
         self.gemm(0, 0, Md, d, V, dlog_ptr, ldd, o('decoder.output_linear.weight'), d, dA.data_ptr(), d)
+        self.flush_side()
         dcur, dnext = dA, dB
         for i in reversed(range(hp.n_dec)):
             pre = 'decoder.layers.%d.' % i
@@ -495,3 +550,4 @@ class PassEngine:
         ws = self.scratch(lib.mtl_conv0_wgrad_workspace())
         check(self.timed('conv0_wgrad', cf(T, F, 1, 64), lib.mtl_conv0_wgrad, st, S['x'].data_ptr(), dy1.data_ptr(),
                          g('conv.0.weight'), g('conv.0.bias'), ws, B, T, F), 'wgrad0')
+        self.join_side()
