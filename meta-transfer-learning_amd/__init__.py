@@ -7,5 +7,5 @@ from .data import Vocab, SyntheticTask, ManifestTaskDataset, load_vocab, synthet
 from .functions import init_transformer_model, save_meta_model, load_meta_model, post_process  # noqa: F401
 from .metrics import calculate_metrics, calculate_cer  # noqa: F401
 from .model import Transformer, Encoder, Decoder  # noqa: F401
-from .trainer import TransientTrainer, FlatAdam, FlatSGD  # noqa: F401
+from .trainer import TransientTrainer, JointTrainer, FlatAdam, FlatSGD  # noqa: F401
 from . import dist  # noqa: F401

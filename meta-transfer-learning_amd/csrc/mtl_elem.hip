@@ -333,9 +333,11 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ l
     const float l = lse[row];
     const float off = smoothing > 0.f ? smoothing / V : 0.f;
     const float on = smoothing > 0.f ? 1.f - smoothing : 1.f;
+    // the reference's smoothed target (utils/metrics.py:113-118) sums to 1 - eps/V, not 1: d/dx_j = tsum * p_j - t_j
+    const float tsum = on + (V - 1) * off;
     for (int j = lane; j < V; j += 64) {
         const float p = expf(x[j] - l);
-        d[j] = gscale * (p - (j == g ? on : off));
+        d[j] = gscale * (tsum * p - (j == g ? on : off));
     }
 }
 

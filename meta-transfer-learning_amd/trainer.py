@@ -340,3 +340,77 @@ class TransientTrainer():
                 print('EARLY STOP\n')
             return True, best, count_stop
         return False, best, count_stop
+
+
+class JointTrainer():
+    """Drop-in for trainer/asr/joint_trainer.py (BASELINE.json configs[0], joint_train.py): per iteration the gradient of
+    sum_m L_tr,m / n over all tasks, optional clip, ONE Adam(lr=args.lr) step (joint_trainer.py:182-262, no discriminator).
+    Same engine and kernels as the meta loop; tasks shard over ranks the same way."""
+
+    def __init__(self):
+        logging.info('Joint Trainer is initialized')
+
+    def get_lr(self, optimizer):
+        return optimizer.param_groups[0]['lr']
+
+    def run_iteration(self, model, vocab, task_batches, n_tasks, opt, args):
+        dev = model.flat_parameters.device
+        g = model.flat_grad
+        smoothing = float(getattr(args, 'label_smoothing', 0.0) or 0.0)
+        g.zero_()                                                       # opt.zero_grad()
+        reads = []
+        for (tx, tsz, _tp, ty, _tl) in task_batches:
+            out = model.pass_forward(tx.to(dev, non_blocking=True), tsz, ty, smoothing=smoothing)
+            reads.append(_Readback(out, dev))
+            model.pass_backward(g, 1.0 / n_tasks)                       # (tr_loss / n).backward()
+        mdist.allreduce_sum_(g)
+        if args.clip:
+            clip_flat_grad_(model, g, args.max_norm)
+        opt.step(g)
+        torch.cuda.synchronize(dev)
+        total_loss, total_cer, total_char = 0.0, 0, 0
+        for rd in reads:
+            c, n = cer_counts(vocab, rd.gold_host, rd.hyp)
+            total_cer += c
+            total_char += n
+            total_loss += float(rd.loss[0])
+        return mdist.allreduce_scalars([total_loss, total_cer, total_char], dev)
+
+    def train(self, model, vocab, train_data_list, valid_loader_list, loss_type, start_it, num_it, args, evaluate_every=1000,
+              window_size=100, last_summary_every=1000, last_metrics=None, early_stop=10, cpu_state_dict=False, is_copy_grad=False,
+              opt_name='adam', discriminator=None):
+        if loss_type != 'ce' or discriminator is not None or opt_name != 'adam':
+            raise NotImplementedError("accelerated joint training: loss_type='ce', opt_name='adam', no discriminator")
+        rank, world = mdist.rank(), mdist.world_size()
+        if rank == 0:
+            print('TRAIN')
+        model.train()
+        opt = FlatAdam(model, args.lr)                                  # the reference builds a fresh Adam per train() call
+        self.opt = opt
+        n_tasks = len(train_data_list)
+        my_tasks = mdist.shard_tasks(n_tasks, rank, world)
+        buf = [[] for _ in range(n_tasks)]
+
+        def fetch():
+            for m in range(n_tasks):
+                buf[m].insert(0, train_data_list[m].sample(args.k_train, 1, m))
+        prefetch = threading.Thread(target=fetch)
+        prefetch.start()
+        total_time, it = 0, start_it
+        self.loss_trace = []
+        while it < num_it:
+            prefetch.join()
+            prefetch = threading.Thread(target=fetch)
+            prefetch.start()
+            start_time = time.time()
+            popped = [buf[m].pop() for m in range(n_tasks)]
+            total_loss, total_cer, total_char = self.run_iteration(model, vocab, [popped[m][0] for m in my_tasks], n_tasks, opt, args)
+            total_time += time.time() - start_time
+            self.loss_trace.append(total_loss / n_tasks)
+            msg = '(Iteration {}) TRAIN LOSS:{:.4f} CER:{:.2f}% LR:{:.7f} TOTAL TIME:{:.7f}'.format(
+                (it + 1), total_loss / n_tasks, total_cer * 100 / max(total_char, 1), self.get_lr(opt), total_time)
+            if rank == 0:
+                print(msg)
+            logging.info(msg)
+            it += 1
+        prefetch.join()

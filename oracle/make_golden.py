@@ -201,12 +201,84 @@ def run_fixture(name, spec, torch):
     print(name, 'written:', len(store), 'arrays; losses', [round(f[3], 6) for f in fwd_log])
 
 
+def run_joint_fixture(torch):
+    """BASELINE.json configs[0]: joint_train.py semantics (JointTrainer), enc1/dec1 d128, 3 tasks, k_train=2, T=200, L=20."""
+    from utils.data import Vocab
+    from utils.functions import init_transformer_model
+    from trainer.asr.joint_trainer import JointTrainer
+    sys.path.insert(0, ROOT)
+    from oracle.refimpl import synth_batch
+    cfg = FIXTURES['F0']['cfg']
+    spec = dict(k=2, T=200, L=20, n_tasks=3, lr=1e-3, iters=2)
+    vocab = Vocab()
+    for i in range(cfg['vocab_size'] - 4):
+        vocab.add_token(chr(0x4e00 + i))
+        vocab.add_label(chr(0x4e00 + i))
+    args = argparse.Namespace(
+        feat_extractor='vgg_cnn', sample_rate=16000, window_size=.02, feat='spectrogram', dim_input=161,
+        num_enc_layers=cfg['num_enc_layers'], num_dec_layers=cfg['num_dec_layers'], num_heads=cfg['num_heads'],
+        dim_model=cfg['dim_model'], dim_key=cfg['dim_key'], dim_value=cfg['dim_value'], dim_inner=cfg['dim_inner'],
+        dim_emb=cfg['dim_emb'], src_max_len=cfg['src_max_len'], tgt_max_len=cfg['tgt_max_len'], dropout=0.0,
+        emb_trg_sharing=False, label_smoothing=0.0, name='golden_J0', lr=spec['lr'], k_train=spec['k'], cuda=False, clip=False,
+        max_norm=400, save_every=10 ** 9, save_folder='/tmp/golden_ckpt')
+    torch.manual_seed(123456)
+    torch.set_num_threads(8)
+    model = init_transformer_model(args, vocab, is_factorized=False, r=cfg['r'])
+    names = [n for n, _ in model.named_parameters()]
+
+    class FakeTask:
+        def __init__(self, task):
+            self.task, self.calls = task, 0
+
+        def sample(self, k_train, k_valid, manifest_id):
+            it = self.calls
+            self.calls += 1
+            out = []
+            for part in (0, 1):
+                x, lens, y = synth_batch(1000 * it + 10 * self.task + part, spec['k'], spec['T'], spec['L'], cfg['vocab_size'], True)
+                out.append((x, lens, lens.float() / spec['T'], y, (y != 0).sum(1).to(torch.int32)))
+            return tuple(out)
+
+    tasks = [FakeTask(m) for m in range(spec['n_tasks'])]
+    grads, thetas, losses = [], [], []
+    orig_step = torch.optim.Adam.step
+
+    def spy_step(self_opt, *a, **kw):
+        grads.append([p.grad.detach().clone() for p in model.parameters()])
+        return orig_step(self_opt, *a, **kw)
+    torch.optim.Adam.step = spy_step
+    fwd = []
+    model.register_forward_hook(lambda m, i, o: fwd.append((o[1].clone(), o[2].clone(),
+                                float(torch.nn.functional.cross_entropy(o[0].detach().view(-1, o[0].size(2)), o[1].view(-1), ignore_index=0)))))
+    # JointTrainer builds a fresh Adam per train() call, so both iterations run inside ONE call (data calls 0 and 1)
+    JointTrainer().train(model, vocab, tasks, [], 'ce', 0, spec['iters'], args, evaluate_every=10 ** 9, early_stop='cer,200')
+    torch.optim.Adam.step = orig_step
+    assert len(grads) == spec['iters'] and len(fwd) == spec['iters'] * spec['n_tasks']
+    store = {'param_names': np.array(names), 'lr': np.float64(spec['lr']),
+             'spec': np.array([spec['k'], spec['T'], spec['L'], spec['n_tasks'], spec['iters'], 1], dtype=np.int64),
+             'cfg_keys': np.array(sorted(cfg.keys())), 'cfg_vals': np.array([cfg[k_] for k_ in sorted(cfg.keys())], dtype=np.int64),
+             'meta_lr': np.float64(spec['lr']), 'data_call_index': np.arange(spec['iters'], dtype=np.int64)}
+    for it in range(spec['iters']):
+        pack('G/%d' % it, zip(names, grads[it]), store)
+        for j in range(spec['n_tasks']):
+            gold, hyp, loss = fwd[it * spec['n_tasks'] + j]
+            store['fwd/%d/%d/gold' % (it, j)] = gold.numpy().astype(np.int64)
+            store['fwd/%d/%d/hyp' % (it, j)] = hyp.numpy().astype(np.int64)
+            store['fwd/%d/%d/loss' % (it, j)] = np.float64(loss)
+    pack('theta/final', model.named_parameters(), store)
+    np.savez_compressed(os.path.join(OUT, 'J0.npz'), **store)
+    print('J0 written; losses', [round(f[2], 6) for f in fwd])
+
+
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--ns', action='store_true')
     ap.add_argument('--only', default='')
     a = ap.parse_args()
     torch = bootstrap_reference()
-    todo = [a.only] if a.only else (['F0', 'F1'] + (['NS'] if a.ns else []))
+    todo = [a.only] if a.only else (['F0', 'F1', 'J0'] + (['NS'] if a.ns else []))
     for name in todo:
-        run_fixture(name, FIXTURES[name], torch)
+        if name == 'J0':
+            run_joint_fixture(torch)
+        else:
+            run_fixture(name, FIXTURES[name], torch)

@@ -243,10 +243,21 @@ def flat(tensors):
     return torch.cat([t.reshape(-1) for t in tensors])
 
 
-def meta_gradient(model, task_batches, val_batch, alpha):
+def clip_(grads, max_norm):
+    """torch.nn.utils.clip_grad_norm_ semantics on a list of gradient tensors (in place)."""
+    total = torch.sqrt(sum((g.detach() ** 2).sum() for g in grads))
+    coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+    for g in grads:
+        g.mul_(coef)
+    return grads
+
+
+def meta_gradient(model, task_batches, val_batch, alpha, max_norm=None):
     """G = sum_m [ grad L_tr,m(theta0) + (1/n) grad L_val(theta0 - alpha grad L_tr,m(theta0)) ]  (SURVEY Q1).
 
     task_batches: list of (x, lengths, y); val_batch: (x, lengths, y).  Restores theta0 before returning.
+    max_norm: `--clip` (transient_trainer.py:205-206): the train gradient is clipped BEFORE the inner step and the
+    clipped tensor is what stays in .grad.
     Returns (G list per parameter, [tr losses], [val losses], [(gold, hyp) of every forward]).
     """
     params = list(model.parameters())
@@ -258,6 +269,8 @@ def meta_gradient(model, task_batches, val_batch, alpha):
         pred, gold, hyp = model(x, lens, y)
         loss = ce_loss(pred, gold)
         g_tr = torch.autograd.grad(loss, params)                           # :198-199
+        if max_norm is not None:
+            g_tr = clip_([g.clone() for g in g_tr], max_norm)
         tr_losses.append(float(loss.detach()))
         labels.append((gold.clone(), hyp.clone()))
         with torch.no_grad():
@@ -296,10 +309,30 @@ class AdamState:
                 p.addcdiv_(m, denom, value=-self.lr / bc1)
 
 
-def meta_step(model, adam, task_batches, val_batch, alpha):
-    G, tr, va, labels = meta_gradient(model, task_batches, val_batch, alpha)
+def meta_step(model, adam, task_batches, val_batch, alpha, max_norm=None):
+    G, tr, va, labels = meta_gradient(model, task_batches, val_batch, alpha, max_norm)
+    if max_norm is not None:
+        clip_(G, max_norm)                                                 # :253-254
     adam.step(list(model.parameters()), G)                                 # :248-255
     return G, tr, va, labels
+
+
+def joint_step(model, adam, task_batches, max_norm=None):
+    """trainer/asr/joint_trainer.py:182-262 without discriminator: grad of sum_m L_tr,m / n, one Adam(lr) step."""
+    params = list(model.parameters())
+    n = len(task_batches)
+    G = [torch.zeros_like(p) for p in params]
+    losses = []
+    for (x, lens, y) in task_batches:
+        pred, gold, _ = model(x, lens, y)
+        loss = ce_loss(pred, gold)
+        losses.append(float(loss.detach()))
+        for acc, g in zip(G, torch.autograd.grad(loss / n, params)):
+            acc.add_(g)
+    if max_norm is not None:
+        clip_(G, max_norm)
+    adam.step(params, G)
+    return G, losses
 
 
 # --------------------------------------------------------------------------------------

@@ -75,3 +75,24 @@ def test_appendix_a_known_answers():
     loss.backward()
     gn = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters())))
     assert abs(gn - 15.68509186) < 1e-4
+
+
+def test_joint_trainer_config0_matches_reference():
+    """BASELINE.json configs[0]: joint_train.py / JointTrainer semantics (CPU-only plumbing case)."""
+    torch.set_num_threads(8)
+    z, cfg, spec = gu.load('J0')
+    m = R.build_model(cfg)
+    names = [n for n, _ in m.named_parameters()]
+    adam = R.AdamState(list(m.parameters()), spec['lr'])
+    for it in range(spec['iters']):
+        tr = [R.synth_batch(1000 * it + 10 * t, spec['k'], spec['T'], spec['L'], cfg['vocab_size'], True) for t in range(spec['n_tasks'])]
+        G, losses = R.joint_step(m, adam, tr)
+        for j, v in enumerate(losses):
+            assert abs(v - float(z['fwd/%d/%d/loss' % (it, j)])) <= 2e-6 * abs(v)
+        floor = 1e-4 * gu.global_l2(z, 'G/%d' % it, names)
+        for nm, g in zip(names, G):
+            gu.check_digest(z, 'G/%d' % it, nm, g, rtol=2e-5, what='J0', floor=floor)
+    for nm, p in zip(names, m.parameters()):
+        if 'key_linear_b.bias' in nm:
+            continue
+        gu.check_digest(z, 'theta/final', nm, p, rtol=1e-5, what='J0')

@@ -210,3 +210,97 @@ def test_round_trip_properties_full_size():
     model.pass_backward(g3, 1.0)
     assert torch.equal(g1, g3)                                        # fixed-order reductions: bitwise reproducible
     assert abs(l1 - np.log(cfg['vocab_size'])) < 0.5                  # CE at init ~ ln V
+
+
+def test_joint_trainer_config0_against_reference_golden():
+    """BASELINE.json configs[0] (joint_train.py) through the HIP path: loss trace, labels, gradients of both iterations."""
+    z, cfg, spec = gu.load('J0')
+    spec = dict(spec, meta_lr=spec['lr'])
+    mtl_amd, args, vocab, model = make(cfg, spec)
+    model = model.cuda()
+    names = [str(s) for s in z['param_names']]
+    tasks = [mtl_amd.SyntheticTask(m, spec['k'], spec['T'], spec['L'], cfg['vocab_size'], variable=True) for m in range(spec['n_tasks'])]
+    tr = mtl_amd.JointTrainer()
+    grads = []
+    orig = tr.run_iteration
+
+    def spy(model_, vocab_, batches, n, opt, a):
+        step = opt.step
+        opt.step = lambda g: (grads.append(g.clone()), step(g))[1]
+        try:
+            return orig(model_, vocab_, batches, n, opt, a)
+        finally:
+            opt.step = step
+    tr.run_iteration = spy
+    tr.train(model, vocab, tasks, [], 'ce', 0, spec['iters'], args, evaluate_every=10 ** 9, early_stop='cer,200')
+    for it in range(spec['iters']):
+        ref = sum(float(z['fwd/%d/%d/loss' % (it, j)]) for j in range(spec['n_tasks'])) / spec['n_tasks']
+        assert abs(tr.loss_trace[it] - ref) <= RTOL * ref
+        floor = 1e-4 * gu.global_l2(z, 'G/%d' % it, names)
+        errs = [gu.check_digest(z, 'G/%d' % it, nm, model._layout.view(grads[it], nm), rtol=GOLDEN_BAND['F0'], what='J0', floor=floor)
+                for nm in names]
+        assert sum(e <= RTOL for e in errs) >= 0.6 * len(errs)
+        print('J0 it %d: %d/%d gradient tensors within 1e-4, worst %.2e' % (it, sum(e <= RTOL for e in errs), len(errs), max(errs)))
+
+
+def test_clip_and_label_smoothing_meta_step_against_oracle():
+    """--clip (transient_trainer.py:205-206,253-254) and --label-smoothing (utils/metrics.py:113-124) through train()."""
+    from oracle import refimpl as R
+    import torch.nn.functional as F
+    z, cfg, spec = gu.load('F0')
+    mtl_amd, args, vocab, model = make(cfg, spec)
+    model = model.cuda()
+    args.clip, args.max_norm = True, 3.0
+    oracle = R.build_model(cfg)
+    tr, val = gu.batches_for(cfg, spec, 0, z['data_call_index'])
+    G_r, _, _, _ = R.meta_gradient(oracle, tr, val, spec['lr'], max_norm=3.0)
+    inner = mtl_amd.FlatSGD(model, spec['lr'])
+    model.zero_copy_grad()
+    as5 = lambda b: (b[0], b[1], None, b[2], None)
+    mtl_amd.TransientTrainer().meta_iteration(model, vocab, [as5(b) for b in tr], as5(val), len(tr), inner, None, args)
+    gn = float(torch.sqrt(sum((g.double() ** 2).sum() for g in G_r)))
+    errs = [float((model._layout.view(model._G, nm).cpu() - g).norm() / max(float(g.norm()), 1e-4 * gn))
+            for (nm, _), g in zip(oracle.named_parameters(), G_r)]
+    assert max(errs) < FLIP_BAND and sum(e < RTOL for e in errs) >= 0.6 * len(errs), max(errs)
+    # label smoothing: loss + gradient of one pass against the reference formula restated in torch
+    eps = 0.1
+    x, lens, y = tr[0]
+    out = model.pass_forward(x.cuda(), lens, y, smoothing=eps)
+    g = torch.zeros_like(model.flat_grad)
+    model.pass_backward(g, 1.0)
+    pred, gold, _ = oracle(x, lens, y)
+    V = pred.size(2)
+    p2, g2 = pred.view(-1, V), gold.view(-1)
+    mask = g2.ne(0)
+    one_hot = torch.zeros_like(p2).scatter(1, (mask.long() * g2).view(-1, 1), 1)
+    one_hot = one_hot * (1 - eps) + (1 - one_hot) * eps / V
+    loss = -(one_hot * F.log_softmax(p2, dim=1)).sum(1).masked_select(mask).sum() / int(mask.sum())
+    grads = torch.autograd.grad(loss, list(oracle.parameters()))
+    assert abs(float(out['loss']) - float(loss)) < RTOL * float(loss)
+    gn = float(torch.sqrt(sum((t.double() ** 2).sum() for t in grads)))
+    errs = [float((model._layout.view(g, nm).cpu() - t).norm() / max(float(t.norm()), 1e-4 * gn))
+            for (nm, _), t in zip(oracle.named_parameters(), grads)]
+    assert max(errs) < FLIP_BAND and sum(e < RTOL for e in errs) >= 0.9 * len(errs), max(errs)
+
+
+def test_long_utterance_stress_config():
+    """BASELINE.json configs[3]: src-max-len 5000 (T' = 1250), dim-input 5120: runs, is finite, deterministic, and the
+    backward is linear in the loss scale (size-independent properties; the oracle needs minutes at this size)."""
+    z, cfg, spec = gu.load('NS')
+    mtl_amd, args, vocab, model = make(cfg, spec)
+    model = model.cuda()
+    x, lens, y = mtl_amd.synth_batch(3, 8, 5000, 100, cfg['vocab_size'])
+    lens[3], lens[5] = 300, 2500                      # exercises the raw-length masks on the pooled axis (Q2)
+    x[3, :, :, 300:] = 0
+    x[5, :, :, 2500:] = 0
+    xd = x.cuda()
+    out = model.pass_forward(xd, lens, y)
+    l1 = float(out['loss'])
+    g1 = torch.zeros_like(model.flat_grad)
+    model.pass_backward(g1, 1.0)
+    assert np.isfinite(l1) and bool(torch.isfinite(g1).all()) and abs(l1 - np.log(cfg['vocab_size'])) < 0.5
+    out = model.pass_forward(xd, lens, y)
+    g2 = torch.zeros_like(g1)
+    model.pass_backward(g2, 0.25)
+    assert float(out['loss']) == l1 and float((g1 * 0.25 - g2).norm() / g2.norm()) < 1e-6
+    assert out['hyp'].shape == (8, 101) and int(out['hyp'].max()) < cfg['vocab_size']
