@@ -27,11 +27,14 @@ def init_from_env(backend=None):
     """Initialise from torchrun's RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*; no-op for a single process."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world <= 1 or is_on():
-        return int(os.environ.get('LOCAL_RANK', '0'))
+        lr_ = int(os.environ.get('LOCAL_RANK', '0'))
+        return lr_ % torch.cuda.device_count() if torch.cuda.is_available() else lr_
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if backend is None:
-        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
-    if backend == 'nccl':
+        # MTL_DIST_BACKEND=gloo lets several ranks share one GPU (functional test of the sharded path on a 1-GPU box)
+        backend = os.environ.get('MTL_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
+    if torch.cuda.is_available():
+        local = local % torch.cuda.device_count()
         torch.cuda.set_device(local)
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     td.init_process_group(backend=backend, rank=int(os.environ['RANK']), world_size=world)

@@ -304,3 +304,27 @@ def test_long_utterance_stress_config():
     model.pass_backward(g2, 0.25)
     assert float(out['loss']) == l1 and float((g1 * 0.25 - g2).norm() / g2.norm()) < 1e-6
     assert out['hyp'].shape == (8, 101) and int(out['hyp'].max()) < cfg['vocab_size']
+
+
+def test_two_ranks_sharded_bench_equals_single_rank():
+    """bench.py under torchrun with 2 ranks (sharing this box's single GPU over gloo): the sharded meta-step with ONE
+    all-reduce of G must reproduce the single-rank step (same loss / CER of the last step)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ['--steps', '2', '--warmup', '1', '--tasks', '4', '--k', '2', '--frames', '200', '--labels', '20', '--no-cpu-baseline']
+    env = dict(os.environ, MTL_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    one = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1'] + common, capture_output=True, text=True,
+                         env=env, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    two = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+                          '127.0.0.1', '--master-port', '29733', os.path.join(root, 'bench.py'), '--gpus', '2'] + common,
+                         capture_output=True, text=True, env=env, timeout=600)
+    assert two.returncode == 0, two.stderr[-2000:]
+    j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith('{')][-1])
+    j2 = json.loads([l for l in two.stdout.splitlines() if l.startswith('{')][-1])
+    assert j2['n_gpus'] == 2 and j1['n_gpus'] == 1 and j2['scaling'] == 'strong'
+    assert j1['last_step']['chars'] == j2['last_step']['chars'] and j1['last_step']['cer_edits'] == j2['last_step']['cer_edits']
+    assert abs(j1['last_step']['val_loss'] - j2['last_step']['val_loss']) < 1e-4 * abs(j1['last_step']['val_loss'])
