@@ -11,6 +11,7 @@ Reference symbols mirrored: Transformer (models/asr/transformer.py:14-240), Enco
 FactorizedMultiHeadAttention / PositionwiseFeedForward / PositionalEncoding (modules/common_layers.py:86-132,238-306).
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -174,6 +175,8 @@ class Transformer(nn.Module):
         self._theta = self._gflat = self._G = None
         self._theta_override = None
         self.engine = None
+        self.engines, self.lane_streams = [], []
+        self.n_lanes = max(1, int(os.environ.get('MTL_TASK_LANES', '2')))
         self._pass_token = 0
         self._last = None
         self._anchor = None
@@ -200,8 +203,11 @@ class Transformer(nn.Module):
             hp = Hyper(d=e.dim_model, r=e.r, h=e.num_heads, dk=e.dim_key, dv=e.dim_value, inner=e.dim_inner,
                        d_in=e.dim_input, n_enc=e.num_layers, n_dec=d.num_layers, V=len(self.vocab.label2id),
                        temperature=np.power(e.dim_key, 0.5), src_max_len=e.src_max_length, tgt_max_len=d.trg_max_length)
-            self.engine = PassEngine(self._layout, hp, device, e.positional_encoding.pe[0].contiguous(),
-                                     d.positional_encoding.pe[0].contiguous())
+            pe_e, pe_d = e.positional_encoding.pe[0].contiguous(), d.positional_encoding.pe[0].contiguous()
+            # task lanes: independent tasks of a meta-step run concurrently, each on its own stream with its own arena
+            self.engines = [PassEngine(self._layout, hp, device, pe_e, pe_d) for _ in range(self.n_lanes)]
+            self.lane_streams = [torch.cuda.Stream(device) for _ in range(self.n_lanes)]
+            self.engine = self.engines[0]
 
     def _apply(self, fn, *a, **kw):
         out = super()._apply(fn, *a, **kw)
@@ -273,11 +279,18 @@ class Transformer(nn.Module):
         return dpred
 
     # fast path used by the trainer: no autograd objects at all
-    def pass_forward(self, x, lengths, target, theta=None, smoothing=0.0):
-        return self._run_forward(self._theta if theta is None else theta, x, lengths, target, smoothing)
+    def pass_forward(self, x, lengths, target, theta=None, smoothing=0.0, lane=0):
+        if lane == 0:
+            return self._run_forward(self._theta if theta is None else theta, x, lengths, target, smoothing)
+        self._need_engine()
+        th = self._theta if theta is None else theta
+        if x.device != th.device:
+            x = x.to(th.device, non_blocking=True)
+        return self.engines[lane].forward(th, x.float(), lengths, target, smoothing=smoothing)
 
-    def pass_backward(self, grad=None, scale=1.0):
-        self._need_engine().backward(self._gflat if grad is None else grad, scale)
+    def pass_backward(self, grad=None, scale=1.0, lane=0):
+        self._need_engine()
+        self.engines[lane].backward(self._gflat if grad is None else grad, scale)
 
     # ------------------------------------------------------------------ copy_grad API (models/asr/transformer.py:205-240)
     def init_copy_grad_(self):

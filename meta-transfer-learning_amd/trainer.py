@@ -89,16 +89,18 @@ class FlatSGD:
     def zero_grad(self):
         self.model.zero_grad()
 
-    def theta_prime_from(self, theta0, grad):
+    def theta_prime_from(self, theta0, grad, out=None):
+        out = self.theta_prime if out is None else out
         check(_lib.lib().mtl_sgd_theta_prime(torch.cuda.current_stream(theta0.device).cuda_stream, theta0.data_ptr(),
-                                             grad.data_ptr(), float(self.param_groups[0]['lr']), self.theta_prime.data_ptr(),
+                                             grad.data_ptr(), float(self.param_groups[0]['lr']), out.data_ptr(),
                                              theta0.numel()), 'mtl_sgd_theta_prime')
-        return self.theta_prime
+        return out
 
 
-def clip_flat_grad_(model, grad, max_norm):
+def clip_flat_grad_(model, grad, max_norm, lane=0):
     """torch.nn.utils.clip_grad_norm_ on the flat buffer: grad *= min(1, max_norm / (||grad|| + 1e-6)), no host sync."""
-    eng = model._need_engine()
+    model._need_engine()
+    eng = model.engines[lane]
     ws = eng.scratch(8192)
     coef = eng.buf('_clip_coef', (1,))
     st = eng.stream
@@ -160,28 +162,68 @@ class TransientTrainer():
     # ------------------------------------------------------------------ one meta-iteration on the device
     def meta_iteration(self, model, vocab, task_batches, val_batch, n_tasks, inner, outer, args, task_ids=None):
         """task_batches: this rank's [(inputs, input_sizes, percentages, targets, target_sizes)], val_batch: same 5-tuple.
-        n_tasks is the GLOBAL task count (the 1/n of the validation loss).  Returns (sum val loss, cer, chars) local."""
+        n_tasks is the GLOBAL task count (the 1/n of the validation loss).  Leaves G in model._G; returns the read-backs.
+
+        Tasks are independent given theta0, so they are dealt round-robin onto the model's task lanes (own stream, buffer
+        arena, gradient / theta' / G buffers): one task's many small transformer kernels fill the CUs another task's
+        convolutions leave idle.  Lane accumulators are summed in lane order, so G stays run-to-run deterministic."""
         dev = model.flat_parameters.device
-        theta0, g, G = model.flat_parameters, model.flat_grad, model._G
+        theta0 = model.flat_parameters
         smoothing = float(getattr(args, 'label_smoothing', 0.0) or 0.0)
-        reads = []
-        G.zero_()
+        n_lanes = min(model.n_lanes, max(len(task_batches), 1))
+        bufs = self._lane_buffers(model, n_lanes)
+        main = torch.cuda.current_stream(dev)
         vx = val_batch[0].to(dev, non_blocking=True)
-        for (tx, tsz, _tp, ty, _tl) in task_batches:
-            tx = tx.to(dev, non_blocking=True)
-            g.zero_()                                                            # inner_opt.zero_grad()   (:198)
-            out = model.pass_forward(tx, tsz, ty, theta=theta0, smoothing=smoothing)   # meta-train forward (:188)
-            tr_read = _Readback(out, dev)
-            model.pass_backward(g, 1.0)                                          # tr_loss.backward()      (:199)
-            if args.clip:
-                clip_flat_grad_(model, g, args.max_norm)                         # (:205-206)
-            theta1 = inner.theta_prime_from(theta0, g)                           # inner_opt.step()        (:207)
-            out = model.pass_forward(vx, val_batch[1], val_batch[3], theta=theta1, smoothing=smoothing)   # (:215)
-            va_read = _Readback(out, dev)
-            model.pass_backward(g, 1.0 / n_tasks)                                # (val_loss/n).backward(): g += g_val/n (:226-227, Q1)
-            model._axpy(G, g, 1.0)                                               # add_copy_grad()         (:229)
-            reads.append((tr_read, va_read))
+        ready = torch.cuda.Event()
+        ready.record(main)
+        reads = [None] * len(task_batches)
+        streams = [model.lane_streams[lane] if n_lanes > 1 else main for lane in range(n_lanes)]
+        for lane in range(n_lanes):
+            with torch.cuda.stream(streams[lane]):
+                streams[lane].wait_event(ready)
+                bufs[lane][2].zero_()
+        for idx, (tx, tsz, _tp, ty, _tl) in enumerate(task_batches):      # enqueue task by task, alternating lanes
+            lane = idx % n_lanes
+            g, theta1, G = bufs[lane]
+            with torch.cuda.stream(streams[lane]):
+                tx = tx.to(dev, non_blocking=True)
+                g.zero_()                                                        # inner_opt.zero_grad()   (:198)
+                out = model.pass_forward(tx, tsz, ty, theta=theta0, smoothing=smoothing, lane=lane)   # (:188)
+                tr_read = _Readback(out, dev)
+                model.pass_backward(g, 1.0, lane=lane)                           # tr_loss.backward()      (:199)
+                if args.clip:
+                    clip_flat_grad_(model, g, args.max_norm, lane=lane)          # (:205-206)
+                inner.theta_prime_from(theta0, g, out=theta1)                    # inner_opt.step()        (:207)
+                out = model.pass_forward(vx, val_batch[1], val_batch[3], theta=theta1, smoothing=smoothing, lane=lane)  # (:215)
+                va_read = _Readback(out, dev)
+                model.pass_backward(g, 1.0 / n_tasks, lane=lane)                 # (val_loss/n).backward(): g += g_val/n (Q1)
+                model._axpy(G, g, 1.0)                                           # add_copy_grad()         (:229)
+                reads[idx] = (tr_read, va_read)
+        if n_lanes > 1:
+            for lane in range(n_lanes):
+                done = torch.cuda.Event()
+                done.record(streams[lane])
+                main.wait_event(done)
+        Gm = model._G
+        if n_lanes == 1:
+            pass                                              # lane 0 accumulated straight into model._G
+        else:
+            Gm.copy_(bufs[0][2])
+            for lane in range(1, n_lanes):
+                model._axpy(Gm, bufs[lane][2], 1.0)
         return reads
+
+    def _lane_buffers(self, model, n_lanes):
+        """(grad, theta', G) per lane; lane 0 uses the model's own flat_grad / copy_grad buffers when it is the only lane."""
+        key = (id(model.flat_parameters), n_lanes)
+        if getattr(self, '_lane_key', None) != key:
+            th = model.flat_parameters
+            if n_lanes == 1:
+                self._lanes = [(model.flat_grad, torch.empty_like(th), model._G)]
+            else:
+                self._lanes = [(torch.zeros_like(th), torch.empty_like(th), torch.zeros_like(th)) for _ in range(n_lanes)]
+            self._lane_key = key
+        return self._lanes
 
     def run_iteration(self, model, vocab, task_batches, val_data, n_tasks, inner_opt, outer_opt, args):
         """The timed body of one meta-iteration (transient_trainer.py:152-264): local tasks, ONE all-reduce of G, Adam,
