@@ -176,14 +176,15 @@ def main():
     for e in model.engines:
         e.prof = None
 
+    # every rank runs the serial profiling step (it contains the collective); only rank 0 reports it
+    conc = conv_rows(prof)
+    rows = serial_profile(trainer, model, vocab, tasks, my_tasks, a.tasks, inner, outer, args, dev)
     out = None
     if rank == 0:
         ms = dt / a.steps * 1e3
         # dominant kernel = the conv class with the largest accumulated time; its duration is taken from a serial profiling
         # step (lanes / side stream off) because HIP events around a launch that shares the GPU with another lane's kernels
         # measure the sharing, not the kernel; the concurrent figures of the timed region are kept next to it
-        conc = conv_rows(prof)
-        rows = serial_profile(trainer, model, vocab, tasks, my_tasks, a.tasks, inner, outer, args, dev)
         tot, name, flops, avg, cnt = rows[0]
         conv_time = sum(r[0] for r in rows)
         conv_flops = sum(r[2] * r[4] for r in rows)

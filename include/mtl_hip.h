@@ -94,15 +94,17 @@ int mtl_softmax_bwd(void* stream, const float* P, float* dP /*in place -> dS*/, 
 
 /* ---- embedding + positional encoding: modules/decoder.py:96 ------------------------------------------- */
 int mtl_embed_pe_fwd(void* stream, const long* ids, const float* table, const float* pe, float* out, int rows, int T, int d);
-/* rank[r] = number of rows r' < r with ids[r'] == ids[r] (host-computed), n_pass = 1 + max rank: duplicates are added in
- * row order, pass by pass, so the scatter-add is parallel AND deterministic. */
-int mtl_embed_bwd(void* stream, const long* ids, const int* rank, int n_pass, const float* dout, float* dtable /*accum*/,
-                  int rows, int d, long pad_id);
+/* first[r] = 1 if no earlier row has ids[r]; next[r] = next row with the same id or -1 (both host-built): duplicates are
+ * summed in row order by the thread of the chain head, so the scatter-add is one launch, parallel AND deterministic. */
+int mtl_embed_bwd(void* stream, const long* ids, const int* first, const int* next, const float* dout,
+                  float* dtable /*accum*/, int rows, int d, long pad_id);
 
 /* ---- cross-entropy + arg-max: utils/metrics.py:113-126, models/asr/transformer.py:146-147 ----------------
  * loss_out[0] = sum_rows(gold!=pad ? -log softmax(logits)[gold] : 0) / n_nonpad ; hyp = lowest arg-max index. */
+/* inv_count_dev (nullable): device scalar 1/n_nonpad used instead of n_nonpad (keeps a captured hipGraph batch-independent) */
 int mtl_ce_argmax_fwd(void* stream, const float* logits, const long* gold, int rows, int V, int ld, long pad_id,
-                      float smoothing, int n_nonpad, float* lse, long* hyp, float* rowloss, float* loss_out);
+                      float smoothing, int n_nonpad, const float* inv_count_dev, float* lse, long* hyp, float* rowloss,
+                      float* loss_out);
 /* dlogits = gscale * (gscale_dev ? *gscale_dev : 1) * (softmax - target) on non-pad rows, 0 elsewhere */
 int mtl_ce_bwd(void* stream, const float* logits, const float* lse, const long* gold, int rows, int V, int ld, long pad_id,
                float smoothing, float gscale, const float* gscale_dev, float* dlogits, int ldd);

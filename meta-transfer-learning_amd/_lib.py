@@ -33,8 +33,8 @@ SIGNATURES = {
     'mtl_softmax_mask_fwd': (I, [P, P, P, I, F, I, I, I, I, I]),
     'mtl_softmax_bwd': (I, [P, P, P, F, L, I, I]),
     'mtl_embed_pe_fwd': (I, [P, P, P, P, P, I, I, I]),
-    'mtl_embed_bwd': (I, [P, P, P, I, P, P, I, I, L]),
-    'mtl_ce_argmax_fwd': (I, [P, P, P, I, I, I, L, F, I, P, P, P, P]),
+    'mtl_embed_bwd': (I, [P, P, P, P, P, P, I, I, L]),
+    'mtl_ce_argmax_fwd': (I, [P, P, P, I, I, I, L, F, I, P, P, P, P, P]),
     'mtl_ce_bwd': (I, [P, P, P, P, I, I, I, L, F, F, P, P, I]),
     'mtl_colsum_workspace': (L, [L, I]),
     'mtl_colsum_accum': (I, [P, P, L, I, L, P, P]),

@@ -76,8 +76,9 @@ __global__ void sumsq_partial_kernel(const float* __restrict__ x, long n, float*
     __syncthreads();
     if (threadIdx.x == 0) part[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
 }
-__global__ void sum_final_kernel(const float* __restrict__ part, int np, float* __restrict__ out, int mode, float arg) {
-    // mode 0: out = sum ; mode 1: out = sum/arg ; mode 2: out = clip coefficient min(1, arg/(sqrt(sum)+1e-6))
+__global__ void sum_final_kernel(const float* __restrict__ part, int np, float* __restrict__ out, int mode, float arg,
+                                 const float* __restrict__ inv_dev) {
+    // mode 0: out = sum ; mode 1: out = sum/arg (or sum * *inv_dev) ; mode 2: clip coefficient min(1, arg/(sqrt(sum)+1e-6))
     __shared__ float sh[4];
     float s = 0.f;
     for (int i = threadIdx.x; i < np; i += blockDim.x) s += part[i];
@@ -86,7 +87,7 @@ __global__ void sum_final_kernel(const float* __restrict__ part, int np, float* 
     __syncthreads();
     if (threadIdx.x == 0) {
         float t = sh[0] + sh[1] + sh[2] + sh[3];
-        if (mode == 1) t = t / arg;
+        if (mode == 1) t = inv_dev ? t * (*inv_dev) : t / arg;
         if (mode == 2) t = fminf(1.f, arg / (sqrtf(t) + 1e-6f));
         *out = t;
     }
@@ -249,15 +250,18 @@ __global__ void embed_pe_fwd_kernel(const long* __restrict__ ids, const float* _
         out[e] = table[ids[r] * d + c] + pe[(long)(r % T) * d + c];
     }
 }
-// Scatter-add with duplicate ids, deterministic and parallel: `rank[r]` (host-computed) is the number of earlier rows
-// with the same id; pass j adds the rows of rank j (all distinct ids -> conflict-free), passes run in order.
-__global__ void embed_bwd_kernel(const long* __restrict__ ids, const int* __restrict__ rank, const float* __restrict__ dout,
-                                 float* __restrict__ dtable, int rows, int d, long pad_id, int pass) {
+// Scatter-add with duplicate ids, deterministic, ONE launch: `next[r]` (host-built) links row r to the next row with the
+// same id (-1 = last) and `first[r]` marks chain heads; the thread of (head row, column) walks its chain in row order.
+__global__ void embed_bwd_kernel(const long* __restrict__ ids, const int* __restrict__ first, const int* __restrict__ next,
+                                 const float* __restrict__ dout, float* __restrict__ dtable, int rows, int d, long pad_id) {
     const long total = (long)rows * d;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
         const int r = (int)(e / d), c = (int)(e - (long)r * d);
         const long id = ids[r];
-        if (id != pad_id && rank[r] == pass) dtable[id * d + c] += dout[e];
+        if (id == pad_id || !first[r]) continue;
+        float acc = 0.f;
+        for (int q = r; q >= 0; q = next[q]) acc += dout[(long)q * d + c];
+        dtable[id * d + c] += acc;
     }
 }
 
@@ -542,7 +546,7 @@ int mtl_sumsq(void* stream, const float* x, long n, float* out, float* workspace
     if (!x || !out || !workspace || n <= 0) return MTL_EINVAL;
     const int nb = grid_for(n, 256 * 8, 1024);
     hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb), dim3(256), 0, as_stream(stream), x, n, workspace);
-    hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(256), 0, as_stream(stream), workspace, nb, out, mode, arg);
+    hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(256), 0, as_stream(stream), workspace, nb, out, mode, arg, (const float*)nullptr);
     MTL_CHECK_LAUNCH();
     return MTL_OK;
 }
@@ -621,23 +625,24 @@ int mtl_embed_pe_fwd(void* stream, const long* ids, const float* table, const fl
     return MTL_OK;
 }
 
-int mtl_embed_bwd(void* stream, const long* ids, const int* rank, int n_pass, const float* dout, float* dtable, int rows, int d,
-                  long pad_id) {
-    if (!ids || !rank || !dout || !dtable || rows <= 0 || n_pass < 1) return MTL_EINVAL;
-    for (int j = 0; j < n_pass; ++j)
-        hipLaunchKernelGGL(embed_bwd_kernel, dim3(grid_for((long)rows * d, 256, 2048)), dim3(256), 0, as_stream(stream), ids, rank,
-                           dout, dtable, rows, d, pad_id, j);
+int mtl_embed_bwd(void* stream, const long* ids, const int* first, const int* next, const float* dout, float* dtable, int rows,
+                  int d, long pad_id) {
+    if (!ids || !first || !next || !dout || !dtable || rows <= 0) return MTL_EINVAL;
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(grid_for((long)rows * d, 256, 2048)), dim3(256), 0, as_stream(stream), ids, first,
+                       next, dout, dtable, rows, d, pad_id);
     MTL_CHECK_LAUNCH();
     return MTL_OK;
 }
 
 int mtl_ce_argmax_fwd(void* stream, const float* logits, const long* gold, int rows, int V, int ld, long pad_id,
-                      float smoothing, int n_nonpad, float* lse, long* hyp, float* rowloss, float* loss_out) {
-    if (!logits || !gold || !lse || !hyp || !rowloss || !loss_out || rows <= 0 || V <= 0 || n_nonpad <= 0) return MTL_EINVAL;
+                      float smoothing, int n_nonpad, const float* inv_count_dev, float* lse, long* hyp, float* rowloss,
+                      float* loss_out) {
+    if (!logits || !gold || !lse || !hyp || !rowloss || !loss_out || rows <= 0 || V <= 0 || (n_nonpad <= 0 && !inv_count_dev))
+        return MTL_EINVAL;
     hipStream_t s = as_stream(stream);
     hipLaunchKernelGGL(ce_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, logits, gold, rows, V, ld, pad_id, smoothing, lse,
                        hyp, rowloss);
-    hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(256), 0, s, rowloss, rows, loss_out, 1, (float)n_nonpad);
+    hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(256), 0, s, rowloss, rows, loss_out, 1, (float)n_nonpad, inv_count_dev);
     MTL_CHECK_LAUNCH();
     return MTL_OK;
 }

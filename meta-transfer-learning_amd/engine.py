@@ -317,13 +317,66 @@ class PassEngine:
         self.flush_side()
 
     # ---------------------------------------------------------------- the pass
-    def forward(self, theta, x, lengths, target, smoothing=0.0):
+    def prepare(self, lengths, target, B, T, slot=0):
+        """Host-side integer prep of one batch (modules/decoder.py:55-69 target shifting; every mask is derived inside the
+        kernels from these few integers) + asynchronous H2D into STATIC per-slot buffers.  Kept separate from the kernels so
+        a captured hipGraph of the pass can be replayed for any batch of the same shape."""
+        hp = self.hp
+        T4 = (T // 2) // 2
+        seq_in, seq_out = decoder_io(target)
+        Td = seq_in.shape[1]
+        if T4 > hp.src_max_len or Td > hp.tgt_max_len:
+            raise ValueError('sequence longer than the positional tables')
+        lens = lengths.detach().to('cpu', torch.int64)
+        is_pad = seq_in.eq(EOS_ID)
+        dec_len = (~is_pad).sum(1)
+        if not bool((is_pad == (torch.arange(Td).unsqueeze(0) >= dec_len.unsqueeze(1))).all()):
+            raise ValueError('EOS inside a target sequence is not supported')
+        pos = torch.arange(T4).unsqueeze(0)
+        # occurrence chains of the decoder input ids (deterministic embedding scatter-add, mtl_embed_bwd)
+        flat_in = seq_in.reshape(-1)
+        order = torch.argsort(flat_in, stable=True)
+        srt = flat_in[order]
+        same_as_prev = torch.zeros_like(srt, dtype=torch.bool)
+        same_as_prev[1:] = srt[1:] == srt[:-1]
+        first = torch.empty_like(flat_in, dtype=torch.int32)
+        first[order] = (~same_as_prev).to(torch.int32)
+        nxt = torch.full_like(flat_in, -1, dtype=torch.int32)
+        nxt[order[:-1]] = torch.where(same_as_prev[1:], order[1:], torch.full_like(order[1:], -1)).to(torch.int32)
+        n_nonpad = int((seq_out != PAD_ID).sum())
+        meta_i32 = torch.cat([
+            torch.clamp(lens, max=T4).to(torch.int32),                        # klen_enc (B)      (SURVEY Q2: raw lengths)
+            dec_len.to(torch.int32),                                           # klen_dec (B)
+            (pos < lens.unsqueeze(1)).to(torch.int32).reshape(-1),             # keep_enc (B*T4)
+            (~is_pad).to(torch.int32).reshape(-1),                             # keep_dec (B*Td)
+            first, nxt,                                                        # embed chains (B*Td each)
+            torch.tensor([1.0 / n_nonpad], dtype=torch.float32).view(torch.int32)])   # 1/n_nonpad (fp32 bits)
+        dev_i32 = self.buf('meta_i32.%d' % slot, (meta_i32.numel(),), torch.int32)
+        dev_i32.copy_(meta_i32, non_blocking=True)
+        ids = self.buf('ids.%d' % slot, (2, B, Td), torch.int64)
+        ids.copy_(torch.stack([seq_in, seq_out]), non_blocking=True)
+        klen_enc = dev_i32.data_ptr()
+        klen_dec = klen_enc + 4 * B
+        keep_enc = klen_dec + 4 * B
+        keep_dec = keep_enc + 4 * B * T4
+        embed_first = keep_dec + 4 * B * Td
+        embed_next = embed_first + 4 * B * Td
+        inv_count = embed_next + 4 * B * Td
+        return dict(B=B, T=T, Td=Td, n_nonpad=n_nonpad, gold_host=seq_out, ids=ids, klen_enc=klen_enc, klen_dec=klen_dec,
+                    keep_enc=keep_enc, keep_dec=keep_dec, embed_first=embed_first, embed_next=embed_next, inv_count=inv_count)
+
+    def forward(self, theta, x, lengths, target, smoothing=0.0, slot=0):
         """x (B,1,F,T) fp32 on device; lengths (B) int; target (B,L) int64 PAD-padded.  Returns a dict with device
         tensors pred (B,Td,V), gold, hyp (B,Td) int64 and `loss` (1,) fp32; keeps what the backward needs."""
-        hp, L, lib, st = self.hp, self.L, self.lib, self.stream
-        assert theta.numel() == L.total and theta.dtype == torch.float32 and theta.is_contiguous()
         if x.dim() != 4 or x.shape[1] != 1:
             raise ValueError('expected (B,1,F,T) input')
+        meta = self.prepare(lengths, target, x.shape[0], x.shape[3], slot)
+        return self.forward_device(theta, x, meta, smoothing)
+
+    def forward_device(self, theta, x, meta, smoothing=0.0):
+        """Kernel launches only (hipGraph-capturable): everything batch-dependent comes from `meta`'s device buffers."""
+        hp, L, lib, st = self.hp, self.L, self.lib, self.stream
+        assert theta.numel() == L.total and theta.dtype == torch.float32 and theta.is_contiguous()
         x = x.contiguous()
         if x.dtype != torch.float32 or x.device != self.device:
             raise ValueError('input must be fp32 on %s' % self.device)
@@ -335,43 +388,8 @@ class PassEngine:
         P = theta.data_ptr()
         o = lambda n: P + 4 * L.off(n)
         d, V = hp.d, hp.V
-
-        # ---- host-side integer prep (masks are derived from lengths inside the kernels) ----
-        seq_in, seq_out = decoder_io(target)
-        Td = seq_in.shape[1]
-        if T4 > hp.src_max_len or Td > hp.tgt_max_len:
-            raise ValueError('sequence longer than the positional tables')
-        lens = lengths.detach().to('cpu', torch.int64)
-        is_pad = seq_in.eq(EOS_ID)
-        dec_len = (~is_pad).sum(1)
-        if not bool((is_pad == (torch.arange(Td).unsqueeze(0) >= dec_len.unsqueeze(1))).all()):
-            raise ValueError('EOS inside a target sequence is not supported')
-        pos = torch.arange(T4).unsqueeze(0)
-        flat_in = seq_in.reshape(-1)
-        order = torch.argsort(flat_in, stable=True)                           # occurrence rank of every decoder input id
-        srt = flat_in[order]
-        start = torch.ones_like(srt, dtype=torch.bool)
-        start[1:] = srt[1:] != srt[:-1]
-        idx = torch.arange(srt.numel())
-        first = torch.cummax(torch.where(start, idx, torch.zeros_like(idx)), 0)[0]
-        rank = torch.empty_like(idx)
-        rank[order] = idx - first
-        meta_i32 = torch.cat([
-            torch.clamp(lens, max=T4).to(torch.int32),                        # klen_enc (B)      (raw lengths)
-            dec_len.to(torch.int32),                                           # klen_dec (B)
-            (pos < lens.unsqueeze(1)).to(torch.int32).reshape(-1),             # keep_enc (B*T4)
-            (~is_pad).to(torch.int32).reshape(-1),                             # keep_dec (B*Td)
-            rank.to(torch.int32)])                                             # embed_rank (B*Td)
-        dev_i32 = self.buf('meta_i32', (meta_i32.numel(),), torch.int32)
-        dev_i32.copy_(meta_i32, non_blocking=True)
-        ids = self.buf('ids', (2, B, Td), torch.int64)
-        ids.copy_(torch.stack([seq_in, seq_out]), non_blocking=True)
-        klen_enc = dev_i32.data_ptr()
-        klen_dec = klen_enc + 4 * B
-        keep_enc = klen_dec + 4 * B
-        keep_dec = keep_enc + 4 * B * T4
-        embed_rank = keep_dec + 4 * B * Td
-        n_nonpad = int((seq_out != PAD_ID).sum())
+        Td, ids, n_nonpad = meta['Td'], meta['ids'], meta['n_nonpad']
+        klen_enc, klen_dec, keep_enc, keep_dec = meta['klen_enc'], meta['klen_dec'], meta['keep_enc'], meta['keep_dec']
         Me, Md = B * T4, B * Td
 
         # ---- VGG front-end ----
@@ -433,13 +451,12 @@ class PassEngine:
         rowloss = self.buf('rowloss', (Md,))
         loss = self.buf('loss', (1,))
         gold_ptr = ids.data_ptr() + 8 * Md
-        check(lib.mtl_ce_argmax_fwd(st, pred.data_ptr(), gold_ptr, Md, V, V, PAD_ID, float(smoothing), n_nonpad, lse.data_ptr(),
-                                    hyp.data_ptr(), rowloss.data_ptr(), loss.data_ptr()), 'ce_fwd')
-        self.saved = dict(theta=theta, x=x, B=B, T=T, F=F, Td=Td, n_nonpad=n_nonpad, smoothing=float(smoothing),
+        check(lib.mtl_ce_argmax_fwd(st, pred.data_ptr(), gold_ptr, Md, V, V, PAD_ID, float(smoothing), 0, meta['inv_count'],
+                                    lse.data_ptr(), hyp.data_ptr(), rowloss.data_ptr(), loss.data_ptr()), 'ce_fwd')
+        self.saved = dict(theta=theta, x=x, B=B, T=T, F=F, Td=Td, n_nonpad=n_nonpad, smoothing=float(smoothing), meta=meta,
                           klen_enc=klen_enc, klen_dec=klen_dec, keep_enc=keep_enc, keep_dec=keep_dec, dec_last=cur,
-                          embed_rank=embed_rank, embed_passes=int(rank.max()) + 1,
                           enc_inputs=enc_inputs)
-        return dict(pred=pred, gold=ids[1], hyp=hyp, loss=loss, gold_host=seq_out, n_nonpad=n_nonpad)
+        return dict(pred=pred, gold=ids[1], hyp=hyp, loss=loss, gold_host=meta['gold_host'], n_nonpad=n_nonpad)
 
     def backward(self, grad, scale=1.0, dpred=None):
         """Accumulate `scale` * dLoss/dtheta of the LAST forward into the flat buffer `grad` (+=).
@@ -462,9 +479,9 @@ class PassEngine:
         if dpred is None:
             ldd = (V + 3) // 4 * 4        # padded leading dimension -> 16-byte operand loads in the two GEMMs below
             dlog = self.buf('_dpred', (Md, ldd))
-            gold_ptr = A['ids'].data_ptr() + 8 * Md
+            gold_ptr = S['meta']['ids'].data_ptr() + 8 * Md
             check(lib.mtl_ce_bwd(st, A['pred'].data_ptr(), A['lse'].data_ptr(), gold_ptr, Md, V, V, PAD_ID, S['smoothing'],
-                                 float(scale) / S['n_nonpad'], None, dlog.data_ptr(), ldd), 'ce_bwd')
+                                 float(scale), S['meta']['inv_count'], dlog.data_ptr(), ldd), 'ce_bwd')
             dlog_ptr = dlog.data_ptr()
         else:
             ldd = V
@@ -495,7 +512,7 @@ class PassEngine:
             self.mha_bwd('d%d.sa.' % i, P, G, pre + 'self_attn.', dcur.data_ptr(), x_in.data_ptr(), B, Td, x_in.data_ptr(), Td,
                          keep_dec, dnext.data_ptr(), dnext.data_ptr(), True)
             dcur, dnext = dnext, dcur
-        check(lib.mtl_embed_bwd(st, A['ids'].data_ptr(), S['embed_rank'], S['embed_passes'], dcur.data_ptr(),
+        check(lib.mtl_embed_bwd(st, S['meta']['ids'].data_ptr(), S['meta']['embed_first'], S['meta']['embed_next'], dcur.data_ptr(),
                                 g('decoder.trg_embedding.weight'), Md, d, PAD_ID), 'embed_bwd')
 
         # ---- encoder ----

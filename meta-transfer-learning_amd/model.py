@@ -272,7 +272,7 @@ class Transformer(nn.Module):
         eng, A, S = self.engine, self.engine.arena, self.engine.saved
         Md, V = A['pred'].shape[0] * A['pred'].shape[1], A['pred'].shape[2]
         dpred = torch.empty_like(A['pred'])
-        gold_ptr = A['ids'].data_ptr() + 8 * Md
+        gold_ptr = S['meta']['ids'].data_ptr() + 8 * Md
         g = gout.reshape(1).to(torch.float32).contiguous()
         check(eng.lib.mtl_ce_bwd(eng.stream, A['pred'].data_ptr(), A['lse'].data_ptr(), gold_ptr, Md, V, V, 0, S['smoothing'],
                                  1.0 / S['n_nonpad'], g.data_ptr(), dpred.data_ptr(), V), 'ce_bwd')

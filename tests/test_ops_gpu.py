@@ -250,12 +250,14 @@ def test_embed_and_ce(L):
     tg = torch.zeros(V, d).cuda()
     ddo = dev(dout)
     flat = ids.view(-1).tolist()
-    seen, rk = {}, []
-    for v in flat:
-        rk.append(seen.get(v, 0))
-        seen[v] = seen.get(v, 0) + 1
-    drk = torch.tensor(rk, dtype=torch.int32).cuda()
-    assert L.mtl_embed_bwd(st(), dids.data_ptr(), drk.data_ptr(), max(rk) + 1, ddo.data_ptr(), tg.data_ptr(), B * T, d, 0) == 0
+    last, first, nxt = {}, [], [-1] * len(flat)
+    for r, v in enumerate(flat):
+        first.append(0 if v in last else 1)
+        if v in last:
+            nxt[last[v]] = r
+        last[v] = r
+    dfirst, dnext = torch.tensor(first, dtype=torch.int32).cuda(), torch.tensor(nxt, dtype=torch.int32).cuda()
+    assert L.mtl_embed_bwd(st(), dids.data_ptr(), dfirst.data_ptr(), dnext.data_ptr(), ddo.data_ptr(), tg.data_ptr(), B * T, d, 0) == 0
     ref = torch.zeros(V, d).index_add_(0, ids.view(-1), dout)
     assert rel(tg, ref) < 1e-6
     # cross entropy + arg-max (ties -> lowest index; padded rows are all-zero logits)
@@ -273,8 +275,13 @@ def test_embed_and_ce(L):
     lse, hyp = torch.empty(rows).cuda(), torch.empty(rows, dtype=torch.int64).cuda()
     rowloss, loss = torch.empty(rows).cuda(), torch.empty(1).cuda()
     nn_ = int((gold != 0).sum())
-    assert L.mtl_ce_argmax_fwd(st(), dl.data_ptr(), dgold.data_ptr(), rows, V, V, 0, 0.0, nn_, lse.data_ptr(), hyp.data_ptr(),
+    assert L.mtl_ce_argmax_fwd(st(), dl.data_ptr(), dgold.data_ptr(), rows, V, V, 0, 0.0, nn_, None, lse.data_ptr(), hyp.data_ptr(),
                                rowloss.data_ptr(), loss.data_ptr()) == 0
+    inv = torch.tensor([1.0 / nn_]).cuda()
+    loss2 = torch.empty(1).cuda()
+    assert L.mtl_ce_argmax_fwd(st(), dl.data_ptr(), dgold.data_ptr(), rows, V, V, 0, 0.0, 0, inv.data_ptr(), lse.data_ptr(),
+                               hyp.data_ptr(), rowloss.data_ptr(), loss2.data_ptr()) == 0
+    assert abs(float(loss2) - float(loss)) < 1e-6 * float(loss)
     assert abs(float(loss) - float(loss_ref)) < 2e-6 * float(loss_ref)
     assert torch.equal(hyp.cpu(), torch.topk(logits, 1, dim=1)[1].squeeze(1))
     assert int(hyp[5]) == 0 and int(hyp[6]) == 50

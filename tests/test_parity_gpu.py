@@ -317,11 +317,11 @@ def test_two_ranks_sharded_bench_equals_single_rank():
     common = ['--steps', '2', '--warmup', '1', '--tasks', '4', '--k', '2', '--frames', '200', '--labels', '20', '--no-cpu-baseline']
     env = dict(os.environ, MTL_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
     one = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1'] + common, capture_output=True, text=True,
-                         env=env, timeout=600)
+                         env=env, timeout=240)
     assert one.returncode == 0, one.stderr[-2000:]
     two = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
                           '127.0.0.1', '--master-port', '29733', os.path.join(root, 'bench.py'), '--gpus', '2'] + common,
-                         capture_output=True, text=True, env=env, timeout=600)
+                         capture_output=True, text=True, env=env, timeout=240)
     assert two.returncode == 0, two.stderr[-2000:]
     j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith('{')][-1])
     j2 = json.loads([l for l in two.stdout.splitlines() if l.startswith('{')][-1])
