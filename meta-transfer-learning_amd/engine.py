@@ -86,6 +86,7 @@ class PassEngine:
         self.gemm_ws_side = torch.empty(8 << 20, dtype=torch.float32, device=device) if device.type == 'cuda' else None
         self.scratch_side = torch.empty(4 << 20, dtype=torch.float32, device=device) if device.type == 'cuda' else None
         self.on_side = False
+        self.after_conv_hook = None
         self.deferred = []
         self.use_side_stream = True
         self.prof = None    # optional {name: [flops, [(start_event, end_event), ...]]}: HIP events around the conv launches
@@ -413,6 +414,10 @@ class PassEngine:
         am2 = self.buf('am2', (B, T4, F4, 128), torch.uint8)
         check(self.timed('conv7_fwd_pool', cf(T2, F2, 128, 128), lib.mtl_conv3x3_relu_pool_fwd, st, y5.data_ptr(), wf[7].data_ptr(),
                          o('conv.7.bias'), p2.data_ptr(), am2.data_ptr(), B, T2, F2, 128, 128), 'conv7')
+
+        if self.after_conv_hook is not None:      # lets the trainer de-phase concurrent task lanes (see trainer.meta_iteration)
+            hook, self.after_conv_hook = self.after_conv_hook, None
+            hook()
 
         # ---- encoder ----
         wp = self.buf('wp_in', (d, hp.d_in))

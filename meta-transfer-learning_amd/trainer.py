@@ -12,6 +12,7 @@ but the iteration is restructured for the device:
     all-reduce (RCCL over xGMI) before the (replicated, deterministic) Adam step.
 """
 import logging
+import os
 import threading
 import time
 from collections import deque
@@ -137,6 +138,8 @@ def cer_counts(vocab, gold, hyp):
 class TransientTrainer():
     def __init__(self):
         logging.info('Transient Trainer is initialized')
+        self.use_graphs = os.environ.get('MTL_GRAPHS', '1') != '0'
+        self._graphs = {}
 
     # ------------------------------------------------------------------ drop-in single-batch API
     def forward_one_batch(self, model, vocab, src, trg, src_percentages, src_lengths, trg_lengths, smoothing, loss_type,
@@ -177,29 +180,40 @@ class TransientTrainer():
         ready = torch.cuda.Event()
         ready.record(main)
         reads = [None] * len(task_batches)
-        streams = [model.lane_streams[lane] if n_lanes > 1 else main for lane in range(n_lanes)]
+        use_graphs = self.use_graphs and not any(e.prof is not None for e in model.engines)
+        streams = [model.lane_streams[lane] if (n_lanes > 1 or use_graphs) else main for lane in range(n_lanes)]
         for lane in range(n_lanes):
             with torch.cuda.stream(streams[lane]):
                 streams[lane].wait_event(ready)
                 bufs[lane][2].zero_()
+        stagger = os.environ.get('MTL_STAGGER', '0') == '1' and n_lanes > 1
+        phase_ev = torch.cuda.Event() if stagger else None
         for idx, (tx, tsz, _tp, ty, _tl) in enumerate(task_batches):      # enqueue task by task, alternating lanes
             lane = idx % n_lanes
-            g, theta1, G = bufs[lane]
+            eng = model.engines[lane]
             with torch.cuda.stream(streams[lane]):
+                if stagger and idx == 0:
+                    eng.after_conv_hook = lambda: phase_ev.record(torch.cuda.current_stream(dev))
+                if stagger and 0 < idx < n_lanes:
+                    streams[lane].wait_event(phase_ev)        # start this lane half a phase behind lane 0
                 tx = tx.to(dev, non_blocking=True)
-                g.zero_()                                                        # inner_opt.zero_grad()   (:198)
-                out = model.pass_forward(tx, tsz, ty, theta=theta0, smoothing=smoothing, lane=lane)   # (:188)
-                tr_read = _Readback(out, dev)
-                model.pass_backward(g, 1.0, lane=lane)                           # tr_loss.backward()      (:199)
-                if args.clip:
-                    clip_flat_grad_(model, g, args.max_norm, lane=lane)          # (:205-206)
-                inner.theta_prime_from(theta0, g, out=theta1)                    # inner_opt.step()        (:207)
-                out = model.pass_forward(vx, val_batch[1], val_batch[3], theta=theta1, smoothing=smoothing, lane=lane)  # (:215)
-                va_read = _Readback(out, dev)
-                model.pass_backward(g, 1.0 / n_tasks, lane=lane)                 # (val_loss/n).backward(): g += g_val/n (Q1)
-                model._axpy(G, g, 1.0)                                           # add_copy_grad()         (:229)
-                reads[idx] = (tr_read, va_read)
-        if n_lanes > 1:
+                m_tr = eng.prepare(tsz, ty, tx.shape[0], tx.shape[3], slot=0)             # host ints -> static device buffers
+                m_va = eng.prepare(val_batch[1], val_batch[3], vx.shape[0], vx.shape[3], slot=1)
+                slots = self._slots(model, lane, m_tr, m_va)
+                key = (lane, tuple(tx.shape), tuple(vx.shape), m_tr['Td'], m_va['Td'], n_tasks, bool(args.clip),
+                       float(args.max_norm), smoothing, float(inner.param_groups[0]['lr']), theta0.data_ptr())
+                body = lambda xa, xb: self._task_body(model, lane, bufs[lane], theta0, xa, m_tr, xb, m_va, n_tasks, inner, args,
+                                                      smoothing, slots)
+                graph = self._graph_for(key, lane, tx, vx, body, streams[lane]) if use_graphs else None
+                if graph is None:
+                    body(tx, vx)
+                else:
+                    graph['x_tr'].copy_(tx, non_blocking=True)
+                    graph['x_va'].copy_(vx, non_blocking=True)
+                    graph['g'].replay()
+                reads[idx] = (_Readback(dict(gold_host=m_tr['gold_host'], hyp=slots['hyp_tr'], loss=slots['loss_tr']), dev),
+                              _Readback(dict(gold_host=m_va['gold_host'], hyp=slots['hyp_va'], loss=slots['loss_va']), dev))
+        if streams[0] is not main:
             for lane in range(n_lanes):
                 done = torch.cuda.Event()
                 done.record(streams[lane])
@@ -212,6 +226,58 @@ class TransientTrainer():
             for lane in range(1, n_lanes):
                 model._axpy(Gm, bufs[lane][2], 1.0)
         return reads
+
+    def _task_body(self, model, lane, bufs, theta0, x_tr, m_tr, x_va, m_va, n_tasks, inner, args, smoothing, slots):
+        """Kernels of ONE task on the current stream (eager, or recorded into a hipGraph): train pass at theta0, fused inner
+        SGD into theta', validation pass at theta', accumulation into the lane's copy_grad buffer."""
+        eng = model.engines[lane]
+        g, theta1, G = bufs
+        g.zero_()                                                        # inner_opt.zero_grad()   (:198)
+        out = eng.forward_device(theta0, x_tr, m_tr, smoothing)          # meta-train forward      (:188)
+        slots['hyp_tr'].copy_(out['hyp'])
+        slots['loss_tr'].copy_(out['loss'])
+        eng.backward(g, 1.0)                                             # tr_loss.backward()      (:199)
+        if args.clip:
+            clip_flat_grad_(model, g, args.max_norm, lane=lane)          # (:205-206)
+        inner.theta_prime_from(theta0, g, out=theta1)                    # inner_opt.step()        (:207)
+        out = eng.forward_device(theta1, x_va, m_va, smoothing)          # meta-validation forward (:215)
+        slots['hyp_va'].copy_(out['hyp'])
+        slots['loss_va'].copy_(out['loss'])
+        eng.backward(g, 1.0 / n_tasks)                                   # (val_loss/n).backward(): g += g_val/n (Q1)
+        model._axpy(G, g, 1.0)                                           # add_copy_grad()         (:229)
+
+    def _slots(self, model, lane, m_tr, m_va):
+        eng = model.engines[lane]
+        return dict(hyp_tr=eng.buf('slot.hyp_tr', (m_tr['B'], m_tr['Td']), torch.int64), loss_tr=eng.buf('slot.loss_tr', (1,)),
+                    hyp_va=eng.buf('slot.hyp_va', (m_va['B'], m_va['Td']), torch.int64), loss_va=eng.buf('slot.loss_va', (1,)))
+
+    def _graph_for(self, key, lane, tx, vx, body, stream):
+        """hipGraph of a task body, keyed by everything baked into it (shapes, scalars, buffer addresses).  First sighting of
+        a key -> None (the eager run is the warm-up that allocates every buffer); second sighting -> capture; then replay.
+        The per-launch Python/ctypes cost (~7 us x ~1400 launches per task) disappears from the loop."""
+        ent = self._graphs.get(key)
+        if ent is None:
+            if len(self._graphs) >= 32:
+                return None
+            self._graphs[key] = 'warm'
+            return None
+        if ent == 'warm':
+            try:
+                x_tr, x_va = torch.empty_like(tx), torch.empty_like(vx)
+                x_tr.copy_(tx)
+                x_va.copy_(vx)
+                stream.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=stream):
+                    body(x_tr, x_va)
+                ent = dict(g=g, x_tr=x_tr, x_va=x_va)
+            except Exception as exc:                                      # capture unsupported -> stay eager, loudly
+                logging.warning('hipGraph capture failed (%s); task body stays eager', exc)
+                print('WARNING: hipGraph capture failed, running eagerly:', exc, flush=True)
+                torch.cuda.synchronize()
+                ent = 'eager'
+            self._graphs[key] = ent
+        return ent if isinstance(ent, dict) else None
 
     def _lane_buffers(self, model, n_lanes):
         """(grad, theta', G) per lane; lane 0 uses the model's own flat_grad / copy_grad buffers when it is the only lane."""
