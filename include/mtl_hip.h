@@ -77,27 +77,39 @@ int mtl_permute_hc(void* stream, const float* src, float* dst, int rows, int C, 
  * nn.LayerNorm eps inside the sqrt, biased variance (modules/common_layers.py:131,304; modules/encoder.py:72-73)
  * with the non_pad_mask multiplies of modules/encoder.py:101,104 and modules/decoder.py:314,318,321 fused.
  * d in {64,128,256,512,1024}.  Saves xhat (rows x d) and rstd (rows) for the backward. */
+/* xmask (nullable u8 keep-mask of x, from mtl_dropout_mask) / xscale = 1/(1-p): dropout of the sub-layer output BEFORE the
+ * residual add (modules/common_layers.py:130,303). */
 int mtl_layernorm_fwd(void* stream, const float* x, const float* residual, const float* gamma, const float* beta,
-                      const float* pe, const int* keep, float* y, float* xhat, float* rstd, int rows, int d, int T,
-                      float eps);
+                      const float* pe, const int* keep, const unsigned char* xmask, float xscale, float* y, float* xhat,
+                      float* rstd, int rows, int d, int T, float eps);
 long mtl_layernorm_bwd_workspace(int rows, int d);
+/* with xmask: dz is the residual-branch gradient and dzm = dz * mask * xscale the sub-layer-branch gradient (dsum sums dzm) */
 int mtl_layernorm_bwd(void* stream, const float* dy, const float* xhat, const float* rstd, const float* gamma,
-                      const int* keep, float* dz, float* dgamma /*accum*/, float* dbeta /*accum*/,
-                      float* dsum /*nullable, accum: += column sums of dz (bias gradient of the producing linear)*/,
+                      const int* keep, const unsigned char* xmask, float xscale, float* dz, float* dzm /*nullable*/,
+                      float* dgamma /*accum*/, float* dbeta /*accum*/,
+                      float* dsum /*nullable, accum: += column sums of the sub-layer-branch gradient (its linear's bias grad)*/,
                       float* workspace, int rows, int d);
 
 /* ---- masked softmax: modules/common_layers.py:322-327.  S is [B][H][Tq][ld], in place.
  * keys k >= klen[b] (klen nullable) and, if causal, k > q are filled with -inf before the softmax. */
+/* pmask (nullable u8 keep-mask, same [B][H][Tq][ld] layout) / pscale: dropout on the probabilities (common_layers.py:328);
+ * P stays un-dropped in S (needed by the backward), the dropped copy that feeds P.V is written to P_dropped. */
 int mtl_softmax_mask_fwd(void* stream, float* S, const int* klen, int causal, float scale, int B, int H, int Tq, int Tk,
-                         int ld);
-int mtl_softmax_bwd(void* stream, const float* P, float* dP /*in place -> dS*/, float scale, long rows, int Tk, int ld);
+                         int ld, const unsigned char* pmask, float pscale, float* P_dropped);
+int mtl_softmax_bwd(void* stream, const float* P, float* dP /*in place -> dS*/, float scale, long rows, int Tk, int ld,
+                    const unsigned char* pmask, float pscale);
 
 /* ---- embedding + positional encoding: modules/decoder.py:96 ------------------------------------------- */
-int mtl_embed_pe_fwd(void* stream, const long* ids, const float* table, const float* pe, float* out, int rows, int T, int d);
+int mtl_embed_pe_fwd(void* stream, const long* ids, const float* table, const float* pe, float* out, int rows, int T, int d,
+                     const unsigned char* mask /*nullable: dropout keep-mask*/, float mscale);
 /* first[r] = 1 if no earlier row has ids[r]; next[r] = next row with the same id or -1 (both host-built): duplicates are
  * summed in row order by the thread of the chain head, so the scatter-add is one launch, parallel AND deterministic. */
 int mtl_embed_bwd(void* stream, const long* ids, const int* first, const int* next, const float* dout,
-                  float* dtable /*accum*/, int rows, int d, long pad_id);
+                  float* dtable /*accum*/, int rows, int d, long pad_id, const unsigned char* mask, float mscale);
+
+/* ---- dropout keep-masks: keep[i] = 1 with probability 1-p, Philox4x32-10(counter = offset + i/4, key = *seed_dev).
+ * Active sites in the meta loop (model.train()): modules/decoder.py:96, modules/common_layers.py:130,303,328. */
+int mtl_dropout_mask(void* stream, unsigned char* keep, long n, float p, const long* seed_dev, unsigned long long offset);
 
 /* ---- cross-entropy + arg-max: utils/metrics.py:113-126, models/asr/transformer.py:146-147 ----------------
  * loss_out[0] = sum_rows(gold!=pad ? -log softmax(logits)[gold] : 0) / n_nonpad ; hyp = lowest arg-max index. */

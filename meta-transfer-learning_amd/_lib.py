@@ -27,13 +27,14 @@ SIGNATURES = {
     'mtl_conv3x3_wgrad_workspace': (L, [I, I, I, I, I, I]),
     'mtl_conv3x3_wgrad': (I, [P, P, P, P, P, P, L, I, I, I, I, I]),
     'mtl_permute_hc': (I, [P, P, P, I, I, I, I]),
-    'mtl_layernorm_fwd': (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, F]),
+    'mtl_layernorm_fwd': (I, [P, P, P, P, P, P, P, P, F, P, P, P, I, I, I, F]),
     'mtl_layernorm_bwd_workspace': (L, [I, I]),
-    'mtl_layernorm_bwd': (I, [P, P, P, P, P, P, P, P, P, P, P, I, I]),
-    'mtl_softmax_mask_fwd': (I, [P, P, P, I, F, I, I, I, I, I]),
-    'mtl_softmax_bwd': (I, [P, P, P, F, L, I, I]),
-    'mtl_embed_pe_fwd': (I, [P, P, P, P, P, I, I, I]),
-    'mtl_embed_bwd': (I, [P, P, P, P, P, P, I, I, L]),
+    'mtl_layernorm_bwd': (I, [P, P, P, P, P, P, P, F, P, P, P, P, P, P, I, I]),
+    'mtl_softmax_mask_fwd': (I, [P, P, P, I, F, I, I, I, I, I, P, F, P]),
+    'mtl_softmax_bwd': (I, [P, P, P, F, L, I, I, P, F]),
+    'mtl_embed_pe_fwd': (I, [P, P, P, P, P, I, I, I, P, F]),
+    'mtl_embed_bwd': (I, [P, P, P, P, P, P, I, I, L, P, F]),
+    'mtl_dropout_mask': (I, [P, P, L, F, P, ctypes.c_ulonglong]),
     'mtl_ce_argmax_fwd': (I, [P, P, P, I, I, I, L, F, I, P, P, P, P, P]),
     'mtl_ce_bwd': (I, [P, P, P, P, I, I, I, L, F, F, P, P, I]),
     'mtl_colsum_workspace': (L, [L, I]),

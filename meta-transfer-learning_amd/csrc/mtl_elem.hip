@@ -93,12 +93,44 @@ __global__ void sum_final_kernel(const float* __restrict__ part, int np, float* 
     }
 }
 
+// ------------------------------------------------------------------ dropout keep-masks (Philox4x32-10, counter based)
+// keep[i] = 1 with probability 1-p.  The 64-bit seed is read from DEVICE memory so that a captured hipGraph draws fresh
+// masks on every replay; `offset` separates the dropout sites of one pass.  (reference sites: modules/decoder.py:96,
+// modules/common_layers.py:130,303,328 -- active because the meta loop runs in model.train())
+__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c.x;
+        const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c.z;
+        c = make_uint4((unsigned)(p1 >> 32) ^ c.y ^ k.x, (unsigned)p1, (unsigned)(p0 >> 32) ^ c.w ^ k.y, (unsigned)p0);
+        k.x += 0x9E3779B9u;
+        k.y += 0xBB67AE85u;
+    }
+    return c;
+}
+__global__ void dropout_mask_kernel(uint8_t* __restrict__ keep, long n, unsigned thresh, const long* __restrict__ seed_dev,
+                                    unsigned long long offset) {
+    const unsigned long long seed = (unsigned long long)*seed_dev;
+    const uint2 key = make_uint2((unsigned)seed, (unsigned)(seed >> 32));
+    const long n4 = (n + 3) / 4;
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += (long)gridDim.x * blockDim.x) {
+        const unsigned long long ctr = offset + (unsigned long long)q;
+        const uint4 r = philox4x32_10(make_uint4((unsigned)ctr, (unsigned)(ctr >> 32), 0u, 0u), key);
+        const long i = q * 4;
+        if (i < n) keep[i] = r.x >= thresh;
+        if (i + 1 < n) keep[i + 1] = r.y >= thresh;
+        if (i + 2 < n) keep[i + 2] = r.z >= thresh;
+        if (i + 3 < n) keep[i + 3] = r.w >= thresh;
+    }
+}
+
 // ------------------------------------------------------------------ LayerNorm (+residual, +positional table, *row keep)
 // one wave per row; d is a multiple of 64 up to 1024 (NPL = d/64 values per lane, lane-strided so loads coalesce)
 template <int NPL>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             const float* __restrict__ pe, const int* __restrict__ keep,
+                                                            const uint8_t* __restrict__ xmask, float xscale,
                                                             float* __restrict__ y, float* __restrict__ xhat,
                                                             float* __restrict__ rstd, int rows, int T, float eps) {
     constexpr int D = NPL * 64;
@@ -111,6 +143,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     for (int i = 0; i < NPL; ++i) {
         const int c = i * 64 + lane;
         float t = x[(long)row * D + c];
+        if (xmask) t = xmask[(long)row * D + c] ? t * xscale : 0.f;      // dropout on the sub-layer output, before the residual
         if (res) t += res[(long)row * D + c];
         v[i] = t;
         s += t;
@@ -141,7 +174,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 template <int NPL>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ xhat,
                                                             const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                            const int* __restrict__ keep, float* __restrict__ dz,
+                                                            const int* __restrict__ keep, const uint8_t* __restrict__ xmask,
+                                                            float xscale, float* __restrict__ dz, float* __restrict__ dzm,
                                                             float* __restrict__ part, int rows, int rows_per_wave) {
     constexpr int D = NPL * 64;
     const int lane = threadIdx.x & 63;
@@ -177,7 +211,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         for (int i = 0; i < NPL; ++i) {
             const float o = rs * (g[i] - s1 - h[i] * s2);
             dz[(long)row * D + i * 64 + lane] = o;
-            az[i] += o;
+            float om = o;
+            if (xmask) {                                   // gradient of the dropped sub-layer branch (residual branch gets dz)
+                om = xmask[(long)row * D + i * 64 + lane] ? o * xscale : 0.f;
+                dzm[(long)row * D + i * 64 + lane] = om;
+            }
+            az[i] += om;
         }
     }
 #pragma unroll
@@ -209,7 +248,9 @@ __global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __res
 // ------------------------------------------------------------------ masked softmax over keys, one wave per (b,h,q) row
 // P = softmax(S*scale) with keys k >= klen[b] (and k > q when causal) filled with -inf.   In place.
 __global__ __launch_bounds__(256) void softmax_fwd_kernel(float* __restrict__ S, const int* __restrict__ klen, int causal,
-                                                          float scale, int H, int Tq, int Tk, int ld, long rows) {
+                                                          float scale, int H, int Tq, int Tk, int ld, long rows,
+                                                          const uint8_t* __restrict__ pmask, float pscale,
+                                                          float* __restrict__ Pd) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -225,42 +266,57 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(float* __restrict__ S,
     for (int k = lane; k < lim; k += 64) sum += expf(s[k] * scale - mx);
     sum = wave_sum(sum);
     const float inv = 1.f / sum;
-    for (int k = lane; k < Tk; k += 64) s[k] = k < lim ? expf(s[k] * scale - mx) * inv : 0.f;
+    for (int k = lane; k < Tk; k += 64) {
+        const float p = k < lim ? expf(s[k] * scale - mx) * inv : 0.f;
+        s[k] = p;
+        if (pmask) Pd[row * ld + k] = pmask[row * ld + k] ? p * pscale : 0.f;     // dropped copy feeds P.V; P itself feeds the bwd
+    }
 }
 // dS = P * (dP - sum_k dP*P) * scale, in place on dP
 __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ P, float* __restrict__ dP, float scale,
-                                                          int Tk, int ld, long rows) {
+                                                          int Tk, int ld, long rows, const uint8_t* __restrict__ pmask,
+                                                          float pscale) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const float* p = P + row * ld;
     float* d = dP + row * ld;
+    const uint8_t* m = pmask ? pmask + row * ld : nullptr;
     float dot = 0.f;
-    for (int k = lane; k < Tk; k += 64) dot += p[k] * d[k];
+    for (int k = lane; k < Tk; k += 64) {
+        if (m) d[k] = m[k] ? d[k] * pscale : 0.f;           // gradient through the dropout on the probabilities
+        dot += p[k] * d[k];
+    }
     dot = wave_sum(dot);
     for (int k = lane; k < Tk; k += 64) d[k] = p[k] * (d[k] - dot) * scale;
 }
 
 // ------------------------------------------------------------------ embedding + positional encoding
 __global__ void embed_pe_fwd_kernel(const long* __restrict__ ids, const float* __restrict__ table, const float* __restrict__ pe,
-                                    float* __restrict__ out, int rows, int T, int d) {
+                                    float* __restrict__ out, int rows, int T, int d, const uint8_t* __restrict__ mask, float mscale) {
     const long total = (long)rows * d;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
         const int r = (int)(e / d), c = (int)(e - (long)r * d);
-        out[e] = table[ids[r] * d + c] + pe[(long)(r % T) * d + c];
+        float v = table[ids[r] * d + c] + pe[(long)(r % T) * d + c];
+        if (mask) v = mask[e] ? v * mscale : 0.f;
+        out[e] = v;
     }
 }
 // Scatter-add with duplicate ids, deterministic, ONE launch: `next[r]` (host-built) links row r to the next row with the
 // same id (-1 = last) and `first[r]` marks chain heads; the thread of (head row, column) walks its chain in row order.
 __global__ void embed_bwd_kernel(const long* __restrict__ ids, const int* __restrict__ first, const int* __restrict__ next,
-                                 const float* __restrict__ dout, float* __restrict__ dtable, int rows, int d, long pad_id) {
+                                 const float* __restrict__ dout, float* __restrict__ dtable, int rows, int d, long pad_id,
+                                 const uint8_t* __restrict__ mask, float mscale) {
     const long total = (long)rows * d;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
         const int r = (int)(e / d), c = (int)(e - (long)r * d);
         const long id = ids[r];
         if (id == pad_id || !first[r]) continue;
         float acc = 0.f;
-        for (int q = r; q >= 0; q = next[q]) acc += dout[(long)q * d + c];
+        for (int q = r; q >= 0; q = next[q]) {
+            const float v = dout[(long)q * d + c];
+            acc += mask ? (mask[(long)q * d + c] ? v * mscale : 0.f) : v;
+        }
         dtable[id * d + c] += acc;
     }
 }
@@ -519,6 +575,15 @@ int mtl_axpy(void* stream, float* y, const float* x, float a, long n) {
     return MTL_OK;
 }
 
+int mtl_dropout_mask(void* stream, unsigned char* keep, long n, float p, const long* seed_dev, unsigned long long offset) {
+    if (!keep || !seed_dev || n <= 0 || !(p >= 0.f && p < 1.f)) return MTL_EINVAL;
+    const unsigned thresh = (unsigned)((double)p * 4294967296.0);
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for((n + 3) / 4, 256, 2048)), dim3(256), 0, as_stream(stream), keep, n, thresh,
+                       seed_dev, offset);
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}
+
 int mtl_copy_f32(void* stream, float* dst, const float* src, long n) {
     if (!dst || !src || n <= 0) return MTL_EINVAL;
     return hipMemcpyAsync(dst, src, (size_t)n * 4, hipMemcpyDeviceToDevice, as_stream(stream)) == hipSuccess ? MTL_OK : MTL_ELAUNCH;
@@ -552,13 +617,13 @@ int mtl_sumsq(void* stream, const float* x, long n, float* out, float* workspace
 }
 
 int mtl_layernorm_fwd(void* stream, const float* x, const float* residual, const float* gamma, const float* beta,
-                      const float* pe, const int* keep, float* y, float* xhat, float* rstd, int rows, int d, int T,
-                      float eps) {
+                      const float* pe, const int* keep, const unsigned char* xmask, float xscale, float* y, float* xhat,
+                      float* rstd, int rows, int d, int T, float eps) {
     if (!x || !gamma || !beta || !y || !xhat || !rstd || rows <= 0) return MTL_EINVAL;
     dim3 grid((rows + 3) / 4), block(256);
     hipStream_t s = as_stream(stream);
 #define LN_FWD(N) \
-    hipLaunchKernelGGL(layernorm_fwd_kernel<N>, grid, block, 0, s, x, residual, gamma, beta, pe, keep, y, xhat, rstd, rows, T > 0 ? T : 1, eps)
+    hipLaunchKernelGGL(layernorm_fwd_kernel<N>, grid, block, 0, s, x, residual, gamma, beta, pe, keep, xmask, xscale, y, xhat, rstd, rows, T > 0 ? T : 1, eps)
     switch (d) {
         case 64: LN_FWD(1); break;
         case 128: LN_FWD(2); break;
@@ -578,13 +643,14 @@ long mtl_layernorm_bwd_workspace(int rows, int d) {
 }
 
 int mtl_layernorm_bwd(void* stream, const float* dy, const float* xhat, const float* rstd, const float* gamma,
-                      const int* keep, float* dz, float* dgamma, float* dbeta, float* dsum, float* workspace, int rows, int d) {
-    if (!dy || !xhat || !rstd || !gamma || !dz || !dgamma || !dbeta || !workspace || rows <= 0) return MTL_EINVAL;
+                      const int* keep, const unsigned char* xmask, float xscale, float* dz, float* dzm, float* dgamma,
+                      float* dbeta, float* dsum, float* workspace, int rows, int d) {
+    if (!dy || !xhat || !rstd || !gamma || !dz || !dgamma || !dbeta || !workspace || rows <= 0 || (xmask && !dzm)) return MTL_EINVAL;
     const int rpw = 8;
     const int waves = ((rows + rpw - 1) / rpw + 3) / 4 * 4;
     dim3 grid(waves / 4), block(256);
     hipStream_t s = as_stream(stream);
-#define LN_BWD(N) hipLaunchKernelGGL(layernorm_bwd_kernel<N>, grid, block, 0, s, dy, xhat, rstd, gamma, keep, dz, workspace, rows, rpw)
+#define LN_BWD(N) hipLaunchKernelGGL(layernorm_bwd_kernel<N>, grid, block, 0, s, dy, xhat, rstd, gamma, keep, xmask, xscale, dz, dzm, workspace, rows, rpw)
     switch (d) {
         case 64: LN_BWD(1); break;
         case 128: LN_BWD(2); break;
@@ -600,36 +666,38 @@ int mtl_layernorm_bwd(void* stream, const float* dy, const float* xhat, const fl
 }
 
 int mtl_softmax_mask_fwd(void* stream, float* S, const int* klen, int causal, float scale, int B, int H, int Tq, int Tk,
-                         int ld) {
-    if (!S || B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0 || ld < Tk) return MTL_EINVAL;
+                         int ld, const unsigned char* pmask, float pscale, float* P_dropped) {
+    if (!S || B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0 || ld < Tk || (pmask && !P_dropped)) return MTL_EINVAL;
     const long rows = (long)B * H * Tq;
     hipLaunchKernelGGL(softmax_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, as_stream(stream), S, klen, causal,
-                       scale, H, Tq, Tk, ld, rows);
+                       scale, H, Tq, Tk, ld, rows, pmask, pscale, P_dropped);
     MTL_CHECK_LAUNCH();
     return MTL_OK;
 }
 
-int mtl_softmax_bwd(void* stream, const float* P, float* dP, float scale, long rows, int Tk, int ld) {
+int mtl_softmax_bwd(void* stream, const float* P, float* dP, float scale, long rows, int Tk, int ld, const unsigned char* pmask,
+                    float pscale) {
     if (!P || !dP || rows <= 0 || Tk <= 0 || ld < Tk) return MTL_EINVAL;
     hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, as_stream(stream), P, dP, scale, Tk,
-                       ld, rows);
+                       ld, rows, pmask, pscale);
     MTL_CHECK_LAUNCH();
     return MTL_OK;
 }
 
-int mtl_embed_pe_fwd(void* stream, const long* ids, const float* table, const float* pe, float* out, int rows, int T, int d) {
+int mtl_embed_pe_fwd(void* stream, const long* ids, const float* table, const float* pe, float* out, int rows, int T, int d,
+                     const unsigned char* mask, float mscale) {
     if (!ids || !table || !pe || !out || rows <= 0 || T <= 0) return MTL_EINVAL;
     hipLaunchKernelGGL(embed_pe_fwd_kernel, dim3(grid_for((long)rows * d, 256, 2048)), dim3(256), 0, as_stream(stream), ids,
-                       table, pe, out, rows, T, d);
+                       table, pe, out, rows, T, d, mask, mscale);
     MTL_CHECK_LAUNCH();
     return MTL_OK;
 }
 
 int mtl_embed_bwd(void* stream, const long* ids, const int* first, const int* next, const float* dout, float* dtable, int rows,
-                  int d, long pad_id) {
+                  int d, long pad_id, const unsigned char* mask, float mscale) {
     if (!ids || !first || !next || !dout || !dtable || rows <= 0) return MTL_EINVAL;
     hipLaunchKernelGGL(embed_bwd_kernel, dim3(grid_for((long)rows * d, 256, 2048)), dim3(256), 0, as_stream(stream), ids, first,
-                       next, dout, dtable, rows, d, pad_id);
+                       next, dout, dtable, rows, d, pad_id, mask, mscale);
     MTL_CHECK_LAUNCH();
     return MTL_OK;
 }

@@ -86,6 +86,8 @@ class PassEngine:
         self.gemm_ws_side = torch.empty(8 << 20, dtype=torch.float32, device=device) if device.type == 'cuda' else None
         self.scratch_side = torch.empty(4 << 20, dtype=torch.float32, device=device) if device.type == 'cuda' else None
         self.on_side = False
+        self.dropout_p = 0.0          # set by the model: hp.dropout when model.training else 0
+        self._site = 0                # dropout site counter of the current pass (Philox offset = site << 40)
         self.after_conv_hook = None
         self.deferred = []
         self.use_side_stream = True
@@ -187,14 +189,29 @@ class PassEngine:
         ws = self.scratch(self.lib.mtl_colsum_workspace(rows, cols))
         check(self.lib.mtl_colsum_accum(self.stream, x, rows, cols, cols, out, ws), 'mtl_colsum_accum')
 
-    def ln_fwd(self, x, res, g, b, pe, keep, y, xhat, rstd, rows, T):
-        check(self.lib.mtl_layernorm_fwd(self.stream, x, res, g, b, pe, keep, y, xhat, rstd, rows, self.hp.d, T, 1e-5),
-              'mtl_layernorm_fwd')
+    def drop_mask(self, name, shape):
+        """u8 keep-mask for one dropout site of this pass (None when dropout is off); fresh Philox stream per site."""
+        if self.dropout_p <= 0.0:
+            self.arena.pop(name, None)
+            return None
+        m = self.buf(name, shape, torch.uint8)
+        self._site += 1
+        check(self.lib.mtl_dropout_mask(self.stream, m.data_ptr(), m.numel(), float(self.dropout_p), self._seed_ptr,
+                                        self._site << 40), 'mtl_dropout_mask')
+        return m
 
-    def ln_bwd(self, dy, xhat, rstd, g, keep, dz, dg, db, rows, dsum=None):
+    @property
+    def drop_scale(self):
+        return 1.0 / (1.0 - self.dropout_p)
+
+    def ln_fwd(self, x, res, g, b, pe, keep, y, xhat, rstd, rows, T, xmask=None):
+        check(self.lib.mtl_layernorm_fwd(self.stream, x, res, g, b, pe, keep, xmask.data_ptr() if xmask is not None else None,
+                                         self.drop_scale, y, xhat, rstd, rows, self.hp.d, T, 1e-5), 'mtl_layernorm_fwd')
+
+    def ln_bwd(self, dy, xhat, rstd, g, keep, dz, dg, db, rows, dsum=None, xmask=None, dzm=None):
         ws = self.scratch(self.lib.mtl_layernorm_bwd_workspace(rows, self.hp.d))
-        check(self.lib.mtl_layernorm_bwd(self.stream, dy, xhat, rstd, g, keep, dz, dg, db, dsum, ws, rows, self.hp.d),
-              'mtl_layernorm_bwd')
+        check(self.lib.mtl_layernorm_bwd(self.stream, dy, xhat, rstd, g, keep, xmask.data_ptr() if xmask is not None else None,
+                                         self.drop_scale, dz, dzm, dg, db, dsum, ws, rows, self.hp.d), 'mtl_layernorm_bwd')
 
     # ---------------------------------------------------------------- attention / ffn blocks
     def mha_fwd(self, tag, P, pre, xq, Bn, Tq, xkv, Tk, klen, causal, keep):
@@ -216,10 +233,13 @@ class PassEngine:
         S = self.buf(tag + 'P', (Bn, h, Tq, ldS))
         self.gemm(0, 1, Tq, Tk, dk, t['q'].data_ptr(), hk, t['k'].data_ptr(), hk, S.data_ptr(), ldS, batch=Bn * h, H=h,
                   sA=(Tq * hk, dk), sB=(Tk * hk, dk), sC=(h * Tq * ldS, Tq * ldS))
+        mP = self.drop_mask(tag + 'mP', (Bn, h, Tq, ldS))                       # dropout on the probabilities (:328)
+        Pd = self.buf(tag + 'Pd', (Bn, h, Tq, ldS)) if mP is not None else S
         check(self.lib.mtl_softmax_mask_fwd(self.stream, S.data_ptr(), klen, causal, 1.0 / float(hp.temperature), Bn, h, Tq,
-                                            Tk, ldS), 'mtl_softmax_mask_fwd')
+                                            Tk, ldS, mP.data_ptr() if mP is not None else None, self.drop_scale,
+                                            Pd.data_ptr() if mP is not None else None), 'mtl_softmax_mask_fwd')
         O = self.buf(tag + 'O', (Mq, hv))
-        self.gemm(0, 0, Tq, dv, Tk, S.data_ptr(), ldS, t['v'].data_ptr(), hv, O.data_ptr(), hv, batch=Bn * h, H=h,
+        self.gemm(0, 0, Tq, dv, Tk, Pd.data_ptr(), ldS, t['v'].data_ptr(), hv, O.data_ptr(), hv, batch=Bn * h, H=h,
                   sA=(h * Tq * ldS, Tq * ldS), sB=(Tk * hv, dv), sC=(Tq * hv, dv))
         oa = self.buf(tag + 'oa', (Mq, r))
         ob = self.buf(tag + 'ob', (Mq, d))
@@ -228,8 +248,9 @@ class PassEngine:
         y = self.buf(tag + 'y', (Mq, d))
         xhat = self.buf(tag + 'xhat', (Mq, d))
         rstd = self.buf(tag + 'rstd', (Mq,))
+        mo = self.drop_mask(tag + 'mo', (Mq, d))                                # dropout before the residual add (:303)
         self.ln_fwd(ob.data_ptr(), xq, o('layer_norm.weight'), o('layer_norm.bias'), None, keep, y.data_ptr(),
-                    xhat.data_ptr(), rstd.data_ptr(), Mq, Tq)
+                    xhat.data_ptr(), rstd.data_ptr(), Mq, Tq, xmask=mo)
         return y
 
     def mha_bwd(self, tag, P, G, pre, dy, xq, Bn, Tq, xkv, Tk, keep, dxq, dxkv, dxkv_accum):
@@ -244,10 +265,13 @@ class PassEngine:
         Pm, O, oa = A[tag + 'P'], A[tag + 'O'], A[tag + 'oa']
         # LayerNorm(o + residual) * keep
         dzb = self.buf(tag + '_dz', (Mq, d))       # kept intact for the deferred dW GEMM; dxq = dz + projections
+        mo, mP = A.get(tag + 'mo'), A.get(tag + 'mP')
+        dzm = self.buf(tag + '_dzm', (Mq, d)) if mo is not None else None
         self.ln_bwd(dy, A[tag + 'xhat'].data_ptr(), A[tag + 'rstd'].data_ptr(), o('layer_norm.weight'), keep, dzb.data_ptr(),
-                    g('layer_norm.weight'), g('layer_norm.bias'), Mq, dsum=g('output_linear_b.bias'))
-        dz = dzb.data_ptr()
-        check(self.lib.mtl_copy_f32(self.stream, dxq, dz, Mq * d), 'mtl_copy_f32')   # residual path
+                    g('layer_norm.weight'), g('layer_norm.bias'), Mq, dsum=g('output_linear_b.bias'), xmask=mo,
+                    dzm=dzm.data_ptr() if dzm is not None else None)
+        check(self.lib.mtl_copy_f32(self.stream, dxq, dzb.data_ptr(), Mq * d), 'mtl_copy_f32')   # residual path
+        dz = dzm.data_ptr() if dzm is not None else dzb.data_ptr()          # gradient of the (dropped) sub-layer branch
         doa = self.buf(tag + '_doa', (Mq, r))
         self.linear_bwd(oa.data_ptr(), dz, Mq, r, d, o('output_linear_b.weight'), g('output_linear_b.weight'),
                         None, doa.data_ptr(), False)
@@ -261,12 +285,14 @@ class PassEngine:
         dP = self.buf('_dP', (Bn, h, Tq, ldS))
         sP = (h * Tq * ldS, Tq * ldS)
         # dV = P^T dO ; dP = dO V^T ; dS = softmax'(P, dP)/temp ; dQ = dS K ; dK = dS^T Q
-        self.gemm(1, 0, Tk, dv, Tq, Pm.data_ptr(), ldS, dO.data_ptr(), hv, dvv.data_ptr(), hv, batch=Bn * h, H=h,
+        Pv = A[tag + 'Pd'] if mP is not None else Pm                      # the probabilities that actually multiplied V
+        self.gemm(1, 0, Tk, dv, Tq, Pv.data_ptr(), ldS, dO.data_ptr(), hv, dvv.data_ptr(), hv, batch=Bn * h, H=h,
                   sA=sP, sB=(Tq * hv, dv), sC=(Tk * hv, dv))
         self.gemm(0, 1, Tq, Tk, dv, dO.data_ptr(), hv, v.data_ptr(), hv, dP.data_ptr(), ldS, batch=Bn * h, H=h,
                   sA=(Tq * hv, dv), sB=(Tk * hv, dv), sC=sP)
         check(self.lib.mtl_softmax_bwd(self.stream, Pm.data_ptr(), dP.data_ptr(), 1.0 / float(hp.temperature),
-                                       Bn * h * Tq, Tk, ldS), 'mtl_softmax_bwd')
+                                       Bn * h * Tq, Tk, ldS, mP.data_ptr() if mP is not None else None, self.drop_scale),
+              'mtl_softmax_bwd')
         self.gemm(0, 0, Tq, dk, Tk, dP.data_ptr(), ldS, k.data_ptr(), hk, dq.data_ptr(), hk, batch=Bn * h, H=h,
                   sA=sP, sB=(Tk * hk, dk), sC=(Tq * hk, dk))
         self.gemm(1, 0, Tk, dk, Tq, dP.data_ptr(), ldS, q.data_ptr(), hk, dkk.data_ptr(), hk, batch=Bn * h, H=h,
@@ -297,8 +323,9 @@ class PassEngine:
         y = self.buf(tag + 'y', (rows, hp.d))
         xhat = self.buf(tag + 'xhat', (rows, hp.d))
         rstd = self.buf(tag + 'rstd', (rows,))
+        mf = self.drop_mask(tag + 'mf', (rows, hp.d))                           # dropout before the residual add (:130)
         self.ln_fwd(h2.data_ptr(), x, o('layer_norm.weight'), o('layer_norm.bias'), None, keep, y.data_ptr(), xhat.data_ptr(),
-                    rstd.data_ptr(), rows, T)
+                    rstd.data_ptr(), rows, T, xmask=mf)
         return y
 
     def ffn_bwd(self, tag, P, G, pre, dy, x, rows, keep, dx):
@@ -306,12 +333,16 @@ class PassEngine:
         o = lambda n: P + 4 * L.off(pre + n)
         g = lambda n: G + 4 * L.off(pre + n)
         dzb = self.buf(tag + '_dz', (rows, hp.d))
+        mf = A.get(tag + 'mf')
+        dzm = self.buf(tag + '_dzm', (rows, hp.d)) if mf is not None else None
         self.ln_bwd(dy, A[tag + 'xhat'].data_ptr(), A[tag + 'rstd'].data_ptr(), o('layer_norm.weight'), keep, dzb.data_ptr(),
-                    g('layer_norm.weight'), g('layer_norm.bias'), rows, dsum=g('linear_2.bias'))
+                    g('layer_norm.weight'), g('layer_norm.bias'), rows, dsum=g('linear_2.bias'), xmask=mf,
+                    dzm=dzm.data_ptr() if dzm is not None else None)
         check(self.lib.mtl_copy_f32(self.stream, dx, dzb.data_ptr(), rows * hp.d), 'mtl_copy_f32')   # residual path
+        dbr = dzm.data_ptr() if dzm is not None else dzb.data_ptr()
         h1 = A[tag + 'h1']
         dh1 = self.buf(tag + '_dh1', (rows, hp.inner))
-        self.linear_bwd(h1.data_ptr(), dzb.data_ptr(), rows, hp.inner, hp.d, o('linear_2.weight'), g('linear_2.weight'),
+        self.linear_bwd(h1.data_ptr(), dbr, rows, hp.inner, hp.d, o('linear_2.weight'), g('linear_2.weight'),
                         None, dh1.data_ptr(), False, gate=h1.data_ptr())
         self.linear_bwd(x, dh1.data_ptr(), rows, hp.d, hp.inner, o('linear_1.weight'), g('linear_1.weight'),
                         g('linear_1.bias'), dx, True)
@@ -346,24 +377,27 @@ class PassEngine:
         nxt[order[:-1]] = torch.where(same_as_prev[1:], order[1:], torch.full_like(order[1:], -1)).to(torch.int32)
         n_nonpad = int((seq_out != PAD_ID).sum())
         meta_i32 = torch.cat([
+            torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).view(torch.int32),    # dropout seed of this pass (torch CPU RNG), 8-byte aligned
+            torch.tensor([1.0 / n_nonpad], dtype=torch.float32).view(torch.int32),    # 1/n_nonpad (fp32 bits)
+            torch.zeros(1, dtype=torch.int32),
             torch.clamp(lens, max=T4).to(torch.int32),                        # klen_enc (B)      (raw lengths)
             dec_len.to(torch.int32),                                           # klen_dec (B)
             (pos < lens.unsqueeze(1)).to(torch.int32).reshape(-1),             # keep_enc (B*T4)
             (~is_pad).to(torch.int32).reshape(-1),                             # keep_dec (B*Td)
-            first, nxt,                                                        # embed chains (B*Td each)
-            torch.tensor([1.0 / n_nonpad], dtype=torch.float32).view(torch.int32)])   # 1/n_nonpad (fp32 bits)
+            first, nxt])                                                       # embed chains (B*Td each)
         dev_i32 = self.buf('meta_i32.%d' % slot, (meta_i32.numel(),), torch.int32)
         dev_i32.copy_(meta_i32, non_blocking=True)
         ids = self.buf('ids.%d' % slot, (2, B, Td), torch.int64)
         ids.copy_(torch.stack([seq_in, seq_out]), non_blocking=True)
-        klen_enc = dev_i32.data_ptr()
+        seed = dev_i32.data_ptr()
+        inv_count = seed + 8
+        klen_enc = seed + 16
         klen_dec = klen_enc + 4 * B
         keep_enc = klen_dec + 4 * B
         keep_dec = keep_enc + 4 * B * T4
         embed_first = keep_dec + 4 * B * Td
         embed_next = embed_first + 4 * B * Td
-        inv_count = embed_next + 4 * B * Td
-        return dict(B=B, T=T, Td=Td, n_nonpad=n_nonpad, gold_host=seq_out, ids=ids, klen_enc=klen_enc, klen_dec=klen_dec,
+        return dict(seed=seed, B=B, T=T, Td=Td, n_nonpad=n_nonpad, gold_host=seq_out, ids=ids, klen_enc=klen_enc, klen_dec=klen_dec,
                     keep_enc=keep_enc, keep_dec=keep_dec, embed_first=embed_first, embed_next=embed_next, inv_count=inv_count)
 
     def forward(self, theta, x, lengths, target, smoothing=0.0, slot=0):
@@ -390,6 +424,7 @@ class PassEngine:
         o = lambda n: P + 4 * L.off(n)
         d, V = hp.d, hp.V
         Td, ids, n_nonpad = meta['Td'], meta['ids'], meta['n_nonpad']
+        self._seed_ptr, self._site = meta['seed'], 0
         klen_enc, klen_dec, keep_enc, keep_dec = meta['klen_enc'], meta['klen_dec'], meta['keep_enc'], meta['keep_dec']
         Me, Md = B * T4, B * Td
 
@@ -439,8 +474,9 @@ class PassEngine:
 
         # ---- decoder ----
         d0 = self.buf('dec_in.y', (Md, d))
+        me = self.drop_mask('dec_in.me', (Md, d))                               # dropout(emb + PE) (modules/decoder.py:96)
         check(lib.mtl_embed_pe_fwd(st, ids.data_ptr(), o('decoder.trg_embedding.weight'), self.pe_dec.data_ptr(), d0.data_ptr(),
-                                   Md, Td, d), 'embed')
+                                   Md, Td, d, me.data_ptr() if me is not None else None, self.drop_scale), 'embed')
         cur = d0
         for i in range(hp.n_dec):
             pre = 'decoder.layers.%d.' % i
@@ -517,8 +553,10 @@ class PassEngine:
             self.mha_bwd('d%d.sa.' % i, P, G, pre + 'self_attn.', dcur.data_ptr(), x_in.data_ptr(), B, Td, x_in.data_ptr(), Td,
                          keep_dec, dnext.data_ptr(), dnext.data_ptr(), True)
             dcur, dnext = dnext, dcur
+        me = A.get('dec_in.me')
         check(lib.mtl_embed_bwd(st, S['meta']['ids'].data_ptr(), S['meta']['embed_first'], S['meta']['embed_next'], dcur.data_ptr(),
-                                g('decoder.trg_embedding.weight'), Md, d, PAD_ID), 'embed_bwd')
+                                g('decoder.trg_embedding.weight'), Md, d, PAD_ID, me.data_ptr() if me is not None else None,
+                                self.drop_scale), 'embed_bwd')
 
         # ---- encoder ----
         eA = self.buf('_deA', (Me, d))

@@ -160,8 +160,8 @@ class Transformer(nn.Module):
         self.encoder, self.decoder, self.vocab = encoder, decoder, vocab
         self.feat_extractor, self.is_factorized, self.r = feat_extractor, is_factorized, r
         self.copy_grad = None
-        if encoder.dropout_rate != 0.0 or decoder.dropout_rate != 0.0:
-            raise NotImplementedError('dropout > 0 is not implemented in the HIP path yet (parity is defined at dropout 0)')
+        if encoder.dropout_rate != decoder.dropout_rate:
+            raise ValueError('encoder and decoder are built with one --dropout value in the reference factory')
         print('feat extractor:', feat_extractor)
         # indices 0,2,5,7 hold the convolutions exactly like the reference nn.Sequential (ReLU/MaxPool are parameter-free)
         self.conv = nn.Sequential(nn.Conv2d(1, 64, 3, stride=1, padding=1), nn.ReLU(),
@@ -208,6 +208,8 @@ class Transformer(nn.Module):
             self.engines = [PassEngine(self._layout, hp, device, pe_e, pe_d) for _ in range(self.n_lanes)]
             self.lane_streams = [torch.cuda.Stream(device) for _ in range(self.n_lanes)]
             self.engine = self.engines[0]
+            for eng in self.engines:
+                eng.dropout_p = float(e.dropout_rate) if self.training else 0.0
 
     def _apply(self, fn, *a, **kw):
         out = super()._apply(fn, *a, **kw)
@@ -239,6 +241,14 @@ class Transformer(nn.Module):
         self._gflat.zero_()
 
     # ------------------------------------------------------------------ forward / backward
+    def train(self, mode=True):
+        """nn.Module.train/eval: dropout (Philox keep-masks inside the HIP kernels) is active only in training mode."""
+        out = super().train(mode)
+        p = float(self.encoder.dropout_rate) if mode else 0.0
+        for e in getattr(self, 'engines', []):
+            e.dropout_p = p
+        return out
+
     def _need_engine(self):
         if self.engine is None:
             raise RuntimeError('the model lives on %s: the product path needs an MI355X (call .cuda()); there is no CPU '

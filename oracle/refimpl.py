@@ -91,8 +91,9 @@ class LowRankMHA(nn.Module):
         nn.init.xavier_normal_(self.output_linear_a.weight)
         nn.init.xavier_normal_(self.output_linear_b.weight)
 
-    def forward(self, xq, xkv, blocked):
-        """blocked: (B, Tq, Tk) bool, True = masked out."""
+    def forward(self, xq, xkv, blocked, drop=None, tag=''):
+        """blocked: (B, Tq, Tk) bool, True = masked out.  drop: optional {site: multiplicative keep-mask already scaled by
+        1/(1-p)} replaying a given dropout realisation (sites: common_layers.py:328 -> tag+'mP', :303 -> tag+'mo')."""
         B, Tq, _ = xq.shape
         Tk = xkv.shape[1]
         q = self.query_linear_b(self.query_linear_a(xq)).view(B, Tq, self.h, self.dk).transpose(1, 2)
@@ -101,8 +102,12 @@ class LowRankMHA(nn.Module):
         s = torch.matmul(q, k.transpose(2, 3)) / self.temperature          # :321-322 (divide AFTER the product)
         s = s.masked_fill(blocked.unsqueeze(1), -np.inf)                   # :325
         p = torch.softmax(s, dim=-1)                                       # :327
+        if drop is not None:
+            p = p * drop[tag + 'mP']                                       # :328
         o = torch.matmul(p, v).transpose(1, 2).reshape(B, Tq, self.h * self.dv)
         o = self.output_linear_b(self.output_linear_a(o))                  # :303
+        if drop is not None:
+            o = o * drop[tag + 'mo']
         return self.layer_norm(o + xq)                                     # :304
 
 
@@ -115,8 +120,11 @@ class FFN(nn.Module):
         self.linear_2 = nn.Linear(inner, d)
         self.layer_norm = nn.LayerNorm(d)
 
-    def forward(self, x):
-        return self.layer_norm(self.linear_2(F.relu(self.linear_1(x))) + x)
+    def forward(self, x, drop=None, tag=''):
+        h = self.linear_2(F.relu(self.linear_1(x)))
+        if drop is not None:
+            h = h * drop[tag + 'mf']                                       # common_layers.py:130
+        return self.layer_norm(h + x)
 
 
 class EncLayer(nn.Module):
@@ -127,9 +135,9 @@ class EncLayer(nn.Module):
         self.self_attn = LowRankMHA(heads, d, dk, dv, r)
         self.pos_ffn = FFN(d, inner)
 
-    def forward(self, x, keep, blocked):
-        x = self.self_attn(x, x, blocked) * keep
-        return self.pos_ffn(x) * keep
+    def forward(self, x, keep, blocked, drop=None, tag=''):
+        x = self.self_attn(x, x, blocked, drop, tag + 'sa.') * keep
+        return self.pos_ffn(x, drop, tag + 'ff.') * keep
 
 
 class Enc(nn.Module):
@@ -142,13 +150,13 @@ class Enc(nn.Module):
         self.positional_encoding = PositionTable(d, src_max_len)
         self.layers = nn.ModuleList([EncLayer(heads, d, inner, dk, dv, r) for _ in range(layers)])
 
-    def forward(self, feats, lengths):
+    def forward(self, feats, lengths, drop=None):
         B, T, _ = feats.shape
         keep = length_mask(lengths, T)                                     # encoder.py:64 (Q2)
         blocked = (keep < 1).unsqueeze(1).expand(B, T, T)                  # encoder.py:66
         x = self.layer_norm_input(self.input_linear(feats)) + self.positional_encoding.pe[:, :T]  # :72-73
-        for layer in self.layers:
-            x = layer(x, keep.unsqueeze(-1), blocked)
+        for i, layer in enumerate(self.layers):
+            x = layer(x, keep.unsqueeze(-1), blocked, drop, 'e%d.' % i)
         return x
 
 
@@ -161,10 +169,10 @@ class DecLayer(nn.Module):
         self.encoder_attn = LowRankMHA(heads, d, dk, dv, r)
         self.pos_ffn = FFN(d, inner)
 
-    def forward(self, x, mem, keep, self_blocked, cross_blocked):
-        x = self.self_attn(x, x, self_blocked) * keep
-        x = self.encoder_attn(x, mem, cross_blocked) * keep
-        return self.pos_ffn(x) * keep
+    def forward(self, x, mem, keep, self_blocked, cross_blocked, drop=None, tag=''):
+        x = self.self_attn(x, x, self_blocked, drop, tag + 'sa.') * keep
+        x = self.encoder_attn(x, mem, cross_blocked, drop, tag + 'ca.') * keep
+        return self.pos_ffn(x, drop, tag + 'ff.') * keep
 
 
 class Dec(nn.Module):
@@ -178,16 +186,18 @@ class Dec(nn.Module):
         self.output_linear = nn.Linear(d, vocab_size, bias=False)
         nn.init.xavier_normal_(self.output_linear.weight)
 
-    def forward(self, padded_target, mem, src_lengths):
+    def forward(self, padded_target, mem, src_lengths, drop=None):
         seq_in, seq_out = decoder_io(padded_target)
         B, L = seq_in.shape
         keep = seq_in.ne(EOS_ID).float().unsqueeze(-1)                     # decoder.py:86 (Q7: keyed on EOS)
         future = torch.triu(torch.ones(L, L, dtype=torch.bool), diagonal=1).unsqueeze(0)
         self_blocked = seq_in.eq(EOS_ID).unsqueeze(1).expand(B, L, L) | future          # :87-90
         cross_blocked = (length_mask(src_lengths, mem.shape[1]) < 1).unsqueeze(1).expand(B, L, mem.shape[1])  # :93-94
-        x = self.trg_embedding(seq_in) + self.positional_encoding.pe[:, :L]             # :96 (scale 1.0, dropout 0)
-        for layer in self.layers:
-            x = layer(x, mem, keep, self_blocked, cross_blocked)
+        x = self.trg_embedding(seq_in) + self.positional_encoding.pe[:, :L]             # :96 (scale 1.0)
+        if drop is not None:
+            x = x * drop['dec_in.me']
+        for i, layer in enumerate(self.layers):
+            x = layer(x, mem, keep, self_blocked, cross_blocked, drop, 'd%d.' % i)
         return self.output_linear(x), seq_out                                          # :108-113
 
 
@@ -211,12 +221,12 @@ class SpeechTransformer(nn.Module):
             if p.dim() > 1:
                 nn.init.xavier_uniform_(p)
 
-    def forward(self, padded_input, input_lengths, padded_target):
+    def forward(self, padded_input, input_lengths, padded_target, drop=None):
         f = self.conv(padded_input)                                        # :133
         B, C, H, W = f.shape
         f = f.view(B, C * H, W).transpose(1, 2).contiguous()               # :136-138
-        mem = self.encoder(f, input_lengths)
-        pred, gold = self.decoder(padded_target, mem, input_lengths)
+        mem = self.encoder(f, input_lengths, drop)
+        pred, gold = self.decoder(padded_target, mem, input_lengths, drop)
         hyp = torch.topk(pred, 1, dim=2)[1].squeeze(2)                     # :146-147
         return pred, gold, hyp
 

@@ -197,16 +197,34 @@ def test_layernorm(L, d):
     a = [dev(t) for t in (x, res, gam, bet, pe)]
     kd = keep.cuda()
     assert L.mtl_layernorm_fwd(st(), a[0].data_ptr(), a[1].data_ptr(), a[2].data_ptr(), a[3].data_ptr(), a[4].data_ptr(),
-                               kd.data_ptr(), y.data_ptr(), xhat.data_ptr(), rstd.data_ptr(), rows, d, T, 1e-5) == 0
+                               kd.data_ptr(), None, 1.0, y.data_ptr(), xhat.data_ptr(), rstd.data_ptr(), rows, d, T, 1e-5) == 0
     assert rel(y, yr) < 2e-6
     dz, dg, db = torch.empty(rows, d).cuda(), torch.zeros(d).cuda(), torch.zeros(d).cuda()
     ws = torch.empty(L.mtl_layernorm_bwd_workspace(rows, d) // 4).cuda()
     ddy = dev(dy)
     dsum = torch.ones(d).cuda()
-    assert L.mtl_layernorm_bwd(st(), ddy.data_ptr(), xhat.data_ptr(), rstd.data_ptr(), a[2].data_ptr(), kd.data_ptr(),
-                               dz.data_ptr(), dg.data_ptr(), db.data_ptr(), dsum.data_ptr(), ws.data_ptr(), rows, d) == 0
+    assert L.mtl_layernorm_bwd(st(), ddy.data_ptr(), xhat.data_ptr(), rstd.data_ptr(), a[2].data_ptr(), kd.data_ptr(), None, 1.0,
+                               dz.data_ptr(), None, dg.data_ptr(), db.data_ptr(), dsum.data_ptr(), ws.data_ptr(), rows, d) == 0
     assert rel(dz, xr.grad) < 1e-5 and rel(dg, gr.grad) < 1e-5 and rel(db, br.grad) < 1e-5
     assert rel(dsum, xr.grad.sum(0) + 1) < 1e-5
+    # with dropout on the sub-layer output x (before the residual): forward and both gradient branches
+    p = 0.25
+    seed = torch.tensor([1234567], dtype=torch.int64).cuda()
+    mask = torch.empty(rows, d, dtype=torch.uint8).cuda()
+    assert L.mtl_dropout_mask(st(), mask.data_ptr(), rows * d, p, seed.data_ptr(), 7 << 40) == 0
+    mf = mask.cpu().float() / (1 - p)
+    xr, rr, gr, br = [t.clone().requires_grad_(True) for t in (x, res, gam, bet)]
+    yr = (F.layer_norm(xr * mf + rr, (d,), gr, br, 1e-5) + pe[torch.arange(rows) % T]) * keep.unsqueeze(1)
+    yr.backward(dy)
+    sc = 1.0 / (1 - p)
+    assert L.mtl_layernorm_fwd(st(), a[0].data_ptr(), a[1].data_ptr(), a[2].data_ptr(), a[3].data_ptr(), a[4].data_ptr(),
+                               kd.data_ptr(), mask.data_ptr(), sc, y.data_ptr(), xhat.data_ptr(), rstd.data_ptr(), rows, d, T, 1e-5) == 0
+    assert rel(y, yr) < 2e-6
+    dzm = torch.empty(rows, d).cuda()
+    dsum.zero_(); dg.zero_(); db.zero_()
+    assert L.mtl_layernorm_bwd(st(), ddy.data_ptr(), xhat.data_ptr(), rstd.data_ptr(), a[2].data_ptr(), kd.data_ptr(), mask.data_ptr(),
+                               sc, dz.data_ptr(), dzm.data_ptr(), dg.data_ptr(), db.data_ptr(), dsum.data_ptr(), ws.data_ptr(), rows, d) == 0
+    assert rel(dz, rr.grad) < 1e-5 and rel(dzm, xr.grad) < 1e-5 and rel(dsum, xr.grad.sum(0)) < 1e-5 and rel(dg, gr.grad) < 1e-5
 
 
 @pytest.mark.parametrize('causal', [0, 1])
@@ -227,12 +245,29 @@ def test_softmax(L, causal):
     S[..., :Tk] = s
     S = S.cuda()
     kd = klen.cuda()
-    assert L.mtl_softmax_mask_fwd(st(), S.data_ptr(), kd.data_ptr(), causal, 0.25, Bn, H, Tq, Tk, ld) == 0
+    assert L.mtl_softmax_mask_fwd(st(), S.data_ptr(), kd.data_ptr(), causal, 0.25, Bn, H, Tq, Tk, ld, None, 1.0, None) == 0
     assert rel(S[..., :Tk], pr) < 2e-6
     D = torch.zeros(Bn, H, Tq, ld)
     D[..., :Tk] = dp
     D = D.cuda()
-    assert L.mtl_softmax_bwd(st(), S.data_ptr(), D.data_ptr(), 0.25, Bn * H * Tq, Tk, ld) == 0
+    assert L.mtl_softmax_bwd(st(), S.data_ptr(), D.data_ptr(), 0.25, Bn * H * Tq, Tk, ld, None, 1.0) == 0
+    assert rel(D[..., :Tk], sr.grad) < 1e-5
+    # dropout on the probabilities: dropped copy for P.V, un-dropped P kept for the backward
+    p = 0.3
+    seed = torch.tensor([99], dtype=torch.int64).cuda()
+    mask = torch.empty(Bn, H, Tq, ld, dtype=torch.uint8).cuda()
+    assert L.mtl_dropout_mask(st(), mask.data_ptr(), mask.numel(), p, seed.data_ptr(), 3 << 40) == 0
+    mf = mask.cpu().float()[..., :Tk] / (1 - p)
+    sr = s.clone().requires_grad_(True)
+    pd_ref = torch.softmax((sr / 4.0).masked_fill(blocked, -np.inf), -1) * mf
+    pd_ref.backward(dp)
+    S = torch.zeros(Bn, H, Tq, ld); S[..., :Tk] = s; S = S.cuda()
+    Pd = torch.zeros(Bn, H, Tq, ld).cuda()
+    assert L.mtl_softmax_mask_fwd(st(), S.data_ptr(), kd.data_ptr(), causal, 0.25, Bn, H, Tq, Tk, ld, mask.data_ptr(), 1 / (1 - p),
+                                  Pd.data_ptr()) == 0
+    assert rel(Pd[..., :Tk], pd_ref) < 2e-6 and rel(S[..., :Tk], pr) < 2e-6
+    D = torch.zeros(Bn, H, Tq, ld); D[..., :Tk] = dp; D = D.cuda()
+    assert L.mtl_softmax_bwd(st(), S.data_ptr(), D.data_ptr(), 0.25, Bn * H * Tq, Tk, ld, mask.data_ptr(), 1 / (1 - p)) == 0
     assert rel(D[..., :Tk], sr.grad) < 1e-5
 
 
@@ -244,7 +279,7 @@ def test_embed_and_ce(L):
     ids[0, 1] = ids[0, 0]
     out = torch.empty(B * T, d).cuda()
     dt, dpe, dids = dev(table), dev(pe), ids.cuda()
-    assert L.mtl_embed_pe_fwd(st(), dids.data_ptr(), dt.data_ptr(), dpe.data_ptr(), out.data_ptr(), B * T, T, d) == 0
+    assert L.mtl_embed_pe_fwd(st(), dids.data_ptr(), dt.data_ptr(), dpe.data_ptr(), out.data_ptr(), B * T, T, d, None, 1.0) == 0
     assert rel(out, (table[ids] + pe.unsqueeze(0)).view(B * T, d)) == 0
     dout = torch.randn(B * T, d, generator=g)
     tg = torch.zeros(V, d).cuda()
@@ -257,7 +292,8 @@ def test_embed_and_ce(L):
             nxt[last[v]] = r
         last[v] = r
     dfirst, dnext = torch.tensor(first, dtype=torch.int32).cuda(), torch.tensor(nxt, dtype=torch.int32).cuda()
-    assert L.mtl_embed_bwd(st(), dids.data_ptr(), dfirst.data_ptr(), dnext.data_ptr(), ddo.data_ptr(), tg.data_ptr(), B * T, d, 0) == 0
+    assert L.mtl_embed_bwd(st(), dids.data_ptr(), dfirst.data_ptr(), dnext.data_ptr(), ddo.data_ptr(), tg.data_ptr(), B * T, d, 0, None,
+                           1.0) == 0
     ref = torch.zeros(V, d).index_add_(0, ids.view(-1), dout)
     assert rel(tg, ref) < 1e-6
     # cross entropy + arg-max (ties -> lowest index; padded rows are all-zero logits)
@@ -335,3 +371,18 @@ def test_flat_updates_colsum_permute(L):
     back = torch.zeros(rows, C * H).cuda()
     assert L.mtl_permute_hc(st(), wp.data_ptr(), back.data_ptr(), rows, C, H, 1) == 0
     assert torch.equal(back.cpu(), wt)
+
+
+def test_dropout_mask_statistics_and_determinism(L):
+    n = 1 << 22
+    seed = torch.tensor([2 ** 40 + 17], dtype=torch.int64).cuda()
+    a, b, c = (torch.empty(n, dtype=torch.uint8).cuda() for _ in range(3))
+    for p in (0.1, 0.5):
+        assert L.mtl_dropout_mask(st(), a.data_ptr(), n, p, seed.data_ptr(), 1 << 40) == 0
+        assert L.mtl_dropout_mask(st(), b.data_ptr(), n, p, seed.data_ptr(), 1 << 40) == 0
+        assert L.mtl_dropout_mask(st(), c.data_ptr(), n, p, seed.data_ptr(), 2 << 40) == 0
+        keep = float(a.float().mean())
+        assert abs(keep - (1 - p)) < 4 * np.sqrt(p * (1 - p) / n) + 1e-4          # 4 sigma
+        assert torch.equal(a, b) and not torch.equal(a, c)                        # same (seed, offset) -> same mask
+        assert abs(float((a.float() * c.float()).mean()) - (1 - p) ** 2) < 2e-3    # sites are independent
+    assert set(a.unique().tolist()) <= {0, 1}

@@ -328,3 +328,53 @@ def test_two_ranks_sharded_bench_equals_single_rank():
     assert j2['n_gpus'] == 2 and j1['n_gpus'] == 1 and j2['scaling'] == 'strong'
     assert j1['last_step']['chars'] == j2['last_step']['chars'] and j1['last_step']['cer_edits'] == j2['last_step']['cer_edits']
     assert abs(j1['last_step']['val_loss'] - j2['last_step']['val_loss']) < 1e-4 * abs(j1['last_step']['val_loss'])
+
+
+def test_dropout_pass_matches_oracle_with_the_same_masks():
+    """--dropout 0.1 (README config): the keep-masks the HIP pass drew are replayed inside the oracle, so
+    forward and backward must agree exactly like the dropout-free pass (the masks themselves come from Philox, not from
+    torch's RNG stream, which is why parity with the reference is defined only given the masks)."""
+    from oracle import refimpl as R
+    z, cfg, spec = gu.load('F0')
+    mtl_amd, args, vocab, model = make(cfg, spec)
+    args.dropout = 0.1
+    torch.manual_seed(123456)
+    model = mtl_amd.init_transformer_model(args, vocab, r=cfg['r']).cuda()
+    model.train()
+    oracle = R.build_model(cfg)
+    (x, lens, y) = gu.batches_for(cfg, spec, 0, z['data_call_index'])[0][0]
+    out = model.pass_forward(x.cuda(), lens, y)
+    g = torch.zeros_like(model.flat_grad)
+    model.pass_backward(g, 1.0)
+    A = model.engine.arena
+    B, Td = out['hyp'].shape
+    h, d, sc = cfg['num_heads'], cfg['dim_model'], 1.0 / 0.9
+    drop = {}
+    for name, m in A.items():
+        if name.endswith('.mP'):
+            Tk = A[name[:-2] + 'k'].shape[0] // B
+            drop[name] = m.cpu().float()[..., :Tk] * sc
+        elif name.endswith('.mo') or name.endswith('.mf') or name == 'dec_in.me':
+            drop[name] = m.cpu().float().view(B, -1, d) * sc
+    assert len(drop) == 3 * cfg['num_enc_layers'] + 5 * cfg['num_dec_layers'] + 1
+    keep_rate = float(torch.cat([v.reshape(-1) for v in drop.values()]).gt(0).float().mean())
+    assert abs(keep_rate - 0.9) < 0.01
+    pred_r, gold_r, hyp_r = oracle(x, lens, y, drop=drop)
+    loss_r = R.ce_loss(pred_r, gold_r)
+    grads = torch.autograd.grad(loss_r, list(oracle.parameters()))
+    assert torch.equal(out['hyp'].cpu(), hyp_r)
+    assert float((out['pred'].cpu() - pred_r).norm() / pred_r.norm()) < 1e-5
+    assert abs(float(out['loss']) - float(loss_r)) < RTOL * float(loss_r)
+    gn = float(torch.sqrt(sum((t.double() ** 2).sum() for t in grads)))
+    errs = [float((model._layout.view(g, nm).cpu() - t).norm() / max(float(t.norm()), 1e-4 * gn))
+            for (nm, _), t in zip(oracle.named_parameters(), grads)]
+    assert max(errs) < FLIP_BAND and sum(e < RTOL for e in errs) >= 0.9 * len(errs), max(errs)
+    # fresh masks on the next pass, none in eval mode
+    m0 = A['dec_in.me'].clone()
+    model.pass_forward(x.cuda(), lens, y)
+    assert not torch.equal(m0, model.engine.arena['dec_in.me'])
+    model.eval()
+    out_e = model.pass_forward(x.cuda(), lens, y)
+    assert 'dec_in.me' not in model.engine.arena
+    pr0, _, _ = oracle(x, lens, y)
+    assert float((out_e['pred'].cpu() - pr0).norm() / pr0.norm()) < 1e-5
