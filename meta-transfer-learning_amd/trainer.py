@@ -138,7 +138,9 @@ def cer_counts(vocab, gold, hyp):
 class TransientTrainer():
     def __init__(self):
         logging.info('Transient Trainer is initialized')
-        self.use_graphs = os.environ.get('MTL_GRAPHS', '1') != '0'
+        # hipGraph replay of the task body is validated but opt-in: at 2 task lanes the loop is GPU-throughput-bound and replay
+        # measured equal (8 tasks) or slower (3 tasks, dropout) than eager launches on ROCm 7.2
+        self.use_graphs = os.environ.get('MTL_GRAPHS', '0') == '1'
         self._graphs = {}
 
     # ------------------------------------------------------------------ drop-in single-batch API
@@ -201,7 +203,7 @@ class TransientTrainer():
                 m_va = eng.prepare(val_batch[1], val_batch[3], vx.shape[0], vx.shape[3], slot=1)
                 slots = self._slots(model, lane, m_tr, m_va)
                 key = (lane, tuple(tx.shape), tuple(vx.shape), m_tr['Td'], m_va['Td'], n_tasks, bool(args.clip),
-                       float(args.max_norm), smoothing, float(inner.param_groups[0]['lr']), theta0.data_ptr())
+                       float(args.max_norm), smoothing, float(inner.param_groups[0]['lr']), theta0.data_ptr(), eng.dropout_p)
                 body = lambda xa, xb: self._task_body(model, lane, bufs[lane], theta0, xa, m_tr, xb, m_va, n_tasks, inner, args,
                                                       smoothing, slots)
                 graph = self._graph_for(key, lane, tx, vx, body, streams[lane]) if use_graphs else None

@@ -378,3 +378,29 @@ def test_dropout_pass_matches_oracle_with_the_same_masks():
     assert 'dec_in.me' not in model.engine.arena
     pr0, _, _ = oracle(x, lens, y)
     assert float((out_e['pred'].cpu() - pr0).norm() / pr0.norm()) < 1e-5
+
+
+def test_hipgraph_replay_is_bitwise_equal_to_eager():
+    """The per-task body captured into a hipGraph (trainer._graph_for, opt-in via MTL_GRAPHS=1) must reproduce the eager
+    meta-gradient bit for bit, also for a batch it was not captured on."""
+    z, cfg, spec = gu.load('F0')
+    mtl_amd, args, vocab, model = make(cfg, spec)
+    model = model.cuda()
+    as5 = lambda b: (b[0].cuda(), b[1], None, b[2], None)
+    mk = lambda s0: [as5(mtl_amd.synth_batch(s0 + i, 2, 64, 8, cfg['vocab_size'])) for i in range(6)]
+    val = as5(mtl_amd.synth_batch(77, 2, 64, 8, cfg['vocab_size']))
+    inner = mtl_amd.FlatSGD(model, spec['lr'])
+    model.zero_copy_grad()
+    res = {}
+    for mode in (False, True):
+        tr = mtl_amd.TransientTrainer()
+        tr.use_graphs = mode
+        outs = []
+        for s0 in (100, 200):                      # second batch set runs purely on replays when graphs are on
+            tr.meta_iteration(model, vocab, mk(s0), val, 6, inner, None, args)
+            torch.cuda.synchronize()
+            outs.append(model._G.clone())
+        res[mode] = outs
+        if mode:
+            assert any(isinstance(v, dict) for v in tr._graphs.values()), 'no graph was captured'
+    assert torch.equal(res[False][0], res[True][0]) and torch.equal(res[False][1], res[True][1])
