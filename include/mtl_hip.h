@@ -65,6 +65,16 @@ int mtl_conv3x3_relu_pool_fwd(void* stream, const float* x, const float* w_fwd, 
  * T,F,Cin,Cout describe the FORWARD convolution. */
 int mtl_conv3x3_dgrad(void* stream, const float* dy, const unsigned char* argmax, const float* w_dgrad,
                       const float* act, float* dx, int B, int T, int F, int Cin, int Cout);
+/* Split-bf16 ("x3") variants of the three calls above: identical semantics and fp32-class error, computed with six
+ * v_mfma_f32_32x32x16_bf16 per 16-deep step on exact 3-way bf16 splits of both operands (2.67x the fp32 MFMA roof).
+ * w3_fwd / w3_dgrad: bf16 [3][9][rows][K] buffers (3 * 9*Cin*Cout * 2 bytes each) from mtl_conv3x3_wprep_x3. */
+int mtl_conv3x3_wprep_x3(void* stream, const float* w_ref, void* w3_fwd, void* w3_dgrad, int Cout, int Cin);
+int mtl_conv3x3_relu_fwd_x3(void* stream, const float* x, const void* w3_fwd, const float* bias, float* y, int B, int T, int F,
+                            int Cin, int Cout);
+int mtl_conv3x3_relu_pool_fwd_x3(void* stream, const float* x, const void* w3_fwd, const float* bias, float* p_out,
+                                 unsigned char* argmax, int B, int T, int F, int Cin, int Cout);
+int mtl_conv3x3_dgrad_x3(void* stream, const float* dy, const unsigned char* argmax, const void* w3_dgrad, const float* act,
+                         float* dx, int B, int T, int F, int Cin, int Cout);
 long mtl_conv3x3_wgrad_workspace(int B, int T, int F, int Cin, int Cout, int pooled);
 /* dw_ref (Cout,Cin,3,3) += sum_pixels x (x) dy ; dy dense (B,T,F,Cout) or pooled + argmax as above. */
 int mtl_conv3x3_wgrad(void* stream, const float* x, const float* dy, const unsigned char* argmax, float* dw_ref,

@@ -24,6 +24,10 @@ SIGNATURES = {
     'mtl_conv3x3_relu_fwd': (I, [P, P, P, P, P, I, I, I, I, I]),
     'mtl_conv3x3_relu_pool_fwd': (I, [P, P, P, P, P, P, I, I, I, I, I]),
     'mtl_conv3x3_dgrad': (I, [P, P, P, P, P, P, I, I, I, I, I]),
+    'mtl_conv3x3_wprep_x3': (I, [P, P, P, P, I, I]),
+    'mtl_conv3x3_relu_fwd_x3': (I, [P, P, P, P, P, I, I, I, I, I]),
+    'mtl_conv3x3_relu_pool_fwd_x3': (I, [P, P, P, P, P, P, I, I, I, I, I]),
+    'mtl_conv3x3_dgrad_x3': (I, [P, P, P, P, P, P, I, I, I, I, I]),
     'mtl_conv3x3_wgrad_workspace': (L, [I, I, I, I, I, I]),
     'mtl_conv3x3_wgrad': (I, [P, P, P, P, P, P, L, I, I, I, I, I]),
     'mtl_permute_hc': (I, [P, P, P, I, I, I, I]),

@@ -609,6 +609,198 @@ int dispatch_conv(ConvP& p, int Te, int Fe, hipStream_t s) {
     return launch_conv<64, UNPOOL, EPI>(p, Te, Fe, s);
 }
 
+// ------------------------------------------------------------------ split-bf16 ("x3") convolution: fp32-exact results at the bf16 MFMA rate
+// Every fp32 operand is split EXACTLY into three bf16 pieces (x = h + m + l: 3 x 8 significand bits); a product is the sum
+// of the six piece products with i+j <= 4 (the dropped ones are < 2^-24 relative), accumulated in fp32 by
+// v_mfma_f32_32x32x16_bf16.  Six bf16 MFMAs of K=16 (32 cycles each) replace eight fp32 MFMAs of K=2 (64 cycles each):
+// 2.67x the fp32 matrix roof with fp32-class error (CPU emulation: 4.7e-7 rms vs 3.2e-7 for an fp32 GEMM, K = 1152).
+// Same tile geometry / epilogues as conv3x3_kernel; LDS holds three bf16 planes per operand, K-contiguous rows of
+// 32 bf16 padded to 80 B (ds_read_b128 fragment reads hit 16 distinct 16-B slots), single-buffered, 2 workgroups per CU.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int X3_ROWB = 80;                      // bytes per LDS row
+constexpr int X3_APLANE = 128 * X3_ROWB;         // one bf16 plane of the 128-pixel A tile
+
+__device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l) {
+    h = (__bf16)x;
+    const float r = x - (float)h;
+    m = (__bf16)r;
+    l = (__bf16)(r - (float)m);
+}
+
+__device__ __forceinline__ void commit_a_x3(unsigned char* smA, int row, int kq, float4 v) {
+    __bf16 hh[4], mm[4], ll[4];
+    split3(v.x, hh[0], mm[0], ll[0]);
+    split3(v.y, hh[1], mm[1], ll[1]);
+    split3(v.z, hh[2], mm[2], ll[2]);
+    split3(v.w, hh[3], mm[3], ll[3]);
+    const bf16x4 h = {hh[0], hh[1], hh[2], hh[3]}, m = {mm[0], mm[1], mm[2], mm[3]}, l = {ll[0], ll[1], ll[2], ll[3]};
+    unsigned char* q = smA + row * X3_ROWB + kq * 2;
+    *reinterpret_cast<bf16x4*>(q) = h;
+    *reinterpret_cast<bf16x4*>(q + X3_APLANE) = m;
+    *reinterpret_cast<bf16x4*>(q + 2 * X3_APLANE) = l;
+}
+
+// (Cout,Cin,3,3) fp32 -> w3f[piece][tap][cout][cin] and w3d[piece][8-tap][cin][cout]   (bf16, reduction index contiguous)
+__global__ void conv_wprep_x3_kernel(const float* w, __bf16* wf, __bf16* wd, int Cout, int Cin) {
+    const int total = 9 * Cin * Cout;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int tap = e % 9;
+        const int cin = (e / 9) % Cin;
+        const int cout = e / (9 * Cin);
+        __bf16 pc[3];
+        split3(w[e], pc[0], pc[1], pc[2]);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            wf[(((long)p * 9 + tap) * Cout + cout) * Cin + cin] = pc[p];
+            wd[(((long)p * 9 + (8 - tap)) * Cin + cin) * Cout + cout] = pc[p];
+        }
+    }
+}
+
+struct ConvX3P {
+    const float* x;
+    const uint8_t* am_in;
+    const __bf16* w3;    // [3][9][N rows = output channels][K = input channels]
+    const float* bias;
+    const float* act;
+    float* y;
+    uint8_t* am_out;
+    ConvGeom g;          // Cin = reduction channels, Cout = output channels of THIS conv (dgrad: swapped by the caller)
+    int ntile;
+};
+
+template <int BN, bool UNPOOL, int EPI>
+__global__ __launch_bounds__(NT) void conv3x3_x3_kernel(ConvX3P p) {
+    using LA = LoadConvA<UNPOOL>;
+    using E = Engine<128, BN, LA, LoadMNMajor<BN, true>>;     // only for the tile constants and the epilogue walk
+    constexpr int TM = E::TM, TN = E::TN, WTM = E::WTM, WTN = E::WTN;
+    constexpr int BPLANE = BN * X3_ROWB;
+    constexpr int NVB = 3 * BN * 4 / NT;                       // 16-byte chunks of the weight tile per thread
+    extern __shared__ __attribute__((aligned(16))) unsigned char smx[];
+    unsigned char* smA = smx;
+    unsigned char* smB = smx + 3 * X3_APLANE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, hi = lane >> 5;
+    const int b = blockIdx.z / p.ntile, n0 = (blockIdx.z % p.ntile) * BN;
+    const int t0 = blockIdx.y * 8, f0 = blockIdx.x * 16;
+    const int Cin = p.g.Cin, Cout = p.g.Cout, cch = Cin / BK, nk = 9 * cch;
+    LA la;
+    la.init(p.x, p.am_in, p.g, Cin, b, t0, f0, tid);
+    typename LA::Regs ra;
+    uint4 rb[NVB];
+    f32x16 acc[TM][TN];
+    E::zero(acc);
+
+    auto fetch_b = [&](int kt) {
+        const int tap = kt / cch, c0 = (kt - tap * cch) * BK;
+#pragma unroll
+        for (int i = 0; i < NVB; ++i) {
+            const int q = tid + i * NT, piece = q / (BN * 4), within = q - piece * (BN * 4);
+            const int row = within >> 2, k8 = (within & 3) * 8;
+            rb[i] = *reinterpret_cast<const uint4*>(p.w3 + (((long)piece * 9 + tap) * Cout + n0 + row) * Cin + c0 + k8);
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < LA::NV; ++i) {
+            float4 v = ra.v[i];
+            const bool ok = ra.m[i] & 1u;
+            if (!UNPOOL) {
+                v = mask4(v, ok ? 15u : 0u);
+            } else {
+                const unsigned sub = ra.m[i] >> 1;
+                v.x = (ok && ra.a[i].x == sub) ? v.x : 0.f;
+                v.y = (ok && ra.a[i].y == sub) ? v.y : 0.f;
+                v.z = (ok && ra.a[i].z == sub) ? v.z : 0.f;
+                v.w = (ok && ra.a[i].w == sub) ? v.w : 0.f;
+            }
+            commit_a_x3(smA, (tid >> 3) + i * 32, (tid & 7) * 4, v);
+        }
+#pragma unroll
+        for (int i = 0; i < NVB; ++i) {
+            const int q = tid + i * NT, piece = q / (BN * 4), within = q - piece * (BN * 4);
+            *reinterpret_cast<uint4*>(smB + piece * BPLANE + (within >> 2) * X3_ROWB + (within & 3) * 16) = rb[i];
+        }
+    };
+
+    la.fetch(0, ra, tid);
+    fetch_b(0);
+    commit();
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        if (more) {                                            // next tile's global loads fly under this tile's MFMAs
+            la.fetch(kt + 1, ra, tid);
+            fetch_b(kt + 1);
+        }
+#pragma unroll
+        for (int st = 0; st < BK / 16; ++st) {
+            bf16x8 a[TM][3], bb[TN][3];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc)
+                    a[i][pc] = *reinterpret_cast<const bf16x8*>(smA + pc * X3_APLANE + (wm * WTM + i * 32 + l31) * X3_ROWB + st * 32 + hi * 16);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc)
+                    bb[j][pc] = *reinterpret_cast<const bf16x8*>(smB + pc * BPLANE + (wn * WTN + j * 32 + l31) * X3_ROWB + st * 32 + hi * 16);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    f32x16 c = acc[i][j];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], bb[j][0], c, 0, 0, 0);   // smallest terms first
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], bb[j][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], bb[j][2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], bb[j][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], bb[j][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], bb[j][0], c, 0, 0, 0);
+                    acc[i][j] = c;
+                }
+        }
+        __syncthreads();                                       // everyone is done reading this tile
+        if (more) {
+            commit();
+            __syncthreads();
+        }
+    }
+    if (EPI == EPI_RELU) {
+        EpiConvRelu e{p.y, p.bias, b, t0, f0, p.g.T, p.g.F, Cout, n0};
+        E::finish(acc, e);
+    } else if (EPI == EPI_POOL) {
+        EpiConvPool e{p.y, p.am_out, p.bias, b, t0, f0, p.g.Tp, p.g.Fp, Cout, n0};
+        E::finish(acc, e);
+    } else {
+        EpiConvDgrad e{p.y, p.act, b, t0, f0, p.g.T, p.g.F, Cout, n0};
+        E::finish(acc, e);
+    }
+}
+
+template <int BN, bool UNPOOL, int EPI>
+int launch_conv_x3(const ConvX3P& p, int Te, int Fe, hipStream_t s) {
+    constexpr int SMEM = 3 * X3_APLANE + 3 * BN * X3_ROWB;
+    static int attr = set_smem(conv3x3_x3_kernel<BN, UNPOOL, EPI>, SMEM);
+    if (attr) return attr;
+    dim3 grid((Fe + 15) / 16, (Te + 7) / 8, p.g.B * p.ntile);
+    hipLaunchKernelGGL((conv3x3_x3_kernel<BN, UNPOOL, EPI>), grid, dim3(NT), SMEM, s, p);
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}
+
+template <bool UNPOOL, int EPI>
+int dispatch_conv_x3(ConvX3P& p, int Te, int Fe, hipStream_t s) {
+    if (p.g.Cin % 32 || p.g.Cout % 64) return MTL_EINVAL;
+    if (p.g.Cout % 128 == 0) {
+        p.ntile = p.g.Cout / 128;
+        return launch_conv_x3<128, UNPOOL, EPI>(p, Te, Fe, s);
+    }
+    p.ntile = p.g.Cout / 64;
+    return launch_conv_x3<64, UNPOOL, EPI>(p, Te, Fe, s);
+}
+
 // ------------------------------------------------------------------ weight gradient
 // dW[tap][cin][cout] = sum over valid output pixels of x[t+kw-1, f+kh-1, cin] * dy[t, f, cout]
 // GEMM view: M = 9*Cin (64-row tiles never straddle a tap), N = Cout, K = pixels (f fastest), split over grid.z.
@@ -895,6 +1087,36 @@ int mtl_conv3x3_dgrad(void* stream, const float* dy, const unsigned char* argmax
     ConvP p{dy, argmax, w_dgrad, nullptr, act, dx, nullptr, {B, T, F, Cout, Cin, T / 2, F / 2}, 1};
     if (argmax) return dispatch_conv<true, EPI_DGRAD>(p, T, F, as_stream(stream));
     return dispatch_conv<false, EPI_DGRAD>(p, T, F, as_stream(stream));
+}
+
+int mtl_conv3x3_wprep_x3(void* stream, const float* w_ref, void* w3_fwd, void* w3_dgrad, int Cout, int Cin) {
+    if (!w_ref || !w3_fwd || !w3_dgrad) return MTL_EINVAL;
+    hipLaunchKernelGGL(conv_wprep_x3_kernel, dim3(grid_for(9L * Cin * Cout, 256)), dim3(256), 0, as_stream(stream), w_ref,
+                       reinterpret_cast<__bf16*>(w3_fwd), reinterpret_cast<__bf16*>(w3_dgrad), Cout, Cin);
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}
+
+int mtl_conv3x3_relu_fwd_x3(void* stream, const float* x, const void* w3_fwd, const float* bias, float* y, int B, int T, int F,
+                            int Cin, int Cout) {
+    if (!x || !w3_fwd || !bias || !y) return MTL_EINVAL;
+    ConvX3P p{x, nullptr, reinterpret_cast<const __bf16*>(w3_fwd), bias, nullptr, y, nullptr, {B, T, F, Cin, Cout, T / 2, F / 2}, 1};
+    return dispatch_conv_x3<false, EPI_RELU>(p, T, F, as_stream(stream));
+}
+
+int mtl_conv3x3_relu_pool_fwd_x3(void* stream, const float* x, const void* w3_fwd, const float* bias, float* p_out,
+                                 unsigned char* argmax, int B, int T, int F, int Cin, int Cout) {
+    if (!x || !w3_fwd || !bias || !p_out || !argmax) return MTL_EINVAL;
+    ConvX3P p{x, nullptr, reinterpret_cast<const __bf16*>(w3_fwd), bias, nullptr, p_out, argmax, {B, T, F, Cin, Cout, T / 2, F / 2}, 1};
+    return dispatch_conv_x3<false, EPI_POOL>(p, 2 * (T / 2), 2 * (F / 2), as_stream(stream));
+}
+
+int mtl_conv3x3_dgrad_x3(void* stream, const float* dy, const unsigned char* argmax, const void* w3_dgrad, const float* act,
+                         float* dx, int B, int T, int F, int Cin, int Cout) {
+    if (!dy || !w3_dgrad || !act || !dx) return MTL_EINVAL;
+    ConvX3P p{dy, argmax, reinterpret_cast<const __bf16*>(w3_dgrad), nullptr, act, dx, nullptr, {B, T, F, Cout, Cin, T / 2, F / 2}, 1};
+    if (argmax) return dispatch_conv_x3<true, EPI_DGRAD>(p, T, F, as_stream(stream));
+    return dispatch_conv_x3<false, EPI_DGRAD>(p, T, F, as_stream(stream));
 }
 
 long mtl_conv3x3_wgrad_workspace(int B, int T, int F, int Cin, int Cout, int pooled) {

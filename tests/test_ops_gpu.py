@@ -386,3 +386,49 @@ def test_dropout_mask_statistics_and_determinism(L):
         assert torch.equal(a, b) and not torch.equal(a, c)                        # same (seed, offset) -> same mask
         assert abs(float((a.float() * c.float()).mean()) - (1 - p) ** 2) < 2e-3    # sites are independent
     assert set(a.unique().tolist()) <= {0, 1}
+
+
+@pytest.mark.parametrize('Cin,Cout,B,T,Fq', [(64, 64, 2, 21, 161), (64, 128, 2, 18, 80), (128, 128, 1, 9, 19)])
+def test_conv3x3_split_bf16_matches_fp32_reference(L, Cin, Cout, B, T, Fq):
+    """the "x3" kernels (3-way bf16 operand split, six bf16 MFMAs per product) keep fp32-class accuracy: same tolerances as
+    the fp32-MFMA kernels, bit-identical pool arg-max decisions on this data"""
+    g = torch.Generator().manual_seed(Cin + Cout + T + 1)
+    x = torch.relu(torch.randn(B, Cin, Fq, T, generator=g))
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * (1.0 / np.sqrt(9 * Cin))
+    b = torch.randn(Cout, generator=g) * 0.1
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = torch.relu(F.conv2d(xr, wr, b, padding=1))
+    pr, idx = F.max_pool2d(yr, 2, stride=2, return_indices=True)
+    dxn, dw, db = dev(nhwc(x)), dev(w), dev(b)
+    w3f = torch.empty(3 * 9 * Cin * Cout, dtype=torch.bfloat16).cuda()
+    w3d = torch.empty(3 * 9 * Cin * Cout, dtype=torch.bfloat16).cuda()
+    assert L.mtl_conv3x3_wprep_x3(st(), dw.data_ptr(), w3f.data_ptr(), w3d.data_ptr(), Cout, Cin) == 0
+    pieces = w3f.view(3, 9, Cout, Cin).float().sum(0).cpu()                 # the split is exact
+    assert torch.equal(pieces, w.permute(2, 3, 0, 1).reshape(9, Cout, Cin))
+    y = torch.empty(B, T, Fq, Cout).cuda()
+    assert L.mtl_conv3x3_relu_fwd_x3(st(), dxn.data_ptr(), w3f.data_ptr(), db.data_ptr(), y.data_ptr(), B, T, Fq, Cin, Cout) == 0
+    assert rel(from_nhwc(y), yr) < 3e-6
+    Tp, Fp = T // 2, Fq // 2
+    p = torch.empty(B, Tp, Fp, Cout).cuda()
+    am = torch.empty(B, Tp, Fp, Cout, dtype=torch.uint8).cuda()
+    assert L.mtl_conv3x3_relu_pool_fwd_x3(st(), dxn.data_ptr(), w3f.data_ptr(), db.data_ptr(), p.data_ptr(), am.data_ptr(), B, T, Fq,
+                                          Cin, Cout) == 0
+    assert rel(from_nhwc(p), pr) < 3e-6
+    amc = from_nhwc(am).long().cpu()
+    fgrid = torch.arange(Fp).view(1, 1, Fp, 1) * 2 + (amc >> 1)
+    tgrid = torch.arange(Tp).view(1, 1, 1, Tp) * 2 + (amc & 1)
+    assert int(((fgrid * T + tgrid) != idx).sum()) == 0
+    dp = torch.randn(pr.shape, generator=g)
+    pr.backward(dp)
+    dpn = dev(nhwc(dp * (pr.detach() > 0)))
+    dx = torch.empty(B, T, Fq, Cin).cuda()
+    assert L.mtl_conv3x3_dgrad_x3(st(), dpn.data_ptr(), am.data_ptr(), w3d.data_ptr(), dxn.data_ptr(), dx.data_ptr(), B, T, Fq, Cin,
+                                  Cout) == 0
+    assert rel(from_nhwc(dx), xr.grad * (x > 0)) < 1e-5
+    xr2 = x.clone().requires_grad_(True)
+    y2 = torch.relu(F.conv2d(xr2, w, b, padding=1))
+    dy = torch.randn(y2.shape, generator=g)
+    y2.backward(dy)
+    dyn = dev(nhwc(dy * (y2.detach() > 0)))
+    assert L.mtl_conv3x3_dgrad_x3(st(), dyn.data_ptr(), None, w3d.data_ptr(), dxn.data_ptr(), dx.data_ptr(), B, T, Fq, Cin, Cout) == 0
+    assert rel(from_nhwc(dx), xr2.grad * (x > 0)) < 1e-5

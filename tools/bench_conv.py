@@ -41,6 +41,15 @@ def conv_case(name, T_, F_, cin, cout, pooled):
     dx = torch.empty_like(x)
     t = timeit(lambda: L.mtl_conv3x3_dgrad(st(), dy.data_ptr(), amp, wd.data_ptr(), x.data_ptr(), dx.data_ptr(), B, T_, F_, cin, cout))
     print('%-8s dgrad %.3f ms %6.1f TF' % (name, t, flops / t / 1e9))
+    w3f = torch.empty(3 * 9 * cin * cout, dtype=torch.bfloat16, device=dev); w3d = torch.empty_like(w3f)
+    L.mtl_conv3x3_wprep_x3(st(), w.data_ptr(), w3f.data_ptr(), w3d.data_ptr(), cout, cin)
+    if pooled:
+        t = timeit(lambda: L.mtl_conv3x3_relu_pool_fwd_x3(st(), x.data_ptr(), w3f.data_ptr(), bias.data_ptr(), y.data_ptr(), am.data_ptr(), B, T_, F_, cin, cout))
+    else:
+        t = timeit(lambda: L.mtl_conv3x3_relu_fwd_x3(st(), x.data_ptr(), w3f.data_ptr(), bias.data_ptr(), y.data_ptr(), B, T_, F_, cin, cout))
+    print('%-8s fwd   x3 %.3f ms %6.1f TF' % (name, t, flops / t / 1e9))
+    t = timeit(lambda: L.mtl_conv3x3_dgrad_x3(st(), dy.data_ptr(), amp, w3d.data_ptr(), x.data_ptr(), dx.data_ptr(), B, T_, F_, cin, cout))
+    print('%-8s dgrad x3 %.3f ms %6.1f TF' % (name, t, flops / t / 1e9))
     need = L.mtl_conv3x3_wgrad_workspace(B, T_, F_, cin, cout, 1 if pooled else 0)
     ws = torch.empty(need // 4 + 64, device=dev); dw = torch.zeros_like(w)
     t = timeit(lambda: L.mtl_conv3x3_wgrad(st(), x.data_ptr(), dy.data_ptr(), amp, dw.data_ptr(), ws.data_ptr(), need, B, T_, F_, cin, cout))
