@@ -67,7 +67,7 @@ int mtl_conv3x3_dgrad(void* stream, const float* dy, const unsigned char* argmax
                       const float* act, float* dx, int B, int T, int F, int Cin, int Cout);
 /* Split-bf16 ("x3") variants of the three calls above: identical semantics and fp32-class error, computed with six
  * v_mfma_f32_32x32x16_bf16 per 16-deep step on exact 3-way bf16 splits of both operands (2.67x the fp32 MFMA roof).
- * w3_fwd / w3_dgrad: bf16 [3][9][rows][K] buffers (3 * 9*Cin*Cout * 2 bytes each) from mtl_conv3x3_wprep_x3. */
+ * w3_fwd / w3_dgrad: bf16 [3][K-tile][rows][32] buffers (3 * 9*Cin*Cout * 2 bytes each) from mtl_conv3x3_wprep_x3. */
 int mtl_conv3x3_wprep_x3(void* stream, const float* w_ref, void* w3_fwd, void* w3_dgrad, int Cout, int Cin);
 int mtl_conv3x3_relu_fwd_x3(void* stream, const float* x, const void* w3_fwd, const float* bias, float* y, int B, int T, int F,
                             int Cin, int Cout);

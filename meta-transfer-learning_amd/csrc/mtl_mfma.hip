@@ -641,9 +641,12 @@ __device__ __forceinline__ void commit_a_x3(unsigned char* smA, int row, int kq,
     *reinterpret_cast<bf16x4*>(q + 2 * X3_APLANE) = l;
 }
 
-// (Cout,Cin,3,3) fp32 -> w3f[piece][tap][cout][cin] and w3d[piece][8-tap][cin][cout]   (bf16, reduction index contiguous)
+// (Cout,Cin,3,3) fp32 -> bf16 pieces laid out per K-TILE: w3f[piece][kt = tap*Cin/32 + cin/32][cout][cin%32] and
+// w3d[piece][kt = (8-tap)*Cout/32 + cout/32][cin][cout%32]: the rows a workgroup stages for one K-tile are one contiguous
+// block of full cache lines (a [rows][K] layout makes them 64-byte halves of lines 2*K bytes apart: 2.9x the L2 requests)
 __global__ void conv_wprep_x3_kernel(const float* w, __bf16* wf, __bf16* wd, int Cout, int Cin) {
     const int total = 9 * Cin * Cout;
+    const int nkf = 9 * (Cin / 32), nkd = 9 * (Cout / 32);
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
         const int tap = e % 9;
         const int cin = (e / 9) % Cin;
@@ -652,8 +655,8 @@ __global__ void conv_wprep_x3_kernel(const float* w, __bf16* wf, __bf16* wd, int
         split3(w[e], pc[0], pc[1], pc[2]);
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
-            wf[(((long)p * 9 + tap) * Cout + cout) * Cin + cin] = pc[p];
-            wd[(((long)p * 9 + (8 - tap)) * Cin + cin) * Cout + cout] = pc[p];
+            wf[(((long)p * nkf + tap * (Cin / 32) + (cin >> 5)) * Cout + cout) * 32 + (cin & 31)] = pc[p];
+            wd[(((long)p * nkd + (8 - tap) * (Cout / 32) + (cout >> 5)) * Cin + cin) * 32 + (cout & 31)] = pc[p];
         }
     }
 }
@@ -661,7 +664,7 @@ __global__ void conv_wprep_x3_kernel(const float* w, __bf16* wf, __bf16* wd, int
 struct ConvX3P {
     const float* x;
     const uint8_t* am_in;
-    const __bf16* w3;    // [3][9][N rows = output channels][K = input channels]
+    const __bf16* w3;    // [3][K-tile][N rows = output channels][32]   (see conv_wprep_x3_kernel)
     const float* bias;
     const float* act;
     float* y;
@@ -670,70 +673,94 @@ struct ConvX3P {
     int ntile;
 };
 
+// Wave-specialised workgroup (512 threads): waves 0-3 are CONSUMERS (2x2 over the 128 x BN tile: ds_read_b128 + MFMA only),
+// waves 4-7 are PRODUCERS (im2col gather, 3-way split, LDS writes, weight staging).  A workgroup's waves are placed on the
+// SIMDs cyclically, so every SIMD hosts one consumer and one producer: the VALU-heavy staging (7 VALU per MFMA in a
+// monolithic wave, PMC: MFMA pipe 28 % busy) runs on the vector pipe while the partner wave keeps the matrix pipe fed.
+// LDS is double-buffered (2 x 3 planes x (128 + BN) rows x 80 B = 120 KiB), one barrier per K-tile for both roles.
 template <int BN, bool UNPOOL, int EPI>
-__global__ __launch_bounds__(NT) void conv3x3_x3_kernel(ConvX3P p) {
+__global__ __launch_bounds__(512) void conv3x3_x3_kernel(ConvX3P p) {
     using LA = LoadConvA<UNPOOL>;
     using E = Engine<128, BN, LA, LoadMNMajor<BN, true>>;     // only for the tile constants and the epilogue walk
     constexpr int TM = E::TM, TN = E::TN, WTM = E::WTM, WTN = E::WTN;
     constexpr int BPLANE = BN * X3_ROWB;
-    constexpr int NVB = 3 * BN * 4 / NT;                       // 16-byte chunks of the weight tile per thread
+    constexpr int ABUF = 3 * X3_APLANE, BBUF = 3 * BPLANE, STAGE = ABUF + BBUF;
+    constexpr int NVB = 3 * BN * 4 / NT;                       // 16-byte chunks of the weight tile per producer thread
     extern __shared__ __attribute__((aligned(16))) unsigned char smx[];
-    unsigned char* smA = smx;
-    unsigned char* smB = smx + 3 * X3_APLANE;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, hi = lane >> 5;
+    const int tid = threadIdx.x;
     const int b = blockIdx.z / p.ntile, n0 = (blockIdx.z % p.ntile) * BN;
     const int t0 = blockIdx.y * 8, f0 = blockIdx.x * 16;
     const int Cin = p.g.Cin, Cout = p.g.Cout, cch = Cin / BK, nk = 9 * cch;
-    LA la;
-    la.init(p.x, p.am_in, p.g, Cin, b, t0, f0, tid);
-    typename LA::Regs ra;
-    uint4 rb[NVB];
+
+    if (tid >= NT) {
+        // ------------------------------------------------------------------ producers
+        const int ptid = tid - NT;
+        LA la;
+        la.init(p.x, p.am_in, p.g, Cin, b, t0, f0, ptid);
+        // Two register sets for both operands, tiles requested TWO ahead.  Every fetch is unconditional (tile index clamped)
+        // and nk is even, so the number of loads in flight at each commit is a compile-time constant and hipcc emits a
+        // counted vmcnt(N) instead of draining the prefetch it has just issued (seen in the ISA of the conditional form).
+        typename LA::Regs ra0, ra1;
+        uint4 rb0[NVB], rb1[NVB];
+        auto fetch_b = [&](int kt, uint4 (&rb)[NVB]) {
+#pragma unroll
+            for (int i = 0; i < NVB; ++i) {
+                const int q = ptid + i * NT, piece = q / (BN * 4), within = q - piece * (BN * 4);
+                rb[i] = *reinterpret_cast<const uint4*>(p.w3 + (((long)piece * nk + kt) * Cout + n0) * 32 + within * 8);   // contiguous
+            }
+        };
+        auto commit = [&](const typename LA::Regs& ra, const uint4 (&rb)[NVB], unsigned char* st) {
+#pragma unroll
+            for (int i = 0; i < LA::NV; ++i) {
+                float4 v = ra.v[i];
+                const bool ok = ra.m[i] & 1u;
+                if (!UNPOOL) {
+                    v = mask4(v, ok ? 15u : 0u);
+                } else {
+                    const unsigned sub = ra.m[i] >> 1;
+                    v.x = (ok && ra.a[i].x == sub) ? v.x : 0.f;
+                    v.y = (ok && ra.a[i].y == sub) ? v.y : 0.f;
+                    v.z = (ok && ra.a[i].z == sub) ? v.z : 0.f;
+                    v.w = (ok && ra.a[i].w == sub) ? v.w : 0.f;
+                }
+                commit_a_x3(st, (ptid >> 3) + i * 32, (ptid & 7) * 4, v);
+            }
+#pragma unroll
+            for (int i = 0; i < NVB; ++i) {
+                const int q = ptid + i * NT, piece = q / (BN * 4), within = q - piece * (BN * 4);
+                *reinterpret_cast<uint4*>(st + ABUF + piece * BPLANE + (within >> 2) * X3_ROWB + (within & 3) * 16) = rb[i];
+            }
+        };
+        la.fetch(0, ra0, ptid);
+        fetch_b(0, rb0);
+        la.fetch(1, ra1, ptid);
+        fetch_b(1, rb1);
+        commit(ra0, rb0, smx);
+        __syncthreads();                                       // stage 0 holds tile 0
+        for (int kt = 0; kt < nk; kt += 2) {                   // nk is even (C_in % 64 == 0)
+            const int k2 = min(kt + 2, nk - 1), k3 = min(kt + 3, nk - 1);
+            la.fetch(k2, ra0, ptid);                           // consumers work on stage 0 (tile kt)
+            fetch_b(k2, rb0);
+            commit(ra1, rb1, smx + STAGE);                     // stage 1 <- tile kt+1
+            __syncthreads();
+            la.fetch(k3, ra1, ptid);                           // consumers work on stage 1 (tile kt+1)
+            fetch_b(k3, rb1);
+            if (kt + 2 < nk) commit(ra0, rb0, smx);            // stage 0 <- tile kt+2
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- consumers
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, hi = lane >> 5;
     f32x16 acc[TM][TN];
     E::zero(acc);
-
-    auto fetch_b = [&](int kt) {
-        const int tap = kt / cch, c0 = (kt - tap * cch) * BK;
-#pragma unroll
-        for (int i = 0; i < NVB; ++i) {
-            const int q = tid + i * NT, piece = q / (BN * 4), within = q - piece * (BN * 4);
-            const int row = within >> 2, k8 = (within & 3) * 8;
-            rb[i] = *reinterpret_cast<const uint4*>(p.w3 + (((long)piece * 9 + tap) * Cout + n0 + row) * Cin + c0 + k8);
-        }
-    };
-    auto commit = [&]() {
-#pragma unroll
-        for (int i = 0; i < LA::NV; ++i) {
-            float4 v = ra.v[i];
-            const bool ok = ra.m[i] & 1u;
-            if (!UNPOOL) {
-                v = mask4(v, ok ? 15u : 0u);
-            } else {
-                const unsigned sub = ra.m[i] >> 1;
-                v.x = (ok && ra.a[i].x == sub) ? v.x : 0.f;
-                v.y = (ok && ra.a[i].y == sub) ? v.y : 0.f;
-                v.z = (ok && ra.a[i].z == sub) ? v.z : 0.f;
-                v.w = (ok && ra.a[i].w == sub) ? v.w : 0.f;
-            }
-            commit_a_x3(smA, (tid >> 3) + i * 32, (tid & 7) * 4, v);
-        }
-#pragma unroll
-        for (int i = 0; i < NVB; ++i) {
-            const int q = tid + i * NT, piece = q / (BN * 4), within = q - piece * (BN * 4);
-            *reinterpret_cast<uint4*>(smB + piece * BPLANE + (within >> 2) * X3_ROWB + (within & 3) * 16) = rb[i];
-        }
-    };
-
-    la.fetch(0, ra, tid);
-    fetch_b(0);
-    commit();
-    __syncthreads();
+    const unsigned char* aBase = smx + (wm * WTM + l31) * X3_ROWB + hi * 16;
+    const unsigned char* bBase = smx + ABUF + (wn * WTN + l31) * X3_ROWB + hi * 16;
+    __syncthreads();                                           // stage 0 holds tile 0
     for (int kt = 0; kt < nk; ++kt) {
-        const bool more = kt + 1 < nk;
-        if (more) {                                            // next tile's global loads fly under this tile's MFMAs
-            la.fetch(kt + 1, ra, tid);
-            fetch_b(kt + 1);
-        }
+        const int so = (kt & 1) * STAGE;
 #pragma unroll
         for (int st = 0; st < BK / 16; ++st) {
             bf16x8 a[TM][3], bb[TN][3];
@@ -741,12 +768,12 @@ __global__ __launch_bounds__(NT) void conv3x3_x3_kernel(ConvX3P p) {
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int pc = 0; pc < 3; ++pc)
-                    a[i][pc] = *reinterpret_cast<const bf16x8*>(smA + pc * X3_APLANE + (wm * WTM + i * 32 + l31) * X3_ROWB + st * 32 + hi * 16);
+                    a[i][pc] = *reinterpret_cast<const bf16x8*>(aBase + so + pc * X3_APLANE + i * 32 * X3_ROWB + st * 32);
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int pc = 0; pc < 3; ++pc)
-                    bb[j][pc] = *reinterpret_cast<const bf16x8*>(smB + pc * BPLANE + (wn * WTN + j * 32 + l31) * X3_ROWB + st * 32 + hi * 16);
+                    bb[j][pc] = *reinterpret_cast<const bf16x8*>(bBase + so + pc * BPLANE + j * 32 * X3_ROWB + st * 32);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -761,11 +788,7 @@ __global__ __launch_bounds__(NT) void conv3x3_x3_kernel(ConvX3P p) {
                     acc[i][j] = c;
                 }
         }
-        __syncthreads();                                       // everyone is done reading this tile
-        if (more) {
-            commit();
-            __syncthreads();
-        }
+        __syncthreads();
     }
     if (EPI == EPI_RELU) {
         EpiConvRelu e{p.y, p.bias, b, t0, f0, p.g.T, p.g.F, Cout, n0};
@@ -781,18 +804,18 @@ __global__ __launch_bounds__(NT) void conv3x3_x3_kernel(ConvX3P p) {
 
 template <int BN, bool UNPOOL, int EPI>
 int launch_conv_x3(const ConvX3P& p, int Te, int Fe, hipStream_t s) {
-    constexpr int SMEM = 3 * X3_APLANE + 3 * BN * X3_ROWB;
+    constexpr int SMEM = 2 * (3 * X3_APLANE + 3 * BN * X3_ROWB);
     static int attr = set_smem(conv3x3_x3_kernel<BN, UNPOOL, EPI>, SMEM);
     if (attr) return attr;
     dim3 grid((Fe + 15) / 16, (Te + 7) / 8, p.g.B * p.ntile);
-    hipLaunchKernelGGL((conv3x3_x3_kernel<BN, UNPOOL, EPI>), grid, dim3(NT), SMEM, s, p);
+    hipLaunchKernelGGL((conv3x3_x3_kernel<BN, UNPOOL, EPI>), grid, dim3(2 * NT), SMEM, s, p);
     MTL_CHECK_LAUNCH();
     return MTL_OK;
 }
 
 template <bool UNPOOL, int EPI>
 int dispatch_conv_x3(ConvX3P& p, int Te, int Fe, hipStream_t s) {
-    if (p.g.Cin % 32 || p.g.Cout % 64) return MTL_EINVAL;
+    if (p.g.Cin % 64 || p.g.Cout % 64) return MTL_EINVAL;     // C_in % 64: even number of K-tiles (producer loop is unrolled by 2)
     if (p.g.Cout % 128 == 0) {
         p.ntile = p.g.Cout / 128;
         return launch_conv_x3<128, UNPOOL, EPI>(p, Te, Fe, s);

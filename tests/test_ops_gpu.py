@@ -403,8 +403,8 @@ def test_conv3x3_split_bf16_matches_fp32_reference(L, Cin, Cout, B, T, Fq):
     w3f = torch.empty(3 * 9 * Cin * Cout, dtype=torch.bfloat16).cuda()
     w3d = torch.empty(3 * 9 * Cin * Cout, dtype=torch.bfloat16).cuda()
     assert L.mtl_conv3x3_wprep_x3(st(), dw.data_ptr(), w3f.data_ptr(), w3d.data_ptr(), Cout, Cin) == 0
-    pieces = w3f.view(3, 9, Cout, Cin).float().sum(0).cpu()                 # the split is exact
-    assert torch.equal(pieces, w.permute(2, 3, 0, 1).reshape(9, Cout, Cin))
+    pieces = w3f.view(3, 9, Cin // 32, Cout, 32).float().sum(0).cpu()       # the split is exact; layout [tap][cin/32][cout][cin%32]
+    assert torch.equal(pieces, w.reshape(Cout, Cin // 32, 32, 9).permute(3, 1, 0, 2))
     y = torch.empty(B, T, Fq, Cout).cuda()
     assert L.mtl_conv3x3_relu_fwd_x3(st(), dxn.data_ptr(), w3f.data_ptr(), db.data_ptr(), y.data_ptr(), B, T, Fq, Cin, Cout) == 0
     assert rel(from_nhwc(y), yr) < 3e-6
