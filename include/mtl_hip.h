@@ -149,6 +149,12 @@ int mtl_adam_step(void* stream, float* theta, const float* G, float* m, float* v
                   float beta2, float eps, long n);
 int mtl_sumsq(void* stream, const float* x, long n, float* out, float* workspace /* >= 4 KiB */, int mode, float arg);
 
+/* ---- spectrogram front-end (utils/data_loader.py:65-96): after the STFT has been computed as
+ * mtl_gemm_f32(frames (T x n_fft, lda = hop: overlapping rows of the padded waveform) . windowed DFT basis (n_fft x 2F)),
+ * out[f*T + t] = log1p(|X[t][f]|), optionally followed by (x - mean) / std (unbiased) over the whole utterance.
+ * partials: >= 256 doubles of scratch. */
+int mtl_spect_logmag(void* stream, const float* reim, int ld, int T, int F, float* out, double* partials, int normalize);
+
 /* ---- host helper: Levenshtein distance on code points (utils/metrics.py:38-44 uses python-Levenshtein) ---- */
 int mtl_levenshtein_u32(const unsigned int* a_host, int na, const unsigned int* b_host, int nb);
 

@@ -3,7 +3,8 @@
 Import as `mtl_amd` (see mtl_amd.py at the repository root; the directory name carries a hyphen).
 """
 from . import _lib  # noqa: F401
-from .data import Vocab, SyntheticTask, ManifestTaskDataset, load_vocab, synthetic_vocab, synth_batch  # noqa: F401
+from .data import (Vocab, SyntheticTask, ManifestTaskDataset, SpectrogramFrontEnd, load_vocab, load_wav_pcm16, synthetic_vocab,  # noqa: F401
+                   synth_batch)
 from .functions import init_transformer_model, save_meta_model, load_meta_model, post_process  # noqa: F401
 from .metrics import calculate_metrics, calculate_cer  # noqa: F401
 from .model import Transformer, Encoder, Decoder  # noqa: F401

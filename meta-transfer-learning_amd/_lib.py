@@ -49,6 +49,7 @@ SIGNATURES = {
     'mtl_scale': (I, [P, P, F, P, L]),
     'mtl_adam_step': (I, [P, P, P, P, P, I, F, F, F, F, L]),
     'mtl_sumsq': (I, [P, P, L, P, P, I, F]),
+    'mtl_spect_logmag': (I, [P, P, I, I, I, P, P, I]),
     'mtl_levenshtein_u32': (I, [P, I, P, I]),
 }
 

@@ -551,9 +551,65 @@ __global__ void permute_hc_kernel(const float* __restrict__ w, float* __restrict
     }
 }
 
+// ------------------------------------------------------------------ spectrogram front-end
+// reim is the DFT-as-GEMM output (T frames x [F real | F imag], ld); out[f*T + t] = log1p(|X[t][f]|) (the reference's
+// (freq, time) layout, utils/data_loader.py:80-88) plus per-block partial (sum, sum of squares) for the normalisation.
+__global__ __launch_bounds__(256) void spect_logmag_kernel(const float* __restrict__ reim, int ld, int T, int F,
+                                                           float* __restrict__ out, double* __restrict__ part) {
+    __shared__ double sh[2][4];
+    double s = 0.0, q = 0.0;
+    const long total = (long)T * F;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int t = (int)(e / F), f = (int)(e - (long)t * F);
+        const float re = reim[(long)t * ld + f], im = reim[(long)t * ld + F + f];
+        const float v = log1pf(sqrtf(re * re + im * im));
+        out[(long)f * T + t] = v;
+        s += v;
+        q += (double)v * v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_xor(s, o, 64);
+        q += __shfl_xor(q, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        sh[0][threadIdx.x >> 6] = s;
+        sh[1][threadIdx.x >> 6] = q;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[2 * blockIdx.x] = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
+        part[2 * blockIdx.x + 1] = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
+    }
+}
+// x = (x - mean) / std, std unbiased (torch.Tensor.std), statistics combined in fp64 from the fixed-order partials
+__global__ void spect_normalize_kernel(float* __restrict__ x, long n, const double* __restrict__ part, int nb) {
+    double s = 0.0, q = 0.0;
+    for (int b = 0; b < nb; ++b) {
+        s += part[2 * b];
+        q += part[2 * b + 1];
+    }
+    const double mean = s / (double)n;
+    const double var = (q - (double)n * mean * mean) / (double)(n - 1);
+    const float m = (float)mean, inv = (float)(1.0 / sqrt(var));
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) x[e] = (x[e] - m) * inv;
+}
+
 }  // namespace
 
 extern "C" {
+
+int mtl_spect_logmag(void* stream, const float* reim, int ld, int T, int F, float* out, double* partials, int normalize) {
+    if (!reim || !out || !partials || T <= 0 || F <= 0 || ld < 2 * F) return MTL_EINVAL;
+    const int nb = grid_for((long)T * F, 256, 128);
+    hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL(spect_logmag_kernel, dim3(nb), dim3(256), 0, s, reim, ld, T, F, out, partials);
+    if (normalize)
+        hipLaunchKernelGGL(spect_normalize_kernel, dim3(grid_for((long)T * F, 256, 256)), dim3(256), 0, s, out, (long)T * F, partials, nb);
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}
+
 
 int mtl_sgd_theta_prime(void* stream, const float* theta0, const float* g, float alpha, float* theta1, long n) {
     if (!theta0 || !g || !theta1 || n <= 0) return MTL_EINVAL;

@@ -98,7 +98,12 @@ class ManifestTaskDataset:
     feature_fn(wav_path) -> (F, T) float tensor replaces `parse_audio`; sampling uses np.random.choice with the same
     per-manifest probabilities (uniform, or uniform over the leading `partitions[i]` fraction)."""
 
-    def __init__(self, vocab, args, manifest_filepath_list, feature_fn, partitions=None):
+    def __init__(self, vocab, args, manifest_filepath_list, feature_fn=None, partitions=None):
+        if feature_fn is None:
+            # default: 16-bit PCM wav -> device spectrogram front-end (SpectrogramParser.parse_audio, normalize=True as in
+            # meta_transfer_train.py:161), handed back on the host like the reference's parse_audio output
+            fe = SpectrogramFrontEnd(args.sample_rate, args.window_size, args.window_stride, getattr(args, 'window', 'hamming'), True)
+            feature_fn = lambda path: fe(load_wav_pcm16(path)).cpu()
         self.vocab, self.args, self.feature_fn = vocab, args, feature_fn
         self.ids_list = [read_manifest(p) for p in manifest_filepath_list]
         self.proba = []
@@ -163,3 +168,61 @@ class SyntheticTask:
                 x = x.pin_memory()
             out.append((x, lens, lens.float() / self.T, y, (y != 0).sum(1).to(torch.int32)))
         return tuple(out)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Spectrogram front-end on the device: SpectrogramParser.parse_audio, utils/data_loader.py:65-96
+# ------------------------------------------------------------------------------------------------------------------
+def load_wav_pcm16(path):
+    """16-bit PCM .wav -> float32 mono in [-1, 1) (utils/audio.py:7-15 uses torchaudio.load(normalization=True); channels averaged)."""
+    import wave
+    with wave.open(path, 'rb') as w:
+        if w.getsampwidth() != 2:
+            raise ValueError('only 16-bit PCM wav files are supported here')
+        raw = np.frombuffer(w.readframes(w.getnframes()), dtype='<i2').astype(np.float32) / 32768.0
+        ch = w.getnchannels()
+    return raw.reshape(-1, ch).mean(axis=1).astype(np.float32) if ch > 1 else raw
+
+
+class SpectrogramFrontEnd:
+    """wav -> STFT (n_fft = win = sample_rate*window_size, hop = sample_rate*window_stride, symmetric Hamming window,
+    center + reflect padding = librosa.stft defaults of the reference era) -> |.| -> log1p -> (x-mean)/std, all on the MI355X:
+    the STFT is one fp32-MFMA GEMM (frames = overlapping rows of the padded waveform, lda = hop) against a windowed DFT basis."""
+
+    def __init__(self, sample_rate=16000, window_size=0.02, window_stride=0.01, window='hamming', normalize=True, device='cuda'):
+        from scipy.signal import windows as sw
+        self.n_fft = int(sample_rate * window_size)
+        self.hop = int(sample_rate * window_stride)
+        self.F = self.n_fft // 2 + 1
+        self.normalize = normalize
+        self.device = torch.device(device)
+        table = {'hamming': sw.hamming, 'hann': sw.hann, 'blackman': sw.blackman, 'bartlett': sw.bartlett}
+        win = table[window](self.n_fft)                       # the reference passes the scipy FUNCTION -> symmetric window
+        n = np.arange(self.n_fft)[:, None].astype(np.float64)
+        f = np.arange(self.F)[None, :].astype(np.float64)
+        ang = 2.0 * np.pi * n * f / self.n_fft
+        self.ldb = (2 * self.F + 3) // 4 * 4
+        basis = np.zeros((self.n_fft, self.ldb), dtype=np.float32)
+        basis[:, :self.F] = (win[:, None] * np.cos(ang)).astype(np.float32)
+        basis[:, self.F:2 * self.F] = (-win[:, None] * np.sin(ang)).astype(np.float32)
+        self.basis = torch.from_numpy(basis).to(self.device)
+        self.partials = torch.empty(512, dtype=torch.float64, device=self.device)
+
+    def __call__(self, y):
+        """y: 1-D float waveform (numpy or tensor) -> (F, T) fp32 tensor on the device, T = 1 + len(y) // hop."""
+        from . import _lib
+        if self.device.type != 'cuda':
+            raise RuntimeError('the spectrogram front-end runs on the MI355X only (no CPU fallback)')
+        lib = _lib.lib()
+        y = np.asarray(y.detach().cpu() if torch.is_tensor(y) else y, dtype=np.float32).reshape(-1)
+        pad = self.n_fft // 2
+        yp = torch.from_numpy(np.pad(y, (pad, pad), mode='reflect')).to(self.device)
+        T = 1 + y.shape[0] // self.hop
+        reim = torch.empty(T, self.ldb, device=self.device)
+        out = torch.empty(self.F, T, device=self.device)
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(lib.mtl_gemm_f32(st, 0, 0, T, 2 * self.F, self.n_fft, 1.0, yp.data_ptr(), self.hop, self.basis.data_ptr(), self.ldb,
+                                    reim.data_ptr(), self.ldb, None, None, 0, 0, 1, 1, 0, 0, 0, 0, 0, 0, None, 0), 'stft gemm')
+        _lib.check(lib.mtl_spect_logmag(st, reim.data_ptr(), self.ldb, T, self.F, out.data_ptr(), self.partials.data_ptr(),
+                                        1 if self.normalize else 0), 'mtl_spect_logmag')
+        return out

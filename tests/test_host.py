@@ -112,3 +112,25 @@ def test_task_sharding():
     assert mtl_amd.dist.shard_tasks(8, 3, 8) == [3]
     assert mtl_amd.dist.shard_tasks(8, 1, 2) == [1, 3, 5, 7]
     assert sorted(sum((mtl_amd.dist.shard_tasks(3, r, 2) for r in range(2)), [])) == [0, 1, 2]
+
+
+def test_frontend_oracle_is_the_textbook_stft():
+    """oracle/frontend.py (numpy restatement of librosa.stft for the reference's call; parity unpinned, no librosa here) against
+    the DFT definition evaluated directly in float64."""
+    from oracle import frontend
+    from scipy.signal import windows
+    rng = np.random.RandomState(1)
+    y = rng.randn(1000).astype(np.float32)
+    n_fft, hop = 320, 160
+    mag = frontend.stft_magnitude(y, n_fft, hop)
+    assert mag.shape == (161, 1 + 1000 // 160)
+    yp = np.pad(y.astype(np.float64), 160, mode='reflect')
+    w = windows.hamming(n_fft)
+    assert abs(w[0] - w[-1]) < 1e-12 and abs(w[0] - 0.08) < 1e-12            # symmetric window (callable passed to librosa)
+    for t in (0, 3, 6):
+        frame = yp[t * hop:t * hop + n_fft] * w
+        for f in (0, 1, 57, 160):
+            ref = abs(np.sum(frame * np.exp(-2j * np.pi * f * np.arange(n_fft) / n_fft)))
+            assert abs(mag[f, t] - ref) < 1e-3 * max(ref, 1.0)
+    sp = frontend.parse_audio(y)
+    assert abs(float(sp.mean())) < 1e-5 and abs(float(sp.std()) - 1.0) < 1e-5

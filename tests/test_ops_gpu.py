@@ -432,3 +432,27 @@ def test_conv3x3_split_bf16_matches_fp32_reference(L, Cin, Cout, B, T, Fq):
     dyn = dev(nhwc(dy * (y2.detach() > 0)))
     assert L.mtl_conv3x3_dgrad_x3(st(), dyn.data_ptr(), None, w3d.data_ptr(), dxn.data_ptr(), dx.data_ptr(), B, T, Fq, Cin, Cout) == 0
     assert rel(from_nhwc(dx), xr2.grad * (x > 0)) < 1e-5
+
+
+def test_spectrogram_front_end_matches_oracle(L, tmp_path):
+    """wav -> STFT (DFT-as-GEMM) -> log1p|.| -> normalise on the device vs the numpy restatement."""
+    import wave
+    import mtl_amd
+    from oracle import frontend
+    rng = np.random.RandomState(0)
+    t = np.arange(16000 * 2 + 37) / 16000.0
+    y = (0.3 * np.sin(2 * np.pi * 440 * t) + 0.2 * np.sin(2 * np.pi * 3100 * t * (1 + 0.1 * t)) + 0.05 * rng.randn(t.size)).astype(np.float32)
+    fe = mtl_amd.SpectrogramFrontEnd(16000, 0.02, 0.01, 'hamming', normalize=True)
+    got = fe(y).cpu()
+    ref = frontend.parse_audio(y)
+    assert got.shape == ref.shape == (161, 1 + y.size // 160)
+    assert rel(got, ref) < 2e-5                       # fp32 DFT with K = 320 vs float32 FFT
+    raw = mtl_amd.SpectrogramFrontEnd(16000, 0.02, 0.01, 'hamming', normalize=False)(y).cpu()
+    assert rel(raw, frontend.parse_audio(y, normalize=False)) < 2e-5
+    # 16-bit PCM wav path (utils/audio.py:7-15)
+    p = str(tmp_path / 'a.wav')
+    with wave.open(p, 'wb') as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000)
+        w.writeframes((np.clip(y, -1, 1) * 32767).astype('<i2').tobytes())
+    yw = mtl_amd.load_wav_pcm16(p)
+    assert abs(yw - np.clip(y, -1, 1)).max() < 1e-4 and rel(fe(yw).cpu(), frontend.parse_audio(yw)) < 2e-5
