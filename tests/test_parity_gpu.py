@@ -404,3 +404,25 @@ def test_hipgraph_replay_is_bitwise_equal_to_eager():
         if mode:
             assert any(isinstance(v, dict) for v in tr._graphs.values()), 'no graph was captured'
     assert torch.equal(res[False][0], res[True][0]) and torch.equal(res[False][1], res[True][1])
+
+
+@pytest.mark.parametrize('B,T,L,lens,tlens', [
+    (1, 17, 1, [17], [1]),                       # single utterance, T' = 4, one label
+    (3, 50, 5, [50, 13, 4], [5, 2, 1]),          # T not a multiple of 4/8; a row shorter than T/4; ragged targets
+    (2, 129, 12, [129, 65], [12, 7]),            # odd T, pooled tails (129 -> 64 -> 32)
+    (5, 36, 3, [36, 36, 9, 30, 1], [3, 3, 1, 2, 3]),   # a length-1 utterance (everything past key 0 masked)
+])
+def test_ragged_shapes_against_live_oracle(B, T, L, lens, tlens):
+    """edge shapes of the path (empty/ragged inputs): tile tails of every kernel, Q2 masks, PAD/EOS handling"""
+    from oracle import refimpl as R
+    z, cfg, spec = gu.load('F0')
+    mtl_amd, args, vocab, model = make(cfg, spec)
+    model = model.cuda()
+    oracle = R.build_model(cfg)
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    x = torch.randn(B, 1, 161, T, generator=g)
+    y = torch.randint(4, cfg['vocab_size'], (B, L), generator=g)
+    for i in range(B):
+        x[i, :, :, lens[i]:] = 0
+        y[i, tlens[i]:] = 0
+    _pass_parity(model, oracle, (x, torch.tensor(lens, dtype=torch.int32), y), model.flat_parameters, 'ragged B%d T%d' % (B, T))
