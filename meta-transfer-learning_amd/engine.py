@@ -499,6 +499,92 @@ class PassEngine:
                           enc_inputs=enc_inputs)
         return dict(pred=pred, gold=ids[1], hyp=hyp, loss=loss, gold_host=meta['gold_host'], n_nonpad=n_nonpad)
 
+    # ---------------------------------------------------------------- greedy decoding
+    def greedy_decode(self, theta, mem, B, T4, start_token, max_steps=300):
+        """Decoder.greedy_search (modules/decoder.py:131-185) on the device: max_steps arg-max steps from `start_token`,
+        no padding masks (the reference passes dec_enc_attn_mask=None and an all-ones non_pad_mask), only causality.
+        The reference re-runs the whole decoder on the growing prefix at every step; here each layer keeps a K/V cache
+        and only the new position is computed (same per-row arithmetic), and the chosen token is fed back through device
+        memory, so the 300 steps run without a single host synchronisation.  Returns the (max_steps, B) int64 token ids."""
+        hp, L, lib = self.hp, self.L, self.lib
+        d, r, h, dk, dv, V = hp.d, hp.r, hp.h, hp.dk, hp.dv, hp.V
+        hk, hv = h * dk, h * dv
+        if max_steps + 1 > hp.tgt_max_len:
+            raise ValueError('tgt_max_len too small for %d decoding steps' % max_steps)
+        P = theta.data_ptr()
+        S = max_steps + 1
+        ys = self.buf('g.ys', (S, B), torch.int64)
+        ys[0].fill_(int(start_token))
+        zero_gold = self.buf('g.zero', (B,), torch.int64)
+        zero_gold.zero_()
+        x = self.buf('g.x', (B, d))
+        kc = [self.buf('g.kc%d' % i, (B, S, hk)) for i in range(hp.n_dec)]
+        vc = [self.buf('g.vc%d' % i, (B, S, hv)) for i in range(hp.n_dec)]
+        ck = [self.buf('g.ck%d' % i, (B * T4, hk)) for i in range(hp.n_dec)]
+        cv = [self.buf('g.cv%d' % i, (B * T4, hv)) for i in range(hp.n_dec)]
+        ta, tq = self.buf('g.ta', (max(B * T4, B), r)), self.buf('g.q', (B, hk))
+        to, toa, tob = self.buf('g.o', (B, hv)), self.buf('g.oa', (B, r)), self.buf('g.ob', (B, d))
+        y1, y2, y3 = self.buf('g.y1', (B, d)), self.buf('g.y2', (B, d)), self.buf('g.y3', (B, d))
+        h1, h2 = self.buf('g.h1', (B, hp.inner)), self.buf('g.h2', (B, d))
+        xhat, rstd = self.buf('g.xhat', (B, d)), self.buf('g.rstd', (B,))
+        ldS = (max(S, T4) + 3) // 4 * 4
+        Sc = self.buf('g.S', (B, h, 1, ldS))
+        logits = self.buf('g.logits', (B, V))
+        junk = self.buf('g.junk', (3 * B + 4,))
+        scale = 1.0 / float(hp.temperature)
+
+        def lowrank(pre, name, src, rows, dst, ldc=None, width=hk):
+            o = lambda n: P + 4 * L.off(pre + n)
+            self.linear_fwd(src, rows, d if name != 'output' else hv, o(name + '_linear_a.weight'), None, ta.data_ptr(), r)
+            self.gemm(0, 1, rows, width, r, ta.data_ptr(), r, o(name + '_linear_b.weight'), r, dst, ldc or width,
+                      bias=o(name + '_linear_b.bias'))
+
+        def attend(q, kbuf, vbuf, kv_rows, kv_stride, out):
+            # one query row per (b, h): scores over kv_rows keys, softmax, weighted sum of the values
+            self.gemm(0, 1, 1, kv_rows, dk, q, hk, kbuf, hk, Sc.data_ptr(), ldS, batch=B * h, H=h, sA=(hk, dk), sB=(kv_stride, dk),
+                      sC=(h * ldS, ldS))
+            check(lib.mtl_softmax_mask_fwd(self.stream, Sc.data_ptr(), None, 0, scale, B, h, 1, kv_rows, ldS, None, 1.0, None), 'softmax')
+            self.gemm(0, 0, 1, dv, kv_rows, Sc.data_ptr(), ldS, vbuf, hv, out, hv, batch=B * h, H=h, sA=(h * ldS, ldS),
+                      sB=(kv_stride, dv), sC=(hv, dv))
+
+        for i in range(hp.n_dec):                                   # cross-attention keys / values of the encoder output, once
+            pre = 'decoder.layers.%d.encoder_attn.' % i
+            lowrank(pre, 'key', mem, B * T4, ck[i].data_ptr())
+            lowrank(pre, 'value', mem, B * T4, cv[i].data_ptr(), width=hv)
+        for t in range(max_steps):
+            check(lib.mtl_embed_pe_fwd(self.stream, ys.data_ptr() + 8 * t * B, P + 4 * L.off('decoder.trg_embedding.weight'),
+                                       self.pe_dec.data_ptr() + 4 * t * d, x.data_ptr(), B, 1, d, None, 1.0), 'embed')
+            cur = x
+            for i in range(hp.n_dec):
+                pre = 'decoder.layers.%d.' % i
+                o = lambda n: P + 4 * L.off(pre + n)
+                sa = pre + 'self_attn.'
+                lowrank(sa, 'query', cur.data_ptr(), B, tq.data_ptr())
+                lowrank(sa, 'key', cur.data_ptr(), B, kc[i].data_ptr() + 4 * t * hk, ldc=S * hk)      # row t of the cache
+                lowrank(sa, 'value', cur.data_ptr(), B, vc[i].data_ptr() + 4 * t * hv, ldc=S * hv, width=hv)
+                attend(tq.data_ptr(), kc[i].data_ptr(), vc[i].data_ptr(), t + 1, S * hk, to.data_ptr())
+                lowrank(sa, 'output', to.data_ptr(), B, tob.data_ptr(), width=d)
+                self.ln_fwd(tob.data_ptr(), cur.data_ptr(), o('self_attn.layer_norm.weight'), o('self_attn.layer_norm.bias'), None, None,
+                            y1.data_ptr(), xhat.data_ptr(), rstd.data_ptr(), B, 1)
+                ca = pre + 'encoder_attn.'
+                lowrank(ca, 'query', y1.data_ptr(), B, tq.data_ptr())
+                attend(tq.data_ptr(), ck[i].data_ptr(), cv[i].data_ptr(), T4, T4 * hk, to.data_ptr())
+                lowrank(ca, 'output', to.data_ptr(), B, tob.data_ptr(), width=d)
+                self.ln_fwd(tob.data_ptr(), y1.data_ptr(), o('encoder_attn.layer_norm.weight'), o('encoder_attn.layer_norm.bias'), None,
+                            None, y2.data_ptr(), xhat.data_ptr(), rstd.data_ptr(), B, 1)
+                self.linear_fwd(y2.data_ptr(), B, d, o('pos_ffn.linear_1.weight'), o('pos_ffn.linear_1.bias'), h1.data_ptr(), hp.inner,
+                                relu=True)
+                self.linear_fwd(h1.data_ptr(), B, hp.inner, o('pos_ffn.linear_2.weight'), o('pos_ffn.linear_2.bias'), h2.data_ptr(), d)
+                self.ln_fwd(h2.data_ptr(), y2.data_ptr(), o('pos_ffn.layer_norm.weight'), o('pos_ffn.layer_norm.bias'), None, None,
+                            y3.data_ptr(), xhat.data_ptr(), rstd.data_ptr(), B, 1)
+                cur = self.buf('g.cur%d' % (i & 1), (B, d))
+                check(lib.mtl_copy_f32(self.stream, cur.data_ptr(), y3.data_ptr(), B * d), 'copy')
+            self.gemm(0, 1, B, V, d, cur.data_ptr(), d, P + 4 * L.off('decoder.output_linear.weight'), d, logits.data_ptr(), V)
+            check(lib.mtl_ce_argmax_fwd(self.stream, logits.data_ptr(), zero_gold.data_ptr(), B, V, V, PAD_ID, 0.0, 1, None,
+                                        junk.data_ptr(), ys.data_ptr() + 8 * (t + 1) * B, junk.data_ptr() + 4 * B,
+                                        junk.data_ptr() + 8 * B), 'argmax')
+        return ys[1:]
+
     def backward(self, grad, scale=1.0, dpred=None):
         """Accumulate `scale` * dLoss/dtheta of the LAST forward into the flat buffer `grad` (+=).
         dpred: optional externally supplied gradient w.r.t. pred (B,Td,V) instead of the fused CE backward."""

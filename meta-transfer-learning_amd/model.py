@@ -338,5 +338,33 @@ class Transformer(nn.Module):
         else:
             raise RuntimeError('copy_grad accumulation needs the HIP library on an MI355X device')
 
-    def evaluate(self, *a, **kw):
-        raise NotImplementedError('greedy/beam decoding (Transformer.evaluate) is outside the accelerated hot path (SURVEY 8(f) f2)')
+    def evaluate(self, padded_input, input_lengths, padded_target, args=None, beam_search=False, beam_width=0, beam_nbest=0, lm=None,
+                 lm_rescoring=False, lm_weight=0.1, c_weight=1, start_token=-1, verbose=False, max_steps=300):
+        """models/asr/transformer.py:162-202 for the greedy branch: returns (None, strs_hyps, strs_gold).
+        The encoder + teacher-forced decoder pass supplies the gold strings exactly like the reference; hypotheses come from
+        PassEngine.greedy_decode (K/V-cached, device-resident token feedback).  Beam search / LM rescoring are not accelerated."""
+        if beam_search or lm_rescoring:
+            raise NotImplementedError('beam search / LM rescoring are outside the accelerated path; use greedy decoding')
+        eng = self._need_engine()
+        was_training = self.training
+        self.eval()
+        try:
+            out = self.pass_forward(padded_input, input_lengths, padded_target)
+            B, T = padded_input.shape[0], padded_input.shape[3]
+            T4 = (T // 2) // 2
+            mem = eng.arena['e%d.ff.y' % (eng.hp.n_enc - 1)] if eng.hp.n_enc else eng.arena['enc_in.y']
+            start = self.vocab.SOS_ID if start_token < 0 else start_token      # the reference's callers pass vocab.SOS_ID
+            ids = eng.greedy_decode(self._theta, mem.data_ptr(), B, T4, start, max_steps).cpu()          # (steps, B)
+        finally:
+            self.train(was_training)
+        strs_gold = [''.join(self.vocab.id2label[int(t)] for t in row) for row in out['gold_host']]
+        strs_hyps = []
+        for b in range(ids.shape[1]):
+            st = ''
+            for t in ids[:, b].tolist():
+                if t == self.vocab.EOS_ID:
+                    break
+                st += self.vocab.id2label[t]
+            strs_hyps.append(st)
+        self.last_greedy_ids = ids
+        return None, strs_hyps, strs_gold

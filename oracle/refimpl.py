@@ -231,6 +231,30 @@ class SpeechTransformer(nn.Module):
         return pred, gold, hyp
 
 
+def greedy_search(model, padded_input, input_lengths, start_token, steps):
+    """Decoder.greedy_search (modules/decoder.py:131-185) restated: at every step the WHOLE decoder is re-run on the prefix,
+    non_pad_mask all ones, causal self-attention mask only, no encoder padding mask; arg-max of the last position."""
+    model.eval()
+    with torch.no_grad():
+        f = model.conv(padded_input)
+        B, C, H, W = f.shape
+        mem = model.encoder(f.view(B, C * H, W).transpose(1, 2).contiguous(), input_lengths)
+        dec = model.decoder
+        ys = torch.full((B, 1), int(start_token), dtype=torch.int64)
+        for _ in range(steps):
+            Lq = ys.shape[1]
+            future = torch.triu(torch.ones(Lq, Lq, dtype=torch.bool), diagonal=1).unsqueeze(0).expand(B, Lq, Lq)
+            nomask = torch.zeros(B, Lq, mem.shape[1], dtype=torch.bool)
+            keep = torch.ones(B, Lq, 1)
+            x = dec.trg_embedding(ys) + dec.positional_encoding.pe[:, :Lq]
+            for layer in dec.layers:
+                x = layer(x, mem, keep, future, nomask)
+            nxt = dec.output_linear(x)[:, -1].max(dim=1)[1]
+            ys = torch.cat([ys, nxt.unsqueeze(1)], dim=1)
+    model.train()
+    return ys[:, 1:]
+
+
 def build_model(cfg, seed=123456):
     """cfg: dict with the hyper-parameters of utils/functions.py:307-351; seeds like meta_transfer_train.py:109."""
     torch.manual_seed(seed)

@@ -426,3 +426,27 @@ def test_ragged_shapes_against_live_oracle(B, T, L, lens, tlens):
         x[i, :, :, lens[i]:] = 0
         y[i, tlens[i]:] = 0
     _pass_parity(model, oracle, (x, torch.tensor(lens, dtype=torch.int32), y), model.flat_parameters, 'ragged B%d T%d' % (B, T))
+
+
+def test_greedy_decoding_matches_oracle():
+    """Transformer.evaluate / Decoder.greedy_search -- token ids of every step, bit-exact, and the strings."""
+    from oracle import refimpl as R
+    z, cfg, spec = gu.load('F0')
+    mtl_amd, args, vocab, model = make(cfg, spec)
+    model = model.cuda()
+    oracle = R.build_model(cfg)
+    x, lens, y = R.synth_batch(5, 3, 72, 6, cfg['vocab_size'], True)
+    steps = 24
+    _, hyps, golds = model.evaluate(x.cuda(), lens, y, args, start_token=vocab.SOS_ID, max_steps=steps)
+    ref = R.greedy_search(oracle, x, lens, vocab.SOS_ID, steps)             # (B, steps)
+    assert torch.equal(model.last_greedy_ids.t().contiguous(), ref)
+    for b in range(3):
+        exp = ''
+        for t in ref[b].tolist():
+            if t == vocab.EOS_ID:
+                break
+            exp += vocab.id2label[t]
+        assert hyps[b] == exp
+    _, gold_ref, _ = oracle(x, lens, y)
+    assert golds == [''.join(vocab.id2label[int(t)] for t in row) for row in gold_ref]
+    assert model.training                                                   # evaluate() restores the mode
