@@ -16,6 +16,7 @@
 // Reference ops replaced (file:line in /root/reference): nn.Linear fwd/bwd (modules/encoder.py:72,
 // modules/common_layers.py:130,287-289,303, modules/decoder.py:109), torch.bmm (common_layers.py:321,329),
 // nn.Conv2d/ReLU/MaxPool2d (models/asr/transformer.py:48-59).
+#include <cstdlib>
 #include <type_traits>
 
 #include "mtl_common.h"
@@ -813,15 +814,229 @@ int launch_conv_x3(const ConvX3P& p, int Te, int Fe, hipStream_t s) {
     return MTL_OK;
 }
 
+// ------------------------------------------------------------------ halo-tiled x3 convolution (the one the C ABI dispatches to)
+// What the ablation of conv3x3_x3_kernel showed: the consumer side can run 256 TF-equivalent, the producer
+// side is bound by (a) re-gathering + re-splitting every input element once per tap and (b) the weight tile per 128 pixels.
+// Here a workgroup owns a 16(T) x 16(F) pixel tile (two pool-aligned 8x16 sub-tiles, 8 consumer waves) and, per 32-channel
+// chunk, stages the 18x18 input HALO once (gather + 3-way split + LDS write) for all nine taps; the consumers address the
+// halo with a per-tap offset.  Weight tiles ([piece][K-tile][row][32], double-buffered) are shared by 256 pixels.
+// LDS: halo 324 px x 80 B x 3 planes = 76 KiB + 2 x 3 x BN x 80 B weights (60 KiB at BN = 128) = 136 KiB, 12 waves per CU.
+constexpr int XH_HT = 18, XH_HF = 18, XH_NPIX = XH_HT * XH_HF;       // halo of a 16 x 16 tile
+constexpr int XH_APLANE = XH_NPIX * X3_ROWB;                       // one bf16 plane of the halo
+constexpr int XH_NVA = (XH_NPIX * 8 + NT - 1) / NT;                // float4 (4 channels) per producer thread and chunk
+
+template <int BN, bool UNPOOL, int EPI>
+__global__ __launch_bounds__(768) void conv3x3_x3h_kernel(ConvX3P p) {
+    using E = Engine<128, BN, LoadConvA<UNPOOL>, LoadMNMajor<BN, true>>;   // tile constants only
+    constexpr int TM = E::TM, TN = E::TN, WTM = E::WTM, WTN = E::WTN;
+    constexpr int BPLANE = BN * X3_ROWB, BBUF = 3 * BPLANE, ABUF = 3 * XH_APLANE;
+    constexpr int NVB = 3 * BN * 4 / NT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smx[];
+    unsigned char* smA = smx;
+    unsigned char* smB = smx + ABUF;
+    const int tid = threadIdx.x;
+    const int b = blockIdx.z / p.ntile, n0 = (blockIdx.z % p.ntile) * BN;
+    const int t0 = blockIdx.y * 16, f0 = blockIdx.x * 16;
+    const int Cin = p.g.Cin, Cout = p.g.Cout, cch = Cin / BK, nk = 9 * cch;
+    const int T = p.g.T, F = p.g.F, Tp = p.g.Tp, Fp = p.g.Fp;
+
+    if (tid >= 2 * NT) {
+        // ------------------------------------------------------------------ producers (4 waves)
+        const int ptid = tid - 2 * NT;
+        float4 hv[XH_NVA];
+        uchar4 ha[XH_NVA];
+        unsigned hm[XH_NVA];
+        uint4 rb[NVB];
+        auto fetch_halo = [&](int c) {          // chunk c: channels c*32 .. +31 of the 18 x 18 halo pixels
+#pragma unroll
+            for (int i = 0; i < XH_NVA; ++i) {
+                const int q = ptid + i * NT;
+                const int hp = min(q >> 3, XH_NPIX - 1), c4 = (q & 7) * 4;
+                const int ht = hp / XH_HF, hf = hp - ht * XH_HF;
+                const int ts = t0 + ht - 1, fs = f0 + hf - 1;
+                bool ok = (q >> 3) < XH_NPIX && (unsigned)ts < (unsigned)T && (unsigned)fs < (unsigned)F;
+                const int tc = min(max(ts, 0), T - 1), fc = min(max(fs, 0), F - 1);
+                if (!UNPOOL) {
+                    hv[i] = *reinterpret_cast<const float4*>(p.x + (((long)b * T + tc) * F + fc) * Cin + c * BK + c4);
+                    hm[i] = ok ? 1u : 0u;
+                } else {
+                    const int tp = tc >> 1, fp = fc >> 1;
+                    ok = ok && tp < Tp && fp < Fp;
+                    const long o = (((long)b * Tp + min(tp, Tp - 1)) * Fp + min(fp, Fp - 1)) * Cin + c * BK + c4;
+                    ha[i] = *reinterpret_cast<const uchar4*>(p.am_in + o);
+                    hv[i] = *reinterpret_cast<const float4*>(p.x + o);
+                    hm[i] = (ok ? 1u : 0u) | ((unsigned)(((fs & 1) << 1) | (ts & 1)) << 1);
+                }
+            }
+        };
+        auto commit_halo = [&]() {
+#pragma unroll
+            for (int i = 0; i < XH_NVA; ++i) {
+                const int q = ptid + i * NT;
+                if ((q >> 3) >= XH_NPIX) continue;
+                float4 v = hv[i];
+                const bool ok = hm[i] & 1u;
+                if (!UNPOOL) {
+                    v = mask4(v, ok ? 15u : 0u);
+                } else {
+                    const unsigned sub = hm[i] >> 1;
+                    v.x = (ok && ha[i].x == sub) ? v.x : 0.f;
+                    v.y = (ok && ha[i].y == sub) ? v.y : 0.f;
+                    v.z = (ok && ha[i].z == sub) ? v.z : 0.f;
+                    v.w = (ok && ha[i].w == sub) ? v.w : 0.f;
+                }
+                __bf16 hh[4], mm[4], ll[4];
+                split3(v.x, hh[0], mm[0], ll[0]);
+                split3(v.y, hh[1], mm[1], ll[1]);
+                split3(v.z, hh[2], mm[2], ll[2]);
+                split3(v.w, hh[3], mm[3], ll[3]);
+                unsigned char* dst = smA + (q >> 3) * X3_ROWB + (q & 7) * 8;
+                *reinterpret_cast<bf16x4*>(dst) = bf16x4{hh[0], hh[1], hh[2], hh[3]};
+                *reinterpret_cast<bf16x4*>(dst + XH_APLANE) = bf16x4{mm[0], mm[1], mm[2], mm[3]};
+                *reinterpret_cast<bf16x4*>(dst + 2 * XH_APLANE) = bf16x4{ll[0], ll[1], ll[2], ll[3]};
+            }
+        };
+        auto fetch_b = [&](int kt) {
+#pragma unroll
+            for (int i = 0; i < NVB; ++i) {
+                const int q = ptid + i * NT, piece = q / (BN * 4), within = q - piece * (BN * 4);
+                rb[i] = *reinterpret_cast<const uint4*>(p.w3 + (((long)piece * nk + kt) * Cout + n0) * 32 + within * 8);
+            }
+        };
+        auto commit_b = [&](int stage) {
+#pragma unroll
+            for (int i = 0; i < NVB; ++i) {
+                const int q = ptid + i * NT, piece = q / (BN * 4), within = q - piece * (BN * 4);
+                *reinterpret_cast<uint4*>(smB + stage * BBUF + piece * BPLANE + (within >> 2) * X3_ROWB + (within & 3) * 16) = rb[i];
+            }
+        };
+        // step s = chunk * 9 + tap uses weight stage s & 1 and K-tile (s % 9) * cch + s / 9; the weight tile of step s + 2 is in
+        // flight (registers) while step s + 1's is committed, so neither L2 latency nor the commit is exposed
+        auto ktile = [&](int s) { const int c = s / 9; return (s - c * 9) * cch + c; };
+        fetch_halo(0);
+        fetch_b(ktile(0));
+        commit_halo();
+        commit_b(0);
+        fetch_b(ktile(1));
+        if (cch > 1) fetch_halo(1);
+        __syncthreads();                                       // halo(0) and the weights of step 0 are visible
+        int tap = 0, c = 0;
+#pragma unroll 1
+        for (int s = 0; s < nk; ++s) {
+            if (s + 1 < nk) {
+                commit_b((s + 1) & 1);
+                if (s + 2 < nk) fetch_b(ktile(s + 2));
+            }
+            __syncthreads();                                   // consumers are done with step s
+            if (++tap == 9) {
+                tap = 0;
+                ++c;
+                if (c < cch) {
+                    commit_halo();                             // nobody reads the halo between these two barriers
+                    if (c + 1 < cch) fetch_halo(c + 1);
+                    __syncthreads();
+                }
+            }
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- consumers (8 waves: 2 sub-tiles x (2 x 2))
+    const int lane = tid & 63, wave = tid >> 6;
+    const int grp = wave >> 2, w4 = wave & 3;
+    const int wm = w4 >> 1, wn = w4 & 1, l31 = lane & 31, hi = lane >> 5;
+    f32x16 acc[TM][TN];
+    E::zero(acc);
+    int abase[TM];                                             // byte offset of this lane's pixel (tap centre) in the halo plane
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        int t, f;
+        tile_row_to_tf(wm * WTM + i * 32 + l31, t, f);
+        abase[i] = ((t + grp * 8 + 1) * XH_HF + (f + 1)) * X3_ROWB + hi * 16;
+    }
+    const unsigned char* bBase = smB + (wn * WTN + l31) * X3_ROWB + hi * 16;
+    __syncthreads();
+    int sidx = 0;
+    for (int c = 0; c < cch; ++c) {
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap, ++sidx) {
+            const int kh = tap / 3, kw = tap - kh * 3;
+            const int toff = ((kw - 1) * XH_HF + (kh - 1)) * X3_ROWB;
+            const unsigned char* bS = bBase + (sidx & 1) * BBUF;
+#pragma unroll
+            for (int st = 0; st < BK / 16; ++st) {
+                bf16x8 a[TM][3], bb[TN][3];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int pc = 0; pc < 3; ++pc)
+                        a[i][pc] = *reinterpret_cast<const bf16x8*>(smA + pc * XH_APLANE + abase[i] + toff + st * 32);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int pc = 0; pc < 3; ++pc)
+                        bb[j][pc] = *reinterpret_cast<const bf16x8*>(bS + pc * BPLANE + j * 32 * X3_ROWB + st * 32);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        f32x16 cc = acc[i][j];
+                        cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], bb[j][0], cc, 0, 0, 0);   // smallest terms first
+                        cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], bb[j][1], cc, 0, 0, 0);
+                        cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], bb[j][2], cc, 0, 0, 0);
+                        cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], bb[j][0], cc, 0, 0, 0);
+                        cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], bb[j][1], cc, 0, 0, 0);
+                        cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], bb[j][0], cc, 0, 0, 0);
+                        acc[i][j] = cc;
+                    }
+            }
+            __syncthreads();
+        }
+        if (c + 1 < cch) __syncthreads();                      // the producers replace the halo between these two barriers
+    }
+    // epilogue: same row -> (pool window, position) walk as Engine::finish, with this wave's sub-tile origin
+    const int ts0 = t0 + grp * 8;
+    auto walk = [&](auto&& epi) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float v[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                    epi.store4(wm * WTM + i * 32 + 8 * g + 4 * hi, wn * WTN + j * 32 + l31, v);
+                }
+    };
+    if (EPI == EPI_RELU) {
+        walk(EpiConvRelu{p.y, p.bias, b, ts0, f0, T, F, Cout, n0});
+    } else if (EPI == EPI_POOL) {
+        walk(EpiConvPool{p.y, p.am_out, p.bias, b, ts0, f0, Tp, Fp, Cout, n0});
+    } else {
+        walk(EpiConvDgrad{p.y, p.act, b, ts0, f0, T, F, Cout, n0});
+    }
+}
+
+template <int BN, bool UNPOOL, int EPI>
+int launch_conv_x3h(const ConvX3P& p, int Te, int Fe, hipStream_t s) {
+    constexpr int SMEM = 3 * XH_APLANE + 2 * 3 * BN * X3_ROWB;
+    static int attr = set_smem(conv3x3_x3h_kernel<BN, UNPOOL, EPI>, SMEM);
+    if (attr) return attr;
+    dim3 grid((Fe + 15) / 16, (Te + 15) / 16, p.g.B * p.ntile);
+    hipLaunchKernelGGL((conv3x3_x3h_kernel<BN, UNPOOL, EPI>), grid, dim3(3 * NT), SMEM, s, p);
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}
+
 template <bool UNPOOL, int EPI>
 int dispatch_conv_x3(ConvX3P& p, int Te, int Fe, hipStream_t s) {
     if (p.g.Cin % 64 || p.g.Cout % 64) return MTL_EINVAL;     // C_in % 64: even number of K-tiles (producer loop is unrolled by 2)
+    static const bool halo = getenv("MTL_X3_WS") == nullptr;       // MTL_X3_WS=1: the earlier per-tap wave-specialised kernel
     if (p.g.Cout % 128 == 0) {
         p.ntile = p.g.Cout / 128;
-        return launch_conv_x3<128, UNPOOL, EPI>(p, Te, Fe, s);
+        return halo ? launch_conv_x3h<128, UNPOOL, EPI>(p, Te, Fe, s) : launch_conv_x3<128, UNPOOL, EPI>(p, Te, Fe, s);
     }
     p.ntile = p.g.Cout / 64;
-    return launch_conv_x3<64, UNPOOL, EPI>(p, Te, Fe, s);
+    return halo ? launch_conv_x3h<64, UNPOOL, EPI>(p, Te, Fe, s) : launch_conv_x3<64, UNPOOL, EPI>(p, Te, Fe, s);
 }
 
 // ------------------------------------------------------------------ weight gradient

@@ -13,6 +13,8 @@ What a pass computes follows the reference line by line:
 """
 import math
 
+import os
+
 import torch
 
 from . import _lib
@@ -91,6 +93,9 @@ class PassEngine:
         self.after_conv_hook = None
         self.deferred = []
         self.use_side_stream = True
+        # 3x3 convolutions (forward and data gradient): '1' = exact 3-way bf16 split on the bf16 MFMA pipe (fp32-accurate, see
+        # DESIGN.md 5.1), '0' = the fp32 MFMA kernels
+        self.conv_x3 = os.environ.get('MTL_CONV_X3', '1') != '0'
         self.prof = None    # optional {name: [flops, [(start_event, end_event), ...]]}: HIP events around the conv launches
         if device.type != 'cuda':
             raise RuntimeError('PassEngine needs an MI355X device (got %s); there is no CPU product path' % device)
@@ -434,20 +439,28 @@ class PassEngine:
         check(self.timed('conv0_fwd', cf(T, F, 1, 64), lib.mtl_conv0_relu_fwd, st, x.data_ptr(), o('conv.0.weight'),
                          o('conv.0.bias'), y1.data_ptr(), B, T, F), 'conv0')
         wf, wd = {}, {}
+        x3 = self.conv_x3
+        wprep = lib.mtl_conv3x3_wprep_x3 if x3 else lib.mtl_conv3x3_wprep
+        conv_fwd = lib.mtl_conv3x3_relu_fwd_x3 if x3 else lib.mtl_conv3x3_relu_fwd
+        conv_fwd_pool = lib.mtl_conv3x3_relu_pool_fwd_x3 if x3 else lib.mtl_conv3x3_relu_pool_fwd
         for idx, cin, cout in ((2, 64, 64), (5, 64, 128), (7, 128, 128)):
-            wf[idx] = self.buf('wf%d' % idx, (9, cin, cout))
-            wd[idx] = self.buf('wd%d' % idx, (9, cout, cin))
-            check(lib.mtl_conv3x3_wprep(st, o('conv.%d.weight' % idx), wf[idx].data_ptr(), wd[idx].data_ptr(), cout, cin), 'wprep')
+            if x3:      # three exact bf16 pieces of every weight, [piece][tap][cin/32][cout][32]
+                wf[idx] = self.buf('wf%d' % idx, (3, 9, cin, cout), torch.bfloat16)
+                wd[idx] = self.buf('wd%d' % idx, (3, 9, cout, cin), torch.bfloat16)
+            else:
+                wf[idx] = self.buf('wf%d' % idx, (9, cin, cout))
+                wd[idx] = self.buf('wd%d' % idx, (9, cout, cin))
+            check(wprep(st, o('conv.%d.weight' % idx), wf[idx].data_ptr(), wd[idx].data_ptr(), cout, cin), 'wprep')
         p1 = self.buf('p1', (B, T2, F2, 64))
         am1 = self.buf('am1', (B, T2, F2, 64), torch.uint8)
-        check(self.timed('conv2_fwd_pool', cf(T, F, 64, 64), lib.mtl_conv3x3_relu_pool_fwd, st, y1.data_ptr(), wf[2].data_ptr(),
+        check(self.timed('conv2_fwd_pool', cf(T, F, 64, 64), conv_fwd_pool, st, y1.data_ptr(), wf[2].data_ptr(),
                          o('conv.2.bias'), p1.data_ptr(), am1.data_ptr(), B, T, F, 64, 64), 'conv2')
         y5 = self.buf('y5', (B, T2, F2, 128))
-        check(self.timed('conv5_fwd', cf(T2, F2, 64, 128), lib.mtl_conv3x3_relu_fwd, st, p1.data_ptr(), wf[5].data_ptr(),
+        check(self.timed('conv5_fwd', cf(T2, F2, 64, 128), conv_fwd, st, p1.data_ptr(), wf[5].data_ptr(),
                          o('conv.5.bias'), y5.data_ptr(), B, T2, F2, 64, 128), 'conv5')
         p2 = self.buf('p2', (B, T4, F4, 128))
         am2 = self.buf('am2', (B, T4, F4, 128), torch.uint8)
-        check(self.timed('conv7_fwd_pool', cf(T2, F2, 128, 128), lib.mtl_conv3x3_relu_pool_fwd, st, y5.data_ptr(), wf[7].data_ptr(),
+        check(self.timed('conv7_fwd_pool', cf(T2, F2, 128, 128), conv_fwd_pool, st, y5.data_ptr(), wf[7].data_ptr(),
                          o('conv.7.bias'), p2.data_ptr(), am2.data_ptr(), B, T2, F2, 128, 128), 'conv7')
 
         if self.after_conv_hook is not None:      # lets the trainer de-phase concurrent task lanes (see trainer.meta_iteration)
@@ -671,6 +684,7 @@ class PassEngine:
 
         # ---- VGG front-end ----
         cf = lambda t_, f_, ci, co: 2.0 * B * t_ * f_ * 9 * ci * co
+        conv_dgrad = lib.mtl_conv3x3_dgrad_x3 if self.conv_x3 else lib.mtl_conv3x3_dgrad
 
         def wgrad(xa, dy, am, idx, Bq, Tq, Fq, cin, cout):
             need = lib.mtl_conv3x3_wgrad_workspace(Bq, Tq, Fq, cin, cout, 1 if am else 0)
@@ -681,17 +695,17 @@ class PassEngine:
         self.colsum(dp2.data_ptr(), B * T4 * F4, 128, g('conv.7.bias'))
         wgrad(y5.data_ptr(), dp2.data_ptr(), A['am2'].data_ptr(), 7, B, T2, F2, 128, 128)
         dy5 = self.buf('_dy5', (B, T2, F2, 128))
-        check(self.timed('conv7_dgrad', cf(T2, F2, 128, 128), lib.mtl_conv3x3_dgrad, st, dp2.data_ptr(), A['am2'].data_ptr(),
+        check(self.timed('conv7_dgrad', cf(T2, F2, 128, 128), conv_dgrad, st, dp2.data_ptr(), A['am2'].data_ptr(),
                          A['wd7'].data_ptr(), y5.data_ptr(), dy5.data_ptr(), B, T2, F2, 128, 128), 'dgrad7')
         self.colsum(dy5.data_ptr(), B * T2 * F2, 128, g('conv.5.bias'))
         wgrad(p1.data_ptr(), dy5.data_ptr(), None, 5, B, T2, F2, 64, 128)
         dp1 = self.buf('_dp1', (B, T2, F2, 64))
-        check(self.timed('conv5_dgrad', cf(T2, F2, 64, 128), lib.mtl_conv3x3_dgrad, st, dy5.data_ptr(), None, A['wd5'].data_ptr(),
+        check(self.timed('conv5_dgrad', cf(T2, F2, 64, 128), conv_dgrad, st, dy5.data_ptr(), None, A['wd5'].data_ptr(),
                          p1.data_ptr(), dp1.data_ptr(), B, T2, F2, 64, 128), 'dgrad5')
         self.colsum(dp1.data_ptr(), B * T2 * F2, 64, g('conv.2.bias'))
         wgrad(y1.data_ptr(), dp1.data_ptr(), A['am1'].data_ptr(), 2, B, T, F, 64, 64)
         dy1 = self.buf('_dy1', (B, T, F, 64))
-        check(self.timed('conv2_dgrad', cf(T, F, 64, 64), lib.mtl_conv3x3_dgrad, st, dp1.data_ptr(), A['am1'].data_ptr(),
+        check(self.timed('conv2_dgrad', cf(T, F, 64, 64), conv_dgrad, st, dp1.data_ptr(), A['am1'].data_ptr(),
                          A['wd2'].data_ptr(), y1.data_ptr(), dy1.data_ptr(), B, T, F, 64, 64), 'dgrad2')
         ws = self.scratch(lib.mtl_conv0_wgrad_workspace())
         check(self.timed('conv0_wgrad', cf(T, F, 1, 64), lib.mtl_conv0_wgrad, st, S['x'].data_ptr(), dy1.data_ptr(),
