@@ -544,6 +544,26 @@ struct EpiConvDgrad {  // dx = acc masked by the ReLU of the forward activation 
             }
         }
     }
+    // two-phase form for epilogues that own many accumulator groups: gate4 for ALL groups first (loads from clamped
+    // addresses, all in flight together), then store4g -- one exposed HBM latency per tile instead of one per group
+    __device__ __forceinline__ void gate4(int lr, int lc, float (&m)[4]) const {
+        const int col = n0 + lc;
+        const int w = (lr >> 5) * 8 + ((lr >> 2) & 7);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int t = min(t0 + 2 * (w >> 3) + (j & 1), T - 1), f = min(f0 + 2 * (w & 7) + (j >> 1), F - 1);
+            m[j] = act[(((long)b * T + t) * F + f) * Cout + col];
+        }
+    }
+    __device__ __forceinline__ void store4g(int lr, int lc, const float (&v)[4], const float (&m)[4]) const {
+        const int col = n0 + lc;
+        const int w = (lr >> 5) * 8 + ((lr >> 2) & 7);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int t = t0 + 2 * (w >> 3) + (j & 1), f = f0 + 2 * (w & 7) + (j >> 1);
+            if (t < T && f < F) dx[(((long)b * T + t) * F + f) * Cout + col] = m[j] > 0.f ? v[j] : 0.f;
+        }
+    }
 };
 
 struct ConvP {
@@ -620,7 +640,6 @@ int dispatch_conv(ConvP& p, int Te, int Fe, hipStream_t s) {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 constexpr int X3_ROWB = 80;                      // bytes per LDS row
-constexpr int X3_APLANE = 128 * X3_ROWB;         // one bf16 plane of the 128-pixel A tile
 
 __device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l) {
     h = (__bf16)x;
@@ -629,22 +648,14 @@ __device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l)
     l = (__bf16)(r - (float)m);
 }
 
-__device__ __forceinline__ void commit_a_x3(unsigned char* smA, int row, int kq, float4 v) {
-    __bf16 hh[4], mm[4], ll[4];
-    split3(v.x, hh[0], mm[0], ll[0]);
-    split3(v.y, hh[1], mm[1], ll[1]);
-    split3(v.z, hh[2], mm[2], ll[2]);
-    split3(v.w, hh[3], mm[3], ll[3]);
-    const bf16x4 h = {hh[0], hh[1], hh[2], hh[3]}, m = {mm[0], mm[1], mm[2], mm[3]}, l = {ll[0], ll[1], ll[2], ll[3]};
-    unsigned char* q = smA + row * X3_ROWB + kq * 2;
-    *reinterpret_cast<bf16x4*>(q) = h;
-    *reinterpret_cast<bf16x4*>(q + X3_APLANE) = m;
-    *reinterpret_cast<bf16x4*>(q + 2 * X3_APLANE) = l;
-}
-
 // (Cout,Cin,3,3) fp32 -> bf16 pieces laid out per K-TILE: w3f[piece][kt = tap*Cin/32 + cin/32][cout][cin%32] and
 // w3d[piece][kt = (8-tap)*Cout/32 + cout/32][cin][cout%32]: the rows a workgroup stages for one K-tile are one contiguous
-// block of full cache lines (a [rows][K] layout makes them 64-byte halves of lines 2*K bytes apart: 2.9x the L2 requests)
+// block of full cache lines, which is exactly the LDS image the convolution wants, so it is moved by global_load_lds
+// (lane-linear destination) without touching a register.  Rows are 64 bytes = four 16-byte chunks (8 k-values each);
+// chunk c of row r is stored at position c ^ ((r >> 2) & 3), which makes the consumers' ds_read_b128 of one chunk from
+// 16 rows {0-3,12-15,20-27} conflict-free with no padding.
+__host__ __device__ inline int x3_swz(int k, int row) { return (((k >> 3) ^ ((row >> 2) & 3)) << 3) | (k & 7); }
+
 __global__ void conv_wprep_x3_kernel(const float* w, __bf16* wf, __bf16* wd, int Cout, int Cin) {
     const int total = 9 * Cin * Cout;
     const int nkf = 9 * (Cin / 32), nkd = 9 * (Cout / 32);
@@ -656,8 +667,8 @@ __global__ void conv_wprep_x3_kernel(const float* w, __bf16* wf, __bf16* wd, int
         split3(w[e], pc[0], pc[1], pc[2]);
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
-            wf[(((long)p * nkf + tap * (Cin / 32) + (cin >> 5)) * Cout + cout) * 32 + (cin & 31)] = pc[p];
-            wd[(((long)p * nkd + (8 - tap) * (Cout / 32) + (cout >> 5)) * Cin + cin) * 32 + (cout & 31)] = pc[p];
+            wf[(((long)p * nkf + tap * (Cin / 32) + (cin >> 5)) * Cout + cout) * 32 + x3_swz(cin & 31, cout)] = pc[p];
+            wd[(((long)p * nkd + (8 - tap) * (Cout / 32) + (cout >> 5)) * Cin + cin) * 32 + x3_swz(cout & 31, cin)] = pc[p];
         }
     }
 }
@@ -672,208 +683,105 @@ struct ConvX3P {
     uint8_t* am_out;
     ConvGeom g;          // Cin = reduction channels, Cout = output channels of THIS conv (dgrad: swapped by the caller)
     int ntile;
+    int dbg;             // ablation switches (MTL_X3_DBG), 0 in production
+    int ntf, ntt, tiles; // halo kernel: pixel tiles along F and T, and tiles in total (F fastest, then T, then output-channel tile, then sample)
 };
-
-// Wave-specialised workgroup (512 threads): waves 0-3 are CONSUMERS (2x2 over the 128 x BN tile: ds_read_b128 + MFMA only),
-// waves 4-7 are PRODUCERS (im2col gather, 3-way split, LDS writes, weight staging).  A workgroup's waves are placed on the
-// SIMDs cyclically, so every SIMD hosts one consumer and one producer: the VALU-heavy staging (7 VALU per MFMA in a
-// monolithic wave, PMC: MFMA pipe 28 % busy) runs on the vector pipe while the partner wave keeps the matrix pipe fed.
-// LDS is double-buffered (2 x 3 planes x (128 + BN) rows x 80 B = 120 KiB), one barrier per K-tile for both roles.
-template <int BN, bool UNPOOL, int EPI>
-__global__ __launch_bounds__(512) void conv3x3_x3_kernel(ConvX3P p) {
-    using LA = LoadConvA<UNPOOL>;
-    using E = Engine<128, BN, LA, LoadMNMajor<BN, true>>;     // only for the tile constants and the epilogue walk
-    constexpr int TM = E::TM, TN = E::TN, WTM = E::WTM, WTN = E::WTN;
-    constexpr int BPLANE = BN * X3_ROWB;
-    constexpr int ABUF = 3 * X3_APLANE, BBUF = 3 * BPLANE, STAGE = ABUF + BBUF;
-    constexpr int NVB = 3 * BN * 4 / NT;                       // 16-byte chunks of the weight tile per producer thread
-    extern __shared__ __attribute__((aligned(16))) unsigned char smx[];
-    const int tid = threadIdx.x;
-    const int b = blockIdx.z / p.ntile, n0 = (blockIdx.z % p.ntile) * BN;
-    const int t0 = blockIdx.y * 8, f0 = blockIdx.x * 16;
-    const int Cin = p.g.Cin, Cout = p.g.Cout, cch = Cin / BK, nk = 9 * cch;
-
-    if (tid >= NT) {
-        // ------------------------------------------------------------------ producers
-        const int ptid = tid - NT;
-        LA la;
-        la.init(p.x, p.am_in, p.g, Cin, b, t0, f0, ptid);
-        // Two register sets for both operands, tiles requested TWO ahead.  Every fetch is unconditional (tile index clamped)
-        // and nk is even, so the number of loads in flight at each commit is a compile-time constant and hipcc emits a
-        // counted vmcnt(N) instead of draining the prefetch it has just issued (seen in the ISA of the conditional form).
-        typename LA::Regs ra0, ra1;
-        uint4 rb0[NVB], rb1[NVB];
-        auto fetch_b = [&](int kt, uint4 (&rb)[NVB]) {
-#pragma unroll
-            for (int i = 0; i < NVB; ++i) {
-                const int q = ptid + i * NT, piece = q / (BN * 4), within = q - piece * (BN * 4);
-                rb[i] = *reinterpret_cast<const uint4*>(p.w3 + (((long)piece * nk + kt) * Cout + n0) * 32 + within * 8);   // contiguous
-            }
-        };
-        auto commit = [&](const typename LA::Regs& ra, const uint4 (&rb)[NVB], unsigned char* st) {
-#pragma unroll
-            for (int i = 0; i < LA::NV; ++i) {
-                float4 v = ra.v[i];
-                const bool ok = ra.m[i] & 1u;
-                if (!UNPOOL) {
-                    v = mask4(v, ok ? 15u : 0u);
-                } else {
-                    const unsigned sub = ra.m[i] >> 1;
-                    v.x = (ok && ra.a[i].x == sub) ? v.x : 0.f;
-                    v.y = (ok && ra.a[i].y == sub) ? v.y : 0.f;
-                    v.z = (ok && ra.a[i].z == sub) ? v.z : 0.f;
-                    v.w = (ok && ra.a[i].w == sub) ? v.w : 0.f;
-                }
-                commit_a_x3(st, (ptid >> 3) + i * 32, (ptid & 7) * 4, v);
-            }
-#pragma unroll
-            for (int i = 0; i < NVB; ++i) {
-                const int q = ptid + i * NT, piece = q / (BN * 4), within = q - piece * (BN * 4);
-                *reinterpret_cast<uint4*>(st + ABUF + piece * BPLANE + (within >> 2) * X3_ROWB + (within & 3) * 16) = rb[i];
-            }
-        };
-        la.fetch(0, ra0, ptid);
-        fetch_b(0, rb0);
-        la.fetch(1, ra1, ptid);
-        fetch_b(1, rb1);
-        commit(ra0, rb0, smx);
-        __syncthreads();                                       // stage 0 holds tile 0
-        for (int kt = 0; kt < nk; kt += 2) {                   // nk is even (C_in % 64 == 0)
-            const int k2 = min(kt + 2, nk - 1), k3 = min(kt + 3, nk - 1);
-            la.fetch(k2, ra0, ptid);                           // consumers work on stage 0 (tile kt)
-            fetch_b(k2, rb0);
-            commit(ra1, rb1, smx + STAGE);                     // stage 1 <- tile kt+1
-            __syncthreads();
-            la.fetch(k3, ra1, ptid);                           // consumers work on stage 1 (tile kt+1)
-            fetch_b(k3, rb1);
-            if (kt + 2 < nk) commit(ra0, rb0, smx);            // stage 0 <- tile kt+2
-            __syncthreads();
-        }
-        return;
-    }
-
-    // ---------------------------------------------------------------------- consumers
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, hi = lane >> 5;
-    f32x16 acc[TM][TN];
-    E::zero(acc);
-    const unsigned char* aBase = smx + (wm * WTM + l31) * X3_ROWB + hi * 16;
-    const unsigned char* bBase = smx + ABUF + (wn * WTN + l31) * X3_ROWB + hi * 16;
-    __syncthreads();                                           // stage 0 holds tile 0
-    for (int kt = 0; kt < nk; ++kt) {
-        const int so = (kt & 1) * STAGE;
-#pragma unroll
-        for (int st = 0; st < BK / 16; ++st) {
-            bf16x8 a[TM][3], bb[TN][3];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int pc = 0; pc < 3; ++pc)
-                    a[i][pc] = *reinterpret_cast<const bf16x8*>(aBase + so + pc * X3_APLANE + i * 32 * X3_ROWB + st * 32);
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int pc = 0; pc < 3; ++pc)
-                    bb[j][pc] = *reinterpret_cast<const bf16x8*>(bBase + so + pc * BPLANE + j * 32 * X3_ROWB + st * 32);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    f32x16 c = acc[i][j];
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], bb[j][0], c, 0, 0, 0);   // smallest terms first
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], bb[j][1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], bb[j][2], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], bb[j][0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], bb[j][1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], bb[j][0], c, 0, 0, 0);
-                    acc[i][j] = c;
-                }
-        }
-        __syncthreads();
-    }
-    if (EPI == EPI_RELU) {
-        EpiConvRelu e{p.y, p.bias, b, t0, f0, p.g.T, p.g.F, Cout, n0};
-        E::finish(acc, e);
-    } else if (EPI == EPI_POOL) {
-        EpiConvPool e{p.y, p.am_out, p.bias, b, t0, f0, p.g.Tp, p.g.Fp, Cout, n0};
-        E::finish(acc, e);
-    } else {
-        EpiConvDgrad e{p.y, p.act, b, t0, f0, p.g.T, p.g.F, Cout, n0};
-        E::finish(acc, e);
-    }
-}
-
-template <int BN, bool UNPOOL, int EPI>
-int launch_conv_x3(const ConvX3P& p, int Te, int Fe, hipStream_t s) {
-    constexpr int SMEM = 2 * (3 * X3_APLANE + 3 * BN * X3_ROWB);
-    static int attr = set_smem(conv3x3_x3_kernel<BN, UNPOOL, EPI>, SMEM);
-    if (attr) return attr;
-    dim3 grid((Fe + 15) / 16, (Te + 7) / 8, p.g.B * p.ntile);
-    hipLaunchKernelGGL((conv3x3_x3_kernel<BN, UNPOOL, EPI>), grid, dim3(2 * NT), SMEM, s, p);
-    MTL_CHECK_LAUNCH();
-    return MTL_OK;
-}
 
 // ------------------------------------------------------------------ halo-tiled x3 convolution (the one the C ABI dispatches to)
 // What the ablation of conv3x3_x3_kernel showed: the consumer side can run 256 TF-equivalent, the producer
 // side is bound by (a) re-gathering + re-splitting every input element once per tap and (b) the weight tile per 128 pixels.
-// Here a workgroup owns a 16(T) x 16(F) pixel tile (two pool-aligned 8x16 sub-tiles, 8 consumer waves) and, per 32-channel
-// chunk, stages the 18x18 input HALO once (gather + 3-way split + LDS write) for all nine taps; the consumers address the
-// halo with a per-tap offset.  Weight tiles ([piece][K-tile][row][32], double-buffered) are shared by 256 pixels.
-// LDS: halo 324 px x 80 B x 3 planes = 76 KiB + 2 x 3 x BN x 80 B weights (60 KiB at BN = 128) = 136 KiB, 12 waves per CU.
-constexpr int XH_HT = 18, XH_HF = 18, XH_NPIX = XH_HT * XH_HF;       // halo of a 16 x 16 tile
-constexpr int XH_APLANE = XH_NPIX * X3_ROWB;                       // one bf16 plane of the halo
-constexpr int XH_NVA = (XH_NPIX * 8 + NT - 1) / NT;                // float4 (4 channels) per producer thread and chunk
+// Here a workgroup owns an (8 G) x 16 pixel tile (G pool-aligned 8 x 16 sub-tiles, 4 G consumer waves) and, per 32-channel
+// chunk, stages the input HALO once (gather + 3-way split + LDS write) for all nine taps; the consumers address the halo
+// with a per-tap offset.  Weight tiles ([piece][K-tile][row][32], double-buffered) are shared by all pixels of the tile.
+// Workgroups are PERSISTENT: (tile, chunk) pairs form one sequence of stages, so the producers fetch the next tile's first
+// halo under the current tile's last chunk and the consumers' epilogue runs while the producers commit it -- no per-tile
+// prologue on the matrix pipe.  G = 2: LDS = halo 324 px x 80 B x 3 planes (76 KiB) + 2 x 3 x BN x 80 B weights (60 KiB at
+// BN = 128), 12 waves per CU.
+constexpr int XH_HF = 18;                                          // halo width (F) of a 16-wide tile
 
-template <int BN, bool UNPOOL, int EPI>
-__global__ __launch_bounds__(768) void conv3x3_x3h_kernel(ConvX3P p) {
+struct X3Tile {
+    int b, n0, t0, f0;
+};
+
+inline int device_cu_count() {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+        n = 256;
+    return n;
+}
+
+template <int G>
+__device__ inline X3Tile x3_tile(const ConvX3P& p, int id) {
+    X3Tile t;
+    const int fx = id % p.ntf;
+    id /= p.ntf;
+    const int ty = id % p.ntt;
+    id /= p.ntt;
+    t.f0 = fx * 16;
+    t.t0 = ty * (8 * G);
+    t.n0 = id % p.ntile;           // output-channel tile index (x BN at the use site)
+    t.b = id / p.ntile;
+    return t;
+}
+
+template <int BN, int G, bool UNPOOL, int EPI>
+__global__ __launch_bounds__((4 * G + 4) * 64) void conv3x3_x3h_kernel(ConvX3P p) {
     using E = Engine<128, BN, LoadConvA<UNPOOL>, LoadMNMajor<BN, true>>;   // tile constants only
     constexpr int TM = E::TM, TN = E::TN, WTM = E::WTM, WTN = E::WTN;
-    constexpr int BPLANE = BN * X3_ROWB, BBUF = 3 * BPLANE, ABUF = 3 * XH_APLANE;
-    constexpr int NVB = 3 * BN * 4 / NT;
+    constexpr int XH_HT = 8 * G + 2, XH_NPIX = XH_HT * XH_HF;      // halo of an (8 G) x 16 tile
+    constexpr int XH_APLANE = XH_NPIX * X3_ROWB;                   // one bf16 plane of the halo
+    constexpr int NHALO = 3 * 64;                                  // halo threads (producer waves 1-3)
+    constexpr int XH_NVA = (XH_NPIX * 8 + NHALO - 1) / NHALO;      // float4 (4 channels) per halo thread and chunk
+    constexpr int NCONS = 4 * G * 64;                              // consumer threads
+    constexpr int BPLANE = BN * 64, BBUF = 3 * BPLANE, ABUF = 3 * XH_APLANE;   // weights: unpadded swizzled 64-byte rows
+    constexpr int NDMA = BBUF / 1024;                              // wave-wide 16-byte DMA instructions per weight tile
     extern __shared__ __attribute__((aligned(16))) unsigned char smx[];
     unsigned char* smA = smx;
-    unsigned char* smB = smx + ABUF;
+    unsigned char* smB = smx + ABUF;                               // three stages of BBUF
     const int tid = threadIdx.x;
-    const int b = blockIdx.z / p.ntile, n0 = (blockIdx.z % p.ntile) * BN;
-    const int t0 = blockIdx.y * 16, f0 = blockIdx.x * 16;
     const int Cin = p.g.Cin, Cout = p.g.Cout, cch = Cin / BK, nk = 9 * cch;
     const int T = p.g.T, F = p.g.F, Tp = p.g.Tp, Fp = p.g.Fp;
+    const int my_tiles = (p.tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int nstage = my_tiles * cch;                             // stage q = (tile q / cch of this workgroup, chunk q % cch)
+    const int nstep = nstage * 9;                                  // step s = stage * 9 + tap; weight stage s % 3
 
-    if (tid >= 2 * NT) {
-        // ------------------------------------------------------------------ producers (4 waves)
-        const int ptid = tid - 2 * NT;
+    if (tid >= NCONS + 64) {
+        // ------------------------------------------------------------------ halo waves (3): gather, 3-way split, LDS image
+        const int ptid = tid - NCONS - 64;
         float4 hv[XH_NVA];
         uchar4 ha[XH_NVA];
         unsigned hm[XH_NVA];
-        uint4 rb[NVB];
-        auto fetch_halo = [&](int c) {          // chunk c: channels c*32 .. +31 of the 18 x 18 halo pixels
+        auto fetch_halo = [&](int q) {          // stage q: channels c*32 .. +31 of the halo pixels of its tile
+            const int j = q / cch, c = q - j * cch;
+            const X3Tile tl = x3_tile<G>(p, blockIdx.x + j * gridDim.x);
 #pragma unroll
             for (int i = 0; i < XH_NVA; ++i) {
-                const int q = ptid + i * NT;
-                const int hp = min(q >> 3, XH_NPIX - 1), c4 = (q & 7) * 4;
+                const int e = ptid + i * NHALO;
+                const int hp = min(e >> 3, XH_NPIX - 1), c4 = (e & 7) * 4;
                 const int ht = hp / XH_HF, hf = hp - ht * XH_HF;
-                const int ts = t0 + ht - 1, fs = f0 + hf - 1;
-                bool ok = (q >> 3) < XH_NPIX && (unsigned)ts < (unsigned)T && (unsigned)fs < (unsigned)F;
+                const int ts = tl.t0 + ht - 1, fs = tl.f0 + hf - 1;
+                bool ok = (e >> 3) < XH_NPIX && (unsigned)ts < (unsigned)T && (unsigned)fs < (unsigned)F;
                 const int tc = min(max(ts, 0), T - 1), fc = min(max(fs, 0), F - 1);
                 if (!UNPOOL) {
-                    hv[i] = *reinterpret_cast<const float4*>(p.x + (((long)b * T + tc) * F + fc) * Cin + c * BK + c4);
+                    hv[i] = *reinterpret_cast<const float4*>(p.x + (((long)tl.b * T + tc) * F + fc) * Cin + c * BK + c4);
                     hm[i] = ok ? 1u : 0u;
                 } else {
                     const int tp = tc >> 1, fp = fc >> 1;
                     ok = ok && tp < Tp && fp < Fp;
-                    const long o = (((long)b * Tp + min(tp, Tp - 1)) * Fp + min(fp, Fp - 1)) * Cin + c * BK + c4;
+                    const long o = (((long)tl.b * Tp + min(tp, Tp - 1)) * Fp + min(fp, Fp - 1)) * Cin + c * BK + c4;
                     ha[i] = *reinterpret_cast<const uchar4*>(p.am_in + o);
                     hv[i] = *reinterpret_cast<const float4*>(p.x + o);
                     hm[i] = (ok ? 1u : 0u) | ((unsigned)(((fs & 1) << 1) | (ts & 1)) << 1);
                 }
             }
         };
+        // (Splitting ahead of the swap barrier so that only the ds_writes sit between the two barriers was tried: the 84
+        // extra live registers spill under the 168-VGPR cap of a 12-wave workgroup and every launch gets 15-40 % slower.)
         auto commit_halo = [&]() {
 #pragma unroll
             for (int i = 0; i < XH_NVA; ++i) {
-                const int q = ptid + i * NT;
-                if ((q >> 3) >= XH_NPIX) continue;
+                const int e = ptid + i * NHALO;
+                if ((e >> 3) >= XH_NPIX) continue;
                 float4 v = hv[i];
                 const bool ok = hm[i] & 1u;
                 if (!UNPOOL) {
@@ -890,63 +798,84 @@ __global__ __launch_bounds__(768) void conv3x3_x3h_kernel(ConvX3P p) {
                 split3(v.y, hh[1], mm[1], ll[1]);
                 split3(v.z, hh[2], mm[2], ll[2]);
                 split3(v.w, hh[3], mm[3], ll[3]);
-                unsigned char* dst = smA + (q >> 3) * X3_ROWB + (q & 7) * 8;
+                unsigned char* dst = smA + (e >> 3) * X3_ROWB + (e & 7) * 8;
                 *reinterpret_cast<bf16x4*>(dst) = bf16x4{hh[0], hh[1], hh[2], hh[3]};
                 *reinterpret_cast<bf16x4*>(dst + XH_APLANE) = bf16x4{mm[0], mm[1], mm[2], mm[3]};
                 *reinterpret_cast<bf16x4*>(dst + 2 * XH_APLANE) = bf16x4{ll[0], ll[1], ll[2], ll[3]};
             }
         };
-        auto fetch_b = [&](int kt) {
-#pragma unroll
-            for (int i = 0; i < NVB; ++i) {
-                const int q = ptid + i * NT, piece = q / (BN * 4), within = q - piece * (BN * 4);
-                rb[i] = *reinterpret_cast<const uint4*>(p.w3 + (((long)piece * nk + kt) * Cout + n0) * 32 + within * 8);
-            }
-        };
-        auto commit_b = [&](int stage) {
-#pragma unroll
-            for (int i = 0; i < NVB; ++i) {
-                const int q = ptid + i * NT, piece = q / (BN * 4), within = q - piece * (BN * 4);
-                *reinterpret_cast<uint4*>(smB + stage * BBUF + piece * BPLANE + (within >> 2) * X3_ROWB + (within & 3) * 16) = rb[i];
-            }
-        };
-        // step s = chunk * 9 + tap uses weight stage s & 1 and K-tile (s % 9) * cch + s / 9; the weight tile of step s + 2 is in
-        // flight (registers) while step s + 1's is committed, so neither L2 latency nor the commit is exposed
-        auto ktile = [&](int s) { const int c = s / 9; return (s - c * 9) * cch + c; };
-        fetch_halo(0);
-        fetch_b(ktile(0));
-        commit_halo();
-        commit_b(0);
-        fetch_b(ktile(1));
-        if (cch > 1) fetch_halo(1);
-        __syncthreads();                                       // halo(0) and the weights of step 0 are visible
-        int tap = 0, c = 0;
+        const bool doA = !(p.dbg & 2);
+        if (doA) fetch_halo(0);
+        if (doA) commit_halo();
+        if (nstage > 1 && doA) fetch_halo(1);
+        __syncthreads();                                       // halo of stage 0 (and the weights of step 0) are visible
 #pragma unroll 1
-        for (int s = 0; s < nk; ++s) {
-            if (s + 1 < nk) {
-                commit_b((s + 1) & 1);
-                if (s + 2 < nk) fetch_b(ktile(s + 2));
+        for (int q = 0; q < nstage; ++q) {
+#pragma unroll 1
+            for (int tap = 0; tap < 9; ++tap) __syncthreads();
+            if (q + 1 < nstage) {
+                if (doA) commit_halo();                        // nobody reads the halo between these two barriers
+                if (q + 2 < nstage && doA) fetch_halo(q + 2);  // a whole stage of flight time
+                __syncthreads();
             }
-            __syncthreads();                                   // consumers are done with step s
+        }
+        return;
+    }
+    if (tid >= NCONS) {
+        // ------------------------------------------------------------------ weight wave: global_load_lds only
+        // The K-tile of step s (tap * cch + chunk, output-channel tile n0) is one contiguous, pre-swizzled 3 x BN x 64 B
+        // block per piece; NDMA wave-wide 16-byte DMA instructions move it into stage s % 3 with no registers and no
+        // ds_write.  This wave's vmcnt counts only those DMAs (in order), so "tile s + 1 has landed" is vmcnt(NDMA) right
+        // after the tile of step s + 2 was issued: two steps of flight time, never a drain.  Raw s_barrier: __syncthreads
+        // would add vmcnt(0).
+        const int lane = tid & 63;
+        const bool doB = !(p.dbg & 4);
+        auto dma = [&](int s_) {
+            const int q = s_ / 9, tap = s_ - q * 9;
+            const int j = q / cch, c = q - j * cch;
+            const int n0 = p.ntile == 1 ? 0 : x3_tile<G>(p, blockIdx.x + j * gridDim.x).n0 * BN;
+            const int kt = tap * cch + c;
+            unsigned char* dst = smB + (s_ % 3) * BBUF;            // scalar ALU
+#pragma unroll
+            for (int i = 0; i < NDMA; ++i) {
+                const int piece = i / (BN / 16), r16 = i - piece * (BN / 16);       // 16 rows (1 KiB) per instruction
+                const unsigned char* g = reinterpret_cast<const unsigned char*>(p.w3) +
+                                         (((long)piece * nk + kt) * Cout + n0 + r16 * 16) * 64 + lane * 16;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                                 (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+            }
+        };
+        if (doB) {
+            dma(0);
+            if (nstep > 1) dma(1);
+        }
+        if (nstep > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        int tap = 0, q = 0;
+#pragma unroll 1
+        for (int s_ = 0; s_ < nstep; ++s_) {
+            // stage (s_ + 2) % 3 was read at step s_ - 1, and every consumer has passed that step's barrier
+            if (s_ + 2 < nstep) {
+                if (doB) dma(s_ + 2);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");      // tile s_ + 1 is in LDS
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
             if (++tap == 9) {
                 tap = 0;
-                ++c;
-                if (c < cch) {
-                    commit_halo();                             // nobody reads the halo between these two barriers
-                    if (c + 1 < cch) fetch_halo(c + 1);
-                    __syncthreads();
-                }
+                if (++q < nstage) __builtin_amdgcn_s_barrier();                   // the halo swap
             }
         }
         return;
     }
 
-    // ---------------------------------------------------------------------- consumers (8 waves: 2 sub-tiles x (2 x 2))
+    // ---------------------------------------------------------------------- consumers (G sub-tiles x (2 x 2) waves)
     const int lane = tid & 63, wave = tid >> 6;
     const int grp = wave >> 2, w4 = wave & 3;
     const int wm = w4 >> 1, wn = w4 & 1, l31 = lane & 31, hi = lane >> 5;
     f32x16 acc[TM][TN];
-    E::zero(acc);
     int abase[TM];                                             // byte offset of this lane's pixel (tap centre) in the halo plane
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -954,75 +883,110 @@ __global__ __launch_bounds__(768) void conv3x3_x3h_kernel(ConvX3P p) {
         tile_row_to_tf(wm * WTM + i * 32 + l31, t, f);
         abase[i] = ((t + grp * 8 + 1) * XH_HF + (f + 1)) * X3_ROWB + hi * 16;
     }
-    const unsigned char* bBase = smB + (wn * WTN + l31) * X3_ROWB + hi * 16;
+    const unsigned char* bBase = smB + (wn * WTN + l31) * 64;
+    int bsw[BK / 16];                                          // swizzled position of this lane's 16-byte chunk per k-step
+#pragma unroll
+    for (int st = 0; st < BK / 16; ++st) bsw[st] = (((st * 2 + hi) ^ ((l31 >> 2) & 3))) * 16;
     __syncthreads();
-    int sidx = 0;
-    for (int c = 0; c < cch; ++c) {
+    int bst = 0;                                               // weight stage of the current step (step % 3)
 #pragma unroll 1
-        for (int tap = 0; tap < 9; ++tap, ++sidx) {
-            const int kh = tap / 3, kw = tap - kh * 3;
-            const int toff = ((kw - 1) * XH_HF + (kh - 1)) * X3_ROWB;
-            const unsigned char* bS = bBase + (sidx & 1) * BBUF;
+    for (int j = 0; j < my_tiles; ++j) {
+        E::zero(acc);
+#pragma unroll 1
+        for (int c = 0; c < cch; ++c) {
+#pragma unroll 1
+            for (int tap = 0; tap < 9; ++tap, bst = bst == 2 ? 0 : bst + 1) {
+                const int kh = tap / 3, kw = tap - kh * 3;
+                const int toff = ((kw - 1) * XH_HF + (kh - 1)) * X3_ROWB;
+                const unsigned char* bS = bBase + bst * BBUF;
 #pragma unroll
-            for (int st = 0; st < BK / 16; ++st) {
-                bf16x8 a[TM][3], bb[TN][3];
+                for (int st = 0; st < BK / 16; ++st) {
+                    bf16x8 a[TM][3], bb[TN][3];
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+                    for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int pc = 0; pc < 3; ++pc)
-                        a[i][pc] = *reinterpret_cast<const bf16x8*>(smA + pc * XH_APLANE + abase[i] + toff + st * 32);
+                        for (int pc = 0; pc < 3; ++pc)
+                            a[i][pc] = *reinterpret_cast<const bf16x8*>(smA + pc * XH_APLANE + abase[i] + toff + st * 32);
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
+                    for (int jn = 0; jn < TN; ++jn)
 #pragma unroll
-                    for (int pc = 0; pc < 3; ++pc)
-                        bb[j][pc] = *reinterpret_cast<const bf16x8*>(bS + pc * BPLANE + j * 32 * X3_ROWB + st * 32);
+                        for (int pc = 0; pc < 3; ++pc)
+                            bb[jn][pc] = *reinterpret_cast<const bf16x8*>(bS + pc * BPLANE + jn * 32 * 64 + bsw[st]);
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+                    for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        f32x16 cc = acc[i][j];
-                        cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], bb[j][0], cc, 0, 0, 0);   // smallest terms first
-                        cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], bb[j][1], cc, 0, 0, 0);
-                        cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], bb[j][2], cc, 0, 0, 0);
-                        cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], bb[j][0], cc, 0, 0, 0);
-                        cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], bb[j][1], cc, 0, 0, 0);
-                        cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], bb[j][0], cc, 0, 0, 0);
-                        acc[i][j] = cc;
-                    }
-            }
-            __syncthreads();
-        }
-        if (c + 1 < cch) __syncthreads();                      // the producers replace the halo between these two barriers
-    }
-    // epilogue: same row -> (pool window, position) walk as Engine::finish, with this wave's sub-tile origin
-    const int ts0 = t0 + grp * 8;
-    auto walk = [&](auto&& epi) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    float v[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-                    epi.store4(wm * WTM + i * 32 + 8 * g + 4 * hi, wn * WTN + j * 32 + l31, v);
+                        for (int jn = 0; jn < TN; ++jn) {
+                            f32x16 cc = acc[i][jn];
+                            cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], bb[jn][0], cc, 0, 0, 0);   // smallest terms first
+                            cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], bb[jn][1], cc, 0, 0, 0);
+                            cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], bb[jn][2], cc, 0, 0, 0);
+                            cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], bb[jn][0], cc, 0, 0, 0);
+                            cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], bb[jn][1], cc, 0, 0, 0);
+                            cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], bb[jn][0], cc, 0, 0, 0);
+                            acc[i][jn] = cc;
+                        }
                 }
-    };
-    if (EPI == EPI_RELU) {
-        walk(EpiConvRelu{p.y, p.bias, b, ts0, f0, T, F, Cout, n0});
-    } else if (EPI == EPI_POOL) {
-        walk(EpiConvPool{p.y, p.am_out, p.bias, b, ts0, f0, Tp, Fp, Cout, n0});
-    } else {
-        walk(EpiConvDgrad{p.y, p.act, b, ts0, f0, T, F, Cout, n0});
+                __syncthreads();
+            }
+            if (c + 1 == cch && !(p.dbg & 8)) {
+                // epilogue (no LDS): same row -> (pool window, position) walk as Engine::finish with this wave's sub-tile
+                // origin; it runs while the producers commit the next tile's halo
+                const X3Tile tl = x3_tile<G>(p, blockIdx.x + j * gridDim.x);
+                const int ts0 = tl.t0 + grp * 8, n0 = tl.n0 * BN;
+                auto walk = [&](auto&& epi) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                float v[4] = {acc[i][jn][4 * g], acc[i][jn][4 * g + 1], acc[i][jn][4 * g + 2], acc[i][jn][4 * g + 3]};
+                                epi.store4(wm * WTM + i * 32 + 8 * g + 4 * hi, wn * WTN + jn * 32 + l31, v);
+                            }
+                };
+                if (EPI == EPI_RELU) {
+                    walk(EpiConvRelu{p.y, p.bias, tl.b, ts0, tl.f0, T, F, Cout, n0});
+                } else if (EPI == EPI_POOL) {
+                    walk(EpiConvPool{p.y, p.am_out, p.bias, tl.b, ts0, tl.f0, Tp, Fp, Cout, n0});
+                } else {
+                    const EpiConvDgrad epi{p.y, p.act, tl.b, ts0, tl.f0, T, F, Cout, n0};
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {             // 32 gate values in flight per half (all 64 would spill)
+                        float gate[TN][4][4];
+#pragma unroll
+                        for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+                            for (int g = 0; g < 4; ++g)
+                                epi.gate4(wm * WTM + i * 32 + 8 * g + 4 * hi, wn * WTN + jn * 32 + l31, gate[jn][g]);
+#pragma unroll
+                        for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                float v[4] = {acc[i][jn][4 * g], acc[i][jn][4 * g + 1], acc[i][jn][4 * g + 2], acc[i][jn][4 * g + 3]};
+                                epi.store4g(wm * WTM + i * 32 + 8 * g + 4 * hi, wn * WTN + jn * 32 + l31, v, gate[jn][g]);
+                            }
+                    }
+                }
+            }
+            if (j * cch + c + 1 < nstage) __syncthreads();     // the producers replaced the halo between these two barriers
+        }
     }
 }
 
-template <int BN, bool UNPOOL, int EPI>
-int launch_conv_x3h(const ConvX3P& p, int Te, int Fe, hipStream_t s) {
-    constexpr int SMEM = 3 * XH_APLANE + 2 * 3 * BN * X3_ROWB;
-    static int attr = set_smem(conv3x3_x3h_kernel<BN, UNPOOL, EPI>, SMEM);
+template <int BN, int G, bool UNPOOL, int EPI>
+int launch_conv_x3h(ConvX3P p, int Te, int Fe, hipStream_t s) {
+    constexpr int SMEM = 3 * (8 * G + 2) * XH_HF * X3_ROWB + 3 * 3 * BN * 64;
+    static int attr = set_smem(conv3x3_x3h_kernel<BN, G, UNPOOL, EPI>, SMEM);
     if (attr) return attr;
-    dim3 grid((Fe + 15) / 16, (Te + 15) / 16, p.g.B * p.ntile);
-    hipLaunchKernelGGL((conv3x3_x3h_kernel<BN, UNPOOL, EPI>), grid, dim3(3 * NT), SMEM, s, p);
+    static const int per_cu = SMEM > 80 * 1024 ? 1 : 2;
+    static const int ncu = device_cu_count();
+    static const int dbg = getenv("MTL_X3_DBG") ? atoi(getenv("MTL_X3_DBG")) : 0;
+    p.dbg = dbg;
+    p.ntf = (Fe + 15) / 16;
+    p.ntt = (Te + 8 * G - 1) / (8 * G);
+    p.tiles = p.ntf * p.ntt * p.g.B * p.ntile;
+    const int grid = p.tiles < ncu * per_cu ? p.tiles : ncu * per_cu;
+    hipLaunchKernelGGL((conv3x3_x3h_kernel<BN, G, UNPOOL, EPI>), dim3(grid), dim3((4 * G + 4) * 64), SMEM, s, p);
     MTL_CHECK_LAUNCH();
     return MTL_OK;
 }
@@ -1030,13 +994,12 @@ int launch_conv_x3h(const ConvX3P& p, int Te, int Fe, hipStream_t s) {
 template <bool UNPOOL, int EPI>
 int dispatch_conv_x3(ConvX3P& p, int Te, int Fe, hipStream_t s) {
     if (p.g.Cin % 64 || p.g.Cout % 64) return MTL_EINVAL;     // C_in % 64: even number of K-tiles (producer loop is unrolled by 2)
-    static const bool halo = getenv("MTL_X3_WS") == nullptr;       // MTL_X3_WS=1: the earlier per-tap wave-specialised kernel
     if (p.g.Cout % 128 == 0) {
         p.ntile = p.g.Cout / 128;
-        return halo ? launch_conv_x3h<128, UNPOOL, EPI>(p, Te, Fe, s) : launch_conv_x3<128, UNPOOL, EPI>(p, Te, Fe, s);
+        return launch_conv_x3h<128, 2, UNPOOL, EPI>(p, Te, Fe, s);
     }
     p.ntile = p.g.Cout / 64;
-    return halo ? launch_conv_x3h<64, UNPOOL, EPI>(p, Te, Fe, s) : launch_conv_x3<64, UNPOOL, EPI>(p, Te, Fe, s);
+    return launch_conv_x3h<64, 2, UNPOOL, EPI>(p, Te, Fe, s);
 }
 
 // ------------------------------------------------------------------ weight gradient

@@ -403,7 +403,13 @@ def test_conv3x3_split_bf16_matches_fp32_reference(L, Cin, Cout, B, T, Fq):
     w3f = torch.empty(3 * 9 * Cin * Cout, dtype=torch.bfloat16).cuda()
     w3d = torch.empty(3 * 9 * Cin * Cout, dtype=torch.bfloat16).cuda()
     assert L.mtl_conv3x3_wprep_x3(st(), dw.data_ptr(), w3f.data_ptr(), w3d.data_ptr(), Cout, Cin) == 0
-    pieces = w3f.view(3, 9, Cin // 32, Cout, 32).float().sum(0).cpu()       # the split is exact; layout [tap][cin/32][cout][cin%32]
+    # the split is exact; layout [tap][cin/32][cout][cin%32] with the four 8-value chunks of a row stored at chunk ^ ((cout >> 2) & 3)
+    pieces = w3f.view(3, 9, Cin // 32, Cout, 4, 8).float().sum(0).cpu()
+    unsw = torch.empty_like(pieces)
+    for co in range(Cout):
+        for c in range(4):
+            unsw[:, :, co, c] = pieces[:, :, co, c ^ ((co >> 2) & 3)]
+    pieces = unsw.reshape(9, Cin // 32, Cout, 32)
     assert torch.equal(pieces, w.reshape(Cout, Cin // 32, 32, 9).permute(3, 1, 0, 2))
     y = torch.empty(B, T, Fq, Cout).cuda()
     assert L.mtl_conv3x3_relu_fwd_x3(st(), dxn.data_ptr(), w3f.data_ptr(), db.data_ptr(), y.data_ptr(), B, T, Fq, Cin, Cout) == 0
