@@ -67,7 +67,8 @@ int mtl_conv3x3_dgrad(void* stream, const float* dy, const unsigned char* argmax
                       const float* act, float* dx, int B, int T, int F, int Cin, int Cout);
 /* Split-bf16 ("x3") variants of the three calls above: identical semantics and fp32-class error, computed with six
  * v_mfma_f32_32x32x16_bf16 per 16-deep step on exact 3-way bf16 splits of both operands (2.67x the fp32 MFMA roof).
- * w3_fwd / w3_dgrad: bf16 [3][K-tile][rows][32] buffers (3 * 9*Cin*Cout * 2 bytes each) from mtl_conv3x3_wprep_x3. */
+ * w3_fwd / w3_dgrad: bf16 [3][K-tile][rows][32] buffers (3 * 9*Cin*Cout * 2 bytes each) from mtl_conv3x3_wprep_x3; the four
+ * 16-byte chunks of a row are stored at chunk ^ ((row >> 2) & 3) (the LDS image the kernels DMA with global_load_lds). */
 int mtl_conv3x3_wprep_x3(void* stream, const float* w_ref, void* w3_fwd, void* w3_dgrad, int Cout, int Cin);
 int mtl_conv3x3_relu_fwd_x3(void* stream, const float* x, const void* w3_fwd, const float* bias, float* y, int B, int T, int F,
                             int Cin, int Cout);
@@ -79,6 +80,11 @@ long mtl_conv3x3_wgrad_workspace(int B, int T, int F, int Cin, int Cout, int poo
 /* dw_ref (Cout,Cin,3,3) += sum_pixels x (x) dy ; dy dense (B,T,F,Cout) or pooled + argmax as above. */
 int mtl_conv3x3_wgrad(void* stream, const float* x, const float* dy, const unsigned char* argmax, float* dw_ref,
                       float* workspace, long workspace_bytes, int B, int T, int F, int Cin, int Cout);
+/* Split-bf16 ("x3") weight gradient: same contract as the two calls above (its own workspace size).  Halo-tiled x staged in
+ * LDS, transpose reads (ds_read_b64_tr_b16) for the pixel-major reduction, dy fragments loaded straight into MFMA layout. */
+long mtl_conv3x3_wgrad_x3_workspace(int B, int T, int F, int Cin, int Cout, int pooled);
+int mtl_conv3x3_wgrad_x3(void* stream, const float* x, const float* dy, const unsigned char* argmax, float* dw_ref,
+                         float* workspace, long workspace_bytes, int B, int T, int F, int Cin, int Cout);
 /* wp[o][h*C+c] = w[o][c*Hh+h]  (inverse_accum: dst[o][c*Hh+h] += src[o][h*C+c]); the (C*H) flattening of
  * models/asr/transformer.py:136-138 folded into encoder.input_linear's weight instead of an activation copy. */
 int mtl_permute_hc(void* stream, const float* src, float* dst, int rows, int C, int Hh, int inverse_accum);

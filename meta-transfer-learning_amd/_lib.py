@@ -30,6 +30,8 @@ SIGNATURES = {
     'mtl_conv3x3_dgrad_x3': (I, [P, P, P, P, P, P, I, I, I, I, I]),
     'mtl_conv3x3_wgrad_workspace': (L, [I, I, I, I, I, I]),
     'mtl_conv3x3_wgrad': (I, [P, P, P, P, P, P, L, I, I, I, I, I]),
+    'mtl_conv3x3_wgrad_x3_workspace': (L, [I, I, I, I, I, I]),
+    'mtl_conv3x3_wgrad_x3': (I, [P, P, P, P, P, P, L, I, I, I, I, I]),
     'mtl_permute_hc': (I, [P, P, P, I, I, I, I]),
     'mtl_layernorm_fwd': (I, [P, P, P, P, P, P, P, P, F, P, P, P, I, I, I, F]),
     'mtl_layernorm_bwd_workspace': (L, [I, I]),

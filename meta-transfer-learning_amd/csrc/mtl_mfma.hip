@@ -1228,6 +1228,228 @@ int launch_wgrad(const WgradP& p, int nsplit, hipStream_t s) {
     return MTL_OK;
 }
 
+// ------------------------------------------------------------------ x3 weight gradient
+// dW[tap][ci][co] = sum over pixels of x[pixel + tap][ci] * dy[pixel][co]: the reduction runs over PIXELS, so both MFMA
+// operands want 8 consecutive pixels of one channel per lane while memory is channel-contiguous.
+//   * x: a workgroup owns an 8(T) x 16(F) pixel tile and 64 input channels; producers (4 waves) gather the 10 x 18 halo once
+//     for all nine taps, split it into the three bf16 pieces and store it as [piece][ci half][halo pixel][32 ci] (64-byte
+//     rows).  Consumers fetch A fragments with ds_read_b64_tr_b16 (each 16-lane group transposes a [4 pixels][16 channels]
+//     block; four consecutive halo pixels x 64 B = all 64 banks once, conflict-free without padding), tap = constant offset.
+//     The halo is double-buffered: ONE barrier per pixel tile (8 k-steps x 54 MFMAs per consumer wave).
+//   * dy: every B fragment is used by all nine taps of one k-step and by nothing else, so consumers load it straight into
+//     MFMA layout (lane = output channel, 8 pixels = 8 coalesced 128-byte rows), un-pool + split in registers, three
+//     k-steps ahead in a register ring.  No LDS, no producer work.
+//   * 4 consumer waves = (ci half, co half) quadrants of a 64 x 64 channel block, nine 32 x 32 accumulators each (one per
+//     tap); larger layers are covered by (Cin/64)(Cout/64) workgroup classes.  Workgroups are persistent and write one
+//     slab [9*Cin][Cout] sub-block each; wgrad_reduce_kernel sums the slabs in a fixed order (deterministic).
+struct WgradX3P {
+    const float* x;
+    const float* dy;
+    const uint8_t* am;
+    float* partial;
+    int B, T, F, Ty, Fy, Tp, Fp, Cin, Cout;
+    int npairs, npj;      // channel-block pairs, and pairs along Cout
+    int ntf, ntt, tiles;  // pixel tiles along F, along T, in total (F fastest)
+};
+
+constexpr int WX_HF = 18, WX_NPIX = 10 * WX_HF;          // halo of an 8 x 16 tile
+constexpr int WX_SUB = WX_NPIX * 64;                      // one (piece, ci half) sub-plane in bytes
+constexpr int WX_BUF = 6 * WX_SUB;                        // one halo buffer
+constexpr int WX_NVA = (WX_NPIX * 16 + NT - 1) / NT;      // float4 per producer thread and tile
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ bf16x8 tr_read8(const unsigned char* a) {    // 8 pixels (2 x 4) of this lane's channel
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a + 4 * 64));
+    union {
+        s16x4 h[2];
+        bf16x8 v;
+    } u;
+    u.h[0] = lo;
+    u.h[1] = hi;
+    return u.v;
+}
+
+template <bool UNPOOL>
+__global__ __launch_bounds__(512) void conv3x3_wgrad_x3_kernel(WgradX3P p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smx[];
+    const int tid = threadIdx.x;
+    const int pair = blockIdx.x % p.npairs, slot = blockIdx.x / p.npairs, nslots = gridDim.x / p.npairs;
+    const int cib = (pair / p.npj) * 64, cob = (pair % p.npj) * 64;
+    const int my_tiles = (p.tiles - slot + nslots - 1) / nslots;
+    const int T = p.T, F = p.F, Cin = p.Cin, Cout = p.Cout;
+    auto tile_of = [&](int j, int& b, int& t0, int& f0) {
+        int id = slot + j * nslots;
+        const int fx = id % p.ntf;
+        id /= p.ntf;
+        f0 = fx * 16;
+        t0 = (id % p.ntt) * 8;
+        b = id / p.ntt;
+    };
+
+    if (tid >= NT) {
+        // ------------------------------------------------------------------ producers: the x halo
+        const int ptid = tid - NT;
+        float4 hv[WX_NVA];
+        unsigned okbits = 0;
+        auto fetch = [&](int j) {
+            int b, t0, f0;
+            tile_of(j, b, t0, f0);
+            okbits = 0;
+#pragma unroll
+            for (int i = 0; i < WX_NVA; ++i) {
+                const int e = ptid + i * NT;
+                const int hp = min(e >> 4, WX_NPIX - 1), c4 = (e & 15) * 4;
+                const int ht = hp / WX_HF, hf = hp - ht * WX_HF;
+                const int ts = t0 + ht - 1, fs = f0 + hf - 1;
+                const bool ok = (unsigned)ts < (unsigned)T && (unsigned)fs < (unsigned)F;
+                const int tc = min(max(ts, 0), T - 1), fc = min(max(fs, 0), F - 1);
+                hv[i] = *reinterpret_cast<const float4*>(p.x + (((long)b * T + tc) * F + fc) * Cin + cib + c4);
+                okbits |= (ok ? 1u : 0u) << i;
+            }
+        };
+        auto commit = [&](int buf) {
+#pragma unroll
+            for (int i = 0; i < WX_NVA; ++i) {
+                const int e = ptid + i * NT;
+                if ((e >> 4) >= WX_NPIX) continue;
+                const int hp = e >> 4, c4 = (e & 15) * 4;
+                const float4 v = mask4(hv[i], ((okbits >> i) & 1u) ? 15u : 0u);
+                __bf16 hh[4], mm[4], ll[4];
+                split3(v.x, hh[0], mm[0], ll[0]);
+                split3(v.y, hh[1], mm[1], ll[1]);
+                split3(v.z, hh[2], mm[2], ll[2]);
+                split3(v.w, hh[3], mm[3], ll[3]);
+                unsigned char* dst = smx + buf * WX_BUF + ((c4 >> 5) * WX_NPIX + hp) * 64 + (c4 & 31) * 2;
+                *reinterpret_cast<bf16x4*>(dst) = bf16x4{hh[0], hh[1], hh[2], hh[3]};
+                *reinterpret_cast<bf16x4*>(dst + 2 * WX_SUB) = bf16x4{mm[0], mm[1], mm[2], mm[3]};
+                *reinterpret_cast<bf16x4*>(dst + 4 * WX_SUB) = bf16x4{ll[0], ll[1], ll[2], ll[3]};
+            }
+        };
+        if (my_tiles > 0) {
+            fetch(0);
+            commit(0);
+        }
+        if (my_tiles > 1) fetch(1);
+        __syncthreads();
+#pragma unroll 1
+        for (int j = 0; j < my_tiles; ++j) {
+            if (j + 1 < my_tiles) {
+                commit((j + 1) & 1);                   // the buffer tile j - 1 was read from
+                if (j + 2 < my_tiles) fetch(j + 2);
+            }
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- consumers: quadrant (qi, qj) of the 64 x 64 block
+    const int lane = tid & 63, wave = tid >> 6;
+    const int qi = wave >> 1, qj = wave & 1;
+    const int g = lane >> 4, x16 = lane & 15, l31 = lane & 31, hi = lane >> 5;
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+    // halo pixel (s + kw) * 18 + f + kh with f = (g >> 1) * 8 + r * 4 + (x16 >> 2); channels qi * 32 + 16 * (g & 1) + 4 * (x16 & 3)
+    const int abase = ((qi * WX_NPIX) + (g >> 1) * 8 + (x16 >> 2)) * 64 + (16 * (g & 1) + 4 * (x16 & 3)) * 2;
+    const int co = cob + qj * 32 + l31;
+    constexpr int RING = 4, NB = UNPOOL ? 4 : 8;
+    float bv[RING][NB];
+    uint8_t ba[RING][NB];
+    unsigned bok[RING];
+    const int nsteps = my_tiles * 8;
+    auto fetch_b = [&](int gs, float (&v)[NB], uint8_t (&a)[NB], unsigned& okm) {
+        const int j = gs >> 3, s = gs & 7;
+        int b, t0, f0;
+        tile_of(min(j, my_tiles - 1), b, t0, f0);
+        const int t = t0 + s, fb = f0 + hi * 8;
+        okm = 0;
+        if (!UNPOOL) {
+            const int tc = min(t, T - 1);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int f = fb + k;
+                v[k] = p.dy[(((long)b * T + tc) * F + min(f, F - 1)) * Cout + co];
+                okm |= ((t < p.Ty && f < p.Fy && j < my_tiles) ? 1u : 0u) << k;
+            }
+        } else {
+            const int tp = min(t >> 1, p.Tp - 1);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int fp = (fb >> 1) + k;
+                const long o = (((long)b * p.Tp + tp) * p.Fp + min(fp, p.Fp - 1)) * Cout + co;
+                v[k] = p.dy[o];
+                a[k] = p.am[o];
+                okm |= ((t < p.Ty && 2 * fp < p.Fy && j < my_tiles) ? 1u : 0u) << k;
+            }
+            okm |= (unsigned)(t & 1) << 8;
+        }
+    };
+    auto make_b = [&](const float (&v)[NB], const uint8_t (&a)[NB], unsigned okm, bf16x8 (&b3)[3]) {
+        __bf16 hh[8], mm[8], ll[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float val;
+            if (!UNPOOL) {
+                val = ((okm >> k) & 1u) ? v[k] : 0.f;
+            } else {
+                const unsigned sub = ((unsigned)(k & 1) << 1) | (okm >> 8);
+                val = (((okm >> (k >> 1)) & 1u) && a[k >> 1] == sub) ? v[k >> 1] : 0.f;
+            }
+            split3(val, hh[k], mm[k], ll[k]);
+        }
+        b3[0] = bf16x8{hh[0], hh[1], hh[2], hh[3], hh[4], hh[5], hh[6], hh[7]};
+        b3[1] = bf16x8{mm[0], mm[1], mm[2], mm[3], mm[4], mm[5], mm[6], mm[7]};
+        b3[2] = bf16x8{ll[0], ll[1], ll[2], ll[3], ll[4], ll[5], ll[6], ll[7]};
+    };
+    constexpr int AHEAD = UNPOOL ? 3 : 2;                      // dense dy: 8 registers per step, three steps ahead spills
+    if (nsteps > 0) {
+        fetch_b(0, bv[0], ba[0], bok[0]);
+        fetch_b(1, bv[1], ba[1], bok[1]);
+        if (AHEAD > 2) fetch_b(2, bv[2], ba[2], bok[2]);
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int j = 0; j < my_tiles; ++j) {
+#pragma unroll 1
+        for (int s4 = 0; s4 < 8; s4 += 4) {                    // 4 k-steps per trip: static ring indices, bounded live ranges
+        const unsigned char* A = smx + (j & 1) * WX_BUF + abase + s4 * WX_HF * 64;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            bf16x8 b3[3];
+            make_b(bv[s & 3], ba[s & 3], bok[s & 3], b3);
+            fetch_b(j * 8 + s4 + s + AHEAD, bv[(s + AHEAD) & 3], ba[(s + AHEAD) & 3], bok[(s + AHEAD) & 3]);     // past the end: clamped, masked off
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int kh = tap / 3, kw = tap - kh * 3;
+                const unsigned char* At = A + ((s + kw) * WX_HF + kh) * 64;
+                const bf16x8 a0 = tr_read8(At), a1 = tr_read8(At + 2 * WX_SUB), a2 = tr_read8(At + 4 * WX_SUB);
+                f32x16 cc = acc[tap];
+                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b3[0], cc, 0, 0, 0);      // smallest terms first
+                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3[1], cc, 0, 0, 0);
+                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b3[2], cc, 0, 0, 0);
+                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3[0], cc, 0, 0, 0);
+                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b3[1], cc, 0, 0, 0);
+                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b3[0], cc, 0, 0, 0);
+                acc[tap] = cc;
+            }
+        }
+        }
+        __syncthreads();
+    }
+    float* slab = p.partial + (long)slot * 9 * Cin * Cout;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int ci = cib + qi * 32 + 8 * (v >> 2) + 4 * hi + (v & 3);
+            slab[((long)tap * Cin + ci) * Cout + co] = acc[tap][v];
+        }
+}
+
 // w_ref (Cout,Cin,3,3) -> w_fwd[tap][cin][cout]  and  w_dgrad[tap'][cout][cin] with tap' the 180-degree flipped tap
 __global__ void conv_wprep_kernel(const float* w, float* wf, float* wd, int Cout, int Cin) {
     const int total = 9 * Cin * Cout;
@@ -1361,6 +1583,66 @@ int mtl_conv3x3_wgrad(void* stream, const float* x, const float* dy, const unsig
     if (rc) return rc;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(9L * Cin * Cout, 256)), dim3(256), 0, s, workspace, dw_ref,
                        nsplit, Cin, Cout);
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}
+
+static int wgrad_x3_grid(int Cin, int Cout) {
+    const int npairs = (Cin / 64) * (Cout / 64);
+    const int ncu = device_cu_count();
+    const int grid = ncu / npairs * npairs;
+    return grid < npairs ? npairs : grid;
+}
+
+long mtl_conv3x3_wgrad_x3_workspace(int B, int T, int F, int Cin, int Cout, int pooled) {
+    (void)B;
+    (void)T;
+    (void)F;
+    (void)pooled;
+    if (Cin % 64 || Cout % 64) return 0;
+    const int npairs = (Cin / 64) * (Cout / 64);
+    return (long)(wgrad_x3_grid(Cin, Cout) / npairs) * 9L * Cin * Cout * 4;
+}
+
+int mtl_conv3x3_wgrad_x3(void* stream, const float* x, const float* dy, const unsigned char* argmax, float* dw_ref,
+                         float* workspace, long workspace_bytes, int B, int T, int F, int Cin, int Cout) {
+    if (!x || !dy || !dw_ref || !workspace || Cin % 64 || Cout % 64) return MTL_EINVAL;
+    const int pooled = argmax != nullptr;
+    if (workspace_bytes < mtl_conv3x3_wgrad_x3_workspace(B, T, F, Cin, Cout, pooled)) return MTL_EINVAL;
+    WgradX3P p;
+    p.x = x;
+    p.dy = dy;
+    p.am = argmax;
+    p.partial = workspace;
+    p.B = B;
+    p.T = T;
+    p.F = F;
+    p.Ty = pooled ? 2 * (T / 2) : T;
+    p.Fy = pooled ? 2 * (F / 2) : F;
+    p.Tp = T / 2;
+    p.Fp = F / 2;
+    p.Cin = Cin;
+    p.Cout = Cout;
+    p.npj = Cout / 64;
+    p.npairs = (Cin / 64) * p.npj;
+    p.ntf = (p.Fy + 15) / 16;
+    p.ntt = (p.Ty + 7) / 8;
+    p.tiles = p.ntf * p.ntt * B;
+    const int grid = wgrad_x3_grid(Cin, Cout);
+    hipStream_t s = as_stream(stream);
+    constexpr int SMEM = 2 * WX_BUF;
+    if (pooled) {
+        static int attr = set_smem(conv3x3_wgrad_x3_kernel<true>, SMEM);
+        if (attr) return attr;
+        hipLaunchKernelGGL(conv3x3_wgrad_x3_kernel<true>, dim3(grid), dim3(512), SMEM, s, p);
+    } else {
+        static int attr = set_smem(conv3x3_wgrad_x3_kernel<false>, SMEM);
+        if (attr) return attr;
+        hipLaunchKernelGGL(conv3x3_wgrad_x3_kernel<false>, dim3(grid), dim3(512), SMEM, s, p);
+    }
+    MTL_CHECK_LAUNCH();
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(9L * Cin * Cout, 256)), dim3(256), 0, s, workspace, dw_ref,
+                       grid / p.npairs, Cin, Cout);
     MTL_CHECK_LAUNCH();
     return MTL_OK;
 }

@@ -96,6 +96,7 @@ class PassEngine:
         # 3x3 convolutions (forward and data gradient): '1' = exact 3-way bf16 split on the bf16 MFMA pipe (fp32-accurate, see
         # DESIGN.md 5.1), '0' = the fp32 MFMA kernels
         self.conv_x3 = os.environ.get('MTL_CONV_X3', '1') != '0'
+        self.wgrad_x3_dense = os.environ.get('MTL_WGRAD_X3_DENSE', '0') != '0'    # conv5 (dy not pooled): see DESIGN.md 5.1
         self.prof = None    # optional {name: [flops, [(start_event, end_event), ...]]}: HIP events around the conv launches
         if device.type != 'cuda':
             raise RuntimeError('PassEngine needs an MI355X device (got %s); there is no CPU product path' % device)
@@ -687,9 +688,12 @@ class PassEngine:
         conv_dgrad = lib.mtl_conv3x3_dgrad_x3 if self.conv_x3 else lib.mtl_conv3x3_dgrad
 
         def wgrad(xa, dy, am, idx, Bq, Tq, Fq, cin, cout):
-            need = lib.mtl_conv3x3_wgrad_workspace(Bq, Tq, Fq, cin, cout, 1 if am else 0)
+            x3 = self.conv_x3 and (am is not None or self.wgrad_x3_dense)
+            wsfn, fn = ((lib.mtl_conv3x3_wgrad_x3_workspace, lib.mtl_conv3x3_wgrad_x3) if x3 else
+                        (lib.mtl_conv3x3_wgrad_workspace, lib.mtl_conv3x3_wgrad))
+            need = wsfn(Bq, Tq, Fq, cin, cout, 1 if am else 0)
             ws = self.scratch(need)
-            check(self.timed('conv%d_wgrad' % idx, cf(Tq, Fq, cin, cout), lib.mtl_conv3x3_wgrad, st, xa, dy, am,
+            check(self.timed('conv%d_wgrad' % idx, cf(Tq, Fq, cin, cout), fn, st, xa, dy, am,
                              g('conv.%d.weight' % idx), ws, need, Bq, Tq, Fq, cin, cout), 'wgrad')
 
         self.colsum(dp2.data_ptr(), B * T4 * F4, 128, g('conv.7.bias'))

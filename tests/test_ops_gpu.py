@@ -165,6 +165,15 @@ def test_conv3x3_all(L, Cin, Cout, B, T, Fq):
     assert L.mtl_conv3x3_wgrad(st(), dxn.data_ptr(), dpn.data_ptr(), am.data_ptr(), wg.data_ptr(), ws.data_ptr(), need, B, T, Fq,
                                Cin, Cout) == 0
     assert rel(wg, wr.grad) < 1e-5
+    # split-bf16 weight gradient (halo-tiled, transpose reads): same contract, accumulates into dw like the fp32 one
+    need3 = L.mtl_conv3x3_wgrad_x3_workspace(B, T, Fq, Cin, Cout, 1)
+    ws3 = torch.empty(need3 // 4 + 16).cuda()
+    wg3 = torch.ones(Cout, Cin, 3, 3).cuda()
+    assert L.mtl_conv3x3_wgrad_x3(st(), dxn.data_ptr(), dpn.data_ptr(), am.data_ptr(), wg3.data_ptr(), ws3.data_ptr(), need3, B, T,
+                                  Fq, Cin, Cout) == 0
+    assert rel(wg3 - 1.0, wr.grad) < 1e-5
+    assert L.mtl_conv3x3_wgrad_x3(st(), dxn.data_ptr(), dpn.data_ptr(), am.data_ptr(), wg3.data_ptr(), ws3.data_ptr(), need3 - 4, B,
+                                  T, Fq, Cin, Cout) != 0          # short workspace is refused
     # dense (un-pooled) backward
     xr2 = x.clone().requires_grad_(True)
     wr2 = w.clone().requires_grad_(True)
@@ -180,6 +189,17 @@ def test_conv3x3_all(L, Cin, Cout, B, T, Fq):
     assert L.mtl_conv3x3_wgrad(st(), dxn.data_ptr(), dyn.data_ptr(), None, wg.data_ptr(), ws.data_ptr(), need, B, T, Fq, Cin,
                                Cout) == 0
     assert rel(wg, wr2.grad) < 1e-5
+    need3 = L.mtl_conv3x3_wgrad_x3_workspace(B, T, Fq, Cin, Cout, 0)
+    ws3 = torch.empty(need3 // 4 + 16).cuda()
+    wg3 = torch.zeros(Cout, Cin, 3, 3).cuda()
+    for _ in range(2):          # bitwise reproducible (fixed slab assignment and reduction order)
+        wg3.zero_()
+        assert L.mtl_conv3x3_wgrad_x3(st(), dxn.data_ptr(), dyn.data_ptr(), None, wg3.data_ptr(), ws3.data_ptr(), need3, B, T, Fq,
+                                      Cin, Cout) == 0
+        torch.cuda.synchronize()
+        first = wg3.clone() if _ == 0 else first
+    assert torch.equal(first, wg3)
+    assert rel(wg3, wr2.grad) < 1e-5
 
 
 @pytest.mark.parametrize('d', [128, 512])

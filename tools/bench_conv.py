@@ -54,6 +54,10 @@ def conv_case(name, T_, F_, cin, cout, pooled):
     ws = torch.empty(need // 4 + 64, device=dev); dw = torch.zeros_like(w)
     t = timeit(lambda: L.mtl_conv3x3_wgrad(st(), x.data_ptr(), dy.data_ptr(), amp, dw.data_ptr(), ws.data_ptr(), need, B, T_, F_, cin, cout))
     print('%-8s wgrad %.3f ms %6.1f TF' % (name, t, flops / t / 1e9))
+    need = L.mtl_conv3x3_wgrad_x3_workspace(B, T_, F_, cin, cout, 1 if pooled else 0)
+    ws = torch.empty(need // 4 + 64, device=dev)
+    t = timeit(lambda: L.mtl_conv3x3_wgrad_x3(st(), x.data_ptr(), dy.data_ptr(), amp, dw.data_ptr(), ws.data_ptr(), need, B, T_, F_, cin, cout))
+    print('%-8s wgrad x3 %.3f ms %6.1f TF' % (name, t, flops / t / 1e9))
 
 conv_case('conv2', T, F, 64, 64, True)
 conv_case('conv5', T // 2, F // 2, 64, 128, False)
