@@ -31,6 +31,19 @@ import torch  # noqa: E402
 CFG = dict(num_enc_layers=2, num_dec_layers=4, num_heads=8, dim_model=512, dim_key=64, dim_value=64, dim_inner=512,
            dim_emb=512, src_max_len=5000, tgt_max_len=2500, r=100, vocab_size=3765)
 PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, no TF32 on gfx950
+PEAK_BF16_MFMA_TFLOPS = 2516.6    # same guide: v_mfma_f32_32x32x16_bf16, 16x the f32 MFMA rate, dense
+# The split-bf16 ("x3") convolution kernels issue SIX bf16 MFMAs per fp32-equivalent multiply-accumulate step, so the
+# roof of their ALGORITHMIC (fp32-equivalent) FLOP rate is the dense bf16 peak / 6.
+PEAK_X3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
+
+
+def conv_arithmetic(engine, name):
+    """Which MFMA pipe a conv-stack kernel class runs on (mirrors the choices in PassEngine.forward/backward)."""
+    if not engine.conv_x3 or name.startswith('conv0'):
+        return 'f32'
+    if name == 'conv5_wgrad' and not engine.wgrad_x3_dense:
+        return 'f32'
+    return 'x3'
 
 
 class ResidentTask:
@@ -193,18 +206,27 @@ def main():
             pmc = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
         except Exception:
             pass
-        roofline = dict(bound='mfma', kernel=name, achieved=flops / avg / 1e12, peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s',
-                        frac=flops / avg / 1e12 / PEAK_F32_MFMA_TFLOPS, traffic=pmc.get(name), gflop_per_launch=flops / 1e9,
+        arith = conv_arithmetic(model.engine, name)
+        peak = PEAK_X3_TFLOPS if arith == 'x3' else PEAK_F32_MFMA_TFLOPS
+        peak_of = lambda n: PEAK_X3_TFLOPS if conv_arithmetic(model.engine, n) == 'x3' else PEAK_F32_MFMA_TFLOPS
+        roofline = dict(bound='mfma', kernel=name, achieved=flops / avg / 1e12, peak=peak, unit='TFLOP/s',
+                        frac=flops / avg / 1e12 / peak, traffic=pmc.get(name), gflop_per_launch=flops / 1e9,
+                        arithmetic=('split-bf16 x3: 6 v_mfma_f32_32x32x16_bf16 per fp32-equivalent step, peak = dense bf16 / 6'
+                                    if arith == 'x3' else 'v_mfma_f32_32x32x2_f32'),
                         avg_launch_ms=avg * 1e3, launches_timed=cnt, timing='HIP events, serial profiling step after the timed region',
                         conv_stack=dict(tflops=conv_flops / conv_time / 1e12, ms_per_pass=conv_time / (2 * len(my_tasks)) * 1e3,
-                                        per_kernel={r[1]: dict(ms=r[3] * 1e3, tflops=r[2] / r[3] / 1e12) for r in rows}),
+                                        per_kernel={r[1]: dict(ms=r[3] * 1e3, tflops=r[2] / r[3] / 1e12,
+                                                               frac=r[2] / r[3] / 1e12 / peak_of(r[1])) for r in rows}),
                         timed_region_concurrent={r[1]: dict(ms=r[3] * 1e3, tflops=r[2] / r[3] / 1e12, launches=r[4]) for r in conc})
         out = dict(metric='meta-steps/sec', value=a.steps / dt, unit='meta-steps/s', n_gpus=world, steps=a.steps, warmup=a.warmup,
                    ms_per_step=ms, higher_is_better=True, scaling='strong', vs_baseline=None, dtype='f32', data='synthetic',
                    config=dict(workload='meta_transfer_train --copy-grad, enc2/dec4 d512 h8 r100 V3765, %d synthetic tasks '
                                         '(%d per GPU), k_train=k_valid=%d, %d frames x 161 bins, %d labels, dropout 0'
                                         % (a.tasks, len(my_tasks), a.k, a.frames, a.labels),
-                               tasks=a.tasks, k_train=a.k, src_frames=a.frames, tgt_len=a.labels, parallelism='task-sharded dp%d' % world),
+                               tasks=a.tasks, k_train=a.k, src_frames=a.frames, tgt_len=a.labels, parallelism='task-sharded dp%d' % world,
+                               conv_arithmetic=('3x3 convolutions as exact 3-way bf16 splits of fp32 operands, fp32 accumulate '
+                                                '(fp32-class error, same test tolerances as the fp32-MFMA kernels)'
+                                                if model.engine.conv_x3 else 'fp32 MFMA')),
                    roofline=roofline, last_step=dict(val_loss=last[0] / a.tasks, cer_edits=last[1], chars=last[2]))
 
     if world == 1:

@@ -425,16 +425,30 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     __syncthreads();
     if (wv == 0 && c < cols) part[(long)blockIdx.y * cols + c] = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
 }
-__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int nblk, int cols, float* __restrict__ out) {
-    __shared__ float sh[4][64];
+// 16 waves per column block: the tall conv-bias sums leave ~1000 partial rows, which 4 waves walked in 126 us
+__global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restrict__ part, int nblk, int cols, float* __restrict__ out) {
+    __shared__ float sh[16][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
-    float s = 0.f;
-    if (c < cols)
-        for (int b = wv; b < nblk; b += 4) s += part[(long)b * cols + c];
-    sh[wv][lane] = s;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < cols) {
+        int b = wv;
+        for (; b + 48 < nblk; b += 64) {
+            s0 += part[(long)b * cols + c];
+            s1 += part[(long)(b + 16) * cols + c];
+            s2 += part[(long)(b + 32) * cols + c];
+            s3 += part[(long)(b + 48) * cols + c];
+        }
+        for (; b < nblk; b += 16) s0 += part[(long)b * cols + c];
+    }
+    sh[wv][lane] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (wv == 0 && c < cols) out[c] += (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
+    if (wv == 0 && c < cols) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += sh[w][lane];
+        out[c] += t;
+    }
 }
 
 // ------------------------------------------------------------------ first conv layer (C_in = 1): direct, HBM-bound
@@ -783,7 +797,7 @@ int mtl_ce_bwd(void* stream, const float* logits, const float* lse, const long* 
 static long colsum_chunks(long rows, int cols) {
     const long colblocks = (cols + 63) / 64;
     long nblk = (rows + 31) / 32;                 // >= 32 rows per block
-    const long want = (2048 + colblocks - 1) / colblocks;
+    const long want = (1024 + colblocks - 1) / colblocks;
     if (nblk > want) nblk = want;
     if (nblk < 1) nblk = 1;
     return nblk;
@@ -798,7 +812,7 @@ int mtl_colsum_accum(void* stream, const float* X, long rows, int cols, long ld,
     hipStream_t s = as_stream(stream);
     hipLaunchKernelGGL(colsum_partial_kernel, dim3((cols + 63) / 64, (unsigned)nblk), dim3(256), 0, s, X, rows, cols, ld, rpb,
                        workspace);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((cols + 63) / 64), dim3(256), 0, s, workspace, (int)nblk, cols, out);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((cols + 63) / 64), dim3(1024), 0, s, workspace, (int)nblk, cols, out);
     MTL_CHECK_LAUNCH();
     return MTL_OK;
 }

@@ -1368,12 +1368,23 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_x3_kernel(WgradX3P p) {
         const int t = t0 + s, fb = f0 + hi * 8;
         okm = 0;
         if (!UNPOOL) {
+            // one base address + 8 immediate offsets (pixel stride Cout * 4 bytes) whenever the 8 pixels lie inside the row --
+            // per-pixel clamped addresses (the ragged last group of a row only) cost 16 more live registers and spill
             const int tc = min(t, T - 1);
+            const int fs = max(min(fb, F - 8), 0);
+            const float* rowp = p.dy + (((long)b * T + tc) * F + fs) * Cout + co;
+            const bool rowok = t < p.Ty && j < my_tiles;
+            if (fs == fb) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int f = fb + k;
-                v[k] = p.dy[(((long)b * T + tc) * F + min(f, F - 1)) * Cout + co];
-                okm |= ((t < p.Ty && f < p.Fy && j < my_tiles) ? 1u : 0u) << k;
+                for (int k = 0; k < 8; ++k) v[k] = rowp[(long)k * Cout];
+                okm = rowok ? ((fb + 8 <= p.Fy) ? 0xffu : ((1u << max(p.Fy - fb, 0)) - 1u)) : 0u;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int f = fb + k;
+                    v[k] = p.dy[(((long)b * T + tc) * F + min(f, F - 1)) * Cout + co];
+                    okm |= ((rowok && f < p.Fy) ? 1u : 0u) << k;
+                }
             }
         } else {
             const int tp = min(t >> 1, p.Tp - 1);
@@ -1405,7 +1416,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_x3_kernel(WgradX3P p) {
         b3[1] = bf16x8{mm[0], mm[1], mm[2], mm[3], mm[4], mm[5], mm[6], mm[7]};
         b3[2] = bf16x8{ll[0], ll[1], ll[2], ll[3], ll[4], ll[5], ll[6], ll[7]};
     };
-    constexpr int AHEAD = UNPOOL ? 3 : 2;                      // dense dy: 8 registers per step, three steps ahead spills
+    constexpr int AHEAD = 3;
     if (nsteps > 0) {
         fetch_b(0, bv[0], ba[0], bok[0]);
         fetch_b(1, bv[1], ba[1], bok[1]);

@@ -96,7 +96,7 @@ class PassEngine:
         # 3x3 convolutions (forward and data gradient): '1' = exact 3-way bf16 split on the bf16 MFMA pipe (fp32-accurate, see
         # DESIGN.md 5.1), '0' = the fp32 MFMA kernels
         self.conv_x3 = os.environ.get('MTL_CONV_X3', '1') != '0'
-        self.wgrad_x3_dense = os.environ.get('MTL_WGRAD_X3_DENSE', '0') != '0'    # conv5 (dy not pooled): see DESIGN.md 5.1
+        self.wgrad_x3_dense = os.environ.get('MTL_WGRAD_X3_DENSE', '1') != '0'    # conv5 (dy not pooled)
         self.prof = None    # optional {name: [flops, [(start_event, end_event), ...]]}: HIP events around the conv launches
         if device.type != 'cuda':
             raise RuntimeError('PassEngine needs an MI355X device (got %s); there is no CPU product path' % device)
