@@ -544,13 +544,13 @@ struct EpiConvDgrad {  // dx = acc masked by the ReLU of the forward activation 
             }
         }
     }
-    // two-phase form for epilogues that own many accumulator groups: gate4 for ALL groups first (loads from clamped
-    // addresses, all in flight together), then store4g -- one exposed HBM latency per tile instead of one per group
+    // two-phase form for epilogues that own many accumulator groups: gate4 for a batch of groups first (all loads in flight
+    // together), then store4g -- one exposed HBM latency per batch instead of one per group
     __device__ __forceinline__ void gate4(int lr, int lc, float (&m)[4]) const {
         const int col = n0 + lc;
         const int w = (lr >> 5) * 8 + ((lr >> 2) & 7);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 4; ++j) {        // unconditional loads from clamped addresses: no branch between the loads
             const int t = min(t0 + 2 * (w >> 3) + (j & 1), T - 1), f = min(f0 + 2 * (w & 7) + (j >> 1), F - 1);
             m[j] = act[(((long)b * T + t) * F + f) * Cout + col];
         }
@@ -931,7 +931,11 @@ __global__ __launch_bounds__((4 * G + 4) * 64) void conv3x3_x3h_kernel(ConvX3P p
             if (c + 1 == cch && !(p.dbg & 8)) {
                 // epilogue (no LDS): same row -> (pool window, position) walk as Engine::finish with this wave's sub-tile
                 // origin; it runs while the producers commit the next tile's halo
-                const X3Tile tl = x3_tile<G>(p, blockIdx.x + j * gridDim.x);
+                // (the tile index goes through an opaque asm so that the per-lane output addresses are computed HERE: hoisted
+                // above the MFMA loops they were spilled per tile, and the scratch traffic doubled the dgrad kernels' HBM writes)
+                int jj = j;
+                asm volatile("" : "+s"(jj));
+                const X3Tile tl = x3_tile<G>(p, blockIdx.x + jj * gridDim.x);
                 const int ts0 = tl.t0 + grp * 8, n0 = tl.n0 * BN;
                 auto walk = [&](auto&& epi) {
 #pragma unroll
@@ -950,22 +954,23 @@ __global__ __launch_bounds__((4 * G + 4) * 64) void conv3x3_x3h_kernel(ConvX3P p
                     walk(EpiConvPool{p.y, p.am_out, p.bias, tl.b, ts0, tl.f0, Tp, Fp, Cout, n0});
                 } else {
                     const EpiConvDgrad epi{p.y, p.act, tl.b, ts0, tl.f0, T, F, Cout, n0};
+                    float gate[TM][TN][4][4];                  // all gate values of the wave in flight together
 #pragma unroll
-                    for (int i = 0; i < TM; ++i) {             // 32 gate values in flight per half (all 64 would spill)
-                        float gate[TN][4][4];
+                    for (int i = 0; i < TM; ++i)
 #pragma unroll
                         for (int jn = 0; jn < TN; ++jn)
 #pragma unroll
                             for (int g = 0; g < 4; ++g)
-                                epi.gate4(wm * WTM + i * 32 + 8 * g + 4 * hi, wn * WTN + jn * 32 + l31, gate[jn][g]);
+                                epi.gate4(wm * WTM + i * 32 + 8 * g + 4 * hi, wn * WTN + jn * 32 + l31, gate[i][jn][g]);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
 #pragma unroll
                         for (int jn = 0; jn < TN; ++jn)
 #pragma unroll
                             for (int g = 0; g < 4; ++g) {
                                 float v[4] = {acc[i][jn][4 * g], acc[i][jn][4 * g + 1], acc[i][jn][4 * g + 2], acc[i][jn][4 * g + 3]};
-                                epi.store4g(wm * WTM + i * 32 + 8 * g + 4 * hi, wn * WTN + jn * 32 + l31, v, gate[jn][g]);
+                                epi.store4g(wm * WTM + i * 32 + 8 * g + 4 * hi, wn * WTN + jn * 32 + l31, v, gate[i][jn][g]);
                             }
-                    }
                 }
             }
             if (j * cch + c + 1 < nstage) __syncthreads();     // the producers replaced the halo between these two barriers
