@@ -33,7 +33,9 @@ int mtl_abi_version(void);
  *   transB = 0: B is K x N (ldb)   | 1: B is stored N x K (ldb)
  *   epilogue: + bias[n] (nullable) ; ReLU if flags&MTL_GEMM_RELU ; zero where gate[m*ldg+n] <= 0 (nullable,
  *             same batch offsets as C) ; += C if flags&MTL_GEMM_ACCUM.
- *   workspace (nullable): when batch == 1 and the output has too few tiles to fill the 256 CUs, K is split over the grid
+ *   sBias: bias stride (floats) of the outer batch index b (0 = one bias vector for every item) -- lets the three Q/K/V
+ *             projections of an attention block, whose parameters sit at a constant stride in the flat buffer, run as ONE call.
+ *   workspace (nullable): when the output has too few tiles (x batch items) to fill the 256 CUs, K is split over the grid
  *             into workspace slabs that a second kernel sums in fixed order (deterministic split-K).
  * Replaces nn.Linear forward/backward (modules/encoder.py:72; modules/common_layers.py:130,287-289,303;
  * modules/decoder.py:108-110) and torch.bmm (modules/common_layers.py:321,329) incl. the permute/contiguous
@@ -42,7 +44,7 @@ int mtl_abi_version(void);
 #define MTL_GEMM_ACCUM 2
 int mtl_gemm_f32(void* stream, int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
                  const float* B, int ldb, float* C, int ldc, const float* bias, const float* gate, int ldg, int flags,
-                 int batch, int H, long sAb, long sAh, long sBb, long sBh, long sCb, long sCh, float* workspace,
+                 int batch, int H, long sAb, long sAh, long sBb, long sBh, long sCb, long sCh, long sBias, float* workspace,
                  long workspace_bytes);
 
 /* ---- VGG front-end: models/asr/transformer.py:48-59 (Conv2d 3x3 s1 p1 + ReLU [+ MaxPool2d(2,2)]) ------

@@ -16,7 +16,7 @@ P, I, L, F = c_void_p, c_int, c_long, c_float
 # name -> (restype, argtypes); mirrors include/mtl_hip.h one-to-one (tests/test_abi.py checks both directions)
 SIGNATURES = {
     'mtl_abi_version': (I, []),
-    'mtl_gemm_f32': (I, [P, I, I, I, I, I, F, P, I, P, I, P, I, P, P, I, I, I, I, L, L, L, L, L, L, P, L]),
+    'mtl_gemm_f32': (I, [P, I, I, I, I, I, F, P, I, P, I, P, I, P, P, I, I, I, I, L, L, L, L, L, L, L, P, L]),
     'mtl_conv0_relu_fwd': (I, [P, P, P, P, P, I, I, I]),
     'mtl_conv0_wgrad_workspace': (L, []),
     'mtl_conv0_wgrad': (I, [P, P, P, P, P, P, I, I, I]),

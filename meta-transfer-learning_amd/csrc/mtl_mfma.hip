@@ -248,8 +248,10 @@ struct GemmP {
     float alpha;
     int flags, H;
     long sAb, sAh, sBb, sBh, sCb, sCh;
-    int ksplit, kchunk;   // ksplit > 1: grid.z indexes K-chunks (batch must be 1); raw partial tiles go to `partial`
-    float* partial;       // [ksplit][M][N]
+    int ksplit, kchunk;   // ksplit > 1: grid.z = (batch item) * ksplit + K-chunk; raw partial tiles go to `partial`
+    float* partial;       // [batch item][ksplit][M][N]
+    long sBias;           // bias stride of the OUTER batch index (0: one bias for all)
+    int nz;               // batch items in total (grid.z without split-K)
 };
 
 struct EpiGemm {
@@ -289,11 +291,15 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
     f32x16 acc[E::TM][E::TN];
     E::zero(acc);
     if (p.ksplit > 1) {
-        // split-K: this block owns k in [k0, k0+Kc); partial sums are combined in fixed order by splitk_reduce_kernel
-        const int k0 = blockIdx.z * p.kchunk;
+        // split-K: this block owns k in [k0, k0+Kc) of batch item zi; partial sums are combined in fixed order by splitk_reduce_kernel
+        const int zi = blockIdx.z / p.ksplit, zs = blockIdx.z - zi * p.ksplit;
+        const int zb = zi / p.H, zh = zi - zb * p.H;
+        const int k0 = zs * p.kchunk;
         const int Kc = min(p.kchunk, p.K - k0);
-        la.init(p.A + (TA ? (long)k0 * p.lda : (long)k0), p.lda, m0, p.M, Kc, tid);
-        lb.init(p.B + (TB ? (long)k0 : (long)k0 * p.ldb), p.ldb, n0, p.N, Kc, tid);
+        const float* A = p.A + zb * p.sAb + zh * p.sAh;
+        const float* B = p.B + zb * p.sBb + zh * p.sBh;
+        la.init(A + (TA ? (long)k0 * p.lda : (long)k0), p.lda, m0, p.M, Kc, tid);
+        lb.init(B + (TB ? (long)k0 : (long)k0 * p.ldb), p.ldb, n0, p.N, Kc, tid);
         E::run(la, lb, (Kc + BK - 1) / BK, smem, acc);
         EpiGemm epi{p.partial + (long)blockIdx.z * p.M * p.N, nullptr, nullptr, p.M, p.N, m0, n0, p.N, 0, 0, 1.f};
         E::finish(acc, epi);
@@ -307,21 +313,26 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
     lb.init(B, p.ldb, n0, p.N, p.K, tid);
     E::run(la, lb, (p.K + BK - 1) / BK, smem, acc);
     const float* gate = p.gate ? p.gate + zb * p.sCb + zh * p.sCh : nullptr;
-    EpiGemm epi{C, p.bias, gate, p.M, p.N, m0, n0, p.ldc, p.ldg, p.flags, p.alpha};
+    EpiGemm epi{C, p.bias ? p.bias + zb * p.sBias : nullptr, gate, p.M, p.N, m0, n0, p.ldc, p.ldg, p.flags, p.alpha};
     E::finish(acc, epi);
 }
 
 // C = epilogue(sum_z partial[z]) -- fixed summation order, so split-K stays run-to-run deterministic
 __global__ void splitk_reduce_kernel(GemmP p) {
-    const long total = (long)p.M * p.N;
+    const long mn = (long)p.M * p.N, total = mn * p.nz;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const int row = (int)(e / p.N), col = (int)(e - (long)row * p.N);
+        const int zi = (int)(e / mn);
+        const long r = e - zi * mn;
+        const int row = (int)(r / p.N), col = (int)(r - (long)row * p.N);
+        const int zb = zi / p.H, zh = zi - zb * p.H;
+        const float* part = p.partial + (long)zi * p.ksplit * mn + r;
         float s = 0.f;
-        for (int z = 0; z < p.ksplit; ++z) s += p.partial[(long)z * total + e];
-        float x = p.alpha * s + (p.bias ? p.bias[col] : 0.f);
+        for (int z = 0; z < p.ksplit; ++z) s += part[(long)z * mn];
+        float x = p.alpha * s + (p.bias ? p.bias[zb * p.sBias + col] : 0.f);
         if (p.flags & MTL_GEMM_RELU) x = fmaxf(x, 0.f);
-        if (p.gate) x = p.gate[(long)row * p.ldg + col] > 0.f ? x : 0.f;
-        float* c = p.C + (long)row * p.ldc + col;
+        const long co = zb * p.sCb + zh * p.sCh;
+        if (p.gate) x = p.gate[co + (long)row * p.ldg + col] > 0.f ? x : 0.f;
+        float* c = p.C + co + (long)row * p.ldc + col;
         if (p.flags & MTL_GEMM_ACCUM) x += *c;
         *c = x;
     }
@@ -363,12 +374,12 @@ int dispatch_gemm(GemmP& p, int batch, hipStream_t s, float* workspace, long wor
     // big tiles only when they still give >= 1 workgroup per CU
     const long big = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * batch;
     if (big >= 256) return launch_gemm<128, 128, TA, TB>(p, batch, s);
-    const long tiles = (long)((p.M + 63) / 64) * ((p.N + 63) / 64);
-    if (batch == 1 && workspace && tiles < 192 && p.K >= 128) {
+    const long tiles = (long)((p.M + 63) / 64) * ((p.N + 63) / 64) * batch;
+    if (workspace && tiles < 192 && p.K >= 128 && (batch == 1 || p.H == 1)) {      // (b,h)-batched attention products stay unsplit
         // too few output tiles to fill 256 CUs: split K over grid.z into a workspace, then a fixed-order reduction
         long S = (512 + tiles - 1) / tiles;
         if (S > p.K / 64) S = p.K / 64;
-        const long fit = workspace_bytes / ((long)p.M * p.N * 4);
+        const long fit = workspace_bytes / ((long)p.M * p.N * 4 * batch);
         if (S > fit) S = fit;
         if (S > 32) S = 32;
         if (S >= 2) {
@@ -376,9 +387,9 @@ int dispatch_gemm(GemmP& p, int batch, hipStream_t s, float* workspace, long wor
             p.ksplit = (p.K + p.kchunk - 1) / p.kchunk;
             p.partial = workspace;
             if (p.ksplit >= 2) {
-                int rc = launch_gemm<64, 64, TA, TB>(p, p.ksplit, s);
+                int rc = launch_gemm<64, 64, TA, TB>(p, batch * p.ksplit, s);
                 if (rc) return rc;
-                hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for((long)p.M * p.N, 256, 1024)), dim3(256), 0, s, p);
+                hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for((long)p.M * p.N * batch, 256, 1024)), dim3(256), 0, s, p);
                 MTL_CHECK_LAUNCH();
                 return MTL_OK;
             }
@@ -1486,10 +1497,10 @@ extern "C" {
 
 int mtl_gemm_f32(void* stream, int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
                  const float* B, int ldb, float* C, int ldc, const float* bias, const float* gate, int ldg, int flags,
-                 int batch, int H, long sAb, long sAh, long sBb, long sBh, long sCb, long sCh, float* workspace,
+                 int batch, int H, long sAb, long sAh, long sBb, long sBh, long sCb, long sCh, long sBias, float* workspace,
                  long workspace_bytes) {
     if (M <= 0 || N <= 0 || K <= 0 || batch <= 0 || H <= 0 || !A || !B || !C) return MTL_EINVAL;
-    GemmP p{A, B, C, bias, gate, M, N, K, lda, ldb, ldc, ldg, alpha, flags, H, sAb, sAh, sBb, sBh, sCb, sCh, 1, 0, nullptr};
+    GemmP p{A, B, C, bias, gate, M, N, K, lda, ldb, ldc, ldg, alpha, flags, H, sAb, sAh, sBb, sBh, sCb, sCh, 1, 0, nullptr, sBias, batch};
     hipStream_t s = as_stream(stream);
     if (!transA && transB) return dispatch_gemm<false, true>(p, batch, s, workspace, workspace_bytes);
     if (!transA && !transB) return dispatch_gemm<false, false>(p, batch, s, workspace, workspace_bytes);

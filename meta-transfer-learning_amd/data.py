@@ -222,7 +222,7 @@ class SpectrogramFrontEnd:
         out = torch.empty(self.F, T, device=self.device)
         st = torch.cuda.current_stream(self.device).cuda_stream
         _lib.check(lib.mtl_gemm_f32(st, 0, 0, T, 2 * self.F, self.n_fft, 1.0, yp.data_ptr(), self.hop, self.basis.data_ptr(), self.ldb,
-                                    reim.data_ptr(), self.ldb, None, None, 0, 0, 1, 1, 0, 0, 0, 0, 0, 0, None, 0), 'stft gemm')
+                                    reim.data_ptr(), self.ldb, None, None, 0, 0, 1, 1, 0, 0, 0, 0, 0, 0, 0, None, 0), 'stft gemm')
         _lib.check(lib.mtl_spect_logmag(st, reim.data_ptr(), self.ldb, T, self.F, out.data_ptr(), self.partials.data_ptr(),
                                         1 if self.normalize else 0), 'mtl_spect_logmag')
         return out

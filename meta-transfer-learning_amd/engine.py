@@ -71,6 +71,9 @@ def decoder_io(padded_target, pad_id=PAD_ID, sos_id=SOS_ID, eos_id=EOS_ID):
     return seq_in, seq_out
 
 
+_FULL = {'q': 'query', 'k': 'key', 'v': 'value'}
+
+
 class PassEngine:
     def __init__(self, layout, hp, device, pe_enc, pe_dec):
         self.pe_enc, self.pe_dec = pe_enc, pe_dec   # (max_len, d) fp32 device tables (non-trainable buffers)
@@ -96,6 +99,7 @@ class PassEngine:
         # 3x3 convolutions (forward and data gradient): '1' = exact 3-way bf16 split on the bf16 MFMA pipe (fp32-accurate, see
         # DESIGN.md 5.1), '0' = the fp32 MFMA kernels
         self.conv_x3 = os.environ.get('MTL_CONV_X3', '1') != '0'
+        self.batch_qkv = os.environ.get('MTL_BATCH_QKV', '1') != '0'   # q/k/v projections as strided-batch GEMMs
         self.wgrad_x3_dense = os.environ.get('MTL_WGRAD_X3_DENSE', '1') != '0'    # conv5 (dy not pooled)
         self.prof = None    # optional {name: [flops, [(start_event, end_event), ...]]}: HIP events around the conv launches
         if device.type != 'cuda':
@@ -138,11 +142,11 @@ class PassEngine:
         return torch.cuda.current_stream(self.device).cuda_stream
 
     def gemm(self, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias=None, gate=None, ldg=0, flags=0, alpha=1.0,
-             batch=1, H=1, sA=(0, 0), sB=(0, 0), sC=(0, 0)):
+             batch=1, H=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), sbias=0):
         wst = self.gemm_ws_side if self.on_side else self.gemm_ws
-        ws, wsb = (wst.data_ptr(), wst.numel() * 4) if batch == 1 else (None, 0)
         check(self.lib.mtl_gemm_f32(self.stream, ta, tb, M, N, K, alpha, A, lda, B, ldb, C, ldc, bias, gate, ldg, flags,
-                                    batch, H, sA[0], sA[1], sB[0], sB[1], sC[0], sC[1], ws, wsb), 'mtl_gemm_f32')
+                                    batch, H, sA[0], sA[1], sB[0], sB[1], sC[0], sC[1], sbias, wst.data_ptr(),
+                                    wst.numel() * 4), 'mtl_gemm_f32')
 
     # ---- side stream: deferred parameter-gradient work
     def defer(self, fn):
@@ -227,14 +231,24 @@ class PassEngine:
         hk, hv = h * dk, h * dv
         o = lambda n: P + 4 * L.off(pre + n)
         t = {}
-        for nm, src, rows, width in (('q', xq, Mq, hk), ('k', xkv, Mk, hk), ('v', xkv, Mk, hv)):
-            full = {'q': 'query', 'k': 'key', 'v': 'value'}[nm]
-            a = self.buf(tag + nm + 'a', (rows, r))
-            bfull = self.buf(tag + nm, (rows, width))
-            self.linear_fwd(src, rows, d, o(full + '_linear_a.weight'), None, a.data_ptr(), r)
-            self.linear_fwd(a.data_ptr(), rows, r, o(full + '_linear_b.weight'), o(full + '_linear_b.bias'),
-                            bfull.data_ptr(), width)
-            t[nm + 'a'], t[nm] = a, bfull
+        # The three projections have identical shapes and their parameters sit at a constant stride in the flat theta / G
+        # buffers, so projections that share their input run as ONE strided-batch GEMM per low-rank stage (self-attention:
+        # q,k,v; encoder-decoder attention: k,v) instead of two launches (+ a split-K reduction) each.
+        groups = self._qkv_groups(pre, xq, Mq, xkv, Mk, hk, hv)
+        for names, src, rows in groups:
+            n, f0 = len(names), _FULL[names[0]]
+            wd = hv if names == 'v' else hk                  # groups of several projections exist only when hk == hv
+            a_all = self.buf(tag + names + 'a', (n, rows, r))
+            b_all = self.buf(tag + names, (n, rows, wd))
+            sa, sb, sbias = (self._pstride(pre, names, sfx) for sfx in ('_linear_a.weight', '_linear_b.weight', '_linear_b.bias'))
+            self.gemm(0, 1, rows, r, d, src, d, o(f0 + '_linear_a.weight'), d, a_all.data_ptr(), r, batch=n, sB=(sa, 0),
+                      sC=(rows * r, 0))
+            self.gemm(0, 1, rows, wd, r, a_all.data_ptr(), r, o(f0 + '_linear_b.weight'), r, b_all.data_ptr(), wd,
+                      bias=o(f0 + '_linear_b.bias'), batch=n, sA=(rows * r, 0), sB=(sb, 0), sC=(rows * wd, 0), sbias=sbias)
+            for i, nm in enumerate(names):
+                self.arena[tag + nm + 'a'], self.arena[tag + nm] = a_all[i], b_all[i]
+                t[nm + 'a'], t[nm] = a_all[i], b_all[i]
+        self.arena[tag + 'groups'] = groups
         ldS = (Tk + 3) // 4 * 4
         S = self.buf(tag + 'P', (Bn, h, Tq, ldS))
         self.gemm(0, 1, Tq, Tk, dk, t['q'].data_ptr(), hk, t['k'].data_ptr(), hk, S.data_ptr(), ldS, batch=Bn * h, H=h,
@@ -285,9 +299,14 @@ class PassEngine:
         self.linear_bwd(O.data_ptr(), doa.data_ptr(), Mq, hv, r, o('output_linear_a.weight'), g('output_linear_a.weight'),
                         None, dO.data_ptr(), False)
         q, k, v = A[tag + 'q'], A[tag + 'k'], A[tag + 'v']
-        dq = self.buf(tag + '_dq', (Mq, hk))
-        dkk = self.buf(tag + '_dk', (Mk, hk))
-        dvv = self.buf(tag + '_dv', (Mk, hv))
+        groups = A[tag + 'groups']
+        dfull = {}                                       # gradients of the projected q / k / v, grouped like the forward
+        for names, _src, rows in groups:
+            d_all = self.buf(tag + '_d' + names, (len(names), rows, hv if names == 'v' else hk))
+            for i, nm in enumerate(names):
+                dfull[nm] = d_all[i]
+            dfull[names] = d_all
+        dq, dkk, dvv = dfull['q'], dfull['k'], dfull['v']
         dP = self.buf('_dP', (Bn, h, Tq, ldS))
         sP = (h * Tq * ldS, Tq * ldS)
         # dV = P^T dO ; dP = dO V^T ; dS = softmax'(P, dP)/temp ; dQ = dS K ; dK = dS^T Q
@@ -304,20 +323,62 @@ class PassEngine:
         self.gemm(1, 0, Tk, dk, Tq, dP.data_ptr(), ldS, q.data_ptr(), hk, dkk.data_ptr(), hk, batch=Bn * h, H=h,
                   sA=sP, sB=(Tq * hk, dk), sC=(Tk * hk, dk))
         first_kv = True
-        for nm, full, dfull, src, rows, width, dst in (('q', 'query', dq, xq, Mq, hk, dxq), ('k', 'key', dkk, xkv, Mk, hk, dxkv),
-                                                       ('v', 'value', dvv, xkv, Mk, hv, dxkv)):
-            a = A[tag + nm + 'a']
-            da = self.buf(tag + '_da' + nm, (rows, r))
-            self.linear_bwd(a.data_ptr(), dfull.data_ptr(), rows, r, width, o(full + '_linear_b.weight'),
-                            g(full + '_linear_b.weight'), g(full + '_linear_b.bias'), da.data_ptr(), False)
-            if nm == 'q':
-                accum = True
-            else:
-                accum = dxkv_accum or (dxkv == dxq) or not first_kv
-                first_kv = False
-            self.linear_bwd(src, da.data_ptr(), rows, d, r, o(full + '_linear_a.weight'), g(full + '_linear_a.weight'), None,
-                            dst, accum)
+        for names, src, rows in groups:
+            n, f0 = len(names), _FULL[names[0]]
+            wd = hv if names == 'v' else hk
+            a_all, d_all = A[tag + names + 'a'], dfull[names]
+            da_all = self.buf(tag + '_da' + names, (n, rows, r))
+            sa, sb, sbias = (self._pstride(pre, names, sfx) for sfx in ('_linear_a.weight', '_linear_b.weight', '_linear_b.bias'))
+            a_ptr, d_ptr, da_ptr = a_all.data_ptr(), d_all.data_ptr(), da_all.data_ptr()
+
+            def grads_b(n=n, f0=f0, rows=rows, a_ptr=a_ptr, d_ptr=d_ptr, sb=sb, names=names, wd=wd):
+                # dW_b[i] += d[i]^T a[i]  (one strided-batch call, outputs strided into G) ; db_b[i] += colsum(d[i])
+                self.gemm(1, 0, wd, r, rows, d_ptr, wd, a_ptr, r, g(f0 + '_linear_b.weight'), r, flags=ACCUM, batch=n,
+                          sA=(rows * wd, 0), sB=(rows * r, 0), sC=(sb, 0))
+                for i, nm in enumerate(names):
+                    self.colsum(d_ptr + 4 * i * rows * wd, rows, wd, g(_FULL[nm] + '_linear_b.bias'))
+            self.defer(grads_b)
+            # da[i] = d[i] . W_b[i]
+            self.gemm(0, 0, rows, r, wd, d_ptr, wd, o(f0 + '_linear_b.weight'), r, da_ptr, r, batch=n, sA=(rows * wd, 0),
+                      sB=(sb, 0), sC=(rows * r, 0))
+
+            def grads_a(n=n, f0=f0, rows=rows, da_ptr=da_ptr, src=src, sa=sa):
+                # dW_a[i] += da[i]^T x
+                self.gemm(1, 0, r, d, rows, da_ptr, r, src, d, g(f0 + '_linear_a.weight'), d, flags=ACCUM, batch=n,
+                          sA=(rows * r, 0), sC=(sa, 0))
+            self.defer(grads_a)
+            # dx += da[i] . W_a[i]: the items accumulate into ONE tensor, so they stay separate (ordered) launches
+            for i, nm in enumerate(names):
+                if nm == 'q':
+                    dst, accum = dxq, True
+                else:
+                    dst, accum = dxkv, (dxkv_accum or (dxkv == dxq) or not first_kv)
+                    first_kv = False
+                self.gemm(0, 0, rows, d, r, da_ptr + 4 * i * rows * r, r, o(_FULL[nm] + '_linear_a.weight'), d, dst, d,
+                          flags=ACCUM if accum else 0)
         self.flush_side()
+
+    def _pstride(self, pre, names, suffix):
+        """Distance (floats) between consecutive projections' parameters `suffix` in the flat buffer (0 for a single one)."""
+        if len(names) == 1:
+            return 0
+        offs = [self.L.off(pre + _FULL[nm] + suffix) for nm in names]
+        return offs[1] - offs[0]
+
+    def _qkv_groups(self, pre, xq, Mq, xkv, Mk, hk, hv):
+        """[(names, input pointer, rows)]: projections that can share one strided-batch launch."""
+        def uniform(names):
+            for sfx in ('_linear_a.weight', '_linear_b.weight', '_linear_b.bias'):
+                offs = [self.L.off(pre + _FULL[nm] + sfx) for nm in names]
+                steps = {b - a for a, b in zip(offs, offs[1:])}
+                if len(steps) != 1 or min(steps) <= 0 or min(steps) % 4:
+                    return False
+            return hk == hv
+        if self.batch_qkv and xq == xkv and Mq == Mk and uniform('qkv'):
+            return [('qkv', xq, Mq)]
+        if self.batch_qkv and uniform('kv'):
+            return [('q', xq, Mq), ('kv', xkv, Mk)]
+        return [('q', xq, Mq), ('k', xkv, Mk), ('v', xkv, Mk)]
 
     def ffn_fwd(self, tag, P, pre, x, rows, T, keep):
         hp, L = self.hp, self.L

@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol(built):
 def test_argument_validation_without_gpu(built):
     L = built._lib.lib()
     # bad arguments are rejected before any launch (no device needed)
-    assert L.mtl_gemm_f32(None, 0, 1, 0, 4, 4, 1.0, None, 4, None, 4, None, 4, None, None, 0, 0, 1, 1, 0, 0, 0, 0, 0, 0, None, 0) == -22
+    assert L.mtl_gemm_f32(None, 0, 1, 0, 4, 4, 1.0, None, 4, None, 4, None, 4, None, None, 0, 0, 1, 1, 0, 0, 0, 0, 0, 0, 0, None, 0) == -22
     assert L.mtl_adam_step(None, None, None, None, None, 1, 1e-3, 0.9, 0.999, 1e-8, 16) == -22
     assert L.mtl_conv3x3_wgrad_workspace(8, 1000, 161, 64, 64, 1) > 0
     assert L.mtl_layernorm_bwd_workspace(2000, 512) > 0

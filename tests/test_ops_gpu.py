@@ -42,11 +42,11 @@ def test_gemm_transposes(L, ta, tb, M, N, K):
     dA, dB, dbias = dev(A), dev(B), dev(bias)
     C = dev(C0.clone())
     assert L.mtl_gemm_f32(st(), ta, tb, M, N, K, 1.0, dA.data_ptr(), A.shape[1], dB.data_ptr(), B.shape[1], C.data_ptr(), N,
-                          None, None, 0, 0, 1, 1, 0, 0, 0, 0, 0, 0, None, 0) == 0
+                          None, None, 0, 0, 1, 1, 0, 0, 0, 0, 0, 0, 0, None, 0) == 0
     assert rel(C, ref) < 2e-6
     C = dev(C0.clone())           # bias + relu + accumulate
     assert L.mtl_gemm_f32(st(), ta, tb, M, N, K, 0.5, dA.data_ptr(), A.shape[1], dB.data_ptr(), B.shape[1], C.data_ptr(), N,
-                          dbias.data_ptr(), None, 0, 3, 1, 1, 0, 0, 0, 0, 0, 0, None, 0) == 0
+                          dbias.data_ptr(), None, 0, 3, 1, 1, 0, 0, 0, 0, 0, 0, 0, None, 0) == 0
     assert rel(C, torch.relu(0.5 * ref + bias) + C0) < 2e-6
 
 
@@ -65,7 +65,7 @@ def test_gemm_split_k_deterministic(L, ta, tb):
     for _ in range(2):
         C = dev(C0.clone())
         assert L.mtl_gemm_f32(st(), ta, tb, M, N, K, 1.0, dA.data_ptr(), A.shape[1], dB.data_ptr(), B.shape[1], C.data_ptr(), N,
-                              dbias.data_ptr(), dgate.data_ptr(), N, 3, 1, 1, 0, 0, 0, 0, 0, 0, ws.data_ptr(), ws.numel() * 4) == 0
+                              dbias.data_ptr(), dgate.data_ptr(), N, 3, 1, 1, 0, 0, 0, 0, 0, 0, 0, ws.data_ptr(), ws.numel() * 4) == 0
         outs.append(C.cpu())
     assert rel(outs[0], ref) < 3e-6
     assert torch.equal(outs[0], outs[1])
@@ -80,7 +80,7 @@ def test_gemm_gate_and_batched_heads(L):
     S = torch.full((Bn, H, Tq, ld), float('nan')).cuda()
     dq, dk_ = dev(q), dev(k)
     assert L.mtl_gemm_f32(st(), 0, 1, Tq, Tk, dk, 1.0, dq.data_ptr(), H * dk, dk_.data_ptr(), H * dk, S.data_ptr(), ld, None, None,
-                          0, 0, Bn * H, H, Tq * H * dk, dk, Tk * H * dk, dk, H * Tq * ld, Tq * ld, None, 0) == 0
+                          0, 0, Bn * H, H, Tq * H * dk, dk, Tk * H * dk, dk, H * Tq * ld, Tq * ld, 0, None, 0) == 0
     ref = torch.einsum('bqhd,bkhd->bhqk', q.view(Bn, Tq, H, dk), k.view(Bn, Tk, H, dk))
     assert rel(S[..., :Tk], ref) < 2e-6
     M, N, K = 300, 200, 96
@@ -88,8 +88,41 @@ def test_gemm_gate_and_batched_heads(L):
     C = torch.empty(M, N).cuda()
     dA, dB, dg = dev(A), dev(Bm), dev(gate)
     assert L.mtl_gemm_f32(st(), 0, 0, M, N, K, 1.0, dA.data_ptr(), K, dB.data_ptr(), N, C.data_ptr(), N, None, dg.data_ptr(), N, 0,
-                          1, 1, 0, 0, 0, 0, 0, 0, None, 0) == 0
+                          1, 1, 0, 0, 0, 0, 0, 0, 0, None, 0) == 0
     assert rel(C, (A @ Bm) * (gate > 0)) < 2e-6
+
+
+@pytest.mark.parametrize('M,N,K,ta,tb', [(333, 100, 512, 0, 1), (512, 100, 700, 1, 0), (100, 512, 1999, 1, 0), (2000, 512, 100, 0, 1)])
+def test_gemm_strided_parameter_batch(L, M, N, K, ta, tb):
+    """three products in one call (the Q/K/V projections: operands at a constant stride inside one flat buffer, per-item
+    bias, accumulate into strided outputs), with and without split-K; bitwise repeatable and equal to three separate calls"""
+    g = torch.Generator().manual_seed(M + N + K)
+    pad = 52                                              # other parameters sit between the batched ones
+    sa, sb = (K * M if ta else M * K) + pad, (N * K if tb else K * N) + pad
+    A, Bm = torch.randn(3 * sa, generator=g), torch.randn(3 * sb, generator=g)
+    bias, C0 = torch.randn(3 * (N + 12), generator=g), torch.randn(3 * (M * N + pad), generator=g)
+    dA, dB, dbias = dev(A), dev(Bm), dev(bias)
+    ws = torch.empty(8 << 20).cuda()
+    lda, ldb = (M if ta else K), (K if tb else N)
+    outs = []
+    for _ in range(2):
+        C = dev(C0.clone())
+        assert L.mtl_gemm_f32(st(), ta, tb, M, N, K, 1.0, dA.data_ptr(), lda, dB.data_ptr(), ldb, C.data_ptr(), N, dbias.data_ptr(), None,
+                              0, 2, 3, 1, sa, 0, sb, 0, M * N + pad, 0, N + 12, ws.data_ptr(), ws.numel() * 4) == 0
+        outs.append(C.cpu())
+    assert torch.equal(outs[0], outs[1])
+    ref, single = C0.clone(), dev(C0.clone())
+    for i in range(3):
+        a = A[i * sa:i * sa + M * K].view((K, M) if ta else (M, K))
+        b = Bm[i * sb:i * sb + N * K].view((N, K) if tb else (K, N))
+        o = i * (M * N + pad)
+        ref[o:o + M * N] += ((a.t() if ta else a) @ (b.t() if tb else b) + bias[i * (N + 12):i * (N + 12) + N]).reshape(-1)
+        assert L.mtl_gemm_f32(st(), ta, tb, M, N, K, 1.0, dA.data_ptr() + 4 * i * sa, lda, dB.data_ptr() + 4 * i * sb, ldb,
+                              single.data_ptr() + 4 * o, N, dbias.data_ptr() + 4 * i * (N + 12), None, 0, 2, 1, 1, 0, 0, 0, 0, 0, 0, 0,
+                              None, 0) == 0
+    assert rel(outs[0], ref) < 3e-6
+    assert rel(outs[0], single.cpu()) < 2e-6            # (split-K changes the summation order, not the value class)
+    assert torch.equal(outs[0][M * N:M * N + pad], C0[M * N:M * N + pad])       # the gaps are untouched
 
 
 def nhwc(t):   # reference (B,C,F,T) -> ours (B,T,F,C)

@@ -65,5 +65,5 @@ conv_case('conv7', T // 2, F // 2, 128, 128, True)
 for (M, N, K, ta, tb) in ((2000, 512, 5120, 0, 1), (2000, 5120, 512, 0, 0), (512, 5120, 2000, 1, 0), (4096, 4096, 4096, 0, 1), (808, 3765, 512, 0, 1)):
     A = torch.randn((K, M) if ta else (M, K), device=dev); Bm = torch.randn((N, K) if tb else (K, N), device=dev); C = torch.empty(M, N, device=dev)
     ws = torch.empty(8 << 20, device=dev)
-    t = timeit(lambda: L.mtl_gemm_f32(st(), ta, tb, M, N, K, 1.0, A.data_ptr(), A.shape[1], Bm.data_ptr(), Bm.shape[1], C.data_ptr(), N, None, None, 0, 0, 1, 1, 0, 0, 0, 0, 0, 0, ws.data_ptr(), ws.numel() * 4))
+    t = timeit(lambda: L.mtl_gemm_f32(st(), ta, tb, M, N, K, 1.0, A.data_ptr(), A.shape[1], Bm.data_ptr(), Bm.shape[1], C.data_ptr(), N, None, None, 0, 0, 1, 1, 0, 0, 0, 0, 0, 0, 0, ws.data_ptr(), ws.numel() * 4))
     print('gemm %dx%dx%d ta%d tb%d  %.3f ms %6.1f TF' % (M, N, K, ta, tb, t, 2.0 * M * N * K / t / 1e9))
