@@ -718,6 +718,11 @@ inline int device_cu_count() {
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
         n = 256;
+    // experiment (MTL_X3_CUS): persistent convolution grids that leave some CUs to the other task lane's small kernels
+    if (const char* e = getenv("MTL_X3_CUS")) {
+        const int lim = atoi(e);
+        if (lim >= 8 && lim < n) n = lim / 8 * 8;
+    }
     return n;
 }
 
@@ -1010,11 +1015,14 @@ int launch_conv_x3h(ConvX3P p, int Te, int Fe, hipStream_t s) {
 template <bool UNPOOL, int EPI>
 int dispatch_conv_x3(ConvX3P& p, int Te, int Fe, hipStream_t s) {
     if (p.g.Cin % 64 || p.g.Cout % 64) return MTL_EINVAL;     // C_in % 64: even number of K-tiles (producer loop is unrolled by 2)
+    // 8 x 16 tiles (G = 1: 79 KiB of LDS at BN = 64, two workgroups per CU) measured faster only on the 64 -> 64 layer
+    // (conv2 fwd 0.52 -> 0.50 ms, dgrad 0.61 -> 0.59); every 128-wide shape and conv5-dgrad is faster with 16 x 16 tiles.
     if (p.g.Cout % 128 == 0) {
         p.ntile = p.g.Cout / 128;
         return launch_conv_x3h<128, 2, UNPOOL, EPI>(p, Te, Fe, s);
     }
     p.ntile = p.g.Cout / 64;
+    if (p.g.Cin == 64) return launch_conv_x3h<64, 1, UNPOOL, EPI>(p, Te, Fe, s);
     return launch_conv_x3h<64, 2, UNPOOL, EPI>(p, Te, Fe, s);
 }
 
@@ -1374,10 +1382,10 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_x3_kernel(WgradX3P p) {
     const int co = cob + qj * 32 + l31;
     constexpr int RING = 4, NB = UNPOOL ? 4 : 8;
     float bv[RING][NB];
-    uint8_t ba[RING][NB];
+    unsigned ba[RING];                                         // pooled dy: the four arg-max codes of a step, one byte each
     unsigned bok[RING];
     const int nsteps = my_tiles * 8;
-    auto fetch_b = [&](int gs, float (&v)[NB], uint8_t (&a)[NB], unsigned& okm) {
+    auto fetch_b = [&](int gs, float (&v)[NB], unsigned& a, unsigned& okm) {
         const int j = gs >> 3, s = gs & 7;
         int b, t0, f0;
         tile_of(min(j, my_tiles - 1), b, t0, f0);
@@ -1403,19 +1411,33 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_x3_kernel(WgradX3P p) {
                 }
             }
         } else {
-            const int tp = min(t >> 1, p.Tp - 1);
+            const int tp = min(t >> 1, p.Tp - 1), fp0 = fb >> 1;
+            const bool rowok = t < p.Ty && j < my_tiles;
+            a = 0;
+            if (fp0 + 4 <= p.Fp) {                             // one base + immediate offsets (see the dense form above)
+                const long o = (((long)b * p.Tp + tp) * p.Fp + fp0) * Cout + co;
+                const float* rowp = p.dy + o;
+                const uint8_t* rowa = p.am + o;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int fp = (fb >> 1) + k;
-                const long o = (((long)b * p.Tp + tp) * p.Fp + min(fp, p.Fp - 1)) * Cout + co;
-                v[k] = p.dy[o];
-                a[k] = p.am[o];
-                okm |= ((t < p.Ty && 2 * fp < p.Fy && j < my_tiles) ? 1u : 0u) << k;
+                for (int k = 0; k < 4; ++k) {
+                    v[k] = rowp[(long)k * Cout];
+                    a |= (unsigned)rowa[(long)k * Cout] << (8 * k);
+                }
+                okm = rowok ? 0xfu : 0u;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int fp = fp0 + k;
+                    const long o = (((long)b * p.Tp + tp) * p.Fp + min(fp, p.Fp - 1)) * Cout + co;
+                    v[k] = p.dy[o];
+                    a |= (unsigned)p.am[o] << (8 * k);
+                    okm |= ((rowok && fp < p.Fp) ? 1u : 0u) << k;
+                }
             }
             okm |= (unsigned)(t & 1) << 8;
         }
     };
-    auto make_b = [&](const float (&v)[NB], const uint8_t (&a)[NB], unsigned okm, bf16x8 (&b3)[3]) {
+    auto make_b = [&](const float (&v)[NB], unsigned a, unsigned okm, bf16x8 (&b3)[3]) {
         __bf16 hh[8], mm[8], ll[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -1424,7 +1446,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_x3_kernel(WgradX3P p) {
                 val = ((okm >> k) & 1u) ? v[k] : 0.f;
             } else {
                 const unsigned sub = ((unsigned)(k & 1) << 1) | (okm >> 8);
-                val = (((okm >> (k >> 1)) & 1u) && a[k >> 1] == sub) ? v[k >> 1] : 0.f;
+                val = (((okm >> (k >> 1)) & 1u) && ((a >> (8 * (k >> 1))) & 0xffu) == sub) ? v[k >> 1] : 0.f;
             }
             split3(val, hh[k], mm[k], ll[k]);
         }
