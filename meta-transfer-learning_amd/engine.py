@@ -53,12 +53,14 @@ class Hyper:
         self.__dict__.update(kw)
 
 
-def decoder_io(padded_target, pad_id=PAD_ID, sos_id=SOS_ID, eos_id=EOS_ID):
-    """modules/decoder.py:55-69 on the host: seq_in = [SOS, y..] padded with EOS; seq_out = [y.., EOS] padded with PAD."""
+def decoder_io(padded_target, pad_id=PAD_ID, sos_id=SOS_ID, eos_id=EOS_ID, width=None):
+    """modules/decoder.py:55-69 on the host: seq_in = [SOS, y..] padded with EOS; seq_out = [y.., EOS] padded with PAD.
+    width: at least this many decoder positions (a slice of a batch keeps the whole batch's width, so that the labels
+    predicted at padded positions -- which the reference's CER strings include -- are the same)."""
     tgt = padded_target.detach().to('cpu', torch.int64)
     B = tgt.shape[0]
     lens = (tgt != pad_id).sum(1)
-    width = int(lens.max()) + 1
+    width = max(int(lens.max()) + 1, int(width or 0))
     seq_in = torch.full((B, width), eos_id, dtype=torch.int64)
     seq_out = torch.full((B, width), pad_id, dtype=torch.int64)
     for i in range(B):
@@ -416,13 +418,13 @@ class PassEngine:
         self.flush_side()
 
     # ---------------------------------------------------------------- the pass
-    def prepare(self, lengths, target, B, T, slot=0):
+    def prepare(self, lengths, target, B, T, slot=0, norm_count=None, width=None):
         """Host-side integer prep of one batch (modules/decoder.py:55-69 target shifting; every mask is derived inside the
         kernels from these few integers) + asynchronous H2D into STATIC per-slot buffers.  Kept separate from the kernels so
         a captured hipGraph of the pass can be replayed for any batch of the same shape."""
         hp = self.hp
         T4 = (T // 2) // 2
-        seq_in, seq_out = decoder_io(target)
+        seq_in, seq_out = decoder_io(target, width=width)
         Td = seq_in.shape[1]
         if T4 > hp.src_max_len or Td > hp.tgt_max_len:
             raise ValueError('sequence longer than the positional tables')
@@ -443,6 +445,8 @@ class PassEngine:
         nxt = torch.full_like(flat_in, -1, dtype=torch.int32)
         nxt[order[:-1]] = torch.where(same_as_prev[1:], order[1:], torch.full_like(order[1:], -1)).to(torch.int32)
         n_nonpad = int((seq_out != PAD_ID).sum())
+        if norm_count is not None:        # this is a slice of a larger batch: normalise the loss by the WHOLE batch's token count
+            n_nonpad = int(norm_count)
         meta_i32 = torch.cat([
             torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).view(torch.int32),    # dropout seed of this pass (torch CPU RNG), 8-byte aligned
             torch.tensor([1.0 / n_nonpad], dtype=torch.float32).view(torch.int32),    # 1/n_nonpad (fp32 bits)

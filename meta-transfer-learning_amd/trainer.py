@@ -20,6 +20,7 @@ from collections import deque
 import torch
 
 from . import _lib, dist as mdist
+from .engine import PAD_ID, decoder_io
 from .functions import post_process, save_meta_model
 from .metrics import calculate_cer
 
@@ -141,6 +142,9 @@ class TransientTrainer():
         # hipGraph replay of the task body is validated but opt-in: at 2 task lanes the loop is GPU-throughput-bound and replay
         # measured equal (8 tasks) or slower (3 tasks, dropout) than eager launches on ROCm 7.2
         self.use_graphs = os.environ.get('MTL_GRAPHS', '0') == '1'
+        # a rank with a single task can split its batch over the two lanes (_single_task_split; exact, tested) -- measured no
+        # faster than the unsplit task (18.4 vs 18.7 ms per 1-task step, slower with dropout), so it is opt-in
+        self.split_single_task = os.environ.get('MTL_SPLIT_TASK', '0') == '1'
         self._graphs = {}
 
     # ------------------------------------------------------------------ drop-in single-batch API
@@ -175,6 +179,11 @@ class TransientTrainer():
         dev = model.flat_parameters.device
         theta0 = model.flat_parameters
         smoothing = float(getattr(args, 'label_smoothing', 0.0) or 0.0)
+        use_graphs = self.use_graphs and not any(e.prof is not None for e in model.engines)
+        if (len(task_batches) == 1 and model.n_lanes >= 2 and self.split_single_task and not use_graphs
+                and task_batches[0][0].shape[0] >= 2 and val_batch[0].shape[0] >= 2
+                and not any(e.prof is not None for e in model.engines)):
+            return self._single_task_split(model, task_batches[0], val_batch, n_tasks, inner, args)
         n_lanes = min(model.n_lanes, max(len(task_batches), 1))
         bufs = self._lane_buffers(model, n_lanes)
         main = torch.cuda.current_stream(dev)
@@ -182,7 +191,6 @@ class TransientTrainer():
         ready = torch.cuda.Event()
         ready.record(main)
         reads = [None] * len(task_batches)
-        use_graphs = self.use_graphs and not any(e.prof is not None for e in model.engines)
         streams = [model.lane_streams[lane] if (n_lanes > 1 or use_graphs) else main for lane in range(n_lanes)]
         for lane in range(n_lanes):
             with torch.cuda.stream(streams[lane]):
@@ -228,6 +236,91 @@ class TransientTrainer():
             for lane in range(1, n_lanes):
                 model._axpy(Gm, bufs[lane][2], 1.0)
         return reads
+
+    def _single_task_split(self, model, task, val_batch, n_tasks, inner, args):
+        """A rank that holds ONE task (8 tasks on 8 GPUs) would leave the second lane idle, and the task's own chain
+        (training pass -> theta' -> validation pass) is sequential.  No op of the network couples samples except the loss
+        normaliser, so each pass is split by samples over the two lanes (same 1/n_tokens of the WHOLE batch in both halves):
+        g = g_a + g_b before the clip / inner step, G = G_a + G_b at the end.  Equal to the unsplit step up to fp32 summation
+        order, deterministic run to run."""
+        dev = model.flat_parameters.device
+        theta0 = model.flat_parameters
+        smoothing = float(getattr(args, 'label_smoothing', 0.0) or 0.0)
+        bufs = self._lane_buffers(model, 2)
+        main = torch.cuda.current_stream(dev)
+        streams = [model.lane_streams[0], model.lane_streams[1]]
+        tx, tsz, _tp, ty, _tl = task
+        vx, vsz, _vp, vy, _vl = val_batch
+        tx = tx.to(dev, non_blocking=True)
+        vx = vx.to(dev, non_blocking=True)
+        ready = torch.cuda.Event()
+        ready.record(main)
+
+        def halves(x, sz, y):
+            h = x.shape[0] // 2
+            seq_out = decoder_io(y)[1]
+            total, width = int((seq_out != PAD_ID).sum()), seq_out.shape[1]  # non-pad targets / decoder width of the WHOLE batch
+            return [(x[sl], sz[sl], y[sl], total, width) for sl in (slice(0, h), slice(h, x.shape[0]))]
+        tr, va = halves(tx, tsz, ty), halves(vx, vsz, vy)
+        metas, slots = [], []
+        for lane in range(2):
+            eng = model.engines[lane]
+            with torch.cuda.stream(streams[lane]):
+                streams[lane].wait_event(ready)
+                bufs[lane][2].zero_()
+                m_tr = eng.prepare(tr[lane][1], tr[lane][2], tr[lane][0].shape[0], tx.shape[3], slot=0, norm_count=tr[lane][3],
+                                   width=tr[lane][4])
+                m_va = eng.prepare(va[lane][1], va[lane][2], va[lane][0].shape[0], vx.shape[3], slot=1, norm_count=va[lane][3],
+                                   width=va[lane][4])
+                metas.append((m_tr, m_va))
+                slots.append(self._slots(model, lane, m_tr, m_va))
+        # ---- training pass, one half per lane
+        for lane in range(2):
+            eng, (g, _t1, _G) = model.engines[lane], bufs[lane]
+            with torch.cuda.stream(streams[lane]):
+                g.zero_()
+                out = eng.forward_device(theta0, tr[lane][0], metas[lane][0], smoothing)
+                slots[lane]['hyp_tr'].copy_(out['hyp'])
+                slots[lane]['loss_tr'].copy_(out['loss'])
+                eng.backward(g, 1.0)
+        # ---- join: g = g_a + g_b on lane 0, clip, theta'; lane 1 restarts its accumulator for the validation half
+        ev = torch.cuda.Event()
+        ev.record(streams[1])
+        g0, theta1, _ = bufs[0]
+        with torch.cuda.stream(streams[0]):
+            streams[0].wait_event(ev)
+            model._axpy(g0, bufs[1][0], 1.0)
+            if args.clip:
+                clip_flat_grad_(model, g0, args.max_norm, lane=0)
+            inner.theta_prime_from(theta0, g0, out=theta1)
+            ev2 = torch.cuda.Event()
+            ev2.record(streams[0])
+        with torch.cuda.stream(streams[1]):
+            streams[1].wait_event(ev2)
+            bufs[1][0].zero_()
+        # ---- validation pass at theta', one half per lane; Q1: the validation gradient accumulates onto g
+        for lane in range(2):
+            eng, (g, _t1, G) = model.engines[lane], bufs[lane]
+            with torch.cuda.stream(streams[lane]):
+                out = eng.forward_device(theta1, va[lane][0], metas[lane][1], smoothing)
+                slots[lane]['hyp_va'].copy_(out['hyp'])
+                slots[lane]['loss_va'].copy_(out['loss'])
+                eng.backward(g, 1.0 / n_tasks)
+                model._axpy(G, g, 1.0)
+        for lane in range(2):
+            done = torch.cuda.Event()
+            done.record(streams[lane])
+            main.wait_event(done)
+        Gm = model._G
+        Gm.copy_(bufs[0][2])
+        model._axpy(Gm, bufs[1][2], 1.0)
+        reads = []
+        for part, key_h, key_l in ((0, 'hyp_tr', 'loss_tr'), (1, 'hyp_va', 'loss_va')):
+            gold = torch.cat([metas[0][part]['gold_host'], metas[1][part]['gold_host']])
+            hyp = torch.cat([slots[0][key_h], slots[1][key_h]])
+            loss = slots[0][key_l] + slots[1][key_l]
+            reads.append(_Readback(dict(gold_host=gold, hyp=hyp, loss=loss), dev))
+        return [tuple(reads)]
 
     def _task_body(self, model, lane, bufs, theta0, x_tr, m_tr, x_va, m_va, n_tasks, inner, args, smoothing, slots):
         """Kernels of ONE task on the current stream (eager, or recorded into a hipGraph): train pass at theta0, fused inner

@@ -411,6 +411,37 @@ def test_hipgraph_replay_is_bitwise_equal_to_eager():
     assert torch.equal(res[False][0], res[True][0]) and torch.equal(res[False][1], res[True][1])
 
 
+@pytest.mark.parametrize('B,variable', [(4, False), (5, True)])
+def test_single_task_split_over_lanes_equals_unsplit(B, variable):
+    """a rank that holds ONE task splits each pass by samples over the two lanes (trainer._single_task_split: what 8 tasks on 8
+    GPUs runs): same losses, labels and meta-gradient as the unsplit step up to fp32 summation order; bitwise repeatable;
+    with gradient clipping on (the clip acts on the joined gradient)"""
+    z, cfg, spec = gu.load('F0')
+    mtl_amd, args, vocab, model = make(cfg, spec)
+    args.clip, args.max_norm = True, 0.5
+    model = model.cuda()
+    as5 = lambda b: (b[0].cuda(), b[1], None, b[2], None)
+    task = [as5(mtl_amd.synth_batch(31, B, 64, 8, cfg['vocab_size'], variable=variable))]
+    val = as5(mtl_amd.synth_batch(32, B, 64, 8, cfg['vocab_size'], variable=variable))
+    inner = mtl_amd.FlatSGD(model, spec['lr'])
+    model.zero_copy_grad()
+    res = {}
+    for split in (False, True, True):
+        tr = mtl_amd.TransientTrainer()
+        tr.split_single_task = split
+        reads = tr.meta_iteration(model, vocab, task, val, 3, inner, None, args)
+        torch.cuda.synchronize()
+        res.setdefault(split, []).append((model._G.clone(), [(r.loss.clone(), r.hyp.clone(), r.gold_host.clone()) for r in reads[0]]))
+    (G0, r0), (G1, r1), (G2, r2) = res[False][0], res[True][0], res[True][1]
+    assert torch.equal(G1, G2)                                       # deterministic
+    for (l0, h0, g0), (l1, h1, g1) in zip(r0, r1):
+        assert torch.equal(g0, g1) and torch.equal(h0, h1)          # labels: bit-exact, in batch order
+        assert abs(float(l0) - float(l1)) <= 2e-6 * abs(float(l0))
+    rel = float((G1 - G0).norm() / G0.norm())
+    print('split vs unsplit: global rel %.2e' % rel)
+    assert rel < 1e-4
+
+
 @pytest.mark.parametrize('B,T,L,lens,tlens', [
     (1, 17, 1, [17], [1]),                       # single utterance, T' = 4, one label
     (3, 50, 5, [50, 13, 4], [5, 2, 1]),          # T not a multiple of 4/8; a row shorter than T/4; ragged targets
