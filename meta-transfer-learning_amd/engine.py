@@ -76,6 +76,122 @@ def decoder_io(padded_target, pad_id=PAD_ID, sos_id=SOS_ID, eos_id=EOS_ID, width
 _FULL = {'q': 'query', 'k': 'key', 'v': 'value'}
 
 
+class _DecodeSession:
+    """See PassEngine.decode_session."""
+
+    def __init__(self, eng, theta, mem, B, T4, S, shared_memory):
+        self.eng, self.B, self.T4, self.S = eng, B, T4, S
+        hp = eng.hp
+        d, r, h, dk, dv, V = hp.d, hp.r, hp.h, hp.dk, hp.dv, hp.V
+        hk, hv = h * dk, h * dv
+        if S > eng.pe_dec.shape[0] + 1:
+            raise ValueError('tgt_max_len too small for %d decoding positions' % S)
+        self.P = theta.data_ptr()
+        buf = eng.buf
+        self.x = buf('g.x', (B, d))
+        self.kc = [buf('g.kc%d' % i, (B, S, hk)) for i in range(hp.n_dec)]
+        self.vc = [buf('g.vc%d' % i, (B, S, hv)) for i in range(hp.n_dec)]
+        Bm = 1 if shared_memory else B
+        self.cross_stride = 0 if shared_memory else T4
+        self.ck = [buf('g.ck%d' % i, (Bm * T4, hk)) for i in range(hp.n_dec)]
+        self.cv = [buf('g.cv%d' % i, (Bm * T4, hv)) for i in range(hp.n_dec)]
+        self.ta, self.tq = buf('g.ta', (max(Bm * T4, B), r)), buf('g.q', (B, hk))
+        self.to, self.tob = buf('g.o', (B, hv)), buf('g.ob', (B, d))
+        self.y1, self.y2, self.y3 = buf('g.y1', (B, d)), buf('g.y2', (B, d)), buf('g.y3', (B, d))
+        self.h1, self.h2 = buf('g.h1', (B, hp.inner)), buf('g.h2', (B, d))
+        self.xhat, self.rstd = buf('g.xhat', (B, d)), buf('g.rstd', (B,))
+        self.ldS = (max(S, T4) + 3) // 4 * 4
+        self.Sc = buf('g.S', (B, h, 1, self.ldS))
+        self.logits = buf('g.logits', (B, V))
+        self.junk = buf('g.junk', (3 * B + 4,))
+        self.zero_gold = buf('g.zero', (B,), torch.int64)
+        self.zero_gold.zero_()
+        self.cur = [buf('g.cur0', (B, d)), buf('g.cur1', (B, d))]
+        self.last = None
+        for i in range(hp.n_dec):                                   # cross-attention keys / values of the encoder output, once
+            pre = 'decoder.layers.%d.encoder_attn.' % i
+            self._lowrank(pre, 'key', mem, Bm * T4, self.ck[i].data_ptr())
+            self._lowrank(pre, 'value', mem, Bm * T4, self.cv[i].data_ptr(), width=hv)
+
+    def _lowrank(self, pre, name, src, rows, dst, ldc=None, width=None):
+        eng, hp = self.eng, self.eng.hp
+        hk, hv = hp.h * hp.dk, hp.h * hp.dv
+        width = hk if width is None else width
+        o = lambda n: self.P + 4 * eng.L.off(pre + n)
+        eng.linear_fwd(src, rows, hp.d if name != 'output' else hv, o(name + '_linear_a.weight'), None, self.ta.data_ptr(), hp.r)
+        eng.gemm(0, 1, rows, width, hp.r, self.ta.data_ptr(), hp.r, o(name + '_linear_b.weight'), hp.r, dst, ldc or width,
+                 bias=o(name + '_linear_b.bias'))
+
+    def _attend(self, q, kbuf, vbuf, kv_rows, kv_stride, out):
+        # one query row per (b, h): scores over kv_rows keys, softmax, weighted sum of the values
+        eng, hp, B = self.eng, self.eng.hp, self.B
+        h, dk, dv = hp.h, hp.dk, hp.dv
+        hk, hv, ldS = h * dk, h * dv, self.ldS
+        eng.gemm(0, 1, 1, kv_rows, dk, q, hk, kbuf, hk, self.Sc.data_ptr(), ldS, batch=B * h, H=h, sA=(hk, dk), sB=(kv_stride, dk),
+                 sC=(h * ldS, ldS))
+        check(eng.lib.mtl_softmax_mask_fwd(eng.stream, self.Sc.data_ptr(), None, 0, 1.0 / float(hp.temperature), B, h, 1, kv_rows,
+                                           ldS, None, 1.0, None), 'softmax')
+        eng.gemm(0, 0, 1, dv, kv_rows, self.Sc.data_ptr(), ldS, vbuf, hv, out, hv, batch=B * h, H=h, sA=(h * ldS, ldS),
+                 sB=(kv_stride, dv), sC=(hv, dv))
+
+    def step(self, t, tok_ptr):
+        """Feed the B tokens at device address tok_ptr as position t; leaves the logits of that position in self.logits."""
+        eng, hp, B, S, T4 = self.eng, self.eng.hp, self.B, self.S, self.T4
+        d, V = hp.d, hp.V
+        hk, hv = hp.h * hp.dk, hp.h * hp.dv
+        L, lib, P = eng.L, eng.lib, self.P
+        check(lib.mtl_embed_pe_fwd(eng.stream, tok_ptr, P + 4 * L.off('decoder.trg_embedding.weight'),
+                                   eng.pe_dec.data_ptr() + 4 * t * d, self.x.data_ptr(), B, 1, d, None, 1.0), 'embed')
+        cur = self.x
+        for i in range(hp.n_dec):
+            pre = 'decoder.layers.%d.' % i
+            o = lambda n: P + 4 * L.off(pre + n)
+            sa = pre + 'self_attn.'
+            self._lowrank(sa, 'query', cur.data_ptr(), B, self.tq.data_ptr())
+            self._lowrank(sa, 'key', cur.data_ptr(), B, self.kc[i].data_ptr() + 4 * t * hk, ldc=S * hk)      # row t of the cache
+            self._lowrank(sa, 'value', cur.data_ptr(), B, self.vc[i].data_ptr() + 4 * t * hv, ldc=S * hv, width=hv)
+            self._attend(self.tq.data_ptr(), self.kc[i].data_ptr(), self.vc[i].data_ptr(), t + 1, S * hk, self.to.data_ptr())
+            self._lowrank(sa, 'output', self.to.data_ptr(), B, self.tob.data_ptr(), width=d)
+            eng.ln_fwd(self.tob.data_ptr(), cur.data_ptr(), o('self_attn.layer_norm.weight'), o('self_attn.layer_norm.bias'), None, None,
+                       self.y1.data_ptr(), self.xhat.data_ptr(), self.rstd.data_ptr(), B, 1)
+            ca = pre + 'encoder_attn.'
+            self._lowrank(ca, 'query', self.y1.data_ptr(), B, self.tq.data_ptr())
+            self._attend(self.tq.data_ptr(), self.ck[i].data_ptr(), self.cv[i].data_ptr(), T4, self.cross_stride * hk, self.to.data_ptr())
+            self._lowrank(ca, 'output', self.to.data_ptr(), B, self.tob.data_ptr(), width=d)
+            eng.ln_fwd(self.tob.data_ptr(), self.y1.data_ptr(), o('encoder_attn.layer_norm.weight'), o('encoder_attn.layer_norm.bias'), None,
+                       None, self.y2.data_ptr(), self.xhat.data_ptr(), self.rstd.data_ptr(), B, 1)
+            eng.linear_fwd(self.y2.data_ptr(), B, d, o('pos_ffn.linear_1.weight'), o('pos_ffn.linear_1.bias'), self.h1.data_ptr(), hp.inner,
+                           relu=True)
+            eng.linear_fwd(self.h1.data_ptr(), B, hp.inner, o('pos_ffn.linear_2.weight'), o('pos_ffn.linear_2.bias'), self.h2.data_ptr(), d)
+            eng.ln_fwd(self.h2.data_ptr(), self.y2.data_ptr(), o('pos_ffn.layer_norm.weight'), o('pos_ffn.layer_norm.bias'), None, None,
+                       self.y3.data_ptr(), self.xhat.data_ptr(), self.rstd.data_ptr(), B, 1)
+            cur = self.cur[i & 1]
+            check(lib.mtl_copy_f32(eng.stream, cur.data_ptr(), self.y3.data_ptr(), B * d), 'copy')
+        eng.gemm(0, 1, B, V, d, cur.data_ptr(), d, P + 4 * L.off('decoder.output_linear.weight'), d, self.logits.data_ptr(), V)
+        return self.logits
+
+    def argmax_into(self, dst_ptr):
+        """arg-max of the current logits (lowest index on ties) written as B int64 at dst_ptr; log-sum-exp lands in junk[0:B]."""
+        eng, B, V = self.eng, self.B, self.eng.hp.V
+        check(eng.lib.mtl_ce_argmax_fwd(eng.stream, self.logits.data_ptr(), self.zero_gold.data_ptr(), B, V, V, PAD_ID, 0.0, 1, None,
+                                        self.junk.data_ptr(), dst_ptr, self.junk.data_ptr() + 4 * B, self.junk.data_ptr() + 8 * B),
+              'argmax')
+
+    def logits_and_lse(self):
+        """(B,V) logits and (B,) log-sum-exp of the current position on the host (one synchronising copy each)."""
+        hyp = self.eng.buf('g.hyp', (self.B,), torch.int64)
+        self.argmax_into(hyp.data_ptr())
+        return self.logits.cpu(), self.junk[:self.B].cpu()
+
+    def reorder(self, rows, t):
+        """caches[r, :t] <- caches[rows[r], :t] for every layer (beam search: row r continues hypothesis rows[r])."""
+        if list(rows) == list(range(self.B)):
+            return
+        idx = torch.tensor(rows, dtype=torch.int64, device=self.logits.device)
+        for c in self.kc + self.vc:
+            c[:, :t] = c.index_select(0, idx)[:, :t]
+
+
 class PassEngine:
     def __init__(self, layout, hp, device, pe_enc, pe_dec):
         self.pe_enc, self.pe_dec = pe_enc, pe_dec   # (max_len, d) fp32 device tables (non-trainable buffers)
@@ -579,90 +695,75 @@ class PassEngine:
         return dict(pred=pred, gold=ids[1], hyp=hyp, loss=loss, gold_host=meta['gold_host'], n_nonpad=n_nonpad)
 
     # ---------------------------------------------------------------- greedy decoding
+    def decode_session(self, theta, mem, B, T4, S, shared_memory=False):
+        """K/V-cached incremental decoder over `B` hypothesis rows and up to `S` positions (greedy and beam search share it).
+        mem: device pointer of the encoder output, (B, T4, d) -- or (1, T4, d) with shared_memory=True, when all rows are
+        hypotheses of ONE utterance (beam search) and address the same cross-attention keys / values with batch stride 0."""
+        return _DecodeSession(self, theta, mem, B, T4, S, shared_memory)
+
     def greedy_decode(self, theta, mem, B, T4, start_token, max_steps=300):
         """Decoder.greedy_search (modules/decoder.py:131-185) on the device: max_steps arg-max steps from `start_token`,
         no padding masks (the reference passes dec_enc_attn_mask=None and an all-ones non_pad_mask), only causality.
         The reference re-runs the whole decoder on the growing prefix at every step; here each layer keeps a K/V cache
         and only the new position is computed (same per-row arithmetic), and the chosen token is fed back through device
         memory, so the 300 steps run without a single host synchronisation.  Returns the (max_steps, B) int64 token ids."""
-        hp, L, lib = self.hp, self.L, self.lib
-        d, r, h, dk, dv, V = hp.d, hp.r, hp.h, hp.dk, hp.dv, hp.V
-        hk, hv = h * dk, h * dv
-        if max_steps + 1 > hp.tgt_max_len:
+        if max_steps + 1 > self.hp.tgt_max_len:
             raise ValueError('tgt_max_len too small for %d decoding steps' % max_steps)
-        P = theta.data_ptr()
-        S = max_steps + 1
-        ys = self.buf('g.ys', (S, B), torch.int64)
+        ses = self.decode_session(theta, mem, B, T4, max_steps + 1)
+        ys = self.buf('g.ys', (max_steps + 1, B), torch.int64)
         ys[0].fill_(int(start_token))
-        zero_gold = self.buf('g.zero', (B,), torch.int64)
-        zero_gold.zero_()
-        x = self.buf('g.x', (B, d))
-        kc = [self.buf('g.kc%d' % i, (B, S, hk)) for i in range(hp.n_dec)]
-        vc = [self.buf('g.vc%d' % i, (B, S, hv)) for i in range(hp.n_dec)]
-        ck = [self.buf('g.ck%d' % i, (B * T4, hk)) for i in range(hp.n_dec)]
-        cv = [self.buf('g.cv%d' % i, (B * T4, hv)) for i in range(hp.n_dec)]
-        ta, tq = self.buf('g.ta', (max(B * T4, B), r)), self.buf('g.q', (B, hk))
-        to, toa, tob = self.buf('g.o', (B, hv)), self.buf('g.oa', (B, r)), self.buf('g.ob', (B, d))
-        y1, y2, y3 = self.buf('g.y1', (B, d)), self.buf('g.y2', (B, d)), self.buf('g.y3', (B, d))
-        h1, h2 = self.buf('g.h1', (B, hp.inner)), self.buf('g.h2', (B, d))
-        xhat, rstd = self.buf('g.xhat', (B, d)), self.buf('g.rstd', (B,))
-        ldS = (max(S, T4) + 3) // 4 * 4
-        Sc = self.buf('g.S', (B, h, 1, ldS))
-        logits = self.buf('g.logits', (B, V))
-        junk = self.buf('g.junk', (3 * B + 4,))
-        scale = 1.0 / float(hp.temperature)
-
-        def lowrank(pre, name, src, rows, dst, ldc=None, width=hk):
-            o = lambda n: P + 4 * L.off(pre + n)
-            self.linear_fwd(src, rows, d if name != 'output' else hv, o(name + '_linear_a.weight'), None, ta.data_ptr(), r)
-            self.gemm(0, 1, rows, width, r, ta.data_ptr(), r, o(name + '_linear_b.weight'), r, dst, ldc or width,
-                      bias=o(name + '_linear_b.bias'))
-
-        def attend(q, kbuf, vbuf, kv_rows, kv_stride, out):
-            # one query row per (b, h): scores over kv_rows keys, softmax, weighted sum of the values
-            self.gemm(0, 1, 1, kv_rows, dk, q, hk, kbuf, hk, Sc.data_ptr(), ldS, batch=B * h, H=h, sA=(hk, dk), sB=(kv_stride, dk),
-                      sC=(h * ldS, ldS))
-            check(lib.mtl_softmax_mask_fwd(self.stream, Sc.data_ptr(), None, 0, scale, B, h, 1, kv_rows, ldS, None, 1.0, None), 'softmax')
-            self.gemm(0, 0, 1, dv, kv_rows, Sc.data_ptr(), ldS, vbuf, hv, out, hv, batch=B * h, H=h, sA=(h * ldS, ldS),
-                      sB=(kv_stride, dv), sC=(hv, dv))
-
-        for i in range(hp.n_dec):                                   # cross-attention keys / values of the encoder output, once
-            pre = 'decoder.layers.%d.encoder_attn.' % i
-            lowrank(pre, 'key', mem, B * T4, ck[i].data_ptr())
-            lowrank(pre, 'value', mem, B * T4, cv[i].data_ptr(), width=hv)
         for t in range(max_steps):
-            check(lib.mtl_embed_pe_fwd(self.stream, ys.data_ptr() + 8 * t * B, P + 4 * L.off('decoder.trg_embedding.weight'),
-                                       self.pe_dec.data_ptr() + 4 * t * d, x.data_ptr(), B, 1, d, None, 1.0), 'embed')
-            cur = x
-            for i in range(hp.n_dec):
-                pre = 'decoder.layers.%d.' % i
-                o = lambda n: P + 4 * L.off(pre + n)
-                sa = pre + 'self_attn.'
-                lowrank(sa, 'query', cur.data_ptr(), B, tq.data_ptr())
-                lowrank(sa, 'key', cur.data_ptr(), B, kc[i].data_ptr() + 4 * t * hk, ldc=S * hk)      # row t of the cache
-                lowrank(sa, 'value', cur.data_ptr(), B, vc[i].data_ptr() + 4 * t * hv, ldc=S * hv, width=hv)
-                attend(tq.data_ptr(), kc[i].data_ptr(), vc[i].data_ptr(), t + 1, S * hk, to.data_ptr())
-                lowrank(sa, 'output', to.data_ptr(), B, tob.data_ptr(), width=d)
-                self.ln_fwd(tob.data_ptr(), cur.data_ptr(), o('self_attn.layer_norm.weight'), o('self_attn.layer_norm.bias'), None, None,
-                            y1.data_ptr(), xhat.data_ptr(), rstd.data_ptr(), B, 1)
-                ca = pre + 'encoder_attn.'
-                lowrank(ca, 'query', y1.data_ptr(), B, tq.data_ptr())
-                attend(tq.data_ptr(), ck[i].data_ptr(), cv[i].data_ptr(), T4, T4 * hk, to.data_ptr())
-                lowrank(ca, 'output', to.data_ptr(), B, tob.data_ptr(), width=d)
-                self.ln_fwd(tob.data_ptr(), y1.data_ptr(), o('encoder_attn.layer_norm.weight'), o('encoder_attn.layer_norm.bias'), None,
-                            None, y2.data_ptr(), xhat.data_ptr(), rstd.data_ptr(), B, 1)
-                self.linear_fwd(y2.data_ptr(), B, d, o('pos_ffn.linear_1.weight'), o('pos_ffn.linear_1.bias'), h1.data_ptr(), hp.inner,
-                                relu=True)
-                self.linear_fwd(h1.data_ptr(), B, hp.inner, o('pos_ffn.linear_2.weight'), o('pos_ffn.linear_2.bias'), h2.data_ptr(), d)
-                self.ln_fwd(h2.data_ptr(), y2.data_ptr(), o('pos_ffn.layer_norm.weight'), o('pos_ffn.layer_norm.bias'), None, None,
-                            y3.data_ptr(), xhat.data_ptr(), rstd.data_ptr(), B, 1)
-                cur = self.buf('g.cur%d' % (i & 1), (B, d))
-                check(lib.mtl_copy_f32(self.stream, cur.data_ptr(), y3.data_ptr(), B * d), 'copy')
-            self.gemm(0, 1, B, V, d, cur.data_ptr(), d, P + 4 * L.off('decoder.output_linear.weight'), d, logits.data_ptr(), V)
-            check(lib.mtl_ce_argmax_fwd(self.stream, logits.data_ptr(), zero_gold.data_ptr(), B, V, V, PAD_ID, 0.0, 1, None,
-                                        junk.data_ptr(), ys.data_ptr() + 8 * (t + 1) * B, junk.data_ptr() + 4 * B,
-                                        junk.data_ptr() + 8 * B), 'argmax')
+            ses.step(t, ys.data_ptr() + 8 * t * B)
+            ses.argmax_into(ys.data_ptr() + 8 * (t + 1) * B)
         return ys[1:]
+
+    def beam_decode(self, theta, mem_row, T4, start_token, beam_width, nbest, tgt_max_len, num_words, eos_id=EOS_ID, c_weight=1.0):
+        """Decoder.beam_search (modules/decoder.py:187-291, no LM rescoring) for ONE utterance: the host keeps the reference's
+        hypothesis bookkeeping verbatim in behaviour (expansion order, stable sorts, cumulative truncation to the beam, EOS
+        forced at step T' - 1, final_score = score + sqrt(num_words) * c_weight, fp32 score arithmetic); the device runs one
+        K/V-cached decoder step for all live hypotheses per iteration (caches re-ordered by parent) and returns the last
+        position's logits and log-sum-exp.  num_words(yseq) -> int is the caller's word counter (it needs the vocabulary).
+        -> list of (yseq incl. start token and EOS, final_score) sorted best first, at most nbest."""
+        import numpy as np
+        W = int(beam_width)
+        steps = int(tgt_max_len)
+        if steps > self.pe_dec.shape[0] or W < 1:
+            raise ValueError('bad beam search arguments')
+        ses = self.decode_session(theta, mem_row, W, T4, steps, shared_memory=True)
+        toks = self.buf('b.tok', (W,), torch.int64)
+        hyps = [dict(score=np.float32(0.0), yseq=[int(start_token)], row=0)]
+        ended = []
+        for i in range(steps):
+            n = len(hyps)
+            rows = [h['row'] for h in hyps] + [0] * (W - n)
+            if i > 0:
+                ses.reorder(rows, i)                              # row r of the caches <- its parent's rows 0..i-1
+            toks.copy_(torch.tensor([h['yseq'][-1] for h in hyps] + [int(eos_id)] * (W - n), dtype=torch.int64))
+            ses.step(i, toks.data_ptr())
+            logits, lse = ses.logits_and_lse()
+            local = (logits[:n] - lse[:n].unsqueeze(1))           # F.log_softmax of the last position, fp32
+            kept = []
+            for r, h in enumerate(hyps):
+                best, ids = torch.topk(local[r], W)
+                for j in range(W):
+                    kept.append(dict(score=np.float32(h['score'] + np.float32(best[j].item())), yseq=h['yseq'] + [int(ids[j])], row=r))
+                kept = sorted(kept, key=lambda x: x['score'], reverse=True)[:W]
+            hyps = kept
+            if i == T4 - 1:
+                for h in hyps:
+                    h['yseq'] = h['yseq'] + [int(eos_id)]
+            live = []
+            for h in hyps:
+                if h['yseq'][-1] == eos_id:
+                    h['final_score'] = np.float32(h['score'] + np.float32(math.sqrt(num_words(h['yseq'])) * c_weight))
+                    ended.append(h)
+                else:
+                    live.append(h)
+            hyps = live
+            if not hyps:
+                break
+        out = sorted(ended, key=lambda x: x['final_score'], reverse=True)[:min(len(ended), int(nbest))]
+        return [(h['yseq'], float(h['final_score'])) for h in out]
 
     def backward(self, grad, scale=1.0, dpred=None):
         """Accumulate `scale` * dLoss/dtheta of the LAST forward into the flat buffer `grad` (+=).

@@ -340,23 +340,44 @@ class Transformer(nn.Module):
 
     def evaluate(self, padded_input, input_lengths, padded_target, args=None, beam_search=False, beam_width=0, beam_nbest=0, lm=None,
                  lm_rescoring=False, lm_weight=0.1, c_weight=1, start_token=-1, verbose=False, max_steps=300):
-        """models/asr/transformer.py:162-202 for the greedy branch: returns (None, strs_hyps, strs_gold).
-        The encoder + teacher-forced decoder pass supplies the gold strings exactly like the reference; hypotheses come from
-        PassEngine.greedy_decode (K/V-cached, device-resident token feedback).  Beam search / LM rescoring are not accelerated."""
-        if beam_search or lm_rescoring:
-            raise NotImplementedError('beam search / LM rescoring are outside the accelerated path; use greedy decoding')
+        """models/asr/transformer.py:162-202: returns (None, strs_hyps, strs_gold).
+        The encoder + teacher-forced decoder pass supplies the gold strings exactly like the reference.  Greedy hypotheses come
+        from PassEngine.greedy_decode (K/V-cached, device-resident token feedback); beam_search=True runs
+        PassEngine.beam_decode per utterance with args.beam_width / args.beam_nbest / args.tgt_max_len like the reference
+        (all n-best strings of all utterances, concatenated; falls back to greedy when the best hypothesis is empty).
+        LM rescoring is not on the accelerated path."""
+        if lm_rescoring:
+            raise NotImplementedError('LM rescoring is outside the accelerated path')
         eng = self._need_engine()
         was_training = self.training
         self.eval()
+        ids_nbest = None
         try:
             out = self.pass_forward(padded_input, input_lengths, padded_target)
             B, T = padded_input.shape[0], padded_input.shape[3]
             T4 = (T // 2) // 2
             mem = eng.arena['e%d.ff.y' % (eng.hp.n_enc - 1)] if eng.hp.n_enc else eng.arena['enc_in.y']
             start = self.vocab.SOS_ID if start_token < 0 else start_token      # the reference's callers pass vocab.SOS_ID
-            ids = eng.greedy_decode(self._theta, mem.data_ptr(), B, T4, start, max_steps).cpu()          # (steps, B)
+            strs_beam = None
+            if beam_search:
+                mem = mem.clone()                                              # the decode buffers live in the same arena
+                ids_nbest, strs_beam = [], []
+                for b in range(B):
+                    res = eng.beam_decode(self._theta, mem.data_ptr() + 4 * b * T4 * eng.hp.d, T4, start, args.beam_width,
+                                          args.beam_nbest, args.tgt_max_len, self._num_words, self.vocab.EOS_ID, c_weight)
+                    for yseq, _score in res:
+                        ids_nbest.append(yseq)
+                        strs_beam.append(self._post_process_hyp(yseq))
+                if len(strs_beam) == 0 or len(strs_beam[0].strip()) == 0:
+                    strs_beam = None                                           # ">>>>>>> switch to greedy" (:190-196)
+            if strs_beam is None:
+                ids = eng.greedy_decode(self._theta, mem.data_ptr(), B, T4, start, max_steps).cpu()          # (steps, B)
         finally:
             self.train(was_training)
+        if strs_beam is not None:
+            strs_gold = [''.join(self.vocab.id2label[int(t)] for t in row) for row in out['gold_host']]
+            self.last_beam_ids = ids_nbest
+            return None, strs_beam, strs_gold
         strs_gold = [''.join(self.vocab.id2label[int(t)] for t in row) for row in out['gold_host']]
         strs_hyps = []
         for b in range(ids.shape[1]):
@@ -368,3 +389,16 @@ class Transformer(nn.Module):
             strs_hyps.append(st)
         self.last_greedy_ids = ids
         return None, strs_hyps, strs_gold
+
+    def _num_words(self, yseq):
+        """word count of a finished hypothesis as modules/decoder.py:257-259 computes it (label string minus specials, split)"""
+        v = self.vocab
+        st = ''.join(v.id2label[int(c)] for c in yseq).replace(v.PAD_TOKEN, '').replace(v.SOS_TOKEN, '').replace(v.EOS_TOKEN, '')
+        return len(st.replace('  ', ' ').split())
+
+    def _post_process_hyp(self, yseq):
+        """modules/decoder.py:117-128"""
+        st = ''.join(self.vocab.id2label[int(x)] for x in yseq[1:])
+        for tok in self.vocab.special_token_list:
+            st = st.replace(tok, '')
+        return st.replace('\u2581', ' ')

@@ -9,6 +9,7 @@ synthetic batches and stores inputs + expected outputs as data fixtures.  Recipe
 """
 import argparse
 import hashlib
+import json
 import os
 import sys
 import types
@@ -270,15 +271,67 @@ def run_joint_fixture(torch):
     print('J0 written; losses', [round(f[2], 6) for f in fwd])
 
 
+def run_beam_fixture(torch):
+    """Decoder.beam_search / Transformer.evaluate(beam_search=True) of the reference on the F0 model whose
+    vocabulary projection is perturbed (seeded) so that hypotheses differ and some end with a natural EOS.  Stores the n-best
+    id sequences and strings of 3 utterances (beam 3, n-best 2).  (The reference's greedy search needs tgt_max_len > 300.)"""
+    from utils.data import Vocab
+    from utils.functions import init_transformer_model
+    sys.path.insert(0, ROOT)
+    from oracle.refimpl import synth_batch
+    cfg = FIXTURES['F0']['cfg']
+    vocab = Vocab()
+    for i in range(cfg['vocab_size'] - 4):
+        vocab.add_token(chr(0x4e00 + i))
+        vocab.add_label(chr(0x4e00 + i))
+    args = argparse.Namespace(
+        feat_extractor='vgg_cnn', sample_rate=16000, window_size=.02, feat='spectrogram', dim_input=161,
+        num_enc_layers=cfg['num_enc_layers'], num_dec_layers=cfg['num_dec_layers'], num_heads=cfg['num_heads'],
+        dim_model=cfg['dim_model'], dim_key=cfg['dim_key'], dim_value=cfg['dim_value'], dim_inner=cfg['dim_inner'],
+        dim_emb=cfg['dim_emb'], src_max_len=cfg['src_max_len'], tgt_max_len=cfg['tgt_max_len'], dropout=0.0,
+        emb_trg_sharing=False, label_smoothing=0.0, name='golden_B0', cuda=False, beam_width=3, beam_nbest=2)
+    torch.manual_seed(123456)
+    torch.set_num_threads(8)
+    model = init_transformer_model(args, vocab, is_factorized=False, r=cfg['r'])
+    g = torch.Generator().manual_seed(7)
+    W = model.decoder.output_linear.weight
+    W.data += 0.5 * torch.randn(W.shape, generator=g)
+    W.data[2] = 1.02 * W.data[47]                               # EOS row ~ a token that dominates late positions: natural terminations
+    model.eval()
+    x, lens, y = synth_batch(500, 3, 64, 8, cfg['vocab_size'], variable=True)
+    with torch.no_grad():
+        _, strs_beam, strs_gold = model.evaluate(x, lens, y, args, beam_search=True, start_token=vocab.SOS_ID)
+        f = model.conv(x)
+        sz = f.size()
+        enc, _ = model.encoder(f.view(sz[0], sz[1] * sz[2], sz[3]).transpose(1, 2).contiguous(), lens)
+        ids, strs = model.decoder.beam_search(enc, args, beam_width=3, nbest=2, start_token=vocab.SOS_ID)
+    width = max(len(r) for r in ids)
+    arr = np.full((len(ids), width), -1, dtype=np.int64)
+    for i, r in enumerate(ids):
+        arr[i, :len(r)] = r
+    enc_str = lambda lst: np.frombuffer('\n'.join(lst).encode('utf-8'), dtype=np.uint8)
+    store = dict(beam_ids=arr, beam_strs=enc_str(strs), eval_beam_strs=enc_str(strs_beam), gold_strs=enc_str(strs_gold),
+                 spec=np.frombuffer(json.dumps(dict(seed=500, k=3, T=64, L=8, beam_width=3,
+                                                                                         nbest=2, noise_seed=7, noise=0.5,
+                                                                                         eos_from=47, eos_gain=1.02)).encode(), dtype=np.uint8))
+    np.savez_compressed(os.path.join(ROOT, 'tests', 'golden', 'B0.npz'), **store)
+    print('B0: %d hypotheses, lengths %s, natural EOS in %d' % (len(ids), [len(r) for r in ids],
+                                                                  sum(len(r) < 18 for r in ids)))
+    for st in strs:
+        print('   ', repr(st))
+
+
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--ns', action='store_true')
     ap.add_argument('--only', default='')
     a = ap.parse_args()
     torch = bootstrap_reference()
-    todo = [a.only] if a.only else (['F0', 'F1', 'J0'] + (['NS'] if a.ns else []))
+    todo = [a.only] if a.only else (['F0', 'F1', 'J0', 'B0'] + (['NS'] if a.ns else []))
     for name in todo:
-        if name == 'J0':
+        if name == 'B0':
+            run_beam_fixture(torch)
+        elif name == 'J0':
             run_joint_fixture(torch)
         else:
             run_fixture(name, FIXTURES[name], torch)

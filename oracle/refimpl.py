@@ -255,6 +255,59 @@ def greedy_search(model, padded_input, input_lengths, start_token, steps):
     return ys[:, 1:]
 
 
+def beam_search(model, padded_input, input_lengths, start_token, beam_width, nbest, tgt_max_len, num_words, c_weight=1.0):
+    """Decoder.beam_search (modules/decoder.py:187-291, lm_rescoring=False) restated, utterance by utterance: every live
+    hypothesis re-runs the WHOLE decoder on its prefix (no padding masks), log_softmax of the last position, top beam_width
+    expansions, cumulative stable sort + truncation to the beam inside the hypothesis loop, EOS forced at step T' - 1,
+    final_score = score + sqrt(num_words(yseq)) * c_weight, n-best by final_score.  -> per utterance a list of
+    (yseq incl. start token and EOS, final_score)."""
+    import math
+    model.eval()
+    out = []
+    with torch.no_grad():
+        f = model.conv(padded_input)
+        B, C, H, W = f.shape
+        mem_all = model.encoder(f.view(B, C * H, W).transpose(1, 2).contiguous(), input_lengths)
+        dec = model.decoder
+        max_len = mem_all.shape[1]
+        for b in range(B):
+            mem = mem_all[b:b + 1]
+            hyps = [dict(score=0.0, yseq=torch.full((1, 1), int(start_token), dtype=torch.int64))]
+            ended = []
+            for i in range(tgt_max_len):
+                kept = []
+                for hyp in hyps:
+                    ys = hyp['yseq']
+                    Lq = ys.shape[1]
+                    future = torch.triu(torch.ones(Lq, Lq, dtype=torch.bool), diagonal=1).unsqueeze(0)
+                    x = dec.trg_embedding(ys) + dec.positional_encoding.pe[:, :Lq]
+                    for layer in dec.layers:
+                        x = layer(x, mem, torch.ones(1, Lq, 1), future, torch.zeros(1, Lq, max_len, dtype=torch.bool))
+                    local = F.log_softmax(dec.output_linear(x[:, -1]), dim=1)
+                    best, ids = torch.topk(local, beam_width, dim=1)
+                    for j in range(beam_width):
+                        kept.append(dict(score=hyp['score'] + best[0, j], yseq=torch.cat([ys, ids[0, j].view(1, 1)], dim=1)))
+                    kept = sorted(kept, key=lambda h: h['score'], reverse=True)[:beam_width]
+                hyps = kept
+                if i == max_len - 1:
+                    for hyp in hyps:
+                        hyp['yseq'] = torch.cat([hyp['yseq'], torch.full((1, 1), EOS_ID, dtype=torch.int64)], dim=1)
+                live = []
+                for hyp in hyps:
+                    if int(hyp['yseq'][0, -1]) == EOS_ID:
+                        hyp['final_score'] = hyp['score'] + math.sqrt(num_words(hyp['yseq'][0].tolist())) * c_weight
+                        ended.append(hyp)
+                    else:
+                        live.append(hyp)
+                hyps = live
+                if not hyps:
+                    break
+            best_n = sorted(ended, key=lambda h: h['final_score'], reverse=True)[:min(len(ended), nbest)]
+            out.append([(h['yseq'][0].tolist(), float(h['final_score'])) for h in best_n])
+    model.train()
+    return out
+
+
 def build_model(cfg, seed=123456):
     """cfg: dict with the hyper-parameters of utils/functions.py:307-351; seeds like meta_transfer_train.py:109."""
     torch.manual_seed(seed)

@@ -53,3 +53,33 @@ def batches_for(cfg, spec, it, data_call_index):
 
 def global_l2(z, prefix, names):
     return float(np.sqrt(sum(float(z['%s/%s/l2' % (prefix, n)]) ** 2 for n in names)))
+
+
+def load_beam():
+    """B0.npz (reference Decoder.beam_search on the F0 model with a seeded perturbation of the vocabulary projection):
+    -> (spec dict, list of id lists, list of strings, list of evaluate() strings)."""
+    import json
+    z = np.load(os.path.join(ROOT, 'tests', 'golden', 'B0.npz'))
+    spec = json.loads(bytes(z['spec']).decode())
+    ids = [[int(v) for v in row if v >= 0] for row in z['beam_ids']]
+    dec = lambda k: bytes(z[k]).decode('utf-8').split('\n')
+    return spec, ids, dec('beam_strs'), dec('eval_beam_strs')
+
+
+def perturb_output_layer(weight, spec):
+    """the fixture's deterministic change of decoder.output_linear.weight (in place), as oracle/make_golden.py applies it"""
+    import torch
+    g = torch.Generator().manual_seed(int(spec['noise_seed']))
+    with torch.no_grad():
+        weight += float(spec['noise']) * torch.randn(weight.shape, generator=g).to(weight.device)
+        weight[2] = float(spec['eos_gain']) * weight[int(spec['eos_from'])]
+
+
+def label_words(id2label, specials):
+    """num_words(yseq) of modules/decoder.py:257-259 for a synthetic vocabulary"""
+    def num_words(yseq):
+        st = ''.join(id2label[int(c)] for c in yseq)
+        for tok in specials:
+            st = st.replace(tok, '')
+        return len(st.replace('  ', ' ').split())
+    return num_words

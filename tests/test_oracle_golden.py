@@ -96,3 +96,20 @@ def test_joint_trainer_config0_matches_reference():
         if 'key_linear_b.bias' in nm:
             continue
         gu.check_digest(z, 'theta/final', nm, p, rtol=1e-5, what='J0')
+
+
+def test_beam_search_matches_reference():
+    """the oracle's restatement of Decoder.beam_search reproduces the reference's n-best id sequences
+    (natural EOS terminations of different lengths, n-best order by final_score) on the B0 fixture."""
+    torch.set_num_threads(8)
+    spec, ids, strs, _ = gu.load_beam()
+    _, cfg, _ = gu.load('F0')
+    m = R.build_model(cfg)
+    gu.perturb_output_layer(m.decoder.output_linear.weight, spec)
+    labels = ['<PAD>', '<SOS>', '<EOS>', '<OOV>'] + [chr(0x4e00 + i) for i in range(cfg['vocab_size'] - 4)]
+    nw = gu.label_words(labels, labels[:3])                # decoder.py:257 strips PAD / SOS / EOS only
+    x, lens, y = R.synth_batch(spec['seed'], spec['k'], spec['T'], spec['L'], cfg['vocab_size'], True)
+    out = R.beam_search(m, x, lens, R.SOS_ID, spec['beam_width'], spec['nbest'], cfg['tgt_max_len'], nw)
+    got = [seq for utt in out for seq, _ in utt]
+    assert got == ids
+    assert [''.join(labels[t] for t in seq[1:]).replace('<EOS>', '') for seq in got] == strs

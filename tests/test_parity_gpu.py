@@ -486,3 +486,30 @@ def test_greedy_decoding_matches_oracle():
     _, gold_ref, _ = oracle(x, lens, y)
     assert golds == [''.join(vocab.id2label[int(t)] for t in row) for row in gold_ref]
     assert model.training                                                   # evaluate() restores the mode
+
+
+def test_beam_search_matches_reference_golden_and_oracle():
+    """Transformer.evaluate(beam_search=True) -> PassEngine.beam_decode reproduces the REAL reference's n-best id
+    sequences and strings (tests/golden/B0.npz: natural EOS terminations of different lengths, n-best order) token for token,
+    and a second input against the live oracle."""
+    from oracle import refimpl as R
+    bspec, ids, strs, eval_strs = gu.load_beam()
+    z, cfg, spec = gu.load('F0')
+    mtl_amd, args, vocab, model = make(cfg, spec)
+    gu.perturb_output_layer(model.decoder.output_linear.weight, bspec)
+    model = model.cuda()
+    args.beam_width, args.beam_nbest, args.tgt_max_len = bspec['beam_width'], bspec['nbest'], cfg['tgt_max_len']
+    x, lens, y = R.synth_batch(bspec['seed'], bspec['k'], bspec['T'], bspec['L'], cfg['vocab_size'], True)
+    _, hyps, golds = model.evaluate(x.cuda(), lens, y, args, beam_search=True, start_token=vocab.SOS_ID)
+    assert model.last_beam_ids == ids
+    assert hyps == strs == eval_strs
+    # a different batch (other lengths, beam 4, n-best 3) against the oracle's restatement
+    oracle = R.build_model(cfg)
+    gu.perturb_output_layer(oracle.decoder.output_linear.weight, bspec)
+    x, lens, y = R.synth_batch(909, 2, 80, 5, cfg['vocab_size'], True)
+    args.beam_width, args.beam_nbest = 4, 3
+    model.evaluate(x.cuda(), lens, y, args, beam_search=True, start_token=vocab.SOS_ID)
+    nw = gu.label_words(vocab.id2label, [vocab.PAD_TOKEN, vocab.SOS_TOKEN, vocab.EOS_TOKEN])
+    ref = R.beam_search(oracle, x, lens, vocab.SOS_ID, 4, 3, cfg['tgt_max_len'], nw)
+    assert model.last_beam_ids == [seq for utt in ref for seq, _ in utt]
+    assert model.training
