@@ -113,3 +113,22 @@ def test_beam_search_matches_reference():
     got = [seq for utt in out for seq, _ in utt]
     assert got == ids
     assert [''.join(labels[t] for t in seq[1:]).replace('<EOS>', '') for seq in got] == strs
+
+
+def test_frontend_restatement_agrees_with_scipy_stft():
+    """oracle/frontend.py is PARITY UNPINNED (librosa, which the reference calls, is not in this image).  Independent cross-check
+    of its framing / window / FFT conventions against scipy.signal.stft on the same reflect-padded signal: this does not pin
+    it to the reference, it only rules out a private convention error (frame count, hop, symmetric Hamming, one-sided bins)."""
+    import scipy.signal as ss
+    from oracle import frontend as Fe
+    rng = np.random.RandomState(3)
+    y = (rng.randn(16000 // 3 + 77) * 0.1).astype(np.float32)
+    n_fft, hop = 320, 160
+    mag = Fe.stft_magnitude(y, n_fft, hop)
+    win = ss.windows.hamming(n_fft)                                   # sym=True, what a callable window yields in librosa
+    yp = np.pad(y.astype(np.float64), n_fft // 2, mode='reflect')
+    _, _, Z = ss.stft(yp, window=win, nperseg=n_fft, noverlap=n_fft - hop, nfft=n_fft, boundary=None, padded=False,
+                      return_onesided=True, scaling='spectrum')
+    ref = np.abs(Z) * win.sum()                                       # undo scipy's spectrum scaling
+    assert mag.shape == ref.shape == (n_fft // 2 + 1, 1 + len(y) // hop)
+    assert np.max(np.abs(mag - ref)) <= 2e-5 * np.max(ref)
