@@ -5,9 +5,13 @@ Mirrors utils/functions.py: `init_transformer_model` (:307-351), `save_meta_mode
 {'vocab','args','epoch','model_state_dict','inner_opt','outer_opt','metrics'} with torch.optim objects pickled
 whole, so files are interchangeable with reference-trained models.
 """
+import contextlib
 import logging
 import math
 import os
+import pickle
+import sys
+import types
 
 import torch
 
@@ -44,44 +48,93 @@ def _as_torch_opt(opt):
 
 
 def save_meta_model(model, vocab, epoch, inner_opt, outer_opt, metrics, args, best_model=False):
+    """utils/functions.py:101-126: the same `.th` dict ('vocab', 'args', 'epoch', 'model_state_dict', 'inner_opt', 'outer_opt',
+    'metrics').  Written so that BOTH stacks can read it: tensors on the CPU; the optimizers as real
+    torch.optim.SGD / Adam objects (the reference calls `.state_dict()` on the pickled objects, :185-186) over parameters that
+    share storage with the state dict (no duplication in the file); the vocabulary pickled under the reference's class path
+    `utils.data.Vocab`, which the reference resolves to its own class and `load_meta_model` here to this package's."""
     folder = '{}/{}'.format(args.save_folder, args.name)
     save_path = folder + ('/best_model.th' if best_model else '/epoch_{}.th'.format(epoch))
     os.makedirs(folder, exist_ok=True)
     print('SAVE MODEL to', save_path)
     logging.info('SAVE MODEL to ' + save_path)
     state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
-    # optimizers are exported as torch.optim objects over CPU copies so the file loads without a GPU
+    params = [torch.nn.Parameter(state[n], requires_grad=True) for n, _ in model.named_parameters()]
     payload = {'vocab': vocab, 'args': args, 'epoch': epoch, 'model_state_dict': state,
-               'inner_opt': _opt_state_only(_as_torch_opt(inner_opt)), 'outer_opt': _opt_state_only(_as_torch_opt(outer_opt)),
-               'metrics': metrics}
-    torch.save(payload, save_path)
+               'inner_opt': _export_opt(inner_opt, params), 'outer_opt': _export_opt(outer_opt, params), 'metrics': metrics}
+    with _vocab_as_reference_class(vocab):
+        torch.save(payload, save_path)
     return save_path
 
 
-class _OptStateCarrier:
-    """Pickle-friendly stand-in exposing `.state_dict()` like the optimizer objects the reference pickles
-    (utils/functions.py:185-186 only ever calls `.state_dict()` on them)."""
-
-    def __init__(self, sd):
-        self._sd = sd
-
-    def state_dict(self):
-        return self._sd
-
-
-def _opt_state_only(opt):
-    sd = opt.state_dict()
+def _export_opt(opt, params):
+    """a torch.optim object of the same kind / hyper-parameters / state over the CPU parameter copies"""
+    src = _as_torch_opt(opt)
+    sd = src.state_dict()
     for st in sd['state'].values():
         for k, v in list(st.items()):
             if torch.is_tensor(v):
                 st[k] = v.detach().cpu().clone()
-    return _OptStateCarrier(sd)
+    out = type(src)(params, lr=src.param_groups[0]['lr'])
+    out.load_state_dict(sd)
+    return out
+
+
+@contextlib.contextmanager
+def _vocab_as_reference_class(vocab):
+    """While pickling, this package's Vocab answers to the reference's global name `utils.data.Vocab` (pickle verifies a
+    class by importing its module, so a stand-in module is registered for the duration of the dump)."""
+    from .data import Vocab
+    if type(vocab) is not Vocab:
+        yield
+        return
+    saved = {k: sys.modules.get(k) for k in ('utils', 'utils.data')}
+    old_module = Vocab.__module__
+    pkg = saved['utils'] if saved['utils'] is not None else types.ModuleType('utils')
+    mod = types.ModuleType('utils.data')
+    mod.Vocab = Vocab
+    sys.modules['utils'], sys.modules['utils.data'] = pkg, mod
+    Vocab.__module__ = 'utils.data'
+    try:
+        yield
+    finally:
+        Vocab.__module__ = old_module
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+
+class _CompatUnpickler(pickle.Unpickler):
+    """Checkpoints written by the reference pickle its `utils.data.Vocab`; resolve it to this package's Vocab (same attributes:
+    utils/data.py:1-28) so a reference-trained `.th` file resumes here without the reference on the path."""
+
+    def find_class(self, module, name):
+        if (module, name) == ('utils.data', 'Vocab'):
+            from .data import Vocab
+            return Vocab
+        return super().find_class(module, name)
+
+
+class _compat_pickle:                   # the `pickle_module` duck-type torch.load expects
+    __name__ = 'pickle'
+    Unpickler = _CompatUnpickler
+    load = staticmethod(lambda f, **kw: _CompatUnpickler(f, **kw).load())
+    loads = staticmethod(pickle.loads)
+    dump, dumps, Pickler = pickle.dump, pickle.dumps, pickle.Pickler
+    HIGHEST_PROTOCOL, DEFAULT_PROTOCOL = pickle.HIGHEST_PROTOCOL, pickle.DEFAULT_PROTOCOL
+
+
+def load_checkpoint_dict(load_path):
+    """the raw `.th` dict of either stack on the CPU (reference-written files resolve `utils.data.Vocab` to this package's)"""
+    return torch.load(load_path, map_location=torch.device('cpu'), weights_only=False, pickle_module=_compat_pickle)
 
 
 def load_meta_model(load_path, train=True):
     """-> (model, vocab, inner_opt, outer_opt, epoch, metrics, args); optimizers come back as torch.optim objects holding
     the saved state (TransientTrainer.train converts them to its flat-buffer optimizers)."""
-    ckpt = torch.load(load_path, map_location=torch.device('cpu'), weights_only=False)
+    ckpt = load_checkpoint_dict(load_path)
     args, vocab = ckpt['args'], ckpt['vocab']
     model = init_transformer_model(args, vocab, train=train, is_factorized=getattr(args, 'is_factorized', False),
                                    r=getattr(args, 'r', 100))

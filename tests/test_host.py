@@ -98,8 +98,15 @@ def test_checkpoint_roundtrip_reference_format(tmp_path):
     inner = torch.optim.SGD(m.parameters(), lr=args.lr)
     outer = torch.optim.Adam(m.parameters(), lr=args.meta_lr)
     path = mtl_amd.save_meta_model(m, vocab, 7, inner, outer, {'avg_valid_cer': 1.0}, args, best_model=False)
-    ck = torch.load(path, weights_only=False)
+    ck = mtl_amd.functions.load_checkpoint_dict(path)
     assert sorted(ck.keys()) == ['args', 'epoch', 'inner_opt', 'metrics', 'model_state_dict', 'outer_opt', 'vocab']
+    # what the reference's loader needs (utils/functions.py:158-188): optimizer OBJECTS with .state_dict(), its own Vocab class path
+    assert isinstance(ck['inner_opt'], torch.optim.SGD) and isinstance(ck['outer_opt'], torch.optim.Adam)
+    import zipfile
+    with zipfile.ZipFile(path) as zf:
+        pkl = zf.read([n for n in zf.namelist() if n.endswith('data.pkl')][0])
+    assert b'utils.data' in pkl and b'Vocab' in pkl and b'mtl_amd' not in pkl and b'meta-transfer' not in pkl
+    assert mtl_amd.Vocab.__module__ != 'utils.data'                     # the alias exists only while dumping
     m2, v2, i2, o2, ep, met, a2 = mtl_amd.load_meta_model(path)
     assert ep == 7 and met['avg_valid_cer'] == 1.0 and len(v2.label2id) == 64
     for (n1, p1), (n2, p2) in zip(m.named_parameters(), m2.named_parameters()):
@@ -134,3 +141,63 @@ def test_frontend_oracle_is_the_textbook_stft():
             assert abs(mag[f, t] - ref) < 1e-3 * max(ref, 1.0)
     sp = frontend.parse_audio(y)
     assert abs(float(sp.mean())) < 1e-5 and abs(float(sp.std()) - 1.0) < 1e-5
+
+
+REF = '/root/reference'
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason='needs the reference checkout (build container only)')
+def test_checkpoints_cross_load_with_the_real_reference(tmp_path):
+    """SURVEY 8(f) f4, both directions, in a subprocess that imports the REAL reference: (1) a `.th` written by the reference's
+    save_meta_model (after one Adam step, so optimizer state exists) loads here with identical weights, vocabulary and Adam
+    moments; (2) a `.th` written here is consumed by the reference's own load path (its classes, its load_state_dict)."""
+    import subprocess
+    import sys
+    import mtl_amd
+    z, cfg, spec = gu.load('F0')
+    args = make_args(cfg, save_folder=str(tmp_path), name='ours')
+    args.is_factorized, args.r, args.cuda = False, 100, False
+    vocab = mtl_amd.synthetic_vocab(64)
+    m = mtl_amd.init_transformer_model(args, vocab, is_factorized=False, r=100)
+    outer = torch.optim.Adam(m.parameters(), lr=args.meta_lr)
+    for p in m.parameters():
+        p.grad = torch.full_like(p, 0.01)
+    outer.step()
+    ours = mtl_amd.save_meta_model(m, vocab, 3, torch.optim.SGD(m.parameters(), lr=args.lr), outer, {'avg_valid_cer': 2.0}, args)
+    script = r"""
+import sys, torch
+sys.path.insert(0, %r)
+from oracle.make_golden import bootstrap_reference
+bootstrap_reference()
+import argparse
+from utils.data import Vocab
+from utils import functions as RF
+# (2) our file through the reference's load path (its torch.load call predates weights_only, so the dict is read explicitly)
+ck = torch.load(%r, map_location='cpu', weights_only=False)
+assert type(ck['vocab']).__module__ == 'utils.data' and type(ck['vocab']) is Vocab
+a = ck['args']
+model = RF.init_transformer_model(a, ck['vocab'], train=True, is_factorized=a.is_factorized, r=a.r)
+model.load_state_dict(ck['model_state_dict'])
+io = torch.optim.SGD(model.parameters(), lr=a.lr); oo = torch.optim.Adam(model.parameters(), lr=a.meta_lr)
+io.load_state_dict(ck['inner_opt'].state_dict()); oo.load_state_dict(ck['outer_opt'].state_dict())
+assert len(oo.state) == len(list(model.parameters())) and ck['epoch'] == 3
+# (1) a checkpoint written by the reference itself
+for p in model.parameters():
+    p.grad = torch.full_like(p, -0.02)
+oo.step()
+a.save_folder, a.name = %r, 'theirs'
+RF.save_meta_model(model, ck['vocab'], 4, io, oo, {'avg_valid_cer': 1.5}, a)
+print('REFERENCE_OK')
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), ours, str(tmp_path))
+    env = dict(os.environ, PYTHONPATH=REF)
+    out = subprocess.run([sys.executable, '-c', script], capture_output=True, text=True, env=env, cwd=str(tmp_path), timeout=600)
+    assert 'REFERENCE_OK' in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+    theirs = os.path.join(str(tmp_path), 'theirs', 'epoch_4.th')
+    m2, v2, i2, o2, ep, met, a2 = mtl_amd.load_meta_model(theirs)
+    assert ep == 4 and met['avg_valid_cer'] == 1.5 and type(v2) is mtl_amd.Vocab and v2.id2label == vocab.id2label
+    raw = mtl_amd.functions.load_checkpoint_dict(theirs)
+    for (n, p) in m2.named_parameters():
+        assert torch.equal(p, raw['model_state_dict'][n])
+    st = o2.state_dict()['state']
+    assert len(st) == len(list(m2.parameters())) and float(st[0]['step']) == 2.0
+    assert torch.equal(st[0]['exp_avg'], raw['outer_opt'].state_dict()['state'][0]['exp_avg'])
