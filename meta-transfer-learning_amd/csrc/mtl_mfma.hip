@@ -1291,6 +1291,7 @@ struct WgradX3P {
     int B, T, F, Ty, Fy, Tp, Fp, Cin, Cout;
     int npairs, npj;      // channel-block pairs, and pairs along Cout
     int ntf, ntt, tiles;  // pixel tiles along F, along T, in total (F fastest)
+    int dbg;              // ablation switches (MTL_X3_DBG): 1 no halo staging, 2 no dy loads / splits; 0 in production
 };
 
 constexpr int WX_HF = 18, WX_NPIX = 10 * WX_HF;          // halo of an 8 x 16 tile
@@ -1312,6 +1313,11 @@ __device__ __forceinline__ bf16x8 tr_read8(const unsigned char* a) {    // 8 pix
     return u.v;
 }
 
+// B ring: 2 slots x 2 k-steps x [piece][k half][64 co] 16-byte fragments (6 KiB per k-step), behind the two halo buffers
+constexpr int WX_BSTEP = 3 * 2 * 64 * 16;
+constexpr int WX_BOFF = 2 * WX_BUF;
+constexpr int WX_SMEM = WX_BOFF + 4 * WX_BSTEP;
+
 template <bool UNPOOL>
 __global__ __launch_bounds__(512) void conv3x3_wgrad_x3_kernel(WgradX3P p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smx[];
@@ -1320,6 +1326,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_x3_kernel(WgradX3P p) {
     const int cib = (pair / p.npj) * 64, cob = (pair % p.npj) * 64;
     const int my_tiles = (p.tiles - slot + nslots - 1) / nslots;
     const int T = p.T, F = p.F, Cin = p.Cin, Cout = p.Cout;
+    const int npairs_k = my_tiles * 4;                         // pairs of k-steps (2 x 16 pixels): the B hand-over granule
     auto tile_of = [&](int j, int& b, int& t0, int& f0) {
         int id = slot + j * nslots;
         const int fx = id % p.ntf;
@@ -1330,7 +1337,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_x3_kernel(WgradX3P p) {
     };
 
     if (tid >= NT) {
-        // ------------------------------------------------------------------ producers: the x halo
+        // ------------------------------------------------------------------ producers: the x halo AND the dy fragments
         const int ptid = tid - NT;
         float4 hv[WX_NVA];
         unsigned okbits = 0;
@@ -1365,17 +1372,96 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_x3_kernel(WgradX3P p) {
                 *reinterpret_cast<bf16x4*>(dst + 4 * WX_SUB) = ll;
             }
         };
+        // dy: this thread owns ONE B fragment per pair of k-steps -- (k-step parity, k half, output channel) -- i.e. 8 pixels
+        // of one channel: 8 coalesced row loads (4 + 4 arg-max bytes when pooled), un-pool, 3-way split, three 16-byte stores
+        // in the layout the consumers' ds_read_b128 wants ([piece][k half][co], conflict-free).  Loaded two pairs ahead.
+        const int bs = ptid >> 7, bhi = (ptid >> 6) & 1, bco = ptid & 63;
+        constexpr int NB = UNPOOL ? 4 : 8;
+        float bv[2][NB];
+        unsigned ba[2], bok[2];
+        auto fetch_b = [&](int pk, float (&v)[NB], unsigned& a, unsigned& okm) {
+            const int j = pk >> 2, s = (pk & 3) * 2 + bs;
+            int b, t0, f0;
+            tile_of(min(j, my_tiles - 1), b, t0, f0);
+            const int t = t0 + s, fb = f0 + bhi * 8, co = cob + bco;
+            okm = 0;
+            a = 0;
+            if (!UNPOOL) {
+                const int tc = min(t, T - 1);
+                const int fs = max(min(fb, F - 8), 0);
+                const float* rowp = p.dy + (((long)b * T + tc) * F + fs) * Cout + co;
+                const bool rowok = t < p.Ty && j < my_tiles;
+                if (fs == fb) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = rowp[(long)k * Cout];
+                    okm = rowok ? ((fb + 8 <= p.Fy) ? 0xffu : ((1u << max(p.Fy - fb, 0)) - 1u)) : 0u;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int f = fb + k;
+                        v[k] = p.dy[(((long)b * T + tc) * F + min(f, F - 1)) * Cout + co];
+                        okm |= ((rowok && f < p.Fy) ? 1u : 0u) << k;
+                    }
+                }
+            } else {
+                const int tp = min(t >> 1, p.Tp - 1), fp0 = fb >> 1;
+                const bool rowok = t < p.Ty && j < my_tiles;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int fp = fp0 + k;
+                    const long o = (((long)b * p.Tp + tp) * p.Fp + min(fp, p.Fp - 1)) * Cout + co;
+                    v[k] = p.dy[o];
+                    a |= (unsigned)p.am[o] << (8 * k);
+                    okm |= ((rowok && fp < p.Fp) ? 1u : 0u) << k;
+                }
+                okm |= (unsigned)(t & 1) << 8;
+            }
+        };
+        auto commit_b = [&](int pk, const float (&v)[NB], unsigned a, unsigned okm) {
+            float val[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (!UNPOOL) {
+                    val[k] = ((okm >> k) & 1u) ? v[k] : 0.f;
+                } else {
+                    const unsigned sub = ((unsigned)(k & 1) << 1) | (okm >> 8);
+                    val[k] = (((okm >> (k >> 1)) & 1u) && ((a >> (8 * (k >> 1))) & 0xffu) == sub) ? v[k >> 1] : 0.f;
+                }
+            }
+            uint4 hh, mm, ll;
+            split3x2(val[0], val[1], hh.x, mm.x, ll.x);
+            split3x2(val[2], val[3], hh.y, mm.y, ll.y);
+            split3x2(val[4], val[5], hh.z, mm.z, ll.z);
+            split3x2(val[6], val[7], hh.w, mm.w, ll.w);
+            unsigned char* dst = smx + WX_BOFF + ((pk & 1) * 2 + bs) * WX_BSTEP + (bhi * 64 + bco) * 16;
+            *reinterpret_cast<uint4*>(dst) = hh;
+            *reinterpret_cast<uint4*>(dst + 2 * 64 * 16) = mm;
+            *reinterpret_cast<uint4*>(dst + 4 * 64 * 16) = ll;
+        };
         if (my_tiles > 0) {
             fetch(0);
+            fetch_b(0, bv[0], ba[0], bok[0]);
+            fetch_b(1, bv[1], ba[1], bok[1]);
             commit(0);
+            commit_b(0, bv[0], ba[0], bok[0]);
+            fetch_b(2, bv[0], ba[0], bok[0]);
         }
         if (my_tiles > 1) fetch(1);
-        __syncthreads();
+        __syncthreads();                                       // halo 0 and the fragments of pair 0 are visible
 #pragma unroll 1
-        for (int j = 0; j < my_tiles; ++j) {
-            if (j + 1 < my_tiles) {
-                commit((j + 1) & 1);                   // the buffer tile j - 1 was read from
-                if (j + 2 < my_tiles) fetch(j + 2);
+        for (int pk = 0; pk < npairs_k; pk += 2) {
+            // pair pk is being consumed; write pair pk + 1 (its slot was released by the previous barrier), fetch pair pk + 3
+            commit_b(pk + 1, bv[1], ba[1], bok[1]);
+            fetch_b(pk + 3, bv[1], ba[1], bok[1]);
+            __syncthreads();
+            commit_b(pk + 2, bv[0], ba[0], bok[0]);
+            fetch_b(pk + 4, bv[0], ba[0], bok[0]);
+            if ((pk & 3) == 2) {                               // last pair of tile j: the next tile's halo goes into the other buffer
+                const int j = pk >> 2;
+                if (j + 1 < my_tiles) {
+                    commit((j + 1) & 1);
+                    if (j + 2 < my_tiles) fetch(j + 2);
+                }
             }
             __syncthreads();
         }
@@ -1394,100 +1480,18 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_x3_kernel(WgradX3P p) {
     // halo pixel (s + kw) * 18 + f + kh with f = (g >> 1) * 8 + r * 4 + (x16 >> 2); channels qi * 32 + 16 * (g & 1) + 4 * (x16 & 3)
     const int abase = ((qi * WX_NPIX) + (g >> 1) * 8 + (x16 >> 2)) * 64 + (16 * (g & 1) + 4 * (x16 & 3)) * 2;
     const int co = cob + qj * 32 + l31;
-    constexpr int RING = 4, NB = UNPOOL ? 4 : 8;
-    float bv[RING][NB];
-    unsigned ba[RING];                                         // pooled dy: the four arg-max codes of a step, one byte each
-    unsigned bok[RING];
-    const int nsteps = my_tiles * 8;
-    auto fetch_b = [&](int gs, float (&v)[NB], unsigned& a, unsigned& okm) {
-        const int j = gs >> 3, s = gs & 7;
-        int b, t0, f0;
-        tile_of(min(j, my_tiles - 1), b, t0, f0);
-        const int t = t0 + s, fb = f0 + hi * 8;
-        okm = 0;
-        if (!UNPOOL) {
-            // one base address + 8 immediate offsets (pixel stride Cout * 4 bytes) whenever the 8 pixels lie inside the row --
-            // per-pixel clamped addresses (the ragged last group of a row only) cost 16 more live registers and spill
-            const int tc = min(t, T - 1);
-            const int fs = max(min(fb, F - 8), 0);
-            const float* rowp = p.dy + (((long)b * T + tc) * F + fs) * Cout + co;
-            const bool rowok = t < p.Ty && j < my_tiles;
-            if (fs == fb) {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] = rowp[(long)k * Cout];
-                okm = rowok ? ((fb + 8 <= p.Fy) ? 0xffu : ((1u << max(p.Fy - fb, 0)) - 1u)) : 0u;
-            } else {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int f = fb + k;
-                    v[k] = p.dy[(((long)b * T + tc) * F + min(f, F - 1)) * Cout + co];
-                    okm |= ((rowok && f < p.Fy) ? 1u : 0u) << k;
-                }
-            }
-        } else {
-            const int tp = min(t >> 1, p.Tp - 1), fp0 = fb >> 1;
-            const bool rowok = t < p.Ty && j < my_tiles;
-            a = 0;
-            if (fp0 + 4 <= p.Fp) {                             // one base + immediate offsets (see the dense form above)
-                const long o = (((long)b * p.Tp + tp) * p.Fp + fp0) * Cout + co;
-                const float* rowp = p.dy + o;
-                const uint8_t* rowa = p.am + o;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    v[k] = rowp[(long)k * Cout];
-                    a |= (unsigned)rowa[(long)k * Cout] << (8 * k);
-                }
-                okm = rowok ? 0xfu : 0u;
-            } else {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int fp = fp0 + k;
-                    const long o = (((long)b * p.Tp + tp) * p.Fp + min(fp, p.Fp - 1)) * Cout + co;
-                    v[k] = p.dy[o];
-                    a |= (unsigned)p.am[o] << (8 * k);
-                    okm |= ((rowok && fp < p.Fp) ? 1u : 0u) << k;
-                }
-            }
-            okm |= (unsigned)(t & 1) << 8;
-        }
-    };
-    auto make_b = [&](const float (&v)[NB], unsigned a, unsigned okm, bf16x8 (&b3)[3]) {
-        float val[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            if (!UNPOOL) {
-                val[k] = ((okm >> k) & 1u) ? v[k] : 0.f;
-            } else {
-                const unsigned sub = ((unsigned)(k & 1) << 1) | (okm >> 8);
-                val[k] = (((okm >> (k >> 1)) & 1u) && ((a >> (8 * (k >> 1))) & 0xffu) == sub) ? v[k >> 1] : 0.f;
-            }
-        }
-        uint4 hh, mm, ll;
-        split3x2(val[0], val[1], hh.x, mm.x, ll.x);
-        split3x2(val[2], val[3], hh.y, mm.y, ll.y);
-        split3x2(val[4], val[5], hh.z, mm.z, ll.z);
-        split3x2(val[6], val[7], hh.w, mm.w, ll.w);
-        b3[0] = __builtin_bit_cast(bf16x8, hh);
-        b3[1] = __builtin_bit_cast(bf16x8, mm);
-        b3[2] = __builtin_bit_cast(bf16x8, ll);
-    };
-    constexpr int AHEAD = 3;
-    if (nsteps > 0) {
-        fetch_b(0, bv[0], ba[0], bok[0]);
-        fetch_b(1, bv[1], ba[1], bok[1]);
-        if (AHEAD > 2) fetch_b(2, bv[2], ba[2], bok[2]);
-    }
+    const unsigned char* Bl = smx + WX_BOFF + (hi * 64 + qj * 32 + l31) * 16;
     __syncthreads();
 #pragma unroll 1
-    for (int j = 0; j < my_tiles; ++j) {
-#pragma unroll 1
-        for (int s4 = 0; s4 < 8; s4 += 4) {                    // 4 k-steps per trip: static ring indices, bounded live ranges
-        const unsigned char* A = smx + (j & 1) * WX_BUF + abase + s4 * WX_HF * 64;
+    for (int pk = 0; pk < npairs_k; ++pk) {
+        const int j = pk >> 2;
+        const unsigned char* A = smx + (j & 1) * WX_BUF + abase + (pk & 3) * 2 * WX_HF * 64;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 0; s < 2; ++s) {
+            const unsigned char* Bs = Bl + ((pk & 1) * 2 + s) * WX_BSTEP;
             bf16x8 b3[3];
-            make_b(bv[s & 3], ba[s & 3], bok[s & 3], b3);
-            fetch_b(j * 8 + s4 + s + AHEAD, bv[(s + AHEAD) & 3], ba[(s + AHEAD) & 3], bok[(s + AHEAD) & 3]);     // past the end: clamped, masked off
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) b3[pc] = *reinterpret_cast<const bf16x8*>(Bs + pc * 2 * 64 * 16);
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int kh = tap / 3, kw = tap - kh * 3;
@@ -1502,7 +1506,6 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_x3_kernel(WgradX3P p) {
                 cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b3[0], cc, 0, 0, 0);
                 acc[tap] = cc;
             }
-        }
         }
         __syncthreads();
     }
@@ -1694,9 +1697,10 @@ int mtl_conv3x3_wgrad_x3(void* stream, const float* x, const float* dy, const un
     p.ntf = (p.Fy + 15) / 16;
     p.ntt = (p.Ty + 7) / 8;
     p.tiles = p.ntf * p.ntt * B;
+    p.dbg = 0;
     const int grid = wgrad_x3_grid(Cin, Cout);
     hipStream_t s = as_stream(stream);
-    constexpr int SMEM = 2 * WX_BUF;
+    constexpr int SMEM = WX_SMEM;
     if (pooled) {
         static int attr = set_smem(conv3x3_wgrad_x3_kernel<true>, SMEM);
         if (attr) return attr;
