@@ -1034,12 +1034,13 @@ int dispatch_conv_x3(ConvX3P& p, int Te, int Fe, hipStream_t s) {
     if (p.g.Cin % 64 || p.g.Cout % 64) return MTL_EINVAL;     // C_in % 64: even number of K-tiles (producer loop is unrolled by 2)
     // 8 x 16 tiles (G = 1: 79 KiB of LDS at BN = 64, two workgroups per CU) measured faster only on the 64 -> 64 layer
     // (conv2 fwd 0.52 -> 0.50 ms, dgrad 0.61 -> 0.59); every 128-wide shape and conv5-dgrad is faster with 16 x 16 tiles.
+    static const bool g1 = getenv("MTL_X3_G1") != nullptr;          // experiment: 8 x 16 tiles everywhere (LDS room for co-resident kernels)
     if (p.g.Cout % 128 == 0) {
         p.ntile = p.g.Cout / 128;
-        return launch_conv_x3h<128, 2, UNPOOL, EPI>(p, Te, Fe, s);
+        return g1 ? launch_conv_x3h<128, 1, UNPOOL, EPI>(p, Te, Fe, s) : launch_conv_x3h<128, 2, UNPOOL, EPI>(p, Te, Fe, s);
     }
     p.ntile = p.g.Cout / 64;
-    if (p.g.Cin == 64) return launch_conv_x3h<64, 1, UNPOOL, EPI>(p, Te, Fe, s);
+    if (p.g.Cin == 64 || g1) return launch_conv_x3h<64, 1, UNPOOL, EPI>(p, Te, Fe, s);
     return launch_conv_x3h<64, 2, UNPOOL, EPI>(p, Te, Fe, s);
 }
 
