@@ -1277,10 +1277,11 @@ int launch_wgrad(const WgradP& p, int nsplit, hipStream_t s) {
 //     for all nine taps, split it into the three bf16 pieces and store it as [piece][ci half][halo pixel][32 ci] (64-byte
 //     rows).  Consumers fetch A fragments with ds_read_b64_tr_b16 (each 16-lane group transposes a [4 pixels][16 channels]
 //     block; four consecutive halo pixels x 64 B = all 64 banks once, conflict-free without padding), tap = constant offset.
-//     The halo is double-buffered: ONE barrier per pixel tile (8 k-steps x 54 MFMAs per consumer wave).
-//   * dy: every B fragment is used by all nine taps of one k-step and by nothing else, so consumers load it straight into
-//     MFMA layout (lane = output channel, 8 pixels = 8 coalesced 128-byte rows), un-pool + split in registers, three
-//     k-steps ahead in a register ring.  No LDS, no producer work.
+//     The halo is double-buffered per pixel tile (8 k-steps x 54 MFMAs per consumer wave).
+//   * dy: every B fragment is used by all nine taps of one k-step and by nothing else, so it needs LDS only for the hand-over:
+//     each PRODUCER thread owns one fragment per pair of k-steps (lane = output channel, 8 pixels = 8 coalesced 128-byte row
+//     loads two pairs ahead, un-pool + split in registers) and stores it in MFMA register layout into a 24 KiB ring read with
+//     ds_read_b128; one barrier per two k-steps.  (Consumers doing this themselves cost 25-30 % of the kernel: ablation.)
 //   * 4 consumer waves = (ci half, co half) quadrants of a 64 x 64 channel block, nine 32 x 32 accumulators each (one per
 //     tap); larger layers are covered by (Cin/64)(Cout/64) workgroup classes.  Workgroups are persistent and write one
 //     slab [9*Cin][Cout] sub-block each; wgrad_reduce_kernel sums the slabs in a fixed order (deterministic).
