@@ -1,6 +1,6 @@
 """GPU diagnostic: where does the meta-step error come from? compares g_tr, theta', g_val(theta') stage by stage."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from tests import golden_util as gu
 from tests.test_parity_gpu import make

@@ -1,6 +1,6 @@
 """How reproducible is the CPU oracle itself across thread counts (north-star size, single pass)?"""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from tests import golden_util as gu
 from oracle import refimpl as R

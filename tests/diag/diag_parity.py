@@ -1,6 +1,6 @@
 """GPU diagnostic: per-tensor relative error of one pass's gradients (HIP vs CPU oracle)."""
 import argparse, sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from tests import golden_util as gu
 from tests.test_parity_gpu import make

@@ -1,6 +1,6 @@
 """GPU timing: Transformer.evaluate greedy decoding (B=8, T=1000, 300 steps) vs the oracle's reference-style loop (30 steps)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from tests import golden_util as gu
 from tests.test_parity_gpu import make
