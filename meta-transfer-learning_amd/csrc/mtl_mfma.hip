@@ -374,6 +374,28 @@ int dispatch_gemm(GemmP& p, int batch, hipStream_t s, float* workspace, long wor
     // big tiles only when they still give >= 1 workgroup per CU
     const long big = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * batch;
     if (big >= 256) return launch_gemm<128, 128, TA, TB>(p, batch, s);
+    if (workspace && big >= 48 && big <= 96 && p.K >= 2048 && (batch == 1 || p.H == 1)) {
+        // a long-K product with too few 128 x 128 tiles for 256 CUs (the 5120-deep input projection: 64 tiles): the big tile
+        // runs 1.5x the rate of the 64 x 64 one, so split K to fill the chip (151 -> 125 us).  Measured and NOT extended to
+        // 16-tile (FFN dW: 22 -> 36 us), 28-tile (69 -> 76 us) or 160-tile (128 -> 159 us) shapes.
+        long S = (256 + big - 1) / big;
+        if (S > p.K / 256) S = p.K / 256;
+        const long fit = workspace_bytes / ((long)p.M * p.N * 4 * batch);
+        if (S > fit) S = fit;
+        if (S >= 2) {
+            p.kchunk = (int)(((p.K + S - 1) / S + BK - 1) / BK * BK);
+            p.ksplit = (p.K + p.kchunk - 1) / p.kchunk;
+            p.partial = workspace;
+            if (p.ksplit >= 2) {
+                int rc = launch_gemm<128, 128, TA, TB>(p, batch * p.ksplit, s);
+                if (rc) return rc;
+                hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for((long)p.M * p.N * batch, 256, 1024)), dim3(256), 0, s, p);
+                MTL_CHECK_LAUNCH();
+                return MTL_OK;
+            }
+            p.ksplit = 1;
+        }
+    }
     const long tiles = (long)((p.M + 63) / 64) * ((p.N + 63) / 64) * batch;
     if (workspace && tiles < 192 && p.K >= 128 && (batch == 1 || p.H == 1)) {      // (b,h)-batched attention products stay unsplit
         // too few output tiles to fill 256 CUs: split K over grid.z into a workspace, then a fixed-order reduction
