@@ -212,6 +212,7 @@ class PassEngine:
         self.dropout_p = 0.0          # set by the model: hp.dropout when model.training else 0
         self._site = 0                # dropout site counter of the current pass (Philox offset = site << 40)
         self.after_conv_hook = None
+        self.forward_hook = None      # optional callable(engine) after every forward has been enqueued (tests capture the arena)
         self.deferred = []
         self.use_side_stream = True
         # 3x3 convolutions (forward and data gradient): '1' = exact 3-way bf16 split on the bf16 MFMA pipe (fp32-accurate, see
@@ -692,6 +693,8 @@ class PassEngine:
         self.saved = dict(theta=theta, x=x, B=B, T=T, F=F, Td=Td, n_nonpad=n_nonpad, smoothing=float(smoothing), meta=meta,
                           klen_enc=klen_enc, klen_dec=klen_dec, keep_enc=keep_enc, keep_dec=keep_dec, dec_last=cur,
                           enc_inputs=enc_inputs)
+        if self.forward_hook is not None:
+            self.forward_hook(self)
         return dict(pred=pred, gold=ids[1], hyp=hyp, loss=loss, gold_host=meta['gold_host'], n_nonpad=n_nonpad)
 
     # ---------------------------------------------------------------- greedy decoding

@@ -60,9 +60,12 @@ def tensor_digest(t, full_below=2048, nsample=256):
     return d
 
 
+NSAMPLE = {'n': 256}     # strided samples kept per large tensor (the north-star record stores 4096)
+
+
 def pack(prefix, named, store):
     for name, t in named:
-        for k, v in tensor_digest(t).items():
+        for k, v in tensor_digest(t, nsample=NSAMPLE['n']).items():
             store['%s/%s/%s' % (prefix, name, k)] = v
 
 
@@ -195,7 +198,7 @@ def run_fixture(name, spec, torch):
             store[key + '/hyp'] = hyp.numpy().astype(np.int64)
             store[key + '/loss'] = np.float64(loss)
             store[key + '/cer'] = np.array(cer_log[it * 2 * n + j], dtype=np.int64)
-            for k_, v in tensor_digest(pred).items():
+            for k_, v in tensor_digest(pred, nsample=NSAMPLE['n']).items():
                 store[key + '/pred/' + k_] = v
     os.makedirs(OUT, exist_ok=True)
     np.savez_compressed(os.path.join(OUT, name + '.npz'), **store)
@@ -334,4 +337,5 @@ if __name__ == '__main__':
         elif name == 'J0':
             run_joint_fixture(torch)
         else:
+            NSAMPLE['n'] = 4096 if name == 'NS' else 256
             run_fixture(name, FIXTURES[name], torch)

@@ -59,6 +59,24 @@ def decoder_io(padded_target):
     return seq_in, seq_out
 
 
+def relu_replay(x, gate):
+    """ReLU whose branch decisions are REPLAYED from `gate` (bool, x.shape, True = pass) instead of taken from sign(x).
+    Test infrastructure for the 1e-4 parity bar: two exact-fp32 implementations differ by ~1e-7 in pre-activations, so an
+    element within rounding of 0 can be gated differently; replaying the device path's own decisions removes that branch
+    noise (exactly like the dropout-mask replay) while every arithmetic op stays the oracle's."""
+    return x * gate.to(x.dtype)
+
+
+def pool_replay(z, argmax, gate):
+    """ReLU + MaxPool2d(2, stride 2, floor) of the pre-activation z (B,C,F,T) with replayed decisions: `argmax` (B,C,F//2,T//2)
+    in {0..3} = 2*(f&1) + (t&1) names the window element that is routed, `gate` (bool) is the sign of that maximum."""
+    B, C, Fz, Tz = z.shape
+    Fp, Tp = Fz // 2, Tz // 2
+    w = z[:, :, :2 * Fp, :2 * Tp].reshape(B, C, Fp, 2, Tp, 2).permute(0, 1, 2, 4, 3, 5).reshape(B, C, Fp, Tp, 4)
+    v = w.gather(4, argmax.long().unsqueeze(-1)).squeeze(-1)
+    return v * gate.to(z.dtype)
+
+
 class PositionTable(nn.Module):
     def __init__(self, d, max_len):
         super().__init__()
@@ -120,8 +138,10 @@ class FFN(nn.Module):
         self.linear_2 = nn.Linear(inner, d)
         self.layer_norm = nn.LayerNorm(d)
 
-    def forward(self, x, drop=None, tag=''):
-        h = self.linear_2(F.relu(self.linear_1(x)))
+    def forward(self, x, drop=None, tag='', gates=None):
+        h = self.linear_1(x)
+        h = F.relu(h) if gates is None else relu_replay(h, gates[tag + 'h1'].reshape(h.shape))
+        h = self.linear_2(h)
         if drop is not None:
             h = h * drop[tag + 'mf']                                       # common_layers.py:130
         return self.layer_norm(h + x)
@@ -135,9 +155,9 @@ class EncLayer(nn.Module):
         self.self_attn = LowRankMHA(heads, d, dk, dv, r)
         self.pos_ffn = FFN(d, inner)
 
-    def forward(self, x, keep, blocked, drop=None, tag=''):
+    def forward(self, x, keep, blocked, drop=None, tag='', gates=None):
         x = self.self_attn(x, x, blocked, drop, tag + 'sa.') * keep
-        return self.pos_ffn(x, drop, tag + 'ff.') * keep
+        return self.pos_ffn(x, drop, tag + 'ff.', gates) * keep
 
 
 class Enc(nn.Module):
@@ -150,13 +170,13 @@ class Enc(nn.Module):
         self.positional_encoding = PositionTable(d, src_max_len)
         self.layers = nn.ModuleList([EncLayer(heads, d, inner, dk, dv, r) for _ in range(layers)])
 
-    def forward(self, feats, lengths, drop=None):
+    def forward(self, feats, lengths, drop=None, gates=None):
         B, T, _ = feats.shape
         keep = length_mask(lengths, T)                                     # encoder.py:64 (Q2)
         blocked = (keep < 1).unsqueeze(1).expand(B, T, T)                  # encoder.py:66
         x = self.layer_norm_input(self.input_linear(feats)) + self.positional_encoding.pe[:, :T]  # :72-73
         for i, layer in enumerate(self.layers):
-            x = layer(x, keep.unsqueeze(-1), blocked, drop, 'e%d.' % i)
+            x = layer(x, keep.unsqueeze(-1), blocked, drop, 'e%d.' % i, gates)
         return x
 
 
@@ -169,10 +189,10 @@ class DecLayer(nn.Module):
         self.encoder_attn = LowRankMHA(heads, d, dk, dv, r)
         self.pos_ffn = FFN(d, inner)
 
-    def forward(self, x, mem, keep, self_blocked, cross_blocked, drop=None, tag=''):
+    def forward(self, x, mem, keep, self_blocked, cross_blocked, drop=None, tag='', gates=None):
         x = self.self_attn(x, x, self_blocked, drop, tag + 'sa.') * keep
         x = self.encoder_attn(x, mem, cross_blocked, drop, tag + 'ca.') * keep
-        return self.pos_ffn(x, drop, tag + 'ff.') * keep
+        return self.pos_ffn(x, drop, tag + 'ff.', gates) * keep
 
 
 class Dec(nn.Module):
@@ -186,7 +206,7 @@ class Dec(nn.Module):
         self.output_linear = nn.Linear(d, vocab_size, bias=False)
         nn.init.xavier_normal_(self.output_linear.weight)
 
-    def forward(self, padded_target, mem, src_lengths, drop=None):
+    def forward(self, padded_target, mem, src_lengths, drop=None, gates=None):
         seq_in, seq_out = decoder_io(padded_target)
         B, L = seq_in.shape
         keep = seq_in.ne(EOS_ID).float().unsqueeze(-1)                     # decoder.py:86 (Q7: keyed on EOS)
@@ -197,7 +217,7 @@ class Dec(nn.Module):
         if drop is not None:
             x = x * drop['dec_in.me']
         for i, layer in enumerate(self.layers):
-            x = layer(x, mem, keep, self_blocked, cross_blocked, drop, 'd%d.' % i)
+            x = layer(x, mem, keep, self_blocked, cross_blocked, drop, 'd%d.' % i, gates)
         return self.output_linear(x), seq_out                                          # :108-113
 
 
@@ -221,12 +241,23 @@ class SpeechTransformer(nn.Module):
             if p.dim() > 1:
                 nn.init.xavier_uniform_(p)
 
-    def forward(self, padded_input, input_lengths, padded_target, drop=None):
-        f = self.conv(padded_input)                                        # :133
+    def conv_stack(self, x, gates=None):
+        """transformer.py:48-59; with `gates` the ReLU / max-pool decisions are replayed (relu_replay / pool_replay):
+        gates['conv0'], gates['conv5'] bool (B,C,F,T); gates['am1'/'am2'] window indices, gates['pool1'/'pool2'] bool."""
+        if gates is None:
+            return self.conv(x)
+        c = self.conv
+        z = relu_replay(c[0](x), gates['conv0'])
+        z = pool_replay(c[2](z), gates['am1'], gates['pool1'])
+        z = relu_replay(c[5](z), gates['conv5'])
+        return pool_replay(c[7](z), gates['am2'], gates['pool2'])
+
+    def forward(self, padded_input, input_lengths, padded_target, drop=None, gates=None):
+        f = self.conv_stack(padded_input, gates)                           # :133
         B, C, H, W = f.shape
-        f = f.view(B, C * H, W).transpose(1, 2).contiguous()               # :136-138
-        mem = self.encoder(f, input_lengths, drop)
-        pred, gold = self.decoder(padded_target, mem, input_lengths, drop)
+        f = f.reshape(B, C * H, W).transpose(1, 2).contiguous()            # :136-138
+        mem = self.encoder(f, input_lengths, drop, gates)
+        pred, gold = self.decoder(padded_target, mem, input_lengths, drop, gates)
         hyp = torch.topk(pred, 1, dim=2)[1].squeeze(2)                     # :146-147
         return pred, gold, hyp
 
@@ -339,12 +370,14 @@ def clip_(grads, max_norm):
     return grads
 
 
-def meta_gradient(model, task_batches, val_batch, alpha, max_norm=None):
+def meta_gradient(model, task_batches, val_batch, alpha, max_norm=None, gates=None):
     """G = sum_m [ grad L_tr,m(theta0) + (1/n) grad L_val(theta0 - alpha grad L_tr,m(theta0)) ]  (SURVEY Q1).
 
     task_batches: list of (x, lengths, y); val_batch: (x, lengths, y).  Restores theta0 before returning.
     max_norm: `--clip` (transient_trainer.py:205-206): the train gradient is clipped BEFORE the inner step and the
     clipped tensor is what stays in .grad.
+    gates: optional list of 2n gate dicts (SpeechTransformer.conv_stack), one per forward in execution order (task 0 train,
+    task 0 valid, task 1 train, ...): replays the device path's ReLU / max-pool decisions.
     Returns (G list per parameter, [tr losses], [val losses], [(gold, hyp) of every forward]).
     """
     params = list(model.parameters())
@@ -352,8 +385,8 @@ def meta_gradient(model, task_batches, val_batch, alpha, max_norm=None):
     n = len(task_batches)
     G = [torch.zeros_like(p) for p in params]
     tr_losses, val_losses, labels = [], [], []
-    for (x, lens, y) in task_batches:
-        pred, gold, hyp = model(x, lens, y)
+    for m_, (x, lens, y) in enumerate(task_batches):
+        pred, gold, hyp = model(x, lens, y, gates=gates[2 * m_] if gates is not None else None)
         loss = ce_loss(pred, gold)
         g_tr = torch.autograd.grad(loss, params)                           # :198-199
         if max_norm is not None:
@@ -363,7 +396,7 @@ def meta_gradient(model, task_batches, val_batch, alpha, max_norm=None):
         with torch.no_grad():
             for p, g in zip(params, g_tr):                                 # inner SGD, :207
                 p.add_(g, alpha=-alpha)
-        pred, gold, hyp = model(*val_batch)
+        pred, gold, hyp = model(*val_batch, gates=gates[2 * m_ + 1] if gates is not None else None)
         vloss = ce_loss(pred, gold)
         val_losses.append(float(vloss.detach()))
         labels.append((gold.clone(), hyp.clone()))

@@ -79,6 +79,57 @@ def disagreements(engine, pre):
     return n, worst
 
 
+def gates_from_engine(engine):
+    """The ReLU / max-pool decisions of the engine's LAST forward, in the layout oracle.refimpl's gate replay expects
+    (conv maps as (B,C,F,T); FFN masks as (rows, inner)).  Everything is copied to the host."""
+    A = engine.arena
+    g = {'conv0': _nhwc_to_ref(A['y1'] > 0), 'conv5': _nhwc_to_ref(A['y5'] > 0),
+         'am1': _nhwc_to_ref(A['am1']), 'pool1': _nhwc_to_ref(A['p1'] > 0),
+         'am2': _nhwc_to_ref(A['am2']), 'pool2': _nhwc_to_ref(A['p2'] > 0)}
+    for name, t in A.items():
+        if name.endswith('.ff.h1'):
+            g[name] = (t > 0).cpu()
+    return g
+
+
+class capture_gates:
+    """with capture_gates(model) as log: ... -> log = [gates of every forward in enqueue order] (every lane's engine).
+    The hook waits for the lane's stream, so lanes are serialised while capturing (test only)."""
+
+    def __init__(self, model):
+        self.model, self.log = model, []
+
+    def __enter__(self):
+        def hook(eng):
+            torch.cuda.current_stream(eng.device).synchronize()
+            self.log.append(gates_from_engine(eng))
+        for e in self.model.engines:
+            e.forward_hook = hook
+        return self.log
+
+    def __exit__(self, *exc):
+        for e in self.model.engines:
+            e.forward_hook = None
+        return False
+
+
+def gates_from_oracle_trace(pre):
+    """Same dict built from the ORACLE's own pre-activations (oracle_trace): replaying them must reproduce the free-running
+    oracle exactly -- pins relu_replay / pool_replay and the 2*(f&1)+(t&1) window encoding against F.max_pool2d."""
+    g = {'conv0': pre['conv0'] > 0, 'conv5': pre['conv5'] > 0}
+    for key, name in (('conv2', '1'), ('conv7', '2')):
+        z = pre[key]
+        p, idx = F.max_pool2d(torch.relu(z), 2, stride=2, return_indices=True)
+        T = z.shape[3]
+        f, t = idx // T, idx % T
+        g['am' + name] = (2 * (f & 1) + (t & 1)).to(torch.uint8)
+        g['pool' + name] = p > 0
+    for key, ref in pre.items():
+        if key.endswith('.ff'):
+            g[key + '.h1'] = ref.reshape(-1, ref.shape[-1]) > 0
+    return g
+
+
 def grad_tolerance(n_flips, worst_margin, clean=1e-4, flipped=1e-2):
     """1e-4 when HIP and oracle took identical branches; otherwise every disagreement must be a near-tie and the bound
     is the (documented) single-flip band."""

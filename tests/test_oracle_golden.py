@@ -132,3 +132,25 @@ def test_frontend_restatement_agrees_with_scipy_stft():
     ref = np.abs(Z) * win.sum()                                       # undo scipy's spectrum scaling
     assert mag.shape == ref.shape == (n_fft // 2 + 1, 1 + len(y) // hop)
     assert np.max(np.abs(mag - ref)) <= 2e-5 * np.max(ref)
+
+
+def test_gate_replay_of_the_oracles_own_decisions_is_exact():
+    """relu_replay / pool_replay (the branch-replay used by the 1e-4 GPU parity tests) fed with the oracle's OWN ReLU / max-pool
+    decisions must reproduce the free-running oracle: outputs, loss and every gradient tensor bit for bit (odd F and T so
+    the floor-mode pooling tails are exercised)."""
+    from tests import branches
+    z, cfg, spec = gu.load('F0')
+    m = R.build_model(cfg)
+    x, lens, y = R.synth_batch(11, 3, 70, 6, cfg['vocab_size'], True)
+    (pred, gold, hyp), pre = branches.oracle_trace(m, x, lens, y)
+    g0 = torch.autograd.grad(R.ce_loss(pred, gold), list(m.parameters()))
+    gates = branches.gates_from_oracle_trace(pre)
+    assert set(gates) == {'conv0', 'conv5', 'am1', 'am2', 'pool1', 'pool2', 'e0.ff.h1', 'd0.ff.h1'}
+    pred2, gold2, hyp2 = m(x, lens, y, gates=gates)
+    assert torch.equal(pred, pred2) and torch.equal(hyp, hyp2)
+    g1 = torch.autograd.grad(R.ce_loss(pred2, gold2), list(m.parameters()))
+    for a, b in zip(g0, g1):
+        assert torch.equal(a, b)
+    # a flipped gate changes the result (the replay is really consumed)
+    gates['conv5'] = ~gates['conv5']
+    assert not torch.equal(m(x, lens, y, gates=gates)[0], pred)

@@ -13,13 +13,15 @@ from tests import golden_util as gu
 
 pytestmark = pytest.mark.gpu
 RTOL = 1e-4          # north_star: fp32 loss and meta-gradients within 1e-4 relative
-FLIP_BAND = 1e-2     # bound when a ReLU / max-pool branch sits within fp32 rounding of its switching point (tests/branches.py)
-# fraction of the 190 (68) gradient tensors that must meet 1e-4 against the reference goldens; at the north-star size
-# ~10 near-tie branch flips per pass are expected between ANY two fp32 implementations, so only the band is asserted there
-CLEAN_FRACTION = {'F0': 0.6, 'F1': 0.9, 'NS': 0.0}
+# fraction of the 190 (68) gradient tensors that must meet 1e-4 against the reference GOLDENS, whose ReLU / max-pool decisions are
+# frozen in the file: ~20 near-tie branch flips per north-star pass are expected between ANY two fp32 implementations (measured
+# 154/190 at NS, 186/190 at F1).  The 1e-4 bar on ALL tensors is asserted against the live oracle with the device path's own
+# decisions replayed (test_single_pass_at_north_star_size_against_live_oracle, test_meta_gradient_at_north_star_size_...).
+CLEAN_FRACTION = {'F0': 0.6, 'F1': 0.9, 'NS': 0.7}
 # F0 is zero-padded (variable lengths): its padded region is a constant feature map, so a near-tie there flips a whole
 # region at once (second iteration, after a 1e-3 Adam step); F1 (the real architecture) must stay inside 1e-2.
 GOLDEN_BAND = {'F0': 5e-2, 'F1': 1e-2, 'NS': 1e-2}
+NS_FLIP_BOUND = 120   # free-running ReLU / max-pool near-tie disagreements per north-star pass (measured ~25 of ~250 M branch points)
 
 
 def make(cfg, spec, name='parity'):
@@ -97,8 +99,19 @@ def _set_oracle_params(oracle, model, flat):
             p.copy_(model._layout.view(flat, nm).cpu())
 
 
-def _pass_parity(model, oracle, batch, theta, what):
-    """One forward+backward of both implementations at IDENTICAL parameters; branch-aware gradient comparison."""
+def _rel_errs(model, flat_g, oracle, grads):
+    """per-tensor relative L2 error of the flat HIP gradient vs the oracle's list; exactly-zero tensors (key-projection biases:
+    softmax is shift-invariant) are measured against 1e-4 of the global gradient norm"""
+    gn = float(torch.sqrt(sum((t.double() ** 2).sum() for t in grads)))
+    return {nm: float((model._layout.view(flat_g, nm).cpu() - t).norm() / max(float(t.norm()), 1e-4 * gn))
+            for (nm, _), t in zip(oracle.named_parameters(), grads)}
+
+
+def _pass_parity(model, oracle, batch, theta, what, max_flips=8):
+    """One forward+backward of both implementations at IDENTICAL parameters.
+    (1) free-running oracle: labels bit-exact, logits / loss, and the census of ReLU / max-pool decisions that differ (each
+        must be a provable rounding near-tie, and there must be few);
+    (2) oracle with the HIP pass's own branch decisions replayed (oracle.refimpl gates=): EVERY gradient tensor within 1e-4."""
     from oracle import refimpl as R
     from tests import branches
     x, lens, y = batch
@@ -106,21 +119,26 @@ def _pass_parity(model, oracle, batch, theta, what):
     out = model.pass_forward(x.cuda(), lens, y, theta=theta)
     g = torch.zeros_like(model.flat_grad)
     model.pass_backward(g, 1.0)
-    (pred_r, gold_r, hyp_r), pre = branches.oracle_trace(oracle, x, lens, y)
-    loss_r = R.ce_loss(pred_r, gold_r)
-    grads = torch.autograd.grad(loss_r, list(oracle.parameters()))
+    gates = branches.gates_from_engine(model.engine)
+    with torch.no_grad():
+        (pred_r, gold_r, hyp_r), pre = branches.oracle_trace(oracle, x, lens, y)
+        loss_r = R.ce_loss(pred_r, gold_r)
     assert torch.equal(out['hyp'].cpu(), hyp_r) and torch.equal(out['gold'].cpu(), gold_r), what   # bit-exact labels
     assert float((out['pred'].cpu() - pred_r).norm() / pred_r.norm()) < 1e-5, what
     assert abs(float(out['loss']) - float(loss_r)) < RTOL * float(loss_r), what
     flips, margin = branches.disagreements(model.engine, pre)
-    tol = branches.grad_tolerance(flips, margin, RTOL, FLIP_BAND)
-    gn = float(torch.sqrt(sum((t.double() ** 2).sum() for t in grads)))
-    worst = 0.0
-    for (nm, _), t in zip(oracle.named_parameters(), grads):
-        err = float((model._layout.view(g, nm).cpu() - t).norm() / max(float(t.norm()), 1e-4 * gn))
-        worst = max(worst, err)
-        assert err < tol, (what, nm, err, flips)
-    print('%s: %d branch flips (margin %.1e), worst gradient rel err %.2e' % (what, flips, margin, worst))
+    assert flips <= max_flips, (what, flips)
+    assert flips == 0 or margin < branches.NEAR_TIE, (what, flips, margin)
+    del pre
+    pred_g, gold_g, hyp_g = oracle(x, lens, y, gates=gates)
+    loss_g = R.ce_loss(pred_g, gold_g)
+    grads = torch.autograd.grad(loss_g, list(oracle.parameters()))
+    assert torch.equal(hyp_g, hyp_r) and abs(float(loss_g) - float(loss_r)) < 1e-6 * float(loss_r), what
+    errs = _rel_errs(model, g, oracle, grads)
+    worst = max(errs, key=errs.get)
+    print('%s: %d branch near-ties decided differently (margin %.1e); %d/%d gradient tensors within 1e-4, worst %.2e (%s)'
+          % (what, flips, margin, sum(e < RTOL for e in errs.values()), len(errs), errs[worst], worst))
+    assert errs[worst] < RTOL, (what, worst, errs[worst], flips)
     return g, flips
 
 
@@ -152,6 +170,9 @@ def test_every_pass_of_a_meta_step_against_live_oracle(name):
 
 
 def test_single_pass_at_north_star_size_against_live_oracle():
+    """190/190 gradient tensors within 1e-4 at the north-star size (k=8, T=1000, L=100, enc2/dec4 d512) with the HIP pass's
+    ~250 M ReLU / max-pool decisions replayed in the oracle; the free-running census bounds how many of them differ (DESIGN 4:
+    ~25 per pass, all rounding near-ties)."""
     from oracle import refimpl as R
     z, cfg, spec = gu.load('NS')
     mtl_amd, args, vocab, model = make(cfg, spec)
@@ -159,7 +180,42 @@ def test_single_pass_at_north_star_size_against_live_oracle():
     torch.set_num_threads(min(32, torch.get_num_threads()))
     oracle = R.build_model(cfg)
     batch = R.synth_batch(0, spec['k'], spec['T'], spec['L'], cfg['vocab_size'], False)
-    _pass_parity(model, oracle, batch, model.flat_parameters, 'NS single pass')
+    _pass_parity(model, oracle, batch, model.flat_parameters, 'NS single pass', max_flips=NS_FLIP_BOUND)
+
+
+def test_meta_gradient_at_north_star_size_with_branch_replay():
+    """BASELINE.json configs[1] at full size: the 3-task meta-gradient G of TransientTrainer.meta_iteration (task lanes, side
+    stream, fused inner step) against the LIVE oracle's G = sum_m [g_tr,m + g_val,m / n] computed with its own inner steps and
+    the device path's branch decisions of all six passes replayed: 190/190 tensors within 1e-4, losses within 1e-4, labels
+    bit-exact."""
+    from oracle import refimpl as R
+    from tests import branches
+    z, cfg, spec = gu.load('NS')
+    mtl_amd, args, vocab, model = make(cfg, spec)
+    model = model.cuda()
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    oracle = R.build_model(cfg)
+    n = spec['n_tasks']
+    tr = [R.synth_batch(10 * m, spec['k'], spec['T'], spec['L'], cfg['vocab_size'], False) for m in range(n)]
+    val = R.synth_batch(10 * (n - 1) + 1, spec['k'], spec['T'], spec['L'], cfg['vocab_size'], False)
+    inner = mtl_amd.FlatSGD(model, spec['lr'])
+    model.zero_copy_grad()
+    as5 = lambda b: (b[0], b[1], None, b[2], None)
+    trainer = mtl_amd.TransientTrainer()
+    with branches.capture_gates(model) as log:
+        reads = trainer.meta_iteration(model, vocab, [as5(b) for b in tr], as5(val), n, inner, None, args)
+        torch.cuda.synchronize()
+    assert len(log) == 2 * n
+    G_r, trl, val_l, labels = R.meta_gradient(oracle, tr, val, spec['lr'], gates=log)
+    for m, (rd_tr, rd_va) in enumerate(reads):
+        for rd, (gold, hyp), loss in ((rd_tr, labels[2 * m], trl[m]), (rd_va, labels[2 * m + 1], val_l[m])):
+            assert torch.equal(rd.hyp, hyp) and torch.equal(rd.gold_host, gold)
+            assert abs(float(rd.loss[0]) - loss) < RTOL * loss
+    errs = _rel_errs(model, model._G, oracle, G_r)
+    worst = max(errs, key=errs.get)
+    print('NS 3-task meta-gradient: %d/%d tensors within 1e-4, worst %.2e (%s)'
+          % (sum(e < RTOL for e in errs.values()), len(errs), errs[worst], worst))
+    assert len(errs) == 190 and errs[worst] < RTOL, (worst, errs[worst])
 
 
 def test_dropin_autograd_api_matches_oracle():
@@ -175,7 +231,8 @@ def test_dropin_autograd_api_matches_oracle():
     pred, gold, hyp = model(x.cuda(), lens, y)
     loss, ncorrect = mtl_amd.calculate_metrics(pred, gold, 0, smoothing=0.0, loss_type='ce')
     (loss / 3).backward()
-    pr, gr, hr = oracle(x, lens, y)
+    from tests import branches
+    pr, gr, hr = oracle(x, lens, y, gates=branches.gates_from_engine(model.engine))
     lref = R.ce_loss(pr, gr)
     (lref / 3).backward()
     assert abs(float(loss) - float(lref)) < RTOL * float(lref)
@@ -258,22 +315,23 @@ def test_clip_and_label_smoothing_meta_step_against_oracle():
     args.clip, args.max_norm = True, 3.0
     oracle = R.build_model(cfg)
     tr, val = gu.batches_for(cfg, spec, 0, z['data_call_index'])
-    G_r, _, _, _ = R.meta_gradient(oracle, tr, val, spec['lr'], max_norm=3.0)
+    from tests import branches
     inner = mtl_amd.FlatSGD(model, spec['lr'])
     model.zero_copy_grad()
     as5 = lambda b: (b[0], b[1], None, b[2], None)
-    mtl_amd.TransientTrainer().meta_iteration(model, vocab, [as5(b) for b in tr], as5(val), len(tr), inner, None, args)
-    gn = float(torch.sqrt(sum((g.double() ** 2).sum() for g in G_r)))
-    errs = [float((model._layout.view(model._G, nm).cpu() - g).norm() / max(float(g.norm()), 1e-4 * gn))
-            for (nm, _), g in zip(oracle.named_parameters(), G_r)]
-    assert max(errs) < FLIP_BAND and sum(e < RTOL for e in errs) >= 0.6 * len(errs), max(errs)
+    with branches.capture_gates(model) as log:
+        mtl_amd.TransientTrainer().meta_iteration(model, vocab, [as5(b) for b in tr], as5(val), len(tr), inner, None, args)
+        torch.cuda.synchronize()
+    G_r, _, _, _ = R.meta_gradient(oracle, tr, val, spec['lr'], max_norm=3.0, gates=log)
+    errs = _rel_errs(model, model._G, oracle, G_r)
+    assert max(errs.values()) < RTOL, max(errs.items(), key=lambda kv: kv[1])
     # label smoothing: loss + gradient of one pass against the reference formula restated in torch
     eps = 0.1
     x, lens, y = tr[0]
     out = model.pass_forward(x.cuda(), lens, y, smoothing=eps)
     g = torch.zeros_like(model.flat_grad)
     model.pass_backward(g, 1.0)
-    pred, gold, _ = oracle(x, lens, y)
+    pred, gold, _ = oracle(x, lens, y, gates=branches.gates_from_engine(model.engine))
     V = pred.size(2)
     p2, g2 = pred.view(-1, V), gold.view(-1)
     mask = g2.ne(0)
@@ -282,10 +340,8 @@ def test_clip_and_label_smoothing_meta_step_against_oracle():
     loss = -(one_hot * F.log_softmax(p2, dim=1)).sum(1).masked_select(mask).sum() / int(mask.sum())
     grads = torch.autograd.grad(loss, list(oracle.parameters()))
     assert abs(float(out['loss']) - float(loss)) < RTOL * float(loss)
-    gn = float(torch.sqrt(sum((t.double() ** 2).sum() for t in grads)))
-    errs = [float((model._layout.view(g, nm).cpu() - t).norm() / max(float(t.norm()), 1e-4 * gn))
-            for (nm, _), t in zip(oracle.named_parameters(), grads)]
-    assert max(errs) < FLIP_BAND and sum(e < RTOL for e in errs) >= 0.9 * len(errs), max(errs)
+    errs = _rel_errs(model, g, oracle, grads)
+    assert max(errs.values()) < RTOL, max(errs.items(), key=lambda kv: kv[1])
 
 
 def test_long_utterance_stress_config():
@@ -364,16 +420,15 @@ def test_dropout_pass_matches_oracle_with_the_same_masks():
     assert len(drop) == 3 * cfg['num_enc_layers'] + 5 * cfg['num_dec_layers'] + 1
     keep_rate = float(torch.cat([v.reshape(-1) for v in drop.values()]).gt(0).float().mean())
     assert abs(keep_rate - 0.9) < 0.01
-    pred_r, gold_r, hyp_r = oracle(x, lens, y, drop=drop)
+    from tests import branches
+    pred_r, gold_r, hyp_r = oracle(x, lens, y, drop=drop, gates=branches.gates_from_engine(model.engine))
     loss_r = R.ce_loss(pred_r, gold_r)
     grads = torch.autograd.grad(loss_r, list(oracle.parameters()))
     assert torch.equal(out['hyp'].cpu(), hyp_r)
     assert float((out['pred'].cpu() - pred_r).norm() / pred_r.norm()) < 1e-5
     assert abs(float(out['loss']) - float(loss_r)) < RTOL * float(loss_r)
-    gn = float(torch.sqrt(sum((t.double() ** 2).sum() for t in grads)))
-    errs = [float((model._layout.view(g, nm).cpu() - t).norm() / max(float(t.norm()), 1e-4 * gn))
-            for (nm, _), t in zip(oracle.named_parameters(), grads)]
-    assert max(errs) < FLIP_BAND and sum(e < RTOL for e in errs) >= 0.9 * len(errs), max(errs)
+    errs = _rel_errs(model, g, oracle, grads)
+    assert max(errs.values()) < RTOL, max(errs.items(), key=lambda kv: kv[1])
     # fresh masks on the next pass, none in eval mode
     m0 = A['dec_in.me'].clone()
     model.pass_forward(x.cuda(), lens, y)
