@@ -224,6 +224,7 @@ def main():
                                         '(%d per GPU), k_train=k_valid=%d, %d frames x 161 bins, %d labels, dropout 0'
                                         % (a.tasks, len(my_tasks), a.k, a.frames, a.labels),
                                tasks=a.tasks, k_train=a.k, src_frames=a.frames, tgt_len=a.labels, parallelism='task-sharded dp%d' % world,
+                               collective=mdist.backend_name(),
                                conv_arithmetic=('3x3 convolutions as exact 3-way bf16 splits of fp32 operands, fp32 accumulate '
                                                 '(fp32-class error, same test tolerances as the fp32-MFMA kernels)'
                                                 if model.engine.conv_x3 else 'fp32 MFMA')),

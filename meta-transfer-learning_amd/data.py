@@ -96,9 +96,13 @@ class ManifestTaskDataset:
     """`.sample(k_train, k_valid, manifest_id)` over manifest CSVs like SpectrogramDataset (utils/data_loader.py:171-321).
 
     feature_fn(wav_path) -> (F, T) float tensor replaces `parse_audio`; sampling uses np.random.choice with the same
-    per-manifest probabilities (uniform, or uniform over the leading `partitions[i]` fraction)."""
+    per-manifest probabilities (uniform, or uniform over the leading `partitions[i]` fraction).
+    seed=None draws from the global np.random like the reference (seeded once by the entry script,
+    meta_transfer_train.py:109-112); seed=<int> gives the dataset its own RandomState -- with several ranks every rank must
+    see the same draws (tasks are sharded AFTER sampling, the validation batch is shared), so pass the same seed on all ranks.
+    `__getitem__` / `__len__` follow utils/data_loader.py:323-340 (validation / test use: manifest 0 only unless is_train)."""
 
-    def __init__(self, vocab, args, manifest_filepath_list, feature_fn=None, partitions=None):
+    def __init__(self, vocab, args, manifest_filepath_list, feature_fn=None, partitions=None, seed=None, is_train=False):
         if feature_fn is None:
             # default: 16-bit PCM wav -> device spectrogram front-end (SpectrogramParser.parse_audio, normalize=True as in
             # meta_transfer_train.py:161), handed back on the host like the reference's parse_audio output
@@ -106,6 +110,11 @@ class ManifestTaskDataset:
             feature_fn = lambda path: fe(load_wav_pcm16(path)).cpu()
         self.vocab, self.args, self.feature_fn = vocab, args, feature_fn
         self.ids_list = [read_manifest(p) for p in manifest_filepath_list]
+        self.rng = np.random if seed is None else np.random.RandomState(seed)
+        self.is_train = is_train
+        self.max_size = max(len(ids) for ids in self.ids_list) * len(self.ids_list)
+        if is_train and len(self.ids_list) > 1:
+            self.max_size = 30000                                   # utils/data_loader.py:198-203
         self.proba = []
         for i, ids in enumerate(self.ids_list):
             if partitions is not None:
@@ -126,10 +135,41 @@ class ManifestTaskDataset:
 
     def sample(self, k_train, k_val, manifest_id):
         ids = self.ids_list[manifest_id]
-        picks = np.random.choice(np.arange(0, len(ids)), k_train + k_val, p=self.proba[manifest_id], replace=True)
+        picks = self.rng.choice(np.arange(0, len(ids)), k_train + k_val, p=self.proba[manifest_id], replace=True)
         tr = collate(*self._rows(ids, picks[:k_train]), pad_id=self.vocab.PAD_ID)
         va = collate(*self._rows(ids, picks[k_train:k_train + k_val]), pad_id=self.vocab.PAD_ID)
         return tr, va
+
+
+    def __len__(self):
+        return self.max_size
+
+    def __getitem__(self, index):
+        if self.is_train:
+            ids = self.ids_list[index % len(self.ids_list)]
+            row = ids[(index // len(self.ids_list)) % len(ids)]
+        else:
+            ids = self.ids_list[0]
+            row = ids[index % len(ids)]
+        return self.feature_fn(row[0])[:, :self.args.src_max_len], parse_transcript(self.vocab, row[1])
+
+
+class AudioDataLoader(torch.utils.data.DataLoader):
+    """utils/data_loader.py:401-440: a DataLoader over (spectrogram (F,T), transcript ids) items whose batches are sorted by
+    descending frame count, zero-padded to the longest utterance / PAD-padded to the longest transcript, and returned as
+    (inputs (B,1,F,T), targets (B,L) int64, input_percentages (B) f32, input_sizes (B) i32, target_sizes (B) i32) -- the layout
+    the in-loop validation of TransientTrainer / JointTrainer consumes."""
+
+    def __init__(self, pad_token_id, *args, **kwargs):
+        self.pad_token_id = pad_token_id
+        kwargs['collate_fn'] = self._collate
+        super().__init__(*args, **kwargs)
+
+    def _collate(self, batch):
+        batch = sorted(batch, key=lambda sample: sample[0].size(1), reverse=True)
+        inputs, input_sizes, input_percentages, targets, target_sizes = collate(
+            [s for s, _ in batch], [t for _, t in batch], pad_id=self.pad_token_id)
+        return inputs, targets, input_percentages, input_sizes, target_sizes
 
 
 def synth_batch(seed, k, T, L, vocab_size, variable=False, freq_bins=161):

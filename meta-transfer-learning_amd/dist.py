@@ -23,10 +23,20 @@ def world_size():
     return td.get_world_size() if is_on() else 1
 
 
+def _always():
+    """MTL_DIST_ALWAYS=1: build the process group and issue the collectives even with ONE rank (lets a 1-GPU box execute the
+    RCCL path end to end: tests/test_trainer_gpu.py::test_rccl_collective_path_executes)."""
+    return os.environ.get('MTL_DIST_ALWAYS', '0') == '1'
+
+
+def backend_name():
+    return td.get_backend() if is_on() else 'none'
+
+
 def init_from_env(backend=None):
     """Initialise from torchrun's RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*; no-op for a single process."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    if world <= 1 or is_on():
+    if (world <= 1 and not (_always() and 'RANK' in os.environ)) or is_on():
         lr_ = int(os.environ.get('LOCAL_RANK', '0'))
         return lr_ % torch.cuda.device_count() if torch.cuda.is_available() else lr_
     local = int(os.environ.get('LOCAL_RANK', '0'))
@@ -48,7 +58,7 @@ def shard_tasks(n_tasks, rank_, world):
 
 def allreduce_sum_(flat):
     """In-place SUM all-reduce of the flat meta-gradient (56 MB at the north-star size): one collective per meta-step."""
-    if is_on() and world_size() > 1:
+    if is_on() and (world_size() > 1 or _always()):
         td.all_reduce(flat, op=td.ReduceOp.SUM)
     return flat
 

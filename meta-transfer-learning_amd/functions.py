@@ -5,13 +5,10 @@ Mirrors utils/functions.py: `init_transformer_model` (:307-351), `save_meta_mode
 {'vocab','args','epoch','model_state_dict','inner_opt','outer_opt','metrics'} with torch.optim objects pickled
 whole, so files are interchangeable with reference-trained models.
 """
-import contextlib
 import logging
 import math
 import os
 import pickle
-import sys
-import types
 
 import torch
 
@@ -62,8 +59,23 @@ def save_meta_model(model, vocab, epoch, inner_opt, outer_opt, metrics, args, be
     params = [torch.nn.Parameter(state[n], requires_grad=True) for n, _ in model.named_parameters()]
     payload = {'vocab': vocab, 'args': args, 'epoch': epoch, 'model_state_dict': state,
                'inner_opt': _export_opt(inner_opt, params), 'outer_opt': _export_opt(outer_opt, params), 'metrics': metrics}
-    with _vocab_as_reference_class(vocab):
-        torch.save(payload, save_path)
+    torch.save(payload, save_path, pickle_module=_ref_path_pickle)
+    return save_path
+
+
+def save_joint_model(model, vocab, epoch, opt, metrics, args, best_model=False):
+    """utils/functions.py:43-71: the joint-training `.th` dict ('vocab', 'args', 'epoch', 'model_state_dict', 'opt', 'metrics'),
+    written like save_meta_model so that both stacks read it."""
+    folder = '{}/{}'.format(args.save_folder, args.name)
+    save_path = folder + ('/best_model.th' if best_model else '/epoch_{}.th'.format(epoch))
+    os.makedirs(folder, exist_ok=True)
+    print('SAVE MODEL to', save_path)
+    logging.info('SAVE MODEL to ' + save_path)
+    state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    params = [torch.nn.Parameter(state[n], requires_grad=True) for n, _ in model.named_parameters()]
+    payload = {'vocab': vocab, 'args': args, 'epoch': epoch, 'model_state_dict': state, 'opt': _export_opt(opt, params),
+               'metrics': metrics}
+    torch.save(payload, save_path, pickle_module=_ref_path_pickle)
     return save_path
 
 
@@ -80,30 +92,38 @@ def _export_opt(opt, params):
     return out
 
 
-@contextlib.contextmanager
-def _vocab_as_reference_class(vocab):
-    """While pickling, this package's Vocab answers to the reference's global name `utils.data.Vocab` (pickle verifies a
-    class by importing its module, so a stand-in module is registered for the duration of the dump)."""
-    from .data import Vocab
-    if type(vocab) is not Vocab:
-        yield
-        return
-    saved = {k: sys.modules.get(k) for k in ('utils', 'utils.data')}
-    old_module = Vocab.__module__
-    pkg = saved['utils'] if saved['utils'] is not None else types.ModuleType('utils')
-    mod = types.ModuleType('utils.data')
-    mod.Vocab = Vocab
-    sys.modules['utils'], sys.modules['utils.data'] = pkg, mod
-    Vocab.__module__ = 'utils.data'
-    try:
-        yield
-    finally:
-        Vocab.__module__ = old_module
-        for k, v in saved.items():
-            if v is None:
-                sys.modules.pop(k, None)
-            else:
-                sys.modules[k] = v
+class _RefPathPickler(pickle._Pickler):
+    """Pickles this package's `Vocab` CLASS under the reference's global name `utils.data.Vocab` (which the reference resolves
+    to its own class and `load_*_model` here back to this package's).  The opcode is written directly, so nothing process-global
+    (sys.modules, Vocab.__module__) is touched while the trainer's prefetch thread or a user feature_fn may be importing.
+    Pure-Python pickler: only the small object graph goes through it, tensor storages are written by torch.save itself."""
+
+    def save_global(self, obj, name=None):
+        from .data import Vocab
+        if obj is Vocab:
+            self.write(pickle.GLOBAL + b'utils.data\nVocab\n')
+            self.memoize(obj)
+            return
+        super().save_global(obj, name)
+
+
+class _ref_path_pickle:                 # the `pickle_module` duck-type torch.save expects
+    __name__ = 'pickle'
+    Pickler = _RefPathPickler
+    Unpickler = pickle.Unpickler
+    load, loads = pickle.load, pickle.loads
+    HIGHEST_PROTOCOL, DEFAULT_PROTOCOL = pickle.HIGHEST_PROTOCOL, pickle.DEFAULT_PROTOCOL
+
+    @staticmethod
+    def dump(obj, f, protocol=None, **kw):
+        _RefPathPickler(f, protocol).dump(obj)
+
+    @staticmethod
+    def dumps(obj, protocol=None, **kw):
+        import io
+        buf = io.BytesIO()
+        _RefPathPickler(buf, protocol).dump(obj)
+        return buf.getvalue()
 
 
 class _CompatUnpickler(pickle.Unpickler):
@@ -145,3 +165,16 @@ def load_meta_model(load_path, train=True):
     inner_opt.load_state_dict(ckpt['inner_opt'].state_dict())
     outer_opt.load_state_dict(ckpt['outer_opt'].state_dict())
     return model, vocab, inner_opt, outer_opt, ckpt['epoch'], ckpt['metrics'], args
+
+
+def load_joint_model(load_path, train=True):
+    """utils/functions.py:190-218 -> (model, vocab, opt, epoch, metrics, args); the optimizer comes back as torch.optim.Adam."""
+    ckpt = load_checkpoint_dict(load_path)
+    args, vocab = ckpt['args'], ckpt['vocab']
+    model = init_transformer_model(args, vocab, train=train, is_factorized=getattr(args, 'is_factorized', False),
+                                   r=getattr(args, 'r', 100))
+    model.load_state_dict(ckpt['model_state_dict'])
+    model = model.cuda() if getattr(args, 'cuda', False) and torch.cuda.is_available() else model.cpu()
+    opt = torch.optim.Adam(model.parameters(), lr=args.lr)
+    opt.load_state_dict(ckpt['opt'].state_dict())
+    return model, vocab, opt, ckpt['epoch'], ckpt['metrics'], args

@@ -138,20 +138,6 @@ class _ModelFn(torch.autograd.Function):
         return None, None, None, None, None
 
 
-class _LossFn(torch.autograd.Function):
-    """CE loss of the model's own pred tensor: forward value from the fused CE kernel, backward = full HIP backward."""
-
-    @staticmethod
-    def forward(ctx, pred, model):
-        ctx.model = model
-        ctx.token = model._pass_token
-        return model._last['loss'].clone().reshape(())
-
-    @staticmethod
-    def backward(ctx, gout):
-        return ctx.model._ce_backward_into_pred(gout, ctx.token), None
-
-
 class Transformer(nn.Module):
     def __init__(self, encoder, decoder, vocab, feat_extractor='vgg_cnn', train=True, is_factorized=False, r=100):
         super().__init__()
@@ -271,22 +257,6 @@ class Transformer(nn.Module):
         """(B,1,F,T) fp32, (B) int, (B,L) int64 PAD=0  ->  pred (B,L+1,V), gold (B,L+1), hyp (B,L+1)
         Same contract as models/asr/transformer.py:120-149."""
         return _ModelFn.apply(self._anchor, self, padded_input, input_lengths, padded_target)
-
-    def loss_from_last_forward(self, pred):
-        """CE loss tensor of the last forward (utils/metrics.py:126 semantics) wired to the fused HIP backward."""
-        return _LossFn.apply(pred, self)
-
-    def _ce_backward_into_pred(self, gout, token):
-        if token != self._pass_token:
-            raise RuntimeError('backward through a stale forward')
-        eng, A, S = self.engine, self.engine.arena, self.engine.saved
-        Md, V = A['pred'].shape[0] * A['pred'].shape[1], A['pred'].shape[2]
-        dpred = torch.empty_like(A['pred'])
-        gold_ptr = S['meta']['ids'].data_ptr() + 8 * Md
-        g = gout.reshape(1).to(torch.float32).contiguous()
-        check(eng.lib.mtl_ce_bwd(eng.stream, A['pred'].data_ptr(), A['lse'].data_ptr(), gold_ptr, Md, V, V, 0, S['smoothing'],
-                                 1.0 / S['n_nonpad'], g.data_ptr(), dpred.data_ptr(), V), 'ce_bwd')
-        return dpred
 
     # fast path used by the trainer: no autograd objects at all
     def pass_forward(self, x, lengths, target, theta=None, smoothing=0.0, lane=0):

@@ -21,8 +21,8 @@ import torch
 
 from . import _lib, dist as mdist
 from .engine import PAD_ID, decoder_io
-from .functions import post_process, save_meta_model
-from .metrics import calculate_cer
+from .functions import post_process, save_joint_model, save_meta_model
+from .metrics import calculate_cer, calculate_metrics
 
 check = _lib.check
 
@@ -110,13 +110,28 @@ def clip_flat_grad_(model, grad, max_norm, lane=0):
     check(eng.lib.mtl_scale(st, grad.data_ptr(), 1.0, coef.data_ptr(), grad.numel()), 'mtl_scale')
 
 
-class _Readback:
-    """Asynchronous D2H of (gold, hyp, loss) of one forward; resolved after the iteration's single sync."""
+_PINNED = {}
 
-    def __init__(self, out, stream_device):
+
+def _pinned(key, shape, dtype):
+    """Page-locked host buffer cached per (call site, shape): pin_memory() costs a host allocation + registration per call, and
+    the read-backs of one iteration are only consumed after that iteration's device sync, so the buffers can be re-used."""
+    k = (key, tuple(shape), dtype)
+    t = _PINNED.get(k)
+    if t is None:
+        t = torch.empty(tuple(shape), dtype=dtype).pin_memory()
+        _PINNED[k] = t
+    return t
+
+
+class _Readback:
+    """Asynchronous D2H of (gold, hyp, loss) of one forward; resolved after the iteration's single sync.  `key` names the
+    call site (task index, pass) whose pinned buffers are re-used from iteration to iteration."""
+
+    def __init__(self, out, key):
         self.gold_host = out['gold_host']
-        self.hyp = torch.empty(out['hyp'].shape, dtype=torch.int64).pin_memory()
-        self.loss = torch.empty(1, dtype=torch.float32).pin_memory()
+        self.hyp = _pinned(('hyp', key), out['hyp'].shape, torch.int64)
+        self.loss = _pinned(('loss', key), (1,), torch.float32)
         self.hyp.copy_(out['hyp'], non_blocking=True)
         self.loss.copy_(out['loss'], non_blocking=True)
 
@@ -136,6 +151,105 @@ def cer_counts(vocab, gold, hyp):
     return total_cer, total_char
 
 
+def sync_replicas_from_rank0(model, opts):
+    """Multi-rank start-up: broadcast theta and every optimizer's state (Adam m, v, step count) from rank 0, so that replicas are
+    bit-identical whatever each rank's RNG / checkpoint state was.  From then on they stay identical by construction (same G
+    after the all-reduce, deterministic Adam kernel); check_replicas() verifies that periodically."""
+    if mdist.world_size() <= 1:
+        return
+    import torch.distributed as td
+    td.broadcast(model.flat_parameters, src=0)
+    for opt in opts:
+        if isinstance(opt, FlatAdam):
+            td.broadcast(opt.m, src=0)
+            td.broadcast(opt.v, src=0)
+            step = torch.tensor([opt.step_count], dtype=torch.int64, device=model.flat_parameters.device)
+            td.broadcast(step, src=0)
+            opt.step_count = int(step.item())
+
+
+def check_replicas(model, val_batch, it):
+    """Cheap divergence check (two 3-element all-reduces): every rank must hold the same theta and must have drawn the same
+    shared validation batch (ManifestTaskDataset(seed=...) / the seeding contract in INTEGRATION.md).  Raises on a mismatch
+    instead of letting the all-reduced meta-gradient silently mix gradients taken at different parameters."""
+    if mdist.world_size() <= 1:
+        return
+    import torch.distributed as td
+    th = model.flat_parameters
+    vx = val_batch[0]
+    probe = torch.stack([th.double().sum(), th[::997].double().abs().sum(),
+                         vx.to(th.device, non_blocking=True).double().sum() + float(val_batch[3].sum())])
+    lo, hi = probe.clone(), probe.clone()
+    td.all_reduce(lo, op=td.ReduceOp.MIN)
+    td.all_reduce(hi, op=td.ReduceOp.MAX)
+    if not torch.equal(lo, hi):
+        raise RuntimeError('iteration %d: replicas diverged (theta / validation-batch checksums differ across ranks: %s vs %s); '
+                           'seed every rank identically (see INTEGRATION.md)' % (it + 1, lo.tolist(), hi.tolist()))
+
+
+def run_validation(forward_one_batch, model, vocab, valid_loader_list, it, args, history, loss_type, save_fn, criteria, stop_val,
+                   best, count_stop, rank):
+    """The in-loop validation of both trainers (transient_trainer.py:280-360, joint_trainer.py:306-380): eval mode, no autograd,
+    `forward_one_batch` over every batch of every loader (AudioDataLoader layout: src, trg, percentages, src_lengths,
+    trg_lengths), per-loader loss = mean over batches, CER = edits*100/chars, metrics dict + history, save every
+    args.save_every iterations, best-model save and early-stop counter on the chosen criterion.
+    save_fn(metrics, best_model) writes a checkpoint (rank 0 only).  -> (stop, best, count_stop)"""
+    say = print if rank == 0 else (lambda *a, **k: None)
+    say('')
+    logging.info('VALID')
+    smoothing = float(getattr(args, 'label_smoothing', 0.0) or 0.0)
+    dev = model.flat_parameters.device
+    model.eval()
+    final_losses, final_cers = [], []
+    try:
+        with torch.no_grad():
+            for ind, loader in enumerate(valid_loader_list):
+                tot_loss, tot_cer, tot_char, nb = 0.0, 0, 0, 0
+                for data in loader:
+                    src, trg, pct, src_lengths, trg_lengths = data
+                    if getattr(args, 'cuda', True):
+                        src, trg = src.to(dev), trg.to(dev)
+                    loss, cer, nchar = forward_one_batch(model, vocab, src, trg, pct, src_lengths, trg_lengths, smoothing, loss_type)
+                    tot_cer += cer
+                    tot_char += nchar
+                    tot_loss += loss.item()
+                    nb += 1
+                final_losses.append(tot_loss / max(nb, 1))
+                final_cers.append(tot_cer * 100 / max(tot_char, 1))
+                msg = '(Iteration {}) VALID SET {} LOSS:{:.4f} CER:{:.2f}%'.format((it + 1), ind, final_losses[-1], final_cers[-1])
+                say(msg)
+                logging.info(msg)
+    finally:
+        model.train()
+    if not final_losses:
+        return False, best, count_stop
+    metrics = {'avg_valid_loss': sum(final_losses) / len(final_losses), 'avg_valid_cer': sum(final_cers) / len(final_cers),
+               'valid_loss': final_losses, 'valid_cer': final_cers, 'history': history}
+    history.append(metrics)
+    msg = '(Iteration {}) AVG VALID LOSS:{:.4f} AVG CER:{:.2f}%'.format((it + 1), metrics['avg_valid_loss'], metrics['avg_valid_cer'])
+    say(msg)
+    logging.info(msg)
+    if rank == 0 and (it + 1) % args.save_every == 0:
+        save_fn(metrics, False)
+    cur = metrics['avg_valid_cer'] if criteria == 'cer' else metrics['avg_valid_loss']
+    say('CRITERIA: CER' if criteria == 'cer' else 'CRITERIA: LOSS')
+    if best > cur:
+        count_stop, best = 0, cur
+        if rank == 0:
+            save_fn(metrics, True)
+    else:
+        count_stop += 1
+        say('count_stop:', count_stop)
+    if count_stop >= stop_val:
+        logging.info('EARLY STOP')
+        say('EARLY STOP\n')
+        return True, best, count_stop
+    return False, best, count_stop
+
+
+MAX_CONSECUTIVE_FAILURES = 20
+
+
 class TransientTrainer():
     def __init__(self):
         logging.info('Transient Trainer is initialized')
@@ -150,14 +264,15 @@ class TransientTrainer():
     # ------------------------------------------------------------------ drop-in single-batch API
     def forward_one_batch(self, model, vocab, src, trg, src_percentages, src_lengths, trg_lengths, smoothing, loss_type,
                           verbose=False):
-        """-> (loss tensor, total_cer, total_char); `loss.backward()` runs the HIP backward (transient_trainer.py:25-73)."""
+        """-> (loss tensor, total_cer, total_char); `loss.backward()` runs the HIP backward (transient_trainer.py:25-73).
+        Same steps as the reference: model forward, calculate_metrics (label smoothing included), CER of the post-processed
+        strings; the ~2*B*T per-element `int(x)` device syncs become one D2H copy of gold / hyp."""
         if loss_type != 'ce':
             raise NotImplementedError("only loss_type='ce' is on the accelerated path")
         pred, gold, hyp = model(src, src_lengths, trg, verbose=False)
-        if smoothing and smoothing > 0:
-            raise NotImplementedError('label smoothing is available through train() (fused pass), not this compatibility call')
-        src_percentages.mul_(int(pred.size(1)))     # SURVEY Q6: the reference scales the caller's tensor in place
-        loss = model.loss_from_last_forward(pred)
+        sizes = src_percentages.mul_(int(pred.size(1))).int()     # SURVEY Q6: the reference scales the caller's tensor in place
+        loss, _ = calculate_metrics(pred, gold, vocab.PAD_ID, input_lengths=sizes, target_lengths=trg_lengths,
+                                    smoothing=smoothing, loss_type=loss_type)
         total_cer, total_char = cer_counts(vocab, gold.cpu(), hyp.cpu())
         if verbose:
             print('Total CER', total_cer)
@@ -221,8 +336,8 @@ class TransientTrainer():
                     graph['x_tr'].copy_(tx, non_blocking=True)
                     graph['x_va'].copy_(vx, non_blocking=True)
                     graph['g'].replay()
-                reads[idx] = (_Readback(dict(gold_host=m_tr['gold_host'], hyp=slots['hyp_tr'], loss=slots['loss_tr']), dev),
-                              _Readback(dict(gold_host=m_va['gold_host'], hyp=slots['hyp_va'], loss=slots['loss_va']), dev))
+                reads[idx] = (_Readback(dict(gold_host=m_tr['gold_host'], hyp=slots['hyp_tr'], loss=slots['loss_tr']), (idx, 0)),
+                              _Readback(dict(gold_host=m_va['gold_host'], hyp=slots['hyp_va'], loss=slots['loss_va']), (idx, 1)))
         if streams[0] is not main:
             for lane in range(n_lanes):
                 done = torch.cuda.Event()
@@ -319,7 +434,7 @@ class TransientTrainer():
             gold = torch.cat([metas[0][part]['gold_host'], metas[1][part]['gold_host']])
             hyp = torch.cat([slots[0][key_h], slots[1][key_h]])
             loss = slots[0][key_l] + slots[1][key_l]
-            reads.append(_Readback(dict(gold_host=gold, hyp=hyp, loss=loss), dev))
+            reads.append(_Readback(dict(gold_host=gold, hyp=hyp, loss=loss), ('split', part)))
         return [tuple(reads)]
 
     def _task_body(self, model, lane, bufs, theta0, x_tr, m_tr, x_va, m_va, n_tasks, inner, args, smoothing, slots):
@@ -449,100 +564,66 @@ class TransientTrainer():
         prefetch = threading.Thread(target=fetch_train_batch, args=(train_data_buffer,))
         prefetch.start()
         dev = model.flat_parameters.device
+        sync_replicas_from_rank0(model, [outer_opt])
+        check_every = int(os.environ.get('MTL_REPLICA_CHECK_EVERY', '100'))
         it = start_it
+        failures = 0
         while it < num_it:
-            prefetch.join()
-            prefetch = threading.Thread(target=fetch_train_batch, args=(train_data_buffer,))
-            prefetch.start()
+            # like the reference (:141-376) a failing iteration is reported and skipped (new data is fetched, `it` does not
+            # advance); unlike it, MAX_CONSECUTIVE_FAILURES failures in a row re-raise instead of looping forever
+            try:
+                prefetch.join()
+                prefetch = threading.Thread(target=fetch_train_batch, args=(train_data_buffer,))
+                prefetch.start()
 
-            start_time = time.time()
-            _, val_data = train_data_buffer[-1][-1]                  # the LAST task's validation batch, shared by all (:168)
-            popped = [train_data_buffer[m].pop() for m in range(n_tasks)]
-            task_batches = [popped[m][0] for m in my_tasks]
-            total_loss, total_cer, total_char = self.run_iteration(model, vocab, task_batches, val_data, n_tasks, inner_opt,
-                                                                   outer_opt, args)
-            last_sum_cer.append(total_cer)
-            last_sum_char.append(total_char)
-            last_sum_loss.append(total_loss / n_tasks)
-            diff_time = time.time() - start_time
-            total_time += diff_time
-            self.last_iteration_seconds = diff_time
+                start_time = time.time()
+                _, val_data = train_data_buffer[-1][-1]                  # the LAST task's validation batch, shared by all (:168)
+                popped = [train_data_buffer[m].pop() for m in range(n_tasks)]
+                task_batches = [popped[m][0] for m in my_tasks]
+                if world > 1 and (it == start_it or (check_every > 0 and (it + 1) % check_every == 0)):
+                    check_replicas(model, val_data, it)
+                total_loss, total_cer, total_char = self.run_iteration(model, vocab, task_batches, val_data, n_tasks, inner_opt,
+                                                                       outer_opt, args)
+                last_sum_cer.append(total_cer)
+                last_sum_char.append(total_char)
+                last_sum_loss.append(total_loss / n_tasks)
+                diff_time = time.time() - start_time
+                total_time += diff_time
+                self.last_iteration_seconds = diff_time
 
-            msg = '(Iteration {}) TRAIN LOSS:{:.4f} CER:{:.2f}% LR:{:.7f} TOTAL TIME:{:.7f}'.format(
-                (it + 1), total_loss / n_tasks, total_cer * 100 / max(total_char, 1), self.get_lr(outer_opt), total_time)
-            if rank == 0:
-                print(msg)
-            logging.info(msg)
-            if (it + 1) % last_summary_every == 0:
-                msg = '(Summary Iteration {} | MA {}) TRAIN LOSS:{:.4f} CER:{:.2f}%'.format(
-                    (it + 1), window_size, sum(last_sum_loss) / len(last_sum_loss), sum(last_sum_cer) * 100 / sum(last_sum_char))
+                msg = '(Iteration {}) TRAIN LOSS:{:.4f} CER:{:.2f}% LR:{:.7f} TOTAL TIME:{:.7f}'.format(
+                    (it + 1), total_loss / n_tasks, total_cer * 100 / max(total_char, 1), self.get_lr(outer_opt), total_time)
                 if rank == 0:
-                    print(msg, flush=True)
+                    print(msg)
                 logging.info(msg)
+                if (it + 1) % last_summary_every == 0:
+                    msg = '(Summary Iteration {} | MA {}) TRAIN LOSS:{:.4f} CER:{:.2f}%'.format(
+                        (it + 1), window_size, sum(last_sum_loss) / len(last_sum_loss), sum(last_sum_cer) * 100 / sum(last_sum_char))
+                    if rank == 0:
+                        print(msg, flush=True)
+                    logging.info(msg)
 
-            if (it + 1) % evaluate_every == 0:
-                stop, best_valid_val, count_stop = self._validate(model, vocab, valid_loader_list, it, args, history, inner_opt,
-                                                                  outer_opt, early_stop_criteria, early_stop_val, best_valid_val,
-                                                                  count_stop, rank)
-                if stop:
-                    break
-            it += 1
+                if (it + 1) % evaluate_every == 0:
+                    save_fn = lambda metrics, best_model: save_meta_model(model, vocab, (it + 1), inner_opt, outer_opt, metrics,
+                                                                          args, best_model=best_model)
+                    stop, best_valid_val, count_stop = run_validation(
+                        self.forward_one_batch, model, vocab, valid_loader_list, it, args, history, loss_type, save_fn,
+                        early_stop_criteria, early_stop_val, best_valid_val, count_stop, rank)
+                    if stop:
+                        break
+                it += 1
+                failures = 0
+            except KeyboardInterrupt:
+                raise
+            except Exception as e:
+                failures += 1
+                if failures >= MAX_CONSECUTIVE_FAILURES or world > 1:     # ranks must not skip different iterations
+                    raise
+                print('Error: {}, fetching new data...'.format(e), flush=True)
+                logging.info('Error: {}, fetching new data...'.format(e))
+                torch.cuda.synchronize(dev)
         prefetch.join()
-
-    # ------------------------------------------------------------------ validation + checkpoints (transient_trainer.py:280-360)
-    def _validate(self, model, vocab, valid_loader_list, it, args, history, inner_opt, outer_opt, criteria, stop_val, best, count_stop,
-                  rank):
-        if rank == 0:
-            print('')
-        logging.info('VALID')
-        model.eval()
-        final_losses, final_cers = [], []
-        dev = model.flat_parameters.device
-        for ind, loader in enumerate(valid_loader_list):
-            tot_loss, tot_cer, tot_char, nb = 0.0, 0, 0, 0
-            for data in loader:
-                src, trg, _pct, src_lengths, _tl = data
-                out = model.pass_forward(src.to(dev), src_lengths, trg)
-                c, n = cer_counts(vocab, out['gold_host'], out['hyp'].cpu())
-                tot_cer += c
-                tot_char += n
-                tot_loss += float(out['loss'].item())
-                nb += 1
-            final_losses.append(tot_loss / max(nb, 1))
-            final_cers.append(tot_cer * 100 / max(tot_char, 1))
-            msg = '(Iteration {}) VALID SET {} LOSS:{:.4f} CER:{:.2f}%'.format((it + 1), ind, final_losses[-1], final_cers[-1])
-            if rank == 0:
-                print(msg)
-            logging.info(msg)
-        model.train()
-        if not final_losses:
-            return False, best, count_stop
-        metrics = {'avg_valid_loss': sum(final_losses) / len(final_losses), 'avg_valid_cer': sum(final_cers) / len(final_cers),
-                   'valid_loss': final_losses, 'valid_cer': final_cers, 'history': history}
-        history.append(metrics)
-        msg = '(Iteration {}) AVG VALID LOSS:{:.4f} AVG CER:{:.2f}%'.format((it + 1), metrics['avg_valid_loss'], metrics['avg_valid_cer'])
-        if rank == 0:
-            print(msg)
-        logging.info(msg)
-        if rank == 0 and (it + 1) % args.save_every == 0:
-            save_meta_model(model, vocab, (it + 1), inner_opt, outer_opt, metrics, args, best_model=False)
-        cur = metrics['avg_valid_cer'] if criteria == 'cer' else metrics['avg_valid_loss']
-        if rank == 0:
-            print('CRITERIA: CER' if criteria == 'cer' else 'CRITERIA: LOSS')
-        if best > cur:
-            count_stop, best = 0, cur
-            if rank == 0:
-                save_meta_model(model, vocab, (it + 1), inner_opt, outer_opt, metrics, args, best_model=True)
-        else:
-            count_stop += 1
-            if rank == 0:
-                print('count_stop:', count_stop)
-        if count_stop >= stop_val:
-            logging.info('EARLY STOP')
-            if rank == 0:
-                print('EARLY STOP\n')
-            return True, best, count_stop
-        return False, best, count_stop
+        self.history = history
 
 
 class JointTrainer():
@@ -564,7 +645,7 @@ class JointTrainer():
         reads = []
         for (tx, tsz, _tp, ty, _tl) in task_batches:
             out = model.pass_forward(tx.to(dev, non_blocking=True), tsz, ty, smoothing=smoothing)
-            reads.append(_Readback(out, dev))
+            reads.append(_Readback(out, ('joint', len(reads))))
             model.pass_backward(g, 1.0 / n_tasks)                       # (tr_loss / n).backward()
         mdist.allreduce_sum_(g)
         if args.clip:
@@ -601,19 +682,55 @@ class JointTrainer():
         prefetch.start()
         total_time, it = 0, start_it
         self.loss_trace = []
+        history = []
+        best_valid_val, count_stop, failures = 1000000000, 0, 0
+        early_stop_criteria, early_stop_val = early_stop.split(',')[0], int(early_stop.split(',')[1])
+        last_sum_loss, last_sum_cer, last_sum_char = deque(maxlen=window_size), deque(maxlen=window_size), deque(maxlen=window_size)
+        sync_replicas_from_rank0(model, [opt])
+        fob = TransientTrainer.forward_one_batch.__get__(self)             # the two reference trainers share this method body
         while it < num_it:
-            prefetch.join()
-            prefetch = threading.Thread(target=fetch)
-            prefetch.start()
-            start_time = time.time()
-            popped = [buf[m].pop() for m in range(n_tasks)]
-            total_loss, total_cer, total_char = self.run_iteration(model, vocab, [popped[m][0] for m in my_tasks], n_tasks, opt, args)
-            total_time += time.time() - start_time
-            self.loss_trace.append(total_loss / n_tasks)
-            msg = '(Iteration {}) TRAIN LOSS:{:.4f} CER:{:.2f}% LR:{:.7f} TOTAL TIME:{:.7f}'.format(
-                (it + 1), total_loss / n_tasks, total_cer * 100 / max(total_char, 1), self.get_lr(opt), total_time)
-            if rank == 0:
-                print(msg)
-            logging.info(msg)
-            it += 1
+            try:
+                prefetch.join()
+                prefetch = threading.Thread(target=fetch)
+                prefetch.start()
+                start_time = time.time()
+                popped = [buf[m].pop() for m in range(n_tasks)]
+                total_loss, total_cer, total_char = self.run_iteration(model, vocab, [popped[m][0] for m in my_tasks], n_tasks, opt,
+                                                                       args)
+                total_time += time.time() - start_time
+                self.loss_trace.append(total_loss / n_tasks)
+                last_sum_cer.append(total_cer)
+                last_sum_char.append(total_char)
+                last_sum_loss.append(total_loss)
+                msg = '(Iteration {}) TRAIN LOSS:{:.4f} CER:{:.2f}% LR:{:.7f} TOTAL TIME:{:.7f}'.format(
+                    (it + 1), total_loss / n_tasks, total_cer * 100 / max(total_char, 1), self.get_lr(opt), total_time)
+                if rank == 0:
+                    print(msg)
+                logging.info(msg)
+                if (it + 1) % last_summary_every == 0:
+                    msg = '(Summary Iteration {} | MA {}) TRAIN LOSS:{:.4f} CER:{:.2f}%'.format(
+                        (it + 1), window_size, sum(last_sum_loss) / len(last_sum_loss), sum(last_sum_cer) * 100 / sum(last_sum_char))
+                    if rank == 0:
+                        print(msg, flush=True)
+                    logging.info(msg)
+                if (it + 1) % evaluate_every == 0:                         # joint_trainer.py:306-380
+                    save_fn = lambda metrics, best_model: save_joint_model(model, vocab, (it + 1), opt, metrics, args,
+                                                                           best_model=best_model)
+                    stop, best_valid_val, count_stop = run_validation(
+                        fob, model, vocab, valid_loader_list, it, args, history, loss_type, save_fn, early_stop_criteria,
+                        early_stop_val, best_valid_val, count_stop, rank)
+                    if stop:
+                        break
+                it += 1
+                failures = 0
+            except KeyboardInterrupt:
+                raise
+            except Exception as e:                                          # joint_trainer.py:382-392: report, fetch new data
+                failures += 1
+                if failures >= MAX_CONSECUTIVE_FAILURES or world > 1:
+                    raise
+                print('Error: {}, fetching new data...'.format(e), flush=True)
+                logging.info('Error: {}, fetching new data...'.format(e))
+                torch.cuda.synchronize(model.flat_parameters.device)
         prefetch.join()
+        self.history = history

@@ -4,7 +4,7 @@ Runs only in the build container, where /root/reference exists.  It imports the 
 Python modules (never copies them), drives `TransientTrainer.train(..., is_copy_grad=True)` on seeded
 synthetic batches and stores inputs + expected outputs as data fixtures.  Recipe: SURVEY.md 8(c).
 
-    python oracle/make_golden.py            # F0 (tiny), F1 (small-real)
+    python oracle/make_golden.py            # F0 (tiny), F1 (small-real), J0 (joint), B0 (beam search), G0 (greedy search)
     python oracle/make_golden.py --ns       # additionally the north-star-size checksum record (~1 min)
 """
 import argparse
@@ -324,16 +324,67 @@ def run_beam_fixture(torch):
         print('   ', repr(st))
 
 
+def run_greedy_fixture(torch):
+    """Decoder.greedy_search / Transformer.evaluate(beam_search=False) of the REAL reference (300 fixed arg-max
+    steps, whole decoder re-run on the growing prefix, modules/decoder.py:131-185) on the F0 model built with tgt_max_len = 320
+    (the positional table must cover 301 positions) and the B0 perturbation of the vocabulary projection, so the three
+    utterances end with a natural EOS at different steps.  Stores the token ids of all 300 steps (captured at the arg-max of
+    output_linear's last position, which is what greedy_search takes) and the returned strings."""
+    from utils.data import Vocab
+    from utils.functions import init_transformer_model
+    sys.path.insert(0, ROOT)
+    from oracle.refimpl import synth_batch
+    cfg = dict(FIXTURES['F0']['cfg'], tgt_max_len=320)
+    vocab = Vocab()
+    for i in range(cfg['vocab_size'] - 4):
+        vocab.add_token(chr(0x4e00 + i))
+        vocab.add_label(chr(0x4e00 + i))
+    args = argparse.Namespace(
+        feat_extractor='vgg_cnn', sample_rate=16000, window_size=.02, feat='spectrogram', dim_input=161,
+        num_enc_layers=cfg['num_enc_layers'], num_dec_layers=cfg['num_dec_layers'], num_heads=cfg['num_heads'],
+        dim_model=cfg['dim_model'], dim_key=cfg['dim_key'], dim_value=cfg['dim_value'], dim_inner=cfg['dim_inner'],
+        dim_emb=cfg['dim_emb'], src_max_len=cfg['src_max_len'], tgt_max_len=cfg['tgt_max_len'], dropout=0.0,
+        emb_trg_sharing=False, label_smoothing=0.0, name='golden_G0', cuda=False)
+    torch.manual_seed(123456)
+    torch.set_num_threads(8)
+    model = init_transformer_model(args, vocab, is_factorized=False, r=cfg['r'])
+    spec = dict(seed=321, k=3, T=72, L=6, noise_seed=7, noise=0.5, eos_from=47, eos_gain=1.02, tgt_max_len=320, steps=300)
+    g = torch.Generator().manual_seed(spec['noise_seed'])
+    W = model.decoder.output_linear.weight
+    W.data += spec['noise'] * torch.randn(W.shape, generator=g)
+    W.data[2] = spec['eos_gain'] * W.data[spec['eos_from']]
+    model.eval()
+    x, lens, y = synth_batch(spec['seed'], spec['k'], spec['T'], spec['L'], cfg['vocab_size'], variable=True)
+    steps = []
+    # greedy_search projects the whole (B, t, d) prefix; the teacher-forced pass before it projects sample by sample (batch 1)
+    hook = model.decoder.output_linear.register_forward_hook(
+        lambda m, i, o: steps.append(o[:, -1].max(dim=1)[1].clone()) if o.size(0) == spec['k'] else None)
+    with torch.no_grad():
+        _, strs_hyps, strs_gold = model.evaluate(x, lens, y, args, beam_search=False, start_token=vocab.SOS_ID)
+    hook.remove()
+    assert len(steps) == 300
+    ids = torch.stack(steps).numpy().astype(np.int64)                       # (300, B)
+    enc_str = lambda lst: np.frombuffer('\n'.join(lst).encode('utf-8'), dtype=np.uint8)
+    store = dict(greedy_ids=ids, greedy_strs=enc_str(strs_hyps), gold_strs=enc_str(strs_gold),
+                 spec=np.frombuffer(json.dumps(spec).encode(), dtype=np.uint8))
+    np.savez_compressed(os.path.join(ROOT, 'tests', 'golden', 'G0.npz'), **store)
+    print('G0: first EOS at steps', [int((ids[:, b] == 2).nonzero()[0][0]) if (ids[:, b] == 2).any() else -1 for b in range(ids.shape[1])])
+    for st in strs_hyps:
+        print('   ', repr(st))
+
+
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--ns', action='store_true')
     ap.add_argument('--only', default='')
     a = ap.parse_args()
     torch = bootstrap_reference()
-    todo = [a.only] if a.only else (['F0', 'F1', 'J0', 'B0'] + (['NS'] if a.ns else []))
+    todo = [a.only] if a.only else (['F0', 'F1', 'J0', 'B0', 'G0'] + (['NS'] if a.ns else []))
     for name in todo:
         if name == 'B0':
             run_beam_fixture(torch)
+        elif name == 'G0':
+            run_greedy_fixture(torch)
         elif name == 'J0':
             run_joint_fixture(torch)
         else:

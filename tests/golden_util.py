@@ -66,6 +66,16 @@ def load_beam():
     return spec, ids, dec('beam_strs'), dec('eval_beam_strs')
 
 
+def load_greedy():
+    """G0.npz (reference Decoder.greedy_search, 300 steps, on the F0 model with tgt_max_len 320 and the B0-style perturbation):
+    -> (spec dict, (300, B) int64 ids, list of strings, list of gold strings)."""
+    import json
+    z = np.load(os.path.join(ROOT, 'tests', 'golden', 'G0.npz'))
+    spec = json.loads(bytes(z['spec']).decode())
+    dec = lambda k: bytes(z[k]).decode('utf-8').split('\n')
+    return spec, z['greedy_ids'], dec('greedy_strs'), dec('gold_strs')
+
+
 def perturb_output_layer(weight, spec):
     """the fixture's deterministic change of decoder.output_linear.weight (in place), as oracle/make_golden.py applies it"""
     import torch

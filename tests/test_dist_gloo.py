@@ -43,3 +43,54 @@ def test_two_rank_allreduce_equals_sequential():
     ret = mgr.dict()
     mp.spawn(_worker, args=(2, 29611, ret), nprocs=2, join=True)
     assert ret['err'] < 1e-6, ret['err']
+
+
+def _replica_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    import argparse
+    import mtl_amd
+    from mtl_amd import trainer as T
+    mtl_amd.dist.init_from_env(backend='gloo')
+    z, cfg, spec = gu.load('F0')
+    args = argparse.Namespace(feat_extractor='vgg_cnn', sample_rate=16000, window_size=.02, feat='spectrogram', dim_input=161,
+                              dropout=0.0, emb_trg_sharing=False, **{k: v for k, v in cfg.items() if k not in ('vocab_size', 'r')})
+    torch.manual_seed(1000 + rank)                                  # ranks start from DIFFERENT weights and Adam states
+    model = mtl_amd.init_transformer_model(args, mtl_amd.synthetic_vocab(cfg['vocab_size']), r=cfg['r'])
+    adam = mtl_amd.FlatAdam(model, 1e-3)
+    adam.m.fill_(float(rank + 1))
+    adam.v.fill_(float(rank + 2))
+    adam.step_count = 5 + rank
+    T.sync_replicas_from_rank0(model, [adam])
+    probe = torch.stack([model.flat_parameters.double().sum(), adam.m.double().sum(), adam.v.double().sum()])
+    lo, hi = probe.clone(), probe.clone()
+    torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
+    torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
+    val = mtl_amd.synth_batch(3, 2, 64, 8, cfg['vocab_size'])
+    val5 = (val[0], val[1], None, val[2], None)
+    T.check_replicas(model, val5, 0)                                # identical replicas, identical validation batch: passes
+    raised = [False, False]
+    try:
+        bad = mtl_amd.synth_batch(3 + rank, 2, 64, 8, cfg['vocab_size'])         # rank 1 drew a different validation batch
+        T.check_replicas(model, (bad[0], bad[1], None, bad[2], None), 1)
+    except RuntimeError:
+        raised[0] = True
+    if rank == 1:
+        model.flat_parameters[123] += 1.0                           # a replica drifted
+    try:
+        T.check_replicas(model, val5, 2)
+    except RuntimeError:
+        raised[1] = True
+    ret[rank] = (bool(torch.equal(lo, hi)), adam.step_count, float(adam.m[0]), raised)
+    mtl_amd.dist.barrier()
+
+
+def test_replicas_are_synchronised_at_start_and_divergence_is_detected():
+    """trainer.sync_replicas_from_rank0 / check_replicas (the multi-rank contract of TransientTrainer.train): broadcast of theta,
+    Adam m / v / step from rank 0; a different validation batch or a drifted replica raises on EVERY rank."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_replica_worker, args=(2, 29613, ret), nprocs=2, join=True)
+    for rank in (0, 1):
+        same, step, m0, raised = ret[rank]
+        assert same and step == 5 and m0 == 1.0 and raised == [True, True], (rank, ret[rank])

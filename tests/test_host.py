@@ -89,6 +89,74 @@ def test_vocab_manifest_and_sampling(tmp_path):
     assert (x[0, 0, :, int(sizes[0]):] == 0).all()
 
 
+def test_seeded_dataset_item_access_and_audio_loader(tmp_path):
+    """ManifestTaskDataset(seed=...) draws from its own RandomState (ranks in lock-step, unaffected by other users of np.random),
+    __getitem__ / __len__ follow utils/data_loader.py:323-340, and AudioDataLoader yields the reference's validation batch layout
+    (utils/data_loader.py:401-440): sorted by descending length, zero / PAD padded, (inputs, targets, percentages, sizes, sizes)."""
+    import mtl_amd
+    vocab = mtl_amd.synthetic_vocab(64)
+    rows = []
+    for i in range(6):
+        t = tmp_path / ('u%d.txt' % i)
+        t.write_text(''.join(chr(0x4e00 + j) for j in range(1 + i)), encoding='utf8')
+        rows.append('%s,%s' % (tmp_path / ('u%d.wav' % i), t))
+    mp_ = tmp_path / 'm.csv'
+    mp_.write_text('\n'.join(rows) + '\n')
+    args = argparse.Namespace(src_max_len=40)
+    feats = lambda wav: torch.full((161, 20 + 5 * int(os.path.basename(wav)[1])), float(os.path.basename(wav)[1]))
+    a = mtl_amd.ManifestTaskDataset(vocab, args, [str(mp_)], feats, seed=11)
+    b = mtl_amd.ManifestTaskDataset(vocab, args, [str(mp_)], feats, seed=11)
+    np.random.seed(1)
+    ta, _ = a.sample(3, 2, 0)
+    np.random.rand(7)                                   # another consumer of the global RNG between the two ranks' draws
+    tb, _ = b.sample(3, 2, 0)
+    assert all(torch.equal(u, v) for u, v in zip(ta, tb))
+    assert len(a) == 6
+    spect, trans = a[7]                                 # evaluation indexing: manifest 0, index modulo its length
+    assert spect.shape == (161, 25) and trans == [4, 5]
+    assert a[5][0].shape == (161, 40)                   # truncated to src_max_len
+    loader = mtl_amd.AudioDataLoader(vocab.PAD_ID, dataset=a, batch_size=4)
+    batches = list(loader)
+    assert len(batches) == 2
+    inputs, targets, pct, sizes, tsizes = batches[0]
+    assert inputs.shape == (4, 1, 161, 35) and sizes.tolist() == [35, 30, 25, 20] and sizes.dtype == torch.int32
+    assert targets.shape == (4, 4) and targets.dtype == torch.int64 and tsizes.tolist() == [4, 3, 2, 1]
+    assert targets[3].tolist() == [4, 0, 0, 0] and torch.allclose(pct, sizes.float() / 35)
+    assert float(inputs[3, 0, :, 20:].abs().max()) == 0.0 and float(inputs[3, 0, 0, 0]) == 0.0 and float(inputs[0, 0, 0, 0]) == 3.0
+
+
+def test_joint_checkpoint_roundtrip_and_pickling_is_side_effect_free(tmp_path):
+    """save_joint_model / load_joint_model (utils/functions.py:43-71,190-218) and the pickling of Vocab under the reference's
+    class path WITHOUT touching process-global state (sys.modules, Vocab.__module__) while another thread may be importing."""
+    import sys
+    import mtl_amd
+    z, cfg, spec = gu.load('F0')
+    args = make_args(cfg, save_folder=str(tmp_path), name='jk', loss='ce')
+    vocab = mtl_amd.synthetic_vocab(64)
+    m = mtl_amd.init_transformer_model(args, vocab)
+    opt = torch.optim.Adam(m.parameters(), lr=args.lr)
+    for p in m.parameters():
+        p.grad = torch.ones_like(p)
+    opt.step()
+    before = (sys.modules.get('utils'), sys.modules.get('utils.data'), mtl_amd.Vocab.__module__)
+    path = mtl_amd.save_joint_model(m, vocab, 3, opt, {'avg_valid_loss': 2.0}, args, best_model=True)
+    assert (sys.modules.get('utils'), sys.modules.get('utils.data'), mtl_amd.Vocab.__module__) == before
+    assert path.endswith('jk/best_model.th')
+    ck = mtl_amd.functions.load_checkpoint_dict(path)
+    assert sorted(ck.keys()) == ['args', 'epoch', 'metrics', 'model_state_dict', 'opt', 'vocab']
+    assert isinstance(ck['opt'], torch.optim.Adam) and type(ck['vocab']) is mtl_amd.Vocab
+    import zipfile
+    with zipfile.ZipFile(path) as zf:
+        pkl = zf.read([n for n in zf.namelist() if n.endswith('data.pkl')][0])
+    assert b'utils.data' in pkl and b'mtl_amd' not in pkl
+    m2, v2, o2, ep, met, a2 = mtl_amd.load_joint_model(path)
+    assert ep == 3 and met['avg_valid_loss'] == 2.0 and v2.id2label == vocab.id2label
+    for (n1, p1), (n2, p2) in zip(m.named_parameters(), m2.named_parameters()):
+        assert n1 == n2 and torch.equal(p1, p2)
+    s1, s2 = opt.state_dict()['state'], o2.state_dict()['state']
+    assert len(s1) == len(s2) and all(torch.equal(s1[k]['exp_avg'], s2[k]['exp_avg']) for k in s1)
+
+
 def test_checkpoint_roundtrip_reference_format(tmp_path):
     import mtl_amd
     z, cfg, spec = gu.load('F0')

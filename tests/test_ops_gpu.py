@@ -71,6 +71,37 @@ def test_gemm_split_k_deterministic(L, ta, tb):
     assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize('ta,tb', [(0, 1), (0, 0), (1, 0), (1, 1)])
+def test_gemm_long_k_big_tile_split_k(L, ta, tb):
+    """the 128x128-tile split-K branch of the dispatch (48..96 big tiles, K >= 2048: the 5120-deep input projection and the
+    shapes it also captures): all transposes, bias + ReLU + gate + accumulate epilogue, a strided batch with H = 1, bitwise
+    repeatability, and a workspace too small for the split (falls back to the plain path, same result)"""
+    g = torch.Generator().manual_seed(41 + ta * 2 + tb)
+    M, N, K, nb = 2048, 512, 5120, 3
+    A = torch.randn((nb, K, M) if ta else (nb, M, K), generator=g)
+    B = torch.randn((nb, N, K) if tb else (nb, K, N), generator=g)
+    bias, C0, gate = torch.randn(nb, N, generator=g), torch.randn(nb, M, N, generator=g), torch.randn(nb, M, N, generator=g)
+    prod = torch.stack([(A[i].t() if ta else A[i]).double() @ (B[i].t() if tb else B[i]).double() for i in range(nb)])
+    ref = torch.relu(prod + bias.double().unsqueeze(1)) * (gate > 0) + C0.double()
+    dA, dB, dbias, dgate = dev(A), dev(B), dev(bias), dev(gate)
+    lda, ldb = A.shape[2], B.shape[2]
+    big = torch.empty(48 << 20).cuda()                         # 192 MiB: room for the slabs of all three items
+    small = torch.empty(1 << 10).cuda()
+
+    def run(ws, batch):
+        C = dev(C0.clone())
+        assert L.mtl_gemm_f32(st(), ta, tb, M, N, K, 1.0, dA.data_ptr(), lda, dB.data_ptr(), ldb, C.data_ptr(), N,
+                              dbias.data_ptr(), dgate.data_ptr(), N, 3, batch, 1, A[0].numel(), 0, B[0].numel(), 0, M * N, 0, N,
+                              ws.data_ptr() if ws is not None else None, ws.numel() * 4 if ws is not None else 0) == 0
+        return C.cpu()
+    one = run(big, 1)
+    assert rel(one[0], ref[0]) < 3e-6 and torch.equal(one[1], C0[1])
+    assert torch.equal(run(big, 1), one)
+    assert rel(run(small, 1)[0], ref[0]) < 3e-6 and rel(run(None, 1)[0], ref[0]) < 3e-6
+    allb = run(big, nb)
+    assert rel(allb, ref) < 3e-6 and torch.equal(run(big, nb), allb)
+
+
 def test_gemm_gate_and_batched_heads(L):
     g = torch.Generator().manual_seed(5)
     Bn, H, Tq, Tk, dk = 3, 8, 101, 250, 16

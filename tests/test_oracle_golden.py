@@ -154,3 +154,16 @@ def test_gate_replay_of_the_oracles_own_decisions_is_exact():
     # a flipped gate changes the result (the replay is really consumed)
     gates['conv5'] = ~gates['conv5']
     assert not torch.equal(m(x, lens, y, gates=gates)[0], pred)
+
+
+def test_greedy_search_matches_reference_golden():
+    """Decoder.greedy_search of the REAL reference (tests/golden/G0.npz: all 300 arg-max steps of 3 utterances, natural EOS at
+    different steps) pins the oracle's restatement token for token."""
+    gspec, ids, strs, golds = gu.load_greedy()
+    _, cfg, _ = gu.load('F0')
+    cfg = dict(cfg, tgt_max_len=gspec['tgt_max_len'])
+    m = R.build_model(cfg)
+    gu.perturb_output_layer(m.decoder.output_linear.weight, gspec)
+    x, lens, y = R.synth_batch(gspec['seed'], gspec['k'], gspec['T'], gspec['L'], cfg['vocab_size'], True)
+    out = R.greedy_search(m, x, lens, R.SOS_ID, gspec['steps'])            # (B, steps)
+    assert np.array_equal(out.t().numpy(), ids)

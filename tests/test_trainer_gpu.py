@@ -1,0 +1,278 @@
+"""Drop-in trainer API on the MI355X: forward_one_batch against the reference goldens, calculate_metrics on arbitrary tensors,
+in-loop validation + checkpoints + early stop through an AudioDataLoader (both trainers), greedy decoding against the
+reference golden, the long-utterance configuration against the live oracle, one RCCL execution of the collective path."""
+import argparse
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from tests import golden_util as gu
+from tests.test_parity_gpu import make, _pass_parity, _rel_errs, _set_oracle_params, RTOL
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize('name', ['F0', 'F1'])
+def test_forward_one_batch_matches_reference_goldens(name):
+    """TransientTrainer.forward_one_batch (transient_trainer.py:25-73): loss, total_cer, total_char of the three training
+    batches evaluated at theta0 against what the REAL reference returned (golden `fwd/0/{0,2,4}/{loss,cer}`), the in-place
+    scaling of src_percentages (Q6), and loss.backward() against the oracle with the pass's branch decisions replayed."""
+    from oracle import refimpl as R
+    from tests import branches
+    z, cfg, spec = gu.load(name)
+    mtl_amd, args, vocab, model = make(cfg, spec)
+    model = model.cuda()
+    oracle = R.build_model(cfg)
+    tr, _val = gu.batches_for(cfg, spec, 0, z['data_call_index'])
+    trainer = mtl_amd.TransientTrainer()
+    for m, (x, lens, y) in enumerate(tr):
+        key = 'fwd/0/%d' % (2 * m)
+        pct = lens.float() / x.shape[3]
+        pct0 = pct.clone()
+        model.zero_grad()
+        loss, cer, nchar = trainer.forward_one_batch(model, vocab, x.cuda(), y.cuda(), pct, lens, (y != 0).sum(1).to(torch.int32), 0.0, 'ce')
+        assert (cer, nchar) == tuple(int(v) for v in z[key + '/cer']), key
+        assert abs(float(loss) - float(z[key + '/loss'])) <= RTOL * float(z[key + '/loss'])
+        assert torch.equal(pct, pct0 * int(y.shape[1] + 1))                  # reference quirk: caller's tensor scaled in place
+        loss.backward()
+        gates = branches.gates_from_engine(model.engine)
+        pr, gr, _ = oracle(x, lens, y, gates=gates)
+        grads = torch.autograd.grad(R.ce_loss(pr, gr), list(oracle.parameters()))
+        errs = _rel_errs(model, model.flat_grad, oracle, grads)
+        assert max(errs.values()) < RTOL, max(errs.items(), key=lambda kv: kv[1])
+
+
+def test_forward_one_batch_label_smoothing_matches_reference_formula():
+    """--label-smoothing through the compatibility call: loss and gradients vs utils/metrics.py:113-124 restated in torch."""
+    import torch.nn.functional as F
+    from oracle import refimpl as R
+    from tests import branches
+    z, cfg, spec = gu.load('F0')
+    mtl_amd, args, vocab, model = make(cfg, spec)
+    model = model.cuda()
+    oracle = R.build_model(cfg)
+    x, lens, y = gu.batches_for(cfg, spec, 0, z['data_call_index'])[0][1]
+    eps = 0.1
+    model.zero_grad()
+    loss, _, _ = mtl_amd.TransientTrainer().forward_one_batch(model, vocab, x.cuda(), y.cuda(), lens.float() / x.shape[3], lens,
+                                                            (y != 0).sum(1).to(torch.int32), eps, 'ce')
+    loss.backward()
+    pred, gold, _ = oracle(x, lens, y, gates=branches.gates_from_engine(model.engine))
+    V = pred.size(2)
+    p2, g2 = pred.view(-1, V), gold.view(-1)
+    mask = g2.ne(0)
+    one_hot = torch.zeros_like(p2).scatter(1, (mask.long() * g2).view(-1, 1), 1)
+    one_hot = one_hot * (1 - eps) + (1 - one_hot) * eps / V
+    ref = -(one_hot * F.log_softmax(p2, dim=1)).sum(1).masked_select(mask).sum() / int(mask.sum())
+    assert abs(float(loss) - float(ref)) < RTOL * float(ref)
+    grads = torch.autograd.grad(ref, list(oracle.parameters()))
+    errs = _rel_errs(model, model.flat_grad, oracle, grads)
+    assert max(errs.values()) < RTOL, max(errs.items(), key=lambda kv: kv[1])
+
+
+def test_calculate_metrics_on_arbitrary_tensors():
+    """calculate_metrics is a real op (utils/metrics.py:68-126), not a view of the engine's last forward: leaf logits, a SLICE of a
+    model output, an explicit non_pad_mask (in-place padding of gold like the reference), smoothing; d(pred) vs torch autograd."""
+    import torch.nn.functional as F
+    import mtl_amd
+    g = torch.Generator().manual_seed(5)
+    pred = torch.randn(3, 7, 100, generator=g)
+    gold = torch.randint(1, 100, (3, 7), generator=g)
+    gold[1, 4:] = 0
+    gold[2, 6:] = 0
+    for smoothing in (0.0, 0.2):
+        pd = pred.clone().cuda().requires_grad_(True)
+        loss, ncorrect = mtl_amd.calculate_metrics(pd[:2], gold[:2].cuda(), 0, smoothing=smoothing)      # a slice of "pred"
+        (2.5 * loss).backward()
+        pc = pred.clone().requires_grad_(True)
+        p2, g2 = pc[:2].reshape(-1, 100), gold[:2].reshape(-1)
+        if smoothing > 0:
+            mask = g2.ne(0)
+            one_hot = torch.zeros_like(p2).scatter(1, (mask.long() * g2).view(-1, 1), 1)
+            one_hot = one_hot * (1 - smoothing) + (1 - one_hot) * smoothing / 100
+            ref = -(one_hot * F.log_softmax(p2, dim=1)).sum(1).masked_select(mask).sum() / int(mask.sum())
+        else:
+            ref = F.cross_entropy(p2, g2, ignore_index=0, reduction='mean')
+        (2.5 * ref).backward()
+        assert abs(float(loss) - float(ref)) < 2e-6 * float(ref)
+        assert ncorrect == int((p2.max(1)[1].eq(g2) & g2.ne(0)).sum())
+        assert float((pd.grad.cpu() - pc.grad).abs().max()) < 2e-6 * float(pc.grad.abs().max())
+        assert float(pd.grad[2].abs().max()) == 0.0
+    # explicit mask: positions masked out are padded in the caller's gold tensor, exactly like the reference
+    gd = gold.clone().cuda()
+    mask = gd.ne(0)
+    mask[0, 0] = False
+    loss, _ = mtl_amd.calculate_metrics(pred.cuda(), gd, 0, non_pad_mask=mask)
+    assert int(gd[0, 0]) == 0
+    g3 = gold.clone()
+    g3[0, 0] = 0
+    assert abs(float(loss) - float(F.cross_entropy(pred.view(-1, 100), g3.view(-1), ignore_index=0))) < 2e-6 * float(loss)
+    with pytest.raises(RuntimeError):
+        mtl_amd.calculate_metrics(pred, gold, 0)                         # CPU tensors: no fallback
+
+
+class _ListDataset(torch.utils.data.Dataset):
+    """(spectrogram (F, T), transcript ids) items, what SpectrogramDataset.__getitem__ yields (utils/data_loader.py:323-340)"""
+
+    def __init__(self, seed, n, V):
+        g = torch.Generator().manual_seed(seed)
+        self.items = []
+        for _ in range(n):
+            T = int(torch.randint(24, 72, (1,), generator=g))
+            L = int(torch.randint(2, 8, (1,), generator=g))
+            self.items.append((torch.randn(161, T, generator=g), torch.randint(4, V, (L,), generator=g).tolist()))
+
+    def __len__(self):
+        return len(self.items)
+
+    def __getitem__(self, i):
+        return self.items[i]
+
+
+def _oracle_validation(oracle, vocab, loader):
+    """what the reference's validation loop computes for one loader, through the oracle in eval mode"""
+    from oracle import refimpl as R
+    import mtl_amd
+    from mtl_amd.trainer import cer_counts
+    oracle.eval()
+    tot_loss, tot_cer, tot_char, nb = 0.0, 0, 0, 0
+    with torch.no_grad():
+        for src, trg, _pct, src_lengths, _tl in loader:
+            pred, gold, hyp = oracle(src, src_lengths, trg)
+            tot_loss += float(R.ce_loss(pred, gold))
+            c, n = cer_counts(vocab, gold, hyp)
+            tot_cer += c
+            tot_char += n
+            nb += 1
+    oracle.train()
+    return tot_loss / nb, tot_cer * 100 / tot_char
+
+
+def test_in_loop_validation_checkpoints_and_early_stop(tmp_path):
+    """TransientTrainer.train with evaluate_every=1 over two AudioDataLoaders (utils/data_loader.py:401-440 layout): per-set loss
+    and CER equal the oracle's on the same batches, metrics / history like transient_trainer.py:280-331, epoch_N.th every
+    save_every, best_model.th on improvement, and the early-stop counter ends the run (meta_lr = 0: nothing improves)."""
+    from oracle import refimpl as R
+    z, cfg, spec = gu.load('F0')
+    mtl_amd, args, vocab, model = make(cfg, dict(spec, meta_lr=0.0), name='valid')
+    args.save_folder, args.save_every = str(tmp_path), 2
+    model = model.cuda()
+    oracle = R.build_model(cfg)
+    V = cfg['vocab_size']
+    loaders = [mtl_amd.AudioDataLoader(vocab.PAD_ID, dataset=_ListDataset(100 + i, 5, V), batch_size=2) for i in range(2)]
+    expect = [_oracle_validation(oracle, vocab, ld) for ld in loaders]
+    tasks = [mtl_amd.SyntheticTask(m, 2, 64, 8, V, variable=True) for m in range(3)]
+    trainer = mtl_amd.TransientTrainer()
+    trainer.train(model, vocab, tasks, loaders, 'ce', 0, 10, args, evaluate_every=1, early_stop='cer,2', is_copy_grad=True)
+    hist = trainer.history
+    assert len(hist) == 3                                   # best at it 1, count_stop 1 at it 2, 2 at it 3 -> EARLY STOP
+    for h in hist:
+        for i, (loss_ref, cer_ref) in enumerate(expect):
+            assert abs(h['valid_loss'][i] - loss_ref) < RTOL * loss_ref
+            assert abs(h['valid_cer'][i] - cer_ref) < 1e-9
+        assert abs(h['avg_valid_cer'] - sum(c for _, c in expect) / 2) < 1e-9
+    folder = os.path.join(str(tmp_path), 'valid')
+    assert sorted(os.listdir(folder)) == ['best_model.th', 'epoch_2.th']
+    m2, v2, inner2, outer2, epoch, metrics, a2 = mtl_amd.load_meta_model(os.path.join(folder, 'epoch_2.th'))
+    assert epoch == 2 and metrics['valid_cer'] == hist[1]['valid_cer'] and v2.id2label == vocab.id2label
+    for (n1, p1), (n2, p2) in zip(model.named_parameters(), m2.named_parameters()):
+        assert n1 == n2 and torch.equal(p1.cpu(), p2.cpu())            # meta_lr 0: theta never moved
+    assert model.training
+
+
+def test_joint_trainer_validation_and_checkpoint(tmp_path):
+    """JointTrainer.train (joint_trainer.py:306-380): validation every iteration, save_joint_model layout
+    ('vocab','args','epoch','model_state_dict','opt','metrics'), load_joint_model restores weights and the Adam state."""
+    from oracle import refimpl as R
+    z, cfg, spec = gu.load('F0')
+    mtl_amd, args, vocab, model = make(cfg, spec, name='joint')
+    args.save_folder, args.save_every, args.loss = str(tmp_path), 1, 'ce'
+    model = model.cuda()
+    V = cfg['vocab_size']
+    loaders = [mtl_amd.AudioDataLoader(vocab.PAD_ID, dataset=_ListDataset(7, 4, V), batch_size=4)]
+    tasks = [mtl_amd.SyntheticTask(m, 2, 64, 8, V, variable=True) for m in range(3)]
+    tr = mtl_amd.JointTrainer()
+    tr.train(model, vocab, tasks, loaders, 'ce', 0, 2, args, evaluate_every=1, early_stop='loss,5')
+    assert len(tr.history) == 2 and np.isfinite(tr.history[1]['avg_valid_loss'])
+    assert tr.history[1]['avg_valid_loss'] != tr.history[0]['avg_valid_loss']                            # theta moved
+    folder = os.path.join(str(tmp_path), 'joint')
+    assert sorted(os.listdir(folder)) == ['best_model.th', 'epoch_1.th', 'epoch_2.th']
+    raw = mtl_amd.functions.load_checkpoint_dict(os.path.join(folder, 'epoch_2.th'))
+    assert sorted(raw) == ['args', 'epoch', 'metrics', 'model_state_dict', 'opt', 'vocab']
+    m2, v2, opt2, epoch, metrics, a2 = mtl_amd.load_joint_model(os.path.join(folder, 'epoch_2.th'))
+    assert epoch == 2
+    for (n1, p1), (_, p2) in zip(model.named_parameters(), m2.named_parameters()):
+        assert torch.equal(p1.cpu(), p2.cpu())
+    st = opt2.state_dict()['state']
+    assert len(st) == 68 and int(st[0]['step']) == 2
+    flat = mtl_amd.FlatAdam.from_torch(m2, opt2)
+    assert torch.equal(flat.m.cpu(), tr.opt.m.cpu()) and torch.equal(flat.v.cpu(), tr.opt.v.cpu())
+    # validation loss of the final model against the oracle carrying the same weights
+    oracle = R.build_model(cfg)
+    _set_oracle_params(oracle, model, model.flat_parameters)
+    loss_ref, cer_ref = _oracle_validation(oracle, vocab, loaders[0])
+    assert abs(tr.history[1]['valid_loss'][0] - loss_ref) < RTOL * loss_ref and abs(tr.history[1]['valid_cer'][0] - cer_ref) < 1e-9
+
+
+def test_greedy_decoding_matches_reference_golden():
+    """Transformer.evaluate / PassEngine.greedy_decode (K/V-cached, device-resident feedback) against the REAL reference's
+    Decoder.greedy_search (tests/golden/G0.npz): the token ids of all 300 steps and the returned strings."""
+    gspec, ids, strs, golds = gu.load_greedy()
+    z, cfg, spec = gu.load('F0')
+    cfg = dict(cfg, tgt_max_len=gspec['tgt_max_len'])
+    mtl_amd, args, vocab, model = make(cfg, spec)
+    gu.perturb_output_layer(model.decoder.output_linear.weight, gspec)
+    model = model.cuda()
+    from oracle import refimpl as R
+    x, lens, y = R.synth_batch(gspec['seed'], gspec['k'], gspec['T'], gspec['L'], cfg['vocab_size'], True)
+    _, hyps, gold_strs = model.evaluate(x.cuda(), lens, y, args, start_token=vocab.SOS_ID)
+    assert np.array_equal(model.last_greedy_ids.numpy(), ids)
+    assert hyps == strs and gold_strs == golds
+
+
+@pytest.mark.parametrize('B,lens', [(1, [5000]), (2, [5000, 1300])])
+def test_long_utterance_config_against_live_oracle(B, lens):
+    """BASELINE.json configs[3] (src-max-len 5000, T' = 1250, dim-input 5120) against the oracle at small batch: labels
+    bit-exact, loss, and every gradient tensor within 1e-4 with the branch decisions replayed (second case: a padded row,
+    raw-length masks on the pooled axis)."""
+    from oracle import refimpl as R
+    z, cfg, spec = gu.load('NS')
+    mtl_amd, args, vocab, model = make(cfg, spec)
+    model = model.cuda()
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    oracle = R.build_model(cfg)
+    g = torch.Generator().manual_seed(50 + B)
+    x = torch.randn(B, 1, 161, 5000, generator=g)
+    y = torch.randint(4, cfg['vocab_size'], (B, 40), generator=g)
+    for i, n in enumerate(lens):
+        x[i, :, :, n:] = 0
+    if B > 1:
+        y[1, 25:] = 0
+    _pass_parity(model, oracle, (x, torch.tensor(lens, dtype=torch.int32), y), model.flat_parameters, 'T=5000 B=%d' % B,
+                 max_flips=120)
+
+
+def test_rccl_collective_path_executes():
+    """The `nccl` (= RCCL) branch of dist.init_from_env and the flat-G all-reduce on this box's GPU: one rank under torchrun with
+    MTL_DIST_ALWAYS=1 (the collective is issued even at world size 1).  Multi-rank arithmetic is covered by the gloo tests; this
+    pins that RCCL initialises and runs the collective in this environment, and that it leaves the step unchanged."""
+    common = ['--steps', '2', '--warmup', '1', '--tasks', '2', '--k', '2', '--frames', '200', '--labels', '20', '--no-cpu-baseline']
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('MTL_DIST_BACKEND', None)
+    one = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1'] + common, capture_output=True, text=True,
+                         env=env, timeout=300)
+    assert one.returncode == 0, one.stderr[-2000:]
+    rccl = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr',
+                           '127.0.0.1', '--master-port', '29741', os.path.join(ROOT, 'bench.py'), '--gpus', '1'] + common,
+                          capture_output=True, text=True, env=dict(env, MTL_DIST_ALWAYS='1'), timeout=300)
+    assert rccl.returncode == 0, rccl.stderr[-2000:]
+    j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith('{')][-1])
+    j2 = json.loads([l for l in rccl.stdout.splitlines() if l.startswith('{')][-1])
+    assert j2['config']['collective'] == 'nccl' and j1['config']['collective'] == 'none'
+    assert j1['last_step'] == j2['last_step']
