@@ -117,6 +117,24 @@ int mtl_softmax_mask_fwd(void* stream, float* S, const int* klen, int causal, fl
 int mtl_softmax_bwd(void* stream, const float* P, float* dP /*in place -> dS*/, float scale, long rows, int Tk, int ld,
                     const unsigned char* pmask, float pscale);
 
+/* ---- fused scaled-dot-product attention: modules/common_layers.py:317-331 (bmm, /temperature, masked_fill(-inf), softmax,
+ * dropout, bmm) with the head split / merge of :291-293,301 done by stride and the masks of :296 derived in-kernel.
+ * q (B*Tq rows, row stride ldq floats), k, v (B*Tk rows): head h occupies columns [h*dk, (h+1)*dk) of a row (dv for v / O).
+ * keys k >= klen[b] (klen nullable) and, if causal, k > q are masked.  O (B*Tq rows, ldo) = softmax(q.k^T * scale) [* pmask *
+ * pscale] . v ; lse[(b*H+h)*Tq + q] = log-sum-exp of the scaled scores (saved for the backward).  The (B,H,Tq,Tk) score tensor
+ * is never written: 64-query workgroups stream 64-key tiles with an online softmax; the backward recomputes the probabilities.
+ * pmask (nullable): u8 keep-mask [B][H][Tq][ldm] from mtl_dropout_mask, pscale = 1/(1-p).  (dk, dv) in {(64,64), (16,16)}
+ * (mtl_attn_supported); q/k/v/dO 16-byte aligned with row strides that are multiples of 4.
+ * Backward: dq, dk, dv are OVERWRITTEN (head-strided like their inputs); delta: B*H*Tq floats of scratch. */
+int mtl_attn_supported(int dk, int dv);
+int mtl_attn_fwd(void* stream, const float* q, const float* k, const float* v, int ldq, int ldk, int ldv, const int* klen,
+                 int causal, float scale, int B, int H, int Tq, int Tk, int dk, int dv, const unsigned char* pmask, int ldm,
+                 float pscale, float* O, int ldo, float* lse);
+int mtl_attn_bwd(void* stream, const float* q, const float* k, const float* v, int ldq, int ldk, int ldv, const int* klen,
+                 int causal, float scale, int B, int H, int Tq, int Tk, int dk, int dv, const unsigned char* pmask, int ldm,
+                 float pscale, const float* O, const float* dO, int ldo, const float* lse, float* delta, float* dq, float* dk_,
+                 float* dv_, int lddq, int lddk, int lddv);
+
 /* ---- embedding + positional encoding: modules/decoder.py:96 ------------------------------------------- */
 int mtl_embed_pe_fwd(void* stream, const long* ids, const float* table, const float* pe, float* out, int rows, int T, int d,
                      const unsigned char* mask /*nullable: dropout keep-mask*/, float mscale);

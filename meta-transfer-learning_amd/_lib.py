@@ -38,6 +38,9 @@ SIGNATURES = {
     'mtl_layernorm_bwd': (I, [P, P, P, P, P, P, P, F, P, P, P, P, P, P, I, I]),
     'mtl_softmax_mask_fwd': (I, [P, P, P, I, F, I, I, I, I, I, P, F, P]),
     'mtl_softmax_bwd': (I, [P, P, P, F, L, I, I, P, F]),
+    'mtl_attn_supported': (I, [I, I]),
+    'mtl_attn_fwd': (I, [P, P, P, P, I, I, I, P, I, F, I, I, I, I, I, I, P, I, F, P, I, P]),
+    'mtl_attn_bwd': (I, [P, P, P, P, I, I, I, P, I, F, I, I, I, I, I, I, P, I, F, P, P, I, P, P, P, P, P, I, I, I]),
     'mtl_embed_pe_fwd': (I, [P, P, P, P, P, I, I, I, P, F]),
     'mtl_embed_bwd': (I, [P, P, P, P, P, P, I, I, L, P, F]),
     'mtl_dropout_mask': (I, [P, P, L, F, P, ctypes.c_ulonglong]),

@@ -1,0 +1,480 @@
+// Fused scaled-dot-product attention for gfx950 (MI355X), exact fp32 on the matrix cores.
+//
+// Replaces ScaledDotProductAttention.forward (modules/common_layers.py:317-331: bmm -> /temperature -> masked_fill(-inf) ->
+// softmax -> dropout -> bmm) and its autograd backward, including the head split / merge copies of
+// FactorizedMultiHeadAttention.forward (common_layers.py:291-293,301: heads are addressed by stride) and the h-fold
+// `mask.repeat` (:296: masks are derived in-kernel from klen[] / the causal flag).
+//
+// The (B, h, Tq, Tk) score tensor never exists in HBM (it was 16 MB per layer at T = 1000 and 400 MB per layer at T = 5000,
+// written and re-read forward and backward): one workgroup owns 64 query rows of one (batch, head), streams 64-key tiles of
+// K and V through LDS and keeps an online softmax (running max / sum) per row; the backward recomputes the probabilities from
+// the saved log-sum-exp.  All reductions are fixed-order -> bitwise reproducible.
+//
+// Arithmetic: v_mfma_f32_16x16x4_f32 (exact fp32, 32-cycle issue).  One wave owns 16 rows; the 16 x 64 score tile is four
+// independent accumulators, so back-to-back MFMAs never wait on the 40-cycle dependent latency.  Operand fragments:
+//   A (rows x k):  lane l supplies A[l & 15][k(l >> 4)],   B (k x cols): lane l supplies B[k(l >> 4)][l & 15],
+//   C/D: lane l, register r holds C[4 (l >> 4) + r][l & 15].
+// The contraction index may be permuted freely as long as A and B use the same permutation: an MFMA pair (x, y) of step s
+// uses k = 8 s + 2 (l >> 4) + {0, 1}, so that each lane fetches both operands of the pair with ONE 8-byte LDS read.
+// LDS tiles are stored [row][D + 4]: the 8-byte fragment reads of 16 rows x 2 lane groups then hit 32 distinct bank pairs.
+// A probability tile leaves the MFMA in C layout and is needed as an A operand by the next product: it takes one round trip
+// through a wave-private LDS patch (ds_write_b32 in C layout, ds_read_b64 in A layout), no workgroup barrier involved.
+#include "mtl_common.h"
+#include "../../include/mtl_hip.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int AT_ROWS = 64;   // rows (queries, or keys in the key/value-gradient kernel) per workgroup: 16 per wave
+constexpr int AT_TILE = 64;   // streamed tile (keys, or queries in the key/value-gradient kernel)
+constexpr int AT_LDP = AT_TILE + 4;
+
+struct AttnP {
+    const float *q, *k, *v;
+    int ldq, ldk, ldv;
+    const int* klen;
+    int causal;
+    float scale;
+    int B, H, Tq, Tk;
+    const uint8_t* pmask;
+    int ldm;
+    float pscale;
+    float* O;
+    int ldo;
+    float* lse;
+    const float* Oc;      // backward: forward output
+    const float* dO;
+    float* delta;
+    float *dq, *dk, *dv;
+    int lddq, lddk, lddv;
+};
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 zero_acc() {
+    f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    return z;
+}
+// max / sum over the 16 lanes that hold one C-layout row
+__device__ __forceinline__ float row16_max(float v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float row16_sum(float v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// LDS writes of this wave become visible to its own later LDS reads (DS ops of one wave execute in order; this only stops the
+// compiler from moving the reads above the writes)
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// A 64-row x D tile of a head-strided matrix: HBM -> registers (16-byte loads, rows past `nrows` read as zero) -> LDS [row][D+4]
+template <int D>
+struct Tile {
+    static constexpr int LD = D + 4;
+    static constexpr int VPR = D / 4;          // float4 per row
+    static constexpr int RPP = 256 / VPR;      // rows per pass of the 256 threads
+    static constexpr int NV = 64 / RPP;
+    float4 v[NV];
+    __device__ __forceinline__ void fetch(const float* base, int ld, int row0, int nrows, int tid) {
+        const int c4 = (tid % VPR) * 4;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int row = row0 + tid / VPR + i * RPP;
+            const bool ok = row < nrows;
+            const float4 x = *reinterpret_cast<const float4*>(base + (long)(ok ? row : 0) * ld + c4);
+            v[i] = ok ? x : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    __device__ __forceinline__ void commit(float* lds, int tid) const {
+        const int c4 = (tid % VPR) * 4;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) *reinterpret_cast<float4*>(lds + (tid / VPR + i * RPP) * LD + c4) = v[i];
+    }
+};
+
+// acc[t] (16 rows x 16 cols, t = 0..3) += frag (16 x D, registers, A layout) . tile[16 t + j][.]^T   (tile rows as columns)
+template <int D>
+__device__ __forceinline__ void mm_rows_x_tile_t(f32x4 (&acc)[4], const float2 (&frag)[D / 8], const float* tile, int l16, int g) {
+#pragma unroll
+    for (int s = 0; s < D / 8; ++s) {
+        float2 b[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) b[t] = *reinterpret_cast<const float2*>(tile + (16 * t + l16) * (D + 4) + 8 * s + 2 * g);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = mfma4(frag[s].x, b[t].x, acc[t]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = mfma4(frag[s].y, b[t].y, acc[t]);
+    }
+}
+// acc[n] (16 x 16, n = 0..D/16-1) += P (16 x 64, wave-private LDS patch, A layout reads) . tile (64 x D)
+template <int D>
+__device__ __forceinline__ void mm_patch_x_tile(f32x4 (&acc)[D / 16], const float* patch, const float* tile, int l16, int g) {
+#pragma unroll
+    for (int s = 0; s < AT_TILE / 8; ++s) {
+        const float2 a = *reinterpret_cast<const float2*>(patch + l16 * AT_LDP + 8 * s + 2 * g);
+        float b0[D / 16], b1[D / 16];
+#pragma unroll
+        for (int n = 0; n < D / 16; ++n) {
+            b0[n] = tile[(8 * s + 2 * g) * (D + 4) + 16 * n + l16];
+            b1[n] = tile[(8 * s + 2 * g + 1) * (D + 4) + 16 * n + l16];
+        }
+#pragma unroll
+        for (int n = 0; n < D / 16; ++n) acc[n] = mfma4(a.x, b0[n], acc[n]);
+#pragma unroll
+        for (int n = 0; n < D / 16; ++n) acc[n] = mfma4(a.y, b1[n], acc[n]);
+    }
+}
+// 16 rows x D of a head-strided matrix straight into A-layout registers (row index clamped by the caller)
+template <int D>
+__device__ __forceinline__ void load_frag(float2 (&f)[D / 8], const float* rowptr, int g) {
+#pragma unroll
+    for (int s = 0; s < D / 8; ++s) f[s] = *reinterpret_cast<const float2*>(rowptr + 8 * s + 2 * g);
+}
+
+// ------------------------------------------------------------------ forward
+template <int DK, int DV>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
+    __shared__ __attribute__((aligned(16))) float Ks[AT_TILE * (DK + 4)];
+    __shared__ __attribute__((aligned(16))) float Vs[AT_TILE * (DV + 4)];
+    __shared__ __attribute__((aligned(16))) float Ps[4 * 16 * AT_LDP];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l16 = lane & 15, g = lane >> 4;
+    const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
+    const int q0 = blockIdx.x * AT_ROWS;
+    const int klim = p.klen ? min(p.klen[b], p.Tk) : p.Tk;
+    int kmax = klim;
+    if (p.causal) kmax = min(kmax, min(q0 + AT_ROWS, p.Tq));
+    const int nkt = (kmax + AT_TILE - 1) / AT_TILE;
+    const float* kbase = p.k + (long)b * p.Tk * p.ldk + h * DK;
+    const float* vbase = p.v + (long)b * p.Tk * p.ldv + h * DV;
+    float2 qf[DK / 8];
+    load_frag<DK>(qf, p.q + ((long)b * p.Tq + min(q0 + 16 * w + l16, p.Tq - 1)) * p.ldq + h * DK, g);
+    f32x4 o[DV / 16];
+#pragma unroll
+    for (int n = 0; n < DV / 16; ++n) o[n] = zero_acc();
+    float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, lsum[4] = {0.f, 0.f, 0.f, 0.f};
+    float* Pw = Ps + w * 16 * AT_LDP;
+    Tile<DK> rk;
+    Tile<DV> rv;
+    rk.fetch(kbase, p.ldk, 0, p.Tk, tid);
+    rv.fetch(vbase, p.ldv, 0, p.Tk, tid);
+    for (int kt = 0; kt < nkt; ++kt) {
+        rk.commit(Ks, tid);
+        rv.commit(Vs, tid);
+        __syncthreads();
+        if (kt + 1 < nkt) {                      // next tile's loads fly under this tile's MFMAs
+            rk.fetch(kbase, p.ldk, (kt + 1) * AT_TILE, p.Tk, tid);
+            rv.fetch(vbase, p.ldv, (kt + 1) * AT_TILE, p.Tk, tid);
+        }
+        f32x4 sc[4] = {zero_acc(), zero_acc(), zero_acc(), zero_acc()};
+        mm_rows_x_tile_t<DK>(sc, qf, Ks, l16, g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int qi = q0 + 16 * w + 4 * g + r;
+            float mx = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int key = kt * AT_TILE + 16 * t + l16;
+                const bool valid = key < klim && (!p.causal || key <= qi);
+                const float x = valid ? sc[t][r] * p.scale : -INFINITY;       // (q.k)/temperature, then masked_fill(-inf)
+                sc[t][r] = x;
+                mx = fmaxf(mx, x);
+            }
+            mx = row16_max(mx);
+            const float mnew = fmaxf(m[r], mx);
+            const float msafe = mnew == -INFINITY ? 0.f : mnew;
+            const float alpha = expf(m[r] - msafe);          // m = -inf (first tile) -> 0
+            float rs = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float e = expf(sc[t][r] - msafe);
+                sc[t][r] = e;
+                rs += e;
+            }
+            rs = row16_sum(rs);
+            lsum[r] = lsum[r] * alpha + rs;
+            m[r] = mnew;
+#pragma unroll
+            for (int n = 0; n < DV / 16; ++n) o[n][r] *= alpha;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                float e = sc[t][r];
+                if (p.pmask) {                    // dropout on the probabilities (common_layers.py:328); the row sum stays un-dropped
+                    const int key = kt * AT_TILE + 16 * t + l16;
+                    const bool keep = key < p.Tk && qi < p.Tq && p.pmask[((long)bh * p.Tq + qi) * p.ldm + key];
+                    e = keep ? e * p.pscale : 0.f;
+                }
+                Pw[(4 * g + r) * AT_LDP + 16 * t + l16] = e;
+            }
+        }
+        wave_lds_sync();
+        mm_patch_x_tile<DV>(o, Pw, Vs, l16, g);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int qi = q0 + 16 * w + 4 * g + r;
+        if (qi >= p.Tq) continue;
+        const float inv = 1.f / lsum[r];
+        float* orow = p.O + ((long)b * p.Tq + qi) * p.ldo + h * DV;
+#pragma unroll
+        for (int n = 0; n < DV / 16; ++n) orow[16 * n + l16] = o[n][r] * inv;
+        if (l16 == 0) p.lse[(long)bh * p.Tq + qi] = m[r] + logf(lsum[r]);
+    }
+}
+
+// ------------------------------------------------------------------ backward, query side: dQ (and delta = rowsum(dO * O))
+// dS = P * (dP - delta) * scale with P = exp(S * scale - lse) recomputed, dP = (dO . V^T) [* mask * pscale];  dQ = dS . K
+template <int DK, int DV>
+__global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnP p) {
+    __shared__ __attribute__((aligned(16))) float Ks[AT_TILE * (DK + 4)];
+    __shared__ __attribute__((aligned(16))) float Vs[AT_TILE * (DV + 4)];
+    __shared__ __attribute__((aligned(16))) float Ps[4 * 16 * AT_LDP];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l16 = lane & 15, g = lane >> 4;
+    const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
+    const int q0 = blockIdx.x * AT_ROWS;
+    const int klim = p.klen ? min(p.klen[b], p.Tk) : p.Tk;
+    int kmax = klim;
+    if (p.causal) kmax = min(kmax, min(q0 + AT_ROWS, p.Tq));
+    const int nkt = (kmax + AT_TILE - 1) / AT_TILE;
+    const float* kbase = p.k + (long)b * p.Tk * p.ldk + h * DK;
+    const float* vbase = p.v + (long)b * p.Tk * p.ldv + h * DV;
+    const int qrow = min(q0 + 16 * w + l16, p.Tq - 1);
+    float2 qf[DK / 8], dof[DV / 8];
+    load_frag<DK>(qf, p.q + ((long)b * p.Tq + qrow) * p.ldq + h * DK, g);
+    load_frag<DV>(dof, p.dO + ((long)b * p.Tq + qrow) * p.ldo + h * DV, g);
+    float dl_row;
+    {
+        float2 of[DV / 8];
+        load_frag<DV>(of, p.Oc + ((long)b * p.Tq + qrow) * p.ldo + h * DV, g);
+        float part = 0.f;
+#pragma unroll
+        for (int s = 0; s < DV / 8; ++s) part += dof[s].x * of[s].x + dof[s].y * of[s].y;
+        part += __shfl_xor(part, 16, 64);
+        part += __shfl_xor(part, 32, 64);
+        dl_row = part;                             // delta of row l16, in every lane group
+        if (g == 0 && q0 + 16 * w + l16 < p.Tq) p.delta[(long)bh * p.Tq + q0 + 16 * w + l16] = part;
+    }
+    float dl[4], ls[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        dl[r] = __shfl(dl_row, 4 * g + r, 64);
+        ls[r] = p.lse[(long)bh * p.Tq + min(q0 + 16 * w + 4 * g + r, p.Tq - 1)];
+    }
+    f32x4 dq[DK / 16];
+#pragma unroll
+    for (int n = 0; n < DK / 16; ++n) dq[n] = zero_acc();
+    float* Pw = Ps + w * 16 * AT_LDP;
+    Tile<DK> rk;
+    Tile<DV> rv;
+    rk.fetch(kbase, p.ldk, 0, p.Tk, tid);
+    rv.fetch(vbase, p.ldv, 0, p.Tk, tid);
+    for (int kt = 0; kt < nkt; ++kt) {
+        rk.commit(Ks, tid);
+        rv.commit(Vs, tid);
+        __syncthreads();
+        if (kt + 1 < nkt) {
+            rk.fetch(kbase, p.ldk, (kt + 1) * AT_TILE, p.Tk, tid);
+            rv.fetch(vbase, p.ldv, (kt + 1) * AT_TILE, p.Tk, tid);
+        }
+        f32x4 sc[4] = {zero_acc(), zero_acc(), zero_acc(), zero_acc()};
+        f32x4 dp[4] = {zero_acc(), zero_acc(), zero_acc(), zero_acc()};
+        mm_rows_x_tile_t<DK>(sc, qf, Ks, l16, g);
+        mm_rows_x_tile_t<DV>(dp, dof, Vs, l16, g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int qi = q0 + 16 * w + 4 * g + r;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int key = kt * AT_TILE + 16 * t + l16;
+                const bool valid = key < klim && (!p.causal || key <= qi);
+                const float pr = valid ? expf(sc[t][r] * p.scale - ls[r]) : 0.f;
+                float d = dp[t][r];
+                if (p.pmask) {
+                    const bool keep = valid && qi < p.Tq && p.pmask[((long)bh * p.Tq + qi) * p.ldm + key];
+                    d = keep ? d * p.pscale : 0.f;
+                }
+                Pw[(4 * g + r) * AT_LDP + 16 * t + l16] = pr * (d - dl[r]) * p.scale;
+            }
+        }
+        wave_lds_sync();
+        mm_patch_x_tile<DK>(dq, Pw, Ks, l16, g);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int qi = q0 + 16 * w + 4 * g + r;
+        if (qi >= p.Tq) continue;
+        float* drow = p.dq + ((long)b * p.Tq + qi) * p.lddq + h * DK;
+#pragma unroll
+        for (int n = 0; n < DK / 16; ++n) drow[16 * n + l16] = dq[n][r];
+    }
+}
+
+// ------------------------------------------------------------------ backward, key side: dK = dS^T . Q, dV = Pd^T . dO
+// one workgroup owns 64 keys (16 per wave) and streams 64-query tiles of Q and dO; everything is computed transposed
+// (keys are the MFMA rows), so the per-query statistics lse / delta are per-COLUMN values here
+template <int DK, int DV>
+__global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnP p) {
+    __shared__ __attribute__((aligned(16))) float Qs[AT_TILE * (DK + 4)];
+    __shared__ __attribute__((aligned(16))) float Ds[AT_TILE * (DV + 4)];
+    __shared__ __attribute__((aligned(16))) float Ps[4 * 16 * AT_LDP];
+    __shared__ float lse_s[AT_TILE], dl_s[AT_TILE];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l16 = lane & 15, g = lane >> 4;
+    const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
+    const int k0 = blockIdx.x * AT_ROWS;
+    const int klim = p.klen ? min(p.klen[b], p.Tk) : p.Tk;
+    f32x4 dk[DK / 16], dv[DV / 16];
+#pragma unroll
+    for (int n = 0; n < DK / 16; ++n) dk[n] = zero_acc();
+#pragma unroll
+    for (int n = 0; n < DV / 16; ++n) dv[n] = zero_acc();
+    const int nqt = (p.Tq + AT_TILE - 1) / AT_TILE;
+    const int qt0 = p.causal ? k0 / AT_TILE : 0;           // queries before the first key of this block never see it
+    if (k0 < klim) {                                       // (keys at or beyond klen[b] are masked for every query: zero gradient)
+        const int krow = min(k0 + 16 * w + l16, p.Tk - 1);
+        float2 kf[DK / 8], vf[DV / 8];
+        load_frag<DK>(kf, p.k + ((long)b * p.Tk + krow) * p.ldk + h * DK, g);
+        load_frag<DV>(vf, p.v + ((long)b * p.Tk + krow) * p.ldv + h * DV, g);
+        const float* qbase = p.q + (long)b * p.Tq * p.ldq + h * DK;
+        const float* dobase = p.dO + (long)b * p.Tq * p.ldo + h * DV;
+        float* Pw = Ps + w * 16 * AT_LDP;
+        Tile<DK> rq;
+        Tile<DV> rd;
+        float r_lse = 0.f, r_dl = 0.f;
+        auto fetch_stats = [&](int qt) {
+            if (tid < AT_TILE) {
+                const int qi = min(qt * AT_TILE + tid, p.Tq - 1);
+                r_lse = p.lse[(long)bh * p.Tq + qi];
+                r_dl = p.delta[(long)bh * p.Tq + qi];
+            }
+        };
+        if (qt0 < nqt) {
+            rq.fetch(qbase, p.ldq, qt0 * AT_TILE, p.Tq, tid);
+            rd.fetch(dobase, p.ldo, qt0 * AT_TILE, p.Tq, tid);
+            fetch_stats(qt0);
+        }
+        for (int qt = qt0; qt < nqt; ++qt) {
+            rq.commit(Qs, tid);
+            rd.commit(Ds, tid);
+            if (tid < AT_TILE) {
+                lse_s[tid] = r_lse;
+                dl_s[tid] = r_dl;
+            }
+            __syncthreads();
+            if (qt + 1 < nqt) {
+                rq.fetch(qbase, p.ldq, (qt + 1) * AT_TILE, p.Tq, tid);
+                rd.fetch(dobase, p.ldo, (qt + 1) * AT_TILE, p.Tq, tid);
+                fetch_stats(qt + 1);
+            }
+            f32x4 st[4] = {zero_acc(), zero_acc(), zero_acc(), zero_acc()};
+            f32x4 dpt[4] = {zero_acc(), zero_acc(), zero_acc(), zero_acc()};
+            mm_rows_x_tile_t<DK>(st, kf, Qs, l16, g);      // S^T  [key][query]
+            mm_rows_x_tile_t<DV>(dpt, vf, Ds, l16, g);     // dPd^T = V . dO^T
+            float ds[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = k0 + 16 * w + 4 * g + r;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int qi = qt * AT_TILE + 16 * t + l16;
+                    const bool valid = key < klim && qi < p.Tq && (!p.causal || key <= qi);
+                    const float pr = valid ? expf(st[t][r] * p.scale - lse_s[16 * t + l16]) : 0.f;
+                    float pd = pr, d = dpt[t][r];
+                    if (p.pmask) {
+                        const bool keep = valid && p.pmask[((long)bh * p.Tq + qi) * p.ldm + key];
+                        pd = keep ? pr * p.pscale : 0.f;
+                        d = keep ? d * p.pscale : 0.f;
+                    }
+                    ds[t][r] = pr * (d - dl_s[16 * t + l16]) * p.scale;
+                    Pw[(4 * g + r) * AT_LDP + 16 * t + l16] = pd;
+                }
+            }
+            wave_lds_sync();
+            mm_patch_x_tile<DV>(dv, Pw, Ds, l16, g);       // dV += Pd^T . dO
+            wave_lds_sync();
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) Pw[(4 * g + r) * AT_LDP + 16 * t + l16] = ds[t][r];
+            wave_lds_sync();
+            mm_patch_x_tile<DK>(dk, Pw, Qs, l16, g);       // dK += dS^T . Q
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int key = k0 + 16 * w + 4 * g + r;
+        if (key >= p.Tk) continue;
+        float* kr = p.dk + ((long)b * p.Tk + key) * p.lddk + h * DK;
+        float* vr = p.dv + ((long)b * p.Tk + key) * p.lddv + h * DV;
+#pragma unroll
+        for (int n = 0; n < DK / 16; ++n) kr[16 * n + l16] = dk[n][r];
+#pragma unroll
+        for (int n = 0; n < DV / 16; ++n) vr[16 * n + l16] = dv[n][r];
+    }
+}
+
+inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+
+bool attn_args_ok(const AttnP& p, int dk, int dv) {
+    if (!p.q || !p.k || !p.v || p.B <= 0 || p.H <= 0 || p.Tq <= 0 || p.Tk <= 0) return false;
+    if (!((dk == 64 && dv == 64) || (dk == 16 && dv == 16))) return false;
+    if (!al16(p.q) || !al16(p.k) || !al16(p.v) || (p.ldq & 3) || (p.ldk & 3) || (p.ldv & 3)) return false;
+    if (p.ldq < p.H * dk || p.ldk < p.H * dk || p.ldv < p.H * dv) return false;
+    if (p.pmask && p.ldm < p.Tk) return false;
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mtl_attn_supported(int dk, int dv) { return (dk == 64 && dv == 64) || (dk == 16 && dv == 16); }
+
+int mtl_attn_fwd(void* stream, const float* q, const float* k, const float* v, int ldq, int ldk, int ldv, const int* klen,
+                 int causal, float scale, int B, int H, int Tq, int Tk, int dk, int dv, const unsigned char* pmask, int ldm,
+                 float pscale, float* O, int ldo, float* lse) {
+    AttnP p{};
+    p.q = q, p.k = k, p.v = v, p.ldq = ldq, p.ldk = ldk, p.ldv = ldv, p.klen = klen, p.causal = causal, p.scale = scale;
+    p.B = B, p.H = H, p.Tq = Tq, p.Tk = Tk, p.pmask = pmask, p.ldm = ldm, p.pscale = pscale, p.O = O, p.ldo = ldo, p.lse = lse;
+    if (!attn_args_ok(p, dk, dv) || !O || !lse || ldo < H * dv) return MTL_EINVAL;
+    dim3 grid((Tq + AT_ROWS - 1) / AT_ROWS, B * H);
+    if (dk == 64)
+        hipLaunchKernelGGL((attn_fwd_kernel<64, 64>), grid, dim3(256), 0, as_stream(stream), p);
+    else
+        hipLaunchKernelGGL((attn_fwd_kernel<16, 16>), grid, dim3(256), 0, as_stream(stream), p);
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}
+
+int mtl_attn_bwd(void* stream, const float* q, const float* k, const float* v, int ldq, int ldk, int ldv, const int* klen,
+                 int causal, float scale, int B, int H, int Tq, int Tk, int dk, int dv, const unsigned char* pmask, int ldm,
+                 float pscale, const float* O, const float* dO, int ldo, const float* lse, float* delta, float* dq, float* dk_,
+                 float* dv_, int lddq, int lddk, int lddv) {
+    AttnP p{};
+    p.q = q, p.k = k, p.v = v, p.ldq = ldq, p.ldk = ldk, p.ldv = ldv, p.klen = klen, p.causal = causal, p.scale = scale;
+    p.B = B, p.H = H, p.Tq = Tq, p.Tk = Tk, p.pmask = pmask, p.ldm = ldm, p.pscale = pscale, p.Oc = O, p.dO = dO, p.ldo = ldo;
+    p.lse = const_cast<float*>(lse), p.delta = delta, p.dq = dq, p.dk = dk_, p.dv = dv_, p.lddq = lddq, p.lddk = lddk, p.lddv = lddv;
+    if (!attn_args_ok(p, dk, dv) || !O || !dO || !lse || !delta || !dq || !dk_ || !dv_) return MTL_EINVAL;
+    if (!al16(dO) || (ldo & 3) || ldo < H * dv || lddq < H * dk || lddk < H * dk || lddv < H * dv) return MTL_EINVAL;
+    dim3 gq((Tq + AT_ROWS - 1) / AT_ROWS, B * H), gk((Tk + AT_ROWS - 1) / AT_ROWS, B * H);
+    hipStream_t s = as_stream(stream);
+    if (dk == 64) {
+        hipLaunchKernelGGL((attn_bwd_q_kernel<64, 64>), gq, dim3(256), 0, s, p);
+        hipLaunchKernelGGL((attn_bwd_kv_kernel<64, 64>), gk, dim3(256), 0, s, p);
+    } else {
+        hipLaunchKernelGGL((attn_bwd_q_kernel<16, 16>), gq, dim3(256), 0, s, p);
+        hipLaunchKernelGGL((attn_bwd_kv_kernel<16, 16>), gk, dim3(256), 0, s, p);
+    }
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}
+
+}  // extern "C"

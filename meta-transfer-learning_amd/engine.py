@@ -220,6 +220,10 @@ class PassEngine:
         self.conv_x3 = os.environ.get('MTL_CONV_X3', '1') != '0'
         self.batch_qkv = os.environ.get('MTL_BATCH_QKV', '1') != '0'   # q/k/v projections as strided-batch GEMMs
         self.wgrad_x3_dense = os.environ.get('MTL_WGRAD_X3_DENSE', '1') != '0'    # conv5 (dy not pooled)
+        # scaled-dot-product attention as ONE flash-style kernel forward and two backward (no score tensor in HBM); head sizes
+        # outside mtl_attn_supported() take the batched-GEMM + softmax path ('0' forces it, for A/B measurements)
+        self.fused_attn = (os.environ.get('MTL_FUSED_ATTN', '1') != '0' and device.type == 'cuda'
+                           and bool(self.lib.mtl_attn_supported(hp.dk, hp.dv)))
         self.prof = None    # optional {name: [flops, [(start_event, end_event), ...]]}: HIP events around the conv launches
         if device.type != 'cuda':
             raise RuntimeError('PassEngine needs an MI355X device (got %s); there is no CPU product path' % device)
@@ -369,17 +373,24 @@ class PassEngine:
                 t[nm + 'a'], t[nm] = a_all[i], b_all[i]
         self.arena[tag + 'groups'] = groups
         ldS = (Tk + 3) // 4 * 4
-        S = self.buf(tag + 'P', (Bn, h, Tq, ldS))
-        self.gemm(0, 1, Tq, Tk, dk, t['q'].data_ptr(), hk, t['k'].data_ptr(), hk, S.data_ptr(), ldS, batch=Bn * h, H=h,
-                  sA=(Tq * hk, dk), sB=(Tk * hk, dk), sC=(h * Tq * ldS, Tq * ldS))
         mP = self.drop_mask(tag + 'mP', (Bn, h, Tq, ldS))                       # dropout on the probabilities (:328)
-        Pd = self.buf(tag + 'Pd', (Bn, h, Tq, ldS)) if mP is not None else S
-        check(self.lib.mtl_softmax_mask_fwd(self.stream, S.data_ptr(), klen, causal, 1.0 / float(hp.temperature), Bn, h, Tq,
-                                            Tk, ldS, mP.data_ptr() if mP is not None else None, self.drop_scale,
-                                            Pd.data_ptr() if mP is not None else None), 'mtl_softmax_mask_fwd')
         O = self.buf(tag + 'O', (Mq, hv))
-        self.gemm(0, 0, Tq, dv, Tk, Pd.data_ptr(), ldS, t['v'].data_ptr(), hv, O.data_ptr(), hv, batch=Bn * h, H=h,
-                  sA=(h * Tq * ldS, Tq * ldS), sB=(Tk * hv, dv), sC=(Tq * hv, dv))
+        if self.fused_attn:
+            lse = self.buf(tag + 'lse', (Bn, h, Tq))
+            check(self.lib.mtl_attn_fwd(self.stream, t['q'].data_ptr(), t['k'].data_ptr(), t['v'].data_ptr(), hk, hk, hv, klen, causal,
+                                        1.0 / float(hp.temperature), Bn, h, Tq, Tk, dk, dv, mP.data_ptr() if mP is not None else None,
+                                        ldS, self.drop_scale, O.data_ptr(), hv, lse.data_ptr()), 'mtl_attn_fwd')
+        else:
+            S = self.buf(tag + 'P', (Bn, h, Tq, ldS))
+            self.gemm(0, 1, Tq, Tk, dk, t['q'].data_ptr(), hk, t['k'].data_ptr(), hk, S.data_ptr(), ldS, batch=Bn * h, H=h,
+                      sA=(Tq * hk, dk), sB=(Tk * hk, dk), sC=(h * Tq * ldS, Tq * ldS))
+            Pd = self.buf(tag + 'Pd', (Bn, h, Tq, ldS)) if mP is not None else S
+            check(self.lib.mtl_softmax_mask_fwd(self.stream, S.data_ptr(), klen, causal, 1.0 / float(hp.temperature), Bn, h, Tq,
+                                                Tk, ldS, mP.data_ptr() if mP is not None else None, self.drop_scale,
+                                                Pd.data_ptr() if mP is not None else None), 'mtl_softmax_mask_fwd')
+            self.gemm(0, 0, Tq, dv, Tk, Pd.data_ptr(), ldS, t['v'].data_ptr(), hv, O.data_ptr(), hv, batch=Bn * h, H=h,
+                      sA=(h * Tq * ldS, Tq * ldS), sB=(Tk * hv, dv), sC=(Tq * hv, dv))
+        self.arena[tag + 'attn'] = (klen, causal)
         oa = self.buf(tag + 'oa', (Mq, r))
         ob = self.buf(tag + 'ob', (Mq, d))
         self.linear_fwd(O.data_ptr(), Mq, hv, o('output_linear_a.weight'), None, oa.data_ptr(), r)
@@ -401,7 +412,7 @@ class PassEngine:
         o = lambda n: P + 4 * L.off(pre + n)
         g = lambda n: G + 4 * L.off(pre + n)
         ldS = (Tk + 3) // 4 * 4
-        Pm, O, oa = A[tag + 'P'], A[tag + 'O'], A[tag + 'oa']
+        O, oa = A[tag + 'O'], A[tag + 'oa']
         # LayerNorm(o + residual) * keep
         dzb = self.buf(tag + '_dz', (Mq, d))       # kept intact for the deferred dW GEMM; dxq = dz + projections
         mo, mP = A.get(tag + 'mo'), A.get(tag + 'mP')
@@ -426,21 +437,30 @@ class PassEngine:
                 dfull[nm] = d_all[i]
             dfull[names] = d_all
         dq, dkk, dvv = dfull['q'], dfull['k'], dfull['v']
-        dP = self.buf('_dP', (Bn, h, Tq, ldS))
-        sP = (h * Tq * ldS, Tq * ldS)
-        # dV = P^T dO ; dP = dO V^T ; dS = softmax'(P, dP)/temp ; dQ = dS K ; dK = dS^T Q
-        Pv = A[tag + 'Pd'] if mP is not None else Pm                      # the probabilities that actually multiplied V
-        self.gemm(1, 0, Tk, dv, Tq, Pv.data_ptr(), ldS, dO.data_ptr(), hv, dvv.data_ptr(), hv, batch=Bn * h, H=h,
-                  sA=sP, sB=(Tq * hv, dv), sC=(Tk * hv, dv))
-        self.gemm(0, 1, Tq, Tk, dv, dO.data_ptr(), hv, v.data_ptr(), hv, dP.data_ptr(), ldS, batch=Bn * h, H=h,
-                  sA=(Tq * hv, dv), sB=(Tk * hv, dv), sC=sP)
-        check(self.lib.mtl_softmax_bwd(self.stream, Pm.data_ptr(), dP.data_ptr(), 1.0 / float(hp.temperature),
-                                       Bn * h * Tq, Tk, ldS, mP.data_ptr() if mP is not None else None, self.drop_scale),
-              'mtl_softmax_bwd')
-        self.gemm(0, 0, Tq, dk, Tk, dP.data_ptr(), ldS, k.data_ptr(), hk, dq.data_ptr(), hk, batch=Bn * h, H=h,
-                  sA=sP, sB=(Tk * hk, dk), sC=(Tq * hk, dk))
-        self.gemm(1, 0, Tk, dk, Tq, dP.data_ptr(), ldS, q.data_ptr(), hk, dkk.data_ptr(), hk, batch=Bn * h, H=h,
-                  sA=sP, sB=(Tq * hk, dk), sC=(Tk * hk, dk))
+        if self.fused_attn:
+            klen, causal = A[tag + 'attn']
+            delta = self.buf('_delta', (Bn * h * Tq,))
+            check(self.lib.mtl_attn_bwd(self.stream, q.data_ptr(), k.data_ptr(), v.data_ptr(), hk, hk, hv, klen, causal,
+                                        1.0 / float(hp.temperature), Bn, h, Tq, Tk, dk, dv, mP.data_ptr() if mP is not None else None,
+                                        ldS, self.drop_scale, O.data_ptr(), dO.data_ptr(), hv, A[tag + 'lse'].data_ptr(),
+                                        delta.data_ptr(), dq.data_ptr(), dkk.data_ptr(), dvv.data_ptr(), hk, hk, hv), 'mtl_attn_bwd')
+        else:
+            Pm = A[tag + 'P']
+            dP = self.buf('_dP', (Bn, h, Tq, ldS))
+            sP = (h * Tq * ldS, Tq * ldS)
+            # dV = P^T dO ; dP = dO V^T ; dS = softmax'(P, dP)/temp ; dQ = dS K ; dK = dS^T Q
+            Pv = A[tag + 'Pd'] if mP is not None else Pm                      # the probabilities that actually multiplied V
+            self.gemm(1, 0, Tk, dv, Tq, Pv.data_ptr(), ldS, dO.data_ptr(), hv, dvv.data_ptr(), hv, batch=Bn * h, H=h,
+                      sA=sP, sB=(Tq * hv, dv), sC=(Tk * hv, dv))
+            self.gemm(0, 1, Tq, Tk, dv, dO.data_ptr(), hv, v.data_ptr(), hv, dP.data_ptr(), ldS, batch=Bn * h, H=h,
+                      sA=(Tq * hv, dv), sB=(Tk * hv, dv), sC=sP)
+            check(self.lib.mtl_softmax_bwd(self.stream, Pm.data_ptr(), dP.data_ptr(), 1.0 / float(hp.temperature),
+                                           Bn * h * Tq, Tk, ldS, mP.data_ptr() if mP is not None else None, self.drop_scale),
+                  'mtl_softmax_bwd')
+            self.gemm(0, 0, Tq, dk, Tk, dP.data_ptr(), ldS, k.data_ptr(), hk, dq.data_ptr(), hk, batch=Bn * h, H=h,
+                      sA=sP, sB=(Tk * hk, dk), sC=(Tq * hk, dk))
+            self.gemm(1, 0, Tk, dk, Tq, dP.data_ptr(), ldS, q.data_ptr(), hk, dkk.data_ptr(), hk, batch=Bn * h, H=h,
+                      sA=sP, sB=(Tq * hk, dk), sC=(Tk * hk, dk))
         first_kv = True
         for names, src, rows in groups:
             n, f0 = len(names), _FULL[names[0]]

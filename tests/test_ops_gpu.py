@@ -311,6 +311,75 @@ def test_layernorm(L, d):
     assert rel(dz, rr.grad) < 1e-5 and rel(dzm, xr.grad) < 1e-5 and rel(dsum, xr.grad.sum(0)) < 1e-5 and rel(dg, gr.grad) < 1e-5
 
 
+@pytest.mark.parametrize('B,H,Tq,Tk,dk,causal,klens,drop', [
+    (3, 8, 101, 250, 64, 0, [250, 31, 1], 0.0),       # encoder-decoder attention: ragged key lengths, one key only
+    (2, 8, 101, 101, 64, 1, [101, 40], 0.0),          # decoder self-attention: causal + EOS-keyed lengths
+    (2, 8, 250, 250, 64, 0, None, 0.0),               # encoder self-attention, tile tails (250 = 3 x 64 + 58)
+    (2, 4, 130, 130, 64, 1, [130, 65], 0.25),         # dropout on the probabilities, causal, three key tiles
+    (3, 8, 9, 16, 16, 0, [16, 10, 3], 0.0),           # fixture head size (d_k = 16)
+    (2, 8, 70, 70, 16, 1, [70, 9], 0.3),
+])
+def test_fused_attention_forward_and_backward(L, B, H, Tq, Tk, dk, causal, klens, drop):
+    """mtl_attn_fwd / mtl_attn_bwd against ScaledDotProductAttention written out in torch (modules/common_layers.py:317-331:
+    bmm, /temperature, masked_fill(-inf), softmax, dropout mask, bmm) and its autograd gradients: output 3e-6, gradients 1e-5,
+    bitwise repeatable.  Heads are read by stride from (rows, H*d) matrices, exactly as the engine stores q / k / v."""
+    g = torch.Generator().manual_seed(B * 100 + Tq + Tk + dk + causal)
+    dv = dk
+    q = torch.randn(B, Tq, H * dk, generator=g, requires_grad=True)
+    k = torch.randn(B, Tk, H * dk, generator=g, requires_grad=True)
+    v = torch.randn(B, Tk, H * dv, generator=g, requires_grad=True)
+    dO = torch.randn(B, Tq, H * dv, generator=g)
+    temp = float(np.power(dk, 0.5))
+    blocked = torch.zeros(B, 1, Tq, Tk, dtype=torch.bool)
+    if klens is not None:
+        blocked = blocked | (torch.arange(Tk).view(1, 1, 1, Tk) >= torch.tensor(klens).view(B, 1, 1, 1))
+    if causal:
+        blocked = blocked | torch.triu(torch.ones(Tq, Tk, dtype=torch.bool), diagonal=1).view(1, 1, Tq, Tk)
+    ldm = (Tk + 3) // 4 * 4
+    keep = (torch.rand(B, H, Tq, ldm, generator=g) >= drop).to(torch.uint8) if drop > 0 else None
+    qh = q.view(B, Tq, H, dk).transpose(1, 2)
+    kh = k.view(B, Tk, H, dk).transpose(1, 2)
+    vh = v.view(B, Tk, H, dv).transpose(1, 2)
+    sc = (qh @ kh.transpose(2, 3)) / temp
+    pr = torch.softmax(sc.masked_fill(blocked, -np.inf), dim=-1)
+    if keep is not None:
+        pr = pr * keep[..., :Tk].float() / (1 - drop)
+    ref = (pr @ vh).transpose(1, 2).reshape(B, Tq, H * dv)
+    ref.backward(dO)
+    lse_ref = torch.logsumexp(sc.masked_fill(blocked, -np.inf), dim=-1).detach()
+
+    dq_, dk_, dv_, ddO = dev(q.detach()), dev(k.detach()), dev(v.detach()), dev(dO)
+    klen = dev(torch.tensor(klens, dtype=torch.int32)) if klens is not None else None
+    dkeep = dev(keep) if keep is not None else None
+    outs = []
+    for _ in range(2):
+        O = torch.full((B, Tq, H * dv), float('nan')).cuda()
+        lse = torch.empty(B, H, Tq).cuda()
+        assert L.mtl_attn_fwd(st(), dq_.data_ptr(), dk_.data_ptr(), dv_.data_ptr(), H * dk, H * dk, H * dv,
+                              klen.data_ptr() if klen is not None else None, causal, 1.0 / temp, B, H, Tq, Tk, dk, dv,
+                              dkeep.data_ptr() if dkeep is not None else None, ldm, 1.0 / (1 - drop), O.data_ptr(), H * dv,
+                              lse.data_ptr()) == 0
+        gq = torch.full((B, Tq, H * dk), float('nan')).cuda()
+        gk = torch.full((B, Tk, H * dk), float('nan')).cuda()
+        gv = torch.full((B, Tk, H * dv), float('nan')).cuda()
+        delta = torch.empty(B * H * Tq).cuda()
+        assert L.mtl_attn_bwd(st(), dq_.data_ptr(), dk_.data_ptr(), dv_.data_ptr(), H * dk, H * dk, H * dv,
+                              klen.data_ptr() if klen is not None else None, causal, 1.0 / temp, B, H, Tq, Tk, dk, dv,
+                              dkeep.data_ptr() if dkeep is not None else None, ldm, 1.0 / (1 - drop), O.data_ptr(), ddO.data_ptr(),
+                              H * dv, lse.data_ptr(), delta.data_ptr(), gq.data_ptr(), gk.data_ptr(), gv.data_ptr(), H * dk, H * dk,
+                              H * dv) == 0
+        outs.append([t.cpu() for t in (O, lse, gq, gk, gv)])
+    O, lse, gq, gk, gv = outs[0]
+    assert rel(O, ref.detach()) < 3e-6
+    assert float((lse - lse_ref).abs().max()) < 1e-5
+    assert rel(gq, q.grad) < 1e-5 and rel(gk, k.grad) < 1e-5 and rel(gv, v.grad) < 1e-5
+    if klens is not None:      # keys beyond a sample's length never receive gradient: exact zeros, not rounding noise
+        for b, n in enumerate(klens):
+            assert float(gk[b, n:].abs().max() if n < Tk else 0.0) == 0.0 and float(gv[b, n:].abs().max() if n < Tk else 0.0) == 0.0
+    for a, b_ in zip(outs[0], outs[1]):
+        assert torch.equal(a, b_)
+
+
 @pytest.mark.parametrize('causal', [0, 1])
 def test_softmax(L, causal):
     g = torch.Generator().manual_seed(causal)
