@@ -55,15 +55,24 @@ __device__ __forceinline__ f32x4 zero_acc() {
     f32x4 z = {0.f, 0.f, 0.f, 0.f};
     return z;
 }
-// max / sum over the 16 lanes that hold one C-layout row
+// max / sum over the 16 lanes that hold one C-layout row: four DPP moves (xor 1, xor 2 inside the quad, half-row mirror, row
+// mirror) -- plain VALU; the ds_bpermute form of __shfl_xor cost one LDS-crossbar round trip per step (32 serialised per tile)
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
 __device__ __forceinline__ float row16_max(float v) {
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    v = fmaxf(v, dpp_mov<0xB1>(v));     // quad_perm [1,0,3,2]
+    v = fmaxf(v, dpp_mov<0x4E>(v));     // quad_perm [2,3,0,1]
+    v = fmaxf(v, dpp_mov<0x141>(v));    // row_half_mirror
+    v = fmaxf(v, dpp_mov<0x140>(v));    // row_mirror
     return v;
 }
 __device__ __forceinline__ float row16_sum(float v) {
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    v += dpp_mov<0x141>(v);
+    v += dpp_mov<0x140>(v);
     return v;
 }
 // LDS writes of this wave become visible to its own later LDS reads (DS ops of one wave execute in order; this only stops the
@@ -100,35 +109,60 @@ struct Tile {
 };
 
 // acc[t] (16 rows x 16 cols, t = 0..3) += frag (16 x D, registers, A layout) . tile[16 t + j][.]^T   (tile rows as columns)
+// The B fragments of step s+1 are requested before the MFMAs of step s issue (pinned with sched_barrier), so an MFMA group
+// never waits on its own LDS read.
 template <int D>
 __device__ __forceinline__ void mm_rows_x_tile_t(f32x4 (&acc)[4], const float2 (&frag)[D / 8], const float* tile, int l16, int g) {
+    const float* src = tile + l16 * (D + 4) + 2 * g;
+    float2 b[2][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) b[0][t] = *reinterpret_cast<const float2*>(src + 16 * t * (D + 4));
 #pragma unroll
     for (int s = 0; s < D / 8; ++s) {
-        float2 b[4];
+        const int cur = s & 1, nxt = cur ^ 1;
+        if (s + 1 < D / 8) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) b[t] = *reinterpret_cast<const float2*>(tile + (16 * t + l16) * (D + 4) + 8 * s + 2 * g);
+            for (int t = 0; t < 4; ++t) b[nxt][t] = *reinterpret_cast<const float2*>(src + 16 * t * (D + 4) + 8 * (s + 1));
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = mfma4(frag[s].x, b[t].x, acc[t]);
+        for (int t = 0; t < 4; ++t) acc[t] = mfma4(frag[s].x, b[cur][t].x, acc[t]);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = mfma4(frag[s].y, b[t].y, acc[t]);
+        for (int t = 0; t < 4; ++t) acc[t] = mfma4(frag[s].y, b[cur][t].y, acc[t]);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 // acc[n] (16 x 16, n = 0..D/16-1) += P (16 x 64, wave-private LDS patch, A layout reads) . tile (64 x D)
 template <int D>
 __device__ __forceinline__ void mm_patch_x_tile(f32x4 (&acc)[D / 16], const float* patch, const float* tile, int l16, int g) {
+    constexpr int N = D / 16;
+    const float* pa = patch + l16 * AT_LDP + 2 * g;
+    const float* pb = tile + 2 * g * (D + 4) + l16;
+    float2 a[2];
+    float b0[2][N], b1[2][N];
+    a[0] = *reinterpret_cast<const float2*>(pa);
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+        b0[0][n] = pb[16 * n];
+        b1[0][n] = pb[(D + 4) + 16 * n];
+    }
 #pragma unroll
     for (int s = 0; s < AT_TILE / 8; ++s) {
-        const float2 a = *reinterpret_cast<const float2*>(patch + l16 * AT_LDP + 8 * s + 2 * g);
-        float b0[D / 16], b1[D / 16];
+        const int cur = s & 1, nxt = cur ^ 1;
+        if (s + 1 < AT_TILE / 8) {
+            a[nxt] = *reinterpret_cast<const float2*>(pa + 8 * (s + 1));
 #pragma unroll
-        for (int n = 0; n < D / 16; ++n) {
-            b0[n] = tile[(8 * s + 2 * g) * (D + 4) + 16 * n + l16];
-            b1[n] = tile[(8 * s + 2 * g + 1) * (D + 4) + 16 * n + l16];
+            for (int n = 0; n < N; ++n) {
+                b0[nxt][n] = pb[8 * (s + 1) * (D + 4) + 16 * n];
+                b1[nxt][n] = pb[(8 * (s + 1) + 1) * (D + 4) + 16 * n];
+            }
         }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int n = 0; n < D / 16; ++n) acc[n] = mfma4(a.x, b0[n], acc[n]);
+        for (int n = 0; n < N; ++n) acc[n] = mfma4(a[cur].x, b0[cur][n], acc[n]);
 #pragma unroll
-        for (int n = 0; n < D / 16; ++n) acc[n] = mfma4(a.y, b1[n], acc[n]);
+        for (int n = 0; n < N; ++n) acc[n] = mfma4(a[cur].y, b1[cur][n], acc[n]);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 // 16 rows x D of a head-strided matrix straight into A-layout registers (row index clamped by the caller)
@@ -172,44 +206,65 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
             rk.fetch(kbase, p.ldk, (kt + 1) * AT_TILE, p.Tk, tid);
             rv.fetch(vbase, p.ldv, (kt + 1) * AT_TILE, p.Tk, tid);
         }
+        unsigned keepbits = 0xffffu;                 // dropout keep bits of this lane's 4 x 4 scores, fetched under the MFMAs
+        if (p.pmask) {
+            keepbits = 0u;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qi = q0 + 16 * w + 4 * g + r;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int key = kt * AT_TILE + 16 * t + l16;
+                    const bool in = key < p.Tk && qi < p.Tq;
+                    const unsigned kb = in ? p.pmask[((long)bh * p.Tq + qi) * p.ldm + key] : 0u;
+                    keepbits |= (kb ? 1u : 0u) << (4 * r + t);
+                }
+            }
+        }
         f32x4 sc[4] = {zero_acc(), zero_acc(), zero_acc(), zero_acc()};
         mm_rows_x_tile_t<DK>(sc, qf, Ks, l16, g);
+        float mx[4], alpha[4], rs[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int qi = q0 + 16 * w + 4 * g + r;
-            float mx = -INFINITY;
+            mx[r] = -INFINITY;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int key = kt * AT_TILE + 16 * t + l16;
                 const bool valid = key < klim && (!p.causal || key <= qi);
                 const float x = valid ? sc[t][r] * p.scale : -INFINITY;       // (q.k)/temperature, then masked_fill(-inf)
                 sc[t][r] = x;
-                mx = fmaxf(mx, x);
+                mx[r] = fmaxf(mx[r], x);
             }
-            mx = row16_max(mx);
-            const float mnew = fmaxf(m[r], mx);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx[r] = row16_max(mx[r]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float mnew = fmaxf(m[r], mx[r]);
             const float msafe = mnew == -INFINITY ? 0.f : mnew;
-            const float alpha = expf(m[r] - msafe);          // m = -inf (first tile) -> 0
-            float rs = 0.f;
+            alpha[r] = expf(m[r] - msafe);           // m = -inf (first tile) -> 0
+            m[r] = mnew;
+            rs[r] = 0.f;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const float e = expf(sc[t][r] - msafe);
                 sc[t][r] = e;
-                rs += e;
+                rs[r] += e;
             }
-            rs = row16_sum(rs);
-            lsum[r] = lsum[r] * alpha + rs;
-            m[r] = mnew;
+        }
 #pragma unroll
-            for (int n = 0; n < DV / 16; ++n) o[n][r] *= alpha;
+        for (int r = 0; r < 4; ++r) rs[r] = row16_sum(rs[r]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            lsum[r] = lsum[r] * alpha[r] + rs[r];
+#pragma unroll
+            for (int n = 0; n < DV / 16; ++n) o[n][r] *= alpha[r];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 float e = sc[t][r];
-                if (p.pmask) {                    // dropout on the probabilities (common_layers.py:328); the row sum stays un-dropped
-                    const int key = kt * AT_TILE + 16 * t + l16;
-                    const bool keep = key < p.Tk && qi < p.Tq && p.pmask[((long)bh * p.Tq + qi) * p.ldm + key];
-                    e = keep ? e * p.pscale : 0.f;
-                }
+                // dropout on the probabilities (common_layers.py:328); the row sum stays un-dropped
+                if (p.pmask) e = (keepbits >> (4 * r + t)) & 1u ? e * p.pscale : 0.f;
                 Pw[(4 * g + r) * AT_LDP + 16 * t + l16] = e;
             }
         }
@@ -283,6 +338,21 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnP p) {
             rk.fetch(kbase, p.ldk, (kt + 1) * AT_TILE, p.Tk, tid);
             rv.fetch(vbase, p.ldv, (kt + 1) * AT_TILE, p.Tk, tid);
         }
+        unsigned keepbits = 0xffffu;
+        if (p.pmask) {
+            keepbits = 0u;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qi = q0 + 16 * w + 4 * g + r;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int key = kt * AT_TILE + 16 * t + l16;
+                    const bool in = key < p.Tk && qi < p.Tq;
+                    const unsigned kb = in ? p.pmask[((long)bh * p.Tq + qi) * p.ldm + key] : 0u;
+                    keepbits |= (kb ? 1u : 0u) << (4 * r + t);
+                }
+            }
+        }
         f32x4 sc[4] = {zero_acc(), zero_acc(), zero_acc(), zero_acc()};
         f32x4 dp[4] = {zero_acc(), zero_acc(), zero_acc(), zero_acc()};
         mm_rows_x_tile_t<DK>(sc, qf, Ks, l16, g);
@@ -296,10 +366,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnP p) {
                 const bool valid = key < klim && (!p.causal || key <= qi);
                 const float pr = valid ? expf(sc[t][r] * p.scale - ls[r]) : 0.f;
                 float d = dp[t][r];
-                if (p.pmask) {
-                    const bool keep = valid && qi < p.Tq && p.pmask[((long)bh * p.Tq + qi) * p.ldm + key];
-                    d = keep ? d * p.pscale : 0.f;
-                }
+                if (p.pmask) d = (keepbits >> (4 * r + t)) & 1u ? d * p.pscale : 0.f;
                 Pw[(4 * g + r) * AT_LDP + 16 * t + l16] = pr * (d - dl[r]) * p.scale;
             }
         }
@@ -373,6 +440,19 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnP p) {
                 rd.fetch(dobase, p.ldo, (qt + 1) * AT_TILE, p.Tq, tid);
                 fetch_stats(qt + 1);
             }
+            unsigned keepbits = 0xffffu;
+            if (p.pmask) {
+                keepbits = 0u;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int qi = qt * AT_TILE + 16 * t + l16;
+                    const int key4 = k0 + 16 * w + 4 * g;            // 4 consecutive keys of one query row: one 4-byte load
+                    unsigned word = 0u;
+                    if (qi < p.Tq && key4 < p.Tk) word = *reinterpret_cast<const unsigned*>(p.pmask + ((long)bh * p.Tq + qi) * p.ldm + key4);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) keepbits |= (((word >> (8 * r)) & 0xffu) ? 1u : 0u) << (4 * r + t);
+                }
+            }
             f32x4 st[4] = {zero_acc(), zero_acc(), zero_acc(), zero_acc()};
             f32x4 dpt[4] = {zero_acc(), zero_acc(), zero_acc(), zero_acc()};
             mm_rows_x_tile_t<DK>(st, kf, Qs, l16, g);      // S^T  [key][query]
@@ -388,7 +468,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnP p) {
                     const float pr = valid ? expf(st[t][r] * p.scale - lse_s[16 * t + l16]) : 0.f;
                     float pd = pr, d = dpt[t][r];
                     if (p.pmask) {
-                        const bool keep = valid && p.pmask[((long)bh * p.Tq + qi) * p.ldm + key];
+                        const bool keep = (keepbits >> (4 * r + t)) & 1u;
                         pd = keep ? pr * p.pscale : 0.f;
                         d = keep ? d * p.pscale : 0.f;
                     }
