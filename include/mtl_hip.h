@@ -47,6 +47,18 @@ int mtl_gemm_f32(void* stream, int transA, int transB, int M, int N, int K, floa
                  int batch, int H, long sAb, long sAh, long sBb, long sBh, long sCb, long sCh, long sBias, float* workspace,
                  long workspace_bytes);
 
+/* mtl_gemm_f32 with two extensions, and a small-tile engine (32 x 32 tiles on v_mfma_f32_16x16x4_f32, no workspace, no second
+ * launch) for products whose 64 x 64 tiling would leave most of the 256 CUs idle (< 192 tiles):
+ *   kbatch > 1: C = epilogue( alpha * sum_{z<kbatch} opA(A + z*sAk) . opB(B + z*sBk) ) -- the K loop runs over the z items inside
+ *               ONE launch (dx of the Q/K/V low-rank a-stages: three serialised accumulate launches before);
+ *   rowsum (nullable, transA only): rowsum[(z/H)*sRowsum + m] += sum_k opA(A)[m][k] -- the bias gradient colsum(dy) of
+ *               dW = dy^T . x as a by-product of the weight-gradient product (fixed-order reduction).
+ * Products that fill the chip (and the few-tile very-long-K ones) are forwarded to mtl_gemm_f32 unchanged. */
+int mtl_gemm_f32_ex(void* stream, int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
+                    const float* B, int ldb, float* C, int ldc, const float* bias, const float* gate, int ldg, int flags,
+                    int batch, int H, long sAb, long sAh, long sBb, long sBh, long sCb, long sCh, long sBias, int kbatch, long sAk,
+                    long sBk, float* rowsum, long sRowsum, float* workspace, long workspace_bytes);
+
 /* ---- VGG front-end: models/asr/transformer.py:48-59 (Conv2d 3x3 s1 p1 + ReLU [+ MaxPool2d(2,2)]) ------
  * x_ref is the reference's (B,1,F,T) input; everything downstream is (B,T,F,C). */
 int mtl_conv0_relu_fwd(void* stream, const float* x_ref, const float* w /*(64,1,3,3)*/, const float* bias, float* y,

@@ -17,6 +17,7 @@ P, I, L, F = c_void_p, c_int, c_long, c_float
 SIGNATURES = {
     'mtl_abi_version': (I, []),
     'mtl_gemm_f32': (I, [P, I, I, I, I, I, F, P, I, P, I, P, I, P, P, I, I, I, I, L, L, L, L, L, L, L, P, L]),
+    'mtl_gemm_f32_ex': (I, [P, I, I, I, I, I, F, P, I, P, I, P, I, P, P, I, I, I, I, L, L, L, L, L, L, L, I, L, L, P, L, P, L]),
     'mtl_conv0_relu_fwd': (I, [P, P, P, P, P, I, I, I]),
     'mtl_conv0_wgrad_workspace': (L, []),
     'mtl_conv0_wgrad': (I, [P, P, P, P, P, P, I, I, I]),

@@ -265,11 +265,12 @@ class PassEngine:
         return torch.cuda.current_stream(self.device).cuda_stream
 
     def gemm(self, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias=None, gate=None, ldg=0, flags=0, alpha=1.0,
-             batch=1, H=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), sbias=0):
+             batch=1, H=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), sbias=0, kbatch=1, sAk=0, sBk=0, rowsum=None, srow=0):
+        """kbatch / sAk / sBk: sum over several (A, B) pairs inside one launch; rowsum: += row sums of op(A) (bias gradient)."""
         wst = self.gemm_ws_side if self.on_side else self.gemm_ws
-        check(self.lib.mtl_gemm_f32(self.stream, ta, tb, M, N, K, alpha, A, lda, B, ldb, C, ldc, bias, gate, ldg, flags,
-                                    batch, H, sA[0], sA[1], sB[0], sB[1], sC[0], sC[1], sbias, wst.data_ptr(),
-                                    wst.numel() * 4), 'mtl_gemm_f32')
+        check(self.lib.mtl_gemm_f32_ex(self.stream, ta, tb, M, N, K, alpha, A, lda, B, ldb, C, ldc, bias, gate, ldg, flags,
+                                       batch, H, sA[0], sA[1], sB[0], sB[1], sC[0], sC[1], sbias, kbatch, sAk, sBk, rowsum, srow,
+                                       wst.data_ptr(), wst.numel() * 4), 'mtl_gemm_f32_ex')
 
     # ---- side stream: deferred parameter-gradient work
     def defer(self, fn):
@@ -309,10 +310,8 @@ class PassEngine:
     def linear_bwd(self, x, dy, rows, k_in, n_out, w, dw, db, dx, dx_accum, gate=None):
         """dw += dy^T x ; db += colsum(dy) (db None: no bias, or already produced by the LayerNorm backward) ;
         dx (=|+=) dy.W  (gate: ReLU mask source for dx)"""
-        def param_grads():
-            self.gemm(1, 0, n_out, k_in, rows, dy, n_out, x, k_in, dw, k_in, flags=ACCUM)
-            if db is not None:
-                self.colsum(dy, rows, n_out, db)
+        def param_grads():        # db rides on the weight-gradient product (row sums of dy^T), no separate reduction launches
+            self.gemm(1, 0, n_out, k_in, rows, dy, n_out, x, k_in, dw, k_in, flags=ACCUM, rowsum=db)
         self.defer(param_grads)
         if dx is not None:
             self.gemm(0, 0, rows, k_in, n_out, dy, n_out, w, k_in, dx, k_in, gate=gate, ldg=k_in,
@@ -461,7 +460,7 @@ class PassEngine:
                       sA=sP, sB=(Tk * hk, dk), sC=(Tq * hk, dk))
             self.gemm(1, 0, Tk, dk, Tq, dP.data_ptr(), ldS, q.data_ptr(), hk, dkk.data_ptr(), hk, batch=Bn * h, H=h,
                       sA=sP, sB=(Tq * hk, dk), sC=(Tk * hk, dk))
-        first_kv = True
+        kv_written = False
         for names, src, rows in groups:
             n, f0 = len(names), _FULL[names[0]]
             wd = hv if names == 'v' else hk
@@ -470,12 +469,10 @@ class PassEngine:
             sa, sb, sbias = (self._pstride(pre, names, sfx) for sfx in ('_linear_a.weight', '_linear_b.weight', '_linear_b.bias'))
             a_ptr, d_ptr, da_ptr = a_all.data_ptr(), d_all.data_ptr(), da_all.data_ptr()
 
-            def grads_b(n=n, f0=f0, rows=rows, a_ptr=a_ptr, d_ptr=d_ptr, sb=sb, names=names, wd=wd):
-                # dW_b[i] += d[i]^T a[i]  (one strided-batch call, outputs strided into G) ; db_b[i] += colsum(d[i])
+            def grads_b(n=n, f0=f0, rows=rows, a_ptr=a_ptr, d_ptr=d_ptr, sb=sb, sbias=sbias, wd=wd):
+                # dW_b[i] += d[i]^T a[i]  and  db_b[i] += colsum(d[i])  in one strided-batch call (outputs strided into G)
                 self.gemm(1, 0, wd, r, rows, d_ptr, wd, a_ptr, r, g(f0 + '_linear_b.weight'), r, flags=ACCUM, batch=n,
-                          sA=(rows * wd, 0), sB=(rows * r, 0), sC=(sb, 0))
-                for i, nm in enumerate(names):
-                    self.colsum(d_ptr + 4 * i * rows * wd, rows, wd, g(_FULL[nm] + '_linear_b.bias'))
+                          sA=(rows * wd, 0), sB=(rows * r, 0), sC=(sb, 0), rowsum=g(f0 + '_linear_b.bias'), srow=sbias)
             self.defer(grads_b)
             # da[i] = d[i] . W_b[i]
             self.gemm(0, 0, rows, r, wd, d_ptr, wd, o(f0 + '_linear_b.weight'), r, da_ptr, r, batch=n, sA=(rows * wd, 0),
@@ -486,15 +483,14 @@ class PassEngine:
                 self.gemm(1, 0, r, d, rows, da_ptr, r, src, d, g(f0 + '_linear_a.weight'), d, flags=ACCUM, batch=n,
                           sA=(rows * r, 0), sC=(sa, 0))
             self.defer(grads_a)
-            # dx += da[i] . W_a[i]: the items accumulate into ONE tensor, so they stay separate (ordered) launches
-            for i, nm in enumerate(names):
-                if nm == 'q':
-                    dst, accum = dxq, True
-                else:
-                    dst, accum = dxkv, (dxkv_accum or (dxkv == dxq) or not first_kv)
-                    first_kv = False
-                self.gemm(0, 0, rows, d, r, da_ptr + 4 * i * rows * r, r, o(_FULL[nm] + '_linear_a.weight'), d, dst, d,
-                          flags=ACCUM if accum else 0)
+            # dx (+)= sum_i da[i] . W_a[i]: the items of a group accumulate into ONE tensor -> one K-batched launch
+            if names[0] == 'q':
+                dst, accum = dxq, True
+            else:
+                dst, accum = dxkv, (dxkv_accum or (dxkv == dxq) or kv_written)
+                kv_written = True
+            self.gemm(0, 0, rows, d, r, da_ptr, r, o(f0 + '_linear_a.weight'), d, dst, d, flags=ACCUM if accum else 0,
+                      kbatch=n, sAk=rows * r, sBk=sa)
         self.flush_side()
 
     def _pstride(self, pre, names, suffix):

@@ -102,6 +102,77 @@ def test_gemm_long_k_big_tile_split_k(L, ta, tb):
     assert rel(allb, ref) < 3e-6 and torch.equal(run(big, nb), allb)
 
 
+def _gemm_ex(L, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias=None, gate=None, ldg=0, flags=0, alpha=1.0, batch=1, H=1,
+             sA=(0, 0), sB=(0, 0), sC=(0, 0), sbias=0, kbatch=1, sAk=0, sBk=0, rowsum=None, srow=0):
+    return L.mtl_gemm_f32_ex(st(), ta, tb, M, N, K, alpha, A.data_ptr(), lda, B.data_ptr(), ldb, C.data_ptr(), ldc,
+                             bias.data_ptr() if bias is not None else None, gate.data_ptr() if gate is not None else None, ldg, flags,
+                             batch, H, sA[0], sA[1], sB[0], sB[1], sC[0], sC[1], sbias, kbatch, sAk, sBk,
+                             rowsum.data_ptr() if rowsum is not None else None, srow, None, 0)
+
+
+@pytest.mark.parametrize('ta,tb', [(0, 1), (0, 0), (1, 0), (1, 1)])
+@pytest.mark.parametrize('M,N,K', [(101, 250, 64), (808, 100, 512), (100, 512, 2000), (33, 31, 7), (512, 100, 808), (5, 3765, 301)])
+def test_small_tile_gemm(L, ta, tb, M, N, K):
+    """mtl_gemm_f32_ex on the small-tile engine (every shape here has < 192 tiles of 64 x 64): all transposes, tile tails in
+    M / N / K, unaligned leading dimensions (dword-load instantiation), bias + ReLU + gate + accumulate, bitwise repeatable."""
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K + ta * 2 + tb)
+    A = torch.randn((K, M) if ta else (M, K), generator=g)
+    B = torch.randn((N, K) if tb else (K, N), generator=g)
+    bias, C0, gate = torch.randn(N, generator=g), torch.randn(M, N, generator=g), torch.randn(M, N, generator=g)
+    prod = (A.t() if ta else A).double() @ (B.t() if tb else B).double()
+    dA, dB, dbias, dgate = dev(A), dev(B), dev(bias), dev(gate)
+    C = dev(C0.clone())
+    assert _gemm_ex(L, ta, tb, M, N, K, dA, A.shape[1], dB, B.shape[1], C, N) == 0
+    assert rel(C, prod) < 2e-6
+    outs = []
+    for _ in range(2):
+        C = dev(C0.clone())
+        assert _gemm_ex(L, ta, tb, M, N, K, dA, A.shape[1], dB, B.shape[1], C, N, bias=dbias, gate=dgate, ldg=N, flags=3, alpha=0.5) == 0
+        outs.append(C.cpu())
+    assert rel(outs[0], torch.relu(0.5 * prod + bias.double()) * (gate > 0) + C0.double()) < 2e-6
+    assert torch.equal(outs[0], outs[1])
+
+
+def test_gemm_k_batching_and_row_sums(L):
+    """the two extensions of mtl_gemm_f32_ex: dx += sum_z da[z] . W_a[z] in ONE launch (parameters at a constant stride, like the
+    Q/K/V a-stages in the flat buffer), and the bias gradient colsum(dy) produced by the weight-gradient product dW = dy^T . x,
+    also strided-batch (three b-stage gradients + three bias gradients in one call)."""
+    g = torch.Generator().manual_seed(77)
+    rows, r, d, n = 808, 100, 512, 3
+    da = torch.randn(n, rows, r, generator=g)
+    theta = torch.randn(n * (r * d + 1000), generator=g)                    # a "flat parameter buffer": W_a[z] every r*d+1000 floats
+    sa = r * d + 1000
+    Wa = [theta[z * sa: z * sa + r * d].view(r, d) for z in range(n)]
+    dx0 = torch.randn(rows, d, generator=g)
+    ref = dx0.double() + sum(da[z].double() @ Wa[z].double() for z in range(n))
+    dda, dth = dev(da), dev(theta)
+    outs = []
+    for _ in range(2):
+        dx = dev(dx0.clone())
+        assert _gemm_ex(L, 0, 0, rows, d, r, dda, r, dth, d, dx, d, flags=2, kbatch=n, sAk=rows * r, sBk=sa) == 0
+        outs.append(dx.cpu())
+    assert rel(outs[0], ref) < 2e-6 and torch.equal(outs[0], outs[1])
+    # dW_b[z] += dy[z]^T a[z]  and  db[z] += colsum(dy[z]),  z = 0..2, outputs strided into a flat gradient buffer
+    wd = 512
+    dy = torch.randn(n, rows, wd, generator=g)
+    a = torch.randn(n, rows, r, generator=g)
+    sb = wd * r + wd + 24                                                    # weight, then its bias, then something else
+    G0 = torch.randn(n * sb, generator=g)
+    ddy, da_, G = dev(dy), dev(a), dev(G0.clone())
+    Wview = G[:].data_ptr()
+    assert L.mtl_gemm_f32_ex(st(), 1, 0, wd, r, rows, 1.0, ddy.data_ptr(), wd, da_.data_ptr(), r, Wview, r, None, None, 0, 2,
+                             n, 1, rows * wd, 0, rows * r, 0, sb, 0, 0, 1, 0, 0, Wview + 4 * wd * r, sb, None, 0) == 0
+    Gc = G.cpu()
+    for z in range(n):
+        w_ref = G0[z * sb: z * sb + wd * r].view(wd, r).double() + dy[z].double().t() @ a[z].double()
+        b_ref = G0[z * sb + wd * r: z * sb + wd * r + wd].double() + dy[z].double().sum(0)
+        assert rel(Gc[z * sb: z * sb + wd * r].view(wd, r), w_ref) < 2e-6
+        assert rel(Gc[z * sb + wd * r: z * sb + wd * r + wd], b_ref) < 3e-6
+        assert torch.equal(Gc[z * sb + wd * r + wd: (z + 1) * sb], G0[z * sb + wd * r + wd: (z + 1) * sb])   # untouched
+    assert L.mtl_gemm_f32_ex(st(), 0, 0, 8, 8, 8, 1.0, ddy.data_ptr(), 8, da_.data_ptr(), 8, Wview, 8, None, None, 0, 0,
+                             1, 1, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, Wview, 0, None, 0) == -22      # row sums need transA
+
+
 def test_gemm_gate_and_batched_heads(L):
     g = torch.Generator().manual_seed(5)
     Bn, H, Tq, Tk, dk = 3, 8, 101, 250, 16
