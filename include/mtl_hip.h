@@ -58,6 +58,9 @@ int mtl_gemm_f32_ex(void* stream, int transA, int transB, int M, int N, int K, f
                     const float* B, int ldb, float* C, int ldc, const float* bias, const float* gate, int ldg, int flags,
                     int batch, int H, long sAb, long sAh, long sBb, long sBh, long sCb, long sCh, long sBias, int kbatch, long sAk,
                     long sBk, float* rowsum, long sRowsum, float* workspace, long workspace_bytes);
+/* which engine mtl_gemm_f32_ex picks: 1 = small-tile (kernel symbol gemm16_kernel<...>), 0 = forwarded to mtl_gemm_f32
+ * (gemm_kernel<...>); used by bench.py to attribute launch timings to the rocprofv3 kernel classes */
+int mtl_gemm_f32_ex_route(int M, int N, int K, int batch, int kbatch, int has_rowsum);
 
 /* ---- VGG front-end: models/asr/transformer.py:48-59 (Conv2d 3x3 s1 p1 + ReLU [+ MaxPool2d(2,2)]) ------
  * x_ref is the reference's (B,1,F,T) input; everything downstream is (B,T,F,C). */
@@ -113,10 +116,11 @@ int mtl_layernorm_fwd(void* stream, const float* x, const float* residual, const
                       const float* pe, const int* keep, const unsigned char* xmask, float xscale, float* y, float* xhat,
                       float* rstd, int rows, int d, int T, float eps);
 long mtl_layernorm_bwd_workspace(int rows, int d);
-/* with xmask: dz is the residual-branch gradient and dzm = dz * mask * xscale the sub-layer-branch gradient (dsum sums dzm) */
+/* with xmask: dz is the residual-branch gradient and dzm = dz * mask * xscale the sub-layer-branch gradient (dsum sums dzm);
+ * dz2 (nullable): a second copy of dz (the residual path accumulates onto it while dz stays intact for the weight gradient) */
 int mtl_layernorm_bwd(void* stream, const float* dy, const float* xhat, const float* rstd, const float* gamma,
                       const int* keep, const unsigned char* xmask, float xscale, float* dz, float* dzm /*nullable*/,
-                      float* dgamma /*accum*/, float* dbeta /*accum*/,
+                      float* dz2 /*nullable*/, float* dgamma /*accum*/, float* dbeta /*accum*/,
                       float* dsum /*nullable, accum: += column sums of the sub-layer-branch gradient (its linear's bias grad)*/,
                       float* workspace, int rows, int d);
 
@@ -192,6 +196,33 @@ int mtl_sumsq(void* stream, const float* x, long n, float* out, float* workspace
  * out[f*T + t] = log1p(|X[t][f]|), optionally followed by (x - mean) / std (unbiased) over the whole utterance.
  * partials: >= 256 doubles of scratch. */
 int mtl_spect_logmag(void* stream, const float* reim, int ld, int T, int F, float* out, double* partials, int normalize);
+
+/* ---- raw byte helpers on a stream (so that a whole task body consists of library calls only and can be replayed) ---- */
+int mtl_memset_zero(void* stream, void* dst, long bytes);
+int mtl_memcpy_d2d(void* stream, void* dst, const void* src, long bytes);
+/* hipEventRecord / hipStreamWaitEvent on caller-owned handles (fork / join of the parameter-gradient side stream) */
+int mtl_event_record(void* event, void* stream);
+int mtl_stream_wait_event(void* stream, void* event);
+
+/* ---- command lists: ONE call from the host language replays a recorded sequence of the calls above ------------------------
+ * The per-task body of the meta step (trainer/asr/transient_trainer.py:178-237: train pass, inner SGD, validation pass,
+ * copy_grad accumulation) is ~700 library calls whose arguments -- device pointers into the caller's static buffers, shapes,
+ * scalars, stream and event handles -- do not change from task to task: everything batch-dependent lives in device buffers the
+ * host refreshes before the replay.  The host layer records the calls of one eager run (`mtl_cmd` entries: opcode = position of
+ * the function in this header's declaration order, see mtl_cmdlist_opcode; arguments in declaration order, one 8-byte slot
+ * each: pointers / integers as-is, floats as double) and afterwards issues mtl_cmdlist_run, which performs exactly those calls
+ * in order from C.  Returns 0, or the first failing call's code with *failed_index = its position (nullable). */
+typedef struct mtl_cmd {
+    int op;
+    int nargs;
+    union {
+        void* p;
+        long l;
+        double d;
+    } a[34];
+} mtl_cmd;
+int mtl_cmdlist_opcode(const char* function_name);     /* -1 if the function cannot be recorded */
+int mtl_cmdlist_run(const mtl_cmd* cmds, int n, int* failed_index);
 
 /* ---- host helper: Levenshtein distance on code points (utils/metrics.py:38-44 uses python-Levenshtein) ---- */
 int mtl_levenshtein_u32(const unsigned int* a_host, int na, const unsigned int* b_host, int nb);

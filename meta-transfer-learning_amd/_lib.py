@@ -18,6 +18,7 @@ SIGNATURES = {
     'mtl_abi_version': (I, []),
     'mtl_gemm_f32': (I, [P, I, I, I, I, I, F, P, I, P, I, P, I, P, P, I, I, I, I, L, L, L, L, L, L, L, P, L]),
     'mtl_gemm_f32_ex': (I, [P, I, I, I, I, I, F, P, I, P, I, P, I, P, P, I, I, I, I, L, L, L, L, L, L, L, I, L, L, P, L, P, L]),
+    'mtl_gemm_f32_ex_route': (I, [I, I, I, I, I, I]),
     'mtl_conv0_relu_fwd': (I, [P, P, P, P, P, I, I, I]),
     'mtl_conv0_wgrad_workspace': (L, []),
     'mtl_conv0_wgrad': (I, [P, P, P, P, P, P, I, I, I]),
@@ -36,7 +37,7 @@ SIGNATURES = {
     'mtl_permute_hc': (I, [P, P, P, I, I, I, I]),
     'mtl_layernorm_fwd': (I, [P, P, P, P, P, P, P, P, F, P, P, P, I, I, I, F]),
     'mtl_layernorm_bwd_workspace': (L, [I, I]),
-    'mtl_layernorm_bwd': (I, [P, P, P, P, P, P, P, F, P, P, P, P, P, P, I, I]),
+    'mtl_layernorm_bwd': (I, [P, P, P, P, P, P, P, F, P, P, P, P, P, P, P, I, I]),
     'mtl_softmax_mask_fwd': (I, [P, P, P, I, F, I, I, I, I, I, P, F, P]),
     'mtl_softmax_bwd': (I, [P, P, P, F, L, I, I, P, F]),
     'mtl_attn_supported': (I, [I, I]),
@@ -56,6 +57,12 @@ SIGNATURES = {
     'mtl_adam_step': (I, [P, P, P, P, P, I, F, F, F, F, L]),
     'mtl_sumsq': (I, [P, P, L, P, P, I, F]),
     'mtl_spect_logmag': (I, [P, P, I, I, I, P, P, I]),
+    'mtl_memset_zero': (I, [P, P, L]),
+    'mtl_memcpy_d2d': (I, [P, P, P, L]),
+    'mtl_event_record': (I, [P, P]),
+    'mtl_stream_wait_event': (I, [P, P]),
+    'mtl_cmdlist_opcode': (I, [ctypes.c_char_p]),
+    'mtl_cmdlist_run': (I, [P, I, P]),
     'mtl_levenshtein_u32': (I, [P, I, P, I]),
 }
 
@@ -84,6 +91,95 @@ def lib():
         raise MtlLibraryError('libmtl_hip.so ABI %d != expected %d; rebuild' % (h.mtl_abi_version(), ABI_VERSION))
     _lib = h
     return h
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# command lists (include/mtl_hip.h "command lists"): record the C calls of one eager run, replay them with ONE ctypes call
+# ---------------------------------------------------------------------------------------------------------------------
+class _CmdArg(ctypes.Union):
+    _fields_ = [('p', c_void_p), ('l', c_long), ('d', ctypes.c_double)]
+
+
+class MtlCmd(ctypes.Structure):
+    _fields_ = [('op', c_int), ('nargs', c_int), ('a', _CmdArg * 34)]
+
+
+def _kinds(name):
+    return ['p' if t is P or t is ctypes.c_char_p else ('d' if t is F else 'l') for t in SIGNATURES[name][1]]
+
+
+class CommandList:
+    """An ordered record of library calls with their arguments.  `finish()` packs it into an mtl_cmd array; `run()` hands that
+    array to mtl_cmdlist_run.  `repoint(old, new)` rewrites every POINTER argument equal to `old` (the input batch of a task
+    is the only argument that moves between replays)."""
+
+    def __init__(self):
+        self.entries, self.buf, self.n = [], None, 0
+        self._failed = c_int(-1)
+        self._ptr_sites = {}
+
+    def add(self, op, kinds, args):
+        self.entries.append((op, kinds, args))
+
+    def finish(self):
+        self.n = len(self.entries)
+        self.buf = (MtlCmd * max(self.n, 1))()
+        for i, (op, kinds, args) in enumerate(self.entries):
+            c = self.buf[i]
+            c.op, c.nargs = op, len(args)
+            for j, (k, v) in enumerate(zip(kinds, args)):
+                if k == 'p':
+                    v = int(v or 0)
+                    c.a[j].p = v
+                    if v:
+                        self._ptr_sites.setdefault(v, []).append((i, j))
+                elif k == 'd':
+                    c.a[j].d = float(v)
+                else:
+                    c.a[j].l = int(v)
+        self.entries = None
+        return self
+
+    def repoint(self, old, new):
+        if old == new:
+            return
+        sites = self._ptr_sites.pop(old, None)
+        if sites is None:
+            raise KeyError('pointer %#x is not an argument of this command list' % old)
+        for i, j in sites:
+            self.buf[i].a[j].p = new
+        self._ptr_sites.setdefault(new, []).extend(sites)
+
+    def run(self):
+        rc = lib().mtl_cmdlist_run(self.buf, self.n, ctypes.byref(self._failed))
+        if rc != 0:
+            raise RuntimeError('mtl_cmdlist_run: command %d failed with code %d' % (self._failed.value, rc))
+
+
+class Recorder:
+    """Stands in for the ctypes library handle while a CommandList is being recorded: every recordable call is executed AND
+    logged; size queries (`*_workspace`, ...) are only executed (their results become arguments of later calls)."""
+
+    def __init__(self, handle, cmdlist):
+        self._h, self._cl, self._cache = handle, cmdlist, {}
+
+    def __getattr__(self, name):
+        fn = self._cache.get(name)
+        if fn is None:
+            real = getattr(self._h, name)
+            op = self._h.mtl_cmdlist_opcode(name.encode()) if name in SIGNATURES else -1
+            if op < 0:
+                fn = real
+            else:
+                kinds, cl = _kinds(name), self._cl
+
+                def fn(*args, _real=real, _op=op, _kinds=kinds):
+                    rc = _real(*args)
+                    if rc == 0:
+                        cl.add(_op, _kinds, args)
+                    return rc
+            self._cache[name] = fn
+        return fn
 
 
 def check(rc, what):

@@ -176,7 +176,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                             const int* __restrict__ keep, const uint8_t* __restrict__ xmask,
                                                             float xscale, float* __restrict__ dz, float* __restrict__ dzm,
-                                                            float* __restrict__ part, int rows, int rows_per_wave) {
+                                                            float* __restrict__ dz2, float* __restrict__ part, int rows,
+                                                            int rows_per_wave) {
     constexpr int D = NPL * 64;
     const int lane = threadIdx.x & 63;
     const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -227,6 +228,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
             for (int i = 0; i < NPL; ++i) {
                 const float o = rs[q] * (g[i] - s1 - hv[q][i] * s2);
                 dz[(long)row * D + i * 64 + lane] = o;
+                if (dz2) dz2[(long)row * D + i * 64 + lane] = o;      // second copy: the residual path starts from dz
                 float om = o;
                 if (xmask) {                               // gradient of the dropped sub-layer branch (residual branch gets dz)
                     om = xmask[(long)row * D + i * 64 + lane] ? o * xscale : 0.f;
@@ -741,14 +743,14 @@ long mtl_layernorm_bwd_workspace(int rows, int d) {
 }
 
 int mtl_layernorm_bwd(void* stream, const float* dy, const float* xhat, const float* rstd, const float* gamma,
-                      const int* keep, const unsigned char* xmask, float xscale, float* dz, float* dzm, float* dgamma,
+                      const int* keep, const unsigned char* xmask, float xscale, float* dz, float* dzm, float* dz2, float* dgamma,
                       float* dbeta, float* dsum, float* workspace, int rows, int d) {
     if (!dy || !xhat || !rstd || !gamma || !dz || !dgamma || !dbeta || !workspace || rows <= 0 || (xmask && !dzm)) return MTL_EINVAL;
     const int rpw = 4;
     const int waves = ((rows + rpw - 1) / rpw + 3) / 4 * 4;
     dim3 grid(waves / 4), block(256);
     hipStream_t s = as_stream(stream);
-#define LN_BWD(N) hipLaunchKernelGGL(layernorm_bwd_kernel<N>, grid, block, 0, s, dy, xhat, rstd, gamma, keep, xmask, xscale, dz, dzm, workspace, rows, rpw)
+#define LN_BWD(N) hipLaunchKernelGGL(layernorm_bwd_kernel<N>, grid, block, 0, s, dy, xhat, rstd, gamma, keep, xmask, xscale, dz, dzm, dz2, workspace, rows, rpw)
     switch (d) {
         case 64: LN_BWD(1); break;
         case 128: LN_BWD(2); break;

@@ -1,19 +1,28 @@
-// Small-tile fp32 GEMM for gfx950 (MI355X): 32 x 32 output tiles on v_mfma_f32_16x16x4_f32.
+// Small-product fp32 GEMM for gfx950 (MI355X) on v_mfma_f32_16x16x4_f32: 32..64-row tiles, K groups, K-batching, row sums.
 //
 // The transformer half of the pass is ~200 products per pass whose outputs are only a few hundred KB (rank-100 low-rank
-// projections, their weight gradients, decoder-side linears): with the 64 x 64 tiles of the big engine they fill a quarter
-// of the 256 CUs, every wave walks the whole K loop alone (6.8 us at K = 512) and the remedy used so far -- split-K into a
-// workspace plus a second reduction launch -- doubles the launch count.  Here a workgroup owns a 32 x 32 tile (4 waves, one
-// 16 x 16 MFMA tile each, K alternating between two accumulators so consecutive MFMAs are independent): 4x the workgroups,
-// a quarter of the K-loop latency per wave, no workspace and no second launch.  Two extensions remove further launches:
+// projections, their weight gradients, decoder-side linears).  With the fixed 64 x 64 tiles of the big engine they fill a
+// quarter of the 256 CUs, every wave walks the whole K loop alone (6.8 us at K = 512) and the remedy used so far -- split-K
+// into a workspace plus a second reduction launch -- doubles the launch count.  This engine picks, per product,
+//   * the workgroup tile (32 x 32, 64 x 32 or 64 x 64; a wave owns 1, 2 or 4 16 x 16 MFMA tiles): 32 x 32 up to ~1000
+//     workgroups (4x the workgroups of the big engine, a quarter of the K-loop latency per wave), larger tiles beyond;
+//   * the number of K groups (1, 2 or 4 groups of 4 waves per workgroup, each streaming every KG-th K tile through its own
+//     LDS buffers): a long-K weight-gradient product with 64 output tiles keeps 4x the loads in flight per CU and its
+//     partial accumulators are combined through LDS in group order -- no workspace, no second launch.
+// Two extensions remove further launches:
 //   * K-batching: C = sum_z opA(A_z) . opB(B_z) inside ONE launch (dx of the three Q/K/V low-rank a-stages, which used to be
 //     three serialised accumulate launches);
 //   * row sums of op(A) over K as a by-product of transposed-A products (the bias gradient colsum(dy) of dW = dy^T x, which
 //     used to be two more launches per linear).
-// All reductions are fixed-order: bitwise reproducible.
+// All reductions are fixed-order: bitwise reproducible.  Workgroups are numbered XCD-aware: XCD x (= workgroup id % 8, the
+// observed dispatch order, used for speed only) owns a contiguous range of the (z, m, n) tile sequence, so tiles that share
+// an A row-block are neighbours in one XCD's L2.
 //
 // Same contract as mtl_gemm_f32 (include/mtl_hip.h); replaces nn.Linear forward / backward of the small products
 // (modules/common_layers.py:130,287-289,303) and the bias-gradient reductions of their autograd backward.
+#include <cstdlib>
+#include <type_traits>
+
 #include "mtl_common.h"
 #include "../../include/mtl_hip.h"
 
@@ -21,7 +30,8 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int TM = 32, TN = 32, TK = 64, LDT = TK + 4;
+constexpr int TK = 64;
+constexpr int LDT = TK + 4;      // K-major LDS tile [row][k]: 8-byte fragment reads of 16 rows x 2 lane groups hit 32 distinct bank pairs
 
 struct G16P {
     const float *A, *B;
@@ -35,165 +45,311 @@ struct G16P {
     long sAb, sAh, sBb, sBh, sCb, sCh, sBias;
     int kb;
     long sAk, sBk, sRow;
+    int total;       // workgroups = tiles in N x tiles in M x batch
 };
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
-// One 32-row x 64-k operand tile: HBM -> registers -> LDS [row][k] (ld 68).  KMAJ: the source is [row][k] (k contiguous),
-// otherwise [k][row] (row contiguous; transposed while committing).  Out-of-range elements read as zero.
-template <bool KMAJ, bool VEC>
+// One ROWS x 64-k operand tile: HBM -> registers -> LDS, kept in the orientation it has in memory so that every commit is a
+// 16-byte store: KMAJ source [row][k] -> LDS [row][68], otherwise source [k][row] -> LDS [k][ROWS + 8] (the two k rows of a
+// lane-group pair land 16 banks apart).  frag() returns the two operand values (k = 8 s + 2 g, + 1) of row `rb + l16` for one
+// MFMA pair.  fetch() is BRANCH-FREE: unconditional loads from clamped (always valid) addresses plus a 4-bit validity mask; the
+// zero-fill happens in commit(), i.e. after the MFMAs of the current tile (with the bounds checks as branches hipcc waits for
+// every load right where it is issued: four serialised round trips per K tile).
+template <bool KMAJ, bool VEC, int ROWS>
 struct Opnd {
-    float4 v[2];
+    static constexpr int NV = ROWS / 16;                  // float4 per thread per tile
+    static constexpr int LDM = ROWS + 8;
+    static constexpr int FLOATS = KMAJ ? ROWS * LDT : TK * LDM;
+    static constexpr int TPR = ROWS / 4;                  // MN-major: threads per k row
+    float4 v[NV];
+    unsigned m[NV];
     __device__ __forceinline__ void fetch(const float* src, long ld, int row0, int nrows, int k0, int K, int tid) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NV; ++i) {
             int r, k, dr, dk;              // (r, k) of element 0; the 4 elements step along dr / dk
             if (KMAJ) {
                 r = row0 + (tid >> 4) + 16 * i, k = k0 + (tid & 15) * 4, dr = 0, dk = 1;
             } else {
-                k = k0 + (tid >> 3) + 32 * i, r = row0 + (tid & 7) * 4, dr = 1, dk = 0;
+                k = k0 + tid / TPR + (256 / TPR) * i, r = row0 + (tid % TPR) * 4, dr = 1, dk = 0;
             }
-            const bool ok0 = r < nrows && k < K;
-            const float* q = src + (KMAJ ? (long)r * ld + k : (long)k * ld + r);
-            const bool ok1 = r + dr < nrows && k + dk < K, ok2 = r + 2 * dr < nrows && k + 2 * dk < K,
+            const bool ok0 = r < nrows && k < K, ok1 = r + dr < nrows && k + dk < K, ok2 = r + 2 * dr < nrows && k + 2 * dk < K,
                        ok3 = r + 3 * dr < nrows && k + 3 * dk < K;
-            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (VEC) {
-                if (ok0) x = *reinterpret_cast<const float4*>(q);
-            } else {
-                if (ok0) x.x = q[0];
-                if (ok1) x.y = q[1];
-                if (ok2) x.z = q[2];
-                if (ok3) x.w = q[3];
-            }
-            x.y = ok1 ? x.y : 0.f;
-            x.z = ok2 ? x.z : 0.f;
-            x.w = ok3 ? x.w : 0.f;
-            v[i] = x;
+            m[i] = (ok0 ? 1u : 0u) | (ok1 ? 2u : 0u) | (ok2 ? 4u : 0u) | (ok3 ? 8u : 0u);
+            const float* q = src + (ok0 ? (KMAJ ? (long)r * ld + k : (long)k * ld + r) : 0);
+            if (VEC)
+                v[i] = *reinterpret_cast<const float4*>(q);      // 16-byte aligned; a partially valid quad stays inside the row's ld
+            else
+                v[i] = make_float4(q[0], q[ok1 ? 1 : 0], q[ok2 ? 2 : 0], q[ok3 ? 3 : 0]);
         }
+    }
+    __device__ __forceinline__ float4 masked(int i) const {
+        float4 x = v[i];
+        x.x = (m[i] & 1u) ? x.x : 0.f;
+        x.y = (m[i] & 2u) ? x.y : 0.f;
+        x.z = (m[i] & 4u) ? x.z : 0.f;
+        x.w = (m[i] & 8u) ? x.w : 0.f;
+        return x;
+    }
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) m[i] = 0u;
     }
     __device__ __forceinline__ void commit(float* lds, int tid) const {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            if (KMAJ) {
-                *reinterpret_cast<float4*>(lds + ((tid >> 4) + 16 * i) * LDT + (tid & 15) * 4) = v[i];
-            } else {
-                float* d = lds + (tid & 7) * 4 * LDT + (tid >> 3) + 32 * i;
-                d[0] = v[i].x;
-                d[LDT] = v[i].y;
-                d[2 * LDT] = v[i].z;
-                d[3 * LDT] = v[i].w;
-            }
+        for (int i = 0; i < NV; ++i) {
+            const float4 x = masked(i);
+            if (KMAJ)
+                *reinterpret_cast<float4*>(lds + ((tid >> 4) + 16 * i) * LDT + (tid & 15) * 4) = x;
+            else
+                *reinterpret_cast<float4*>(lds + (tid / TPR + (256 / TPR) * i) * LDM + (tid % TPR) * 4) = x;
         }
+    }
+    static __device__ __forceinline__ float2 frag(const float* lds, int rb, int s, int l16, int g) {
+        if (KMAJ) return *reinterpret_cast<const float2*>(lds + (rb + l16) * LDT + 8 * s + 2 * g);
+        const float* q = lds + (8 * s + 2 * g) * LDM + rb + l16;
+        return make_float2(q[0], q[LDM]);
     }
 };
 
-template <bool TA, bool TB, bool VEC>
-__global__ __launch_bounds__(256) void gemm16_kernel(G16P p) {
-    __shared__ __attribute__((aligned(16))) float As[TM * LDT];
-    __shared__ __attribute__((aligned(16))) float Bs[TN * LDT];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l16 = lane & 15, g = lane >> 4;
+// Workgroup tile (32 WM) x (32 WN): 4 waves as 2 x 2, a wave owns WM x WN MFMA tiles (rows 16 (2 i + wm), cols 16 (2 j + wn)).
+// KG "K groups" of 4 waves each share the output tile: group kg takes the K tiles kg, kg + KG, ...
+template <bool TA, bool TB, bool VEC, int KG, int WM, int WN>
+__global__ __launch_bounds__(256 * KG) void gemm16_kernel(G16P p) {
+    using OA = Opnd<!TA, VEC, 32 * WM>;          // op(A) is M x K: stored [m][k] unless transposed
+    using OB = Opnd<TB, VEC, 32 * WN>;           // op(B) is K x N: stored [n][k] when transposed
+    constexpr int TM = 32 * WM, TN = 32 * WN;
+    __shared__ __attribute__((aligned(16))) float As[KG][OA::FLOATS];
+    __shared__ __attribute__((aligned(16))) float Bs[KG][OB::FLOATS];
+    const int kg = threadIdx.x >> 8, tid = threadIdx.x & 255;
+    const int lane = tid & 63, w = tid >> 6, l16 = lane & 15, g = lane >> 4;
     const int wm = w >> 1, wn = w & 1;
-    const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
-    const int z = blockIdx.z, zb = z / p.H, zh = z - zb * p.H;
+    const int nx = (p.N + TN - 1) / TN, ny = (p.M + TM - 1) / TM;
+    const int per = (p.total + 7) >> 3;
+    const int t = (blockIdx.x & 7) * per + (blockIdx.x >> 3);       // XCD-aware order (see the header)
+    if (t >= p.total) return;
+    const int z = t / (nx * ny), rem = t - z * (nx * ny);
+    const int m0 = (rem / nx) * TM, n0 = (rem % nx) * TN;
+    const int zb = z / p.H, zh = z - zb * p.H;
     const float* A = p.A + zb * p.sAb + zh * p.sAh;
     const float* B = p.B + zb * p.sBb + zh * p.sBh;
-    Opnd<!TA, VEC> ra;           // op(A) is M x K: stored [m][k] unless transposed
-    Opnd<TB, VEC> rb;            // op(B) is K x N: stored [n][k] when transposed
-    const int nk = (p.K + TK - 1) / TK, iters = nk * p.kb;
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    const bool do_rowsum = TA && p.rowsum && blockIdx.x == 0;
-    float rs[4] = {0.f, 0.f, 0.f, 0.f};
-    ra.fetch(A, p.lda, m0, p.M, 0, p.K, tid);
-    rb.fetch(B, p.ldb, n0, p.N, 0, p.K, tid);
+    OA ra;
+    OB rb;
+    const int nk = (p.K + TK - 1) / TK, tiles = nk * p.kb, iters = (tiles + KG - 1) / KG;
+    f32x4 acc[WM][WN][2];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) acc[i][j][h] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool do_rowsum = TA && p.rowsum && n0 == 0;
+    float rs[OA::NV][4];
+#pragma unroll
+    for (int i = 0; i < OA::NV; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rs[i][j] = 0.f;
+    auto fetch = [&](int it) {
+        const int tile = it * KG + kg;
+        if (tile < tiles) {
+            const int zn = tile / nk, kt = tile - zn * nk;
+            ra.fetch(A + zn * p.sAk, p.lda, m0, p.M, kt * TK, p.K, tid);
+            rb.fetch(B + zn * p.sBk, p.ldb, n0, p.N, kt * TK, p.K, tid);
+        } else {                                     // this group has run out of K tiles: contribute zeros
+            ra.zero();
+            rb.zero();
+        }
+    };
+    fetch(0);
     for (int it = 0; it < iters; ++it) {
-        ra.commit(As, tid);
-        rb.commit(Bs, tid);
+        ra.commit(As[kg], tid);
+        rb.commit(Bs[kg], tid);
         if (do_rowsum) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                rs[0] += ra.v[i].x;
-                rs[1] += ra.v[i].y;
-                rs[2] += ra.v[i].z;
-                rs[3] += ra.v[i].w;
+            for (int i = 0; i < OA::NV; ++i) {
+                const float4 x = ra.masked(i);
+                rs[i][0] += x.x;
+                rs[i][1] += x.y;
+                rs[i][2] += x.z;
+                rs[i][3] += x.w;
             }
         }
         __syncthreads();
-        if (it + 1 < iters) {                         // next tile's loads fly under this tile's MFMAs
-            const int zn = (it + 1) / nk, kt = (it + 1) - zn * nk;
-            ra.fetch(A + zn * p.sAk, p.lda, m0, p.M, kt * TK, p.K, tid);
-            rb.fetch(B + zn * p.sBk, p.ldb, n0, p.N, kt * TK, p.K, tid);
-        }
-        const float* pa = As + (16 * wm + l16) * LDT + 2 * g;
-        const float* pb = Bs + (16 * wn + l16) * LDT + 2 * g;
-        float2 a[2], b[2];
-        a[0] = *reinterpret_cast<const float2*>(pa);
-        b[0] = *reinterpret_cast<const float2*>(pb);
+        if (it + 1 < iters) fetch(it + 1);           // next tile's loads fly under this tile's MFMAs
+        float2 a[2][WM], b[2][WN];
+#pragma unroll
+        for (int i = 0; i < WM; ++i) a[0][i] = OA::frag(As[kg], 16 * (2 * i + wm), 0, l16, g);
+#pragma unroll
+        for (int j = 0; j < WN; ++j) b[0][j] = OB::frag(Bs[kg], 16 * (2 * j + wn), 0, l16, g);
 #pragma unroll
         for (int s = 0; s < TK / 8; ++s) {
             const int cur = s & 1, nxt = cur ^ 1;
             if (s + 1 < TK / 8) {
-                a[nxt] = *reinterpret_cast<const float2*>(pa + 8 * (s + 1));
-                b[nxt] = *reinterpret_cast<const float2*>(pb + 8 * (s + 1));
+#pragma unroll
+                for (int i = 0; i < WM; ++i) a[nxt][i] = OA::frag(As[kg], 16 * (2 * i + wm), s + 1, l16, g);
+#pragma unroll
+                for (int j = 0; j < WN; ++j) b[nxt][j] = OB::frag(Bs[kg], 16 * (2 * j + wn), s + 1, l16, g);
             }
-            __builtin_amdgcn_sched_barrier(0);
-            acc0 = mfma4(a[cur].x, b[cur].x, acc0);
-            acc1 = mfma4(a[cur].y, b[cur].y, acc1);
+            __builtin_amdgcn_sched_barrier(0);       // next step's LDS reads are issued BEFORE this step's MFMAs
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) acc[i][j][0] = mfma4(a[cur][i].x, b[cur][j].x, acc[i][j][0]);
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) acc[i][j][1] = mfma4(a[cur][i].y, b[cur][j].y, acc[i][j][1]);
             __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
     }
-    const long co = zb * p.sCb + zh * p.sCh;
-    float* C = p.C + co;
-    const float* gate = p.gate ? p.gate + co : nullptr;
-    const int col = n0 + 16 * wn + l16;
-    if (col < p.N) {
-        const float bb = p.bias ? p.bias[zb * p.sBias + col] : 0.f;
+    float* red = &As[0][0];                          // the tile buffers are free: the loop ended with a barrier
+    constexpr int NACC = WM * WN * 4;
+    float out[WM][WN][4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = m0 + 16 * wm + 4 * g + r;
-            if (row >= p.M) continue;
-            float x = p.alpha * (acc0[r] + acc1[r]) + bb;
-            if (p.flags & MTL_GEMM_RELU) x = fmaxf(x, 0.f);
-            if (gate) x = gate[(long)row * p.ldg + col] > 0.f ? x : 0.f;
-            float* c = C + (long)row * p.ldc + col;
-            if (p.flags & MTL_GEMM_ACCUM) x += *c;
-            *c = x;
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[i][j][r] = acc[i][j][0][r] + acc[i][j][1][r];
+    if (KG > 1) {
+        // [group][register][thread]: conflict-free; group 0 adds the others in fixed order
+        static_assert((KG - 1) * NACC * 256 <= KG * OA::FLOATS, "reduction scratch exceeds the A tile buffers");
+        if (kg > 0) {
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) red[((kg - 1) * NACC + (i * WN + j) * 4 + r) * 256 + tid] = out[i][j][r];
+        }
+        __syncthreads();
+        if (kg == 0) {
+#pragma unroll
+            for (int q = 1; q < KG; ++q)
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) out[i][j][r] += red[((q - 1) * NACC + (i * WN + j) * 4 + r) * 256 + tid];
+        }
+        __syncthreads();
+    }
+    if (kg == 0) {
+        const long co = zb * p.sCb + zh * p.sCh;
+        float* C = p.C + co;
+        const float* gate = p.gate ? p.gate + co : nullptr;
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int col = n0 + 16 * (2 * j + wn) + l16;
+            if (col >= p.N) continue;
+            const float bb = p.bias ? p.bias[zb * p.sBias + col] : 0.f;
+#pragma unroll
+            for (int i = 0; i < WM; ++i) {
+                // the accumulate / gate operands of the four rows are requested together (clamped rows), then consumed
+                float cold[4], gt[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = min(m0 + 16 * (2 * i + wm) + 4 * g + r, p.M - 1);
+                    cold[r] = (p.flags & MTL_GEMM_ACCUM) ? C[(long)row * p.ldc + col] : 0.f;
+                    gt[r] = gate ? gate[(long)row * p.ldg + col] : 1.f;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = m0 + 16 * (2 * i + wm) + 4 * g + r;
+                    if (row >= p.M) continue;
+                    float x = p.alpha * out[i][j][r] + bb;
+                    if (p.flags & MTL_GEMM_RELU) x = fmaxf(x, 0.f);
+                    x = gt[r] > 0.f ? x : 0.f;
+                    C[(long)row * p.ldc + col] = x + cold[r];
+                }
+            }
         }
     }
     if (do_rowsum) {
-        // thread (k-lane q = tid >> 3, row group tid & 7) holds the sum over ITS k's of 4 rows: combine the 32 k-lanes through
-        // LDS in a fixed order (the tile buffers are free: the loop ended with a barrier)
-        float* red = As;
+        // thread (group kg, k-lane tid / TPR, row quad tid % TPR) holds the sum over ITS k's of 4 rows: combine the
+        // KG x (256 / TPR) partial rows through LDS in a fixed order
+        constexpr int KL = 256 / OA::TPR, LDR = TM + 1;
+        static_assert(KG * KL * LDR <= KG * OA::FLOATS, "row-sum scratch exceeds the A tile buffers");
+        float part[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) red[(tid >> 3) * 33 + (tid & 7) * 4 + j] = rs[j];
+        for (int i = 0; i < OA::NV; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) part[j] += rs[i][j];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[(kg * KL + tid / OA::TPR) * LDR + (tid % OA::TPR) * 4 + j] = part[j];
         __syncthreads();
-        if (tid < TM && m0 + tid < p.M) {
-            float t = 0.f;
-            for (int q = 0; q < 32; ++q) t += red[q * 33 + tid];
-            p.rowsum[zb * p.sRow + m0 + tid] += t;
+        if (kg == 0 && tid < TM && m0 + tid < p.M) {
+            float tsum = 0.f;
+            for (int q = 0; q < KG * KL; ++q) tsum += red[q * LDR + tid];
+            p.rowsum[zb * p.sRow + m0 + tid] += tsum;
         }
     }
 }
 
 inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
-template <bool TA, bool TB>
-int launch16(const G16P& p, int batch, hipStream_t s) {
-    const bool vec = al16(p.A) && al16(p.B) && (p.lda & 3) == 0 && (p.ldb & 3) == 0 &&
-                     ((p.sAb | p.sAh | p.sBb | p.sBh | p.sAk | p.sBk) & 3) == 0;
-    dim3 grid((p.N + TN - 1) / TN, (p.M + TM - 1) / TM, batch);
-    if (vec)
-        hipLaunchKernelGGL((gemm16_kernel<TA, TB, true>), grid, dim3(256), 0, s, p);
-    else
-        hipLaunchKernelGGL((gemm16_kernel<TA, TB, false>), grid, dim3(256), 0, s, p);
+template <bool TA, bool TB, bool VEC, int KG, int WM, int WN>
+int launch_cfg(const G16P& p, int batch, hipStream_t s) {
+    G16P q = p;
+    q.total = ((p.N + 32 * WN - 1) / (32 * WN)) * ((p.M + 32 * WM - 1) / (32 * WM)) * batch;
+    dim3 grid(((q.total + 7) / 8) * 8);
+    hipLaunchKernelGGL((gemm16_kernel<TA, TB, VEC, KG, WM, WN>), grid, dim3(256 * KG), 0, s, q);
     MTL_CHECK_LAUNCH();
     return MTL_OK;
 }
 
+template <bool TA, bool TB, int WM, int WN>
+int launch_kg(const G16P& p, int batch, hipStream_t s, int kg) {
+    if (kg == 4) return launch_cfg<TA, TB, true, 4, WM, WN>(p, batch, s);
+    if (kg == 2) return launch_cfg<TA, TB, true, 2, WM, WN>(p, batch, s);
+    return launch_cfg<TA, TB, true, 1, WM, WN>(p, batch, s);
+}
+
+template <bool TA, bool TB>
+int launch16(const G16P& p, int batch, hipStream_t s) {
+    const bool vec = al16(p.A) && al16(p.B) && (p.lda & 3) == 0 && (p.ldb & 3) == 0 &&
+                     ((p.sAb | p.sAh | p.sBb | p.sBh | p.sAk | p.sBk) & 3) == 0;
+    if (!vec) return launch_cfg<TA, TB, false, 1, 1, 1>(p, batch, s);     // dword loads: unaligned operands (rare)
+    auto wgs = [&](int wm, int wn) { return (long)((p.M + 32 * wm - 1) / (32 * wm)) * ((p.N + 32 * wn - 1) / (32 * wn)) * batch; };
+    // grow the tile while the grid still holds about one chip-full of workgroups (256 CUs); tuning knobs for tools/bench_gemm16.py
+    static const int f_kg = getenv("MTL_G16_KG") ? atoi(getenv("MTL_G16_KG")) : 0;
+    static const int f_tile = getenv("MTL_G16_TILE") ? atoi(getenv("MTL_G16_TILE")) : 0;
+    // measured (tools/bench_gemm16.py): 32 x 32 tiles win or tie up to ~1000 workgroups; beyond that the larger tiles' operand
+    // re-use pays (vocabulary-projection dX: 64 -> 57 us with 64 x 32)
+    int tile = wgs(1, 1) <= 1024 ? 1 : (wgs(2, 1) <= 1024 ? 2 : 3);
+    if (f_tile) tile = f_tile;
+    const long n_wg = tile == 3 ? wgs(2, 2) : (tile == 2 ? wgs(2, 1) : wgs(1, 1));
+    // K groups: only while the chip is not already full of workgroups, and each group keeps >= 2 K tiles
+    const long ktiles = (long)((p.K + TK - 1) / TK) * p.kb;
+    int kg = 1;
+    if (n_wg <= 320 && ktiles >= 8) kg = 4;
+    else if (n_wg <= 640 && ktiles >= 4) kg = 2;
+    if (f_kg) kg = f_kg;
+    if (tile == 3) return launch_kg<TA, TB, 2, 2>(p, batch, s, kg == 4 ? 2 : kg);    // 64 x 64 x 4 groups would exceed 160 KiB of LDS
+    if (tile == 2) return launch_kg<TA, TB, 2, 1>(p, batch, s, kg);
+    return launch_kg<TA, TB, 1, 1>(p, batch, s, kg);
+}
+
 }  // namespace
 
+static bool route_small(int M, int N, int K, int batch, int kbatch, bool rowsum) {
+    const long tiles64 = (long)((M + 63) / 64) * ((N + 63) / 64) * batch;
+    const long tiles32 = (long)((M + 31) / 32) * ((N + 31) / 32) * batch;
+    static const int f_small = getenv("MTL_G16_FORCE") ? atoi(getenv("MTL_G16_FORCE")) : 0;      // tuning knob
+    // the big engine (64 x 64 / 128 x 128 tiles of v_mfma_f32_32x32x2_f32, split-K through the workspace) keeps every product
+    // that fills the chip with its own tiles, and the few-tile / very-long-K ones (the 5120-deep input projection)
+    const bool small = f_small ? f_small > 0 : (tiles64 <= 320 && !(tiles32 < 48 && (long)K * kbatch >= 4096));
+    return kbatch > 1 || rowsum || small;
+}
+
 extern "C" {
+
+/* 1: this product runs on the small-tile engine (gemm16_kernel<...>), 0: it is forwarded to mtl_gemm_f32 (gemm_kernel<...>) */
+int mtl_gemm_f32_ex_route(int M, int N, int K, int batch, int kbatch, int has_rowsum) {
+    return route_small(M, N, K, batch, kbatch, has_rowsum != 0) ? 1 : 0;
+}
 
 int mtl_gemm_f32_ex(void* stream, int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
                     const float* B, int ldb, float* C, int ldc, const float* bias, const float* gate, int ldg, int flags,
@@ -201,16 +357,11 @@ int mtl_gemm_f32_ex(void* stream, int transA, int transB, int M, int N, int K, f
                     long sBk, float* rowsum, long sRowsum, float* workspace, long workspace_bytes) {
     if (M <= 0 || N <= 0 || K <= 0 || batch <= 0 || H <= 0 || kbatch <= 0 || !A || !B || !C) return MTL_EINVAL;
     if (rowsum && !transA) return MTL_EINVAL;
-    const long tiles64 = (long)((M + 63) / 64) * ((N + 63) / 64) * batch;
-    const long tiles32 = (long)((M + 31) / 32) * ((N + 31) / 32) * batch;
-    // the big engine (64 x 64 / 128 x 128 tiles, split-K through the workspace) keeps every product that fills the chip with
-    // its own tiles, and the few-tile / very-long-K ones (the 5120-deep input projection's weight gradient)
-    const bool small = tiles64 < 192 && !(tiles32 < 48 && (long)K * kbatch >= 4096);
-    if (kbatch == 1 && !rowsum && !small)
+    if (!route_small(M, N, K, batch, kbatch, rowsum != nullptr))
         return mtl_gemm_f32(stream, transA, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, bias, gate, ldg, flags, batch, H, sAb,
                             sAh, sBb, sBh, sCb, sCh, sBias, workspace, workspace_bytes);
     G16P p{A, B, C, bias, gate, rowsum, M, N, K, lda, ldb, ldc, ldg, alpha, flags, H, sAb, sAh, sBb, sBh, sCb, sCh, sBias, kbatch,
-           sAk, sBk, sRowsum};
+           sAk, sBk, sRowsum, 0};
     hipStream_t s = as_stream(stream);
     if (!transA && transB) return launch16<false, true>(p, batch, s);
     if (!transA && !transB) return launch16<false, false>(p, batch, s);

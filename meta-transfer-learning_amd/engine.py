@@ -209,6 +209,8 @@ class PassEngine:
         self.gemm_ws_side = torch.empty(8 << 20, dtype=torch.float32, device=device) if device.type == 'cuda' else None
         self.scratch_side = torch.empty(4 << 20, dtype=torch.float32, device=device) if device.type == 'cuda' else None
         self.on_side = False
+        self.scratch_epoch = 0
+        self._events, self._ev_next = [], 0    # fork / join events of the side stream (raw handles: recordable library calls)
         self.dropout_p = 0.0          # set by the model: hp.dropout when model.training else 0
         self._site = 0                # dropout site counter of the current pass (Philox offset = site << 40)
         self.after_conv_hook = None
@@ -224,7 +226,7 @@ class PassEngine:
         # outside mtl_attn_supported() take the batched-GEMM + softmax path ('0' forces it, for A/B measurements)
         self.fused_attn = (os.environ.get('MTL_FUSED_ATTN', '1') != '0' and device.type == 'cuda'
                            and bool(self.lib.mtl_attn_supported(hp.dk, hp.dv)))
-        self.prof = None    # optional {name: [flops, [(start_event, end_event), ...]]}: HIP events around the conv launches
+        self.prof = None    # set (to anything) while a profiling proxy stands in for self.lib: replay / graphs / lane tricks are bypassed
         if device.type != 'cuda':
             raise RuntimeError('PassEngine needs an MI355X device (got %s); there is no CPU product path' % device)
 
@@ -247,18 +249,8 @@ class PassEngine:
         if t is None or t.numel() * 4 < nbytes:
             t = torch.empty((int(nbytes) + 3) // 4 + 1024, dtype=torch.float32, device=self.device)
             self.arena['_scratch'] = t
+            self.scratch_epoch += 1          # recorded command lists hold the old address: they are re-recorded (trainer._run_recorded)
         return t.data_ptr()
-
-    def timed(self, name, flops, fn, *args):
-        """Run one library call; when profiling is on, bracket it with events on the launch stream (bench.py roofline)."""
-        if self.prof is None:
-            return fn(*args)
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record(torch.cuda.current_stream(self.device))
-        rc = fn(*args)
-        b.record(torch.cuda.current_stream(self.device))
-        self.prof.setdefault(name, [flops, []])[1].append((a, b))
-        return rc
 
     @property
     def stream(self):
@@ -272,6 +264,34 @@ class PassEngine:
                                        batch, H, sA[0], sA[1], sB[0], sB[1], sC[0], sC[1], sbias, kbatch, sAk, sBk, rowsum, srow,
                                        wst.data_ptr(), wst.numel() * 4), 'mtl_gemm_f32_ex')
 
+    # ---- byte-level helpers and flat-vector updates as LIBRARY calls (a task body made of library calls only can be recorded
+    # into a command list and replayed from C; torch's own fill / copy kernels cannot)
+    def zero_(self, t):
+        check(self.lib.mtl_memset_zero(self.stream, t.data_ptr(), t.numel() * t.element_size()), 'mtl_memset_zero')
+
+    def copy_(self, dst, src):
+        assert dst.numel() * dst.element_size() == src.numel() * src.element_size()
+        check(self.lib.mtl_memcpy_d2d(self.stream, dst.data_ptr(), src.data_ptr(), src.numel() * src.element_size()), 'mtl_memcpy_d2d')
+
+    def axpy_(self, y, x, a):
+        check(self.lib.mtl_axpy(self.stream, y.data_ptr(), x.data_ptr(), float(a), y.numel()), 'mtl_axpy')
+
+    def sgd_theta_prime(self, theta0, g, lr, out):
+        check(self.lib.mtl_sgd_theta_prime(self.stream, theta0.data_ptr(), g.data_ptr(), float(lr), out.data_ptr(), theta0.numel()),
+              'mtl_sgd_theta_prime')
+
+    def _event(self):
+        """next event handle of a small ring (an event may be re-recorded once its earlier waits have been ENQUEUED: a wait binds
+        to the record that precedes it in host order)"""
+        if not self._events:
+            for _ in range(8):
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(self.device))       # materialises the hipEvent_t
+                self._events.append(ev)
+        ev = self._events[self._ev_next]
+        self._ev_next = (self._ev_next + 1) % len(self._events)
+        return ev.cuda_event
+
     # ---- side stream: deferred parameter-gradient work
     def defer(self, fn):
         if self.use_side_stream:
@@ -284,10 +304,9 @@ class PassEngine:
         stream.  Their inputs are per-block buffers that the main stream never rewrites within this backward."""
         if not self.deferred:
             return
-        main = torch.cuda.current_stream(self.device)
-        ev = torch.cuda.Event()
-        ev.record(main)
-        self.side.wait_event(ev)
+        ev = self._event()
+        check(self.lib.mtl_event_record(ev, self.stream), 'mtl_event_record')
+        check(self.lib.mtl_stream_wait_event(self.side.cuda_stream, ev), 'mtl_stream_wait_event')
         jobs, self.deferred = self.deferred, []
         with torch.cuda.stream(self.side):
             self.on_side = True
@@ -300,9 +319,9 @@ class PassEngine:
     def join_side(self):
         self.flush_side()
         if self.use_side_stream:
-            ev = torch.cuda.Event()
-            ev.record(self.side)
-            torch.cuda.current_stream(self.device).wait_event(ev)
+            ev = self._event()
+            check(self.lib.mtl_event_record(ev, self.side.cuda_stream), 'mtl_event_record')
+            check(self.lib.mtl_stream_wait_event(self.stream, ev), 'mtl_stream_wait_event')
 
     def linear_fwd(self, x, rows, k_in, w, b, y, n_out, relu=False):
         self.gemm(0, 1, rows, n_out, k_in, x, k_in, w, k_in, y, n_out, bias=b, flags=RELU if relu else 0)
@@ -340,10 +359,10 @@ class PassEngine:
         check(self.lib.mtl_layernorm_fwd(self.stream, x, res, g, b, pe, keep, xmask.data_ptr() if xmask is not None else None,
                                          self.drop_scale, y, xhat, rstd, rows, self.hp.d, T, 1e-5), 'mtl_layernorm_fwd')
 
-    def ln_bwd(self, dy, xhat, rstd, g, keep, dz, dg, db, rows, dsum=None, xmask=None, dzm=None):
+    def ln_bwd(self, dy, xhat, rstd, g, keep, dz, dg, db, rows, dsum=None, xmask=None, dzm=None, dz2=None):
         ws = self.scratch(self.lib.mtl_layernorm_bwd_workspace(rows, self.hp.d))
         check(self.lib.mtl_layernorm_bwd(self.stream, dy, xhat, rstd, g, keep, xmask.data_ptr() if xmask is not None else None,
-                                         self.drop_scale, dz, dzm, dg, db, dsum, ws, rows, self.hp.d), 'mtl_layernorm_bwd')
+                                         self.drop_scale, dz, dzm, dz2, dg, db, dsum, ws, rows, self.hp.d), 'mtl_layernorm_bwd')
 
     # ---------------------------------------------------------------- attention / ffn blocks
     def mha_fwd(self, tag, P, pre, xq, Bn, Tq, xkv, Tk, klen, causal, keep):
@@ -418,8 +437,7 @@ class PassEngine:
         dzm = self.buf(tag + '_dzm', (Mq, d)) if mo is not None else None
         self.ln_bwd(dy, A[tag + 'xhat'].data_ptr(), A[tag + 'rstd'].data_ptr(), o('layer_norm.weight'), keep, dzb.data_ptr(),
                     g('layer_norm.weight'), g('layer_norm.bias'), Mq, dsum=g('output_linear_b.bias'), xmask=mo,
-                    dzm=dzm.data_ptr() if dzm is not None else None)
-        check(self.lib.mtl_copy_f32(self.stream, dxq, dzb.data_ptr(), Mq * d), 'mtl_copy_f32')   # residual path
+                    dzm=dzm.data_ptr() if dzm is not None else None, dz2=dxq)        # dxq = dz: the residual path
         dz = dzm.data_ptr() if dzm is not None else dzb.data_ptr()          # gradient of the (dropped) sub-layer branch
         doa = self.buf(tag + '_doa', (Mq, r))
         self.linear_bwd(oa.data_ptr(), dz, Mq, r, d, o('output_linear_b.weight'), g('output_linear_b.weight'),
@@ -539,8 +557,7 @@ class PassEngine:
         dzm = self.buf(tag + '_dzm', (rows, hp.d)) if mf is not None else None
         self.ln_bwd(dy, A[tag + 'xhat'].data_ptr(), A[tag + 'rstd'].data_ptr(), o('layer_norm.weight'), keep, dzb.data_ptr(),
                     g('layer_norm.weight'), g('layer_norm.bias'), rows, dsum=g('linear_2.bias'), xmask=mf,
-                    dzm=dzm.data_ptr() if dzm is not None else None)
-        check(self.lib.mtl_copy_f32(self.stream, dx, dzb.data_ptr(), rows * hp.d), 'mtl_copy_f32')   # residual path
+                    dzm=dzm.data_ptr() if dzm is not None else None, dz2=dx)         # dx = dz: the residual path
         dbr = dzm.data_ptr() if dzm is not None else dzb.data_ptr()
         h1 = A[tag + 'h1']
         dh1 = self.buf(tag + '_dh1', (rows, hp.inner))
@@ -634,8 +651,7 @@ class PassEngine:
 
         # ---- VGG front-end ----
         y1 = self.buf('y1', (B, T, F, 64))
-        cf = lambda t_, f_, ci, co: 2.0 * B * t_ * f_ * 9 * ci * co     # algorithmic FLOPs of one 3x3 conv launch
-        check(self.timed('conv0_fwd', cf(T, F, 1, 64), lib.mtl_conv0_relu_fwd, st, x.data_ptr(), o('conv.0.weight'),
+        check(lib.mtl_conv0_relu_fwd(st, x.data_ptr(), o('conv.0.weight'),
                          o('conv.0.bias'), y1.data_ptr(), B, T, F), 'conv0')
         wf, wd = {}, {}
         x3 = self.conv_x3
@@ -652,14 +668,14 @@ class PassEngine:
             check(wprep(st, o('conv.%d.weight' % idx), wf[idx].data_ptr(), wd[idx].data_ptr(), cout, cin), 'wprep')
         p1 = self.buf('p1', (B, T2, F2, 64))
         am1 = self.buf('am1', (B, T2, F2, 64), torch.uint8)
-        check(self.timed('conv2_fwd_pool', cf(T, F, 64, 64), conv_fwd_pool, st, y1.data_ptr(), wf[2].data_ptr(),
+        check(conv_fwd_pool(st, y1.data_ptr(), wf[2].data_ptr(),
                          o('conv.2.bias'), p1.data_ptr(), am1.data_ptr(), B, T, F, 64, 64), 'conv2')
         y5 = self.buf('y5', (B, T2, F2, 128))
-        check(self.timed('conv5_fwd', cf(T2, F2, 64, 128), conv_fwd, st, p1.data_ptr(), wf[5].data_ptr(),
+        check(conv_fwd(st, p1.data_ptr(), wf[5].data_ptr(),
                          o('conv.5.bias'), y5.data_ptr(), B, T2, F2, 64, 128), 'conv5')
         p2 = self.buf('p2', (B, T4, F4, 128))
         am2 = self.buf('am2', (B, T4, F4, 128), torch.uint8)
-        check(self.timed('conv7_fwd_pool', cf(T2, F2, 128, 128), conv_fwd_pool, st, y5.data_ptr(), wf[7].data_ptr(),
+        check(conv_fwd_pool(st, y5.data_ptr(), wf[7].data_ptr(),
                          o('conv.7.bias'), p2.data_ptr(), am2.data_ptr(), B, T2, F2, 128, 128), 'conv7')
 
         if self.after_conv_hook is not None:      # lets the trainer de-phase concurrent task lanes (see trainer.meta_iteration)
@@ -869,7 +885,6 @@ class PassEngine:
                   gate=p2.data_ptr(), ldg=hp.d_in)
 
         # ---- VGG front-end ----
-        cf = lambda t_, f_, ci, co: 2.0 * B * t_ * f_ * 9 * ci * co
         conv_dgrad = lib.mtl_conv3x3_dgrad_x3 if self.conv_x3 else lib.mtl_conv3x3_dgrad
 
         def wgrad(xa, dy, am, idx, Bq, Tq, Fq, cin, cout):
@@ -878,25 +893,25 @@ class PassEngine:
                         (lib.mtl_conv3x3_wgrad_workspace, lib.mtl_conv3x3_wgrad))
             need = wsfn(Bq, Tq, Fq, cin, cout, 1 if am else 0)
             ws = self.scratch(need)
-            check(self.timed('conv%d_wgrad' % idx, cf(Tq, Fq, cin, cout), fn, st, xa, dy, am,
+            check(fn(st, xa, dy, am,
                              g('conv.%d.weight' % idx), ws, need, Bq, Tq, Fq, cin, cout), 'wgrad')
 
         self.colsum(dp2.data_ptr(), B * T4 * F4, 128, g('conv.7.bias'))
         wgrad(y5.data_ptr(), dp2.data_ptr(), A['am2'].data_ptr(), 7, B, T2, F2, 128, 128)
         dy5 = self.buf('_dy5', (B, T2, F2, 128))
-        check(self.timed('conv7_dgrad', cf(T2, F2, 128, 128), conv_dgrad, st, dp2.data_ptr(), A['am2'].data_ptr(),
+        check(conv_dgrad(st, dp2.data_ptr(), A['am2'].data_ptr(),
                          A['wd7'].data_ptr(), y5.data_ptr(), dy5.data_ptr(), B, T2, F2, 128, 128), 'dgrad7')
         self.colsum(dy5.data_ptr(), B * T2 * F2, 128, g('conv.5.bias'))
         wgrad(p1.data_ptr(), dy5.data_ptr(), None, 5, B, T2, F2, 64, 128)
         dp1 = self.buf('_dp1', (B, T2, F2, 64))
-        check(self.timed('conv5_dgrad', cf(T2, F2, 64, 128), conv_dgrad, st, dy5.data_ptr(), None, A['wd5'].data_ptr(),
+        check(conv_dgrad(st, dy5.data_ptr(), None, A['wd5'].data_ptr(),
                          p1.data_ptr(), dp1.data_ptr(), B, T2, F2, 64, 128), 'dgrad5')
         self.colsum(dp1.data_ptr(), B * T2 * F2, 64, g('conv.2.bias'))
         wgrad(y1.data_ptr(), dp1.data_ptr(), A['am1'].data_ptr(), 2, B, T, F, 64, 64)
         dy1 = self.buf('_dy1', (B, T, F, 64))
-        check(self.timed('conv2_dgrad', cf(T, F, 64, 64), conv_dgrad, st, dp1.data_ptr(), A['am1'].data_ptr(),
+        check(conv_dgrad(st, dp1.data_ptr(), A['am1'].data_ptr(),
                          A['wd2'].data_ptr(), y1.data_ptr(), dy1.data_ptr(), B, T, F, 64, 64), 'dgrad2')
         ws = self.scratch(lib.mtl_conv0_wgrad_workspace())
-        check(self.timed('conv0_wgrad', cf(T, F, 1, 64), lib.mtl_conv0_wgrad, st, S['x'].data_ptr(), dy1.data_ptr(),
+        check(lib.mtl_conv0_wgrad(st, S['x'].data_ptr(), dy1.data_ptr(),
                          g('conv.0.weight'), g('conv.0.bias'), ws, B, T, F), 'wgrad0')
         self.join_side()

@@ -256,6 +256,10 @@ class TransientTrainer():
         # hipGraph replay of the task body is validated but opt-in: at 2 task lanes the loop is GPU-throughput-bound and replay
         # measured equal (8 tasks) or slower (3 tasks, dropout) than eager launches on ROCm 7.2
         self.use_graphs = os.environ.get('MTL_GRAPHS', '0') == '1'
+        # command lists (default on): the library calls of a task body are recorded once per (lane, shapes, scalars) and then
+        # replayed from C with one ctypes call per task (include/mtl_hip.h "command lists"): host cost per pass 4.4 -> ~1 ms
+        self.use_cmdlists = os.environ.get('MTL_CMDLISTS', '1') != '0'
+        self._cmdlists = {}
         # a rank with a single task can split its batch over the two lanes (_single_task_split; exact, tested) -- measured no
         # faster than the unsplit task (18.4 vs 18.7 ms per 1-task step, slower with dropout), so it is opt-in
         self.split_single_task = os.environ.get('MTL_SPLIT_TASK', '0') == '1'
@@ -294,7 +298,9 @@ class TransientTrainer():
         dev = model.flat_parameters.device
         theta0 = model.flat_parameters
         smoothing = float(getattr(args, 'label_smoothing', 0.0) or 0.0)
-        use_graphs = self.use_graphs and not any(e.prof is not None for e in model.engines)
+        hooked = any(e.prof is not None or e.forward_hook is not None or e.after_conv_hook is not None for e in model.engines)
+        use_graphs = self.use_graphs and not hooked
+        use_cmdlists = self.use_cmdlists and not use_graphs and not hooked and os.environ.get('MTL_STAGGER', '0') != '1'
         if (len(task_batches) == 1 and model.n_lanes >= 2 and self.split_single_task and not use_graphs
                 and task_batches[0][0].shape[0] >= 2 and val_batch[0].shape[0] >= 2
                 and not any(e.prof is not None for e in model.engines)):
@@ -326,11 +332,14 @@ class TransientTrainer():
                 m_va = eng.prepare(val_batch[1], val_batch[3], vx.shape[0], vx.shape[3], slot=1)
                 slots = self._slots(model, lane, m_tr, m_va)
                 key = (lane, tuple(tx.shape), tuple(vx.shape), m_tr['Td'], m_va['Td'], n_tasks, bool(args.clip),
-                       float(args.max_norm), smoothing, float(inner.param_groups[0]['lr']), theta0.data_ptr(), eng.dropout_p)
+                       float(args.max_norm), smoothing, float(inner.param_groups[0]['lr']), theta0.data_ptr(), eng.dropout_p,
+                       tuple(b.data_ptr() for b in bufs[lane]), streams[lane].cuda_stream, eng.use_side_stream)
                 body = lambda xa, xb: self._task_body(model, lane, bufs[lane], theta0, xa, m_tr, xb, m_va, n_tasks, inner, args,
                                                       smoothing, slots)
                 graph = self._graph_for(key, lane, tx, vx, body, streams[lane]) if use_graphs else None
-                if graph is None:
+                if graph is None and use_cmdlists:
+                    self._run_recorded(key, eng, tx, vx, body)
+                elif graph is None:
                     body(tx, vx)
                 else:
                     graph['x_tr'].copy_(tx, non_blocking=True)
@@ -442,24 +451,58 @@ class TransientTrainer():
         SGD into theta', validation pass at theta', accumulation into the lane's copy_grad buffer."""
         eng = model.engines[lane]
         g, theta1, G = bufs
-        g.zero_()                                                        # inner_opt.zero_grad()   (:198)
+        eng.zero_(g)                                                     # inner_opt.zero_grad()   (:198)
         out = eng.forward_device(theta0, x_tr, m_tr, smoothing)          # meta-train forward      (:188)
-        slots['hyp_tr'].copy_(out['hyp'])
-        slots['loss_tr'].copy_(out['loss'])
+        eng.copy_(slots['hyp_tr'], out['hyp'])
+        eng.copy_(slots['loss_tr'], out['loss'])
         eng.backward(g, 1.0)                                             # tr_loss.backward()      (:199)
         if args.clip:
             clip_flat_grad_(model, g, args.max_norm, lane=lane)          # (:205-206)
-        inner.theta_prime_from(theta0, g, out=theta1)                    # inner_opt.step()        (:207)
+        eng.sgd_theta_prime(theta0, g, inner.param_groups[0]['lr'], theta1)     # inner_opt.step() (:207)
         out = eng.forward_device(theta1, x_va, m_va, smoothing)          # meta-validation forward (:215)
-        slots['hyp_va'].copy_(out['hyp'])
-        slots['loss_va'].copy_(out['loss'])
+        eng.copy_(slots['hyp_va'], out['hyp'])
+        eng.copy_(slots['loss_va'], out['loss'])
         eng.backward(g, 1.0 / n_tasks)                                   # (val_loss/n).backward(): g += g_val/n (Q1)
-        model._axpy(G, g, 1.0)                                           # add_copy_grad()         (:229)
+        eng.axpy_(G, g, 1.0)                                             # add_copy_grad()         (:229)
 
     def _slots(self, model, lane, m_tr, m_va):
         eng = model.engines[lane]
         return dict(hyp_tr=eng.buf('slot.hyp_tr', (m_tr['B'], m_tr['Td']), torch.int64), loss_tr=eng.buf('slot.loss_tr', (1,)),
                     hyp_va=eng.buf('slot.hyp_va', (m_va['B'], m_va['Td']), torch.int64), loss_va=eng.buf('slot.loss_va', (1,)))
+
+    def _run_recorded(self, key, eng, tx, vx, body):
+        """Command-list execution of a task body.  First sighting of a key: plain eager run (it also brings every arena buffer to
+        its final size); second sighting: eager run through a Recorder that logs the calls; afterwards: the two input pointers
+        are re-pointed to this task's batches and the recorded calls are replayed by mtl_cmdlist_run."""
+        ent = self._cmdlists.get(key)
+        if ent is None:
+            if len(self._cmdlists) >= 64:
+                return body(tx, vx)
+            self._cmdlists[key] = 'warm'
+            return body(tx, vx)
+        if ent != 'warm' and ent['epoch'] != eng.scratch_epoch:
+            ent = 'warm'                                  # the engine's scratch buffer moved since the recording
+        if ent == 'warm':
+            if tx.data_ptr() == vx.data_ptr():
+                return body(tx, vx)                       # the two inputs must be distinguishable by address to be re-pointed
+            cl = _lib.CommandList()
+            real, epoch = eng.lib, eng.scratch_epoch
+            eng.lib = _lib.Recorder(real, cl)
+            try:
+                body(tx, vx)
+            finally:
+                eng.lib = real
+            if eng.scratch_epoch == epoch:                # (a buffer that moved during the run would leave stale addresses)
+                self._cmdlists[key] = dict(cl=cl.finish(), x_tr=tx.data_ptr(), x_va=vx.data_ptr(), epoch=epoch)
+            return
+        cl = ent['cl']
+        if ent['x_tr'] != tx.data_ptr() or ent['x_va'] != vx.data_ptr():
+            tmp = 8                                       # two-step re-pointing through a dummy value: the batches may swap addresses
+            cl.repoint(ent['x_tr'], tmp)
+            cl.repoint(ent['x_va'], vx.data_ptr())
+            cl.repoint(tmp, tx.data_ptr())
+            ent['x_tr'], ent['x_va'] = tx.data_ptr(), vx.data_ptr()
+        cl.run()
 
     def _graph_for(self, key, lane, tx, vx, body, stream):
         """hipGraph of a task body, keyed by everything baked into it (shapes, scalars, buffer addresses).  First sighting of

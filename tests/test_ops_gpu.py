@@ -359,7 +359,7 @@ def test_layernorm(L, d):
     ddy = dev(dy)
     dsum = torch.ones(d).cuda()
     assert L.mtl_layernorm_bwd(st(), ddy.data_ptr(), xhat.data_ptr(), rstd.data_ptr(), a[2].data_ptr(), kd.data_ptr(), None, 1.0,
-                               dz.data_ptr(), None, dg.data_ptr(), db.data_ptr(), dsum.data_ptr(), ws.data_ptr(), rows, d) == 0
+                               dz.data_ptr(), None, None, dg.data_ptr(), db.data_ptr(), dsum.data_ptr(), ws.data_ptr(), rows, d) == 0
     assert rel(dz, xr.grad) < 1e-5 and rel(dg, gr.grad) < 1e-5 and rel(db, br.grad) < 1e-5
     assert rel(dsum, xr.grad.sum(0) + 1) < 1e-5
     # with dropout on the sub-layer output x (before the residual): forward and both gradient branches
@@ -375,11 +375,13 @@ def test_layernorm(L, d):
     assert L.mtl_layernorm_fwd(st(), a[0].data_ptr(), a[1].data_ptr(), a[2].data_ptr(), a[3].data_ptr(), a[4].data_ptr(),
                                kd.data_ptr(), mask.data_ptr(), sc, y.data_ptr(), xhat.data_ptr(), rstd.data_ptr(), rows, d, T, 1e-5) == 0
     assert rel(y, yr) < 2e-6
-    dzm = torch.empty(rows, d).cuda()
+    dzm, dz2 = torch.empty(rows, d).cuda(), torch.empty(rows, d).cuda()
     dsum.zero_(); dg.zero_(); db.zero_()
     assert L.mtl_layernorm_bwd(st(), ddy.data_ptr(), xhat.data_ptr(), rstd.data_ptr(), a[2].data_ptr(), kd.data_ptr(), mask.data_ptr(),
-                               sc, dz.data_ptr(), dzm.data_ptr(), dg.data_ptr(), db.data_ptr(), dsum.data_ptr(), ws.data_ptr(), rows, d) == 0
+                               sc, dz.data_ptr(), dzm.data_ptr(), dz2.data_ptr(), dg.data_ptr(), db.data_ptr(), dsum.data_ptr(), ws.data_ptr(),
+                               rows, d) == 0
     assert rel(dz, rr.grad) < 1e-5 and rel(dzm, xr.grad) < 1e-5 and rel(dsum, xr.grad.sum(0)) < 1e-5 and rel(dg, gr.grad) < 1e-5
+    assert torch.equal(dz2, dz)                                             # second copy for the residual path
 
 
 @pytest.mark.parametrize('B,H,Tq,Tk,dk,causal,klens,drop', [

@@ -468,6 +468,41 @@ def test_hipgraph_replay_is_bitwise_equal_to_eager():
     assert torch.equal(res[False][0], res[True][0]) and torch.equal(res[False][1], res[True][1])
 
 
+@pytest.mark.parametrize('dropout', [0.0, 0.1])
+def test_command_list_replay_is_bitwise_equal_to_eager(dropout):
+    """The per-task body recorded into a command list and replayed by mtl_cmdlist_run (trainer._run_recorded, default on) must
+    reproduce the eager meta-gradient bit for bit -- side-stream fork / join, re-pointed input batches and (with dropout) the
+    per-pass Philox seeds read from device memory included -- also for batches it was not recorded on."""
+    z, cfg, spec = gu.load('F0')
+    mtl_amd, args, vocab, model = make(cfg, spec)
+    args.dropout = dropout
+    torch.manual_seed(123456)
+    model = mtl_amd.init_transformer_model(args, vocab, r=cfg['r']).cuda()
+    as5 = lambda b: (b[0].cuda(), b[1], None, b[2], None)
+    mk = lambda s0: [as5(mtl_amd.synth_batch(s0 + i, 2, 64, 8, cfg['vocab_size'])) for i in range(6)]
+    val = as5(mtl_amd.synth_batch(77, 2, 64, 8, cfg['vocab_size']))
+    inner = mtl_amd.FlatSGD(model, spec['lr'])
+    model.zero_copy_grad()
+    res = {}
+    for mode in (False, True):
+        tr = mtl_amd.TransientTrainer()
+        tr.use_cmdlists = mode
+        outs = []
+        for s0 in (100, 200, 300):                 # the third batch set runs purely on replays when command lists are on
+            torch.manual_seed(s0)                  # the dropout seeds of the passes come from torch's CPU generator
+            reads = tr.meta_iteration(model, vocab, mk(s0), val, 6, inner, None, args)
+            torch.cuda.synchronize()
+            outs.append((model._G.clone(), [(r.loss.clone(), r.hyp.clone()) for pair in reads for r in pair]))
+        res[mode] = outs
+        if mode:
+            recorded = [v for v in tr._cmdlists.values() if isinstance(v, dict)]
+            assert len(recorded) == model.n_lanes and all(v['cl'].n > 100 for v in recorded)
+    for (G0, r0), (G1, r1) in zip(res[False], res[True]):
+        assert torch.equal(G0, G1)
+        for (l0, h0), (l1, h1) in zip(r0, r1):
+            assert torch.equal(l0, l1) and torch.equal(h0, h1)
+
+
 @pytest.mark.parametrize('B,variable', [(4, False), (5, True)])
 def test_single_task_split_over_lanes_equals_unsplit(B, variable):
     """a rank that holds ONE task splits each pass by samples over the two lanes (trainer._single_task_split: what 8 tasks on 8
