@@ -200,13 +200,16 @@ def serial_profile(mtl, trainer, model, vocab, tasks, my_tasks, n_tasks, inner, 
     torch.cuda._sleep(2000000)
     b.record()
     torch.cuda.synchronize(dev)
-    per_cycle = a.elapsed_time(b) / 2000000.0                 # ms per spin count
+    per_count = max(a.elapsed_time(b) - 0.01, 1e-3) / 2000000.0          # ms per spin count
     hold_ms = 40.0 + 60.0 * max(len(local), 1)               # generous: ~60 ms of enqueue per task at this instrumentation level
+    h0, h1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    torch.cuda._sleep(int(hold_ms / per_cycle))
+    h0.record()
+    torch.cuda._sleep(int(hold_ms / per_count))
+    h1.record()
     trainer.run_iteration(model, vocab, local, val, n_tasks, inner, outer, args)
     torch.cuda.synchronize(dev)
-    wall = time.perf_counter() - t0 - hold_ms * 1e-3
+    wall = time.perf_counter() - t0 - h0.elapsed_time(h1) * 1e-3          # GPU-side time of the step once the hold ended
     for e, (lib_, side) in zip(model.engines, saved):
         e.lib, e.use_side_stream, e.prof = lib_, side, None
     model.n_lanes = lanes
@@ -357,7 +360,7 @@ def main():
                             dom, 'split-bf16 x3: 6 v_mfma_f32_32x32x16_bf16 per fp32-equivalent step, peak = dense bf16 / 6'
                             if dr['peak'] == PEAK_X3_TFLOPS else ('exact fp32 MFMA' if dr['bound'] == 'mfma' else 'HBM streaming')),
                         serial_step=dict(launches_per_pass=n_launch / passes, gpu_ms_per_pass=sum(c['time'] for c in classes.values()) / passes * 1e3,
-                                         wall_ms_per_pass=serial_wall / passes * 1e3),
+                                         gpu_span_ms_per_pass=serial_wall / passes * 1e3),
                         per_class=table)
         ms = dt / a.steps * 1e3
         out = dict(metric='meta-steps/sec', value=a.steps / dt, unit='meta-steps/s', n_gpus=world, steps=a.steps, warmup=a.warmup,

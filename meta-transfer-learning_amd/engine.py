@@ -210,6 +210,7 @@ class PassEngine:
         self.scratch_side = torch.empty(4 << 20, dtype=torch.float32, device=device) if device.type == 'cuda' else None
         self.on_side = False
         self.scratch_epoch = 0
+        self._stage, self._stage_turn = {}, {}   # pinned host staging of prepare()
         self._events, self._ev_next = [], 0    # fork / join events of the side stream (raw handles: recordable library calls)
         self.dropout_p = 0.0          # set by the model: hp.dropout when model.training else 0
         self._site = 0                # dropout site counter of the current pass (Philox offset = site << 40)
@@ -606,10 +607,26 @@ class PassEngine:
             (pos < lens.unsqueeze(1)).to(torch.int32).reshape(-1),             # keep_enc (B*T4)
             (~is_pad).to(torch.int32).reshape(-1),                             # keep_dec (B*Td)
             first, nxt])                                                       # embed chains (B*Td each)
+        # page-locked staging (two alternating buffers per slot, each guarded by an event): the uploads are truly asynchronous and
+        # the host never rewrites a staging buffer whose copy has not been consumed yet
         dev_i32 = self.buf('meta_i32.%d' % slot, (meta_i32.numel(),), torch.int32)
-        dev_i32.copy_(meta_i32, non_blocking=True)
         ids = self.buf('ids.%d' % slot, (2, B, Td), torch.int64)
-        ids.copy_(torch.stack([seq_in, seq_out]), non_blocking=True)
+        turn = self._stage_turn.get(slot, 0)
+        self._stage_turn[slot] = turn ^ 1
+        key = (slot, turn, meta_i32.numel(), B, Td)
+        st = self._stage.get(key)
+        if st is None:
+            st = dict(i32=torch.empty(meta_i32.numel(), dtype=torch.int32).pin_memory(),
+                      ids=torch.empty((2, B, Td), dtype=torch.int64).pin_memory(), ev=torch.cuda.Event())
+            self._stage[key] = st
+        else:
+            st['ev'].synchronize()
+        st['i32'].copy_(meta_i32)
+        st['ids'][0].copy_(seq_in)
+        st['ids'][1].copy_(seq_out)
+        dev_i32.copy_(st['i32'], non_blocking=True)
+        ids.copy_(st['ids'], non_blocking=True)
+        st['ev'].record(torch.cuda.current_stream(self.device))
         seed = dev_i32.data_ptr()
         inv_count = seed + 8
         klen_enc = seed + 16

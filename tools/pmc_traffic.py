@@ -1,5 +1,5 @@
 """Build profiles/pmc_traffic.json from two rocprofv3 counter_collection CSVs (separate --pmc FETCH_SIZE and --pmc WRITE_SIZE
-passes of `bench.py --tasks 1 --serial`): HBM bytes per launch of every conv class = (2 x FETCH_SIZE + WRITE_SIZE) x 1024
+passes of `bench.py --tasks 1 --serial`): HBM bytes per launch of every kernel class = (2 x FETCH_SIZE + WRITE_SIZE) x 1024
 (FETCH_SIZE doubled per /opt/skills/guides/MI355X_MICROARCH.md's gfx950 correction).
 usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>"""
 import collections
@@ -17,10 +17,29 @@ CLASSES = {  # kernel template instance -> bench.py conv class (see PassEngine.f
 }
 
 
+# kernel-name substring -> bench.py class for the non-convolution classes (a class = one C-ABI call; calls that launch two
+# kernels, e.g. mtl_attn_bwd, are averaged per kernel and summed)
+GROUPS = {'gemm_small': ['gemm16_kernel'], 'gemm_big': ['gemm_kernel<', 'splitk_reduce_kernel'], 'attn_fwd': ['attn_fwd_kernel'],
+          'attn_bwd': ['attn_bwd_q_kernel', 'attn_bwd_kv_kernel'], 'layernorm_fwd': ['layernorm_fwd_kernel'],
+          'layernorm_bwd': ['layernorm_bwd_kernel', 'ln_param_reduce_kernel'], 'conv0_fwd': ['conv0_fwd_kernel'],
+          'conv0_wgrad': ['conv0_wgrad_kernel', 'conv0_wgrad_final_kernel']}
+
+
 def per_class(path, counter):
     rows = [r for r in csv.DictReader(open(path)) if r['Counter_Name'] == counter]
     rows.sort(key=lambda r: int(r['Dispatch_Id']))
     out, seen = collections.defaultdict(list), collections.Counter()
+    parts = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in rows:
+        for cls, subs in GROUPS.items():
+            for sub in subs:
+                if sub in r['Kernel_Name']:
+                    parts[cls][sub].append(float(r['Counter_Value']))
+    for cls, d in parts.items():
+        n = max(len(v) for v in d.values())
+        if cls == 'gemm_big':
+            n = len(d.get('gemm_kernel<', [])) or n          # a split-K reduction belongs to the call of its GEMM
+        out[cls] = [sum(sum(v) for v in d.values()) / n]
     for r in rows:
         m = re.search(r'(conv3x3_\w+<[^>]*>)', r['Kernel_Name'])
         if not m or m.group(1) not in CLASSES:
