@@ -61,3 +61,35 @@ def test_levenshtein_host_helper(built):
         a = ''.join(rnd.choice('abcd') for _ in range(rnd.randint(0, 30)))
         b = ''.join(rnd.choice('abcd') for _ in range(rnd.randint(0, 30)))
         assert lev(a, b) == dp(a, b)
+
+
+def test_command_list_dispatch_is_generated_from_the_header(built):
+    """csrc/mtl_cmdlist_gen.inc (the switch mtl_cmdlist_run dispatches through) must be what tools/gen_cmdlist.py produces from the
+    CURRENT include/mtl_hip.h, and every recordable function must resolve to an opcode."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('gen_cmdlist', os.path.join(ROOT, 'tools', 'gen_cmdlist.py'))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    have = open(os.path.join(ROOT, 'meta-transfer-learning_amd', 'csrc', 'mtl_cmdlist_gen.inc')).read()
+    assert have == gen.generate(), 'run `python tools/gen_cmdlist.py` and rebuild'
+    L = built._lib.lib()
+    for name in ('mtl_gemm_f32_ex', 'mtl_attn_fwd', 'mtl_attn_bwd', 'mtl_layernorm_bwd', 'mtl_event_record', 'mtl_memcpy_d2d'):
+        assert L.mtl_cmdlist_opcode(name.encode()) >= 0, name
+    for name in ('mtl_colsum_workspace', 'mtl_cmdlist_run', 'mtl_abi_version', 'nope'):
+        assert L.mtl_cmdlist_opcode(name.encode()) == -1, name
+
+
+def test_command_list_records_only_successful_calls_and_reports_failures(built):
+    """host side of the command lists without a GPU: a Recorder executes and logs, size queries are not logged, a failing call
+    is reported with its index (argument validation happens before any launch)."""
+    lib_mod = built._lib
+    L = lib_mod.lib()
+    cl = lib_mod.CommandList()
+    rec = lib_mod.Recorder(L, cl)
+    assert rec.mtl_colsum_workspace(100, 64) == L.mtl_colsum_workspace(100, 64)
+    assert rec.mtl_adam_step(None, None, None, None, None, 1, 1e-3, 0.9, 0.999, 1e-8, 16) == -22        # rejected -> not recorded
+    assert len(cl.entries) == 0
+    cl.add(L.mtl_cmdlist_opcode(b'mtl_adam_step'), lib_mod._kinds('mtl_adam_step'), (None, None, None, None, None, 1, 1e-3, 0.9, 0.999, 1e-8, 16))
+    cl.finish()
+    with pytest.raises(RuntimeError, match='command 0 failed with code -22'):
+        cl.run()
