@@ -158,6 +158,9 @@ def classify(lib, name, a, conv_x3, wgrad_x3_dense):
         return 'ce_bwd', 8.0 * a[4] * a[5], 'byte', 'ce_bwd_kernel'
     if name == 'mtl_colsum_accum':
         return 'colsum', 4.0 * a[2] * a[3], 'byte', 'colsum_partial_kernel + colsum_final_kernel'
+    if name in ('mtl_lstm_cell_fwd', 'mtl_lstm_cell_bwd'):
+        B, H = a[-2:]
+        return name[4:], 4.0 * B * H * (15 if name.endswith('fwd') else 17), 'byte', name[4:] + '_kernel'
     if name in ('mtl_sgd_theta_prime', 'mtl_axpy'):
         return name[4:], 12.0 * a[-1], 'byte', name[4:] + '_kernel'
     if name == 'mtl_adam_step':
@@ -274,6 +277,105 @@ def cpu_baseline(n_tasks, k, T, L, threads, timed_tasks):
                 seconds_per_task=t_task)
 
 
+LM_CFG = dict(ntoken=10000, ninp=512, nhid=512, nlayers=2, bptt=35, batch_size=20, dropout=0.2, lr=1.0, meta_lr_factor=3.0, clip=0.25,
+              ratio=0.8, corpus_len=40000)
+
+
+def main_lm(a, mtl_amd, mdist, dev, rank, world):
+    """BASELINE.json configs[4]: the LM meta loop (lm/main_meta_transfer.py) -- token-only, d512 2-layer LSTM, `--tasks` synthetic
+    corpora sharded over the ranks, one all-reduce of the flat G.  One step = one meta-iteration (every task: train pass, clipped
+    inner SGD step, validation pass at theta'; clipped outer SGD step).  Parity of this path is pinned to the oracle's documented
+    first-order restatement only (the reference's loop does not run on torch >= 2)."""
+    from oracle import lm_refimpl as LR               # synthetic corpus generator + cpu_baseline leg only
+    c = LM_CFG
+    torch.manual_seed(1111)
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = mtl_amd.lm.RNNModel('LSTM', c['ntoken'], c['ninp'], c['nhid'], c['nlayers'], c['dropout']).to(dev)
+    model.train()
+    n = a.tasks
+    streams = [LR.synth_corpus(100 + i, c['ntoken'], c['corpus_len']) for i in range(n)]
+    ds = mtl_amd.lm.LMDataset(streams, argparse.Namespace(bptt=c['bptt'], batch_size=c['batch_size'], cuda=False))
+    ds.task_list = [t.to(dev) for t in ds.task_list]
+    mine = mdist.shard_tasks(n, rank, world)
+    tr = mtl_amd.lm.LMMetaTrainer(model, c['lr'], c['meta_lr_factor'], c['clip'], c['ratio'])
+
+    def one(it):
+        vb = ds.sample(-1, it)[2:]
+        return tr.run_iteration([ds.sample(i, it)[:2] for i in mine], vb, n, mine)
+    for it in range(a.warmup):
+        one(it)
+    mdist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for it in range(a.warmup, a.warmup + a.steps):
+        last = one(it)
+    torch.cuda.synchronize(dev)
+    mdist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t)
+    # serial profiling iteration: every launch bracketed with events (same scheme as the ASR workload)
+    prof = LaunchProfiler(mtl_amd._lib.lib(), dev)
+    eng = model.engine
+    real = eng.lib
+    eng.lib = prof
+    torch.cuda.synchronize(dev)
+    one(a.warmup + a.steps)
+    torch.cuda.synchronize(dev)
+    eng.lib = real
+    classes = {}
+    for name, args_, e0, e1 in prof.records:
+        cls, work, unit, sym = classify(mtl_amd._lib.lib(), name, args_, False, False)
+        cc = classes.setdefault(cls, dict(time=0.0, work=0.0, unit=unit, launches=0, symbols=sym))
+        cc['time'] += e0.elapsed_time(e1) * 1e-3
+        cc['work'] += work or 0.0
+        cc['launches'] += 1
+    out = None
+    if rank == 0:
+        passes = 2 * max(len(mine), 1)
+        table = {}
+        for cls, cc in sorted(classes.items(), key=lambda kv: -kv[1]['time']):
+            row = dict(ms_per_pass=cc['time'] / passes * 1e3, launches_per_pass=cc['launches'] / passes, symbols=cc['symbols'])
+            if cc['unit'] is not None and cc['work'] > 0:
+                peak, unit, bound = peak_of(cls, cc['unit'], False, False)
+                ach = cc['work'] / cc['time'] / (1e12 if cc['unit'] == 'flop' else 1e9)
+                row.update(bound=bound, achieved=ach, peak=peak, unit=unit, frac=ach / peak)
+            table[cls] = row
+        dom = next(k for k in table if 'frac' in table[k])
+        dr, dc = table[dom], classes[dom]
+        out = dict(metric='meta-steps/sec', value=a.steps / dt, unit='meta-steps/s', n_gpus=world, steps=a.steps, warmup=a.warmup,
+                   ms_per_step=dt / a.steps * 1e3, higher_is_better=True, scaling='strong', vs_baseline=None, dtype='f32', data='synthetic',
+                   config=dict(workload='lm/main_meta_transfer.py meta loop (first-order reading, parity unpinned vs the reference loop): '
+                                        '2-layer LSTM d%d V%d, bptt %d, batch %d, %d synthetic corpora (%d per GPU), dropout %.1f'
+                                        % (c['nhid'], c['ntoken'], c['bptt'], c['batch_size'], n, len(mine), c['dropout']),
+                               tasks=n, parallelism='task-sharded dp%d' % world, collective=mdist.backend_name(), **{k: c[k] for k in ('bptt', 'batch_size', 'nhid', 'ntoken')}),
+                   roofline=dict(bound=dr['bound'], kernel=dom, symbols=dr['symbols'], achieved=dr['achieved'], peak=dr['peak'], unit=dr['unit'],
+                                 frac=dr['frac'], traffic=None, work_per_launch=dc['work'] / dc['launches'],
+                                 avg_launch_ms=dc['time'] / dc['launches'] * 1e3, launches_timed=dc['launches'],
+                                 timing='HIP events around every library call of one serial meta-iteration', per_class=table),
+                   last_step=dict(weighted_val_loss=last[0]))
+        if world == 1 and not a.no_cpu_baseline:
+            threads = a.cpu_threads or min(32, physical_cores())
+            torch.set_num_threads(threads)
+            oracle = LR.RNNModel(c['ntoken'], c['ninp'], c['nhid'], c['nlayers'], 0.0)
+            otasks = [LR.batchify(s_, c['batch_size']) for s_ in streams]
+            hid = oracle.init_hidden(c['batch_size'])
+            nb = min(n, 3)
+            batches = [LR.sample(otasks, i, 0, c['bptt'])[:2] for i in range(nb)]
+            vb = LR.sample(otasks, -1, 0, c['bptt'])[2:]
+            LR.meta_step(oracle, hid, batches[:1], vb, c['lr'], c['meta_lr_factor'], c['clip'], c['ratio'])     # warm-up
+            t0 = time.perf_counter()
+            LR.meta_step(oracle, hid, batches, vb, c['lr'], c['meta_lr_factor'], c['clip'], c['ratio'])
+            tc = time.perf_counter() - t0
+            out['cpu_baseline'] = dict(value=1.0 / (tc * n / nb), unit='meta-steps/s', cores=threads, kind='port',
+                                       sample='%d of %d tasks of one meta-iteration timed after a 1-task warm-up (%.2f s), scaled x%d/%d'
+                                              % (nb, n, tc, n, nb))
+        print(json.dumps(out), flush=True)
+    mdist.barrier()
+
+
 def physical_cores():
     try:
         import psutil
@@ -295,6 +397,7 @@ def main():
     ap.add_argument('--cpu-threads', type=int, default=0)
     ap.add_argument('--no-extras', action='store_true', help='only the headline timed region + the serial roofline step')
     ap.add_argument('--serial', action='store_true', help='no task lanes / side stream / replay (for rocprofv3 per-kernel durations)')
+    ap.add_argument('--workload', default='asr', choices=['asr', 'lm'], help="'lm': the LSTM-LM meta loop (BASELINE.json configs[4], SURVEY 8(f) f3)")
     a = ap.parse_args()
 
     with contextlib.redirect_stdout(io.StringIO()):          # the model factory prints; keep stdout to ONE JSON line
@@ -309,6 +412,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
 
+    if a.workload == 'lm':
+        return main_lm(a, mtl_amd, mdist, dev, rank, world)
     args = make_args(a.k)
     vocab = mtl_amd.synthetic_vocab(CFG['vocab_size'])
     torch.manual_seed(123456)

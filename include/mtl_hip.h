@@ -197,6 +197,18 @@ int mtl_sumsq(void* stream, const float* x, long n, float* out, float* workspace
  * partials: >= 256 doubles of scratch. */
 int mtl_spect_logmag(void* stream, const float* reim, int ld, int T, int F, float* out, double* partials, int normalize);
 
+/* ---- LSTM cell, one time step (lm/model/rnn_model.py:20 nn.LSTM; lm/main_meta_transfer.py:277-411) ----------
+ * gx = x_t . W_ih^T + b_ih and gh = h_{t-1} . W_hh^T + b_hh come from mtl_gemm_f32_ex (B x 4H each, torch gate order i|f|g|o).
+ * forward: acts = activated gates (saved), c = f*c_prev + i*g, h = o*tanh(c); h_drop (nullable) = h [* mask * mscale]: the
+ * copy that feeds the next layer (nn.LSTM's inter-layer dropout) / the decoder (self.drop).
+ * backward: dh = dh_up [* mask * mscale] + dh_rec (both nullable), dc = dc_next (nullable) + dh*o*(1-tanh(c)^2);
+ * dgates = pre-activation gradients (B x 4H), dc_prev = dc*f. */
+int mtl_lstm_cell_fwd(void* stream, const float* gx, const float* gh, const float* c_prev, float* acts, float* c, float* h,
+                      float* h_drop, const unsigned char* mask, float mscale, int B, int H);
+int mtl_lstm_cell_bwd(void* stream, const float* dh_up, const unsigned char* mask, float mscale, const float* dh_rec,
+                      const float* dc_next, const float* acts, const float* c, const float* c_prev, float* dgates, float* dc_prev,
+                      int B, int H);
+
 /* ---- raw byte helpers on a stream (so that a whole task body consists of library calls only and can be replayed) ---- */
 int mtl_memset_zero(void* stream, void* dst, long bytes);
 int mtl_memcpy_d2d(void* stream, void* dst, const void* src, long bytes);

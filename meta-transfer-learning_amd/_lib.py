@@ -57,6 +57,8 @@ SIGNATURES = {
     'mtl_adam_step': (I, [P, P, P, P, P, I, F, F, F, F, L]),
     'mtl_sumsq': (I, [P, P, L, P, P, I, F]),
     'mtl_spect_logmag': (I, [P, P, I, I, I, P, P, I]),
+    'mtl_lstm_cell_fwd': (I, [P, P, P, P, P, P, P, P, P, F, I, I]),
+    'mtl_lstm_cell_bwd': (I, [P, P, P, F, P, P, P, P, P, P, P, I, I]),
     'mtl_memset_zero': (I, [P, P, L]),
     'mtl_memcpy_d2d': (I, [P, P, P, L]),
     'mtl_event_record': (I, [P, P]),

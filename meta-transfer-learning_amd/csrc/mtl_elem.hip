@@ -639,9 +639,75 @@ __global__ void spect_normalize_kernel(float* __restrict__ x, long n, const doub
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) x[e] = (x[e] - m) * inv;
 }
 
+// ------------------------------------------------------------------ LSTM cell (lm/model/rnn_model.py:20 nn.LSTM), one time step
+// gates = gx + gh (both B x 4H, biases already added by the two GEMMs), torch order [i | f | g | o]:
+//   i, f, o = sigmoid, g = tanh;  c = f * c_prev + i * g;  h = o * tanh(c)   (+ optional dropped copy of h for the next layer)
+__global__ __launch_bounds__(256) void lstm_cell_fwd_kernel(const float* __restrict__ gx, const float* __restrict__ gh,
+                                                            const float* __restrict__ c_prev, float* __restrict__ acts,
+                                                            float* __restrict__ c, float* __restrict__ h, float* __restrict__ h_drop,
+                                                            const uint8_t* __restrict__ mask, float mscale, int B, int H) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= B * H) return;
+    const int b = e / H, j = e - b * H;
+    const long base = (long)b * 4 * H + j;
+    const float pi = gx[base] + gh[base], pf = gx[base + H] + gh[base + H], pg = gx[base + 2 * H] + gh[base + 2 * H],
+                po = gx[base + 3 * H] + gh[base + 3 * H];
+    const float ai = 1.f / (1.f + expf(-pi)), af = 1.f / (1.f + expf(-pf)), ag = tanhf(pg), ao = 1.f / (1.f + expf(-po));
+    const float cn = af * c_prev[e] + ai * ag;
+    const float hn = ao * tanhf(cn);
+    acts[base] = ai;
+    acts[base + H] = af;
+    acts[base + 2 * H] = ag;
+    acts[base + 3 * H] = ao;
+    c[e] = cn;
+    h[e] = hn;
+    if (h_drop) h_drop[e] = mask ? (mask[e] ? hn * mscale : 0.f) : hn;
+}
+// dh_total = dh_up [* mask * mscale] + dh_rec ; do = dh_total * tanh(c) ; dc = dc_next + dh_total * o * (1 - tanh(c)^2)
+// di = dc * g ; df = dc * c_prev ; dg = dc * i ; dc_prev = dc * f ; pre-activation gradients through sigmoid' / tanh'
+__global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(const float* __restrict__ dh_up, const uint8_t* __restrict__ mask,
+                                                            float mscale, const float* __restrict__ dh_rec,
+                                                            const float* __restrict__ dc_next, const float* __restrict__ acts,
+                                                            const float* __restrict__ c, const float* __restrict__ c_prev,
+                                                            float* __restrict__ dgates, float* __restrict__ dc_prev, int B, int H) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= B * H) return;
+    const int b = e / H, j = e - b * H;
+    const long base = (long)b * 4 * H + j;
+    float dh = dh_up ? (mask ? (mask[e] ? dh_up[e] * mscale : 0.f) : dh_up[e]) : 0.f;
+    if (dh_rec) dh += dh_rec[e];
+    const float ai = acts[base], af = acts[base + H], ag = acts[base + 2 * H], ao = acts[base + 3 * H];
+    const float tc = tanhf(c[e]);
+    const float dc = (dc_next ? dc_next[e] : 0.f) + dh * ao * (1.f - tc * tc);
+    dgates[base] = dc * ag * ai * (1.f - ai);
+    dgates[base + H] = dc * c_prev[e] * af * (1.f - af);
+    dgates[base + 2 * H] = dc * ai * (1.f - ag * ag);
+    dgates[base + 3 * H] = dh * tc * ao * (1.f - ao);
+    dc_prev[e] = dc * af;
+}
+
 }  // namespace
 
 extern "C" {
+
+int mtl_lstm_cell_fwd(void* stream, const float* gx, const float* gh, const float* c_prev, float* acts, float* c, float* h,
+                      float* h_drop, const unsigned char* mask, float mscale, int B, int H) {
+    if (!gx || !gh || !c_prev || !acts || !c || !h || B <= 0 || H <= 0) return MTL_EINVAL;
+    hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3((B * H + 255) / 256), dim3(256), 0, as_stream(stream), gx, gh, c_prev, acts, c, h,
+                       h_drop, mask, mscale, B, H);
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}
+
+int mtl_lstm_cell_bwd(void* stream, const float* dh_up, const unsigned char* mask, float mscale, const float* dh_rec,
+                      const float* dc_next, const float* acts, const float* c, const float* c_prev, float* dgates, float* dc_prev,
+                      int B, int H) {
+    if (!acts || !c || !c_prev || !dgates || !dc_prev || B <= 0 || H <= 0) return MTL_EINVAL;
+    hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3((B * H + 255) / 256), dim3(256), 0, as_stream(stream), dh_up, mask, mscale, dh_rec,
+                       dc_next, acts, c, c_prev, dgates, dc_prev, B, H);
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}
 
 int mtl_spect_logmag(void* stream, const float* reim, int ld, int T, int F, float* out, double* partials, int normalize) {
     if (!reim || !out || !partials || T <= 0 || F <= 0 || ld < 2 * F) return MTL_EINVAL;

@@ -373,18 +373,68 @@ def run_greedy_fixture(torch):
         print('   ', repr(st))
 
 
+def run_lm_fixture(torch):
+    """what CAN be pinned of the LM meta-transfer path (its loop raises on torch >= 2, see oracle/lm_refimpl.py):
+    the real `lm/model/rnn_model.py:RNNModel` (LSTM, 2 layers) -- initialisation hash, logits / loss / gradients / new hidden
+    state of one batch at dropout 0 -- and the real `lm/util/data.py:LMDataset` batchify / sample on a seeded token stream."""
+    for name in [m for m in list(sys.modules) if m == 'utils' or m.startswith('utils.') or m == 'models' or m.startswith('models.')]:
+        del sys.modules[name]                                        # the ASR tree's `utils` would shadow lm/util? (different names; be safe)
+    sys.path.insert(0, '/root/reference/lm')
+    from model.rnn_model import RNNModel
+    import util.data as ldata
+    sys.path.insert(0, ROOT)
+    from oracle.lm_refimpl import synth_corpus
+    spec = dict(ntoken=300, ninp=48, nhid=48, nlayers=2, bptt=7, batch_size=4, seed=1111, corpus_seeds=[5, 6, 7], corpus_len=403, it=9)
+    torch.manual_seed(spec['seed'])
+    torch.set_num_threads(8)
+    model = RNNModel('LSTM', spec['ntoken'], spec['ninp'], spec['nhid'], spec['nlayers'], 0.0, False)
+    model.train()
+    names = [n for n, _ in model.named_parameters()]
+    h = hashlib.sha256()
+    for _, p in model.named_parameters():
+        h.update(p.detach().numpy().tobytes())
+    args = argparse.Namespace(bptt=spec['bptt'], batch_size=spec['batch_size'], cuda=False)
+    streams = [synth_corpus(s_, spec['ntoken'], spec['corpus_len']) for s_ in spec['corpus_seeds']]
+    ds = ldata.LMDataset(streams, args)
+    store = {'spec': np.frombuffer(json.dumps(spec).encode(), dtype=np.uint8), 'param_names': np.array(names),
+             'theta0_sha256': np.frombuffer(h.hexdigest().encode(), dtype=np.uint8)}
+    for m in range(3):
+        store['batchified/%d' % m] = ds.task_list[m].numpy()
+        for it in (0, spec['it'], 57):
+            tr_x, tr_y, va_x, va_y = ds.sample(m if m < 2 else -1, it)
+            for k_, v in (('tr_x', tr_x), ('tr_y', tr_y), ('va_x', va_x), ('va_y', va_y)):
+                store['sample/%d/%d/%s' % (m, it, k_)] = v.numpy()
+    x, y, _, _ = ds.sample(0, spec['it'])
+    hidden = model.init_hidden(spec['batch_size'])
+    g = torch.Generator().manual_seed(3)
+    hidden = tuple(0.1 * torch.randn(t.shape, generator=g) for t in hidden)          # a non-trivial carried state
+    out, hn = model(x, hidden)
+    loss = torch.nn.CrossEntropyLoss()(out.view(-1, spec['ntoken']), y)
+    loss.backward()
+    store['h0'], store['c0'] = hidden[0].numpy(), hidden[1].numpy()
+    store['out'] = out.detach().numpy()
+    store['hn'], store['cn'] = hn[0].detach().numpy(), hn[1].detach().numpy()
+    store['loss'] = np.float64(float(loss))
+    for n_, p in model.named_parameters():
+        store['grad/' + n_] = p.grad.numpy()
+    np.savez_compressed(os.path.join(ROOT, 'tests', 'golden', 'L0.npz'), **store)
+    print('L0 written: loss %.6f, %d parameters' % (float(loss), len(names)))
+
+
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--ns', action='store_true')
     ap.add_argument('--only', default='')
     a = ap.parse_args()
     torch = bootstrap_reference()
-    todo = [a.only] if a.only else (['F0', 'F1', 'J0', 'B0', 'G0'] + (['NS'] if a.ns else []))
+    todo = [a.only] if a.only else (['F0', 'F1', 'J0', 'B0', 'G0'] + (['NS'] if a.ns else []) + ['L0'])
     for name in todo:
         if name == 'B0':
             run_beam_fixture(torch)
         elif name == 'G0':
             run_greedy_fixture(torch)
+        elif name == 'L0':
+            run_lm_fixture(torch)
         elif name == 'J0':
             run_joint_fixture(torch)
         else:
