@@ -119,6 +119,9 @@ def _conv_layer(cin, cout):
     return {(64, 64): 2, (64, 128): 5, (128, 128): 7}.get((cin, cout), 0)
 
 
+GROUP_FLOPS = {}     # table address -> FLOPs of a grouped weight-gradient launch (filled from the engines before classification)
+
+
 def classify(lib, name, a, conv_x3, wgrad_x3_dense):
     """(class, algorithmic work, 'flop' | 'byte' | None, rocprofv3 kernel symbol(s)) of one library call; `a` = its arguments in
     the order of include/mtl_hip.h.  FLOPs are 2 x MACs of the dense extent of the reference op; bytes are the tensors the op
@@ -129,6 +132,8 @@ def classify(lib, name, a, conv_x3, wgrad_x3_dense):
         small = name == 'mtl_gemm_f32_ex' and lib.mtl_gemm_f32_ex_route(M, N, K, batch, kb, 1 if rs else 0)
         return ('gemm_small' if small else 'gemm_big', 2.0 * M * N * K * batch * kb, 'flop',
                 'gemm16_kernel<...>' if small else 'gemm_kernel<...> (+ splitk_reduce_kernel)')
+    if name == 'mtl_gemm_wgrad_grouped':
+        return 'gemm_wgrad_grouped', GROUP_FLOPS.get(int(a[1] or 0)), 'flop', 'gemm16_kernel<true,false,true,4,1,1> (grouped)'
     if name.startswith('mtl_conv3x3_') and 'wprep' not in name:
         B, T, F, cin, cout = a[-5:]
         kind = 'wgrad' if 'wgrad' in name else ('dgrad' if 'dgrad' in name else ('fwd_pool' if 'pool' in name else 'fwd'))
@@ -217,6 +222,8 @@ def serial_profile(mtl, trainer, model, vocab, tasks, my_tasks, n_tasks, inner, 
         e.lib, e.use_side_stream, e.prof = lib_, side, None
     model.n_lanes = lanes
     eng = model.engine
+    for e in model.engines:
+        GROUP_FLOPS.update(e.wgrad_flops)
     classes = {}
     for name, a, e0, e1 in prof.records:
         cls, work, unit, sym = classify(mtl._lib.lib(), name, a, eng.conv_x3, eng.wgrad_x3_dense)
@@ -461,7 +468,8 @@ def main():
                         selection='kernel class with the largest accumulated time over ALL library launches of a serial meta-step',
                         timing='HIP events on the launch stream around every library call, serial step after the timed region '
                                '(task lanes, side stream and command-list replay off)',
-                        arithmetic={'gemm_small': 'exact fp32: v_mfma_f32_16x16x4_f32', 'gemm_big': 'exact fp32: v_mfma_f32_32x32x2_f32'}.get(
+                        arithmetic={'gemm_small': 'exact fp32: v_mfma_f32_16x16x4_f32', 'gemm_wgrad_grouped': 'exact fp32: v_mfma_f32_16x16x4_f32',
+                                    'gemm_big': 'exact fp32: v_mfma_f32_32x32x2_f32'}.get(
                             dom, 'split-bf16 x3: 6 v_mfma_f32_32x32x16_bf16 per fp32-equivalent step, peak = dense bf16 / 6'
                             if dr['peak'] == PEAK_X3_TFLOPS else ('exact fp32 MFMA' if dr['bound'] == 'mfma' else 'HBM streaming')),
                         serial_step=dict(launches_per_pass=n_launch / passes, gpu_ms_per_pass=sum(c['time'] for c in classes.values()) / passes * 1e3,

@@ -19,6 +19,7 @@ SIGNATURES = {
     'mtl_gemm_f32': (I, [P, I, I, I, I, I, F, P, I, P, I, P, I, P, P, I, I, I, I, L, L, L, L, L, L, L, P, L]),
     'mtl_gemm_f32_ex': (I, [P, I, I, I, I, I, F, P, I, P, I, P, I, P, P, I, I, I, I, L, L, L, L, L, L, L, I, L, L, P, L, P, L]),
     'mtl_gemm_f32_ex_route': (I, [I, I, I, I, I, I]),
+    'mtl_gemm_wgrad_grouped': (I, [P, P, I, I]),
     'mtl_conv0_relu_fwd': (I, [P, P, P, P, P, I, I, I]),
     'mtl_conv0_wgrad_workspace': (L, []),
     'mtl_conv0_wgrad': (I, [P, P, P, P, P, P, I, I, I]),
@@ -98,6 +99,12 @@ def lib():
 # ---------------------------------------------------------------------------------------------------------------------
 # command lists (include/mtl_hip.h "command lists"): record the C calls of one eager run, replay them with ONE ctypes call
 # ---------------------------------------------------------------------------------------------------------------------
+class WgradDesc(ctypes.Structure):
+    """mtl_wgrad_desc of include/mtl_hip.h (64 bytes)"""
+    _fields_ = [('A', c_void_p), ('B', c_void_p), ('C', c_void_p), ('rowsum', c_void_p), ('M', c_int), ('N', c_int), ('K', c_int),
+                ('lda', c_int), ('ldb', c_int), ('ldc', c_int), ('tile0', c_int), ('reserved', c_int)]
+
+
 class _CmdArg(ctypes.Union):
     _fields_ = [('p', c_void_p), ('l', c_long), ('d', ctypes.c_double)]
 

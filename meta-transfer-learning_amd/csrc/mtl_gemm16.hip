@@ -46,6 +46,8 @@ struct G16P {
     int kb;
     long sAk, sBk, sRow;
     int total;       // workgroups = tiles in N x tiles in M x batch
+    const mtl_wgrad_desc* groups;   // grouped mode: one launch covers `ngroups` independent products (descriptor table in HBM)
+    int ngroups;
 };
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
@@ -115,7 +117,7 @@ struct Opnd {
 // Workgroup tile (32 WM) x (32 WN): 4 waves as 2 x 2, a wave owns WM x WN MFMA tiles (rows 16 (2 i + wm), cols 16 (2 j + wn)).
 // KG "K groups" of 4 waves each share the output tile: group kg takes the K tiles kg, kg + KG, ...
 template <bool TA, bool TB, bool VEC, int KG, int WM, int WN>
-__global__ __launch_bounds__(256 * KG) void gemm16_kernel(G16P p) {
+__global__ __launch_bounds__(256 * KG) void gemm16_kernel(G16P p0) {
     using OA = Opnd<!TA, VEC, 32 * WM>;          // op(A) is M x K: stored [m][k] unless transposed
     using OB = Opnd<TB, VEC, 32 * WN>;           // op(B) is K x N: stored [n][k] when transposed
     constexpr int TM = 32 * WM, TN = 32 * WN;
@@ -124,11 +126,25 @@ __global__ __launch_bounds__(256 * KG) void gemm16_kernel(G16P p) {
     const int kg = threadIdx.x >> 8, tid = threadIdx.x & 255;
     const int lane = tid & 63, w = tid >> 6, l16 = lane & 15, g = lane >> 4;
     const int wm = w >> 1, wn = w & 1;
-    const int nx = (p.N + TN - 1) / TN, ny = (p.M + TM - 1) / TM;
-    const int per = (p.total + 7) >> 3;
+    const int per = (p0.total + 7) >> 3;
     const int t = (blockIdx.x & 7) * per + (blockIdx.x >> 3);       // XCD-aware order (see the header)
-    if (t >= p.total) return;
-    const int z = t / (nx * ny), rem = t - z * (nx * ny);
+    if (t >= p0.total) return;
+    G16P p = p0;
+    int rem = t, z = 0;
+    if (p0.groups) {
+        // grouped mode (mtl_gemm_wgrad_grouped): find the product this tile belongs to (uniform scalar scan of the table)
+        int gi = 0;
+        while (gi + 1 < p0.ngroups && p0.groups[gi + 1].tile0 <= t) ++gi;
+        const mtl_wgrad_desc d = p0.groups[gi];
+        p.A = d.A, p.B = d.B, p.C = d.C, p.rowsum = d.rowsum;
+        p.M = d.M, p.N = d.N, p.K = d.K, p.lda = d.lda, p.ldb = d.ldb, p.ldc = d.ldc;
+        rem = t - d.tile0;
+    }
+    const int nx = (p.N + TN - 1) / TN, ny = (p.M + TM - 1) / TM;
+    if (!p0.groups) {
+        z = t / (nx * ny);
+        rem = t - z * (nx * ny);
+    }
     const int m0 = (rem / nx) * TM, n0 = (rem % nx) * TN;
     const int zb = z / p.H, zh = z - zb * p.H;
     const float* A = p.A + zb * p.sAb + zh * p.sAh;
@@ -351,6 +367,17 @@ int mtl_gemm_f32_ex_route(int M, int N, int K, int batch, int kbatch, int has_ro
     return route_small(M, N, K, batch, kbatch, has_rowsum != 0) ? 1 : 0;
 }
 
+/* see include/mtl_hip.h */
+int mtl_gemm_wgrad_grouped(void* stream, const mtl_wgrad_desc* table_dev, int n_products, int total_tiles) {
+    if (!table_dev || n_products <= 0 || total_tiles <= 0) return MTL_EINVAL;
+    G16P p{};
+    p.alpha = 1.f, p.flags = MTL_GEMM_ACCUM, p.H = 1, p.kb = 1, p.total = total_tiles, p.groups = table_dev, p.ngroups = n_products;
+    dim3 grid(((total_tiles + 7) / 8) * 8);
+    hipLaunchKernelGGL((gemm16_kernel<true, false, true, 4, 1, 1>), grid, dim3(1024), 0, as_stream(stream), p);
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}
+
 int mtl_gemm_f32_ex(void* stream, int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
                     const float* B, int ldb, float* C, int ldc, const float* bias, const float* gate, int ldg, int flags,
                     int batch, int H, long sAb, long sAh, long sBb, long sBh, long sCb, long sCh, long sBias, int kbatch, long sAk,
@@ -361,7 +388,7 @@ int mtl_gemm_f32_ex(void* stream, int transA, int transB, int M, int N, int K, f
         return mtl_gemm_f32(stream, transA, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, bias, gate, ldg, flags, batch, H, sAb,
                             sAh, sBb, sBh, sCb, sCh, sBias, workspace, workspace_bytes);
     G16P p{A, B, C, bias, gate, rowsum, M, N, K, lda, ldb, ldc, ldg, alpha, flags, H, sAb, sAh, sBb, sBh, sCb, sCh, sBias, kbatch,
-           sAk, sBk, sRowsum, 0};
+           sAk, sBk, sRowsum, 0, nullptr, 0};
     hipStream_t s = as_stream(stream);
     if (!transA && transB) return launch16<false, true>(p, batch, s);
     if (!transA && !transB) return launch16<false, false>(p, batch, s);

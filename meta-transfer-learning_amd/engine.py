@@ -210,6 +210,11 @@ class PassEngine:
         self.scratch_side = torch.empty(4 << 20, dtype=torch.float32, device=device) if device.type == 'cuda' else None
         self.on_side = False
         self.scratch_epoch = 0
+        # small weight-gradient products of a backward are collected and issued as ONE grouped launch (mtl_gemm_wgrad_grouped)
+        self.wgrads, self._wgrad_tables, self.wgrad_flops = [], {}, {}
+        # opt-in: measured SLOWER than per-block launches on the side stream (8.57 vs 9.36 meta-steps/s; one task per GPU 18.1 vs
+        # 16.0 ms): the grouped launch is as L2-bound as the single ones (19 TF, 32 x 32 tiles) and lands on top of the VGG backward
+        self.group_wgrads = os.environ.get('MTL_GROUP_WGRADS', '0') == '1'
         self._stage, self._stage_turn = {}, {}   # pinned host staging of prepare()
         self._events, self._ev_next = [], 0    # fork / join events of the side stream (raw handles: recordable library calls)
         self.dropout_p = 0.0          # set by the model: hp.dropout when model.training else 0
@@ -293,6 +298,42 @@ class PassEngine:
         self._ev_next = (self._ev_next + 1) % len(self._events)
         return ev.cuda_event
 
+    # ---- grouped weight gradients
+    def wgrad(self, dy, x, rows, n_out, k_in, dw, db=None):
+        """dw (n_out x k_in) += dy^T x ; db += colsum(dy).  Small products are only REGISTERED here and computed by one grouped launch
+        (flush_wgrads); the few large ones (vocabulary projection, FFN at encoder size ...) go to the side stream as single calls."""
+        if self.group_wgrads and self.lib.mtl_gemm_f32_ex_route(n_out, k_in, rows, 1, 1, 1 if db else 0):
+            self.wgrads.append((int(dy), int(x), int(dw), int(db or 0), n_out, k_in, rows, n_out, k_in, k_in))
+        else:
+            self.defer(lambda: self.gemm(1, 0, n_out, k_in, rows, dy, n_out, x, k_in, dw, k_in, flags=ACCUM, rowsum=db))
+
+    def flush_wgrads(self):
+        """issue the registered products (their operands are per-block buffers that stay intact until the end of the backward):
+        on the side stream behind everything the main stream has enqueued so far, so that they overlap the rest of the backward"""
+        if not self.wgrads:
+            return
+        descs, self.wgrads = tuple(self.wgrads), []
+        ent = self._wgrad_tables.get(descs)
+        if ent is None:
+            import numpy as np
+            dt = np.dtype([('A', 'u8'), ('B', 'u8'), ('C', 'u8'), ('rowsum', 'u8'), ('M', 'i4'), ('N', 'i4'), ('K', 'i4'), ('lda', 'i4'),
+                           ('ldb', 'i4'), ('ldc', 'i4'), ('tile0', 'i4'), ('reserved', 'i4')])
+            arr = np.zeros(len(descs), dtype=dt)
+            tiles = 0
+            for i, d in enumerate(descs):
+                arr[i] = d + (tiles, 0)
+                tiles += ((d[4] + 31) // 32) * ((d[5] + 31) // 32)
+            table = torch.from_numpy(arr.view(np.uint8).copy()).to(self.device)
+            ent = (table, tiles)
+            self._wgrad_tables[descs] = ent            # kept alive: recorded command lists hold the table's address
+            self.wgrad_flops[table.data_ptr()] = sum(2.0 * d[4] * d[5] * d[6] for d in descs)
+        table, tiles = ent
+
+        def launch():
+            check(self.lib.mtl_gemm_wgrad_grouped(self.stream, table.data_ptr(), len(descs), tiles), 'mtl_gemm_wgrad_grouped')
+        self.defer(launch)
+        self.flush_side()
+
     # ---- side stream: deferred parameter-gradient work
     def defer(self, fn):
         if self.use_side_stream:
@@ -318,6 +359,7 @@ class PassEngine:
                 self.on_side = False
 
     def join_side(self):
+        self.flush_wgrads()
         self.flush_side()
         if self.use_side_stream:
             ev = self._event()
@@ -330,9 +372,7 @@ class PassEngine:
     def linear_bwd(self, x, dy, rows, k_in, n_out, w, dw, db, dx, dx_accum, gate=None):
         """dw += dy^T x ; db += colsum(dy) (db None: no bias, or already produced by the LayerNorm backward) ;
         dx (=|+=) dy.W  (gate: ReLU mask source for dx)"""
-        def param_grads():        # db rides on the weight-gradient product (row sums of dy^T), no separate reduction launches
-            self.gemm(1, 0, n_out, k_in, rows, dy, n_out, x, k_in, dw, k_in, flags=ACCUM, rowsum=db)
-        self.defer(param_grads)
+        self.wgrad(dy, x, rows, n_out, k_in, dw, db)     # db rides on the weight-gradient product (row sums of dy^T)
         if dx is not None:
             self.gemm(0, 0, rows, k_in, n_out, dy, n_out, w, k_in, dx, k_in, gate=gate, ldg=k_in,
                       flags=ACCUM if dx_accum else 0)
@@ -488,20 +528,26 @@ class PassEngine:
             sa, sb, sbias = (self._pstride(pre, names, sfx) for sfx in ('_linear_a.weight', '_linear_b.weight', '_linear_b.bias'))
             a_ptr, d_ptr, da_ptr = a_all.data_ptr(), d_all.data_ptr(), da_all.data_ptr()
 
-            def grads_b(n=n, f0=f0, rows=rows, a_ptr=a_ptr, d_ptr=d_ptr, sb=sb, sbias=sbias, wd=wd):
-                # dW_b[i] += d[i]^T a[i]  and  db_b[i] += colsum(d[i])  in one strided-batch call (outputs strided into G)
-                self.gemm(1, 0, wd, r, rows, d_ptr, wd, a_ptr, r, g(f0 + '_linear_b.weight'), r, flags=ACCUM, batch=n,
-                          sA=(rows * wd, 0), sB=(rows * r, 0), sC=(sb, 0), rowsum=g(f0 + '_linear_b.bias'), srow=sbias)
-            self.defer(grads_b)
+            # dW_b[i] += d[i]^T a[i]  and  db_b[i] += colsum(d[i])
+            if self.group_wgrads:
+                for i, nm in enumerate(names):
+                    self.wgrad(d_ptr + 4 * i * rows * wd, a_ptr + 4 * i * rows * r, rows, wd, r, g(_FULL[nm] + '_linear_b.weight'),
+                               g(_FULL[nm] + '_linear_b.bias'))
+            else:       # one strided-batch call on the side stream (outputs strided into G)
+                self.defer(lambda n=n, f0=f0, rows=rows, a_ptr=a_ptr, d_ptr=d_ptr, sb=sb, sbias=sbias, wd=wd: self.gemm(
+                    1, 0, wd, r, rows, d_ptr, wd, a_ptr, r, g(f0 + '_linear_b.weight'), r, flags=ACCUM, batch=n, sA=(rows * wd, 0),
+                    sB=(rows * r, 0), sC=(sb, 0), rowsum=g(f0 + '_linear_b.bias'), srow=sbias))
             # da[i] = d[i] . W_b[i]
             self.gemm(0, 0, rows, r, wd, d_ptr, wd, o(f0 + '_linear_b.weight'), r, da_ptr, r, batch=n, sA=(rows * wd, 0),
                       sB=(sb, 0), sC=(rows * r, 0))
 
-            def grads_a(n=n, f0=f0, rows=rows, da_ptr=da_ptr, src=src, sa=sa):
-                # dW_a[i] += da[i]^T x
-                self.gemm(1, 0, r, d, rows, da_ptr, r, src, d, g(f0 + '_linear_a.weight'), d, flags=ACCUM, batch=n,
-                          sA=(rows * r, 0), sC=(sa, 0))
-            self.defer(grads_a)
+            # dW_a[i] += da[i]^T x
+            if self.group_wgrads:
+                for i, nm in enumerate(names):
+                    self.wgrad(da_ptr + 4 * i * rows * r, src, rows, r, d, g(_FULL[nm] + '_linear_a.weight'))
+            else:
+                self.defer(lambda n=n, f0=f0, rows=rows, da_ptr=da_ptr, src=src, sa=sa: self.gemm(
+                    1, 0, r, d, rows, da_ptr, r, src, d, g(f0 + '_linear_a.weight'), d, flags=ACCUM, batch=n, sA=(rows * r, 0), sC=(sa, 0)))
             # dx (+)= sum_i da[i] . W_a[i]: the items of a group accumulate into ONE tensor -> one K-batched launch
             if names[0] == 'q':
                 dst, accum = dxq, True
@@ -854,7 +900,7 @@ class PassEngine:
         last = S['dec_last']
         # vocab projection (no bias)
         self.defer(lambda: self.gemm(1, 0, V, d, Md, dlog_ptr, ldd, last.data_ptr(), d, g('decoder.output_linear.weight'), d,
-                                     flags=ACCUM))
+                                     flags=ACCUM))                     # (lda = ldd != V: stays a single call)
         self.gemm(0, 0, Md, d, V, dlog_ptr, ldd, o('decoder.output_linear.weight'), d, dA.data_ptr(), d)
         self.flush_side()
         dcur, dnext = dA, dB
@@ -901,6 +947,7 @@ class PassEngine:
         self.gemm(0, 0, Me, hp.d_in, d, de0.data_ptr(), d, A['wp_in'].data_ptr(), hp.d_in, dp2.data_ptr(), hp.d_in,
                   gate=p2.data_ptr(), ldg=hp.d_in)
 
+        self.flush_wgrads()        # every small dW of the transformer half: one grouped launch, overlapping the VGG backward
         # ---- VGG front-end ----
         conv_dgrad = lib.mtl_conv3x3_dgrad_x3 if self.conv_x3 else lib.mtl_conv3x3_dgrad
 
