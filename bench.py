@@ -38,6 +38,8 @@ PEAK_BF16_MFMA_TFLOPS = 2516.6    # v_mfma_f32_32x32x16_bf16, dense
 # the split-bf16 ("x3") convolution kernels issue SIX bf16 MFMAs per fp32-equivalent multiply-accumulate step, so the roof of
 # their ALGORITHMIC (fp32-equivalent) FLOP rate is the dense bf16 peak / 6
 PEAK_X3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
+# the two-piece fp16 ("h2") kernels issue THREE v_mfma_f32_32x32x16_f16 (same dense rate as bf16) per fp32-equivalent step
+PEAK_H2_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 3.0
 PEAK_HBM_GBS = 8000.0             # HBM3E spec (6.3 TB/s measured achievable)
 
 
@@ -78,7 +80,7 @@ def make_args(k, lr=1e-4, meta_lr=1e-4):
 # ------------------------------------------------------------------------------------------------------------------
 # launch-level profiling: every library call that launches kernels, bracketed with HIP events on the stream it is given
 # ------------------------------------------------------------------------------------------------------------------
-_NOT_LAUNCHES = {'mtl_event_record', 'mtl_stream_wait_event', 'mtl_cmdlist_run', 'mtl_cmdlist_opcode', 'mtl_abi_version',
+_NOT_LAUNCHES = {'mtl_lowrank_supported', 'mtl_event_record', 'mtl_stream_wait_event', 'mtl_cmdlist_run', 'mtl_cmdlist_opcode', 'mtl_abi_version',
                  'mtl_attn_supported', 'mtl_gemm_f32_ex_route', 'mtl_levenshtein_u32'}
 
 
@@ -100,7 +102,7 @@ class LaunchProfiler:
         fn = self._cache.get(name)
         if fn is None:
             real = getattr(self._h, name)
-            if name in _NOT_LAUNCHES or name.endswith('_workspace'):
+            if name in _NOT_LAUNCHES or name.endswith('_workspace') or name.endswith('_bytes'):
                 fn = real
             else:
                 def fn(*args, _real=real, _name=name):
@@ -122,7 +124,7 @@ def _conv_layer(cin, cout):
 GROUP_FLOPS = {}     # table address -> FLOPs of a grouped weight-gradient launch (filled from the engines before classification)
 
 
-def classify(lib, name, a, conv_x3, wgrad_x3_dense):
+def classify(lib, name, a, conv_mode, wgrad_x3_dense):
     """(class, algorithmic work, 'flop' | 'byte' | None, rocprofv3 kernel symbol(s)) of one library call; `a` = its arguments in
     the order of include/mtl_hip.h.  FLOPs are 2 x MACs of the dense extent of the reference op; bytes are the tensors the op
     must read and write once."""
@@ -132,16 +134,21 @@ def classify(lib, name, a, conv_x3, wgrad_x3_dense):
         small = name == 'mtl_gemm_f32_ex' and lib.mtl_gemm_f32_ex_route(M, N, K, batch, kb, 1 if rs else 0)
         return ('gemm_small' if small else 'gemm_big', 2.0 * M * N * K * batch * kb, 'flop',
                 'gemm16_kernel<...>' if small else 'gemm_kernel<...> (+ splitk_reduce_kernel)')
+    if name == 'mtl_lowrank_pair':
+        M, Kin, r, N, n = a[15], a[16], a[17], a[18], a[19]
+        return 'lowrank_pair', 2.0 * M * r * (Kin + N) * n, 'flop', 'lowrank_pair_kernel<RT,SUM>'
     if name == 'mtl_gemm_wgrad_grouped':
         return 'gemm_wgrad_grouped', GROUP_FLOPS.get(int(a[1] or 0)), 'flop', 'gemm16_kernel<true,false,true,4,1,1> (grouped)'
     if name.startswith('mtl_conv3x3_') and 'wprep' not in name:
         B, T, F, cin, cout = a[-5:]
         kind = 'wgrad' if 'wgrad' in name else ('dgrad' if 'dgrad' in name else ('fwd_pool' if 'pool' in name else 'fwd'))
-        sym = ('conv3x3_wgrad_x3_kernel' if kind == 'wgrad' else 'conv3x3_x3h_kernel') if name.endswith('_x3') else \
-              ('conv3x3_wgrad_kernel' if kind == 'wgrad' else 'conv3x3_kernel')
+        if name.endswith('_x3') or name.endswith('_h2'):
+            sym = ('conv3x3_wgrad_x3_kernel<.,%d>' if kind == 'wgrad' else 'conv3x3_x3h_kernel<...,%d>') % (2 if name.endswith('_h2') else 3)
+        else:
+            sym = 'conv3x3_wgrad_kernel' if kind == 'wgrad' else 'conv3x3_kernel'
         return ('conv%d_%s' % (_conv_layer(cin, cout), kind), 2.0 * B * T * F * 9 * cin * cout, 'flop', sym)
     if name == 'mtl_conv0_relu_fwd':
-        B, T, F = a[-3:]
+        B, T, F = a[-4:-1]
         return 'conv0_fwd', 4.0 * B * T * F * (1 + 64), 'byte', 'conv0_fwd_kernel'
     if name == 'mtl_conv0_wgrad':
         B, T, F = a[-3:]
@@ -179,11 +186,11 @@ def classify(lib, name, a, conv_x3, wgrad_x3_dense):
     return name[4:], None, None, name[4:] + '_kernel'
 
 
-def peak_of(cls, unit, conv_x3, wgrad_x3_dense):
+def peak_of(cls, unit, conv_mode, wgrad_x3_dense):
     if unit == 'byte':
         return PEAK_HBM_GBS, 'GB/s', 'hbm'
-    if cls.startswith('conv') and conv_x3 and not (cls == 'conv5_wgrad' and not wgrad_x3_dense):
-        return PEAK_X3_TFLOPS, 'TFLOP/s', 'mfma'
+    if cls.startswith('conv') and conv_mode != 'f32' and not (cls == 'conv5_wgrad' and not wgrad_x3_dense):
+        return (PEAK_H2_TFLOPS if conv_mode == 'h2' else PEAK_X3_TFLOPS), 'TFLOP/s', 'mfma'
     return PEAK_F32_MFMA_TFLOPS, 'TFLOP/s', 'mfma'
 
 
@@ -226,12 +233,33 @@ def serial_profile(mtl, trainer, model, vocab, tasks, my_tasks, n_tasks, inner, 
         GROUP_FLOPS.update(e.wgrad_flops)
     classes = {}
     for name, a, e0, e1 in prof.records:
-        cls, work, unit, sym = classify(mtl._lib.lib(), name, a, eng.conv_x3, eng.wgrad_x3_dense)
+        cls, work, unit, sym = classify(mtl._lib.lib(), name, a, eng.conv_mode, eng.wgrad_x3_dense)
         c = classes.setdefault(cls, dict(time=0.0, work=0.0, unit=unit, launches=0, symbols=sym))
         c['time'] += e0.elapsed_time(e1) * 1e-3
         c['work'] += work or 0.0
         c['launches'] += 1
+    dump = os.environ.get('MTL_BENCH_SHAPES')
+    if dump:            # diagnostics: per-shape time of the product launches of the profiled step
+        shapes = {}
+        for name, a, e0, e1 in prof.records:
+            if name == 'mtl_gemm_f32_ex':
+                key = 'gemm ta%d tb%d M%d N%d K%d b%d kb%d rs%d' % (a[1], a[2], a[3], a[4], a[5], a[17], a[26], 1 if a[29] else 0)
+            elif name == 'mtl_lowrank_pair':
+                key = 'pair M%d Kin%d r%d N%d n%d sum%d acc%d' % tuple(a[15:22])
+            elif name in ('mtl_attn_fwd', 'mtl_attn_bwd', 'mtl_layernorm_fwd', 'mtl_layernorm_bwd'):
+                key = name + ' ' + ' '.join(str(v) for v in a if isinstance(v, int) and 0 <= v < 100000)
+            else:
+                continue
+            t = shapes.setdefault(key, [0, 0.0])
+            t[0] += 1
+            t[1] += e0.elapsed_time(e1) * 1e3
+        with open(dump, 'w') as f:
+            for key, (cnt, us) in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
+                f.write('%8.1f us total  %3d x %6.1f us   %s\n' % (us, cnt, us / cnt, key))
     return classes, len(prof.records), wall
+
+
+HOST_ENQUEUE = {}
 
 
 def timed_steps(trainer, model, vocab, tasks, my_tasks, n_tasks, inner, outer, args, steps, warmup, mdist, dev):
@@ -245,8 +273,11 @@ def timed_steps(trainer, model, vocab, tasks, my_tasks, n_tasks, inner, outer, a
     mdist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
+    host = 0.0
     for _ in range(steps):
         last = one()
+        host += getattr(trainer, 'host_enqueue_s', 0.0)
+    HOST_ENQUEUE['ms_per_step'] = host / steps * 1e3     # host time to enqueue a step (the rest of the span it waits for the GPU)
     torch.cuda.synchronize(dev)
     mdist.barrier()
     dt = time.perf_counter() - t0
@@ -455,7 +486,7 @@ def main():
         for cls, c in sorted(classes.items(), key=lambda kv: -kv[1]['time']):
             row = dict(ms_per_pass=c['time'] / passes * 1e3, launches_per_pass=c['launches'] / passes, symbols=c['symbols'])
             if c['unit'] is not None and c['work'] > 0:
-                peak, unit, bound = peak_of(cls, c['unit'], eng.conv_x3, eng.wgrad_x3_dense)
+                peak, unit, bound = peak_of(cls, c['unit'], eng.conv_mode, eng.wgrad_x3_dense)
                 ach = c['work'] / c['time'] / (1e12 if c['unit'] == 'flop' else 1e9)
                 row.update(bound=bound, achieved=ach, peak=peak, unit=unit, frac=ach / peak)
             table[cls] = row
@@ -471,7 +502,9 @@ def main():
                         arithmetic={'gemm_small': 'exact fp32: v_mfma_f32_16x16x4_f32', 'gemm_wgrad_grouped': 'exact fp32: v_mfma_f32_16x16x4_f32',
                                     'gemm_big': 'exact fp32: v_mfma_f32_32x32x2_f32'}.get(
                             dom, 'split-bf16 x3: 6 v_mfma_f32_32x32x16_bf16 per fp32-equivalent step, peak = dense bf16 / 6'
-                            if dr['peak'] == PEAK_X3_TFLOPS else ('exact fp32 MFMA' if dr['bound'] == 'mfma' else 'HBM streaming')),
+                            if dr['peak'] == PEAK_X3_TFLOPS else (
+                                'two fp16 pieces: 3 v_mfma_f32_32x32x16_f16 per fp32-equivalent step, peak = dense fp16 / 3'
+                                if dr['peak'] == PEAK_H2_TFLOPS else ('exact fp32 MFMA' if dr['bound'] == 'mfma' else 'HBM streaming'))),
                         serial_step=dict(launches_per_pass=n_launch / passes, gpu_ms_per_pass=sum(c['time'] for c in classes.values()) / passes * 1e3,
                                          gpu_span_ms_per_pass=serial_wall / passes * 1e3),
                         per_class=table)
@@ -485,10 +518,13 @@ def main():
                                collective=mdist.backend_name(), inputs='resident in HBM before the timed region',
                                schedule='serial' if a.serial else '%d task lanes + side stream, command-list replay %s'
                                         % (model.n_lanes, 'on' if trainer.use_cmdlists else 'off'),
-                               conv_arithmetic=('3x3 convolutions as exact 3-way bf16 splits of fp32 operands, fp32 accumulate '
-                                                '(fp32-class error, same test tolerances as the fp32-MFMA kernels)'
-                                                if model.engine.conv_x3 else 'fp32 MFMA')),
-                   roofline=roofline, last_step=dict(val_loss=last[0] / a.tasks, cer_edits=last[1], chars=last[2]))
+                               conv_arithmetic={'h2': '3x3 convolutions on 2-way fp16 splits of power-of-two-scaled fp32 operands (22 '
+                                                      'significand bits, 3 fp16 MFMAs per step), fp32 accumulate: error <= 2.5x that of an '
+                                                      'fp32 convolution against fp64 (tests/test_ops_gpu.py), parity bar unchanged',
+                                                'x3': '3x3 convolutions as exact 3-way bf16 splits of fp32 operands, fp32 accumulate '
+                                                      '(fp32-class error, same test tolerances as the fp32-MFMA kernels)',
+                                                'f32': 'fp32 MFMA'}[model.engine.conv_mode]),
+                   roofline=roofline, host_enqueue_ms_per_step=HOST_ENQUEUE.get('ms_per_step'), last_step=dict(val_loss=last[0] / a.tasks, cer_edits=last[1], chars=last[2]))
 
     extras = world == 1 and not a.no_extras
     if extras:

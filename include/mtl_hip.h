@@ -78,10 +78,29 @@ typedef struct mtl_wgrad_desc {
 } mtl_wgrad_desc;
 int mtl_gemm_wgrad_grouped(void* stream, const mtl_wgrad_desc* table_dev, int n_products, int total_tiles);
 
+/* ---- fused low-rank pair: y_z = (x_z . A_z^T) . B_z^T (+ bias_z), z = 0..n-1 (modules/common_layers.py:287-289,303: W_b(W_a x)) ---
+ * x_z = x + z*sx (M x Kin, ldx); A_z = A + z*sA (r x Kin, row-major); B_z = B + z*sB (N x r, row-major); bias_z = bias + z*sbias
+ * (nullable); t_z = t + z*st (M x r, nullable): the intermediate, stored once for the weight gradient; y_z = y + z*sy (M x N, ldy).
+ * sum_over_z: ONE output y (+)= sum_z (x_z . A_z^T) . B_z^T (n <= 3; accum adds to the existing y) -- the backward data path
+ * dx = sum_z (dy_z . W_b,z) . W_a,z of the Q / K / V projections when A / B point at TRANSPOSED weight copies (mtl_transpose_batch).
+ * r <= 104, r % 4 == 0, Kin % 4 == 0 (mtl_lowrank_supported); x / A / B 16-byte aligned.  The M x r intermediate stays in LDS. */
+int mtl_lowrank_supported(int Kin, int r, int N);
+int mtl_lowrank_pair(void* stream, const float* x, long sx, int ldx, const float* A, long sA, const float* B, long sB,
+                     const float* bias, long sbias, float* t, long st, float* y, long sy, int ldy, int M, int Kin, int r, int N,
+                     int n, int sum_over_z, int accum);
+/* dst_i (cols x rows) = src_i (rows x cols)^T for a DEVICE table of n matrices in one launch */
+typedef struct mtl_transpose_desc {
+    const float* src;
+    float* dst;
+    int rows, cols;
+} mtl_transpose_desc;
+int mtl_transpose_batch(void* stream, const mtl_transpose_desc* table_dev, int n);
+
 /* ---- VGG front-end: models/asr/transformer.py:48-59 (Conv2d 3x3 s1 p1 + ReLU [+ MaxPool2d(2,2)]) ------
  * x_ref is the reference's (B,1,F,T) input; everything downstream is (B,T,F,C). */
+/* amax_y (optional): device scalar, atomically raised to max(y) -- the `amax_x` of a following *_h2 convolution; zero it first. */
 int mtl_conv0_relu_fwd(void* stream, const float* x_ref, const float* w /*(64,1,3,3)*/, const float* bias, float* y,
-                       int B, int T, int F);
+                       int B, int T, int F, float* amax_y);
 long mtl_conv0_wgrad_workspace(void);
 int mtl_conv0_wgrad(void* stream, const float* x_ref, const float* dy, float* dw /*accum*/, float* db /*accum*/,
                     float* workspace, int B, int T, int F);
@@ -109,6 +128,24 @@ int mtl_conv3x3_relu_pool_fwd_x3(void* stream, const float* x, const void* w3_fw
                                  unsigned char* argmax, int B, int T, int F, int Cin, int Cout);
 int mtl_conv3x3_dgrad_x3(void* stream, const float* dy, const unsigned char* argmax, const void* w3_dgrad, const float* act,
                          float* dx, int B, int T, int F, int Cin, int Cout);
+/* Two-piece fp16 ("h2") variants: the same calls on 2-way fp16 splits of both operands -- three v_mfma_f32_32x32x16_f16 per
+ * 16-deep step (half the matrix work of x3, twice its roof), fp32 accumulation, error ~1.5x that of an fp32 convolution
+ * (h l' + l h' + h h' keeps 22 significand bits).  fp16 has 5 exponent bits, so every operand tensor comes with a DEVICE
+ * SCALAR `amax_*` >= max|tensor| (an upper bound within a few powers of two is as good): the kernels scale by the power of two
+ * that puts amax into [2^14, 2^15) before splitting and un-scale the accumulators exactly.  Producers deliver the scalars for
+ * free: `amax_y` / `amax_p` / `amax_dx` (optional outputs, atomically raised; zero them first), mtl_conv0_relu_fwd's amax_y,
+ * mtl_colsum_accum's amax (the bias-gradient pass reads the whole gradient anyway), or mtl_absmax_f32.
+ * w2_fwd / w2_dgrad: mtl_conv3x3_wprep_h2_bytes() each: [2][K-tile][rows][32] fp16 in the x3 layout + the fp32 weight scale. */
+long mtl_conv3x3_wprep_h2_bytes(int Cout, int Cin);
+int mtl_conv3x3_wprep_h2(void* stream, const float* w_ref, void* w2_fwd, void* w2_dgrad, int Cout, int Cin);
+int mtl_conv3x3_relu_fwd_h2(void* stream, const float* x, const float* amax_x, const void* w2_fwd, const float* bias, float* y,
+                            float* amax_y, int B, int T, int F, int Cin, int Cout);
+int mtl_conv3x3_relu_pool_fwd_h2(void* stream, const float* x, const float* amax_x, const void* w2_fwd, const float* bias,
+                                 float* p_out, unsigned char* argmax, float* amax_p, int B, int T, int F, int Cin, int Cout);
+int mtl_conv3x3_dgrad_h2(void* stream, const float* dy, const float* amax_dy, const unsigned char* argmax, const void* w2_dgrad,
+                         const float* act, float* dx, float* amax_dx, int B, int T, int F, int Cin, int Cout);
+/* *amax = max(*amax, max|x[0..n)|) (atomic; zero it first) */
+int mtl_absmax_f32(void* stream, const float* x, long n, float* amax);
 long mtl_conv3x3_wgrad_workspace(int B, int T, int F, int Cin, int Cout, int pooled);
 /* dw_ref (Cout,Cin,3,3) += sum_pixels x (x) dy ; dy dense (B,T,F,Cout) or pooled + argmax as above. */
 int mtl_conv3x3_wgrad(void* stream, const float* x, const float* dy, const unsigned char* argmax, float* dw_ref,
@@ -118,6 +155,10 @@ int mtl_conv3x3_wgrad(void* stream, const float* x, const float* dy, const unsig
 long mtl_conv3x3_wgrad_x3_workspace(int B, int T, int F, int Cin, int Cout, int pooled);
 int mtl_conv3x3_wgrad_x3(void* stream, const float* x, const float* dy, const unsigned char* argmax, float* dw_ref,
                          float* workspace, long workspace_bytes, int B, int T, int F, int Cin, int Cout);
+/* h2 weight gradient (workspace: mtl_conv3x3_wgrad_x3_workspace); amax_dy bounds the dense OR the pooled gradient it is given */
+int mtl_conv3x3_wgrad_h2(void* stream, const float* x, const float* amax_x, const float* dy, const float* amax_dy,
+                         const unsigned char* argmax, float* dw_ref, float* workspace, long workspace_bytes, int B, int T, int F,
+                         int Cin, int Cout);
 /* wp[o][h*C+c] = w[o][c*Hh+h]  (inverse_accum: dst[o][c*Hh+h] += src[o][h*C+c]); the (C*H) flattening of
  * models/asr/transformer.py:136-138 folded into encoder.input_linear's weight instead of an activation copy. */
 int mtl_permute_hc(void* stream, const float* src, float* dst, int rows, int C, int Hh, int inverse_accum);
@@ -191,7 +232,8 @@ int mtl_ce_bwd(void* stream, const float* logits, const float* lse, const long* 
 
 /* ---- out[c] += sum_r X[r*ld + c]  (bias gradients) -------------------------------------------------------- */
 long mtl_colsum_workspace(long rows, int cols);
-int mtl_colsum_accum(void* stream, const float* X, long rows, int cols, long ld, float* out, float* workspace);
+/* amax (optional): *amax = max|X| (written, not accumulated) -- the same pass over X */
+int mtl_colsum_accum(void* stream, const float* X, long rows, int cols, long ld, float* out, float* workspace, float* amax);
 
 /* ---- flat-parameter updates over ONE contiguous fp32 buffer (190 tensors in the reference) ----------------
  * inner SGD  trainer/asr/transient_trainer.py:106,207 -> theta1 = theta0 - alpha*g (theta0 is never mutated, which

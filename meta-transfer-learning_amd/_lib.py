@@ -20,7 +20,10 @@ SIGNATURES = {
     'mtl_gemm_f32_ex': (I, [P, I, I, I, I, I, F, P, I, P, I, P, I, P, P, I, I, I, I, L, L, L, L, L, L, L, I, L, L, P, L, P, L]),
     'mtl_gemm_f32_ex_route': (I, [I, I, I, I, I, I]),
     'mtl_gemm_wgrad_grouped': (I, [P, P, I, I]),
-    'mtl_conv0_relu_fwd': (I, [P, P, P, P, P, I, I, I]),
+    'mtl_lowrank_supported': (I, [I, I, I]),
+    'mtl_lowrank_pair': (I, [P, P, L, I, P, L, P, L, P, L, P, L, P, L, I, I, I, I, I, I, I, I]),
+    'mtl_transpose_batch': (I, [P, P, I]),
+    'mtl_conv0_relu_fwd': (I, [P, P, P, P, P, I, I, I, P]),
     'mtl_conv0_wgrad_workspace': (L, []),
     'mtl_conv0_wgrad': (I, [P, P, P, P, P, P, I, I, I]),
     'mtl_conv3x3_wprep': (I, [P, P, P, P, I, I]),
@@ -35,6 +38,13 @@ SIGNATURES = {
     'mtl_conv3x3_wgrad': (I, [P, P, P, P, P, P, L, I, I, I, I, I]),
     'mtl_conv3x3_wgrad_x3_workspace': (L, [I, I, I, I, I, I]),
     'mtl_conv3x3_wgrad_x3': (I, [P, P, P, P, P, P, L, I, I, I, I, I]),
+    'mtl_conv3x3_wprep_h2_bytes': (L, [I, I]),
+    'mtl_conv3x3_wprep_h2': (I, [P, P, P, P, I, I]),
+    'mtl_conv3x3_relu_fwd_h2': (I, [P, P, P, P, P, P, P, I, I, I, I, I]),
+    'mtl_conv3x3_relu_pool_fwd_h2': (I, [P, P, P, P, P, P, P, P, I, I, I, I, I]),
+    'mtl_conv3x3_dgrad_h2': (I, [P, P, P, P, P, P, P, P, I, I, I, I, I]),
+    'mtl_conv3x3_wgrad_h2': (I, [P, P, P, P, P, P, P, P, L, I, I, I, I, I]),
+    'mtl_absmax_f32': (I, [P, P, L, P]),
     'mtl_permute_hc': (I, [P, P, P, I, I, I, I]),
     'mtl_layernorm_fwd': (I, [P, P, P, P, P, P, P, P, F, P, P, P, I, I, I, F]),
     'mtl_layernorm_bwd_workspace': (L, [I, I]),
@@ -50,7 +60,7 @@ SIGNATURES = {
     'mtl_ce_argmax_fwd': (I, [P, P, P, I, I, I, L, F, I, P, P, P, P, P]),
     'mtl_ce_bwd': (I, [P, P, P, P, I, I, I, L, F, F, P, P, I]),
     'mtl_colsum_workspace': (L, [L, I]),
-    'mtl_colsum_accum': (I, [P, P, L, I, L, P, P]),
+    'mtl_colsum_accum': (I, [P, P, L, I, L, P, P, P]),
     'mtl_sgd_theta_prime': (I, [P, P, P, F, P, L]),
     'mtl_axpy': (I, [P, P, P, F, L]),
     'mtl_copy_f32': (I, [P, P, P, L]),
@@ -103,6 +113,11 @@ class WgradDesc(ctypes.Structure):
     """mtl_wgrad_desc of include/mtl_hip.h (64 bytes)"""
     _fields_ = [('A', c_void_p), ('B', c_void_p), ('C', c_void_p), ('rowsum', c_void_p), ('M', c_int), ('N', c_int), ('K', c_int),
                 ('lda', c_int), ('ldb', c_int), ('ldc', c_int), ('tile0', c_int), ('reserved', c_int)]
+
+
+class TransposeDesc(ctypes.Structure):
+    """mtl_transpose_desc of include/mtl_hip.h (24 bytes)"""
+    _fields_ = [('src', c_void_p), ('dst', c_void_p), ('rows', c_int), ('cols', c_int)]
 
 
 class _CmdArg(ctypes.Union):

@@ -434,30 +434,61 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ l
 // ------------------------------------------------------------------ column sums (bias gradients), deterministic two-stage
 // stage 1: block (64 columns, row chunk): 4 waves stride the rows of the chunk, lanes = columns (256-B coalesced rows),
 // combined through LDS -> part[chunk][c];  stage 2: out[c] += sum_chunk part[chunk][c] in fixed order.
+// AMAX: the pass over X also yields max|X| (what a 2-piece fp16 convolution needs of its input): per-block maxima behind the
+// partial sums, reduced by the final kernel -- no second read of X.
+template <bool AMAX>
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ X, long rows, int cols, long ld,
-                                                             long rows_per_block, float* __restrict__ part) {
+                                                             long rows_per_block, float* __restrict__ part, float* __restrict__ pmax) {
     __shared__ float sh[4][64];
+    __shared__ float shm[4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
     const long r0 = (long)blockIdx.y * rows_per_block;
     long r1 = r0 + rows_per_block;
     if (r1 > rows) r1 = rows;
-    float s0 = 0.f, s1 = 0.f;
+    float s0 = 0.f, s1 = 0.f, mx = 0.f;
     if (c < cols) {
         long r = r0 + wv;
         for (; r + 4 < r1; r += 8) {
-            s0 += X[r * ld + c];
-            s1 += X[(r + 4) * ld + c];
+            const float a = X[r * ld + c], b = X[(r + 4) * ld + c];
+            s0 += a;
+            s1 += b;
+            if (AMAX) mx = fmaxf(mx, fmaxf(fabsf(a), fabsf(b)));
         }
-        if (r < r1) s0 += X[r * ld + c];
+        if (r < r1) {
+            const float a = X[r * ld + c];
+            s0 += a;
+            if (AMAX) mx = fmaxf(mx, fabsf(a));
+        }
     }
     sh[wv][lane] = s0 + s1;
+    if (AMAX) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        if (lane == 0) shm[wv] = mx;
+    }
     __syncthreads();
     if (wv == 0 && c < cols) part[(long)blockIdx.y * cols + c] = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
+    if (AMAX && threadIdx.x == 0) pmax[(long)blockIdx.y * gridDim.x + blockIdx.x] = fmaxf(fmaxf(shm[0], shm[1]), fmaxf(shm[2], shm[3]));
 }
 // 16 waves per column block: the tall conv-bias sums leave ~1000 partial rows, which 4 waves walked in 126 us
-__global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restrict__ part, int nblk, int cols, float* __restrict__ out) {
+__global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restrict__ part, int nblk, int cols, float* __restrict__ out,
+                                                            const float* __restrict__ pmax, int npmax, float* __restrict__ amax) {
     __shared__ float sh[16][64];
+    if (amax && blockIdx.x == 0) {             // block 0 also reduces the per-block maxima and WRITES the result (no atomics, no reset)
+        __shared__ float shm[16];
+        float mx = 0.f;
+        for (int i = threadIdx.x; i < npmax; i += 1024) mx = fmaxf(mx, pmax[i]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        if ((threadIdx.x & 63) == 0) shm[threadIdx.x >> 6] = mx;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int i = 1; i < 16; ++i) mx = fmaxf(mx, shm[i]);
+            *amax = mx;
+        }
+    }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -486,8 +517,9 @@ __global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restr
 // lane = (pixel, 4-channel group): a wave writes 4 pixels x 64 channels = 1 KiB contiguous.
 __global__ __launch_bounds__(256) void conv0_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, float* __restrict__ y, int B, int T,
-                                                        int F) {
+                                                        int F, float* __restrict__ amax_y) {
     const int cg = threadIdx.x & 15;  // channels 4cg..4cg+3
+    float mx = 0.f;
     float wr[4][9], bb[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -515,6 +547,15 @@ __global__ __launch_bounds__(256) void conv0_fwd_kernel(const float* __restrict_
         }
         *reinterpret_cast<float4*>(y + pix * 64 + cg * 4) =
             make_float4(fmaxf(acc[0], 0.f), fmaxf(acc[1], 0.f), fmaxf(acc[2], 0.f), fmaxf(acc[3], 0.f));
+        mx = fmaxf(fmaxf(mx, fmaxf(acc[0], acc[1])), fmaxf(acc[2], acc[3]));
+    }
+    if (amax_y) {       // max of the outputs (>= 0 after the ReLU): one atomic per wave; the caller zeroes the scalar
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        // same-address atomics (and coherent loads) serialise -- 32 k of them cost 0.3 ms here: only a wave that would RAISE the
+        // value issues one, judged by a plain cached load (a stale smaller value only costs a redundant atomic)
+        if ((threadIdx.x & 63) == 0 && mx > *amax_y)
+            atomicMax(reinterpret_cast<unsigned*>(amax_y), __float_as_uint(mx));
     }
 }
 // dw0[c][tap] = sum_pix x[pix+tap]*dy[pix][c], db0[c] = sum_pix dy[pix][c]: per-block partials [blk][64][10]
@@ -890,6 +931,14 @@ int mtl_ce_bwd(void* stream, const float* logits, const float* lse, const long* 
     return MTL_OK;
 }
 
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long n, float* __restrict__ amax) {
+    float mx = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) mx = fmaxf(mx, fabsf(x[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0 && mx > *amax) atomicMax(reinterpret_cast<unsigned*>(amax), __float_as_uint(mx));
+}
+
 static long colsum_chunks(long rows, int cols) {
     const long colblocks = (cols + 63) / 64;
     long nblk = (rows + 31) / 32;                 // >= 32 rows per block
@@ -898,25 +947,39 @@ static long colsum_chunks(long rows, int cols) {
     if (nblk < 1) nblk = 1;
     return nblk;
 }
-long mtl_colsum_workspace(long rows, int cols) { return colsum_chunks(rows, cols) * cols * 4; }
+int mtl_absmax_f32(void* stream, const float* x, long n, float* amax) {
+    if (!x || !amax || n <= 0) return MTL_EINVAL;
+    hipLaunchKernelGGL(absmax_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, as_stream(stream), x, n, amax);
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}
 
-int mtl_colsum_accum(void* stream, const float* X, long rows, int cols, long ld, float* out, float* workspace) {
+long mtl_colsum_workspace(long rows, int cols) {
+    const long chunks = colsum_chunks(rows, cols);
+    return chunks * cols * 4 + chunks * ((cols + 63) / 64) * 4;       // partial sums + per-block maxima
+}
+
+int mtl_colsum_accum(void* stream, const float* X, long rows, int cols, long ld, float* out, float* workspace, float* amax) {
     if (!X || !out || !workspace || rows <= 0 || cols <= 0) return MTL_EINVAL;
     long nblk = colsum_chunks(rows, cols);
     const long rpb = (rows + nblk - 1) / nblk;
     nblk = (rows + rpb - 1) / rpb;
     hipStream_t s = as_stream(stream);
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3((cols + 63) / 64, (unsigned)nblk), dim3(256), 0, s, X, rows, cols, ld, rpb,
-                       workspace);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((cols + 63) / 64), dim3(1024), 0, s, workspace, (int)nblk, cols, out);
+    const int cb = (cols + 63) / 64;
+    float* pmax = workspace + colsum_chunks(rows, cols) * cols;
+    if (amax)
+        hipLaunchKernelGGL(colsum_partial_kernel<true>, dim3(cb, (unsigned)nblk), dim3(256), 0, s, X, rows, cols, ld, rpb, workspace, pmax);
+    else
+        hipLaunchKernelGGL(colsum_partial_kernel<false>, dim3(cb, (unsigned)nblk), dim3(256), 0, s, X, rows, cols, ld, rpb, workspace, pmax);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cb), dim3(1024), 0, s, workspace, (int)nblk, cols, out, pmax, (int)(nblk * cb), amax);
     MTL_CHECK_LAUNCH();
     return MTL_OK;
 }
 
-int mtl_conv0_relu_fwd(void* stream, const float* x, const float* w, const float* bias, float* y, int B, int T, int F) {
+int mtl_conv0_relu_fwd(void* stream, const float* x, const float* w, const float* bias, float* y, int B, int T, int F, float* amax_y) {
     if (!x || !w || !bias || !y) return MTL_EINVAL;
     hipLaunchKernelGGL(conv0_fwd_kernel, dim3(grid_for((long)B * T * F, 16, 8192)), dim3(256), 0, as_stream(stream), x, w, bias,
-                       y, B, T, F);
+                       y, B, T, F, amax_y);
     MTL_CHECK_LAUNCH();
     return MTL_OK;
 }

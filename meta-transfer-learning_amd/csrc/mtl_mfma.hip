@@ -701,6 +701,77 @@ __device__ __forceinline__ void split3x4(const float4& v, bf16x4& h, bf16x4& m, 
     l = __builtin_bit_cast(bf16x4, ll);
 }
 
+// ------------------------------------------------------------------ two fp16 pieces ("h2"): half the MFMA work of x3
+// x s = h + l (+ at most 2^-23 |x s|) with two fp16 pieces (2 x 11 significand bits), s a power of two that puts the LARGEST
+// magnitude of the tensor into [2^14, 2^15) -- fp16 has 5 exponent bits, so the caller passes an upper bound of max|x| (a device
+// scalar: `amax`), and everything above 2^-39 of that maximum keeps its full 22 bits (below, the absolute error is 2^-40 of the
+// maximum).  A product is h h' + h l' + l h' (the dropped l l' is < 2^-22 relative): three v_mfma_f32_32x32x16_f16 instead of six
+// bf16 ones, fp32 accumulation, un-scaled exactly (powers of two) in the epilogue.  Measured error of a K = 1152 convolution
+// against fp64: 1.3-1.6x that of an fp32 convolution (tests/test_ops_gpu.py), i.e. fp32-class like x3, at twice its MFMA roof.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float pow2_scale(float amax) {   // 2^k with amax 2^k in [2^14, 2^15); 1 for amax = 0 / denormal
+    const int e = (int)((__builtin_bit_cast(unsigned, amax) >> 23) & 0xffu);     // amax in [2^(e-127), 2^(e-126))
+    int k = 141 - e;
+    k = e == 0 ? 0 : min(max(k, -60), 60);
+    return __builtin_bit_cast(float, (unsigned)(k + 127) << 23);
+}
+
+__device__ __forceinline__ void split2x2(float x0, float x1, unsigned& h, unsigned& l) {
+    const f16x2 hh = __builtin_convertvector(f32x2{x0, x1}, f16x2);
+    const f32x2 r = f32x2{x0, x1} - __builtin_convertvector(hh, f32x2);            // exact
+    h = __builtin_bit_cast(unsigned, hh);
+    l = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
+}
+
+// NP 16-bit pieces per fp32 value: 3 = exact bf16 triple (scale ignored), 2 = fp16 pair of the scaled value
+template <int NP>
+struct Split;
+template <>
+struct Split<3> {
+    static __device__ __forceinline__ void x2(float x0, float x1, float, unsigned (&pc)[3]) { split3x2(x0, x1, pc[0], pc[1], pc[2]); }
+    static __device__ __forceinline__ f32x16 mfma(const uint4 (&a)[3], const uint4 (&b)[3], f32x16 cc) {
+        const bf16x8 a0 = __builtin_bit_cast(bf16x8, a[0]), a1 = __builtin_bit_cast(bf16x8, a[1]), a2 = __builtin_bit_cast(bf16x8, a[2]);
+        const bf16x8 b0 = __builtin_bit_cast(bf16x8, b[0]), b1 = __builtin_bit_cast(bf16x8, b[1]), b2 = __builtin_bit_cast(bf16x8, b[2]);
+        cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, cc, 0, 0, 0);   // smallest terms first
+        cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, cc, 0, 0, 0);
+        cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, cc, 0, 0, 0);
+        cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, cc, 0, 0, 0);
+        cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, cc, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, cc, 0, 0, 0);
+    }
+};
+template <>
+struct Split<2> {
+    static __device__ __forceinline__ void x2(float x0, float x1, float s, unsigned (&pc)[2]) { split2x2(x0 * s, x1 * s, pc[0], pc[1]); }
+    static __device__ __forceinline__ f32x16 mfma(const uint4 (&a)[2], const uint4 (&b)[2], f32x16 cc) {
+        const f16x8 a0 = __builtin_bit_cast(f16x8, a[0]), a1 = __builtin_bit_cast(f16x8, a[1]);
+        const f16x8 b0 = __builtin_bit_cast(f16x8, b[0]), b1 = __builtin_bit_cast(f16x8, b[1]);
+        cc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, cc, 0, 0, 0);
+        cc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, cc, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, cc, 0, 0, 0);
+    }
+};
+template <int NP>
+__device__ __forceinline__ void split_x4(const float4& v, float s, uint2 (&pc)[NP]) {
+    unsigned a[NP], b[NP];
+    Split<NP>::x2(v.x, v.y, s, a);
+    Split<NP>::x2(v.z, v.w, s, b);
+#pragma unroll
+    for (int q = 0; q < NP; ++q) pc[q] = make_uint2(a[q], b[q]);
+}
+
+// upper bound of max|.| over a wave's lanes -> atomic max into a device scalar (non-negative floats order like their bits)
+__device__ __forceinline__ void wave_amax_to(float* slot, float mx) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    // same-address atomics serialise (~9 ns each, and so do coherent loads): only a wave that would RAISE the value issues one,
+    // judged by a plain CACHED load -- a stale (smaller) value only costs a redundant atomic, the maximum is monotone
+    if ((threadIdx.x & 63) == 0 && mx > *slot)
+        atomicMax(reinterpret_cast<unsigned*>(slot), __builtin_bit_cast(unsigned, mx));
+}
+
 // (Cout,Cin,3,3) fp32 -> bf16 pieces laid out per K-TILE: w3f[piece][kt = tap*Cin/32 + cin/32][cout][cin%32] and
 // w3d[piece][kt = (8-tap)*Cout/32 + cout/32][cin][cout%32]: the rows a workgroup stages for one K-tile are one contiguous
 // block of full cache lines, which is exactly the LDS image the convolution wants, so it is moved by global_load_lds
@@ -709,27 +780,52 @@ __device__ __forceinline__ void split3x4(const float4& v, bf16x4& h, bf16x4& m, 
 // 16 rows {0-3,12-15,20-27} conflict-free with no padding.
 __host__ __device__ inline int x3_swz(int k, int row) { return (((k >> 3) ^ ((row >> 2) & 3)) << 3) | (k & 7); }
 
-__global__ void conv_wprep_x3_kernel(const float* w, __bf16* wf, __bf16* wd, int Cout, int Cin) {
+// NP = 2: the planes are followed by one fp32 -- the power-of-two scale the pieces were taken at (conv_wscale_kernel).
+template <int NP>
+__global__ void conv_wprep_x3_kernel(const float* w, unsigned short* wf, unsigned short* wd, int Cout, int Cin) {
     const int total = 9 * Cin * Cout;
     const int nkf = 9 * (Cin / 32), nkd = 9 * (Cout / 32);
+    const float s = NP == 2 ? *reinterpret_cast<const float*>(wf + (long)NP * total) : 1.f;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
         const int tap = e % 9;
         const int cin = (e / 9) % Cin;
         const int cout = e / (9 * Cin);
-        __bf16 pc[3];
-        split3(w[e], pc[0], pc[1], pc[2]);
+        unsigned pc[NP];
+        Split<NP>::x2(w[e], 0.f, s, pc);
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            wf[(((long)p * nkf + tap * (Cin / 32) + (cin >> 5)) * Cout + cout) * 32 + x3_swz(cin & 31, cout)] = pc[p];
-            wd[(((long)p * nkd + (8 - tap) * (Cout / 32) + (cout >> 5)) * Cin + cin) * 32 + x3_swz(cout & 31, cin)] = pc[p];
+        for (int p = 0; p < NP; ++p) {
+            const unsigned short v = (unsigned short)(pc[p] & 0xffffu);
+            wf[(((long)p * nkf + tap * (Cin / 32) + (cin >> 5)) * Cout + cout) * 32 + x3_swz(cin & 31, cout)] = v;
+            wd[(((long)p * nkd + (8 - tap) * (Cout / 32) + (cout >> 5)) * Cin + cin) * 32 + x3_swz(cout & 31, cin)] = v;
         }
+    }
+}
+
+// one workgroup: s = pow2_scale(max|w|) into the trailer of both prepared buffers
+__global__ __launch_bounds__(1024) void conv_wscale_kernel(const float* w, int total, float* hdr_f, float* hdr_d) {
+    __shared__ float sh[16];
+    float mx = 0.f;
+    for (int e = threadIdx.x * 4; e < total; e += 4096) {
+        const float4 v = *reinterpret_cast<const float4*>(w + e);
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 1; i < 16; ++i) mx = fmaxf(mx, sh[i]);
+        const float s = pow2_scale(mx);
+        *hdr_f = s;
+        *hdr_d = s;
     }
 }
 
 struct ConvX3P {
     const float* x;
     const uint8_t* am_in;
-    const __bf16* w3;    // [3][K-tile][N rows = output channels][32]   (see conv_wprep_x3_kernel)
+    const unsigned char* w3;   // [NP][K-tile][N rows = output channels][32] 16-bit pieces (+ fp32 scale when NP = 2): conv_wprep_x3_kernel
     const float* bias;
     const float* act;
     float* y;
@@ -738,6 +834,8 @@ struct ConvX3P {
     int ntile;
     int dbg;             // ablation switches (MTL_X3_DBG), 0 in production
     int ntf, ntt, tiles; // halo kernel: pixel tiles along F and T, and tiles in total (F fastest, then T, then output-channel tile, then sample)
+    const float* amax_in;   // NP = 2: device scalar >= max|x|
+    float* amax_out;        // optional: atomic max of an upper bound of max|y| (the next layer's amax_in)
 };
 
 // ------------------------------------------------------------------ halo-tiled x3 convolution (the one the C ABI dispatches to)
@@ -782,7 +880,7 @@ __device__ inline X3Tile x3_tile(const ConvX3P& p, int id) {
     return t;
 }
 
-template <int BN, int G, bool UNPOOL, int EPI>
+template <int BN, int G, bool UNPOOL, int EPI, int NP>
 __global__ __launch_bounds__((4 * G + 4) * 64) void conv3x3_x3h_kernel(ConvX3P p) {
     using E = Engine<128, BN, LoadConvA<UNPOOL>, LoadMNMajor<BN, true>>;   // tile constants only
     constexpr int TM = E::TM, TN = E::TN, WTM = E::WTM, WTN = E::WTN;
@@ -791,7 +889,7 @@ __global__ __launch_bounds__((4 * G + 4) * 64) void conv3x3_x3h_kernel(ConvX3P p
     constexpr int NHALO = 3 * 64;                                  // halo threads (producer waves 1-3)
     constexpr int XH_NVA = (XH_NPIX * 8 + NHALO - 1) / NHALO;      // float4 (4 channels) per halo thread and chunk
     constexpr int NCONS = 4 * G * 64;                              // consumer threads
-    constexpr int BPLANE = BN * 64, BBUF = 3 * BPLANE, ABUF = 3 * XH_APLANE;   // weights: unpadded swizzled 64-byte rows
+    constexpr int BPLANE = BN * 64, BBUF = NP * BPLANE, ABUF = NP * XH_APLANE;   // weights: unpadded swizzled 64-byte rows
     constexpr int NDMA = BBUF / 1024;                              // wave-wide 16-byte DMA instructions per weight tile
     extern __shared__ __attribute__((aligned(16))) unsigned char smx[];
     unsigned char* smA = smx;
@@ -806,6 +904,7 @@ __global__ __launch_bounds__((4 * G + 4) * 64) void conv3x3_x3h_kernel(ConvX3P p
     if (tid >= NCONS + 64) {
         // ------------------------------------------------------------------ halo waves (3): gather, 3-way split, LDS image
         const int ptid = tid - NCONS - 64;
+        const float sx = NP == 2 ? pow2_scale(*p.amax_in) : 1.f;
         float4 hv[XH_NVA];
         uchar4 ha[XH_NVA];
         unsigned hm[XH_NVA];
@@ -851,12 +950,11 @@ __global__ __launch_bounds__((4 * G + 4) * 64) void conv3x3_x3h_kernel(ConvX3P p
                     v.z = (ok && ha[i].z == sub) ? v.z : 0.f;
                     v.w = (ok && ha[i].w == sub) ? v.w : 0.f;
                 }
-                bf16x4 hh, mm, ll;
-                split3x4(v, hh, mm, ll);
+                uint2 pc[NP];
+                split_x4<NP>(v, sx, pc);
                 unsigned char* dst = smA + (e >> 3) * X3_ROWB + (e & 7) * 8;
-                *reinterpret_cast<bf16x4*>(dst) = hh;
-                *reinterpret_cast<bf16x4*>(dst + XH_APLANE) = mm;
-                *reinterpret_cast<bf16x4*>(dst + 2 * XH_APLANE) = ll;
+#pragma unroll
+                for (int q = 0; q < NP; ++q) *reinterpret_cast<uint2*>(dst + q * XH_APLANE) = pc[q];
             }
         };
         const bool doA = !(p.dbg & 2);
@@ -894,8 +992,7 @@ __global__ __launch_bounds__((4 * G + 4) * 64) void conv3x3_x3h_kernel(ConvX3P p
 #pragma unroll
             for (int i = 0; i < NDMA; ++i) {
                 const int piece = i / (BN / 16), r16 = i - piece * (BN / 16);       // 16 rows (1 KiB) per instruction
-                const unsigned char* g = reinterpret_cast<const unsigned char*>(p.w3) +
-                                         (((long)piece * nk + kt) * Cout + n0 + r16 * 16) * 64 + lane * 16;
+                const unsigned char* g = p.w3 + (((long)piece * nk + kt) * Cout + n0 + r16 * 16) * 64 + lane * 16;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                                  (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
             }
@@ -931,6 +1028,8 @@ __global__ __launch_bounds__((4 * G + 4) * 64) void conv3x3_x3h_kernel(ConvX3P p
     const int grp = wave >> 2, w4 = wave & 3;
     const int wm = w4 >> 1, wn = w4 & 1, l31 = lane & 31, hi = lane >> 5;
     f32x16 acc[TM][TN];
+    float inv = 1.f, mx = 0.f;                                 // NP = 2: 1 / (activation scale x weight scale); running bound of max|y|
+    if (NP == 2) inv = 1.f / (pow2_scale(*p.amax_in) * *reinterpret_cast<const float*>(p.w3 + (long)NP * nk * Cout * 64));
     int abase[TM];                                             // byte offset of this lane's pixel (tap centre) in the halo plane
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -956,30 +1055,21 @@ __global__ __launch_bounds__((4 * G + 4) * 64) void conv3x3_x3h_kernel(ConvX3P p
                 const unsigned char* bS = bBase + bst * BBUF;
 #pragma unroll
                 for (int st = 0; st < BK / 16; ++st) {
-                    bf16x8 a[TM][3], bb[TN][3];
+                    uint4 a[TM][NP], bb[TN][NP];
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
-                        for (int pc = 0; pc < 3; ++pc)
-                            a[i][pc] = *reinterpret_cast<const bf16x8*>(smA + pc * XH_APLANE + abase[i] + toff + st * 32);
+                        for (int pc = 0; pc < NP; ++pc)
+                            a[i][pc] = *reinterpret_cast<const uint4*>(smA + pc * XH_APLANE + abase[i] + toff + st * 32);
 #pragma unroll
                     for (int jn = 0; jn < TN; ++jn)
 #pragma unroll
-                        for (int pc = 0; pc < 3; ++pc)
-                            bb[jn][pc] = *reinterpret_cast<const bf16x8*>(bS + pc * BPLANE + jn * 32 * 64 + bsw[st]);
+                        for (int pc = 0; pc < NP; ++pc)
+                            bb[jn][pc] = *reinterpret_cast<const uint4*>(bS + pc * BPLANE + jn * 32 * 64 + bsw[st]);
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
-                        for (int jn = 0; jn < TN; ++jn) {
-                            f32x16 cc = acc[i][jn];
-                            cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], bb[jn][0], cc, 0, 0, 0);   // smallest terms first
-                            cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], bb[jn][1], cc, 0, 0, 0);
-                            cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], bb[jn][2], cc, 0, 0, 0);
-                            cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], bb[jn][0], cc, 0, 0, 0);
-                            cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], bb[jn][1], cc, 0, 0, 0);
-                            cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], bb[jn][0], cc, 0, 0, 0);
-                            acc[i][jn] = cc;
-                        }
+                        for (int jn = 0; jn < TN; ++jn) acc[i][jn] = Split<NP>::mfma(a[i], bb[jn], acc[i][jn]);
                 }
                 __syncthreads();
             }
@@ -1000,6 +1090,11 @@ __global__ __launch_bounds__((4 * G + 4) * 64) void conv3x3_x3h_kernel(ConvX3P p
 #pragma unroll
                             for (int g = 0; g < 4; ++g) {
                                 float v[4] = {acc[i][jn][4 * g], acc[i][jn][4 * g + 1], acc[i][jn][4 * g + 2], acc[i][jn][4 * g + 3]};
+                                if (NP == 2) {
+#pragma unroll
+                                    for (int k = 0; k < 4; ++k) v[k] *= inv;
+                                }
+                                mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
                                 epi.store4(wm * WTM + i * 32 + 8 * g + 4 * hi, wn * WTN + jn * 32 + l31, v);
                             }
                 };
@@ -1024,6 +1119,11 @@ __global__ __launch_bounds__((4 * G + 4) * 64) void conv3x3_x3h_kernel(ConvX3P p
 #pragma unroll
                             for (int g = 0; g < 4; ++g) {
                                 float v[4] = {acc[i][jn][4 * g], acc[i][jn][4 * g + 1], acc[i][jn][4 * g + 2], acc[i][jn][4 * g + 3]};
+                                if (NP == 2) {
+#pragma unroll
+                                    for (int k = 0; k < 4; ++k) v[k] *= inv;
+                                }
+                                mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
                                 epi.store4g(wm * WTM + i * 32 + 8 * g + 4 * hi, wn * WTN + jn * 32 + l31, v, gate[i][jn][g]);
                             }
                 }
@@ -1031,14 +1131,23 @@ __global__ __launch_bounds__((4 * G + 4) * 64) void conv3x3_x3h_kernel(ConvX3P p
             if (j * cch + c + 1 < nstage) __syncthreads();     // the producers replaced the halo between these two barriers
         }
     }
+    if (p.amax_out) {       // |relu(v + b)| <= |v| + |b| (pooling takes a maximum of those); dgrad: |gate v| <= |v|
+        float bmax = 0.f;
+        if (EPI != EPI_DGRAD) {
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn)
+                for (int nt = 0; nt < p.ntile; ++nt) bmax = fmaxf(bmax, fabsf(p.bias[nt * BN + wn * WTN + jn * 32 + l31]));
+        }
+        wave_amax_to(p.amax_out, mx + bmax);
+    }
 }
 
-template <int BN, int G, bool UNPOOL, int EPI>
+template <int BN, int G, bool UNPOOL, int EPI, int NP>
 int launch_conv_x3h(ConvX3P p, int Te, int Fe, hipStream_t s) {
-    constexpr int SMEM = 3 * (8 * G + 2) * XH_HF * X3_ROWB + 3 * 3 * BN * 64;
-    static int attr = set_smem(conv3x3_x3h_kernel<BN, G, UNPOOL, EPI>, SMEM);
+    constexpr int SMEM = NP * (8 * G + 2) * XH_HF * X3_ROWB + 3 * NP * BN * 64;
+    static int attr = set_smem(conv3x3_x3h_kernel<BN, G, UNPOOL, EPI, NP>, SMEM);
     if (attr) return attr;
-    static const int per_cu = SMEM > 80 * 1024 ? 1 : 2;
+    static const int per_cu = (G == 1 && SMEM <= 80 * 1024) ? 2 : 1;     // 12-wave workgroups (G = 2) never share a CU
     static const int ncu = device_cu_count();
     static const int dbg = getenv("MTL_X3_DBG") ? atoi(getenv("MTL_X3_DBG")) : 0;
     p.dbg = dbg;
@@ -1046,12 +1155,12 @@ int launch_conv_x3h(ConvX3P p, int Te, int Fe, hipStream_t s) {
     p.ntt = (Te + 8 * G - 1) / (8 * G);
     p.tiles = p.ntf * p.ntt * p.g.B * p.ntile;
     const int grid = p.tiles < ncu * per_cu ? p.tiles : ncu * per_cu;
-    hipLaunchKernelGGL((conv3x3_x3h_kernel<BN, G, UNPOOL, EPI>), dim3(grid), dim3((4 * G + 4) * 64), SMEM, s, p);
+    hipLaunchKernelGGL((conv3x3_x3h_kernel<BN, G, UNPOOL, EPI, NP>), dim3(grid), dim3((4 * G + 4) * 64), SMEM, s, p);
     MTL_CHECK_LAUNCH();
     return MTL_OK;
 }
 
-template <bool UNPOOL, int EPI>
+template <bool UNPOOL, int EPI, int NP>
 int dispatch_conv_x3(ConvX3P& p, int Te, int Fe, hipStream_t s) {
     if (p.g.Cin % 64 || p.g.Cout % 64) return MTL_EINVAL;     // C_in % 64: even number of K-tiles (producer loop is unrolled by 2)
     // 8 x 16 tiles (G = 1: 79 KiB of LDS at BN = 64, two workgroups per CU) measured faster only on the 64 -> 64 layer
@@ -1059,11 +1168,11 @@ int dispatch_conv_x3(ConvX3P& p, int Te, int Fe, hipStream_t s) {
     static const bool g1 = getenv("MTL_X3_G1") != nullptr;          // experiment: 8 x 16 tiles everywhere (LDS room for co-resident kernels)
     if (p.g.Cout % 128 == 0) {
         p.ntile = p.g.Cout / 128;
-        return g1 ? launch_conv_x3h<128, 1, UNPOOL, EPI>(p, Te, Fe, s) : launch_conv_x3h<128, 2, UNPOOL, EPI>(p, Te, Fe, s);
+        return g1 ? launch_conv_x3h<128, 1, UNPOOL, EPI, NP>(p, Te, Fe, s) : launch_conv_x3h<128, 2, UNPOOL, EPI, NP>(p, Te, Fe, s);
     }
     p.ntile = p.g.Cout / 64;
-    if (p.g.Cin == 64 || g1) return launch_conv_x3h<64, 1, UNPOOL, EPI>(p, Te, Fe, s);
-    return launch_conv_x3h<64, 2, UNPOOL, EPI>(p, Te, Fe, s);
+    if (p.g.Cin == 64 || g1) return launch_conv_x3h<64, 1, UNPOOL, EPI, NP>(p, Te, Fe, s);
+    return launch_conv_x3h<64, 2, UNPOOL, EPI, NP>(p, Te, Fe, s);
 }
 
 // ------------------------------------------------------------------ weight gradient
@@ -1316,34 +1425,34 @@ struct WgradX3P {
     int npairs, npj;      // channel-block pairs, and pairs along Cout
     int ntf, ntt, tiles;  // pixel tiles along F, along T, in total (F fastest)
     int dbg;              // ablation switches (MTL_X3_DBG): 1 no halo staging, 2 no dy loads / splits; 0 in production
+    const float* amax_x;  // NP = 2: device scalars >= max|x|, >= max|dy|
+    const float* amax_dy;
 };
 
 constexpr int WX_HF = 18, WX_NPIX = 10 * WX_HF;          // halo of an 8 x 16 tile
-constexpr int WX_SUB = WX_NPIX * 64;                      // one (piece, ci half) sub-plane in bytes
-constexpr int WX_BUF = 6 * WX_SUB;                        // one halo buffer
+constexpr int WX_SUB = WX_NPIX * 64;                      // one (piece, ci half) sub-plane in bytes; a halo buffer holds 2 NP of them
 constexpr int WX_NVA = (WX_NPIX * 16 + NT - 1) / NT;      // float4 per producer thread and tile
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ bf16x8 tr_read8(const unsigned char* a) {    // 8 pixels (2 x 4) of this lane's channel
+__device__ __forceinline__ uint4 tr_read8(const unsigned char* a) {    // 8 pixels (2 x 4) of this lane's channel
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a));
     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a + 4 * 64));
     union {
         s16x4 h[2];
-        bf16x8 v;
+        uint4 v;
     } u;
     u.h[0] = lo;
     u.h[1] = hi;
     return u.v;
 }
 
-// B ring: 2 slots x 2 k-steps x [piece][k half][64 co] 16-byte fragments (6 KiB per k-step), behind the two halo buffers
-constexpr int WX_BSTEP = 3 * 2 * 64 * 16;
-constexpr int WX_BOFF = 2 * WX_BUF;
-constexpr int WX_SMEM = WX_BOFF + 4 * WX_BSTEP;
+// B ring: 2 slots x 2 k-steps x [piece][k half][64 co] 16-byte fragments (2 KiB per piece and k-step), behind the two halo buffers
+constexpr int wx_smem(int np) { return 2 * (2 * np * WX_SUB) + 4 * (np * 2 * 64 * 16); }
 
-template <bool UNPOOL>
+template <bool UNPOOL, int NP>
 __global__ __launch_bounds__(512) void conv3x3_wgrad_x3_kernel(WgradX3P p) {
+    constexpr int WX_BUF = 2 * NP * WX_SUB, WX_BSTEP = NP * 2 * 64 * 16, WX_BOFF = 2 * WX_BUF;
     extern __shared__ __attribute__((aligned(16))) unsigned char smx[];
     const int tid = threadIdx.x;
     const int pair = blockIdx.x % p.npairs, slot = blockIdx.x / p.npairs, nslots = gridDim.x / p.npairs;
@@ -1363,6 +1472,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_x3_kernel(WgradX3P p) {
     if (tid >= NT) {
         // ------------------------------------------------------------------ producers: the x halo AND the dy fragments
         const int ptid = tid - NT;
+        const float sx = NP == 2 ? pow2_scale(*p.amax_x) : 1.f, sdy = NP == 2 ? pow2_scale(*p.amax_dy) : 1.f;
         float4 hv[WX_NVA];
         unsigned okbits = 0;
         auto fetch = [&](int j) {
@@ -1388,12 +1498,11 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_x3_kernel(WgradX3P p) {
                 if ((e >> 4) >= WX_NPIX) continue;
                 const int hp = e >> 4, c4 = (e & 15) * 4;
                 const float4 v = mask4(hv[i], ((okbits >> i) & 1u) ? 15u : 0u);
-                bf16x4 hh, mm, ll;
-                split3x4(v, hh, mm, ll);
+                uint2 pc[NP];
+                split_x4<NP>(v, sx, pc);
                 unsigned char* dst = smx + buf * WX_BUF + ((c4 >> 5) * WX_NPIX + hp) * 64 + (c4 & 31) * 2;
-                *reinterpret_cast<bf16x4*>(dst) = hh;
-                *reinterpret_cast<bf16x4*>(dst + 2 * WX_SUB) = mm;
-                *reinterpret_cast<bf16x4*>(dst + 4 * WX_SUB) = ll;
+#pragma unroll
+                for (int q = 0; q < NP; ++q) *reinterpret_cast<uint2*>(dst + 2 * q * WX_SUB) = pc[q];
             }
         };
         // dy: this thread owns ONE B fragment per pair of k-steps -- (k-step parity, k half, output channel) -- i.e. 8 pixels
@@ -1452,15 +1561,14 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_x3_kernel(WgradX3P p) {
                     val[k] = (((okm >> (k >> 1)) & 1u) && ((a >> (8 * (k >> 1))) & 0xffu) == sub) ? v[k >> 1] : 0.f;
                 }
             }
-            uint4 hh, mm, ll;
-            split3x2(val[0], val[1], hh.x, mm.x, ll.x);
-            split3x2(val[2], val[3], hh.y, mm.y, ll.y);
-            split3x2(val[4], val[5], hh.z, mm.z, ll.z);
-            split3x2(val[6], val[7], hh.w, mm.w, ll.w);
+            unsigned q0[NP], q1[NP], q2[NP], q3[NP];
+            Split<NP>::x2(val[0], val[1], sdy, q0);
+            Split<NP>::x2(val[2], val[3], sdy, q1);
+            Split<NP>::x2(val[4], val[5], sdy, q2);
+            Split<NP>::x2(val[6], val[7], sdy, q3);
             unsigned char* dst = smx + WX_BOFF + ((pk & 1) * 2 + bs) * WX_BSTEP + (bhi * 64 + bco) * 16;
-            *reinterpret_cast<uint4*>(dst) = hh;
-            *reinterpret_cast<uint4*>(dst + 2 * 64 * 16) = mm;
-            *reinterpret_cast<uint4*>(dst + 4 * 64 * 16) = ll;
+#pragma unroll
+            for (int q = 0; q < NP; ++q) *reinterpret_cast<uint4*>(dst + q * 2 * 64 * 16) = make_uint4(q0[q], q1[q], q2[q], q3[q]);
         };
         if (my_tiles > 0) {
             fetch(0);
@@ -1513,33 +1621,29 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_x3_kernel(WgradX3P p) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const unsigned char* Bs = Bl + ((pk & 1) * 2 + s) * WX_BSTEP;
-            bf16x8 b3[3];
+            uint4 b3[NP];
 #pragma unroll
-            for (int pc = 0; pc < 3; ++pc) b3[pc] = *reinterpret_cast<const bf16x8*>(Bs + pc * 2 * 64 * 16);
+            for (int pc = 0; pc < NP; ++pc) b3[pc] = *reinterpret_cast<const uint4*>(Bs + pc * 2 * 64 * 16);
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int kh = tap / 3, kw = tap - kh * 3;
                 const unsigned char* At = A + ((s + kw) * WX_HF + kh) * 64;
-                const bf16x8 a0 = tr_read8(At), a1 = tr_read8(At + 2 * WX_SUB), a2 = tr_read8(At + 4 * WX_SUB);
-                f32x16 cc = acc[tap];
-                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b3[0], cc, 0, 0, 0);      // smallest terms first
-                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3[1], cc, 0, 0, 0);
-                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b3[2], cc, 0, 0, 0);
-                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3[0], cc, 0, 0, 0);
-                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b3[1], cc, 0, 0, 0);
-                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b3[0], cc, 0, 0, 0);
-                acc[tap] = cc;
+                uint4 a3[NP];
+#pragma unroll
+                for (int pc = 0; pc < NP; ++pc) a3[pc] = tr_read8(At + 2 * pc * WX_SUB);
+                acc[tap] = Split<NP>::mfma(a3, b3, acc[tap]);
             }
         }
         __syncthreads();
     }
     float* slab = p.partial + (long)slot * 9 * Cin * Cout;
+    const float inv = NP == 2 ? 1.f / (pow2_scale(*p.amax_x) * pow2_scale(*p.amax_dy)) : 1.f;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
             const int ci = cib + qi * 32 + 8 * (v >> 2) + 4 * hi + (v & 3);
-            slab[((long)tap * Cin + ci) * Cout + co] = acc[tap][v];
+            slab[((long)tap * Cin + ci) * Cout + co] = NP == 2 ? acc[tap][v] * inv : acc[tap][v];
         }
 }
 
@@ -1605,34 +1709,86 @@ int mtl_conv3x3_dgrad(void* stream, const float* dy, const unsigned char* argmax
     return dispatch_conv<false, EPI_DGRAD>(p, T, F, as_stream(stream));
 }
 
-int mtl_conv3x3_wprep_x3(void* stream, const float* w_ref, void* w3_fwd, void* w3_dgrad, int Cout, int Cin) {
-    if (!w_ref || !w3_fwd || !w3_dgrad) return MTL_EINVAL;
-    hipLaunchKernelGGL(conv_wprep_x3_kernel, dim3(grid_for(9L * Cin * Cout, 256)), dim3(256), 0, as_stream(stream), w_ref,
-                       reinterpret_cast<__bf16*>(w3_fwd), reinterpret_cast<__bf16*>(w3_dgrad), Cout, Cin);
+}  // extern "C"
+
+static int wprep_pieces(int np, hipStream_t s, const float* w_ref, void* wf, void* wd, int Cout, int Cin) {
+    if (!w_ref || !wf || !wd || Cin % 32 || Cout % 32) return MTL_EINVAL;
+    const long total = 9L * Cin * Cout;
+    unsigned short* f = reinterpret_cast<unsigned short*>(wf);
+    unsigned short* d = reinterpret_cast<unsigned short*>(wd);
+    if (np == 2) {
+        hipLaunchKernelGGL(conv_wscale_kernel, dim3(1), dim3(1024), 0, s, w_ref, (int)total, reinterpret_cast<float*>(f + 2 * total),
+                           reinterpret_cast<float*>(d + 2 * total));
+        hipLaunchKernelGGL(conv_wprep_x3_kernel<2>, dim3(grid_for(total, 256)), dim3(256), 0, s, w_ref, f, d, Cout, Cin);
+    } else {
+        hipLaunchKernelGGL(conv_wprep_x3_kernel<3>, dim3(grid_for(total, 256)), dim3(256), 0, s, w_ref, f, d, Cout, Cin);
+    }
     MTL_CHECK_LAUNCH();
     return MTL_OK;
 }
 
+template <int NP>
+static int conv_fwd_pieces(hipStream_t s, const float* x, const float* amax_x, const void* w, const float* bias, float* y,
+                           unsigned char* argmax, float* amax_y, bool pool, int B, int T, int F, int Cin, int Cout) {
+    if (!x || !w || !bias || !y || (pool && !argmax) || (NP == 2 && !amax_x)) return MTL_EINVAL;
+    ConvX3P p{x, nullptr, reinterpret_cast<const unsigned char*>(w), bias, nullptr, y, argmax, {B, T, F, Cin, Cout, T / 2, F / 2}, 1};
+    p.amax_in = amax_x;
+    p.amax_out = amax_y;
+    if (pool) return dispatch_conv_x3<false, EPI_POOL, NP>(p, 2 * (T / 2), 2 * (F / 2), s);
+    return dispatch_conv_x3<false, EPI_RELU, NP>(p, T, F, s);
+}
+
+template <int NP>
+static int conv_dgrad_pieces(hipStream_t s, const float* dy, const float* amax_dy, const unsigned char* argmax, const void* w,
+                             const float* act, float* dx, float* amax_dx, int B, int T, int F, int Cin, int Cout) {
+    if (!dy || !w || !act || !dx || (NP == 2 && !amax_dy)) return MTL_EINVAL;
+    ConvX3P p{dy, argmax, reinterpret_cast<const unsigned char*>(w), nullptr, act, dx, nullptr, {B, T, F, Cout, Cin, T / 2, F / 2}, 1};
+    p.amax_in = amax_dy;
+    p.amax_out = amax_dx;
+    if (argmax) return dispatch_conv_x3<true, EPI_DGRAD, NP>(p, T, F, s);
+    return dispatch_conv_x3<false, EPI_DGRAD, NP>(p, T, F, s);
+}
+
+extern "C" {
+
+int mtl_conv3x3_wprep_x3(void* stream, const float* w_ref, void* w3_fwd, void* w3_dgrad, int Cout, int Cin) {
+    return wprep_pieces(3, as_stream(stream), w_ref, w3_fwd, w3_dgrad, Cout, Cin);
+}
+
 int mtl_conv3x3_relu_fwd_x3(void* stream, const float* x, const void* w3_fwd, const float* bias, float* y, int B, int T, int F,
                             int Cin, int Cout) {
-    if (!x || !w3_fwd || !bias || !y) return MTL_EINVAL;
-    ConvX3P p{x, nullptr, reinterpret_cast<const __bf16*>(w3_fwd), bias, nullptr, y, nullptr, {B, T, F, Cin, Cout, T / 2, F / 2}, 1};
-    return dispatch_conv_x3<false, EPI_RELU>(p, T, F, as_stream(stream));
+    return conv_fwd_pieces<3>(as_stream(stream), x, nullptr, w3_fwd, bias, y, nullptr, nullptr, false, B, T, F, Cin, Cout);
 }
 
 int mtl_conv3x3_relu_pool_fwd_x3(void* stream, const float* x, const void* w3_fwd, const float* bias, float* p_out,
                                  unsigned char* argmax, int B, int T, int F, int Cin, int Cout) {
-    if (!x || !w3_fwd || !bias || !p_out || !argmax) return MTL_EINVAL;
-    ConvX3P p{x, nullptr, reinterpret_cast<const __bf16*>(w3_fwd), bias, nullptr, p_out, argmax, {B, T, F, Cin, Cout, T / 2, F / 2}, 1};
-    return dispatch_conv_x3<false, EPI_POOL>(p, 2 * (T / 2), 2 * (F / 2), as_stream(stream));
+    return conv_fwd_pieces<3>(as_stream(stream), x, nullptr, w3_fwd, bias, p_out, argmax, nullptr, true, B, T, F, Cin, Cout);
 }
 
 int mtl_conv3x3_dgrad_x3(void* stream, const float* dy, const unsigned char* argmax, const void* w3_dgrad, const float* act,
                          float* dx, int B, int T, int F, int Cin, int Cout) {
-    if (!dy || !w3_dgrad || !act || !dx) return MTL_EINVAL;
-    ConvX3P p{dy, argmax, reinterpret_cast<const __bf16*>(w3_dgrad), nullptr, act, dx, nullptr, {B, T, F, Cout, Cin, T / 2, F / 2}, 1};
-    if (argmax) return dispatch_conv_x3<true, EPI_DGRAD>(p, T, F, as_stream(stream));
-    return dispatch_conv_x3<false, EPI_DGRAD>(p, T, F, as_stream(stream));
+    return conv_dgrad_pieces<3>(as_stream(stream), dy, nullptr, argmax, w3_dgrad, act, dx, nullptr, B, T, F, Cin, Cout);
+}
+
+long mtl_conv3x3_wprep_h2_bytes(int Cout, int Cin) { return 2L * 9 * Cin * Cout * 2 + 16; }
+
+int mtl_conv3x3_wprep_h2(void* stream, const float* w_ref, void* w2_fwd, void* w2_dgrad, int Cout, int Cin) {
+    return wprep_pieces(2, as_stream(stream), w_ref, w2_fwd, w2_dgrad, Cout, Cin);
+}
+
+int mtl_conv3x3_relu_fwd_h2(void* stream, const float* x, const float* amax_x, const void* w2_fwd, const float* bias, float* y,
+                            float* amax_y, int B, int T, int F, int Cin, int Cout) {
+    return conv_fwd_pieces<2>(as_stream(stream), x, amax_x, w2_fwd, bias, y, nullptr, amax_y, false, B, T, F, Cin, Cout);
+}
+
+int mtl_conv3x3_relu_pool_fwd_h2(void* stream, const float* x, const float* amax_x, const void* w2_fwd, const float* bias,
+                                 float* p_out, unsigned char* argmax, float* amax_p, int B, int T, int F, int Cin, int Cout) {
+    return conv_fwd_pieces<2>(as_stream(stream), x, amax_x, w2_fwd, bias, p_out, argmax, amax_p, true, B, T, F, Cin, Cout);
+}
+
+int mtl_conv3x3_dgrad_h2(void* stream, const float* dy, const float* amax_dy, const unsigned char* argmax, const void* w2_dgrad,
+                         const float* act, float* dx, float* amax_dx, int B, int T, int F, int Cin, int Cout) {
+    return conv_dgrad_pieces<2>(as_stream(stream), dy, amax_dy, argmax, w2_dgrad, act, dx, amax_dx, B, T, F, Cin, Cout);
 }
 
 long mtl_conv3x3_wgrad_workspace(int B, int T, int F, int Cin, int Cout, int pooled) {
@@ -1697,9 +1853,13 @@ long mtl_conv3x3_wgrad_x3_workspace(int B, int T, int F, int Cin, int Cout, int 
     return (long)(wgrad_x3_grid(Cin, Cout) / npairs) * 9L * Cin * Cout * 4;
 }
 
-int mtl_conv3x3_wgrad_x3(void* stream, const float* x, const float* dy, const unsigned char* argmax, float* dw_ref,
-                         float* workspace, long workspace_bytes, int B, int T, int F, int Cin, int Cout) {
-    if (!x || !dy || !dw_ref || !workspace || Cin % 64 || Cout % 64) return MTL_EINVAL;
+}  // extern "C"
+
+template <int NP>
+static int wgrad_pieces(hipStream_t s, const float* x, const float* amax_x, const float* dy, const float* amax_dy,
+                        const unsigned char* argmax, float* dw_ref, float* workspace, long workspace_bytes, int B, int T, int F,
+                        int Cin, int Cout) {
+    if (!x || !dy || !dw_ref || !workspace || Cin % 64 || Cout % 64 || (NP == 2 && (!amax_x || !amax_dy))) return MTL_EINVAL;
     const int pooled = argmax != nullptr;
     if (workspace_bytes < mtl_conv3x3_wgrad_x3_workspace(B, T, F, Cin, Cout, pooled)) return MTL_EINVAL;
     WgradX3P p;
@@ -1722,23 +1882,37 @@ int mtl_conv3x3_wgrad_x3(void* stream, const float* x, const float* dy, const un
     p.ntt = (p.Ty + 7) / 8;
     p.tiles = p.ntf * p.ntt * B;
     p.dbg = 0;
+    p.amax_x = amax_x;
+    p.amax_dy = amax_dy;
     const int grid = wgrad_x3_grid(Cin, Cout);
-    hipStream_t s = as_stream(stream);
-    constexpr int SMEM = WX_SMEM;
+    constexpr int SMEM = wx_smem(NP);
     if (pooled) {
-        static int attr = set_smem(conv3x3_wgrad_x3_kernel<true>, SMEM);
+        static int attr = set_smem(conv3x3_wgrad_x3_kernel<true, NP>, SMEM);
         if (attr) return attr;
-        hipLaunchKernelGGL(conv3x3_wgrad_x3_kernel<true>, dim3(grid), dim3(512), SMEM, s, p);
+        hipLaunchKernelGGL((conv3x3_wgrad_x3_kernel<true, NP>), dim3(grid), dim3(512), SMEM, s, p);
     } else {
-        static int attr = set_smem(conv3x3_wgrad_x3_kernel<false>, SMEM);
+        static int attr = set_smem(conv3x3_wgrad_x3_kernel<false, NP>, SMEM);
         if (attr) return attr;
-        hipLaunchKernelGGL(conv3x3_wgrad_x3_kernel<false>, dim3(grid), dim3(512), SMEM, s, p);
+        hipLaunchKernelGGL((conv3x3_wgrad_x3_kernel<false, NP>), dim3(grid), dim3(512), SMEM, s, p);
     }
     MTL_CHECK_LAUNCH();
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(9L * Cin * Cout, 256)), dim3(256), 0, s, workspace, dw_ref,
                        grid / p.npairs, Cin, Cout);
     MTL_CHECK_LAUNCH();
     return MTL_OK;
+}
+
+extern "C" {
+
+int mtl_conv3x3_wgrad_x3(void* stream, const float* x, const float* dy, const unsigned char* argmax, float* dw_ref,
+                         float* workspace, long workspace_bytes, int B, int T, int F, int Cin, int Cout) {
+    return wgrad_pieces<3>(as_stream(stream), x, nullptr, dy, nullptr, argmax, dw_ref, workspace, workspace_bytes, B, T, F, Cin, Cout);
+}
+
+int mtl_conv3x3_wgrad_h2(void* stream, const float* x, const float* amax_x, const float* dy, const float* amax_dy,
+                         const unsigned char* argmax, float* dw_ref, float* workspace, long workspace_bytes, int B, int T, int F,
+                         int Cin, int Cout) {
+    return wgrad_pieces<2>(as_stream(stream), x, amax_x, dy, amax_dy, argmax, dw_ref, workspace, workspace_bytes, B, T, F, Cin, Cout);
 }
 
 }  // extern "C"

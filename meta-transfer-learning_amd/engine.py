@@ -225,7 +225,18 @@ class PassEngine:
         self.use_side_stream = True
         # 3x3 convolutions (forward and data gradient): '1' = exact 3-way bf16 split on the bf16 MFMA pipe (fp32-accurate, see
         # DESIGN.md 5.1), '0' = the fp32 MFMA kernels
-        self.conv_x3 = os.environ.get('MTL_CONV_X3', '1') != '0'
+        # 3x3 convolutions: 'h2' two fp16 pieces per fp32 operand (3 MFMAs per step, per-tensor power-of-two scaling from device
+        # scalars the producers deliver), 'x3' three exact bf16 pieces (6 MFMAs), 'f32' the fp32-MFMA engine
+        self.conv_mode = os.environ.get('MTL_CONV', 'h2' if os.environ.get('MTL_CONV_X3', '1') != '0' else 'f32')
+        if self.conv_mode not in ('h2', 'x3', 'f32'):
+            raise ValueError('MTL_CONV must be h2, x3 or f32')
+        self.conv_x3 = self.conv_mode != 'f32'
+        self.conv_h2 = self.conv_mode == 'h2'
+        # rank-r projection pairs W_b(W_a x) as ONE launch forward and ONE backward (intermediate in LDS; the backward reads transposed
+        # weight copies made once per pass).  Parity-green but SLOWER than the two batched GEMMs (40-100 us vs 2 x 8-17 us: one
+        # workgroup per 16-32 rows streams all 400 KB of both weights at the per-CU rate), so opt-in.
+        self.fused_pairs = os.environ.get('MTL_FUSED_PAIRS', '0') == '1'
+        self._tr_tables = {}
         self.batch_qkv = os.environ.get('MTL_BATCH_QKV', '1') != '0'   # q/k/v projections as strided-batch GEMMs
         self.wgrad_x3_dense = os.environ.get('MTL_WGRAD_X3_DENSE', '1') != '0'    # conv5 (dy not pooled)
         # scaled-dot-product attention as ONE flash-style kernel forward and two backward (no score tensor in HBM); head sizes
@@ -297,6 +308,34 @@ class PassEngine:
         ev = self._events[self._ev_next]
         self._ev_next = (self._ev_next + 1) % len(self._events)
         return ev.cuda_event
+
+    # ---- fused low-rank pairs
+    def pair_ok(self, k_in, n_out):
+        return self.fused_pairs and bool(self.lib.mtl_lowrank_supported(k_in, self.hp.r, n_out))
+
+    def pair(self, x, sx, ldx, A, sA, B, sB, bias, sbias, t, st, y, sy, ldy, M, k_in, n_out, n, sum_z=0, accum=0):
+        check(self.lib.mtl_lowrank_pair(self.stream, x, sx, ldx, A, sA, B, sB, bias, sbias, t, st, y, sy, ldy, M, k_in, self.hp.r, n_out,
+                                        n, sum_z, accum), 'mtl_lowrank_pair')
+
+    def transpose_lowrank_weights(self, theta):
+        """wT[off(name)] = theta[off(name)]^T for every `*_linear_a.weight` / `*_linear_b.weight` (same offsets, so the constant
+        strides between the Q / K / V parameters carry over): what the backward pair product multiplies with.  One launch per pass."""
+        wT = self.buf('wT', (self.L.total,))
+        key = (theta.data_ptr(), wT.data_ptr())
+        ent = self._tr_tables.get(key)
+        if ent is None:
+            names = [n for n in self.L.order if n.endswith('_linear_a.weight') or n.endswith('_linear_b.weight')]
+            table = (_lib.TransposeDesc * max(len(names), 1))()
+            for i, n in enumerate(names):
+                off, shape, _ = self.L.entries[n]
+                table[i].src, table[i].dst = theta.data_ptr() + 4 * off, wT.data_ptr() + 4 * off
+                table[i].rows, table[i].cols = shape[0], shape[1]
+            dev = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8).to(self.device)
+            ent = (dev, len(names))
+            self._tr_tables[key] = ent
+        if ent[1]:
+            check(self.lib.mtl_transpose_batch(self.stream, ent[0].data_ptr(), ent[1]), 'mtl_transpose_batch')
+        return wT
 
     # ---- grouped weight gradients
     def wgrad(self, dy, x, rows, n_out, k_in, dw, db=None):
@@ -377,9 +416,9 @@ class PassEngine:
             self.gemm(0, 0, rows, k_in, n_out, dy, n_out, w, k_in, dx, k_in, gate=gate, ldg=k_in,
                       flags=ACCUM if dx_accum else 0)
 
-    def colsum(self, x, rows, cols, out):
+    def colsum(self, x, rows, cols, out, amax=None):
         ws = self.scratch(self.lib.mtl_colsum_workspace(rows, cols))
-        check(self.lib.mtl_colsum_accum(self.stream, x, rows, cols, cols, out, ws), 'mtl_colsum_accum')
+        check(self.lib.mtl_colsum_accum(self.stream, x, rows, cols, cols, out, ws, amax), 'mtl_colsum_accum')
 
     def drop_mask(self, name, shape):
         """u8 keep-mask for one dropout site of this pass (None when dropout is off); fresh Philox stream per site."""
@@ -423,10 +462,14 @@ class PassEngine:
             a_all = self.buf(tag + names + 'a', (n, rows, r))
             b_all = self.buf(tag + names, (n, rows, wd))
             sa, sb, sbias = (self._pstride(pre, names, sfx) for sfx in ('_linear_a.weight', '_linear_b.weight', '_linear_b.bias'))
-            self.gemm(0, 1, rows, r, d, src, d, o(f0 + '_linear_a.weight'), d, a_all.data_ptr(), r, batch=n, sB=(sa, 0),
-                      sC=(rows * r, 0))
-            self.gemm(0, 1, rows, wd, r, a_all.data_ptr(), r, o(f0 + '_linear_b.weight'), r, b_all.data_ptr(), wd,
-                      bias=o(f0 + '_linear_b.bias'), batch=n, sA=(rows * r, 0), sB=(sb, 0), sC=(rows * wd, 0), sbias=sbias)
+            if self.pair_ok(d, wd):
+                self.pair(src, 0, d, o(f0 + '_linear_a.weight'), sa, o(f0 + '_linear_b.weight'), sb, o(f0 + '_linear_b.bias'), sbias,
+                          a_all.data_ptr(), rows * r, b_all.data_ptr(), rows * wd, wd, rows, d, wd, n)
+            else:
+                self.gemm(0, 1, rows, r, d, src, d, o(f0 + '_linear_a.weight'), d, a_all.data_ptr(), r, batch=n, sB=(sa, 0),
+                          sC=(rows * r, 0))
+                self.gemm(0, 1, rows, wd, r, a_all.data_ptr(), r, o(f0 + '_linear_b.weight'), r, b_all.data_ptr(), wd,
+                          bias=o(f0 + '_linear_b.bias'), batch=n, sA=(rows * r, 0), sB=(sb, 0), sC=(rows * wd, 0), sbias=sbias)
             for i, nm in enumerate(names):
                 self.arena[tag + nm + 'a'], self.arena[tag + nm] = a_all[i], b_all[i]
                 t[nm + 'a'], t[nm] = a_all[i], b_all[i]
@@ -452,8 +495,12 @@ class PassEngine:
         self.arena[tag + 'attn'] = (klen, causal)
         oa = self.buf(tag + 'oa', (Mq, r))
         ob = self.buf(tag + 'ob', (Mq, d))
-        self.linear_fwd(O.data_ptr(), Mq, hv, o('output_linear_a.weight'), None, oa.data_ptr(), r)
-        self.linear_fwd(oa.data_ptr(), Mq, r, o('output_linear_b.weight'), o('output_linear_b.bias'), ob.data_ptr(), d)
+        if self.pair_ok(hv, d):
+            self.pair(O.data_ptr(), 0, hv, o('output_linear_a.weight'), 0, o('output_linear_b.weight'), 0, o('output_linear_b.bias'), 0,
+                      oa.data_ptr(), 0, ob.data_ptr(), 0, d, Mq, hv, d, 1)
+        else:
+            self.linear_fwd(O.data_ptr(), Mq, hv, o('output_linear_a.weight'), None, oa.data_ptr(), r)
+            self.linear_fwd(oa.data_ptr(), Mq, r, o('output_linear_b.weight'), o('output_linear_b.bias'), ob.data_ptr(), d)
         y = self.buf(tag + 'y', (Mq, d))
         xhat = self.buf(tag + 'xhat', (Mq, d))
         rstd = self.buf(tag + 'rstd', (Mq,))
@@ -481,11 +528,19 @@ class PassEngine:
                     dzm=dzm.data_ptr() if dzm is not None else None, dz2=dxq)        # dxq = dz: the residual path
         dz = dzm.data_ptr() if dzm is not None else dzb.data_ptr()          # gradient of the (dropped) sub-layer branch
         doa = self.buf(tag + '_doa', (Mq, r))
-        self.linear_bwd(oa.data_ptr(), dz, Mq, r, d, o('output_linear_b.weight'), g('output_linear_b.weight'),
-                        None, doa.data_ptr(), False)
         dO = self.buf(tag + '_dO', (Mq, hv))
-        self.linear_bwd(O.data_ptr(), doa.data_ptr(), Mq, hv, r, o('output_linear_a.weight'), g('output_linear_a.weight'),
-                        None, dO.data_ptr(), False)
+        if self.pair_ok(d, hv):
+            wt = lambda n: self._wT + 4 * L.off(pre + n)
+            self.wgrad(dz, oa.data_ptr(), Mq, d, r, g('output_linear_b.weight'))
+            # dO = (dz . W_ob) . W_oa  through the transposed copies; doa is stored for the weight gradient of the a-stage
+            self.pair(dz, 0, d, wt('output_linear_b.weight'), 0, wt('output_linear_a.weight'), 0, None, 0, doa.data_ptr(), 0,
+                      dO.data_ptr(), 0, hv, Mq, d, hv, 1)
+            self.wgrad(doa.data_ptr(), O.data_ptr(), Mq, r, hv, g('output_linear_a.weight'))
+        else:
+            self.linear_bwd(oa.data_ptr(), dz, Mq, r, d, o('output_linear_b.weight'), g('output_linear_b.weight'),
+                            None, doa.data_ptr(), False)
+            self.linear_bwd(O.data_ptr(), doa.data_ptr(), Mq, hv, r, o('output_linear_a.weight'), g('output_linear_a.weight'),
+                            None, dO.data_ptr(), False)
         q, k, v = A[tag + 'q'], A[tag + 'k'], A[tag + 'v']
         groups = A[tag + 'groups']
         dfull = {}                                       # gradients of the projected q / k / v, grouped like the forward
@@ -537,9 +592,10 @@ class PassEngine:
                 self.defer(lambda n=n, f0=f0, rows=rows, a_ptr=a_ptr, d_ptr=d_ptr, sb=sb, sbias=sbias, wd=wd: self.gemm(
                     1, 0, wd, r, rows, d_ptr, wd, a_ptr, r, g(f0 + '_linear_b.weight'), r, flags=ACCUM, batch=n, sA=(rows * wd, 0),
                     sB=(rows * r, 0), sC=(sb, 0), rowsum=g(f0 + '_linear_b.bias'), srow=sbias))
-            # da[i] = d[i] . W_b[i]
-            self.gemm(0, 0, rows, r, wd, d_ptr, wd, o(f0 + '_linear_b.weight'), r, da_ptr, r, batch=n, sA=(rows * wd, 0),
-                      sB=(sb, 0), sC=(rows * r, 0))
+            fused = self.pair_ok(wd, d)
+            if not fused:     # da[i] = d[i] . W_b[i]
+                self.gemm(0, 0, rows, r, wd, d_ptr, wd, o(f0 + '_linear_b.weight'), r, da_ptr, r, batch=n, sA=(rows * wd, 0),
+                          sB=(sb, 0), sC=(rows * r, 0))
 
             # dW_a[i] += da[i]^T x
             if self.group_wgrads:
@@ -554,8 +610,13 @@ class PassEngine:
             else:
                 dst, accum = dxkv, (dxkv_accum or (dxkv == dxq) or kv_written)
                 kv_written = True
-            self.gemm(0, 0, rows, d, r, da_ptr, r, o(f0 + '_linear_a.weight'), d, dst, d, flags=ACCUM if accum else 0,
-                      kbatch=n, sAk=rows * r, sBk=sa)
+            if fused:         # dst (+)= sum_i (d[i] . W_b[i]) . W_a[i] in one launch; da[i] stored for the a-stage weight gradients
+                self.pair(d_ptr, rows * wd, wd, self._wT + 4 * L.off(pre + f0 + '_linear_b.weight'), sb,
+                          self._wT + 4 * L.off(pre + f0 + '_linear_a.weight'), sa, None, 0, da_ptr, rows * r, dst, 0, d, rows, wd, d, n,
+                          sum_z=1, accum=1 if accum else 0)
+            else:
+                self.gemm(0, 0, rows, d, r, da_ptr, r, o(f0 + '_linear_a.weight'), d, dst, d, flags=ACCUM if accum else 0,
+                          kbatch=n, sAk=rows * r, sBk=sa)
         self.flush_side()
 
     def _pstride(self, pre, names, suffix):
@@ -714,32 +775,50 @@ class PassEngine:
 
         # ---- VGG front-end ----
         y1 = self.buf('y1', (B, T, F, 64))
+        x3, h2 = self.conv_x3, self.conv_h2
+        # h2: device scalars max|tensor| (upper bounds) of y1, p1, y5 | dp2, dy5, dp1 -- raised by the producers' epilogues
+        # (forward) or written by the bias-gradient column sums (backward)
+        amax = self.buf('amax', (8,))
+        am_ = (lambda i: amax.data_ptr() + 4 * i) if h2 else (lambda i: None)
+        if h2:
+            check(lib.mtl_memset_zero(st, amax.data_ptr(), 32), 'mtl_memset_zero')
         check(lib.mtl_conv0_relu_fwd(st, x.data_ptr(), o('conv.0.weight'),
-                         o('conv.0.bias'), y1.data_ptr(), B, T, F), 'conv0')
+                         o('conv.0.bias'), y1.data_ptr(), B, T, F, am_(0)), 'conv0')
         wf, wd = {}, {}
-        x3 = self.conv_x3
-        wprep = lib.mtl_conv3x3_wprep_x3 if x3 else lib.mtl_conv3x3_wprep
-        conv_fwd = lib.mtl_conv3x3_relu_fwd_x3 if x3 else lib.mtl_conv3x3_relu_fwd
-        conv_fwd_pool = lib.mtl_conv3x3_relu_pool_fwd_x3 if x3 else lib.mtl_conv3x3_relu_pool_fwd
+        wprep = lib.mtl_conv3x3_wprep_h2 if h2 else (lib.mtl_conv3x3_wprep_x3 if x3 else lib.mtl_conv3x3_wprep)
+        if h2:
+            conv_fwd = lambda s_, x_, w_, b_, y_, ai, ao, *dims: lib.mtl_conv3x3_relu_fwd_h2(s_, x_, am_(ai), w_, b_, y_, am_(ao), *dims)
+            conv_fwd_pool = lambda s_, x_, w_, b_, y_, a_, ai, ao, *dims: lib.mtl_conv3x3_relu_pool_fwd_h2(
+                s_, x_, am_(ai), w_, b_, y_, a_, am_(ao) if ao is not None else None, *dims)
+        else:
+            f1 = lib.mtl_conv3x3_relu_fwd_x3 if x3 else lib.mtl_conv3x3_relu_fwd
+            f2 = lib.mtl_conv3x3_relu_pool_fwd_x3 if x3 else lib.mtl_conv3x3_relu_pool_fwd
+            conv_fwd = lambda s_, x_, w_, b_, y_, ai, ao, *dims: f1(s_, x_, w_, b_, y_, *dims)
+            conv_fwd_pool = lambda s_, x_, w_, b_, y_, a_, ai, ao, *dims: f2(s_, x_, w_, b_, y_, a_, *dims)
         for idx, cin, cout in ((2, 64, 64), (5, 64, 128), (7, 128, 128)):
-            if x3:      # three exact bf16 pieces of every weight, [piece][tap][cin/32][cout][32]
+            if h2:      # two fp16 pieces of every (scaled) weight + the scale
+                nb = lib.mtl_conv3x3_wprep_h2_bytes(cout, cin)
+                wf[idx] = self.buf('wf%d' % idx, (nb,), torch.uint8)
+                wd[idx] = self.buf('wd%d' % idx, (nb,), torch.uint8)
+            elif x3:    # three exact bf16 pieces of every weight, [piece][tap][cin/32][cout][32]
                 wf[idx] = self.buf('wf%d' % idx, (3, 9, cin, cout), torch.bfloat16)
                 wd[idx] = self.buf('wd%d' % idx, (3, 9, cout, cin), torch.bfloat16)
             else:
                 wf[idx] = self.buf('wf%d' % idx, (9, cin, cout))
                 wd[idx] = self.buf('wd%d' % idx, (9, cout, cin))
             check(wprep(st, o('conv.%d.weight' % idx), wf[idx].data_ptr(), wd[idx].data_ptr(), cout, cin), 'wprep')
+        self._wT = self.transpose_lowrank_weights(theta).data_ptr() if self.fused_pairs else None
         p1 = self.buf('p1', (B, T2, F2, 64))
         am1 = self.buf('am1', (B, T2, F2, 64), torch.uint8)
         check(conv_fwd_pool(st, y1.data_ptr(), wf[2].data_ptr(),
-                         o('conv.2.bias'), p1.data_ptr(), am1.data_ptr(), B, T, F, 64, 64), 'conv2')
+                         o('conv.2.bias'), p1.data_ptr(), am1.data_ptr(), 0, 1, B, T, F, 64, 64), 'conv2')
         y5 = self.buf('y5', (B, T2, F2, 128))
         check(conv_fwd(st, p1.data_ptr(), wf[5].data_ptr(),
-                         o('conv.5.bias'), y5.data_ptr(), B, T2, F2, 64, 128), 'conv5')
+                         o('conv.5.bias'), y5.data_ptr(), 1, 2, B, T2, F2, 64, 128), 'conv5')
         p2 = self.buf('p2', (B, T4, F4, 128))
         am2 = self.buf('am2', (B, T4, F4, 128), torch.uint8)
         check(conv_fwd_pool(st, y5.data_ptr(), wf[7].data_ptr(),
-                         o('conv.7.bias'), p2.data_ptr(), am2.data_ptr(), B, T2, F2, 128, 128), 'conv7')
+                         o('conv.7.bias'), p2.data_ptr(), am2.data_ptr(), 2, None, B, T2, F2, 128, 128), 'conv7')
 
         if self.after_conv_hook is not None:      # lets the trainer de-phase concurrent task lanes (see trainer.meta_iteration)
             hook, self.after_conv_hook = self.after_conv_hook, None
@@ -949,31 +1028,42 @@ class PassEngine:
 
         self.flush_wgrads()        # every small dW of the transformer half: one grouped launch, overlapping the VGG backward
         # ---- VGG front-end ----
-        conv_dgrad = lib.mtl_conv3x3_dgrad_x3 if self.conv_x3 else lib.mtl_conv3x3_dgrad
+        h2 = self.conv_h2
+        amax = A['amax']
+        am_ = (lambda i: amax.data_ptr() + 4 * i) if h2 else (lambda i: None)      # slots: y1, p1, y5 | dp2, dy5, dp1
+        dgrad_fn = lib.mtl_conv3x3_dgrad_x3 if self.conv_x3 else lib.mtl_conv3x3_dgrad
 
-        def wgrad(xa, dy, am, idx, Bq, Tq, Fq, cin, cout):
+        def conv_dgrad(dy, ai, am, w, act, dx, *dims):
+            if h2:
+                return lib.mtl_conv3x3_dgrad_h2(st, dy, am_(ai), am, w, act, dx, None, *dims)
+            return dgrad_fn(st, dy, am, w, act, dx, *dims)
+
+        def wgrad(xa, axi, dy, adi, am, idx, Bq, Tq, Fq, cin, cout):
             x3 = self.conv_x3 and (am is not None or self.wgrad_x3_dense)
-            wsfn, fn = ((lib.mtl_conv3x3_wgrad_x3_workspace, lib.mtl_conv3x3_wgrad_x3) if x3 else
-                        (lib.mtl_conv3x3_wgrad_workspace, lib.mtl_conv3x3_wgrad))
+            wsfn = lib.mtl_conv3x3_wgrad_x3_workspace if x3 else lib.mtl_conv3x3_wgrad_workspace
             need = wsfn(Bq, Tq, Fq, cin, cout, 1 if am else 0)
             ws = self.scratch(need)
-            check(fn(st, xa, dy, am,
-                             g('conv.%d.weight' % idx), ws, need, Bq, Tq, Fq, cin, cout), 'wgrad')
+            if x3 and h2:
+                rc = lib.mtl_conv3x3_wgrad_h2(st, xa, am_(axi), dy, am_(adi), am, g('conv.%d.weight' % idx), ws, need, Bq, Tq, Fq, cin, cout)
+            else:
+                fn = lib.mtl_conv3x3_wgrad_x3 if x3 else lib.mtl_conv3x3_wgrad
+                rc = fn(st, xa, dy, am, g('conv.%d.weight' % idx), ws, need, Bq, Tq, Fq, cin, cout)
+            check(rc, 'wgrad')
 
-        self.colsum(dp2.data_ptr(), B * T4 * F4, 128, g('conv.7.bias'))
-        wgrad(y5.data_ptr(), dp2.data_ptr(), A['am2'].data_ptr(), 7, B, T2, F2, 128, 128)
+        self.colsum(dp2.data_ptr(), B * T4 * F4, 128, g('conv.7.bias'), am_(3))
+        wgrad(y5.data_ptr(), 2, dp2.data_ptr(), 3, A['am2'].data_ptr(), 7, B, T2, F2, 128, 128)
         dy5 = self.buf('_dy5', (B, T2, F2, 128))
-        check(conv_dgrad(st, dp2.data_ptr(), A['am2'].data_ptr(),
+        check(conv_dgrad(dp2.data_ptr(), 3, A['am2'].data_ptr(),
                          A['wd7'].data_ptr(), y5.data_ptr(), dy5.data_ptr(), B, T2, F2, 128, 128), 'dgrad7')
-        self.colsum(dy5.data_ptr(), B * T2 * F2, 128, g('conv.5.bias'))
-        wgrad(p1.data_ptr(), dy5.data_ptr(), None, 5, B, T2, F2, 64, 128)
+        self.colsum(dy5.data_ptr(), B * T2 * F2, 128, g('conv.5.bias'), am_(4))
+        wgrad(p1.data_ptr(), 1, dy5.data_ptr(), 4, None, 5, B, T2, F2, 64, 128)
         dp1 = self.buf('_dp1', (B, T2, F2, 64))
-        check(conv_dgrad(st, dy5.data_ptr(), None, A['wd5'].data_ptr(),
+        check(conv_dgrad(dy5.data_ptr(), 4, None, A['wd5'].data_ptr(),
                          p1.data_ptr(), dp1.data_ptr(), B, T2, F2, 64, 128), 'dgrad5')
-        self.colsum(dp1.data_ptr(), B * T2 * F2, 64, g('conv.2.bias'))
-        wgrad(y1.data_ptr(), dp1.data_ptr(), A['am1'].data_ptr(), 2, B, T, F, 64, 64)
+        self.colsum(dp1.data_ptr(), B * T2 * F2, 64, g('conv.2.bias'), am_(5))
+        wgrad(y1.data_ptr(), 0, dp1.data_ptr(), 5, A['am1'].data_ptr(), 2, B, T, F, 64, 64)
         dy1 = self.buf('_dy1', (B, T, F, 64))
-        check(conv_dgrad(st, dp1.data_ptr(), A['am1'].data_ptr(),
+        check(conv_dgrad(dp1.data_ptr(), 5, A['am1'].data_ptr(),
                          A['wd2'].data_ptr(), y1.data_ptr(), dy1.data_ptr(), B, T, F, 64, 64), 'dgrad2')
         ws = self.scratch(lib.mtl_conv0_wgrad_workspace())
         check(lib.mtl_conv0_wgrad(st, S['x'].data_ptr(), dy1.data_ptr(),

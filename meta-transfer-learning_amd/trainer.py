@@ -548,6 +548,7 @@ class TransientTrainer():
         """The timed body of one meta-iteration (transient_trainer.py:152-264): local tasks, ONE all-reduce of G, Adam,
         then a single device sync to resolve the loss / label read-backs.  -> (sum val loss, CER edits, chars), global."""
         dev = model.flat_parameters.device
+        t_host = time.perf_counter()
         outer_opt.zero_grad()
         reads = self.meta_iteration(model, vocab, task_batches, val_data, n_tasks, inner_opt, outer_opt, args)
         G = model._G
@@ -555,6 +556,7 @@ class TransientTrainer():
         if args.clip:
             clip_flat_grad_(model, G, args.max_norm)             # (:253-254) on the summed meta-gradient
         outer_opt.step(G)                                        # from_copy_grad() + outer_opt.step()  (:248-255)
+        self.host_enqueue_s = time.perf_counter() - t_host       # host side of the iteration (diagnostics: bench.py reports it)
         torch.cuda.synchronize(dev)
         total_loss, total_cer, total_char = 0.0, 0, 0
         for tr_read, va_read in reads:

@@ -173,6 +173,65 @@ def test_gemm_k_batching_and_row_sums(L):
                              1, 1, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, Wview, 0, None, 0) == -22      # row sums need transA
 
 
+@pytest.mark.parametrize('M,Kin,r,N,n', [(808, 512, 100, 512, 3), (2000, 512, 100, 512, 3), (37, 128, 100, 128, 2), (101, 512, 16, 200, 1),
+                                         (250, 128, 100, 136, 1)])
+def test_fused_low_rank_pair(L, M, Kin, r, N, n):
+    """mtl_lowrank_pair: y_z = (x . A_z^T) . B_z^T + b_z for z strided pairs in one launch (the Q / K / V projections with their
+    parameters at a constant stride in a flat buffer), the stored intermediate, and the SUM mode on transposed weight copies
+    (mtl_transpose_batch) = the backward data path dx += sum_z (dy_z . W_b,z) . W_a,z; against torch, bitwise repeatable."""
+    import mtl_amd
+    g = torch.Generator().manual_seed(M + Kin + r + N + n)
+    stride = r * Kin + N * r + N + 40                                        # A_z, B_z, bias_z and something else, like the flat theta
+    theta = torch.randn(n * stride, generator=g) * 0.1
+    Az = [theta[z * stride: z * stride + r * Kin].view(r, Kin) for z in range(n)]
+    Bz = [theta[z * stride + r * Kin: z * stride + r * Kin + N * r].view(N, r) for z in range(n)]
+    bz = [theta[z * stride + r * Kin + N * r: z * stride + r * Kin + N * r + N] for z in range(n)]
+    x = torch.randn(M, Kin, generator=g)
+    dth, dx_ = dev(theta), dev(x)
+    outs = []
+    for _ in range(2):
+        t = torch.full((n, M, r), float('nan')).cuda()
+        y = torch.full((n, M, N), float('nan')).cuda()
+        assert L.mtl_lowrank_pair(st(), dx_.data_ptr(), 0, Kin, dth.data_ptr(), stride, dth.data_ptr() + 4 * r * Kin, stride,
+                                  dth.data_ptr() + 4 * (r * Kin + N * r), stride, t.data_ptr(), M * r, y.data_ptr(), M * N, N, M, Kin, r, N,
+                                  n, 0, 0) == 0
+        outs.append((t.cpu(), y.cpu()))
+    for z in range(n):
+        t_ref = x.double() @ Az[z].double().t()
+        assert rel(outs[0][0][z], t_ref) < 2e-6
+        assert rel(outs[0][1][z], t_ref @ Bz[z].double().t() + bz[z].double()) < 3e-6
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    # backward data path: dx0 + sum_z (dy_z . B_z) . A_z  through transposed copies laid out at the SAME offsets as the originals
+    dy = torch.randn(n, M, N, generator=g)
+    dx0 = torch.randn(M, Kin, generator=g)
+    wT = torch.zeros_like(dth)
+    table = (mtl_amd._lib.TransposeDesc * (2 * n))()
+    for z in range(n):
+        oa, ob = z * stride, z * stride + r * Kin
+        table[2 * z].src, table[2 * z].dst, table[2 * z].rows, table[2 * z].cols = dth.data_ptr() + 4 * oa, wT.data_ptr() + 4 * oa, r, Kin
+        table[2 * z + 1].src, table[2 * z + 1].dst = dth.data_ptr() + 4 * ob, wT.data_ptr() + 4 * ob
+        table[2 * z + 1].rows, table[2 * z + 1].cols = N, r
+    tdev = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8).cuda()
+    assert L.mtl_transpose_batch(st(), tdev.data_ptr(), 2 * n) == 0
+    wTc = wT.cpu()
+    assert torch.equal(wTc[:r * Kin].view(Kin, r), Az[0].t().contiguous()) and torch.equal(wTc[r * Kin: r * Kin + N * r].view(r, N), Bz[0].t().contiguous())
+    if N % 4 == 0:
+        ddy = dev(dy)
+        ref = dx0.double() + sum((dy[z].double() @ Bz[z].double()) @ Az[z].double() for z in range(n))
+        res = []
+        for _ in range(2):
+            dxo, da = dev(dx0.clone()), torch.full((n, M, r), float('nan')).cuda()
+            # x := dy_z (M x N), "A" := B_z^T (r x N) at the b-offset of wT, "B" := A_z^T (Kin x r) at the a-offset of wT
+            assert L.mtl_lowrank_pair(st(), ddy.data_ptr(), M * N, N, wT.data_ptr() + 4 * r * Kin, stride, wT.data_ptr(), stride, None, 0,
+                                      da.data_ptr(), M * r, dxo.data_ptr(), 0, Kin, M, N, r, Kin, n, 1, 1) == 0
+            res.append((dxo.cpu(), da.cpu()))
+        assert rel(res[0][0], ref) < 3e-6 and torch.equal(res[0][0], res[1][0])
+        for z in range(n):
+            assert rel(res[0][1][z], dy[z].double() @ Bz[z].double()) < 2e-6
+    assert L.mtl_lowrank_pair(st(), dx_.data_ptr(), 0, Kin, dth.data_ptr(), stride, dth.data_ptr(), stride, None, 0, None, 0,
+                              dx_.data_ptr(), 0, N, M, Kin, 108, N, 1, 0, 0) == -22                      # rank beyond the LDS tile
+
+
 def test_grouped_weight_gradients(L):
     """mtl_gemm_wgrad_grouped: ONE launch for a table of independent dW_i += dy_i^T x_i (+ db_i += colsum(dy_i)) products of
     different shapes -- every small weight gradient of a backward pass -- against torch, bitwise repeatable"""
@@ -276,8 +335,10 @@ def test_conv0(L, B, T, Fq):
     ref = torch.relu(F.conv2d(x, w, b, padding=1))
     dx, dw, db = dev(x), dev(w), dev(b)
     y = torch.empty(B, T, Fq, 64).cuda()
-    assert L.mtl_conv0_relu_fwd(st(), dx.data_ptr(), dw.data_ptr(), db.data_ptr(), y.data_ptr(), B, T, Fq) == 0
+    amax = torch.zeros(1).cuda()
+    assert L.mtl_conv0_relu_fwd(st(), dx.data_ptr(), dw.data_ptr(), db.data_ptr(), y.data_ptr(), B, T, Fq, amax.data_ptr()) == 0
     assert rel(from_nhwc(y), ref) < 2e-6
+    assert float(amax) == float(y.max())                                        # the scalar a following h2 convolution scales by
     dy = torch.randn(B, 64, Fq, T, generator=g)
     wg = torch.zeros(64, 1, 3, 3).cuda()
     bg = torch.zeros(64).cuda()
@@ -618,7 +679,7 @@ def test_flat_updates_colsum_permute(L):
     out = torch.ones(100).cuda()
     ws = torch.empty(L.mtl_colsum_workspace(5000, 100) // 4).cuda()
     dX = dev(X)
-    assert L.mtl_colsum_accum(st(), dX.data_ptr(), 5000, 100, 100, out.data_ptr(), ws.data_ptr()) == 0
+    assert L.mtl_colsum_accum(st(), dX.data_ptr(), 5000, 100, 100, out.data_ptr(), ws.data_ptr(), None) == 0
     assert rel(out, X.sum(0) + 1) < 1e-5
     # (c,h) <-> (h,c) permutation of input_linear columns
     rows, C, H = 7, 128, 5
@@ -697,6 +758,130 @@ def test_conv3x3_split_bf16_matches_fp32_reference(L, Cin, Cout, B, T, Fq):
     dyn = dev(nhwc(dy * (y2.detach() > 0)))
     assert L.mtl_conv3x3_dgrad_x3(st(), dyn.data_ptr(), None, w3d.data_ptr(), dxn.data_ptr(), dx.data_ptr(), B, T, Fq, Cin, Cout) == 0
     assert rel(from_nhwc(dx), xr2.grad * (x > 0)) < 1e-5
+
+
+@pytest.mark.parametrize('Cin,Cout,B,T,Fq', [(64, 64, 2, 21, 161), (64, 128, 2, 18, 80), (128, 128, 1, 9, 19)])
+@pytest.mark.parametrize('mag', [1.0, 3e-7, 4e5])
+def test_conv3x3_two_piece_fp16_is_fp32_class(L, Cin, Cout, B, T, Fq, mag):
+    """the "h2" kernels (2-way fp16 split of power-of-two-scaled operands, three fp16 MFMAs per product): measured against an
+    fp64 convolution their error is that of the exact-fp32 MFMA kernels of this library on the same data (0.9x forward, at most
+    1.6x on the sparse pooled gradients; both are dominated by the fp32 accumulation chain, the split itself is good to 2^-22)
+    and below 1e-6 normwise, at any operand magnitude and with loose amax bounds: forward, fused pool, both dgrads, both wgrads."""
+    g = torch.Generator().manual_seed(Cin + Cout + T + 2)
+    x = torch.relu(torch.randn(B, Cin, Fq, T, generator=g)) * mag
+    x[0, 0, 0, 0] = 40.0 * mag                                 # an outlier 10x above the bulk: small values keep their bits
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * (1.0 / np.sqrt(9 * Cin))
+    b = torch.randn(Cout, generator=g) * 0.1 * mag
+    x64, w64 = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    y64 = torch.relu(F.conv2d(x64, w64, b.double(), padding=1))
+    p64, idx = F.max_pool2d(y64, 2, stride=2, return_indices=True)
+    dxn, dw, db = dev(nhwc(x)), dev(w), dev(b)
+    wf, wd = torch.empty(9, Cin, Cout).cuda(), torch.empty(9, Cout, Cin).cuda()
+    assert L.mtl_conv3x3_wprep(st(), dw.data_ptr(), wf.data_ptr(), wd.data_ptr(), Cout, Cin) == 0
+    nb = L.mtl_conv3x3_wprep_h2_bytes(Cout, Cin)
+    w2f, w2d = torch.empty(nb, dtype=torch.uint8).cuda(), torch.empty(nb, dtype=torch.uint8).cuda()
+    assert L.mtl_conv3x3_wprep_h2(st(), dw.data_ptr(), w2f.data_ptr(), w2d.data_ptr(), Cout, Cin) == 0
+    # the two pieces re-assemble every weight to 2^-21 of the largest; the trailer is the power-of-two scale
+    nw = 2 * 9 * Cin * Cout * 2
+    scale = float(w2f[nw:nw + 4].view(torch.float32))
+    assert 2 ** 14 <= float(w.abs().max()) * scale < 2 ** 15 and np.log2(scale) == int(np.log2(scale))
+    pieces = (w2f[:nw].view(torch.float16).view(2, 9, Cin // 32, Cout, 4, 8).double().sum(0) / scale).cpu()
+    unsw = torch.empty_like(pieces)
+    for co in range(Cout):
+        for c in range(4):
+            unsw[:, :, co, c] = pieces[:, :, co, c ^ ((co >> 2) & 3)]
+    wt = w.double().reshape(Cout, Cin // 32, 32, 9).permute(3, 1, 0, 2)
+    assert float((unsw.reshape(9, Cin // 32, Cout, 32) - wt).abs().max()) <= 2.0 ** -21 * float(w.abs().max())
+    ax = dxn.abs().max().reshape(1).clone()
+    slots = torch.zeros(4).cuda()
+    report = []
+
+    def cmp(what, got_h2, got_f32, want):
+        e2, e32 = rel(got_h2.double().cpu(), want.detach()), rel(got_f32.double().cpu(), want.detach())
+        report.append('%s: h2 %.2e, fp32 MFMA kernel %.2e' % (what, e2, e32))
+        assert e2 < 2.0 * e32 + 1e-30 and e2 < 1e-6, report
+
+    y, yf = torch.empty(B, T, Fq, Cout).cuda(), torch.empty(B, T, Fq, Cout).cuda()
+    assert L.mtl_conv3x3_relu_fwd(st(), dxn.data_ptr(), wf.data_ptr(), db.data_ptr(), yf.data_ptr(), B, T, Fq, Cin, Cout) == 0
+    assert L.mtl_conv3x3_relu_fwd_h2(st(), dxn.data_ptr(), ax.data_ptr(), w2f.data_ptr(), db.data_ptr(), y.data_ptr(),
+                                     slots.data_ptr(), B, T, Fq, Cin, Cout) == 0
+    cmp('fwd', from_nhwc(y), from_nhwc(yf), y64)
+    assert float(y.max()) <= float(slots[0]) <= 8.0 * float(y.max())     # amax_y: an upper bound (max|acc| + max|bias|) within a few bits
+    loose = ax * 64.0                                                      # a bound 6 bits too high costs nothing
+    y2 = torch.empty_like(y)
+    assert L.mtl_conv3x3_relu_fwd_h2(st(), dxn.data_ptr(), loose.data_ptr(), w2f.data_ptr(), db.data_ptr(), y2.data_ptr(), None, B, T, Fq,
+                                     Cin, Cout) == 0
+    cmp('fwd, amax x64', from_nhwc(y2), from_nhwc(yf), y64)
+    Tp, Fp = T // 2, Fq // 2
+    p, pf = torch.empty(B, Tp, Fp, Cout).cuda(), torch.empty(B, Tp, Fp, Cout).cuda()
+    am, amf = torch.empty(B, Tp, Fp, Cout, dtype=torch.uint8).cuda(), torch.empty(B, Tp, Fp, Cout, dtype=torch.uint8).cuda()
+    assert L.mtl_conv3x3_relu_pool_fwd(st(), dxn.data_ptr(), wf.data_ptr(), db.data_ptr(), pf.data_ptr(), amf.data_ptr(), B, T, Fq, Cin, Cout) == 0
+    assert L.mtl_conv3x3_relu_pool_fwd_h2(st(), dxn.data_ptr(), ax.data_ptr(), w2f.data_ptr(), db.data_ptr(), p.data_ptr(),
+                                          am.data_ptr(), slots[1:].data_ptr(), B, T, Fq, Cin, Cout) == 0
+    cmp('pool', from_nhwc(p), from_nhwc(pf), p64)
+    assert float(p.max()) <= float(slots[1])
+    amc = from_nhwc(am).long().cpu()
+    flat = (torch.arange(Fp).view(1, 1, Fp, 1) * 2 + (amc >> 1)) * T + torch.arange(Tp).view(1, 1, 1, Tp) * 2 + (amc & 1)
+    mism = flat != idx
+    if int(mism.sum()):      # arg-max decisions equal the fp64 ones except where the two candidates tie to fp32 precision
+        ydense = y64.detach().reshape(B, Cout, -1)
+        a = torch.gather(ydense, 2, flat.reshape(B, Cout, -1))
+        bb = torch.gather(ydense, 2, idx.reshape(B, Cout, -1))
+        assert float(((a - bb).abs() / (bb.abs() + 1e-30))[mism.reshape(B, Cout, -1)].max()) < 1e-5
+    gate = (x > 0).double()
+    dx, dxf = torch.empty(B, T, Fq, Cin).cuda(), torch.empty(B, T, Fq, Cin).cuda()
+    if int(mism.sum()) == 0:      # pooled backward (needs identical pooling decisions to have ONE truth)
+        dp = torch.randn(p64.shape, generator=g) * 1e-3 * mag
+        p64.backward(dp.double(), retain_graph=True)
+        dpn = dev(nhwc(dp * (p64.detach() > 0).float()))
+        adp = dpn.abs().max().reshape(1).clone()
+        assert L.mtl_conv3x3_dgrad(st(), dpn.data_ptr(), am.data_ptr(), wd.data_ptr(), dxn.data_ptr(), dxf.data_ptr(), B, T, Fq, Cin, Cout) == 0
+        assert L.mtl_conv3x3_dgrad_h2(st(), dpn.data_ptr(), adp.data_ptr(), am.data_ptr(), w2d.data_ptr(), dxn.data_ptr(), dx.data_ptr(),
+                                      None, B, T, Fq, Cin, Cout) == 0
+        cmp('dgrad (pooled)', from_nhwc(dx), from_nhwc(dxf), x64.grad * gate)
+        need, needf = L.mtl_conv3x3_wgrad_x3_workspace(B, T, Fq, Cin, Cout, 1), L.mtl_conv3x3_wgrad_workspace(B, T, Fq, Cin, Cout, 1)
+        ws = torch.empty(max(need, needf) // 4 + 16).cuda()
+        wg, wgf = torch.zeros(Cout, Cin, 3, 3).cuda(), torch.zeros(Cout, Cin, 3, 3).cuda()
+        assert L.mtl_conv3x3_wgrad(st(), dxn.data_ptr(), dpn.data_ptr(), am.data_ptr(), wgf.data_ptr(), ws.data_ptr(), needf, B, T, Fq, Cin, Cout) == 0
+        assert L.mtl_conv3x3_wgrad_h2(st(), dxn.data_ptr(), ax.data_ptr(), dpn.data_ptr(), adp.data_ptr(), am.data_ptr(), wg.data_ptr(),
+                                      ws.data_ptr(), need, B, T, Fq, Cin, Cout) == 0
+        cmp('wgrad (pooled)', wg, wgf, w64.grad)
+        x64.grad = None
+        w64.grad = None
+    # dense backward
+    dy = torch.randn(y64.shape, generator=g) * 1e-3 * mag
+    y64.backward(dy.double())
+    dyn = dev(nhwc(dy * (y64.detach() > 0).float()))
+    ady = (dyn.abs().max() * 3.0).reshape(1).clone()            # an upper BOUND is enough
+    assert L.mtl_conv3x3_dgrad(st(), dyn.data_ptr(), None, wd.data_ptr(), dxn.data_ptr(), dxf.data_ptr(), B, T, Fq, Cin, Cout) == 0
+    assert L.mtl_conv3x3_dgrad_h2(st(), dyn.data_ptr(), ady.data_ptr(), None, w2d.data_ptr(), dxn.data_ptr(), dx.data_ptr(), slots[2:].data_ptr(),
+                                  B, T, Fq, Cin, Cout) == 0
+    cmp('dgrad', from_nhwc(dx), from_nhwc(dxf), x64.grad * gate)
+    assert float(dx.abs().max()) <= float(slots[2])
+    need, needf = L.mtl_conv3x3_wgrad_x3_workspace(B, T, Fq, Cin, Cout, 0), L.mtl_conv3x3_wgrad_workspace(B, T, Fq, Cin, Cout, 0)
+    ws = torch.empty(max(need, needf) // 4 + 16).cuda()
+    wg, wgf = torch.zeros(Cout, Cin, 3, 3).cuda(), torch.zeros(Cout, Cin, 3, 3).cuda()
+    assert L.mtl_conv3x3_wgrad(st(), dxn.data_ptr(), dyn.data_ptr(), None, wgf.data_ptr(), ws.data_ptr(), needf, B, T, Fq, Cin, Cout) == 0
+    assert L.mtl_conv3x3_wgrad_h2(st(), dxn.data_ptr(), ax.data_ptr(), dyn.data_ptr(), ady.data_ptr(), None, wg.data_ptr(), ws.data_ptr(),
+                                  need, B, T, Fq, Cin, Cout) == 0
+    cmp('wgrad', wg, wgf, w64.grad)
+    # missing scalars are refused
+    assert L.mtl_conv3x3_relu_fwd_h2(st(), dxn.data_ptr(), None, w2f.data_ptr(), db.data_ptr(), y.data_ptr(), None, B, T, Fq, Cin, Cout) != 0
+    print(report)
+
+
+def test_absmax_and_colsum_amax(L):
+    g = torch.Generator().manual_seed(5)
+    X = torch.randn(3000, 128, generator=g)
+    X[1234, 77] = -9.5
+    dX = dev(X)
+    slot = torch.zeros(2).cuda()
+    assert L.mtl_absmax_f32(st(), dX.data_ptr(), X.numel(), slot.data_ptr()) == 0
+    out = torch.zeros(128).cuda()
+    ws = torch.empty(L.mtl_colsum_workspace(3000, 128) // 4).cuda()
+    assert L.mtl_colsum_accum(st(), dX.data_ptr(), 3000, 128, 128, out.data_ptr(), ws.data_ptr(), slot[1:].data_ptr()) == 0
+    assert float(slot[0]) == 9.5 and float(slot[1]) == 9.5
+    assert rel(out, X.sum(0)) < 1e-5
 
 
 def test_spectrogram_front_end_matches_oracle(L, tmp_path):

@@ -50,6 +50,18 @@ def conv_case(name, T_, F_, cin, cout, pooled):
     print('%-8s fwd   x3 %.3f ms %6.1f TF' % (name, t, flops / t / 1e9))
     t = timeit(lambda: L.mtl_conv3x3_dgrad_x3(st(), dy.data_ptr(), amp, w3d.data_ptr(), x.data_ptr(), dx.data_ptr(), B, T_, F_, cin, cout))
     print('%-8s dgrad x3 %.3f ms %6.1f TF' % (name, t, flops / t / 1e9))
+    nb = L.mtl_conv3x3_wprep_h2_bytes(cout, cin)
+    w2f = torch.empty(nb, dtype=torch.uint8, device=dev); w2d = torch.empty_like(w2f)
+    L.mtl_conv3x3_wprep_h2(st(), w.data_ptr(), w2f.data_ptr(), w2d.data_ptr(), cout, cin)
+    ax, ady = x.abs().max().reshape(1).clone(), dy.abs().max().reshape(1).clone()
+    slot = torch.zeros(1, device=dev)
+    if pooled:
+        t = timeit(lambda: L.mtl_conv3x3_relu_pool_fwd_h2(st(), x.data_ptr(), ax.data_ptr(), w2f.data_ptr(), bias.data_ptr(), y.data_ptr(), am.data_ptr(), slot.data_ptr(), B, T_, F_, cin, cout))
+    else:
+        t = timeit(lambda: L.mtl_conv3x3_relu_fwd_h2(st(), x.data_ptr(), ax.data_ptr(), w2f.data_ptr(), bias.data_ptr(), y.data_ptr(), slot.data_ptr(), B, T_, F_, cin, cout))
+    print('%-8s fwd   h2 %.3f ms %6.1f TF' % (name, t, flops / t / 1e9))
+    t = timeit(lambda: L.mtl_conv3x3_dgrad_h2(st(), dy.data_ptr(), ady.data_ptr(), amp, w2d.data_ptr(), x.data_ptr(), dx.data_ptr(), None, B, T_, F_, cin, cout))
+    print('%-8s dgrad h2 %.3f ms %6.1f TF' % (name, t, flops / t / 1e9))
     need = L.mtl_conv3x3_wgrad_workspace(B, T_, F_, cin, cout, 1 if pooled else 0)
     ws = torch.empty(need // 4 + 64, device=dev); dw = torch.zeros_like(w)
     t = timeit(lambda: L.mtl_conv3x3_wgrad(st(), x.data_ptr(), dy.data_ptr(), amp, dw.data_ptr(), ws.data_ptr(), need, B, T_, F_, cin, cout))
@@ -58,6 +70,8 @@ def conv_case(name, T_, F_, cin, cout, pooled):
     ws = torch.empty(need // 4 + 64, device=dev)
     t = timeit(lambda: L.mtl_conv3x3_wgrad_x3(st(), x.data_ptr(), dy.data_ptr(), amp, dw.data_ptr(), ws.data_ptr(), need, B, T_, F_, cin, cout))
     print('%-8s wgrad x3 %.3f ms %6.1f TF' % (name, t, flops / t / 1e9))
+    t = timeit(lambda: L.mtl_conv3x3_wgrad_h2(st(), x.data_ptr(), ax.data_ptr(), dy.data_ptr(), ady.data_ptr(), amp, dw.data_ptr(), ws.data_ptr(), need, B, T_, F_, cin, cout))
+    print('%-8s wgrad h2 %.3f ms %6.1f TF' % (name, t, flops / t / 1e9))
 
 conv_case('conv2', T, F, 64, 64, True)
 conv_case('conv5', T // 2, F // 2, 64, 128, False)
