@@ -528,10 +528,20 @@ __global__ __launch_bounds__(256) void conv0_fwd_kernel(const float* __restrict_
         for (int k = 0; k < 9; ++k) wr[c][k] = w[(cg * 4 + c) * 9 + k];
     }
     const long npix = (long)B * T * F;
-    for (long pix = (long)blockIdx.x * 16 + (threadIdx.x >> 4); pix < npix; pix += (long)gridDim.x * 16) {
-        const int f = (int)(pix % F);
-        const long bt = pix / F;
-        const int t = (int)(bt % T), b = (int)(bt / T);
+    const int pl = threadIdx.x >> 4;
+    for (long base = (long)blockIdx.x * 16; base < npix; base += (long)gridDim.x * 16) {
+        // (b, t, f) of the block's first pixel: wave-uniform (scalar) divisions; the thread's own pixel is a carry away
+        const long bt0 = base / F;
+        int f = (int)(base - bt0 * F) + pl, t = (int)(bt0 % T), b = (int)(bt0 / T);
+        while (f >= F) {
+            f -= F;
+            if (++t == T) {
+                t = 0;
+                ++b;
+            }
+        }
+        const long pix = base + pl;
+        if (pix >= npix) break;
         const float* xb = x + (long)b * F * T;
         float acc[4] = {bb[0], bb[1], bb[2], bb[3]};
 #pragma unroll
@@ -569,10 +579,18 @@ __global__ __launch_bounds__(256) void conv0_wgrad_kernel(const float* __restric
 #pragma unroll
         for (int k = 0; k < 10; ++k) acc[c][k] = 0.f;
     const long npix = (long)B * T * F;
-    for (long pix = (long)blockIdx.x * 16 + pl; pix < npix; pix += (long)gridDim.x * 16) {
-        const int f = (int)(pix % F);
-        const long bt = pix / F;
-        const int t = (int)(bt % T), b = (int)(bt / T);
+    for (long base = (long)blockIdx.x * 16; base < npix; base += (long)gridDim.x * 16) {
+        const long bt0 = base / F;                       // wave-uniform (scalar) divisions, see conv0_fwd_kernel
+        int f = (int)(base - bt0 * F) + pl, t = (int)(bt0 % T), b = (int)(bt0 / T);
+        while (f >= F) {
+            f -= F;
+            if (++t == T) {
+                t = 0;
+                ++b;
+            }
+        }
+        const long pix = base + pl;
+        if (pix >= npix) break;
         const float* xb = x + (long)b * F * T;
         const float4 d4 = *reinterpret_cast<const float4*>(dy + pix * 64 + cg * 4);
         const float d[4] = {d4.x, d4.y, d4.z, d4.w};

@@ -8,13 +8,14 @@ import json
 import re
 import sys
 
-CLASSES = {  # kernel template instance -> bench.py conv class (see PassEngine.forward/backward)
-    'conv3x3_x3h_kernel<64, 1, false, 1>': 'conv2_fwd_pool', 'conv3x3_x3h_kernel<128, 2, false, 1>': 'conv7_fwd_pool',
-    'conv3x3_x3h_kernel<128, 2, false, 0>': 'conv5_fwd', 'conv3x3_x3h_kernel<64, 1, true, 2>': 'conv2_dgrad',
-    'conv3x3_x3h_kernel<128, 2, true, 2>': 'conv7_dgrad', 'conv3x3_x3h_kernel<64, 2, false, 2>': 'conv5_dgrad',
-    'conv3x3_wgrad_x3_kernel<false>': 'conv5_wgrad',
-    'conv3x3_wgrad_x3_kernel<true>': ('conv7_wgrad', 'conv2_wgrad'),      # same instance: the backward runs conv7 first, then conv2
+_BASE = {  # kernel template instance (without the trailing piece count) -> bench.py conv class (see PassEngine.forward/backward)
+    'conv3x3_x3h_kernel<64, 1, false, 1': 'conv2_fwd_pool', 'conv3x3_x3h_kernel<128, 2, false, 1': 'conv7_fwd_pool',
+    'conv3x3_x3h_kernel<128, 2, false, 0': 'conv5_fwd', 'conv3x3_x3h_kernel<64, 1, true, 2': 'conv2_dgrad',
+    'conv3x3_x3h_kernel<128, 2, true, 2': 'conv7_dgrad', 'conv3x3_x3h_kernel<64, 2, false, 2': 'conv5_dgrad',
+    'conv3x3_wgrad_x3_kernel<false': 'conv5_wgrad',
+    'conv3x3_wgrad_x3_kernel<true': ('conv7_wgrad', 'conv2_wgrad'),      # same instance: the backward runs conv7 first, then conv2
 }
+CLASSES = {'%s, %d>' % (k, np_): v for k, v in _BASE.items() for np_ in (2, 3)}      # 2 = fp16 pieces (h2), 3 = bf16 pieces (x3)
 
 
 # kernel-name substring -> bench.py class for the non-convolution classes (a class = one C-ABI call; calls that launch two
