@@ -98,7 +98,7 @@ int mtl_transpose_batch(void* stream, const mtl_transpose_desc* table_dev, int n
 
 /* ---- VGG front-end: models/asr/transformer.py:48-59 (Conv2d 3x3 s1 p1 + ReLU [+ MaxPool2d(2,2)]) ------
  * x_ref is the reference's (B,1,F,T) input; everything downstream is (B,T,F,C). */
-/* amax_y (optional): device scalar, atomically raised to max(y) -- the `amax_x` of a following *_h2 convolution; zero it first. */
+/* amax_y (optional): MTL_AMAX_SLOTS floats, atomically raised to max(y) -- the `amax_x` of a following *_h2 convolution; zero them first. */
 int mtl_conv0_relu_fwd(void* stream, const float* x_ref, const float* w /*(64,1,3,3)*/, const float* bias, float* y,
                        int B, int T, int F, float* amax_y);
 long mtl_conv0_wgrad_workspace(void);
@@ -131,11 +131,16 @@ int mtl_conv3x3_dgrad_x3(void* stream, const float* dy, const unsigned char* arg
 /* Two-piece fp16 ("h2") variants: the same calls on 2-way fp16 splits of both operands -- three v_mfma_f32_32x32x16_f16 per
  * 16-deep step (half the matrix work of x3, twice its roof), fp32 accumulation, error ~1.5x that of an fp32 convolution
  * (h l' + l h' + h h' keeps 22 significand bits).  fp16 has 5 exponent bits, so every operand tensor comes with a DEVICE
- * SCALAR `amax_*` >= max|tensor| (an upper bound within a few powers of two is as good): the kernels scale by the power of two
- * that puts amax into [2^14, 2^15) before splitting and un-scale the accumulators exactly.  Producers deliver the scalars for
- * free: `amax_y` / `amax_p` / `amax_dx` (optional outputs, atomically raised; zero them first), mtl_conv0_relu_fwd's amax_y,
- * mtl_colsum_accum's amax (the bias-gradient pass reads the whole gradient anyway), or mtl_absmax_f32.
+ * BOUND `amax_*` >= max|tensor| (an upper bound within a few powers of two is as good): the kernels scale by the power of two
+ * that puts the bound into [2^14, 2^15) before splitting and un-scale the accumulators exactly.  A bound is MTL_AMAX_SLOTS
+ * floats whose maximum counts (producers raise slot (workgroup % 64) atomically -- one hot address would serialise thousands of
+ * atomics).  Producers deliver the bounds for free: `amax_y` / `amax_p` / `amax_dx` (optional outputs; zero all slots first),
+ * mtl_conv0_relu_fwd's amax_y, mtl_colsum_accum's amax (the bias-gradient pass reads the whole gradient anyway; it WRITES all
+ * slots), or mtl_absmax_f32.
  * w2_fwd / w2_dgrad: mtl_conv3x3_wprep_h2_bytes() each: [2][K-tile][rows][32] fp16 in the x3 layout + the fp32 weight scale. */
+#ifndef MTL_AMAX_SLOTS
+#define MTL_AMAX_SLOTS 64
+#endif                      /* every amax_* argument is an array of this many floats; the bound is the maximum over them */
 long mtl_conv3x3_wprep_h2_bytes(int Cout, int Cin);
 int mtl_conv3x3_wprep_h2(void* stream, const float* w_ref, void* w2_fwd, void* w2_dgrad, int Cout, int Cin);
 int mtl_conv3x3_relu_fwd_h2(void* stream, const float* x, const float* amax_x, const void* w2_fwd, const float* bias, float* y,
@@ -144,7 +149,7 @@ int mtl_conv3x3_relu_pool_fwd_h2(void* stream, const float* x, const float* amax
                                  float* p_out, unsigned char* argmax, float* amax_p, int B, int T, int F, int Cin, int Cout);
 int mtl_conv3x3_dgrad_h2(void* stream, const float* dy, const float* amax_dy, const unsigned char* argmax, const void* w2_dgrad,
                          const float* act, float* dx, float* amax_dx, int B, int T, int F, int Cin, int Cout);
-/* *amax = max(*amax, max|x[0..n)|) (atomic; zero it first) */
+/* amax[MTL_AMAX_SLOTS]: raised so that their maximum is >= max|x[0..n)| (atomic; zero them first) */
 int mtl_absmax_f32(void* stream, const float* x, long n, float* amax);
 long mtl_conv3x3_wgrad_workspace(int B, int T, int F, int Cin, int Cout, int pooled);
 /* dw_ref (Cout,Cin,3,3) += sum_pixels x (x) dy ; dy dense (B,T,F,Cout) or pooled + argmax as above. */
@@ -232,7 +237,7 @@ int mtl_ce_bwd(void* stream, const float* logits, const float* lse, const long* 
 
 /* ---- out[c] += sum_r X[r*ld + c]  (bias gradients) -------------------------------------------------------- */
 long mtl_colsum_workspace(long rows, int cols);
-/* amax (optional): *amax = max|X| (written, not accumulated) -- the same pass over X */
+/* amax (optional, MTL_AMAX_SLOTS floats): all set to max|X| (written, not accumulated) -- the same pass over X */
 int mtl_colsum_accum(void* stream, const float* X, long rows, int cols, long ld, float* out, float* workspace, float* amax);
 
 /* ---- flat-parameter updates over ONE contiguous fp32 buffer (190 tensors in the reference) ----------------

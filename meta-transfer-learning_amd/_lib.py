@@ -115,6 +115,9 @@ class WgradDesc(ctypes.Structure):
                 ('lda', c_int), ('ldb', c_int), ('ldc', c_int), ('tile0', c_int), ('reserved', c_int)]
 
 
+AMAX_SLOTS = 64         # MTL_AMAX_SLOTS of include/mtl_hip.h: floats per max|tensor| bound of the h2 convolutions
+
+
 class TransposeDesc(ctypes.Structure):
     """mtl_transpose_desc of include/mtl_hip.h (24 bytes)"""
     _fields_ = [('src', c_void_p), ('dst', c_void_p), ('rows', c_int), ('cols', c_int)]

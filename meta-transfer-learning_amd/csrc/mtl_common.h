@@ -29,6 +29,19 @@ __device__ __forceinline__ float wave_max(float v) {
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+#ifndef MTL_AMAX_SLOTS
+#define MTL_AMAX_SLOTS 64
+#endif
+// A bound max|tensor| is kept in MTL_AMAX_SLOTS floats (include/mtl_hip.h): readers take the maximum (full waves only) ...
+__device__ __forceinline__ float amax_read(const float* a) { return wave_max(a[threadIdx.x & (MTL_AMAX_SLOTS - 1)]); }
+// ... writers raise the slot of their workgroup.  Same-address atomics (and coherent loads) serialise at ~9 ns each: only a wave
+// that would RAISE its slot issues one, judged by a plain CACHED load (a stale smaller value only costs a redundant atomic).
+__device__ __forceinline__ void amax_raise(float* a, float mx) {
+    mx = wave_max(mx);
+    float* slot = a + (blockIdx.x & (MTL_AMAX_SLOTS - 1));
+    if ((threadIdx.x & 63) == 0 && mx > *slot) atomicMax(reinterpret_cast<unsigned*>(slot), __float_as_uint(mx));
+}
+
 static inline int grid_for(long n, int per_block, int cap = 4096) {
     long g = (n + per_block - 1) / per_block;
     if (g < 1) g = 1;

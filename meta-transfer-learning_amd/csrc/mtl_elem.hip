@@ -483,10 +483,10 @@ __global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restr
         for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
         if ((threadIdx.x & 63) == 0) shm[threadIdx.x >> 6] = mx;
         __syncthreads();
-        if (threadIdx.x == 0) {
+        if (threadIdx.x < MTL_AMAX_SLOTS) {
 #pragma unroll
-            for (int i = 1; i < 16; ++i) mx = fmaxf(mx, shm[i]);
-            *amax = mx;
+            for (int i = 0; i < 16; ++i) mx = fmaxf(mx, shm[i]);
+            amax[threadIdx.x] = mx;
         }
     }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -559,13 +559,12 @@ __global__ __launch_bounds__(256) void conv0_fwd_kernel(const float* __restrict_
             make_float4(fmaxf(acc[0], 0.f), fmaxf(acc[1], 0.f), fmaxf(acc[2], 0.f), fmaxf(acc[3], 0.f));
         mx = fmaxf(fmaxf(mx, fmaxf(acc[0], acc[1])), fmaxf(acc[2], acc[3]));
     }
-    if (amax_y) {       // max of the outputs (>= 0 after the ReLU): one atomic per wave; the caller zeroes the scalar
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-        // same-address atomics (and coherent loads) serialise -- 32 k of them cost 0.3 ms here: only a wave that would RAISE the
-        // value issues one, judged by a plain cached load (a stale smaller value only costs a redundant atomic)
-        if ((threadIdx.x & 63) == 0 && mx > *amax_y)
-            atomicMax(reinterpret_cast<unsigned*>(amax_y), __float_as_uint(mx));
+    if (amax_y) {       // max of the outputs (>= 0 after the ReLU), one candidate per workgroup; the caller zeroes the slots
+        __shared__ float shm[4];
+        mx = wave_max(mx);
+        if ((threadIdx.x & 63) == 0) shm[threadIdx.x >> 6] = mx;
+        __syncthreads();
+        if (threadIdx.x < 64) amax_raise(amax_y, fmaxf(fmaxf(shm[0], shm[1]), fmaxf(shm[2], shm[3])));
     }
 }
 // dw0[c][tap] = sum_pix x[pix+tap]*dy[pix][c], db0[c] = sum_pix dy[pix][c]: per-block partials [blk][64][10]
@@ -952,9 +951,7 @@ int mtl_ce_bwd(void* stream, const float* logits, const float* lse, const long* 
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long n, float* __restrict__ amax) {
     float mx = 0.f;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) mx = fmaxf(mx, fabsf(x[i]));
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-    if ((threadIdx.x & 63) == 0 && mx > *amax) atomicMax(reinterpret_cast<unsigned*>(amax), __float_as_uint(mx));
+    amax_raise(amax, mx);
 }
 
 static long colsum_chunks(long rows, int cols) {

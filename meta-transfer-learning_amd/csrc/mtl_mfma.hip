@@ -762,16 +762,6 @@ __device__ __forceinline__ void split_x4(const float4& v, float s, uint2 (&pc)[N
     for (int q = 0; q < NP; ++q) pc[q] = make_uint2(a[q], b[q]);
 }
 
-// upper bound of max|.| over a wave's lanes -> atomic max into a device scalar (non-negative floats order like their bits)
-__device__ __forceinline__ void wave_amax_to(float* slot, float mx) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-    // same-address atomics serialise (~9 ns each, and so do coherent loads): only a wave that would RAISE the value issues one,
-    // judged by a plain CACHED load -- a stale (smaller) value only costs a redundant atomic, the maximum is monotone
-    if ((threadIdx.x & 63) == 0 && mx > *slot)
-        atomicMax(reinterpret_cast<unsigned*>(slot), __builtin_bit_cast(unsigned, mx));
-}
-
 // (Cout,Cin,3,3) fp32 -> bf16 pieces laid out per K-TILE: w3f[piece][kt = tap*Cin/32 + cin/32][cout][cin%32] and
 // w3d[piece][kt = (8-tap)*Cout/32 + cout/32][cin][cout%32]: the rows a workgroup stages for one K-tile are one contiguous
 // block of full cache lines, which is exactly the LDS image the convolution wants, so it is moved by global_load_lds
@@ -834,7 +824,7 @@ struct ConvX3P {
     int ntile;
     int dbg;             // ablation switches (MTL_X3_DBG), 0 in production
     int ntf, ntt, tiles; // halo kernel: pixel tiles along F and T, and tiles in total (F fastest, then T, then output-channel tile, then sample)
-    const float* amax_in;   // NP = 2: device scalar >= max|x|
+    const float* amax_in;   // NP = 2: MTL_AMAX_SLOTS floats whose maximum is >= max|x|
     float* amax_out;        // optional: atomic max of an upper bound of max|y| (the next layer's amax_in)
 };
 
@@ -904,7 +894,7 @@ __global__ __launch_bounds__((4 * G + 4) * 64) void conv3x3_x3h_kernel(ConvX3P p
     if (tid >= NCONS + 64) {
         // ------------------------------------------------------------------ halo waves (3): gather, 3-way split, LDS image
         const int ptid = tid - NCONS - 64;
-        const float sx = NP == 2 ? pow2_scale(*p.amax_in) : 1.f;
+        const float sx = NP == 2 ? pow2_scale(amax_read(p.amax_in)) : 1.f;
         float4 hv[XH_NVA];
         uchar4 ha[XH_NVA];
         unsigned hm[XH_NVA];
@@ -1029,7 +1019,7 @@ __global__ __launch_bounds__((4 * G + 4) * 64) void conv3x3_x3h_kernel(ConvX3P p
     const int wm = w4 >> 1, wn = w4 & 1, l31 = lane & 31, hi = lane >> 5;
     f32x16 acc[TM][TN];
     float inv = 1.f, mx = 0.f;                                 // NP = 2: 1 / (activation scale x weight scale); running bound of max|y|
-    if (NP == 2) inv = 1.f / (pow2_scale(*p.amax_in) * *reinterpret_cast<const float*>(p.w3 + (long)NP * nk * Cout * 64));
+    if (NP == 2) inv = 1.f / (pow2_scale(amax_read(p.amax_in)) * *reinterpret_cast<const float*>(p.w3 + (long)NP * nk * Cout * 64));
     int abase[TM];                                             // byte offset of this lane's pixel (tap centre) in the halo plane
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -1138,7 +1128,7 @@ __global__ __launch_bounds__((4 * G + 4) * 64) void conv3x3_x3h_kernel(ConvX3P p
             for (int jn = 0; jn < TN; ++jn)
                 for (int nt = 0; nt < p.ntile; ++nt) bmax = fmaxf(bmax, fabsf(p.bias[nt * BN + wn * WTN + jn * 32 + l31]));
         }
-        wave_amax_to(p.amax_out, mx + bmax);
+        amax_raise(p.amax_out, mx + bmax);
     }
 }
 
@@ -1472,7 +1462,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_x3_kernel(WgradX3P p) {
     if (tid >= NT) {
         // ------------------------------------------------------------------ producers: the x halo AND the dy fragments
         const int ptid = tid - NT;
-        const float sx = NP == 2 ? pow2_scale(*p.amax_x) : 1.f, sdy = NP == 2 ? pow2_scale(*p.amax_dy) : 1.f;
+        const float sx = NP == 2 ? pow2_scale(amax_read(p.amax_x)) : 1.f, sdy = NP == 2 ? pow2_scale(amax_read(p.amax_dy)) : 1.f;
         float4 hv[WX_NVA];
         unsigned okbits = 0;
         auto fetch = [&](int j) {
@@ -1637,7 +1627,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_x3_kernel(WgradX3P p) {
         __syncthreads();
     }
     float* slab = p.partial + (long)slot * 9 * Cin * Cout;
-    const float inv = NP == 2 ? 1.f / (pow2_scale(*p.amax_x) * pow2_scale(*p.amax_dy)) : 1.f;
+    const float inv = NP == 2 ? 1.f / (pow2_scale(amax_read(p.amax_x)) * pow2_scale(amax_read(p.amax_dy))) : 1.f;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
 #pragma unroll

@@ -776,12 +776,12 @@ class PassEngine:
         # ---- VGG front-end ----
         y1 = self.buf('y1', (B, T, F, 64))
         x3, h2 = self.conv_x3, self.conv_h2
-        # h2: device scalars max|tensor| (upper bounds) of y1, p1, y5 | dp2, dy5, dp1 -- raised by the producers' epilogues
+        # h2: device bounds max|tensor| (64 slots each) of y1, p1, y5 | dp2, dy5, dp1 -- raised by the producers' epilogues
         # (forward) or written by the bias-gradient column sums (backward)
-        amax = self.buf('amax', (8,))
-        am_ = (lambda i: amax.data_ptr() + 4 * i) if h2 else (lambda i: None)
+        amax = self.buf('amax', (8, _lib.AMAX_SLOTS))
+        am_ = (lambda i: amax.data_ptr() + 4 * _lib.AMAX_SLOTS * i) if h2 else (lambda i: None)
         if h2:
-            check(lib.mtl_memset_zero(st, amax.data_ptr(), 32), 'mtl_memset_zero')
+            check(lib.mtl_memset_zero(st, amax.data_ptr(), 4 * 4 * _lib.AMAX_SLOTS), 'mtl_memset_zero')
         check(lib.mtl_conv0_relu_fwd(st, x.data_ptr(), o('conv.0.weight'),
                          o('conv.0.bias'), y1.data_ptr(), B, T, F, am_(0)), 'conv0')
         wf, wd = {}, {}
@@ -1030,7 +1030,7 @@ class PassEngine:
         # ---- VGG front-end ----
         h2 = self.conv_h2
         amax = A['amax']
-        am_ = (lambda i: amax.data_ptr() + 4 * i) if h2 else (lambda i: None)      # slots: y1, p1, y5 | dp2, dy5, dp1
+        am_ = (lambda i: amax.data_ptr() + 4 * _lib.AMAX_SLOTS * i) if h2 else (lambda i: None)      # bounds: y1, p1, y5 | dp2, dy5, dp1
         dgrad_fn = lib.mtl_conv3x3_dgrad_x3 if self.conv_x3 else lib.mtl_conv3x3_dgrad
 
         def conv_dgrad(dy, ai, am, w, act, dx, *dims):

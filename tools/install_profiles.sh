@@ -1,0 +1,12 @@
+#!/bin/bash
+# Copies the summaries collect_profiles.sh left in gpurun_out/r2 into profiles/r2 (tracked) and refreshes profiles/pmc_traffic.json.
+set -e
+S=gpurun_out/r2 D=profiles/r2
+mkdir -p $D/t5000
+cp $S/bench.json $S/bench_lanes_traced.json $S/bench_serial_traced.json $S/pmc_fetch_size_per_kernel.csv $S/pmc_write_size_per_kernel.csv $S/pmc_traffic.json $S/pmc_traffic.txt $D/
+cp $S/serial/serial_kernel_stats.csv $D/kernel_stats_serial.csv
+cp $S/lanes/lanes_kernel_stats.csv $D/kernel_stats_lanes.csv
+cp $S/bench_t5000.json $D/t5000/bench_t5000.json
+cp $S/bench_t5000_serial_traced.json $D/t5000/bench_t5000_serial_traced.json
+cp $S/t5000/t5000_kernel_stats.csv $D/t5000/kernel_stats_serial.csv
+cp $S/pmc_traffic.json profiles/pmc_traffic.json
