@@ -771,11 +771,23 @@ __device__ __forceinline__ void split_x4(const float4& v, float s, uint2 (&pc)[N
 __host__ __device__ inline int x3_swz(int k, int row) { return (((k >> 3) ^ ((row >> 2) & 3)) << 3) | (k & 7); }
 
 // NP = 2: the planes are followed by one fp32 -- the power-of-two scale the pieces were taken at (conv_wscale_kernel).
+constexpr int WSCALE_PARTS = 16;
 template <int NP>
 __global__ void conv_wprep_x3_kernel(const float* w, unsigned short* wf, unsigned short* wd, int Cout, int Cin) {
     const int total = 9 * Cin * Cout;
     const int nkf = 9 * (Cin / 32), nkd = 9 * (Cout / 32);
-    const float s = NP == 2 ? *reinterpret_cast<const float*>(wf + (long)NP * total) : 1.f;
+    float s = 1.f;
+    if (NP == 2) {      // trailer: [scale][16 partial maxima from conv_wscale_kernel] for both buffers
+        float* hf = reinterpret_cast<float*>(wf + (long)NP * total);
+        float mx = 0.f;
+#pragma unroll
+        for (int i = 1; i <= WSCALE_PARTS; ++i) mx = fmaxf(mx, hf[i]);
+        s = pow2_scale(mx);
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            hf[0] = s;
+            *reinterpret_cast<float*>(wd + (long)NP * total) = s;
+        }
+    }
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
         const int tap = e % 9;
         const int cin = (e / 9) % Cin;
@@ -791,25 +803,19 @@ __global__ void conv_wprep_x3_kernel(const float* w, unsigned short* wf, unsigne
     }
 }
 
-// one workgroup: s = pow2_scale(max|w|) into the trailer of both prepared buffers
-__global__ __launch_bounds__(1024) void conv_wscale_kernel(const float* w, int total, float* hdr_f, float* hdr_d) {
-    __shared__ float sh[16];
+// WSCALE_PARTS workgroups: max|w| of one slice each into trailer[1 + part] of the forward buffer (plain stores: no atomics, no
+// reset; one workgroup took 13 us for 147 k weights)
+__global__ __launch_bounds__(256) void conv_wscale_kernel(const float* w, int total, float* hdr_f) {
+    __shared__ float sh[4];
     float mx = 0.f;
-    for (int e = threadIdx.x * 4; e < total; e += 4096) {
+    for (int e = (blockIdx.x * 256 + threadIdx.x) * 4; e < total; e += WSCALE_PARTS * 1024) {
         const float4 v = *reinterpret_cast<const float4*>(w + e);
         mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    mx = wave_max(mx);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = mx;
     __syncthreads();
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int i = 1; i < 16; ++i) mx = fmaxf(mx, sh[i]);
-        const float s = pow2_scale(mx);
-        *hdr_f = s;
-        *hdr_d = s;
-    }
+    if (threadIdx.x == 0) hdr_f[1 + blockIdx.x] = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
 }
 
 struct ConvX3P {
@@ -1370,9 +1376,15 @@ __global__ void wgrad_reduce_kernel(const float* partial, float* dw, int nsplit,
         const int cout = e % Cout;
         const int mc = e / Cout;  // tap*Cin + cin
         const int tap = mc / Cin, cin = mc - tap * Cin;
-        float s = 0.f;
-        for (int k = 0; k < nsplit; ++k) s += partial[(long)k * total + e];
-        dw[((long)cout * Cin + cin) * 9 + tap] += s;
+        // eight slabs in flight per thread (the serial form spent 39 us on 37 MB); fixed order -> deterministic
+        float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int k = 0;
+        for (; k + 8 <= nsplit; k += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s[u] += partial[(long)(k + u) * total + e];
+        }
+        for (; k < nsplit; ++k) s[0] += partial[(long)k * total + e];
+        dw[((long)cout * Cin + cin) * 9 + tap] += ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
     }
 }
 
@@ -1707,8 +1719,7 @@ static int wprep_pieces(int np, hipStream_t s, const float* w_ref, void* wf, voi
     unsigned short* f = reinterpret_cast<unsigned short*>(wf);
     unsigned short* d = reinterpret_cast<unsigned short*>(wd);
     if (np == 2) {
-        hipLaunchKernelGGL(conv_wscale_kernel, dim3(1), dim3(1024), 0, s, w_ref, (int)total, reinterpret_cast<float*>(f + 2 * total),
-                           reinterpret_cast<float*>(d + 2 * total));
+        hipLaunchKernelGGL(conv_wscale_kernel, dim3(WSCALE_PARTS), dim3(256), 0, s, w_ref, (int)total, reinterpret_cast<float*>(f + 2 * total));
         hipLaunchKernelGGL(conv_wprep_x3_kernel<2>, dim3(grid_for(total, 256)), dim3(256), 0, s, w_ref, f, d, Cout, Cin);
     } else {
         hipLaunchKernelGGL(conv_wprep_x3_kernel<3>, dim3(grid_for(total, 256)), dim3(256), 0, s, w_ref, f, d, Cout, Cin);
@@ -1760,7 +1771,7 @@ int mtl_conv3x3_dgrad_x3(void* stream, const float* dy, const unsigned char* arg
     return conv_dgrad_pieces<3>(as_stream(stream), dy, nullptr, argmax, w3_dgrad, act, dx, nullptr, B, T, F, Cin, Cout);
 }
 
-long mtl_conv3x3_wprep_h2_bytes(int Cout, int Cin) { return 2L * 9 * Cin * Cout * 2 + 16; }
+long mtl_conv3x3_wprep_h2_bytes(int Cout, int Cin) { return 2L * 9 * Cin * Cout * 2 + 4 * (1 + WSCALE_PARTS) + 12; }
 
 int mtl_conv3x3_wprep_h2(void* stream, const float* w_ref, void* w2_fwd, void* w2_dgrad, int Cout, int Cin) {
     return wprep_pieces(2, as_stream(stream), w_ref, w2_fwd, w2_dgrad, Cout, Cin);
