@@ -80,7 +80,7 @@ def make_args(k, lr=1e-4, meta_lr=1e-4):
 # ------------------------------------------------------------------------------------------------------------------
 # launch-level profiling: every library call that launches kernels, bracketed with HIP events on the stream it is given
 # ------------------------------------------------------------------------------------------------------------------
-_NOT_LAUNCHES = {'mtl_lowrank_supported', 'mtl_event_record', 'mtl_stream_wait_event', 'mtl_cmdlist_run', 'mtl_cmdlist_opcode', 'mtl_abi_version',
+_NOT_LAUNCHES = {'mtl_lowrank_supported', 'mtl_gemm_nt_h2_supported', 'mtl_event_record', 'mtl_stream_wait_event', 'mtl_cmdlist_run', 'mtl_cmdlist_opcode', 'mtl_abi_version',
                  'mtl_attn_supported', 'mtl_gemm_f32_ex_route', 'mtl_levenshtein_u32'}
 
 
@@ -134,6 +134,8 @@ def classify(lib, name, a, conv_mode, wgrad_x3_dense):
         small = name == 'mtl_gemm_f32_ex' and lib.mtl_gemm_f32_ex_route(M, N, K, batch, kb, 1 if rs else 0)
         return ('gemm_small' if small else 'gemm_big', 2.0 * M * N * K * batch * kb, 'flop',
                 'gemm16_kernel<...>' if small else 'gemm_kernel<...> (+ splitk_reduce_kernel)')
+    if name == 'mtl_gemm_nt_h2':
+        return 'gemm_h2', 2.0 * a[1] * a[2] * a[3], 'flop', 'gemm_nt_h2_kernel (+ gemm_h2_reduce_kernel)'
     if name == 'mtl_lowrank_pair':
         M, Kin, r, N, n = a[15], a[16], a[17], a[18], a[19]
         return 'lowrank_pair', 2.0 * M * r * (Kin + N) * n, 'flop', 'lowrank_pair_kernel<RT,SUM>'
@@ -189,6 +191,8 @@ def classify(lib, name, a, conv_mode, wgrad_x3_dense):
 def peak_of(cls, unit, conv_mode, wgrad_x3_dense):
     if unit == 'byte':
         return PEAK_HBM_GBS, 'GB/s', 'hbm'
+    if cls == 'gemm_h2':
+        return PEAK_H2_TFLOPS, 'TFLOP/s', 'mfma'
     if cls.startswith('conv') and conv_mode != 'f32' and not (cls == 'conv5_wgrad' and not wgrad_x3_dense):
         return (PEAK_H2_TFLOPS if conv_mode == 'h2' else PEAK_X3_TFLOPS), 'TFLOP/s', 'mfma'
     return PEAK_F32_MFMA_TFLOPS, 'TFLOP/s', 'mfma'

@@ -62,6 +62,18 @@ int mtl_gemm_f32_ex(void* stream, int transA, int transB, int M, int N, int K, f
  * (gemm_kernel<...>); used by bench.py to attribute launch timings to the rocprofv3 kernel classes */
 int mtl_gemm_f32_ex_route(int M, int N, int K, int batch, int kbatch, int has_rowsum);
 
+/* C[M,N] = A[M,K] . B[N,K]^T (+ bias[N]) (gate: C = gate[m][n] > 0 ? C : 0) on two-piece fp16 splits of both operands
+ * (3 v_mfma_f32_32x32x16_f16 per 16-deep step, see the *_h2 convolutions below for the arithmetic and for amax_a / amax_b:
+ * MTL_AMAX_SLOTS floats each whose maximum bounds max|A|, max|B|).  For the two compute-bound products of the pass: the Linear
+ * on the flattened VGG feature map (models/asr/transformer.py:136-140, K = 5120) and its data gradient (B = the transposed
+ * weight).  K % 32 == 0, N % 4 == 0, leading dimensions multiples of 4, 16-byte aligned operands.  Few-tile products split K over
+ * workgroups (workspace) and finish in a fixed-order reduction kernel. */
+int mtl_gemm_nt_h2_supported(int M, int N, int K);
+long mtl_gemm_nt_h2_workspace(int M, int N, int K);
+int mtl_gemm_nt_h2(void* stream, int M, int N, int K, const float* A, int lda, const float* amax_a, const float* B, int ldb,
+                   const float* amax_b, float* C, int ldc, const float* bias, const float* gate, int ldg, float* workspace,
+                   long workspace_bytes);
+
 /* Grouped weight gradients: ONE launch computes  C_i += A_i^T . B_i  (and rowsum_i += column sums of A_i, nullable) for a whole
  * table of independent products -- all the small dW = dy^T . x of a backward pass (nn.Linear weight + bias gradients,
  * modules/common_layers.py:130,287-289,303), which are otherwise ~60 launches of 64..256 workgroups each.  A_i is K x M (lda), B_i is
@@ -98,7 +110,7 @@ int mtl_transpose_batch(void* stream, const mtl_transpose_desc* table_dev, int n
 
 /* ---- VGG front-end: models/asr/transformer.py:48-59 (Conv2d 3x3 s1 p1 + ReLU [+ MaxPool2d(2,2)]) ------
  * x_ref is the reference's (B,1,F,T) input; everything downstream is (B,T,F,C). */
-/* amax_y (optional): MTL_AMAX_SLOTS floats, atomically raised to max(y) -- the `amax_x` of a following *_h2 convolution; zero them first. */
+/* amax_y (optional): MTL_AMAX_FLOATS floats, slot heads atomically raised to max(y) -- the `amax_x` of a following *_h2 convolution; zero them first. */
 int mtl_conv0_relu_fwd(void* stream, const float* x_ref, const float* w /*(64,1,3,3)*/, const float* bias, float* y,
                        int B, int T, int F, float* amax_y);
 long mtl_conv0_wgrad_workspace(void);
@@ -132,15 +144,17 @@ int mtl_conv3x3_dgrad_x3(void* stream, const float* dy, const unsigned char* arg
  * 16-deep step (half the matrix work of x3, twice its roof), fp32 accumulation, error ~1.5x that of an fp32 convolution
  * (h l' + l h' + h h' keeps 22 significand bits).  fp16 has 5 exponent bits, so every operand tensor comes with a DEVICE
  * BOUND `amax_*` >= max|tensor| (an upper bound within a few powers of two is as good): the kernels scale by the power of two
- * that puts the bound into [2^14, 2^15) before splitting and un-scale the accumulators exactly.  A bound is MTL_AMAX_SLOTS
- * floats whose maximum counts (producers raise slot (workgroup % 64) atomically -- one hot address would serialise thousands of
- * atomics).  Producers deliver the bounds for free: `amax_y` / `amax_p` / `amax_dx` (optional outputs; zero all slots first),
+ * that puts the bound into [2^14, 2^15) before splitting and un-scale the accumulators exactly.  A bound is MTL_AMAX_FLOATS
+ * floats: the maximum over its 64 slot heads counts (producers raise slot (workgroup % 64) atomically -- L2 serialises atomics
+ * per cache line, one hot line costs thousands of them 40-300 us).  Producers deliver the bounds for free: `amax_y` / `amax_p` / `amax_dx` (optional outputs; zero all slots first),
  * mtl_conv0_relu_fwd's amax_y, mtl_colsum_accum's amax (the bias-gradient pass reads the whole gradient anyway; it WRITES all
  * slots), or mtl_absmax_f32.
  * w2_fwd / w2_dgrad: mtl_conv3x3_wprep_h2_bytes() each: [2][K-tile][rows][32] fp16 in the x3 layout + the fp32 weight scale. */
 #ifndef MTL_AMAX_SLOTS
-#define MTL_AMAX_SLOTS 64
-#endif                      /* every amax_* argument is an array of this many floats; the bound is the maximum over them */
+#define MTL_AMAX_SLOTS 64   /* every amax_* argument is MTL_AMAX_FLOATS floats: 64 slots, one 128-byte line apart (slot i at */
+#define MTL_AMAX_STRIDE 32  /* [i * 32]); the bound is the maximum over the slot heads, the other floats are padding          */
+#define MTL_AMAX_FLOATS (MTL_AMAX_SLOTS * MTL_AMAX_STRIDE)
+#endif
 long mtl_conv3x3_wprep_h2_bytes(int Cout, int Cin);
 int mtl_conv3x3_wprep_h2(void* stream, const float* w_ref, void* w2_fwd, void* w2_dgrad, int Cout, int Cin);
 int mtl_conv3x3_relu_fwd_h2(void* stream, const float* x, const float* amax_x, const void* w2_fwd, const float* bias, float* y,
@@ -149,7 +163,7 @@ int mtl_conv3x3_relu_pool_fwd_h2(void* stream, const float* x, const float* amax
                                  float* p_out, unsigned char* argmax, float* amax_p, int B, int T, int F, int Cin, int Cout);
 int mtl_conv3x3_dgrad_h2(void* stream, const float* dy, const float* amax_dy, const unsigned char* argmax, const void* w2_dgrad,
                          const float* act, float* dx, float* amax_dx, int B, int T, int F, int Cin, int Cout);
-/* amax[MTL_AMAX_SLOTS]: raised so that their maximum is >= max|x[0..n)| (atomic; zero them first) */
+/* amax[MTL_AMAX_FLOATS]: slot heads raised so that their maximum is >= max|x[0..n)| (atomic; zero them first) */
 int mtl_absmax_f32(void* stream, const float* x, long n, float* amax);
 long mtl_conv3x3_wgrad_workspace(int B, int T, int F, int Cin, int Cout, int pooled);
 /* dw_ref (Cout,Cin,3,3) += sum_pixels x (x) dy ; dy dense (B,T,F,Cout) or pooled + argmax as above. */
@@ -237,7 +251,7 @@ int mtl_ce_bwd(void* stream, const float* logits, const float* lse, const long* 
 
 /* ---- out[c] += sum_r X[r*ld + c]  (bias gradients) -------------------------------------------------------- */
 long mtl_colsum_workspace(long rows, int cols);
-/* amax (optional, MTL_AMAX_SLOTS floats): all set to max|X| (written, not accumulated) -- the same pass over X */
+/* amax (optional, MTL_AMAX_FLOATS floats): all slot heads set to max|X| (written, not accumulated) -- the same pass over X */
 int mtl_colsum_accum(void* stream, const float* X, long rows, int cols, long ld, float* out, float* workspace, float* amax);
 
 /* ---- flat-parameter updates over ONE contiguous fp32 buffer (190 tensors in the reference) ----------------

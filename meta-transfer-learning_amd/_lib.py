@@ -45,6 +45,9 @@ SIGNATURES = {
     'mtl_conv3x3_dgrad_h2': (I, [P, P, P, P, P, P, P, P, I, I, I, I, I]),
     'mtl_conv3x3_wgrad_h2': (I, [P, P, P, P, P, P, P, P, L, I, I, I, I, I]),
     'mtl_absmax_f32': (I, [P, P, L, P]),
+    'mtl_gemm_nt_h2_supported': (I, [I, I, I]),
+    'mtl_gemm_nt_h2_workspace': (L, [I, I, I]),
+    'mtl_gemm_nt_h2': (I, [P, I, I, I, P, I, P, P, I, P, P, I, P, P, I, P, L]),
     'mtl_permute_hc': (I, [P, P, P, I, I, I, I]),
     'mtl_layernorm_fwd': (I, [P, P, P, P, P, P, P, P, F, P, P, P, I, I, I, F]),
     'mtl_layernorm_bwd_workspace': (L, [I, I]),
@@ -115,7 +118,7 @@ class WgradDesc(ctypes.Structure):
                 ('lda', c_int), ('ldb', c_int), ('ldc', c_int), ('tile0', c_int), ('reserved', c_int)]
 
 
-AMAX_SLOTS = 64         # MTL_AMAX_SLOTS of include/mtl_hip.h: floats per max|tensor| bound of the h2 convolutions
+AMAX_SLOTS = 64 * 32    # MTL_AMAX_FLOATS of include/mtl_hip.h: floats per max|tensor| bound of the h2 kernels (64 slot heads, 128 B apart)
 
 
 class TransposeDesc(ctypes.Structure):

@@ -31,14 +31,17 @@ static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream
 
 #ifndef MTL_AMAX_SLOTS
 #define MTL_AMAX_SLOTS 64
+#define MTL_AMAX_STRIDE 32
+#define MTL_AMAX_FLOATS (MTL_AMAX_SLOTS * MTL_AMAX_STRIDE)
 #endif
-// A bound max|tensor| is kept in MTL_AMAX_SLOTS floats (include/mtl_hip.h): readers take the maximum (full waves only) ...
-__device__ __forceinline__ float amax_read(const float* a) { return wave_max(a[threadIdx.x & (MTL_AMAX_SLOTS - 1)]); }
+// A bound max|tensor| is kept in MTL_AMAX_SLOTS floats, one 128-byte line apart (include/mtl_hip.h: L2 serialises atomics per
+// LINE, 8 k raises of one line cost 40 us): readers take the maximum of the slot heads (full waves only) ...
+__device__ __forceinline__ float amax_read(const float* a) { return wave_max(a[(threadIdx.x & (MTL_AMAX_SLOTS - 1)) * MTL_AMAX_STRIDE]); }
 // ... writers raise the slot of their workgroup.  Same-address atomics (and coherent loads) serialise at ~9 ns each: only a wave
 // that would RAISE its slot issues one, judged by a plain CACHED load (a stale smaller value only costs a redundant atomic).
 __device__ __forceinline__ void amax_raise(float* a, float mx) {
     mx = wave_max(mx);
-    float* slot = a + (blockIdx.x & (MTL_AMAX_SLOTS - 1));
+    float* slot = a + (blockIdx.x & (MTL_AMAX_SLOTS - 1)) * MTL_AMAX_STRIDE;
     if ((threadIdx.x & 63) == 0 && mx > *slot) atomicMax(reinterpret_cast<unsigned*>(slot), __float_as_uint(mx));
 }
 

@@ -486,7 +486,7 @@ __global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restr
         if (threadIdx.x < MTL_AMAX_SLOTS) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) mx = fmaxf(mx, shm[i]);
-            amax[threadIdx.x] = mx;
+            amax[threadIdx.x * MTL_AMAX_STRIDE] = mx;
         }
     }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -972,8 +972,17 @@ int mtl_ce_bwd(void* stream, const float* logits, const float* lse, const long* 
 
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long n, float* __restrict__ amax) {
     float mx = 0.f;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) mx = fmaxf(mx, fabsf(x[i]));
-    amax_raise(amax, mx);
+    const long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) mx = fmaxf(mx, fabsf(x[(n4 << 2) + threadIdx.x]));
+    __shared__ float shm[4];                    // one candidate per workgroup
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) shm[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x < 64) amax_raise(amax, fmaxf(fmaxf(shm[0], shm[1]), fmaxf(shm[2], shm[3])));
 }
 
 static long colsum_chunks(long rows, int cols) {
@@ -986,7 +995,8 @@ static long colsum_chunks(long rows, int cols) {
 }
 int mtl_absmax_f32(void* stream, const float* x, long n, float* amax) {
     if (!x || !amax || n <= 0) return MTL_EINVAL;
-    hipLaunchKernelGGL(absmax_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, as_stream(stream), x, n, amax);
+    if (reinterpret_cast<uintptr_t>(x) & 15) return MTL_EINVAL;
+    hipLaunchKernelGGL(absmax_kernel, dim3(grid_for(n / 4 + 1, 256, 1024)), dim3(256), 0, as_stream(stream), x, n, amax);
     MTL_CHECK_LAUNCH();
     return MTL_OK;
 }

@@ -317,7 +317,8 @@ int mtl_lowrank_pair(void* stream, const float* x, long sx, int ldx, const float
 
 int mtl_transpose_batch(void* stream, const mtl_transpose_desc* table_dev, int n) {
     if (!table_dev || n <= 0) return MTL_EINVAL;
-    hipLaunchKernelGGL(transpose_batch_kernel, dim3(16, 1, n), dim3(256), 0, as_stream(stream), table_dev, n);
+    const int gx = n >= 64 ? 16 : (n >= 8 ? 128 : 1024);        // workgroups per matrix (each strides over the 32 x 32 tiles)
+    hipLaunchKernelGGL(transpose_batch_kernel, dim3(gx, 1, n), dim3(256), 0, as_stream(stream), table_dev, n);
     MTL_CHECK_LAUNCH();
     return MTL_OK;
 }

@@ -20,6 +20,7 @@
 #include <type_traits>
 
 #include "mtl_common.h"
+#include "mtl_h2.h"
 #include "../../include/mtl_hip.h"
 
 namespace {
@@ -683,7 +684,6 @@ __device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l)
 
 // The same split for two values at once: v_cvt_pk_bf16_f32 converts a pair per instruction and the residuals become
 // v_pk_add_f32 (20 VALU per float4 instead of 36 with the scalar form; bit-identical pieces).
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split3x2(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
     h = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{x0, x1}, bf16x2));
@@ -701,30 +701,7 @@ __device__ __forceinline__ void split3x4(const float4& v, bf16x4& h, bf16x4& m, 
     l = __builtin_bit_cast(bf16x4, ll);
 }
 
-// ------------------------------------------------------------------ two fp16 pieces ("h2"): half the MFMA work of x3
-// x s = h + l (+ at most 2^-23 |x s|) with two fp16 pieces (2 x 11 significand bits), s a power of two that puts the LARGEST
-// magnitude of the tensor into [2^14, 2^15) -- fp16 has 5 exponent bits, so the caller passes an upper bound of max|x| (a device
-// scalar: `amax`), and everything above 2^-39 of that maximum keeps its full 22 bits (below, the absolute error is 2^-40 of the
-// maximum).  A product is h h' + h l' + l h' (the dropped l l' is < 2^-22 relative): three v_mfma_f32_32x32x16_f16 instead of six
-// bf16 ones, fp32 accumulation, un-scaled exactly (powers of two) in the epilogue.  Measured error of a K = 1152 convolution
-// against fp64: 1.3-1.6x that of an fp32 convolution (tests/test_ops_gpu.py), i.e. fp32-class like x3, at twice its MFMA roof.
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ float pow2_scale(float amax) {   // 2^k with amax 2^k in [2^14, 2^15); 1 for amax = 0 / denormal
-    const int e = (int)((__builtin_bit_cast(unsigned, amax) >> 23) & 0xffu);     // amax in [2^(e-127), 2^(e-126))
-    int k = 141 - e;
-    k = e == 0 ? 0 : min(max(k, -60), 60);
-    return __builtin_bit_cast(float, (unsigned)(k + 127) << 23);
-}
-
-__device__ __forceinline__ void split2x2(float x0, float x1, unsigned& h, unsigned& l) {
-    const f16x2 hh = __builtin_convertvector(f32x2{x0, x1}, f16x2);
-    const f32x2 r = f32x2{x0, x1} - __builtin_convertvector(hh, f32x2);            // exact
-    h = __builtin_bit_cast(unsigned, hh);
-    l = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
-}
-
+// two fp16 pieces ("h2"): mtl_h2.h
 // NP 16-bit pieces per fp32 value: 3 = exact bf16 triple (scale ignored), 2 = fp16 pair of the scaled value
 template <int NP>
 struct Split;
@@ -745,13 +722,7 @@ struct Split<3> {
 template <>
 struct Split<2> {
     static __device__ __forceinline__ void x2(float x0, float x1, float s, unsigned (&pc)[2]) { split2x2(x0 * s, x1 * s, pc[0], pc[1]); }
-    static __device__ __forceinline__ f32x16 mfma(const uint4 (&a)[2], const uint4 (&b)[2], f32x16 cc) {
-        const f16x8 a0 = __builtin_bit_cast(f16x8, a[0]), a1 = __builtin_bit_cast(f16x8, a[1]);
-        const f16x8 b0 = __builtin_bit_cast(f16x8, b[0]), b1 = __builtin_bit_cast(f16x8, b[1]);
-        cc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, cc, 0, 0, 0);
-        cc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, cc, 0, 0, 0);
-        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, cc, 0, 0, 0);
-    }
+    static __device__ __forceinline__ f32x16 mfma(const uint4 (&a)[2], const uint4 (&b)[2], f32x16 cc) { return h2_mfma(a, b, cc); }
 };
 template <int NP>
 __device__ __forceinline__ void split_x4(const float4& v, float s, uint2 (&pc)[NP]) {
@@ -768,7 +739,6 @@ __device__ __forceinline__ void split_x4(const float4& v, float s, uint2 (&pc)[N
 // (lane-linear destination) without touching a register.  Rows are 64 bytes = four 16-byte chunks (8 k-values each);
 // chunk c of row r is stored at position c ^ ((r >> 2) & 3), which makes the consumers' ds_read_b128 of one chunk from
 // 16 rows {0-3,12-15,20-27} conflict-free with no padding.
-__host__ __device__ inline int x3_swz(int k, int row) { return (((k >> 3) ^ ((row >> 2) & 3)) << 3) | (k & 7); }
 
 // NP = 2: the planes are followed by one fp32 -- the power-of-two scale the pieces were taken at (conv_wscale_kernel).
 constexpr int WSCALE_PARTS = 16;

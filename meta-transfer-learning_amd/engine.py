@@ -337,6 +337,16 @@ class PassEngine:
             check(self.lib.mtl_transpose_batch(self.stream, ent[0].data_ptr(), ent[1]), 'mtl_transpose_batch')
         return wT
 
+    def _transpose_table(self, src, dst, rows, cols):
+        key = ('tr', src.data_ptr(), dst.data_ptr(), rows, cols)
+        dev = self._tr_tables.get(key)
+        if dev is None:
+            table = (_lib.TransposeDesc * 1)()
+            table[0].src, table[0].dst, table[0].rows, table[0].cols = src.data_ptr(), dst.data_ptr(), rows, cols
+            dev = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8).to(self.device)
+            self._tr_tables[key] = dev
+        return dev.data_ptr()
+
     # ---- grouped weight gradients
     def wgrad(self, dy, x, rows, n_out, k_in, dw, db=None):
         """dw (n_out x k_in) += dy^T x ; db += colsum(dy).  Small products are only REGISTERED here and computed by one grouped launch
@@ -778,10 +788,11 @@ class PassEngine:
         x3, h2 = self.conv_x3, self.conv_h2
         # h2: device bounds max|tensor| (64 slots each) of y1, p1, y5 | dp2, dy5, dp1 -- raised by the producers' epilogues
         # (forward) or written by the bias-gradient column sums (backward)
-        amax = self.buf('amax', (8, _lib.AMAX_SLOTS))
+        # (6, 7, 8: p2, the permuted input_linear weight, de0 -- operands of the two h2 GEMMs around the encoder's input Linear)
+        amax = self.buf('amax', (12, _lib.AMAX_SLOTS))
         am_ = (lambda i: amax.data_ptr() + 4 * _lib.AMAX_SLOTS * i) if h2 else (lambda i: None)
         if h2:
-            check(lib.mtl_memset_zero(st, amax.data_ptr(), 4 * 4 * _lib.AMAX_SLOTS), 'mtl_memset_zero')
+            check(lib.mtl_memset_zero(st, amax.data_ptr(), 12 * 4 * _lib.AMAX_SLOTS), 'mtl_memset_zero')
         check(lib.mtl_conv0_relu_fwd(st, x.data_ptr(), o('conv.0.weight'),
                          o('conv.0.bias'), y1.data_ptr(), B, T, F, am_(0)), 'conv0')
         wf, wd = {}, {}
@@ -818,7 +829,7 @@ class PassEngine:
         p2 = self.buf('p2', (B, T4, F4, 128))
         am2 = self.buf('am2', (B, T4, F4, 128), torch.uint8)
         check(conv_fwd_pool(st, y5.data_ptr(), wf[7].data_ptr(),
-                         o('conv.7.bias'), p2.data_ptr(), am2.data_ptr(), 2, None, B, T2, F2, 128, 128), 'conv7')
+                         o('conv.7.bias'), p2.data_ptr(), am2.data_ptr(), 2, 6, B, T2, F2, 128, 128), 'conv7')
 
         if self.after_conv_hook is not None:      # lets the trainer de-phase concurrent task lanes (see trainer.meta_iteration)
             hook, self.after_conv_hook = self.after_conv_hook, None
@@ -828,7 +839,16 @@ class PassEngine:
         wp = self.buf('wp_in', (d, hp.d_in))
         check(lib.mtl_permute_hc(st, o('encoder.input_linear.weight'), wp.data_ptr(), d, 128, F4, 0), 'permute')
         e0 = self.buf('e0', (Me, d))
-        self.linear_fwd(p2.data_ptr(), Me, hp.d_in, wp.data_ptr(), o('encoder.input_linear.bias'), e0.data_ptr(), d)
+        self.in_h2 = h2 and bool(lib.mtl_gemm_nt_h2_supported(Me, d, hp.d_in)) and bool(lib.mtl_gemm_nt_h2_supported(Me, hp.d_in, d))
+        if self.in_h2:      # the two compute-bound products of the pass on fp16 pairs: e0 = p2 . wp^T here, dp2 = de0 . (wp^T)^T in the backward
+            wpT = self.buf('wpT_in', (hp.d_in, d))
+            check(lib.mtl_transpose_batch(st, self._transpose_table(wp, wpT, d, hp.d_in), 1), 'mtl_transpose_batch')
+            check(lib.mtl_absmax_f32(st, wp.data_ptr(), wp.numel(), am_(7)), 'mtl_absmax_f32')
+            need = lib.mtl_gemm_nt_h2_workspace(Me, d, hp.d_in)
+            check(lib.mtl_gemm_nt_h2(st, Me, d, hp.d_in, p2.data_ptr(), hp.d_in, am_(6), wp.data_ptr(), hp.d_in, am_(7), e0.data_ptr(), d,
+                                     o('encoder.input_linear.bias'), None, 0, self.scratch(need) if need else None, need), 'mtl_gemm_nt_h2')
+        else:
+            self.linear_fwd(p2.data_ptr(), Me, hp.d_in, wp.data_ptr(), o('encoder.input_linear.bias'), e0.data_ptr(), d)
         ex = self.buf('enc_in.y', (Me, d))
         self.ln_fwd(e0.data_ptr(), None, o('encoder.layer_norm_input.weight'), o('encoder.layer_norm_input.bias'),
                     self.pe_enc.data_ptr(), None, ex.data_ptr(), self.buf('enc_in.xhat', (Me, d)).data_ptr(),
@@ -1023,8 +1043,16 @@ class PassEngine:
         dp2 = self.buf('_dp2', (B, T4, F4, 128))
         self.gemm(1, 0, d, hp.d_in, Me, de0.data_ptr(), d, p2.data_ptr(), hp.d_in, dwp.data_ptr(), hp.d_in)
         check(lib.mtl_permute_hc(st, dwp.data_ptr(), g('encoder.input_linear.weight'), d, 128, F4, 1), 'permute_inv')
-        self.gemm(0, 0, Me, hp.d_in, d, de0.data_ptr(), d, A['wp_in'].data_ptr(), hp.d_in, dp2.data_ptr(), hp.d_in,
-                  gate=p2.data_ptr(), ldg=hp.d_in)
+        if self.in_h2:
+            amax = A['amax']
+            a8, a7 = (amax.data_ptr() + 4 * _lib.AMAX_SLOTS * i for i in (8, 7))
+            check(lib.mtl_absmax_f32(st, de0.data_ptr(), de0.numel(), a8), 'mtl_absmax_f32')
+            need = lib.mtl_gemm_nt_h2_workspace(Me, hp.d_in, d)
+            check(lib.mtl_gemm_nt_h2(st, Me, hp.d_in, d, de0.data_ptr(), d, a8, A['wpT_in'].data_ptr(), d, a7, dp2.data_ptr(), hp.d_in,
+                                     None, p2.data_ptr(), hp.d_in, self.scratch(need) if need else None, need), 'mtl_gemm_nt_h2')
+        else:
+            self.gemm(0, 0, Me, hp.d_in, d, de0.data_ptr(), d, A['wp_in'].data_ptr(), hp.d_in, dp2.data_ptr(), hp.d_in,
+                      gate=p2.data_ptr(), ldg=hp.d_in)
 
         self.flush_wgrads()        # every small dW of the transformer half: one grouped launch, overlapping the VGG backward
         # ---- VGG front-end ----

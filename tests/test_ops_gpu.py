@@ -335,7 +335,7 @@ def test_conv0(L, B, T, Fq):
     ref = torch.relu(F.conv2d(x, w, b, padding=1))
     dx, dw, db = dev(x), dev(w), dev(b)
     y = torch.empty(B, T, Fq, 64).cuda()
-    amax = torch.zeros(64).cuda()                                               # MTL_AMAX_SLOTS floats: their maximum is the bound
+    amax = torch.zeros(2048).cuda()                                             # MTL_AMAX_FLOATS: 64 slot heads, 32 floats apart
     assert L.mtl_conv0_relu_fwd(st(), dx.data_ptr(), dw.data_ptr(), db.data_ptr(), y.data_ptr(), B, T, Fq, amax.data_ptr()) == 0
     assert rel(from_nhwc(y), ref) < 2e-6
     assert float(amax.max()) == float(y.max())                                        # the scalar a following h2 convolution scales by
@@ -792,9 +792,9 @@ def test_conv3x3_two_piece_fp16_is_fp32_class(L, Cin, Cout, B, T, Fq, mag):
             unsw[:, :, co, c] = pieces[:, :, co, c ^ ((co >> 2) & 3)]
     wt = w.double().reshape(Cout, Cin // 32, 32, 9).permute(3, 1, 0, 2)
     assert float((unsw.reshape(9, Cin // 32, Cout, 32) - wt).abs().max()) <= 2.0 ** -21 * float(w.abs().max())
-    S = 64                                                     # MTL_AMAX_SLOTS: a bound is 64 floats whose maximum counts
+    S = 2048                                                   # MTL_AMAX_FLOATS: a bound is 64 slot heads (32 floats apart)
     ax = dxn.abs().max().reshape(1).repeat(S)
-    ax[1:] = 0
+    ax[32:] = 0                                                # ... any ONE head carrying the bound is enough
     slots = torch.zeros(4 * S).cuda()
     report = []
 
@@ -809,7 +809,7 @@ def test_conv3x3_two_piece_fp16_is_fp32_class(L, Cin, Cout, B, T, Fq, mag):
                                      slots.data_ptr(), B, T, Fq, Cin, Cout) == 0
     cmp('fwd', from_nhwc(y), from_nhwc(yf), y64)
     assert float(y.max()) <= float(slots[:S].max()) <= 8.0 * float(y.max())     # amax_y: an upper bound (max|acc| + max|bias|) within a few bits
-    loose = ax.flip(0) * 64.0                                                      # a bound 6 bits too high costs nothing
+    loose = ax.roll(63 * 32) * 64.0                                                      # a bound 6 bits too high costs nothing
     y2 = torch.empty_like(y)
     assert L.mtl_conv3x3_relu_fwd_h2(st(), dxn.data_ptr(), loose.data_ptr(), w2f.data_ptr(), db.data_ptr(), y2.data_ptr(), None, B, T, Fq,
                                      Cin, Cout) == 0
@@ -877,12 +877,12 @@ def test_absmax_and_colsum_amax(L):
     X = torch.randn(3000, 128, generator=g)
     X[1234, 77] = -9.5
     dX = dev(X)
-    slot = torch.zeros(128).cuda()
+    slot = torch.zeros(4096).cuda()
     assert L.mtl_absmax_f32(st(), dX.data_ptr(), X.numel(), slot.data_ptr()) == 0
     out = torch.zeros(128).cuda()
     ws = torch.empty(L.mtl_colsum_workspace(3000, 128) // 4).cuda()
-    assert L.mtl_colsum_accum(st(), dX.data_ptr(), 3000, 128, 128, out.data_ptr(), ws.data_ptr(), slot[64:].data_ptr()) == 0
-    assert float(slot[:64].max()) == 9.5 and bool((slot[64:] == 9.5).all())
+    assert L.mtl_colsum_accum(st(), dX.data_ptr(), 3000, 128, 128, out.data_ptr(), ws.data_ptr(), slot[2048:].data_ptr()) == 0
+    assert float(slot[:2048].max()) == 9.5 and bool((slot[2048::32] == 9.5).all())
     assert rel(out, X.sum(0)) < 1e-5
 
 
@@ -908,3 +908,47 @@ def test_spectrogram_front_end_matches_oracle(L, tmp_path):
         w.writeframes((np.clip(y, -1, 1) * 32767).astype('<i2').tobytes())
     yw = mtl_amd.load_wav_pcm16(p)
     assert abs(yw - np.clip(y, -1, 1)).max() < 1e-4 and rel(fe(yw).cpu(), frontend.parse_audio(yw)) < 2e-5
+
+
+@pytest.mark.parametrize('M,N,K,gate,bias', [(2000, 512, 5120, False, True), (300, 640, 512, True, False), (77, 132, 96, True, True),
+                                             (1000, 5120, 512, True, False)])
+def test_gemm_nt_two_piece_fp16(L, M, N, K, gate, bias):
+    """C = A . B^T (+ bias) (gated) on fp16 pairs (mtl_gemm_nt_h2; split-K with a fixed-order reduction for few-tile products):
+    against fp64 no less accurate than 2x the exact-fp32 MFMA GEMM of this library, bitwise reproducible, any magnitude."""
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g) * 3e-4
+    A[0, 0] = 0.05                                         # outlier far above the bulk
+    B = torch.randn(N, K, generator=g) * 7.0
+    bv = torch.randn(N, generator=g) * 1e-3 if bias else None
+    gt = torch.randn(M, N, generator=g) if gate else None
+    want = A.double() @ B.double().t()
+    if bias:
+        want = want + bv.double()
+    if gate:
+        want = want * (gt > 0).double()
+    dA, dB = dev(A), dev(B)
+    dbv, dgt = (dev(bv) if bias else None), (dev(gt) if gate else None)
+    S = 2048
+    aa = torch.zeros(S).cuda()
+    ab = torch.zeros(S).cuda()
+    assert L.mtl_absmax_f32(st(), dA.data_ptr(), A.numel(), aa.data_ptr()) == 0
+    assert L.mtl_absmax_f32(st(), dB.data_ptr(), B.numel(), ab.data_ptr()) == 0
+    assert float(aa.max()) == float(A.abs().max()) and float(ab.max()) == float(B.abs().max())
+    assert L.mtl_gemm_nt_h2_supported(M, N, K) == 1 and L.mtl_gemm_nt_h2_supported(M, N, K + 8) == 0
+    need = L.mtl_gemm_nt_h2_workspace(M, N, K)
+    ws = torch.empty(need // 4 + 4).cuda()
+    C, C2 = torch.full((M, N), 7.0).cuda(), torch.empty(M, N).cuda()
+    args = lambda out: (st(), M, N, K, dA.data_ptr(), K, aa.data_ptr(), dB.data_ptr(), K, ab.data_ptr(), out.data_ptr(), N,
+                        dbv.data_ptr() if bias else None, dgt.data_ptr() if gate else None, N, ws.data_ptr(), need)
+    assert L.mtl_gemm_nt_h2(*args(C)) == 0
+    assert L.mtl_gemm_nt_h2(*args(C2)) == 0
+    assert torch.equal(C, C2)
+    F32 = torch.empty(M, N).cuda()
+    need32 = 64 << 20
+    ws32 = torch.empty(need32 // 4).cuda()
+    assert L.mtl_gemm_f32(st(), 0, 1, M, N, K, 1.0, dA.data_ptr(), K, dB.data_ptr(), K, F32.data_ptr(), N, dbv.data_ptr() if bias else None,
+                          dgt.data_ptr() if gate else None, N, 0, 1, 1, 0, 0, 0, 0, 0, 0, 0, ws32.data_ptr(), need32) == 0
+    e2, e32 = rel(C.double().cpu(), want), rel(F32.double().cpu(), want)
+    assert e2 < 2.0 * e32 + 1e-30 and e2 < 1e-6, (e2, e32)
+    if need:
+        assert L.mtl_gemm_nt_h2(*(args(C)[:-1] + (need - 4,))) != 0       # short workspace is refused

@@ -53,8 +53,8 @@ def conv_case(name, T_, F_, cin, cout, pooled):
     nb = L.mtl_conv3x3_wprep_h2_bytes(cout, cin)
     w2f = torch.empty(nb, dtype=torch.uint8, device=dev); w2d = torch.empty_like(w2f)
     L.mtl_conv3x3_wprep_h2(st(), w.data_ptr(), w2f.data_ptr(), w2d.data_ptr(), cout, cin)
-    ax, ady = x.abs().max().reshape(1).repeat(64), dy.abs().max().reshape(1).repeat(64)
-    slot = torch.zeros(64, device=dev)
+    ax, ady = x.abs().max().reshape(1).repeat(2048), dy.abs().max().reshape(1).repeat(2048)
+    slot = torch.zeros(2048, device=dev)
     if pooled:
         t = timeit(lambda: L.mtl_conv3x3_relu_pool_fwd_h2(st(), x.data_ptr(), ax.data_ptr(), w2f.data_ptr(), bias.data_ptr(), y.data_ptr(), am.data_ptr(), slot.data_ptr(), B, T_, F_, cin, cout))
     else:

@@ -5,7 +5,7 @@ L = mtl_amd._lib.lib()
 st = lambda: torch.cuda.current_stream().cuda_stream
 B, T, F = 8, 1000, 161
 x = torch.randn(B, 1, F, T, device='cuda'); w = torch.randn(64, 1, 3, 3, device='cuda') * 0.3; b = torch.randn(64, device='cuda')
-y = torch.empty(B, T, F, 64, device='cuda'); slot = torch.zeros(64, device='cuda')
+y = torch.empty(B, T, F, 64, device='cuda'); slot = torch.zeros(2048, device='cuda')
 def timeit(fn, reps=20):
     fn(); torch.cuda.synchronize()
     a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -30,7 +30,7 @@ for Cin, Cout, B, T, Fq in [(64, 64, 2, 21, 161), (128, 128, 1, 9, 19)]:
     w2f = torch.empty(nb, dtype=torch.uint8).cuda(); w2d = torch.empty_like(w2f)
     L.mtl_conv3x3_wprep_h2(st(), dw.data_ptr(), w2f.data_ptr(), w2d.data_ptr(), Cout, Cin)
     for name, ax in (('h2', 40.0), ('h2 amax x8', 320.0), ('h2 amax x64', 2560.0)):
-        a = torch.tensor([ax] * 64).cuda()
+        a = torch.tensor([ax] * 2048).cuda()
         L.mtl_conv3x3_relu_fwd_h2(st(), dxn.data_ptr(), a.data_ptr(), w2f.data_ptr(), db.data_ptr(), y.data_ptr(), None, B, T, Fq, Cin, Cout)
         out[name] = rel(y.permute(0, 3, 2, 1).double().cpu(), y64)
     print((Cin, Cout), ' '.join('%s=%.2e' % kv for kv in out.items()))
