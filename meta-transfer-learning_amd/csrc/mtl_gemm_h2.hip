@@ -56,15 +56,17 @@ __global__ __launch_bounds__(NT) void gemm_nt_h2_kernel(H2P p) {
         gb[i] = p.B + (long)min(n0 + r, p.N - 1) * p.ldb + (long)kt0 * BK + k4;
         dst[i] = r * 64 + (((k4 >> 3) ^ ((r >> 2) & 3)) << 4) + (k4 & 7) * 2;
     }
-    float4 ra[4], rb[4];
-    auto fetch = [&](int kt) {
+    // two register sets: the tile of step s lives in set s & 1 from the start of step s - 2 (two steps of flight time) until it is
+    // split into LDS stage (s & 1) during step s - 1
+    float4 ra0[4], rb0[4], ra1[4], rb1[4];
+    auto fetch = [&](int kt, float4 (&ra)[4], float4 (&rb)[4]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             ra[i] = *reinterpret_cast<const float4*>(ga[i] + (long)kt * BK);
             rb[i] = *reinterpret_cast<const float4*>(gb[i] + (long)kt * BK);
         }
     };
-    auto commit = [&](int stage) {
+    auto commit = [&](int stage, const float4 (&ra)[4], const float4 (&rb)[4]) {
         unsigned char* s = sm + stage * STAGE;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -93,15 +95,8 @@ __global__ __launch_bounds__(NT) void gemm_nt_h2_kernel(H2P p) {
 #pragma unroll
     for (int st = 0; st < 2; ++st) csw[st] = ((st * 2 + hi) ^ ((l31 >> 2) & 3)) << 4;
 
-    if (nk > 0) {
-        fetch(0);
-        commit(0);
-    }
-    __syncthreads();
-#pragma unroll 1
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) fetch(kt + 1);
-        const unsigned char* s = sm + (kt & 1) * STAGE;
+    auto compute = [&](int stage) {
+        const unsigned char* s = sm + stage * STAGE;
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
             uint4 a[2][2], b[2][2];
@@ -117,8 +112,26 @@ __global__ __launch_bounds__(NT) void gemm_nt_h2_kernel(H2P p) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = h2_mfma(a[i], b[j], acc[i][j]);
         }
-        if (kt + 1 < nk) commit((kt + 1) & 1);       // the other stage: last read in step kt - 1, every wave is past that barrier
+    };
+    // step kt: issue the loads of step kt + 2 (their set was emptied during step kt - 1), multiply stage kt & 1, then split the
+    // tile of step kt + 1 into the other stage (last read in step kt - 1: every wave is past that barrier).  The scheduling
+    // barriers keep the split -- and the wait for its loads -- BEHIND the MFMAs instead of hoisted above them.
+    auto step = [&](int kt, float4 (&rac)[4], float4 (&rbc)[4], const float4 (&ran)[4], const float4 (&rbn)[4]) {
+        if (kt + 2 < nk) fetch(kt + 2, rac, rbc);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(kt & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < nk) commit((kt + 1) & 1, ran, rbn);
         __syncthreads();
+    };
+    if (nk > 0) fetch(0, ra0, rb0);
+    if (nk > 1) fetch(1, ra1, rb1);
+    if (nk > 0) commit(0, ra0, rb0);
+    __syncthreads();
+#pragma unroll 1
+    for (int kt = 0; kt < nk; kt += 2) {
+        step(kt, ra0, rb0, ra1, rb1);
+        if (kt + 1 < nk) step(kt + 1, ra1, rb1, ra0, rb0);
     }
 
     const float inv = 1.f / (sa * sb);
@@ -129,19 +142,24 @@ __global__ __launch_bounds__(NT) void gemm_nt_h2_kernel(H2P p) {
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wn * 64 + j * 32 + l31;
-            if (col >= p.N) continue;
+            const int col = min(n0 + wn * 64 + j * 32 + l31, p.N - 1);
+            const bool cok = n0 + wn * 64 + j * 32 + l31 < p.N;
             const float bb = (direct && p.bias) ? p.bias[col] : 0.f;
+            float gt[16];                                   // the 16 gate values of this accumulator in flight together
+            if (direct && p.gate) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int row = m0 + wm * 64 + i * 32 + 8 * g + 4 * hi + k;
-                    if (row >= p.M) continue;
-                    float v = acc[i][j][4 * g + k] * inv + bb;
-                    if (direct && p.gate) v = p.gate[(long)row * p.ldg + col] > 0.f ? v : 0.f;
-                    out[(long)row * ldo + col] = v;
+                for (int v = 0; v < 16; ++v) {
+                    const int row = min(m0 + wm * 64 + i * 32 + 8 * (v >> 2) + 4 * hi + (v & 3), p.M - 1);
+                    gt[v] = p.gate[(long)row * p.ldg + col];
                 }
+            }
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int row = m0 + wm * 64 + i * 32 + 8 * (v >> 2) + 4 * hi + (v & 3);
+                float x = acc[i][j][v] * inv + bb;
+                if (direct && p.gate) x = gt[v] > 0.f ? x : 0.f;
+                if (cok && row < p.M) out[(long)row * ldo + col] = x;
+            }
         }
 }
 
