@@ -846,15 +846,19 @@ __device__ inline X3Tile x3_tile(const ConvX3P& p, int id) {
     return t;
 }
 
-template <int BN, int G, bool UNPOOL, int EPI, int NP>
-__global__ __launch_bounds__((4 * G + 4) * 64) void conv3x3_x3h_kernel(ConvX3P p) {
-    using E = Engine<128, BN, LoadConvA<UNPOOL>, LoadMNMajor<BN, true>>;   // tile constants only
-    constexpr int TM = E::TM, TN = E::TN, WTM = E::WTM, WTN = E::WTN;
+// WN = consumer waves along the output channels of a 128-pixel sub-tile (2 pixel halves x WN): 2 -> each wave owns 64 px x BN/2 ch,
+// 1 -> 64 px x BN ch.  The fragment reads of a wave feed TM x TN MFMA groups, (TM + TN) NP ds_read_b128 per TM TN groups: with
+// 64 output channels WN = 2 means 3 reads per group (two-piece fp16: LDS 100 % busy at 50 % matrix-pipe load), WN = 1 means 2.
+template <int BN, int G, bool UNPOOL, int EPI, int NP, int WN>
+__global__ __launch_bounds__((2 * WN * G + 4) * 64) __attribute__((amdgpu_waves_per_eu(WN == 1 ? 4 : 1)))   // WN = 1: two workgroups per CU
+void conv3x3_x3h_kernel(ConvX3P p) {
+    constexpr int CW = 2 * WN;                                      // consumer waves per 8 x 16 sub-tile
+    constexpr int WTM = 64, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
     constexpr int XH_HT = 8 * G + 2, XH_NPIX = XH_HT * XH_HF;      // halo of an (8 G) x 16 tile
     constexpr int XH_APLANE = XH_NPIX * X3_ROWB;                   // one bf16 plane of the halo
     constexpr int NHALO = 3 * 64;                                  // halo threads (producer waves 1-3)
     constexpr int XH_NVA = (XH_NPIX * 8 + NHALO - 1) / NHALO;      // float4 (4 channels) per halo thread and chunk
-    constexpr int NCONS = 4 * G * 64;                              // consumer threads
+    constexpr int NCONS = CW * G * 64;                             // consumer threads
     constexpr int BPLANE = BN * 64, BBUF = NP * BPLANE, ABUF = NP * XH_APLANE;   // weights: unpadded swizzled 64-byte rows
     constexpr int NDMA = BBUF / 1024;                              // wave-wide 16-byte DMA instructions per weight tile
     extern __shared__ __attribute__((aligned(16))) unsigned char smx[];
@@ -991,8 +995,8 @@ __global__ __launch_bounds__((4 * G + 4) * 64) void conv3x3_x3h_kernel(ConvX3P p
 
     // ---------------------------------------------------------------------- consumers (G sub-tiles x (2 x 2) waves)
     const int lane = tid & 63, wave = tid >> 6;
-    const int grp = wave >> 2, w4 = wave & 3;
-    const int wm = w4 >> 1, wn = w4 & 1, l31 = lane & 31, hi = lane >> 5;
+    const int grp = wave / CW, w4 = wave % CW;
+    const int wm = w4 / WN, wn = w4 % WN, l31 = lane & 31, hi = lane >> 5;
     f32x16 acc[TM][TN];
     float inv = 1.f, mx = 0.f;                                 // NP = 2: 1 / (activation scale x weight scale); running bound of max|y|
     if (NP == 2) inv = 1.f / (pow2_scale(amax_read(p.amax_in)) * *reinterpret_cast<const float*>(p.w3 + (long)NP * nk * Cout * 64));
@@ -1011,7 +1015,12 @@ __global__ __launch_bounds__((4 * G + 4) * 64) void conv3x3_x3h_kernel(ConvX3P p
     int bst = 0;                                               // weight stage of the current step (step % 3)
 #pragma unroll 1
     for (int j = 0; j < my_tiles; ++j) {
-        E::zero(acc);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) acc[i][jn][v] = 0.f;
 #pragma unroll 1
         for (int c = 0; c < cch; ++c) {
 #pragma unroll 1
@@ -1108,12 +1117,13 @@ __global__ __launch_bounds__((4 * G + 4) * 64) void conv3x3_x3h_kernel(ConvX3P p
     }
 }
 
-template <int BN, int G, bool UNPOOL, int EPI, int NP>
+template <int BN, int G, bool UNPOOL, int EPI, int NP, int WN = 2>
 int launch_conv_x3h(ConvX3P p, int Te, int Fe, hipStream_t s) {
     constexpr int SMEM = NP * (8 * G + 2) * XH_HF * X3_ROWB + 3 * NP * BN * 64;
-    static int attr = set_smem(conv3x3_x3h_kernel<BN, G, UNPOOL, EPI, NP>, SMEM);
+    constexpr int THREADS = (2 * WN * G + 4) * 64;
+    static int attr = set_smem(conv3x3_x3h_kernel<BN, G, UNPOOL, EPI, NP, WN>, SMEM);
     if (attr) return attr;
-    static const int per_cu = (G == 1 && SMEM <= 80 * 1024) ? 2 : 1;     // 12-wave workgroups (G = 2) never share a CU
+    static const int per_cu = (THREADS <= 512 && SMEM <= 80 * 1024) ? 2 : 1;     // 12-wave workgroups never share a CU
     static const int ncu = device_cu_count();
     static const int dbg = getenv("MTL_X3_DBG") ? atoi(getenv("MTL_X3_DBG")) : 0;
     p.dbg = dbg;
@@ -1121,7 +1131,7 @@ int launch_conv_x3h(ConvX3P p, int Te, int Fe, hipStream_t s) {
     p.ntt = (Te + 8 * G - 1) / (8 * G);
     p.tiles = p.ntf * p.ntt * p.g.B * p.ntile;
     const int grid = p.tiles < ncu * per_cu ? p.tiles : ncu * per_cu;
-    hipLaunchKernelGGL((conv3x3_x3h_kernel<BN, G, UNPOOL, EPI, NP>), dim3(grid), dim3((4 * G + 4) * 64), SMEM, s, p);
+    hipLaunchKernelGGL((conv3x3_x3h_kernel<BN, G, UNPOOL, EPI, NP, WN>), dim3(grid), dim3(THREADS), SMEM, s, p);
     MTL_CHECK_LAUNCH();
     return MTL_OK;
 }
@@ -1137,6 +1147,13 @@ int dispatch_conv_x3(ConvX3P& p, int Te, int Fe, hipStream_t s) {
         return g1 ? launch_conv_x3h<128, 1, UNPOOL, EPI, NP>(p, Te, Fe, s) : launch_conv_x3h<128, 2, UNPOOL, EPI, NP>(p, Te, Fe, s);
     }
     p.ntile = p.g.Cout / 64;
+    // two-piece fp16 forward, 64 output channels: 16 x 16 tiles with FOUR consumer waves of 64 px x 64 ch, two workgroups per CU
+    // (LDS-bound with 32-channel waves, see the kernel's header: conv2 forward 0.385 -> 0.341 ms); the data-gradient epilogue does not
+    // fit the 128-VGPR budget of that shape (spills: 0.45 -> 0.71 ms).  MTL_X3_WN2 keeps the older shape for A/B measurements
+    static const bool wn2 = getenv("MTL_X3_WN2") != nullptr;
+    if constexpr (NP == 2 && EPI != EPI_DGRAD) {
+        if (!wn2 && !g1) return launch_conv_x3h<64, 2, UNPOOL, EPI, NP, 1>(p, Te, Fe, s);
+    }
     if (p.g.Cin == 64 || g1) return launch_conv_x3h<64, 1, UNPOOL, EPI, NP>(p, Te, Fe, s);
     return launch_conv_x3h<64, 2, UNPOOL, EPI, NP>(p, Te, Fe, s);
 }
