@@ -165,7 +165,7 @@ def classify(lib, name, a, conv_mode, wgrad_x3_dense):
         return 'layernorm_fwd', 4.0 * rows * d * (4 if a[2] else 3), 'byte', 'layernorm_fwd_kernel'
     if name == 'mtl_layernorm_bwd':
         rows, d = a[15], a[16]
-        return 'layernorm_bwd', 4.0 * rows * d * (4 if a[10] else 3), 'byte', 'layernorm_bwd_kernel + ln_param_reduce_kernel'
+        return 'layernorm_bwd', 4.0 * rows * d * (4 if a[10] else 3), 'byte', 'layernorm_bwd_kernel (parameter reductions: ln_param_reduce_batch_kernel, once per pass)'
     if name == 'mtl_ce_argmax_fwd':
         return 'ce_fwd', 4.0 * a[3] * a[4], 'byte', 'ce_fwd_kernel'
     if name == 'mtl_ce_bwd':

@@ -198,7 +198,19 @@ int mtl_layernorm_bwd(void* stream, const float* dy, const float* xhat, const fl
                       const int* keep, const unsigned char* xmask, float xscale, float* dz, float* dzm /*nullable*/,
                       float* dz2 /*nullable*/, float* dgamma /*accum*/, float* dbeta /*accum*/,
                       float* dsum /*nullable, accum: += column sums of the sub-layer-branch gradient (its linear's bias grad)*/,
-                      float* workspace, int rows, int d);
+                      float* workspace, int rows, int d,
+                      int defer_reduce /* 1: leave the per-wave partials in `workspace` (keep it alive, one per instance) and add them
+                                          to dgamma / dbeta / dsum later with mtl_ln_param_reduce_batch */);
+/* the deferred parameter reductions of several mtl_layernorm_bwd calls in ONE launch (table in device memory; nw = workspace bytes
+ * / (3 * d * 4); dmax = largest d of the table) */
+typedef struct mtl_ln_reduce_desc {
+    const float* part;
+    float* dgamma;
+    float* dbeta;
+    float* dsum; /* nullable */
+    int nw, d;
+} mtl_ln_reduce_desc;
+int mtl_ln_param_reduce_batch(void* stream, const mtl_ln_reduce_desc* table_dev, int n, int dmax);
 
 /* ---- masked softmax: modules/common_layers.py:322-327.  S is [B][H][Tq][ld], in place.
  * keys k >= klen[b] (klen nullable) and, if causal, k > q are filled with -inf before the softmax. */

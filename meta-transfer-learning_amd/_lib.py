@@ -51,7 +51,8 @@ SIGNATURES = {
     'mtl_permute_hc': (I, [P, P, P, I, I, I, I]),
     'mtl_layernorm_fwd': (I, [P, P, P, P, P, P, P, P, F, P, P, P, I, I, I, F]),
     'mtl_layernorm_bwd_workspace': (L, [I, I]),
-    'mtl_layernorm_bwd': (I, [P, P, P, P, P, P, P, F, P, P, P, P, P, P, P, I, I]),
+    'mtl_layernorm_bwd': (I, [P, P, P, P, P, P, P, F, P, P, P, P, P, P, P, I, I, I]),
+    'mtl_ln_param_reduce_batch': (I, [P, P, I, I]),
     'mtl_softmax_mask_fwd': (I, [P, P, P, I, F, I, I, I, I, I, P, F, P]),
     'mtl_softmax_bwd': (I, [P, P, P, F, L, I, I, P, F]),
     'mtl_attn_supported': (I, [I, I]),
@@ -119,6 +120,11 @@ class WgradDesc(ctypes.Structure):
 
 
 AMAX_SLOTS = 64 * 32    # MTL_AMAX_FLOATS of include/mtl_hip.h: floats per max|tensor| bound of the h2 kernels (64 slot heads, 128 B apart)
+
+
+class LnReduceDesc(ctypes.Structure):
+    """mtl_ln_reduce_desc of include/mtl_hip.h (40 bytes)"""
+    _fields_ = [('part', c_void_p), ('dgamma', c_void_p), ('dbeta', c_void_p), ('dsum', c_void_p), ('nw', c_int), ('d', c_int)]
 
 
 class TransposeDesc(ctypes.Structure):

@@ -237,6 +237,7 @@ class PassEngine:
         # workgroup per 16-32 rows streams all 400 KB of both weights at the per-CU rate), so opt-in.
         self.fused_pairs = os.environ.get('MTL_FUSED_PAIRS', '0') == '1'
         self._tr_tables = {}
+        self._ln_pending, self._ln_tables = [], {}
         self.batch_qkv = os.environ.get('MTL_BATCH_QKV', '1') != '0'   # q/k/v projections as strided-batch GEMMs
         self.wgrad_x3_dense = os.environ.get('MTL_WGRAD_X3_DENSE', '1') != '0'    # conv5 (dy not pooled)
         # scaled-dot-product attention as ONE flash-style kernel forward and two backward (no score tensor in HBM); head sizes
@@ -450,9 +451,28 @@ class PassEngine:
                                          self.drop_scale, y, xhat, rstd, rows, self.hp.d, T, 1e-5), 'mtl_layernorm_fwd')
 
     def ln_bwd(self, dy, xhat, rstd, g, keep, dz, dg, db, rows, dsum=None, xmask=None, dzm=None, dz2=None):
-        ws = self.scratch(self.lib.mtl_layernorm_bwd_workspace(rows, self.hp.d))
+        """LayerNorm backward; the reduction of its per-wave partials into dgamma / dbeta / dsum is DEFERRED: every instance keeps
+        its partials in its own buffer and flush_ln_reduce() adds all of them with one launch (17 launches of 5 us before)."""
+        d = self.hp.d
+        nbytes = self.lib.mtl_layernorm_bwd_workspace(rows, d)
+        part = self.buf('lnpart.%x' % xhat, (nbytes // 4,))
         check(self.lib.mtl_layernorm_bwd(self.stream, dy, xhat, rstd, g, keep, xmask.data_ptr() if xmask is not None else None,
-                                         self.drop_scale, dz, dzm, dz2, dg, db, dsum, ws, rows, self.hp.d), 'mtl_layernorm_bwd')
+                                         self.drop_scale, dz, dzm, dz2, dg, db, dsum, part.data_ptr(), rows, d, 1), 'mtl_layernorm_bwd')
+        self._ln_pending.append((part.data_ptr(), dg, db, dsum or 0, nbytes // (3 * d * 4), d))
+
+    def flush_ln_reduce(self):
+        pend, self._ln_pending = tuple(self._ln_pending), []
+        if not pend:
+            return
+        dev = self._ln_tables.get(pend)
+        if dev is None:
+            table = (_lib.LnReduceDesc * len(pend))()
+            for t, (part, dg, db, dsum, nw, d) in zip(table, pend):
+                t.part, t.dgamma, t.dbeta, t.dsum, t.nw, t.d = part, dg, db, dsum or None, nw, d
+            dev = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8).to(self.device)
+            self._ln_tables[pend] = dev
+        check(self.lib.mtl_ln_param_reduce_batch(self.stream, dev.data_ptr(), len(pend), max(p[5] for p in pend)),
+              'mtl_ln_param_reduce_batch')
 
     # ---------------------------------------------------------------- attention / ffn blocks
     def mha_fwd(self, tag, P, pre, xq, Bn, Tq, xkv, Tk, klen, causal, keep):
@@ -1038,6 +1058,7 @@ class PassEngine:
         self.ln_bwd(dcur.data_ptr(), A['enc_in.xhat'].data_ptr(), A['enc_in.rstd'].data_ptr(), o('encoder.layer_norm_input.weight'),
                     None, de0.data_ptr(), g('encoder.layer_norm_input.weight'), g('encoder.layer_norm_input.bias'), Me,
                     dsum=g('encoder.input_linear.bias'))
+        self.flush_ln_reduce()     # the parameter / bias gradients of all 17 LayerNorms of the pass: one launch
         p2, y5, p1, y1 = A['p2'], A['y5'], A['p1'], A['y1']
         dwp = self.buf('_dwp', (d, hp.d_in))
         dp2 = self.buf('_dp2', (B, T4, F4, 128))

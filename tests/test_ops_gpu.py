@@ -453,9 +453,25 @@ def test_layernorm(L, d):
     ddy = dev(dy)
     dsum = torch.ones(d).cuda()
     assert L.mtl_layernorm_bwd(st(), ddy.data_ptr(), xhat.data_ptr(), rstd.data_ptr(), a[2].data_ptr(), kd.data_ptr(), None, 1.0,
-                               dz.data_ptr(), None, None, dg.data_ptr(), db.data_ptr(), dsum.data_ptr(), ws.data_ptr(), rows, d) == 0
+                               dz.data_ptr(), None, None, dg.data_ptr(), db.data_ptr(), dsum.data_ptr(), ws.data_ptr(), rows, d, 0) == 0
     assert rel(dz, xr.grad) < 1e-5 and rel(dg, gr.grad) < 1e-5 and rel(db, br.grad) < 1e-5
     assert rel(dsum, xr.grad.sum(0) + 1) < 1e-5
+    # deferred form: the partials stay in the workspace, one batched launch adds them (two table entries here, one without dsum)
+    import ctypes
+    from mtl_amd import _lib
+    dz_b, dg2, db2, dg3, db3, ds2 = (torch.empty(rows, d).cuda(), torch.zeros(d).cuda(), torch.zeros(d).cuda(), torch.ones(d).cuda(),
+                                     torch.zeros(d).cuda(), torch.zeros(d).cuda())
+    assert L.mtl_layernorm_bwd(st(), ddy.data_ptr(), xhat.data_ptr(), rstd.data_ptr(), a[2].data_ptr(), kd.data_ptr(), None, 1.0,
+                               dz_b.data_ptr(), None, None, dg2.data_ptr(), db2.data_ptr(), ds2.data_ptr(), ws.data_ptr(), rows, d, 1) == 0
+    torch.cuda.synchronize()
+    assert float(dg2.abs().sum()) == 0.0 and torch.equal(dz_b, dz)
+    table = (_lib.LnReduceDesc * 2)()
+    nw = L.mtl_layernorm_bwd_workspace(rows, d) // (3 * d * 4)
+    table[0].part, table[0].dgamma, table[0].dbeta, table[0].dsum, table[0].nw, table[0].d = ws.data_ptr(), dg2.data_ptr(), db2.data_ptr(), ds2.data_ptr(), nw, d
+    table[1].part, table[1].dgamma, table[1].dbeta, table[1].dsum, table[1].nw, table[1].d = ws.data_ptr(), dg3.data_ptr(), db3.data_ptr(), None, nw, d
+    tdev = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8).cuda()
+    assert L.mtl_ln_param_reduce_batch(st(), tdev.data_ptr(), 2, d) == 0
+    assert torch.equal(dg2, dg) and torch.equal(db2, db) and torch.equal(ds2 + 1, dsum) and torch.equal(dg3, dg + 1) and torch.equal(db3, db)
     # with dropout on the sub-layer output x (before the residual): forward and both gradient branches
     p = 0.25
     seed = torch.tensor([1234567], dtype=torch.int64).cuda()
@@ -473,7 +489,7 @@ def test_layernorm(L, d):
     dsum.zero_(); dg.zero_(); db.zero_()
     assert L.mtl_layernorm_bwd(st(), ddy.data_ptr(), xhat.data_ptr(), rstd.data_ptr(), a[2].data_ptr(), kd.data_ptr(), mask.data_ptr(),
                                sc, dz.data_ptr(), dzm.data_ptr(), dz2.data_ptr(), dg.data_ptr(), db.data_ptr(), dsum.data_ptr(), ws.data_ptr(),
-                               rows, d) == 0
+                               rows, d, 0) == 0
     assert rel(dz, rr.grad) < 1e-5 and rel(dzm, xr.grad) < 1e-5 and rel(dsum, xr.grad.sum(0)) < 1e-5 and rel(dg, gr.grad) < 1e-5
     assert torch.equal(dz2, dz)                                             # second copy for the residual path
 
