@@ -57,7 +57,9 @@ int mtl_gemm_f32(void* stream, int transA, int transB, int M, int N, int K, floa
 int mtl_gemm_f32_ex(void* stream, int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
                     const float* B, int ldb, float* C, int ldc, const float* bias, const float* gate, int ldg, int flags,
                     int batch, int H, long sAb, long sAh, long sBb, long sBh, long sCb, long sCh, long sBias, int kbatch, long sAk,
-                    long sBk, float* rowsum, long sRowsum, float* workspace, long workspace_bytes);
+                    long sBk, float* rowsum, long sRowsum, float* workspace, long workspace_bytes,
+                    long sBiasH, long sRowsumH /* bias / rowsum strides of the INNER batch index (z % H); sBias / sRowsum belong to z / H:
+                                                  e.g. the K and V projections (inner) of all decoder layers (outer) in one launch */);
 /* which engine mtl_gemm_f32_ex picks: 1 = small-tile (kernel symbol gemm16_kernel<...>), 0 = forwarded to mtl_gemm_f32
  * (gemm_kernel<...>); used by bench.py to attribute launch timings to the rocprofv3 kernel classes */
 int mtl_gemm_f32_ex_route(int M, int N, int K, int batch, int kbatch, int has_rowsum);
@@ -320,7 +322,7 @@ typedef struct mtl_cmd {
         void* p;
         long l;
         double d;
-    } a[34];
+    } a[36];
 } mtl_cmd;
 int mtl_cmdlist_opcode(const char* function_name);     /* -1 if the function cannot be recorded */
 int mtl_cmdlist_run(const mtl_cmd* cmds, int n, int* failed_index);

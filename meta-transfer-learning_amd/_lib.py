@@ -17,7 +17,7 @@ P, I, L, F = c_void_p, c_int, c_long, c_float
 SIGNATURES = {
     'mtl_abi_version': (I, []),
     'mtl_gemm_f32': (I, [P, I, I, I, I, I, F, P, I, P, I, P, I, P, P, I, I, I, I, L, L, L, L, L, L, L, P, L]),
-    'mtl_gemm_f32_ex': (I, [P, I, I, I, I, I, F, P, I, P, I, P, I, P, P, I, I, I, I, L, L, L, L, L, L, L, I, L, L, P, L, P, L]),
+    'mtl_gemm_f32_ex': (I, [P, I, I, I, I, I, F, P, I, P, I, P, I, P, P, I, I, I, I, L, L, L, L, L, L, L, I, L, L, P, L, P, L, L, L]),
     'mtl_gemm_f32_ex_route': (I, [I, I, I, I, I, I]),
     'mtl_gemm_wgrad_grouped': (I, [P, P, I, I]),
     'mtl_lowrank_supported': (I, [I, I, I]),
@@ -137,7 +137,7 @@ class _CmdArg(ctypes.Union):
 
 
 class MtlCmd(ctypes.Structure):
-    _fields_ = [('op', c_int), ('nargs', c_int), ('a', _CmdArg * 34)]
+    _fields_ = [('op', c_int), ('nargs', c_int), ('a', _CmdArg * 36)]
 
 
 def _kinds(name):

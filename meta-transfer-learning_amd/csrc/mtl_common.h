@@ -27,6 +27,11 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// big-engine GEMM with bias strides for both batch levels (mtl_mfma.hip; what mtl_gemm_f32_ex forwards to)
+int mtl_gemm_f32_2l(void* stream, int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda, const float* B,
+                    int ldb, float* C, int ldc, const float* bias, const float* gate, int ldg, int flags, int batch, int H, long sAb,
+                    long sAh, long sBb, long sBh, long sCb, long sCh, long sBias, long sBiasH, float* workspace, long workspace_bytes);
+
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 #ifndef MTL_AMAX_SLOTS

@@ -45,6 +45,7 @@ struct G16P {
     long sAb, sAh, sBb, sBh, sCb, sCh, sBias;
     int kb;
     long sAk, sBk, sRow;
+    long sBiasH, sRowH;           // strides of the INNER batch index for bias / rowsum
     int total;       // workgroups = tiles in N x tiles in M x batch
     const mtl_wgrad_desc* groups;   // grouped mode: one launch covers `ngroups` independent products (descriptor table in HBM)
     int ngroups;
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(256 * KG) void gemm16_kernel(G16P p0) {
         for (int j = 0; j < WN; ++j) {
             const int col = n0 + 16 * (2 * j + wn) + l16;
             if (col >= p.N) continue;
-            const float bb = p.bias ? p.bias[zb * p.sBias + col] : 0.f;
+            const float bb = p.bias ? p.bias[zb * p.sBias + zh * p.sBiasH + col] : 0.f;
 #pragma unroll
             for (int i = 0; i < WM; ++i) {
                 // the accumulate / gate operands of the four rows are requested together (clamped rows), then consumed
@@ -299,7 +300,7 @@ __global__ __launch_bounds__(256 * KG) void gemm16_kernel(G16P p0) {
         if (kg == 0 && tid < TM && m0 + tid < p.M) {
             float tsum = 0.f;
             for (int q = 0; q < KG * KL; ++q) tsum += red[q * LDR + tid];
-            p.rowsum[zb * p.sRow + m0 + tid] += tsum;
+            p.rowsum[zb * p.sRow + zh * p.sRowH + m0 + tid] += tsum;
         }
     }
 }
@@ -381,14 +382,14 @@ int mtl_gemm_wgrad_grouped(void* stream, const mtl_wgrad_desc* table_dev, int n_
 int mtl_gemm_f32_ex(void* stream, int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
                     const float* B, int ldb, float* C, int ldc, const float* bias, const float* gate, int ldg, int flags,
                     int batch, int H, long sAb, long sAh, long sBb, long sBh, long sCb, long sCh, long sBias, int kbatch, long sAk,
-                    long sBk, float* rowsum, long sRowsum, float* workspace, long workspace_bytes) {
+                    long sBk, float* rowsum, long sRowsum, float* workspace, long workspace_bytes, long sBiasH, long sRowsumH) {
     if (M <= 0 || N <= 0 || K <= 0 || batch <= 0 || H <= 0 || kbatch <= 0 || !A || !B || !C) return MTL_EINVAL;
     if (rowsum && !transA) return MTL_EINVAL;
     if (!route_small(M, N, K, batch, kbatch, rowsum != nullptr))
-        return mtl_gemm_f32(stream, transA, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, bias, gate, ldg, flags, batch, H, sAb,
-                            sAh, sBb, sBh, sCb, sCh, sBias, workspace, workspace_bytes);
+        return mtl_gemm_f32_2l(stream, transA, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, bias, gate, ldg, flags, batch, H, sAb,
+                               sAh, sBb, sBh, sCb, sCh, sBias, sBiasH, workspace, workspace_bytes);
     G16P p{A, B, C, bias, gate, rowsum, M, N, K, lda, ldb, ldc, ldg, alpha, flags, H, sAb, sAh, sBb, sBh, sCb, sCh, sBias, kbatch,
-           sAk, sBk, sRowsum, 0, nullptr, 0};
+           sAk, sBk, sRowsum, sBiasH, sRowsumH, 0, nullptr, 0};
     hipStream_t s = as_stream(stream);
     if (!transA && transB) return launch16<false, true>(p, batch, s);
     if (!transA && !transB) return launch16<false, false>(p, batch, s);

@@ -252,6 +252,7 @@ struct GemmP {
     int ksplit, kchunk;   // ksplit > 1: grid.z = (batch item) * ksplit + K-chunk; raw partial tiles go to `partial`
     float* partial;       // [batch item][ksplit][M][N]
     long sBias;           // bias stride of the OUTER batch index (0: one bias for all)
+    long sBiasH;          // ... and of the inner one
     int nz;               // batch items in total (grid.z without split-K)
 };
 
@@ -314,7 +315,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
     lb.init(B, p.ldb, n0, p.N, p.K, tid);
     E::run(la, lb, (p.K + BK - 1) / BK, smem, acc);
     const float* gate = p.gate ? p.gate + zb * p.sCb + zh * p.sCh : nullptr;
-    EpiGemm epi{C, p.bias ? p.bias + zb * p.sBias : nullptr, gate, p.M, p.N, m0, n0, p.ldc, p.ldg, p.flags, p.alpha};
+    EpiGemm epi{C, p.bias ? p.bias + zb * p.sBias + zh * p.sBiasH : nullptr, gate, p.M, p.N, m0, n0, p.ldc, p.ldg, p.flags, p.alpha};
     E::finish(acc, epi);
 }
 
@@ -329,7 +330,7 @@ __global__ void splitk_reduce_kernel(GemmP p) {
         const float* part = p.partial + (long)zi * p.ksplit * mn + r;
         float s = 0.f;
         for (int z = 0; z < p.ksplit; ++z) s += part[(long)z * mn];
-        float x = p.alpha * s + (p.bias ? p.bias[zb * p.sBias + col] : 0.f);
+        float x = p.alpha * s + (p.bias ? p.bias[zb * p.sBias + zh * p.sBiasH + col] : 0.f);
         if (p.flags & MTL_GEMM_RELU) x = fmaxf(x, 0.f);
         const long co = zb * p.sCb + zh * p.sCh;
         if (p.gate) x = p.gate[co + (long)row * p.ldg + col] > 0.f ? x : 0.f;
@@ -1652,19 +1653,27 @@ __global__ void conv_wprep_kernel(const float* w, float* wf, float* wd, int Cout
 }  // namespace
 
 // ================================================================== C ABI
+// mtl_gemm_f32 with a bias stride for the inner batch index too (library-internal: mtl_gemm_f32_ex forwards here)
+int mtl_gemm_f32_2l(void* stream, int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda, const float* B,
+                    int ldb, float* C, int ldc, const float* bias, const float* gate, int ldg, int flags, int batch, int H, long sAb,
+                    long sAh, long sBb, long sBh, long sCb, long sCh, long sBias, long sBiasH, float* workspace, long workspace_bytes) {
+    if (M <= 0 || N <= 0 || K <= 0 || batch <= 0 || H <= 0 || !A || !B || !C) return MTL_EINVAL;
+    GemmP p{A, B, C, bias, gate, M, N, K, lda, ldb, ldc, ldg, alpha, flags, H, sAb, sAh, sBb, sBh, sCb, sCh, 1, 0, nullptr, sBias, sBiasH, batch};
+    hipStream_t s = as_stream(stream);
+    if (!transA && transB) return dispatch_gemm<false, true>(p, batch, s, workspace, workspace_bytes);
+    if (!transA && !transB) return dispatch_gemm<false, false>(p, batch, s, workspace, workspace_bytes);
+    if (transA && !transB) return dispatch_gemm<true, false>(p, batch, s, workspace, workspace_bytes);
+    return dispatch_gemm<true, true>(p, batch, s, workspace, workspace_bytes);
+}
+
 extern "C" {
 
 int mtl_gemm_f32(void* stream, int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
                  const float* B, int ldb, float* C, int ldc, const float* bias, const float* gate, int ldg, int flags,
                  int batch, int H, long sAb, long sAh, long sBb, long sBh, long sCb, long sCh, long sBias, float* workspace,
                  long workspace_bytes) {
-    if (M <= 0 || N <= 0 || K <= 0 || batch <= 0 || H <= 0 || !A || !B || !C) return MTL_EINVAL;
-    GemmP p{A, B, C, bias, gate, M, N, K, lda, ldb, ldc, ldg, alpha, flags, H, sAb, sAh, sBb, sBh, sCb, sCh, 1, 0, nullptr, sBias, batch};
-    hipStream_t s = as_stream(stream);
-    if (!transA && transB) return dispatch_gemm<false, true>(p, batch, s, workspace, workspace_bytes);
-    if (!transA && !transB) return dispatch_gemm<false, false>(p, batch, s, workspace, workspace_bytes);
-    if (transA && !transB) return dispatch_gemm<true, false>(p, batch, s, workspace, workspace_bytes);
-    return dispatch_gemm<true, true>(p, batch, s, workspace, workspace_bytes);
+    return mtl_gemm_f32_2l(stream, transA, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, bias, gate, ldg, flags, batch, H, sAb, sAh, sBb,
+                           sBh, sCb, sCh, sBias, 0, workspace, workspace_bytes);
 }
 
 int mtl_conv3x3_wprep(void* stream, const float* w_ref, float* w_fwd, float* w_dgrad, int Cout, int Cin) {

@@ -238,6 +238,9 @@ class PassEngine:
         self.fused_pairs = os.environ.get('MTL_FUSED_PAIRS', '0') == '1'
         self._tr_tables = {}
         self._ln_pending, self._ln_tables = [], {}
+        # the K / V projections of ALL decoder layers' encoder-decoder attention read the same encoder output: one batched launch per
+        # low-rank stage forward, five launches backward (after the last decoder layer) instead of 2 + 4 per layer
+        self.hoist_kv = os.environ.get('MTL_HOIST_KV', '1') != '0'
         self.batch_qkv = os.environ.get('MTL_BATCH_QKV', '1') != '0'   # q/k/v projections as strided-batch GEMMs
         self.wgrad_x3_dense = os.environ.get('MTL_WGRAD_X3_DENSE', '1') != '0'    # conv5 (dy not pooled)
         # scaled-dot-product attention as ONE flash-style kernel forward and two backward (no score tensor in HBM); head sizes
@@ -275,12 +278,13 @@ class PassEngine:
         return torch.cuda.current_stream(self.device).cuda_stream
 
     def gemm(self, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias=None, gate=None, ldg=0, flags=0, alpha=1.0,
-             batch=1, H=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), sbias=0, kbatch=1, sAk=0, sBk=0, rowsum=None, srow=0):
-        """kbatch / sAk / sBk: sum over several (A, B) pairs inside one launch; rowsum: += row sums of op(A) (bias gradient)."""
+             batch=1, H=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), sbias=0, kbatch=1, sAk=0, sBk=0, rowsum=None, srow=0, sbias_h=0, srow_h=0):
+        """kbatch / sAk / sBk: sum over several (A, B) pairs inside one launch; rowsum: += row sums of op(A) (bias gradient);
+        sbias / srow stride the OUTER batch index z // H, sbias_h / srow_h the inner one z % H."""
         wst = self.gemm_ws_side if self.on_side else self.gemm_ws
         check(self.lib.mtl_gemm_f32_ex(self.stream, ta, tb, M, N, K, alpha, A, lda, B, ldb, C, ldc, bias, gate, ldg, flags,
                                        batch, H, sA[0], sA[1], sB[0], sB[1], sC[0], sC[1], sbias, kbatch, sAk, sBk, rowsum, srow,
-                                       wst.data_ptr(), wst.numel() * 4), 'mtl_gemm_f32_ex')
+                                       wst.data_ptr(), wst.numel() * 4, sbias_h, srow_h), 'mtl_gemm_f32_ex')
 
     # ---- byte-level helpers and flat-vector updates as LIBRARY calls (a task body made of library calls only can be recorded
     # into a command list and replayed from C; torch's own fill / copy kernels cannot)
@@ -475,7 +479,7 @@ class PassEngine:
               'mtl_ln_param_reduce_batch')
 
     # ---------------------------------------------------------------- attention / ffn blocks
-    def mha_fwd(self, tag, P, pre, xq, Bn, Tq, xkv, Tk, klen, causal, keep):
+    def mha_fwd(self, tag, P, pre, xq, Bn, Tq, xkv, Tk, klen, causal, keep, kv_ready=None):
         hp, L = self.hp, self.L
         d, r, h, dk, dv = hp.d, hp.r, hp.h, hp.dk, hp.dv
         Mq, Mk = Bn * Tq, Bn * Tk
@@ -489,6 +493,13 @@ class PassEngine:
         for names, src, rows in groups:
             n, f0 = len(names), _FULL[names[0]]
             wd = hv if names == 'v' else hk                  # groups of several projections exist only when hk == hv
+            if kv_ready is not None and names == 'kv':          # projected for all layers at once by cross_kv_fwd
+                a_all, b_all = kv_ready
+                self.arena[tag + names + 'a'], self.arena[tag + names] = a_all, b_all
+                for i, nm in enumerate(names):
+                    self.arena[tag + nm + 'a'], self.arena[tag + nm] = a_all[i], b_all[i]
+                    t[nm + 'a'], t[nm] = a_all[i], b_all[i]
+                continue
             a_all = self.buf(tag + names + 'a', (n, rows, r))
             b_all = self.buf(tag + names, (n, rows, wd))
             sa, sb, sbias = (self._pstride(pre, names, sfx) for sfx in ('_linear_a.weight', '_linear_b.weight', '_linear_b.bias'))
@@ -539,8 +550,10 @@ class PassEngine:
                     xhat.data_ptr(), rstd.data_ptr(), Mq, Tq, xmask=mo)
         return y
 
-    def mha_bwd(self, tag, P, G, pre, dy, xq, Bn, Tq, xkv, Tk, keep, dxq, dxkv, dxkv_accum):
-        """dy: grad of the block output.  Writes dxq (overwrite) and dxkv (accumulate when dxkv is dxq or flagged)."""
+    def mha_bwd(self, tag, P, G, pre, dy, xq, Bn, Tq, xkv, Tk, keep, dxq, dxkv, dxkv_accum, dkv_hoisted=None):
+        """dy: grad of the block output.  Writes dxq (overwrite) and dxkv (accumulate when dxkv is dxq or flagged).
+        dkv_hoisted: (2, rows, h d_k) slice that receives dK / dV when the K / V projections' backward runs once for all decoder
+        layers afterwards (cross_kv_bwd); dxkv is not touched then."""
         hp, L, A = self.hp, self.L, self.arena
         d, r, h, dk, dv = hp.d, hp.r, hp.h, hp.dk, hp.dv
         Mq, Mk = Bn * Tq, Bn * Tk
@@ -575,7 +588,8 @@ class PassEngine:
         groups = A[tag + 'groups']
         dfull = {}                                       # gradients of the projected q / k / v, grouped like the forward
         for names, _src, rows in groups:
-            d_all = self.buf(tag + '_d' + names, (len(names), rows, hv if names == 'v' else hk))
+            d_all = (dkv_hoisted if (dkv_hoisted is not None and names == 'kv') else
+                     self.buf(tag + '_d' + names, (len(names), rows, hv if names == 'v' else hk)))
             for i, nm in enumerate(names):
                 dfull[nm] = d_all[i]
             dfull[names] = d_all
@@ -606,6 +620,8 @@ class PassEngine:
                       sA=sP, sB=(Tq * hk, dk), sC=(Tk * hk, dk))
         kv_written = False
         for names, src, rows in groups:
+            if dkv_hoisted is not None and names == 'kv':
+                continue
             n, f0 = len(names), _FULL[names[0]]
             wd = hv if names == 'v' else hk
             a_all, d_all = A[tag + names + 'a'], dfull[names]
@@ -647,6 +663,67 @@ class PassEngine:
             else:
                 self.gemm(0, 0, rows, d, r, da_ptr, r, o(f0 + '_linear_a.weight'), d, dst, d, flags=ACCUM if accum else 0,
                           kbatch=n, sAk=rows * r, sBk=sa)
+        self.flush_side()
+
+    # ---- encoder-decoder attention: K / V projections of all decoder layers in one go
+    def _cross_kv_plan(self, Mk):
+        """(layer stride, projection stride) in floats when the K / V low-rank parameters of the decoder layers' encoder_attn blocks
+        sit at constant strides in the flat buffer (they do for the reference's module tree), else None."""
+        hp, L = self.hp, self.L
+        if not (self.hoist_kv and self.batch_qkv and hp.n_dec >= 2 and not self.fused_pairs and not self.group_wgrads) or hp.dk != hp.dv:
+            return None
+        plan = None
+        for sfx in ('_linear_a.weight', '_linear_b.weight', '_linear_b.bias'):
+            k = [L.off('decoder.layers.%d.encoder_attn.key%s' % (i, sfx)) for i in range(hp.n_dec)]
+            v = [L.off('decoder.layers.%d.encoder_attn.value%s' % (i, sfx)) for i in range(hp.n_dec)]
+            ls = {b - a for a, b in zip(k, k[1:])}
+            ps = {b - a for a, b in zip(k, v)}
+            if len(ls) != 1 or len(ps) != 1 or min(ls) <= 0 or min(ps) <= 0 or (min(ls) | min(ps)) % 4:
+                return None
+            if plan is not None and plan != (min(ls), min(ps)):
+                return None
+            plan = (min(ls), min(ps))
+        return plan
+
+    def cross_kv_fwd(self, P, mem, Mk):
+        """k_l, v_l = W_b (W_a mem) (+ b) for every decoder layer l: two launches with batch = 2 n_dec (layers outer, k / v inner)."""
+        plan = self._cross_kv_plan(Mk)
+        self.arena['xkv.plan'] = plan
+        if plan is None:
+            return None
+        hp, L = self.hp, self.L
+        Ls, Ps = plan
+        d, r, wd, NL = hp.d, hp.r, hp.h * hp.dk, hp.n_dec
+        o0 = lambda n: P + 4 * L.off('decoder.layers.0.encoder_attn.' + n)
+        a_all = self.buf('xkv.a', (NL, 2, Mk, r))
+        b_all = self.buf('xkv.b', (NL, 2, Mk, wd))
+        self.gemm(0, 1, Mk, r, d, mem, d, o0('key_linear_a.weight'), d, a_all.data_ptr(), r, batch=2 * NL, H=2, sB=(Ls, Ps),
+                  sC=(2 * Mk * r, Mk * r))
+        self.gemm(0, 1, Mk, wd, r, a_all.data_ptr(), r, o0('key_linear_b.weight'), r, b_all.data_ptr(), wd, bias=o0('key_linear_b.bias'),
+                  batch=2 * NL, H=2, sA=(2 * Mk * r, Mk * r), sB=(Ls, Ps), sC=(2 * Mk * wd, Mk * wd), sbias=Ls, sbias_h=Ps)
+        return a_all, b_all
+
+    def cross_kv_bwd(self, P, G, mem, Mk, dmem):
+        """backward of cross_kv_fwd from the dK / dV of all layers ('xkv.d'): the two weight-gradient products (batch 2 n_dec, bias
+        gradients folded in) on the side stream, da, and dmem = sum over layers and k / v of da . W_a (two K-batched launches)."""
+        hp, L, A = self.hp, self.L, self.arena
+        Ls, Ps = A['xkv.plan']
+        d, r, wd, NL = hp.d, hp.r, hp.h * hp.dk, hp.n_dec
+        o0 = lambda n: P + 4 * L.off('decoder.layers.0.encoder_attn.' + n)
+        g0 = lambda n: G + 4 * L.off('decoder.layers.0.encoder_attn.' + n)
+        a_ptr, d_ptr = A['xkv.a'].data_ptr(), A['xkv.d'].data_ptr()
+        da = self.buf('xkv.da', (NL, 2, Mk, r))
+        da_ptr = da.data_ptr()
+        self.defer(lambda: self.gemm(1, 0, wd, r, Mk, d_ptr, wd, a_ptr, r, g0('key_linear_b.weight'), r, flags=ACCUM, batch=2 * NL, H=2,
+                                     sA=(2 * Mk * wd, Mk * wd), sB=(2 * Mk * r, Mk * r), sC=(Ls, Ps), rowsum=g0('key_linear_b.bias'),
+                                     srow=Ls, srow_h=Ps))
+        self.gemm(0, 0, Mk, r, wd, d_ptr, wd, o0('key_linear_b.weight'), r, da_ptr, r, batch=2 * NL, H=2, sA=(2 * Mk * wd, Mk * wd),
+                  sB=(Ls, Ps), sC=(2 * Mk * r, Mk * r))
+        self.defer(lambda: self.gemm(1, 0, r, d, Mk, da_ptr, r, mem, d, g0('key_linear_a.weight'), d, flags=ACCUM, batch=2 * NL, H=2,
+                                     sA=(2 * Mk * r, Mk * r), sC=(Ls, Ps)))
+        for pj, name in enumerate(('key', 'value')):      # dmem (=|+=) sum_l da[l, pj] . W_a[l, pj]
+            self.gemm(0, 0, Mk, d, r, da_ptr + 4 * pj * Mk * r, r, o0(name + '_linear_a.weight'), d, dmem, d, flags=ACCUM if pj else 0,
+                      kbatch=NL, sAk=2 * Mk * r, sBk=Ls)
         self.flush_side()
 
     def _pstride(self, pre, names, suffix):
@@ -888,10 +965,12 @@ class PassEngine:
         check(lib.mtl_embed_pe_fwd(st, ids.data_ptr(), o('decoder.trg_embedding.weight'), self.pe_dec.data_ptr(), d0.data_ptr(),
                                    Md, Td, d, me.data_ptr() if me is not None else None, self.drop_scale), 'embed')
         cur = d0
+        xkv = self.cross_kv_fwd(P, mem.data_ptr(), Me)
         for i in range(hp.n_dec):
             pre = 'decoder.layers.%d.' % i
             a = self.mha_fwd('d%d.sa.' % i, P, pre + 'self_attn.', cur.data_ptr(), B, Td, cur.data_ptr(), Td, klen_dec, 1, keep_dec)
-            c = self.mha_fwd('d%d.ca.' % i, P, pre + 'encoder_attn.', a.data_ptr(), B, Td, mem.data_ptr(), T4, klen_enc, 0, keep_dec)
+            c = self.mha_fwd('d%d.ca.' % i, P, pre + 'encoder_attn.', a.data_ptr(), B, Td, mem.data_ptr(), T4, klen_enc, 0, keep_dec,
+                             kv_ready=(xkv[0][i], xkv[1][i]) if xkv is not None else None)
             cur = self.ffn_fwd('d%d.ff.' % i, P, pre + 'pos_ffn.', c.data_ptr(), Md, Td, keep_dec)
         pred = self.buf('pred', (B, Td, V))
         self.gemm(0, 1, Md, V, d, cur.data_ptr(), d, o('decoder.output_linear.weight'), d, pred.data_ptr(), V)
@@ -1023,19 +1102,23 @@ class PassEngine:
         self.gemm(0, 0, Md, d, V, dlog_ptr, ldd, o('decoder.output_linear.weight'), d, dA.data_ptr(), d)
         self.flush_side()
         dcur, dnext = dA, dB
+        hoisted = A.get('xkv.plan') is not None
+        mem_ptr = A['e%d.ff.y' % (hp.n_enc - 1)].data_ptr() if hp.n_enc else A['enc_in.y'].data_ptr()
+        dkv_all = self.buf('xkv.d', (hp.n_dec, 2, Me, hp.h * hp.dk)) if hoisted else None
         for i in reversed(range(hp.n_dec)):
             pre = 'decoder.layers.%d.' % i
             x_in = A['dec_in.y'] if i == 0 else A['d%d.ff.y' % (i - 1)]
             sa_y, ca_y = A['d%d.sa.y' % i], A['d%d.ca.y' % i]
             self.ffn_bwd('d%d.ff.' % i, P, G, pre + 'pos_ffn.', dcur.data_ptr(), ca_y.data_ptr(), Md, keep_dec, dnext.data_ptr())
             dcur, dnext = dnext, dcur
-            self.mha_bwd('d%d.ca.' % i, P, G, pre + 'encoder_attn.', dcur.data_ptr(), sa_y.data_ptr(), B, Td,
-                         A['e%d.ff.y' % (hp.n_enc - 1)].data_ptr() if hp.n_enc else A['enc_in.y'].data_ptr(), T4, keep_dec,
-                         dnext.data_ptr(), dmem.data_ptr(), i != hp.n_dec - 1)
+            self.mha_bwd('d%d.ca.' % i, P, G, pre + 'encoder_attn.', dcur.data_ptr(), sa_y.data_ptr(), B, Td, mem_ptr, T4, keep_dec,
+                         dnext.data_ptr(), dmem.data_ptr(), i != hp.n_dec - 1, dkv_hoisted=dkv_all[i] if hoisted else None)
             dcur, dnext = dnext, dcur
             self.mha_bwd('d%d.sa.' % i, P, G, pre + 'self_attn.', dcur.data_ptr(), x_in.data_ptr(), B, Td, x_in.data_ptr(), Td,
                          keep_dec, dnext.data_ptr(), dnext.data_ptr(), True)
             dcur, dnext = dnext, dcur
+        if hoisted:
+            self.cross_kv_bwd(P, G, mem_ptr, Me, dmem.data_ptr())
         me = A.get('dec_in.me')
         check(lib.mtl_embed_bwd(st, S['meta']['ids'].data_ptr(), S['meta']['embed_first'], S['meta']['embed_next'], dcur.data_ptr(),
                                 g('decoder.trg_embedding.weight'), Md, d, PAD_ID, me.data_ptr() if me is not None else None,

@@ -114,7 +114,7 @@ class LMEngine:
 
     def gemm(self, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias=None, flags=0, rowsum=None):
         check(self.lib.mtl_gemm_f32_ex(self.stream, ta, tb, M, N, K, 1.0, A, lda, B, ldb, C, ldc, bias, None, 0, flags, 1, 1, 0, 0, 0, 0,
-                                       0, 0, 0, 1, 0, 0, rowsum, 0, self.ws.data_ptr(), self.ws.numel() * 4), 'mtl_gemm_f32_ex')
+                                       0, 0, 0, 1, 0, 0, rowsum, 0, self.ws.data_ptr(), self.ws.numel() * 4, 0, 0), 'mtl_gemm_f32_ex')
 
     def _chains(self, ids_host):
         """occurrence chains for the deterministic embedding scatter-add (mtl_embed_bwd)"""

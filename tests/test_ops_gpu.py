@@ -103,11 +103,11 @@ def test_gemm_long_k_big_tile_split_k(L, ta, tb):
 
 
 def _gemm_ex(L, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias=None, gate=None, ldg=0, flags=0, alpha=1.0, batch=1, H=1,
-             sA=(0, 0), sB=(0, 0), sC=(0, 0), sbias=0, kbatch=1, sAk=0, sBk=0, rowsum=None, srow=0):
+             sA=(0, 0), sB=(0, 0), sC=(0, 0), sbias=0, kbatch=1, sAk=0, sBk=0, rowsum=None, srow=0, sbias_h=0, srow_h=0):
     return L.mtl_gemm_f32_ex(st(), ta, tb, M, N, K, alpha, A.data_ptr(), lda, B.data_ptr(), ldb, C.data_ptr(), ldc,
                              bias.data_ptr() if bias is not None else None, gate.data_ptr() if gate is not None else None, ldg, flags,
                              batch, H, sA[0], sA[1], sB[0], sB[1], sC[0], sC[1], sbias, kbatch, sAk, sBk,
-                             rowsum.data_ptr() if rowsum is not None else None, srow, None, 0)
+                             rowsum.data_ptr() if rowsum is not None else None, srow, None, 0, sbias_h, srow_h)
 
 
 @pytest.mark.parametrize('ta,tb', [(0, 1), (0, 0), (1, 0), (1, 1)])
@@ -161,7 +161,7 @@ def test_gemm_k_batching_and_row_sums(L):
     ddy, da_, G = dev(dy), dev(a), dev(G0.clone())
     Wview = G[:].data_ptr()
     assert L.mtl_gemm_f32_ex(st(), 1, 0, wd, r, rows, 1.0, ddy.data_ptr(), wd, da_.data_ptr(), r, Wview, r, None, None, 0, 2,
-                             n, 1, rows * wd, 0, rows * r, 0, sb, 0, 0, 1, 0, 0, Wview + 4 * wd * r, sb, None, 0) == 0
+                             n, 1, rows * wd, 0, rows * r, 0, sb, 0, 0, 1, 0, 0, Wview + 4 * wd * r, sb, None, 0, 0, 0) == 0
     Gc = G.cpu()
     for z in range(n):
         w_ref = G0[z * sb: z * sb + wd * r].view(wd, r).double() + dy[z].double().t() @ a[z].double()
@@ -170,7 +170,7 @@ def test_gemm_k_batching_and_row_sums(L):
         assert rel(Gc[z * sb + wd * r: z * sb + wd * r + wd], b_ref) < 3e-6
         assert torch.equal(Gc[z * sb + wd * r + wd: (z + 1) * sb], G0[z * sb + wd * r + wd: (z + 1) * sb])   # untouched
     assert L.mtl_gemm_f32_ex(st(), 0, 0, 8, 8, 8, 1.0, ddy.data_ptr(), 8, da_.data_ptr(), 8, Wview, 8, None, None, 0, 0,
-                             1, 1, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, Wview, 0, None, 0) == -22      # row sums need transA
+                             1, 1, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, Wview, 0, None, 0, 0, 0) == -22      # row sums need transA
 
 
 @pytest.mark.parametrize('M,Kin,r,N,n', [(808, 512, 100, 512, 3), (2000, 512, 100, 512, 3), (37, 128, 100, 128, 2), (101, 512, 16, 200, 1),

@@ -20,7 +20,7 @@ for name, ta, tb, M, N, K, nb, rsum in shapes:
     lda, ldb = A.shape[2], B.shape[2]
     def run():
         assert L.mtl_gemm_f32_ex(st, ta, tb, M, N, K, 1.0, A.data_ptr(), lda, B.data_ptr(), ldb, C.data_ptr(), N, None, None, 0, 2, nb, 1,
-                                 A[0].numel(), 0, B[0].numel(), 0, M * N, 0, 0, 1, 0, 0, rs.data_ptr() if rsum else None, M, None, 0) == 0
+                                 A[0].numel(), 0, B[0].numel(), 0, M * N, 0, 0, 1, 0, 0, rs.data_ptr() if rsum else None, M, None, 0, 0, 0) == 0
     for _ in range(5):
         run()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

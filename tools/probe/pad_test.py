@@ -7,7 +7,7 @@ def bench(name, ta, tb, M, N, K, nb, pada, padb, fl=0):
     A = torch.randn(nb, *sa, device=dev); B = torch.randn(nb, *sb, device=dev); C = torch.zeros(nb, M, N, device=dev)
     def run():
         assert L.mtl_gemm_f32_ex(st, ta, tb, M, N, K, 1.0, A.data_ptr(), sa[1], B.data_ptr(), sb[1], C.data_ptr(), N, None, None, 0, fl, nb, 1,
-                                 A[0].numel(), 0, B[0].numel(), 0, M * N, 0, 0, 1, 0, 0, None, 0, None, 0) == 0
+                                 A[0].numel(), 0, B[0].numel(), 0, M * N, 0, 0, 1, 0, 0, None, 0, None, 0, 0, 0) == 0
     for _ in range(5): run()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
