@@ -380,18 +380,20 @@ __global__ void embed_bwd_kernel(const long* __restrict__ ids, const int* __rest
     }
 }
 
-// ------------------------------------------------------------------ cross-entropy (+arg-max), one wave per row
+// ------------------------------------------------------------------ cross-entropy (+arg-max), one workgroup (4 waves) per row
 // lse = max + log(sum exp(x-max)); rowloss = gold!=pad ? lse - x[gold] : 0 ; hyp = lowest index of the max
+// (one WAVE per row walked V = 3765 logits in 59 dependent steps per pass over the row: 30 us for 808 rows)
 __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ logits, const long* __restrict__ gold, int rows,
                                                      int V, int ld, long pad_id, float smoothing, float* __restrict__ lse,
                                                      long* __restrict__ hyp, float* __restrict__ rowloss) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
+    __shared__ float smx[4], ssum[4], ssx[4];
+    __shared__ int sarg[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int row = blockIdx.x;
     const float* x = logits + (long)row * ld;
     float mx = -INFINITY;
     int arg = 0x7fffffff;
-    for (int j = lane; j < V; j += 64) {
+    for (int j = tid; j < V; j += 256) {
         const float v = x[j];
         if (v > mx) {
             mx = v;
@@ -407,14 +409,36 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ l
             arg = oa;
         }
     }
+    if (lane == 0) {
+        smx[wv] = mx;
+        sarg[wv] = arg;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const float om = smx[w];
+        const int oa = sarg[w];
+        if (om > mx || (om == mx && oa < arg)) {
+            mx = om;
+            arg = oa;
+        }
+    }
     float s = 0.f, sx = 0.f;
-    for (int j = lane; j < V; j += 64) {
-        s += expf(x[j] - mx);
-        sx += x[j];
+    for (int j = tid; j < V; j += 256) {
+        const float v = x[j];
+        s += expf(v - mx);
+        sx += v;
     }
     s = wave_sum(s);
     sx = wave_sum(sx);
     if (lane == 0) {
+        ssum[wv] = s;
+        ssx[wv] = sx;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        s = (ssum[0] + ssum[1]) + (ssum[2] + ssum[3]);
+        sx = (ssx[0] + ssx[1]) + (ssx[2] + ssx[3]);
         const float l = mx + logf(s);
         lse[row] = l;
         hyp[row] = arg;
@@ -990,7 +1014,7 @@ int mtl_ce_argmax_fwd(void* stream, const float* logits, const long* gold, int r
     if (!logits || !gold || !lse || !hyp || !rowloss || !loss_out || rows <= 0 || V <= 0 || (n_nonpad <= 0 && !inv_count_dev))
         return MTL_EINVAL;
     hipStream_t s = as_stream(stream);
-    hipLaunchKernelGGL(ce_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, logits, gold, rows, V, ld, pad_id, smoothing, lse,
+    hipLaunchKernelGGL(ce_fwd_kernel, dim3(rows), dim3(256), 0, s, logits, gold, rows, V, ld, pad_id, smoothing, lse,
                        hyp, rowloss);
     hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(256), 0, s, rowloss, rows, loss_out, 1, (float)n_nonpad, inv_count_dev);
     MTL_CHECK_LAUNCH();
