@@ -573,6 +573,10 @@ __global__ __launch_bounds__(256) void conv0_fwd_kernel(const float* __restrict_
                                                         int F, float* __restrict__ amax_y) {
     const int cg = threadIdx.x & 15;  // channels 4cg..4cg+3
     float mx = 0.f;
+    // this workgroup's slot of the bound, read NOW (a stale value only costs a redundant atomic): read at the end, the round trip
+    // sat on the tail of every short-lived workgroup (+24 us per launch)
+    float* slot = amax_y ? amax_y + (blockIdx.x & (MTL_AMAX_SLOTS - 1)) * MTL_AMAX_STRIDE : nullptr;
+    const float seen = slot ? *slot : 0.f;
     float wr[4][9], bb[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -608,8 +612,9 @@ __global__ __launch_bounds__(256) void conv0_fwd_kernel(const float* __restrict_
                 for (int c = 0; c < 4; ++c) acc[c] += xv * wr[c][kh * 3 + kw];
             }
         }
-        *reinterpret_cast<float4*>(y + pix * 64 + cg * 4) =
-            make_float4(fmaxf(acc[0], 0.f), fmaxf(acc[1], 0.f), fmaxf(acc[2], 0.f), fmaxf(acc[3], 0.f));
+        typedef float f32x4_t __attribute__((ext_vector_type(4)));
+        const f32x4_t out = {fmaxf(acc[0], 0.f), fmaxf(acc[1], 0.f), fmaxf(acc[2], 0.f), fmaxf(acc[3], 0.f)};
+        __builtin_nontemporal_store(out, reinterpret_cast<f32x4_t*>(y + pix * 64 + cg * 4));      // streamed: 330 MB, read next by another kernel
         mx = fmaxf(fmaxf(mx, fmaxf(acc[0], acc[1])), fmaxf(acc[2], acc[3]));
     }
     if (amax_y) {       // max of the outputs (>= 0 after the ReLU), one candidate per workgroup; the caller zeroes the slots
@@ -617,7 +622,8 @@ __global__ __launch_bounds__(256) void conv0_fwd_kernel(const float* __restrict_
         mx = wave_max(mx);
         if ((threadIdx.x & 63) == 0) shm[threadIdx.x >> 6] = mx;
         __syncthreads();
-        if (threadIdx.x < 64) amax_raise(amax_y, fmaxf(fmaxf(shm[0], shm[1]), fmaxf(shm[2], shm[3])));
+        const float cand = fmaxf(fmaxf(shm[0], shm[1]), fmaxf(shm[2], shm[3]));
+        if (threadIdx.x == 0 && cand > seen) atomicMax(reinterpret_cast<unsigned*>(slot), __float_as_uint(cand));
     }
 }
 // dw0[c][tap] = sum_pix x[pix+tap]*dy[pix][c], db0[c] = sum_pix dy[pix][c]: per-block partials [blk][64][10]
@@ -644,7 +650,8 @@ __global__ __launch_bounds__(256) void conv0_wgrad_kernel(const float* __restric
         const long pix = base + pl;
         if (pix >= npix) break;
         const float* xb = x + (long)b * F * T;
-        const float4 d4 = *reinterpret_cast<const float4*>(dy + pix * 64 + cg * 4);
+        typedef float f32x4_t __attribute__((ext_vector_type(4)));
+        const f32x4_t d4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(dy + pix * 64 + cg * 4));
         const float d[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {

@@ -19,3 +19,6 @@ def cold():
     slot.zero_()
     L.mtl_conv0_relu_fwd(st(), x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), B, T, F, slot.data_ptr())
 print('amax cold %.1f us (incl. fill)' % timeit(cold))
+dy = torch.randn(B, T, F, 64, device='cuda'); dw = torch.zeros(64, 1, 3, 3, device='cuda'); db = torch.zeros(64, device='cuda')
+ws = torch.empty(L.mtl_conv0_wgrad_workspace() // 4, device='cuda')
+print('wgrad     %.1f us' % timeit(lambda: L.mtl_conv0_wgrad(st(), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), db.data_ptr(), ws.data_ptr(), B, T, F)))
