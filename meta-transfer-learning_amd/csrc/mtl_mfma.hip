@@ -531,7 +531,7 @@ struct EpiConvRelu {  // y = relu(acc + bias), dense NHWC
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int t = t0 + 2 * (w >> 3) + (j & 1), f = f0 + 2 * (w & 7) + (j >> 1);
-            if (t < T && f < F) y[(((long)b * T + t) * F + f) * Cout + col] = fmaxf(v[j] + bb, 0.f);
+            if (t < T && f < F) __builtin_nontemporal_store(fmaxf(v[j] + bb, 0.f), y + (((long)b * T + t) * F + f) * Cout + col);
         }
     }
 };
@@ -587,7 +587,7 @@ struct EpiConvDgrad {  // dx = acc masked by the ReLU of the forward activation 
 #pragma unroll
         for (int j = 0; j < 4; ++j) {        // unconditional loads from clamped addresses: no branch between the loads
             const int t = min(t0 + 2 * (w >> 3) + (j & 1), T - 1), f = min(f0 + 2 * (w & 7) + (j >> 1), F - 1);
-            m[j] = act[(((long)b * T + t) * F + f) * Cout + col];
+            m[j] = __builtin_nontemporal_load(act + (((long)b * T + t) * F + f) * Cout + col);
         }
     }
     __device__ __forceinline__ void store4g(int lr, int lc, const float (&v)[4], const float (&m)[4]) const {
@@ -596,7 +596,7 @@ struct EpiConvDgrad {  // dx = acc masked by the ReLU of the forward activation 
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int t = t0 + 2 * (w >> 3) + (j & 1), f = f0 + 2 * (w & 7) + (j >> 1);
-            if (t < T && f < F) dx[(((long)b * T + t) * F + f) * Cout + col] = m[j] > 0.f ? v[j] : 0.f;
+            if (t < T && f < F) __builtin_nontemporal_store(m[j] > 0.f ? v[j] : 0.f, dx + (((long)b * T + t) * F + f) * Cout + col);
         }
     }
 };

@@ -162,7 +162,7 @@ class Transformer(nn.Module):
         self._theta_override = None
         self.engine = None
         self.engines, self.lane_streams = [], []
-        self.n_lanes = max(1, int(os.environ.get('MTL_TASK_LANES', '2')))
+        self.n_lanes = max(1, int(os.environ.get('MTL_TASK_LANES', '3')))
         self._pass_token = 0
         self._last = None
         self._anchor = None
