@@ -159,6 +159,9 @@ int mtl_conv3x3_dgrad_x3(void* stream, const float* dy, const unsigned char* arg
 #endif
 long mtl_conv3x3_wprep_h2_bytes(int Cout, int Cin);
 int mtl_conv3x3_wprep_h2(void* stream, const float* w_ref, void* w2_fwd, void* w2_dgrad, int Cout, int Cin);
+/* the same for n <= 3 layers with one call (the pass prepares conv2 / conv5 / conv7 together); unused triples are ignored */
+int mtl_conv3x3_wprep_h2_batch(void* stream, int n, const float* w0, void* f0, void* d0, int Cout0, int Cin0, const float* w1, void* f1,
+                               void* d1, int Cout1, int Cin1, const float* w2, void* f2, void* d2, int Cout2, int Cin2);
 int mtl_conv3x3_relu_fwd_h2(void* stream, const float* x, const float* amax_x, const void* w2_fwd, const float* bias, float* y,
                             float* amax_y, int B, int T, int F, int Cin, int Cout);
 int mtl_conv3x3_relu_pool_fwd_h2(void* stream, const float* x, const float* amax_x, const void* w2_fwd, const float* bias,
@@ -182,7 +185,8 @@ int mtl_conv3x3_wgrad_h2(void* stream, const float* x, const float* amax_x, cons
                          int Cin, int Cout);
 /* wp[o][h*C+c] = w[o][c*Hh+h]  (inverse_accum: dst[o][c*Hh+h] += src[o][h*C+c]); the (C*H) flattening of
  * models/asr/transformer.py:136-138 folded into encoder.input_linear's weight instead of an activation copy. */
-int mtl_permute_hc(void* stream, const float* src, float* dst, int rows, int C, int Hh, int inverse_accum);
+int mtl_permute_hc(void* stream, const float* src, float* dst, int rows, int C, int Hh, int inverse_accum,
+                   float* amax /* nullable, MTL_AMAX_FLOATS: raised to max|src| (zero it first) */);
 
 /* ---- LayerNorm(x + residual) * gamma + beta (+ pe[row % T]) then * keep[row] -----------------------------
  * nn.LayerNorm eps inside the sqrt, biased variance (modules/common_layers.py:131,304; modules/encoder.py:72-73)

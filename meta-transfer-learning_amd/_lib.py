@@ -40,6 +40,7 @@ SIGNATURES = {
     'mtl_conv3x3_wgrad_x3': (I, [P, P, P, P, P, P, L, I, I, I, I, I]),
     'mtl_conv3x3_wprep_h2_bytes': (L, [I, I]),
     'mtl_conv3x3_wprep_h2': (I, [P, P, P, P, I, I]),
+    'mtl_conv3x3_wprep_h2_batch': (I, [P, I, P, P, P, I, I, P, P, P, I, I, P, P, P, I, I]),
     'mtl_conv3x3_relu_fwd_h2': (I, [P, P, P, P, P, P, P, I, I, I, I, I]),
     'mtl_conv3x3_relu_pool_fwd_h2': (I, [P, P, P, P, P, P, P, P, I, I, I, I, I]),
     'mtl_conv3x3_dgrad_h2': (I, [P, P, P, P, P, P, P, P, I, I, I, I, I]),
@@ -48,7 +49,7 @@ SIGNATURES = {
     'mtl_gemm_nt_h2_supported': (I, [I, I, I]),
     'mtl_gemm_nt_h2_workspace': (L, [I, I, I]),
     'mtl_gemm_nt_h2': (I, [P, I, I, I, P, I, P, P, I, P, P, I, P, P, I, P, L]),
-    'mtl_permute_hc': (I, [P, P, P, I, I, I, I]),
+    'mtl_permute_hc': (I, [P, P, P, I, I, I, I, P]),
     'mtl_layernorm_fwd': (I, [P, P, P, P, P, P, P, P, F, P, P, P, I, I, I, F]),
     'mtl_layernorm_bwd_workspace': (L, [I, I]),
     'mtl_layernorm_bwd': (I, [P, P, P, P, P, P, P, F, P, P, P, P, P, P, P, I, I, I]),

@@ -702,12 +702,18 @@ __global__ __launch_bounds__(256) void conv0_wgrad_final_kernel(const float* __r
 // One workgroup per row: the (C, Hh) <-> (Hh, C) transpose goes through LDS so that both the read and the write of HBM are
 // coalesced (the element-wise form below read 4-byte words 4 Hh bytes apart: 28 us for 10 MB).
 __global__ __launch_bounds__(256) void permute_hc_lds_kernel(const float* __restrict__ w, float* __restrict__ wp, int C, int Hh,
-                                                             int inverse_accum) {
+                                                             int inverse_accum, float* __restrict__ amax) {
     extern __shared__ float tile[];
     const int n = C * Hh;
     const float* src = w + (long)blockIdx.x * n;
     float* dst = wp + (long)blockIdx.x * n;
-    for (int e = threadIdx.x; e < n; e += 256) tile[e] = src[e];
+    float mx = 0.f;
+    for (int e = threadIdx.x; e < n; e += 256) {
+        const float v = src[e];
+        tile[e] = v;
+        mx = fmaxf(mx, fabsf(v));
+    }
+    if (amax) amax_raise(amax, mx);        // max|w| rides along (the bound of the h2 GEMM that multiplies with the permuted weight)
     __syncthreads();
     if (inverse_accum) {      // src is in (h, c) order; dst (reference order, (c, h)) accumulates
         for (int e = threadIdx.x; e < n; e += 256) {
@@ -1110,13 +1116,16 @@ int mtl_conv0_wgrad(void* stream, const float* x, const float* dy, float* dw, fl
     return MTL_OK;
 }
 
-int mtl_permute_hc(void* stream, const float* src, float* dst, int rows, int C, int Hh, int inverse_accum) {
+int mtl_permute_hc(void* stream, const float* src, float* dst, int rows, int C, int Hh, int inverse_accum, float* amax) {
     if (!src || !dst) return MTL_EINVAL;
     if ((long)C * Hh * 4 <= 48 * 1024)
-        hipLaunchKernelGGL(permute_hc_lds_kernel, dim3(rows), dim3(256), C * Hh * 4, as_stream(stream), src, dst, C, Hh, inverse_accum);
-    else
+        hipLaunchKernelGGL(permute_hc_lds_kernel, dim3(rows), dim3(256), C * Hh * 4, as_stream(stream), src, dst, C, Hh, inverse_accum, amax);
+    else {
+        if (amax) hipLaunchKernelGGL(absmax_kernel, dim3(grid_for((long)rows * C * Hh / 4 + 1, 256, 1024)), dim3(256), 0, as_stream(stream), src,
+                                     (long)rows * C * Hh, amax);
         hipLaunchKernelGGL(permute_hc_kernel, dim3(grid_for((long)rows * C * Hh, 256, 4096)), dim3(256), 0, as_stream(stream), src,
                            dst, rows, C, Hh, inverse_accum);
+    }
     MTL_CHECK_LAUNCH();
     return MTL_OK;
 }

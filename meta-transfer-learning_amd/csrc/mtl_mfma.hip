@@ -1724,6 +1724,58 @@ static int wprep_pieces(int np, hipStream_t s, const float* w_ref, void* wf, voi
     return MTL_OK;
 }
 
+// the same two kernels for up to three layers at once (grid.y = layer): the pass prepares conv2 / conv5 / conv7 together
+struct WprepBatch {
+    const float* w[3];
+    unsigned short* wf[3];
+    unsigned short* wd[3];
+    int Cout[3], Cin[3];
+};
+__global__ __launch_bounds__(256) void conv_wscale_batch_kernel(WprepBatch b) {
+    __shared__ float sh[4];
+    const int L = blockIdx.y, total = 9 * b.Cin[L] * b.Cout[L];
+    const float* w = b.w[L];
+    float mx = 0.f;
+    for (int e = (blockIdx.x * 256 + threadIdx.x) * 4; e < total; e += WSCALE_PARTS * 1024) {
+        const float4 v = *reinterpret_cast<const float4*>(w + e);
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) reinterpret_cast<float*>(b.wf[L] + 2L * total)[1 + blockIdx.x] = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+}
+__global__ void conv_wprep_h2_batch_kernel(WprepBatch b) {
+    const int L = blockIdx.y, Cin = b.Cin[L], Cout = b.Cout[L];
+    const float* w = b.w[L];
+    unsigned short* wf = b.wf[L];
+    unsigned short* wd = b.wd[L];
+    const int total = 9 * Cin * Cout;
+    const int nkf = 9 * (Cin / 32), nkd = 9 * (Cout / 32);
+    float* hf = reinterpret_cast<float*>(wf + 2L * total);
+    float mx = 0.f;
+#pragma unroll
+    for (int i = 1; i <= WSCALE_PARTS; ++i) mx = fmaxf(mx, hf[i]);
+    const float s = pow2_scale(mx);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        hf[0] = s;
+        *reinterpret_cast<float*>(wd + 2L * total) = s;
+    }
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int tap = e % 9;
+        const int cin = (e / 9) % Cin;
+        const int cout = e / (9 * Cin);
+        unsigned pc[2];
+        Split<2>::x2(w[e], 0.f, s, pc);
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const unsigned short v = (unsigned short)(pc[p] & 0xffffu);
+            wf[(((long)p * nkf + tap * (Cin / 32) + (cin >> 5)) * Cout + cout) * 32 + x3_swz(cin & 31, cout)] = v;
+            wd[(((long)p * nkd + (8 - tap) * (Cout / 32) + (cout >> 5)) * Cin + cin) * 32 + x3_swz(cout & 31, cin)] = v;
+        }
+    }
+}
+
 template <int NP>
 static int conv_fwd_pieces(hipStream_t s, const float* x, const float* amax_x, const void* w, const float* bias, float* y,
                            unsigned char* argmax, float* amax_y, bool pool, int B, int T, int F, int Cin, int Cout) {
@@ -1765,6 +1817,27 @@ int mtl_conv3x3_relu_pool_fwd_x3(void* stream, const float* x, const void* w3_fw
 int mtl_conv3x3_dgrad_x3(void* stream, const float* dy, const unsigned char* argmax, const void* w3_dgrad, const float* act,
                          float* dx, int B, int T, int F, int Cin, int Cout) {
     return conv_dgrad_pieces<3>(as_stream(stream), dy, nullptr, argmax, w3_dgrad, act, dx, nullptr, B, T, F, Cin, Cout);
+}
+
+int mtl_conv3x3_wprep_h2_batch(void* stream, int n, const float* w0, void* f0, void* d0, int Cout0, int Cin0, const float* w1, void* f1,
+                               void* d1, int Cout1, int Cin1, const float* w2, void* f2, void* d2, int Cout2, int Cin2) {
+    if (n < 1 || n > 3) return MTL_EINVAL;
+    WprepBatch b{{w0, w1, w2},
+                 {reinterpret_cast<unsigned short*>(f0), reinterpret_cast<unsigned short*>(f1), reinterpret_cast<unsigned short*>(f2)},
+                 {reinterpret_cast<unsigned short*>(d0), reinterpret_cast<unsigned short*>(d1), reinterpret_cast<unsigned short*>(d2)},
+                 {Cout0, Cout1, Cout2},
+                 {Cin0, Cin1, Cin2}};
+    long tmax = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!b.w[i] || !b.wf[i] || !b.wd[i] || b.Cin[i] % 32 || b.Cout[i] % 32 || b.Cin[i] <= 0 || b.Cout[i] <= 0) return MTL_EINVAL;
+        const long t = 9L * b.Cin[i] * b.Cout[i];
+        tmax = t > tmax ? t : tmax;
+    }
+    hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL(conv_wscale_batch_kernel, dim3(WSCALE_PARTS, n), dim3(256), 0, s, b);
+    hipLaunchKernelGGL(conv_wprep_h2_batch_kernel, dim3(grid_for(tmax, 256, 256), n), dim3(256), 0, s, b);
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
 }
 
 long mtl_conv3x3_wprep_h2_bytes(int Cout, int Cin) { return 2L * 9 * Cin * Cout * 2 + 4 * (1 + WSCALE_PARTS) + 12; }

@@ -860,7 +860,7 @@ class PassEngine:
         meta = self.prepare(lengths, target, x.shape[0], x.shape[3], slot)
         return self.forward_device(theta, x, meta, smoothing)
 
-    def forward_device(self, theta, x, meta, smoothing=0.0):
+    def forward_device(self, theta, x, meta, smoothing=0.0, hyp_out=None, loss_out=None):
         """Kernel launches only (hipGraph-capturable): everything batch-dependent comes from `meta`'s device buffers."""
         hp, L, lib, st = self.hp, self.L, self.lib, self.stream
         assert theta.numel() == L.total and theta.dtype == torch.float32 and theta.is_contiguous()
@@ -914,7 +914,13 @@ class PassEngine:
             else:
                 wf[idx] = self.buf('wf%d' % idx, (9, cin, cout))
                 wd[idx] = self.buf('wd%d' % idx, (9, cout, cin))
-            check(wprep(st, o('conv.%d.weight' % idx), wf[idx].data_ptr(), wd[idx].data_ptr(), cout, cin), 'wprep')
+            if not h2:
+                check(wprep(st, o('conv.%d.weight' % idx), wf[idx].data_ptr(), wd[idx].data_ptr(), cout, cin), 'wprep')
+        if h2:          # all three layers: one call (two launches)
+            spec = []
+            for idx, cin, cout in ((2, 64, 64), (5, 64, 128), (7, 128, 128)):
+                spec += [o('conv.%d.weight' % idx), wf[idx].data_ptr(), wd[idx].data_ptr(), cout, cin]
+            check(lib.mtl_conv3x3_wprep_h2_batch(st, 3, *spec), 'wprep')
         self._wT = self.transpose_lowrank_weights(theta).data_ptr() if self.fused_pairs else None
         p1 = self.buf('p1', (B, T2, F2, 64))
         am1 = self.buf('am1', (B, T2, F2, 64), torch.uint8)
@@ -934,13 +940,12 @@ class PassEngine:
 
         # ---- encoder ----
         wp = self.buf('wp_in', (d, hp.d_in))
-        check(lib.mtl_permute_hc(st, o('encoder.input_linear.weight'), wp.data_ptr(), d, 128, F4, 0), 'permute')
+        check(lib.mtl_permute_hc(st, o('encoder.input_linear.weight'), wp.data_ptr(), d, 128, F4, 0, am_(7)), 'permute')      # am_(7): max|w| rides along
         e0 = self.buf('e0', (Me, d))
         self.in_h2 = h2 and bool(lib.mtl_gemm_nt_h2_supported(Me, d, hp.d_in)) and bool(lib.mtl_gemm_nt_h2_supported(Me, hp.d_in, d))
         if self.in_h2:      # the two compute-bound products of the pass on fp16 pairs: e0 = p2 . wp^T here, dp2 = de0 . (wp^T)^T in the backward
             wpT = self.buf('wpT_in', (hp.d_in, d))
             check(lib.mtl_transpose_batch(st, self._transpose_table(wp, wpT, d, hp.d_in), 1), 'mtl_transpose_batch')
-            check(lib.mtl_absmax_f32(st, wp.data_ptr(), wp.numel(), am_(7)), 'mtl_absmax_f32')
             need = lib.mtl_gemm_nt_h2_workspace(Me, d, hp.d_in)
             check(lib.mtl_gemm_nt_h2(st, Me, d, hp.d_in, p2.data_ptr(), hp.d_in, am_(6), wp.data_ptr(), hp.d_in, am_(7), e0.data_ptr(), d,
                                      o('encoder.input_linear.bias'), None, 0, self.scratch(need) if need else None, need), 'mtl_gemm_nt_h2')
@@ -977,9 +982,10 @@ class PassEngine:
 
         # ---- loss + arg-max ----
         lse = self.buf('lse', (Md,))
-        hyp = self.buf('hyp', (B, Td), torch.int64)
+        # hyp_out / loss_out: caller-owned destinations (the trainer's per-pass read-back slots: no device copies afterwards)
+        hyp = self.buf('hyp', (B, Td), torch.int64) if hyp_out is None else hyp_out
         rowloss = self.buf('rowloss', (Md,))
-        loss = self.buf('loss', (1,))
+        loss = self.buf('loss', (1,)) if loss_out is None else loss_out
         gold_ptr = ids.data_ptr() + 8 * Md
         check(lib.mtl_ce_argmax_fwd(st, pred.data_ptr(), gold_ptr, Md, V, V, PAD_ID, float(smoothing), 0, meta['inv_count'],
                                     lse.data_ptr(), hyp.data_ptr(), rowloss.data_ptr(), loss.data_ptr()), 'ce_fwd')
@@ -1146,7 +1152,7 @@ class PassEngine:
         dwp = self.buf('_dwp', (d, hp.d_in))
         dp2 = self.buf('_dp2', (B, T4, F4, 128))
         self.gemm(1, 0, d, hp.d_in, Me, de0.data_ptr(), d, p2.data_ptr(), hp.d_in, dwp.data_ptr(), hp.d_in)
-        check(lib.mtl_permute_hc(st, dwp.data_ptr(), g('encoder.input_linear.weight'), d, 128, F4, 1), 'permute_inv')
+        check(lib.mtl_permute_hc(st, dwp.data_ptr(), g('encoder.input_linear.weight'), d, 128, F4, 1, None), 'permute_inv')
         if self.in_h2:
             amax = A['amax']
             a8, a7 = (amax.data_ptr() + 4 * _lib.AMAX_SLOTS * i for i in (8, 7))

@@ -452,16 +452,12 @@ class TransientTrainer():
         eng = model.engines[lane]
         g, theta1, G = bufs
         eng.zero_(g)                                                     # inner_opt.zero_grad()   (:198)
-        out = eng.forward_device(theta0, x_tr, m_tr, smoothing)          # meta-train forward      (:188)
-        eng.copy_(slots['hyp_tr'], out['hyp'])
-        eng.copy_(slots['loss_tr'], out['loss'])
+        eng.forward_device(theta0, x_tr, m_tr, smoothing, hyp_out=slots['hyp_tr'], loss_out=slots['loss_tr'])   # meta-train forward (:188)
         eng.backward(g, 1.0)                                             # tr_loss.backward()      (:199)
         if args.clip:
             clip_flat_grad_(model, g, args.max_norm, lane=lane)          # (:205-206)
         eng.sgd_theta_prime(theta0, g, inner.param_groups[0]['lr'], theta1)     # inner_opt.step() (:207)
-        out = eng.forward_device(theta1, x_va, m_va, smoothing)          # meta-validation forward (:215)
-        eng.copy_(slots['hyp_va'], out['hyp'])
-        eng.copy_(slots['loss_va'], out['loss'])
+        eng.forward_device(theta1, x_va, m_va, smoothing, hyp_out=slots['hyp_va'], loss_out=slots['loss_va'])   # meta-validation forward (:215)
         eng.backward(g, 1.0 / n_tasks)                                   # (val_loss/n).backward(): g += g_val/n (Q1)
         eng.axpy_(G, g, 1.0)                                             # add_copy_grad()         (:229)
 

@@ -702,10 +702,12 @@ def test_flat_updates_colsum_permute(L):
     wt = torch.randn(rows, C * H, generator=g)
     wp = torch.empty(rows, C * H).cuda()
     dwt = dev(wt)
-    assert L.mtl_permute_hc(st(), dwt.data_ptr(), wp.data_ptr(), rows, C, H, 0) == 0
+    amx = torch.zeros(2048).cuda()
+    assert L.mtl_permute_hc(st(), dwt.data_ptr(), wp.data_ptr(), rows, C, H, 0, amx.data_ptr()) == 0
+    assert float(amx.max()) == float(dwt.abs().max())
     assert torch.equal(wp.cpu(), wt.view(rows, C, H).transpose(1, 2).reshape(rows, -1))
     back = torch.zeros(rows, C * H).cuda()
-    assert L.mtl_permute_hc(st(), wp.data_ptr(), back.data_ptr(), rows, C, H, 1) == 0
+    assert L.mtl_permute_hc(st(), wp.data_ptr(), back.data_ptr(), rows, C, H, 1, None) == 0
     assert torch.equal(back.cpu(), wt)
 
 
