@@ -8,21 +8,27 @@ import json
 import re
 import sys
 
-_BASE = {  # kernel template instance (without the trailing piece count) -> bench.py conv class (see PassEngine.forward/backward)
-    'conv3x3_x3h_kernel<64, 1, false, 1': 'conv2_fwd_pool', 'conv3x3_x3h_kernel<128, 2, false, 1': 'conv7_fwd_pool',
+_BASE = {  # kernel template instance <BN, sub-tiles, UNPOOL, EPI (0 relu / 1 pool / 2 dgrad)> (the trailing piece count and consumer
+    # layout arguments are stripped before the lookup) -> bench.py conv class (see PassEngine.forward/backward)
+    'conv3x3_x3h_kernel<64, 1, false, 1': 'conv2_fwd_pool', 'conv3x3_x3h_kernel<64, 2, false, 1': 'conv2_fwd_pool',
+    'conv3x3_x3h_kernel<128, 2, false, 1': 'conv7_fwd_pool',
     'conv3x3_x3h_kernel<128, 2, false, 0': 'conv5_fwd', 'conv3x3_x3h_kernel<64, 1, true, 2': 'conv2_dgrad',
     'conv3x3_x3h_kernel<128, 2, true, 2': 'conv7_dgrad', 'conv3x3_x3h_kernel<64, 2, false, 2': 'conv5_dgrad',
     'conv3x3_wgrad_x3_kernel<false': 'conv5_wgrad',
     'conv3x3_wgrad_x3_kernel<true': ('conv7_wgrad', 'conv2_wgrad'),      # same instance: the backward runs conv7 first, then conv2
 }
-CLASSES = {'%s, %d>' % (k, np_): v for k, v in _BASE.items() for np_ in (2, 3)}      # 2 = fp16 pieces (h2), 3 = bf16 pieces (x3)
+
+
+def conv_class(kernel_name):
+    m = re.search(r'(conv3x3_x3h_kernel<\d+, \d+, \w+, \d+|conv3x3_wgrad_x3_kernel<\w+)', kernel_name)
+    return _BASE.get(m.group(1)) if m else None
 
 
 # kernel-name substring -> bench.py class for the non-convolution classes (a class = one C-ABI call; calls that launch two
 # kernels, e.g. mtl_attn_bwd, are averaged per kernel and summed)
-GROUPS = {'gemm_small': ['gemm16_kernel'], 'gemm_big': ['gemm_kernel<', 'splitk_reduce_kernel'], 'attn_fwd': ['attn_fwd_kernel'],
+GROUPS = {'gemm_small': ['gemm16_kernel'], 'gemm_h2': ['gemm_nt_h2_kernel', 'gemm_h2_reduce_kernel'], 'gemm_big': ['gemm_kernel<', 'splitk_reduce_kernel'], 'attn_fwd': ['attn_fwd_kernel'],
           'attn_bwd': ['attn_bwd_q_kernel', 'attn_bwd_kv_kernel'], 'layernorm_fwd': ['layernorm_fwd_kernel'],
-          'layernorm_bwd': ['layernorm_bwd_kernel', 'ln_param_reduce_kernel'], 'conv0_fwd': ['conv0_fwd_kernel'],
+          'layernorm_bwd': ['layernorm_bwd_kernel', 'ln_param_reduce_kernel', 'ln_param_reduce_batch_kernel'], 'conv0_fwd': ['conv0_fwd_kernel'],
           'conv0_wgrad': ['conv0_wgrad_kernel', 'conv0_wgrad_final_kernel']}
 
 
@@ -42,13 +48,12 @@ def per_class(path, counter):
             n = len(d.get('gemm_kernel<', [])) or n          # a split-K reduction belongs to the call of its GEMM
         out[cls] = [sum(sum(v) for v in d.values()) / n]
     for r in rows:
-        m = re.search(r'(conv3x3_\w+<[^>]*>)', r['Kernel_Name'])
-        if not m or m.group(1) not in CLASSES:
+        cls = conv_class(r['Kernel_Name'])
+        if cls is None:
             continue
-        cls = CLASSES[m.group(1)]
         if isinstance(cls, tuple):
-            cls = cls[seen[m.group(1)] % 2]
-            seen[m.group(1)] += 1
+            cls = cls[seen[cls] % 2]
+            seen[conv_class(r['Kernel_Name'])] += 1
         out[cls].append(float(r['Counter_Value']))
     return {k: sum(v) / len(v) for k, v in out.items()}
 
