@@ -179,10 +179,12 @@ int mtl_conv3x3_wgrad(void* stream, const float* x, const float* dy, const unsig
 long mtl_conv3x3_wgrad_x3_workspace(int B, int T, int F, int Cin, int Cout, int pooled);
 int mtl_conv3x3_wgrad_x3(void* stream, const float* x, const float* dy, const unsigned char* argmax, float* dw_ref,
                          float* workspace, long workspace_bytes, int B, int T, int F, int Cin, int Cout);
-/* h2 weight gradient (workspace: mtl_conv3x3_wgrad_x3_workspace); amax_dy bounds the dense OR the pooled gradient it is given */
+/* h2 weight gradient (workspace: mtl_conv3x3_wgrad_x3_workspace); amax_dy bounds the dense OR the pooled gradient it is given.
+ * db (nullable, accum): the bias gradient db[c] += sum over pixels of dy -- the kernel's dy loaders see every element anyway, so
+ * the separate column-sum pass over dy (164 MB for conv5) is not needed. */
 int mtl_conv3x3_wgrad_h2(void* stream, const float* x, const float* amax_x, const float* dy, const float* amax_dy,
-                         const unsigned char* argmax, float* dw_ref, float* workspace, long workspace_bytes, int B, int T, int F,
-                         int Cin, int Cout);
+                         const unsigned char* argmax, float* dw_ref, float* db, float* workspace, long workspace_bytes, int B, int T,
+                         int F, int Cin, int Cout);
 /* wp[o][h*C+c] = w[o][c*Hh+h]  (inverse_accum: dst[o][c*Hh+h] += src[o][h*C+c]); the (C*H) flattening of
  * models/asr/transformer.py:136-138 folded into encoder.input_linear's weight instead of an activation copy. */
 int mtl_permute_hc(void* stream, const float* src, float* dst, int rows, int C, int Hh, int inverse_accum,

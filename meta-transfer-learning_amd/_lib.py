@@ -44,7 +44,7 @@ SIGNATURES = {
     'mtl_conv3x3_relu_fwd_h2': (I, [P, P, P, P, P, P, P, I, I, I, I, I]),
     'mtl_conv3x3_relu_pool_fwd_h2': (I, [P, P, P, P, P, P, P, P, I, I, I, I, I]),
     'mtl_conv3x3_dgrad_h2': (I, [P, P, P, P, P, P, P, P, I, I, I, I, I]),
-    'mtl_conv3x3_wgrad_h2': (I, [P, P, P, P, P, P, P, P, L, I, I, I, I, I]),
+    'mtl_conv3x3_wgrad_h2': (I, [P, P, P, P, P, P, P, P, P, L, I, I, I, I, I]),
     'mtl_absmax_f32': (I, [P, P, L, P]),
     'mtl_gemm_nt_h2_supported': (I, [I, I, I]),
     'mtl_gemm_nt_h2_workspace': (L, [I, I, I]),

@@ -1358,8 +1358,15 @@ __global__ __launch_bounds__(NT) void conv3x3_wgrad_kernel(WgradP p) {
 }
 
 // dw_ref[cout][cin][kh][kw] += sum_s partial[s][(tap*Cin + cin)][cout]      (fixed order -> deterministic)
-__global__ void wgrad_reduce_kernel(const float* partial, float* dw, int nsplit, int Cin, int Cout) {
+__global__ void wgrad_reduce_kernel(const float* partial, float* dw, int nsplit, int Cin, int Cout, const float* bias_part, float* db) {
     const int total = 9 * Cin * Cout;
+    if (db && blockIdx.x == 0) {              // bias gradient: per-slot sums of dy, added in slot order
+        for (int c = threadIdx.x; c < Cout; c += blockDim.x) {
+            float s = 0.f;
+            for (int k = 0; k < nsplit; ++k) s += bias_part[(long)k * Cout + c];
+            db[c] += s;
+        }
+    }
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
         const int cout = e % Cout;
         const int mc = e / Cout;  // tap*Cin + cin
@@ -1417,6 +1424,8 @@ struct WgradX3P {
     int dbg;              // ablation switches (MTL_X3_DBG): 1 no halo staging, 2 no dy loads / splits; 0 in production
     const float* amax_x;  // NP = 2: device scalars >= max|x|, >= max|dy|
     const float* amax_dy;
+    float* bias_part;     // optional [slot][Cout]: per-slot sums of dy over the slot's pixels (the bias gradient rides along: the
+                          // producers see every dy element exactly once per input-channel block; block 0 keeps the sums)
 };
 
 constexpr int WX_HF = 18, WX_NPIX = 10 * WX_HF;          // halo of an 8 x 16 tile
@@ -1499,6 +1508,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_x3_kernel(WgradX3P p) {
         // of one channel: 8 coalesced row loads (4 + 4 arg-max bytes when pooled), un-pool, 3-way split, three 16-byte stores
         // in the layout the consumers' ds_read_b128 wants ([piece][k half][co], conflict-free).  Loaded two pairs ahead.
         const int bs = ptid >> 7, bhi = (ptid >> 6) & 1, bco = ptid & 63;
+        f32x2 bsum2 = {0.f, 0.f};                              // sum of this thread's dy values (bias gradient of channel cob + bco)
         constexpr int NB = UNPOOL ? 4 : 8;
         float bv[2][NB];
         unsigned ba[2], bok[2];
@@ -1551,6 +1561,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_x3_kernel(WgradX3P p) {
                     val[k] = (((okm >> (k >> 1)) & 1u) && ((a >> (8 * (k >> 1))) & 0xffu) == sub) ? v[k >> 1] : 0.f;
                 }
             }
+            bsum2 += (f32x2{val[0], val[1]} + f32x2{val[2], val[3]}) + (f32x2{val[4], val[5]} + f32x2{val[6], val[7]});      // v_pk_add_f32
             unsigned q0[NP], q1[NP], q2[NP], q3[NP];
             Split<NP>::x2(val[0], val[1], sdy, q0);
             Split<NP>::x2(val[2], val[3], sdy, q1);
@@ -1586,6 +1597,14 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_x3_kernel(WgradX3P p) {
                 }
             }
             __syncthreads();
+        }
+        if (p.bias_part && cib == 0) {      // the four threads of a channel (k-step parity x k half) combine in a fixed order
+            float* sb = reinterpret_cast<float*>(smx);           // the halo buffers are free now (all consumers are past the last barrier)
+            sb[(bs * 2 + bhi) * 64 + bco] = bsum2.x + bsum2.y;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_s_barrier();                         // producers only (named barrier semantics: all 4 producer waves arrive)
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if (ptid < 64) p.bias_part[(long)slot * Cout + cob + bco] = (sb[bco] + sb[64 + bco]) + (sb[128 + bco] + sb[192 + bco]);
         }
         return;
     }
@@ -1901,7 +1920,7 @@ int mtl_conv3x3_wgrad(void* stream, const float* x, const float* dy, const unsig
         rc = pooled ? launch_wgrad<64, true>(p, nsplit, s) : launch_wgrad<64, false>(p, nsplit, s);
     if (rc) return rc;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(9L * Cin * Cout, 256)), dim3(256), 0, s, workspace, dw_ref,
-                       nsplit, Cin, Cout);
+                       nsplit, Cin, Cout, nullptr, nullptr);
     MTL_CHECK_LAUNCH();
     return MTL_OK;
 }
@@ -1920,15 +1939,16 @@ long mtl_conv3x3_wgrad_x3_workspace(int B, int T, int F, int Cin, int Cout, int 
     (void)pooled;
     if (Cin % 64 || Cout % 64) return 0;
     const int npairs = (Cin / 64) * (Cout / 64);
-    return (long)(wgrad_x3_grid(Cin, Cout) / npairs) * 9L * Cin * Cout * 4;
+    const long nslots = wgrad_x3_grid(Cin, Cout) / npairs;
+    return nslots * 9L * Cin * Cout * 4 + nslots * Cout * 4;          // slabs + per-slot bias-gradient sums
 }
 
 }  // extern "C"
 
 template <int NP>
 static int wgrad_pieces(hipStream_t s, const float* x, const float* amax_x, const float* dy, const float* amax_dy,
-                        const unsigned char* argmax, float* dw_ref, float* workspace, long workspace_bytes, int B, int T, int F,
-                        int Cin, int Cout) {
+                        const unsigned char* argmax, float* dw_ref, float* db, float* workspace, long workspace_bytes, int B, int T,
+                        int F, int Cin, int Cout) {
     if (!x || !dy || !dw_ref || !workspace || Cin % 64 || Cout % 64 || (NP == 2 && (!amax_x || !amax_dy))) return MTL_EINVAL;
     const int pooled = argmax != nullptr;
     if (workspace_bytes < mtl_conv3x3_wgrad_x3_workspace(B, T, F, Cin, Cout, pooled)) return MTL_EINVAL;
@@ -1955,6 +1975,7 @@ static int wgrad_pieces(hipStream_t s, const float* x, const float* amax_x, cons
     p.amax_x = amax_x;
     p.amax_dy = amax_dy;
     const int grid = wgrad_x3_grid(Cin, Cout);
+    p.bias_part = db ? workspace + (long)(grid / p.npairs) * 9L * Cin * Cout : nullptr;
     constexpr int SMEM = wx_smem(NP);
     if (pooled) {
         static int attr = set_smem(conv3x3_wgrad_x3_kernel<true, NP>, SMEM);
@@ -1967,7 +1988,7 @@ static int wgrad_pieces(hipStream_t s, const float* x, const float* amax_x, cons
     }
     MTL_CHECK_LAUNCH();
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(9L * Cin * Cout, 256)), dim3(256), 0, s, workspace, dw_ref,
-                       grid / p.npairs, Cin, Cout);
+                       grid / p.npairs, Cin, Cout, p.bias_part, db);
     MTL_CHECK_LAUNCH();
     return MTL_OK;
 }
@@ -1976,13 +1997,13 @@ extern "C" {
 
 int mtl_conv3x3_wgrad_x3(void* stream, const float* x, const float* dy, const unsigned char* argmax, float* dw_ref,
                          float* workspace, long workspace_bytes, int B, int T, int F, int Cin, int Cout) {
-    return wgrad_pieces<3>(as_stream(stream), x, nullptr, dy, nullptr, argmax, dw_ref, workspace, workspace_bytes, B, T, F, Cin, Cout);
+    return wgrad_pieces<3>(as_stream(stream), x, nullptr, dy, nullptr, argmax, dw_ref, nullptr, workspace, workspace_bytes, B, T, F, Cin, Cout);
 }
 
 int mtl_conv3x3_wgrad_h2(void* stream, const float* x, const float* amax_x, const float* dy, const float* amax_dy,
-                         const unsigned char* argmax, float* dw_ref, float* workspace, long workspace_bytes, int B, int T, int F,
-                         int Cin, int Cout) {
-    return wgrad_pieces<2>(as_stream(stream), x, amax_x, dy, amax_dy, argmax, dw_ref, workspace, workspace_bytes, B, T, F, Cin, Cout);
+                         const unsigned char* argmax, float* dw_ref, float* db, float* workspace, long workspace_bytes, int B, int T,
+                         int F, int Cin, int Cout) {
+    return wgrad_pieces<2>(as_stream(stream), x, amax_x, dy, amax_dy, argmax, dw_ref, db, workspace, workspace_bytes, B, T, F, Cin, Cout);
 }
 
 }  // extern "C"

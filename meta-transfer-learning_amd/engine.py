@@ -1171,18 +1171,24 @@ class PassEngine:
         am_ = (lambda i: amax.data_ptr() + 4 * _lib.AMAX_SLOTS * i) if h2 else (lambda i: None)      # bounds: y1, p1, y5 | dp2, dy5, dp1
         dgrad_fn = lib.mtl_conv3x3_dgrad_x3 if self.conv_x3 else lib.mtl_conv3x3_dgrad
 
-        def conv_dgrad(dy, ai, am, w, act, dx, *dims):
-            if h2:
-                return lib.mtl_conv3x3_dgrad_h2(st, dy, am_(ai), am, w, act, dx, None, *dims)
+        def conv_dgrad(dy, ai, am, w, act, dx, *dims, ao=None):
+            if h2:      # ao: slot that receives the bound of dx (the next layer's amax_dy)
+                return lib.mtl_conv3x3_dgrad_h2(st, dy, am_(ai), am, w, act, dx, am_(ao) if ao is not None else None, *dims)
             return dgrad_fn(st, dy, am, w, act, dx, *dims)
 
-        def wgrad(xa, axi, dy, adi, am, idx, Bq, Tq, Fq, cin, cout):
+        # h2: the weight-gradient kernel's dy loaders also sum dy (bias gradient) and the data-gradient epilogue delivers the bound of
+        # its output, so the column-sum passes over dy5 (164 MB) and dp1 (82 MB) are not needed; dp2 keeps its pass (its bound has no
+        # other producer)
+        fold = lambda am: h2 and (am is not None or self.wgrad_x3_dense)
+
+        def wgrad(xa, axi, dy, adi, am, idx, Bq, Tq, Fq, cin, cout, db=None):
             x3 = self.conv_x3 and (am is not None or self.wgrad_x3_dense)
             wsfn = lib.mtl_conv3x3_wgrad_x3_workspace if x3 else lib.mtl_conv3x3_wgrad_workspace
             need = wsfn(Bq, Tq, Fq, cin, cout, 1 if am else 0)
             ws = self.scratch(need)
             if x3 and h2:
-                rc = lib.mtl_conv3x3_wgrad_h2(st, xa, am_(axi), dy, am_(adi), am, g('conv.%d.weight' % idx), ws, need, Bq, Tq, Fq, cin, cout)
+                rc = lib.mtl_conv3x3_wgrad_h2(st, xa, am_(axi), dy, am_(adi), am, g('conv.%d.weight' % idx), db, ws, need, Bq, Tq, Fq,
+                                              cin, cout)
             else:
                 fn = lib.mtl_conv3x3_wgrad_x3 if x3 else lib.mtl_conv3x3_wgrad
                 rc = fn(st, xa, dy, am, g('conv.%d.weight' % idx), ws, need, Bq, Tq, Fq, cin, cout)
@@ -1191,15 +1197,18 @@ class PassEngine:
         self.colsum(dp2.data_ptr(), B * T4 * F4, 128, g('conv.7.bias'), am_(3))
         wgrad(y5.data_ptr(), 2, dp2.data_ptr(), 3, A['am2'].data_ptr(), 7, B, T2, F2, 128, 128)
         dy5 = self.buf('_dy5', (B, T2, F2, 128))
+        f5, f2 = fold(None), fold(A['am1'])
         check(conv_dgrad(dp2.data_ptr(), 3, A['am2'].data_ptr(),
-                         A['wd7'].data_ptr(), y5.data_ptr(), dy5.data_ptr(), B, T2, F2, 128, 128), 'dgrad7')
-        self.colsum(dy5.data_ptr(), B * T2 * F2, 128, g('conv.5.bias'), am_(4))
-        wgrad(p1.data_ptr(), 1, dy5.data_ptr(), 4, None, 5, B, T2, F2, 64, 128)
+                         A['wd7'].data_ptr(), y5.data_ptr(), dy5.data_ptr(), B, T2, F2, 128, 128, ao=4 if f5 else None), 'dgrad7')
+        if not f5:
+            self.colsum(dy5.data_ptr(), B * T2 * F2, 128, g('conv.5.bias'), am_(4))
+        wgrad(p1.data_ptr(), 1, dy5.data_ptr(), 4, None, 5, B, T2, F2, 64, 128, db=g('conv.5.bias') if f5 else None)
         dp1 = self.buf('_dp1', (B, T2, F2, 64))
         check(conv_dgrad(dy5.data_ptr(), 4, None, A['wd5'].data_ptr(),
-                         p1.data_ptr(), dp1.data_ptr(), B, T2, F2, 64, 128), 'dgrad5')
-        self.colsum(dp1.data_ptr(), B * T2 * F2, 64, g('conv.2.bias'), am_(5))
-        wgrad(y1.data_ptr(), 0, dp1.data_ptr(), 5, A['am1'].data_ptr(), 2, B, T, F, 64, 64)
+                         p1.data_ptr(), dp1.data_ptr(), B, T2, F2, 64, 128, ao=5 if f2 else None), 'dgrad5')
+        if not f2:
+            self.colsum(dp1.data_ptr(), B * T2 * F2, 64, g('conv.2.bias'), am_(5))
+        wgrad(y1.data_ptr(), 0, dp1.data_ptr(), 5, A['am1'].data_ptr(), 2, B, T, F, 64, 64, db=g('conv.2.bias') if f2 else None)
         dy1 = self.buf('_dy1', (B, T, F, 64))
         check(conv_dgrad(dp1.data_ptr(), 5, A['am1'].data_ptr(),
                          A['wd2'].data_ptr(), y1.data_ptr(), dy1.data_ptr(), B, T, F, 64, 64), 'dgrad2')

@@ -863,9 +863,11 @@ def test_conv3x3_two_piece_fp16_is_fp32_class(L, Cin, Cout, B, T, Fq, mag):
         ws = torch.empty(max(need, needf) // 4 + 16).cuda()
         wg, wgf = torch.zeros(Cout, Cin, 3, 3).cuda(), torch.zeros(Cout, Cin, 3, 3).cuda()
         assert L.mtl_conv3x3_wgrad(st(), dxn.data_ptr(), dpn.data_ptr(), am.data_ptr(), wgf.data_ptr(), ws.data_ptr(), needf, B, T, Fq, Cin, Cout) == 0
+        dbp = torch.zeros(Cout).cuda()
         assert L.mtl_conv3x3_wgrad_h2(st(), dxn.data_ptr(), ax.data_ptr(), dpn.data_ptr(), adp.data_ptr(), am.data_ptr(), wg.data_ptr(),
-                                      ws.data_ptr(), need, B, T, Fq, Cin, Cout) == 0
+                                      dbp.data_ptr(), ws.data_ptr(), need, B, T, Fq, Cin, Cout) == 0
         cmp('wgrad (pooled)', wg, wgf, w64.grad)
+        assert rel(dbp.double().cpu(), dpn.double().sum((0, 1, 2)).cpu()) < 1e-5           # the bias gradient rides along
         x64.grad = None
         w64.grad = None
     # dense backward
@@ -882,9 +884,14 @@ def test_conv3x3_two_piece_fp16_is_fp32_class(L, Cin, Cout, B, T, Fq, mag):
     ws = torch.empty(max(need, needf) // 4 + 16).cuda()
     wg, wgf = torch.zeros(Cout, Cin, 3, 3).cuda(), torch.zeros(Cout, Cin, 3, 3).cuda()
     assert L.mtl_conv3x3_wgrad(st(), dxn.data_ptr(), dyn.data_ptr(), None, wgf.data_ptr(), ws.data_ptr(), needf, B, T, Fq, Cin, Cout) == 0
-    assert L.mtl_conv3x3_wgrad_h2(st(), dxn.data_ptr(), ax.data_ptr(), dyn.data_ptr(), ady.data_ptr(), None, wg.data_ptr(), ws.data_ptr(),
-                                  need, B, T, Fq, Cin, Cout) == 0
+    dbd = torch.zeros(Cout).cuda()
+    assert L.mtl_conv3x3_wgrad_h2(st(), dxn.data_ptr(), ax.data_ptr(), dyn.data_ptr(), ady.data_ptr(), None, wg.data_ptr(), dbd.data_ptr(),
+                                  ws.data_ptr(), need, B, T, Fq, Cin, Cout) == 0
     cmp('wgrad', wg, wgf, w64.grad)
+    assert rel(dbd.double().cpu(), dyn.double().sum((0, 1, 2)).cpu()) < 1e-5
+    assert L.mtl_conv3x3_wgrad_h2(st(), dxn.data_ptr(), ax.data_ptr(), dyn.data_ptr(), ady.data_ptr(), None, wg.data_ptr(), dbd.data_ptr(),
+                                  ws.data_ptr(), need, B, T, Fq, Cin, Cout) == 0
+    assert rel(dbd.double().cpu(), 2 * dyn.double().sum((0, 1, 2)).cpu()) < 1e-5             # db accumulates
     # missing scalars are refused
     assert L.mtl_conv3x3_relu_fwd_h2(st(), dxn.data_ptr(), None, w2f.data_ptr(), db.data_ptr(), y.data_ptr(), None, B, T, Fq, Cin, Cout) != 0
     print(report)

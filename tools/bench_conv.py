@@ -70,7 +70,8 @@ def conv_case(name, T_, F_, cin, cout, pooled):
     ws = torch.empty(need // 4 + 64, device=dev)
     t = timeit(lambda: L.mtl_conv3x3_wgrad_x3(st(), x.data_ptr(), dy.data_ptr(), amp, dw.data_ptr(), ws.data_ptr(), need, B, T_, F_, cin, cout))
     print('%-8s wgrad x3 %.3f ms %6.1f TF' % (name, t, flops / t / 1e9))
-    t = timeit(lambda: L.mtl_conv3x3_wgrad_h2(st(), x.data_ptr(), ax.data_ptr(), dy.data_ptr(), ady.data_ptr(), amp, dw.data_ptr(), ws.data_ptr(), need, B, T_, F_, cin, cout))
+    dbias = torch.zeros(cout, device=dev)
+    t = timeit(lambda: L.mtl_conv3x3_wgrad_h2(st(), x.data_ptr(), ax.data_ptr(), dy.data_ptr(), ady.data_ptr(), amp, dw.data_ptr(), dbias.data_ptr(), ws.data_ptr(), need, B, T_, F_, cin, cout))
     print('%-8s wgrad h2 %.3f ms %6.1f TF' % (name, t, flops / t / 1e9))
 
 conv_case('conv2', T, F, 64, 64, True)
