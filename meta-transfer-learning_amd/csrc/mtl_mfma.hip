@@ -1601,9 +1601,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_x3_kernel(WgradX3P p) {
         if (p.bias_part && cib == 0) {      // the four threads of a channel (k-step parity x k half) combine in a fixed order
             float* sb = reinterpret_cast<float*>(smx);           // the halo buffers are free now (all consumers are past the last barrier)
             sb[(bs * 2 + bhi) * 64 + bco] = bsum2.x + bsum2.y;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_s_barrier();                         // producers only (named barrier semantics: all 4 producer waves arrive)
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            __syncthreads();                                      // matched by the consumers' barrier in front of their slab stores
             if (ptid < 64) p.bias_part[(long)slot * Cout + cob + bco] = (sb[bco] + sb[64 + bco]) + (sb[128 + bco] + sb[192 + bco]);
         }
         return;
@@ -1645,6 +1643,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_x3_kernel(WgradX3P p) {
         }
         __syncthreads();
     }
+    if (p.bias_part && cib == 0) __syncthreads();                  // the producers' bias-gradient hand-over (they use LDS once more)
     float* slab = p.partial + (long)slot * 9 * Cin * Cout;
     const float inv = NP == 2 ? 1.f / (pow2_scale(amax_read(p.amax_x)) * pow2_scale(amax_read(p.amax_dy))) : 1.f;
 #pragma unroll
