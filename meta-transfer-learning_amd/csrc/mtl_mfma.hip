@@ -1459,13 +1459,25 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_x3_kernel(WgradX3P p) {
     const int my_tiles = (p.tiles - slot + nslots - 1) / nslots;
     const int T = p.T, F = p.F, Cin = p.Cin, Cout = p.Cout;
     const int npairs_k = my_tiles * 4;                         // pairs of k-steps (2 x 16 pixels): the B hand-over granule
-    auto tile_of = [&](int j, int& b, int& t0, int& f0) {
-        int id = slot + j * nslots;
-        const int fx = id % p.ntf;
-        id /= p.ntf;
-        f0 = fx * 16;
-        t0 = (id % p.ntt) * 8;
-        b = id / p.ntt;
+    // (sample, t0, f0) of this workgroup's j-th tile; each caller keeps its last answer: the producers ask five times per tile, and
+    // the two runtime divisions were as many instructions as the rest of their work
+    struct TileCache {
+        int j = -1, b = 0, t0 = 0, f0 = 0;
+    };
+    TileCache tc_halo, tc_dy;
+    auto tile_of = [&](TileCache& c, int j, int& b, int& t0, int& f0) {
+        if (j != c.j) {
+            int id = slot + j * nslots;
+            const int fx = id % p.ntf;
+            id /= p.ntf;
+            c.f0 = fx * 16;
+            c.t0 = (id % p.ntt) * 8;
+            c.b = id / p.ntt;
+            c.j = j;
+        }
+        b = c.b;
+        t0 = c.t0;
+        f0 = c.f0;
     };
 
     if (tid >= NT) {
@@ -1476,7 +1488,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_x3_kernel(WgradX3P p) {
         unsigned okbits = 0;
         auto fetch = [&](int j) {
             int b, t0, f0;
-            tile_of(j, b, t0, f0);
+            tile_of(tc_halo, j, b, t0, f0);
             okbits = 0;
 #pragma unroll
             for (int i = 0; i < WX_NVA; ++i) {
@@ -1515,7 +1527,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_x3_kernel(WgradX3P p) {
         auto fetch_b = [&](int pk, float (&v)[NB], unsigned& a, unsigned& okm) {
             const int j = pk >> 2, s = (pk & 3) * 2 + bs;
             int b, t0, f0;
-            tile_of(min(j, my_tiles - 1), b, t0, f0);
+            tile_of(tc_dy, min(j, my_tiles - 1), b, t0, f0);
             const int t = t0 + s, fb = f0 + bhi * 8, co = cob + bco;
             okm = 0;
             a = 0;
