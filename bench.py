@@ -278,9 +278,21 @@ def timed_steps(trainer, model, vocab, tasks, my_tasks, n_tasks, inner, outer, a
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     host = 0.0
+    # the loop of TransientTrainer.train: iteration i + 1 is enqueued before iteration i's read-backs are resolved (loss, CER
+    # strings: host work that would otherwise be GPU idle time); every one of the K iterations is resolved INSIDE the timed span
+    pipelined = getattr(trainer, 'pipeline', False) and hasattr(trainer, 'enqueue_iteration')
+    pending = None
     for _ in range(steps):
-        last = one()
+        if pipelined:
+            nxt = trainer.enqueue_iteration(model, vocab, local, val, n_tasks, inner, outer, args)
+            if pending is not None:
+                last = pending.result()
+            pending = nxt
+        else:
+            last = one()
         host += getattr(trainer, 'host_enqueue_s', 0.0)
+    if pending is not None:
+        last = pending.result()
     HOST_ENQUEUE['ms_per_step'] = host / steps * 1e3     # host time to enqueue a step (the rest of the span it waits for the GPU)
     torch.cuda.synchronize(dev)
     mdist.barrier()
@@ -465,6 +477,7 @@ def main():
     if a.serial:
         model.n_lanes = 1
         trainer.use_cmdlists = False
+        trainer.pipeline = False
         for e in model.engines:
             e.use_side_stream = False
     inner, outer = mtl_amd.FlatSGD(model, args.lr), mtl_amd.FlatAdam(model, args.meta_lr)
@@ -520,8 +533,8 @@ def main():
                                         % (a.tasks, len(my_tasks), a.k, a.frames, a.labels),
                                tasks=a.tasks, k_train=a.k, src_frames=a.frames, tgt_len=a.labels, parallelism='task-sharded dp%d' % world,
                                collective=mdist.backend_name(), inputs='resident in HBM before the timed region',
-                               schedule='serial' if a.serial else '%d task lanes + side stream, command-list replay %s'
-                                        % (model.n_lanes, 'on' if trainer.use_cmdlists else 'off'),
+                               schedule='serial' if a.serial else '%d task lanes + side stream, command-list replay %s, host one iteration ahead %s'
+                                        % (model.n_lanes, 'on' if trainer.use_cmdlists else 'off', 'on' if trainer.pipeline else 'off'),
                                conv_arithmetic={'h2': '3x3 convolutions on 2-way fp16 splits of power-of-two-scaled fp32 operands (22 '
                                                       'significand bits, 3 fp16 MFMAs per step), fp32 accumulate: error <= 2.5x that of an '
                                                       'fp32 convolution against fp64 (tests/test_ops_gpu.py), parity bar unchanged',

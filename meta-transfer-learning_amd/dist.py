@@ -48,7 +48,25 @@ def init_from_env(backend=None):
         torch.cuda.set_device(local)
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     td.init_process_group(backend=backend, rank=int(os.environ['RANK']), world_size=world)
+    _scalar_group()
     return local
+
+
+_HOST_GROUP = None
+
+
+def _scalar_group():
+    """Host-side (gloo) group for the per-iteration log scalars.  On the RCCL communicator they would queue up behind the next
+    meta-step's gradient all-reduce -- i.e. behind all of its kernels -- and stall the host, which enqueues one iteration ahead
+    (TransientTrainer.enqueue_iteration).  None = the default group is gloo already."""
+    global _HOST_GROUP
+    if td.get_backend() == 'gloo':
+        return None
+    if _HOST_GROUP is None:
+        if os.environ.get('MASTER_ADDR', '127.0.0.1') in ('127.0.0.1', 'localhost'):
+            os.environ.setdefault('GLOO_SOCKET_IFNAME', 'lo')      # single node: the container hostname may not resolve
+        _HOST_GROUP = td.new_group(backend='gloo')
+    return _HOST_GROUP
 
 
 def shard_tasks(n_tasks, rank_, world):
@@ -66,8 +84,8 @@ def allreduce_sum_(flat):
 def allreduce_scalars(values, device):
     if not (is_on() and world_size() > 1):
         return values
-    t = torch.tensor(values, dtype=torch.float64, device=device)
-    td.all_reduce(t, op=td.ReduceOp.SUM)
+    t = torch.tensor(values, dtype=torch.float64)               # host tensor, host collective: never waits for queued GPU work
+    td.all_reduce(t, op=td.ReduceOp.SUM, group=_scalar_group())
     return t.tolist()
 
 

@@ -124,6 +124,28 @@ def _pinned(key, shape, dtype):
     return t
 
 
+class PendingIteration:
+    """An enqueued meta-iteration: result() waits for ITS end-of-iteration event (not for the device, which may already be
+    running the next iteration), then computes the reference's log quantities from the read-backs."""
+
+    def __init__(self, reads, done, vocab, dev):
+        self.reads, self.done, self.vocab, self.dev = reads, done, vocab, dev
+        self._result = None
+
+    def result(self):
+        if self._result is None:
+            self.done.synchronize()
+            total_loss, total_cer, total_char = 0.0, 0, 0
+            for tr_read, va_read in self.reads:
+                c, n = cer_counts(self.vocab, tr_read.gold_host, tr_read.hyp)    # the reference reports the TRAIN batches' CER
+                total_cer += c
+                total_char += n
+                total_loss += float(va_read.loss[0])
+            self._result = mdist.allreduce_scalars([total_loss, total_cer, total_char], self.dev)
+            self.reads = None
+        return self._result
+
+
 class _Readback:
     """Asynchronous D2H of (gold, hyp, loss) of one forward; resolved after the iteration's single sync.  `key` names the
     call site (task index, pass) whose pinned buffers are re-used from iteration to iteration."""
@@ -264,6 +286,9 @@ class TransientTrainer():
         # faster than the unsplit task (18.4 vs 18.7 ms per 1-task step, slower with dropout), so it is opt-in
         self.split_single_task = os.environ.get('MTL_SPLIT_TASK', '0') == '1'
         self._graphs = {}
+        # train() enqueues iteration i + 1 before it resolves (logs) iteration i (enqueue_iteration); MTL_PIPELINE=0: resolve at once
+        self.pipeline = os.environ.get('MTL_PIPELINE', '1') != '0'
+        self._turn = 0
 
     # ------------------------------------------------------------------ drop-in single-batch API
     def forward_one_batch(self, model, vocab, src, trg, src_percentages, src_lengths, trg_lengths, smoothing, loss_type,
@@ -345,8 +370,8 @@ class TransientTrainer():
                     graph['x_tr'].copy_(tx, non_blocking=True)
                     graph['x_va'].copy_(vx, non_blocking=True)
                     graph['g'].replay()
-                reads[idx] = (_Readback(dict(gold_host=m_tr['gold_host'], hyp=slots['hyp_tr'], loss=slots['loss_tr']), (idx, 0)),
-                              _Readback(dict(gold_host=m_va['gold_host'], hyp=slots['hyp_va'], loss=slots['loss_va']), (idx, 1)))
+                reads[idx] = (_Readback(dict(gold_host=m_tr['gold_host'], hyp=slots['hyp_tr'], loss=slots['loss_tr']), (idx, 0, self._turn)),
+                              _Readback(dict(gold_host=m_va['gold_host'], hyp=slots['hyp_va'], loss=slots['loss_va']), (idx, 1, self._turn)))
         if streams[0] is not main:
             for lane in range(n_lanes):
                 done = torch.cuda.Event()
@@ -443,7 +468,7 @@ class TransientTrainer():
             gold = torch.cat([metas[0][part]['gold_host'], metas[1][part]['gold_host']])
             hyp = torch.cat([slots[0][key_h], slots[1][key_h]])
             loss = slots[0][key_l] + slots[1][key_l]
-            reads.append(_Readback(dict(gold_host=gold, hyp=hyp, loss=loss), ('split', part)))
+            reads.append(_Readback(dict(gold_host=gold, hyp=hyp, loss=loss), ('split', part, self._turn)))
         return [tuple(reads)]
 
     def _task_body(self, model, lane, bufs, theta0, x_tr, m_tr, x_va, m_va, n_tasks, inner, args, smoothing, slots):
@@ -540,11 +565,15 @@ class TransientTrainer():
             self._lane_key = key
         return self._lanes
 
-    def run_iteration(self, model, vocab, task_batches, val_data, n_tasks, inner_opt, outer_opt, args):
-        """The timed body of one meta-iteration (transient_trainer.py:152-264): local tasks, ONE all-reduce of G, Adam,
-        then a single device sync to resolve the loss / label read-backs.  -> (sum val loss, CER edits, chars), global."""
+    def enqueue_iteration(self, model, vocab, task_batches, val_data, n_tasks, inner_opt, outer_opt, args):
+        """Enqueues one meta-iteration (transient_trainer.py:152-264: local tasks, ONE all-reduce of G, Adam) WITHOUT waiting for
+        it and returns a PendingIteration whose result() resolves the loss / label read-backs.  Nothing the host needs to enqueue
+        iteration i + 1 comes from the device, so train() (and bench.py) enqueue it before resolving iteration i: the host's
+        per-iteration work (batch preparation, CER strings, logging: 1.3 - 2.9 ms, all of it GPU idle time when a rank holds a
+        single 12 ms task) runs under the next iteration's kernels.  Read-back buffers alternate between two sets (`_turn`)."""
         dev = model.flat_parameters.device
         t_host = time.perf_counter()
+        self._turn ^= 1
         outer_opt.zero_grad()
         reads = self.meta_iteration(model, vocab, task_batches, val_data, n_tasks, inner_opt, outer_opt, args)
         G = model._G
@@ -552,15 +581,14 @@ class TransientTrainer():
         if args.clip:
             clip_flat_grad_(model, G, args.max_norm)             # (:253-254) on the summed meta-gradient
         outer_opt.step(G)                                        # from_copy_grad() + outer_opt.step()  (:248-255)
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream(dev))
         self.host_enqueue_s = time.perf_counter() - t_host       # host side of the iteration (diagnostics: bench.py reports it)
-        torch.cuda.synchronize(dev)
-        total_loss, total_cer, total_char = 0.0, 0, 0
-        for tr_read, va_read in reads:
-            c, n = cer_counts(vocab, tr_read.gold_host, tr_read.hyp)    # the reference reports the TRAIN batches' CER
-            total_cer += c
-            total_char += n
-            total_loss += float(va_read.loss[0])
-        return mdist.allreduce_scalars([total_loss, total_cer, total_char], dev)
+        return PendingIteration(reads, done, vocab, dev)
+
+    def run_iteration(self, model, vocab, task_batches, val_data, n_tasks, inner_opt, outer_opt, args):
+        """The timed body of one meta-iteration, resolved: -> (sum val loss, CER edits, chars), global."""
+        return self.enqueue_iteration(model, vocab, task_batches, val_data, n_tasks, inner_opt, outer_opt, args).result()
 
     def train(self, model, vocab, train_data_list, valid_loader_list, loss_type, start_it, num_it, args, inner_opt=None,
               outer_opt=None, evaluate_every=1000, window_size=100, last_summary_every=1000, last_metrics=None, early_stop=10,
@@ -609,6 +637,31 @@ class TransientTrainer():
         check_every = int(os.environ.get('MTL_REPLICA_CHECK_EVERY', '100'))
         it = start_it
         failures = 0
+        pending = None
+        clock = [time.time()]
+
+        def resolve(it_, step):
+            nonlocal total_time
+            total_loss, total_cer, total_char = step.result()
+            last_sum_cer.append(total_cer)
+            last_sum_char.append(total_char)
+            last_sum_loss.append(total_loss / n_tasks)
+            now = time.time()
+            diff_time, clock[0] = now - clock[0], now    # iterations overlap: the time between two resolutions is one iteration
+            total_time += diff_time
+            self.last_iteration_seconds = diff_time
+            msg = '(Iteration {}) TRAIN LOSS:{:.4f} CER:{:.2f}% LR:{:.7f} TOTAL TIME:{:.7f}'.format(
+                (it_ + 1), total_loss / n_tasks, total_cer * 100 / max(total_char, 1), self.get_lr(outer_opt), total_time)
+            if rank == 0:
+                print(msg)
+            logging.info(msg)
+            if (it_ + 1) % last_summary_every == 0:
+                msg = '(Summary Iteration {} | MA {}) TRAIN LOSS:{:.4f} CER:{:.2f}%'.format(
+                    (it_ + 1), window_size, sum(last_sum_loss) / len(last_sum_loss), sum(last_sum_cer) * 100 / sum(last_sum_char))
+                if rank == 0:
+                    print(msg, flush=True)
+                logging.info(msg)
+
         while it < num_it:
             # like the reference (:141-376) a failing iteration is reported and skipped (new data is fetched, `it` does not
             # advance); unlike it, MAX_CONSECUTIVE_FAILURES failures in a row re-raise instead of looping forever
@@ -617,32 +670,18 @@ class TransientTrainer():
                 prefetch = threading.Thread(target=fetch_train_batch, args=(train_data_buffer,))
                 prefetch.start()
 
-                start_time = time.time()
                 _, val_data = train_data_buffer[-1][-1]                  # the LAST task's validation batch, shared by all (:168)
                 popped = [train_data_buffer[m].pop() for m in range(n_tasks)]
                 task_batches = [popped[m][0] for m in my_tasks]
                 if world > 1 and (it == start_it or (check_every > 0 and (it + 1) % check_every == 0)):
                     check_replicas(model, val_data, it)
-                total_loss, total_cer, total_char = self.run_iteration(model, vocab, task_batches, val_data, n_tasks, inner_opt,
-                                                                       outer_opt, args)
-                last_sum_cer.append(total_cer)
-                last_sum_char.append(total_char)
-                last_sum_loss.append(total_loss / n_tasks)
-                diff_time = time.time() - start_time
-                total_time += diff_time
-                self.last_iteration_seconds = diff_time
-
-                msg = '(Iteration {}) TRAIN LOSS:{:.4f} CER:{:.2f}% LR:{:.7f} TOTAL TIME:{:.7f}'.format(
-                    (it + 1), total_loss / n_tasks, total_cer * 100 / max(total_char, 1), self.get_lr(outer_opt), total_time)
-                if rank == 0:
-                    print(msg)
-                logging.info(msg)
-                if (it + 1) % last_summary_every == 0:
-                    msg = '(Summary Iteration {} | MA {}) TRAIN LOSS:{:.4f} CER:{:.2f}%'.format(
-                        (it + 1), window_size, sum(last_sum_loss) / len(last_sum_loss), sum(last_sum_cer) * 100 / sum(last_sum_char))
-                    if rank == 0:
-                        print(msg, flush=True)
-                    logging.info(msg)
+                step = self.enqueue_iteration(model, vocab, task_batches, val_data, n_tasks, inner_opt, outer_opt, args)
+                if pending is not None:
+                    resolve(*pending)                     # iteration it - 1 is logged while the device runs iteration it
+                pending = (it, step)
+                if not self.pipeline or (it + 1) % evaluate_every == 0 or it + 1 >= num_it:
+                    resolve(*pending)
+                    pending = None
 
                 if (it + 1) % evaluate_every == 0:
                     save_fn = lambda metrics, best_model: save_meta_model(model, vocab, (it + 1), inner_opt, outer_opt, metrics,
@@ -650,6 +689,7 @@ class TransientTrainer():
                     stop, best_valid_val, count_stop = run_validation(
                         self.forward_one_batch, model, vocab, valid_loader_list, it, args, history, loss_type, save_fn,
                         early_stop_criteria, early_stop_val, best_valid_val, count_stop, rank)
+                    clock[0] = time.time()                # evaluation time is not training time
                     if stop:
                         break
                 it += 1
@@ -663,6 +703,8 @@ class TransientTrainer():
                 print('Error: {}, fetching new data...'.format(e), flush=True)
                 logging.info('Error: {}, fetching new data...'.format(e))
                 torch.cuda.synchronize(dev)
+        if pending is not None:
+            resolve(*pending)
         prefetch.join()
         self.history = history
 

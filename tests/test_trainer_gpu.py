@@ -276,3 +276,26 @@ def test_rccl_collective_path_executes():
     j2 = json.loads([l for l in rccl.stdout.splitlines() if l.startswith('{')][-1])
     assert j2['config']['collective'] == 'nccl' and j1['config']['collective'] == 'none'
     assert j1['last_step'] == j2['last_step']
+
+
+def test_host_one_iteration_ahead_is_bitwise_equal(capsys):
+    """TransientTrainer.train enqueues iteration i + 1 before it resolves iteration i (enqueue_iteration / PendingIteration): the
+    log lines (loss, CER, learning rate of every iteration) and theta after 5 iterations are identical to the loop that resolves
+    every iteration at once (MTL_PIPELINE=0 behaviour), with one task (single lane) and with three (task lanes)."""
+    import re
+    z, cfg, spec = gu.load('F0')
+    for n_tasks in (1, 3):
+        out = {}
+        for pipe in (False, True):
+            mtl_amd, args, vocab, model = make(cfg, spec, name='pipe')
+            model = model.cuda()
+            tasks = [mtl_amd.SyntheticTask(m, 2, 64, 8, cfg['vocab_size'], variable=True) for m in range(n_tasks)]
+            trainer = mtl_amd.TransientTrainer()
+            trainer.pipeline = pipe
+            capsys.readouterr()
+            trainer.train(model, vocab, tasks, [], 'ce', 0, 5, args, evaluate_every=10 ** 9, early_stop='cer,200', is_copy_grad=True)
+            lines = [re.sub(r' TOTAL TIME:.*', '', l) for l in capsys.readouterr().out.splitlines() if l.startswith('(Iteration')]
+            assert len(lines) == 5 and [int(l.split(')')[0].split()[1]) for l in lines] == [1, 2, 3, 4, 5]
+            out[pipe] = (lines, model.flat_parameters.detach().cpu().clone())
+        assert out[False][0] == out[True][0]
+        assert torch.equal(out[False][1], out[True][1])

@@ -21,11 +21,9 @@ calls = collections.Counter()
 orig = eng.gemm
 
 
-def spy(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias=None, gate=None, ldg=0, flags=0, alpha=1.0, batch=1, H=1, sA=(0, 0),
-        sB=(0, 0), sC=(0, 0), sbias=0):
-    calls[(ta, tb, M, N, K, batch, H)] += 1
-    return orig(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias=bias, gate=gate, ldg=ldg, flags=flags, alpha=alpha, batch=batch,
-                H=H, sA=sA, sB=sB, sC=sC, sbias=sbias)
+def spy(ta, tb, M, N, K, *args, **kw):
+    calls[(ta, tb, M, N, K, kw.get('batch', 1), kw.get('H', 1), kw.get('kbatch', 1), bool(kw.get('rowsum')))] += 1
+    return orig(ta, tb, M, N, K, *args, **kw)
 
 
 eng.gemm = spy
@@ -40,7 +38,7 @@ L = eng.lib
 st = torch.cuda.current_stream().cuda_stream
 ws = torch.empty(8 << 20, device=dev)
 rows = []
-for (ta, tb, M, N, K, batch, H), n in calls.items():
+for (ta, tb, M, N, K, batch, H, kb, rs), n in calls.items():
     zb = batch
     A = torch.randn(zb * M * K + 64, device=dev)
     Bm = torch.randn(zb * N * K + 64, device=dev)
@@ -56,10 +54,10 @@ for (ta, tb, M, N, K, batch, H), n in calls.items():
         f()
     torch.cuda.synchronize()
     us = (time.perf_counter() - t0) / 20 * 1e6
-    rows.append((n * us, n, us, (ta, tb, M, N, K, batch, H)))
+    rows.append((n * us, n, us, (ta, tb, M, N, K, batch, H, kb, rs)))
 rows.sort(reverse=True)
 tot = sum(r[0] for r in rows)
 print('total %.2f ms per pass over %d calls' % (tot / 1e3, sum(r[1] for r in rows)))
 for t, n, us, key in rows:
-    ta, tb, M, N, K, batch, H = key
-    print('%5.1f%%  x%-3d %7.1f us  %6.1f TF  ta%d tb%d M%-5d N%-5d K%-5d batch%-3d' % (100 * t / tot, n, us, 2.0 * M * N * K * batch / us / 1e6, ta, tb, M, N, K, batch))
+    ta, tb, M, N, K, batch, H, kb, rs = key
+    print('%5.1f%%  x%-3d %7.1f us  %6.1f TF  ta%d tb%d M%-5d N%-5d K%-5d batch%-3d kbatch%d rowsum%d' % (100 * t / tot, n, us, 2.0 * M * N * K * batch / us / 1e6, ta, tb, M, N, K, batch, kb, rs))
