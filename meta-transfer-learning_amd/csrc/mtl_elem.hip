@@ -9,6 +9,8 @@
 //   F.cross_entropy + topk(1)                 utils/metrics.py:126; models/asr/transformer.py:146-147
 //   Conv2d(1->64)+ReLU                        models/asr/transformer.py:48-49
 //   SGD / copy_grad / Adam                    trainer/asr/transient_trainer.py:207,229,255; models/asr/transformer.py:205-240
+#include <algorithm>
+
 #include "mtl_common.h"
 #include "../../include/mtl_hip.h"
 
@@ -565,117 +567,181 @@ __global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restr
     }
 }
 
-// ------------------------------------------------------------------ first conv layer (C_in = 1): direct, HBM-bound
+// ------------------------------------------------------------------ first conv layer (C_in = 1): direct
 // x is the reference's (B,1,F,T) tensor (T contiguous); y is (B,T,F,64) channels-last.
-// lane = (pixel, 4-channel group): a wave writes 4 pixels x 64 channels = 1 KiB contiguous.
+// The layer is 2.97 G multiply-adds on the vector ALU next to a 330 MB stream: at one v_fmac_f32 per multiply-add the ALU time
+// alone (75 us) exceeds the stream's (52 us at 6.3 TB/s), so the arithmetic runs on v_pk_fma_f32 (two channels per lane and
+// instruction: 38 us) and everything that is not arithmetic is kept off the per-pixel path:
+//   * a workgroup owns C0_NB tiles of C0_TB = 4 frames x all F bins of one utterance; the (F + 2) x 6 input patch of a tile
+//     (5 MB tensor, L2-resident) is staged once in LDS as 8-float rows, zero-padded at the borders -- no bounds logic later;
+//   * a thread = (4-channel group cg, bin slot): it fetches rows f-1, f, f+1 of the patch with six ds_read_b128 and produces the
+//     4 frames x 4 channels of its bin from registers (144 multiply-adds = 72 v_pk_fma_f32), 27 instructions per pixel and lane
+//     instead of ~250 (per-pixel 64-bit index divisions, nine predicated scalar loads);
+//   * a wave's four bin slots are consecutive bins: every store instruction of a wave writes 1 KiB contiguous.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+constexpr int C0_TB = 4, C0_NB = 2, C0_ROW = 8;
+
+// acc += x * w on both halves of w, x = the low (hi = 0) or high (hi = 1) half of the register pair xp: the operand-select bits of
+// v_pk_fma_f32 broadcast either half of src0 (hipcc only finds the low-half form and copies the high halves into new pairs)
+__device__ __forceinline__ f32x2 pk_fma_bcast(int hi, f32x2 xp, f32x2 w, f32x2 acc) {      // (hi folds after unrolling)
+    if (hi)
+        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(xp), "v"(w));
+    else
+        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(xp), "v"(w));
+    return acc;
+}
+
+// the 6 patch values of one row as three register pairs
+struct C0Row {
+    f32x2 p[3];
+    __device__ __forceinline__ void load(const float* r) {
+        const float4 lo = *reinterpret_cast<const float4*>(r);
+        const float2 hi = *reinterpret_cast<const float2*>(r + 4);
+        p[0] = f32x2{lo.x, lo.y}, p[1] = f32x2{lo.z, lo.w}, p[2] = f32x2{hi.x, hi.y};
+    }
+};
+
+// LDS patch of tile g (utterance b, frames t0 .. t0 + 3): xs[(f + 1) * 8 + c] = x[b][f][t0 - 1 + c], c < 6, zero outside the tensor
+__device__ __forceinline__ void conv0_stage(const float* __restrict__ x, float* __restrict__ xs, int g, int ntiles, int ntb, int T,
+                                            int F) {
+    const int c = threadIdx.x & 7;
+    const bool live = g < ntiles && c < 6;
+    const int b = live ? g / ntb : 0;
+    const int t = live ? (g - b * ntb) * C0_TB - 1 + c : -1;
+    const float* xb = x + (long)b * F * T + t;
+    for (int fr = threadIdx.x >> 3; fr < F + 2; fr += 32) {
+        const int f = fr - 1;
+        xs[fr * C0_ROW + c] = (live && (unsigned)t < (unsigned)T && (unsigned)f < (unsigned)F) ? xb[(long)f * T] : 0.f;
+    }
+}
+
 __global__ __launch_bounds__(256) void conv0_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, float* __restrict__ y, int B, int T,
                                                         int F, float* __restrict__ amax_y) {
-    const int cg = threadIdx.x & 15;  // channels 4cg..4cg+3
-    float mx = 0.f;
+    extern __shared__ __attribute__((aligned(16))) float c0_lds[];          // [C0_NB][F + 2][8]
+    const int cg = threadIdx.x & 15, sl = threadIdx.x >> 4;  // channels 4cg..4cg+3, bin slot
     // this workgroup's slot of the bound, read NOW (a stale value only costs a redundant atomic): read at the end, the round trip
     // sat on the tail of every short-lived workgroup (+24 us per launch)
     float* slot = amax_y ? amax_y + (blockIdx.x & (MTL_AMAX_SLOTS - 1)) * MTL_AMAX_STRIDE : nullptr;
     const float seen = slot ? *slot : 0.f;
-    float wr[4][9], bb[4];
+    f32x2 w01[9], w23[9];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        bb[c] = bias[cg * 4 + c];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) wr[c][k] = w[(cg * 4 + c) * 9 + k];
+    for (int k = 0; k < 9; ++k) {
+        w01[k] = f32x2{w[(cg * 4 + 0) * 9 + k], w[(cg * 4 + 1) * 9 + k]};
+        w23[k] = f32x2{w[(cg * 4 + 2) * 9 + k], w[(cg * 4 + 3) * 9 + k]};
     }
-    const long npix = (long)B * T * F;
-    const int pl = threadIdx.x >> 4;
-    for (long base = (long)blockIdx.x * 16; base < npix; base += (long)gridDim.x * 16) {
-        // (b, t, f) of the block's first pixel: wave-uniform (scalar) divisions; the thread's own pixel is a carry away
-        const long bt0 = base / F;
-        int f = (int)(base - bt0 * F) + pl, t = (int)(bt0 % T), b = (int)(bt0 / T);
-        while (f >= F) {
-            f -= F;
-            if (++t == T) {
-                t = 0;
-                ++b;
+    const f32x2 b01 = {bias[cg * 4], bias[cg * 4 + 1]}, b23 = {bias[cg * 4 + 2], bias[cg * 4 + 3]};
+    const int ntb = (T + C0_TB - 1) / C0_TB, rows = F + 2;
+    const int ntiles = B * ntb;
+    f32x2 mx = {0.f, 0.f};
+    for (int g0 = blockIdx.x * C0_NB; g0 < ntiles; g0 += gridDim.x * C0_NB) {
+        __syncthreads();                                     // the previous patches have been consumed
+#pragma unroll
+        for (int nb = 0; nb < C0_NB; ++nb) conv0_stage(x, c0_lds + nb * rows * C0_ROW, g0 + nb, ntiles, ntb, T, F);
+        __syncthreads();
+        const int bA = g0 / ntb, tA = (g0 - bA * ntb) * C0_TB;             // the two tiles' (utterance, first frame): uniform
+        const int bB = (g0 + 1) / ntb, tB = (g0 + 1 - bB * ntb) * C0_TB;
+        const int s_end = (g0 + 1 < ntiles ? 2 : 1) * F;
+        for (int s = sl; s < s_end; s += 16) {
+            const int nb = s >= F ? 1 : 0, f = s - nb * F;   // (C0_NB == 2)
+            const int b = nb ? bB : bA, t0 = nb ? tB : tA;
+            const float* r = c0_lds + (nb * rows + f) * C0_ROW;           // patch row of bin f - 1
+            C0Row xr[3];
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) xr[kh].load(r + kh * C0_ROW);
+            float* yp = y + (((long)b * T + t0) * F + f) * 64 + cg * 4;
+#pragma unroll
+            for (int tt = 0; tt < C0_TB; ++tt) {
+                f32x2 a01 = b01, a23 = b23;
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        a01 = pk_fma_bcast((tt + kw) & 1, xr[kh].p[(tt + kw) >> 1], w01[kh * 3 + kw], a01);
+                        a23 = pk_fma_bcast((tt + kw) & 1, xr[kh].p[(tt + kw) >> 1], w23[kh * 3 + kw], a23);
+                    }
+                const f32x2 z = {0.f, 0.f};
+                a01 = __builtin_elementwise_max(a01, z);
+                a23 = __builtin_elementwise_max(a23, z);
+                if (t0 + tt < T) {
+                    mx = __builtin_elementwise_max(mx, __builtin_elementwise_max(a01, a23));
+                    const f32x4_t out = {a01.x, a01.y, a23.x, a23.y};
+                    __builtin_nontemporal_store(out, reinterpret_cast<f32x4_t*>(yp + (long)tt * F * 64));   // streamed: read next by another kernel
+                }
             }
         }
-        const long pix = base + pl;
-        if (pix >= npix) break;
-        const float* xb = x + (long)b * F * T;
-        float acc[4] = {bb[0], bb[1], bb[2], bb[3]};
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-            const int fs = f + kh - 1;
-#pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                const int ts = t + kw - 1;
-                const float xv = ((unsigned)fs < (unsigned)F && (unsigned)ts < (unsigned)T) ? xb[(long)fs * T + ts] : 0.f;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) acc[c] += xv * wr[c][kh * 3 + kw];
-            }
-        }
-        typedef float f32x4_t __attribute__((ext_vector_type(4)));
-        const f32x4_t out = {fmaxf(acc[0], 0.f), fmaxf(acc[1], 0.f), fmaxf(acc[2], 0.f), fmaxf(acc[3], 0.f)};
-        __builtin_nontemporal_store(out, reinterpret_cast<f32x4_t*>(y + pix * 64 + cg * 4));      // streamed: 330 MB, read next by another kernel
-        mx = fmaxf(fmaxf(mx, fmaxf(acc[0], acc[1])), fmaxf(acc[2], acc[3]));
     }
     if (amax_y) {       // max of the outputs (>= 0 after the ReLU), one candidate per workgroup; the caller zeroes the slots
         __shared__ float shm[4];
-        mx = wave_max(mx);
-        if ((threadIdx.x & 63) == 0) shm[threadIdx.x >> 6] = mx;
+        float m1 = wave_max(fmaxf(mx.x, mx.y));
+        if ((threadIdx.x & 63) == 0) shm[threadIdx.x >> 6] = m1;
         __syncthreads();
         const float cand = fmaxf(fmaxf(shm[0], shm[1]), fmaxf(shm[2], shm[3]));
         if (threadIdx.x == 0 && cand > seen) atomicMax(reinterpret_cast<unsigned*>(slot), __float_as_uint(cand));
     }
 }
-// dw0[c][tap] = sum_pix x[pix+tap]*dy[pix][c], db0[c] = sum_pix dy[pix][c]: per-block partials [blk][64][10]
+// dw0[c][tap] = sum_pix x[pix+tap]*dy[pix][c], db0[c] = sum_pix dy[pix][c]: per-block partials [blk][64][10].  Same tiling as the
+// forward kernel; a thread keeps the 4 channels x (9 taps + bias) sums of its bin slot as v_pk_fma_f32 pairs.
 __global__ __launch_bounds__(256) void conv0_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                           float* __restrict__ part, int B, int T, int F) {
-    __shared__ float sh[16][64][10];
-    const int cg = threadIdx.x & 15, pl = threadIdx.x >> 4;
-    float acc[4][10];
+    extern __shared__ __attribute__((aligned(16))) float c0_lds[];          // [C0_NB][F + 2][8], re-used for the final [16][64][10]
+    const int cg = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    f32x2 a01[10], a23[10];
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
+    for (int k = 0; k < 10; ++k) a01[k] = a23[k] = f32x2{0.f, 0.f};
+    const int ntb = (T + C0_TB - 1) / C0_TB, rows = F + 2;
+    const int ntiles = B * ntb;
+    for (int g0 = blockIdx.x * C0_NB; g0 < ntiles; g0 += gridDim.x * C0_NB) {
+        __syncthreads();
 #pragma unroll
-        for (int k = 0; k < 10; ++k) acc[c][k] = 0.f;
-    const long npix = (long)B * T * F;
-    for (long base = (long)blockIdx.x * 16; base < npix; base += (long)gridDim.x * 16) {
-        const long bt0 = base / F;                       // wave-uniform (scalar) divisions, see conv0_fwd_kernel
-        int f = (int)(base - bt0 * F) + pl, t = (int)(bt0 % T), b = (int)(bt0 / T);
-        while (f >= F) {
-            f -= F;
-            if (++t == T) {
-                t = 0;
-                ++b;
+        for (int nb = 0; nb < C0_NB; ++nb) conv0_stage(x, c0_lds + nb * rows * C0_ROW, g0 + nb, ntiles, ntb, T, F);
+        __syncthreads();
+        const int bA = g0 / ntb, tA = (g0 - bA * ntb) * C0_TB;             // the two tiles' (utterance, first frame): uniform
+        const int bB = (g0 + 1) / ntb, tB = (g0 + 1 - bB * ntb) * C0_TB;
+        const int s_end = (g0 + 1 < ntiles ? 2 : 1) * F;
+        for (int s = sl; s < s_end; s += 16) {
+            const int nb = s >= F ? 1 : 0, f = s - nb * F;   // (C0_NB == 2)
+            const int b = nb ? bB : bA, t0 = nb ? tB : tA;
+            const float* dp = dy + (((long)b * T + t0) * F + f) * 64 + cg * 4;
+            f32x4_t d[C0_TB];
+#pragma unroll
+            for (int tt = 0; tt < C0_TB; ++tt)               // the four 16-byte loads of the stream are issued together
+                d[tt] = (t0 + tt < T) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(dp + (long)tt * F * 64))
+                                      : f32x4_t{0.f, 0.f, 0.f, 0.f};
+            const float* r = c0_lds + (nb * rows + f) * C0_ROW;
+            C0Row xr[3];
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) xr[kh].load(r + kh * C0_ROW);
+#pragma unroll
+            for (int tt = 0; tt < C0_TB; ++tt) {
+                const f32x2 d01 = {d[tt].x, d[tt].y}, d23 = {d[tt].z, d[tt].w};
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        a01[kh * 3 + kw] = pk_fma_bcast((tt + kw) & 1, xr[kh].p[(tt + kw) >> 1], d01, a01[kh * 3 + kw]);
+                        a23[kh * 3 + kw] = pk_fma_bcast((tt + kw) & 1, xr[kh].p[(tt + kw) >> 1], d23, a23[kh * 3 + kw]);
+                    }
+                a01[9] += d01;
+                a23[9] += d23;
             }
         }
-        const long pix = base + pl;
-        if (pix >= npix) break;
-        const float* xb = x + (long)b * F * T;
-        typedef float f32x4_t __attribute__((ext_vector_type(4)));
-        const f32x4_t d4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(dy + pix * 64 + cg * 4));
-        const float d[4] = {d4.x, d4.y, d4.z, d4.w};
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-            const int fs = f + kh - 1;
-#pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                const int ts = t + kw - 1;
-                const float xv = ((unsigned)fs < (unsigned)F && (unsigned)ts < (unsigned)T) ? xb[(long)fs * T + ts] : 0.f;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) acc[c][kh * 3 + kw] += xv * d[c];
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[c][9] += d[c];
     }
+    __syncthreads();
+    float* sh = c0_lds;                                      // [16 slots][64 channels][10]
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-        for (int k = 0; k < 10; ++k) sh[pl][cg * 4 + c][k] = acc[c][k];
+    for (int k = 0; k < 10; ++k) {
+        sh[(sl * 64 + cg * 4 + 0) * 10 + k] = a01[k].x;
+        sh[(sl * 64 + cg * 4 + 1) * 10 + k] = a01[k].y;
+        sh[(sl * 64 + cg * 4 + 2) * 10 + k] = a23[k].x;
+        sh[(sl * 64 + cg * 4 + 3) * 10 + k] = a23[k].y;
+    }
     __syncthreads();
     for (int e = threadIdx.x; e < 640; e += 256) {
-        float s = 0.f;
-        for (int p = 0; p < 16; ++p) s += (&sh[p][0][0])[e];
-        part[(long)blockIdx.x * 640 + e] = s;
+        float t = 0.f;
+        for (int p = 0; p < 16; ++p) t += sh[p * 640 + e];
+        part[(long)blockIdx.x * 640 + e] = t;
     }
 }
 // one wave per output element: lanes stride the per-block partials, fixed-order shuffle tree
@@ -1098,8 +1164,11 @@ int mtl_colsum_accum(void* stream, const float* X, long rows, int cols, long ld,
 
 int mtl_conv0_relu_fwd(void* stream, const float* x, const float* w, const float* bias, float* y, int B, int T, int F, float* amax_y) {
     if (!x || !w || !bias || !y) return MTL_EINVAL;
-    hipLaunchKernelGGL(conv0_fwd_kernel, dim3(grid_for((long)B * T * F, 16, 8192)), dim3(256), 0, as_stream(stream), x, w, bias,
-                       y, B, T, F, amax_y);
+    const long lds = (long)C0_NB * (F + 2) * C0_ROW * 4;
+    if (B <= 0 || T <= 0 || F <= 0 || lds > 64 * 1024) return MTL_EINVAL;
+    const long tiles = (long)B * ((T + C0_TB - 1) / C0_TB);
+    hipLaunchKernelGGL(conv0_fwd_kernel, dim3((unsigned)std::min<long>((tiles + C0_NB - 1) / C0_NB, 4096)), dim3(256), (size_t)lds,
+                       as_stream(stream), x, w, bias, y, B, T, F, amax_y);
     MTL_CHECK_LAUNCH();
     return MTL_OK;
 }
@@ -1108,9 +1177,12 @@ long mtl_conv0_wgrad_workspace(void) { return 1024L * 640 * 4; }
 
 int mtl_conv0_wgrad(void* stream, const float* x, const float* dy, float* dw, float* db, float* workspace, int B, int T, int F) {
     if (!x || !dy || !dw || !db || !workspace) return MTL_EINVAL;
-    const int nb = grid_for((long)B * T * F, 16 * 64, 1024);
+    const long lds = std::max<long>((long)C0_NB * (F + 2) * C0_ROW * 4, 16L * 640 * 4);
+    if (B <= 0 || T <= 0 || F <= 0 || lds > 64 * 1024) return MTL_EINVAL;
+    const long tiles = (long)B * ((T + C0_TB - 1) / C0_TB);
+    const int nb = (int)std::min<long>((tiles + C0_NB - 1) / C0_NB, 1024);
     hipStream_t s = as_stream(stream);
-    hipLaunchKernelGGL(conv0_wgrad_kernel, dim3(nb), dim3(256), 0, s, x, dy, workspace, B, T, F);
+    hipLaunchKernelGGL(conv0_wgrad_kernel, dim3(nb), dim3(256), (size_t)lds, s, x, dy, workspace, B, T, F);
     hipLaunchKernelGGL(conv0_wgrad_final_kernel, dim3(160), dim3(256), 0, s, workspace, nb, dw, db);
     MTL_CHECK_LAUNCH();
     return MTL_OK;

@@ -223,6 +223,9 @@ class PassEngine:
         self.forward_hook = None      # optional callable(engine) after every forward has been enqueued (tests capture the arena)
         self.deferred = []
         self.use_side_stream = True
+        self.flush_level = int(os.environ.get('MTL_FLUSH_LEVEL', '0'))      # see flush_side
+        self.flush_delay = os.environ.get('MTL_FLUSH_DELAY', '0') == '1'
+        self._held = None
         # 3x3 convolutions (forward and data gradient): '1' = exact 3-way bf16 split on the bf16 MFMA pipe (fp32-accurate, see
         # DESIGN.md 5.1), '0' = the fp32 MFMA kernels
         # 3x3 convolutions: 'h2' two fp16 pieces per fp32 operand (3 MFMAs per step, per-tensor power-of-two scaling from device
@@ -395,15 +398,29 @@ class PassEngine:
         else:
             fn()
 
-    def flush_side(self):
+    def flush_side(self, level=3):
         """Everything enqueued on the main stream so far is visible to the deferred jobs, which are now issued on the side
-        stream.  Their inputs are per-block buffers that the main stream never rewrites within this backward."""
-        if not self.deferred:
+        stream.  Their inputs are per-block buffers that the main stream never rewrites within this backward, so a fork may be
+        postponed: `level` names the call site (0 end of a sub-layer block, 1 end of a layer, 2 end of the decoder / encoder
+        backward, 3 unconditional) and sites below self.flush_level only let the jobs pile up for the next fork."""
+        if not self.deferred or level < self.flush_level:
             return
         ev = self._event()
         check(self.lib.mtl_event_record(ev, self.stream), 'mtl_event_record')
-        check(self.lib.mtl_stream_wait_event(self.side.cuda_stream, ev), 'mtl_stream_wait_event')
         jobs, self.deferred = self.deferred, []
+        held, self._held = self._held, None
+        if self.flush_delay and level < 3:
+            self._held = (ev, jobs)          # issued at the NEXT fork (or the join): by then the main stream has more work queued
+        else:
+            if held is not None:
+                self._issue_side(*held)
+                held = None
+            self._issue_side(ev, jobs)
+        if held is not None:
+            self._issue_side(*held)
+
+    def _issue_side(self, ev, jobs):
+        check(self.lib.mtl_stream_wait_event(self.side.cuda_stream, ev), 'mtl_stream_wait_event')
         with torch.cuda.stream(self.side):
             self.on_side = True
             try:
@@ -415,6 +432,9 @@ class PassEngine:
     def join_side(self):
         self.flush_wgrads()
         self.flush_side()
+        if self._held is not None:
+            held, self._held = self._held, None
+            self._issue_side(*held)
         if self.use_side_stream:
             ev = self._event()
             check(self.lib.mtl_event_record(ev, self.side.cuda_stream), 'mtl_event_record')
@@ -663,7 +683,7 @@ class PassEngine:
             else:
                 self.gemm(0, 0, rows, d, r, da_ptr, r, o(f0 + '_linear_a.weight'), d, dst, d, flags=ACCUM if accum else 0,
                           kbatch=n, sAk=rows * r, sBk=sa)
-        self.flush_side()
+        self.flush_side(0)
 
     # ---- encoder-decoder attention: K / V projections of all decoder layers in one go
     def _cross_kv_plan(self, Mk):
@@ -724,7 +744,7 @@ class PassEngine:
         for pj, name in enumerate(('key', 'value')):      # dmem (=|+=) sum_l da[l, pj] . W_a[l, pj]
             self.gemm(0, 0, Mk, d, r, da_ptr + 4 * pj * Mk * r, r, o0(name + '_linear_a.weight'), d, dmem, d, flags=ACCUM if pj else 0,
                       kbatch=NL, sAk=2 * Mk * r, sBk=Ls)
-        self.flush_side()
+        self.flush_side(0)
 
     def _pstride(self, pre, names, suffix):
         """Distance (floats) between consecutive projections' parameters `suffix` in the flat buffer (0 for a single one)."""
@@ -780,7 +800,7 @@ class PassEngine:
                         None, dh1.data_ptr(), False, gate=h1.data_ptr())
         self.linear_bwd(x, dh1.data_ptr(), rows, hp.d, hp.inner, o('linear_1.weight'), g('linear_1.weight'),
                         g('linear_1.bias'), dx, True)
-        self.flush_side()
+        self.flush_side(0)
 
     # ---------------------------------------------------------------- the pass
     def prepare(self, lengths, target, B, T, slot=0, norm_count=None, width=None):
@@ -1123,8 +1143,10 @@ class PassEngine:
             self.mha_bwd('d%d.sa.' % i, P, G, pre + 'self_attn.', dcur.data_ptr(), x_in.data_ptr(), B, Td, x_in.data_ptr(), Td,
                          keep_dec, dnext.data_ptr(), dnext.data_ptr(), True)
             dcur, dnext = dnext, dcur
+            self.flush_side(1)
         if hoisted:
             self.cross_kv_bwd(P, G, mem_ptr, Me, dmem.data_ptr())
+        self.flush_side(2)
         me = A.get('dec_in.me')
         check(lib.mtl_embed_bwd(st, S['meta']['ids'].data_ptr(), S['meta']['embed_first'], S['meta']['embed_next'], dcur.data_ptr(),
                                 g('decoder.trg_embedding.weight'), Md, d, PAD_ID, me.data_ptr() if me is not None else None,
@@ -1142,6 +1164,7 @@ class PassEngine:
             self.mha_bwd('e%d.sa.' % i, P, G, pre + 'self_attn.', dcur.data_ptr(), x_in.data_ptr(), B, T4, x_in.data_ptr(), T4,
                          keep_enc, dnext.data_ptr(), dnext.data_ptr(), True)
             dcur, dnext = dnext, dcur
+            self.flush_side(1)
         # input LayerNorm (+PE: no grad) and input_linear
         de0 = dnext
         self.ln_bwd(dcur.data_ptr(), A['enc_in.xhat'].data_ptr(), A['enc_in.rstd'].data_ptr(), o('encoder.layer_norm_input.weight'),
@@ -1165,6 +1188,7 @@ class PassEngine:
                       gate=p2.data_ptr(), ldg=hp.d_in)
 
         self.flush_wgrads()        # every small dW of the transformer half: one grouped launch, overlapping the VGG backward
+        self.flush_side(2)
         # ---- VGG front-end ----
         h2 = self.conv_h2
         amax = A['amax']
