@@ -127,7 +127,50 @@ __global__ void dropout_mask_kernel(uint8_t* __restrict__ keep, long n, unsigned
 }
 
 // ------------------------------------------------------------------ LayerNorm (+residual, +positional table, *row keep)
-// one wave per row; d is a multiple of 64 up to 1024 (NPL = d/64 values per lane, lane-strided so loads coalesce)
+// one wave per row; d is a multiple of 64 up to 1024 (NPL = d/64 values per lane).  For d % 256 == 0 a lane owns NPL/4 quads of four
+// consecutive columns (quad j of lane l = columns 4 (64 j + l) ..): every row access is a 16-byte load / store (these launches
+// are latency-bound -- 8 dword loads per operand and lane cost more issue slots and address registers than 2 dwordx4); otherwise
+// lane-strided single columns.
+template <int NPL>
+struct LnRow {
+    static constexpr bool V4 = NPL % 4 == 0;
+    static __device__ __forceinline__ int col(int i, int lane) { return V4 ? ((i >> 2) * 64 + lane) * 4 + (i & 3) : i * 64 + lane; }
+    static __device__ __forceinline__ void load(const float* __restrict__ p, int lane, float (&v)[NPL]) {
+        if (V4) {
+#pragma unroll
+            for (int j = 0; j < NPL / 4; ++j) {
+                const float4 t = *reinterpret_cast<const float4*>(p + (j * 64 + lane) * 4);
+                v[4 * j] = t.x, v[4 * j + 1] = t.y, v[4 * j + 2] = t.z, v[4 * j + 3] = t.w;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NPL; ++i) v[i] = p[i * 64 + lane];
+        }
+    }
+    static __device__ __forceinline__ void load_mask(const uint8_t* __restrict__ p, int lane, bool (&m)[NPL]) {
+        if (V4) {
+#pragma unroll
+            for (int j = 0; j < NPL / 4; ++j) {
+                const unsigned t = *reinterpret_cast<const unsigned*>(p + (j * 64 + lane) * 4);
+                m[4 * j] = (t & 0xffu) != 0, m[4 * j + 1] = (t & 0xff00u) != 0, m[4 * j + 2] = (t & 0xff0000u) != 0, m[4 * j + 3] = (t >> 24) != 0;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NPL; ++i) m[i] = p[i * 64 + lane] != 0;
+        }
+    }
+    static __device__ __forceinline__ void store(float* __restrict__ p, int lane, const float (&v)[NPL]) {
+        if (V4) {
+#pragma unroll
+            for (int j = 0; j < NPL / 4; ++j)
+                *reinterpret_cast<float4*>(p + (j * 64 + lane) * 4) = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NPL; ++i) p[i * 64 + lane] = v[i];
+        }
+    }
+};
+
 template <int NPL>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -136,17 +179,26 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
                                                             float* __restrict__ y, float* __restrict__ xhat,
                                                             float* __restrict__ rstd, int rows, int T, float eps) {
     constexpr int D = NPL * 64;
+    using IO = LnRow<NPL>;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    float v[NPL];
+    float v[NPL], rv[NPL], gm[NPL], bt[NPL], pv[NPL];
+    bool mk[NPL];
+    // every load of the row is issued before the first reduction
+    IO::load(x + (long)row * D, lane, v);
+    if (res) IO::load(res + (long)row * D, lane, rv);
+    if (xmask) IO::load_mask(xmask + (long)row * D, lane, mk);
+    IO::load(gamma, lane, gm);
+    IO::load(beta, lane, bt);
+    if (pe) IO::load(pe + (long)(row % T) * D, lane, pv);
+    const float kp = keep ? (float)keep[row] : 1.f;
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NPL; ++i) {
-        const int c = i * 64 + lane;
-        float t = x[(long)row * D + c];
-        if (xmask) t = xmask[(long)row * D + c] ? t * xscale : 0.f;      // dropout on the sub-layer output, before the residual
-        if (res) t += res[(long)row * D + c];
+        float t = v[i];
+        if (xmask) t = mk[i] ? t * xscale : 0.f;      // dropout on the sub-layer output, before the residual
+        if (res) t += rv[i];
         v[i] = t;
         s += t;
     }
@@ -158,17 +210,16 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
         q += dlt * dlt;
     }
     const float rs = 1.f / sqrtf(wave_sum(q) * (1.f / D) + eps);
-    const float kp = keep ? (float)keep[row] : 1.f;
-    const float* per = pe ? pe + (long)(row % T) * D : nullptr;
+    float h[NPL], o[NPL];
 #pragma unroll
     for (int i = 0; i < NPL; ++i) {
-        const int c = i * 64 + lane;
-        const float h = (v[i] - mean) * rs;
-        xhat[(long)row * D + c] = h;
-        float o = h * gamma[c] + beta[c];
-        if (per) o += per[c];
-        y[(long)row * D + c] = o * kp;
+        h[i] = (v[i] - mean) * rs;
+        float t = h[i] * gm[i] + bt[i];
+        if (pe) t += pv[i];
+        o[i] = t * kp;
     }
+    IO::store(xhat + (long)row * D, lane, h);
+    IO::store(y + (long)row * D, lane, o);
     if (lane == 0) rstd[row] = rs;
 }
 
@@ -181,6 +232,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             float* __restrict__ dz2, float* __restrict__ part, int rows,
                                                             int rows_per_wave) {
     constexpr int D = NPL * 64;
+    using IO = LnRow<NPL>;
     const int lane = threadIdx.x & 63;
     const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
     float ag[NPL], ab[NPL], az[NPL], gm[NPL];
@@ -189,8 +241,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         ag[i] = 0.f;
         ab[i] = 0.f;
         az[i] = 0.f;
-        gm[i] = gamma[i * 64 + lane];
     }
+    IO::load(gamma, lane, gm);
     // RB rows at a time with every load of the group issued before the first reduction: the wave pays the HBM latency once per
     // group instead of once per row (it was latency-bound: 22 us for 12 MB)
     constexpr int RB = 4;
@@ -198,16 +250,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     const int rend = min(r0 + rows_per_wave, rows);
     for (int rb = r0; rb < rend; rb += RB) {
         float dv[RB][NPL], hv[RB][NPL], kp[RB], rs[RB];
+        bool mk[RB][NPL];
 #pragma unroll
         for (int q = 0; q < RB; ++q) {
             const int row = min(rb + q, rows - 1);
             kp[q] = (rb + q < rend) ? (keep ? (float)keep[row] : 1.f) : 0.f;
             rs[q] = rstd[row];
-#pragma unroll
-            for (int i = 0; i < NPL; ++i) {
-                dv[q][i] = dy[(long)row * D + i * 64 + lane];
-                hv[q][i] = xhat[(long)row * D + i * 64 + lane];
-            }
+            IO::load(dy + (long)row * D, lane, dv[q]);
+            IO::load(xhat + (long)row * D, lane, hv[q]);
+            if (xmask) IO::load_mask(xmask + (long)row * D, lane, mk[q]);
         }
 #pragma unroll
         for (int q = 0; q < RB; ++q) {
@@ -226,26 +277,22 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
             }
             s1 = wave_sum(s1) * (1.f / D);
             s2 = wave_sum(s2) * (1.f / D);
+            float o[NPL], om[NPL];
 #pragma unroll
             for (int i = 0; i < NPL; ++i) {
-                const float o = rs[q] * (g[i] - s1 - hv[q][i] * s2);
-                dz[(long)row * D + i * 64 + lane] = o;
-                if (dz2) dz2[(long)row * D + i * 64 + lane] = o;      // second copy: the residual path starts from dz
-                float om = o;
-                if (xmask) {                               // gradient of the dropped sub-layer branch (residual branch gets dz)
-                    om = xmask[(long)row * D + i * 64 + lane] ? o * xscale : 0.f;
-                    dzm[(long)row * D + i * 64 + lane] = om;
-                }
-                az[i] += om;
+                o[i] = rs[q] * (g[i] - s1 - hv[q][i] * s2);
+                om[i] = o[i];
+                if (xmask) om[i] = mk[q][i] ? o[i] * xscale : 0.f;      // gradient of the dropped sub-layer branch (residual branch gets dz)
+                az[i] += om[i];
             }
+            IO::store(dz + (long)row * D, lane, o);
+            if (dz2) IO::store(dz2 + (long)row * D, lane, o);          // second copy: the residual path starts from dz
+            if (xmask) IO::store(dzm + (long)row * D, lane, om);
         }
     }
-#pragma unroll
-    for (int i = 0; i < NPL; ++i) {
-        part[((long)gw * 3) * D + i * 64 + lane] = ag[i];
-        part[((long)gw * 3 + 1) * D + i * 64 + lane] = ab[i];
-        part[((long)gw * 3 + 2) * D + i * 64 + lane] = az[i];
-    }
+    IO::store(part + ((long)gw * 3) * D, lane, ag);
+    IO::store(part + ((long)gw * 3 + 1) * D, lane, ab);
+    IO::store(part + ((long)gw * 3 + 2) * D, lane, az);
 }
 // out[which][c] += sum_w part[w][which][c]  for which = gamma, beta, colsum(dz); one block per (which, 64 columns),
 // 4 waves stride the partial rows and combine through LDS in a fixed order
