@@ -17,6 +17,8 @@ import os
 
 import torch
 
+import re
+
 from . import _lib
 from ._lib import check
 
@@ -192,6 +194,9 @@ class _DecodeSession:
             c[:, :t] = c.index_select(0, idx)[:, :t]
 
 
+_LAYER_BUF = re.compile(r'^([de])(\d+)\.(.+)$')
+
+
 class PassEngine:
     def __init__(self, layout, hp, device, pe_enc, pe_dec):
         self.pe_enc, self.pe_dec = pe_enc, pe_dec   # (max_len, d) fp32 device tables (non-trainable buffers)
@@ -222,6 +227,9 @@ class PassEngine:
         self.after_conv_hook = None
         self.forward_hook = None      # optional callable(engine) after every forward has been enqueued (tests capture the arena)
         self.deferred = []
+        self._wlog = {}
+        # weight gradients of all layers of a stack as one strided-batch launch per parameter kind (flush_layer_wgrads)
+        self.layer_wgrads = os.environ.get('MTL_LAYER_WGRADS', '1') != '0'
         self.use_side_stream = True
         self.flush_level = int(os.environ.get('MTL_FLUSH_LEVEL', '0'))      # see flush_side
         self.flush_delay = os.environ.get('MTL_FLUSH_DELAY', '0') == '1'
@@ -256,7 +264,26 @@ class PassEngine:
 
     # ---------------------------------------------------------------- plumbing
     def buf(self, name, shape, dtype=torch.float32):
-        key = (name, tuple(int(v) for v in shape), dtype)
+        """Named buffer of the current pass.  Per-layer buffers ('d<i>.<what>', 'e<i>.<what>') are slices of ONE allocation per
+        <what> with the layers at a constant stride -- 'dec_in.y' / 'enc_in.y' are slot 0 of the '<x>.ff.y' group, so that every
+        layer's INPUT is at that stride too -- which lets the weight-gradient products of all layers of a stack run as one
+        strided-batch launch (flush_layer_wgrads)."""
+        shape = tuple(int(v) for v in shape)
+        m = _LAYER_BUF.match(name)
+        if m or name in ('dec_in.y', 'enc_in.y'):
+            kind, idx, rest = (m.group(1), int(m.group(2)), m.group(3)) if m else (name[0], -1, 'ff.y')
+            n = (self.hp.n_dec if kind == 'd' else self.hp.n_enc) + (1 if rest == 'ff.y' else 0)
+            slot = idx + 1 if rest == 'ff.y' else idx
+            if 0 <= slot < n:
+                key = (kind + '*.' + rest, (n,) + shape, dtype)
+                grp = self.pool.get(key)
+                if grp is None:
+                    grp = torch.empty(key[1], dtype=dtype, device=self.device)
+                    self.pool[key] = grp
+                t = grp[slot]
+                self.arena[name] = t
+                return t
+        key = (name, shape, dtype)
         t = self.pool.get(key)
         if t is None:
             t = torch.empty(key[1], dtype=dtype, device=self.device)
@@ -356,9 +383,14 @@ class PassEngine:
         return dev.data_ptr()
 
     # ---- grouped weight gradients
-    def wgrad(self, dy, x, rows, n_out, k_in, dw, db=None):
-        """dw (n_out x k_in) += dy^T x ; db += colsum(dy).  Small products are only REGISTERED here and computed by one grouped launch
-        (flush_wgrads); the few large ones (vocabulary projection, FFN at encoder size ...) go to the side stream as single calls."""
+    def wgrad(self, dy, x, rows, n_out, k_in, dw, db=None, kind=None):
+        """dw (n_out x k_in) += dy^T x ; db += colsum(dy).  With `kind` (the parameter's name without its layer index) the product is
+        only LOGGED: flush_layer_wgrads() issues the products of all layers of a stack as one strided-batch launch per kind.
+        Otherwise: MTL_GROUP_WGRADS registers small products for one grouped launch (flush_wgrads); the rest goes to the side stream
+        as single calls."""
+        if kind is not None and self.layer_wgrads:
+            self.wgrad_job(kind, n_out, k_in, rows, dy, n_out, x, k_in, dw, k_in, rowsum=db)
+            return
         if self.group_wgrads and self.lib.mtl_gemm_f32_ex_route(n_out, k_in, rows, 1, 1, 1 if db else 0):
             self.wgrads.append((int(dy), int(x), int(dw), int(db or 0), n_out, k_in, rows, n_out, k_in, k_in))
         else:
@@ -389,6 +421,37 @@ class PassEngine:
         def launch():
             check(self.lib.mtl_gemm_wgrad_grouped(self.stream, table.data_ptr(), len(descs), tiles), 'mtl_gemm_wgrad_grouped')
         self.defer(launch)
+        self.flush_side()
+
+    def wgrad_job(self, kind, M, N, K, A, lda, B, ldb, C, ldc, n=1, sA=0, sB=0, sC=0, rowsum=None, srow=0):
+        """log C_z (M x N) += A_z^T B_z (z < n, strides in floats), rowsum_z += row sums of A_z^T"""
+        self._wlog.setdefault((kind, M, N, K, lda, ldb, ldc, n, sA, sB, sC, srow, rowsum is not None), []).append(
+            (int(C), int(A), int(B), int(rowsum or 0)))
+
+    def flush_layer_wgrads(self):
+        """Issue the logged weight-gradient products on the side stream.  The entries of a kind differ only in their four pointers;
+        when those advance by constant strides from layer to layer (they do: per-layer buffers and the parameters of a stack sit at
+        constant strides) the whole kind is ONE launch with the layer as outer batch index -- 4 x the workgroups of a single layer's
+        product (64 tiles: a quarter of the chip), a quarter of the launches and no fork per sub-layer block."""
+        log, self._wlog = self._wlog, {}
+        for (kind, M, N, K, lda, ldb, ldc, n, sA, sB, sC, srow, has_rs), items in log.items():
+            items.sort()
+            nl = len(items)
+            steps = [tuple(b[j] - a[j] for j in range(4)) for a, b in zip(items, items[1:])]
+            merged = nl > 1 and all(st == steps[0] for st in steps) and all(v % 16 == 0 for v in steps[0])
+            if merged:
+                dC, dA, dB, dR = (v // 4 for v in steps[0])
+                C0, A0, B0, R0 = items[0]
+                self.defer(lambda M=M, N=N, K=K, A0=A0, lda=lda, B0=B0, ldb=ldb, C0=C0, ldc=ldc, nl=nl, n=n, dA=dA, sA=sA, dB=dB, sB=sB,
+                           dC=dC, sC=sC, R0=R0, dR=dR, srow=srow, has_rs=has_rs: self.gemm(
+                    1, 0, M, N, K, A0, lda, B0, ldb, C0, ldc, flags=ACCUM, batch=nl * n, H=n, sA=(dA, sA), sB=(dB, sB), sC=(dC, sC),
+                    rowsum=R0 if has_rs else None, srow=dR, srow_h=srow))
+            else:
+                for C0, A0, B0, R0 in items:
+                    self.defer(lambda M=M, N=N, K=K, A0=A0, lda=lda, B0=B0, ldb=ldb, C0=C0, ldc=ldc, n=n, sA=sA, sB=sB, sC=sC, R0=R0,
+                               srow=srow, has_rs=has_rs: self.gemm(
+                        1, 0, M, N, K, A0, lda, B0, ldb, C0, ldc, flags=ACCUM, batch=n, sA=(sA, 0), sB=(sB, 0), sC=(sC, 0),
+                        rowsum=R0 if has_rs else None, srow=srow))
         self.flush_side()
 
     # ---- side stream: deferred parameter-gradient work
@@ -443,10 +506,10 @@ class PassEngine:
     def linear_fwd(self, x, rows, k_in, w, b, y, n_out, relu=False):
         self.gemm(0, 1, rows, n_out, k_in, x, k_in, w, k_in, y, n_out, bias=b, flags=RELU if relu else 0)
 
-    def linear_bwd(self, x, dy, rows, k_in, n_out, w, dw, db, dx, dx_accum, gate=None):
+    def linear_bwd(self, x, dy, rows, k_in, n_out, w, dw, db, dx, dx_accum, gate=None, kind=None):
         """dw += dy^T x ; db += colsum(dy) (db None: no bias, or already produced by the LayerNorm backward) ;
         dx (=|+=) dy.W  (gate: ReLU mask source for dx)"""
-        self.wgrad(dy, x, rows, n_out, k_in, dw, db)     # db rides on the weight-gradient product (row sums of dy^T)
+        self.wgrad(dy, x, rows, n_out, k_in, dw, db, kind=kind)     # db rides on the weight-gradient product (row sums of dy^T)
         if dx is not None:
             self.gemm(0, 0, rows, k_in, n_out, dy, n_out, w, k_in, dx, k_in, gate=gate, ldg=k_in,
                       flags=ACCUM if dx_accum else 0)
@@ -582,6 +645,7 @@ class PassEngine:
         g = lambda n: G + 4 * L.off(pre + n)
         ldS = (Tk + 3) // 4 * 4
         O, oa = A[tag + 'O'], A[tag + 'oa']
+        kd = _LAYER_BUF.sub(r'\1*.\3', tag)              # 'd3.sa.' -> 'd*.sa.': the kind prefix of this block's weight gradients
         # LayerNorm(o + residual) * keep
         dzb = self.buf(tag + '_dz', (Mq, d))       # kept intact for the deferred dW GEMM; dxq = dz + projections
         mo, mP = A.get(tag + 'mo'), A.get(tag + 'mP')
@@ -594,16 +658,16 @@ class PassEngine:
         dO = self.buf(tag + '_dO', (Mq, hv))
         if self.pair_ok(d, hv):
             wt = lambda n: self._wT + 4 * L.off(pre + n)
-            self.wgrad(dz, oa.data_ptr(), Mq, d, r, g('output_linear_b.weight'))
+            self.wgrad(dz, oa.data_ptr(), Mq, d, r, g('output_linear_b.weight'), kind=kd + 'ob')
             # dO = (dz . W_ob) . W_oa  through the transposed copies; doa is stored for the weight gradient of the a-stage
             self.pair(dz, 0, d, wt('output_linear_b.weight'), 0, wt('output_linear_a.weight'), 0, None, 0, doa.data_ptr(), 0,
                       dO.data_ptr(), 0, hv, Mq, d, hv, 1)
-            self.wgrad(doa.data_ptr(), O.data_ptr(), Mq, r, hv, g('output_linear_a.weight'))
+            self.wgrad(doa.data_ptr(), O.data_ptr(), Mq, r, hv, g('output_linear_a.weight'), kind=kd + 'oa')
         else:
             self.linear_bwd(oa.data_ptr(), dz, Mq, r, d, o('output_linear_b.weight'), g('output_linear_b.weight'),
-                            None, doa.data_ptr(), False)
+                            None, doa.data_ptr(), False, kind=kd + 'ob')
             self.linear_bwd(O.data_ptr(), doa.data_ptr(), Mq, hv, r, o('output_linear_a.weight'), g('output_linear_a.weight'),
-                            None, dO.data_ptr(), False)
+                            None, dO.data_ptr(), False, kind=kd + 'oa')
         q, k, v = A[tag + 'q'], A[tag + 'k'], A[tag + 'v']
         groups = A[tag + 'groups']
         dfull = {}                                       # gradients of the projected q / k / v, grouped like the forward
@@ -654,6 +718,9 @@ class PassEngine:
                 for i, nm in enumerate(names):
                     self.wgrad(d_ptr + 4 * i * rows * wd, a_ptr + 4 * i * rows * r, rows, wd, r, g(_FULL[nm] + '_linear_b.weight'),
                                g(_FULL[nm] + '_linear_b.bias'))
+            elif self.layer_wgrads and not (dkv_hoisted is not None and names == 'kv'):
+                self.wgrad_job(kd + names + '.b', wd, r, rows, d_ptr, wd, a_ptr, r, g(f0 + '_linear_b.weight'), r, n=n, sA=rows * wd,
+                               sB=rows * r, sC=sb, rowsum=g(f0 + '_linear_b.bias'), srow=sbias)
             else:       # one strided-batch call on the side stream (outputs strided into G)
                 self.defer(lambda n=n, f0=f0, rows=rows, a_ptr=a_ptr, d_ptr=d_ptr, sb=sb, sbias=sbias, wd=wd: self.gemm(
                     1, 0, wd, r, rows, d_ptr, wd, a_ptr, r, g(f0 + '_linear_b.weight'), r, flags=ACCUM, batch=n, sA=(rows * wd, 0),
@@ -667,6 +734,9 @@ class PassEngine:
             if self.group_wgrads:
                 for i, nm in enumerate(names):
                     self.wgrad(da_ptr + 4 * i * rows * r, src, rows, r, d, g(_FULL[nm] + '_linear_a.weight'))
+            elif self.layer_wgrads:
+                self.wgrad_job(kd + names + '.a', r, d, rows, da_ptr, r, src, d, g(f0 + '_linear_a.weight'), d, n=n, sA=rows * r, sB=0,
+                               sC=sa)
             else:
                 self.defer(lambda n=n, f0=f0, rows=rows, da_ptr=da_ptr, src=src, sa=sa: self.gemm(
                     1, 0, r, d, rows, da_ptr, r, src, d, g(f0 + '_linear_a.weight'), d, flags=ACCUM, batch=n, sA=(rows * r, 0), sC=(sa, 0)))
@@ -796,10 +866,11 @@ class PassEngine:
         dbr = dzm.data_ptr() if dzm is not None else dzb.data_ptr()
         h1 = A[tag + 'h1']
         dh1 = self.buf(tag + '_dh1', (rows, hp.inner))
+        kd = _LAYER_BUF.sub(r'\1*.\3', tag)
         self.linear_bwd(h1.data_ptr(), dbr, rows, hp.inner, hp.d, o('linear_2.weight'), g('linear_2.weight'),
-                        None, dh1.data_ptr(), False, gate=h1.data_ptr())
+                        None, dh1.data_ptr(), False, gate=h1.data_ptr(), kind=kd + 'w2')
         self.linear_bwd(x, dh1.data_ptr(), rows, hp.d, hp.inner, o('linear_1.weight'), g('linear_1.weight'),
-                        g('linear_1.bias'), dx, True)
+                        g('linear_1.bias'), dx, True, kind=kd + 'w1')
         self.flush_side(0)
 
     # ---------------------------------------------------------------- the pass
@@ -1146,6 +1217,7 @@ class PassEngine:
             self.flush_side(1)
         if hoisted:
             self.cross_kv_bwd(P, G, mem_ptr, Me, dmem.data_ptr())
+        self.flush_layer_wgrads()       # the decoder stack's weight gradients: one launch per parameter kind
         self.flush_side(2)
         me = A.get('dec_in.me')
         check(lib.mtl_embed_bwd(st, S['meta']['ids'].data_ptr(), S['meta']['embed_first'], S['meta']['embed_next'], dcur.data_ptr(),
@@ -1170,6 +1242,7 @@ class PassEngine:
         self.ln_bwd(dcur.data_ptr(), A['enc_in.xhat'].data_ptr(), A['enc_in.rstd'].data_ptr(), o('encoder.layer_norm_input.weight'),
                     None, de0.data_ptr(), g('encoder.layer_norm_input.weight'), g('encoder.layer_norm_input.bias'), Me,
                     dsum=g('encoder.input_linear.bias'))
+        self.flush_layer_wgrads()       # the encoder stack's weight gradients
         self.flush_ln_reduce()     # the parameter / bias gradients of all 17 LayerNorms of the pass: one launch
         p2, y5, p1, y1 = A['p2'], A['y5'], A['p1'], A['y1']
         dwp = self.buf('_dwp', (d, hp.d_in))
