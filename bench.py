@@ -159,7 +159,7 @@ def classify(lib, name, a, conv_mode, wgrad_x3_dense):
         causal, B, H, Tq, Tk, dk = a[8], a[10], a[11], a[12], a[13], a[14]
         prods = 2 if name == 'mtl_attn_fwd' else 7            # backward recomputes S: 2 x QK^T, dP, dV, dQ, dK (+ the second S)
         return (name[4:], prods * 2.0 * B * H * Tq * Tk * dk * (0.5 if causal else 1.0), 'flop',
-                'attn_fwd_kernel' if prods == 2 else 'attn_bwd_q_kernel + attn_bwd_kv_kernel')
+                'attn_fwd_kernel' if prods == 2 else 'attn_bwd_kernel (key side + query side in one grid)')
     if name == 'mtl_layernorm_fwd':
         rows, d = a[12], a[13]
         return 'layernorm_fwd', 4.0 * rows * d * (4 if a[2] else 3), 'byte', 'layernorm_fwd_kernel'

@@ -287,13 +287,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
 // ------------------------------------------------------------------ backward, query side: dQ (and delta = rowsum(dO * O))
 // dS = P * (dP - delta) * scale with P = exp(S * scale - lse) recomputed, dP = (dO . V^T) [* mask * pscale];  dQ = dS . K
 template <int DK, int DV>
-__global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnP p) {
-    __shared__ __attribute__((aligned(16))) float Ks[AT_TILE * (DK + 4)];
-    __shared__ __attribute__((aligned(16))) float Vs[AT_TILE * (DV + 4)];
-    __shared__ __attribute__((aligned(16))) float Ps[4 * 16 * AT_LDP];
+__device__ __forceinline__ void attn_bwd_q_role(const AttnP& p, int qblk, float* Ks, float* Vs, float* Ps) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l16 = lane & 15, g = lane >> 4;
     const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
-    const int q0 = blockIdx.x * AT_ROWS;
+    const int q0 = qblk * AT_ROWS;
     const int klim = p.klen ? min(p.klen[b], p.Tk) : p.Tk;
     int kmax = klim;
     if (p.causal) kmax = min(kmax, min(q0 + AT_ROWS, p.Tq));
@@ -384,18 +381,32 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnP p) {
     }
 }
 
+// sum over the VPR consecutive lanes that hold one tile row (16 for D = 64: a DPP row; 4 for D = 16: a quad)
+template <int VPR>
+__device__ __forceinline__ float tile_row_sum(float v) {
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    if (VPR == 16) {
+        v += dpp_mov<0x141>(v);
+        v += dpp_mov<0x140>(v);
+    }
+    return v;
+}
+
 // ------------------------------------------------------------------ backward, key side: dK = dS^T . Q, dV = Pd^T . dO
 // one workgroup owns 64 keys (16 per wave) and streams 64-query tiles of Q and dO; everything is computed transposed
-// (keys are the MFMA rows), so the per-query statistics lse / delta are per-COLUMN values here
-template <int DK, int DV>
-__global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnP p) {
-    __shared__ __attribute__((aligned(16))) float Qs[AT_TILE * (DK + 4)];
-    __shared__ __attribute__((aligned(16))) float Ds[AT_TILE * (DV + 4)];
-    __shared__ __attribute__((aligned(16))) float Ps[4 * 16 * AT_LDP];
-    __shared__ float lse_s[AT_TILE], dl_s[AT_TILE];
+// (keys are the MFMA rows), so the per-query statistics lse / delta are per-COLUMN values here.  delta = rowsum(dO * O) of a
+// query tile is computed HERE from the dO tile on its way to LDS and an O tile fetched beside it (one dot product of two float4
+// and four DPP adds per thread and row group): the key side does not depend on the query side's output, so both sides are ONE
+// launch (attn_bwd_kernel) whose workgroups run concurrently instead of two dependent launches of 128-256 workgroups each.
+// OWN_DELTA = false: delta is read from p.delta (written by a query-side launch that ran BEFORE this one): long sequences, where
+// the chip is full either way and the extra O tile only costs (T = 5000: 932 vs 1020 us).
+template <int DK, int DV, bool OWN_DELTA>
+__device__ __forceinline__ void attn_bwd_kv_role(const AttnP& p, int kblk, float* Qs, float* Ds, float* Ps, float* lse_s, float* dl_s) {
+    static_assert(Tile<DV>::VPR == 16 || Tile<DV>::VPR == 4, "tile_row_sum covers 16- and 4-lane rows");
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l16 = lane & 15, g = lane >> 4;
     const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
-    const int k0 = blockIdx.x * AT_ROWS;
+    const int k0 = kblk * AT_ROWS;
     const int klim = p.klen ? min(p.klen[b], p.Tk) : p.Tk;
     f32x4 dk[DK / 16], dv[DV / 16];
 #pragma unroll
@@ -411,20 +422,22 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnP p) {
         load_frag<DV>(vf, p.v + ((long)b * p.Tk + krow) * p.ldv + h * DV, g);
         const float* qbase = p.q + (long)b * p.Tq * p.ldq + h * DK;
         const float* dobase = p.dO + (long)b * p.Tq * p.ldo + h * DV;
+        const float* obase = p.Oc + (long)b * p.Tq * p.ldo + h * DV;
         float* Pw = Ps + w * 16 * AT_LDP;
         Tile<DK> rq;
-        Tile<DV> rd;
+        Tile<DV> rd, ro;
         float r_lse = 0.f, r_dl = 0.f;
         auto fetch_stats = [&](int qt) {
             if (tid < AT_TILE) {
                 const int qi = min(qt * AT_TILE + tid, p.Tq - 1);
                 r_lse = p.lse[(long)bh * p.Tq + qi];
-                r_dl = p.delta[(long)bh * p.Tq + qi];
+                if (!OWN_DELTA) r_dl = p.delta[(long)bh * p.Tq + qi];
             }
         };
         if (qt0 < nqt) {
             rq.fetch(qbase, p.ldq, qt0 * AT_TILE, p.Tq, tid);
             rd.fetch(dobase, p.ldo, qt0 * AT_TILE, p.Tq, tid);
+            if (OWN_DELTA) ro.fetch(obase, p.ldo, qt0 * AT_TILE, p.Tq, tid);
             fetch_stats(qt0);
         }
         for (int qt = qt0; qt < nqt; ++qt) {
@@ -432,12 +445,21 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnP p) {
             rd.commit(Ds, tid);
             if (tid < AT_TILE) {
                 lse_s[tid] = r_lse;
-                dl_s[tid] = r_dl;
+                if (!OWN_DELTA) dl_s[tid] = r_dl;
+            }
+            if (OWN_DELTA) {
+#pragma unroll
+                for (int i = 0; i < Tile<DV>::NV; ++i) {   // delta of tile row tid / VPR + i RPP (rows past Tq were fetched as zeros)
+                    float part = rd.v[i].x * ro.v[i].x + rd.v[i].y * ro.v[i].y + rd.v[i].z * ro.v[i].z + rd.v[i].w * ro.v[i].w;
+                    part = tile_row_sum<Tile<DV>::VPR>(part);
+                    if (tid % Tile<DV>::VPR == 0) dl_s[tid / Tile<DV>::VPR + i * Tile<DV>::RPP] = part;
+                }
             }
             __syncthreads();
             if (qt + 1 < nqt) {
                 rq.fetch(qbase, p.ldq, (qt + 1) * AT_TILE, p.Tq, tid);
                 rd.fetch(dobase, p.ldo, (qt + 1) * AT_TILE, p.Tq, tid);
+                if (OWN_DELTA) ro.fetch(obase, p.ldo, (qt + 1) * AT_TILE, p.Tq, tid);
                 fetch_stats(qt + 1);
             }
             unsigned keepbits = 0xffffu;
@@ -501,6 +523,37 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnP p) {
     }
 }
 
+// ROLES 3: both sides in one grid -- blockIdx.x < nkb -> key side of key block blockIdx.x (the longer role goes first), else query
+// side; ROLES 1 / 2: the query side / the key side (delta from p.delta) alone, for the two-launch form of long sequences
+template <int DK, int DV, int ROLES>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(AttnP p, int nkb) {
+    __shared__ __attribute__((aligned(16))) float As[AT_TILE * (DK + 4)];
+    __shared__ __attribute__((aligned(16))) float Bs[AT_TILE * (DV + 4)];
+    __shared__ __attribute__((aligned(16))) float Ps[4 * 16 * AT_LDP];
+    __shared__ float lse_s[AT_TILE], dl_s[AT_TILE];
+    if (ROLES == 3) {
+        if ((int)blockIdx.x < nkb)
+            attn_bwd_kv_role<DK, DV, true>(p, blockIdx.x, As, Bs, Ps, lse_s, dl_s);
+        else
+            attn_bwd_q_role<DK, DV>(p, blockIdx.x - nkb, As, Bs, Ps);
+    } else if (ROLES == 1) {
+        attn_bwd_q_role<DK, DV>(p, blockIdx.x, As, Bs, Ps);
+    } else {
+        attn_bwd_kv_role<DK, DV, false>(p, blockIdx.x, As, Bs, Ps, lse_s, dl_s);
+    }
+}
+
+template <int DK, int DV>
+void launch_attn_bwd(const AttnP& p, int nqb, int nkb, hipStream_t s) {
+    const int bh = p.B * p.H;
+    if ((long)(nqb + nkb) * bh <= 1024) {      // the two sides together are at most a few workgroups per CU: one launch
+        hipLaunchKernelGGL((attn_bwd_kernel<DK, DV, 3>), dim3(nqb + nkb, bh), dim3(256), 0, s, p, nkb);
+    } else {
+        hipLaunchKernelGGL((attn_bwd_kernel<DK, DV, 1>), dim3(nqb, bh), dim3(256), 0, s, p, 0);
+        hipLaunchKernelGGL((attn_bwd_kernel<DK, DV, 2>), dim3(nkb, bh), dim3(256), 0, s, p, nkb);
+    }
+}
+
 inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
 bool attn_args_ok(const AttnP& p, int dk, int dv) {
@@ -544,15 +597,13 @@ int mtl_attn_bwd(void* stream, const float* q, const float* k, const float* v, i
     p.lse = const_cast<float*>(lse), p.delta = delta, p.dq = dq, p.dk = dk_, p.dv = dv_, p.lddq = lddq, p.lddk = lddk, p.lddv = lddv;
     if (!attn_args_ok(p, dk, dv) || !O || !dO || !lse || !delta || !dq || !dk_ || !dv_) return MTL_EINVAL;
     if (!al16(dO) || (ldo & 3) || ldo < H * dv || lddq < H * dk || lddk < H * dk || lddv < H * dv) return MTL_EINVAL;
-    dim3 gq((Tq + AT_ROWS - 1) / AT_ROWS, B * H), gk((Tk + AT_ROWS - 1) / AT_ROWS, B * H);
+    if (!al16(O)) return MTL_EINVAL;
+    const int nqb = (Tq + AT_ROWS - 1) / AT_ROWS, nkb = (Tk + AT_ROWS - 1) / AT_ROWS;
     hipStream_t s = as_stream(stream);
-    if (dk == 64) {
-        hipLaunchKernelGGL((attn_bwd_q_kernel<64, 64>), gq, dim3(256), 0, s, p);
-        hipLaunchKernelGGL((attn_bwd_kv_kernel<64, 64>), gk, dim3(256), 0, s, p);
-    } else {
-        hipLaunchKernelGGL((attn_bwd_q_kernel<16, 16>), gq, dim3(256), 0, s, p);
-        hipLaunchKernelGGL((attn_bwd_kv_kernel<16, 16>), gk, dim3(256), 0, s, p);
-    }
+    if (dk == 64)
+        launch_attn_bwd<64, 64>(p, nqb, nkb, s);
+    else
+        launch_attn_bwd<16, 16>(p, nqb, nkb, s);
     MTL_CHECK_LAUNCH();
     return MTL_OK;
 }

@@ -501,6 +501,7 @@ def test_layernorm(L, d):
     (2, 4, 130, 130, 64, 1, [130, 65], 0.25),         # dropout on the probabilities, causal, three key tiles
     (3, 8, 9, 16, 16, 0, [16, 10, 3], 0.0),           # fixture head size (d_k = 16)
     (2, 8, 70, 70, 16, 1, [70, 9], 0.3),
+    (2, 8, 2100, 2100, 64, 1, [2100, 900], 0.0),      # > 1024 workgroups: the backward's two-launch form (query side, then key side)
 ])
 def test_fused_attention_forward_and_backward(L, B, H, Tq, Tk, dk, causal, klens, drop):
     """mtl_attn_fwd / mtl_attn_bwd against ScaledDotProductAttention written out in torch (modules/common_layers.py:317-331:
