@@ -231,6 +231,9 @@ class PassEngine:
         # weight gradients of all layers of a stack as one strided-batch launch per parameter kind (flush_layer_wgrads)
         self.layer_wgrads = os.environ.get('MTL_LAYER_WGRADS', '1') != '0'
         self.use_side_stream = True
+        # the decoder's prologue (embedding + layer 0's self-attention block) depends on the labels and theta only: it runs on the side
+        # stream under the encoder, and its backward (which feeds parameter gradients only) under the encoder's backward
+        self.overlap_dec0 = os.environ.get('MTL_OVERLAP_DEC0', '1') != '0'
         self.flush_level = int(os.environ.get('MTL_FLUSH_LEVEL', '0'))      # see flush_side
         self.flush_delay = os.environ.get('MTL_FLUSH_DELAY', '0') == '1'
         self._held = None
@@ -492,6 +495,25 @@ class PassEngine:
             finally:
                 self.on_side = False
 
+    def run_on_side(self, fn):
+        """fn() with the side stream current, behind everything the main stream has enqueued so far; returns (fn's result, event
+        handle recorded on the side stream after it -- wait_side_event() makes the main stream wait for it)"""
+        ev = self._event()
+        check(self.lib.mtl_event_record(ev, self.stream), 'mtl_event_record')
+        check(self.lib.mtl_stream_wait_event(self.side.cuda_stream, ev), 'mtl_stream_wait_event')
+        with torch.cuda.stream(self.side):
+            self.on_side = True
+            try:
+                out = fn()
+            finally:
+                self.on_side = False
+            done = self._event()
+            check(self.lib.mtl_event_record(done, self.side.cuda_stream), 'mtl_event_record')
+        return out, done
+
+    def wait_side_event(self, ev):
+        check(self.lib.mtl_stream_wait_event(self.stream, ev), 'mtl_stream_wait_event')
+
     def join_side(self):
         self.flush_wgrads()
         self.flush_side()
@@ -680,7 +702,7 @@ class PassEngine:
         dq, dkk, dvv = dfull['q'], dfull['k'], dfull['v']
         if self.fused_attn:
             klen, causal = A[tag + 'attn']
-            delta = self.buf('_delta', (Bn * h * Tq,))
+            delta = self.buf('_delta.side' if self.on_side else '_delta', (Bn * h * Tq,))
             check(self.lib.mtl_attn_bwd(self.stream, q.data_ptr(), k.data_ptr(), v.data_ptr(), hk, hk, hv, klen, causal,
                                         1.0 / float(hp.temperature), Bn, h, Tq, Tk, dk, dv, mP.data_ptr() if mP is not None else None,
                                         ldS, self.drop_scale, O.data_ptr(), dO.data_ptr(), hv, A[tag + 'lse'].data_ptr(),
@@ -1032,6 +1054,21 @@ class PassEngine:
         # ---- encoder ----
         wp = self.buf('wp_in', (d, hp.d_in))
         check(lib.mtl_permute_hc(st, o('encoder.input_linear.weight'), wp.data_ptr(), d, 128, F4, 0, am_(7)), 'permute')      # am_(7): max|w| rides along
+        # decoder prologue: embedding (+ PE, dropout) and layer 0's self-attention block read the labels and theta only
+        def dec_prologue():
+            d0_ = self.buf('dec_in.y', (Md, d))
+            me = self.drop_mask('dec_in.me', (Md, d))                           # dropout(emb + PE) (modules/decoder.py:96)
+            check(lib.mtl_embed_pe_fwd(self.stream, ids.data_ptr(), o('decoder.trg_embedding.weight'), self.pe_dec.data_ptr(),
+                                       d0_.data_ptr(), Md, Td, d, me.data_ptr() if me is not None else None, self.drop_scale), 'embed')
+            if hp.n_dec == 0:
+                return d0_, None
+            return d0_, self.mha_fwd('d0.sa.', P, 'decoder.layers.0.self_attn.', d0_.data_ptr(), B, Td, d0_.data_ptr(), Td, klen_dec, 1,
+                                     keep_dec)
+        pro_done = None
+        self.dec0_on_side = bool(self.use_side_stream and self.overlap_dec0 and self.layer_wgrads and not self.group_wgrads
+                                 and not self.fused_pairs and hp.n_dec > 0)
+        if self.dec0_on_side:
+            (d0, a0), pro_done = self.run_on_side(dec_prologue)      # under the input Linear and the encoder
         e0 = self.buf('e0', (Me, d))
         self.in_h2 = h2 and bool(lib.mtl_gemm_nt_h2_supported(Me, d, hp.d_in)) and bool(lib.mtl_gemm_nt_h2_supported(Me, hp.d_in, d))
         if self.in_h2:      # the two compute-bound products of the pass on fp16 pairs: e0 = p2 . wp^T here, dp2 = de0 . (wp^T)^T in the backward
@@ -1056,15 +1093,16 @@ class PassEngine:
         mem = cur
 
         # ---- decoder ----
-        d0 = self.buf('dec_in.y', (Md, d))
-        me = self.drop_mask('dec_in.me', (Md, d))                               # dropout(emb + PE) (modules/decoder.py:96)
-        check(lib.mtl_embed_pe_fwd(st, ids.data_ptr(), o('decoder.trg_embedding.weight'), self.pe_dec.data_ptr(), d0.data_ptr(),
-                                   Md, Td, d, me.data_ptr() if me is not None else None, self.drop_scale), 'embed')
+        if pro_done is not None:
+            self.wait_side_event(pro_done)
+        else:
+            d0, a0 = dec_prologue()
         cur = d0
         xkv = self.cross_kv_fwd(P, mem.data_ptr(), Me)
         for i in range(hp.n_dec):
             pre = 'decoder.layers.%d.' % i
-            a = self.mha_fwd('d%d.sa.' % i, P, pre + 'self_attn.', cur.data_ptr(), B, Td, cur.data_ptr(), Td, klen_dec, 1, keep_dec)
+            a = a0 if i == 0 else self.mha_fwd('d%d.sa.' % i, P, pre + 'self_attn.', cur.data_ptr(), B, Td, cur.data_ptr(), Td,
+                                               klen_dec, 1, keep_dec)
             c = self.mha_fwd('d%d.ca.' % i, P, pre + 'encoder_attn.', a.data_ptr(), B, Td, mem.data_ptr(), T4, klen_enc, 0, keep_dec,
                              kv_ready=(xkv[0][i], xkv[1][i]) if xkv is not None else None)
             cur = self.ffn_fwd('d%d.ff.' % i, P, pre + 'pos_ffn.', c.data_ptr(), Md, Td, keep_dec)
@@ -1202,6 +1240,12 @@ class PassEngine:
         hoisted = A.get('xkv.plan') is not None
         mem_ptr = A['e%d.ff.y' % (hp.n_enc - 1)].data_ptr() if hp.n_enc else A['enc_in.y'].data_ptr()
         dkv_all = self.buf('xkv.d', (hp.n_dec, 2, Me, hp.h * hp.dk)) if hoisted else None
+        def embed_bwd(dx):
+            me = A.get('dec_in.me')
+            check(lib.mtl_embed_bwd(self.stream, S['meta']['ids'].data_ptr(), S['meta']['embed_first'], S['meta']['embed_next'],
+                                    dx.data_ptr(), g('decoder.trg_embedding.weight'), Md, d, PAD_ID,
+                                    me.data_ptr() if me is not None else None, self.drop_scale), 'embed_bwd')
+        embed_done = False
         for i in reversed(range(hp.n_dec)):
             pre = 'decoder.layers.%d.' % i
             x_in = A['dec_in.y'] if i == 0 else A['d%d.ff.y' % (i - 1)]
@@ -1211,6 +1255,17 @@ class PassEngine:
             self.mha_bwd('d%d.ca.' % i, P, G, pre + 'encoder_attn.', dcur.data_ptr(), sa_y.data_ptr(), B, Td, mem_ptr, T4, keep_dec,
                          dnext.data_ptr(), dmem.data_ptr(), i != hp.n_dec - 1, dkv_hoisted=dkv_all[i] if hoisted else None)
             dcur, dnext = dnext, dcur
+            if i == 0 and getattr(self, 'dec0_on_side', False):
+                # layer 0's self-attention block and the embedding feed parameter gradients only (the encoder's backward needs dmem,
+                # which is complete): side stream, under the encoder's backward.  dcur / dnext are not touched by the main stream
+                # again; the block's weight-gradient products are logged like every layer's and issued behind it on the same stream.
+                def dec_epilogue(pre=pre, x_in=x_in, dcur=dcur, dnext=dnext):
+                    self.mha_bwd('d0.sa.', P, G, pre + 'self_attn.', dcur.data_ptr(), x_in.data_ptr(), B, Td, x_in.data_ptr(), Td,
+                                 keep_dec, dnext.data_ptr(), dnext.data_ptr(), True)
+                    embed_bwd(dnext)
+                self.run_on_side(dec_epilogue)
+                embed_done = True
+                continue
             self.mha_bwd('d%d.sa.' % i, P, G, pre + 'self_attn.', dcur.data_ptr(), x_in.data_ptr(), B, Td, x_in.data_ptr(), Td,
                          keep_dec, dnext.data_ptr(), dnext.data_ptr(), True)
             dcur, dnext = dnext, dcur
@@ -1219,10 +1274,8 @@ class PassEngine:
             self.cross_kv_bwd(P, G, mem_ptr, Me, dmem.data_ptr())
         self.flush_layer_wgrads()       # the decoder stack's weight gradients: one launch per parameter kind
         self.flush_side(2)
-        me = A.get('dec_in.me')
-        check(lib.mtl_embed_bwd(st, S['meta']['ids'].data_ptr(), S['meta']['embed_first'], S['meta']['embed_next'], dcur.data_ptr(),
-                                g('decoder.trg_embedding.weight'), Md, d, PAD_ID, me.data_ptr() if me is not None else None,
-                                self.drop_scale), 'embed_bwd')
+        if not embed_done:
+            embed_bwd(dcur)
 
         # ---- encoder ----
         eA = self.buf('_deA', (Me, d))
@@ -1243,7 +1296,6 @@ class PassEngine:
                     None, de0.data_ptr(), g('encoder.layer_norm_input.weight'), g('encoder.layer_norm_input.bias'), Me,
                     dsum=g('encoder.input_linear.bias'))
         self.flush_layer_wgrads()       # the encoder stack's weight gradients
-        self.flush_ln_reduce()     # the parameter / bias gradients of all 17 LayerNorms of the pass: one launch
         p2, y5, p1, y1 = A['p2'], A['y5'], A['p1'], A['y1']
         dwp = self.buf('_dwp', (d, hp.d_in))
         dp2 = self.buf('_dp2', (B, T4, F4, 128))
@@ -1313,3 +1365,5 @@ class PassEngine:
         check(lib.mtl_conv0_wgrad(st, S['x'].data_ptr(), dy1.data_ptr(),
                          g('conv.0.weight'), g('conv.0.bias'), ws, B, T, F), 'wgrad0')
         self.join_side()
+        self.flush_ln_reduce()     # the parameter / bias gradients of all 17 LayerNorms of the pass: one launch (after the join: one of
+                                   # the 17 backward kernels ran on the side stream)
