@@ -340,14 +340,13 @@ def main_lm(a, mtl_amd, mdist, dev, rank, world):
     corpora sharded over the ranks, one all-reduce of the flat G.  One step = one meta-iteration (every task: train pass, clipped
     inner SGD step, validation pass at theta'; clipped outer SGD step).  Parity of this path is pinned to the oracle's documented
     first-order restatement only (the reference's loop does not run on torch >= 2)."""
-    from oracle import lm_refimpl as LR               # synthetic corpus generator + cpu_baseline leg only
     c = LM_CFG
     torch.manual_seed(1111)
     with contextlib.redirect_stdout(io.StringIO()):
         model = mtl_amd.lm.RNNModel('LSTM', c['ntoken'], c['ninp'], c['nhid'], c['nlayers'], c['dropout']).to(dev)
     model.train()
     n = a.tasks
-    streams = [LR.synth_corpus(100 + i, c['ntoken'], c['corpus_len']) for i in range(n)]
+    streams = [mtl_amd.lm.synth_corpus(100 + i, c['ntoken'], c['corpus_len']) for i in range(n)]
     ds = mtl_amd.lm.LMDataset(streams, argparse.Namespace(bptt=c['bptt'], batch_size=c['batch_size'], cuda=False))
     ds.task_list = [t.to(dev) for t in ds.task_list]
     mine = mdist.shard_tasks(n, rank, world)
@@ -411,6 +410,7 @@ def main_lm(a, mtl_amd, mdist, dev, rank, world):
                                  timing='HIP events around every library call of one serial meta-iteration', per_class=table),
                    last_step=dict(weighted_val_loss=last[0]))
         if world == 1 and not a.no_cpu_baseline:
+            from oracle import lm_refimpl as LR           # checker-side restatement: the cpu_baseline leg only
             threads = a.cpu_threads or min(32, physical_cores())
             torch.set_num_threads(threads)
             oracle = LR.RNNModel(c['ntoken'], c['ninp'], c['nhid'], c['nlayers'], 0.0)

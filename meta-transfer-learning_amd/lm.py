@@ -28,6 +28,14 @@ check = _lib.check
 ACCUM = 2
 
 
+
+def synth_corpus(seed, ntoken, length):
+    """Zipf-ish synthetic token stream for benchmarks (the reference's ./data/*.txt corpora do not ship with it)."""
+    g = torch.Generator().manual_seed(seed)
+    u = torch.rand(length, generator=g)
+    return (torch.floor((ntoken - 1) * u * u)).to(torch.int64).clamp_(0, ntoken - 1)
+
+
 class RNNModel(nn.Module):
     def __init__(self, rnn_type, ntoken, ninp, nhid, nlayers, dropout=0.5, tie_weights=False):
         super().__init__()
