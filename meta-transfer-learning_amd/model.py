@@ -162,7 +162,7 @@ class Transformer(nn.Module):
         self._theta_override = None
         self.engine = None
         self.engines, self.lane_streams = [], []
-        self.n_lanes = max(1, int(os.environ.get('MTL_TASK_LANES', '3')))
+        self.n_lanes = max(1, int(os.environ.get('MTL_TASK_LANES', '8')))       # one lane per task of a meta-step, up to 8 (measured: 73.6 vs 76.7 ms at 3)
         self._pass_token = 0
         self._last = None
         self._anchor = None

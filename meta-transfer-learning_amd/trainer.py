@@ -331,6 +331,9 @@ class TransientTrainer():
                 and not any(e.prof is not None for e in model.engines)):
             return self._single_task_split(model, task_batches[0], val_batch, n_tasks, inner, args)
         n_lanes = min(model.n_lanes, max(len(task_batches), 1))
+        if len(task_batches) > n_lanes:                      # several rounds: equal rounds (8 tasks on 6 lanes measured slower than on 3)
+            rounds = -(-len(task_batches) // n_lanes)
+            n_lanes = -(-len(task_batches) // rounds)
         bufs = self._lane_buffers(model, n_lanes)
         main = torch.cuda.current_stream(dev)
         vx = val_batch[0].to(dev, non_blocking=True)

@@ -496,7 +496,7 @@ def test_command_list_replay_is_bitwise_equal_to_eager(dropout):
         res[mode] = outs
         if mode:
             recorded = [v for v in tr._cmdlists.values() if isinstance(v, dict)]
-            assert len(recorded) == model.n_lanes and all(v['cl'].n > 100 for v in recorded)
+            assert len(recorded) == min(model.n_lanes, 6) and all(v['cl'].n > 100 for v in recorded)      # one list per lane in use
     for (G0, r0), (G1, r1) in zip(res[False], res[True]):
         assert torch.equal(G0, G1)
         for (l0, h0), (l1, h1) in zip(r0, r1):
