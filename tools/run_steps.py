@@ -18,6 +18,7 @@ ap.add_argument('--steps', type=int, default=6)
 ap.add_argument('--warmup', type=int, default=3)
 ap.add_argument('--frames', type=int, default=1000)
 ap.add_argument('--serial', action='store_true')
+ap.add_argument('--no-side', action='store_true', help='weight-gradient jobs on the lane stream itself (no side streams)')
 a = ap.parse_args()
 with contextlib.redirect_stdout(io.StringIO()):
     import mtl_amd
@@ -33,6 +34,9 @@ trainer = mtl_amd.TransientTrainer()
 if a.serial:
     model.n_lanes = 1
     trainer.use_cmdlists = False
+    for e in model.engines:
+        e.use_side_stream = False
+if a.no_side:
     for e in model.engines:
         e.use_side_stream = False
 inner, outer = mtl_amd.FlatSGD(model, args.lr), mtl_amd.FlatAdam(model, args.meta_lr)
