@@ -60,6 +60,16 @@ int mtl_gemm_f32_ex(void* stream, int transA, int transB, int M, int N, int K, f
                     long sBk, float* rowsum, long sRowsum, float* workspace, long workspace_bytes,
                     long sBiasH, long sRowsumH /* bias / rowsum strides of the INNER batch index (z % H); sBias / sRowsum belong to z / H:
                                                   e.g. the K and V projections (inner) of all decoder layers (outer) in one launch */);
+/* mtl_gemm_f32_ex with a THIRD, outermost batch level -- the tasks of a meta-step (trainer/asr/transient_trainer.py:178-237: every
+ * task's passes are independent given theta0) batched into one launch: batch = tasks * (items per task); item z belongs to task
+ * zt = z / (batch / tasks) and its operands sit at base + zt * s?t + (the two-level offsets of z % (batch / tasks)).  The weights
+ * of the validation passes differ per task (theta'_t = theta0 - alpha g_t, a stack with stride sBt; 0 for the shared theta0 of
+ * the training passes), per-task gradients accumulate into a stack (sCt / sRowsumT). */
+int mtl_gemm_f32_tb(void* stream, int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
+                    const float* B, int ldb, float* C, int ldc, const float* bias, const float* gate, int ldg, int flags,
+                    int batch, int H, long sAb, long sAh, long sBb, long sBh, long sCb, long sCh, long sBias, int kbatch, long sAk,
+                    long sBk, float* rowsum, long sRowsum, float* workspace, long workspace_bytes, long sBiasH, long sRowsumH,
+                    int tasks, long sAt, long sBt, long sCt, long sBiasT, long sRowsumT);
 /* which engine mtl_gemm_f32_ex picks: 1 = small-tile (kernel symbol gemm16_kernel<...>), 0 = forwarded to mtl_gemm_f32
  * (gemm_kernel<...>); used by bench.py to attribute launch timings to the rocprofv3 kernel classes */
 int mtl_gemm_f32_ex_route(int M, int N, int K, int batch, int kbatch, int has_rowsum);
@@ -199,6 +209,11 @@ int mtl_permute_hc(void* stream, const float* src, float* dst, int rows, int C, 
 int mtl_layernorm_fwd(void* stream, const float* x, const float* residual, const float* gamma, const float* beta,
                       const float* pe, const int* keep, const unsigned char* xmask, float xscale, float* y, float* xhat,
                       float* rstd, int rows, int d, int T, float eps);
+/* Task-grouped form: the rows are consecutive groups of rows_per_group rows (the batches of the tasks of a meta-step in one
+ * launch); group g reads gamma / beta at + g * sParam floats (0: shared parameters). */
+int mtl_layernorm_fwd_g(void* stream, const float* x, const float* residual, const float* gamma, const float* beta,
+                        const float* pe, const int* keep, const unsigned char* xmask, float xscale, float* y, float* xhat,
+                        float* rstd, int rows, int d, int T, float eps, int rows_per_group, long sParam);
 long mtl_layernorm_bwd_workspace(int rows, int d);
 /* with xmask: dz is the residual-branch gradient and dzm = dz * mask * xscale the sub-layer-branch gradient (dsum sums dzm);
  * dz2 (nullable): a second copy of dz (the residual path accumulates onto it while dz stays intact for the weight gradient) */
@@ -209,6 +224,15 @@ int mtl_layernorm_bwd(void* stream, const float* dy, const float* xhat, const fl
                       float* workspace, int rows, int d,
                       int defer_reduce /* 1: leave the per-wave partials in `workspace` (keep it alive, one per instance) and add them
                                           to dgamma / dbeta / dsum later with mtl_ln_param_reduce_batch */);
+/* Task-grouped form: a wave's rows belong to one group; group g owns the partial rows [g * W, (g + 1) * W) of `workspace`
+ * (W = mtl_layernorm_bwd_g_waves(rows_per_group); 3 * d floats per partial row), reads gamma at + g * sParam and -- unless the
+ * reduction is deferred -- adds to dgamma / dbeta / dsum at + g * sGrad. */
+int mtl_layernorm_bwd_g_waves(int rows_per_group);
+long mtl_layernorm_bwd_g_workspace(int rows, int d, int rows_per_group);
+int mtl_layernorm_bwd_g(void* stream, const float* dy, const float* xhat, const float* rstd, const float* gamma,
+                        const int* keep, const unsigned char* xmask, float xscale, float* dz, float* dzm, float* dz2, float* dgamma,
+                        float* dbeta, float* dsum, float* workspace, int rows, int d, int defer_reduce, int rows_per_group,
+                        long sParam, long sGrad);
 /* the deferred parameter reductions of several mtl_layernorm_bwd calls in ONE launch (table in device memory; nw = workspace bytes
  * / (3 * d * 4); dmax = largest d of the table) */
 typedef struct mtl_ln_reduce_desc {
@@ -255,6 +279,13 @@ int mtl_embed_pe_fwd(void* stream, const long* ids, const float* table, const fl
 int mtl_embed_bwd(void* stream, const long* ids, const int* first, const int* next, const float* dout,
                   float* dtable /*accum*/, int rows, int d, long pad_id, const unsigned char* mask, float mscale);
 
+/* Task-grouped forms: rows in groups of rows_per_group; group g uses table + g * sParam / dtable + g * sGrad.  The occurrence
+ * chains (first / next) must not cross groups. */
+int mtl_embed_pe_fwd_g(void* stream, const long* ids, const float* table, const float* pe, float* out, int rows, int T, int d,
+                       const unsigned char* mask, float mscale, int rows_per_group, long sParam);
+int mtl_embed_bwd_g(void* stream, const long* ids, const int* first, const int* next, const float* dout, float* dtable, int rows,
+                    int d, long pad_id, const unsigned char* mask, float mscale, int rows_per_group, long sGrad);
+
 /* ---- dropout keep-masks: keep[i] = 1 with probability 1-p, Philox4x32-10(counter = offset + i/4, key = *seed_dev).
  * Active sites in the meta loop (model.train()): modules/decoder.py:96, modules/common_layers.py:130,303,328. */
 int mtl_dropout_mask(void* stream, unsigned char* keep, long n, float p, const long* seed_dev, unsigned long long offset);
@@ -269,6 +300,13 @@ int mtl_ce_argmax_fwd(void* stream, const float* logits, const long* gold, int r
 int mtl_ce_bwd(void* stream, const float* logits, const float* lse, const long* gold, int rows, int V, int ld, long pad_id,
                float smoothing, float gscale, const float* gscale_dev, float* dlogits, int ldd);
 
+/* Task-grouped forms (rows % rows_per_group == 0): loss_out[g] = sum over the rows of group g * inv_count_dev[g] (one loss per
+ * task, each normalised by ITS non-pad token count); the backward scales group g by gscale * gscale_dev[g]. */
+int mtl_ce_argmax_fwd_g(void* stream, const float* logits, const long* gold, int rows, int V, int ld, long pad_id, float smoothing,
+                        const float* inv_count_dev, float* lse, long* hyp, float* rowloss, float* loss_out, int rows_per_group);
+int mtl_ce_bwd_g(void* stream, const float* logits, const float* lse, const long* gold, int rows, int V, int ld, long pad_id,
+                 float smoothing, float gscale, const float* gscale_dev, float* dlogits, int ldd, int rows_per_group);
+
 /* ---- out[c] += sum_r X[r*ld + c]  (bias gradients) -------------------------------------------------------- */
 long mtl_colsum_workspace(long rows, int cols);
 /* amax (optional, MTL_AMAX_FLOATS floats): all slot heads set to max|X| (written, not accumulated) -- the same pass over X */
@@ -281,6 +319,10 @@ int mtl_colsum_accum(void* stream, const float* X, long rows, int cols, long ld,
  * clip       transient_trainer.py:205-206,253-254     -> mtl_sumsq(mode 2) + mtl_scale(a_dev)
  * Adam       transient_trainer.py:109,255 (torch defaults) */
 int mtl_sgd_theta_prime(void* stream, const float* theta0, const float* g, float alpha, float* theta1, long n);
+/* the inner steps of all local tasks in one launch: theta1[t*n + i] = theta0[i] - alpha * g[t*n + i], t < tasks (n % 4 == 0) */
+int mtl_sgd_theta_prime_tasks(void* stream, const float* theta0, const float* g, float alpha, float* theta1, long n, int tasks);
+/* out[i] (+)= sum_t x[t*n + i] in task order (copy_grad accumulation of a task stack: models/asr/transformer.py:219-229) */
+int mtl_sum_tasks(void* stream, float* out, const float* x, long n, int tasks, int accumulate);
 int mtl_axpy(void* stream, float* y, const float* x, float a, long n);
 int mtl_copy_f32(void* stream, float* dst, const float* src, long n); /* device-to-device, asynchronous on `stream` */
 int mtl_scale(void* stream, float* y, float a, const float* a_dev /*nullable: overrides a*/, long n);
@@ -328,7 +370,7 @@ typedef struct mtl_cmd {
         void* p;
         long l;
         double d;
-    } a[36];
+    } a[48];
 } mtl_cmd;
 int mtl_cmdlist_opcode(const char* function_name);     /* -1 if the function cannot be recorded */
 int mtl_cmdlist_run(const mtl_cmd* cmds, int n, int* failed_index);

@@ -18,6 +18,8 @@ SIGNATURES = {
     'mtl_abi_version': (I, []),
     'mtl_gemm_f32': (I, [P, I, I, I, I, I, F, P, I, P, I, P, I, P, P, I, I, I, I, L, L, L, L, L, L, L, P, L]),
     'mtl_gemm_f32_ex': (I, [P, I, I, I, I, I, F, P, I, P, I, P, I, P, P, I, I, I, I, L, L, L, L, L, L, L, I, L, L, P, L, P, L, L, L]),
+    'mtl_gemm_f32_tb': (I, [P, I, I, I, I, I, F, P, I, P, I, P, I, P, P, I, I, I, I, L, L, L, L, L, L, L, I, L, L, P, L, P, L, L, L,
+                            I, L, L, L, L, L]),
     'mtl_gemm_f32_ex_route': (I, [I, I, I, I, I, I]),
     'mtl_gemm_wgrad_grouped': (I, [P, P, I, I]),
     'mtl_lowrank_supported': (I, [I, I, I]),
@@ -51,7 +53,11 @@ SIGNATURES = {
     'mtl_gemm_nt_h2': (I, [P, I, I, I, P, I, P, P, I, P, P, I, P, P, I, P, L]),
     'mtl_permute_hc': (I, [P, P, P, I, I, I, I, P]),
     'mtl_layernorm_fwd': (I, [P, P, P, P, P, P, P, P, F, P, P, P, I, I, I, F]),
+    'mtl_layernorm_fwd_g': (I, [P, P, P, P, P, P, P, P, F, P, P, P, I, I, I, F, I, L]),
     'mtl_layernorm_bwd_workspace': (L, [I, I]),
+    'mtl_layernorm_bwd_g_waves': (I, [I]),
+    'mtl_layernorm_bwd_g_workspace': (L, [I, I, I]),
+    'mtl_layernorm_bwd_g': (I, [P, P, P, P, P, P, P, F, P, P, P, P, P, P, P, I, I, I, I, L, L]),
     'mtl_layernorm_bwd': (I, [P, P, P, P, P, P, P, F, P, P, P, P, P, P, P, I, I, I]),
     'mtl_ln_param_reduce_batch': (I, [P, P, I, I]),
     'mtl_softmax_mask_fwd': (I, [P, P, P, I, F, I, I, I, I, I, P, F, P]),
@@ -61,12 +67,18 @@ SIGNATURES = {
     'mtl_attn_bwd': (I, [P, P, P, P, I, I, I, P, I, F, I, I, I, I, I, I, P, I, F, P, P, I, P, P, P, P, P, I, I, I]),
     'mtl_embed_pe_fwd': (I, [P, P, P, P, P, I, I, I, P, F]),
     'mtl_embed_bwd': (I, [P, P, P, P, P, P, I, I, L, P, F]),
+    'mtl_embed_pe_fwd_g': (I, [P, P, P, P, P, I, I, I, P, F, I, L]),
+    'mtl_embed_bwd_g': (I, [P, P, P, P, P, P, I, I, L, P, F, I, L]),
     'mtl_dropout_mask': (I, [P, P, L, F, P, ctypes.c_ulonglong]),
     'mtl_ce_argmax_fwd': (I, [P, P, P, I, I, I, L, F, I, P, P, P, P, P]),
     'mtl_ce_bwd': (I, [P, P, P, P, I, I, I, L, F, F, P, P, I]),
+    'mtl_ce_argmax_fwd_g': (I, [P, P, P, I, I, I, L, F, P, P, P, P, P, I]),
+    'mtl_ce_bwd_g': (I, [P, P, P, P, I, I, I, L, F, F, P, P, I, I]),
     'mtl_colsum_workspace': (L, [L, I]),
     'mtl_colsum_accum': (I, [P, P, L, I, L, P, P, P]),
     'mtl_sgd_theta_prime': (I, [P, P, P, F, P, L]),
+    'mtl_sgd_theta_prime_tasks': (I, [P, P, P, F, P, L, I]),
+    'mtl_sum_tasks': (I, [P, P, P, L, I, I]),
     'mtl_axpy': (I, [P, P, P, F, L]),
     'mtl_copy_f32': (I, [P, P, P, L]),
     'mtl_scale': (I, [P, P, F, P, L]),
@@ -138,7 +150,7 @@ class _CmdArg(ctypes.Union):
 
 
 class MtlCmd(ctypes.Structure):
-    _fields_ = [('op', c_int), ('nargs', c_int), ('a', _CmdArg * 36)]
+    _fields_ = [('op', c_int), ('nargs', c_int), ('a', _CmdArg * 48)]
 
 
 def _kinds(name):

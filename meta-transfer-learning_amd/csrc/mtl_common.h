@@ -27,10 +27,12 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-// big-engine GEMM with bias strides for both batch levels (mtl_mfma.hip; what mtl_gemm_f32_ex forwards to)
-int mtl_gemm_f32_2l(void* stream, int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda, const float* B,
+// big-engine GEMM with bias strides for both batch levels and a third, outermost batch level (`tasks` items of batch / tasks
+// each: the tasks of a meta-step in one launch) (mtl_mfma.hip; what mtl_gemm_f32_tb forwards to)
+int mtl_gemm_f32_3l(void* stream, int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda, const float* B,
                     int ldb, float* C, int ldc, const float* bias, const float* gate, int ldg, int flags, int batch, int H, long sAb,
-                    long sAh, long sBb, long sBh, long sCb, long sCh, long sBias, long sBiasH, float* workspace, long workspace_bytes);
+                    long sAh, long sBb, long sBh, long sCb, long sCh, long sBias, long sBiasH, float* workspace, long workspace_bytes,
+                    int tasks, long sAt, long sBt, long sCt, long sBiasT);
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 

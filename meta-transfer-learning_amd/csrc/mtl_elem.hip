@@ -28,6 +28,31 @@ __global__ void sgd_theta_prime_kernel(const float4* __restrict__ t0, const floa
         for (long i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) t1s[i] = t0s[i] - alpha * gs[i];
 }
 
+// theta1[t][i] = theta0[i] - alpha * g[t][i] for the `tasks` gradient rows of a stack (theta0 is read once per element)
+__global__ void sgd_theta_prime_tasks_kernel(const float4* __restrict__ t0, const float4* __restrict__ g, float4* __restrict__ t1,
+                                             float alpha, long n4, int tasks) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const float4 a = t0[i];
+        for (int t = 0; t < tasks; ++t) {
+            const float4 b = g[t * n4 + i];
+            t1[t * n4 + i] = make_float4(a.x - alpha * b.x, a.y - alpha * b.y, a.z - alpha * b.z, a.w - alpha * b.w);
+        }
+    }
+}
+// out[i] (+)= sum_t x[t][i], t ascending (fixed order)
+__global__ void sum_tasks_kernel(float4* __restrict__ out, const float4* __restrict__ x, long n4, int tasks, int accumulate) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 a = accumulate ? out[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int t = 0; t < tasks; ++t) {
+            const float4 b = x[t * n4 + i];
+            a.x += b.x, a.y += b.y, a.z += b.z, a.w += b.w;
+        }
+        out[i] = a;
+    }
+}
+
 __global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, float a, long n) {
     const long n4 = n / 4, stride = (long)gridDim.x * blockDim.x;
     float4* y4 = reinterpret_cast<float4*>(y);
@@ -93,6 +118,18 @@ __global__ void sum_final_kernel(const float* __restrict__ part, int np, float* 
         if (mode == 2) t = fminf(1.f, arg / (sqrtf(t) + 1e-6f));
         *out = t;
     }
+}
+
+// out[g] = (sum of part[g * per .. (g + 1) * per)) * inv_dev[g]: the per-task losses of a task-batched pass, one block per task
+__global__ void sum_groups_kernel(const float* __restrict__ part, int per, float* __restrict__ out, const float* __restrict__ inv_dev) {
+    __shared__ float sh[4];
+    const float* q = part + (long)blockIdx.x * per;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < per; i += blockDim.x) s += q[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = (sh[0] + sh[1] + sh[2] + sh[3]) * inv_dev[blockIdx.x];
 }
 
 // ------------------------------------------------------------------ dropout keep-masks (Philox4x32-10, counter based)
@@ -177,12 +214,15 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
                                                             const float* __restrict__ pe, const int* __restrict__ keep,
                                                             const uint8_t* __restrict__ xmask, float xscale,
                                                             float* __restrict__ y, float* __restrict__ xhat,
-                                                            float* __restrict__ rstd, int rows, int T, float eps) {
+                                                            float* __restrict__ rstd, int rows, int T, float eps, int rpg, long sParam) {
     constexpr int D = NPL * 64;
     using IO = LnRow<NPL>;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
+    const long po = (long)(row / rpg) * sParam;         // parameters of this row's group (task)
+    gamma += po;
+    beta += po;
     float v[NPL], rv[NPL], gm[NPL], bt[NPL], pv[NPL];
     bool mk[NPL];
     // every load of the row is issued before the first reduction
@@ -230,11 +270,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             const int* __restrict__ keep, const uint8_t* __restrict__ xmask,
                                                             float xscale, float* __restrict__ dz, float* __restrict__ dzm,
                                                             float* __restrict__ dz2, float* __restrict__ part, int rows,
-                                                            int rows_per_wave) {
+                                                            int rows_per_wave, int rpg, int wpg, long sParam) {
     constexpr int D = NPL * 64;
     using IO = LnRow<NPL>;
     const int lane = threadIdx.x & 63;
     const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int grp = gw / wpg;                           // a wave's rows belong to ONE group (task): wpg waves per group
+    gamma += (long)min(grp, (rows - 1) / rpg) * sParam;      // (padding waves beyond the last group own no rows)
     float ag[NPL], ab[NPL], az[NPL], gm[NPL];
 #pragma unroll
     for (int i = 0; i < NPL; ++i) {
@@ -246,8 +288,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     // RB rows at a time with every load of the group issued before the first reduction: the wave pays the HBM latency once per
     // group instead of once per row (it was latency-bound: 22 us for 12 MB)
     constexpr int RB = 4;
-    const int r0 = gw * rows_per_wave;
-    const int rend = min(r0 + rows_per_wave, rows);
+    const int r0 = min(grp * rpg + (gw - grp * wpg) * rows_per_wave, rows);
+    const int rend = min(min(r0 + rows_per_wave, (grp + 1) * rpg), rows);
     for (int rb = r0; rb < rend; rb += RB) {
         float dv[RB][NPL], hv[RB][NPL], kp[RB], rs[RB];
         bool mk[RB][NPL];
@@ -401,11 +443,12 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restric
 
 // ------------------------------------------------------------------ embedding + positional encoding
 __global__ void embed_pe_fwd_kernel(const long* __restrict__ ids, const float* __restrict__ table, const float* __restrict__ pe,
-                                    float* __restrict__ out, int rows, int T, int d, const uint8_t* __restrict__ mask, float mscale) {
+                                    float* __restrict__ out, int rows, int T, int d, const uint8_t* __restrict__ mask, float mscale,
+                                    int rpg, long sParam) {
     const long total = (long)rows * d;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
         const int r = (int)(e / d), c = (int)(e - (long)r * d);
-        float v = table[ids[r] * d + c] + pe[(long)(r % T) * d + c];
+        float v = table[(r / rpg) * sParam + ids[r] * d + c] + pe[(long)(r % T) * d + c];
         if (mask) v = mask[e] ? v * mscale : 0.f;
         out[e] = v;
     }
@@ -414,7 +457,7 @@ __global__ void embed_pe_fwd_kernel(const long* __restrict__ ids, const float* _
 // same id (-1 = last) and `first[r]` marks chain heads; the thread of (head row, column) walks its chain in row order.
 __global__ void embed_bwd_kernel(const long* __restrict__ ids, const int* __restrict__ first, const int* __restrict__ next,
                                  const float* __restrict__ dout, float* __restrict__ dtable, int rows, int d, long pad_id,
-                                 const uint8_t* __restrict__ mask, float mscale) {
+                                 const uint8_t* __restrict__ mask, float mscale, int rpg, long sGrad) {
     const long total = (long)rows * d;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
         const int r = (int)(e / d), c = (int)(e - (long)r * d);
@@ -425,7 +468,7 @@ __global__ void embed_bwd_kernel(const long* __restrict__ ids, const int* __rest
             const float v = dout[(long)q * d + c];
             acc += mask ? (mask[(long)q * d + c] ? v * mscale : 0.f) : v;
         }
-        dtable[id * d + c] += acc;
+        dtable[(r / rpg) * sGrad + id * d + c] += acc;
     }
 }
 
@@ -510,11 +553,11 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ l
 __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ logits, const float* __restrict__ lse,
                                                      const long* __restrict__ gold, int rows, int V, int ld, long pad_id,
                                                      float smoothing, float gscale, const float* gscale_dev,
-                                                     float* __restrict__ dlogits, int ldd) {
+                                                     float* __restrict__ dlogits, int ldd, int rpg) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    if (gscale_dev) gscale *= *gscale_dev;
+    if (gscale_dev) gscale *= gscale_dev[row / rpg];
     const float* x = logits + (long)row * ld;
     float* d = dlogits + (long)row * ldd;
     const long g = gold[row];
@@ -992,6 +1035,26 @@ int mtl_sgd_theta_prime(void* stream, const float* theta0, const float* g, float
     return MTL_OK;
 }
 
+int mtl_sgd_theta_prime_tasks(void* stream, const float* theta0, const float* g, float alpha, float* theta1, long n, int tasks) {
+    if (!theta0 || !g || !theta1 || n <= 0 || tasks <= 0 || (n & 3)) return MTL_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(theta0) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(theta1)) & 15)
+        return MTL_EINVAL;
+    hipLaunchKernelGGL(sgd_theta_prime_tasks_kernel, dim3(grid_for(n / 4, 256, 4096)), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const float4*>(theta0), reinterpret_cast<const float4*>(g), reinterpret_cast<float4*>(theta1),
+                       alpha, n / 4, tasks);
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}
+
+int mtl_sum_tasks(void* stream, float* out, const float* x, long n, int tasks, int accumulate) {
+    if (!out || !x || n <= 0 || tasks <= 0 || (n & 3)) return MTL_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(x)) & 15) return MTL_EINVAL;
+    hipLaunchKernelGGL(sum_tasks_kernel, dim3(grid_for(n / 4, 256, 4096)), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<float4*>(out), reinterpret_cast<const float4*>(x), n / 4, tasks, accumulate);
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}
+
 int mtl_axpy(void* stream, float* y, const float* x, float a, long n) {
     if (!y || !x || n <= 0) return MTL_EINVAL;
     if ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(x)) & 15) return MTL_EINVAL;
@@ -1041,14 +1104,15 @@ int mtl_sumsq(void* stream, const float* x, long n, float* out, float* workspace
     return MTL_OK;
 }
 
-int mtl_layernorm_fwd(void* stream, const float* x, const float* residual, const float* gamma, const float* beta,
-                      const float* pe, const int* keep, const unsigned char* xmask, float xscale, float* y, float* xhat,
-                      float* rstd, int rows, int d, int T, float eps) {
-    if (!x || !gamma || !beta || !y || !xhat || !rstd || rows <= 0) return MTL_EINVAL;
+int mtl_layernorm_fwd_g(void* stream, const float* x, const float* residual, const float* gamma, const float* beta,
+                        const float* pe, const int* keep, const unsigned char* xmask, float xscale, float* y, float* xhat,
+                        float* rstd, int rows, int d, int T, float eps, int rows_per_group, long sParam) {
+    if (!x || !gamma || !beta || !y || !xhat || !rstd || rows <= 0 || rows_per_group <= 0) return MTL_EINVAL;
     dim3 grid((rows + 3) / 4), block(256);
     hipStream_t s = as_stream(stream);
-#define LN_FWD(N) \
-    hipLaunchKernelGGL(layernorm_fwd_kernel<N>, grid, block, 0, s, x, residual, gamma, beta, pe, keep, xmask, xscale, y, xhat, rstd, rows, T > 0 ? T : 1, eps)
+#define LN_FWD(N)                                                                                                                  \
+    hipLaunchKernelGGL(layernorm_fwd_kernel<N>, grid, block, 0, s, x, residual, gamma, beta, pe, keep, xmask, xscale, y, xhat, rstd, \
+                       rows, T > 0 ? T : 1, eps, rows_per_group, sParam)
     switch (d) {
         case 64: LN_FWD(1); break;
         case 128: LN_FWD(2); break;
@@ -1062,20 +1126,43 @@ int mtl_layernorm_fwd(void* stream, const float* x, const float* residual, const
     return MTL_OK;
 }
 
+int mtl_layernorm_fwd(void* stream, const float* x, const float* residual, const float* gamma, const float* beta,
+                      const float* pe, const int* keep, const unsigned char* xmask, float xscale, float* y, float* xhat,
+                      float* rstd, int rows, int d, int T, float eps) {
+    return mtl_layernorm_fwd_g(stream, x, residual, gamma, beta, pe, keep, xmask, xscale, y, xhat, rstd, rows, d, T, eps,
+                               rows > 0 ? rows : 1, 0);
+}
+
 long mtl_layernorm_bwd_workspace(int rows, int d) {
     const int waves = ((rows + 3) / 4 + 3) / 4 * 4;
     return (long)waves * 3 * d * 4;
 }
 
-int mtl_layernorm_bwd(void* stream, const float* dy, const float* xhat, const float* rstd, const float* gamma,
-                      const int* keep, const unsigned char* xmask, float xscale, float* dz, float* dzm, float* dz2, float* dgamma,
-                      float* dbeta, float* dsum, float* workspace, int rows, int d, int defer_reduce) {
-    if (!dy || !xhat || !rstd || !gamma || !dz || !dgamma || !dbeta || !workspace || rows <= 0 || (xmask && !dzm)) return MTL_EINVAL;
-    const int rpw = 4;
-    const int waves = ((rows + rpw - 1) / rpw + 3) / 4 * 4;
+static const int kLnRowsPerWave = 4;
+int mtl_layernorm_bwd_g_waves(int rows_per_group) { return (rows_per_group + kLnRowsPerWave - 1) / kLnRowsPerWave; }
+long mtl_layernorm_bwd_g_workspace(int rows, int d, int rows_per_group) {
+    if (rows <= 0 || rows_per_group <= 0) return 0;
+    const int groups = (rows + rows_per_group - 1) / rows_per_group;
+    const int waves = (groups * mtl_layernorm_bwd_g_waves(rows_per_group) + 3) / 4 * 4;
+    return (long)waves * 3 * d * 4;
+}
+
+int mtl_layernorm_bwd_g(void* stream, const float* dy, const float* xhat, const float* rstd, const float* gamma,
+                        const int* keep, const unsigned char* xmask, float xscale, float* dz, float* dzm, float* dz2, float* dgamma,
+                        float* dbeta, float* dsum, float* workspace, int rows, int d, int defer_reduce, int rows_per_group,
+                        long sParam, long sGrad) {
+    if (!dy || !xhat || !rstd || !gamma || !dz || !dgamma || !dbeta || !workspace || rows <= 0 || (xmask && !dzm) ||
+        rows_per_group <= 0)
+        return MTL_EINVAL;
+    const int rpw = kLnRowsPerWave;
+    const int groups = (rows + rows_per_group - 1) / rows_per_group;
+    const int wpg = mtl_layernorm_bwd_g_waves(rows_per_group);
+    const int waves = (groups * wpg + 3) / 4 * 4;
     dim3 grid(waves / 4), block(256);
     hipStream_t s = as_stream(stream);
-#define LN_BWD(N) hipLaunchKernelGGL(layernorm_bwd_kernel<N>, grid, block, 0, s, dy, xhat, rstd, gamma, keep, xmask, xscale, dz, dzm, dz2, workspace, rows, rpw)
+#define LN_BWD(N)                                                                                                                 \
+    hipLaunchKernelGGL(layernorm_bwd_kernel<N>, grid, block, 0, s, dy, xhat, rstd, gamma, keep, xmask, xscale, dz, dzm, dz2, workspace, \
+                       rows, rpw, rows_per_group, wpg, sParam)
     switch (d) {
         case 64: LN_BWD(1); break;
         case 128: LN_BWD(2); break;
@@ -1085,9 +1172,24 @@ int mtl_layernorm_bwd(void* stream, const float* dy, const float* xhat, const fl
         default: return MTL_EINVAL;
     }
 #undef LN_BWD
-    if (!defer_reduce) hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((d + 63) / 64, 3), dim3(1024), 0, s, workspace, waves, d, dgamma, dbeta, dsum);
+    if (!defer_reduce) {
+        if (groups == 1) {
+            hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((d + 63) / 64, 3), dim3(1024), 0, s, workspace, waves, d, dgamma, dbeta, dsum);
+        } else {
+            for (int g = 0; g < groups; ++g)
+                hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((d + 63) / 64, 3), dim3(1024), 0, s, workspace + (long)g * wpg * 3 * d, wpg,
+                                   d, dgamma + g * sGrad, dbeta + g * sGrad, dsum ? dsum + g * sGrad : nullptr);
+        }
+    }
     MTL_CHECK_LAUNCH();
     return MTL_OK;
+}
+
+int mtl_layernorm_bwd(void* stream, const float* dy, const float* xhat, const float* rstd, const float* gamma,
+                      const int* keep, const unsigned char* xmask, float xscale, float* dz, float* dzm, float* dz2, float* dgamma,
+                      float* dbeta, float* dsum, float* workspace, int rows, int d, int defer_reduce) {
+    return mtl_layernorm_bwd_g(stream, dy, xhat, rstd, gamma, keep, xmask, xscale, dz, dzm, dz2, dgamma, dbeta, dsum, workspace, rows, d,
+                               defer_reduce, rows > 0 ? rows : 1, 0, 0);
 }
 
 int mtl_ln_param_reduce_batch(void* stream, const mtl_ln_reduce_desc* table_dev, int n, int dmax) {
@@ -1116,22 +1218,32 @@ int mtl_softmax_bwd(void* stream, const float* P, float* dP, float scale, long r
     return MTL_OK;
 }
 
+int mtl_embed_pe_fwd_g(void* stream, const long* ids, const float* table, const float* pe, float* out, int rows, int T, int d,
+                       const unsigned char* mask, float mscale, int rows_per_group, long sParam) {
+    if (!ids || !table || !pe || !out || rows <= 0 || T <= 0 || rows_per_group <= 0) return MTL_EINVAL;
+    hipLaunchKernelGGL(embed_pe_fwd_kernel, dim3(grid_for((long)rows * d, 256, 2048)), dim3(256), 0, as_stream(stream), ids,
+                       table, pe, out, rows, T, d, mask, mscale, rows_per_group, sParam);
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}
+
 int mtl_embed_pe_fwd(void* stream, const long* ids, const float* table, const float* pe, float* out, int rows, int T, int d,
                      const unsigned char* mask, float mscale) {
-    if (!ids || !table || !pe || !out || rows <= 0 || T <= 0) return MTL_EINVAL;
-    hipLaunchKernelGGL(embed_pe_fwd_kernel, dim3(grid_for((long)rows * d, 256, 2048)), dim3(256), 0, as_stream(stream), ids,
-                       table, pe, out, rows, T, d, mask, mscale);
+    return mtl_embed_pe_fwd_g(stream, ids, table, pe, out, rows, T, d, mask, mscale, rows > 0 ? rows : 1, 0);
+}
+
+int mtl_embed_bwd_g(void* stream, const long* ids, const int* first, const int* next, const float* dout, float* dtable, int rows,
+                    int d, long pad_id, const unsigned char* mask, float mscale, int rows_per_group, long sGrad) {
+    if (!ids || !first || !next || !dout || !dtable || rows <= 0 || rows_per_group <= 0) return MTL_EINVAL;
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(grid_for((long)rows * d, 256, 2048)), dim3(256), 0, as_stream(stream), ids, first,
+                       next, dout, dtable, rows, d, pad_id, mask, mscale, rows_per_group, sGrad);
     MTL_CHECK_LAUNCH();
     return MTL_OK;
 }
 
 int mtl_embed_bwd(void* stream, const long* ids, const int* first, const int* next, const float* dout, float* dtable, int rows,
                   int d, long pad_id, const unsigned char* mask, float mscale) {
-    if (!ids || !first || !next || !dout || !dtable || rows <= 0) return MTL_EINVAL;
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3(grid_for((long)rows * d, 256, 2048)), dim3(256), 0, as_stream(stream), ids, first,
-                       next, dout, dtable, rows, d, pad_id, mask, mscale);
-    MTL_CHECK_LAUNCH();
-    return MTL_OK;
+    return mtl_embed_bwd_g(stream, ids, first, next, dout, dtable, rows, d, pad_id, mask, mscale, rows > 0 ? rows : 1, 0);
 }
 
 int mtl_ce_argmax_fwd(void* stream, const float* logits, const long* gold, int rows, int V, int ld, long pad_id,
@@ -1147,13 +1259,31 @@ int mtl_ce_argmax_fwd(void* stream, const float* logits, const long* gold, int r
     return MTL_OK;
 }
 
-int mtl_ce_bwd(void* stream, const float* logits, const float* lse, const long* gold, int rows, int V, int ld, long pad_id,
-               float smoothing, float gscale, const float* gscale_dev, float* dlogits, int ldd) {
-    if (!logits || !lse || !gold || !dlogits || rows <= 0) return MTL_EINVAL;
-    hipLaunchKernelGGL(ce_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, as_stream(stream), logits, lse, gold, rows, V, ld,
-                       pad_id, smoothing, gscale, gscale_dev, dlogits, ldd);
+int mtl_ce_argmax_fwd_g(void* stream, const float* logits, const long* gold, int rows, int V, int ld, long pad_id, float smoothing,
+                        const float* inv_count_dev, float* lse, long* hyp, float* rowloss, float* loss_out, int rows_per_group) {
+    if (!logits || !gold || !lse || !hyp || !rowloss || !loss_out || rows <= 0 || V <= 0 || !inv_count_dev || rows_per_group <= 0 ||
+        rows % rows_per_group)
+        return MTL_EINVAL;
+    hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL(ce_fwd_kernel, dim3(rows), dim3(256), 0, s, logits, gold, rows, V, ld, pad_id, smoothing, lse,
+                       hyp, rowloss);
+    hipLaunchKernelGGL(sum_groups_kernel, dim3(rows / rows_per_group), dim3(256), 0, s, rowloss, rows_per_group, loss_out, inv_count_dev);
     MTL_CHECK_LAUNCH();
     return MTL_OK;
+}
+
+int mtl_ce_bwd_g(void* stream, const float* logits, const float* lse, const long* gold, int rows, int V, int ld, long pad_id,
+                 float smoothing, float gscale, const float* gscale_dev, float* dlogits, int ldd, int rows_per_group) {
+    if (!logits || !lse || !gold || !dlogits || rows <= 0 || rows_per_group <= 0) return MTL_EINVAL;
+    hipLaunchKernelGGL(ce_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, as_stream(stream), logits, lse, gold, rows, V, ld,
+                       pad_id, smoothing, gscale, gscale_dev, dlogits, ldd, rows_per_group);
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}
+
+int mtl_ce_bwd(void* stream, const float* logits, const float* lse, const long* gold, int rows, int V, int ld, long pad_id,
+               float smoothing, float gscale, const float* gscale_dev, float* dlogits, int ldd) {
+    return mtl_ce_bwd_g(stream, logits, lse, gold, rows, V, ld, pad_id, smoothing, gscale, gscale_dev, dlogits, ldd, rows > 0 ? rows : 1);
 }
 
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long n, float* __restrict__ amax) {

@@ -46,6 +46,8 @@ struct G16P {
     int kb;
     long sAk, sBk, sRow;
     long sBiasH, sRowH;           // strides of the INNER batch index for bias / rowsum
+    int Zt;                       // batch items per TASK (third, outermost batch level: z = (zt * Zt/H + zb) * H + zh)
+    long sAt, sBt, sCt, sBiasT, sRowT;
     int total;       // workgroups = tiles in N x tiles in M x batch
     const mtl_wgrad_desc* groups;   // grouped mode: one launch covers `ngroups` independent products (descriptor table in HBM)
     int ngroups;
@@ -147,9 +149,10 @@ __global__ __launch_bounds__(256 * KG) void gemm16_kernel(G16P p0) {
         rem = t - z * (nx * ny);
     }
     const int m0 = (rem / nx) * TM, n0 = (rem % nx) * TN;
-    const int zb = z / p.H, zh = z - zb * p.H;
-    const float* A = p.A + zb * p.sAb + zh * p.sAh;
-    const float* B = p.B + zb * p.sBb + zh * p.sBh;
+    const int zt = z / p.Zt, zz = z - zt * p.Zt;
+    const int zb = zz / p.H, zh = zz - zb * p.H;
+    const float* A = p.A + zt * p.sAt + zb * p.sAb + zh * p.sAh;
+    const float* B = p.B + zt * p.sBt + zb * p.sBb + zh * p.sBh;
     OA ra;
     OB rb;
     const int nk = (p.K + TK - 1) / TK, tiles = nk * p.kb, iters = (tiles + KG - 1) / KG;
@@ -254,14 +257,14 @@ __global__ __launch_bounds__(256 * KG) void gemm16_kernel(G16P p0) {
         __syncthreads();
     }
     if (kg == 0) {
-        const long co = zb * p.sCb + zh * p.sCh;
+        const long co = zt * p.sCt + zb * p.sCb + zh * p.sCh;
         float* C = p.C + co;
         const float* gate = p.gate ? p.gate + co : nullptr;
 #pragma unroll
         for (int j = 0; j < WN; ++j) {
             const int col = n0 + 16 * (2 * j + wn) + l16;
             if (col >= p.N) continue;
-            const float bb = p.bias ? p.bias[zb * p.sBias + zh * p.sBiasH + col] : 0.f;
+            const float bb = p.bias ? p.bias[zt * p.sBiasT + zb * p.sBias + zh * p.sBiasH + col] : 0.f;
 #pragma unroll
             for (int i = 0; i < WM; ++i) {
                 // the accumulate / gate operands of the four rows are requested together (clamped rows), then consumed
@@ -300,7 +303,7 @@ __global__ __launch_bounds__(256 * KG) void gemm16_kernel(G16P p0) {
         if (kg == 0 && tid < TM && m0 + tid < p.M) {
             float tsum = 0.f;
             for (int q = 0; q < KG * KL; ++q) tsum += red[q * LDR + tid];
-            p.rowsum[zb * p.sRow + zh * p.sRowH + m0 + tid] += tsum;
+            p.rowsum[zt * p.sRowT + zb * p.sRow + zh * p.sRowH + m0 + tid] += tsum;
         }
     }
 }
@@ -327,7 +330,7 @@ int launch_kg(const G16P& p, int batch, hipStream_t s, int kg) {
 template <bool TA, bool TB>
 int launch16(const G16P& p, int batch, hipStream_t s) {
     const bool vec = al16(p.A) && al16(p.B) && (p.lda & 3) == 0 && (p.ldb & 3) == 0 &&
-                     ((p.sAb | p.sAh | p.sBb | p.sBh | p.sAk | p.sBk) & 3) == 0;
+                     ((p.sAb | p.sAh | p.sBb | p.sBh | p.sAk | p.sBk | p.sAt | p.sBt) & 3) == 0;
     if (!vec) return launch_cfg<TA, TB, false, 1, 1, 1>(p, batch, s);     // dword loads: unaligned operands (rare)
     auto wgs = [&](int wm, int wn) { return (long)((p.M + 32 * wm - 1) / (32 * wm)) * ((p.N + 32 * wn - 1) / (32 * wn)) * batch; };
     // grow the tile while the grid still holds about one chip-full of workgroups (256 CUs); tuning knobs for tools/bench_gemm16.py
@@ -373,28 +376,40 @@ int mtl_gemm_wgrad_grouped(void* stream, const mtl_wgrad_desc* table_dev, int n_
     if (!table_dev || n_products <= 0 || total_tiles <= 0) return MTL_EINVAL;
     G16P p{};
     p.alpha = 1.f, p.flags = MTL_GEMM_ACCUM, p.H = 1, p.kb = 1, p.total = total_tiles, p.groups = table_dev, p.ngroups = n_products;
+    p.Zt = 1 << 30;
     dim3 grid(((total_tiles + 7) / 8) * 8);
     hipLaunchKernelGGL((gemm16_kernel<true, false, true, 4, 1, 1>), grid, dim3(1024), 0, as_stream(stream), p);
     MTL_CHECK_LAUNCH();
     return MTL_OK;
 }
 
-int mtl_gemm_f32_ex(void* stream, int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
+int mtl_gemm_f32_tb(void* stream, int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
                     const float* B, int ldb, float* C, int ldc, const float* bias, const float* gate, int ldg, int flags,
                     int batch, int H, long sAb, long sAh, long sBb, long sBh, long sCb, long sCh, long sBias, int kbatch, long sAk,
-                    long sBk, float* rowsum, long sRowsum, float* workspace, long workspace_bytes, long sBiasH, long sRowsumH) {
-    if (M <= 0 || N <= 0 || K <= 0 || batch <= 0 || H <= 0 || kbatch <= 0 || !A || !B || !C) return MTL_EINVAL;
+                    long sBk, float* rowsum, long sRowsum, float* workspace, long workspace_bytes, long sBiasH, long sRowsumH,
+                    int tasks, long sAt, long sBt, long sCt, long sBiasT, long sRowsumT) {
+    if (M <= 0 || N <= 0 || K <= 0 || batch <= 0 || H <= 0 || kbatch <= 0 || tasks <= 0 || !A || !B || !C) return MTL_EINVAL;
     if (rowsum && !transA) return MTL_EINVAL;
+    if (batch % tasks != 0 || (batch / tasks) % H != 0) return MTL_EINVAL;
     if (!route_small(M, N, K, batch, kbatch, rowsum != nullptr))
-        return mtl_gemm_f32_2l(stream, transA, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, bias, gate, ldg, flags, batch, H, sAb,
-                               sAh, sBb, sBh, sCb, sCh, sBias, sBiasH, workspace, workspace_bytes);
+        return mtl_gemm_f32_3l(stream, transA, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, bias, gate, ldg, flags, batch, H, sAb,
+                               sAh, sBb, sBh, sCb, sCh, sBias, sBiasH, workspace, workspace_bytes, tasks, sAt, sBt, sCt, sBiasT);
     G16P p{A, B, C, bias, gate, rowsum, M, N, K, lda, ldb, ldc, ldg, alpha, flags, H, sAb, sAh, sBb, sBh, sCb, sCh, sBias, kbatch,
-           sAk, sBk, sRowsum, sBiasH, sRowsumH, 0, nullptr, 0};
+           sAk, sBk, sRowsum, sBiasH, sRowsumH, batch / tasks, sAt, sBt, sCt, sBiasT, sRowsumT, 0, nullptr, 0};
     hipStream_t s = as_stream(stream);
     if (!transA && transB) return launch16<false, true>(p, batch, s);
     if (!transA && !transB) return launch16<false, false>(p, batch, s);
     if (transA && !transB) return launch16<true, false>(p, batch, s);
     return launch16<true, true>(p, batch, s);
+}
+
+int mtl_gemm_f32_ex(void* stream, int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
+                    const float* B, int ldb, float* C, int ldc, const float* bias, const float* gate, int ldg, int flags,
+                    int batch, int H, long sAb, long sAh, long sBb, long sBh, long sCb, long sCh, long sBias, int kbatch, long sAk,
+                    long sBk, float* rowsum, long sRowsum, float* workspace, long workspace_bytes, long sBiasH, long sRowsumH) {
+    return mtl_gemm_f32_tb(stream, transA, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, bias, gate, ldg, flags, batch, H, sAb, sAh,
+                           sBb, sBh, sCb, sCh, sBias, kbatch, sAk, sBk, rowsum, sRowsum, workspace, workspace_bytes, sBiasH, sRowsumH,
+                           1, 0, 0, 0, 0, 0);
 }
 
 }  // extern "C"

@@ -254,7 +254,20 @@ struct GemmP {
     long sBias;           // bias stride of the OUTER batch index (0: one bias for all)
     long sBiasH;          // ... and of the inner one
     int nz;               // batch items in total (grid.z without split-K)
+    int Zt;               // batch items per task (third, outermost batch level); nz when there is one task
+    long sAt, sBt, sCt, sBiasT;
 };
+
+// batch item z -> element offsets of its operands
+struct ZOff {
+    long a, b, c, bias;
+};
+__device__ __forceinline__ ZOff z_offsets(const GemmP& p, int z) {
+    const int zt = z / p.Zt, zz = z - zt * p.Zt;
+    const int zb = zz / p.H, zh = zz - zb * p.H;
+    return ZOff{zt * p.sAt + zb * p.sAb + zh * p.sAh, zt * p.sBt + zb * p.sBb + zh * p.sBh, zt * p.sCt + zb * p.sCb + zh * p.sCh,
+                zt * p.sBiasT + zb * p.sBias + zh * p.sBiasH};
+}
 
 struct EpiGemm {
     float* C;
@@ -295,11 +308,11 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
     if (p.ksplit > 1) {
         // split-K: this block owns k in [k0, k0+Kc) of batch item zi; partial sums are combined in fixed order by splitk_reduce_kernel
         const int zi = blockIdx.z / p.ksplit, zs = blockIdx.z - zi * p.ksplit;
-        const int zb = zi / p.H, zh = zi - zb * p.H;
+        const ZOff zo = z_offsets(p, zi);
         const int k0 = zs * p.kchunk;
         const int Kc = min(p.kchunk, p.K - k0);
-        const float* A = p.A + zb * p.sAb + zh * p.sAh;
-        const float* B = p.B + zb * p.sBb + zh * p.sBh;
+        const float* A = p.A + zo.a;
+        const float* B = p.B + zo.b;
         la.init(A + (TA ? (long)k0 * p.lda : (long)k0), p.lda, m0, p.M, Kc, tid);
         lb.init(B + (TB ? (long)k0 : (long)k0 * p.ldb), p.ldb, n0, p.N, Kc, tid);
         E::run(la, lb, (Kc + BK - 1) / BK, smem, acc);
@@ -307,15 +320,15 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
         E::finish(acc, epi);
         return;
     }
-    const int z = blockIdx.z, zb = z / p.H, zh = z % p.H;
-    const float* A = p.A + zb * p.sAb + zh * p.sAh;
-    const float* B = p.B + zb * p.sBb + zh * p.sBh;
-    float* C = p.C + zb * p.sCb + zh * p.sCh;
+    const ZOff zo = z_offsets(p, blockIdx.z);
+    const float* A = p.A + zo.a;
+    const float* B = p.B + zo.b;
+    float* C = p.C + zo.c;
     la.init(A, p.lda, m0, p.M, p.K, tid);
     lb.init(B, p.ldb, n0, p.N, p.K, tid);
     E::run(la, lb, (p.K + BK - 1) / BK, smem, acc);
-    const float* gate = p.gate ? p.gate + zb * p.sCb + zh * p.sCh : nullptr;
-    EpiGemm epi{C, p.bias ? p.bias + zb * p.sBias + zh * p.sBiasH : nullptr, gate, p.M, p.N, m0, n0, p.ldc, p.ldg, p.flags, p.alpha};
+    const float* gate = p.gate ? p.gate + zo.c : nullptr;
+    EpiGemm epi{C, p.bias ? p.bias + zo.bias : nullptr, gate, p.M, p.N, m0, n0, p.ldc, p.ldg, p.flags, p.alpha};
     E::finish(acc, epi);
 }
 
@@ -326,13 +339,13 @@ __global__ void splitk_reduce_kernel(GemmP p) {
         const int zi = (int)(e / mn);
         const long r = e - zi * mn;
         const int row = (int)(r / p.N), col = (int)(r - (long)row * p.N);
-        const int zb = zi / p.H, zh = zi - zb * p.H;
+        const ZOff zo = z_offsets(p, zi);
         const float* part = p.partial + (long)zi * p.ksplit * mn + r;
         float s = 0.f;
         for (int z = 0; z < p.ksplit; ++z) s += part[(long)z * mn];
-        float x = p.alpha * s + (p.bias ? p.bias[zb * p.sBias + zh * p.sBiasH + col] : 0.f);
+        float x = p.alpha * s + (p.bias ? p.bias[zo.bias + col] : 0.f);
         if (p.flags & MTL_GEMM_RELU) x = fmaxf(x, 0.f);
-        const long co = zb * p.sCb + zh * p.sCh;
+        const long co = zo.c;
         if (p.gate) x = p.gate[co + (long)row * p.ldg + col] > 0.f ? x : 0.f;
         float* c = p.C + co + (long)row * p.ldc + col;
         if (p.flags & MTL_GEMM_ACCUM) x += *c;
@@ -367,7 +380,7 @@ template <int BM, int BN, bool TA, bool TB>
 int launch_gemm(const GemmP& p, int batch, hipStream_t s) {
     // 16-byte operand loads need 16-byte aligned bases/strides (true for every call of the pass except an
     // odd-width logits matrix); everything else takes the dword-load instantiation
-    const bool vec = aligned16(p.A) && aligned16(p.B) && (p.lda & 3) == 0 && (p.ldb & 3) == 0 && ((p.sAb | p.sAh | p.sBb | p.sBh) & 3) == 0;
+    const bool vec = aligned16(p.A) && aligned16(p.B) && (p.lda & 3) == 0 && (p.ldb & 3) == 0 && ((p.sAb | p.sAh | p.sBb | p.sBh | p.sAt | p.sBt) & 3) == 0;
     return vec ? launch_gemm_v<BM, BN, TA, TB, true>(p, batch, s) : launch_gemm_v<BM, BN, TA, TB, false>(p, batch, s);
 }
 
@@ -1699,12 +1712,15 @@ __global__ void conv_wprep_kernel(const float* w, float* wf, float* wd, int Cout
 }  // namespace
 
 // ================================================================== C ABI
-// mtl_gemm_f32 with a bias stride for the inner batch index too (library-internal: mtl_gemm_f32_ex forwards here)
-int mtl_gemm_f32_2l(void* stream, int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda, const float* B,
+// mtl_gemm_f32 with a bias stride for the inner batch index too and a third, outermost batch level (library-internal:
+// mtl_gemm_f32_tb forwards here)
+int mtl_gemm_f32_3l(void* stream, int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda, const float* B,
                     int ldb, float* C, int ldc, const float* bias, const float* gate, int ldg, int flags, int batch, int H, long sAb,
-                    long sAh, long sBb, long sBh, long sCb, long sCh, long sBias, long sBiasH, float* workspace, long workspace_bytes) {
-    if (M <= 0 || N <= 0 || K <= 0 || batch <= 0 || H <= 0 || !A || !B || !C) return MTL_EINVAL;
-    GemmP p{A, B, C, bias, gate, M, N, K, lda, ldb, ldc, ldg, alpha, flags, H, sAb, sAh, sBb, sBh, sCb, sCh, 1, 0, nullptr, sBias, sBiasH, batch};
+                    long sAh, long sBb, long sBh, long sCb, long sCh, long sBias, long sBiasH, float* workspace, long workspace_bytes,
+                    int tasks, long sAt, long sBt, long sCt, long sBiasT) {
+    if (M <= 0 || N <= 0 || K <= 0 || batch <= 0 || H <= 0 || tasks <= 0 || batch % tasks || !A || !B || !C) return MTL_EINVAL;
+    GemmP p{A, B, C, bias, gate, M, N, K, lda, ldb, ldc, ldg, alpha, flags, H, sAb, sAh, sBb, sBh, sCb, sCh, 1, 0, nullptr, sBias, sBiasH, batch,
+            batch / tasks, sAt, sBt, sCt, sBiasT};
     hipStream_t s = as_stream(stream);
     if (!transA && transB) return dispatch_gemm<false, true>(p, batch, s, workspace, workspace_bytes);
     if (!transA && !transB) return dispatch_gemm<false, false>(p, batch, s, workspace, workspace_bytes);
@@ -1718,8 +1734,8 @@ int mtl_gemm_f32(void* stream, int transA, int transB, int M, int N, int K, floa
                  const float* B, int ldb, float* C, int ldc, const float* bias, const float* gate, int ldg, int flags,
                  int batch, int H, long sAb, long sAh, long sBb, long sBh, long sCb, long sCh, long sBias, float* workspace,
                  long workspace_bytes) {
-    return mtl_gemm_f32_2l(stream, transA, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, bias, gate, ldg, flags, batch, H, sAb, sAh, sBb,
-                           sBh, sCb, sCh, sBias, 0, workspace, workspace_bytes);
+    return mtl_gemm_f32_3l(stream, transA, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, bias, gate, ldg, flags, batch, H, sAb, sAh, sBb,
+                           sBh, sCb, sCh, sBias, 0, workspace, workspace_bytes, 1, 0, 0, 0, 0);
 }
 
 int mtl_conv3x3_wprep(void* stream, const float* w_ref, float* w_fwd, float* w_dgrad, int Cout, int Cin) {

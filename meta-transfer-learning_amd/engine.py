@@ -261,6 +261,10 @@ class PassEngine:
         # outside mtl_attn_supported() take the batched-GEMM + softmax path ('0' forces it, for A/B measurements)
         self.fused_attn = (os.environ.get('MTL_FUSED_ATTN', '1') != '0' and device.type == 'cuda'
                            and bool(self.lib.mtl_attn_supported(hp.dk, hp.dv)))
+        # task batching: a pass may carry the batches of `nt` tasks of a meta-step (rows of task t follow those of task t - 1); task t
+        # reads its parameters at theta + t * sP floats (0: all tasks share theta0 -- the training passes) and accumulates its
+        # gradients at grad + t * sG (see forward_device / backward)
+        self.nt, self.sP, self.sG = 1, 0, 0
         self.prof = None    # set (to anything) while a profiling proxy stands in for self.lib: replay / graphs / lane tricks are bypassed
         if device.type != 'cuda':
             raise RuntimeError('PassEngine needs an MI355X device (got %s); there is no CPU product path' % device)
@@ -311,13 +315,23 @@ class PassEngine:
         return torch.cuda.current_stream(self.device).cuda_stream
 
     def gemm(self, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias=None, gate=None, ldg=0, flags=0, alpha=1.0,
-             batch=1, H=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), sbias=0, kbatch=1, sAk=0, sBk=0, rowsum=None, srow=0, sbias_h=0, srow_h=0):
+             batch=1, H=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), sbias=0, kbatch=1, sAk=0, sBk=0, rowsum=None, srow=0, sbias_h=0, srow_h=0,
+             task=None):
         """kbatch / sAk / sBk: sum over several (A, B) pairs inside one launch; rowsum: += row sums of op(A) (bias gradient);
-        sbias / srow stride the OUTER batch index z // H, sbias_h / srow_h the inner one z % H."""
+        sbias / srow stride the OUTER batch index z // H, sbias_h / srow_h the inner one z % H.
+        task = (sAt, sBt, sCt, sbias_t, srow_t): strides of the task index of a task-batched pass (the product is issued once with
+        `batch` items PER TASK; mandatory when the pass carries several tasks)."""
         wst = self.gemm_ws_side if self.on_side else self.gemm_ws
-        check(self.lib.mtl_gemm_f32_ex(self.stream, ta, tb, M, N, K, alpha, A, lda, B, ldb, C, ldc, bias, gate, ldg, flags,
-                                       batch, H, sA[0], sA[1], sB[0], sB[1], sC[0], sC[1], sbias, kbatch, sAk, sBk, rowsum, srow,
-                                       wst.data_ptr(), wst.numel() * 4, sbias_h, srow_h), 'mtl_gemm_f32_ex')
+        if self.nt == 1:
+            check(self.lib.mtl_gemm_f32_ex(self.stream, ta, tb, M, N, K, alpha, A, lda, B, ldb, C, ldc, bias, gate, ldg, flags,
+                                           batch, H, sA[0], sA[1], sB[0], sB[1], sC[0], sC[1], sbias, kbatch, sAk, sBk, rowsum, srow,
+                                           wst.data_ptr(), wst.numel() * 4, sbias_h, srow_h), 'mtl_gemm_f32_ex')
+            return
+        if task is None:
+            raise RuntimeError('task strides missing for a product of a task-batched pass')
+        check(self.lib.mtl_gemm_f32_tb(self.stream, ta, tb, M, N, K, alpha, A, lda, B, ldb, C, ldc, bias, gate, ldg, flags,
+                                       batch * self.nt, H, sA[0], sA[1], sB[0], sB[1], sC[0], sC[1], sbias, kbatch, sAk, sBk, rowsum,
+                                       srow, wst.data_ptr(), wst.numel() * 4, sbias_h, srow_h, self.nt, *task), 'mtl_gemm_f32_tb')
 
     # ---- byte-level helpers and flat-vector updates as LIBRARY calls (a task body made of library calls only can be recorded
     # into a command list and replayed from C; torch's own fill / copy kernels cannot)
@@ -349,7 +363,7 @@ class PassEngine:
 
     # ---- fused low-rank pairs
     def pair_ok(self, k_in, n_out):
-        return self.fused_pairs and bool(self.lib.mtl_lowrank_supported(k_in, self.hp.r, n_out))
+        return self.fused_pairs and self.nt == 1 and bool(self.lib.mtl_lowrank_supported(k_in, self.hp.r, n_out))
 
     def pair(self, x, sx, ldx, A, sA, B, sB, bias, sbias, t, st, y, sy, ldy, M, k_in, n_out, n, sum_z=0, accum=0):
         check(self.lib.mtl_lowrank_pair(self.stream, x, sx, ldx, A, sA, B, sB, bias, sbias, t, st, y, sy, ldy, M, k_in, self.hp.r, n_out,
@@ -394,10 +408,11 @@ class PassEngine:
         if kind is not None and self.layer_wgrads:
             self.wgrad_job(kind, n_out, k_in, rows, dy, n_out, x, k_in, dw, k_in, rowsum=db)
             return
-        if self.group_wgrads and self.lib.mtl_gemm_f32_ex_route(n_out, k_in, rows, 1, 1, 1 if db else 0):
+        if self.group_wgrads and self.nt == 1 and self.lib.mtl_gemm_f32_ex_route(n_out, k_in, rows, 1, 1, 1 if db else 0):
             self.wgrads.append((int(dy), int(x), int(dw), int(db or 0), n_out, k_in, rows, n_out, k_in, k_in))
         else:
-            self.defer(lambda: self.gemm(1, 0, n_out, k_in, rows, dy, n_out, x, k_in, dw, k_in, flags=ACCUM, rowsum=db))
+            self.defer(lambda: self.gemm(1, 0, n_out, k_in, rows, dy, n_out, x, k_in, dw, k_in, flags=ACCUM, rowsum=db,
+                                         task=(rows * n_out, rows * k_in, self.sG, 0, self.sG)))
 
     def flush_wgrads(self):
         """issue the registered products (their operands are per-block buffers that stay intact until the end of the backward):
@@ -442,19 +457,20 @@ class PassEngine:
             nl = len(items)
             steps = [tuple(b[j] - a[j] for j in range(4)) for a, b in zip(items, items[1:])]
             merged = nl > 1 and all(st == steps[0] for st in steps) and all(v % 16 == 0 for v in steps[0])
+            tk = (K * lda, K * ldb, self.sG, 0, self.sG)       # task t: its K rows of dy / x, its slice of the gradient stack
             if merged:
                 dC, dA, dB, dR = (v // 4 for v in steps[0])
                 C0, A0, B0, R0 = items[0]
                 self.defer(lambda M=M, N=N, K=K, A0=A0, lda=lda, B0=B0, ldb=ldb, C0=C0, ldc=ldc, nl=nl, n=n, dA=dA, sA=sA, dB=dB, sB=sB,
-                           dC=dC, sC=sC, R0=R0, dR=dR, srow=srow, has_rs=has_rs: self.gemm(
+                           dC=dC, sC=sC, R0=R0, dR=dR, srow=srow, has_rs=has_rs, tk=tk: self.gemm(
                     1, 0, M, N, K, A0, lda, B0, ldb, C0, ldc, flags=ACCUM, batch=nl * n, H=n, sA=(dA, sA), sB=(dB, sB), sC=(dC, sC),
-                    rowsum=R0 if has_rs else None, srow=dR, srow_h=srow))
+                    rowsum=R0 if has_rs else None, srow=dR, srow_h=srow, task=tk))
             else:
                 for C0, A0, B0, R0 in items:
                     self.defer(lambda M=M, N=N, K=K, A0=A0, lda=lda, B0=B0, ldb=ldb, C0=C0, ldc=ldc, n=n, sA=sA, sB=sB, sC=sC, R0=R0,
-                               srow=srow, has_rs=has_rs: self.gemm(
+                               srow=srow, has_rs=has_rs, tk=tk: self.gemm(
                         1, 0, M, N, K, A0, lda, B0, ldb, C0, ldc, flags=ACCUM, batch=n, sA=(sA, 0), sB=(sB, 0), sC=(sC, 0),
-                        rowsum=R0 if has_rs else None, srow=srow))
+                        rowsum=R0 if has_rs else None, srow=srow, task=tk))
         self.flush_side()
 
     # ---- side stream: deferred parameter-gradient work
@@ -526,7 +542,9 @@ class PassEngine:
             check(self.lib.mtl_stream_wait_event(self.stream, ev), 'mtl_stream_wait_event')
 
     def linear_fwd(self, x, rows, k_in, w, b, y, n_out, relu=False):
-        self.gemm(0, 1, rows, n_out, k_in, x, k_in, w, k_in, y, n_out, bias=b, flags=RELU if relu else 0)
+        """rows: per task; the rows of task t are x + t * rows * k_in, its weights w + t * sP"""
+        self.gemm(0, 1, rows, n_out, k_in, x, k_in, w, k_in, y, n_out, bias=b, flags=RELU if relu else 0,
+                  task=(rows * k_in, self.sP, rows * n_out, self.sP, 0))
 
     def linear_bwd(self, x, dy, rows, k_in, n_out, w, dw, db, dx, dx_accum, gate=None, kind=None):
         """dw += dy^T x ; db += colsum(dy) (db None: no bias, or already produced by the LayerNorm backward) ;
@@ -534,7 +552,7 @@ class PassEngine:
         self.wgrad(dy, x, rows, n_out, k_in, dw, db, kind=kind)     # db rides on the weight-gradient product (row sums of dy^T)
         if dx is not None:
             self.gemm(0, 0, rows, k_in, n_out, dy, n_out, w, k_in, dx, k_in, gate=gate, ldg=k_in,
-                      flags=ACCUM if dx_accum else 0)
+                      flags=ACCUM if dx_accum else 0, task=(rows * n_out, self.sP, rows * k_in, 0, 0))
 
     def colsum(self, x, rows, cols, out, amax=None):
         ws = self.scratch(self.lib.mtl_colsum_workspace(rows, cols))
@@ -556,18 +574,27 @@ class PassEngine:
         return 1.0 / (1.0 - self.dropout_p)
 
     def ln_fwd(self, x, res, g, b, pe, keep, y, xhat, rstd, rows, T, xmask=None):
-        check(self.lib.mtl_layernorm_fwd(self.stream, x, res, g, b, pe, keep, xmask.data_ptr() if xmask is not None else None,
-                                         self.drop_scale, y, xhat, rstd, rows, self.hp.d, T, 1e-5), 'mtl_layernorm_fwd')
+        """rows: per task (the tasks' row blocks follow each other; task t normalises with g / b + t * sP)"""
+        check(self.lib.mtl_layernorm_fwd_g(self.stream, x, res, g, b, pe, keep, xmask.data_ptr() if xmask is not None else None,
+                                           self.drop_scale, y, xhat, rstd, rows * self.nt, self.hp.d, T, 1e-5, rows, self.sP),
+              'mtl_layernorm_fwd_g')
 
     def ln_bwd(self, dy, xhat, rstd, g, keep, dz, dg, db, rows, dsum=None, xmask=None, dzm=None, dz2=None):
         """LayerNorm backward; the reduction of its per-wave partials into dgamma / dbeta / dsum is DEFERRED: every instance keeps
         its partials in its own buffer and flush_ln_reduce() adds all of them with one launch (17 launches of 5 us before)."""
-        d = self.hp.d
-        nbytes = self.lib.mtl_layernorm_bwd_workspace(rows, d)
+        d, nt = self.hp.d, self.nt
+        nbytes = self.lib.mtl_layernorm_bwd_g_workspace(rows * nt, d, rows)
         part = self.buf('lnpart.%x' % xhat, (nbytes // 4,))
-        check(self.lib.mtl_layernorm_bwd(self.stream, dy, xhat, rstd, g, keep, xmask.data_ptr() if xmask is not None else None,
-                                         self.drop_scale, dz, dzm, dz2, dg, db, dsum, part.data_ptr(), rows, d, 1), 'mtl_layernorm_bwd')
-        self._ln_pending.append((part.data_ptr(), dg, db, dsum or 0, nbytes // (3 * d * 4), d))
+        check(self.lib.mtl_layernorm_bwd_g(self.stream, dy, xhat, rstd, g, keep, xmask.data_ptr() if xmask is not None else None,
+                                           self.drop_scale, dz, dzm, dz2, dg, db, dsum, part.data_ptr(), rows * nt, d, 1, rows, self.sP,
+                                           self.sG), 'mtl_layernorm_bwd_g')
+        if nt == 1:
+            self._ln_pending.append((part.data_ptr(), dg, db, dsum or 0, nbytes // (3 * d * 4), d))
+        else:       # task t: its partial rows, its slice of the gradient stack
+            wpg = self.lib.mtl_layernorm_bwd_g_waves(rows)
+            for t in range(nt):
+                go = 4 * t * self.sG
+                self._ln_pending.append((part.data_ptr() + 4 * t * wpg * 3 * d, dg + go, db + go, (dsum + go) if dsum else 0, wpg, d))
 
     def flush_ln_reduce(self):
         pend, self._ln_pending = tuple(self._ln_pending), []
@@ -585,9 +612,12 @@ class PassEngine:
 
     # ---------------------------------------------------------------- attention / ffn blocks
     def mha_fwd(self, tag, P, pre, xq, Bn, Tq, xkv, Tk, klen, causal, keep, kv_ready=None):
-        hp, L = self.hp, self.L
+        """Bn: samples PER TASK; the pass carries self.nt tasks whose row blocks (Bn * Tq query rows, Bn * Tk key rows each) follow
+        each other in every activation buffer."""
+        hp, L, nt, sP = self.hp, self.L, self.nt, self.sP
         d, r, h, dk, dv = hp.d, hp.r, hp.h, hp.dk, hp.dv
-        Mq, Mk = Bn * Tq, Bn * Tk
+        Mq, Mk = Bn * Tq, Bn * Tk                      # rows per task
+        Rq = nt * Mq                                   # rows of the pass
         hk, hv = h * dk, h * dv
         o = lambda n: P + 4 * L.off(pre + n)
         t = {}
@@ -605,30 +635,35 @@ class PassEngine:
                     self.arena[tag + nm + 'a'], self.arena[tag + nm] = a_all[i], b_all[i]
                     t[nm + 'a'], t[nm] = a_all[i], b_all[i]
                 continue
-            a_all = self.buf(tag + names + 'a', (n, rows, r))
-            b_all = self.buf(tag + names, (n, rows, wd))
+            R = nt * rows
+            a_all = self.buf(tag + names + 'a', (n, R, r))
+            b_all = self.buf(tag + names, (n, R, wd))
             sa, sb, sbias = (self._pstride(pre, names, sfx) for sfx in ('_linear_a.weight', '_linear_b.weight', '_linear_b.bias'))
             if self.pair_ok(d, wd):
                 self.pair(src, 0, d, o(f0 + '_linear_a.weight'), sa, o(f0 + '_linear_b.weight'), sb, o(f0 + '_linear_b.bias'), sbias,
                           a_all.data_ptr(), rows * r, b_all.data_ptr(), rows * wd, wd, rows, d, wd, n)
             else:
                 self.gemm(0, 1, rows, r, d, src, d, o(f0 + '_linear_a.weight'), d, a_all.data_ptr(), r, batch=n, sB=(sa, 0),
-                          sC=(rows * r, 0))
+                          sC=(R * r, 0), task=(rows * d, sP, rows * r, 0, 0))
                 self.gemm(0, 1, rows, wd, r, a_all.data_ptr(), r, o(f0 + '_linear_b.weight'), r, b_all.data_ptr(), wd,
-                          bias=o(f0 + '_linear_b.bias'), batch=n, sA=(rows * r, 0), sB=(sb, 0), sC=(rows * wd, 0), sbias=sbias)
+                          bias=o(f0 + '_linear_b.bias'), batch=n, sA=(R * r, 0), sB=(sb, 0), sC=(R * wd, 0), sbias=sbias,
+                          task=(rows * r, sP, rows * wd, sP, 0))
             for i, nm in enumerate(names):
                 self.arena[tag + nm + 'a'], self.arena[tag + nm] = a_all[i], b_all[i]
                 t[nm + 'a'], t[nm] = a_all[i], b_all[i]
         self.arena[tag + 'groups'] = groups
         ldS = (Tk + 3) // 4 * 4
+        Bn = nt * Bn                                   # the attention core sees one batch of all tasks' samples (no parameters)
         mP = self.drop_mask(tag + 'mP', (Bn, h, Tq, ldS))                       # dropout on the probabilities (:328)
-        O = self.buf(tag + 'O', (Mq, hv))
+        O = self.buf(tag + 'O', (Rq, hv))
         if self.fused_attn:
             lse = self.buf(tag + 'lse', (Bn, h, Tq))
             check(self.lib.mtl_attn_fwd(self.stream, t['q'].data_ptr(), t['k'].data_ptr(), t['v'].data_ptr(), hk, hk, hv, klen, causal,
                                         1.0 / float(hp.temperature), Bn, h, Tq, Tk, dk, dv, mP.data_ptr() if mP is not None else None,
                                         ldS, self.drop_scale, O.data_ptr(), hv, lse.data_ptr()), 'mtl_attn_fwd')
         else:
+            if nt > 1:
+                raise NotImplementedError('task-batched passes need the fused attention kernel (head sizes of mtl_attn_supported)')
             S = self.buf(tag + 'P', (Bn, h, Tq, ldS))
             self.gemm(0, 1, Tq, Tk, dk, t['q'].data_ptr(), hk, t['k'].data_ptr(), hk, S.data_ptr(), ldS, batch=Bn * h, H=h,
                       sA=(Tq * hk, dk), sB=(Tk * hk, dk), sC=(h * Tq * ldS, Tq * ldS))
@@ -639,18 +674,18 @@ class PassEngine:
             self.gemm(0, 0, Tq, dv, Tk, Pd.data_ptr(), ldS, t['v'].data_ptr(), hv, O.data_ptr(), hv, batch=Bn * h, H=h,
                       sA=(h * Tq * ldS, Tq * ldS), sB=(Tk * hv, dv), sC=(Tq * hv, dv))
         self.arena[tag + 'attn'] = (klen, causal)
-        oa = self.buf(tag + 'oa', (Mq, r))
-        ob = self.buf(tag + 'ob', (Mq, d))
+        oa = self.buf(tag + 'oa', (Rq, r))
+        ob = self.buf(tag + 'ob', (Rq, d))
         if self.pair_ok(hv, d):
             self.pair(O.data_ptr(), 0, hv, o('output_linear_a.weight'), 0, o('output_linear_b.weight'), 0, o('output_linear_b.bias'), 0,
                       oa.data_ptr(), 0, ob.data_ptr(), 0, d, Mq, hv, d, 1)
         else:
             self.linear_fwd(O.data_ptr(), Mq, hv, o('output_linear_a.weight'), None, oa.data_ptr(), r)
             self.linear_fwd(oa.data_ptr(), Mq, r, o('output_linear_b.weight'), o('output_linear_b.bias'), ob.data_ptr(), d)
-        y = self.buf(tag + 'y', (Mq, d))
-        xhat = self.buf(tag + 'xhat', (Mq, d))
-        rstd = self.buf(tag + 'rstd', (Mq,))
-        mo = self.drop_mask(tag + 'mo', (Mq, d))                                # dropout before the residual add (:303)
+        y = self.buf(tag + 'y', (Rq, d))
+        xhat = self.buf(tag + 'xhat', (Rq, d))
+        rstd = self.buf(tag + 'rstd', (Rq,))
+        mo = self.drop_mask(tag + 'mo', (Rq, d))                                # dropout before the residual add (:303)
         self.ln_fwd(ob.data_ptr(), xq, o('layer_norm.weight'), o('layer_norm.bias'), None, keep, y.data_ptr(),
                     xhat.data_ptr(), rstd.data_ptr(), Mq, Tq, xmask=mo)
         return y
@@ -659,9 +694,10 @@ class PassEngine:
         """dy: grad of the block output.  Writes dxq (overwrite) and dxkv (accumulate when dxkv is dxq or flagged).
         dkv_hoisted: (2, rows, h d_k) slice that receives dK / dV when the K / V projections' backward runs once for all decoder
         layers afterwards (cross_kv_bwd); dxkv is not touched then."""
-        hp, L, A = self.hp, self.L, self.arena
+        hp, L, A, nt, sP, sG = self.hp, self.L, self.arena, self.nt, self.sP, self.sG
         d, r, h, dk, dv = hp.d, hp.r, hp.h, hp.dk, hp.dv
-        Mq, Mk = Bn * Tq, Bn * Tk
+        Mq, Mk = Bn * Tq, Bn * Tk                      # rows per task
+        Rq = nt * Mq
         hk, hv = h * dk, h * dv
         o = lambda n: P + 4 * L.off(pre + n)
         g = lambda n: G + 4 * L.off(pre + n)
@@ -669,15 +705,15 @@ class PassEngine:
         O, oa = A[tag + 'O'], A[tag + 'oa']
         kd = _LAYER_BUF.sub(r'\1*.\3', tag)              # 'd3.sa.' -> 'd*.sa.': the kind prefix of this block's weight gradients
         # LayerNorm(o + residual) * keep
-        dzb = self.buf(tag + '_dz', (Mq, d))       # kept intact for the deferred dW GEMM; dxq = dz + projections
+        dzb = self.buf(tag + '_dz', (Rq, d))       # kept intact for the deferred dW GEMM; dxq = dz + projections
         mo, mP = A.get(tag + 'mo'), A.get(tag + 'mP')
-        dzm = self.buf(tag + '_dzm', (Mq, d)) if mo is not None else None
+        dzm = self.buf(tag + '_dzm', (Rq, d)) if mo is not None else None
         self.ln_bwd(dy, A[tag + 'xhat'].data_ptr(), A[tag + 'rstd'].data_ptr(), o('layer_norm.weight'), keep, dzb.data_ptr(),
                     g('layer_norm.weight'), g('layer_norm.bias'), Mq, dsum=g('output_linear_b.bias'), xmask=mo,
                     dzm=dzm.data_ptr() if dzm is not None else None, dz2=dxq)        # dxq = dz: the residual path
         dz = dzm.data_ptr() if dzm is not None else dzb.data_ptr()          # gradient of the (dropped) sub-layer branch
-        doa = self.buf(tag + '_doa', (Mq, r))
-        dO = self.buf(tag + '_dO', (Mq, hv))
+        doa = self.buf(tag + '_doa', (Rq, r))
+        dO = self.buf(tag + '_dO', (Rq, hv))
         if self.pair_ok(d, hv):
             wt = lambda n: self._wT + 4 * L.off(pre + n)
             self.wgrad(dz, oa.data_ptr(), Mq, d, r, g('output_linear_b.weight'), kind=kd + 'ob')
@@ -695,16 +731,16 @@ class PassEngine:
         dfull = {}                                       # gradients of the projected q / k / v, grouped like the forward
         for names, _src, rows in groups:
             d_all = (dkv_hoisted if (dkv_hoisted is not None and names == 'kv') else
-                     self.buf(tag + '_d' + names, (len(names), rows, hv if names == 'v' else hk)))
+                     self.buf(tag + '_d' + names, (len(names), nt * rows, hv if names == 'v' else hk)))
             for i, nm in enumerate(names):
                 dfull[nm] = d_all[i]
             dfull[names] = d_all
         dq, dkk, dvv = dfull['q'], dfull['k'], dfull['v']
         if self.fused_attn:
             klen, causal = A[tag + 'attn']
-            delta = self.buf('_delta.side' if self.on_side else '_delta', (Bn * h * Tq,))
+            delta = self.buf('_delta.side' if self.on_side else '_delta', (nt * Bn * h * Tq,))
             check(self.lib.mtl_attn_bwd(self.stream, q.data_ptr(), k.data_ptr(), v.data_ptr(), hk, hk, hv, klen, causal,
-                                        1.0 / float(hp.temperature), Bn, h, Tq, Tk, dk, dv, mP.data_ptr() if mP is not None else None,
+                                        1.0 / float(hp.temperature), nt * Bn, h, Tq, Tk, dk, dv, mP.data_ptr() if mP is not None else None,
                                         ldS, self.drop_scale, O.data_ptr(), dO.data_ptr(), hv, A[tag + 'lse'].data_ptr(),
                                         delta.data_ptr(), dq.data_ptr(), dkk.data_ptr(), dvv.data_ptr(), hk, hk, hv), 'mtl_attn_bwd')
         else:
@@ -731,7 +767,8 @@ class PassEngine:
             n, f0 = len(names), _FULL[names[0]]
             wd = hv if names == 'v' else hk
             a_all, d_all = A[tag + names + 'a'], dfull[names]
-            da_all = self.buf(tag + '_da' + names, (n, rows, r))
+            R = nt * rows
+            da_all = self.buf(tag + '_da' + names, (n, R, r))
             sa, sb, sbias = (self._pstride(pre, names, sfx) for sfx in ('_linear_a.weight', '_linear_b.weight', '_linear_b.bias'))
             a_ptr, d_ptr, da_ptr = a_all.data_ptr(), d_all.data_ptr(), da_all.data_ptr()
 
@@ -741,27 +778,28 @@ class PassEngine:
                     self.wgrad(d_ptr + 4 * i * rows * wd, a_ptr + 4 * i * rows * r, rows, wd, r, g(_FULL[nm] + '_linear_b.weight'),
                                g(_FULL[nm] + '_linear_b.bias'))
             elif self.layer_wgrads and not (dkv_hoisted is not None and names == 'kv'):
-                self.wgrad_job(kd + names + '.b', wd, r, rows, d_ptr, wd, a_ptr, r, g(f0 + '_linear_b.weight'), r, n=n, sA=rows * wd,
-                               sB=rows * r, sC=sb, rowsum=g(f0 + '_linear_b.bias'), srow=sbias)
+                self.wgrad_job(kd + names + '.b', wd, r, rows, d_ptr, wd, a_ptr, r, g(f0 + '_linear_b.weight'), r, n=n, sA=R * wd,
+                               sB=R * r, sC=sb, rowsum=g(f0 + '_linear_b.bias'), srow=sbias)
             else:       # one strided-batch call on the side stream (outputs strided into G)
-                self.defer(lambda n=n, f0=f0, rows=rows, a_ptr=a_ptr, d_ptr=d_ptr, sb=sb, sbias=sbias, wd=wd: self.gemm(
-                    1, 0, wd, r, rows, d_ptr, wd, a_ptr, r, g(f0 + '_linear_b.weight'), r, flags=ACCUM, batch=n, sA=(rows * wd, 0),
-                    sB=(rows * r, 0), sC=(sb, 0), rowsum=g(f0 + '_linear_b.bias'), srow=sbias))
+                self.defer(lambda n=n, f0=f0, rows=rows, R=R, a_ptr=a_ptr, d_ptr=d_ptr, sb=sb, sbias=sbias, wd=wd: self.gemm(
+                    1, 0, wd, r, rows, d_ptr, wd, a_ptr, r, g(f0 + '_linear_b.weight'), r, flags=ACCUM, batch=n, sA=(R * wd, 0),
+                    sB=(R * r, 0), sC=(sb, 0), rowsum=g(f0 + '_linear_b.bias'), srow=sbias, task=(rows * wd, rows * r, sG, 0, sG)))
             fused = self.pair_ok(wd, d)
             if not fused:     # da[i] = d[i] . W_b[i]
-                self.gemm(0, 0, rows, r, wd, d_ptr, wd, o(f0 + '_linear_b.weight'), r, da_ptr, r, batch=n, sA=(rows * wd, 0),
-                          sB=(sb, 0), sC=(rows * r, 0))
+                self.gemm(0, 0, rows, r, wd, d_ptr, wd, o(f0 + '_linear_b.weight'), r, da_ptr, r, batch=n, sA=(R * wd, 0),
+                          sB=(sb, 0), sC=(R * r, 0), task=(rows * wd, sP, rows * r, 0, 0))
 
             # dW_a[i] += da[i]^T x
             if self.group_wgrads:
                 for i, nm in enumerate(names):
                     self.wgrad(da_ptr + 4 * i * rows * r, src, rows, r, d, g(_FULL[nm] + '_linear_a.weight'))
             elif self.layer_wgrads:
-                self.wgrad_job(kd + names + '.a', r, d, rows, da_ptr, r, src, d, g(f0 + '_linear_a.weight'), d, n=n, sA=rows * r, sB=0,
+                self.wgrad_job(kd + names + '.a', r, d, rows, da_ptr, r, src, d, g(f0 + '_linear_a.weight'), d, n=n, sA=R * r, sB=0,
                                sC=sa)
             else:
-                self.defer(lambda n=n, f0=f0, rows=rows, da_ptr=da_ptr, src=src, sa=sa: self.gemm(
-                    1, 0, r, d, rows, da_ptr, r, src, d, g(f0 + '_linear_a.weight'), d, flags=ACCUM, batch=n, sA=(rows * r, 0), sC=(sa, 0)))
+                self.defer(lambda n=n, f0=f0, rows=rows, R=R, da_ptr=da_ptr, src=src, sa=sa: self.gemm(
+                    1, 0, r, d, rows, da_ptr, r, src, d, g(f0 + '_linear_a.weight'), d, flags=ACCUM, batch=n, sA=(R * r, 0), sC=(sa, 0),
+                    task=(rows * r, rows * d, sG, 0, 0)))
             # dx (+)= sum_i da[i] . W_a[i]: the items of a group accumulate into ONE tensor -> one K-batched launch
             if names[0] == 'q':
                 dst, accum = dxq, True
@@ -774,7 +812,7 @@ class PassEngine:
                           sum_z=1, accum=1 if accum else 0)
             else:
                 self.gemm(0, 0, rows, d, r, da_ptr, r, o(f0 + '_linear_a.weight'), d, dst, d, flags=ACCUM if accum else 0,
-                          kbatch=n, sAk=rows * r, sBk=sa)
+                          kbatch=n, sAk=R * r, sBk=sa, task=(rows * r, sP, rows * d, 0, 0))
         self.flush_side(0)
 
     # ---- encoder-decoder attention: K / V projections of all decoder layers in one go
@@ -803,39 +841,42 @@ class PassEngine:
         self.arena['xkv.plan'] = plan
         if plan is None:
             return None
-        hp, L = self.hp, self.L
+        hp, L, nt, sP = self.hp, self.L, self.nt, self.sP
         Ls, Ps = plan
         d, r, wd, NL = hp.d, hp.r, hp.h * hp.dk, hp.n_dec
+        Rk = nt * Mk                                   # Mk: key rows per task
         o0 = lambda n: P + 4 * L.off('decoder.layers.0.encoder_attn.' + n)
-        a_all = self.buf('xkv.a', (NL, 2, Mk, r))
-        b_all = self.buf('xkv.b', (NL, 2, Mk, wd))
+        a_all = self.buf('xkv.a', (NL, 2, Rk, r))
+        b_all = self.buf('xkv.b', (NL, 2, Rk, wd))
         self.gemm(0, 1, Mk, r, d, mem, d, o0('key_linear_a.weight'), d, a_all.data_ptr(), r, batch=2 * NL, H=2, sB=(Ls, Ps),
-                  sC=(2 * Mk * r, Mk * r))
+                  sC=(2 * Rk * r, Rk * r), task=(Mk * d, sP, Mk * r, 0, 0))
         self.gemm(0, 1, Mk, wd, r, a_all.data_ptr(), r, o0('key_linear_b.weight'), r, b_all.data_ptr(), wd, bias=o0('key_linear_b.bias'),
-                  batch=2 * NL, H=2, sA=(2 * Mk * r, Mk * r), sB=(Ls, Ps), sC=(2 * Mk * wd, Mk * wd), sbias=Ls, sbias_h=Ps)
+                  batch=2 * NL, H=2, sA=(2 * Rk * r, Rk * r), sB=(Ls, Ps), sC=(2 * Rk * wd, Rk * wd), sbias=Ls, sbias_h=Ps,
+                  task=(Mk * r, sP, Mk * wd, sP, 0))
         return a_all, b_all
 
     def cross_kv_bwd(self, P, G, mem, Mk, dmem):
         """backward of cross_kv_fwd from the dK / dV of all layers ('xkv.d'): the two weight-gradient products (batch 2 n_dec, bias
         gradients folded in) on the side stream, da, and dmem = sum over layers and k / v of da . W_a (two K-batched launches)."""
-        hp, L, A = self.hp, self.L, self.arena
+        hp, L, A, nt, sP, sG = self.hp, self.L, self.arena, self.nt, self.sP, self.sG
         Ls, Ps = A['xkv.plan']
         d, r, wd, NL = hp.d, hp.r, hp.h * hp.dk, hp.n_dec
+        Rk = nt * Mk
         o0 = lambda n: P + 4 * L.off('decoder.layers.0.encoder_attn.' + n)
         g0 = lambda n: G + 4 * L.off('decoder.layers.0.encoder_attn.' + n)
         a_ptr, d_ptr = A['xkv.a'].data_ptr(), A['xkv.d'].data_ptr()
-        da = self.buf('xkv.da', (NL, 2, Mk, r))
+        da = self.buf('xkv.da', (NL, 2, Rk, r))
         da_ptr = da.data_ptr()
         self.defer(lambda: self.gemm(1, 0, wd, r, Mk, d_ptr, wd, a_ptr, r, g0('key_linear_b.weight'), r, flags=ACCUM, batch=2 * NL, H=2,
-                                     sA=(2 * Mk * wd, Mk * wd), sB=(2 * Mk * r, Mk * r), sC=(Ls, Ps), rowsum=g0('key_linear_b.bias'),
-                                     srow=Ls, srow_h=Ps))
-        self.gemm(0, 0, Mk, r, wd, d_ptr, wd, o0('key_linear_b.weight'), r, da_ptr, r, batch=2 * NL, H=2, sA=(2 * Mk * wd, Mk * wd),
-                  sB=(Ls, Ps), sC=(2 * Mk * r, Mk * r))
+                                     sA=(2 * Rk * wd, Rk * wd), sB=(2 * Rk * r, Rk * r), sC=(Ls, Ps), rowsum=g0('key_linear_b.bias'),
+                                     srow=Ls, srow_h=Ps, task=(Mk * wd, Mk * r, sG, 0, sG)))
+        self.gemm(0, 0, Mk, r, wd, d_ptr, wd, o0('key_linear_b.weight'), r, da_ptr, r, batch=2 * NL, H=2, sA=(2 * Rk * wd, Rk * wd),
+                  sB=(Ls, Ps), sC=(2 * Rk * r, Rk * r), task=(Mk * wd, sP, Mk * r, 0, 0))
         self.defer(lambda: self.gemm(1, 0, r, d, Mk, da_ptr, r, mem, d, g0('key_linear_a.weight'), d, flags=ACCUM, batch=2 * NL, H=2,
-                                     sA=(2 * Mk * r, Mk * r), sC=(Ls, Ps)))
+                                     sA=(2 * Rk * r, Rk * r), sC=(Ls, Ps), task=(Mk * r, Mk * d, sG, 0, 0)))
         for pj, name in enumerate(('key', 'value')):      # dmem (=|+=) sum_l da[l, pj] . W_a[l, pj]
-            self.gemm(0, 0, Mk, d, r, da_ptr + 4 * pj * Mk * r, r, o0(name + '_linear_a.weight'), d, dmem, d, flags=ACCUM if pj else 0,
-                      kbatch=NL, sAk=2 * Mk * r, sBk=Ls)
+            self.gemm(0, 0, Mk, d, r, da_ptr + 4 * pj * Rk * r, r, o0(name + '_linear_a.weight'), d, dmem, d, flags=ACCUM if pj else 0,
+                      kbatch=NL, sAk=2 * Rk * r, sBk=Ls, task=(Mk * r, sP, Mk * d, 0, 0))
         self.flush_side(0)
 
     def _pstride(self, pre, names, suffix):
@@ -863,14 +904,15 @@ class PassEngine:
     def ffn_fwd(self, tag, P, pre, x, rows, T, keep):
         hp, L = self.hp, self.L
         o = lambda n: P + 4 * L.off(pre + n)
-        h1 = self.buf(tag + 'h1', (rows, hp.inner))
-        h2 = self.buf(tag + 'h2', (rows, hp.d))
+        R = self.nt * rows                             # rows: per task
+        h1 = self.buf(tag + 'h1', (R, hp.inner))
+        h2 = self.buf(tag + 'h2', (R, hp.d))
         self.linear_fwd(x, rows, hp.d, o('linear_1.weight'), o('linear_1.bias'), h1.data_ptr(), hp.inner, relu=True)
         self.linear_fwd(h1.data_ptr(), rows, hp.inner, o('linear_2.weight'), o('linear_2.bias'), h2.data_ptr(), hp.d)
-        y = self.buf(tag + 'y', (rows, hp.d))
-        xhat = self.buf(tag + 'xhat', (rows, hp.d))
-        rstd = self.buf(tag + 'rstd', (rows,))
-        mf = self.drop_mask(tag + 'mf', (rows, hp.d))                           # dropout before the residual add (:130)
+        y = self.buf(tag + 'y', (R, hp.d))
+        xhat = self.buf(tag + 'xhat', (R, hp.d))
+        rstd = self.buf(tag + 'rstd', (R,))
+        mf = self.drop_mask(tag + 'mf', (R, hp.d))                              # dropout before the residual add (:130)
         self.ln_fwd(h2.data_ptr(), x, o('layer_norm.weight'), o('layer_norm.bias'), None, keep, y.data_ptr(), xhat.data_ptr(),
                     rstd.data_ptr(), rows, T, xmask=mf)
         return y
@@ -879,15 +921,16 @@ class PassEngine:
         hp, L, A = self.hp, self.L, self.arena
         o = lambda n: P + 4 * L.off(pre + n)
         g = lambda n: G + 4 * L.off(pre + n)
-        dzb = self.buf(tag + '_dz', (rows, hp.d))
+        R = self.nt * rows
+        dzb = self.buf(tag + '_dz', (R, hp.d))
         mf = A.get(tag + 'mf')
-        dzm = self.buf(tag + '_dzm', (rows, hp.d)) if mf is not None else None
+        dzm = self.buf(tag + '_dzm', (R, hp.d)) if mf is not None else None
         self.ln_bwd(dy, A[tag + 'xhat'].data_ptr(), A[tag + 'rstd'].data_ptr(), o('layer_norm.weight'), keep, dzb.data_ptr(),
                     g('layer_norm.weight'), g('layer_norm.bias'), rows, dsum=g('linear_2.bias'), xmask=mf,
                     dzm=dzm.data_ptr() if dzm is not None else None, dz2=dx)         # dx = dz: the residual path
         dbr = dzm.data_ptr() if dzm is not None else dzb.data_ptr()
         h1 = A[tag + 'h1']
-        dh1 = self.buf(tag + '_dh1', (rows, hp.inner))
+        dh1 = self.buf(tag + '_dh1', (R, hp.inner))
         kd = _LAYER_BUF.sub(r'\1*.\3', tag)
         self.linear_bwd(h1.data_ptr(), dbr, rows, hp.inner, hp.d, o('linear_2.weight'), g('linear_2.weight'),
                         None, dh1.data_ptr(), False, gate=h1.data_ptr(), kind=kd + 'w2')
@@ -900,51 +943,74 @@ class PassEngine:
         """Host-side integer prep of one batch (modules/decoder.py:55-69 target shifting; every mask is derived inside the
         kernels from these few integers) + asynchronous H2D into STATIC per-slot buffers.  Kept separate from the kernels so
         a captured hipGraph of the pass can be replayed for any batch of the same shape."""
+        return self.prepare_tasks([(lengths, target)], B, T, slot, norm_count, width)
+
+    def prepare_tasks(self, batches, B, T, slot=0, norm_count=None, width=None):
+        """prepare() for the batches [(lengths, target)] of several tasks that one task-batched pass carries (all B samples x T
+        frames; the decoder width is the largest of the tasks' -- positions beyond a task's own width are padding like any other:
+        masked as keys, zeroed as rows, ignored by the loss).  Everything per-sample is concatenated in task order; the loss
+        normaliser 1 / n_nonpad and the embedding occurrence chains are per task."""
         hp = self.hp
+        nt = len(batches)
         T4 = (T // 2) // 2
-        seq_in, seq_out = decoder_io(target, width=width)
-        Td = seq_in.shape[1]
+        ios = [decoder_io(target, width=width) for _lengths, target in batches]
+        Td = max(io[0].shape[1] for io in ios)
+        if nt > 1 and any(io[0].shape[1] != Td for io in ios):
+            ios = [decoder_io(target, width=Td) for _lengths, target in batches]
         if T4 > hp.src_max_len or Td > hp.tgt_max_len:
             raise ValueError('sequence longer than the positional tables')
-        lens = lengths.detach().to('cpu', torch.int64)
-        is_pad = seq_in.eq(EOS_ID)
-        dec_len = (~is_pad).sum(1)
-        if not bool((is_pad == (torch.arange(Td).unsqueeze(0) >= dec_len.unsqueeze(1))).all()):
-            raise ValueError('EOS inside a target sequence is not supported')
         pos = torch.arange(T4).unsqueeze(0)
-        # occurrence chains of the decoder input ids (deterministic embedding scatter-add, mtl_embed_bwd)
-        flat_in = seq_in.reshape(-1)
-        order = torch.argsort(flat_in, stable=True)
-        srt = flat_in[order]
-        same_as_prev = torch.zeros_like(srt, dtype=torch.bool)
-        same_as_prev[1:] = srt[1:] == srt[:-1]
-        first = torch.empty_like(flat_in, dtype=torch.int32)
-        first[order] = (~same_as_prev).to(torch.int32)
-        nxt = torch.full_like(flat_in, -1, dtype=torch.int32)
-        nxt[order[:-1]] = torch.where(same_as_prev[1:], order[1:], torch.full_like(order[1:], -1)).to(torch.int32)
-        n_nonpad = int((seq_out != PAD_ID).sum())
-        if norm_count is not None:        # this is a slice of a larger batch: normalise the loss by the WHOLE batch's token count
-            n_nonpad = int(norm_count)
+        inv, klen_e, klen_d, keep_e, keep_d, firsts, nexts, n_nonpads = [], [], [], [], [], [], [], []
+        for ti, ((lengths, _target), (seq_in, seq_out)) in enumerate(zip(batches, ios)):
+            if seq_in.shape[0] != B:
+                raise ValueError('every task of a batched pass must bring %d samples' % B)
+            lens = lengths.detach().to('cpu', torch.int64)
+            is_pad = seq_in.eq(EOS_ID)
+            dec_len = (~is_pad).sum(1)
+            if not bool((is_pad == (torch.arange(Td).unsqueeze(0) >= dec_len.unsqueeze(1))).all()):
+                raise ValueError('EOS inside a target sequence is not supported')
+            # occurrence chains of the decoder input ids (deterministic embedding scatter-add, mtl_embed_bwd); row numbers are
+            # those of the whole pass, chains stay inside their task
+            flat_in = seq_in.reshape(-1)
+            order = torch.argsort(flat_in, stable=True)
+            srt = flat_in[order]
+            same_as_prev = torch.zeros_like(srt, dtype=torch.bool)
+            same_as_prev[1:] = srt[1:] == srt[:-1]
+            first = torch.empty_like(flat_in, dtype=torch.int32)
+            first[order] = (~same_as_prev).to(torch.int32)
+            nxt = torch.full_like(flat_in, -1, dtype=torch.int32)
+            base = ti * B * Td
+            nxt[order[:-1]] = torch.where(same_as_prev[1:], order[1:] + base, torch.full_like(order[1:], -1)).to(torch.int32)
+            n_nonpad = int((seq_out != PAD_ID).sum())
+            if norm_count is not None:        # this is a slice of a larger batch: normalise the loss by the WHOLE batch's token count
+                n_nonpad = int(norm_count)
+            n_nonpads.append(n_nonpad)
+            inv.append(1.0 / n_nonpad)
+            klen_e.append(torch.clamp(lens, max=T4).to(torch.int32))           # klen_enc (B)      (SURVEY Q2: raw lengths)
+            klen_d.append(dec_len.to(torch.int32))                             # klen_dec (B)
+            keep_e.append((pos < lens.unsqueeze(1)).to(torch.int32).reshape(-1))   # keep_enc (B*T4)
+            keep_d.append((~is_pad).to(torch.int32).reshape(-1))               # keep_dec (B*Td)
+            firsts.append(first)
+            nexts.append(nxt)
+        head = 2 + nt + (nt & 1)              # seed (8 bytes) | 1 / n_nonpad per task | padding to an even count
         meta_i32 = torch.cat([
             torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).view(torch.int32),    # dropout seed of this pass (torch CPU RNG), 8-byte aligned
-            torch.tensor([1.0 / n_nonpad], dtype=torch.float32).view(torch.int32),    # 1/n_nonpad (fp32 bits)
-            torch.zeros(1, dtype=torch.int32),
-            torch.clamp(lens, max=T4).to(torch.int32),                        # klen_enc (B)      (SURVEY Q2: raw lengths)
-            dec_len.to(torch.int32),                                           # klen_dec (B)
-            (pos < lens.unsqueeze(1)).to(torch.int32).reshape(-1),             # keep_enc (B*T4)
-            (~is_pad).to(torch.int32).reshape(-1),                             # keep_dec (B*Td)
-            first, nxt])                                                       # embed chains (B*Td each)
+            torch.tensor(inv, dtype=torch.float32).view(torch.int32),                # 1/n_nonpad (fp32 bits), per task
+            torch.zeros(head - 2 - nt, dtype=torch.int32)] + klen_e + klen_d + keep_e + keep_d + firsts + nexts)
+        seq_in = torch.cat([io[0] for io in ios]) if nt > 1 else ios[0][0]
+        seq_out = torch.cat([io[1] for io in ios]) if nt > 1 else ios[0][1]
+        Bt = nt * B
         # page-locked staging (two alternating buffers per slot, each guarded by an event): the uploads are truly asynchronous and
         # the host never rewrites a staging buffer whose copy has not been consumed yet
         dev_i32 = self.buf('meta_i32.%d' % slot, (meta_i32.numel(),), torch.int32)
-        ids = self.buf('ids.%d' % slot, (2, B, Td), torch.int64)
+        ids = self.buf('ids.%d' % slot, (2, Bt, Td), torch.int64)
         turn = self._stage_turn.get(slot, 0)
         self._stage_turn[slot] = turn ^ 1
-        key = (slot, turn, meta_i32.numel(), B, Td)
+        key = (slot, turn, meta_i32.numel(), Bt, Td)
         st = self._stage.get(key)
         if st is None:
             st = dict(i32=torch.empty(meta_i32.numel(), dtype=torch.int32).pin_memory(),
-                      ids=torch.empty((2, B, Td), dtype=torch.int64).pin_memory(), ev=torch.cuda.Event())
+                      ids=torch.empty((2, Bt, Td), dtype=torch.int64).pin_memory(), ev=torch.cuda.Event())
             self._stage[key] = st
         else:
             st['ev'].synchronize()
@@ -956,13 +1022,14 @@ class PassEngine:
         st['ev'].record(torch.cuda.current_stream(self.device))
         seed = dev_i32.data_ptr()
         inv_count = seed + 8
-        klen_enc = seed + 16
-        klen_dec = klen_enc + 4 * B
-        keep_enc = klen_dec + 4 * B
-        keep_dec = keep_enc + 4 * B * T4
-        embed_first = keep_dec + 4 * B * Td
-        embed_next = embed_first + 4 * B * Td
-        return dict(seed=seed, B=B, T=T, Td=Td, n_nonpad=n_nonpad, gold_host=seq_out, ids=ids, klen_enc=klen_enc, klen_dec=klen_dec,
+        klen_enc = seed + 4 * head
+        klen_dec = klen_enc + 4 * Bt
+        keep_enc = klen_dec + 4 * Bt
+        keep_dec = keep_enc + 4 * Bt * T4
+        embed_first = keep_dec + 4 * Bt * Td
+        embed_next = embed_first + 4 * Bt * Td
+        return dict(seed=seed, B=B, T=T, Td=Td, nt=nt, n_nonpad=n_nonpads[0], n_nonpads=n_nonpads, gold_host=seq_out,
+                    gold_hosts=[io[1] for io in ios], ids=ids, klen_enc=klen_enc, klen_dec=klen_dec,
                     keep_enc=keep_enc, keep_dec=keep_dec, embed_first=embed_first, embed_next=embed_next, inv_count=inv_count)
 
     def forward(self, theta, x, lengths, target, smoothing=0.0, slot=0):
@@ -973,44 +1040,63 @@ class PassEngine:
         meta = self.prepare(lengths, target, x.shape[0], x.shape[3], slot)
         return self.forward_device(theta, x, meta, smoothing)
 
-    def forward_device(self, theta, x, meta, smoothing=0.0, hyp_out=None, loss_out=None):
-        """Kernel launches only (hipGraph-capturable): everything batch-dependent comes from `meta`'s device buffers."""
+    def forward_device(self, theta, x, meta, smoothing=0.0, hyp_out=None, loss_out=None, sP=0):
+        """Kernel launches only (hipGraph-capturable): everything batch-dependent comes from `meta`'s device buffers.
+
+        Task-batched pass (meta from prepare_tasks with nt > 1 tasks; trainer/asr/transient_trainer.py:178-237: the tasks of a
+        meta-step are independent given theta0): x is (nt * B, 1, F, T) -- or (B, 1, F, T) when every task sees the SAME batch (the
+        shared validation batch) -- and task t reads its parameters at theta + t * sP floats: sP = 0 for the training passes (all
+        at theta0), sP = layout.total for the validation passes at the theta' stack.  Every transformer kernel runs ONCE over the
+        rows of all tasks (task = outermost batch index of the products, row group of LayerNorm / embedding / loss); the
+        convolutions and the two products around the encoder's input Linear are issued per task.  loss is (nt,), hyp
+        (nt * B, Td)."""
         hp, L, lib, st = self.hp, self.L, self.lib, self.stream
-        assert theta.numel() == L.total and theta.dtype == torch.float32 and theta.is_contiguous()
+        nt = int(meta.get('nt', 1))
+        assert theta.dtype == torch.float32 and theta.is_contiguous()
+        assert theta.numel() == L.total * (nt if sP else 1) and (sP == 0 or sP == L.total)
         x = x.contiguous()
         if x.dtype != torch.float32 or x.device != self.device:
             raise ValueError('input must be fp32 on %s' % self.device)
-        B, _, F, T = x.shape
+        Bx, _, F, T = x.shape
+        B = meta['B']
+        if Bx not in (B, nt * B) or T != meta['T']:
+            raise ValueError('input batch does not match the prepared batch')
+        sX = B * F * T if Bx == nt * B and nt > 1 else 0          # task stride of the input (0: one batch shared by all tasks)
         T2, F2 = T // 2, F // 2
         T4, F4 = T2 // 2, F2 // 2
         if F4 * 128 != hp.d_in:
             raise ValueError('dim_input %d does not match %d frequency bins' % (hp.d_in, F))
+        self.nt, self.sP = nt, int(sP)
+        ntw = nt if sP else 1                                       # distinct parameter sets of this pass
         P = theta.data_ptr()
-        o = lambda n: P + 4 * L.off(n)
+        o = lambda n, t=0: P + 4 * (L.off(n) + t * self.sP)
         d, V = hp.d, hp.V
         Td, ids, n_nonpad = meta['Td'], meta['ids'], meta['n_nonpad']
         self._seed_ptr, self._site = meta['seed'], 0
         klen_enc, klen_dec, keep_enc, keep_dec = meta['klen_enc'], meta['klen_dec'], meta['keep_enc'], meta['keep_dec']
-        Me, Md = B * T4, B * Td
+        Me, Md = B * T4, B * Td                                     # encoder / decoder rows PER TASK
+        Bt = nt * B
 
-        # ---- VGG front-end ----
-        y1 = self.buf('y1', (B, T, F, 64))
+        # ---- VGG front-end (per task: its own weights in the validation pass, its own tensor bounds) ----
+        y1 = self.buf('y1', (Bt, T, F, 64))
         x3, h2 = self.conv_x3, self.conv_h2
         # h2: device bounds max|tensor| (64 slots each) of y1, p1, y5 | dp2, dy5, dp1 -- raised by the producers' epilogues
         # (forward) or written by the bias-gradient column sums (backward)
         # (6, 7, 8: p2, the permuted input_linear weight, de0 -- operands of the two h2 GEMMs around the encoder's input Linear)
-        amax = self.buf('amax', (12, _lib.AMAX_SLOTS))
-        am_ = (lambda i: amax.data_ptr() + 4 * _lib.AMAX_SLOTS * i) if h2 else (lambda i: None)
+        amax = self.buf('amax', (nt, 12, _lib.AMAX_SLOTS))
+        am_ = (lambda i, t=0: amax.data_ptr() + 4 * _lib.AMAX_SLOTS * (12 * t + i)) if h2 else (lambda i, t=0: None)
         if h2:
-            check(lib.mtl_memset_zero(st, amax.data_ptr(), 12 * 4 * _lib.AMAX_SLOTS), 'mtl_memset_zero')
-        check(lib.mtl_conv0_relu_fwd(st, x.data_ptr(), o('conv.0.weight'),
-                         o('conv.0.bias'), y1.data_ptr(), B, T, F, am_(0)), 'conv0')
+            check(lib.mtl_memset_zero(st, amax.data_ptr(), nt * 12 * 4 * _lib.AMAX_SLOTS), 'mtl_memset_zero')
+        xp = lambda t: x.data_ptr() + 4 * t * sX
+        for t in range(nt):
+            check(lib.mtl_conv0_relu_fwd(st, xp(t), o('conv.0.weight', t), o('conv.0.bias', t), y1[t * B:].data_ptr(), B, T, F,
+                                         am_(0, t)), 'conv0')
         wf, wd = {}, {}
         wprep = lib.mtl_conv3x3_wprep_h2 if h2 else (lib.mtl_conv3x3_wprep_x3 if x3 else lib.mtl_conv3x3_wprep)
         if h2:
-            conv_fwd = lambda s_, x_, w_, b_, y_, ai, ao, *dims: lib.mtl_conv3x3_relu_fwd_h2(s_, x_, am_(ai), w_, b_, y_, am_(ao), *dims)
+            conv_fwd = lambda s_, x_, w_, b_, y_, ai, ao, *dims: lib.mtl_conv3x3_relu_fwd_h2(s_, x_, ai, w_, b_, y_, ao, *dims)
             conv_fwd_pool = lambda s_, x_, w_, b_, y_, a_, ai, ao, *dims: lib.mtl_conv3x3_relu_pool_fwd_h2(
-                s_, x_, am_(ai), w_, b_, y_, a_, am_(ao) if ao is not None else None, *dims)
+                s_, x_, ai, w_, b_, y_, a_, ao, *dims)
         else:
             f1 = lib.mtl_conv3x3_relu_fwd_x3 if x3 else lib.mtl_conv3x3_relu_fwd
             f2 = lib.mtl_conv3x3_relu_pool_fwd_x3 if x3 else lib.mtl_conv3x3_relu_pool_fwd
@@ -1019,47 +1105,54 @@ class PassEngine:
         for idx, cin, cout in ((2, 64, 64), (5, 64, 128), (7, 128, 128)):
             if h2:      # two fp16 pieces of every (scaled) weight + the scale
                 nb = lib.mtl_conv3x3_wprep_h2_bytes(cout, cin)
-                wf[idx] = self.buf('wf%d' % idx, (nb,), torch.uint8)
-                wd[idx] = self.buf('wd%d' % idx, (nb,), torch.uint8)
+                nb = (nb + 255) // 256 * 256
+                wf[idx] = self.buf('wf%d' % idx, (ntw, nb), torch.uint8)
+                wd[idx] = self.buf('wd%d' % idx, (ntw, nb), torch.uint8)
             elif x3:    # three exact bf16 pieces of every weight, [piece][tap][cin/32][cout][32]
-                wf[idx] = self.buf('wf%d' % idx, (3, 9, cin, cout), torch.bfloat16)
-                wd[idx] = self.buf('wd%d' % idx, (3, 9, cout, cin), torch.bfloat16)
+                wf[idx] = self.buf('wf%d' % idx, (ntw, 3, 9, cin, cout), torch.bfloat16)
+                wd[idx] = self.buf('wd%d' % idx, (ntw, 3, 9, cout, cin), torch.bfloat16)
             else:
-                wf[idx] = self.buf('wf%d' % idx, (9, cin, cout))
-                wd[idx] = self.buf('wd%d' % idx, (9, cout, cin))
+                wf[idx] = self.buf('wf%d' % idx, (ntw, 9, cin, cout))
+                wd[idx] = self.buf('wd%d' % idx, (ntw, 9, cout, cin))
             if not h2:
-                check(wprep(st, o('conv.%d.weight' % idx), wf[idx].data_ptr(), wd[idx].data_ptr(), cout, cin), 'wprep')
-        if h2:          # all three layers: one call (two launches)
-            spec = []
-            for idx, cin, cout in ((2, 64, 64), (5, 64, 128), (7, 128, 128)):
-                spec += [o('conv.%d.weight' % idx), wf[idx].data_ptr(), wd[idx].data_ptr(), cout, cin]
-            check(lib.mtl_conv3x3_wprep_h2_batch(st, 3, *spec), 'wprep')
-        self._wT = self.transpose_lowrank_weights(theta).data_ptr() if self.fused_pairs else None
-        p1 = self.buf('p1', (B, T2, F2, 64))
-        am1 = self.buf('am1', (B, T2, F2, 64), torch.uint8)
-        check(conv_fwd_pool(st, y1.data_ptr(), wf[2].data_ptr(),
-                         o('conv.2.bias'), p1.data_ptr(), am1.data_ptr(), 0, 1, B, T, F, 64, 64), 'conv2')
-        y5 = self.buf('y5', (B, T2, F2, 128))
-        check(conv_fwd(st, p1.data_ptr(), wf[5].data_ptr(),
-                         o('conv.5.bias'), y5.data_ptr(), 1, 2, B, T2, F2, 64, 128), 'conv5')
-        p2 = self.buf('p2', (B, T4, F4, 128))
-        am2 = self.buf('am2', (B, T4, F4, 128), torch.uint8)
-        check(conv_fwd_pool(st, y5.data_ptr(), wf[7].data_ptr(),
-                         o('conv.7.bias'), p2.data_ptr(), am2.data_ptr(), 2, 6, B, T2, F2, 128, 128), 'conv7')
+                for t in range(ntw):
+                    check(wprep(st, o('conv.%d.weight' % idx, t), wf[idx][t].data_ptr(), wd[idx][t].data_ptr(), cout, cin), 'wprep')
+        if h2:          # all three layers: one call (two launches) per parameter set
+            for t in range(ntw):
+                spec = []
+                for idx, cin, cout in ((2, 64, 64), (5, 64, 128), (7, 128, 128)):
+                    spec += [o('conv.%d.weight' % idx, t), wf[idx][t].data_ptr(), wd[idx][t].data_ptr(), cout, cin]
+                check(lib.mtl_conv3x3_wprep_h2_batch(st, 3, *spec), 'wprep')
+        self._wT = self.transpose_lowrank_weights(theta).data_ptr() if (self.fused_pairs and nt == 1) else None
+        p1 = self.buf('p1', (Bt, T2, F2, 64))
+        am1 = self.buf('am1', (Bt, T2, F2, 64), torch.uint8)
+        y5 = self.buf('y5', (Bt, T2, F2, 128))
+        p2 = self.buf('p2', (Bt, T4, F4, 128))
+        am2 = self.buf('am2', (Bt, T4, F4, 128), torch.uint8)
+        for t in range(nt):
+            tw, sl = (t if sP else 0), slice(t * B, (t + 1) * B)
+            check(conv_fwd_pool(st, y1[sl].data_ptr(), wf[2][tw].data_ptr(), o('conv.2.bias', t), p1[sl].data_ptr(), am1[sl].data_ptr(),
+                                am_(0, t), am_(1, t), B, T, F, 64, 64), 'conv2')
+            check(conv_fwd(st, p1[sl].data_ptr(), wf[5][tw].data_ptr(), o('conv.5.bias', t), y5[sl].data_ptr(), am_(1, t), am_(2, t),
+                           B, T2, F2, 64, 128), 'conv5')
+            check(conv_fwd_pool(st, y5[sl].data_ptr(), wf[7][tw].data_ptr(), o('conv.7.bias', t), p2[sl].data_ptr(), am2[sl].data_ptr(),
+                                am_(2, t), am_(6, t), B, T2, F2, 128, 128), 'conv7')
 
         if self.after_conv_hook is not None:      # lets the trainer de-phase concurrent task lanes (see trainer.meta_iteration)
             hook, self.after_conv_hook = self.after_conv_hook, None
             hook()
 
         # ---- encoder ----
-        wp = self.buf('wp_in', (d, hp.d_in))
-        check(lib.mtl_permute_hc(st, o('encoder.input_linear.weight'), wp.data_ptr(), d, 128, F4, 0, am_(7)), 'permute')      # am_(7): max|w| rides along
+        wp = self.buf('wp_in', (ntw, d, hp.d_in))
+        for t in range(ntw):      # am_(7): max|w| rides along
+            check(lib.mtl_permute_hc(st, o('encoder.input_linear.weight', t), wp[t].data_ptr(), d, 128, F4, 0, am_(7, t)), 'permute')
         # decoder prologue: embedding (+ PE, dropout) and layer 0's self-attention block read the labels and theta only
         def dec_prologue():
-            d0_ = self.buf('dec_in.y', (Md, d))
-            me = self.drop_mask('dec_in.me', (Md, d))                           # dropout(emb + PE) (modules/decoder.py:96)
-            check(lib.mtl_embed_pe_fwd(self.stream, ids.data_ptr(), o('decoder.trg_embedding.weight'), self.pe_dec.data_ptr(),
-                                       d0_.data_ptr(), Md, Td, d, me.data_ptr() if me is not None else None, self.drop_scale), 'embed')
+            d0_ = self.buf('dec_in.y', (nt * Md, d))
+            me = self.drop_mask('dec_in.me', (nt * Md, d))                      # dropout(emb + PE) (modules/decoder.py:96)
+            check(lib.mtl_embed_pe_fwd_g(self.stream, ids.data_ptr(), o('decoder.trg_embedding.weight'), self.pe_dec.data_ptr(),
+                                         d0_.data_ptr(), nt * Md, Td, d, me.data_ptr() if me is not None else None, self.drop_scale,
+                                         Md, self.sP), 'embed')
             if hp.n_dec == 0:
                 return d0_, None
             return d0_, self.mha_fwd('d0.sa.', P, 'decoder.layers.0.self_attn.', d0_.data_ptr(), B, Td, d0_.data_ptr(), Td, klen_dec, 1,
@@ -1069,20 +1162,25 @@ class PassEngine:
                                  and not self.fused_pairs and hp.n_dec > 0)
         if self.dec0_on_side:
             (d0, a0), pro_done = self.run_on_side(dec_prologue)      # under the input Linear and the encoder
-        e0 = self.buf('e0', (Me, d))
+        e0 = self.buf('e0', (nt * Me, d))
         self.in_h2 = h2 and bool(lib.mtl_gemm_nt_h2_supported(Me, d, hp.d_in)) and bool(lib.mtl_gemm_nt_h2_supported(Me, hp.d_in, d))
         if self.in_h2:      # the two compute-bound products of the pass on fp16 pairs: e0 = p2 . wp^T here, dp2 = de0 . (wp^T)^T in the backward
-            wpT = self.buf('wpT_in', (hp.d_in, d))
-            check(lib.mtl_transpose_batch(st, self._transpose_table(wp, wpT, d, hp.d_in), 1), 'mtl_transpose_batch')
+            wpT = self.buf('wpT_in', (ntw, hp.d_in, d))
             need = lib.mtl_gemm_nt_h2_workspace(Me, d, hp.d_in)
-            check(lib.mtl_gemm_nt_h2(st, Me, d, hp.d_in, p2.data_ptr(), hp.d_in, am_(6), wp.data_ptr(), hp.d_in, am_(7), e0.data_ptr(), d,
-                                     o('encoder.input_linear.bias'), None, 0, self.scratch(need) if need else None, need), 'mtl_gemm_nt_h2')
+            for t in range(ntw):
+                check(lib.mtl_transpose_batch(st, self._transpose_table(wp[t], wpT[t], d, hp.d_in), 1), 'mtl_transpose_batch')
+            for t in range(nt):
+                tw = t if sP else 0
+                check(lib.mtl_gemm_nt_h2(st, Me, d, hp.d_in, p2[t * B:].data_ptr(), hp.d_in, am_(6, t), wp[tw].data_ptr(), hp.d_in,
+                                         am_(7, tw), e0[t * Me:].data_ptr(), d, o('encoder.input_linear.bias', t), None, 0,
+                                         self.scratch(need) if need else None, need), 'mtl_gemm_nt_h2')
         else:
-            self.linear_fwd(p2.data_ptr(), Me, hp.d_in, wp.data_ptr(), o('encoder.input_linear.bias'), e0.data_ptr(), d)
-        ex = self.buf('enc_in.y', (Me, d))
+            self.gemm(0, 1, Me, d, hp.d_in, p2.data_ptr(), hp.d_in, wp.data_ptr(), hp.d_in, e0.data_ptr(), d,
+                      bias=o('encoder.input_linear.bias'), task=(Me * hp.d_in, d * hp.d_in if sP else 0, Me * d, self.sP, 0))
+        ex = self.buf('enc_in.y', (nt * Me, d))
         self.ln_fwd(e0.data_ptr(), None, o('encoder.layer_norm_input.weight'), o('encoder.layer_norm_input.bias'),
-                    self.pe_enc.data_ptr(), None, ex.data_ptr(), self.buf('enc_in.xhat', (Me, d)).data_ptr(),
-                    self.buf('enc_in.rstd', (Me,)).data_ptr(), Me, T4)
+                    self.pe_enc.data_ptr(), None, ex.data_ptr(), self.buf('enc_in.xhat', (nt * Me, d)).data_ptr(),
+                    self.buf('enc_in.rstd', (nt * Me,)).data_ptr(), Me, T4)
         cur = ex
         enc_inputs = []
         for i in range(hp.n_enc):
@@ -1106,23 +1204,29 @@ class PassEngine:
             c = self.mha_fwd('d%d.ca.' % i, P, pre + 'encoder_attn.', a.data_ptr(), B, Td, mem.data_ptr(), T4, klen_enc, 0, keep_dec,
                              kv_ready=(xkv[0][i], xkv[1][i]) if xkv is not None else None)
             cur = self.ffn_fwd('d%d.ff.' % i, P, pre + 'pos_ffn.', c.data_ptr(), Md, Td, keep_dec)
-        pred = self.buf('pred', (B, Td, V))
-        self.gemm(0, 1, Md, V, d, cur.data_ptr(), d, o('decoder.output_linear.weight'), d, pred.data_ptr(), V)
+        pred = self.buf('pred', (Bt, Td, V))
+        self.gemm(0, 1, Md, V, d, cur.data_ptr(), d, o('decoder.output_linear.weight'), d, pred.data_ptr(), V,
+                  task=(Md * d, self.sP, Md * V, 0, 0))
 
         # ---- loss + arg-max ----
-        lse = self.buf('lse', (Md,))
+        lse = self.buf('lse', (nt * Md,))
         # hyp_out / loss_out: caller-owned destinations (the trainer's per-pass read-back slots: no device copies afterwards)
-        hyp = self.buf('hyp', (B, Td), torch.int64) if hyp_out is None else hyp_out
-        rowloss = self.buf('rowloss', (Md,))
-        loss = self.buf('loss', (1,)) if loss_out is None else loss_out
-        gold_ptr = ids.data_ptr() + 8 * Md
-        check(lib.mtl_ce_argmax_fwd(st, pred.data_ptr(), gold_ptr, Md, V, V, PAD_ID, float(smoothing), 0, meta['inv_count'],
-                                    lse.data_ptr(), hyp.data_ptr(), rowloss.data_ptr(), loss.data_ptr()), 'ce_fwd')
+        hyp = self.buf('hyp', (Bt, Td), torch.int64) if hyp_out is None else hyp_out
+        rowloss = self.buf('rowloss', (nt * Md,))
+        loss = self.buf('loss', (nt,)) if loss_out is None else loss_out
+        gold_ptr = ids.data_ptr() + 8 * nt * Md
+        if nt == 1:
+            check(lib.mtl_ce_argmax_fwd(st, pred.data_ptr(), gold_ptr, Md, V, V, PAD_ID, float(smoothing), 0, meta['inv_count'],
+                                        lse.data_ptr(), hyp.data_ptr(), rowloss.data_ptr(), loss.data_ptr()), 'ce_fwd')
+        else:
+            check(lib.mtl_ce_argmax_fwd_g(st, pred.data_ptr(), gold_ptr, nt * Md, V, V, PAD_ID, float(smoothing), meta['inv_count'],
+                                          lse.data_ptr(), hyp.data_ptr(), rowloss.data_ptr(), loss.data_ptr(), Md), 'ce_fwd')
         self.saved = dict(theta=theta, x=x, B=B, T=T, F=F, Td=Td, n_nonpad=n_nonpad, smoothing=float(smoothing), meta=meta,
                           klen_enc=klen_enc, klen_dec=klen_dec, keep_enc=keep_enc, keep_dec=keep_dec, dec_last=cur,
-                          enc_inputs=enc_inputs)
+                          enc_inputs=enc_inputs, nt=nt, sP=self.sP, sX=sX)
         if self.forward_hook is not None:
             self.forward_hook(self)
+        self.nt, self.sP = 1, 0            # (the backward restores them from `saved`)
         return dict(pred=pred, gold=ids[1], hyp=hyp, loss=loss, gold_host=meta['gold_host'], n_nonpad=n_nonpad)
 
     # ---------------------------------------------------------------- greedy decoding
@@ -1196,30 +1300,36 @@ class PassEngine:
         out = sorted(ended, key=lambda x: x['final_score'], reverse=True)[:min(len(ended), int(nbest))]
         return [(h['yseq'], float(h['final_score'])) for h in out]
 
-    def backward(self, grad, scale=1.0, dpred=None):
+    def backward(self, grad, scale=1.0, dpred=None, sG=0):
         """Accumulate `scale` * dLoss/dtheta of the LAST forward into the flat buffer `grad` (+=).
-        dpred: optional externally supplied gradient w.r.t. pred (B,Td,V) instead of the fused CE backward."""
+        dpred: optional externally supplied gradient w.r.t. pred (B,Td,V) instead of the fused CE backward.
+        Task-batched pass: task t accumulates into grad + t * sG floats (sG = layout.total: a stack of per-task gradients)."""
         S = self.saved
         if S is None:
             raise RuntimeError('backward() without a preceding forward()')
         hp, L, lib, st, A = self.hp, self.L, self.lib, self.stream, self.arena
-        assert grad.numel() == L.total and grad.is_contiguous()
+        nt = S['nt']
+        self.nt, self.sP, self.sG = nt, S['sP'], int(sG) if nt > 1 else 0
+        if nt > 1 and (sG != L.total or grad.numel() != nt * L.total or dpred is not None):
+            raise ValueError('a task-batched backward accumulates into a (tasks, layout.total) gradient stack')
+        assert grad.numel() == L.total * nt and grad.is_contiguous()
+        sP, sG, sX = self.sP, self.sG, S['sX']
         theta = S['theta']
         P, G = theta.data_ptr(), grad.data_ptr()
-        o = lambda n: P + 4 * L.off(n)
-        g = lambda n: G + 4 * L.off(n)
+        o = lambda n, t=0: P + 4 * (L.off(n) + t * sP)
+        g = lambda n, t=0: G + 4 * (L.off(n) + t * sG)
         B, T, F, Td = S['B'], S['T'], S['F'], S['Td']
         T2, F2 = T // 2, F // 2
         T4, F4 = T2 // 2, F2 // 2
-        Me, Md, d, V = B * T4, B * Td, hp.d, hp.V
+        Me, Md, d, V = B * T4, B * Td, hp.d, hp.V                   # rows PER TASK
         keep_enc, keep_dec = S['keep_enc'], S['keep_dec']
 
         if dpred is None:
             ldd = (V + 3) // 4 * 4        # padded leading dimension -> 16-byte operand loads in the two GEMMs below
-            dlog = self.buf('_dpred', (Md, ldd))
-            gold_ptr = S['meta']['ids'].data_ptr() + 8 * Md
-            check(lib.mtl_ce_bwd(st, A['pred'].data_ptr(), A['lse'].data_ptr(), gold_ptr, Md, V, V, PAD_ID, S['smoothing'],
-                                 float(scale), S['meta']['inv_count'], dlog.data_ptr(), ldd), 'ce_bwd')
+            dlog = self.buf('_dpred', (nt * Md, ldd))
+            gold_ptr = S['meta']['ids'].data_ptr() + 8 * nt * Md
+            check(lib.mtl_ce_bwd_g(st, A['pred'].data_ptr(), A['lse'].data_ptr(), gold_ptr, nt * Md, V, V, PAD_ID, S['smoothing'],
+                                   float(scale), S['meta']['inv_count'], dlog.data_ptr(), ldd, Md), 'ce_bwd')
             dlog_ptr = dlog.data_ptr()
         else:
             ldd = V
@@ -1227,24 +1337,25 @@ class PassEngine:
             if scale != 1.0:
                 dlog = dlog * scale
             dlog_ptr = dlog.data_ptr()
-        dA = self.buf('_dxA', (Md, d))
-        dB = self.buf('_dxB', (Md, d))
-        dmem = self.buf('_dmem', (Me, d))
+        dA = self.buf('_dxA', (nt * Md, d))
+        dB = self.buf('_dxB', (nt * Md, d))
+        dmem = self.buf('_dmem', (nt * Me, d))
         last = S['dec_last']
         # vocab projection (no bias)
         self.defer(lambda: self.gemm(1, 0, V, d, Md, dlog_ptr, ldd, last.data_ptr(), d, g('decoder.output_linear.weight'), d,
-                                     flags=ACCUM))                     # (lda = ldd != V: stays a single call)
-        self.gemm(0, 0, Md, d, V, dlog_ptr, ldd, o('decoder.output_linear.weight'), d, dA.data_ptr(), d)
+                                     flags=ACCUM, task=(Md * ldd, Md * d, sG, 0, 0)))    # (lda = ldd != V: stays a single call)
+        self.gemm(0, 0, Md, d, V, dlog_ptr, ldd, o('decoder.output_linear.weight'), d, dA.data_ptr(), d,
+                  task=(Md * ldd, sP, Md * d, 0, 0))
         self.flush_side()
         dcur, dnext = dA, dB
         hoisted = A.get('xkv.plan') is not None
         mem_ptr = A['e%d.ff.y' % (hp.n_enc - 1)].data_ptr() if hp.n_enc else A['enc_in.y'].data_ptr()
-        dkv_all = self.buf('xkv.d', (hp.n_dec, 2, Me, hp.h * hp.dk)) if hoisted else None
+        dkv_all = self.buf('xkv.d', (hp.n_dec, 2, nt * Me, hp.h * hp.dk)) if hoisted else None
         def embed_bwd(dx):
             me = A.get('dec_in.me')
-            check(lib.mtl_embed_bwd(self.stream, S['meta']['ids'].data_ptr(), S['meta']['embed_first'], S['meta']['embed_next'],
-                                    dx.data_ptr(), g('decoder.trg_embedding.weight'), Md, d, PAD_ID,
-                                    me.data_ptr() if me is not None else None, self.drop_scale), 'embed_bwd')
+            check(lib.mtl_embed_bwd_g(self.stream, S['meta']['ids'].data_ptr(), S['meta']['embed_first'], S['meta']['embed_next'],
+                                      dx.data_ptr(), g('decoder.trg_embedding.weight'), nt * Md, d, PAD_ID,
+                                      me.data_ptr() if me is not None else None, self.drop_scale, Md, sG), 'embed_bwd')
         embed_done = False
         for i in reversed(range(hp.n_dec)):
             pre = 'decoder.layers.%d.' % i
@@ -1278,7 +1389,7 @@ class PassEngine:
             embed_bwd(dcur)
 
         # ---- encoder ----
-        eA = self.buf('_deA', (Me, d))
+        eA = self.buf('_deA', (nt * Me, d))
         dcur, dnext = dmem, eA
         for i in reversed(range(hp.n_enc)):
             pre = 'encoder.layers.%d.' % i
@@ -1297,32 +1408,35 @@ class PassEngine:
                     dsum=g('encoder.input_linear.bias'))
         self.flush_layer_wgrads()       # the encoder stack's weight gradients
         p2, y5, p1, y1 = A['p2'], A['y5'], A['p1'], A['y1']
-        dwp = self.buf('_dwp', (d, hp.d_in))
-        dp2 = self.buf('_dp2', (B, T4, F4, 128))
-        self.gemm(1, 0, d, hp.d_in, Me, de0.data_ptr(), d, p2.data_ptr(), hp.d_in, dwp.data_ptr(), hp.d_in)
-        check(lib.mtl_permute_hc(st, dwp.data_ptr(), g('encoder.input_linear.weight'), d, 128, F4, 1, None), 'permute_inv')
+        dwp = self.buf('_dwp', (nt, d, hp.d_in))
+        dp2 = self.buf('_dp2', (nt * B, T4, F4, 128))
+        self.gemm(1, 0, d, hp.d_in, Me, de0.data_ptr(), d, p2.data_ptr(), hp.d_in, dwp.data_ptr(), hp.d_in,
+                  task=(Me * d, Me * hp.d_in, d * hp.d_in, 0, 0))
+        for t in range(nt):
+            check(lib.mtl_permute_hc(st, dwp[t].data_ptr(), g('encoder.input_linear.weight', t), d, 128, F4, 1, None), 'permute_inv')
+        h2 = self.conv_h2
+        amax = A['amax']
+        am_ = (lambda i, t=0: amax.data_ptr() + 4 * _lib.AMAX_SLOTS * (12 * t + i)) if h2 else (lambda i, t=0: None)   # y1, p1, y5 | dp2, dy5, dp1
         if self.in_h2:
-            amax = A['amax']
-            a8, a7 = (amax.data_ptr() + 4 * _lib.AMAX_SLOTS * i for i in (8, 7))
-            check(lib.mtl_absmax_f32(st, de0.data_ptr(), de0.numel(), a8), 'mtl_absmax_f32')
             need = lib.mtl_gemm_nt_h2_workspace(Me, hp.d_in, d)
-            check(lib.mtl_gemm_nt_h2(st, Me, hp.d_in, d, de0.data_ptr(), d, a8, A['wpT_in'].data_ptr(), d, a7, dp2.data_ptr(), hp.d_in,
-                                     None, p2.data_ptr(), hp.d_in, self.scratch(need) if need else None, need), 'mtl_gemm_nt_h2')
+            for t in range(nt):
+                tw = t if sP else 0
+                check(lib.mtl_absmax_f32(st, de0[t * Me:].data_ptr(), Me * d, am_(8, t)), 'mtl_absmax_f32')
+                check(lib.mtl_gemm_nt_h2(st, Me, hp.d_in, d, de0[t * Me:].data_ptr(), d, am_(8, t), A['wpT_in'][tw].data_ptr(), d,
+                                         am_(7, tw), dp2[t * B:].data_ptr(), hp.d_in, None, p2[t * B:].data_ptr(), hp.d_in,
+                                         self.scratch(need) if need else None, need), 'mtl_gemm_nt_h2')
         else:
             self.gemm(0, 0, Me, hp.d_in, d, de0.data_ptr(), d, A['wp_in'].data_ptr(), hp.d_in, dp2.data_ptr(), hp.d_in,
-                      gate=p2.data_ptr(), ldg=hp.d_in)
+                      gate=p2.data_ptr(), ldg=hp.d_in, task=(Me * d, d * hp.d_in if sP else 0, Me * hp.d_in, 0, 0))
 
         self.flush_wgrads()        # every small dW of the transformer half: one grouped launch, overlapping the VGG backward
         self.flush_side(2)
-        # ---- VGG front-end ----
-        h2 = self.conv_h2
-        amax = A['amax']
-        am_ = (lambda i: amax.data_ptr() + 4 * _lib.AMAX_SLOTS * i) if h2 else (lambda i: None)      # bounds: y1, p1, y5 | dp2, dy5, dp1
+        # ---- VGG front-end (per task) ----
         dgrad_fn = lib.mtl_conv3x3_dgrad_x3 if self.conv_x3 else lib.mtl_conv3x3_dgrad
 
-        def conv_dgrad(dy, ai, am, w, act, dx, *dims, ao=None):
+        def conv_dgrad(t, dy, ai, am, w, act, dx, *dims, ao=None):
             if h2:      # ao: slot that receives the bound of dx (the next layer's amax_dy)
-                return lib.mtl_conv3x3_dgrad_h2(st, dy, am_(ai), am, w, act, dx, am_(ao) if ao is not None else None, *dims)
+                return lib.mtl_conv3x3_dgrad_h2(st, dy, am_(ai, t), am, w, act, dx, am_(ao, t) if ao is not None else None, *dims)
             return dgrad_fn(st, dy, am, w, act, dx, *dims)
 
         # h2: the weight-gradient kernel's dy loaders also sum dy (bias gradient) and the data-gradient epilogue delivers the bound of
@@ -1330,40 +1444,45 @@ class PassEngine:
         # other producer)
         fold = lambda am: h2 and (am is not None or self.wgrad_x3_dense)
 
-        def wgrad(xa, axi, dy, adi, am, idx, Bq, Tq, Fq, cin, cout, db=None):
+        def wgrad(t, xa, axi, dy, adi, am, idx, Bq, Tq, Fq, cin, cout, db=None):
             x3 = self.conv_x3 and (am is not None or self.wgrad_x3_dense)
             wsfn = lib.mtl_conv3x3_wgrad_x3_workspace if x3 else lib.mtl_conv3x3_wgrad_workspace
             need = wsfn(Bq, Tq, Fq, cin, cout, 1 if am else 0)
             ws = self.scratch(need)
             if x3 and h2:
-                rc = lib.mtl_conv3x3_wgrad_h2(st, xa, am_(axi), dy, am_(adi), am, g('conv.%d.weight' % idx), db, ws, need, Bq, Tq, Fq,
-                                              cin, cout)
+                rc = lib.mtl_conv3x3_wgrad_h2(st, xa, am_(axi, t), dy, am_(adi, t), am, g('conv.%d.weight' % idx, t), db, ws, need, Bq, Tq,
+                                              Fq, cin, cout)
             else:
                 fn = lib.mtl_conv3x3_wgrad_x3 if x3 else lib.mtl_conv3x3_wgrad
-                rc = fn(st, xa, dy, am, g('conv.%d.weight' % idx), ws, need, Bq, Tq, Fq, cin, cout)
+                rc = fn(st, xa, dy, am, g('conv.%d.weight' % idx, t), ws, need, Bq, Tq, Fq, cin, cout)
             check(rc, 'wgrad')
 
-        self.colsum(dp2.data_ptr(), B * T4 * F4, 128, g('conv.7.bias'), am_(3))
-        wgrad(y5.data_ptr(), 2, dp2.data_ptr(), 3, A['am2'].data_ptr(), 7, B, T2, F2, 128, 128)
-        dy5 = self.buf('_dy5', (B, T2, F2, 128))
+        dy5 = self.buf('_dy5', (nt * B, T2, F2, 128))
+        dp1 = self.buf('_dp1', (nt * B, T2, F2, 64))
+        dy1 = self.buf('_dy1', (nt * B, T, F, 64))
         f5, f2 = fold(None), fold(A['am1'])
-        check(conv_dgrad(dp2.data_ptr(), 3, A['am2'].data_ptr(),
-                         A['wd7'].data_ptr(), y5.data_ptr(), dy5.data_ptr(), B, T2, F2, 128, 128, ao=4 if f5 else None), 'dgrad7')
-        if not f5:
-            self.colsum(dy5.data_ptr(), B * T2 * F2, 128, g('conv.5.bias'), am_(4))
-        wgrad(p1.data_ptr(), 1, dy5.data_ptr(), 4, None, 5, B, T2, F2, 64, 128, db=g('conv.5.bias') if f5 else None)
-        dp1 = self.buf('_dp1', (B, T2, F2, 64))
-        check(conv_dgrad(dy5.data_ptr(), 4, None, A['wd5'].data_ptr(),
-                         p1.data_ptr(), dp1.data_ptr(), B, T2, F2, 64, 128, ao=5 if f2 else None), 'dgrad5')
-        if not f2:
-            self.colsum(dp1.data_ptr(), B * T2 * F2, 64, g('conv.2.bias'), am_(5))
-        wgrad(y1.data_ptr(), 0, dp1.data_ptr(), 5, A['am1'].data_ptr(), 2, B, T, F, 64, 64, db=g('conv.2.bias') if f2 else None)
-        dy1 = self.buf('_dy1', (B, T, F, 64))
-        check(conv_dgrad(dp1.data_ptr(), 5, A['am1'].data_ptr(),
-                         A['wd2'].data_ptr(), y1.data_ptr(), dy1.data_ptr(), B, T, F, 64, 64), 'dgrad2')
-        ws = self.scratch(lib.mtl_conv0_wgrad_workspace())
-        check(lib.mtl_conv0_wgrad(st, S['x'].data_ptr(), dy1.data_ptr(),
-                         g('conv.0.weight'), g('conv.0.bias'), ws, B, T, F), 'wgrad0')
+        xin = S['x']
+        for t in range(nt):
+            tw, sl = (t if sP else 0), slice(t * B, (t + 1) * B)
+            am1_t, am2_t = A['am1'][sl].data_ptr(), A['am2'][sl].data_ptr()
+            self.colsum(dp2[sl].data_ptr(), B * T4 * F4, 128, g('conv.7.bias', t), am_(3, t))
+            wgrad(t, y5[sl].data_ptr(), 2, dp2[sl].data_ptr(), 3, am2_t, 7, B, T2, F2, 128, 128)
+            check(conv_dgrad(t, dp2[sl].data_ptr(), 3, am2_t, A['wd7'][tw].data_ptr(), y5[sl].data_ptr(), dy5[sl].data_ptr(),
+                             B, T2, F2, 128, 128, ao=4 if f5 else None), 'dgrad7')
+            if not f5:
+                self.colsum(dy5[sl].data_ptr(), B * T2 * F2, 128, g('conv.5.bias', t), am_(4, t))
+            wgrad(t, p1[sl].data_ptr(), 1, dy5[sl].data_ptr(), 4, None, 5, B, T2, F2, 64, 128, db=g('conv.5.bias', t) if f5 else None)
+            check(conv_dgrad(t, dy5[sl].data_ptr(), 4, None, A['wd5'][tw].data_ptr(), p1[sl].data_ptr(), dp1[sl].data_ptr(),
+                             B, T2, F2, 64, 128, ao=5 if f2 else None), 'dgrad5')
+            if not f2:
+                self.colsum(dp1[sl].data_ptr(), B * T2 * F2, 64, g('conv.2.bias', t), am_(5, t))
+            wgrad(t, y1[sl].data_ptr(), 0, dp1[sl].data_ptr(), 5, am1_t, 2, B, T, F, 64, 64, db=g('conv.2.bias', t) if f2 else None)
+            check(conv_dgrad(t, dp1[sl].data_ptr(), 5, am1_t, A['wd2'][tw].data_ptr(), y1[sl].data_ptr(), dy1[sl].data_ptr(),
+                             B, T, F, 64, 64), 'dgrad2')
+            ws = self.scratch(lib.mtl_conv0_wgrad_workspace())
+            check(lib.mtl_conv0_wgrad(st, xin.data_ptr() + 4 * t * sX, dy1[sl].data_ptr(), g('conv.0.weight', t), g('conv.0.bias', t),
+                                      ws, B, T, F), 'wgrad0')
         self.join_side()
         self.flush_ln_reduce()     # the parameter / bias gradients of all 17 LayerNorms of the pass: one launch (after the join: one of
                                    # the 17 backward kernels ran on the side stream)
+        self.nt, self.sP, self.sG = 1, 0, 0

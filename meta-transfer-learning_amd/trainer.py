@@ -158,6 +158,14 @@ class _Readback:
         self.loss.copy_(out['loss'], non_blocking=True)
 
 
+class _TaskRead:
+    """One task's share of a task-batched pass's read-backs: views into the pinned whole-pass buffers (valid once the
+    iteration's end event has been waited for)."""
+
+    def __init__(self, gold_host, hyp, loss):
+        self.gold_host, self.hyp, self.loss = gold_host, hyp, loss
+
+
 def _strings(vocab, rows):
     return [''.join(vocab.id2label[int(t)] for t in row) for row in rows.tolist()]
 
@@ -286,6 +294,9 @@ class TransientTrainer():
         # faster than the unsplit task (18.4 vs 18.7 ms per 1-task step, slower with dropout), so it is opt-in
         self.split_single_task = os.environ.get('MTL_SPLIT_TASK', '0') == '1'
         self._graphs = {}
+        # the local tasks of a meta-step as ONE task-batched pass per phase (training passes at theta0, validation passes at the
+        # theta' stack) instead of one pass chain per task on concurrent lanes; MTL_BATCH_TASKS=0: the lanes
+        self.batch_tasks = os.environ.get('MTL_BATCH_TASKS', '1') != '0'
         # train() enqueues iteration i + 1 before it resolves (logs) iteration i (enqueue_iteration); MTL_PIPELINE=0: resolve at once
         self.pipeline = os.environ.get('MTL_PIPELINE', '1') != '0'
         self._turn = 0
@@ -330,6 +341,9 @@ class TransientTrainer():
                 and task_batches[0][0].shape[0] >= 2 and val_batch[0].shape[0] >= 2
                 and not any(e.prof is not None for e in model.engines)):
             return self._single_task_split(model, task_batches[0], val_batch, n_tasks, inner, args)
+        if self._can_batch(model, task_batches, val_batch, use_graphs):
+            return self._batched_iteration(model, task_batches, val_batch, n_tasks, inner, args, smoothing,
+                                           use_cmdlists and not any(e.forward_hook is not None for e in model.engines))
         n_lanes = min(model.n_lanes, max(len(task_batches), 1))
         if len(task_batches) > n_lanes:                      # several rounds: equal rounds (8 tasks on 6 lanes measured slower than on 3)
             rounds = -(-len(task_batches) // n_lanes)
@@ -388,6 +402,79 @@ class TransientTrainer():
             for lane in range(1, n_lanes):
                 model._axpy(Gm, bufs[lane][2], 1.0)
         return reads
+
+    # ------------------------------------------------------------------ task-batched passes
+    def _can_batch(self, model, task_batches, val_batch, use_graphs):
+        """All local tasks in one pass per phase: needs >= 2 tasks with identical batch shapes (samples x frames; label widths may
+        differ), the fused attention kernel and plain launches (no hipGraph capture, no profiling proxy)."""
+        if not self.batch_tasks or len(task_batches) < 2 or use_graphs:
+            return False
+        eng = model.engines[0]
+        if eng.prof is not None or not eng.fused_attn or eng.fused_pairs or eng.group_wgrads or eng.after_conv_hook is not None:
+            return False
+        shape = tuple(task_batches[0][0].shape)
+        return all(tuple(tb[0].shape) == shape and tb[0].dim() == 4 for tb in task_batches) and val_batch[0].dim() == 4
+
+    def _batched_iteration(self, model, task_batches, val_batch, n_tasks, inner, args, smoothing, use_cmdlists):
+        """trainer/asr/transient_trainer.py:178-237 for all local tasks at once.  The tasks of a meta-step are independent given
+        theta0, so their training passes run as ONE pass over nt x k_train samples (shared parameters; per-task losses and a
+        (nt, P) stack of per-task gradients), the nt inner steps as one kernel into a (nt, P) stack of theta', and their
+        validation passes as ONE pass in which task t reads its own theta'_t (task = outermost batch index of every product).
+        G = sum_t (g_tr,t + g_val,t / n) in task order.  The ~200 latency-bound transformer launches of a pass run once per phase
+        instead of once per task."""
+        dev = model.flat_parameters.device
+        theta0 = model.flat_parameters
+        eng = model.engines[0]
+        nt = len(task_batches)
+        total = model._layout.total
+        B, _, F, T = task_batches[0][0].shape
+        vx_in = val_batch[0]
+        key_b = (id(theta0), nt)
+        if getattr(self, '_stack_key', None) != key_b:
+            self._stack = (torch.zeros(nt * total, dtype=torch.float32, device=dev), torch.empty(nt * total, dtype=torch.float32, device=dev))
+            self._stack_key = key_b
+        g, theta1 = self._stack
+        Xtr = eng.buf('tb.x_tr', (nt * B, 1, F, T))
+        Xva = eng.buf('tb.x_va', tuple(vx_in.shape))
+        for t, (tx, _tsz, _tp, _ty, _tl) in enumerate(task_batches):
+            Xtr[t * B:(t + 1) * B].copy_(tx, non_blocking=True)
+        Xva.copy_(vx_in, non_blocking=True)
+        m_tr = eng.prepare_tasks([(tsz, ty) for (_tx, tsz, _tp, ty, _tl) in task_batches], B, T, slot=0)
+        m_va = eng.prepare_tasks([(val_batch[1], val_batch[3])] * nt, vx_in.shape[0], vx_in.shape[3], slot=1)
+        Bv = vx_in.shape[0]
+        slots = dict(hyp_tr=eng.buf('slot.hyp_tr', (nt * B, m_tr['Td']), torch.int64), loss_tr=eng.buf('slot.loss_tr', (nt,)),
+                     hyp_va=eng.buf('slot.hyp_va', (nt * Bv, m_va['Td']), torch.int64), loss_va=eng.buf('slot.loss_va', (nt,)))
+        G = model._G
+        lr = float(inner.param_groups[0]['lr'])
+
+        def body(_xa=None, _xb=None):
+            eng.zero_(g)                                                         # inner_opt.zero_grad()   (:198), every task
+            eng.forward_device(theta0, Xtr, m_tr, smoothing, hyp_out=slots['hyp_tr'], loss_out=slots['loss_tr'])      # (:188)
+            eng.backward(g, 1.0, sG=total)                                       # tr_loss.backward()      (:199)
+            if args.clip:
+                for t in range(nt):
+                    clip_flat_grad_(model, g[t * total:(t + 1) * total], args.max_norm, lane=0)      # (:205-206)
+            check(eng.lib.mtl_sgd_theta_prime_tasks(eng.stream, theta0.data_ptr(), g.data_ptr(), lr, theta1.data_ptr(), total, nt),
+                  'mtl_sgd_theta_prime_tasks')                                   # inner_opt.step()        (:207)
+            eng.forward_device(theta1, Xva, m_va, smoothing, hyp_out=slots['hyp_va'], loss_out=slots['loss_va'], sP=total)   # (:215)
+            eng.backward(g, 1.0 / n_tasks, sG=total)                             # (val_loss/n).backward(): g_t += g_val,t/n (Q1)
+            check(eng.lib.mtl_sum_tasks(eng.stream, G.data_ptr(), g.data_ptr(), total, nt, 0), 'mtl_sum_tasks')    # add_copy_grad() (:229)
+
+        key = ('batched', nt, (B, F, T), tuple(vx_in.shape), m_tr['Td'], m_va['Td'], n_tasks, bool(args.clip), float(args.max_norm),
+               smoothing, lr, theta0.data_ptr(), eng.dropout_p, g.data_ptr(), theta1.data_ptr(), G.data_ptr(),
+               torch.cuda.current_stream(dev).cuda_stream, eng.use_side_stream)
+        if use_cmdlists:
+            self._run_recorded(key, eng, Xtr, Xva, body)
+        else:
+            body()
+        hyp_tr = _pinned(('tb.hyp', 0, self._turn), slots['hyp_tr'].shape, torch.int64)
+        hyp_va = _pinned(('tb.hyp', 1, self._turn), slots['hyp_va'].shape, torch.int64)
+        loss_tr = _pinned(('tb.loss', 0, self._turn), (nt,), torch.float32)
+        loss_va = _pinned(('tb.loss', 1, self._turn), (nt,), torch.float32)
+        for dst, src in ((hyp_tr, slots['hyp_tr']), (hyp_va, slots['hyp_va']), (loss_tr, slots['loss_tr']), (loss_va, slots['loss_va'])):
+            dst.copy_(src, non_blocking=True)
+        return [(_TaskRead(m_tr['gold_hosts'][t], hyp_tr[t * B:(t + 1) * B], loss_tr[t:t + 1]),
+                 _TaskRead(m_va['gold_hosts'][t], hyp_va[t * Bv:(t + 1) * Bv], loss_va[t:t + 1])) for t in range(nt)]
 
     def _single_task_split(self, model, task, val_batch, n_tasks, inner, args):
         """A rank that holds ONE task (8 tasks on 8 GPUs) would leave the second lane idle, and the task's own chain

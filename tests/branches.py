@@ -92,17 +92,29 @@ def gates_from_engine(engine):
     return g
 
 
+def split_gates(g, nt):
+    """gates of a task-batched forward (nt tasks' samples / rows stacked along dim 0) -> one dict per task"""
+    parts = {k: torch.chunk(v, nt, dim=0) for k, v in g.items()}
+    return [{k: parts[k][t] for k in g} for t in range(nt)]
+
+
 class capture_gates:
-    """with capture_gates(model) as log: ... -> log = [gates of every forward in enqueue order] (every lane's engine).
-    The hook waits for the lane's stream, so lanes are serialised while capturing (test only)."""
+    """with capture_gates(model) as log: ... -> log = [gates of every forward in the ORACLE's pass order (task 0 train, task 0
+    validation, task 1 train, ...)] (every lane's engine).  Lanes enqueue in that order; a task-batched meta-iteration runs
+    [training pass of all tasks, validation pass of all tasks], whose gates are split per task and interleaved on exit (one
+    meta-iteration per capture).  The hook waits for the stream, so lanes are serialised while capturing (test only)."""
 
     def __init__(self, model):
-        self.model, self.log = model, []
+        self.model, self.log, self._batched = model, [], []
 
     def __enter__(self):
         def hook(eng):
             torch.cuda.current_stream(eng.device).synchronize()
-            self.log.append(gates_from_engine(eng))
+            g = gates_from_engine(eng)
+            if eng.nt > 1:
+                self._batched.append(split_gates(g, eng.nt))
+            else:
+                self.log.append(g)
         for e in self.model.engines:
             e.forward_hook = hook
         return self.log
@@ -110,6 +122,11 @@ class capture_gates:
     def __exit__(self, *exc):
         for e in self.model.engines:
             e.forward_hook = None
+        if self._batched:
+            nt = len(self._batched[0])
+            for t in range(nt):
+                for phase in self._batched:
+                    self.log.append(phase[t])
         return False
 
 
