@@ -81,7 +81,7 @@ def make_args(k, lr=1e-4, meta_lr=1e-4):
 # launch-level profiling: every library call that launches kernels, bracketed with HIP events on the stream it is given
 # ------------------------------------------------------------------------------------------------------------------
 _NOT_LAUNCHES = {'mtl_lowrank_supported', 'mtl_gemm_nt_h2_supported', 'mtl_event_record', 'mtl_stream_wait_event', 'mtl_cmdlist_run', 'mtl_cmdlist_opcode', 'mtl_abi_version',
-                 'mtl_attn_supported', 'mtl_gemm_f32_ex_route', 'mtl_levenshtein_u32'}
+                 'mtl_attn_supported', 'mtl_gemm_f32_ex_route', 'mtl_levenshtein_u32', 'mtl_layernorm_bwd_g_waves'}
 
 
 class LaunchProfiler:
@@ -128,10 +128,10 @@ def classify(lib, name, a, conv_mode, wgrad_x3_dense):
     """(class, algorithmic work, 'flop' | 'byte' | None, rocprofv3 kernel symbol(s)) of one library call; `a` = its arguments in
     the order of include/mtl_hip.h.  FLOPs are 2 x MACs of the dense extent of the reference op; bytes are the tensors the op
     must read and write once."""
-    if name in ('mtl_gemm_f32_ex', 'mtl_gemm_f32'):
-        M, N, K, batch = a[3], a[4], a[5], a[17]
-        kb, rs = (a[26], a[29]) if name == 'mtl_gemm_f32_ex' else (1, None)
-        small = name == 'mtl_gemm_f32_ex' and lib.mtl_gemm_f32_ex_route(M, N, K, batch, kb, 1 if rs else 0)
+    if name in ('mtl_gemm_f32_ex', 'mtl_gemm_f32', 'mtl_gemm_f32_tb'):
+        M, N, K, batch = a[3], a[4], a[5], a[17]              # (mtl_gemm_f32_tb: batch counts the items of all tasks)
+        kb, rs = (a[26], a[29]) if name != 'mtl_gemm_f32' else (1, None)
+        small = name != 'mtl_gemm_f32' and lib.mtl_gemm_f32_ex_route(M, N, K, batch, kb, 1 if rs else 0)
         return ('gemm_small' if small else 'gemm_big', 2.0 * M * N * K * batch * kb, 'flop',
                 'gemm16_kernel<...>' if small else 'gemm_kernel<...> (+ splitk_reduce_kernel)')
     if name == 'mtl_gemm_nt_h2':
@@ -160,15 +160,15 @@ def classify(lib, name, a, conv_mode, wgrad_x3_dense):
         prods = 2 if name == 'mtl_attn_fwd' else 7            # backward recomputes S: 2 x QK^T, dP, dV, dQ, dK (+ the second S)
         return (name[4:], prods * 2.0 * B * H * Tq * Tk * dk * (0.5 if causal else 1.0), 'flop',
                 'attn_fwd_kernel' if prods == 2 else 'attn_bwd_kernel (key side + query side in one grid)')
-    if name == 'mtl_layernorm_fwd':
+    if name in ('mtl_layernorm_fwd', 'mtl_layernorm_fwd_g'):
         rows, d = a[12], a[13]
         return 'layernorm_fwd', 4.0 * rows * d * (4 if a[2] else 3), 'byte', 'layernorm_fwd_kernel'
-    if name == 'mtl_layernorm_bwd':
+    if name in ('mtl_layernorm_bwd', 'mtl_layernorm_bwd_g'):
         rows, d = a[15], a[16]
         return 'layernorm_bwd', 4.0 * rows * d * (4 if a[10] else 3), 'byte', 'layernorm_bwd_kernel (parameter reductions: ln_param_reduce_batch_kernel, once per pass)'
-    if name == 'mtl_ce_argmax_fwd':
+    if name in ('mtl_ce_argmax_fwd', 'mtl_ce_argmax_fwd_g'):
         return 'ce_fwd', 4.0 * a[3] * a[4], 'byte', 'ce_fwd_kernel'
-    if name == 'mtl_ce_bwd':
+    if name in ('mtl_ce_bwd', 'mtl_ce_bwd_g'):
         return 'ce_bwd', 8.0 * a[4] * a[5], 'byte', 'ce_bwd_kernel'
     if name == 'mtl_colsum_accum':
         return 'colsum', 4.0 * a[2] * a[3], 'byte', 'colsum_partial_kernel + colsum_final_kernel'
@@ -177,6 +177,12 @@ def classify(lib, name, a, conv_mode, wgrad_x3_dense):
         return name[4:], 4.0 * B * H * (15 if name.endswith('fwd') else 17), 'byte', name[4:] + '_kernel'
     if name in ('mtl_sgd_theta_prime', 'mtl_axpy'):
         return name[4:], 12.0 * a[-1], 'byte', name[4:] + '_kernel'
+    if name == 'mtl_sgd_theta_prime_tasks':
+        return 'sgd_theta_prime', 4.0 * a[5] * (1 + 2 * a[6]), 'byte', 'sgd_theta_prime_tasks_kernel'
+    if name == 'mtl_sum_tasks':
+        return 'sum_tasks', 4.0 * a[3] * (1 + a[4]), 'byte', 'sum_tasks_kernel'
+    if name in ('mtl_embed_pe_fwd_g', 'mtl_embed_bwd_g'):
+        return name[4:-2], None, None, name[4:-2] + '_kernel'
     if name == 'mtl_adam_step':
         return 'adam_step', 28.0 * a[-1], 'byte', 'adam_kernel'
     if name == 'mtl_permute_hc':
@@ -199,8 +205,10 @@ def peak_of(cls, unit, conv_mode, wgrad_x3_dense):
 
 
 def serial_profile(mtl, trainer, model, vocab, tasks, my_tasks, n_tasks, inner, outer, args, dev):
-    """One extra meta-iteration with task lanes, the side stream and command-list replay switched off and HIP events around
-    EVERY launch: isolated durations (what rocprofv3 reports for a non-overlapped dispatch), grouped into kernel classes."""
+    """One extra meta-iteration with the side stream and command-list replay switched off (and one lane, where the tasks are not
+    batched) and HIP events around EVERY launch: isolated durations (what rocprofv3 reports for a non-overlapped dispatch),
+    grouped into kernel classes.  The step takes the schedule of the timed region: the task-batched passes when the trainer
+    batches the local tasks."""
     lanes, model.n_lanes = model.n_lanes, 1
     prof = LaunchProfiler(mtl._lib.lib(), dev)
     saved = []
@@ -246,11 +254,11 @@ def serial_profile(mtl, trainer, model, vocab, tasks, my_tasks, n_tasks, inner, 
     if dump:            # diagnostics: per-shape time of the product launches of the profiled step
         shapes = {}
         for name, a, e0, e1 in prof.records:
-            if name == 'mtl_gemm_f32_ex':
+            if name in ('mtl_gemm_f32_ex', 'mtl_gemm_f32_tb'):
                 key = 'gemm ta%d tb%d M%d N%d K%d b%d kb%d rs%d' % (a[1], a[2], a[3], a[4], a[5], a[17], a[26], 1 if a[29] else 0)
             elif name == 'mtl_lowrank_pair':
                 key = 'pair M%d Kin%d r%d N%d n%d sum%d acc%d' % tuple(a[15:22])
-            elif name in ('mtl_attn_fwd', 'mtl_attn_bwd', 'mtl_layernorm_fwd', 'mtl_layernorm_bwd'):
+            elif name in ('mtl_attn_fwd', 'mtl_attn_bwd', 'mtl_layernorm_fwd', 'mtl_layernorm_bwd', 'mtl_layernorm_fwd_g', 'mtl_layernorm_bwd_g'):
                 key = name + ' ' + ' '.join(str(v) for v in a if isinstance(v, int) and 0 <= v < 100000)
             else:
                 continue
@@ -450,6 +458,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-threads', type=int, default=0)
     ap.add_argument('--no-extras', action='store_true', help='only the headline timed region + the serial roofline step')
+    ap.add_argument('--lanes', action='store_true', help='per-task pass chains on concurrent lanes instead of task-batched passes (MTL_BATCH_TASKS=0)')
     ap.add_argument('--serial', action='store_true', help='no task lanes / side stream / replay (for rocprofv3 per-kernel durations)')
     ap.add_argument('--workload', default='asr', choices=['asr', 'lm'], help="'lm': the LSTM-LM meta loop (BASELINE.json configs[4], SURVEY 8(f) f3)")
     a = ap.parse_args()
@@ -474,6 +483,8 @@ def main():
     with contextlib.redirect_stdout(io.StringIO()):
         model = mtl_amd.init_transformer_model(args, vocab, r=CFG['r']).to(dev)
     trainer = mtl_amd.TransientTrainer()
+    if a.lanes:
+        trainer.batch_tasks = False
     if a.serial:
         model.n_lanes = 1
         trainer.use_cmdlists = False
@@ -501,6 +512,7 @@ def main():
             pass
         table = {}
         for cls, c in sorted(classes.items(), key=lambda kv: -kv[1]['time']):
+            # "pass" = forward + backward of ONE task's batch (a task-batched pass of nt tasks counts nt)
             row = dict(ms_per_pass=c['time'] / passes * 1e3, launches_per_pass=c['launches'] / passes, symbols=c['symbols'])
             if c['unit'] is not None and c['work'] > 0:
                 peak, unit, bound = peak_of(cls, c['unit'], eng.conv_mode, eng.wgrad_x3_dense)
@@ -533,8 +545,11 @@ def main():
                                         % (a.tasks, len(my_tasks), a.k, a.frames, a.labels),
                                tasks=a.tasks, k_train=a.k, src_frames=a.frames, tgt_len=a.labels, parallelism='task-sharded dp%d' % world,
                                collective=mdist.backend_name(), inputs='resident in HBM before the timed region',
-                               schedule='serial' if a.serial else '%d task lanes + side stream, command-list replay %s, host one iteration ahead %s'
-                                        % (model.n_lanes, 'on' if trainer.use_cmdlists else 'off', 'on' if trainer.pipeline else 'off'),
+                               schedule=('serial, ' if a.serial else '') + (
+                                   'the %d local tasks as ONE task-batched pass per phase (training passes at theta0, validation passes at the theta\' stack)'
+                                   % len(my_tasks) if (trainer.batch_tasks and len(my_tasks) > 1) else '%d task lanes' % model.n_lanes) + (
+                                   '' if a.serial else ' + side stream, command-list replay %s, host one iteration ahead %s'
+                                   % ('on' if trainer.use_cmdlists else 'off', 'on' if trainer.pipeline else 'off')),
                                conv_arithmetic={'h2': '3x3 convolutions on 2-way fp16 splits of power-of-two-scaled fp32 operands (22 '
                                                       'significand bits, 3 fp16 MFMAs per step), fp32 accumulate: error <= 2.5x that of an '
                                                       'fp32 convolution against fp64 (tests/test_ops_gpu.py), parity bar unchanged',

@@ -342,8 +342,7 @@ class TransientTrainer():
                 and not any(e.prof is not None for e in model.engines)):
             return self._single_task_split(model, task_batches[0], val_batch, n_tasks, inner, args)
         if self._can_batch(model, task_batches, val_batch, use_graphs):
-            return self._batched_iteration(model, task_batches, val_batch, n_tasks, inner, args, smoothing,
-                                           use_cmdlists and not any(e.forward_hook is not None for e in model.engines))
+            return self._batched_iteration(model, task_batches, val_batch, n_tasks, inner, args, smoothing, use_cmdlists)
         n_lanes = min(model.n_lanes, max(len(task_batches), 1))
         if len(task_batches) > n_lanes:                      # several rounds: equal rounds (8 tasks on 6 lanes measured slower than on 3)
             rounds = -(-len(task_batches) // n_lanes)
@@ -410,7 +409,7 @@ class TransientTrainer():
         if not self.batch_tasks or len(task_batches) < 2 or use_graphs:
             return False
         eng = model.engines[0]
-        if eng.prof is not None or not eng.fused_attn or eng.fused_pairs or eng.group_wgrads or eng.after_conv_hook is not None:
+        if not eng.fused_attn or eng.fused_pairs or eng.group_wgrads or eng.after_conv_hook is not None:
             return False
         shape = tuple(task_batches[0][0].shape)
         return all(tuple(tb[0].shape) == shape and tb[0].dim() == 4 for tb in task_batches) and val_batch[0].dim() == 4
