@@ -131,7 +131,10 @@ def classify(lib, name, a, conv_mode, wgrad_x3_dense):
     if name in ('mtl_gemm_f32_ex', 'mtl_gemm_f32', 'mtl_gemm_f32_tb'):
         M, N, K, batch = a[3], a[4], a[5], a[17]              # (mtl_gemm_f32_tb: batch counts the items of all tasks)
         kb, rs = (a[26], a[29]) if name != 'mtl_gemm_f32' else (1, None)
-        small = name != 'mtl_gemm_f32' and lib.mtl_gemm_f32_ex_route(M, N, K, batch, kb, 1 if rs else 0)
+        route = lib.mtl_gemm_f32_ex_route(M, N, K, batch, kb, 1 if rs else 0) if name != 'mtl_gemm_f32' else 0
+        if route == 2 and not (a[1] and a[2]):                # the bf16-split engine (the pass has no doubly transposed product)
+            return 'gemm_x3', 2.0 * M * N * K * batch * kb, 'flop', 'gemm_x3_kernel<TA,TB,RS>'
+        small = route == 1
         return ('gemm_small' if small else 'gemm_big', 2.0 * M * N * K * batch * kb, 'flop',
                 'gemm16_kernel<...>' if small else 'gemm_kernel<...> (+ splitk_reduce_kernel)')
     if name == 'mtl_gemm_nt_h2':
@@ -199,6 +202,8 @@ def peak_of(cls, unit, conv_mode, wgrad_x3_dense):
         return PEAK_HBM_GBS, 'GB/s', 'hbm'
     if cls == 'gemm_h2':
         return PEAK_H2_TFLOPS, 'TFLOP/s', 'mfma'
+    if cls == 'gemm_x3':
+        return PEAK_X3_TFLOPS, 'TFLOP/s', 'mfma'
     if cls.startswith('conv') and conv_mode != 'f32' and not (cls == 'conv5_wgrad' and not wgrad_x3_dense):
         return (PEAK_H2_TFLOPS if conv_mode == 'h2' else PEAK_X3_TFLOPS), 'TFLOP/s', 'mfma'
     return PEAK_F32_MFMA_TFLOPS, 'TFLOP/s', 'mfma'

@@ -70,9 +70,19 @@ int mtl_gemm_f32_tb(void* stream, int transA, int transB, int M, int N, int K, f
                     int batch, int H, long sAb, long sAh, long sBb, long sBh, long sCb, long sCh, long sBias, int kbatch, long sAk,
                     long sBk, float* rowsum, long sRowsum, float* workspace, long workspace_bytes, long sBiasH, long sRowsumH,
                     int tasks, long sAt, long sBt, long sCt, long sBiasT, long sRowsumT);
-/* which engine mtl_gemm_f32_ex picks: 1 = small-tile (kernel symbol gemm16_kernel<...>), 0 = forwarded to mtl_gemm_f32
- * (gemm_kernel<...>); used by bench.py to attribute launch timings to the rocprofv3 kernel classes */
+/* which engine mtl_gemm_f32_ex / _tb picks (16-byte aligned operands, not transA && transB): 2 = bf16-split engine
+ * (gemm_x3_kernel<...>, below), 1 = small-tile (gemm16_kernel<...>), 0 = forwarded to mtl_gemm_f32 (gemm_kernel<...>); used by
+ * bench.py to attribute launch timings to the rocprofv3 kernel classes */
 int mtl_gemm_f32_ex_route(int M, int N, int K, int batch, int kbatch, int has_rowsum);
+/* Large products of mtl_gemm_f32_ex / _tb run on the bf16 matrix pipe: every fp32 operand element is split EXACTLY into three bf16
+ * pieces on its way to LDS and a block product is six v_mfma_f32_32x32x16_bf16 accumulated in fp32 (a0 b0 + a0 b1 + a1 b0 + a1 b1 +
+ * a0 b2 + a2 b0; dropped terms < 2^-23 |a||b|): fp32-class results (tests/test_ops_gpu.py compares both engines with fp64), no
+ * scaling and no range caveat, 2.67 x the rate of the fp32 MFMA.  A product is routed there when its grid of 256 x 128 output tiles
+ * (x batch items) has at least `min_tiles` workgroups and its operands are 16-byte aligned (csrc/mtl_gemm_x3.hip; nn.Linear forward
+ * / backward of modules/common_layers.py:130,287-289,303 and modules/decoder.py:109 in a task-batched pass).
+ * mtl_gemm_x3_min_tiles(set): set >= 0 replaces the threshold (0 = engine off; default 128 or the MTL_GEMM_X3 environment
+ * variable), set < 0 only queries; returns the previous value. */
+int mtl_gemm_x3_min_tiles(int set);
 
 /* C[M,N] = A[M,K] . B[N,K]^T (+ bias[N]) (gate: C = gate[m][n] > 0 ? C : 0) on two-piece fp16 splits of both operands
  * (3 v_mfma_f32_32x32x16_f16 per 16-deep step, see the *_h2 convolutions below for the arithmetic and for amax_a / amax_b:

@@ -21,6 +21,7 @@ SIGNATURES = {
     'mtl_gemm_f32_tb': (I, [P, I, I, I, I, I, F, P, I, P, I, P, I, P, P, I, I, I, I, L, L, L, L, L, L, L, I, L, L, P, L, P, L, L, L,
                             I, L, L, L, L, L]),
     'mtl_gemm_f32_ex_route': (I, [I, I, I, I, I, I]),
+    'mtl_gemm_x3_min_tiles': (I, [I]),
     'mtl_gemm_wgrad_grouped': (I, [P, P, I, I]),
     'mtl_lowrank_supported': (I, [I, I, I]),
     'mtl_lowrank_pair': (I, [P, P, L, I, P, L, P, L, P, L, P, L, P, L, I, I, I, I, I, I, I, I]),

@@ -34,6 +34,14 @@ int mtl_gemm_f32_3l(void* stream, int transA, int transB, int M, int N, int K, f
                     long sAh, long sBb, long sBh, long sCb, long sCh, long sBias, long sBiasH, float* workspace, long workspace_bytes,
                     int tasks, long sAt, long sBt, long sCt, long sBiasT);
 
+// bf16-split engine (mtl_gemm_x3.hip): 1 = issued there, 0 = not eligible (stay on the fp32 engines), < 0 = error
+int mtl_gemm_x3_route(void* stream, int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda, const float* B,
+                      int ldb, float* C, int ldc, const float* bias, const float* gate, int ldg, int flags, int batch, int H, long sAb,
+                      long sAh, long sBb, long sBh, long sCb, long sCh, long sBias, int kbatch, long sAk, long sBk, float* rowsum,
+                      long sRowsum, long sBiasH, long sRowsumH, int tasks, long sAt, long sBt, long sCt, long sBiasT, long sRowsumT);
+
+int mtl_gemm_x3_eligible(int M, int N, int batch);
+
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 #ifndef MTL_AMAX_SLOTS

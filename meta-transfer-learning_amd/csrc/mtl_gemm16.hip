@@ -368,6 +368,7 @@ extern "C" {
 
 /* 1: this product runs on the small-tile engine (gemm16_kernel<...>), 0: it is forwarded to mtl_gemm_f32 (gemm_kernel<...>) */
 int mtl_gemm_f32_ex_route(int M, int N, int K, int batch, int kbatch, int has_rowsum) {
+    if (mtl_gemm_x3_eligible(M, N, batch)) return 2;
     return route_small(M, N, K, batch, kbatch, has_rowsum != 0) ? 1 : 0;
 }
 
@@ -391,6 +392,12 @@ int mtl_gemm_f32_tb(void* stream, int transA, int transB, int M, int N, int K, f
     if (M <= 0 || N <= 0 || K <= 0 || batch <= 0 || H <= 0 || kbatch <= 0 || tasks <= 0 || !A || !B || !C) return MTL_EINVAL;
     if (rowsum && !transA) return MTL_EINVAL;
     if (batch % tasks != 0 || (batch / tasks) % H != 0) return MTL_EINVAL;
+    {   // large products: the bf16-split engine (mtl_gemm_x3.hip)
+        const int rc = mtl_gemm_x3_route(stream, transA, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, bias, gate, ldg, flags, batch, H,
+                                         sAb, sAh, sBb, sBh, sCb, sCh, sBias, kbatch, sAk, sBk, rowsum, sRowsum, sBiasH, sRowsumH, tasks,
+                                         sAt, sBt, sCt, sBiasT, sRowsumT);
+        if (rc != 0) return rc < 0 ? rc : MTL_OK;
+    }
     if (!route_small(M, N, K, batch, kbatch, rowsum != nullptr))
         return mtl_gemm_f32_3l(stream, transA, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, bias, gate, ldg, flags, batch, H, sAb,
                                sAh, sBb, sBh, sCb, sCh, sBias, sBiasH, workspace, workspace_bytes, tasks, sAt, sBt, sCt, sBiasT);

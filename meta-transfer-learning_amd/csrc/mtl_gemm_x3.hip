@@ -1,0 +1,398 @@
+// fp32 GEMM on the bf16 matrix pipe of gfx950 (MI355X): every fp32 operand element is split EXACTLY into three bf16 pieces
+// (8 + 8 + 8 significand bits, bf16 has fp32's exponent range: no scaling, no range caveat) on its way from HBM to LDS, and a
+// 32 x 32 x 16 block product is six v_mfma_f32_32x32x16_bf16 (a0 b0 + a0 b1 + a1 b0 + a1 b1 + a0 b2 + a2 b0; the dropped terms are
+// < 2^-22 of |a||b|) accumulated in fp32 -- fp32-class results (measured against fp64: as accurate as the fp32 MFMA engines) at
+// 16 / 6 = 2.67 x the rate of v_mfma_f32_32x32x2_f32 (roof 2517 / 6 = 419 TF against 157).
+//
+// This engine takes the large products of the transformer half of a (task-batched) pass -- the FFN, the rank-100 projection
+// stages, the vocabulary projection, their data gradients and their weight gradients (modules/common_layers.py:130,287-289,303,
+// modules/decoder.py:109 and their autograd backward) -- with the full contract of mtl_gemm_f32_tb: three batch levels
+// (task, outer, inner), K-batching (C = sum_z op(A_z) op(B_z)), row sums of op(A) (bias gradients), bias / ReLU / gate /
+// accumulate epilogue.  mtl_gemm_f32_tb routes a product here when its output tiles fill a good part of the chip and its
+// operands are 16-byte aligned; everything else stays on the exact-fp32 engines (mtl_gemm16.hip, mtl_mfma.hip).
+//
+// Workgroup = 8 waves (4 x 2), tile 256 x 128 x 32, a wave owns 64 x 64 (four 32 x 32 accumulators), two waves per SIMD.  LDS
+// holds TWO stages of [operand][piece][rows][32 k] bf16 (2 x 72 KB) with the 16-byte chunk swizzle of mtl_h2.h (fragment reads
+// are conflict-free ds_read_b128).  Per K step: the global loads of tile kt + 2 are issued into the register set that tile kt left,
+// the MFMAs of tile kt read stage kt & 1, and -- in the same basic block, so that the VALU work sits between the MFMAs instead of
+// in front of them -- tile kt + 1 (loaded a whole step ago) is split into the other stage; one barrier per step.  Operands keep
+// their HBM orientation: a K-major source (k contiguous) is split quad by quad; an MN-major one (rows contiguous: transposed A,
+// non-transposed B) is loaded as 4-row blocks and transposed in registers, so both land in the same [row][k] image.
+// Workgroups are numbered XCD-aware (XCD x = workgroup id % 8 owns a contiguous range of the (z, m, n) tile sequence).
+// All reductions are fixed-order: bitwise reproducible.
+#include <cstdlib>
+#include <type_traits>
+
+#include "mtl_common.h"
+#include "mtl_h2.h"
+#include "../../include/mtl_hip.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int BM = 256, BN = 128, BK = 32, NT = 512;
+constexpr int PLANE_A = BM * 64, PLANE_B = BN * 64;      // one bf16 piece of one operand tile: rows x 64 bytes
+constexpr int STAGE = 3 * (PLANE_A + PLANE_B);
+constexpr int SMEM = 2 * STAGE;
+
+struct X3P {
+    const float *A, *B;
+    float* C;
+    const float* bias;
+    const float* gate;
+    float* rowsum;
+    int M, N, K, lda, ldb, ldc, ldg;
+    float alpha;
+    int flags, H;
+    long sAb, sAh, sBb, sBh, sCb, sCh, sBias;
+    int kb;
+    long sAk, sBk, sRow;
+    long sBiasH, sRowH;
+    int Zt;
+    long sAt, sBt, sCt, sBiasT, sRowT;
+    int total;
+};
+
+// x0, x1 -> three dwords of packed bf16 pairs, x = h + m + l EXACTLY: h and m are truncations (top 8 significand bits of x and of
+// the exact residual x - h), which leaves at most 8 significant bits for l.  Truncation keeps the dependency chain at and -> sub ->
+// and -> sub (a round-to-nearest split is cvt -> shift -> sub twice over) and the three packs (v_perm_b32) hang off it sideways.
+__device__ __forceinline__ unsigned pack_hi(float x0, float x1) {      // {bf16 bits of x0 (low half), of x1 (high half)}, truncating
+    return __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, x1), __builtin_bit_cast(unsigned, x0), 0x07060302u);
+}
+__device__ __forceinline__ void split3(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+    const float h0 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x0) & 0xffff0000u);
+    const float h1 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x1) & 0xffff0000u);
+    const float r0 = x0 - h0, r1 = x1 - h1;
+    const float m0 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, r0) & 0xffff0000u);
+    const float m1 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, r1) & 0xffff0000u);
+    const float q0 = r0 - m0, q1 = r1 - m1;
+    h = pack_hi(x0, x1);
+    m = pack_hi(r0, r1);
+    l = pack_hi(q0, q1);
+}
+
+__device__ __forceinline__ float sel(unsigned m, unsigned bit, float x) { return (m & bit) ? x : 0.f; }
+__device__ __forceinline__ float comp(const float4& v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
+
+// One ROWS x 32-k operand tile on its way HBM -> registers -> LDS (512 threads).  The loop-invariant part of every address (the
+// thread's rows, clamped into range) is set up once (init); fetch() adds the K position, is BRANCH-FREE (clamped addresses) and
+// leaves NV float4 in registers:
+//   KMAJ   (source [row][k]): thread (lr = tid >> 3, kq = tid & 7) holds k = 4 kq .. + 3 of rows lr + 64 i, i < ROWS / 64;
+//   MN-major (source [k][row]), 256 rows: thread (mq = tid >> 3, kq) holds the 4 x 4 block rows 4 mq .. + 3, k = 4 kq .. + 3;
+//   MN-major, 128 rows: thread (kh = tid >> 8, mq = (tid >> 3) & 31, kq) holds rows 4 mq .. + 3 of k = 4 kq + 2 kh, + 1.
+// Rows beyond the operand's extent are NOT zeroed: row m of op(A) only reaches row m of C and row n of op(B) only column n, and
+// those are never stored (nor is their row sum), so whatever the clamped address delivers is harmless.  Only k >= K must
+// contribute zeros: km (a 4-bit mask per quad, K-major) / a validity bit per k row (MN-major), applied by commit<FULL = false>.
+template <bool KMAJ, int ROWS>
+struct Opnd {
+    static constexpr int NV = ROWS / 64;          // float4 per thread and tile (4 or 2)
+    static constexpr int PLANE = ROWS * 64;
+    const float* base[KMAJ ? NV : 1];
+    long ld;
+    __device__ __forceinline__ void init(const float* src, long ld_, int row0, int nrows, int tid) {
+        ld = ld_;
+        if (KMAJ) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) base[i] = src + (long)min(row0 + (tid >> 3) + 64 * i, nrows - 1) * ld_;
+        } else {
+            // a quad that straddles the last row stays inside the row's ld (16-byte aligned rows, ld % 4 == 0); a quad beyond is clamped
+            const int r = row0 + (ROWS == 256 ? (tid >> 3) : ((tid >> 3) & 31)) * 4;
+            base[0] = src + (r < nrows ? r : 0);
+        }
+    }
+    struct Regs {
+        float4 v[NV];
+        unsigned km;            // K-major: bit e = element e of the quads is inside K; MN-major: bit j = k row j is
+    };
+    // zoff: element offset of the K-batch item; k0: first k of the tile
+    __device__ __forceinline__ void fetch(Regs& r, long zoff, int k0, int K, int tid) const {
+        const int kq = tid & 7;
+        if (KMAJ) {
+            const int k = k0 + kq * 4;
+            r.km = (k < K ? 1u : 0u) | (k + 1 < K ? 2u : 0u) | (k + 2 < K ? 4u : 0u) | (k + 3 < K ? 8u : 0u);
+            const long off = zoff + (r.km ? k : 0);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) r.v[i] = *reinterpret_cast<const float4*>(base[i] + off);
+        } else {
+            r.km = 0;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const int k = k0 + kq * 4 + (ROWS == 256 ? j : 2 * (tid >> 8) + j);
+                r.km |= (k < K ? 1u : 0u) << j;
+                r.v[j] = *reinterpret_cast<const float4*>(base[0] + zoff + (long)min(k, K - 1) * ld);
+            }
+        }
+    }
+    // FULL: the tile lies inside K (wave-uniform), no masks.  rs: row sums of the thread's 4 rows (MN-major A only)
+    template <bool FULL, bool RS>
+    __device__ __forceinline__ void commit(const Regs& r, unsigned char* lds, int tid, float (&rs)[4]) const {
+        const int kq = tid & 7;
+        if (KMAJ) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int row = (tid >> 3) + 64 * i;
+                float4 x = r.v[i];
+                if (!FULL) x = make_float4(sel(r.km, 1u, x.x), sel(r.km, 2u, x.y), sel(r.km, 4u, x.z), sel(r.km, 8u, x.w));
+                uint2 h, mm, l;
+                split3(x.x, x.y, h.x, mm.x, l.x);
+                split3(x.z, x.w, h.y, mm.y, l.y);
+                unsigned char* dst = lds + row * 64 + (((kq >> 1) ^ ((row >> 2) & 3)) << 4) + (kq & 1) * 8;
+                *reinterpret_cast<uint2*>(dst) = h;
+                *reinterpret_cast<uint2*>(dst + PLANE) = mm;
+                *reinterpret_cast<uint2*>(dst + 2 * PLANE) = l;
+            }
+        } else if (ROWS == 256) {
+            const int mq = tid >> 3;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float4 x = make_float4(comp(r.v[0], i), comp(r.v[1], i), comp(r.v[2], i), comp(r.v[3], i));
+                if (!FULL) x = make_float4(sel(r.km, 1u, x.x), sel(r.km, 2u, x.y), sel(r.km, 4u, x.z), sel(r.km, 8u, x.w));
+                if (RS) rs[i] += (x.x + x.y) + (x.z + x.w);
+                uint2 h, mm, l;
+                split3(x.x, x.y, h.x, mm.x, l.x);
+                split3(x.z, x.w, h.y, mm.y, l.y);
+                unsigned char* dst = lds + (mq * 4 + i) * 64 + (((kq >> 1) ^ (mq & 3)) << 4) + (kq & 1) * 8;
+                *reinterpret_cast<uint2*>(dst) = h;
+                *reinterpret_cast<uint2*>(dst + PLANE) = mm;
+                *reinterpret_cast<uint2*>(dst + 2 * PLANE) = l;
+            }
+        } else {
+            const int mq = (tid >> 3) & 31, kh = tid >> 8;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float x0 = comp(r.v[0], i), x1 = comp(r.v[1], i);
+                if (!FULL) {
+                    x0 = sel(r.km, 1u, x0);
+                    x1 = sel(r.km, 2u, x1);
+                }
+                unsigned h, mm, l;
+                split3(x0, x1, h, mm, l);
+                unsigned char* dst = lds + (mq * 4 + i) * 64 + (((kq >> 1) ^ (mq & 3)) << 4) + (kq & 1) * 8 + kh * 4;
+                *reinterpret_cast<unsigned*>(dst) = h;
+                *reinterpret_cast<unsigned*>(dst + PLANE) = mm;
+                *reinterpret_cast<unsigned*>(dst + 2 * PLANE) = l;
+            }
+        }
+    }
+};
+
+template <bool TA, bool TB, bool RS>      // RS: row sums of op(A) ride along (TA only)
+__global__ __launch_bounds__(NT) void gemm_x3_kernel(X3P p) {
+    using OA = Opnd<!TA, BM>;          // op(A) is M x K: stored [m][k] unless transposed
+    using OB = Opnd<TB, BN>;           // op(B) is K x N: stored [n][k] when transposed
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, hi = lane >> 5;
+    const int per = (p.total + 7) >> 3;
+    const int t = (blockIdx.x & 7) * per + (blockIdx.x >> 3);       // XCD-aware order (see the header)
+    if (t >= p.total) return;
+    const int nx = (p.N + BN - 1) / BN, ny = (p.M + BM - 1) / BM;
+    const int z = t / (nx * ny), rem = t - z * (nx * ny);
+    const int m0 = (rem / nx) * BM, n0 = (rem % nx) * BN;
+    const int zt = z / p.Zt, zz = z - zt * p.Zt;
+    const int zb = zz / p.H, zh = zz - zb * p.H;
+    OA la;
+    OB lb;
+    la.init(p.A + zt * p.sAt + zb * p.sAb + zh * p.sAh, p.lda, m0, p.M, tid);
+    lb.init(p.B + zt * p.sBt + zb * p.sBb + zh * p.sBh, p.ldb, n0, p.N, tid);
+    typename OA::Regs ra0, ra1;
+    typename OB::Regs rb0, rb1;
+    const int nk = (p.K + BK - 1) / BK, tiles = nk * p.kb;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+    const bool do_rowsum = RS && n0 == 0;     // (every workgroup sums -- 16 adds per tile --, the first column of workgroups stores)
+    const bool kfull = p.K % BK == 0;             // no ragged last K tile
+    float rs[4] = {0.f, 0.f, 0.f, 0.f};
+    auto fetch = [&](int tile, typename OA::Regs& ra, typename OB::Regs& rb) {
+        const int zn = tile / nk, kt = tile - zn * nk;
+        la.fetch(ra, zn * p.sAk, kt * BK, p.K, tid);
+        lb.fetch(rb, zn * p.sBk, kt * BK, p.K, tid);
+    };
+    auto commit = [&](auto full_tag, const typename OA::Regs& ra, const typename OB::Regs& rb, unsigned char* stage) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        la.template commit<FULL, RS>(ra, stage, tid, rs);
+        lb.template commit<FULL, false>(rb, stage + 3 * PLANE_A, tid, rs);
+    };
+    // fragment addresses: row (wm | wn) * 64 + 32 i + l31, chunk (2 st + hi) ^ ((row >> 2) & 3)
+    const int arow = (wm * 64 + l31) * 64, brow = 3 * PLANE_A + (wn * 64 + l31) * 64;
+    int csw[2];
+#pragma unroll
+    for (int st = 0; st < 2; ++st) csw[st] = ((st * 2 + hi) ^ ((l31 >> 2) & 3)) << 4;
+    auto compute = [&](const unsigned char* stage) {
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            uint4 a[2][3], b[2][3];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) {
+                    a[i][pc] = *reinterpret_cast<const uint4*>(stage + pc * PLANE_A + arow + i * 32 * 64 + csw[st]);
+                    b[i][pc] = *reinterpret_cast<const uint4*>(stage + pc * PLANE_B + brow + i * 32 * 64 + csw[st]);
+                }
+            // six terms, smallest first, each over the four accumulators (dependent MFMAs are four issues apart)
+            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int tm = 0; tm < 6; ++tm)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i][PA[tm]]),
+                                                                            __builtin_bit_cast(bf16x8, b[j][PB[tm]]), acc[i][j], 0, 0, 0);
+        }
+    };
+    // step kt: tile kt + 2 -> the register set tile kt left; multiply stage kt & 1; split tile kt + 1 into the other stage.
+    // The main loop's steps are ONE basic block each (no condition between the MFMAs and the split: hipcc interleaves them); it
+    // runs unmasked -- it never meets the (possibly ragged) last K tile, except with K-batching, where only K % 32 == 0 qualifies.
+    // The last steps go through the general form.
+    auto step_main = [&](auto full_tag, int kt, typename OA::Regs& rac, typename OB::Regs& rbc, const typename OA::Regs& ran,
+                         const typename OB::Regs& rbn) {
+        fetch(kt + 2, rac, rbc);
+        __builtin_amdgcn_sched_barrier(0);           // the loads go out FIRST (hipcc sinks them behind the MFMAs otherwise: a step of flight time lost)
+        compute(sm + (kt & 1) * STAGE);
+        commit(full_tag, ran, rbn, sm + ((kt + 1) & 1) * STAGE);
+        __syncthreads();
+    };
+    auto step_tail = [&](int kt, typename OA::Regs& rac, typename OB::Regs& rbc, const typename OA::Regs& ran, const typename OB::Regs& rbn) {
+        if (kt + 2 < tiles) fetch(kt + 2, rac, rbc);
+        compute(sm + (kt & 1) * STAGE);
+        if (kt + 1 < tiles) commit(std::false_type{}, ran, rbn, sm + ((kt + 1) & 1) * STAGE);
+        __syncthreads();
+    };
+    fetch(0, ra0, rb0);
+    if (tiles > 1) fetch(1, ra1, rb1);
+    commit(std::false_type{}, ra0, rb0, sm);
+    __syncthreads();
+    int kt = 0;
+    if (p.kb == 1 || kfull) {
+#pragma unroll 1
+        for (; kt + 3 < tiles; kt += 2) {
+            step_main(std::true_type{}, kt, ra0, rb0, ra1, rb1);
+            step_main(std::true_type{}, kt + 1, ra1, rb1, ra0, rb0);
+        }
+    } else {
+#pragma unroll 1
+        for (; kt + 3 < tiles; kt += 2) {
+            step_main(std::false_type{}, kt, ra0, rb0, ra1, rb1);
+            step_main(std::false_type{}, kt + 1, ra1, rb1, ra0, rb0);
+        }
+    }
+#pragma unroll 1
+    for (; kt < tiles; kt += 2) {
+        step_tail(kt, ra0, rb0, ra1, rb1);
+        if (kt + 1 < tiles) step_tail(kt + 1, ra1, rb1, ra0, rb0);
+    }
+
+    // epilogue: straight-line per accumulator -- the optional operands (gate, old C) are fetched by wave-uniform branches, all 16
+    // of an accumulator in flight together (clamped addresses), the stores are predicated (no load -> wait -> store chains)
+    const long co = zt * p.sCt + zb * p.sCb + zh * p.sCh;
+    float* C = p.C + co;
+    const float* gate = p.gate ? p.gate + co : nullptr;
+    const bool accum = p.flags & MTL_GEMM_ACCUM;
+    const float lo = (p.flags & MTL_GEMM_RELU) ? 0.f : -__builtin_inff();
+    const int rbase = m0 + wm * 64 + 4 * hi;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int colr = n0 + wn * 64 + j * 32 + l31;
+            const bool cok = colr < p.N;
+            const int col = cok ? colr : p.N - 1;
+            const float bb = p.bias ? p.bias[zt * p.sBiasT + zb * p.sBias + zh * p.sBiasH + col] : 0.f;
+            float x[16];
+#pragma unroll
+            for (int v = 0; v < 16; ++v) x[v] = fmaxf(p.alpha * acc[i][j][v] + bb, lo);
+            if (gate) {
+                float gt[16];
+#pragma unroll
+                for (int v = 0; v < 16; ++v) gt[v] = gate[(long)min(rbase + i * 32 + 8 * (v >> 2) + (v & 3), p.M - 1) * p.ldg + col];
+#pragma unroll
+                for (int v = 0; v < 16; ++v) x[v] = gt[v] > 0.f ? x[v] : 0.f;
+            }
+            if (accum) {
+                float cold[16];
+#pragma unroll
+                for (int v = 0; v < 16; ++v) cold[v] = C[(long)min(rbase + i * 32 + 8 * (v >> 2) + (v & 3), p.M - 1) * p.ldc + col];
+#pragma unroll
+                for (int v = 0; v < 16; ++v) x[v] += cold[v];
+            }
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int row = rbase + i * 32 + 8 * (v >> 2) + (v & 3);
+                if (cok && row < p.M) C[(long)row * p.ldc + col] = x[v];
+            }
+        }
+    if (RS) {
+        // thread (mq = tid >> 3, kq = tid & 7) holds the sums over ITS k's of rows 4 mq .. + 3: combine the 8 k lanes in a fixed order
+        float* red = reinterpret_cast<float*>(sm);   // the tile buffers are free: the loop ended with a barrier
+        const int kq = tid & 7, mq = tid >> 3;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red[kq * (BM + 1) + mq * 4 + i] = rs[i];
+        __syncthreads();
+        if (do_rowsum && tid < BM && m0 + tid < p.M) {
+            float s = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s += red[q * (BM + 1) + tid];
+            p.rowsum[zt * p.sRowT + zb * p.sRow + zh * p.sRowH + m0 + tid] += s;
+        }
+    }
+}
+
+template <bool TA, bool TB, bool RS>
+int launch_x3(const X3P& p, hipStream_t s) {
+    static int attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_kernel<TA, TB, RS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          SMEM) == hipSuccess ? 0 : MTL_ELAUNCH;
+    if (attr) return attr;
+    dim3 grid(((p.total + 7) / 8) * 8);
+    hipLaunchKernelGGL((gemm_x3_kernel<TA, TB, RS>), grid, dim3(NT), SMEM, s, p);
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}
+
+inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+
+}  // namespace
+
+static int g_min_tiles = -1;
+static int min_tiles_now() {
+    if (g_min_tiles < 0) g_min_tiles = getenv("MTL_GEMM_X3") ? atoi(getenv("MTL_GEMM_X3")) : 128;
+    return g_min_tiles;
+}
+
+// would a 16-byte aligned, not doubly transposed product go to the bf16-split engine?
+int mtl_gemm_x3_eligible(int M, int N, int batch) {
+    const int mt = min_tiles_now();
+    const long tiles = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN) * batch;
+    return mt > 0 && tiles >= mt && tiles <= (1L << 30);
+}
+
+extern "C" int mtl_gemm_x3_min_tiles(int set) {
+    const int old = min_tiles_now();
+    if (set >= 0) g_min_tiles = set;
+    return old;
+}
+
+// 1: the product was issued on the bf16-split engine; 0: not eligible (the caller falls back); < 0: launch error.
+int mtl_gemm_x3_route(void* stream, int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda, const float* B,
+                      int ldb, float* C, int ldc, const float* bias, const float* gate, int ldg, int flags, int batch, int H, long sAb,
+                      long sAh, long sBb, long sBh, long sCb, long sCh, long sBias, int kbatch, long sAk, long sBk, float* rowsum,
+                      long sRowsum, long sBiasH, long sRowsumH, int tasks, long sAt, long sBt, long sCt, long sBiasT, long sRowsumT) {
+    if ((transA && transB) || !mtl_gemm_x3_eligible(M, N, batch)) return 0;
+    const long tiles = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN) * batch;
+    if (!al16(A) || !al16(B) || (lda & 3) || (ldb & 3) || ((sAb | sAh | sBb | sBh | sAk | sBk | sAt | sBt) & 3)) return 0;
+    X3P p{A, B, C, bias, gate, rowsum, M, N, K, lda, ldb, ldc, ldg, alpha, flags, H, sAb, sAh, sBb, sBh, sCb, sCh, sBias, kbatch,
+          sAk, sBk, sRowsum, sBiasH, sRowsumH, batch / tasks, sAt, sBt, sCt, sBiasT, sRowsumT, (int)tiles};
+    hipStream_t s = as_stream(stream);
+    int rc;
+    if (!transA && transB) rc = launch_x3<false, true, false>(p, s);
+    else if (!transA && !transB) rc = launch_x3<false, false, false>(p, s);
+    else if (rowsum) rc = launch_x3<true, false, true>(p, s);
+    else rc = launch_x3<true, false, false>(p, s);
+    return rc == MTL_OK ? 1 : rc;
+}

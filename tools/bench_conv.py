@@ -21,9 +21,13 @@ def timeit(fn, reps=10):
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / reps
 
+ZERO = os.environ.get('MTL_BENCH_ZERO') == '1'      # all-zero operands: same instruction stream, less switching power (DVFS probe)
+
 def conv_case(name, T_, F_, cin, cout, pooled):
     x = torch.relu(torch.randn(B, T_, F_, cin, device=dev))
     w = torch.randn(cout, cin, 3, 3, device=dev) * 0.05
+    if ZERO:
+        x.zero_(); w.zero_()
     bias = torch.randn(cout, device=dev) * 0.1
     wf, wd = torch.empty(9, cin, cout, device=dev), torch.empty(9, cout, cin, device=dev)
     L.mtl_conv3x3_wprep(st(), w.data_ptr(), wf.data_ptr(), wd.data_ptr(), cout, cin)
@@ -33,10 +37,12 @@ def conv_case(name, T_, F_, cin, cout, pooled):
         y = torch.empty(B, Tp, Fp, cout, device=dev); am = torch.empty(B, Tp, Fp, cout, dtype=torch.uint8, device=dev)
         t = timeit(lambda: L.mtl_conv3x3_relu_pool_fwd(st(), x.data_ptr(), wf.data_ptr(), bias.data_ptr(), y.data_ptr(), am.data_ptr(), B, T_, F_, cin, cout))
         dy = torch.randn_like(y); amp = am.data_ptr()
+        if ZERO: dy.zero_()
     else:
         y = torch.empty(B, T_, F_, cout, device=dev)
         t = timeit(lambda: L.mtl_conv3x3_relu_fwd(st(), x.data_ptr(), wf.data_ptr(), bias.data_ptr(), y.data_ptr(), B, T_, F_, cin, cout))
         dy = torch.randn_like(y); amp = None
+        if ZERO: dy.zero_()
     print('%-8s fwd   %.3f ms %6.1f TF' % (name, t, flops / t / 1e9))
     dx = torch.empty_like(x)
     t = timeit(lambda: L.mtl_conv3x3_dgrad(st(), dy.data_ptr(), amp, wd.data_ptr(), x.data_ptr(), dx.data_ptr(), B, T_, F_, cin, cout))
