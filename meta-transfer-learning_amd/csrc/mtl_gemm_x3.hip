@@ -11,7 +11,8 @@
 // accumulate epilogue.  mtl_gemm_f32_tb routes a product here when its output tiles fill a good part of the chip and its
 // operands are 16-byte aligned; everything else stays on the exact-fp32 engines (mtl_gemm16.hip, mtl_mfma.hip).
 //
-// Workgroup = 8 waves (4 x 2), tile 256 x 128 x 32, a wave owns 64 x 64 (four 32 x 32 accumulators), two waves per SIMD.  LDS
+// Workgroup = 8 waves (4 x 2), tile 256 x 128 x 32, a wave owns 64 x 64 (four 32 x 32 accumulators), two waves per SIMD
+// (128 x 128 tiles with 32 x 64 per wave for products whose 256-row tiles would leave CUs idle).  LDS
 // holds TWO stages of [operand][piece][rows][32 k] bf16 (2 x 72 KB) with the 16-byte chunk swizzle of mtl_h2.h (fragment reads
 // are conflict-free ds_read_b128).  Per K step: the global loads of tile kt + 2 are issued into the register set that tile kt left,
 // the MFMAs of tile kt read stage kt & 1, and -- in the same basic block, so that the VALU work sits between the MFMAs instead of
@@ -31,10 +32,8 @@ namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int BM = 256, BN = 128, BK = 32, NT = 512;
-constexpr int PLANE_A = BM * 64, PLANE_B = BN * 64;      // one bf16 piece of one operand tile: rows x 64 bytes
-constexpr int STAGE = 3 * (PLANE_A + PLANE_B);
-constexpr int SMEM = 2 * STAGE;
+constexpr int BN = 128, BK = 32, NT = 512;               // BM (256 or 128) is a template parameter of the kernel
+constexpr int PLANE_B = BN * 64;                         // one bf16 piece of one operand tile: rows x 64 bytes
 
 struct X3P {
     const float *A, *B;
@@ -166,6 +165,7 @@ struct Opnd {
                     x0 = sel(r.km, 1u, x0);
                     x1 = sel(r.km, 2u, x1);
                 }
+                if (RS) rs[i] += x0 + x1;
                 unsigned h, mm, l;
                 split3(x0, x1, h, mm, l);
                 unsigned char* dst = lds + (mq * 4 + i) * 64 + (((kq >> 1) ^ (mq & 3)) << 4) + (kq & 1) * 8 + kh * 4;
@@ -177,8 +177,10 @@ struct Opnd {
     }
 };
 
-template <bool TA, bool TB, bool RS>      // RS: row sums of op(A) ride along (TA only)
+// BM = 256: a wave owns 64 x 64 (TM = 2 row blocks); BM = 128 (products with too few 256-row tiles to fill the chip): 32 x 64
+template <bool TA, bool TB, bool RS, int BM>      // RS: row sums of op(A) ride along (TA only)
 __global__ __launch_bounds__(NT) void gemm_x3_kernel(X3P p) {
+    constexpr int PLANE_A = BM * 64, STAGE = 3 * (PLANE_A + PLANE_B), WTM = BM / 4, TM = WTM / 32;
     using OA = Opnd<!TA, BM>;          // op(A) is M x K: stored [m][k] unless transposed
     using OB = Opnd<TB, BN>;           // op(B) is K x N: stored [n][k] when transposed
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
@@ -199,9 +201,9 @@ __global__ __launch_bounds__(NT) void gemm_x3_kernel(X3P p) {
     typename OA::Regs ra0, ra1;
     typename OB::Regs rb0, rb1;
     const int nk = (p.K + BK - 1) / BK, tiles = nk * p.kb;
-    f32x16 acc[2][2];
+    f32x16 acc[TM][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -220,27 +222,27 @@ __global__ __launch_bounds__(NT) void gemm_x3_kernel(X3P p) {
         lb.template commit<FULL, false>(rb, stage + 3 * PLANE_A, tid, rs);
     };
     // fragment addresses: row (wm | wn) * 64 + 32 i + l31, chunk (2 st + hi) ^ ((row >> 2) & 3)
-    const int arow = (wm * 64 + l31) * 64, brow = 3 * PLANE_A + (wn * 64 + l31) * 64;
+    const int arow = (wm * WTM + l31) * 64, brow = 3 * PLANE_A + (wn * 64 + l31) * 64;
     int csw[2];
 #pragma unroll
     for (int st = 0; st < 2; ++st) csw[st] = ((st * 2 + hi) ^ ((l31 >> 2) & 3)) << 4;
     auto compute = [&](const unsigned char* stage) {
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
-            uint4 a[2][3], b[2][3];
+            uint4 a[TM][3], b[2][3];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int pc = 0; pc < 3; ++pc) {
 #pragma unroll
-                for (int pc = 0; pc < 3; ++pc) {
-                    a[i][pc] = *reinterpret_cast<const uint4*>(stage + pc * PLANE_A + arow + i * 32 * 64 + csw[st]);
-                    b[i][pc] = *reinterpret_cast<const uint4*>(stage + pc * PLANE_B + brow + i * 32 * 64 + csw[st]);
-                }
-            // six terms, smallest first, each over the four accumulators (dependent MFMAs are four issues apart)
+                for (int i = 0; i < TM; ++i) a[i][pc] = *reinterpret_cast<const uint4*>(stage + pc * PLANE_A + arow + i * 32 * 64 + csw[st]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) b[j][pc] = *reinterpret_cast<const uint4*>(stage + pc * PLANE_B + brow + j * 32 * 64 + csw[st]);
+            }
+            // six terms, smallest first, each over all accumulators (dependent MFMAs are 2 TM issues apart)
             constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
             for (int tm = 0; tm < 6; ++tm)
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i][PA[tm]]),
@@ -296,9 +298,9 @@ __global__ __launch_bounds__(NT) void gemm_x3_kernel(X3P p) {
     const float* gate = p.gate ? p.gate + co : nullptr;
     const bool accum = p.flags & MTL_GEMM_ACCUM;
     const float lo = (p.flags & MTL_GEMM_RELU) ? 0.f : -__builtin_inff();
-    const int rbase = m0 + wm * 64 + 4 * hi;
+    const int rbase = m0 + wm * WTM + 4 * hi;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int colr = n0 + wn * 64 + j * 32 + l31;
@@ -329,30 +331,38 @@ __global__ __launch_bounds__(NT) void gemm_x3_kernel(X3P p) {
             }
         }
     if (RS) {
-        // thread (mq = tid >> 3, kq = tid & 7) holds the sums over ITS k's of rows 4 mq .. + 3: combine the 8 k lanes in a fixed order
+        // a thread holds the sums over ITS k's of rows 4 mq .. + 3 (BM = 256: 8 k lanes per row; 128: 8 x 2): combined in a fixed order
         float* red = reinterpret_cast<float*>(sm);   // the tile buffers are free: the loop ended with a barrier
-        const int kq = tid & 7, mq = tid >> 3;
+        constexpr int NP = BM == 256 ? 8 : 16;
+        const int kq = tid & 7, mq = BM == 256 ? (tid >> 3) : ((tid >> 3) & 31), part = BM == 256 ? kq : (tid >> 8) * 8 + kq;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) red[kq * (BM + 1) + mq * 4 + i] = rs[i];
+        for (int i = 0; i < 4; ++i) red[part * (BM + 1) + mq * 4 + i] = rs[i];
         __syncthreads();
         if (do_rowsum && tid < BM && m0 + tid < p.M) {
             float s = 0.f;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) s += red[q * (BM + 1) + tid];
+            for (int q = 0; q < NP; ++q) s += red[q * (BM + 1) + tid];
             p.rowsum[zt * p.sRowT + zb * p.sRow + zh * p.sRowH + m0 + tid] += s;
         }
     }
 }
 
-template <bool TA, bool TB, bool RS>
-int launch_x3(const X3P& p, hipStream_t s) {
-    static int attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_kernel<TA, TB, RS>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          SMEM) == hipSuccess ? 0 : MTL_ELAUNCH;
+template <bool TA, bool TB, bool RS, int BM>
+int launch_x3(X3P p, hipStream_t s) {
+    constexpr int SMEM = 2 * 3 * (BM + BN) * 64;
+    static int attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_kernel<TA, TB, RS, BM>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) == hipSuccess ? 0 : MTL_ELAUNCH;
     if (attr) return attr;
+    p.total = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.total;       // (p.total arrives as the number of batch items)
     dim3 grid(((p.total + 7) / 8) * 8);
-    hipLaunchKernelGGL((gemm_x3_kernel<TA, TB, RS>), grid, dim3(NT), SMEM, s, p);
+    hipLaunchKernelGGL((gemm_x3_kernel<TA, TB, RS, BM>), grid, dim3(NT), SMEM, s, p);
     MTL_CHECK_LAUNCH();
     return MTL_OK;
+}
+
+template <bool TA, bool TB, bool RS>
+int launch_x3_bm(const X3P& p, hipStream_t s, bool big) {
+    return big ? launch_x3<TA, TB, RS, 256>(p, s) : launch_x3<TA, TB, RS, 128>(p, s);
 }
 
 inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
@@ -365,10 +375,12 @@ static int min_tiles_now() {
     return g_min_tiles;
 }
 
-// would a 16-byte aligned, not doubly transposed product go to the bf16-split engine?
+static long x3_tiles(int M, int N, int batch, int bm) { return (long)((M + bm - 1) / bm) * ((N + BN - 1) / BN) * batch; }
+
+// would a 16-byte aligned, not doubly transposed product go to the bf16-split engine?  (grid counted in 128 x 128 tiles)
 int mtl_gemm_x3_eligible(int M, int N, int batch) {
     const int mt = min_tiles_now();
-    const long tiles = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN) * batch;
+    const long tiles = x3_tiles(M, N, batch, 128);
     return mt > 0 && tiles >= mt && tiles <= (1L << 30);
 }
 
@@ -384,15 +396,17 @@ int mtl_gemm_x3_route(void* stream, int transA, int transB, int M, int N, int K,
                       long sAh, long sBb, long sBh, long sCb, long sCh, long sBias, int kbatch, long sAk, long sBk, float* rowsum,
                       long sRowsum, long sBiasH, long sRowsumH, int tasks, long sAt, long sBt, long sCt, long sBiasT, long sRowsumT) {
     if ((transA && transB) || !mtl_gemm_x3_eligible(M, N, batch)) return 0;
-    const long tiles = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN) * batch;
     if (!al16(A) || !al16(B) || (lda & 3) || (ldb & 3) || ((sAb | sAh | sBb | sBh | sAk | sBk | sAt | sBt) & 3)) return 0;
     X3P p{A, B, C, bias, gate, rowsum, M, N, K, lda, ldb, ldc, ldg, alpha, flags, H, sAb, sAh, sBb, sBh, sCb, sCh, sBias, kbatch,
-          sAk, sBk, sRowsum, sBiasH, sRowsumH, batch / tasks, sAt, sBt, sCt, sBiasT, sRowsumT, (int)tiles};
+          sAk, sBk, sRowsum, sBiasH, sRowsumH, batch / tasks, sAt, sBt, sCt, sBiasT, sRowsumT, batch};
+    // 256-row tiles (less operand traffic and split work per MFMA) once they give every CU a workgroup; 128-row tiles otherwise
+    static const int big_from = getenv("MTL_GEMM_X3_BIG") ? atoi(getenv("MTL_GEMM_X3_BIG")) : 224;
+    const bool big = x3_tiles(M, N, batch, 256) >= big_from;
     hipStream_t s = as_stream(stream);
     int rc;
-    if (!transA && transB) rc = launch_x3<false, true, false>(p, s);
-    else if (!transA && !transB) rc = launch_x3<false, false, false>(p, s);
-    else if (rowsum) rc = launch_x3<true, false, true>(p, s);
-    else rc = launch_x3<true, false, false>(p, s);
+    if (!transA && transB) rc = launch_x3_bm<false, true, false>(p, s, big);
+    else if (!transA && !transB) rc = launch_x3_bm<false, false, false>(p, s, big);
+    else if (rowsum) rc = launch_x3_bm<true, false, true>(p, s, big);
+    else rc = launch_x3_bm<true, false, false>(p, s, big);
     return rc == MTL_OK ? 1 : rc;
 }

@@ -56,19 +56,29 @@ if ONLY:
     _case = case
     def case(name, *a, **k):
         if name == ONLY: _case(name, *a, **k)
-for nt in ((8,) if ONLY else (8, 1)):
-    case('ffn fwd (enc)', 0, 1, 2000, 512, 512, nt, shared_b=True, relu=True, bias=True)
-    case('ffn fwd (dec)', 0, 1, 808, 512, 512, nt, relu=True, bias=True)
-    case('ffn dgrad (enc)', 0, 0, 2000, 512, 512, nt)
-    case('ffn wgrad (enc)', 1, 0, 512, 512, 2000, nt)
-    case('ffn wgrad (dec)', 1, 0, 512, 512, 808, nt)
-    case('lowrank a fwd (enc)', 0, 1, 2000, 100, 512, nt)
-    case('lowrank b fwd (enc)', 0, 1, 2000, 512, 100, nt, bias=True)
-    case('lowrank a dgrad (enc)', 0, 0, 2000, 512, 100, nt)
-    case('lowrank b dgrad (enc)', 0, 0, 2000, 100, 512, nt)
-    case('lowrank a wgrad (enc)', 1, 0, 100, 512, 2000, nt)
-    case('lowrank b wgrad (enc)', 1, 0, 512, 100, 2000, nt)
-    case('vocab fwd', 0, 1, 808, 3768, 512, nt)
-    case('vocab dgrad', 0, 0, 808, 512, 3768, nt)
-    case('vocab wgrad', 1, 0, 3768, 512, 808, nt)
-    case('input linear wgrad', 1, 0, 512, 5120, 2000, nt)
+# the products of one task-batched pass at the north-star shapes (8 tasks; nz = batch items of the launch)
+case('ffn fwd (enc)', 0, 1, 2000, 512, 512, 8, shared_b=True, relu=True, bias=True)
+case('ffn fwd (dec)', 0, 1, 808, 512, 512, 8, relu=True, bias=True)
+case('ffn dgrad (enc)', 0, 0, 2000, 512, 512, 8)
+case('ffn dgrad (dec)', 0, 0, 808, 512, 512, 8)
+case('ffn wgrad (enc, 2 layers)', 1, 0, 512, 512, 2000, 16)
+case('ffn wgrad (dec, 4 layers)', 1, 0, 512, 512, 808, 32)
+case('lowrank a fwd (enc qkv)', 0, 1, 2000, 100, 512, 24)
+case('lowrank b fwd (enc qkv)', 0, 1, 2000, 512, 100, 24, bias=True)
+case('lowrank a fwd (dec)', 0, 1, 808, 100, 512, 8)
+case('lowrank b fwd (dec)', 0, 1, 808, 512, 100, 8, bias=True)
+case('lowrank b fwd (cross kv)', 0, 1, 2000, 512, 100, 64, bias=True)
+case('lowrank a dgrad (dec)', 0, 0, 808, 512, 100, 8)
+case('lowrank b dgrad (dec)', 0, 0, 808, 100, 512, 8)
+case('lowrank a wgrad (enc)', 1, 0, 100, 512, 2000, 48)
+case('lowrank b wgrad (enc)', 1, 0, 512, 100, 2000, 48)
+case('lowrank a wgrad (dec)', 1, 0, 100, 512, 808, 96)
+case('vocab fwd', 0, 1, 808, 3768, 512, 8)
+case('vocab dgrad', 0, 0, 808, 512, 3768, 8)
+case('vocab wgrad', 1, 0, 3768, 512, 808, 8)
+case('input linear wgrad', 1, 0, 512, 5120, 2000, 8)
+if not ONLY:      # one task per GPU (BASELINE.json configs[2]: the rank's own pass)
+    case('ffn fwd (enc), 1 task', 0, 1, 2000, 512, 512, 1, relu=True, bias=True)
+    case('ffn wgrad (enc), 1 task', 1, 0, 512, 512, 2000, 2)
+    case('vocab fwd, 1 task', 0, 1, 808, 3768, 512, 1)
+    case('input linear wgrad, 1 task', 1, 0, 512, 5120, 2000, 1)
