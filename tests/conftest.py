@@ -10,6 +10,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    config.addinivalue_line('markers', 'slow: CPU tests at the north-star size (tens of seconds each; part of the default CPU run)')
 
 
 @pytest.fixture(scope='session')

@@ -167,3 +167,90 @@ def test_greedy_search_matches_reference_golden():
     x, lens, y = R.synth_batch(gspec['seed'], gspec['k'], gspec['T'], gspec['L'], cfg['vocab_size'], True)
     out = R.greedy_search(m, x, lens, R.SOS_ID, gspec['steps'])            # (B, steps)
     assert np.array_equal(out.t().numpy(), ids)
+
+
+@pytest.mark.slow
+def test_meta_step_at_north_star_size_matches_reference_golden():
+    """Closes the parity chain at the north-star size on the CPU (BASELINE.json configs[1]: 3 tasks, k = 8, 1000 frames, 100 labels):
+    the restated oracle against NS.npz, the digests the REAL reference wrote for that meta-step.  Labels and gold ids are bit-exact
+    and the six losses agree to 2e-6.  The gradients cannot agree to the 2e-5 of the small fixtures: a pass has ~250 M ReLU /
+    max-pool branch points here and the restatement's summation orders differ from the reference's module tree in places, so a few
+    dozen near-ties fall the other way (the census below measures that effect between two runs of the oracle ITSELF); measured
+    here: encoder / convolution tensors 3-5e-5, decoder layer 0 and the embedding 1.1-2.6e-4.  Asserted: every tensor inside
+    1e-3, three quarters of them inside 1e-4, theta after Adam inside 1e-6 of the step it takes (~27 s on 8 cores)."""
+    torch.set_num_threads(8)
+    z, cfg, spec = gu.load('NS')
+    m = R.build_model(cfg)
+    names = [n for n, _ in m.named_parameters()]
+    assert _theta_hash(m) == bytes(z['theta0_sha256']).decode()
+    adam = R.AdamState(list(m.parameters()), spec['meta_lr'])
+    tr, val = gu.batches_for(cfg, spec, 0, z['data_call_index'])
+    G, trl, val_l, labels = R.meta_step(m, adam, tr, val, spec['lr'])
+    for j, (gold, hyp) in enumerate(labels):
+        assert np.array_equal(gold.numpy(), z['fwd/0/%d/gold' % j]) and np.array_equal(hyp.numpy(), z['fwd/0/%d/hyp' % j]), j
+    for j, v in enumerate(v for pair in zip(trl, val_l) for v in pair):
+        assert abs(v - float(z['fwd/0/%d/loss' % j])) <= 2e-6 * abs(v)
+    floor = 1e-4 * gu.global_l2(z, 'G/0', names)
+    errs = {}
+    for nm, g in zip(names, G):
+        if float(z['G/0/%s/l2' % nm]) < floor:            # exactly-zero gradients (key-projection biases): rounding noise only
+            continue
+        errs[nm] = gu.check_digest(z, 'G/0', nm, g, rtol=1e-3, what='NS', floor=floor)
+    tight = sum(e <= 1e-4 for e in errs.values())
+    worst = max(errs, key=errs.get)
+    print('oracle vs reference golden at NS: %d / %d tensors <= 1e-4, worst %.2e (%s)' % (tight, len(errs), errs[worst], worst))
+    assert tight >= 0.75 * len(errs)
+
+
+@pytest.mark.slow
+def test_branch_flip_census_between_two_fp32_implementations_of_the_oracle():
+    """The evidence behind the single-flip band of the GPU parity tests (tests/branches.py): the SAME CPU oracle with
+    torch's two exact-fp32 convolution implementations (oneDNN, and the native im2col + GEMM path with oneDNN switched off) --
+    same arithmetic, other summation orders, pre-activations <= 6e-7 apart -- takes a handful of the ~250 M ReLU / max-pool
+    decisions of one north-star pass the other way, every one a rounding near-tie, and that alone moves individual gradient
+    tensors by up to 3e-4 while labels and loss stay put (measured: 13 decisions, worst tensor conv.0.weight 2.9e-4; thread
+    counts 8 vs 3 of ONE implementation give identical forward passes here).  Any two correct fp32 implementations are this far
+    apart, which is why the 1e-4 bar on every tensor is asserted with the branch decisions replayed and the goldens at the
+    north-star size only inside the single-flip band."""
+    import torch.nn.functional as F
+    from tests import branches
+    z, cfg, spec = gu.load('NS')
+    x, lens, y = R.synth_batch(0, spec['k'], spec['T'], spec['L'], cfg['vocab_size'], False)
+    torch.set_num_threads(8)
+    res = {}
+    for onednn in (True, False):
+        m = R.build_model(cfg)
+        with torch.backends.mkldnn.flags(enabled=onednn):
+            (pred, gold, hyp), pre = branches.oracle_trace(m, x, lens, y)
+            loss = R.ce_loss(pred, gold)
+            res[onednn] = (torch.autograd.grad(loss, list(m.parameters())), pre, hyp, float(loss.detach()))
+    (ga, pa, ha, la), (gb, pb, hb, lb) = res[True], res[False]
+    assert torch.equal(ha, hb) and abs(la - lb) <= 1e-6 * abs(la)
+    flips, margin = 0, 0.0
+    for key in pa:
+        u, v = pa[key], pb[key]
+        if key in ('conv2', 'conv7'):                       # max-pool of the ReLU: sign of the pooled value + arg-max position
+            pu, iu = F.max_pool2d(torch.relu(u), 2, stride=2, return_indices=True)
+            pv, iv = F.max_pool2d(torch.relu(v), 2, stride=2, return_indices=True)
+            sign_bad = (pu > 0) != (pv > 0)
+            arg_bad = (iu != iv) & (pu > 0) & (pv > 0)
+            if int(sign_bad.sum()):
+                margin = max(margin, float(torch.maximum(pu, pv)[sign_bad].max()))
+            if int(arg_bad.sum()):                          # how far the other run's winner is below this run's maximum
+                other = torch.relu(u).flatten(2).gather(2, iv.flatten(2)).view_as(pu)
+                margin = max(margin, float((pu - other)[arg_bad].abs().max()))
+            bad = sign_bad | arg_bad
+        else:
+            bad = (u > 0) != (v > 0)
+            if int(bad.sum()):
+                margin = max(margin, float(torch.maximum(u[bad].abs(), v[bad].abs()).max()))
+        flips += int(bad.sum())
+    names = [n for n, _ in m.named_parameters()]
+    gn = float(torch.sqrt(sum((g.double() ** 2).sum() for g in ga)))
+    errs = {n: float((u - v).norm() / max(float(v.norm()), 1e-4 * gn)) for n, u, v in zip(names, gb, ga)}
+    worst = max(errs, key=errs.get)
+    loose = sum(e > 2e-5 for e in errs.values())
+    print('oracle, oneDNN vs native convolutions, one north-star pass: %d differing branch decisions (largest margin %.2e), %d / %d '
+          'gradient tensors differ by more than 2e-5, worst %.2e (%s)' % (flips, margin, loose, len(errs), errs[worst], worst))
+    assert 1 <= flips <= 400 and margin < branches.NEAR_TIE
+    assert 2e-5 < errs[worst] < 1e-2
