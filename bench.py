@@ -589,13 +589,28 @@ def main():
         out['dropout_0.1'] = dict(value=k3 / dtd, unit='meta-steps/s', ms_per_step=dtd / k3 * 1e3, tasks=a.tasks)
         model.encoder.dropout_rate = model.decoder.dropout_rate = 0.0
         model.train()
+        # the same workload with EVERY product on the exact-fp32 matrix instructions (convolutions: v_mfma_f32_32x32x2_f32, no fp16 /
+        # bf16 pieces anywhere): what the split arithmetic of the headline buys
+        lib = mtl_amd._lib.lib()
+        saved = [(e, e.conv_mode, e.conv_x3, e.conv_h2, e.in_linear) for e in model.engines]
+        old_x3 = lib.mtl_gemm_x3_min_tiles(0)
+        for e in model.engines:
+            e.conv_mode, e.conv_x3, e.conv_h2, e.in_linear = 'f32', False, False, 'f32'
+        tr32 = mtl_amd.TransientTrainer()              # (its own command lists: the recorded ones hold the h2 entry points)
+        dtf, _ = timed_steps(tr32, model, vocab, tasks, my_tasks, a.tasks, inner, outer, args, k3, 2, mdist, dev)
+        out['exact_f32'] = dict(value=k3 / dtf, unit='meta-steps/s', ms_per_step=dtf / k3 * 1e3,
+                                note='same steps with every convolution and product on the fp32 MFMA (MTL_CONV=f32, bf16-split GEMM '
+                                     'engine off, input Linear on the fp32 engine)')
+        for e, cm, cx, ch, il in saved:
+            e.conv_mode, e.conv_x3, e.conv_h2, e.in_linear = cm, cx, ch, il
+        lib.mtl_gemm_x3_min_tiles(old_x3)
     if world == 1 and not a.no_cpu_baseline:
         # torch's CPU kernels do not scale to every core of a large host (measured on the 128-core GPU node: 11.1 s per task at
         # 128 threads, 3.9 s at 32, 4.2 s at 8), so the baseline is timed at the physical core count, at 32 and at 8 threads
         # (SURVEY's 8-core figure) and the FASTEST is reported as `value`, with its thread count in `cores`
         phys = physical_cores()
         counts = [a.cpu_threads] if a.cpu_threads else sorted({phys, min(32, phys), min(8, phys)}, reverse=True)
-        runs = {n: cpu_baseline(a.tasks, a.k, a.frames, a.labels, n, timed_tasks=2 if n == min(32, phys) or a.cpu_threads else 1)
+        runs = {n: cpu_baseline(a.tasks, a.k, a.frames, a.labels, n, timed_tasks=2)       # two full tasks per thread count
                 for n in counts}
         best = max(runs, key=lambda n: runs[n]['value'])
         out['cpu_baseline'] = dict(runs[best])

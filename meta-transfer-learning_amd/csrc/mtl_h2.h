@@ -1,8 +1,12 @@
 // Two-piece fp16 ("h2") arithmetic shared by the convolution and GEMM kernels (gfx950).
 // x s = h + l (+ at most 2^-23 |x s|) with two fp16 pieces (2 x 11 significand bits), s a power of two that puts the LARGEST
 // magnitude of the tensor into [2^14, 2^15) -- fp16 has 5 exponent bits, so the caller passes an upper bound of max|x| (device
-// floats: `amax`, MTL_AMAX_SLOTS of them), and everything above 2^-39 of that maximum keeps its full 22 bits (below, the absolute
-// error is 2^-40 of the maximum).  A product is h h' + h l' + l h' (the dropped l l' is < 2^-22 relative): three
+// floats: `amax`, MTL_AMAX_SLOTS of them).  An element keeps the full 22 bits of both pieces while |x| >= 2^-17.5 of that maximum
+// (the low piece, <= 2^-11 |x s|, is a NORMAL fp16 down to 2^-14); below, the low piece is a subnormal fp16 (spacing 2^-24) and
+// the element carries an absolute error of at most 2^-39 of the maximum -- a relative error of 2^(k - 38.5) for an element 2^k
+// below the maximum (tests/test_ops_gpu.py::test_conv3x3_two_piece_fp16_dynamic_range_inside_one_tensor measures a quiet
+// sample beside a loud one).  The tensors of the path are normalised per utterance and stay in the first regime.
+// A product is h h' + h l' + l h' (the dropped l l' is < 2^-22 relative): three
 // v_mfma_f32_32x32x16_f16 instead of six bf16 ones (x3) or eight fp32 ones, fp32 accumulation, un-scaled exactly (powers of two)
 // in the epilogue.  Measured against fp64 the kernels built on this are as accurate as the exact-fp32 MFMA kernels (both are
 // dominated by the fp32 accumulation chain; tests/test_ops_gpu.py).

@@ -206,6 +206,13 @@ class PassEngine:
         self.lib = _lib.lib()
         self.arena = {}     # name -> buffer of the current pass (looked up again by the backward)
         self.pool = {}      # (name, shape, dtype) -> allocation, so alternating batch shapes do not re-allocate
+        # Real manifests bring a new (T, Td) with almost every batch (collate pads to the batch maximum; padding further would change
+        # results: the reference masks with RAW frame counts).  The pool is therefore bounded: entries carry the number
+        # of the last pass that touched them, and trim_pool() -- start of every forward -- drops the least recently used ones
+        # beyond MTL_POOL_GB (default 48 GiB of the 288) that neither this pass nor the previous one uses.  An eviction bumps
+        # scratch_epoch, which makes the trainer re-record its command lists (they hold raw addresses).
+        self.pool_budget = int(float(os.environ.get('MTL_POOL_GB', '48')) * (1 << 30))
+        self._pool_gen, self._pool_bytes, self._gen = {}, 0, 0
         self.saved = None
         self.gemm_ws = torch.empty(8 << 20, dtype=torch.float32, device=device) if device.type == 'cuda' else None  # split-K slabs
         # weight/bias-gradient kernels are off the critical path (nothing downstream in the backward reads them): they run
@@ -288,6 +295,8 @@ class PassEngine:
                 if grp is None:
                     grp = torch.empty(key[1], dtype=dtype, device=self.device)
                     self.pool[key] = grp
+                    self._pool_bytes += grp.numel() * grp.element_size()
+                self._pool_gen[key] = self._gen
                 t = grp[slot]
                 self.arena[name] = t
                 return t
@@ -296,8 +305,39 @@ class PassEngine:
         if t is None:
             t = torch.empty(key[1], dtype=dtype, device=self.device)
             self.pool[key] = t
+            self._pool_bytes += t.numel() * t.element_size()
+        self._pool_gen[key] = self._gen
         self.arena[name] = t
         return t
+
+    def trim_pool(self):
+        """Start of a pass: count it, and while the pool is over its budget drop least-recently-used buffers that the last two
+        passes did not touch (a forward and its backward, and the pass a pipelined host has already enqueued, keep theirs).
+        Frees go back to torch's caching allocator in stream order: the side stream was joined at the end of the backward."""
+        self._gen += 1
+        if self._pool_bytes <= self.pool_budget:
+            return 0
+        freed = 0
+        for key in sorted(self.pool, key=lambda k: self._pool_gen.get(k, 0)):
+            if self._pool_bytes <= self.pool_budget or self._pool_gen.get(key, 0) >= self._gen - 2:
+                break
+            t = self.pool.pop(key)
+            self._pool_gen.pop(key, None)
+            nb = t.numel() * t.element_size()
+            self._pool_bytes -= nb
+            freed += nb
+        if freed:
+            # device tables keyed by buffer addresses (weight-gradient groups, LayerNorm reductions, transposes) and the pinned
+            # staging of shapes that are gone: rebuilt on demand
+            self._wgrad_tables.clear()
+            self._ln_tables.clear()
+            self._tr_tables.clear()
+            if len(self._stage) > 64:
+                self._stage.clear()
+                self._stage_turn.clear()
+            self.arena = {k: v for k, v in self.arena.items() if not isinstance(v, torch.Tensor) or k == '_scratch'}
+            self.scratch_epoch += 1
+        return freed
 
     def scratch(self, nbytes):
         if self.on_side:
@@ -1053,6 +1093,7 @@ class PassEngine:
         (nt * B, Td)."""
         hp, L, lib, st = self.hp, self.L, self.lib, self.stream
         nt = int(meta.get('nt', 1))
+        self.trim_pool()
         assert theta.dtype == torch.float32 and theta.is_contiguous()
         assert theta.numel() == L.total * (nt if sP else 1) and (sP == 0 or sP == L.total)
         x = x.contiguous()

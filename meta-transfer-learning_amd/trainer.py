@@ -11,6 +11,7 @@ but the iteration is restructured for the device:
   * with torch.distributed initialised, tasks are sharded round-robin over ranks and the flat G is summed with ONE
     all-reduce (RCCL over xGMI) before the (replicated, deterministic) Adam step.
 """
+import collections
 import logging
 import os
 import threading
@@ -110,7 +111,8 @@ def clip_flat_grad_(model, grad, max_norm, lane=0):
     check(eng.lib.mtl_scale(st, grad.data_ptr(), 1.0, coef.data_ptr(), grad.numel()), 'mtl_scale')
 
 
-_PINNED = {}
+_PINNED = collections.OrderedDict()
+_PINNED_MAX = 512          # variable-length data brings new read-back shapes all the time: least recently used entries go
 
 
 def _pinned(key, shape, dtype):
@@ -121,6 +123,10 @@ def _pinned(key, shape, dtype):
     if t is None:
         t = torch.empty(tuple(shape), dtype=dtype).pin_memory()
         _PINNED[k] = t
+        while len(_PINNED) > _PINNED_MAX:
+            _PINNED.popitem(last=False)
+    else:
+        _PINNED.move_to_end(k)
     return t
 
 
@@ -586,10 +592,11 @@ class TransientTrainer():
         are re-pointed to this task's batches and the recorded calls are replayed by mtl_cmdlist_run."""
         ent = self._cmdlists.get(key)
         if ent is None:
-            if len(self._cmdlists) >= 64:
-                return body(tx, vx)
+            while len(self._cmdlists) >= 64:              # least recently used key goes (variable-length data: keys rarely repeat)
+                self._cmdlists.pop(next(iter(self._cmdlists)))
             self._cmdlists[key] = 'warm'
             return body(tx, vx)
+        self._cmdlists[key] = self._cmdlists.pop(key)     # most recently used: to the end
         if ent != 'warm' and ent['epoch'] != eng.scratch_epoch:
             ent = 'warm'                                  # the engine's scratch buffer moved since the recording
         if ent == 'warm':

@@ -299,3 +299,40 @@ def test_host_one_iteration_ahead_is_bitwise_equal(capsys):
             out[pipe] = (lines, model.flat_parameters.detach().cpu().clone())
         assert out[False][0] == out[True][0]
         assert torch.equal(out[False][1], out[True][1])
+
+
+def test_variable_length_batches_keep_the_buffer_pool_and_the_command_lists_bounded():
+    """Real manifests bring a new (frames, label width) with almost every batch (collate pads to the batch maximum).  The engines'
+    buffer pool is LRU-trimmed against a byte budget and the trainer's command-list / read-back caches are bounded: twelve
+    meta-iterations over ever-changing shapes stay under the (here tiny) budget plus the working set of two passes, evictions do
+    happen, and an iteration repeated after the evictions reproduces its first result bit for bit (re-recorded command lists, no
+    stale addresses)."""
+    z, cfg, spec = gu.load('F0')
+    mtl_amd, args, vocab, model = make(cfg, spec)
+    model = model.cuda()
+    as5 = lambda b: (b[0].cuda(), b[1], None, b[2], None)
+    inner = mtl_amd.FlatSGD(model, spec['lr'])
+    model.zero_copy_grad()
+    tr = mtl_amd.TransientTrainer()
+
+    def iteration(T, Lw, seed):
+        tasks = [as5(mtl_amd.synth_batch(seed + m, 2, T, Lw, cfg['vocab_size'], variable=True)) for m in range(2)]
+        val = as5(mtl_amd.synth_batch(seed + 9, 2, T, Lw, cfg['vocab_size'], variable=True))
+        tr.meta_iteration(model, vocab, tasks, val, 2, inner, None, args)
+        torch.cuda.synchronize()
+        return model._G.clone()
+
+    first = iteration(64, 8, 500)
+    eng = model.engine
+    one_pass = eng._pool_bytes
+    for e in model.engines:
+        e.pool_budget = one_pass // 2                    # far below one pass: everything older than two passes must go
+    peak, epochs = 0, eng.scratch_epoch
+    for i in range(12):
+        iteration(64 + 4 * (i % 5) + 4, 5 + i % 4, 600 + 10 * i)
+        peak = max(peak, max(e._pool_bytes for e in model.engines))
+    assert eng.scratch_epoch > epochs, 'nothing was evicted'
+    assert peak < 6 * one_pass, (peak, one_pass)         # without trimming: ~13 distinct shapes' worth
+    assert len(tr._cmdlists) <= 64 and len(eng._stage) <= 64 + 4
+    again = iteration(64, 8, 500)
+    assert torch.equal(first, again)
