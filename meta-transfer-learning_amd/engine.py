@@ -244,10 +244,9 @@ class PassEngine:
         self.flush_level = int(os.environ.get('MTL_FLUSH_LEVEL', '0'))      # see flush_side
         self.flush_delay = os.environ.get('MTL_FLUSH_DELAY', '0') == '1'
         self._held = None
-        # 3x3 convolutions (forward and data gradient): '1' = exact 3-way bf16 split on the bf16 MFMA pipe (fp32-accurate, see
-        # DESIGN.md 5.1), '0' = the fp32 MFMA kernels
-        # 3x3 convolutions: 'h2' two fp16 pieces per fp32 operand (3 MFMAs per step, per-tensor power-of-two scaling from device
-        # scalars the producers deliver), 'x3' three exact bf16 pieces (6 MFMAs), 'f32' the fp32-MFMA engine
+        # 3x3 convolutions (forward, data gradient, weight gradient), MTL_CONV: 'h2' (default) two fp16 pieces per fp32 operand
+        # (3 MFMAs per step, per-tensor power-of-two scaling from device scalars the producers deliver; csrc/mtl_h2.h), 'x3' three
+        # exact bf16 pieces (6 MFMAs), 'f32' the fp32-MFMA engine
         self.conv_mode = os.environ.get('MTL_CONV', 'h2' if os.environ.get('MTL_CONV_X3', '1') != '0' else 'f32')
         if self.conv_mode not in ('h2', 'x3', 'f32'):
             raise ValueError('MTL_CONV must be h2, x3 or f32')

@@ -215,6 +215,10 @@ def check_replicas(model, val_batch, it):
     vx = val_batch[0]
     probe = torch.stack([th.double().sum(), th[::997].double().abs().sum(),
                          vx.to(th.device, non_blocking=True).double().sum() + float(val_batch[3].sum())])
+    if not bool(torch.isfinite(probe).all()):
+        # (MIN / MAX never compare equal on NaN: without this check a numerical blow-up would be reported as a seeding problem)
+        raise RuntimeError('iteration %d: non-finite parameters or validation batch on rank %d (checksums %s): the run diverged '
+                           'numerically, this is not a replica mismatch' % (it + 1, mdist.rank(), probe.tolist()))
     lo, hi = probe.clone(), probe.clone()
     td.all_reduce(lo, op=td.ReduceOp.MIN)
     td.all_reduce(hi, op=td.ReduceOp.MAX)
@@ -289,8 +293,8 @@ MAX_CONSECUTIVE_FAILURES = 20
 class TransientTrainer():
     def __init__(self):
         logging.info('Transient Trainer is initialized')
-        # hipGraph replay of the task body is validated but opt-in: at 2 task lanes the loop is GPU-throughput-bound and replay
-        # measured equal (8 tasks) or slower (3 tasks, dropout) than eager launches on ROCm 7.2
+        # hipGraph replay of a task body (per-task lanes only) is validated but opt-in: the loop is GPU-throughput-bound and replay
+        # measured equal (8 tasks) or slower (3 tasks, dropout) than the command lists below on ROCm 7.2
         self.use_graphs = os.environ.get('MTL_GRAPHS', '0') == '1'
         # command lists (default on): the library calls of a task body are recorded once per (lane, shapes, scalars) and then
         # replayed from C with one ctypes call per task (include/mtl_hip.h "command lists"): host cost per pass 4.4 -> ~1 ms

@@ -154,3 +154,67 @@ def grad_tolerance(n_flips, worst_margin, clean=1e-4, flipped=1e-2):
         return clean
     assert worst_margin < NEAR_TIE, 'branch disagreement with margin %.3e is not a rounding near-tie' % worst_margin
     return flipped
+
+
+class record_preactivations:
+    """with record_preactivations(oracle) as log: ... -> log = [the pre-activation dict of oracle_trace for EVERY forward inside the
+    block] (also with gates= replayed: the hooks sit on the convolution / linear modules, in front of the replayed decisions)."""
+
+    def __init__(self, oracle):
+        self.oracle, self.log, self.hooks = oracle, [], []
+
+    def __enter__(self):
+        o = self.oracle
+        self.hooks.append(o.register_forward_pre_hook(lambda m, i: self.log.append({})))
+        for idx in (0, 2, 5, 7):
+            self.hooks.append(o.conv[idx].register_forward_hook(lambda m, i, out, k=idx: self.log[-1].__setitem__('conv%d' % k, out.detach())))
+        ffns = [('e%d' % i, l.pos_ffn) for i, l in enumerate(o.encoder.layers)] + [('d%d' % i, l.pos_ffn) for i, l in enumerate(o.decoder.layers)]
+        for tag, f in ffns:
+            self.hooks.append(f.linear_1.register_forward_hook(lambda m, i, out, k=tag: self.log[-1].__setitem__(k + '.ff', out.detach())))
+        return self.log
+
+    def __exit__(self, *exc):
+        for h in self.hooks:
+            h.remove()
+        return False
+
+
+def replay_census(pre, gates):
+    """(number of branch points where the decisions `gates` (the device's) differ from what the oracle's OWN pre-activations `pre`
+    of the same forward would decide, largest margin among them).  With the device's decisions replayed the oracle walks the
+    device's path, so every difference must be a rounding near-tie; a systematic gate / arg-max bug of the device path shows up
+    here as many differences with large margins (the replayed oracle alone would mirror it)."""
+    n, worst = 0, 0.0
+    for key, gk in (('conv0', 'conv0'), ('conv5', 'conv5')):
+        bad = (pre[key] > 0) != gates[gk]
+        if int(bad.sum()):
+            n += int(bad.sum())
+            worst = max(worst, float(pre[key][bad].abs().max()))
+    for key, nm in (('conv2', '1'), ('conv7', '2')):
+        zpre = pre[key]
+        post = torch.relu(zpre)
+        p_ref, idx = F.max_pool2d(post, 2, stride=2, return_indices=True)
+        T = zpre.shape[3]
+        am = gates['am' + nm].long()
+        Fp, Tp = p_ref.shape[2], p_ref.shape[3]
+        f = torch.arange(Fp).view(1, 1, Fp, 1) * 2 + (am >> 1)
+        t = torch.arange(Tp).view(1, 1, 1, Tp) * 2 + (am & 1)
+        dev_idx = f * T + t
+        dev_pos = gates['pool' + nm]
+        sign_bad = dev_pos != (p_ref > 0)
+        arg_bad = (dev_idx != idx) & dev_pos & (p_ref > 0)
+        if int(sign_bad.sum()):
+            n += int(sign_bad.sum())
+            worst = max(worst, float(p_ref[sign_bad].abs().max()))
+        if int(arg_bad.sum()):
+            n += int(arg_bad.sum())
+            dev_val = post.flatten(2).gather(2, dev_idx.flatten(2)).view_as(p_ref)
+            worst = max(worst, float((p_ref - dev_val)[arg_bad].abs().max()))
+    for key, ref in pre.items():
+        if key.endswith('.ff'):
+            z2 = ref.reshape(-1, ref.shape[-1])
+            bad = (z2 > 0) != gates[key + '.h1']
+            if int(bad.sum()):
+                n += int(bad.sum())
+                worst = max(worst, float(z2[bad].abs().max()))
+    return n, worst

@@ -211,11 +211,18 @@ def test_meta_gradient_at_north_star_size_with_branch_replay():
         reads = trainer.meta_iteration(model, vocab, [as5(b) for b in tr], as5(val), n, inner, None, args)
         torch.cuda.synchronize()
     assert len(log) == 2 * n
-    G_r, trl, val_l, labels = R.meta_gradient(oracle, tr, val, spec['lr'], gates=log)
+    with branches.record_preactivations(oracle) as pre_log:
+        G_r, trl, val_l, labels = R.meta_gradient(oracle, tr, val, spec['lr'], gates=log)
     for m, (rd_tr, rd_va) in enumerate(reads):
         for rd, (gold, hyp), loss in ((rd_tr, labels[2 * m], trl[m]), (rd_va, labels[2 * m + 1], val_l[m])):
             assert torch.equal(rd.hyp, hyp) and torch.equal(rd.gold_host, gold)
             assert abs(float(rd.loss[0]) - loss) < RTOL * loss
+    # the replayed decisions are not taken on trust: in every one of the six passes (training at theta0 and validation at theta')
+    # the device's decisions differ from what the oracle's own pre-activations say only at a few rounding near-ties
+    assert len(pre_log) == 2 * n
+    census = [branches.replay_census(pre, gates) for pre, gates in zip(pre_log, log)]
+    print('NS branch census per pass (differing decisions, largest margin): ' + ', '.join('%d / %.1e' % c for c in census))
+    assert all(c[0] <= 120 and c[1] < branches.NEAR_TIE for c in census), census
     errs = _rel_errs(model, model._G, oracle, G_r)
     worst = max(errs, key=errs.get)
     print('NS 3-task meta-gradient: %d/%d tensors within 1e-4, worst %.2e (%s)'
