@@ -88,6 +88,10 @@ SIGNATURES = {
     'mtl_spect_logmag': (I, [P, P, I, I, I, P, P, I]),
     'mtl_lstm_cell_fwd': (I, [P, P, P, P, P, P, P, P, P, F, I, I]),
     'mtl_lstm_cell_bwd': (I, [P, P, P, F, P, P, P, P, P, P, P, I, I]),
+    'mtl_lstm_layer_supported': (I, [I, I]),
+    'mtl_lstm_layer_workspace': (L, []),
+    'mtl_lstm_layer_fwd': (I, [P, P, P, P, P, P, P, P, P, F, I, I, I, P]),
+    'mtl_lstm_layer_bwd': (I, [P, P, P, F, P, P, P, P, I, I, I, P]),
     'mtl_memset_zero': (I, [P, P, L]),
     'mtl_memcpy_d2d': (I, [P, P, P, L]),
     'mtl_event_record': (I, [P, P]),

@@ -107,6 +107,11 @@ class LMEngine:
         self.m, self.device, self.lib, self.L = model, device, _lib.lib(), model._layout
         self.pool, self.saved = {}, None
         self.ws = torch.empty(4 << 20, dtype=torch.float32, device=device)
+        # all T steps of a layer in ONE launch per direction (csrc/mtl_lstm.hip) where the shape is supported; '0' keeps the per-step
+        # recurrent product + cell kernel (A/B measurements, unsupported shapes take it anyway)
+        import os
+        self.persistent = os.environ.get('MTL_LSTM_PERSISTENT', '1') != '0'
+        self.sync_ws = torch.zeros(int(self.lib.mtl_lstm_layer_workspace()) // 4, dtype=torch.int32, device=device)
 
     def buf(self, name, shape, dtype=torch.float32):
         key = (name, tuple(int(v) for v in shape), dtype)
@@ -186,7 +191,12 @@ class LMEngine:
             msk = mask('m_l%d' % l, R * H, 2 + l)
             gh = self.buf('gh', (B, 4 * H))
             whh, bhh = o('rnn.weight_hh_l%d' % l), o('rnn.bias_hh_l%d' % l)
-            for t in range(T):
+            fused = self.persistent and bool(lib.mtl_lstm_layer_supported(B, H))
+            if fused:
+                check(lib.mtl_lstm_layer_fwd(st, gx.data_ptr(), whh, bhh, hall.data_ptr(), call.data_ptr(), acts.data_ptr(), xout.data_ptr(),
+                                             msk.data_ptr() if msk is not None else None, sc, T, B, H, self.sync_ws.data_ptr()),
+                      'lstm_layer_fwd')
+            for t in range(0 if fused else T):
                 self.gemm(0, 1, B, 4 * H, H, hall[t].data_ptr(), H, whh, H, gh.data_ptr(), 4 * H, bias=bhh)
                 check(lib.mtl_lstm_cell_fwd(st, gx.data_ptr() + 16 * t * B * H, gh.data_ptr(), call[t].data_ptr(),
                                             acts.data_ptr() + 16 * t * B * H, call[t + 1].data_ptr(), hall[t + 1].data_ptr(),
@@ -236,7 +246,11 @@ class LMEngine:
             dh_rec, dc = self.buf('dh_rec', (B, H)), [self.buf('dc_a', (B, H)), self.buf('dc_b', (B, H))]
             whh = o('rnn.weight_hh_l%d' % l)
             msk = Ly['mask']
-            for t in reversed(range(T)):
+            fused = self.persistent and bool(lib.mtl_lstm_layer_supported(B, H))
+            if fused:
+                check(lib.mtl_lstm_layer_bwd(st, dx.data_ptr(), msk.data_ptr() if msk is not None else None, sc, whh, Ly['acts'].data_ptr(),
+                                             Ly['call'].data_ptr(), dG.data_ptr(), T, B, H, self.sync_ws.data_ptr()), 'lstm_layer_bwd')
+            for t in reversed(range(0 if fused else T)):
                 first = t == T - 1
                 check(lib.mtl_lstm_cell_bwd(st, dx.data_ptr() + 4 * t * B * H, msk.data_ptr() + t * B * H if msk is not None else None, sc,
                                             None if first else dh_rec.data_ptr(), None if first else dc[(t + 1) & 1].data_ptr(),

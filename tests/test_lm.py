@@ -195,3 +195,57 @@ def test_lm_meta_step_matches_oracle_restatement():
             q = model._layout.view(model.flat_parameters, n).cpu()
             assert float((q - p).abs().max()) < 2e-5 * max(float(p.abs().max()), 1e-3), (it, n)
         assert float((tr.hidden[0].cpu() - hid[0]).abs().max()) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('H,B,T,dropout', [(128, 5, 9, 0.0), (256, 7, 6, 0.3), (512, 20, 35, 0.2), (384, 32, 4, 0.0)])
+def test_lm_persistent_lstm_layer_kernels(H, B, T, dropout):
+    """csrc/mtl_lstm.hip (all T steps of a layer in one launch per direction, grid-wide hand-off per step) against the oracle and
+    against the per-step path (recurrent product + cell kernel per step) on the same batch, parameters, carried state and dropout
+    masks: logits, loss, new hidden state, every gradient tensor; run twice to show the launch is reproducible bit for bit
+    (fixed-order reductions, re-zeroed arrival counter) and that no wait timed out."""
+    import mtl_amd
+    V, E = 300, 48
+    torch.manual_seed(3)
+    model = mtl_amd.lm.RNNModel('LSTM', V, E, H, 2, dropout).cuda()
+    model.train()
+    torch.manual_seed(5)
+    oracle = LR.RNNModel(V, E, H, 2, dropout)
+    _to_oracle(oracle, model, model.flat_parameters)
+    g = torch.Generator().manual_seed(21 + H)
+    x = torch.randint(0, V, (T, B), generator=g)
+    y = torch.randint(0, V, (T * B,), generator=g)
+    h0, c0 = 0.2 * torch.randn(2, B, H, generator=g), 0.2 * torch.randn(2, B, H, generator=g)
+    eng = model.engine
+    assert eng.persistent and bool(eng.lib.mtl_lstm_layer_supported(B, H))
+    runs = {}
+    for mode in ('persistent', 'persistent', 'steps'):
+        eng.persistent = mode == 'persistent'
+        torch.manual_seed(77)                                               # same Philox seed draw -> same keep-masks
+        out = eng.forward(model.flat_parameters, x.cuda(), y.cuda(), (h0.cuda(), c0.cuda()), dropout)
+        grad = torch.zeros_like(model.flat_grad)
+        eng.backward(grad, 1.0)
+        torch.cuda.synchronize()
+        res = (out['logits'].clone(), float(out['loss']), out['hidden'][0].clone(), out['hidden'][1].clone(), grad)
+        if mode == 'persistent' and mode in runs:
+            for a, b in zip(res, runs[mode]):
+                assert (a == b) if isinstance(a, float) else torch.equal(a, b)
+        runs[mode] = res
+        assert int(eng.sync_ws[1]) == 0, 'a grid-wide wait timed out'
+    eng.persistent = True
+    masks = None
+    if dropout > 0:
+        sc = 1.0 / (1 - dropout)
+        pool = {k[0]: v for k, v in eng.pool.items()}
+        masks = {'emb': pool['m_emb'].cpu().float().view(T, B, E) * sc, 'l0': pool['m_l0'].cpu().float().view(T, B, H) * sc,
+                 'out': pool['m_l1'].cpu().float().view(T, B, H) * sc}
+    o_out, (hn, cn) = oracle(x, (h0, c0), masks)
+    loss = torch.nn.functional.cross_entropy(o_out.view(-1, V), y)
+    grads = torch.autograd.grad(loss, list(oracle.parameters()))
+    lp, ls = runs['persistent'], runs['steps']
+    assert float((lp[0].cpu() - o_out.view(-1, V)).norm() / o_out.norm()) < 1e-5
+    assert abs(lp[1] - float(loss)) < 1e-6 * float(loss) and abs(lp[1] - ls[1]) < 1e-6 * ls[1]
+    assert float((lp[2].cpu() - hn).abs().max()) < 2e-6 and float((lp[3].cpu() - cn).abs().max()) < 2e-6
+    errs = _errs(model, lp[4], oracle, grads)
+    assert max(errs.values()) < 1e-4, max(errs.items(), key=lambda kv: kv[1])
+    assert float((lp[4] - ls[4]).norm() / ls[4].norm()) < 2e-6              # the two device paths: same arithmetic, other summation orders
