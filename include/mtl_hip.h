@@ -358,14 +358,17 @@ int mtl_lstm_cell_bwd(void* stream, const float* dh_up, const unsigned char* mas
                       const float* dc_next, const float* acts, const float* c, const float* c_prev, float* dgates, float* dc_prev,
                       int B, int H);
 /* Persistent LSTM layer (csrc/mtl_lstm.hip; lm/model/rnn_model.py:20 nn.LSTM over a bptt window): ALL T time steps of one layer in one
- * launch per direction.  Workgroup w owns hidden units [8 w, 8 w + 8) for the whole sequence (its rows / columns of W_hh stay in
- * registers), one grid-wide release / acquire hand-off per step (bounded spins; the grid is H / 8 <= 64 workgroups).
+ * launch per direction.  Workgroup w owns hidden units [8 w, 8 w + 8) for the whole sequence (its 32 gate rows of W_hh stay in
+ * registers), one grid-wide hand-off per step (write-through payload + arrival counter, bounded spins; the grid is H / 8 <= 64
+ * workgroups).  The backward splits dh_rec = dG_{t+1} W_hh by rows: every workgroup publishes the partial of its own 32 columns of dG
+ * and sums the partials of its 8 units in a fixed order (two partial buffers in the workspace).
  *   forward : gx (T B, 4H) = x W_ih^T + b_ih of all steps (one product), hall / call (T + 1, B, H) with slot 0 = the incoming state;
  *             writes hall[1..T], call[1..T], acts (T B, 4H) [i|f|g|o after the nonlinearities], xout (T B, H) = h (dropout applied when
  *             mask != NULL: u8 keep flags, scale mscale) -- exactly what T calls of the recurrent product + mtl_lstm_cell_fwd produce.
  *   backward: dx_up (T B, H) gradient of xout (may be NULL), writes dG (T B, 4H) = gradient of the gate pre-activations of every step
  *             (truncated BPTT: no gradient into the incoming state) -- what T calls of mtl_lstm_cell_bwd + the dh_rec product produce.
- * workspace: mtl_lstm_layer_workspace() bytes of device memory (arrival counter + error word: [1] != 0 after a timed-out wait).
+ * workspace: mtl_lstm_layer_workspace() bytes of device memory, 256-byte aligned (arrival counter + error word -- u32 [1] != 0 after a
+ * timed-out wait -- followed by the backward's partial buffers).
  * mtl_lstm_layer_supported: 1 <= B <= 32 and H in {128, 256, 384, 512}; other shapes take the per-step calls. */
 int mtl_lstm_layer_supported(int B, int H);
 long mtl_lstm_layer_workspace(void);

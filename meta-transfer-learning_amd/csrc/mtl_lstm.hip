@@ -9,14 +9,12 @@
 //     B batch rows (operand reads are LDS broadcasts), the 8 chunk partials of an output are summed in a fixed order, the
 //     threads (b, unit) apply the cell (same formulas as lstm_cell_fwd_kernel, mtl_elem.hip) and store h_t, c_t, the gate
 //     activations and the (dropped) copy for the next layer;
-//   * a grid-wide hand-off per step: plain stores -> workgroup barrier -> one lane: agent-scope release + arrival on a monotonic
-//     counter; consumers: one lane polls (relaxed, agent scope), agent-scope acquire, workgroup barrier, plain loads.  Every spin
+//   * a grid-wide hand-off per step: write-through (sc1) stores of the shared payload -> vmcnt(0) -> workgroup barrier -> one lane
+//     arrives on a monotonic counter; consumers: one lane polls (relaxed, agent scope), workgroup barrier, sc1 loads.  Every spin
 //     is bounded (an error word is set instead of hanging the device); the grid is H / 8 <= 64 workgroups, far below the 256 CUs,
 //     so all of them are resident.
-// The backward runs the same ownership in reverse time: workgroup w produces dh_rec[:, its units] = dG_{t+1} . W_hh[:, its units]
-// (the column slice of W_hh in registers; dG_{t+1}, B x 4H, staged through LDS a quarter at a time), applies the cell backward
-// for its units (dc carried in registers) and stores its 4 x 8 columns of dG_t.  The weight gradients remain three products over
-// all T steps (lm.py).  Reductions are fixed-order: bitwise reproducible.
+// The backward runs the same ownership in reverse time (see lstm_layer_bwd_kernel).  The weight gradients remain three products
+// over all T steps (lm.py).  Reductions are fixed-order: bitwise reproducible.
 #include "mtl_common.h"
 #include "../../include/mtl_hip.h"
 
@@ -37,29 +35,34 @@ struct LstmP {
     float* dG;
 };
 
+// Hand-off without cache maintenance (guide, Guideline 16 form R1): the payload that crosses workgroups (h_t, dG_t) is stored
+// write-through (relaxed agent-scope atomic stores = `global_store ... sc1`) and read with `sc1` loads (relaxed agent-scope atomic
+// loads: served below the reader's L1), so neither an L2 write-back (release fence, 2-6 us with fresh dirty lines) nor an L1
+// invalidate (acquire fence, 1.7 us) is paid per step; the flag follows the payload behind `s_waitcnt vmcnt(0)`.
 __device__ __forceinline__ void grid_wait(unsigned* sync, unsigned target) {
     if (threadIdx.x == 0) {
         unsigned spins = 0;
         while (__hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_s_sleep(1);
             if (++spins > SPIN_LIMIT) {
                 __hip_atomic_store(&sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
 }
 
 __device__ __forceinline__ void grid_arrive(unsigned* sync) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's stores have left
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's write-through stores are acknowledged
     __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (restated where the compiler cannot drop it: guide, G16 pitfall)
-        __hip_atomic_fetch_add(&sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(&sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ void store_shared(float* q, float v) { __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float2 load_shared2(const float* q) {      // 8 bytes, sc1
+    const unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_float2(__builtin_bit_cast(float, (unsigned)u), __builtin_bit_cast(float, (unsigned)(u >> 32)));
 }
 
 template <int KC>      // H = 8 KC
@@ -92,8 +95,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 #pragma unroll 1
     for (int t = 0; t < T; ++t) {
         if (t > 0) grid_wait(p.sync, (unsigned)t * nwg);        // every workgroup has published h_t
-        const float4* src = reinterpret_cast<const float4*>(p.hall + (long)t * B * H);
-        for (int i = tid; i < B * H / 4; i += 256) reinterpret_cast<float4*>(hs)[i] = src[i];
+        const float* src = p.hall + (long)t * B * H;
+        for (int i = tid; i < B * H / 2; i += 256) reinterpret_cast<float2*>(hs)[i] = load_shared2(src + 2 * i);
         __syncthreads();
 #pragma unroll 1
         for (int b = 0; b < B; ++b) {
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
             ac[0] = ai, ac[H] = af, ac[2 * H] = ag, ac[3 * H] = ao;
             const long e = row * H + cj;
             p.call[e + (long)B * H] = cn;              // call[t + 1]
-            p.hall[e + (long)B * H] = hn;              // hall[t + 1]
+            store_shared(p.hall + e + (long)B * H, hn);        // hall[t + 1]: read by every workgroup in the next step
             if (p.xout) p.xout[e] = p.mask ? (p.mask[e] ? hn * p.mscale : 0.f) : hn;
             c_prev = cn;
         }
@@ -136,21 +139,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     }
 }
 
-template <int KC>      // H = 8 KC; a thread holds W_hh[rows of its chunk][unit u] of all four quarters
+// Backward, same ownership as the forward (workgroup w: the 32 gate rows of its 8 units, in registers): the recurrent gradient
+// dh_rec_t = dG_{t+1} . W_hh is split by ROWS -- workgroup w multiplies the 32 columns of dG_{t+1} it has just produced itself
+// (in LDS) with its 32 rows of W_hh, for all H outputs (thread: 1-2 output units, 32 x 1-2 weights in registers, the dG operand is
+// an LDS broadcast) and publishes that partial (B x H, write-through); after the hand-off every workgroup sums the partials of
+// its own 8 units over the workgroups in a fixed order.  Per step a workgroup writes B H floats and reads B x 8 x (H / 8) of them
+// (the column-split alternative re-reads all of dG_{t+1}, B x 4H, in every workgroup: measured 24 us per step).  Two partial
+// buffers alternate with the step parity (a workgroup is at most one hand-off ahead of the slowest).
+template <int KC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void lstm_layer_bwd_kernel(LstmP p) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int B = p.B, H = 8 * KC, T = p.T;
-    constexpr int QC = KC / 4;          // rows per thread and quarter
-    float* gs = sm;                     // [B][H]: one quarter of dG_{t+1}
-    float* red = sm + B * H;            // [32 chunks][B][8 units]
-    const int tid = threadIdx.x, u = tid & 7, rc = tid >> 3;
+    constexpr int JT = KC > 32 ? 2 : 1;           // output units per thread in the partial product
+    float* dgs = sm;                              // [B][32]: this workgroup's columns of dG_t (local row = gate * 8 + unit)
+    const int tid = threadIdx.x;
     const int j0 = blockIdx.x * LU;
     const unsigned nwg = gridDim.x;
-    float w[KC];
+    const int jt = tid * JT;                      // first output unit of this thread
+    const bool active = jt < H;
+    float w[32][JT];
+    if (active) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+        for (int r = 0; r < 32; ++r) {
+            const float* q = p.whh + (long)((r >> 3) * H + j0 + (r & 7)) * H + jt;
 #pragma unroll
-        for (int i = 0; i < QC; ++i) w[q * QC + i] = p.whh[(long)(q * H + rc * QC + i) * H + j0 + u];
+            for (int c = 0; c < JT; ++c) w[r][c] = q[c];
+        }
+    }
+    float* P = reinterpret_cast<float*>(p.sync) + 64;         // two buffers of [nwg][B][H] behind the 256-byte header
+    const long pbuf = (long)nwg * B * H;
     const bool cell = tid < B * LU;
     const int cb = tid / LU, cu = tid % LU, cj = j0 + cu;
     float dc_next = 0.f;
@@ -158,45 +175,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     for (int t = T - 1; t >= 0; --t) {
         float dh_rec = 0.f;
         if (t < T - 1) {
-            grid_wait(p.sync, (unsigned)(T - 1 - t) * nwg);     // every workgroup has stored its columns of dG_{t+1}
-            float part[32];
-#pragma unroll
-            for (int b = 0; b < 32; ++b) part[b] = 0.f;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {                        // (unrolled: w[] must be indexed by constants to stay in registers)
-                __syncthreads();                                 // (the previous quarter / the previous step's reduction is consumed)
-                for (int i = tid; i < B * H / 4; i += 256) {
-                    const int b = i / (H / 4), c4 = i - b * (H / 4);
-                    reinterpret_cast<float4*>(gs)[i] =
-                        *reinterpret_cast<const float4*>(p.dG + ((long)(t + 1) * B + b) * 4 * H + q * H + c4 * 4);
-                }
-                __syncthreads();
-#pragma unroll
-                for (int b = 0; b < 32; ++b) {
-                    if (b < B) {
-                        const float* gb = gs + b * H + rc * QC;
-                        float a = part[b];
-#pragma unroll
-                        for (int i = 0; i < QC; i += 4) {
-                            const float4 gv = *reinterpret_cast<const float4*>(gb + i);
-                            a = fmaf(w[q * QC + i], gv.x, a);
-                            a = fmaf(w[q * QC + i + 1], gv.y, a);
-                            a = fmaf(w[q * QC + i + 2], gv.z, a);
-                            a = fmaf(w[q * QC + i + 3], gv.w, a);
-                        }
-                        part[b] = a;
-                    }
-                }
-            }
-#pragma unroll
-            for (int b = 0; b < 32; ++b)
-                if (b < B) red[(rc * B + b) * 8 + u] = part[b];
-            __syncthreads();
+            grid_wait(p.sync, (unsigned)(T - 1 - t) * nwg);     // every workgroup has published its partial of step t + 1
             if (cell) {
-                float s = 0.f;
-#pragma unroll
-                for (int q = 0; q < 32; ++q) s += red[(q * B + cb) * 8 + cu];
-                dh_rec = s;
+                const float* q = P + ((t + 1) & 1) * pbuf + (long)cb * H + cj;
+                float s0 = 0.f, s1 = 0.f;
+#pragma unroll 4
+                for (unsigned wq = 0; wq < nwg; wq += 2) {      // fixed order (nwg = H / 8 is even)
+                    s0 += __hip_atomic_load(q + (long)wq * B * H, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    s1 += __hip_atomic_load(q + (long)(wq + 1) * B * H, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                dh_rec = s0 + s1;
             }
         }
         if (cell) {
@@ -209,14 +197,46 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
             const float cc = p.call[e + (long)B * H], cprev = p.call[e];
             const float tc = tanhf(cc);
             const float dc = dc_next + dh * ao * (1.f - tc * tc);
+            const float di = dc * ag * ai * (1.f - ai), df = dc * cprev * af * (1.f - af), dg_ = dc * ai * (1.f - ag * ag),
+                        do_ = dh * tc * ao * (1.f - ao);
             float* dg = p.dG + row * 4 * H + cj;
-            dg[0] = dc * ag * ai * (1.f - ai);
-            dg[H] = dc * cprev * af * (1.f - af);
-            dg[2 * H] = dc * ai * (1.f - ag * ag);
-            dg[3 * H] = dh * tc * ao * (1.f - ao);
+            dg[0] = di, dg[H] = df, dg[2 * H] = dg_, dg[3 * H] = do_;
+            float* l = dgs + cb * 32 + cu;
+            l[0] = di, l[8] = df, l[16] = dg_, l[24] = do_;
             dc_next = dc * af;
         }
-        if (t > 0) grid_arrive(p.sync);
+        if (t > 0) {
+            __syncthreads();
+            if (active) {
+                float* out = P + (t & 1) * pbuf + (long)blockIdx.x * B * H + jt;
+#pragma unroll 1
+                for (int b = 0; b < B; ++b) {
+                    const float* gb = dgs + b * 32;
+                    float a[JT];
+#pragma unroll
+                    for (int c = 0; c < JT; ++c) a[c] = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 32; r += 4) {
+                        const float4 gv = *reinterpret_cast<const float4*>(gb + r);
+#pragma unroll
+                        for (int c = 0; c < JT; ++c) {
+                            a[c] = fmaf(gv.x, w[r][c], a[c]);
+                            a[c] = fmaf(gv.y, w[r + 1][c], a[c]);
+                            a[c] = fmaf(gv.z, w[r + 2][c], a[c]);
+                            a[c] = fmaf(gv.w, w[r + 3][c], a[c]);
+                        }
+                    }
+                    if (JT == 2) {
+                        const unsigned long long u = (unsigned long long)__builtin_bit_cast(unsigned, a[0]) |
+                                                     ((unsigned long long)__builtin_bit_cast(unsigned, a[JT - 1]) << 32);
+                        __hip_atomic_store(reinterpret_cast<unsigned long long*>(out + (long)b * H), u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else {
+                        store_shared(out + (long)b * H, a[0]);
+                    }
+                }
+            }
+            grid_arrive(p.sync);
+        }
     }
 }
 
@@ -232,10 +252,7 @@ int launch_fwd(const LstmP& p, hipStream_t s) {
 }
 template <int KC>
 int launch_bwd(const LstmP& p, hipStream_t s) {
-    const int smem = (p.B * 8 * KC + 32 * p.B * 8) * 4;
-    static int attr = hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_layer_bwd_kernel<KC>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (32 * 8 * KC + 32 * 32 * 8) * 4) == hipSuccess ? 0 : MTL_ELAUNCH;
-    if (attr) return attr;
+    const int smem = p.B * 32 * 4;
     hipLaunchKernelGGL(lstm_layer_bwd_kernel<KC>, dim3(p.H / LU), dim3(256), smem, s, p);
     MTL_CHECK_LAUNCH();
     return MTL_OK;
@@ -247,7 +264,7 @@ extern "C" {
 
 int mtl_lstm_layer_supported(int B, int H) { return B >= 1 && B <= 32 && (H == 128 || H == 256 || H == 384 || H == 512); }
 
-long mtl_lstm_layer_workspace(void) { return 256; }
+long mtl_lstm_layer_workspace(void) { return 256 + 2L * 64 * 32 * 512 * 4; }      // header + two partial buffers (backward)
 
 int mtl_lstm_layer_fwd(void* stream, const float* gx, const float* w_hh, const float* b_hh, float* hall, float* call, float* acts,
                        float* xout, const unsigned char* mask, float mscale, int T, int B, int H, void* workspace) {
