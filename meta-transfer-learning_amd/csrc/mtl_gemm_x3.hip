@@ -71,6 +71,14 @@ __device__ __forceinline__ void split3(float x0, float x1, unsigned& h, unsigned
     l = pack_hi(q0, q1);
 }
 
+// Workgroup barrier for the K loop: LDS traffic only.  __syncthreads() also waits for vmcnt(0), i.e. for the global loads of the tile
+// two steps ahead that were issued at the top of the step -- their flight time would be exposed at every barrier.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 __device__ __forceinline__ float sel(unsigned m, unsigned bit, float x) { return (m & bit) ? x : 0.f; }
 __device__ __forceinline__ float comp(const float4& v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
 
@@ -259,18 +267,18 @@ __global__ __launch_bounds__(NT) void gemm_x3_kernel(X3P p) {
         __builtin_amdgcn_sched_barrier(0);           // the loads go out FIRST (hipcc sinks them behind the MFMAs otherwise: a step of flight time lost)
         compute(sm + (kt & 1) * STAGE);
         commit(full_tag, ran, rbn, sm + ((kt + 1) & 1) * STAGE);
-        __syncthreads();
+        lds_barrier();
     };
     auto step_tail = [&](int kt, typename OA::Regs& rac, typename OB::Regs& rbc, const typename OA::Regs& ran, const typename OB::Regs& rbn) {
         if (kt + 2 < tiles) fetch(kt + 2, rac, rbc);
         compute(sm + (kt & 1) * STAGE);
         if (kt + 1 < tiles) commit(std::false_type{}, ran, rbn, sm + ((kt + 1) & 1) * STAGE);
-        __syncthreads();
+        lds_barrier();
     };
     fetch(0, ra0, rb0);
     if (tiles > 1) fetch(1, ra1, rb1);
     commit(std::false_type{}, ra0, rb0, sm);
-    __syncthreads();
+    lds_barrier();
     int kt = 0;
     if (p.kb == 1 || kfull) {
 #pragma unroll 1

@@ -9,14 +9,23 @@ mkdir -p $O
 python bench.py > $O/bench.json 2> $O/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/serial -o serial -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --serial > $O/bench_serial_traced.json 2> /dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/lanes -o lanes -- python bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-extras > $O/bench_lanes_traced.json 2> /dev/null
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- python bench.py --tasks 1 --steps 1 --warmup 1 --no-cpu-baseline --no-extras --serial > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- python bench.py --tasks 1 --steps 1 --warmup 1 --no-cpu-baseline --no-extras --serial > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras --serial > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras --serial > /dev/null 2>&1
 python tools/pmc_traffic.py $O/pmc_fetch/f_counter_collection.csv $O/pmc_write/w_counter_collection.csv $O/pmc_traffic.json > $O/pmc_traffic.txt 2>&1
 python tools/pmc_summary.py $O/pmc_fetch/f_counter_collection.csv FETCH_SIZE $O/pmc_fetch_size_per_kernel.csv
 python tools/pmc_summary.py $O/pmc_write/w_counter_collection.csv WRITE_SIZE $O/pmc_write_size_per_kernel.csv
 # long-utterance configuration (BASELINE.json configs[3]): T = 5000
 python bench.py --frames 5000 --tasks 2 --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $O/bench_t5000.json 2> /dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/t5000 -o t5000 -- python bench.py --frames 5000 --tasks 1 --steps 1 --warmup 1 --no-cpu-baseline --no-extras --serial > $O/bench_t5000_serial_traced.json 2> /dev/null
+# LM meta loop (BASELINE.json configs[4]): bench line + rocprofv3 summary
+mkdir -p $O/lm
+python bench.py --workload lm > $O/lm/bench_lm.json 2> /dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/lm/trace -o lm -- python bench.py --workload lm --steps 3 --warmup 1 --no-cpu-baseline > $O/lm/bench_lm_traced.json 2> /dev/null
+# isolated products on the bf16-split engine vs the fp32 engines, PMC counters of one of them, and the DVFS probe of the convolutions
+python tools/bench_gemm_x3.py 2> /dev/null | grep -v amdgpu.ids > $O/gemm_x3_vs_fp32.txt
+bash tools/pmc_gemm_x3.sh "ffn fwd (enc)" > /dev/null 2>&1; cp gpurun_out/pmc_x3/summary.txt $O/pmc_gemm_x3_ffn_fwd.txt
+python tools/bench_conv.py 2>/dev/null | grep h2 > $O/conv_random_data.txt
+MTL_BENCH_ZERO=1 python tools/bench_conv.py 2>/dev/null | grep h2 > $O/conv_zero_data.txt
 rm -rf $O/pmc_fetch $O/pmc_write
 find $O -name "*_kernel_trace.csv" -delete
 find $O -name "*agent_info.csv" -delete

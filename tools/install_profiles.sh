@@ -10,3 +10,7 @@ cp $S/bench_t5000.json $D/t5000/bench_t5000.json
 cp $S/bench_t5000_serial_traced.json $D/t5000/bench_t5000_serial_traced.json
 cp $S/t5000/t5000_kernel_stats.csv $D/t5000/kernel_stats_serial.csv
 cp $S/pmc_traffic.json profiles/pmc_traffic.json
+mkdir -p $D/lm
+cp $S/lm/bench_lm.json $S/lm/bench_lm_traced.json $D/lm/
+cp $S/lm/trace/lm_kernel_stats.csv $D/lm/kernel_stats.csv
+cp $S/gemm_x3_vs_fp32.txt $S/pmc_gemm_x3_ffn_fwd.txt $S/conv_random_data.txt $S/conv_zero_data.txt $D/
