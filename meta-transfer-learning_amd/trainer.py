@@ -776,9 +776,9 @@ class TransientTrainer():
                 if world > 1 and (it == start_it or (check_every > 0 and (it + 1) % check_every == 0)):
                     check_replicas(model, val_data, it)
                 step = self.enqueue_iteration(model, vocab, task_batches, val_data, n_tasks, inner_opt, outer_opt, args)
-                if pending is not None:
-                    resolve(*pending)                     # iteration it - 1 is logged while the device runs iteration it
-                pending = (it, step)
+                prev, pending = pending, (it, step)       # (the enqueued step is on record before anything else can raise)
+                if prev is not None:
+                    resolve(*prev)                        # iteration it - 1 is logged while the device runs iteration it
                 if not self.pipeline or (it + 1) % evaluate_every == 0 or it + 1 >= num_it:
                     resolve(*pending)
                     pending = None
@@ -803,6 +803,16 @@ class TransientTrainer():
                 print('Error: {}, fetching new data...'.format(e), flush=True)
                 logging.info('Error: {}, fetching new data...'.format(e))
                 torch.cuda.synchronize(dev)
+                # an iteration that was enqueued before the failure is complete now: log it and advance past it BEFORE the retry
+                # re-uses its read-back buffers (the failed enqueue has flipped the buffer set)
+                if pending is not None:
+                    done_it, done_step = pending
+                    pending = None
+                    try:
+                        resolve(done_it, done_step)
+                    except Exception as e2:               # its Adam step has been applied either way
+                        logging.info('Error while resolving iteration {}: {}'.format(done_it + 1, e2))
+                    it = max(it, done_it + 1)
         if pending is not None:
             resolve(*pending)
         prefetch.join()
