@@ -137,6 +137,8 @@ def classify(lib, name, a, conv_mode, wgrad_x3_dense):
         small = route == 1
         return ('gemm_small' if small else 'gemm_big', 2.0 * M * N * K * batch * kb, 'flop',
                 'gemm16_kernel<...>' if small else 'gemm_kernel<...> (+ splitk_reduce_kernel)')
+    if name == 'mtl_gemm_h2_tb':
+        return 'gemm_h2', 2.0 * a[2] * a[3] * a[4] * a[18], 'flop', 'gemm_x3_kernel<.,.,.,BM,2> (two fp16 pieces)'
     if name == 'mtl_gemm_nt_h2':
         return 'gemm_h2', 2.0 * a[1] * a[2] * a[3], 'flop', 'gemm_nt_h2_kernel (+ gemm_h2_reduce_kernel)'
     if name == 'mtl_lowrank_pair':

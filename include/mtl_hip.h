@@ -90,6 +90,16 @@ int mtl_gemm_x3_min_tiles(int set);
  * on the flattened VGG feature map (models/asr/transformer.py:136-140, K = 5120) and its data gradient (B = the transposed
  * weight).  K % 32 == 0, N % 4 == 0, leading dimensions multiples of 4, 16-byte aligned operands.  Few-tile products split K over
  * workgroups (workspace) and finish in a fixed-order reduction kernel. */
+/* Task-batched two-piece fp16 product on the tile engine of csrc/mtl_gemm_x3.hip (256 x 128 x 32 tiles, 8 waves, split interleaved
+ * with the MFMAs; 3 v_mfma_f32_32x32x16_f16 per step): for task t < tasks
+ *   C_t[M,N] = A_t[M,K] . op(B_t) (+ bias_t[N]) (gate: C = gate_t[m][n] > 0 ? C : 0),   op(B) = B[N,K]^T (transB = 1) or B[K,N] (transB = 0),
+ * operands of task t at base + t * s?t (sBt = 0: shared weights), its bounds max|A_t| / max|B_t| at amax_? + t * sAmax? floats
+ * (MTL_AMAX_SLOTS slot heads each, as for the *_h2 convolutions; gate shares C's offsets).  The encoder's input Linear (5120 -> 512,
+ * models/asr/transformer.py:136-140, modules/encoder.py:72) of all tasks of a pass in one launch, and its data gradient straight from the
+ * un-transposed weight (transB = 0).  Any M, N, K; 16-byte aligned operands, lda / ldb / strides multiples of 4. */
+int mtl_gemm_h2_tb(void* stream, int transB, int M, int N, int K, const float* A, int lda, const float* amax_a, long sAmaxA,
+                   const float* B, int ldb, const float* amax_b, long sAmaxB, float* C, int ldc, const float* bias, const float* gate,
+                   int ldg, int tasks, long sAt, long sBt, long sCt, long sBiasT);
 int mtl_gemm_nt_h2_supported(int M, int N, int K);
 long mtl_gemm_nt_h2_workspace(int M, int N, int K);
 int mtl_gemm_nt_h2(void* stream, int M, int N, int K, const float* A, int lda, const float* amax_a, const float* B, int ldb,

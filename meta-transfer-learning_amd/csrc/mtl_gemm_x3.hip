@@ -51,6 +51,9 @@ struct X3P {
     int Zt;
     long sAt, sBt, sCt, sBiasT, sRowT;
     int total;
+    // two-piece fp16 form (NP = 2): bounds of max|A|, max|B| (MTL_AMAX_SLOTS slot heads each, mtl_h2.h) and their task strides in floats
+    const float *amax_a, *amax_b;
+    long sAmaxA, sAmaxB;
 };
 
 // x0, x1 -> three dwords of packed bf16 pairs, x = h + m + l EXACTLY: h and m are truncations (top 8 significand bits of x and of
@@ -79,6 +82,13 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("" ::: "memory");
 }
 
+// NP pieces of a pair: 3 = exact bf16 triple (scale unused), 2 = fp16 pair of the scaled values (mtl_h2.h)
+template <int NP>
+__device__ __forceinline__ void pieces(float x0, float x1, float s, unsigned (&pc)[NP]) {
+    if constexpr (NP == 3) split3(x0, x1, pc[0], pc[1], pc[2]);
+    else split2x2(x0 * s, x1 * s, pc[0], pc[1]);
+}
+
 __device__ __forceinline__ float sel(unsigned m, unsigned bit, float x) { return (m & bit) ? x : 0.f; }
 __device__ __forceinline__ float comp(const float4& v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
 
@@ -91,7 +101,7 @@ __device__ __forceinline__ float comp(const float4& v, int i) { return i == 0 ? 
 // Rows beyond the operand's extent are NOT zeroed: row m of op(A) only reaches row m of C and row n of op(B) only column n, and
 // those are never stored (nor is their row sum), so whatever the clamped address delivers is harmless.  Only k >= K must
 // contribute zeros: km (a 4-bit mask per quad, K-major) / a validity bit per k row (MN-major), applied by commit<FULL = false>.
-template <bool KMAJ, int ROWS>
+template <bool KMAJ, int ROWS, int NP>
 struct Opnd {
     static constexpr int NV = ROWS / 64;          // float4 per thread and tile (4 or 2)
     static constexpr int PLANE = ROWS * 64;
@@ -133,7 +143,7 @@ struct Opnd {
     }
     // FULL: the tile lies inside K (wave-uniform), no masks.  rs: row sums of the thread's 4 rows (MN-major A only)
     template <bool FULL, bool RS>
-    __device__ __forceinline__ void commit(const Regs& r, unsigned char* lds, int tid, float (&rs)[4]) const {
+    __device__ __forceinline__ void commit(const Regs& r, unsigned char* lds, int tid, float (&rs)[4], float sc) const {
         const int kq = tid & 7;
         if (KMAJ) {
 #pragma unroll
@@ -141,13 +151,12 @@ struct Opnd {
                 const int row = (tid >> 3) + 64 * i;
                 float4 x = r.v[i];
                 if (!FULL) x = make_float4(sel(r.km, 1u, x.x), sel(r.km, 2u, x.y), sel(r.km, 4u, x.z), sel(r.km, 8u, x.w));
-                uint2 h, mm, l;
-                split3(x.x, x.y, h.x, mm.x, l.x);
-                split3(x.z, x.w, h.y, mm.y, l.y);
+                unsigned p0[NP], p1[NP];
+                pieces<NP>(x.x, x.y, sc, p0);
+                pieces<NP>(x.z, x.w, sc, p1);
                 unsigned char* dst = lds + row * 64 + (((kq >> 1) ^ ((row >> 2) & 3)) << 4) + (kq & 1) * 8;
-                *reinterpret_cast<uint2*>(dst) = h;
-                *reinterpret_cast<uint2*>(dst + PLANE) = mm;
-                *reinterpret_cast<uint2*>(dst + 2 * PLANE) = l;
+#pragma unroll
+                for (int q = 0; q < NP; ++q) *reinterpret_cast<uint2*>(dst + q * PLANE) = make_uint2(p0[q], p1[q]);
             }
         } else if (ROWS == 256) {
             const int mq = tid >> 3;
@@ -156,13 +165,12 @@ struct Opnd {
                 float4 x = make_float4(comp(r.v[0], i), comp(r.v[1], i), comp(r.v[2], i), comp(r.v[3], i));
                 if (!FULL) x = make_float4(sel(r.km, 1u, x.x), sel(r.km, 2u, x.y), sel(r.km, 4u, x.z), sel(r.km, 8u, x.w));
                 if (RS) rs[i] += (x.x + x.y) + (x.z + x.w);
-                uint2 h, mm, l;
-                split3(x.x, x.y, h.x, mm.x, l.x);
-                split3(x.z, x.w, h.y, mm.y, l.y);
+                unsigned p0[NP], p1[NP];
+                pieces<NP>(x.x, x.y, sc, p0);
+                pieces<NP>(x.z, x.w, sc, p1);
                 unsigned char* dst = lds + (mq * 4 + i) * 64 + (((kq >> 1) ^ (mq & 3)) << 4) + (kq & 1) * 8;
-                *reinterpret_cast<uint2*>(dst) = h;
-                *reinterpret_cast<uint2*>(dst + PLANE) = mm;
-                *reinterpret_cast<uint2*>(dst + 2 * PLANE) = l;
+#pragma unroll
+                for (int q = 0; q < NP; ++q) *reinterpret_cast<uint2*>(dst + q * PLANE) = make_uint2(p0[q], p1[q]);
             }
         } else {
             const int mq = (tid >> 3) & 31, kh = tid >> 8;
@@ -174,23 +182,23 @@ struct Opnd {
                     x1 = sel(r.km, 2u, x1);
                 }
                 if (RS) rs[i] += x0 + x1;
-                unsigned h, mm, l;
-                split3(x0, x1, h, mm, l);
+                unsigned p0[NP];
+                pieces<NP>(x0, x1, sc, p0);
                 unsigned char* dst = lds + (mq * 4 + i) * 64 + (((kq >> 1) ^ (mq & 3)) << 4) + (kq & 1) * 8 + kh * 4;
-                *reinterpret_cast<unsigned*>(dst) = h;
-                *reinterpret_cast<unsigned*>(dst + PLANE) = mm;
-                *reinterpret_cast<unsigned*>(dst + 2 * PLANE) = l;
+#pragma unroll
+                for (int q = 0; q < NP; ++q) *reinterpret_cast<unsigned*>(dst + q * PLANE) = p0[q];
             }
         }
     }
 };
 
 // BM = 256: a wave owns 64 x 64 (TM = 2 row blocks); BM = 128 (products with too few 256-row tiles to fill the chip): 32 x 64
-template <bool TA, bool TB, bool RS, int BM>      // RS: row sums of op(A) ride along (TA only)
+// NP = 3: exact bf16 triples, six MFMAs per block product; NP = 2: fp16 pairs of power-of-two scaled operands, three MFMAs (mtl_h2.h)
+template <bool TA, bool TB, bool RS, int BM, int NP>      // RS: row sums of op(A) ride along (TA only)
 __global__ __launch_bounds__(NT) void gemm_x3_kernel(X3P p) {
-    constexpr int PLANE_A = BM * 64, STAGE = 3 * (PLANE_A + PLANE_B), WTM = BM / 4, TM = WTM / 32;
-    using OA = Opnd<!TA, BM>;          // op(A) is M x K: stored [m][k] unless transposed
-    using OB = Opnd<TB, BN>;           // op(B) is K x N: stored [n][k] when transposed
+    constexpr int PLANE_A = BM * 64, STAGE = NP * (PLANE_A + PLANE_B), WTM = BM / 4, TM = WTM / 32;
+    using OA = Opnd<!TA, BM, NP>;          // op(A) is M x K: stored [m][k] unless transposed
+    using OB = Opnd<TB, BN, NP>;           // op(B) is K x N: stored [n][k] when transposed
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, hi = lane >> 5;
@@ -202,6 +210,11 @@ __global__ __launch_bounds__(NT) void gemm_x3_kernel(X3P p) {
     const int m0 = (rem / nx) * BM, n0 = (rem % nx) * BN;
     const int zt = z / p.Zt, zz = z - zt * p.Zt;
     const int zb = zz / p.H, zh = zz - zb * p.H;
+    float sa = 1.f, sb = 1.f;                     // NP = 2: the power-of-two scales of this task's operands (full waves read the bounds)
+    if constexpr (NP == 2) {
+        sa = pow2_scale(amax_read(p.amax_a + zt * p.sAmaxA));
+        sb = pow2_scale(amax_read(p.amax_b + zt * p.sAmaxB));
+    }
     OA la;
     OB lb;
     la.init(p.A + zt * p.sAt + zb * p.sAb + zh * p.sAh, p.lda, m0, p.M, tid);
@@ -226,35 +239,41 @@ __global__ __launch_bounds__(NT) void gemm_x3_kernel(X3P p) {
     };
     auto commit = [&](auto full_tag, const typename OA::Regs& ra, const typename OB::Regs& rb, unsigned char* stage) {
         constexpr bool FULL = decltype(full_tag)::value;
-        la.template commit<FULL, RS>(ra, stage, tid, rs);
-        lb.template commit<FULL, false>(rb, stage + 3 * PLANE_A, tid, rs);
+        la.template commit<FULL, RS>(ra, stage, tid, rs, sa);
+        lb.template commit<FULL, false>(rb, stage + NP * PLANE_A, tid, rs, sb);
     };
     // fragment addresses: row (wm | wn) * 64 + 32 i + l31, chunk (2 st + hi) ^ ((row >> 2) & 3)
-    const int arow = (wm * WTM + l31) * 64, brow = 3 * PLANE_A + (wn * 64 + l31) * 64;
+    const int arow = (wm * WTM + l31) * 64, brow = NP * PLANE_A + (wn * 64 + l31) * 64;
     int csw[2];
 #pragma unroll
     for (int st = 0; st < 2; ++st) csw[st] = ((st * 2 + hi) ^ ((l31 >> 2) & 3)) << 4;
     auto compute = [&](const unsigned char* stage) {
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
-            uint4 a[TM][3], b[2][3];
+            uint4 a[TM][NP], b[2][NP];
 #pragma unroll
-            for (int pc = 0; pc < 3; ++pc) {
+            for (int pc = 0; pc < NP; ++pc) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i) a[i][pc] = *reinterpret_cast<const uint4*>(stage + pc * PLANE_A + arow + i * 32 * 64 + csw[st]);
 #pragma unroll
                 for (int j = 0; j < 2; ++j) b[j][pc] = *reinterpret_cast<const uint4*>(stage + pc * PLANE_B + brow + j * 32 * 64 + csw[st]);
             }
-            // six terms, smallest first, each over all accumulators (dependent MFMAs are 2 TM issues apart)
-            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+            // the cross terms, smallest first, each over all accumulators (dependent MFMAs are 2 TM issues apart)
+            constexpr int NTERM = NP == 3 ? 6 : 3;
+            constexpr int PA[6] = {NP == 3 ? 2 : 1, 0, NP == 3 ? 1 : 0, 1, 0, 0}, PB[6] = {0, NP == 3 ? 2 : 1, NP == 3 ? 1 : 0, 0, 1, 0};
 #pragma unroll
-            for (int tm = 0; tm < 6; ++tm)
+            for (int tm = 0; tm < NTERM; ++tm)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i][PA[tm]]),
-                                                                            __builtin_bit_cast(bf16x8, b[j][PB[tm]]), acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < 2; ++j) {
+                        if constexpr (NP == 3)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i][PA[tm]]),
+                                                                                __builtin_bit_cast(bf16x8, b[j][PB[tm]]), acc[i][j], 0, 0, 0);
+                        else
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[i][PA[tm]]),
+                                                                               __builtin_bit_cast(f16x8, b[j][PB[tm]]), acc[i][j], 0, 0, 0);
+                    }
         }
     };
     // step kt: tile kt + 2 -> the register set tile kt left; multiply stage kt & 1; split tile kt + 1 into the other stage.
@@ -306,6 +325,7 @@ __global__ __launch_bounds__(NT) void gemm_x3_kernel(X3P p) {
     const float* gate = p.gate ? p.gate + co : nullptr;
     const bool accum = p.flags & MTL_GEMM_ACCUM;
     const float lo = (p.flags & MTL_GEMM_RELU) ? 0.f : -__builtin_inff();
+    const float alpha = NP == 2 ? p.alpha / (sa * sb) : p.alpha;      // (powers of two: exact)
     const int rbase = m0 + wm * WTM + 4 * hi;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -317,7 +337,7 @@ __global__ __launch_bounds__(NT) void gemm_x3_kernel(X3P p) {
             const float bb = p.bias ? p.bias[zt * p.sBiasT + zb * p.sBias + zh * p.sBiasH + col] : 0.f;
             float x[16];
 #pragma unroll
-            for (int v = 0; v < 16; ++v) x[v] = fmaxf(p.alpha * acc[i][j][v] + bb, lo);
+            for (int v = 0; v < 16; ++v) x[v] = fmaxf(alpha * acc[i][j][v] + bb, lo);
             if (gate) {
                 float gt[16];
 #pragma unroll
@@ -341,7 +361,7 @@ __global__ __launch_bounds__(NT) void gemm_x3_kernel(X3P p) {
     if (RS) {
         // a thread holds the sums over ITS k's of rows 4 mq .. + 3 (BM = 256: 8 k lanes per row; 128: 8 x 2): combined in a fixed order
         float* red = reinterpret_cast<float*>(sm);   // the tile buffers are free: the loop ended with a barrier
-        constexpr int NP = BM == 256 ? 8 : 16;
+        constexpr int NPART = BM == 256 ? 8 : 16;
         const int kq = tid & 7, mq = BM == 256 ? (tid >> 3) : ((tid >> 3) & 31), part = BM == 256 ? kq : (tid >> 8) * 8 + kq;
 #pragma unroll
         for (int i = 0; i < 4; ++i) red[part * (BM + 1) + mq * 4 + i] = rs[i];
@@ -349,21 +369,21 @@ __global__ __launch_bounds__(NT) void gemm_x3_kernel(X3P p) {
         if (do_rowsum && tid < BM && m0 + tid < p.M) {
             float s = 0.f;
 #pragma unroll
-            for (int q = 0; q < NP; ++q) s += red[q * (BM + 1) + tid];
+            for (int q = 0; q < NPART; ++q) s += red[q * (BM + 1) + tid];
             p.rowsum[zt * p.sRowT + zb * p.sRow + zh * p.sRowH + m0 + tid] += s;
         }
     }
 }
 
-template <bool TA, bool TB, bool RS, int BM>
+template <bool TA, bool TB, bool RS, int BM, int NP = 3>
 int launch_x3(X3P p, hipStream_t s) {
-    constexpr int SMEM = 2 * 3 * (BM + BN) * 64;
-    static int attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_kernel<TA, TB, RS, BM>),
+    constexpr int SMEM = 2 * NP * (BM + BN) * 64;
+    static int attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_kernel<TA, TB, RS, BM, NP>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) == hipSuccess ? 0 : MTL_ELAUNCH;
     if (attr) return attr;
     p.total = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.total;       // (p.total arrives as the number of batch items)
     dim3 grid(((p.total + 7) / 8) * 8);
-    hipLaunchKernelGGL((gemm_x3_kernel<TA, TB, RS, BM>), grid, dim3(NT), SMEM, s, p);
+    hipLaunchKernelGGL((gemm_x3_kernel<TA, TB, RS, BM, NP>), grid, dim3(NT), SMEM, s, p);
     MTL_CHECK_LAUNCH();
     return MTL_OK;
 }
@@ -406,7 +426,7 @@ int mtl_gemm_x3_route(void* stream, int transA, int transB, int M, int N, int K,
     if ((transA && transB) || !mtl_gemm_x3_eligible(M, N, batch)) return 0;
     if (!al16(A) || !al16(B) || (lda & 3) || (ldb & 3) || ((sAb | sAh | sBb | sBh | sAk | sBk | sAt | sBt) & 3)) return 0;
     X3P p{A, B, C, bias, gate, rowsum, M, N, K, lda, ldb, ldc, ldg, alpha, flags, H, sAb, sAh, sBb, sBh, sCb, sCh, sBias, kbatch,
-          sAk, sBk, sRowsum, sBiasH, sRowsumH, batch / tasks, sAt, sBt, sCt, sBiasT, sRowsumT, batch};
+          sAk, sBk, sRowsum, sBiasH, sRowsumH, batch / tasks, sAt, sBt, sCt, sBiasT, sRowsumT, batch, nullptr, nullptr, 0, 0};
     // 256-row tiles (less operand traffic and split work per MFMA) once they give every CU a workgroup; 128-row tiles otherwise
     static const int big_from = getenv("MTL_GEMM_X3_BIG") ? atoi(getenv("MTL_GEMM_X3_BIG")) : 224;
     const bool big = x3_tiles(M, N, batch, 256) >= big_from;
@@ -417,4 +437,17 @@ int mtl_gemm_x3_route(void* stream, int transA, int transB, int M, int N, int K,
     else if (rowsum) rc = launch_x3_bm<true, false, true>(p, s, big);
     else rc = launch_x3_bm<true, false, false>(p, s, big);
     return rc == MTL_OK ? 1 : rc;
+}
+
+extern "C" int mtl_gemm_h2_tb(void* stream, int transB, int M, int N, int K, const float* A, int lda, const float* amax_a, long sAmaxA,
+                              const float* B, int ldb, const float* amax_b, long sAmaxB, float* C, int ldc, const float* bias,
+                              const float* gate, int ldg, int tasks, long sAt, long sBt, long sCt, long sBiasT) {
+    if (M <= 0 || N <= 0 || K <= 0 || tasks <= 0 || !A || !B || !C || !amax_a || !amax_b) return MTL_EINVAL;
+    if (!al16(A) || !al16(B) || (lda & 3) || (ldb & 3) || ((sAt | sBt) & 3)) return MTL_EINVAL;
+    X3P p{A, B, C, bias, gate, nullptr, M, N, K, lda, ldb, ldc, ldg, 1.f, 0, 1, 0, 0, 0, 0, 0, 0, 0, 1,
+          0, 0, 0, 0, 0, 1, sAt, sBt, sCt, sBiasT, 0, tasks, amax_a, amax_b, sAmaxA, sAmaxB};
+    hipStream_t s = as_stream(stream);
+    const bool big = x3_tiles(M, N, tasks, 256) >= 128;
+    if (transB) return big ? launch_x3<false, true, false, 256, 2>(p, s) : launch_x3<false, true, false, 128, 2>(p, s);
+    return big ? launch_x3<false, false, false, 256, 2>(p, s) : launch_x3<false, false, false, 128, 2>(p, s);
 }

@@ -1205,19 +1205,26 @@ class PassEngine:
             (d0, a0), pro_done = self.run_on_side(dec_prologue)      # under the input Linear and the encoder
         e0 = self.buf('e0', (nt * Me, d))
         # the encoder's input Linear (5120 -> 512) and its data gradient: 'x3' = one task-batched launch each on the bf16-split engine
-        # (exact 3-piece operands, no bounds needed; MTL_IN_LINEAR=x3), 'h2' = per-task launches on two fp16 pieces (default: the step measured 61.2 ms against 63.2)
-        self.in_h2 = (h2 and self.in_linear == 'h2' and bool(lib.mtl_gemm_nt_h2_supported(Me, d, hp.d_in))
-                      and bool(lib.mtl_gemm_nt_h2_supported(Me, hp.d_in, d)))
-        if self.in_h2:      # the two compute-bound products of the pass on fp16 pairs: e0 = p2 . wp^T here, dp2 = de0 . (wp^T)^T in the backward
-            wpT = self.buf('wpT_in', (ntw, hp.d_in, d))
-            need = lib.mtl_gemm_nt_h2_workspace(Me, d, hp.d_in)
-            for t in range(ntw):
-                check(lib.mtl_transpose_batch(st, self._transpose_table(wp[t], wpT[t], d, hp.d_in), 1), 'mtl_transpose_batch')
-            for t in range(nt):
-                tw = t if sP else 0
-                check(lib.mtl_gemm_nt_h2(st, Me, d, hp.d_in, p2[t * B:].data_ptr(), hp.d_in, am_(6, t), wp[tw].data_ptr(), hp.d_in,
-                                         am_(7, tw), e0[t * Me:].data_ptr(), d, o('encoder.input_linear.bias', t), None, 0,
-                                         self.scratch(need) if need else None, need), 'mtl_gemm_nt_h2')
+        # (exact 3-piece operands, no bounds needed; MTL_IN_LINEAR=x3), 'h2' (default) = one task-batched launch each on two fp16 pieces
+        # (mtl_gemm_h2_tb: the same tile engine with three MFMAs per step), 'h2s' = the per-task split-K kernel of round 2
+        self.in_h2 = h2 and (self.in_linear == 'h2' or (self.in_linear == 'h2s' and bool(lib.mtl_gemm_nt_h2_supported(Me, d, hp.d_in))
+                                                        and bool(lib.mtl_gemm_nt_h2_supported(Me, hp.d_in, d))))
+        if self.in_h2:      # the two compute-bound products of the pass on fp16 pairs: e0 = p2 . wp^T here, dp2 = de0 . wp in the backward
+            am_st = 12 * _lib.AMAX_SLOTS                          # floats between two tasks' bounds
+            if self.in_linear == 'h2':      # ONE task-batched launch on the tile engine of mtl_gemm_x3.hip (per-task bounds by stride)
+                check(lib.mtl_gemm_h2_tb(st, 1, Me, d, hp.d_in, p2.data_ptr(), hp.d_in, am_(6), am_st, wp.data_ptr(), hp.d_in, am_(7),
+                                         am_st if sP else 0, e0.data_ptr(), d, o('encoder.input_linear.bias'), None, 0, nt,
+                                         Me * hp.d_in, d * hp.d_in if sP else 0, Me * d, self.sP), 'mtl_gemm_h2_tb')
+            else:                           # 'h2s': per-task launches of the older split-K kernel (mtl_gemm_h2.hip)
+                wpT = self.buf('wpT_in', (ntw, hp.d_in, d))
+                need = lib.mtl_gemm_nt_h2_workspace(Me, d, hp.d_in)
+                for t in range(ntw):
+                    check(lib.mtl_transpose_batch(st, self._transpose_table(wp[t], wpT[t], d, hp.d_in), 1), 'mtl_transpose_batch')
+                for t in range(nt):
+                    tw = t if sP else 0
+                    check(lib.mtl_gemm_nt_h2(st, Me, d, hp.d_in, p2[t * B:].data_ptr(), hp.d_in, am_(6, t), wp[tw].data_ptr(), hp.d_in,
+                                             am_(7, tw), e0[t * Me:].data_ptr(), d, o('encoder.input_linear.bias', t), None, 0,
+                                             self.scratch(need) if need else None, need), 'mtl_gemm_nt_h2')
         else:
             self.gemm(0, 1, Me, d, hp.d_in, p2.data_ptr(), hp.d_in, wp.data_ptr(), hp.d_in, e0.data_ptr(), d,
                       bias=o('encoder.input_linear.bias'), task=(Me * hp.d_in, d * hp.d_in if sP else 0, Me * d, self.sP, 0))
@@ -1462,13 +1469,20 @@ class PassEngine:
         amax = A['amax']
         am_ = (lambda i, t=0: amax.data_ptr() + 4 * _lib.AMAX_SLOTS * (12 * t + i)) if h2 else (lambda i, t=0: None)   # y1, p1, y5 | dp2, dy5, dp1
         if self.in_h2:
-            need = lib.mtl_gemm_nt_h2_workspace(Me, hp.d_in, d)
             for t in range(nt):
-                tw = t if sP else 0
                 check(lib.mtl_absmax_f32(st, de0[t * Me:].data_ptr(), Me * d, am_(8, t)), 'mtl_absmax_f32')
-                check(lib.mtl_gemm_nt_h2(st, Me, hp.d_in, d, de0[t * Me:].data_ptr(), d, am_(8, t), A['wpT_in'][tw].data_ptr(), d,
-                                         am_(7, tw), dp2[t * B:].data_ptr(), hp.d_in, None, p2[t * B:].data_ptr(), hp.d_in,
-                                         self.scratch(need) if need else None, need), 'mtl_gemm_nt_h2')
+            if self.in_linear == 'h2':      # dp2 = (de0 . wp) gated by p2 > 0, straight from the un-transposed weight, all tasks in one launch
+                am_st = 12 * _lib.AMAX_SLOTS
+                check(lib.mtl_gemm_h2_tb(st, 0, Me, hp.d_in, d, de0.data_ptr(), d, am_(8), am_st, A['wp_in'].data_ptr(), hp.d_in, am_(7),
+                                         am_st if sP else 0, dp2.data_ptr(), hp.d_in, None, p2.data_ptr(), hp.d_in, nt, Me * d,
+                                         d * hp.d_in if sP else 0, Me * hp.d_in, 0), 'mtl_gemm_h2_tb')
+            else:
+                need = lib.mtl_gemm_nt_h2_workspace(Me, hp.d_in, d)
+                for t in range(nt):
+                    tw = t if sP else 0
+                    check(lib.mtl_gemm_nt_h2(st, Me, hp.d_in, d, de0[t * Me:].data_ptr(), d, am_(8, t), A['wpT_in'][tw].data_ptr(), d,
+                                             am_(7, tw), dp2[t * B:].data_ptr(), hp.d_in, None, p2[t * B:].data_ptr(), hp.d_in,
+                                             self.scratch(need) if need else None, need), 'mtl_gemm_nt_h2')
         else:
             self.gemm(0, 0, Me, hp.d_in, d, de0.data_ptr(), d, A['wp_in'].data_ptr(), hp.d_in, dp2.data_ptr(), hp.d_in,
                       gate=p2.data_ptr(), ldg=hp.d_in, task=(Me * d, d * hp.d_in if sP else 0, Me * hp.d_in, 0, 0))

@@ -1013,3 +1013,52 @@ def test_gemm_nt_two_piece_fp16(L, M, N, K, gate, bias):
     assert e2 < 2.0 * e32 + 1e-30 and e2 < 1e-6, (e2, e32)
     if need:
         assert L.mtl_gemm_nt_h2(*(args(C)[:-1] + (need - 4,))) != 0       # short workspace is refused
+
+
+@pytest.mark.parametrize('transB,M,N,K,tasks,shared,gate,bias', [(1, 300, 512, 640, 3, True, False, True), (0, 300, 640, 512, 3, True, True, False),
+                                                                 (1, 2000, 512, 5120, 2, False, False, True), (0, 257, 132, 100, 2, False, True, False)])
+def test_gemm_two_piece_fp16_task_batched(L, transB, M, N, K, tasks, shared, gate, bias):
+    """mtl_gemm_h2_tb (the tile engine of mtl_gemm_x3.hip with fp16 pairs): per-task operands, bounds and biases by stride, shared or
+    per-task weights, both weight orientations, gate, ragged M / N / K; against fp64 no less accurate than 2x the exact-fp32 engine of
+    this library, bitwise reproducible; a quiet task beside a loud one keeps its accuracy (the scale is per task)."""
+    g = torch.Generator().manual_seed(M + N + K + tasks)
+    A = torch.randn(tasks, M, K, generator=g) * 3e-3
+    A[1] *= 2.0 ** -12                                       # a quiet task: its own bound, its own scale
+    nb = 1 if shared else tasks
+    Bm = torch.randn(nb, N, K, generator=g) * 0.5 if transB else torch.randn(nb, K, N, generator=g) * 0.5
+    bv = torch.randn(tasks, N, generator=g) * 1e-4 if bias else None
+    gt = torch.randn(tasks, M, N, generator=g) if gate else None
+    opB = Bm.double().transpose(1, 2) if transB else Bm.double()
+    want = A.double() @ (opB.expand(tasks, -1, -1) if shared else opB)
+    if bias:
+        want = want + bv.double().unsqueeze(1)
+    if gate:
+        want = want * (gt > 0).double()
+    dA, dB = dev(A), dev(Bm)
+    S = 2048
+    aa, ab = torch.zeros(tasks, S).cuda(), torch.zeros(nb, S).cuda()
+    for t in range(tasks):
+        assert L.mtl_absmax_f32(st(), dA[t].data_ptr(), A[t].numel(), aa[t].data_ptr()) == 0
+    for t in range(nb):
+        assert L.mtl_absmax_f32(st(), dB[t].data_ptr(), Bm[t].numel(), ab[t].data_ptr()) == 0
+    dbv, dgt = (dev(bv) if bias else None), (dev(gt) if gate else None)
+    C, C2 = torch.full((tasks, M, N), 7.0).cuda(), torch.empty(tasks, M, N).cuda()
+    args = lambda out: (st(), transB, M, N, K, dA.data_ptr(), K, aa.data_ptr(), S, dB.data_ptr(), Bm.shape[2], ab.data_ptr(), 0 if shared else S,
+                        out.data_ptr(), N, dbv.data_ptr() if bias else None, dgt.data_ptr() if gate else None, N, tasks, M * K,
+                        0 if shared else Bm[0].numel(), M * N, N if bias else 0)
+    assert L.mtl_gemm_h2_tb(*args(C)) == 0
+    assert L.mtl_gemm_h2_tb(*args(C2)) == 0
+    assert torch.equal(C, C2)
+    old = L.mtl_gemm_x3_min_tiles(0)                          # the exact-fp32 engines as the yardstick
+    F32 = torch.empty(tasks, M, N).cuda()
+    ws = torch.empty(16 << 20).cuda()
+    try:
+        assert L.mtl_gemm_f32_tb(st(), 0, transB, M, N, K, 1.0, dA.data_ptr(), K, dB.data_ptr(), Bm.shape[2], F32.data_ptr(), N,
+                                 dbv.data_ptr() if bias else None, dgt.data_ptr() if gate else None, N, 0, tasks, 1, 0, 0, 0, 0, 0, 0, 0, 1,
+                                 0, 0, None, 0, ws.data_ptr(), ws.numel() * 4, 0, 0, tasks, M * K, 0 if shared else Bm[0].numel(), M * N,
+                                 N if bias else 0, 0) == 0
+    finally:
+        L.mtl_gemm_x3_min_tiles(old)
+    for t in range(tasks):
+        e2, e32 = rel(C[t].double().cpu(), want[t]), rel(F32[t].double().cpu(), want[t])
+        assert e2 < 2.0 * e32 + 1e-30 and e2 < 1e-6, (t, e2, e32)

@@ -26,7 +26,8 @@ def conv_class(kernel_name):
 
 # kernel-name substring -> bench.py class for the non-convolution classes (a class = one C-ABI call; calls that launch two
 # kernels, e.g. mtl_attn_bwd, are averaged per kernel and summed)
-GROUPS = {'gemm_x3': ['gemm_x3_kernel'], 'gemm_small': ['gemm16_kernel'], 'gemm_h2': ['gemm_nt_h2_kernel', 'gemm_h2_reduce_kernel'], 'gemm_big': ['gemm_kernel<', 'splitk_reduce_kernel'], 'attn_fwd': ['attn_fwd_kernel'],
+GROUPS = {'gemm_x3': [', 3>((anonymous namespace)::X3P'], 'gemm_small': ['gemm16_kernel'],
+          'gemm_h2': [', 2>((anonymous namespace)::X3P', 'gemm_nt_h2_kernel', 'gemm_h2_reduce_kernel'], 'gemm_big': ['gemm_kernel<', 'splitk_reduce_kernel'], 'attn_fwd': ['attn_fwd_kernel'],
           'attn_bwd': ['attn_bwd_kernel'], 'layernorm_fwd': ['layernorm_fwd_kernel'],
           'layernorm_bwd': ['layernorm_bwd_kernel', 'ln_param_reduce_kernel', 'ln_param_reduce_batch_kernel'], 'conv0_fwd': ['conv0_fwd_kernel'],
           'conv0_wgrad': ['conv0_wgrad_kernel', 'conv0_wgrad_final_kernel']}
