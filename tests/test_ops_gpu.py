@@ -1062,3 +1062,74 @@ def test_gemm_two_piece_fp16_task_batched(L, transB, M, N, K, tasks, shared, gat
     for t in range(tasks):
         e2, e32 = rel(C[t].double().cpu(), want[t]), rel(F32[t].double().cpu(), want[t])
         assert e2 < 2.0 * e32 + 1e-30 and e2 < 1e-6, (t, e2, e32)
+
+
+@pytest.fixture
+def x3_forced(L):
+    """every eligible product of mtl_gemm_f32_ex / _tb goes to the bf16-split engine (threshold 1 tile) for the duration of a test"""
+    old = L.mtl_gemm_x3_min_tiles(1)
+    yield
+    L.mtl_gemm_x3_min_tiles(old)
+
+
+@pytest.mark.parametrize('ta,tb', [(0, 1), (0, 0), (1, 0)])
+@pytest.mark.parametrize('M,N,K', [(101, 252, 64), (808, 100, 512), (100, 512, 2000), (33, 36, 7), (512, 100, 808), (5, 3768, 301),
+                                   (2000, 512, 100), (257, 129 * 4, 33)])
+def test_bf16_split_engine_contract(L, x3_forced, ta, tb, M, N, K):
+    """csrc/mtl_gemm_x3.hip with the routing threshold forced to one tile: both tile configurations, the three operand orientations
+    of the pass, ragged M / N / K (K tails inside a quad for the K-major forms, partial 16-byte quads at the row end of the MN-major
+    ones), bias + ReLU + gate + accumulate + alpha, two batch levels with strided operands, against fp64 at the tolerance of the
+    fp32 engines' tests; bitwise repeatable."""
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K + ta * 2 + tb)
+    lda = ((M if ta else K) + 3) // 4 * 4                   # 16-byte aligned rows (the engine's eligibility rule), extents may be ragged
+    ldb = ((K if tb else N) + 3) // 4 * 4
+    nz, H = 4, 2
+    A = torch.randn(nz, (K if ta else M), lda, generator=g)
+    B = torch.randn(nz, (N if tb else K), ldb, generator=g)
+    bias, C0, gate = torch.randn(nz, N, generator=g), torch.randn(nz, M, N, generator=g), torch.randn(nz, M, N, generator=g)
+    opA = (A[:, :, :M].transpose(1, 2) if ta else A[:, :, :K]).double()
+    opB = (B[:, :, :K].transpose(1, 2) if tb else B[:, :, :N]).double()
+    prod = opA @ opB
+    dA, dB, dbias, dgate = dev(A), dev(B), dev(bias), dev(gate)
+    assert L.mtl_gemm_f32_ex_route(M, N, K, nz, 1, 0) == 2
+    sA, sB = A[0].numel(), B[0].numel()
+    C = dev(C0.clone())
+    assert _gemm_ex(L, ta, tb, M, N, K, dA, lda, dB, ldb, C, N, batch=nz, H=H, sA=(H * sA, sA), sB=(H * sB, sB), sC=(H * M * N, M * N)) == 0
+    assert rel(C, prod) < 2e-6
+    outs = []
+    for _ in range(2):
+        C = dev(C0.clone())
+        assert _gemm_ex(L, ta, tb, M, N, K, dA, lda, dB, ldb, C, N, bias=dbias, gate=dgate, ldg=N, flags=3, alpha=0.5, batch=nz, H=H,
+                        sA=(H * sA, sA), sB=(H * sB, sB), sC=(H * M * N, M * N), sbias=H * N, sbias_h=N) == 0
+        outs.append(C.cpu())
+    want = torch.relu(0.5 * prod + bias.double().unsqueeze(1)) * (gate > 0) + C0.double()
+    assert rel(outs[0], want) < 2e-6
+    assert torch.equal(outs[0], outs[1])
+
+
+def test_bf16_split_engine_k_batching_row_sums_and_tasks(L, x3_forced):
+    """the remaining parts of the contract on the bf16-split engine: C += sum_z A_z . B_z inside one launch with a ragged K
+    (the masked main loop), row sums of op(A) as a by-product of transposed-A products (both tile configurations), and the third
+    (task) batch level with per-task weights, outputs and biases."""
+    test_gemm_k_batching_and_row_sums(L)                   # same assertions as on the fp32 engines, now routed to the split engine
+    g = torch.Generator().manual_seed(9)
+    for M, N, K, nz in ((512, 100, 808, 3), (100, 256, 301, 2)):            # 256-row and 128-row tiles, ragged K
+        dy = torch.randn(nz, K, M, generator=g)
+        x = torch.randn(nz, K, N, generator=g)
+        W0, b0 = torch.randn(nz, M, N, generator=g), torch.randn(nz, M, generator=g)
+        dW, db = dev(W0.clone()), dev(b0.clone())
+        assert L.mtl_gemm_f32_ex_route(M, N, K, nz, 1, 1) == 2
+        assert _gemm_ex(L, 1, 0, M, N, K, dev(dy), M, dev(x), N, dW, N, flags=2, batch=nz, sA=(K * M, 0), sB=(K * N, 0), sC=(M * N, 0),
+                        rowsum=db, srow=M) == 0
+        assert rel(dW, W0.double() + dy.double().transpose(1, 2) @ x.double()) < 2e-6
+        assert rel(db, b0.double() + dy.double().sum(1)) < 3e-6
+    tasks, per, M, N, K = 3, 2, 300, 200, 96
+    A, Bm = torch.randn(tasks, per, M, K, generator=g), torch.randn(tasks, N, K, generator=g)
+    bias = torch.randn(tasks, N, generator=g)
+    C = torch.empty(tasks, per, M, N).cuda()
+    ws = torch.empty(1 << 20).cuda()
+    assert L.mtl_gemm_f32_tb(st(), 0, 1, M, N, K, 1.0, dev(A).data_ptr(), K, dev(Bm).data_ptr(), K, C.data_ptr(), N, dev(bias).data_ptr(),
+                             None, 0, 0, tasks * per, 1, M * K, 0, 0, 0, M * N, 0, 0, 1, 0, 0, None, 0, ws.data_ptr(), ws.numel() * 4, 0, 0,
+                             tasks, per * M * K, N * K, per * M * N, N, 0) == 0
+    want = A.double() @ Bm.double().transpose(1, 2).unsqueeze(1) + bias.double().view(tasks, 1, 1, N)
+    assert rel(C, want) < 2e-6
