@@ -468,6 +468,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-threads', type=int, default=0)
     ap.add_argument('--no-extras', action='store_true', help='only the headline timed region + the serial roofline step')
+    ap.add_argument('--dropout', type=float, default=0.0, help='diagnostics: run the headline region and the serial profile with this dropout rate (the extras always report 0.1)')
     ap.add_argument('--lanes', action='store_true', help='per-task pass chains on concurrent lanes instead of task-batched passes (MTL_BATCH_TASKS=0)')
     ap.add_argument('--serial', action='store_true', help='no task lanes / side stream / replay (for rocprofv3 per-kernel durations)')
     ap.add_argument('--workload', default='asr', choices=['asr', 'lm'], help="'lm': the LSTM-LM meta loop (BASELINE.json configs[4], SURVEY 8(f) f3)")
@@ -492,6 +493,9 @@ def main():
     torch.manual_seed(123456)
     with contextlib.redirect_stdout(io.StringIO()):
         model = mtl_amd.init_transformer_model(args, vocab, r=CFG['r']).to(dev)
+    if a.dropout > 0:
+        model.encoder.dropout_rate = model.decoder.dropout_rate = a.dropout
+        model.train()
     trainer = mtl_amd.TransientTrainer()
     if a.lanes:
         trainer.batch_tasks = False
@@ -590,7 +594,7 @@ def main():
         # the README trains with --dropout 0.1: same 8-task workload with the Philox dropout active
         model.encoder.dropout_rate = model.decoder.dropout_rate = 0.1
         model.train()
-        dtd, _ = timed_steps(trainer, model, vocab, tasks, my_tasks, a.tasks, inner, outer, args, k3, 3, mdist, dev)
+        dtd, _ = timed_steps(trainer, model, vocab, tasks, my_tasks, a.tasks, inner, outer, args, k3, 5, mdist, dev)     # (new buffers, eager + recording + replay: 5 untimed)
         out['dropout_0.1'] = dict(value=k3 / dtd, unit='meta-steps/s', ms_per_step=dtd / k3 * 1e3, tasks=a.tasks)
         model.encoder.dropout_rate = model.decoder.dropout_rate = 0.0
         model.train()
@@ -602,7 +606,7 @@ def main():
         for e in model.engines:
             e.conv_mode, e.conv_x3, e.conv_h2, e.in_linear = 'f32', False, False, 'f32'
         tr32 = mtl_amd.TransientTrainer()              # (its own command lists: the recorded ones hold the h2 entry points)
-        dtf, _ = timed_steps(tr32, model, vocab, tasks, my_tasks, a.tasks, inner, outer, args, k3, 2, mdist, dev)
+        dtf, _ = timed_steps(tr32, model, vocab, tasks, my_tasks, a.tasks, inner, outer, args, k3, 4, mdist, dev)
         out['exact_f32'] = dict(value=k3 / dtf, unit='meta-steps/s', ms_per_step=dtf / k3 * 1e3,
                                 note='same steps with every convolution and product on the fp32 MFMA (MTL_CONV=f32, bf16-split GEMM '
                                      'engine off, input Linear on the fp32 engine)')
