@@ -43,7 +43,6 @@ __device__ __forceinline__ void grid_wait(unsigned* sync, unsigned target) {
     if (threadIdx.x == 0) {
         unsigned spins = 0;
         while (__hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(1);
             if (++spins > SPIN_LIMIT) {
                 __hip_atomic_store(&sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
@@ -70,17 +69,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int B = p.B, H = 8 * KC, T = p.T;
     float* hs = sm;                     // [B][H]
-    float* red = sm + B * H;            // [8 chunks][B][32 rows]
-    const int tid = threadIdx.x, r = tid & 31, kc = tid >> 5;
+    float* red = sm + B * H;            // [16 chunks][B][32 rows]
+    // thread (rp = tid & 15, kc = tid >> 4): rows 2 rp, 2 rp + 1 of the 32 gate rows x the k chunk [kc H/16, + H/16): every LDS read of
+    // the state feeds two rows (half the LDS traffic of one row x H/8 per thread: the product is LDS-bound)
+    constexpr int KH = KC / 2;
+    const int tid = threadIdx.x, rp = tid & 15, kc = tid >> 4;
     const int j0 = blockIdx.x * LU;
     const unsigned nwg = gridDim.x;
-    float w[KC];
-    {
-        const float* wrow = p.whh + (long)((r >> 3) * H + j0 + (r & 7)) * H + kc * KC;
+    float w[2][KH];
 #pragma unroll
-        for (int i = 0; i < KC; i += 4) {
+    for (int q = 0; q < 2; ++q) {
+        const int r = 2 * rp + q;
+        const float* wrow = p.whh + (long)((r >> 3) * H + j0 + (r & 7)) * H + kc * KH;
+#pragma unroll
+        for (int i = 0; i < KH; i += 4) {
             const float4 v = *reinterpret_cast<const float4*>(wrow + i);
-            w[i] = v.x, w[i + 1] = v.y, w[i + 2] = v.z, w[i + 3] = v.w;
+            w[q][i] = v.x, w[q][i + 1] = v.y, w[q][i + 2] = v.z, w[q][i + 3] = v.w;
         }
     }
     const bool cell = tid < B * LU;
@@ -94,23 +98,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     }
 #pragma unroll 1
     for (int t = 0; t < T; ++t) {
+        float gxv[4] = {0.f, 0.f, 0.f, 0.f};                    // this step's input contributions: requested before the wait
+        if (cell) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) gxv[g] = p.gx[((long)t * B + cb) * 4 * H + g * H + cj];
+        }
         if (t > 0) grid_wait(p.sync, (unsigned)t * nwg);        // every workgroup has published h_t
         const float* src = p.hall + (long)t * B * H;
         for (int i = tid; i < B * H / 2; i += 256) reinterpret_cast<float2*>(hs)[i] = load_shared2(src + 2 * i);
         __syncthreads();
 #pragma unroll 1
         for (int b = 0; b < B; ++b) {
-            const float* hb = hs + b * H + kc * KC;
+            const float* hb = hs + b * H + kc * KH;
             float a0 = 0.f, a1 = 0.f;
 #pragma unroll
-            for (int i = 0; i < KC; i += 4) {
+            for (int i = 0; i < KH; i += 4) {
                 const float4 hv = *reinterpret_cast<const float4*>(hb + i);
-                a0 = fmaf(w[i], hv.x, a0);
-                a1 = fmaf(w[i + 1], hv.y, a1);
-                a0 = fmaf(w[i + 2], hv.z, a0);
-                a1 = fmaf(w[i + 3], hv.w, a1);
+                a0 = fmaf(w[0][i], hv.x, a0);
+                a1 = fmaf(w[1][i], hv.x, a1);
+                a0 = fmaf(w[0][i + 1], hv.y, a0);
+                a1 = fmaf(w[1][i + 1], hv.y, a1);
+                a0 = fmaf(w[0][i + 2], hv.z, a0);
+                a1 = fmaf(w[1][i + 2], hv.z, a1);
+                a0 = fmaf(w[0][i + 3], hv.w, a0);
+                a1 = fmaf(w[1][i + 3], hv.w, a1);
             }
-            red[(kc * B + b) * 32 + r] = a0 + a1;
+            *reinterpret_cast<float2*>(red + (kc * B + b) * 32 + 2 * rp) = make_float2(a0, a1);
         }
         __syncthreads();
         if (cell) {
@@ -120,8 +133,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
             for (int g = 0; g < 4; ++g) {
                 float s = 0.f;
 #pragma unroll
-                for (int q = 0; q < 8; ++q) s += red[(q * B + cb) * 32 + g * 8 + cu];
-                pre[g] = p.gx[row * 4 * H + g * H + cj] + (s + bias[g]);
+                for (int q = 0; q < 16; ++q) s += red[(q * B + cb) * 32 + g * 8 + cu];
+                pre[g] = gxv[g] + (s + bias[g]);
             }
             const float ai = 1.f / (1.f + expf(-pre[0])), af = 1.f / (1.f + expf(-pre[1])), ag = tanhf(pre[2]),
                         ao = 1.f / (1.f + expf(-pre[3]));
@@ -174,13 +187,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 #pragma unroll 1
     for (int t = T - 1; t >= 0; --t) {
         float dh_rec = 0.f;
+        // this step's own operands do not depend on the other workgroups: requested before the wait
+        float dh_up = 0.f, ai = 0.f, af = 0.f, ag = 0.f, ao = 0.f, cc = 0.f, cprev = 0.f;
+        if (cell) {
+            const long row = (long)t * B + cb;
+            const long e = row * H + cj;
+            dh_up = p.dx_up ? (p.mask ? (p.mask[e] ? p.dx_up[e] * p.mscale : 0.f) : p.dx_up[e]) : 0.f;
+            const float* ac = p.acts + row * 4 * H + cj;
+            ai = ac[0], af = ac[H], ag = ac[2 * H], ao = ac[3 * H];
+            cc = p.call[e + (long)B * H], cprev = p.call[e];
+        }
         if (t < T - 1) {
             grid_wait(p.sync, (unsigned)(T - 1 - t) * nwg);     // every workgroup has published its partial of step t + 1
             if (cell) {
                 const float* q = P + ((t + 1) & 1) * pbuf + (long)cb * H + cj;
                 float s0 = 0.f, s1 = 0.f;
-#pragma unroll 4
-                for (unsigned wq = 0; wq < nwg; wq += 2) {      // fixed order (nwg = H / 8 is even)
+#pragma unroll 16
+                for (unsigned wq = 0; wq < nwg; wq += 2) {      // (32 loads in flight)      // fixed order (nwg = H / 8 is even)
                     s0 += __hip_atomic_load(q + (long)wq * B * H, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     s1 += __hip_atomic_load(q + (long)(wq + 1) * B * H, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
@@ -189,12 +212,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         }
         if (cell) {
             const long row = (long)t * B + cb;
-            const long e = row * H + cj;
-            float dh = p.dx_up ? (p.mask ? (p.mask[e] ? p.dx_up[e] * p.mscale : 0.f) : p.dx_up[e]) : 0.f;
-            dh += dh_rec;
-            const float* ac = p.acts + row * 4 * H + cj;
-            const float ai = ac[0], af = ac[H], ag = ac[2 * H], ao = ac[3 * H];
-            const float cc = p.call[e + (long)B * H], cprev = p.call[e];
+            const float dh = dh_up + dh_rec;
             const float tc = tanhf(cc);
             const float dc = dc_next + dh * ao * (1.f - tc * tc);
             const float di = dc * ag * ai * (1.f - ai), df = dc * cprev * af * (1.f - af), dg_ = dc * ai * (1.f - ag * ag),
@@ -242,9 +260,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 
 template <int KC>
 int launch_fwd(const LstmP& p, hipStream_t s) {
-    const int smem = (p.B * 8 * KC + 8 * p.B * 32) * 4;
+    const int smem = (p.B * 8 * KC + 16 * p.B * 32) * 4;
     static int attr = hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_layer_fwd_kernel<KC>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (32 * 8 * KC + 8 * 32 * 32) * 4) == hipSuccess ? 0 : MTL_ELAUNCH;
+                                          (32 * 8 * KC + 16 * 32 * 32) * 4) == hipSuccess ? 0 : MTL_ELAUNCH;
     if (attr) return attr;
     hipLaunchKernelGGL(lstm_layer_fwd_kernel<KC>, dim3(p.H / LU), dim3(256), smem, s, p);
     MTL_CHECK_LAUNCH();
