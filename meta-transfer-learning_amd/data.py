@@ -133,13 +133,16 @@ class ManifestTaskDataset:
             trans.append(parse_transcript(self.vocab, txt))
         return spects, trans
 
-    def sample(self, k_train, k_val, manifest_id):
+    def sample(self, k_train, k_val, manifest_id, need=(True, True)):
+        """utils/data_loader.py:245-321.  need = (train part, validation part): a part that the caller will not use is still DRAWN
+        (the index stream stays what the reference's is, and identical on every rank) but not loaded / featurised / collated --
+        it is returned as None.  The meta loop uses only the LAST task's validation batch (transient_trainer.py:168) and, with
+        several ranks, only its own tasks' training batches."""
         ids = self.ids_list[manifest_id]
         picks = self.rng.choice(np.arange(0, len(ids)), k_train + k_val, p=self.proba[manifest_id], replace=True)
-        tr = collate(*self._rows(ids, picks[:k_train]), pad_id=self.vocab.PAD_ID)
-        va = collate(*self._rows(ids, picks[k_train:k_train + k_val]), pad_id=self.vocab.PAD_ID)
+        tr = collate(*self._rows(ids, picks[:k_train]), pad_id=self.vocab.PAD_ID) if need[0] else None
+        va = collate(*self._rows(ids, picks[k_train:k_train + k_val]), pad_id=self.vocab.PAD_ID) if need[1] else None
         return tr, va
-
 
     def __len__(self):
         return self.max_size

@@ -727,8 +727,16 @@ class TransientTrainer():
         my_tasks = mdist.shard_tasks(n_tasks, rank, world)
 
         def fetch_train_batch(buf):
-            for manifest_id in range(n_tasks):                       # every rank draws every task: RNG streams stay in lock-step
-                buf[manifest_id].insert(0, train_data_list[manifest_id].sample(k_train, k_valid, manifest_id))
+            # every rank DRAWS every task (the index streams stay in lock-step), but only what this rank uses is loaded and
+            # featurised: its own tasks' training batches and the last task's validation batch, which all tasks share (:168)
+            for manifest_id in range(n_tasks):
+                need = (manifest_id in my_tasks, manifest_id == n_tasks - 1)
+                ds = train_data_list[manifest_id]
+                try:
+                    item = ds.sample(k_train, k_valid, manifest_id, need=need)
+                except TypeError:                                    # a duck-typed dataset with the reference's 3-argument sample()
+                    item = ds.sample(k_train, k_valid, manifest_id)
+                buf[manifest_id].insert(0, item)
 
         prefetch = threading.Thread(target=fetch_train_batch, args=(train_data_buffer,))
         prefetch.start()
@@ -869,8 +877,12 @@ class JointTrainer():
         buf = [[] for _ in range(n_tasks)]
 
         def fetch():
-            for m in range(n_tasks):
-                buf[m].insert(0, train_data_list[m].sample(args.k_train, 1, m))
+            for m in range(n_tasks):                         # all tasks are drawn; only this rank's training batches are loaded
+                try:
+                    item = train_data_list[m].sample(args.k_train, 1, m, need=(m in my_tasks, False))
+                except TypeError:
+                    item = train_data_list[m].sample(args.k_train, 1, m)
+                buf[m].insert(0, item)
         prefetch = threading.Thread(target=fetch)
         prefetch.start()
         total_time, it = 0, start_it

@@ -87,6 +87,12 @@ def test_vocab_manifest_and_sampling(tmp_path):
     # leading ' ' + lower-casing as the reference's parse_transcript
     assert mtl_amd.data.parse_transcript(vocab, 'AB') == [vocab.label2id['a'], vocab.label2id['b']]
     assert (x[0, 0, :, int(sizes[0]):] == 0).all()
+    # need=: a part the caller will not use is drawn (same index stream) but not loaded
+    a = mtl_amd.ManifestTaskDataset(vocab, args, [str(mp)], feats, partitions=None, seed=5)
+    b = mtl_amd.ManifestTaskDataset(vocab, args, [str(mp)], feats, partitions=None, seed=5)
+    for _ in range(3):
+        full, part = a.sample(3, 2, 0), b.sample(3, 2, 0, need=(False, True))
+        assert part[0] is None and torch.equal(full[1][3], part[1][3]) and torch.equal(full[1][1], part[1][1])
 
 
 def test_seeded_dataset_item_access_and_audio_loader(tmp_path):
