@@ -80,7 +80,7 @@ def make_args(k, lr=1e-4, meta_lr=1e-4):
 # ------------------------------------------------------------------------------------------------------------------
 # launch-level profiling: every library call that launches kernels, bracketed with HIP events on the stream it is given
 # ------------------------------------------------------------------------------------------------------------------
-_NOT_LAUNCHES = {'mtl_lstm_layer_supported', 'mtl_gemm_x3_min_tiles', 'mtl_lowrank_supported', 'mtl_gemm_nt_h2_supported', 'mtl_event_record', 'mtl_stream_wait_event', 'mtl_cmdlist_run', 'mtl_cmdlist_opcode', 'mtl_abi_version',
+_NOT_LAUNCHES = {'mtl_lstm_layer_supported', 'mtl_gemm_x3_min_tiles', 'mtl_event_record', 'mtl_stream_wait_event', 'mtl_cmdlist_run', 'mtl_cmdlist_opcode', 'mtl_abi_version',
                  'mtl_attn_supported', 'mtl_gemm_f32_ex_route', 'mtl_levenshtein_u32', 'mtl_layernorm_bwd_g_waves'}
 
 
@@ -139,11 +139,6 @@ def classify(lib, name, a, conv_mode, wgrad_x3_dense):
                 'gemm16_kernel<...>' if small else 'gemm_kernel<...> (+ splitk_reduce_kernel)')
     if name == 'mtl_gemm_h2_tb':
         return 'gemm_h2', 2.0 * a[2] * a[3] * a[4] * a[18], 'flop', 'gemm_x3_kernel<.,.,.,BM,2> (two fp16 pieces)'
-    if name == 'mtl_gemm_nt_h2':
-        return 'gemm_h2', 2.0 * a[1] * a[2] * a[3], 'flop', 'gemm_nt_h2_kernel (+ gemm_h2_reduce_kernel)'
-    if name == 'mtl_lowrank_pair':
-        M, Kin, r, N, n = a[15], a[16], a[17], a[18], a[19]
-        return 'lowrank_pair', 2.0 * M * r * (Kin + N) * n, 'flop', 'lowrank_pair_kernel<RT,SUM>'
     if name == 'mtl_gemm_wgrad_grouped':
         return 'gemm_wgrad_grouped', GROUP_FLOPS.get(int(a[1] or 0)), 'flop', 'gemm16_kernel<true,false,true,4,1,1> (grouped)'
     if name.startswith('mtl_conv3x3_') and 'wprep' not in name:
@@ -266,8 +261,6 @@ def serial_profile(mtl, trainer, model, vocab, tasks, my_tasks, n_tasks, inner, 
         for name, a, e0, e1 in prof.records:
             if name in ('mtl_gemm_f32_ex', 'mtl_gemm_f32_tb'):
                 key = 'gemm ta%d tb%d M%d N%d K%d b%d kb%d rs%d' % (a[1], a[2], a[3], a[4], a[5], a[17], a[26], 1 if a[29] else 0)
-            elif name == 'mtl_lowrank_pair':
-                key = 'pair M%d Kin%d r%d N%d n%d sum%d acc%d' % tuple(a[15:22])
             elif name in ('mtl_attn_fwd', 'mtl_attn_bwd', 'mtl_layernorm_fwd', 'mtl_layernorm_bwd', 'mtl_layernorm_fwd_g', 'mtl_layernorm_bwd_g'):
                 key = name + ' ' + ' '.join(str(v) for v in a if isinstance(v, int) and 0 <= v < 100000)
             else:

@@ -84,12 +84,6 @@ int mtl_gemm_f32_ex_route(int M, int N, int K, int batch, int kbatch, int has_ro
  * variable), set < 0 only queries; returns the previous value. */
 int mtl_gemm_x3_min_tiles(int set);
 
-/* C[M,N] = A[M,K] . B[N,K]^T (+ bias[N]) (gate: C = gate[m][n] > 0 ? C : 0) on two-piece fp16 splits of both operands
- * (3 v_mfma_f32_32x32x16_f16 per 16-deep step, see the *_h2 convolutions below for the arithmetic and for amax_a / amax_b:
- * MTL_AMAX_SLOTS floats each whose maximum bounds max|A|, max|B|).  For the two compute-bound products of the pass: the Linear
- * on the flattened VGG feature map (models/asr/transformer.py:136-140, K = 5120) and its data gradient (B = the transposed
- * weight).  K % 32 == 0, N % 4 == 0, leading dimensions multiples of 4, 16-byte aligned operands.  Few-tile products split K over
- * workgroups (workspace) and finish in a fixed-order reduction kernel. */
 /* Task-batched two-piece fp16 product on the tile engine of csrc/mtl_gemm_x3.hip (256 x 128 x 32 tiles, 8 waves, split interleaved
  * with the MFMAs; 3 v_mfma_f32_32x32x16_f16 per step): for task t < tasks
  *   C_t[M,N] = A_t[M,K] . op(B_t) (+ bias_t[N]) (gate: C = gate_t[m][n] > 0 ? C : 0),   op(B) = B[N,K]^T (transB = 1) or B[K,N] (transB = 0),
@@ -100,11 +94,6 @@ int mtl_gemm_x3_min_tiles(int set);
 int mtl_gemm_h2_tb(void* stream, int transB, int M, int N, int K, const float* A, int lda, const float* amax_a, long sAmaxA,
                    const float* B, int ldb, const float* amax_b, long sAmaxB, float* C, int ldc, const float* bias, const float* gate,
                    int ldg, int tasks, long sAt, long sBt, long sCt, long sBiasT);
-int mtl_gemm_nt_h2_supported(int M, int N, int K);
-long mtl_gemm_nt_h2_workspace(int M, int N, int K);
-int mtl_gemm_nt_h2(void* stream, int M, int N, int K, const float* A, int lda, const float* amax_a, const float* B, int ldb,
-                   const float* amax_b, float* C, int ldc, const float* bias, const float* gate, int ldg, float* workspace,
-                   long workspace_bytes);
 
 /* Grouped weight gradients: ONE launch computes  C_i += A_i^T . B_i  (and rowsum_i += column sums of A_i, nullable) for a whole
  * table of independent products -- all the small dW = dy^T . x of a backward pass (nn.Linear weight + bias gradients,
@@ -121,24 +110,6 @@ typedef struct mtl_wgrad_desc {
     int reserved;
 } mtl_wgrad_desc;
 int mtl_gemm_wgrad_grouped(void* stream, const mtl_wgrad_desc* table_dev, int n_products, int total_tiles);
-
-/* ---- fused low-rank pair: y_z = (x_z . A_z^T) . B_z^T (+ bias_z), z = 0..n-1 (modules/common_layers.py:287-289,303: W_b(W_a x)) ---
- * x_z = x + z*sx (M x Kin, ldx); A_z = A + z*sA (r x Kin, row-major); B_z = B + z*sB (N x r, row-major); bias_z = bias + z*sbias
- * (nullable); t_z = t + z*st (M x r, nullable): the intermediate, stored once for the weight gradient; y_z = y + z*sy (M x N, ldy).
- * sum_over_z: ONE output y (+)= sum_z (x_z . A_z^T) . B_z^T (n <= 3; accum adds to the existing y) -- the backward data path
- * dx = sum_z (dy_z . W_b,z) . W_a,z of the Q / K / V projections when A / B point at TRANSPOSED weight copies (mtl_transpose_batch).
- * r <= 104, r % 4 == 0, Kin % 4 == 0 (mtl_lowrank_supported); x / A / B 16-byte aligned.  The M x r intermediate stays in LDS. */
-int mtl_lowrank_supported(int Kin, int r, int N);
-int mtl_lowrank_pair(void* stream, const float* x, long sx, int ldx, const float* A, long sA, const float* B, long sB,
-                     const float* bias, long sbias, float* t, long st, float* y, long sy, int ldy, int M, int Kin, int r, int N,
-                     int n, int sum_over_z, int accum);
-/* dst_i (cols x rows) = src_i (rows x cols)^T for a DEVICE table of n matrices in one launch */
-typedef struct mtl_transpose_desc {
-    const float* src;
-    float* dst;
-    int rows, cols;
-} mtl_transpose_desc;
-int mtl_transpose_batch(void* stream, const mtl_transpose_desc* table_dev, int n);
 
 /* ---- VGG front-end: models/asr/transformer.py:48-59 (Conv2d 3x3 s1 p1 + ReLU [+ MaxPool2d(2,2)]) ------
  * x_ref is the reference's (B,1,F,T) input; everything downstream is (B,T,F,C). */

@@ -23,9 +23,6 @@ SIGNATURES = {
     'mtl_gemm_f32_ex_route': (I, [I, I, I, I, I, I]),
     'mtl_gemm_x3_min_tiles': (I, [I]),
     'mtl_gemm_wgrad_grouped': (I, [P, P, I, I]),
-    'mtl_lowrank_supported': (I, [I, I, I]),
-    'mtl_lowrank_pair': (I, [P, P, L, I, P, L, P, L, P, L, P, L, P, L, I, I, I, I, I, I, I, I]),
-    'mtl_transpose_batch': (I, [P, P, I]),
     'mtl_conv0_relu_fwd': (I, [P, P, P, P, P, I, I, I, P]),
     'mtl_conv0_wgrad_workspace': (L, []),
     'mtl_conv0_wgrad': (I, [P, P, P, P, P, P, I, I, I]),
@@ -50,9 +47,6 @@ SIGNATURES = {
     'mtl_conv3x3_wgrad_h2': (I, [P, P, P, P, P, P, P, P, P, L, I, I, I, I, I]),
     'mtl_absmax_f32': (I, [P, P, L, P]),
     'mtl_gemm_h2_tb': (I, [P, I, I, I, I, P, I, P, L, P, I, P, L, P, I, P, P, I, I, L, L, L, L]),
-    'mtl_gemm_nt_h2_supported': (I, [I, I, I]),
-    'mtl_gemm_nt_h2_workspace': (L, [I, I, I]),
-    'mtl_gemm_nt_h2': (I, [P, I, I, I, P, I, P, P, I, P, P, I, P, P, I, P, L]),
     'mtl_permute_hc': (I, [P, P, P, I, I, I, I, P]),
     'mtl_layernorm_fwd': (I, [P, P, P, P, P, P, P, P, F, P, P, P, I, I, I, F]),
     'mtl_layernorm_fwd_g': (I, [P, P, P, P, P, P, P, P, F, P, P, P, I, I, I, F, I, L]),
@@ -144,11 +138,6 @@ AMAX_SLOTS = 64 * 32    # MTL_AMAX_FLOATS of include/mtl_hip.h: floats per max|t
 class LnReduceDesc(ctypes.Structure):
     """mtl_ln_reduce_desc of include/mtl_hip.h (40 bytes)"""
     _fields_ = [('part', c_void_p), ('dgamma', c_void_p), ('dbeta', c_void_p), ('dsum', c_void_p), ('nw', c_int), ('d', c_int)]
-
-
-class TransposeDesc(ctypes.Structure):
-    """mtl_transpose_desc of include/mtl_hip.h (24 bytes)"""
-    _fields_ = [('src', c_void_p), ('dst', c_void_p), ('rows', c_int), ('cols', c_int)]
 
 
 class _CmdArg(ctypes.Union):

@@ -252,11 +252,6 @@ class PassEngine:
             raise ValueError('MTL_CONV must be h2, x3 or f32')
         self.conv_x3 = self.conv_mode != 'f32'
         self.conv_h2 = self.conv_mode == 'h2'
-        # rank-r projection pairs W_b(W_a x) as ONE launch forward and ONE backward (intermediate in LDS; the backward reads transposed
-        # weight copies made once per pass).  Parity-green but SLOWER than the two batched GEMMs (40-100 us vs 2 x 8-17 us: one
-        # workgroup per 16-32 rows streams all 400 KB of both weights at the per-CU rate), so opt-in.
-        self.fused_pairs = os.environ.get('MTL_FUSED_PAIRS', '0') == '1'
-        self._tr_tables = {}
         self._ln_pending, self._ln_tables = [], {}
         # the K / V projections of ALL decoder layers' encoder-decoder attention read the same encoder output: one batched launch per
         # low-rank stage forward, five launches backward (after the last decoder layer) instead of 2 + 4 per layer
@@ -330,7 +325,6 @@ class PassEngine:
             # staging of shapes that are gone: rebuilt on demand
             self._wgrad_tables.clear()
             self._ln_tables.clear()
-            self._tr_tables.clear()
             if len(self._stage) > 64:
                 self._stage.clear()
                 self._stage_turn.clear()
@@ -400,44 +394,6 @@ class PassEngine:
         ev = self._events[self._ev_next]
         self._ev_next = (self._ev_next + 1) % len(self._events)
         return ev.cuda_event
-
-    # ---- fused low-rank pairs
-    def pair_ok(self, k_in, n_out):
-        return self.fused_pairs and self.nt == 1 and bool(self.lib.mtl_lowrank_supported(k_in, self.hp.r, n_out))
-
-    def pair(self, x, sx, ldx, A, sA, B, sB, bias, sbias, t, st, y, sy, ldy, M, k_in, n_out, n, sum_z=0, accum=0):
-        check(self.lib.mtl_lowrank_pair(self.stream, x, sx, ldx, A, sA, B, sB, bias, sbias, t, st, y, sy, ldy, M, k_in, self.hp.r, n_out,
-                                        n, sum_z, accum), 'mtl_lowrank_pair')
-
-    def transpose_lowrank_weights(self, theta):
-        """wT[off(name)] = theta[off(name)]^T for every `*_linear_a.weight` / `*_linear_b.weight` (same offsets, so the constant
-        strides between the Q / K / V parameters carry over): what the backward pair product multiplies with.  One launch per pass."""
-        wT = self.buf('wT', (self.L.total,))
-        key = (theta.data_ptr(), wT.data_ptr())
-        ent = self._tr_tables.get(key)
-        if ent is None:
-            names = [n for n in self.L.order if n.endswith('_linear_a.weight') or n.endswith('_linear_b.weight')]
-            table = (_lib.TransposeDesc * max(len(names), 1))()
-            for i, n in enumerate(names):
-                off, shape, _ = self.L.entries[n]
-                table[i].src, table[i].dst = theta.data_ptr() + 4 * off, wT.data_ptr() + 4 * off
-                table[i].rows, table[i].cols = shape[0], shape[1]
-            dev = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8).to(self.device)
-            ent = (dev, len(names))
-            self._tr_tables[key] = ent
-        if ent[1]:
-            check(self.lib.mtl_transpose_batch(self.stream, ent[0].data_ptr(), ent[1]), 'mtl_transpose_batch')
-        return wT
-
-    def _transpose_table(self, src, dst, rows, cols):
-        key = ('tr', src.data_ptr(), dst.data_ptr(), rows, cols)
-        dev = self._tr_tables.get(key)
-        if dev is None:
-            table = (_lib.TransposeDesc * 1)()
-            table[0].src, table[0].dst, table[0].rows, table[0].cols = src.data_ptr(), dst.data_ptr(), rows, cols
-            dev = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8).to(self.device)
-            self._tr_tables[key] = dev
-        return dev.data_ptr()
 
     # ---- grouped weight gradients
     def wgrad(self, dy, x, rows, n_out, k_in, dw, db=None, kind=None):
@@ -679,15 +635,11 @@ class PassEngine:
             a_all = self.buf(tag + names + 'a', (n, R, r))
             b_all = self.buf(tag + names, (n, R, wd))
             sa, sb, sbias = (self._pstride(pre, names, sfx) for sfx in ('_linear_a.weight', '_linear_b.weight', '_linear_b.bias'))
-            if self.pair_ok(d, wd):
-                self.pair(src, 0, d, o(f0 + '_linear_a.weight'), sa, o(f0 + '_linear_b.weight'), sb, o(f0 + '_linear_b.bias'), sbias,
-                          a_all.data_ptr(), rows * r, b_all.data_ptr(), rows * wd, wd, rows, d, wd, n)
-            else:
-                self.gemm(0, 1, rows, r, d, src, d, o(f0 + '_linear_a.weight'), d, a_all.data_ptr(), r, batch=n, sB=(sa, 0),
-                          sC=(R * r, 0), task=(rows * d, sP, rows * r, 0, 0))
-                self.gemm(0, 1, rows, wd, r, a_all.data_ptr(), r, o(f0 + '_linear_b.weight'), r, b_all.data_ptr(), wd,
-                          bias=o(f0 + '_linear_b.bias'), batch=n, sA=(R * r, 0), sB=(sb, 0), sC=(R * wd, 0), sbias=sbias,
-                          task=(rows * r, sP, rows * wd, sP, 0))
+            self.gemm(0, 1, rows, r, d, src, d, o(f0 + '_linear_a.weight'), d, a_all.data_ptr(), r, batch=n, sB=(sa, 0),
+                      sC=(R * r, 0), task=(rows * d, sP, rows * r, 0, 0))
+            self.gemm(0, 1, rows, wd, r, a_all.data_ptr(), r, o(f0 + '_linear_b.weight'), r, b_all.data_ptr(), wd,
+                      bias=o(f0 + '_linear_b.bias'), batch=n, sA=(R * r, 0), sB=(sb, 0), sC=(R * wd, 0), sbias=sbias,
+                      task=(rows * r, sP, rows * wd, sP, 0))
             for i, nm in enumerate(names):
                 self.arena[tag + nm + 'a'], self.arena[tag + nm] = a_all[i], b_all[i]
                 t[nm + 'a'], t[nm] = a_all[i], b_all[i]
@@ -716,12 +668,8 @@ class PassEngine:
         self.arena[tag + 'attn'] = (klen, causal)
         oa = self.buf(tag + 'oa', (Rq, r))
         ob = self.buf(tag + 'ob', (Rq, d))
-        if self.pair_ok(hv, d):
-            self.pair(O.data_ptr(), 0, hv, o('output_linear_a.weight'), 0, o('output_linear_b.weight'), 0, o('output_linear_b.bias'), 0,
-                      oa.data_ptr(), 0, ob.data_ptr(), 0, d, Mq, hv, d, 1)
-        else:
-            self.linear_fwd(O.data_ptr(), Mq, hv, o('output_linear_a.weight'), None, oa.data_ptr(), r)
-            self.linear_fwd(oa.data_ptr(), Mq, r, o('output_linear_b.weight'), o('output_linear_b.bias'), ob.data_ptr(), d)
+        self.linear_fwd(O.data_ptr(), Mq, hv, o('output_linear_a.weight'), None, oa.data_ptr(), r)
+        self.linear_fwd(oa.data_ptr(), Mq, r, o('output_linear_b.weight'), o('output_linear_b.bias'), ob.data_ptr(), d)
         y = self.buf(tag + 'y', (Rq, d))
         xhat = self.buf(tag + 'xhat', (Rq, d))
         rstd = self.buf(tag + 'rstd', (Rq,))
@@ -754,18 +702,10 @@ class PassEngine:
         dz = dzm.data_ptr() if dzm is not None else dzb.data_ptr()          # gradient of the (dropped) sub-layer branch
         doa = self.buf(tag + '_doa', (Rq, r))
         dO = self.buf(tag + '_dO', (Rq, hv))
-        if self.pair_ok(d, hv):
-            wt = lambda n: self._wT + 4 * L.off(pre + n)
-            self.wgrad(dz, oa.data_ptr(), Mq, d, r, g('output_linear_b.weight'), kind=kd + 'ob')
-            # dO = (dz . W_ob) . W_oa  through the transposed copies; doa is stored for the weight gradient of the a-stage
-            self.pair(dz, 0, d, wt('output_linear_b.weight'), 0, wt('output_linear_a.weight'), 0, None, 0, doa.data_ptr(), 0,
-                      dO.data_ptr(), 0, hv, Mq, d, hv, 1)
-            self.wgrad(doa.data_ptr(), O.data_ptr(), Mq, r, hv, g('output_linear_a.weight'), kind=kd + 'oa')
-        else:
-            self.linear_bwd(oa.data_ptr(), dz, Mq, r, d, o('output_linear_b.weight'), g('output_linear_b.weight'),
-                            None, doa.data_ptr(), False, kind=kd + 'ob')
-            self.linear_bwd(O.data_ptr(), doa.data_ptr(), Mq, hv, r, o('output_linear_a.weight'), g('output_linear_a.weight'),
-                            None, dO.data_ptr(), False, kind=kd + 'oa')
+        self.linear_bwd(oa.data_ptr(), dz, Mq, r, d, o('output_linear_b.weight'), g('output_linear_b.weight'),
+                        None, doa.data_ptr(), False, kind=kd + 'ob')
+        self.linear_bwd(O.data_ptr(), doa.data_ptr(), Mq, hv, r, o('output_linear_a.weight'), g('output_linear_a.weight'),
+                        None, dO.data_ptr(), False, kind=kd + 'oa')
         q, k, v = A[tag + 'q'], A[tag + 'k'], A[tag + 'v']
         groups = A[tag + 'groups']
         dfull = {}                                       # gradients of the projected q / k / v, grouped like the forward
@@ -824,10 +764,9 @@ class PassEngine:
                 self.defer(lambda n=n, f0=f0, rows=rows, R=R, a_ptr=a_ptr, d_ptr=d_ptr, sb=sb, sbias=sbias, wd=wd: self.gemm(
                     1, 0, wd, r, rows, d_ptr, wd, a_ptr, r, g(f0 + '_linear_b.weight'), r, flags=ACCUM, batch=n, sA=(R * wd, 0),
                     sB=(R * r, 0), sC=(sb, 0), rowsum=g(f0 + '_linear_b.bias'), srow=sbias, task=(rows * wd, rows * r, sG, 0, sG)))
-            fused = self.pair_ok(wd, d)
-            if not fused:     # da[i] = d[i] . W_b[i]
-                self.gemm(0, 0, rows, r, wd, d_ptr, wd, o(f0 + '_linear_b.weight'), r, da_ptr, r, batch=n, sA=(R * wd, 0),
-                          sB=(sb, 0), sC=(R * r, 0), task=(rows * wd, sP, rows * r, 0, 0))
+            # da[i] = d[i] . W_b[i]
+            self.gemm(0, 0, rows, r, wd, d_ptr, wd, o(f0 + '_linear_b.weight'), r, da_ptr, r, batch=n, sA=(R * wd, 0),
+                      sB=(sb, 0), sC=(R * r, 0), task=(rows * wd, sP, rows * r, 0, 0))
 
             # dW_a[i] += da[i]^T x
             if self.group_wgrads:
@@ -846,13 +785,8 @@ class PassEngine:
             else:
                 dst, accum = dxkv, (dxkv_accum or (dxkv == dxq) or kv_written)
                 kv_written = True
-            if fused:         # dst (+)= sum_i (d[i] . W_b[i]) . W_a[i] in one launch; da[i] stored for the a-stage weight gradients
-                self.pair(d_ptr, rows * wd, wd, self._wT + 4 * L.off(pre + f0 + '_linear_b.weight'), sb,
-                          self._wT + 4 * L.off(pre + f0 + '_linear_a.weight'), sa, None, 0, da_ptr, rows * r, dst, 0, d, rows, wd, d, n,
-                          sum_z=1, accum=1 if accum else 0)
-            else:
-                self.gemm(0, 0, rows, d, r, da_ptr, r, o(f0 + '_linear_a.weight'), d, dst, d, flags=ACCUM if accum else 0,
-                          kbatch=n, sAk=R * r, sBk=sa, task=(rows * r, sP, rows * d, 0, 0))
+            self.gemm(0, 0, rows, d, r, da_ptr, r, o(f0 + '_linear_a.weight'), d, dst, d, flags=ACCUM if accum else 0,
+                      kbatch=n, sAk=R * r, sBk=sa, task=(rows * r, sP, rows * d, 0, 0))
         self.flush_side(0)
 
     # ---- encoder-decoder attention: K / V projections of all decoder layers in one go
@@ -860,7 +794,7 @@ class PassEngine:
         """(layer stride, projection stride) in floats when the K / V low-rank parameters of the decoder layers' encoder_attn blocks
         sit at constant strides in the flat buffer (they do for the reference's module tree), else None."""
         hp, L = self.hp, self.L
-        if not (self.hoist_kv and self.batch_qkv and hp.n_dec >= 2 and not self.fused_pairs and not self.group_wgrads) or hp.dk != hp.dv:
+        if not (self.hoist_kv and self.batch_qkv and hp.n_dec >= 2 and not self.group_wgrads) or hp.dk != hp.dv:
             return None
         plan = None
         for sfx in ('_linear_a.weight', '_linear_b.weight', '_linear_b.bias'):
@@ -1164,7 +1098,6 @@ class PassEngine:
                 for idx, cin, cout in ((2, 64, 64), (5, 64, 128), (7, 128, 128)):
                     spec += [o('conv.%d.weight' % idx, t), wf[idx][t].data_ptr(), wd[idx][t].data_ptr(), cout, cin]
                 check(lib.mtl_conv3x3_wprep_h2_batch(st, 3, *spec), 'wprep')
-        self._wT = self.transpose_lowrank_weights(theta).data_ptr() if (self.fused_pairs and nt == 1) else None
         p1 = self.buf('p1', (Bt, T2, F2, 64))
         am1 = self.buf('am1', (Bt, T2, F2, 64), torch.uint8)
         y5 = self.buf('y5', (Bt, T2, F2, 128))
@@ -1200,31 +1133,20 @@ class PassEngine:
                                      keep_dec)
         pro_done = None
         self.dec0_on_side = bool(self.use_side_stream and self.overlap_dec0 and self.layer_wgrads and not self.group_wgrads
-                                 and not self.fused_pairs and hp.n_dec > 0)
+                                 and hp.n_dec > 0)
         if self.dec0_on_side:
             (d0, a0), pro_done = self.run_on_side(dec_prologue)      # under the input Linear and the encoder
         e0 = self.buf('e0', (nt * Me, d))
         # the encoder's input Linear (5120 -> 512) and its data gradient: 'x3' = one task-batched launch each on the bf16-split engine
         # (exact 3-piece operands, no bounds needed; MTL_IN_LINEAR=x3), 'h2' (default) = one task-batched launch each on two fp16 pieces
-        # (mtl_gemm_h2_tb: the same tile engine with three MFMAs per step), 'h2s' = the per-task split-K kernel of round 2
-        self.in_h2 = h2 and (self.in_linear == 'h2' or (self.in_linear == 'h2s' and bool(lib.mtl_gemm_nt_h2_supported(Me, d, hp.d_in))
-                                                        and bool(lib.mtl_gemm_nt_h2_supported(Me, hp.d_in, d))))
+        # (mtl_gemm_h2_tb: the same tile engine with three MFMAs per step)
+        self.in_h2 = h2 and self.in_linear == 'h2'
         if self.in_h2:      # the two compute-bound products of the pass on fp16 pairs: e0 = p2 . wp^T here, dp2 = de0 . wp in the backward
             am_st = 12 * _lib.AMAX_SLOTS                          # floats between two tasks' bounds
-            if self.in_linear == 'h2':      # ONE task-batched launch on the tile engine of mtl_gemm_x3.hip (per-task bounds by stride)
-                check(lib.mtl_gemm_h2_tb(st, 1, Me, d, hp.d_in, p2.data_ptr(), hp.d_in, am_(6), am_st, wp.data_ptr(), hp.d_in, am_(7),
-                                         am_st if sP else 0, e0.data_ptr(), d, o('encoder.input_linear.bias'), None, 0, nt,
-                                         Me * hp.d_in, d * hp.d_in if sP else 0, Me * d, self.sP), 'mtl_gemm_h2_tb')
-            else:                           # 'h2s': per-task launches of the older split-K kernel (mtl_gemm_h2.hip)
-                wpT = self.buf('wpT_in', (ntw, hp.d_in, d))
-                need = lib.mtl_gemm_nt_h2_workspace(Me, d, hp.d_in)
-                for t in range(ntw):
-                    check(lib.mtl_transpose_batch(st, self._transpose_table(wp[t], wpT[t], d, hp.d_in), 1), 'mtl_transpose_batch')
-                for t in range(nt):
-                    tw = t if sP else 0
-                    check(lib.mtl_gemm_nt_h2(st, Me, d, hp.d_in, p2[t * B:].data_ptr(), hp.d_in, am_(6, t), wp[tw].data_ptr(), hp.d_in,
-                                             am_(7, tw), e0[t * Me:].data_ptr(), d, o('encoder.input_linear.bias', t), None, 0,
-                                             self.scratch(need) if need else None, need), 'mtl_gemm_nt_h2')
+            # ONE task-batched launch on the tile engine of mtl_gemm_x3.hip (per-task bounds by stride)
+            check(lib.mtl_gemm_h2_tb(st, 1, Me, d, hp.d_in, p2.data_ptr(), hp.d_in, am_(6), am_st, wp.data_ptr(), hp.d_in, am_(7),
+                                     am_st if sP else 0, e0.data_ptr(), d, o('encoder.input_linear.bias'), None, 0, nt,
+                                     Me * hp.d_in, d * hp.d_in if sP else 0, Me * d, self.sP), 'mtl_gemm_h2_tb')
         else:
             self.gemm(0, 1, Me, d, hp.d_in, p2.data_ptr(), hp.d_in, wp.data_ptr(), hp.d_in, e0.data_ptr(), d,
                       bias=o('encoder.input_linear.bias'), task=(Me * hp.d_in, d * hp.d_in if sP else 0, Me * d, self.sP, 0))
@@ -1471,18 +1393,11 @@ class PassEngine:
         if self.in_h2:
             for t in range(nt):
                 check(lib.mtl_absmax_f32(st, de0[t * Me:].data_ptr(), Me * d, am_(8, t)), 'mtl_absmax_f32')
-            if self.in_linear == 'h2':      # dp2 = (de0 . wp) gated by p2 > 0, straight from the un-transposed weight, all tasks in one launch
-                am_st = 12 * _lib.AMAX_SLOTS
-                check(lib.mtl_gemm_h2_tb(st, 0, Me, hp.d_in, d, de0.data_ptr(), d, am_(8), am_st, A['wp_in'].data_ptr(), hp.d_in, am_(7),
-                                         am_st if sP else 0, dp2.data_ptr(), hp.d_in, None, p2.data_ptr(), hp.d_in, nt, Me * d,
-                                         d * hp.d_in if sP else 0, Me * hp.d_in, 0), 'mtl_gemm_h2_tb')
-            else:
-                need = lib.mtl_gemm_nt_h2_workspace(Me, hp.d_in, d)
-                for t in range(nt):
-                    tw = t if sP else 0
-                    check(lib.mtl_gemm_nt_h2(st, Me, hp.d_in, d, de0[t * Me:].data_ptr(), d, am_(8, t), A['wpT_in'][tw].data_ptr(), d,
-                                             am_(7, tw), dp2[t * B:].data_ptr(), hp.d_in, None, p2[t * B:].data_ptr(), hp.d_in,
-                                             self.scratch(need) if need else None, need), 'mtl_gemm_nt_h2')
+            # dp2 = (de0 . wp) gated by p2 > 0, straight from the un-transposed weight, all tasks in one launch
+            am_st = 12 * _lib.AMAX_SLOTS
+            check(lib.mtl_gemm_h2_tb(st, 0, Me, hp.d_in, d, de0.data_ptr(), d, am_(8), am_st, A['wp_in'].data_ptr(), hp.d_in, am_(7),
+                                     am_st if sP else 0, dp2.data_ptr(), hp.d_in, None, p2.data_ptr(), hp.d_in, nt, Me * d,
+                                     d * hp.d_in if sP else 0, Me * hp.d_in, 0), 'mtl_gemm_h2_tb')
         else:
             self.gemm(0, 0, Me, hp.d_in, d, de0.data_ptr(), d, A['wp_in'].data_ptr(), hp.d_in, dp2.data_ptr(), hp.d_in,
                       gate=p2.data_ptr(), ldg=hp.d_in, task=(Me * d, d * hp.d_in if sP else 0, Me * hp.d_in, 0, 0))

@@ -419,7 +419,7 @@ class TransientTrainer():
         if not self.batch_tasks or len(task_batches) < 2 or use_graphs:
             return False
         eng = model.engines[0]
-        if not eng.fused_attn or eng.fused_pairs or eng.group_wgrads or eng.after_conv_hook is not None:
+        if not eng.fused_attn or eng.group_wgrads or eng.after_conv_hook is not None:
             return False
         shape = tuple(task_batches[0][0].shape)
         return all(tuple(tb[0].shape) == shape and tb[0].dim() == 4 for tb in task_batches) and val_batch[0].dim() == 4

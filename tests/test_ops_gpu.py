@@ -173,65 +173,6 @@ def test_gemm_k_batching_and_row_sums(L):
                              1, 1, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, Wview, 0, None, 0, 0, 0) == -22      # row sums need transA
 
 
-@pytest.mark.parametrize('M,Kin,r,N,n', [(808, 512, 100, 512, 3), (2000, 512, 100, 512, 3), (37, 128, 100, 128, 2), (101, 512, 16, 200, 1),
-                                         (250, 128, 100, 136, 1)])
-def test_fused_low_rank_pair(L, M, Kin, r, N, n):
-    """mtl_lowrank_pair: y_z = (x . A_z^T) . B_z^T + b_z for z strided pairs in one launch (the Q / K / V projections with their
-    parameters at a constant stride in a flat buffer), the stored intermediate, and the SUM mode on transposed weight copies
-    (mtl_transpose_batch) = the backward data path dx += sum_z (dy_z . W_b,z) . W_a,z; against torch, bitwise repeatable."""
-    import mtl_amd
-    g = torch.Generator().manual_seed(M + Kin + r + N + n)
-    stride = r * Kin + N * r + N + 40                                        # A_z, B_z, bias_z and something else, like the flat theta
-    theta = torch.randn(n * stride, generator=g) * 0.1
-    Az = [theta[z * stride: z * stride + r * Kin].view(r, Kin) for z in range(n)]
-    Bz = [theta[z * stride + r * Kin: z * stride + r * Kin + N * r].view(N, r) for z in range(n)]
-    bz = [theta[z * stride + r * Kin + N * r: z * stride + r * Kin + N * r + N] for z in range(n)]
-    x = torch.randn(M, Kin, generator=g)
-    dth, dx_ = dev(theta), dev(x)
-    outs = []
-    for _ in range(2):
-        t = torch.full((n, M, r), float('nan')).cuda()
-        y = torch.full((n, M, N), float('nan')).cuda()
-        assert L.mtl_lowrank_pair(st(), dx_.data_ptr(), 0, Kin, dth.data_ptr(), stride, dth.data_ptr() + 4 * r * Kin, stride,
-                                  dth.data_ptr() + 4 * (r * Kin + N * r), stride, t.data_ptr(), M * r, y.data_ptr(), M * N, N, M, Kin, r, N,
-                                  n, 0, 0) == 0
-        outs.append((t.cpu(), y.cpu()))
-    for z in range(n):
-        t_ref = x.double() @ Az[z].double().t()
-        assert rel(outs[0][0][z], t_ref) < 2e-6
-        assert rel(outs[0][1][z], t_ref @ Bz[z].double().t() + bz[z].double()) < 3e-6
-    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
-    # backward data path: dx0 + sum_z (dy_z . B_z) . A_z  through transposed copies laid out at the SAME offsets as the originals
-    dy = torch.randn(n, M, N, generator=g)
-    dx0 = torch.randn(M, Kin, generator=g)
-    wT = torch.zeros_like(dth)
-    table = (mtl_amd._lib.TransposeDesc * (2 * n))()
-    for z in range(n):
-        oa, ob = z * stride, z * stride + r * Kin
-        table[2 * z].src, table[2 * z].dst, table[2 * z].rows, table[2 * z].cols = dth.data_ptr() + 4 * oa, wT.data_ptr() + 4 * oa, r, Kin
-        table[2 * z + 1].src, table[2 * z + 1].dst = dth.data_ptr() + 4 * ob, wT.data_ptr() + 4 * ob
-        table[2 * z + 1].rows, table[2 * z + 1].cols = N, r
-    tdev = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8).cuda()
-    assert L.mtl_transpose_batch(st(), tdev.data_ptr(), 2 * n) == 0
-    wTc = wT.cpu()
-    assert torch.equal(wTc[:r * Kin].view(Kin, r), Az[0].t().contiguous()) and torch.equal(wTc[r * Kin: r * Kin + N * r].view(r, N), Bz[0].t().contiguous())
-    if N % 4 == 0:
-        ddy = dev(dy)
-        ref = dx0.double() + sum((dy[z].double() @ Bz[z].double()) @ Az[z].double() for z in range(n))
-        res = []
-        for _ in range(2):
-            dxo, da = dev(dx0.clone()), torch.full((n, M, r), float('nan')).cuda()
-            # x := dy_z (M x N), "A" := B_z^T (r x N) at the b-offset of wT, "B" := A_z^T (Kin x r) at the a-offset of wT
-            assert L.mtl_lowrank_pair(st(), ddy.data_ptr(), M * N, N, wT.data_ptr() + 4 * r * Kin, stride, wT.data_ptr(), stride, None, 0,
-                                      da.data_ptr(), M * r, dxo.data_ptr(), 0, Kin, M, N, r, Kin, n, 1, 1) == 0
-            res.append((dxo.cpu(), da.cpu()))
-        assert rel(res[0][0], ref) < 3e-6 and torch.equal(res[0][0], res[1][0])
-        for z in range(n):
-            assert rel(res[0][1][z], dy[z].double() @ Bz[z].double()) < 2e-6
-    assert L.mtl_lowrank_pair(st(), dx_.data_ptr(), 0, Kin, dth.data_ptr(), stride, dth.data_ptr(), stride, None, 0, None, 0,
-                              dx_.data_ptr(), 0, N, M, Kin, 108, N, 1, 0, 0) == -22                      # rank beyond the LDS tile
-
-
 def test_grouped_weight_gradients(L):
     """mtl_gemm_wgrad_grouped: ONE launch for a table of independent dW_i += dy_i^T x_i (+ db_i += colsum(dy_i)) products of
     different shapes -- every small weight gradient of a backward pass -- against torch, bitwise repeatable"""
@@ -969,50 +910,6 @@ def test_spectrogram_front_end_matches_oracle(L, tmp_path):
         w.writeframes((np.clip(y, -1, 1) * 32767).astype('<i2').tobytes())
     yw = mtl_amd.load_wav_pcm16(p)
     assert abs(yw - np.clip(y, -1, 1)).max() < 1e-4 and rel(fe(yw).cpu(), frontend.parse_audio(yw)) < 2e-5
-
-
-@pytest.mark.parametrize('M,N,K,gate,bias', [(2000, 512, 5120, False, True), (300, 640, 512, True, False), (77, 132, 96, True, True),
-                                             (1000, 5120, 512, True, False)])
-def test_gemm_nt_two_piece_fp16(L, M, N, K, gate, bias):
-    """C = A . B^T (+ bias) (gated) on fp16 pairs (mtl_gemm_nt_h2; split-K with a fixed-order reduction for few-tile products):
-    against fp64 no less accurate than 2x the exact-fp32 MFMA GEMM of this library, bitwise reproducible, any magnitude."""
-    g = torch.Generator().manual_seed(M + N + K)
-    A = torch.randn(M, K, generator=g) * 3e-4
-    A[0, 0] = 0.05                                         # outlier far above the bulk
-    B = torch.randn(N, K, generator=g) * 7.0
-    bv = torch.randn(N, generator=g) * 1e-3 if bias else None
-    gt = torch.randn(M, N, generator=g) if gate else None
-    want = A.double() @ B.double().t()
-    if bias:
-        want = want + bv.double()
-    if gate:
-        want = want * (gt > 0).double()
-    dA, dB = dev(A), dev(B)
-    dbv, dgt = (dev(bv) if bias else None), (dev(gt) if gate else None)
-    S = 2048
-    aa = torch.zeros(S).cuda()
-    ab = torch.zeros(S).cuda()
-    assert L.mtl_absmax_f32(st(), dA.data_ptr(), A.numel(), aa.data_ptr()) == 0
-    assert L.mtl_absmax_f32(st(), dB.data_ptr(), B.numel(), ab.data_ptr()) == 0
-    assert float(aa.max()) == float(A.abs().max()) and float(ab.max()) == float(B.abs().max())
-    assert L.mtl_gemm_nt_h2_supported(M, N, K) == 1 and L.mtl_gemm_nt_h2_supported(M, N, K + 8) == 0
-    need = L.mtl_gemm_nt_h2_workspace(M, N, K)
-    ws = torch.empty(need // 4 + 4).cuda()
-    C, C2 = torch.full((M, N), 7.0).cuda(), torch.empty(M, N).cuda()
-    args = lambda out: (st(), M, N, K, dA.data_ptr(), K, aa.data_ptr(), dB.data_ptr(), K, ab.data_ptr(), out.data_ptr(), N,
-                        dbv.data_ptr() if bias else None, dgt.data_ptr() if gate else None, N, ws.data_ptr(), need)
-    assert L.mtl_gemm_nt_h2(*args(C)) == 0
-    assert L.mtl_gemm_nt_h2(*args(C2)) == 0
-    assert torch.equal(C, C2)
-    F32 = torch.empty(M, N).cuda()
-    need32 = 64 << 20
-    ws32 = torch.empty(need32 // 4).cuda()
-    assert L.mtl_gemm_f32(st(), 0, 1, M, N, K, 1.0, dA.data_ptr(), K, dB.data_ptr(), K, F32.data_ptr(), N, dbv.data_ptr() if bias else None,
-                          dgt.data_ptr() if gate else None, N, 0, 1, 1, 0, 0, 0, 0, 0, 0, 0, ws32.data_ptr(), need32) == 0
-    e2, e32 = rel(C.double().cpu(), want), rel(F32.double().cpu(), want)
-    assert e2 < 2.0 * e32 + 1e-30 and e2 < 1e-6, (e2, e32)
-    if need:
-        assert L.mtl_gemm_nt_h2(*(args(C)[:-1] + (need - 4,))) != 0       # short workspace is refused
 
 
 @pytest.mark.parametrize('transB,M,N,K,tasks,shared,gate,bias', [(1, 300, 512, 640, 3, True, False, True), (0, 300, 640, 512, 3, True, True, False),
