@@ -80,7 +80,7 @@ def make_args(k, lr=1e-4, meta_lr=1e-4):
 # ------------------------------------------------------------------------------------------------------------------
 # launch-level profiling: every library call that launches kernels, bracketed with HIP events on the stream it is given
 # ------------------------------------------------------------------------------------------------------------------
-_NOT_LAUNCHES = {'mtl_lstm_layer_supported', 'mtl_gemm_x3_min_tiles', 'mtl_event_record', 'mtl_stream_wait_event', 'mtl_cmdlist_run', 'mtl_cmdlist_opcode', 'mtl_abi_version',
+_NOT_LAUNCHES = {'mtl_lstm_layer_supported', 'mtl_lstm_stack_supported', 'mtl_lstm_stack_scratch', 'mtl_gemm_x3_min_tiles', 'mtl_event_record', 'mtl_stream_wait_event', 'mtl_cmdlist_run', 'mtl_cmdlist_opcode', 'mtl_abi_version',
                  'mtl_attn_supported', 'mtl_gemm_f32_ex_route', 'mtl_levenshtein_u32', 'mtl_layernorm_bwd_g_waves'}
 
 
@@ -175,6 +175,9 @@ def classify(lib, name, a, conv_mode, wgrad_x3_dense):
     if name in ('mtl_lstm_layer_fwd', 'mtl_lstm_layer_bwd'):
         T, B, H = a[-4:-1]             # the recurrent products of all T steps (forward h W_hh^T, backward dG W_hh)
         return name[4:], 2.0 * T * B * 4 * H * H, 'flop', name[4:] + '_kernel<H/8> (persistent: one launch per layer and direction)'
+    if name in ('mtl_lstm_stack_fwd', 'mtl_lstm_stack_bwd'):
+        T, B, H, NL = a[-5:-1]         # recurrent products of every layer + the input products of the layers above the first
+        return name[4:], 2.0 * T * B * 4 * H * H * (2 * NL - 1), 'flop', name[4:] + '_kernel<H/8> (persistent wavefront: one launch per direction for all layers)'
     if name in ('mtl_lstm_cell_fwd', 'mtl_lstm_cell_bwd'):
         B, H = a[-2:]
         return name[4:], 4.0 * B * H * (15 if name.endswith('fwd') else 17), 'byte', name[4:] + '_kernel'

@@ -348,8 +348,8 @@ int mtl_lstm_cell_bwd(void* stream, const float* dh_up, const unsigned char* mas
  *             mask != NULL: u8 keep flags, scale mscale) -- exactly what T calls of the recurrent product + mtl_lstm_cell_fwd produce.
  *   backward: dx_up (T B, H) gradient of xout (may be NULL), writes dG (T B, 4H) = gradient of the gate pre-activations of every step
  *             (truncated BPTT: no gradient into the incoming state) -- what T calls of mtl_lstm_cell_bwd + the dh_rec product produce.
- * workspace: mtl_lstm_layer_workspace() bytes of device memory, 256-byte aligned (arrival counter + error word -- u32 [1] != 0 after a
- * timed-out wait -- followed by the backward's partial buffers).
+ * workspace: mtl_lstm_layer_workspace() bytes of device memory, 256-byte aligned (1 KB header: arrival counters, one per layer, and the
+ * error word -- u32 [1] != 0 after a timed-out wait -- followed by the backward's partial buffers).
  * mtl_lstm_layer_supported: 1 <= B <= 32 and H in {128, 256, 384, 512}; other shapes take the per-step calls. */
 int mtl_lstm_layer_supported(int B, int H);
 long mtl_lstm_layer_workspace(void);
@@ -357,6 +357,29 @@ int mtl_lstm_layer_fwd(void* stream, const float* gx, const float* w_hh, const f
                        float* xout, const unsigned char* mask, float mscale, int T, int B, int H, void* workspace);
 int mtl_lstm_layer_bwd(void* stream, const float* dx_up, const unsigned char* mask, float mscale, const float* w_hh, const float* acts,
                        const float* call, float* dG, int T, int B, int H, void* workspace);
+
+/* The whole layer stack as ONE wavefront launch per direction (csrc/mtl_lstm.hip; lm/model/rnn_model.py:20 nn.LSTM(ninp, nhid, nlayers,
+ * dropout=...)): layer l runs one step behind layer l - 1 instead of after it.  `layers` is a HOST struct of device pointers, one
+ * entry per layer (read during the call; not recordable in a command list): w_ih/b_ih of layer 0 are not used (its input
+ * contributions come as gx0 = x W_ih0^T + b_ih0 over all T steps), layers >= 1 must have input width H; hall/call/acts/xout/mask/dG
+ * as in the single-layer calls (mask[l]: the dropout on layer l's output, or NULL).
+ *   forward : fills hall, call, acts, xout of every layer.
+ *   backward: fills dG of every layer from dx_up (gradient w.r.t. the top layer's dropped output); scratch = mtl_lstm_stack_scratch()
+ *             bytes (the per-step partial sums handed from a layer to the one below).
+ * Results equal the per-layer calls up to the summation order of the input contribution (formed per step instead of by one product).
+ * mtl_lstm_stack_supported: the single-layer limits, NL <= 4 and NL * H / 8 <= 192 workgroups (all resident). */
+#define MTL_LSTM_MAX_LAYERS 4
+typedef struct mtl_lstm_stack {
+    const float *w_ih[MTL_LSTM_MAX_LAYERS], *b_ih[MTL_LSTM_MAX_LAYERS], *w_hh[MTL_LSTM_MAX_LAYERS], *b_hh[MTL_LSTM_MAX_LAYERS];
+    float *hall[MTL_LSTM_MAX_LAYERS], *call[MTL_LSTM_MAX_LAYERS], *acts[MTL_LSTM_MAX_LAYERS], *xout[MTL_LSTM_MAX_LAYERS], *dG[MTL_LSTM_MAX_LAYERS];
+    const unsigned char* mask[MTL_LSTM_MAX_LAYERS];
+} mtl_lstm_stack;
+int mtl_lstm_stack_supported(int B, int H, int NL);
+long mtl_lstm_stack_scratch(int T, int B, int H, int NL);
+int mtl_lstm_stack_fwd(void* stream, const mtl_lstm_stack* layers, const float* gx0, float mscale, int T, int B, int H, int NL,
+                       void* workspace);
+int mtl_lstm_stack_bwd(void* stream, const mtl_lstm_stack* layers, const float* dx_up, float mscale, float* scratch, int T, int B, int H,
+                       int NL, void* workspace);
 
 
 /* ---- raw byte helpers on a stream (so that a whole task body consists of library calls only and can be replayed) ---- */

@@ -22,6 +22,9 @@ namespace {
 
 constexpr int LU = 8;                        // hidden units per workgroup
 constexpr unsigned SPIN_LIMIT = 1u << 22;    // polls before a wait gives up (~seconds): sets the error word
+constexpr int HDR = 256;                     // workspace header in 4-byte words: arrival counters (one per layer, 128 bytes apart), error word [1]
+constexpr int MAXL = MTL_LSTM_MAX_LAYERS;
+constexpr long PBUF = 64L * 32 * 512;        // largest [nwg][B][H] partial buffer, floats
 
 struct LstmP {
     const float *gx, *whh, *bhh;
@@ -179,7 +182,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
             for (int c = 0; c < JT; ++c) w[r][c] = q[c];
         }
     }
-    float* P = reinterpret_cast<float*>(p.sync) + 64;         // two buffers of [nwg][B][H] behind the 256-byte header
+    float* P = reinterpret_cast<float*>(p.sync) + HDR;        // two buffers of [nwg][B][H] behind the header
     const long pbuf = (long)nwg * B * H;
     const bool cell = tid < B * LU;
     const int cb = tid / LU, cu = tid % LU, cj = j0 + cu;
@@ -258,6 +261,286 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Layer stack as ONE wavefront launch per direction: grid = NL x (H / 8) workgroups, workgroup (l, w) owns units [8 w, 8 w + 8) of
+// layer l.  Layer l step t needs layer l step t - 1 (its own counter) and layer l - 1 step t (the lower layer's counter), so the
+// layers run one step apart instead of one after the other: ~T + NL - 1 hand-offs per pass instead of NL T.
+//   forward:  layers >= 1 keep their 32 rows of W_ih in registers next to W_hh and form the input contribution of step t from the
+//             lower layer's (dropped) output themselves -- BEFORE they wait for their own layer's h_t, i.e. in the shadow of the
+//             hand-off; layer 0 takes its input contributions from one product over all T steps (gx0), as before.
+//   backward: layer l >= 1 also multiplies its columns of dG_t with its rows of W_ih: a second row-split partial (the gradient into
+//             the lower layer's output) -- computed after the arrival that publishes the recurrent partial, again in the shadow of
+//             the hand-off, and acknowledged by the next arrival.  The upper layer is not gated by the lower one and may run ahead,
+//             so these partials are buffered for ALL T steps ([NL-1][T][nwg][B][H], p.p2).
+struct StackP {
+    const float* gx0;
+    const float *wih[MAXL], *bih[MAXL], *whh[MAXL], *bhh[MAXL];
+    float *hall[MAXL], *call[MAXL], *acts[MAXL], *xout[MAXL], *dG[MAXL];
+    const uint8_t* mask[MAXL];
+    const float* dx_up;
+    float* p2;
+    float mscale;
+    int T, B, H, NL;
+    unsigned* sync;
+};
+
+__device__ __forceinline__ void grid_wait2(unsigned* ctr, unsigned* err, unsigned target) {
+    if (threadIdx.x == 0) {
+        unsigned spins = 0;
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            if (++spins > SPIN_LIMIT) {
+                __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+template <int KC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_stack_fwd_kernel(StackP p) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int B = p.B, H = 8 * KC, T = p.T;
+    float* hs = sm;                     // [B][H]: the lower layer's output, then this layer's previous state
+    float* red = sm + B * H;            // [16 chunks][B][32 rows]
+    constexpr int KH = KC / 2;
+    const int tid = threadIdx.x, rp = tid & 15, kc = tid >> 4;
+    const unsigned nwg = H / LU;
+    const int l = blockIdx.x / nwg, j0 = (blockIdx.x % nwg) * LU;
+    unsigned* own = p.sync + 32 * l;
+    unsigned* low = p.sync + 32 * (l > 0 ? l - 1 : 0);
+    unsigned* err = p.sync + 1;
+    float w[2][KH], wi[2][KH];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int r = 2 * rp + q;
+        const long ro = (long)((r >> 3) * H + j0 + (r & 7)) * H + kc * KH;
+#pragma unroll
+        for (int i = 0; i < KH; i += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(p.whh[l] + ro + i);
+            w[q][i] = v.x, w[q][i + 1] = v.y, w[q][i + 2] = v.z, w[q][i + 3] = v.w;
+            const float4 u = l > 0 ? *reinterpret_cast<const float4*>(p.wih[l] + ro + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+            wi[q][i] = u.x, wi[q][i + 1] = u.y, wi[q][i + 2] = u.z, wi[q][i + 3] = u.w;
+        }
+    }
+    const bool cell = tid < B * LU;
+    const int cb = tid / LU, cu = tid % LU, cj = j0 + cu;
+    float bias[4] = {0.f, 0.f, 0.f, 0.f}, bias_x[4] = {0.f, 0.f, 0.f, 0.f};
+    float c_prev = 0.f;
+    float* hall = p.hall[l];
+    float* call = p.call[l];
+    float* acts = p.acts[l];
+    float* xout = p.xout[l];
+    const uint8_t* mask = p.mask[l];
+    const float* xlow = l > 0 ? p.xout[l - 1] : nullptr;
+    if (cell) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            bias[g] = p.bhh[l][g * H + cj];
+            if (l > 0) bias_x[g] = p.bih[l][g * H + cj];
+        }
+        c_prev = call[(long)cb * H + cj];
+    }
+    // one pass of the B x H operand in `hs` against this thread's two row chunks -> red
+    auto product = [&](const float (&ww)[2][KH]) {
+#pragma unroll 1
+        for (int b = 0; b < B; ++b) {
+            const float* hb = hs + b * H + kc * KH;
+            float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < KH; i += 4) {
+                const float4 hv = *reinterpret_cast<const float4*>(hb + i);
+                a0 = fmaf(ww[0][i], hv.x, a0);
+                a1 = fmaf(ww[1][i], hv.x, a1);
+                a0 = fmaf(ww[0][i + 1], hv.y, a0);
+                a1 = fmaf(ww[1][i + 1], hv.y, a1);
+                a0 = fmaf(ww[0][i + 2], hv.z, a0);
+                a1 = fmaf(ww[1][i + 2], hv.z, a1);
+                a0 = fmaf(ww[0][i + 3], hv.w, a0);
+                a1 = fmaf(ww[1][i + 3], hv.w, a1);
+            }
+            *reinterpret_cast<float2*>(red + (kc * B + b) * 32 + 2 * rp) = make_float2(a0, a1);
+        }
+    };
+#pragma unroll 1
+    for (int t = 0; t < T; ++t) {
+        float gxv[4] = {0.f, 0.f, 0.f, 0.f};                    // input contributions W_ih x_t + b_ih of this thread's cell
+        if (l == 0) {
+            if (cell) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) gxv[g] = p.gx0[((long)t * B + cb) * 4 * H + g * H + cj];
+            }
+        } else {
+            grid_wait2(low, err, (unsigned)(t + 1) * nwg);      // the lower layer has published its output of step t
+            const float* src = xlow + (long)t * B * H;
+            for (int i = tid; i < B * H / 2; i += 256) reinterpret_cast<float2*>(hs)[i] = load_shared2(src + 2 * i);
+            __syncthreads();
+            product(wi);
+            __syncthreads();
+            if (cell) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) s += red[(q * B + cb) * 32 + g * 8 + cu];
+                    gxv[g] = s + bias_x[g];
+                }
+            }
+        }
+        if (t > 0) grid_wait2(own, err, (unsigned)t * nwg);     // every workgroup of this layer has published h_t
+        const float* src = hall + (long)t * B * H;
+        for (int i = tid; i < B * H / 2; i += 256) reinterpret_cast<float2*>(hs)[i] = load_shared2(src + 2 * i);
+        __syncthreads();
+        product(w);
+        __syncthreads();
+        if (cell) {
+            const long row = (long)t * B + cb;
+            float pre[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float s = 0.f;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) s += red[(q * B + cb) * 32 + g * 8 + cu];
+                pre[g] = gxv[g] + (s + bias[g]);
+            }
+            const float ai = 1.f / (1.f + expf(-pre[0])), af = 1.f / (1.f + expf(-pre[1])), ag = tanhf(pre[2]),
+                        ao = 1.f / (1.f + expf(-pre[3]));
+            const float cn = af * c_prev + ai * ag;
+            const float hn = ao * tanhf(cn);
+            float* ac = acts + row * 4 * H + cj;
+            ac[0] = ai, ac[H] = af, ac[2 * H] = ag, ac[3 * H] = ao;
+            const long e = row * H + cj;
+            call[e + (long)B * H] = cn;
+            store_shared(hall + e + (long)B * H, hn);
+            store_shared(xout + e, mask ? (mask[e] ? hn * p.mscale : 0.f) : hn);      // read by the layer above
+            c_prev = cn;
+        }
+        grid_arrive(own);      // also after the last step: the layer above waits for it
+    }
+}
+
+template <int KC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_stack_bwd_kernel(StackP p) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int B = p.B, H = 8 * KC, T = p.T, NL = p.NL;
+    constexpr int JT = KC > 32 ? 2 : 1;
+    float* dgs = sm;                              // [B][32]
+    const int tid = threadIdx.x;
+    const unsigned nwg = H / LU;
+    const int l = blockIdx.x / nwg, wg = blockIdx.x % nwg, j0 = wg * LU;
+    unsigned* own = p.sync + 32 * l;
+    unsigned* up = p.sync + 32 * (l + 1 < NL ? l + 1 : l);
+    unsigned* err = p.sync + 1;
+    const int jt = tid * JT;
+    const bool active = jt < H;
+    float w[32][JT], wi[32][JT];
+    if (active) {
+#pragma unroll
+        for (int r = 0; r < 32; ++r) {
+            const long ro = (long)((r >> 3) * H + j0 + (r & 7)) * H + jt;
+#pragma unroll
+            for (int c = 0; c < JT; ++c) {
+                w[r][c] = p.whh[l][ro + c];
+                wi[r][c] = l > 0 ? p.wih[l][ro + c] : 0.f;
+            }
+        }
+    }
+    const long pbuf = (long)nwg * B * H;
+    float* P1 = reinterpret_cast<float*>(p.sync) + HDR + (long)l * 2 * PBUF;       // this layer's recurrent partials, two parities
+    const float* P2r = p.p2 + (long)l * T * pbuf;                                      // partials from the layer above (l < NL - 1)
+    float* P2w = l > 0 ? p.p2 + (long)(l - 1) * T * pbuf + (long)wg * B * H : nullptr; // partials for the layer below
+    const bool cell = tid < B * LU;
+    const int cb = tid / LU, cu = tid % LU, cj = j0 + cu;
+    const float* acts = p.acts[l];
+    const float* call = p.call[l];
+    float* dG = p.dG[l];
+    const uint8_t* mask = p.mask[l];
+    const bool top = l == NL - 1;
+    float dc_next = 0.f;
+    // partial product of this workgroup's 32 columns of dG_t (in dgs) with its 32 rows of a weight matrix, all H outputs
+    auto partial = [&](const float (&ww)[32][JT], float* out) {
+#pragma unroll 1
+        for (int b = 0; b < B; ++b) {
+            const float* gb = dgs + b * 32;
+            float a[JT];
+#pragma unroll
+            for (int c = 0; c < JT; ++c) a[c] = 0.f;
+#pragma unroll
+            for (int r = 0; r < 32; r += 4) {
+                const float4 gv = *reinterpret_cast<const float4*>(gb + r);
+#pragma unroll
+                for (int c = 0; c < JT; ++c) {
+                    a[c] = fmaf(gv.x, ww[r][c], a[c]);
+                    a[c] = fmaf(gv.y, ww[r + 1][c], a[c]);
+                    a[c] = fmaf(gv.z, ww[r + 2][c], a[c]);
+                    a[c] = fmaf(gv.w, ww[r + 3][c], a[c]);
+                }
+            }
+            if (JT == 2) {
+                const unsigned long long u = (unsigned long long)__builtin_bit_cast(unsigned, a[0]) |
+                                             ((unsigned long long)__builtin_bit_cast(unsigned, a[JT - 1]) << 32);
+                __hip_atomic_store(reinterpret_cast<unsigned long long*>(out + (long)b * H), u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                store_shared(out + (long)b * H, a[0]);
+            }
+        }
+    };
+    auto gather = [&](const float* q) {            // fixed-order sum of the nwg partials of this thread's (b, unit)
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll 16
+        for (unsigned wq = 0; wq < nwg; wq += 2) {
+            s0 += __hip_atomic_load(q + (long)wq * B * H, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s1 += __hip_atomic_load(q + (long)(wq + 1) * B * H, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return s0 + s1;
+    };
+#pragma unroll 1
+    for (int t = T - 1; t >= 0; --t) {
+        float dh_rec = 0.f, dh_up = 0.f, ai = 0.f, af = 0.f, ag = 0.f, ao = 0.f, cc = 0.f, cprev = 0.f, keep = 1.f;
+        if (cell) {
+            const long row = (long)t * B + cb;
+            const long e = row * H + cj;
+            keep = mask ? (mask[e] ? p.mscale : 0.f) : 1.f;
+            if (top) dh_up = p.dx_up[e];
+            const float* ac = acts + row * 4 * H + cj;
+            ai = ac[0], af = ac[H], ag = ac[2 * H], ao = ac[3 * H];
+            cc = call[e + (long)B * H], cprev = call[e];
+        }
+        if (!top) {
+            // the layer above acknowledges its input-gradient partial of step t with the arrival of step t - 1 (the final one for t <= 1)
+            const int k = T - t + 1 < T ? T - t + 1 : T;
+            grid_wait2(up, err, (unsigned)k * nwg);
+            if (cell) dh_up = gather(P2r + (long)t * pbuf + (long)cb * H + cj);
+        }
+        dh_up *= keep;
+        if (t < T - 1) {
+            grid_wait2(own, err, (unsigned)(T - 1 - t) * nwg);
+            if (cell) dh_rec = gather(P1 + ((t + 1) & 1) * pbuf + (long)cb * H + cj);
+        }
+        if (cell) {
+            const long row = (long)t * B + cb;
+            const float dh = dh_up + dh_rec;
+            const float tc = tanhf(cc);
+            const float dc = dc_next + dh * ao * (1.f - tc * tc);
+            const float di = dc * ag * ai * (1.f - ai), df = dc * cprev * af * (1.f - af), dg_ = dc * ai * (1.f - ag * ag),
+                        do_ = dh * tc * ao * (1.f - ao);
+            float* dg = dG + row * 4 * H + cj;
+            dg[0] = di, dg[H] = df, dg[2 * H] = dg_, dg[3 * H] = do_;
+            float* q = dgs + cb * 32 + cu;
+            q[0] = di, q[8] = df, q[16] = dg_, q[24] = do_;
+            dc_next = dc * af;
+        }
+        __syncthreads();
+        if (t > 0) {
+            if (active) partial(w, P1 + (t & 1) * pbuf + (long)wg * B * H + jt);
+            grid_arrive(own);
+        }
+        if (l > 0 && active) partial(wi, P2w + (long)t * pbuf + jt);     // in the shadow of the hand-off; acknowledged by the next arrival
+    }
+    if (l > 0) grid_arrive(own);
+}
+
 template <int KC>
 int launch_fwd(const LstmP& p, hipStream_t s) {
     const int smem = (p.B * 8 * KC + 16 * p.B * 32) * 4;
@@ -276,13 +559,79 @@ int launch_bwd(const LstmP& p, hipStream_t s) {
     return MTL_OK;
 }
 
+template <int KC>
+int launch_stack_fwd(const StackP& p, hipStream_t s) {
+    const int smem = (p.B * 8 * KC + 16 * p.B * 32) * 4;
+    static int attr = hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_stack_fwd_kernel<KC>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (32 * 8 * KC + 16 * 32 * 32) * 4) == hipSuccess ? 0 : MTL_ELAUNCH;
+    if (attr) return attr;
+    hipLaunchKernelGGL(lstm_stack_fwd_kernel<KC>, dim3(p.NL * (p.H / LU)), dim3(256), smem, s, p);
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}
+template <int KC>
+int launch_stack_bwd(const StackP& p, hipStream_t s) {
+    hipLaunchKernelGGL(lstm_stack_bwd_kernel<KC>, dim3(p.NL * (p.H / LU)), dim3(256), p.B * 32 * 4, s, p);
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}
+
+bool fill_stack(StackP& p, const mtl_lstm_stack* d, int NL, bool bwd) {
+    for (int l = 0; l < NL; ++l) {
+        p.wih[l] = d->w_ih[l], p.bih[l] = d->b_ih[l], p.whh[l] = d->w_hh[l], p.bhh[l] = d->b_hh[l];
+        p.hall[l] = d->hall[l], p.call[l] = d->call[l], p.acts[l] = d->acts[l], p.xout[l] = d->xout[l], p.dG[l] = d->dG[l];
+        p.mask[l] = d->mask[l];
+        if (!p.whh[l] || !p.call[l] || !p.acts[l] || (l > 0 && !p.wih[l])) return false;
+        if (bwd ? !p.dG[l] : (!p.bhh[l] || !p.hall[l] || !p.xout[l] || (l > 0 && !p.bih[l]))) return false;
+    }
+    return true;
+}
+
 }  // namespace
 
 extern "C" {
 
 int mtl_lstm_layer_supported(int B, int H) { return B >= 1 && B <= 32 && (H == 128 || H == 256 || H == 384 || H == 512); }
 
-long mtl_lstm_layer_workspace(void) { return 256 + 2L * 64 * 32 * 512 * 4; }      // header + two partial buffers (backward)
+long mtl_lstm_layer_workspace(void) { return HDR * 4 + MAXL * 2 * PBUF * 4; }      // header + two partial buffers per layer (backward)
+
+int mtl_lstm_stack_supported(int B, int H, int NL) {      // every workgroup must be resident: NL H / 8 of the 256 CUs
+    return mtl_lstm_layer_supported(B, H) && NL >= 1 && NL <= MAXL && NL * (H / LU) <= 192;
+}
+
+long mtl_lstm_stack_scratch(int T, int B, int H, int NL) { return NL > 1 ? (long)(NL - 1) * T * (H / LU) * B * H * 4 : 0; }
+
+int mtl_lstm_stack_fwd(void* stream, const mtl_lstm_stack* layers, const float* gx0, float mscale, int T, int B, int H, int NL,
+                       void* workspace) {
+    if (!layers || !gx0 || !workspace || T <= 0 || !mtl_lstm_stack_supported(B, H, NL)) return MTL_EINVAL;
+    StackP p{};
+    if (!fill_stack(p, layers, NL, false)) return MTL_EINVAL;
+    p.gx0 = gx0, p.mscale = mscale, p.T = T, p.B = B, p.H = H, p.NL = NL, p.sync = reinterpret_cast<unsigned*>(workspace);
+    hipStream_t s = as_stream(stream);
+    if (hipMemsetAsync(workspace, 0, HDR * 4, s) != hipSuccess) return MTL_ELAUNCH;
+    switch (H / 8) {
+        case 16: return launch_stack_fwd<16>(p, s);
+        case 32: return launch_stack_fwd<32>(p, s);
+        case 48: return launch_stack_fwd<48>(p, s);
+        default: return launch_stack_fwd<64>(p, s);
+    }
+}
+
+int mtl_lstm_stack_bwd(void* stream, const mtl_lstm_stack* layers, const float* dx_up, float mscale, float* scratch, int T, int B, int H,
+                       int NL, void* workspace) {
+    if (!layers || !dx_up || !workspace || T <= 0 || !mtl_lstm_stack_supported(B, H, NL) || (NL > 1 && !scratch)) return MTL_EINVAL;
+    StackP p{};
+    if (!fill_stack(p, layers, NL, true)) return MTL_EINVAL;
+    p.dx_up = dx_up, p.p2 = scratch, p.mscale = mscale, p.T = T, p.B = B, p.H = H, p.NL = NL, p.sync = reinterpret_cast<unsigned*>(workspace);
+    hipStream_t s = as_stream(stream);
+    if (hipMemsetAsync(workspace, 0, HDR * 4, s) != hipSuccess) return MTL_ELAUNCH;
+    switch (H / 8) {
+        case 16: return launch_stack_bwd<16>(p, s);
+        case 32: return launch_stack_bwd<32>(p, s);
+        case 48: return launch_stack_bwd<48>(p, s);
+        default: return launch_stack_bwd<64>(p, s);
+    }
+}
 
 int mtl_lstm_layer_fwd(void* stream, const float* gx, const float* w_hh, const float* b_hh, float* hall, float* call, float* acts,
                        float* xout, const unsigned char* mask, float mscale, int T, int B, int H, void* workspace) {

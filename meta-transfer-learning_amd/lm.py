@@ -15,6 +15,7 @@
   loop with ONE all-reduce of the flat G.  **Parity unpinned** against the reference loop; pinned against the oracle restatement.
 No CPU fallback: without a GPU / the built library every compute call raises.
 """
+import ctypes
 import math
 import time
 
@@ -111,6 +112,8 @@ class LMEngine:
         # recurrent product + cell kernel (A/B measurements, unsupported shapes take it anyway)
         import os
         self.persistent = os.environ.get('MTL_LSTM_PERSISTENT', '1') != '0'
+        # the whole stack as one wavefront launch per direction (layers one step apart); '0': one launch per layer and direction
+        self.stacked = os.environ.get('MTL_LSTM_STACK', '1') != '0'
         self.sync_ws = torch.zeros(int(self.lib.mtl_lstm_layer_workspace()) // 4, dtype=torch.int32, device=device)
 
     def buf(self, name, shape, dtype=torch.float32):
@@ -179,9 +182,9 @@ class LMEngine:
         layers = []
         xin, kin = emb, E
         hn, cn = self.buf('hn', (NL, B, H)), self.buf('cn', (NL, B, H))
+        stacked = self.persistent and self.stacked and NL > 1 and bool(lib.mtl_lstm_stack_supported(B, H, NL))
+        desc = _lib.LstmStack() if stacked else None
         for l in range(NL):
-            gx = self.buf('gx%d' % l, (R, 4 * H))
-            self.gemm(0, 1, R, 4 * H, kin, xin.data_ptr(), kin, o('rnn.weight_ih_l%d' % l), kin, gx.data_ptr(), 4 * H, bias=o('rnn.bias_ih_l%d' % l))
             hall = self.buf('hall%d' % l, (T + 1, B, H))
             call = self.buf('call%d' % l, (T + 1, B, H))
             hall[0].copy_(h0[l])
@@ -189,8 +192,18 @@ class LMEngine:
             acts = self.buf('acts%d' % l, (R, 4 * H))
             xout = self.buf('xout%d' % l, (R, H))               # this layer's output after its dropout (next layer's / decoder's input)
             msk = mask('m_l%d' % l, R * H, 2 + l)
-            gh = self.buf('gh', (B, 4 * H))
             whh, bhh = o('rnn.weight_hh_l%d' % l), o('rnn.bias_hh_l%d' % l)
+            layers.append(dict(x=xin, kin=kin, hall=hall, call=call, acts=acts, mask=msk))
+            if stacked:
+                # every layer in ONE wavefront launch below: only layer 0 takes its input contributions from a product over all steps
+                desc.w_ih[l], desc.b_ih[l], desc.w_hh[l], desc.b_hh[l] = o('rnn.weight_ih_l%d' % l), o('rnn.bias_ih_l%d' % l), whh, bhh
+                desc.hall[l], desc.call[l], desc.acts[l], desc.xout[l] = hall.data_ptr(), call.data_ptr(), acts.data_ptr(), xout.data_ptr()
+                desc.mask[l] = msk.data_ptr() if msk is not None else None
+                xin, kin = xout, H
+                continue
+            gx = self.buf('gx%d' % l, (R, 4 * H))
+            self.gemm(0, 1, R, 4 * H, kin, xin.data_ptr(), kin, o('rnn.weight_ih_l%d' % l), kin, gx.data_ptr(), 4 * H, bias=o('rnn.bias_ih_l%d' % l))
+            gh = self.buf('gh', (B, 4 * H))
             fused = self.persistent and bool(lib.mtl_lstm_layer_supported(B, H))
             if fused:
                 check(lib.mtl_lstm_layer_fwd(st, gx.data_ptr(), whh, bhh, hall.data_ptr(), call.data_ptr(), acts.data_ptr(), xout.data_ptr(),
@@ -202,10 +215,14 @@ class LMEngine:
                                             acts.data_ptr() + 16 * t * B * H, call[t + 1].data_ptr(), hall[t + 1].data_ptr(),
                                             xout.data_ptr() + 4 * t * B * H, msk.data_ptr() + t * B * H if msk is not None else None, sc,
                                             B, H), 'lstm_cell_fwd')
-            hn[l].copy_(hall[T])
-            cn[l].copy_(call[T])
-            layers.append(dict(x=xin, kin=kin, hall=hall, call=call, acts=acts, mask=msk))
             xin, kin = xout, H
+        if stacked:
+            gx = self.buf('gx0', (R, 4 * H))
+            self.gemm(0, 1, R, 4 * H, E, emb.data_ptr(), E, o('rnn.weight_ih_l0'), E, gx.data_ptr(), 4 * H, bias=o('rnn.bias_ih_l0'))
+            check(lib.mtl_lstm_stack_fwd(st, ctypes.byref(desc), gx.data_ptr(), sc, T, B, H, NL, self.sync_ws.data_ptr()), 'lstm_stack_fwd')
+        for l in range(NL):
+            hn[l].copy_(layers[l]['hall'][T])
+            cn[l].copy_(layers[l]['call'][T])
         logits = self.buf('logits', (R, V))
         self.gemm(0, 1, R, V, H, xin.data_ptr(), H, o('decoder.weight'), H, logits.data_ptr(), V, bias=o('decoder.bias'))
         loss = None
@@ -215,7 +232,7 @@ class LMEngine:
             lse, hyp, rowloss, loss = self.buf('lse', (R,)), self.buf('hyp', (R,), torch.int64), self.buf('rowloss', (R,)), self.buf('loss', (1,))
             check(lib.mtl_ce_argmax_fwd(st, logits.data_ptr(), gold.data_ptr(), R, V, V, -1, 0.0, R, None, lse.data_ptr(), hyp.data_ptr(),
                                         rowloss.data_ptr(), loss.data_ptr()), 'ce_fwd')     # nn.CrossEntropyLoss(): mean over all T*B rows
-        self.saved = dict(theta=theta, T=T, B=B, layers=layers, last=xin, m_emb=m_emb, sc=sc, ids=ids, chains=chains)
+        self.saved = dict(theta=theta, T=T, B=B, layers=layers, last=xin, m_emb=m_emb, sc=sc, ids=ids, chains=chains, stacked=stacked)
         return dict(logits=logits, loss=loss, hidden=(hn.clone(), cn.clone()))
 
     def backward(self, grad, scale=1.0):
@@ -239,6 +256,18 @@ class LMEngine:
         self.gemm(1, 0, V, H, R, dlog.data_ptr(), ldd, last.data_ptr(), H, g('decoder.weight'), H, flags=ACCUM, rowsum=g('decoder.bias'))
         dx = self.buf('dx_out', (R, H))
         self.gemm(0, 0, R, H, V, dlog.data_ptr(), ldd, o('decoder.weight'), H, dx.data_ptr(), H)
+        stacked = S['stacked']
+        if stacked:
+            desc = _lib.LstmStack()
+            for l in range(NL):
+                Ly = S['layers'][l]
+                desc.w_ih[l], desc.w_hh[l] = o('rnn.weight_ih_l%d' % l), o('rnn.weight_hh_l%d' % l)
+                desc.call[l], desc.acts[l] = Ly['call'].data_ptr(), Ly['acts'].data_ptr()
+                desc.dG[l] = self.buf('dG%d' % l, (R, 4 * H)).data_ptr()
+                desc.mask[l] = Ly['mask'].data_ptr() if Ly['mask'] is not None else None
+            scratch = self.buf('stack_scratch', (int(lib.mtl_lstm_stack_scratch(T, B, H, NL)) // 4,))
+            check(lib.mtl_lstm_stack_bwd(st, ctypes.byref(desc), dx.data_ptr(), sc, scratch.data_ptr(), T, B, H, NL, self.sync_ws.data_ptr()),
+                  'lstm_stack_bwd')
         for l in reversed(range(NL)):
             Ly = S['layers'][l]
             kin = Ly['kin']
@@ -246,8 +275,8 @@ class LMEngine:
             dh_rec, dc = self.buf('dh_rec', (B, H)), [self.buf('dc_a', (B, H)), self.buf('dc_b', (B, H))]
             whh = o('rnn.weight_hh_l%d' % l)
             msk = Ly['mask']
-            fused = self.persistent and bool(lib.mtl_lstm_layer_supported(B, H))
-            if fused:
+            fused = stacked or (self.persistent and bool(lib.mtl_lstm_layer_supported(B, H)))
+            if fused and not stacked:
                 check(lib.mtl_lstm_layer_bwd(st, dx.data_ptr(), msk.data_ptr() if msk is not None else None, sc, whh, Ly['acts'].data_ptr(),
                                              Ly['call'].data_ptr(), dG.data_ptr(), T, B, H, self.sync_ws.data_ptr()), 'lstm_layer_bwd')
             for t in reversed(range(0 if fused else T)):
@@ -263,6 +292,8 @@ class LMEngine:
                       rowsum=g('rnn.bias_hh_l%d' % l))
             self.gemm(1, 0, 4 * H, kin, R, dG.data_ptr(), 4 * H, Ly['x'].data_ptr(), kin, g('rnn.weight_ih_l%d' % l), kin, flags=ACCUM,
                       rowsum=g('rnn.bias_ih_l%d' % l))
+            if stacked and l > 0:
+                continue                                          # the stack kernel has handed the input gradient down itself
             dxin = self.buf('dx_in%d' % l, (R, kin))
             self.gemm(0, 0, R, kin, 4 * H, dG.data_ptr(), 4 * H, o('rnn.weight_ih_l%d' % l), kin, dxin.data_ptr(), kin)
             dx = dxin

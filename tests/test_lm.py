@@ -198,54 +198,60 @@ def test_lm_meta_step_matches_oracle_restatement():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('H,B,T,dropout', [(128, 5, 9, 0.0), (256, 7, 6, 0.3), (512, 20, 35, 0.2), (384, 32, 4, 0.0)])
-def test_lm_persistent_lstm_layer_kernels(H, B, T, dropout):
-    """csrc/mtl_lstm.hip (all T steps of a layer in one launch per direction, grid-wide hand-off per step) against the oracle and
-    against the per-step path (recurrent product + cell kernel per step) on the same batch, parameters, carried state and dropout
-    masks: logits, loss, new hidden state, every gradient tensor; run twice to show the launch is reproducible bit for bit
-    (fixed-order reductions, re-zeroed arrival counter) and that no wait timed out."""
+@pytest.mark.parametrize('H,B,T,dropout,NL', [(128, 5, 9, 0.0, 2), (256, 7, 6, 0.3, 3), (512, 20, 35, 0.2, 2), (384, 32, 4, 0.0, 2),
+                                              (512, 20, 1, 0.0, 2), (256, 3, 5, 0.5, 1)])
+def test_lm_persistent_lstm_layer_kernels(H, B, T, dropout, NL):
+    """csrc/mtl_lstm.hip -- the layer stack as one wavefront launch per direction ('stack': layers one step apart, per-step hand-offs
+    within and between layers) and one launch per layer and direction ('layers') -- against the oracle and against the per-step path
+    (recurrent product + cell kernel per step) on the same batch, parameters, carried state and dropout masks: logits, loss, new
+    hidden state, every gradient tensor; each persistent mode runs twice to show the launch is reproducible bit for bit
+    (fixed-order reductions, re-zeroed arrival counters) and that no wait timed out."""
     import mtl_amd
     V, E = 300, 48
     torch.manual_seed(3)
-    model = mtl_amd.lm.RNNModel('LSTM', V, E, H, 2, dropout).cuda()
+    model = mtl_amd.lm.RNNModel('LSTM', V, E, H, NL, dropout).cuda()
     model.train()
     torch.manual_seed(5)
-    oracle = LR.RNNModel(V, E, H, 2, dropout)
+    oracle = LR.RNNModel(V, E, H, NL, dropout)
     _to_oracle(oracle, model, model.flat_parameters)
     g = torch.Generator().manual_seed(21 + H)
     x = torch.randint(0, V, (T, B), generator=g)
     y = torch.randint(0, V, (T * B,), generator=g)
-    h0, c0 = 0.2 * torch.randn(2, B, H, generator=g), 0.2 * torch.randn(2, B, H, generator=g)
+    h0, c0 = 0.2 * torch.randn(NL, B, H, generator=g), 0.2 * torch.randn(NL, B, H, generator=g)
     eng = model.engine
-    assert eng.persistent and bool(eng.lib.mtl_lstm_layer_supported(B, H))
+    assert eng.persistent and eng.stacked and bool(eng.lib.mtl_lstm_layer_supported(B, H)) and bool(eng.lib.mtl_lstm_stack_supported(B, H, NL))
     runs = {}
-    for mode in ('persistent', 'persistent', 'steps'):
-        eng.persistent = mode == 'persistent'
+    for mode in ('stack', 'stack', 'layers', 'layers', 'steps'):
+        eng.persistent, eng.stacked = mode != 'steps', mode == 'stack'
         torch.manual_seed(77)                                               # same Philox seed draw -> same keep-masks
         out = eng.forward(model.flat_parameters, x.cuda(), y.cuda(), (h0.cuda(), c0.cuda()), dropout)
         grad = torch.zeros_like(model.flat_grad)
         eng.backward(grad, 1.0)
         torch.cuda.synchronize()
         res = (out['logits'].clone(), float(out['loss']), out['hidden'][0].clone(), out['hidden'][1].clone(), grad)
-        if mode == 'persistent' and mode in runs:
+        assert eng.saved['stacked'] == (mode == 'stack' and NL > 1)
+        if mode in runs:
             for a, b in zip(res, runs[mode]):
                 assert (a == b) if isinstance(a, float) else torch.equal(a, b)
         runs[mode] = res
         assert int(eng.sync_ws[1]) == 0, 'a grid-wide wait timed out'
-    eng.persistent = True
+    eng.persistent = eng.stacked = True
     masks = None
     if dropout > 0:
         sc = 1.0 / (1 - dropout)
         pool = {k[0]: v for k, v in eng.pool.items()}
-        masks = {'emb': pool['m_emb'].cpu().float().view(T, B, E) * sc, 'l0': pool['m_l0'].cpu().float().view(T, B, H) * sc,
-                 'out': pool['m_l1'].cpu().float().view(T, B, H) * sc}
+        masks = {'emb': pool['m_emb'].cpu().float().view(T, B, E) * sc}
+        for l in range(NL):
+            masks['l%d' % l if l < NL - 1 else 'out'] = pool['m_l%d' % l].cpu().float().view(T, B, H) * sc
     o_out, (hn, cn) = oracle(x, (h0, c0), masks)
     loss = torch.nn.functional.cross_entropy(o_out.view(-1, V), y)
     grads = torch.autograd.grad(loss, list(oracle.parameters()))
-    lp, ls = runs['persistent'], runs['steps']
-    assert float((lp[0].cpu() - o_out.view(-1, V)).norm() / o_out.norm()) < 1e-5
-    assert abs(lp[1] - float(loss)) < 1e-6 * float(loss) and abs(lp[1] - ls[1]) < 1e-6 * ls[1]
-    assert float((lp[2].cpu() - hn).abs().max()) < 2e-6 and float((lp[3].cpu() - cn).abs().max()) < 2e-6
-    errs = _errs(model, lp[4], oracle, grads)
-    assert max(errs.values()) < 1e-4, max(errs.items(), key=lambda kv: kv[1])
-    assert float((lp[4] - ls[4]).norm() / ls[4].norm()) < 2e-6              # the two device paths: same arithmetic, other summation orders
+    ls = runs['steps']
+    for mode in ('stack', 'layers'):
+        lp = runs[mode]
+        assert float((lp[0].cpu() - o_out.view(-1, V)).norm() / o_out.norm()) < 1e-5, mode
+        assert abs(lp[1] - float(loss)) < 1e-6 * float(loss) and abs(lp[1] - ls[1]) < 1e-6 * ls[1], mode
+        assert float((lp[2].cpu() - hn).abs().max()) < 2e-6 and float((lp[3].cpu() - cn).abs().max()) < 2e-6, mode
+        errs = _errs(model, lp[4], oracle, grads)
+        assert max(errs.values()) < 1e-4, (mode, max(errs.items(), key=lambda kv: kv[1]))
+        assert float((lp[4] - ls[4]).norm() / ls[4].norm()) < 2e-6, mode      # the device paths: same arithmetic, other summation orders
