@@ -360,24 +360,24 @@ int mtl_lstm_layer_bwd(void* stream, const float* dx_up, const unsigned char* ma
 
 /* The whole layer stack as ONE wavefront launch per direction (csrc/mtl_lstm.hip; lm/model/rnn_model.py:20 nn.LSTM(ninp, nhid, nlayers,
  * dropout=...)): layer l runs one step behind layer l - 1 instead of after it.  `layers` is a HOST struct of device pointers, one
- * entry per layer (read during the call; not recordable in a command list): w_ih/b_ih of layer 0 are not used (its input
- * contributions come as gx0 = x W_ih0^T + b_ih0 over all T steps), layers >= 1 must have input width H; hall/call/acts/xout/mask/dG
- * as in the single-layer calls (mask[l]: the dropout on layer l's output, or NULL).
+ * entry per layer (read during the call; not recordable in a command list): gx[0] holds layer 0's input contributions
+ * x W_ih0^T + b_ih0 over all T steps (w_ih[0] / b_ih[0] are not used), gx[l >= 1] is T B x 4H scratch the call fills; layers >= 1
+ * must have input width H; hall/call/acts/xout/mask/dG as in the single-layer calls (mask[l]: the dropout on layer l's output, or
+ * NULL).
  *   forward : fills hall, call, acts, xout of every layer.
  *   backward: fills dG of every layer from dx_up (gradient w.r.t. the top layer's dropped output); scratch = mtl_lstm_stack_scratch()
  *             bytes (the per-step partial sums handed from a layer to the one below).
  * Results equal the per-layer calls up to the summation order of the input contribution (formed per step instead of by one product).
- * mtl_lstm_stack_supported: the single-layer limits, NL <= 4 and NL * H / 8 <= 192 workgroups (all resident). */
+ * mtl_lstm_stack_supported: the single-layer limits, NL <= 4 and (2 NL - 1) * H / 8 <= 224 workgroups (all resident). */
 #define MTL_LSTM_MAX_LAYERS 4
 typedef struct mtl_lstm_stack {
     const float *w_ih[MTL_LSTM_MAX_LAYERS], *b_ih[MTL_LSTM_MAX_LAYERS], *w_hh[MTL_LSTM_MAX_LAYERS], *b_hh[MTL_LSTM_MAX_LAYERS];
-    float *hall[MTL_LSTM_MAX_LAYERS], *call[MTL_LSTM_MAX_LAYERS], *acts[MTL_LSTM_MAX_LAYERS], *xout[MTL_LSTM_MAX_LAYERS], *dG[MTL_LSTM_MAX_LAYERS];
+    float *gx[MTL_LSTM_MAX_LAYERS], *hall[MTL_LSTM_MAX_LAYERS], *call[MTL_LSTM_MAX_LAYERS], *acts[MTL_LSTM_MAX_LAYERS], *xout[MTL_LSTM_MAX_LAYERS], *dG[MTL_LSTM_MAX_LAYERS];
     const unsigned char* mask[MTL_LSTM_MAX_LAYERS];
 } mtl_lstm_stack;
 int mtl_lstm_stack_supported(int B, int H, int NL);
 long mtl_lstm_stack_scratch(int T, int B, int H, int NL);
-int mtl_lstm_stack_fwd(void* stream, const mtl_lstm_stack* layers, const float* gx0, float mscale, int T, int B, int H, int NL,
-                       void* workspace);
+int mtl_lstm_stack_fwd(void* stream, const mtl_lstm_stack* layers, float mscale, int T, int B, int H, int NL, void* workspace);
 int mtl_lstm_stack_bwd(void* stream, const mtl_lstm_stack* layers, const float* dx_up, float mscale, float* scratch, int T, int B, int H,
                        int NL, void* workspace);
 

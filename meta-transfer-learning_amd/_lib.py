@@ -89,7 +89,7 @@ SIGNATURES = {
     'mtl_lstm_layer_bwd': (I, [P, P, P, F, P, P, P, P, I, I, I, P]),
     'mtl_lstm_stack_supported': (I, [I, I, I]),
     'mtl_lstm_stack_scratch': (L, [I, I, I, I]),
-    'mtl_lstm_stack_fwd': (I, [P, P, P, F, I, I, I, I, P]),
+    'mtl_lstm_stack_fwd': (I, [P, P, F, I, I, I, I, P]),
     'mtl_lstm_stack_bwd': (I, [P, P, P, F, P, I, I, I, I, P]),
     'mtl_memset_zero': (I, [P, P, L]),
     'mtl_memcpy_d2d': (I, [P, P, P, L]),
@@ -141,7 +141,7 @@ AMAX_SLOTS = 64 * 32    # MTL_AMAX_FLOATS of include/mtl_hip.h: floats per max|t
 
 class LstmStack(ctypes.Structure):
     """mtl_lstm_stack of include/mtl_hip.h: a host struct of device pointers, MTL_LSTM_MAX_LAYERS entries per field"""
-    _fields_ = [(_n, c_void_p * 4) for _n in ('w_ih', 'b_ih', 'w_hh', 'b_hh', 'hall', 'call', 'acts', 'xout', 'dG', 'mask')]
+    _fields_ = [(_n, c_void_p * 4) for _n in ('w_ih', 'b_ih', 'w_hh', 'b_hh', 'gx', 'hall', 'call', 'acts', 'xout', 'dG', 'mask')]
 
 
 class LnReduceDesc(ctypes.Structure):

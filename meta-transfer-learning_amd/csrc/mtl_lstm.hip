@@ -266,15 +266,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 // Layer stack as ONE wavefront launch per direction: grid = NL x (H / 8) workgroups, workgroup (l, w) owns units [8 w, 8 w + 8) of
 // layer l.  Layer l step t needs layer l step t - 1 (its own counter) and layer l - 1 step t (the lower layer's counter), so the
 // layers run one step apart instead of one after the other: ~T + NL - 1 hand-offs per pass instead of NL T.
-//   forward:  layers >= 1 keep their 32 rows of W_ih in registers next to W_hh and form the input contribution of step t from the
-//             lower layer's (dropped) output themselves -- BEFORE they wait for their own layer's h_t, i.e. in the shadow of the
-//             hand-off; layer 0 takes its input contributions from one product over all T steps (gx0), as before.
+//   forward:  the input contributions W_ih x_t + b_ih of a layer >= 1 are formed per step by a SECOND group of H / 8 workgroups (same
+//             ownership, W_ih rows in registers) that depends on the layer below only and therefore runs ahead of its layer: the
+//             layer's own step stays as short as layer 0's (inside the layer's workgroups the product cost 8 us of a 20 us step).
+//             Layer 0 takes its input contributions from one product over all T steps (gx[0]), as before.
 //   backward: layer l >= 1 also multiplies its columns of dG_t with its rows of W_ih: a second row-split partial (the gradient into
 //             the lower layer's output) -- computed after the arrival that publishes the recurrent partial, again in the shadow of
 //             the hand-off, and acknowledged by the next arrival.  The upper layer is not gated by the lower one and may run ahead,
 //             so these partials are buffered for ALL T steps ([NL-1][T][nwg][B][H], p.p2).
 struct StackP {
-    const float* gx0;
+    float* gx[MAXL];
     const float *wih[MAXL], *bih[MAXL], *whh[MAXL], *bhh[MAXL];
     float *hall[MAXL], *call[MAXL], *acts[MAXL], *xout[MAXL], *dG[MAXL];
     const uint8_t* mask[MAXL];
@@ -299,51 +300,57 @@ __device__ __forceinline__ void grid_wait2(unsigned* ctr, unsigned* err, unsigne
 }
 
 template <int KC>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_stack_fwd_kernel(StackP p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void lstm_stack_fwd_kernel(StackP p) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int B = p.B, H = 8 * KC, T = p.T;
-    float* hs = sm;                     // [B][H]: the lower layer's output, then this layer's previous state
+    const int B = p.B, H = 8 * KC, T = p.T, NL = p.NL;
+    float* hs = sm;                     // [B][H]: the operand of this group's product (previous state / the lower layer's output)
     float* red = sm + B * H;            // [16 chunks][B][32 rows]
     constexpr int KH = KC / 2;
     const int tid = threadIdx.x, rp = tid & 15, kc = tid >> 4;
     const unsigned nwg = H / LU;
-    const int l = blockIdx.x / nwg, j0 = (blockIdx.x % nwg) * LU;
-    unsigned* own = p.sync + 32 * l;
+    // groups 0 .. NL-1: the layers; groups NL .. 2 NL - 2: the input products of layers 1 .. NL-1 (they only depend on the layer
+    // below, so they run ahead of their layer instead of lengthening its step)
+    const int grp = blockIdx.x / nwg, j0 = (blockIdx.x % nwg) * LU;
+    const bool xgroup = grp >= NL;
+    const int l = xgroup ? grp - NL + 1 : grp;
+    unsigned* own = p.sync + 32 * l;                         // arrivals of layer l
+    unsigned* xin = p.sync + 32 * (MAXL + l);                // arrivals of the input-product group of layer l
     unsigned* low = p.sync + 32 * (l > 0 ? l - 1 : 0);
     unsigned* err = p.sync + 1;
-    float w[2][KH], wi[2][KH];
+    float w[2][KH];
+    {
+        const float* wsrc = xgroup ? p.wih[l] : p.whh[l];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int r = 2 * rp + q;
-        const long ro = (long)((r >> 3) * H + j0 + (r & 7)) * H + kc * KH;
+        for (int q = 0; q < 2; ++q) {
+            const int r = 2 * rp + q;
+            const float* wrow = wsrc + (long)((r >> 3) * H + j0 + (r & 7)) * H + kc * KH;
 #pragma unroll
-        for (int i = 0; i < KH; i += 4) {
-            const float4 v = *reinterpret_cast<const float4*>(p.whh[l] + ro + i);
-            w[q][i] = v.x, w[q][i + 1] = v.y, w[q][i + 2] = v.z, w[q][i + 3] = v.w;
-            const float4 u = l > 0 ? *reinterpret_cast<const float4*>(p.wih[l] + ro + i) : make_float4(0.f, 0.f, 0.f, 0.f);
-            wi[q][i] = u.x, wi[q][i + 1] = u.y, wi[q][i + 2] = u.z, wi[q][i + 3] = u.w;
+            for (int i = 0; i < KH; i += 4) {
+                const float4 v = *reinterpret_cast<const float4*>(wrow + i);
+                w[q][i] = v.x, w[q][i + 1] = v.y, w[q][i + 2] = v.z, w[q][i + 3] = v.w;
+            }
         }
     }
     const bool cell = tid < B * LU;
     const int cb = tid / LU, cu = tid % LU, cj = j0 + cu;
-    float bias[4] = {0.f, 0.f, 0.f, 0.f}, bias_x[4] = {0.f, 0.f, 0.f, 0.f};
+    float bias[4] = {0.f, 0.f, 0.f, 0.f};
     float c_prev = 0.f;
     float* hall = p.hall[l];
     float* call = p.call[l];
     float* acts = p.acts[l];
     float* xout = p.xout[l];
+    float* gx = p.gx[l];
     const uint8_t* mask = p.mask[l];
-    const float* xlow = l > 0 ? p.xout[l - 1] : nullptr;
     if (cell) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            bias[g] = p.bhh[l][g * H + cj];
-            if (l > 0) bias_x[g] = p.bih[l][g * H + cj];
-        }
-        c_prev = call[(long)cb * H + cj];
+        for (int g = 0; g < 4; ++g) bias[g] = (xgroup ? p.bih[l] : p.bhh[l])[g * H + cj];
+        if (!xgroup) c_prev = call[(long)cb * H + cj];
     }
-    // one pass of the B x H operand in `hs` against this thread's two row chunks -> red
-    auto product = [&](const float (&ww)[2][KH]) {
+    // the B x H operand at `src` (written by other workgroups: sc1 loads) against this thread's two row chunks; the 16 chunk
+    // partials of an output are summed in a fixed order by the cell threads (after the barrier)
+    auto product = [&](const float* src) {
+        for (int i = tid; i < B * H / 2; i += 256) reinterpret_cast<float2*>(hs)[i] = load_shared2(src + 2 * i);
+        __syncthreads();
 #pragma unroll 1
         for (int b = 0; b < B; ++b) {
             const float* hb = hs + b * H + kc * KH;
@@ -351,49 +358,51 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
             for (int i = 0; i < KH; i += 4) {
                 const float4 hv = *reinterpret_cast<const float4*>(hb + i);
-                a0 = fmaf(ww[0][i], hv.x, a0);
-                a1 = fmaf(ww[1][i], hv.x, a1);
-                a0 = fmaf(ww[0][i + 1], hv.y, a0);
-                a1 = fmaf(ww[1][i + 1], hv.y, a1);
-                a0 = fmaf(ww[0][i + 2], hv.z, a0);
-                a1 = fmaf(ww[1][i + 2], hv.z, a1);
-                a0 = fmaf(ww[0][i + 3], hv.w, a0);
-                a1 = fmaf(ww[1][i + 3], hv.w, a1);
+                a0 = fmaf(w[0][i], hv.x, a0);
+                a1 = fmaf(w[1][i], hv.x, a1);
+                a0 = fmaf(w[0][i + 1], hv.y, a0);
+                a1 = fmaf(w[1][i + 1], hv.y, a1);
+                a0 = fmaf(w[0][i + 2], hv.z, a0);
+                a1 = fmaf(w[1][i + 2], hv.z, a1);
+                a0 = fmaf(w[0][i + 3], hv.w, a0);
+                a1 = fmaf(w[1][i + 3], hv.w, a1);
             }
             *reinterpret_cast<float2*>(red + (kc * B + b) * 32 + 2 * rp) = make_float2(a0, a1);
         }
+        __syncthreads();
     };
+    if (xgroup) {
+        const float* xlow = p.xout[l - 1];
 #pragma unroll 1
-    for (int t = 0; t < T; ++t) {
-        float gxv[4] = {0.f, 0.f, 0.f, 0.f};                    // input contributions W_ih x_t + b_ih of this thread's cell
-        if (l == 0) {
-            if (cell) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) gxv[g] = p.gx0[((long)t * B + cb) * 4 * H + g * H + cj];
-            }
-        } else {
-            grid_wait2(low, err, (unsigned)(t + 1) * nwg);      // the lower layer has published its output of step t
-            const float* src = xlow + (long)t * B * H;
-            for (int i = tid; i < B * H / 2; i += 256) reinterpret_cast<float2*>(hs)[i] = load_shared2(src + 2 * i);
-            __syncthreads();
-            product(wi);
-            __syncthreads();
+        for (int t = 0; t < T; ++t) {
+            grid_wait2(low, err, (unsigned)(t + 1) * nwg);      // the layer below has published its output of step t
+            product(xlow + (long)t * B * H);
             if (cell) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     float s = 0.f;
 #pragma unroll
                     for (int q = 0; q < 16; ++q) s += red[(q * B + cb) * 32 + g * 8 + cu];
-                    gxv[g] = s + bias_x[g];
+                    store_shared(gx + ((long)t * B + cb) * 4 * H + g * H + cj, s + bias[g]);
                 }
+            }
+            grid_arrive(xin);      // (its barrier also orders the reads of `red` before the next step's writes)
+        }
+        return;
+    }
+#pragma unroll 1
+    for (int t = 0; t < T; ++t) {
+        float gxv[4] = {0.f, 0.f, 0.f, 0.f};                    // this step's input contributions: requested before the wait
+        if (l > 0) grid_wait2(xin, err, (unsigned)(t + 1) * nwg);      // (its group runs ahead: normally satisfied at once)
+        if (cell) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float* q = gx + ((long)t * B + cb) * 4 * H + g * H + cj;
+                gxv[g] = l > 0 ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *q;
             }
         }
         if (t > 0) grid_wait2(own, err, (unsigned)t * nwg);     // every workgroup of this layer has published h_t
-        const float* src = hall + (long)t * B * H;
-        for (int i = tid; i < B * H / 2; i += 256) reinterpret_cast<float2*>(hs)[i] = load_shared2(src + 2 * i);
-        __syncthreads();
-        product(w);
-        __syncthreads();
+        product(hall + (long)t * B * H);
         if (cell) {
             const long row = (long)t * B + cb;
             float pre[4];
@@ -413,10 +422,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const long e = row * H + cj;
             call[e + (long)B * H] = cn;
             store_shared(hall + e + (long)B * H, hn);
-            store_shared(xout + e, mask ? (mask[e] ? hn * p.mscale : 0.f) : hn);      // read by the layer above
+            store_shared(xout + e, mask ? (mask[e] ? hn * p.mscale : 0.f) : hn);      // read by the group above
             c_prev = cn;
         }
-        grid_arrive(own);      // also after the last step: the layer above waits for it
+        grid_arrive(own);      // also after the last step: the group above waits for it
     }
 }
 
@@ -565,7 +574,7 @@ int launch_stack_fwd(const StackP& p, hipStream_t s) {
     static int attr = hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_stack_fwd_kernel<KC>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (32 * 8 * KC + 16 * 32 * 32) * 4) == hipSuccess ? 0 : MTL_ELAUNCH;
     if (attr) return attr;
-    hipLaunchKernelGGL(lstm_stack_fwd_kernel<KC>, dim3(p.NL * (p.H / LU)), dim3(256), smem, s, p);
+    hipLaunchKernelGGL(lstm_stack_fwd_kernel<KC>, dim3((2 * p.NL - 1) * (p.H / LU)), dim3(256), smem, s, p);
     MTL_CHECK_LAUNCH();
     return MTL_OK;
 }
@@ -580,9 +589,9 @@ bool fill_stack(StackP& p, const mtl_lstm_stack* d, int NL, bool bwd) {
     for (int l = 0; l < NL; ++l) {
         p.wih[l] = d->w_ih[l], p.bih[l] = d->b_ih[l], p.whh[l] = d->w_hh[l], p.bhh[l] = d->b_hh[l];
         p.hall[l] = d->hall[l], p.call[l] = d->call[l], p.acts[l] = d->acts[l], p.xout[l] = d->xout[l], p.dG[l] = d->dG[l];
-        p.mask[l] = d->mask[l];
+        p.mask[l] = d->mask[l], p.gx[l] = d->gx[l];
         if (!p.whh[l] || !p.call[l] || !p.acts[l] || (l > 0 && !p.wih[l])) return false;
-        if (bwd ? !p.dG[l] : (!p.bhh[l] || !p.hall[l] || !p.xout[l] || (l > 0 && !p.bih[l]))) return false;
+        if (bwd ? !p.dG[l] : (!p.bhh[l] || !p.hall[l] || !p.xout[l] || !p.gx[l] || (l > 0 && !p.bih[l]))) return false;
     }
     return true;
 }
@@ -595,18 +604,17 @@ int mtl_lstm_layer_supported(int B, int H) { return B >= 1 && B <= 32 && (H == 1
 
 long mtl_lstm_layer_workspace(void) { return HDR * 4 + MAXL * 2 * PBUF * 4; }      // header + two partial buffers per layer (backward)
 
-int mtl_lstm_stack_supported(int B, int H, int NL) {      // every workgroup must be resident: NL H / 8 of the 256 CUs
-    return mtl_lstm_layer_supported(B, H) && NL >= 1 && NL <= MAXL && NL * (H / LU) <= 192;
+int mtl_lstm_stack_supported(int B, int H, int NL) {      // every workgroup must be resident: (2 NL - 1) H / 8 of the 256 CUs
+    return mtl_lstm_layer_supported(B, H) && NL >= 1 && NL <= MAXL && (2 * NL - 1) * (H / LU) <= 224;
 }
 
 long mtl_lstm_stack_scratch(int T, int B, int H, int NL) { return NL > 1 ? (long)(NL - 1) * T * (H / LU) * B * H * 4 : 0; }
 
-int mtl_lstm_stack_fwd(void* stream, const mtl_lstm_stack* layers, const float* gx0, float mscale, int T, int B, int H, int NL,
-                       void* workspace) {
-    if (!layers || !gx0 || !workspace || T <= 0 || !mtl_lstm_stack_supported(B, H, NL)) return MTL_EINVAL;
+int mtl_lstm_stack_fwd(void* stream, const mtl_lstm_stack* layers, float mscale, int T, int B, int H, int NL, void* workspace) {
+    if (!layers || !workspace || T <= 0 || !mtl_lstm_stack_supported(B, H, NL)) return MTL_EINVAL;
     StackP p{};
     if (!fill_stack(p, layers, NL, false)) return MTL_EINVAL;
-    p.gx0 = gx0, p.mscale = mscale, p.T = T, p.B = B, p.H = H, p.NL = NL, p.sync = reinterpret_cast<unsigned*>(workspace);
+    p.mscale = mscale, p.T = T, p.B = B, p.H = H, p.NL = NL, p.sync = reinterpret_cast<unsigned*>(workspace);
     hipStream_t s = as_stream(stream);
     if (hipMemsetAsync(workspace, 0, HDR * 4, s) != hipSuccess) return MTL_ELAUNCH;
     switch (H / 8) {

@@ -199,6 +199,7 @@ class LMEngine:
                 desc.w_ih[l], desc.b_ih[l], desc.w_hh[l], desc.b_hh[l] = o('rnn.weight_ih_l%d' % l), o('rnn.bias_ih_l%d' % l), whh, bhh
                 desc.hall[l], desc.call[l], desc.acts[l], desc.xout[l] = hall.data_ptr(), call.data_ptr(), acts.data_ptr(), xout.data_ptr()
                 desc.mask[l] = msk.data_ptr() if msk is not None else None
+                desc.gx[l] = self.buf('gx%d' % l, (R, 4 * H)).data_ptr()
                 xin, kin = xout, H
                 continue
             gx = self.buf('gx%d' % l, (R, 4 * H))
@@ -219,7 +220,7 @@ class LMEngine:
         if stacked:
             gx = self.buf('gx0', (R, 4 * H))
             self.gemm(0, 1, R, 4 * H, E, emb.data_ptr(), E, o('rnn.weight_ih_l0'), E, gx.data_ptr(), 4 * H, bias=o('rnn.bias_ih_l0'))
-            check(lib.mtl_lstm_stack_fwd(st, ctypes.byref(desc), gx.data_ptr(), sc, T, B, H, NL, self.sync_ws.data_ptr()), 'lstm_stack_fwd')
+            check(lib.mtl_lstm_stack_fwd(st, ctypes.byref(desc), sc, T, B, H, NL, self.sync_ws.data_ptr()), 'lstm_stack_fwd')
         for l in range(NL):
             hn[l].copy_(layers[l]['hall'][T])
             cn[l].copy_(layers[l]['call'][T])
