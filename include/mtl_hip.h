@@ -348,7 +348,7 @@ int mtl_lstm_cell_bwd(void* stream, const float* dh_up, const unsigned char* mas
  *             mask != NULL: u8 keep flags, scale mscale) -- exactly what T calls of the recurrent product + mtl_lstm_cell_fwd produce.
  *   backward: dx_up (T B, H) gradient of xout (may be NULL), writes dG (T B, 4H) = gradient of the gate pre-activations of every step
  *             (truncated BPTT: no gradient into the incoming state) -- what T calls of mtl_lstm_cell_bwd + the dh_rec product produce.
- * workspace: mtl_lstm_layer_workspace() bytes of device memory, 256-byte aligned (1 KB header: arrival counters, one per layer, and the
+ * workspace: mtl_lstm_layer_workspace() bytes of device memory, 256-byte aligned (4 KB header: arrival counter, per-workgroup step flags and the
  * error word -- u32 [1] != 0 after a timed-out wait -- followed by the backward's partial buffers).
  * mtl_lstm_layer_supported: 1 <= B <= 32 and H in {128, 256, 384, 512}; other shapes take the per-step calls. */
 int mtl_lstm_layer_supported(int B, int H);

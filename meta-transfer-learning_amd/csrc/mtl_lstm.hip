@@ -22,7 +22,8 @@ namespace {
 
 constexpr int LU = 8;                        // hidden units per workgroup
 constexpr unsigned SPIN_LIMIT = 1u << 22;    // polls before a wait gives up (~seconds): sets the error word
-constexpr int HDR = 256;                     // workspace header in 4-byte words: arrival counters (one per layer, 128 bytes apart), error word [1]
+constexpr int HDR = 1024;                    // workspace header in 4-byte words: [0] arrival counter (single-layer kernels), [1] error word,
+                                             // [64 + 64 g ..): the per-workgroup step flags of group g of the stack kernels
 constexpr int MAXL = MTL_LSTM_MAX_LAYERS;
 constexpr long PBUF = 64L * 32 * 512;        // largest [nwg][B][H] partial buffer, floats
 
@@ -286,17 +287,27 @@ struct StackP {
     unsigned* sync;
 };
 
-__device__ __forceinline__ void grid_wait2(unsigned* ctr, unsigned* err, unsigned target) {
-    if (threadIdx.x == 0) {
+// Hand-off of the stack kernels: every workgroup owns ONE flag word (the number of steps it has published) instead of sharing an
+// arrival counter -- 64 read-modify-writes on one address serialise in L2, 64 write-through stores do not; the waiting workgroup's
+// first wave reads all flags of a group with one load per poll.
+__device__ __forceinline__ void flags_wait(const unsigned* flags, unsigned n, unsigned target, unsigned* err) {
+    if (threadIdx.x < 64) {
         unsigned spins = 0;
-        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        for (;;) {
+            const unsigned v = threadIdx.x < n ? __hip_atomic_load(flags + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : target;
+            if (__all(v >= target)) break;
             if (++spins > SPIN_LIMIT) {
-                __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (threadIdx.x == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
             }
         }
     }
     __syncthreads();
+}
+__device__ __forceinline__ void flags_arrive(unsigned* flag, unsigned steps) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's write-through stores are acknowledged
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flag, steps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 template <int KC>
@@ -313,9 +324,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     const int grp = blockIdx.x / nwg, j0 = (blockIdx.x % nwg) * LU;
     const bool xgroup = grp >= NL;
     const int l = xgroup ? grp - NL + 1 : grp;
-    unsigned* own = p.sync + 32 * l;                         // arrivals of layer l
-    unsigned* xin = p.sync + 32 * (MAXL + l);                // arrivals of the input-product group of layer l
-    unsigned* low = p.sync + 32 * (l > 0 ? l - 1 : 0);
+    const int wg = blockIdx.x % nwg;
+    unsigned* own = p.sync + 64 + 64 * l;                    // step flags of layer l
+    unsigned* xin = p.sync + 64 + 64 * (MAXL + l);           // step flags of the input-product group of layer l
+    unsigned* low = p.sync + 64 + 64 * (l > 0 ? l - 1 : 0);
     unsigned* err = p.sync + 1;
     float w[2][KH];
     {
@@ -375,7 +387,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         const float* xlow = p.xout[l - 1];
 #pragma unroll 1
         for (int t = 0; t < T; ++t) {
-            grid_wait2(low, err, (unsigned)(t + 1) * nwg);      // the layer below has published its output of step t
+            flags_wait(low, nwg, (unsigned)(t + 1), err);      // the layer below has published its output of step t
             product(xlow + (long)t * B * H);
             if (cell) {
 #pragma unroll
@@ -386,14 +398,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
                     store_shared(gx + ((long)t * B + cb) * 4 * H + g * H + cj, s + bias[g]);
                 }
             }
-            grid_arrive(xin);      // (its barrier also orders the reads of `red` before the next step's writes)
+            flags_arrive(xin + wg, (unsigned)(t + 1));      // (its barrier also orders the reads of `red` before the next step's writes)
         }
         return;
     }
 #pragma unroll 1
     for (int t = 0; t < T; ++t) {
         float gxv[4] = {0.f, 0.f, 0.f, 0.f};                    // this step's input contributions: requested before the wait
-        if (l > 0) grid_wait2(xin, err, (unsigned)(t + 1) * nwg);      // (its group runs ahead: normally satisfied at once)
+        if (l > 0) flags_wait(xin, nwg, (unsigned)(t + 1), err);      // (its group runs ahead: normally satisfied at once)
         if (cell) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -401,7 +413,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
                 gxv[g] = l > 0 ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *q;
             }
         }
-        if (t > 0) grid_wait2(own, err, (unsigned)t * nwg);     // every workgroup of this layer has published h_t
+        if (t > 0) flags_wait(own, nwg, (unsigned)t, err);     // every workgroup of this layer has published h_t
         product(hall + (long)t * B * H);
         if (cell) {
             const long row = (long)t * B + cb;
@@ -425,7 +437,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
             store_shared(xout + e, mask ? (mask[e] ? hn * p.mscale : 0.f) : hn);      // read by the group above
             c_prev = cn;
         }
-        grid_arrive(own);      // also after the last step: the group above waits for it
+        flags_arrive(own + wg, (unsigned)(t + 1));      // also after the last step: the group above waits for it
     }
 }
 
@@ -438,8 +450,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int tid = threadIdx.x;
     const unsigned nwg = H / LU;
     const int l = blockIdx.x / nwg, wg = blockIdx.x % nwg, j0 = wg * LU;
-    unsigned* own = p.sync + 32 * l;
-    unsigned* up = p.sync + 32 * (l + 1 < NL ? l + 1 : l);
+    unsigned* own = p.sync + 64 + 64 * l;
+    unsigned* up = p.sync + 64 + 64 * (l + 1 < NL ? l + 1 : l);
     unsigned* err = p.sync + 1;
     const int jt = tid * JT;
     const bool active = jt < H;
@@ -519,12 +531,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (!top) {
             // the layer above acknowledges its input-gradient partial of step t with the arrival of step t - 1 (the final one for t <= 1)
             const int k = T - t + 1 < T ? T - t + 1 : T;
-            grid_wait2(up, err, (unsigned)k * nwg);
+            flags_wait(up, nwg, (unsigned)k, err);
             if (cell) dh_up = gather(P2r + (long)t * pbuf + (long)cb * H + cj);
         }
         dh_up *= keep;
         if (t < T - 1) {
-            grid_wait2(own, err, (unsigned)(T - 1 - t) * nwg);
+            flags_wait(own, nwg, (unsigned)(T - 1 - t), err);
             if (cell) dh_rec = gather(P1 + ((t + 1) & 1) * pbuf + (long)cb * H + cj);
         }
         if (cell) {
@@ -543,11 +555,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         __syncthreads();
         if (t > 0) {
             if (active) partial(w, P1 + (t & 1) * pbuf + (long)wg * B * H + jt);
-            grid_arrive(own);
+            flags_arrive(own + wg, (unsigned)(T - t));
         }
         if (l > 0 && active) partial(wi, P2w + (long)t * pbuf + jt);     // in the shadow of the hand-off; acknowledged by the next arrival
     }
-    if (l > 0) grid_arrive(own);
+    if (l > 0) flags_arrive(own + wg, (unsigned)T);
 }
 
 template <int KC>
