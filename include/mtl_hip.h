@@ -349,7 +349,8 @@ int mtl_lstm_cell_bwd(void* stream, const float* dh_up, const unsigned char* mas
  *   backward: dx_up (T B, H) gradient of xout (may be NULL), writes dG (T B, 4H) = gradient of the gate pre-activations of every step
  *             (truncated BPTT: no gradient into the incoming state) -- what T calls of mtl_lstm_cell_bwd + the dh_rec product produce.
  * workspace: mtl_lstm_layer_workspace() bytes of device memory, 256-byte aligned (4 KB header: arrival counter, per-workgroup step flags and the
- * error word -- u32 [1] != 0 after a timed-out wait -- followed by the backward's partial buffers).
+ * error word -- u32 [1] != 0 after a timed-out wait; sticky: launches do not clear it, the caller zeroes the workspace once and checks the
+ * word whenever it synchronises anyway -- followed by the backward's partial buffers).
  * mtl_lstm_layer_supported: 1 <= B <= 32 and H in {128, 256, 384, 512}; other shapes take the per-step calls. */
 int mtl_lstm_layer_supported(int B, int H);
 long mtl_lstm_layer_workspace(void);

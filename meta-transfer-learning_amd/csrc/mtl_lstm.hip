@@ -628,7 +628,7 @@ int mtl_lstm_stack_fwd(void* stream, const mtl_lstm_stack* layers, float mscale,
     if (!fill_stack(p, layers, NL, false)) return MTL_EINVAL;
     p.mscale = mscale, p.T = T, p.B = B, p.H = H, p.NL = NL, p.sync = reinterpret_cast<unsigned*>(workspace);
     hipStream_t s = as_stream(stream);
-    if (hipMemsetAsync(workspace, 0, HDR * 4, s) != hipSuccess) return MTL_ELAUNCH;
+    if (hipMemsetAsync(static_cast<char*>(workspace) + 256, 0, (HDR - 64) * 4, s) != hipSuccess) return MTL_ELAUNCH;      // the step flags; the error word [1] is sticky
     switch (H / 8) {
         case 16: return launch_stack_fwd<16>(p, s);
         case 32: return launch_stack_fwd<32>(p, s);
@@ -644,7 +644,7 @@ int mtl_lstm_stack_bwd(void* stream, const mtl_lstm_stack* layers, const float* 
     if (!fill_stack(p, layers, NL, true)) return MTL_EINVAL;
     p.dx_up = dx_up, p.p2 = scratch, p.mscale = mscale, p.T = T, p.B = B, p.H = H, p.NL = NL, p.sync = reinterpret_cast<unsigned*>(workspace);
     hipStream_t s = as_stream(stream);
-    if (hipMemsetAsync(workspace, 0, HDR * 4, s) != hipSuccess) return MTL_ELAUNCH;
+    if (hipMemsetAsync(static_cast<char*>(workspace) + 256, 0, (HDR - 64) * 4, s) != hipSuccess) return MTL_ELAUNCH;      // the step flags; the error word [1] is sticky
     switch (H / 8) {
         case 16: return launch_stack_bwd<16>(p, s);
         case 32: return launch_stack_bwd<32>(p, s);
@@ -657,7 +657,7 @@ int mtl_lstm_layer_fwd(void* stream, const float* gx, const float* w_hh, const f
                        float* xout, const unsigned char* mask, float mscale, int T, int B, int H, void* workspace) {
     if (!gx || !w_hh || !b_hh || !hall || !call || !acts || !workspace || T <= 0 || !mtl_lstm_layer_supported(B, H)) return MTL_EINVAL;
     hipStream_t s = as_stream(stream);
-    if (hipMemsetAsync(workspace, 0, 8, s) != hipSuccess) return MTL_ELAUNCH;
+    if (hipMemsetAsync(workspace, 0, 4, s) != hipSuccess) return MTL_ELAUNCH;      // the arrival counter; the error word [1] is sticky
     LstmP p{gx, w_hh, b_hh, hall, call, acts, xout, mask, mscale, T, B, H, reinterpret_cast<unsigned*>(workspace), nullptr, nullptr};
     switch (H / 8) {
         case 16: return launch_fwd<16>(p, s);
@@ -671,7 +671,7 @@ int mtl_lstm_layer_bwd(void* stream, const float* dx_up, const unsigned char* ma
                        const float* call, float* dG, int T, int B, int H, void* workspace) {
     if (!w_hh || !acts || !call || !dG || !workspace || T <= 0 || !mtl_lstm_layer_supported(B, H)) return MTL_EINVAL;
     hipStream_t s = as_stream(stream);
-    if (hipMemsetAsync(workspace, 0, 8, s) != hipSuccess) return MTL_ELAUNCH;
+    if (hipMemsetAsync(workspace, 0, 4, s) != hipSuccess) return MTL_ELAUNCH;      // the arrival counter; the error word [1] is sticky
     LstmP p{nullptr, w_hh, nullptr, nullptr, const_cast<float*>(call), const_cast<float*>(acts), nullptr, mask, mscale, T, B, H,
             reinterpret_cast<unsigned*>(workspace), dx_up, dG};
     switch (H / 8) {

@@ -116,6 +116,14 @@ class LMEngine:
         self.stacked = os.environ.get('MTL_LSTM_STACK', '1') != '0'
         self.sync_ws = torch.zeros(int(self.lib.mtl_lstm_layer_workspace()) // 4, dtype=torch.int32, device=device)
 
+    def check_handoff(self):
+        """The persistent LSTM kernels bound every grid-wide wait and set a sticky error word instead of hanging the device (e.g.
+        when their workgroups could not all become resident): raise here, where the caller has synchronised anyway."""
+        if int(self.sync_ws[1]) != 0:
+            self.sync_ws[1] = 0
+            raise RuntimeError('mtl_lstm: a grid-wide wait of a persistent LSTM launch timed out; its results are invalid '
+                               '(MTL_LSTM_STACK=0 / MTL_LSTM_PERSISTENT=0 select the per-layer / per-step launches)')
+
     def buf(self, name, shape, dtype=torch.float32):
         key = (name, tuple(int(v) for v in shape), dtype)
         t = self.pool.get(key)
@@ -381,6 +389,7 @@ class LMMetaTrainer:
             self._clip(self.G)                                                                # (:366-367)
         check(lib.mtl_axpy(st(), theta0.data_ptr(), self.G.data_ptr(), -float(self.lr), theta0.numel()), 'outer sgd')   # (:368)
         torch.cuda.synchronize(dev)
+        eng.check_handoff()
         batch_loss = sum(w[tid] * float(v) for v, tid in zip(val_losses, task_ids))
         return batch_loss, [float(t) for t in tr_losses]
 

@@ -255,3 +255,11 @@ def test_lm_persistent_lstm_layer_kernels(H, B, T, dropout, NL):
         errs = _errs(model, lp[4], oracle, grads)
         assert max(errs.values()) < 1e-4, (mode, max(errs.items(), key=lambda kv: kv[1]))
         assert float((lp[4] - ls[4]).norm() / ls[4].norm()) < 2e-6, mode      # the device paths: same arithmetic, other summation orders
+    # the error word is sticky across launches (they re-zero only their counters / flags) and surfaces as an exception
+    eng.check_handoff()
+    eng.sync_ws[1] = 1
+    eng.forward(model.flat_parameters, x.cuda(), y.cuda(), (h0.cuda(), c0.cuda()), dropout)
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match='timed out'):
+        eng.check_handoff()
+    eng.check_handoff()
