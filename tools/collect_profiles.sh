@@ -26,6 +26,7 @@ python tools/bench_gemm_x3.py 2> /dev/null | grep -v amdgpu.ids > $O/gemm_x3_vs_
 bash tools/pmc_gemm_x3.sh "ffn fwd (enc)" > /dev/null 2>&1; cp gpurun_out/pmc_x3/summary.txt $O/pmc_gemm_x3_ffn_fwd.txt
 python tools/bench_conv.py 2>/dev/null | grep h2 > $O/conv_random_data.txt
 MTL_BENCH_ZERO=1 python tools/bench_conv.py 2>/dev/null | grep h2 > $O/conv_zero_data.txt
+python tools/clock_probe.py 3 2>/dev/null | grep -v amdgpu.ids > $O/clock_probe.txt
 rm -rf $O/pmc_fetch $O/pmc_write
 find $O -name "*_kernel_trace.csv" -delete
 find $O -name "*agent_info.csv" -delete

@@ -13,4 +13,4 @@ cp $S/pmc_traffic.json profiles/pmc_traffic.json
 mkdir -p $D/lm
 cp $S/lm/bench_lm.json $S/lm/bench_lm_traced.json $D/lm/
 cp $S/lm/trace/lm_kernel_stats.csv $D/lm/kernel_stats.csv
-cp $S/gemm_x3_vs_fp32.txt $S/pmc_gemm_x3_ffn_fwd.txt $S/conv_random_data.txt $S/conv_zero_data.txt $D/
+cp $S/gemm_x3_vs_fp32.txt $S/pmc_gemm_x3_ffn_fwd.txt $S/conv_random_data.txt $S/conv_zero_data.txt $S/clock_probe.txt $D/
