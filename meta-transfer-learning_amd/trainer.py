@@ -205,7 +205,8 @@ def sync_replicas_from_rank0(model, opts):
 
 
 def check_replicas(model, val_batch, it):
-    """Cheap divergence check (two 3-element all-reduces): every rank must hold the same theta and must have drawn the same
+    """Cheap divergence check (two small all-reduces: float checksums of theta and the validation batch, bit-level integer
+    checksums of theta): every rank must hold the same theta and must have drawn the same
     shared validation batch (ManifestTaskDataset(seed=...) / the seeding contract in INTEGRATION.md).  Raises on a mismatch
     instead of letting the all-reduced meta-gradient silently mix gradients taken at different parameters."""
     if mdist.world_size() <= 1:
@@ -219,12 +220,23 @@ def check_replicas(model, val_batch, it):
         # (MIN / MAX never compare equal on NaN: without this check a numerical blow-up would be reported as a seeding problem)
         raise RuntimeError('iteration %d: non-finite parameters or validation batch on rank %d (checksums %s): the run diverged '
                            'numerically, this is not a replica mismatch' % (it + 1, mdist.rank(), probe.tolist()))
-    lo, hi = probe.clone(), probe.clone()
-    td.all_reduce(lo, op=td.ReduceOp.MIN)
-    td.all_reduce(hi, op=td.ReduceOp.MAX)
-    if not torch.equal(lo, hi):
-        raise RuntimeError('iteration %d: replicas diverged (theta / validation-batch checksums differ across ranks: %s vs %s); '
-                           'seed every rank identically (see INTEGRATION.md)' % (it + 1, lo.tolist(), hi.tolist()))
+    # float checksums: MAX of [p, -p] gives max and -min with one all-reduce
+    t = torch.cat([probe, -probe])
+    td.all_reduce(t, op=td.ReduceOp.MAX)
+    hi, lo = t[:3], -t[3:]
+    # bit-level checksums of theta (a localised or sign-cancelling divergence does not survive these): integer column sums of the
+    # raw 32-bit words, plain and position-weighted (wrap-around int64 arithmetic is deterministic)
+    bits = th.view(torch.int32)
+    n = bits.numel() // 4096 * 4096
+    cols = bits[:n].view(-1, 4096).sum(0, dtype=torch.int64)
+    tail = bits[n:].sum(dtype=torch.int64)
+    chk = torch.stack([cols.sum() + tail, (cols * torch.arange(1, 4097, dtype=torch.int64, device=th.device)).sum() + 7 * tail])
+    u = torch.cat([chk, -chk])
+    td.all_reduce(u, op=td.ReduceOp.MAX)
+    if not torch.equal(lo, hi) or not torch.equal(u[:2], -u[2:]):
+        raise RuntimeError('iteration %d: replicas diverged (theta / validation-batch checksums differ across ranks: %s vs %s, '
+                           'parameter bit checksums %s vs %s); seed every rank identically (see INTEGRATION.md)'
+                           % (it + 1, lo.tolist(), hi.tolist(), (-u[2:]).tolist(), u[:2].tolist()))
 
 
 def run_validation(forward_one_batch, model, vocab, valid_loader_list, it, args, history, loss_type, save_fn, criteria, stop_val,

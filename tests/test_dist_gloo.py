@@ -69,7 +69,7 @@ def _replica_worker(rank, world, port, ret):
     val = mtl_amd.synth_batch(3, 2, 64, 8, cfg['vocab_size'])
     val5 = (val[0], val[1], None, val[2], None)
     T.check_replicas(model, val5, 0)                                # identical replicas, identical validation batch: passes
-    raised = [False, False]
+    raised = [False, False, False]
     try:
         bad = mtl_amd.synth_batch(3 + rank, 2, 64, 8, cfg['vocab_size'])         # rank 1 drew a different validation batch
         T.check_replicas(model, (bad[0], bad[1], None, bad[2], None), 1)
@@ -81,16 +81,24 @@ def _replica_worker(rank, world, port, ret):
         T.check_replicas(model, val5, 2)
     except RuntimeError:
         raised[1] = True
+    if rank == 1:
+        model.flat_parameters[123] -= 1.0
+        a, b = float(model.flat_parameters[5]), float(model.flat_parameters[6])      # two entries swapped: every float checksum is
+        model.flat_parameters[5], model.flat_parameters[6] = b, a                    # unchanged, only the bit-level one sees it
+    try:
+        T.check_replicas(model, val5, 3)
+    except RuntimeError as e:
+        raised[2] = 'bit checksums' in str(e)
     ret[rank] = (bool(torch.equal(lo, hi)), adam.step_count, float(adam.m[0]), raised)
     mtl_amd.dist.barrier()
 
 
 def test_replicas_are_synchronised_at_start_and_divergence_is_detected():
     """trainer.sync_replicas_from_rank0 / check_replicas (the multi-rank contract of TransientTrainer.train): broadcast of theta,
-    Adam m / v / step from rank 0; a different validation batch or a drifted replica raises on EVERY rank."""
+    Adam m / v / step from rank 0; a different validation batch, a drifted replica, or two swapped entries (invisible to sums) raise on EVERY rank."""
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_replica_worker, args=(2, 29613, ret), nprocs=2, join=True)
     for rank in (0, 1):
         same, step, m0, raised = ret[rank]
-        assert same and step == 5 and m0 == 1.0 and raised == [True, True], (rank, ret[rank])
+        assert same and step == 5 and m0 == 1.0 and raised == [True, True, True], (rank, ret[rank])
