@@ -212,6 +212,27 @@ def peak_of(cls, unit, conv_mode, wgrad_x3_dense):
     return PEAK_F32_MFMA_TFLOPS, 'TFLOP/s', 'mfma'
 
 
+def dump_shapes(records):
+    """diagnostics (MTL_BENCH_SHAPES=<file>): per-shape time of the product / attention / LayerNorm launches of the profiled step"""
+    dump = os.environ.get('MTL_BENCH_SHAPES')
+    if not dump:
+        return
+    shapes = {}
+    for name, a, e0, e1 in records:
+        if name in ('mtl_gemm_f32_ex', 'mtl_gemm_f32_tb'):
+            key = 'gemm ta%d tb%d M%d N%d K%d b%d kb%d rs%d' % (a[1], a[2], a[3], a[4], a[5], a[17], a[26], 1 if a[29] else 0)
+        elif name in ('mtl_attn_fwd', 'mtl_attn_bwd', 'mtl_layernorm_fwd', 'mtl_layernorm_bwd', 'mtl_layernorm_fwd_g', 'mtl_layernorm_bwd_g'):
+            key = name + ' ' + ' '.join(str(v) for v in a if isinstance(v, int) and 0 <= v < 100000)
+        else:
+            continue
+        t = shapes.setdefault(key, [0, 0.0])
+        t[0] += 1
+        t[1] += e0.elapsed_time(e1) * 1e3
+    with open(dump, 'w') as f:
+        for key, (cnt, us) in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
+            f.write('%8.1f us total  %3d x %6.1f us   %s\n' % (us, cnt, us / cnt, key))
+
+
 def serial_profile(mtl, trainer, model, vocab, tasks, my_tasks, n_tasks, inner, outer, args, dev):
     """One extra meta-iteration with the side stream and command-list replay switched off (and one lane, where the tasks are not
     batched) and HIP events around EVERY launch: isolated durations (what rocprofv3 reports for a non-overlapped dispatch),
@@ -258,22 +279,7 @@ def serial_profile(mtl, trainer, model, vocab, tasks, my_tasks, n_tasks, inner, 
         c['time'] += e0.elapsed_time(e1) * 1e-3
         c['work'] += work or 0.0
         c['launches'] += 1
-    dump = os.environ.get('MTL_BENCH_SHAPES')
-    if dump:            # diagnostics: per-shape time of the product launches of the profiled step
-        shapes = {}
-        for name, a, e0, e1 in prof.records:
-            if name in ('mtl_gemm_f32_ex', 'mtl_gemm_f32_tb'):
-                key = 'gemm ta%d tb%d M%d N%d K%d b%d kb%d rs%d' % (a[1], a[2], a[3], a[4], a[5], a[17], a[26], 1 if a[29] else 0)
-            elif name in ('mtl_attn_fwd', 'mtl_attn_bwd', 'mtl_layernorm_fwd', 'mtl_layernorm_bwd', 'mtl_layernorm_fwd_g', 'mtl_layernorm_bwd_g'):
-                key = name + ' ' + ' '.join(str(v) for v in a if isinstance(v, int) and 0 <= v < 100000)
-            else:
-                continue
-            t = shapes.setdefault(key, [0, 0.0])
-            t[0] += 1
-            t[1] += e0.elapsed_time(e1) * 1e3
-        with open(dump, 'w') as f:
-            for key, (cnt, us) in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
-                f.write('%8.1f us total  %3d x %6.1f us   %s\n' % (us, cnt, us / cnt, key))
+    dump_shapes(prof.records)
     return classes, len(prof.records), wall
 
 
@@ -392,6 +398,7 @@ def main_lm(a, mtl_amd, mdist, dev, rank, world):
     one(a.warmup + a.steps)
     torch.cuda.synchronize(dev)
     eng.lib = real
+    dump_shapes(prof.records)
     classes = {}
     for name, args_, e0, e1 in prof.records:
         cls, work, unit, sym = classify(mtl_amd._lib.lib(), name, args_, False, False)

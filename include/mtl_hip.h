@@ -71,8 +71,10 @@ int mtl_gemm_f32_tb(void* stream, int transA, int transB, int M, int N, int K, f
                     long sBk, float* rowsum, long sRowsum, float* workspace, long workspace_bytes, long sBiasH, long sRowsumH,
                     int tasks, long sAt, long sBt, long sCt, long sBiasT, long sRowsumT);
 /* which engine mtl_gemm_f32_ex / _tb picks (16-byte aligned operands, not transA && transB): 2 = bf16-split engine
- * (gemm_x3_kernel<...>, below), 1 = small-tile (gemm16_kernel<...>), 0 = forwarded to mtl_gemm_f32 (gemm_kernel<...>); used by
- * bench.py to attribute launch timings to the rocprofv3 kernel classes */
+ * (gemm_x3_kernel<...>, below -- also its split-K form: a product with fewer tiles than the engine's threshold and K >= 4096 that is
+ * called with a workspace runs as equal K slices (batched launch into the workspace) + x3_splitk_sum_kernel, fixed order),
+ * 1 = small-tile (gemm16_kernel<...>), 0 = forwarded to mtl_gemm_f32 (gemm_kernel<...>); used by bench.py to attribute launch
+ * timings to the rocprofv3 kernel classes */
 int mtl_gemm_f32_ex_route(int M, int N, int K, int batch, int kbatch, int has_rowsum);
 /* Large products of mtl_gemm_f32_ex / _tb run on the bf16 matrix pipe: every fp32 operand element is split EXACTLY into three bf16
  * pieces on its way to LDS and a block product is six v_mfma_f32_32x32x16_bf16 accumulated in fp32 (a0 b0 + a0 b1 + a1 b0 + a1 b1 +

@@ -41,6 +41,9 @@ int mtl_gemm_x3_route(void* stream, int transA, int transB, int M, int N, int K,
                       long sRowsum, long sBiasH, long sRowsumH, int tasks, long sAt, long sBt, long sCt, long sBiasT, long sRowsumT);
 
 int mtl_gemm_x3_eligible(int M, int N, int batch);
+int mtl_gemm_x3_splitk_slices(int transA, int transB, int M, int N, int K, int flags, long ws_bytes);
+int mtl_gemm_x3_splitk(void* stream, int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda, const float* B,
+                       int ldb, float* C, int ldc, const float* bias, int flags, float* ws, long ws_bytes);
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 

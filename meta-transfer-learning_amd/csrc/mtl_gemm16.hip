@@ -360,7 +360,11 @@ static bool route_small(int M, int N, int K, int batch, int kbatch, bool rowsum)
     static const int f_small = getenv("MTL_G16_FORCE") ? atoi(getenv("MTL_G16_FORCE")) : 0;      // tuning knob
     // the big engine (64 x 64 / 128 x 128 tiles of v_mfma_f32_32x32x2_f32, split-K through the workspace) keeps every product
     // that fills the chip with its own tiles, and the few-tile / very-long-K ones (the 5120-deep input projection)
-    const bool small = f_small ? f_small > 0 : (tiles64 <= 320 && !(tiles32 < 48 && (long)K * kbatch >= 4096));
+    // ... and long-K products with few tiles (the LM decoder's dX: 700 x 512 x 10000 on 88 tiles): split-K over the chip instead of
+    // K groups inside 88 workgroups (176 -> 60 us)
+    static const long longk = getenv("MTL_G16_LONGK") ? atol(getenv("MTL_G16_LONGK")) : 4096;
+    const bool small = f_small ? f_small > 0
+                               : (tiles64 <= 320 && !(tiles32 < 48 && (long)K * kbatch >= 4096) && !(tiles64 <= 128 && (long)K * kbatch >= longk));
     return kbatch > 1 || rowsum || small;
 }
 
@@ -369,6 +373,8 @@ extern "C" {
 /* 1: this product runs on the small-tile engine (gemm16_kernel<...>), 0: it is forwarded to mtl_gemm_f32 (gemm_kernel<...>) */
 int mtl_gemm_f32_ex_route(int M, int N, int K, int batch, int kbatch, int has_rowsum) {
     if (mtl_gemm_x3_eligible(M, N, batch)) return 2;
+    // (split-K form of the same engine: assumes an NN / NT / TN call with 16-byte aligned operands and a workspace that holds the slices)
+    if (batch == 1 && kbatch == 1 && !has_rowsum && mtl_gemm_x3_splitk_slices(0, 0, M, N, K, 0, 1L << 40)) return 2;
     return route_small(M, N, K, batch, kbatch, has_rowsum != 0) ? 1 : 0;
 }
 
@@ -396,6 +402,10 @@ int mtl_gemm_f32_tb(void* stream, int transA, int transB, int M, int N, int K, f
         const int rc = mtl_gemm_x3_route(stream, transA, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, bias, gate, ldg, flags, batch, H,
                                          sAb, sAh, sBb, sBh, sCb, sCh, sBias, kbatch, sAk, sBk, rowsum, sRowsum, sBiasH, sRowsumH, tasks,
                                          sAt, sBt, sCt, sBiasT, sRowsumT);
+        if (rc != 0) return rc < 0 ? rc : MTL_OK;
+    }
+    if (batch == 1 && kbatch == 1 && H == 1 && !rowsum && !gate) {      // few tiles x very long K: split-K on the bf16-split engine
+        const int rc = mtl_gemm_x3_splitk(stream, transA, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, bias, flags, workspace, workspace_bytes);
         if (rc != 0) return rc < 0 ? rc : MTL_OK;
     }
     if (!route_small(M, N, K, batch, kbatch, rowsum != nullptr))

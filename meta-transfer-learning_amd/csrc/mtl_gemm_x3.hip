@@ -439,6 +439,71 @@ int mtl_gemm_x3_route(void* stream, int transA, int transB, int M, int N, int K,
     return rc == MTL_OK ? 1 : rc;
 }
 
+// Few output tiles x very long K (the LM decoder's dX: 700 x 512 x 10000, 24 tiles): the K range is split over the grid -- one
+// batched launch writes a partial per K slice into the workspace, a second kernel sums the slices in fixed order (+ bias, + C when
+// accumulating).  1: done, 0: not applicable (the caller takes its other engines), < 0: launch error.
+__global__ __launch_bounds__(256) void x3_splitk_sum_kernel(const float* __restrict__ ws, float* __restrict__ C, const float* __restrict__ bias,
+                                                            int M, int N, int ldc, int S, int accum) {
+    const long n4 = N / 4, total = (long)M * n4, slice = (long)M * N;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long m = i / n4, c = (i - m * n4) * 4;
+        float4 a = *reinterpret_cast<const float4*>(ws + m * N + c);
+        for (int q = 1; q < S; ++q) {
+            const float4 v = *reinterpret_cast<const float4*>(ws + q * slice + m * N + c);
+            a.x += v.x, a.y += v.y, a.z += v.z, a.w += v.w;
+        }
+        float4* dst = reinterpret_cast<float4*>(C + m * ldc + c);
+        if (bias) {
+            const float4 b = *reinterpret_cast<const float4*>(bias + c);
+            a.x += b.x, a.y += b.y, a.z += b.z, a.w += b.w;
+        }
+        if (accum) {
+            const float4 o = *dst;
+            a.x += o.x, a.y += o.y, a.z += o.z, a.w += o.w;
+        }
+        *dst = a;
+    }
+}
+
+// number of K slices the split-K form would use (0: not applicable)
+int mtl_gemm_x3_splitk_slices(int transA, int transB, int M, int N, int K, int flags, long ws_bytes) {
+    const int mt = min_tiles_now();
+    const long tiles = x3_tiles(M, N, 1, 128);
+    static const long longk = getenv("MTL_GEMM_X3_SPLITK") ? atol(getenv("MTL_GEMM_X3_SPLITK")) : 4096;
+    if (mt <= 0 || longk <= 0 || (transA && transB) || tiles >= mt || K < longk || (N & 3) || (flags & ~MTL_GEMM_ACCUM)) return 0;
+    // S slices of equal length (a multiple of 4 elements: 16-byte aligned slice starts), each >= 512 deep, enough of them to fill the chip
+    auto ok = [&](int c) { return K % c == 0 && (K / c) % 4 == 0 && K / c >= 512 && (long)c * M * N * 4 <= ws_bytes && tiles * c >= mt; };
+    const int want = (int)((256 + tiles - 1) / tiles);
+    for (int c = want; c >= 2; --c)
+        if (ok(c)) return c;
+    for (int c = want + 1; c <= 64; ++c)
+        if (ok(c)) return c;
+    return 0;
+}
+
+int mtl_gemm_x3_splitk(void* stream, int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda, const float* B,
+                       int ldb, float* C, int ldc, const float* bias, int flags, float* ws, long ws_bytes) {
+    if (!ws || (ldc & 3) || !al16(C) || (bias && !al16(bias)) || !al16(A) || !al16(B) || (lda & 3) || (ldb & 3)) return 0;
+    const int S = mtl_gemm_x3_splitk_slices(transA, transB, M, N, K, flags, ws_bytes);
+    if (!S) return 0;
+    const int Kc = K / S;
+    const long sA = transA ? (long)Kc * lda : Kc, sB = transB ? Kc : (long)Kc * ldb;
+    X3P p{A, B, ws, nullptr, nullptr, nullptr, M, N, Kc, lda, ldb, N, 0, alpha, 0, 1, sA, 0, sB, 0, (long)M * N, 0, 0, 1,
+          0, 0, 0, 0, 0, S, 0, 0, 0, 0, 0, S, nullptr, nullptr, 0, 0};
+    hipStream_t s = as_stream(stream);
+    const bool big = x3_tiles(M, N, S, 256) >= 224;
+    int rc;
+    if (!transA && transB) rc = launch_x3_bm<false, true, false>(p, s, big);
+    else if (!transA && !transB) rc = launch_x3_bm<false, false, false>(p, s, big);
+    else rc = launch_x3_bm<true, false, false>(p, s, big);
+    if (rc != MTL_OK) return rc;
+    const long total = (long)M * (N / 4);
+    hipLaunchKernelGGL(x3_splitk_sum_kernel, dim3((unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048)), dim3(256), 0, s, ws, C, bias, M, N, ldc, S,
+                       (flags & MTL_GEMM_ACCUM) ? 1 : 0);
+    MTL_CHECK_LAUNCH();
+    return 1;
+}
+
 extern "C" int mtl_gemm_h2_tb(void* stream, int transB, int M, int N, int K, const float* A, int lda, const float* amax_a, long sAmaxA,
                               const float* B, int ldb, const float* amax_b, long sAmaxB, float* C, int ldc, const float* bias,
                               const float* gate, int ldg, int tasks, long sAt, long sBt, long sCt, long sBiasT) {

@@ -1004,6 +1004,35 @@ def test_bf16_split_engine_contract(L, x3_forced, ta, tb, M, N, K):
     assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize('ta,tb', [(0, 0), (0, 1), (1, 0)])
+def test_bf16_split_engine_split_k(L, ta, tb):
+    """few output tiles x very long K (the LM decoder's dX, lm/model/rnn_model.py:56 backward: 700 x 512 x 10000): with a workspace
+    the product runs as K slices on the bf16-split engine + a fixed-order sum (bias once, += C when accumulating); without a
+    workspace, with a K that has no admissible slicing, or with ReLU it takes the other engines -- same results to fp32 rounding;
+    bitwise repeatable."""
+    g = torch.Generator().manual_seed(31 + ta * 2 + tb)
+    ws = torch.empty(4 << 20).cuda()
+    for M, N, K, flags in ((700, 512, 10000, 0), (300, 128, 4096, 2), (700, 512, 4099 * 2, 0), (260, 256, 8192, 1)):
+        A = torch.randn((K, M) if ta else (M, K), generator=g)
+        B = torch.randn((N, K) if tb else (K, N), generator=g)
+        bias, C0 = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+        want = (A.t() if ta else A).double() @ (B.t() if tb else B).double() + bias.double()
+        if flags & 1:
+            want = want.clamp_min(0)
+        if flags & 2:
+            want = want + C0.double()
+        dA, dB, db = dev(A), dev(B), dev(bias)
+        outs = []
+        for w in (ws, ws, None):
+            C = dev(C0.clone())
+            assert L.mtl_gemm_f32_ex(st(), ta, tb, M, N, K, 1.0, dA.data_ptr(), A.shape[1], dB.data_ptr(), B.shape[1], C.data_ptr(), N,
+                                     db.data_ptr(), None, 0, flags, 1, 1, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, None, 0,
+                                     w.data_ptr() if w is not None else None, w.numel() * 4 if w is not None else 0, 0, 0) == 0
+            assert rel(C, want) < 3e-6, (M, N, K, flags, w is None)
+            outs.append(C)
+        assert torch.equal(outs[0], outs[1])
+
+
 def test_bf16_split_engine_k_batching_row_sums_and_tasks(L, x3_forced):
     """the remaining parts of the contract on the bf16-split engine: C += sum_z A_z . B_z inside one launch with a ragged K
     (the masked main loop), row sums of op(A) as a by-product of transposed-A products (both tile configurations), and the third
