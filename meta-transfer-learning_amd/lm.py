@@ -182,7 +182,11 @@ class LMEngine:
         if not getattr(self, '_zpe_ok', None) == (R, E):
             zpe.zero_()
             self._zpe_ok = (R, E)
-        emb = self.buf('emb', (R, E))
+        # with E == H the inputs of the weight-gradient products -- per layer x_l (R x H) and the previous states hall_l[:T] (R x H)
+        # -- live in ONE arena [layer][x, hall] with constant strides, and the gate gradients in one [layer] stack: backward() then
+        # forms all 2 NL weight gradients (+ bias gradients) with a single batched product instead of 2 NL small ones
+        arena = self.buf('wg_arena', (NL, 2, (T + 1) * B * H)) if (E == H and NL > 1) else None
+        emb = arena[0, 0, :R * E].view(R, E) if arena is not None else self.buf('emb', (R, E))
         m_emb = mask('m_emb', R * E, 1)
         check(lib.mtl_embed_pe_fwd(st, ids.data_ptr(), o('encoder.weight'), zpe.data_ptr(), emb.data_ptr(), R, R, E,
                                    m_emb.data_ptr() if m_emb is not None else None, sc), 'embed')
@@ -193,12 +197,13 @@ class LMEngine:
         stacked = self.persistent and self.stacked and NL > 1 and bool(lib.mtl_lstm_stack_supported(B, H, NL))
         desc = _lib.LstmStack() if stacked else None
         for l in range(NL):
-            hall = self.buf('hall%d' % l, (T + 1, B, H))
+            hall = arena[l, 1].view(T + 1, B, H) if arena is not None else self.buf('hall%d' % l, (T + 1, B, H))
             call = self.buf('call%d' % l, (T + 1, B, H))
             hall[0].copy_(h0[l])
             call[0].copy_(c0[l])
             acts = self.buf('acts%d' % l, (R, 4 * H))
-            xout = self.buf('xout%d' % l, (R, H))               # this layer's output after its dropout (next layer's / decoder's input)
+            # this layer's output after its dropout (next layer's / decoder's input)
+            xout = arena[l + 1, 0, :R * H].view(R, H) if (arena is not None and l + 1 < NL) else self.buf('xout%d' % l, (R, H))
             msk = mask('m_l%d' % l, R * H, 2 + l)
             whh, bhh = o('rnn.weight_hh_l%d' % l), o('rnn.bias_hh_l%d' % l)
             layers.append(dict(x=xin, kin=kin, hall=hall, call=call, acts=acts, mask=msk))
@@ -241,7 +246,7 @@ class LMEngine:
             lse, hyp, rowloss, loss = self.buf('lse', (R,)), self.buf('hyp', (R,), torch.int64), self.buf('rowloss', (R,)), self.buf('loss', (1,))
             check(lib.mtl_ce_argmax_fwd(st, logits.data_ptr(), gold.data_ptr(), R, V, V, -1, 0.0, R, None, lse.data_ptr(), hyp.data_ptr(),
                                         rowloss.data_ptr(), loss.data_ptr()), 'ce_fwd')     # nn.CrossEntropyLoss(): mean over all T*B rows
-        self.saved = dict(theta=theta, T=T, B=B, layers=layers, last=xin, m_emb=m_emb, sc=sc, ids=ids, chains=chains, stacked=stacked)
+        self.saved = dict(theta=theta, T=T, B=B, layers=layers, last=xin, m_emb=m_emb, sc=sc, ids=ids, chains=chains, stacked=stacked, arena=arena)
         return dict(logits=logits, loss=loss, hidden=(hn.clone(), cn.clone()))
 
     def backward(self, grad, scale=1.0):
@@ -265,14 +270,15 @@ class LMEngine:
         self.gemm(1, 0, V, H, R, dlog.data_ptr(), ldd, last.data_ptr(), H, g('decoder.weight'), H, flags=ACCUM, rowsum=g('decoder.bias'))
         dx = self.buf('dx_out', (R, H))
         self.gemm(0, 0, R, H, V, dlog.data_ptr(), ldd, o('decoder.weight'), H, dx.data_ptr(), H)
-        stacked = S['stacked']
+        stacked, arena = S['stacked'], S['arena']
+        dGs = self.buf('dG_all', (NL, R, 4 * H))
         if stacked:
             desc = _lib.LstmStack()
             for l in range(NL):
                 Ly = S['layers'][l]
                 desc.w_ih[l], desc.w_hh[l] = o('rnn.weight_ih_l%d' % l), o('rnn.weight_hh_l%d' % l)
                 desc.call[l], desc.acts[l] = Ly['call'].data_ptr(), Ly['acts'].data_ptr()
-                desc.dG[l] = self.buf('dG%d' % l, (R, 4 * H)).data_ptr()
+                desc.dG[l] = dGs[l].data_ptr()
                 desc.mask[l] = Ly['mask'].data_ptr() if Ly['mask'] is not None else None
             scratch = self.buf('stack_scratch', (int(lib.mtl_lstm_stack_scratch(T, B, H, NL)) // 4,))
             check(lib.mtl_lstm_stack_bwd(st, ctypes.byref(desc), dx.data_ptr(), sc, scratch.data_ptr(), T, B, H, NL, self.sync_ws.data_ptr()),
@@ -280,7 +286,7 @@ class LMEngine:
         for l in reversed(range(NL)):
             Ly = S['layers'][l]
             kin = Ly['kin']
-            dG = self.buf('dG%d' % l, (R, 4 * H))
+            dG = dGs[l]
             dh_rec, dc = self.buf('dh_rec', (B, H)), [self.buf('dc_a', (B, H)), self.buf('dc_b', (B, H))]
             whh = o('rnn.weight_hh_l%d' % l)
             msk = Ly['mask']
@@ -297,10 +303,25 @@ class LMEngine:
                 if t > 0:
                     self.gemm(0, 0, B, H, 4 * H, dG.data_ptr() + 16 * t * B * H, 4 * H, whh, H, dh_rec.data_ptr(), H)
             # parameter gradients over all T steps at once; both bias gradients are colsum(dG)
-            self.gemm(1, 0, 4 * H, H, R, dG.data_ptr(), 4 * H, Ly['hall'].data_ptr(), H, g('rnn.weight_hh_l%d' % l), H, flags=ACCUM,
-                      rowsum=g('rnn.bias_hh_l%d' % l))
-            self.gemm(1, 0, 4 * H, kin, R, dG.data_ptr(), 4 * H, Ly['x'].data_ptr(), kin, g('rnn.weight_ih_l%d' % l), kin, flags=ACCUM,
-                      rowsum=g('rnn.bias_ih_l%d' % l))
+            if arena is None:
+                self.gemm(1, 0, 4 * H, H, R, dG.data_ptr(), 4 * H, Ly['hall'].data_ptr(), H, g('rnn.weight_hh_l%d' % l), H, flags=ACCUM,
+                          rowsum=g('rnn.bias_hh_l%d' % l))
+                self.gemm(1, 0, 4 * H, kin, R, dG.data_ptr(), 4 * H, Ly['x'].data_ptr(), kin, g('rnn.weight_ih_l%d' % l), kin, flags=ACCUM,
+                          rowsum=g('rnn.bias_ih_l%d' % l))
+            elif l == 0:
+                # all layers' (weight_ih, weight_hh, bias_ih, bias_hh) gradients as ONE product batched over [layer][ih, hh]: A = dG_l
+                # (shared by the pair), B = arena[l][x_l | hall_l], C / row sums at the parameters' own offsets (constant strides
+                # because every layer has input width H here)
+                po = lambda n: Lo.off(n)
+                lay = po('rnn.weight_ih_l1') - po('rnn.weight_ih_l0')
+                assert all(po('rnn.%s_l%d' % (n, q)) - po('rnn.%s_l0' % n) == q * lay for q in range(NL)
+                           for n in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh'))
+                half = (T + 1) * B * H
+                check(lib.mtl_gemm_f32_ex(st, 1, 0, 4 * H, H, R, 1.0, dGs.data_ptr(), 4 * H, arena.data_ptr(), H, g('rnn.weight_ih_l0'), H,
+                                          None, None, 0, ACCUM, 2 * NL, 2, R * 4 * H, 0, 2 * half, half, lay,
+                                          po('rnn.weight_hh_l0') - po('rnn.weight_ih_l0'), 0, 1, 0, 0, g('rnn.bias_ih_l0'), lay,
+                                          self.ws.data_ptr(), self.ws.numel() * 4, 0, po('rnn.bias_hh_l0') - po('rnn.bias_ih_l0')),
+                      'lstm weight gradients')
             if stacked and l > 0:
                 continue                                          # the stack kernel has handed the input gradient down itself
             dxin = self.buf('dx_in%d' % l, (R, kin))

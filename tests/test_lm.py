@@ -198,16 +198,16 @@ def test_lm_meta_step_matches_oracle_restatement():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('H,B,T,dropout,NL', [(128, 5, 9, 0.0, 2), (256, 7, 6, 0.3, 3), (512, 20, 35, 0.2, 2), (384, 32, 4, 0.0, 2),
-                                              (512, 20, 1, 0.0, 2), (256, 3, 5, 0.5, 1)])
-def test_lm_persistent_lstm_layer_kernels(H, B, T, dropout, NL):
+@pytest.mark.parametrize('H,B,T,dropout,NL,E', [(128, 5, 9, 0.0, 2, 48), (256, 7, 6, 0.3, 3, 48), (512, 20, 35, 0.2, 2, 48), (384, 32, 4, 0.0, 2, 48),
+                                                (512, 20, 1, 0.0, 2, 48), (256, 3, 5, 0.5, 1, 48), (128, 6, 7, 0.3, 2, 128), (256, 4, 5, 0.0, 3, 256)])
+def test_lm_persistent_lstm_layer_kernels(H, B, T, dropout, NL, E):
     """csrc/mtl_lstm.hip -- the layer stack as one wavefront launch per direction ('stack': layers one step apart, per-step hand-offs
     within and between layers) and one launch per layer and direction ('layers') -- against the oracle and against the per-step path
     (recurrent product + cell kernel per step) on the same batch, parameters, carried state and dropout masks: logits, loss, new
     hidden state, every gradient tensor; each persistent mode runs twice to show the launch is reproducible bit for bit
     (fixed-order reductions, re-zeroed arrival counters) and that no wait timed out."""
     import mtl_amd
-    V, E = 300, 48
+    V = 300          # (E == H: the weight-gradient inputs share one arena and all 2 NL weight gradients are ONE batched product)
     torch.manual_seed(3)
     model = mtl_amd.lm.RNNModel('LSTM', V, E, H, NL, dropout).cuda()
     model.train()
@@ -229,7 +229,7 @@ def test_lm_persistent_lstm_layer_kernels(H, B, T, dropout, NL):
         eng.backward(grad, 1.0)
         torch.cuda.synchronize()
         res = (out['logits'].clone(), float(out['loss']), out['hidden'][0].clone(), out['hidden'][1].clone(), grad)
-        assert eng.saved['stacked'] == (mode == 'stack' and NL > 1)
+        assert eng.saved['stacked'] == (mode == 'stack' and NL > 1) and (eng.saved['arena'] is not None) == (E == H and NL > 1)
         if mode in runs:
             for a, b in zip(res, runs[mode]):
                 assert (a == b) if isinstance(a, float) else torch.equal(a, b)
