@@ -141,7 +141,7 @@ class LMEngine:
                                        0, 0, 0, 1, 0, 0, rowsum, 0, self.ws.data_ptr(), self.ws.numel() * 4, 0, 0), 'mtl_gemm_f32_ex')
 
     def _chains(self, ids_host):
-        """occurrence chains for the deterministic embedding scatter-add (mtl_embed_bwd)"""
+        """occurrence chains for the deterministic embedding scatter-add (mtl_embed_bwd); runs on the device `ids_host` lives on"""
         flat = ids_host.reshape(-1)
         order = torch.argsort(flat, stable=True)
         srt = flat[order]
@@ -161,7 +161,9 @@ class LMEngine:
         R, H, E, V, NL = T * B, m.nhid, m.ninp, m.ntoken, m.nlayers
         P = theta.data_ptr()
         o = lambda n: P + 4 * Lo.off(n)
-        xh = x.detach().to('cpu', torch.int64).contiguous()
+        # token ids and the occurrence chains of the embedding scatter-add: where the batch already lives (a device batch is indexed
+        # with device ops -- a read-back here would drain the stream once per pass and leave the GPU idle while the host enqueues)
+        xh = x.detach().to(torch.int64).contiguous()
         ids = self.buf('ids', (R,), torch.int64)
         ids.copy_(xh.reshape(-1), non_blocking=True)
         chains = self.buf('chains', (2, R), torch.int32)
@@ -169,7 +171,8 @@ class LMEngine:
         sc = 1.0 / (1.0 - dropout_p) if dropout_p > 0 else 1.0
         seed = self.buf('seed', (1,), torch.int64)
         if dropout_p > 0:
-            seed.copy_(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64), non_blocking=True)
+            # (drawn from the generator of the batch's device: a pageable host tensor would make the copy wait for the stream)
+            seed.copy_(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64, device=xh.device), non_blocking=True)
 
         def mask(name, n, site):
             if dropout_p <= 0:
