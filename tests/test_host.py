@@ -58,6 +58,23 @@ def test_decoder_io_matches_oracle():
     ra, rb = R.decoder_io(y)
     assert torch.equal(a, ra) and torch.equal(b, rb)
     assert a.tolist()[0] == [1, 5, 6, 7, 2, 2] and b.tolist()[0] == [5, 6, 7, 2, 0, 0]
+    # ragged batches (empty rows, pads in the middle of a row -- the reference drops pads wherever they stand, modules/decoder.py:57),
+    # with and without a forced width: the vectorised host prep against the oracle's per-row restatement
+    g = torch.Generator().manual_seed(0)
+    for trial in range(100):
+        B, L = int(torch.randint(1, 9, (1,), generator=g)), int(torch.randint(1, 20, (1,), generator=g))
+        t = torch.randint(3, 30, (B, L), generator=g)
+        for i in range(B):
+            n = int(torch.randint(0, L + 1, (1,), generator=g))
+            t[i, n:] = 0
+            if trial % 3 == 0 and n > 2:
+                t[i, 1] = 0
+        ra, rb = R.decoder_io(t)
+        a, b = eng.decoder_io(t)
+        assert torch.equal(a, ra) and torch.equal(b, rb), trial
+        a, b = eng.decoder_io(t, width=L + 3)
+        assert torch.equal(a[:, :ra.shape[1]], ra) and torch.equal(b[:, :rb.shape[1]], rb) and a.shape[1] == max(L + 3, ra.shape[1])
+        assert bool((a[:, ra.shape[1]:] == 2).all()) and bool((b[:, rb.shape[1]:] == 0).all())
 
 
 def test_vocab_manifest_and_sampling(tmp_path):
