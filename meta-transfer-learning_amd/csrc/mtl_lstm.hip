@@ -20,6 +20,8 @@
 
 namespace {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 constexpr int LU = 8;                        // hidden units per workgroup
 constexpr unsigned SPIN_LIMIT = 1u << 22;    // polls before a wait gives up (~seconds): sets the error word
 constexpr int HDR = 1024;                    // workspace header in 4-byte words: [0] arrival counter (single-layer kernels), [1] error word,
@@ -329,7 +331,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     unsigned* xin = p.sync + 64 + 64 * (MAXL + l);           // step flags of the input-product group of layer l
     unsigned* low = p.sync + 64 + 64 * (l > 0 ? l - 1 : 0);
     unsigned* err = p.sync + 1;
-    float w[2][KH];
+    f32x2 w[KH];      // {row 2 rp, row 2 rp + 1} at column kc KH + i: one packed FMA (v_pk_fma_f32) per column, the state value broadcast
     {
         const float* wsrc = xgroup ? p.wih[l] : p.whh[l];
 #pragma unroll
@@ -339,7 +341,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 #pragma unroll
             for (int i = 0; i < KH; i += 4) {
                 const float4 v = *reinterpret_cast<const float4*>(wrow + i);
-                w[q][i] = v.x, w[q][i + 1] = v.y, w[q][i + 2] = v.z, w[q][i + 3] = v.w;
+                w[i][q] = v.x, w[i + 1][q] = v.y, w[i + 2][q] = v.z, w[i + 3][q] = v.w;
             }
         }
     }
@@ -366,20 +368,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 #pragma unroll 1
         for (int b = 0; b < B; ++b) {
             const float* hb = hs + b * H + kc * KH;
-            float a0 = 0.f, a1 = 0.f;
+            f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};       // two independent chains (one wave per SIMD: nothing else hides the FMA latency)
 #pragma unroll
             for (int i = 0; i < KH; i += 4) {
                 const float4 hv = *reinterpret_cast<const float4*>(hb + i);
-                a0 = fmaf(w[0][i], hv.x, a0);
-                a1 = fmaf(w[1][i], hv.x, a1);
-                a0 = fmaf(w[0][i + 1], hv.y, a0);
-                a1 = fmaf(w[1][i + 1], hv.y, a1);
-                a0 = fmaf(w[0][i + 2], hv.z, a0);
-                a1 = fmaf(w[1][i + 2], hv.z, a1);
-                a0 = fmaf(w[0][i + 3], hv.w, a0);
-                a1 = fmaf(w[1][i + 3], hv.w, a1);
+                a0 = __builtin_elementwise_fma(w[i], f32x2{hv.x, hv.x}, a0);
+                a1 = __builtin_elementwise_fma(w[i + 1], f32x2{hv.y, hv.y}, a1);
+                a0 = __builtin_elementwise_fma(w[i + 2], f32x2{hv.z, hv.z}, a0);
+                a1 = __builtin_elementwise_fma(w[i + 3], f32x2{hv.w, hv.w}, a1);
             }
-            *reinterpret_cast<float2*>(red + (kc * B + b) * 32 + 2 * rp) = make_float2(a0, a1);
+            *reinterpret_cast<float2*>(red + (kc * B + b) * 32 + 2 * rp) = make_float2(a0.x + a1.x, a0.y + a1.y);
         }
         __syncthreads();
     };
@@ -484,26 +482,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll 1
         for (int b = 0; b < B; ++b) {
             const float* gb = dgs + b * 32;
-            float a[JT];
+            if constexpr (JT == 2) {
+                // two output units per thread: one packed FMA (v_pk_fma_f32) per weight pair, the dG operand broadcast to both halves;
+                // two accumulator pairs keep the dependent chains at half the length
+                f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
 #pragma unroll
-            for (int c = 0; c < JT; ++c) a[c] = 0.f;
-#pragma unroll
-            for (int r = 0; r < 32; r += 4) {
-                const float4 gv = *reinterpret_cast<const float4*>(gb + r);
-#pragma unroll
-                for (int c = 0; c < JT; ++c) {
-                    a[c] = fmaf(gv.x, ww[r][c], a[c]);
-                    a[c] = fmaf(gv.y, ww[r + 1][c], a[c]);
-                    a[c] = fmaf(gv.z, ww[r + 2][c], a[c]);
-                    a[c] = fmaf(gv.w, ww[r + 3][c], a[c]);
+                for (int r = 0; r < 32; r += 4) {
+                    const float4 gv = *reinterpret_cast<const float4*>(gb + r);
+                    a0 = __builtin_elementwise_fma(f32x2{ww[r][0], ww[r][1]}, f32x2{gv.x, gv.x}, a0);
+                    a1 = __builtin_elementwise_fma(f32x2{ww[r + 1][0], ww[r + 1][1]}, f32x2{gv.y, gv.y}, a1);
+                    a0 = __builtin_elementwise_fma(f32x2{ww[r + 2][0], ww[r + 2][1]}, f32x2{gv.z, gv.z}, a0);
+                    a1 = __builtin_elementwise_fma(f32x2{ww[r + 3][0], ww[r + 3][1]}, f32x2{gv.w, gv.w}, a1);
                 }
-            }
-            if (JT == 2) {
-                const unsigned long long u = (unsigned long long)__builtin_bit_cast(unsigned, a[0]) |
-                                             ((unsigned long long)__builtin_bit_cast(unsigned, a[JT - 1]) << 32);
+                const float lo = a0.x + a1.x, hi = a0.y + a1.y;
+                const unsigned long long u = (unsigned long long)__builtin_bit_cast(unsigned, lo) | ((unsigned long long)__builtin_bit_cast(unsigned, hi) << 32);
                 __hip_atomic_store(reinterpret_cast<unsigned long long*>(out + (long)b * H), u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else {
-                store_shared(out + (long)b * H, a[0]);
+                float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+                for (int r = 0; r < 32; r += 4) {
+                    const float4 gv = *reinterpret_cast<const float4*>(gb + r);
+                    a0 = fmaf(gv.x, ww[r][0], a0);
+                    a1 = fmaf(gv.y, ww[r + 1][0], a1);
+                    a0 = fmaf(gv.z, ww[r + 2][0], a0);
+                    a1 = fmaf(gv.w, ww[r + 3][0], a1);
+                }
+                store_shared(out + (long)b * H, a0 + a1);
             }
         }
     };
