@@ -400,17 +400,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         }
         return;
     }
-#pragma unroll 1
-    for (int t = 0; t < T; ++t) {
-        float gxv[4] = {0.f, 0.f, 0.f, 0.f};                    // this step's input contributions: requested before the wait
-        if (l > 0) flags_wait(xin, nwg, (unsigned)(t + 1), err);      // (its group runs ahead: normally satisfied at once)
+    // input contributions W_ih x_t + b_ih of this thread's cell.  Layer 0: plain loads issued before the step's wait.  Layers >= 1:
+    // written by the input-product group during this launch -- the values of step t + 1 are fetched (after a wait on that group,
+    // which runs ahead) at the END of step t, in the shadow of the step's own hand-off, so a step has ONE wait on its critical path
+    float gxn[4] = {0.f, 0.f, 0.f, 0.f};
+    auto fetch_gx = [&](int t) {
+        if (l > 0) flags_wait(xin, nwg, (unsigned)(t + 1), err);
         if (cell) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const float* q = gx + ((long)t * B + cb) * 4 * H + g * H + cj;
-                gxv[g] = l > 0 ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *q;
+                gxn[g] = l > 0 ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *q;
             }
         }
+    };
+    if (l > 0) fetch_gx(0);
+#pragma unroll 1
+    for (int t = 0; t < T; ++t) {
+        if (l == 0) fetch_gx(t);
+        float gxv[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) gxv[g] = gxn[g];
         if (t > 0) flags_wait(own, nwg, (unsigned)t, err);     // every workgroup of this layer has published h_t
         product(hall + (long)t * B * H);
         if (cell) {
@@ -436,6 +446,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
             c_prev = cn;
         }
         flags_arrive(own + wg, (unsigned)(t + 1));      // also after the last step: the group above waits for it
+        if (l > 0 && t + 1 < T) fetch_gx(t + 1);
     }
 }
 
@@ -520,6 +531,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
         return s0 + s1;
     };
+    // gradient into this layer's output from the layer above: the sum of its input-gradient partials of step t.  The layer above
+    // acknowledges the partial of step t with the arrival of step t - 1 (the final one for t <= 1).
+    float dh_up_next = 0.f;
+    auto gather_up = [&](int t) {
+        const int k = T - t + 1 < T ? T - t + 1 : T;
+        flags_wait(up, nwg, (unsigned)k, err);
+        if (cell) dh_up_next = gather(P2r + (long)t * pbuf + (long)cb * H + cj);
+    };
+    if (!top) gather_up(T - 1);
 #pragma unroll 1
     for (int t = T - 1; t >= 0; --t) {
         float dh_rec = 0.f, dh_up = 0.f, ai = 0.f, af = 0.f, ag = 0.f, ao = 0.f, cc = 0.f, cprev = 0.f, keep = 1.f;
@@ -532,12 +552,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             ai = ac[0], af = ac[H], ag = ac[2 * H], ao = ac[3 * H];
             cc = call[e + (long)B * H], cprev = call[e];
         }
-        if (!top) {
-            // the layer above acknowledges its input-gradient partial of step t with the arrival of step t - 1 (the final one for t <= 1)
-            const int k = T - t + 1 < T ? T - t + 1 : T;
-            flags_wait(up, nwg, (unsigned)k, err);
-            if (cell) dh_up = gather(P2r + (long)t * pbuf + (long)cb * H + cj);
-        }
+        if (!top) dh_up = dh_up_next;        // gathered at the end of the previous iteration (below), off this step's critical path
         dh_up *= keep;
         if (t < T - 1) {
             flags_wait(own, nwg, (unsigned)(T - 1 - t), err);
@@ -562,6 +577,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             flags_arrive(own + wg, (unsigned)(T - t));
         }
         if (l > 0 && active) partial(wi, P2w + (long)t * pbuf + jt);     // in the shadow of the hand-off; acknowledged by the next arrival
+        if (!top && t > 0) gather_up(t - 1);                             // likewise: the next step's input gradient
     }
     if (l > 0) flags_arrive(own + wg, (unsigned)T);
 }
