@@ -462,8 +462,8 @@ def physical_cores():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--tasks', type=int, default=8)
     ap.add_argument('--k', type=int, default=8)
     ap.add_argument('--frames', type=int, default=1000)
