@@ -199,7 +199,8 @@ def test_lm_meta_step_matches_oracle_restatement():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('H,B,T,dropout,NL,E', [(128, 5, 9, 0.0, 2, 48), (256, 7, 6, 0.3, 3, 48), (512, 20, 35, 0.2, 2, 48), (384, 32, 4, 0.0, 2, 48),
-                                                (512, 20, 1, 0.0, 2, 48), (256, 3, 5, 0.5, 1, 48), (128, 6, 7, 0.3, 2, 128), (256, 4, 5, 0.0, 3, 256)])
+                                                (512, 20, 1, 0.0, 2, 48), (256, 3, 5, 0.5, 1, 48), (128, 6, 7, 0.3, 2, 128), (256, 4, 5, 0.0, 3, 256),
+                                                (512, 20, 35, 0.2, 2, 512)])
 def test_lm_persistent_lstm_layer_kernels(H, B, T, dropout, NL, E):
     """csrc/mtl_lstm.hip -- the layer stack as one wavefront launch per direction ('stack': layers one step apart, per-step hand-offs
     within and between layers) and one launch per layer and direction ('layers') -- against the oracle and against the per-step path
@@ -207,7 +208,9 @@ def test_lm_persistent_lstm_layer_kernels(H, B, T, dropout, NL, E):
     hidden state, every gradient tensor; each persistent mode runs twice to show the launch is reproducible bit for bit
     (fixed-order reductions, re-zeroed arrival counters) and that no wait timed out."""
     import mtl_amd
-    V = 300          # (E == H: the weight-gradient inputs share one arena and all 2 NL weight gradients are ONE batched product)
+    # E == H: the weight-gradient inputs share one arena and all 2 NL weight gradients are ONE batched product; the last case is the
+    # bench configuration's layer shapes with a vocabulary deep enough (K = 5120) for the decoder's dX to take the split-K form
+    V = 5120 if E == 512 else 300
     torch.manual_seed(3)
     model = mtl_amd.lm.RNNModel('LSTM', V, E, H, NL, dropout).cuda()
     model.train()
