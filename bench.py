@@ -298,21 +298,22 @@ def timed_steps(trainer, model, vocab, tasks, my_tasks, n_tasks, inner, outer, a
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     host = 0.0
-    # the loop of TransientTrainer.train: iteration i + 1 is enqueued before iteration i's read-backs are resolved (loss, CER
-    # strings: host work that would otherwise be GPU idle time); every one of the K iterations is resolved INSIDE the timed span
+    # the loop of TransientTrainer.train: up to `pipeline_depth` iterations are enqueued beyond the one whose read-backs are being
+    # resolved (loss, CER strings: host work that would otherwise be GPU idle time); every one of the K iterations is resolved INSIDE
+    # the timed span
     pipelined = getattr(trainer, 'pipeline', False) and hasattr(trainer, 'enqueue_iteration')
-    pending = None
+    depth = max(getattr(trainer, 'pipeline_depth', 1), 1)
+    pending = []
     for _ in range(steps):
         if pipelined:
-            nxt = trainer.enqueue_iteration(model, vocab, local, val, n_tasks, inner, outer, args)
-            if pending is not None:
-                last = pending.result()
-            pending = nxt
+            pending.append(trainer.enqueue_iteration(model, vocab, local, val, n_tasks, inner, outer, args))
+            while len(pending) > depth:
+                last = pending.pop(0).result()
         else:
             last = one()
         host += getattr(trainer, 'host_enqueue_s', 0.0)
-    if pending is not None:
-        last = pending.result()
+    while pending:
+        last = pending.pop(0).result()
     HOST_ENQUEUE['ms_per_step'] = host / steps * 1e3     # host time to enqueue a step (the rest of the span it waits for the GPU)
     torch.cuda.synchronize(dev)
     mdist.barrier()
@@ -570,8 +571,8 @@ def main():
                                schedule=('serial, ' if a.serial else '') + (
                                    'the %d local tasks as ONE task-batched pass per phase (training passes at theta0, validation passes at the theta\' stack)'
                                    % len(my_tasks) if (trainer.batch_tasks and len(my_tasks) > 1) else '%d task lanes' % model.n_lanes) + (
-                                   '' if a.serial else ' + side stream, command-list replay %s, host one iteration ahead %s'
-                                   % ('on' if trainer.use_cmdlists else 'off', 'on' if trainer.pipeline else 'off')),
+                                   '' if a.serial else ' + side stream, command-list replay %s, host up to %d iteration(s) ahead'
+                                   % ('on' if trainer.use_cmdlists else 'off', getattr(trainer, 'pipeline_depth', 0))),
                                conv_arithmetic={'h2': '3x3 convolutions on 2-way fp16 splits of power-of-two-scaled fp32 operands (22 '
                                                       'significand bits, 3 fp16 MFMAs per step), fp32 accumulate: error <= 2.5x that of an '
                                                       'fp32 convolution against fp64 (tests/test_ops_gpu.py), parity bar unchanged',

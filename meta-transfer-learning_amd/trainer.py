@@ -321,6 +321,10 @@ class TransientTrainer():
         self.batch_tasks = os.environ.get('MTL_BATCH_TASKS', '1') != '0'
         # train() enqueues iteration i + 1 before it resolves (logs) iteration i (enqueue_iteration); MTL_PIPELINE=0: resolve at once
         self.pipeline = os.environ.get('MTL_PIPELINE', '1') != '0'
+        # how many iterations may be enqueued beyond the one being resolved (nothing the host needs to enqueue an iteration comes
+        # from the device): 1 hides the host's per-iteration work, 2 also rides out host stalls of up to one iteration's GPU time
+        # (shared hosts: measured enqueue times of 5 - 90 ms for the same iteration).  Read-back buffer sets: depth + 1.
+        self.pipeline_depth = max(1, int(os.environ.get('MTL_PIPELINE_DEPTH', '2'))) if self.pipeline else 0
         self._turn = 0
 
     # ------------------------------------------------------------------ drop-in single-batch API
@@ -682,10 +686,10 @@ class TransientTrainer():
         it and returns a PendingIteration whose result() resolves the loss / label read-backs.  Nothing the host needs to enqueue
         iteration i + 1 comes from the device, so train() (and bench.py) enqueue it before resolving iteration i: the host's
         per-iteration work (batch preparation, CER strings, logging: 1.3 - 2.9 ms, all of it GPU idle time when a rank holds a
-        single 12 ms task) runs under the next iteration's kernels.  Read-back buffers alternate between two sets (`_turn`)."""
+        single 12 ms task) runs under the next iteration's kernels.  Read-back buffers rotate through pipeline_depth + 1 sets (`_turn`)."""
         dev = model.flat_parameters.device
         t_host = time.perf_counter()
-        self._turn ^= 1
+        self._turn = (self._turn + 1) % (max(getattr(self, 'pipeline_depth', 1), 1) + 1)
         outer_opt.zero_grad()
         reads = self.meta_iteration(model, vocab, task_batches, val_data, n_tasks, inner_opt, outer_opt, args)
         G = model._G
@@ -757,7 +761,7 @@ class TransientTrainer():
         check_every = int(os.environ.get('MTL_REPLICA_CHECK_EVERY', '100'))
         it = start_it
         failures = 0
-        pending = None
+        pending = deque()                                 # enqueued, not yet resolved: (it, step), oldest first
         clock = [time.time()]
 
         def resolve(it_, step):
@@ -796,12 +800,10 @@ class TransientTrainer():
                 if world > 1 and (it == start_it or (check_every > 0 and (it + 1) % check_every == 0)):
                     check_replicas(model, val_data, it)
                 step = self.enqueue_iteration(model, vocab, task_batches, val_data, n_tasks, inner_opt, outer_opt, args)
-                prev, pending = pending, (it, step)       # (the enqueued step is on record before anything else can raise)
-                if prev is not None:
-                    resolve(*prev)                        # iteration it - 1 is logged while the device runs iteration it
-                if not self.pipeline or (it + 1) % evaluate_every == 0 or it + 1 >= num_it:
-                    resolve(*pending)
-                    pending = None
+                pending.append((it, step))                # (the enqueued step is on record before anything else can raise)
+                drain = not self.pipeline or (it + 1) % evaluate_every == 0 or it + 1 >= num_it
+                while pending and (drain or len(pending) > self.pipeline_depth):
+                    resolve(*pending.popleft())           # older iterations are logged while the device runs the newer ones
 
                 if (it + 1) % evaluate_every == 0:
                     save_fn = lambda metrics, best_model: save_meta_model(model, vocab, (it + 1), inner_opt, outer_opt, metrics,
@@ -825,16 +827,15 @@ class TransientTrainer():
                 torch.cuda.synchronize(dev)
                 # an iteration that was enqueued before the failure is complete now: log it and advance past it BEFORE the retry
                 # re-uses its read-back buffers (the failed enqueue has flipped the buffer set)
-                if pending is not None:
-                    done_it, done_step = pending
-                    pending = None
+                while pending:
+                    done_it, done_step = pending.popleft()
                     try:
                         resolve(done_it, done_step)
                     except Exception as e2:               # its Adam step has been applied either way
                         logging.info('Error while resolving iteration {}: {}'.format(done_it + 1, e2))
                     it = max(it, done_it + 1)
-        if pending is not None:
-            resolve(*pending)
+        while pending:
+            resolve(*pending.popleft())
         prefetch.join()
         self.history = history
 
