@@ -554,7 +554,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     };
     auto gather = [&](const float* q) {            // fixed-order sum of the nwg partials of this thread's (b, unit)
         float s0 = 0.f, s1 = 0.f;
-#pragma unroll 16
+#pragma unroll 32
         for (unsigned wq = 0; wq < nwg; wq += 2) {
             s0 += __hip_atomic_load(q + (long)wq * B * H, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s1 += __hip_atomic_load(q + (long)(wq + 1) * B * H, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
