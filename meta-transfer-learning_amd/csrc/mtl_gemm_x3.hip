@@ -424,8 +424,6 @@ int mtl_gemm_x3_route(void* stream, int transA, int transB, int M, int N, int K,
                       long sAh, long sBb, long sBh, long sCb, long sCh, long sBias, int kbatch, long sAk, long sBk, float* rowsum,
                       long sRowsum, long sBiasH, long sRowsumH, int tasks, long sAt, long sBt, long sCt, long sBiasT, long sRowsumT) {
     if ((transA && transB) || !mtl_gemm_x3_eligible(M, N, batch)) return 0;
-    static const long mink = getenv("MTL_GEMM_X3_MINK") ? atol(getenv("MTL_GEMM_X3_MINK")) : 0;      // experiment knob
-    if ((long)K * kbatch < mink) return 0;
     if (!al16(A) || !al16(B) || (lda & 3) || (ldb & 3) || ((sAb | sAh | sBb | sBh | sAk | sBk | sAt | sBt) & 3)) return 0;
     X3P p{A, B, C, bias, gate, rowsum, M, N, K, lda, ldb, ldc, ldg, alpha, flags, H, sAb, sAh, sBb, sBh, sCb, sCh, sBias, kbatch,
           sAk, sBk, sRowsum, sBiasH, sRowsumH, batch / tasks, sAt, sBt, sCt, sBiasT, sRowsumT, batch, nullptr, nullptr, 0, 0};
