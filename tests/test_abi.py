@@ -93,3 +93,28 @@ def test_command_list_records_only_successful_calls_and_reports_failures(built):
     cl.finish()
     with pytest.raises(RuntimeError, match='command 0 failed with code -22'):
         cl.run()
+
+
+def test_product_routing_is_a_pure_host_decision(built):
+    """mtl_gemm_f32_ex_route (what bench.py uses to attribute launch timings): the bf16-split engine from its tile-count threshold,
+    its split-K form for few-tile / very-long-K products, the small-tile engine for K-batched and row-sum products, the fp32 tile
+    engine otherwise; mtl_lstm_*_supported: the shape limits of the persistent LSTM launches.  No GPU involved."""
+    L = built._lib.lib()
+    old = L.mtl_gemm_x3_min_tiles(-1)
+    try:
+        L.mtl_gemm_x3_min_tiles(128)
+        assert L.mtl_gemm_f32_ex_route(2000, 512, 512, 8, 1, 0) == 2          # 16 x 4 x 8 tiles of 128 x 128
+        assert L.mtl_gemm_f32_ex_route(808, 100, 512, 1, 1, 0) == 1           # 7 tiles: small-tile engine
+        assert L.mtl_gemm_f32_ex_route(700, 512, 10000, 1, 1, 0) == 2         # 24 tiles x K = 10000: ten K slices
+        assert L.mtl_gemm_f32_ex_route(700, 512, 10001, 1, 1, 0) != 2         # no equal slicing in multiples of 4
+        assert L.mtl_gemm_f32_ex_route(700, 512, 10000, 1, 1, 1) == 1         # row sums ride on the small-tile engine
+        assert L.mtl_gemm_f32_ex_route(700, 512, 2048, 1, 1, 0) == 1          # K below the split-K threshold
+        L.mtl_gemm_x3_min_tiles(0)
+        assert L.mtl_gemm_f32_ex_route(2000, 512, 512, 8, 1, 0) != 2          # engine off
+    finally:
+        L.mtl_gemm_x3_min_tiles(old)
+    assert L.mtl_lstm_layer_supported(20, 512) == 1 and L.mtl_lstm_layer_supported(33, 512) == 0 and L.mtl_lstm_layer_supported(20, 500) == 0
+    assert L.mtl_lstm_stack_supported(20, 512, 2) == 1 and L.mtl_lstm_stack_supported(20, 512, 3) == 0      # (2 NL - 1) H / 8 <= 224 workgroups
+    assert L.mtl_lstm_stack_supported(20, 256, 3) == 1 and L.mtl_lstm_stack_supported(20, 128, 5) == 0
+    assert L.mtl_lstm_stack_scratch(35, 20, 512, 2) == 35 * 64 * 20 * 512 * 4 and L.mtl_lstm_stack_scratch(35, 20, 512, 1) == 0
+    assert L.mtl_lstm_layer_workspace() >= 4096
