@@ -200,6 +200,53 @@ def classify(lib, name, a, conv_mode, wgrad_x3_dense):
     return name[4:], None, None, name[4:] + '_kernel'
 
 
+# rocprofv3 kernel symbol (template name without its arguments) of every per-layer / per-shape class: the `roofline` object of the
+# bench line aggregates by SYMBOL FAMILY -- what a `rocprofv3 --kernel-trace --stats` summary lists -- so that nine convolution
+# classes (layer x direction) cannot hide behind one GEMM class that lumps thirteen shapes together
+def family_of(cls, symbols):
+    if cls.startswith('conv') and cls.endswith('_wgrad') and not cls.startswith('conv0'):
+        return 'conv3x3_wgrad_x3_kernel' if 'wgrad_x3' in symbols else 'conv3x3_wgrad_kernel'
+    if cls.startswith('conv') and not cls.startswith('conv0') and ('_fwd' in cls or '_dgrad' in cls):
+        return 'conv3x3_x3h_kernel' if 'x3h' in symbols else 'conv3x3_kernel'
+    return {'gemm_x3': 'gemm_x3_kernel<.,.,.,.,3>', 'gemm_h2': 'gemm_x3_kernel<.,.,.,.,2>', 'gemm_small': 'gemm16_kernel', 'gemm_big': 'gemm_kernel',
+            'attn_fwd': 'attn_fwd_kernel', 'attn_bwd': 'attn_bwd_kernel', 'layernorm_fwd': 'layernorm_fwd_kernel',
+            'layernorm_bwd': 'layernorm_bwd_kernel', 'conv0_fwd': 'conv0_fwd_kernel', 'conv0_wgrad': 'conv0_wgrad_kernel'}.get(cls, cls)
+
+
+DTYPE = {'h2': 'f32 (emulated: 3x3 conv + input Linear on 2 x fp16 pieces "h2" = 22 significand bits, big GEMMs on 3 x bf16 pieces "x3" = exact '
+               'fp32 operands, attention / small products / element-wise on fp32 MFMA + VALU; fp32 accumulation everywhere)',
+         'x3': 'f32 (emulated: 3x3 conv + big GEMMs on 3 x bf16 pieces "x3" = exact fp32 operands, input Linear on 2 x fp16 pieces, rest fp32 '
+               'MFMA + VALU; fp32 accumulation everywhere)',
+         'f32': 'f32 (every product on v_mfma_f32_*_f32 / VALU)'}
+
+
+def algorithmic_bytes(name, a, unit, work):
+    """Bytes a launch must move once (operands read once, results written once): the yardstick of `traffic`."""
+    if unit == 'byte':
+        return work
+    if name.startswith('mtl_conv3x3_') and 'wprep' not in name:
+        B, T, F, cin, cout = a[-5:]
+        px = float(B) * T * F
+        pooled_out = 'pool' in name                                   # forward: pooled map + one arg-max byte per pooled element
+        if 'wgrad' in name:
+            pooled_dy = bool(a[5] if name.endswith('_h2') else a[3])  # arg-max pointer: dy lives on the pooled grid
+            return 4 * px * cin + (px / 4 * cout * 5 if pooled_dy else 4 * px * cout) + 4 * 9.0 * cin * cout
+        if 'dgrad' in name:
+            pooled_dy = bool(a[3] if name.endswith('_h2') else a[2])
+            return (px / 4 * cout * 5 if pooled_dy else 4 * px * cout) + 8 * px * cin   # dy (+ arg-max) in, ReLU gate in + dx out
+        return 4 * px * cin + (px / 4 * cout * 5 if pooled_out else 4 * px * cout)
+    if name in ('mtl_gemm_f32_ex', 'mtl_gemm_f32_tb'):
+        M, N, K, batch, kb = a[3], a[4], a[5], a[17], a[26]
+        return 4.0 * batch * (M * K * kb + K * N * kb + M * N)
+    if name == 'mtl_gemm_h2_tb':
+        M, N, K, nt = a[2], a[3], a[4], a[18]
+        return 4.0 * nt * (M * K + K * N + M * N)
+    if name in ('mtl_attn_fwd', 'mtl_attn_bwd'):
+        B, H, Tq, Tk, dk = a[10], a[11], a[12], a[13], a[14]
+        return 4.0 * B * H * dk * ((2 * Tq + 2 * Tk) if name == 'mtl_attn_fwd' else (4 * Tq + 4 * Tk))
+    return 0.0
+
+
 def peak_of(cls, unit, conv_mode, wgrad_x3_dense):
     if unit == 'byte':
         return PEAK_HBM_GBS, 'GB/s', 'hbm'
@@ -275,9 +322,10 @@ def serial_profile(mtl, trainer, model, vocab, tasks, my_tasks, n_tasks, inner, 
     classes = {}
     for name, a, e0, e1 in prof.records:
         cls, work, unit, sym = classify(mtl._lib.lib(), name, a, eng.conv_mode, eng.wgrad_x3_dense)
-        c = classes.setdefault(cls, dict(time=0.0, work=0.0, unit=unit, launches=0, symbols=sym))
+        c = classes.setdefault(cls, dict(time=0.0, work=0.0, unit=unit, launches=0, symbols=sym, abytes=0.0))
         c['time'] += e0.elapsed_time(e1) * 1e-3
         c['work'] += work or 0.0
+        c['abytes'] += algorithmic_bytes(name, a, unit, work or 0.0)
         c['launches'] += 1
     dump_shapes(prof.records)
     return classes, len(prof.records), wall
@@ -521,6 +569,9 @@ def main():
     # ---- the headline number: K meta-steps, inputs resident, nothing else inside the timed region
     dt, last = timed_steps(trainer, model, vocab, tasks, my_tasks, a.tasks, inner, outer, args, a.steps, a.warmup, mdist, dev)
 
+    # (bit-level fingerprint of theta after the timed steps: tests compare schedules / collectives that must not change a single bit)
+    th = model.flat_parameters
+    theta_ck = [float(th.double().sum()), int(th.view(torch.int32).to(torch.int64).sum())]
     # ---- serial profiling step (every rank runs it: it contains the collective; only rank 0 reports)
     classes, n_launch, serial_wall = serial_profile(mtl_amd, trainer, model, vocab, tasks, my_tasks, a.tasks, inner, outer, args, dev)
     out = None
@@ -541,27 +592,59 @@ def main():
                 ach = c['work'] / c['time'] / (1e12 if c['unit'] == 'flop' else 1e9)
                 row.update(bound=bound, achieved=ach, peak=peak, unit=unit, frac=ach / peak)
             table[cls] = row
-        dom = next(cls for cls in table if 'frac' in table[cls])          # largest accumulated time among classes with a roofline
-        dc, dr = classes[dom], table[dom]
-        roofline = dict(bound=dr['bound'], kernel=dom, symbols=dr['symbols'], achieved=dr['achieved'], peak=dr['peak'], unit=dr['unit'],
-                        frac=dr['frac'], traffic=pmc.get(dom),
-                        work_per_launch=dc['work'] / dc['launches'], avg_launch_ms=dc['time'] / dc['launches'] * 1e3,
-                        launches_timed=dc['launches'], ms_per_pass=dr['ms_per_pass'],
-                        selection='kernel class with the largest accumulated time over ALL library launches of a serial meta-step',
+        for cls, row in table.items():
+            if cls in pmc:
+                row['traffic'] = pmc[cls]             # HBM bytes per launch (separate --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/)
+                ab = classes[cls].get('abytes', 0.0) / max(classes[cls]['launches'], 1)
+                if ab > 0:
+                    row['algorithmic_bytes'] = ab
+                    row['traffic_over_algorithmic'] = pmc[cls] / ab
+        # ---- aggregate by rocprofv3 symbol family; the dominant family (largest accumulated time) is the `roofline` object
+        fams = {}
+        for cls, c in classes.items():
+            if c['unit'] is None or c['work'] <= 0:
+                continue
+            f = fams.setdefault(family_of(cls, c['symbols']), dict(time=0.0, work=0.0, launches=0, classes=[], unit=c['unit'], traffic=0.0,
+                                                                   traffic_known=True))
+            f['time'] += c['time']
+            f['work'] += c['work']
+            f['launches'] += c['launches']
+            f['classes'].append(cls)
+            if cls in pmc:
+                f['traffic'] += pmc[cls] * c['launches']
+            else:
+                f['traffic_known'] = False
+        fam_table = {}
+        for name, f in sorted(fams.items(), key=lambda kv: -kv[1]['time']):
+            peak, unit, bound = peak_of(f['classes'][0], f['unit'], eng.conv_mode, eng.wgrad_x3_dense)
+            ach = f['work'] / f['time'] / (1e12 if f['unit'] == 'flop' else 1e9)
+            fam_table[name] = dict(ms_per_pass=f['time'] / passes * 1e3, launches_per_pass=f['launches'] / passes, bound=bound, achieved=ach,
+                                   peak=peak, unit=unit, frac=ach / peak, classes=f['classes'],
+                                   traffic=(f['traffic'] / f['launches']) if (f['traffic_known'] and f['launches']) else None)
+        dom = next(iter(fam_table))                      # (sorted by accumulated time)
+        df, dr = fams[dom], fam_table[dom]
+        arith = ('split-bf16 x3: 6 v_mfma_f32_32x32x16_bf16 per fp32-equivalent step, peak = dense bf16 / 6' if dr['peak'] == PEAK_X3_TFLOPS else (
+            'two fp16 pieces (h2): 3 v_mfma_f32_32x32x16_f16 per fp32-equivalent step, peak = dense fp16 / 3' if dr['peak'] == PEAK_H2_TFLOPS else (
+                'exact fp32 MFMA' if dr['bound'] == 'mfma' else 'HBM streaming')))
+        roofline = dict(bound=dr['bound'], kernel=dom, symbols=dom, achieved=dr['achieved'], peak=dr['peak'], unit=dr['unit'],
+                        frac=dr['frac'], traffic=dr['traffic'],
+                        work_per_launch=df['work'] / df['launches'], avg_launch_ms=df['time'] / df['launches'] * 1e3,
+                        launches_timed=df['launches'], ms_per_pass=dr['ms_per_pass'], classes=dr['classes'],
+                        selection='rocprofv3 symbol family with the largest accumulated time over ALL library launches of a serial meta-step '
+                                  '(per-layer / per-shape classes of one kernel template are summed: `per_family`; the split by layer and '
+                                  'direction stays in `per_class`)',
                         timing='HIP events on the launch stream around every library call, serial step after the timed region '
                                '(task lanes, side stream and command-list replay off)',
-                        arithmetic={'gemm_small': 'exact fp32: v_mfma_f32_16x16x4_f32', 'gemm_wgrad_grouped': 'exact fp32: v_mfma_f32_16x16x4_f32',
-                                    'gemm_big': 'exact fp32: v_mfma_f32_32x32x2_f32'}.get(
-                            dom, 'split-bf16 x3: 6 v_mfma_f32_32x32x16_bf16 per fp32-equivalent step, peak = dense bf16 / 6'
-                            if dr['peak'] == PEAK_X3_TFLOPS else (
-                                'two fp16 pieces: 3 v_mfma_f32_32x32x16_f16 per fp32-equivalent step, peak = dense fp16 / 3'
-                                if dr['peak'] == PEAK_H2_TFLOPS else ('exact fp32 MFMA' if dr['bound'] == 'mfma' else 'HBM streaming'))),
+                        traffic_source='(2 x FETCH_SIZE + WRITE_SIZE) x 1024 bytes per launch, launch-weighted over the family; separate rocprofv3 '
+                                       '--pmc passes (profiles/pmc_traffic.json)',
+                        arithmetic=arith,
                         serial_step=dict(launches_per_pass=n_launch / passes, gpu_ms_per_pass=sum(c['time'] for c in classes.values()) / passes * 1e3,
                                          gpu_span_ms_per_pass=serial_wall / passes * 1e3),
-                        per_class=table)
+                        per_family=fam_table, per_class=table)
         ms = dt / a.steps * 1e3
         out = dict(metric='meta-steps/sec', value=a.steps / dt, unit='meta-steps/s', n_gpus=world, steps=a.steps, warmup=a.warmup,
-                   ms_per_step=ms, higher_is_better=True, scaling='strong', vs_baseline=None, dtype='f32', data='synthetic',
+                   ms_per_step=ms, higher_is_better=True, scaling='strong', vs_baseline=None, dtype=DTYPE[model.engine.conv_mode],
+                   data='synthetic',
                    config=dict(workload='meta_transfer_train --copy-grad, enc2/dec4 d512 h8 r100 V3765, %d synthetic tasks '
                                         '(%d per GPU), k_train=k_valid=%d, %d frames x 161 bins, %d labels, dropout 0'
                                         % (a.tasks, len(my_tasks), a.k, a.frames, a.labels),
@@ -579,7 +662,7 @@ def main():
                                                 'x3': '3x3 convolutions as exact 3-way bf16 splits of fp32 operands, fp32 accumulate '
                                                       '(fp32-class error, same test tolerances as the fp32-MFMA kernels)',
                                                 'f32': 'fp32 MFMA'}[model.engine.conv_mode]),
-                   roofline=roofline, host_enqueue_ms_per_step=HOST_ENQUEUE.get('ms_per_step'), last_step=dict(val_loss=last[0] / a.tasks, cer_edits=last[1], chars=last[2]))
+                   roofline=roofline, host_enqueue_ms_per_step=HOST_ENQUEUE.get('ms_per_step'), last_step=dict(val_loss=last[0] / a.tasks, cer_edits=last[1], chars=last[2]), theta_checksum=theta_ck)
 
     extras = world == 1 and not a.no_extras
     if extras:
@@ -622,6 +705,17 @@ def main():
         for e, cm, cx, ch, il in saved:
             e.conv_mode, e.conv_x3, e.conv_h2, e.in_linear = cm, cx, ch, il
         lib.mtl_gemm_x3_min_tiles(old_x3)
+        # ... and the middle point: the convolutions on the EXACT 3-piece bf16 split (MTL_CONV=x3: every fp32 operand bit kept, six MFMAs
+        # per step; the input Linear then runs on the x3 GEMM engine too) -- no two-piece fp16 operand anywhere in the step
+        for e in model.engines:
+            e.conv_mode, e.conv_x3, e.conv_h2 = 'x3', True, False
+        trx3 = mtl_amd.TransientTrainer()
+        dtx, _ = timed_steps(trx3, model, vocab, tasks, my_tasks, a.tasks, inner, outer, args, k3, 4, mdist, dev)
+        out['conv_x3'] = dict(value=k3 / dtx, unit='meta-steps/s', ms_per_step=dtx / k3 * 1e3,
+                              note='same steps with MTL_CONV=x3: 3x3 convolutions and the input Linear on exact 3 x bf16 splits (24 significand '
+                                   'bits, 6 MFMAs per step) instead of 2 x fp16 (22 bits, 3 MFMAs); everything else as in the headline')
+        for e, cm, cx, ch, il in saved:
+            e.conv_mode, e.conv_x3, e.conv_h2, e.in_linear = cm, cx, ch, il
     if world == 1 and not a.no_cpu_baseline:
         # torch's CPU kernels do not scale to every core of a large host (measured on the 128-core GPU node: 11.1 s per task at
         # 128 threads, 3.9 s at 32, 4.2 s at 8), so the baseline is timed at the physical core count, at 32 and at 8 threads

@@ -316,6 +316,10 @@ int mtl_sgd_theta_prime(void* stream, const float* theta0, const float* g, float
 int mtl_sgd_theta_prime_tasks(void* stream, const float* theta0, const float* g, float alpha, float* theta1, long n, int tasks);
 /* out[i] (+)= sum_t x[t*n + i] in task order (copy_grad accumulation of a task stack: models/asr/transformer.py:219-229) */
 int mtl_sum_tasks(void* stream, float* out, const float* x, long n, int tasks, int accumulate);
+/* the same over a SLICE of the stack: out[i] (+)= sum_t x[t*task_stride + i], i < n (n, task_stride % 4 == 0, 16-byte aligned): one
+ * parameter group (decoder | encoder | conv) of copy_grad as soon as its gradients are final, so that its all-reduce can start under
+ * the rest of the backward (trainer/asr/transient_trainer.py:229,247-255) */
+int mtl_sum_tasks_strided(void* stream, float* out, const float* x, long n, int tasks, long task_stride, int accumulate);
 int mtl_axpy(void* stream, float* y, const float* x, float a, long n);
 int mtl_copy_f32(void* stream, float* dst, const float* src, long n); /* device-to-device, asynchronous on `stream` */
 int mtl_scale(void* stream, float* y, float a, const float* a_dev /*nullable: overrides a*/, long n);

@@ -3,7 +3,7 @@
 Import as `mtl_amd` (see mtl_amd.py at the repository root; the directory name carries a hyphen).
 """
 from . import _lib  # noqa: F401
-from .data import (Vocab, SyntheticTask, ManifestTaskDataset, AudioDataLoader, SpectrogramFrontEnd, load_vocab, load_wav_pcm16, synthetic_vocab,  # noqa: F401
+from .data import (Vocab, SyntheticTask, ManifestTaskDataset, SpectrogramDataset, BucketingSampler, AudioDataLoader, SpectrogramFrontEnd, load_vocab, load_wav_pcm16, synthetic_vocab,  # noqa: F401
                    synth_batch)
 from .functions import (init_transformer_model, save_meta_model, load_meta_model, save_joint_model, load_joint_model,  # noqa: F401
                         post_process)

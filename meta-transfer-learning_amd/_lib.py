@@ -9,7 +9,20 @@ from ctypes import c_float, c_int, c_long, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libmtl_hip.so')
-ABI_VERSION = 1
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'mtl_hip.h')
+
+
+def abi_hash(text):
+    """31-bit CRC of the C header without comments / white-space runs (same function as tools/gen_cmdlist.py, which bakes it into
+    the library as mtl_abi_version()): any change of a prototype, a struct layout or the opcode order bumps it."""
+    import re
+    import zlib
+    text = re.sub(r'/\*.*?\*/', ' ', text, flags=re.S)
+    text = re.sub(r'//[^\n]*', ' ', text)
+    return zlib.crc32(' '.join(text.split()).encode()) & 0x7fffffff
+
+
+ABI_VERSION = abi_hash(open(HEADER_PATH).read()) if os.path.exists(HEADER_PATH) else None
 
 P, I, L, F = c_void_p, c_int, c_long, c_float
 
@@ -75,6 +88,7 @@ SIGNATURES = {
     'mtl_sgd_theta_prime': (I, [P, P, P, F, P, L]),
     'mtl_sgd_theta_prime_tasks': (I, [P, P, P, F, P, L, I]),
     'mtl_sum_tasks': (I, [P, P, P, L, I, I]),
+    'mtl_sum_tasks_strided': (I, [P, P, P, L, I, L, I]),
     'mtl_axpy': (I, [P, P, P, F, L]),
     'mtl_copy_f32': (I, [P, P, P, L]),
     'mtl_scale': (I, [P, P, F, P, L]),
@@ -121,8 +135,9 @@ def lib():
         fn = getattr(h, name)          # AttributeError here = header/library drift
         fn.restype = res
         fn.argtypes = args
-    if h.mtl_abi_version() != ABI_VERSION:
-        raise MtlLibraryError('libmtl_hip.so ABI %d != expected %d; rebuild' % (h.mtl_abi_version(), ABI_VERSION))
+    if ABI_VERSION is not None and h.mtl_abi_version() != ABI_VERSION:
+        raise MtlLibraryError('libmtl_hip.so was built from another revision of include/mtl_hip.h (ABI hash %d, header %d): run '
+                              '`python tools/gen_cmdlist.py` and rebuild' % (h.mtl_abi_version(), ABI_VERSION))
     _lib = h
     return h
 
@@ -170,9 +185,15 @@ class CommandList:
         self.entries, self.buf, self.n = [], None, 0
         self._failed = c_int(-1)
         self._ptr_sites = {}
+        self.breaks = []            # (index of the first command AFTER the break, tag): see add_break
 
     def add(self, op, kinds, args):
         self.entries.append((op, kinds, args))
+
+    def add_break(self, tag):
+        """A point where the replaying host must run code of its own between two library calls (run(on_break=...) calls
+        on_break(tag) there): the overlapped all-reduce of a finished slice of the meta-gradient is a torch.distributed call."""
+        self.breaks.append((len(self.entries), tag))
 
     def finish(self):
         self.n = len(self.entries)
@@ -203,10 +224,16 @@ class CommandList:
             self.buf[i].a[j].p = new
         self._ptr_sites.setdefault(new, []).extend(sites)
 
-    def run(self):
-        rc = lib().mtl_cmdlist_run(self.buf, self.n, ctypes.byref(self._failed))
-        if rc != 0:
-            raise RuntimeError('mtl_cmdlist_run: command %d failed with code %d' % (self._failed.value, rc))
+    def run(self, on_break=None):
+        h, start = lib(), 0
+        for end, tag in self.breaks + [(self.n, None)]:
+            if end > start:
+                rc = h.mtl_cmdlist_run(ctypes.byref(self.buf, start * ctypes.sizeof(MtlCmd)), end - start, ctypes.byref(self._failed))
+                if rc != 0:
+                    raise RuntimeError('mtl_cmdlist_run: command %d failed with code %d' % (start + self._failed.value, rc))
+            start = end
+            if tag is not None and on_break is not None:
+                on_break(tag)
 
 
 class Recorder:
@@ -215,6 +242,9 @@ class Recorder:
 
     def __init__(self, handle, cmdlist):
         self._h, self._cl, self._cache = handle, cmdlist, {}
+
+    def segment_break(self, tag):
+        self._cl.add_break(tag)
 
     def __getattr__(self, name):
         fn = self._cache.get(name)

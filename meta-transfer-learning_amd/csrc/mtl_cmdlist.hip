@@ -38,6 +38,10 @@ int mtl_stream_wait_event(void* stream, void* event) {
 
 #include "mtl_cmdlist_gen.inc"
 
+// CRC of the header this library was generated / built from (tools/gen_cmdlist.py): prototypes, struct layouts and the opcode order
+// derived from them all change it, so a stale library is refused by the binding instead of mis-dispatching
+extern "C" int mtl_abi_version(void) { return MTL_ABI_HASH; }
+
 extern "C" {
 
 int mtl_cmdlist_opcode(const char* function_name) {

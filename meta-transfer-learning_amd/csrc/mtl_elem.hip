@@ -41,12 +41,12 @@ __global__ void sgd_theta_prime_tasks_kernel(const float4* __restrict__ t0, cons
     }
 }
 // out[i] (+)= sum_t x[t][i], t ascending (fixed order)
-__global__ void sum_tasks_kernel(float4* __restrict__ out, const float4* __restrict__ x, long n4, int tasks, int accumulate) {
+__global__ void sum_tasks_kernel(float4* __restrict__ out, const float4* __restrict__ x, long n4, int tasks, long ts4, int accumulate) {
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
         float4 a = accumulate ? out[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         for (int t = 0; t < tasks; ++t) {
-            const float4 b = x[t * n4 + i];
+            const float4 b = x[t * ts4 + i];
             a.x += b.x, a.y += b.y, a.z += b.z, a.w += b.w;
         }
         out[i] = a;
@@ -1046,13 +1046,17 @@ int mtl_sgd_theta_prime_tasks(void* stream, const float* theta0, const float* g,
     return MTL_OK;
 }
 
-int mtl_sum_tasks(void* stream, float* out, const float* x, long n, int tasks, int accumulate) {
-    if (!out || !x || n <= 0 || tasks <= 0 || (n & 3)) return MTL_EINVAL;
+int mtl_sum_tasks_strided(void* stream, float* out, const float* x, long n, int tasks, long task_stride, int accumulate) {
+    if (!out || !x || n <= 0 || tasks <= 0 || (n & 3) || (task_stride & 3) || task_stride < n) return MTL_EINVAL;
     if ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(x)) & 15) return MTL_EINVAL;
     hipLaunchKernelGGL(sum_tasks_kernel, dim3(grid_for(n / 4, 256, 4096)), dim3(256), 0, as_stream(stream),
-                       reinterpret_cast<float4*>(out), reinterpret_cast<const float4*>(x), n / 4, tasks, accumulate);
+                       reinterpret_cast<float4*>(out), reinterpret_cast<const float4*>(x), n / 4, tasks, task_stride / 4, accumulate);
     MTL_CHECK_LAUNCH();
     return MTL_OK;
+}
+
+int mtl_sum_tasks(void* stream, float* out, const float* x, long n, int tasks, int accumulate) {
+    return mtl_sum_tasks_strided(stream, out, x, n, tasks, n, accumulate);
 }
 
 int mtl_axpy(void* stream, float* y, const float* x, float a, long n) {
@@ -1404,6 +1408,5 @@ int mtl_levenshtein_u32(const unsigned int* a, int na, const unsigned int* b, in
     return d;
 }
 
-int mtl_abi_version(void) { return 1; }
 
 }  // extern "C"

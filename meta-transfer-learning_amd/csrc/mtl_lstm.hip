@@ -662,12 +662,23 @@ bool fill_stack(StackP& p, const mtl_lstm_stack* d, int NL, bool bwd) {
 
 extern "C" {
 
-int mtl_lstm_layer_supported(int B, int H) { return B >= 1 && B <= 32 && (H == 128 || H == 256 || H == 384 || H == 512); }
+// Every workgroup of a persistent launch must be resident at once (the grid-wide hand-offs spin on each other): the bound is the
+// device's own CU count (hipDeviceAttributeMultiprocessorCount: a partitioned / shared device reports its share), minus a margin
+// of one eighth for whatever else holds CUs.
+static int lstm_resident_limit() {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+        n = 256;                          // no device visible (shape queries on a build host): the MI355X's own count
+    return n - n / 8;
+}
+int mtl_lstm_layer_supported(int B, int H) {
+    return B >= 1 && B <= 32 && (H == 128 || H == 256 || H == 384 || H == 512) && H / LU <= lstm_resident_limit();
+}
 
 long mtl_lstm_layer_workspace(void) { return HDR * 4 + MAXL * 2 * PBUF * 4; }      // header + two partial buffers per layer (backward)
 
-int mtl_lstm_stack_supported(int B, int H, int NL) {      // every workgroup must be resident: (2 NL - 1) H / 8 of the 256 CUs
-    return mtl_lstm_layer_supported(B, H) && NL >= 1 && NL <= MAXL && (2 * NL - 1) * (H / LU) <= 224;
+int mtl_lstm_stack_supported(int B, int H, int NL) {      // every workgroup must be resident: (2 NL - 1) H / 8 of the device's CUs
+    return mtl_lstm_layer_supported(B, H) && NL >= 1 && NL <= MAXL && (2 * NL - 1) * (H / LU) <= lstm_resident_limit();
 }
 
 long mtl_lstm_stack_scratch(int T, int B, int H, int NL) { return NL > 1 ? (long)(NL - 1) * T * (H / LU) * B * H * 4 : 0; }

@@ -1696,6 +1696,252 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_x3_kernel(WgradX3P p) {
         }
 }
 
+// ------------------------------------------------------------------ weight gradient of a POOLED layer on the 2:4-sparse matrix cores
+// conv2 / conv7 are followed by ReLU + 2x2 max-pool (models/asr/transformer.py:50-52,56-58): the gradient that reaches their output
+// lives on the pooled grid, and the un-pooled dy the product dW = sum_px x[px + tap] dy[px] consumes has exactly ONE non-zero per
+// pooling window and channel -- 75 % structural zeros that the dense kernel above multiplies anyway.  With the pixels of a window as
+// four consecutive reduction indices this is (more than) the 2:4 pattern of v_smfmac_f32_32x32x32_f16: per window the sparse operand
+// stores {value, 0} and a 2-bit index = the stored arg-max code, and one instruction covers 32 pixels with the matrix work of 16.
+// Register layout of the instruction (measured: tools/probe/smfmac_probe.hip, profiles/r4/smfmac_layout.txt):
+//   A (sparse, 8 fp16 per lane): lane = (m = lane & 31, ha = lane >> 5); element pair p = e >> 1 covers the dense reduction indices
+//       k = 16 (p >> 1) + 8 ha + 4 (p & 1) + {0..3}, element e picks index bits [2 e + 1 : 2 e] of the lane's own index register;
+//   B (dense, 16 fp16 per lane): lane = (n = lane & 31, hb = lane >> 5) holds k = 16 hb + e;  C / D: the usual 32 x 32 layout.
+// Here M = output channels (dy, sparse), N = input channels (x), K = pixels: k = 4 * window + position, windows along F inside one
+// window row of an 8 x 16 pixel tile (8 windows = one instruction), position = the arg-max code (f & 1) << 1 | (t & 1).
+//   * x halo: staged exactly as above ([piece][ci half][halo pixel][32 ci]).  A consumer lane fetches, per time offset kw, the
+//     COLUMN STRIP its four windows need for all three frequency offsets: five ds_read_b64_tr_b16 per piece, each returning one
+//     column pair x both rows -- a 32-bit register is one halo column (two rows), so the B fragment of frequency offset kh is
+//     registers [kh, kh + 8) of the strip: 30 LDS reads per 27 instructions instead of 72 per 54.
+//   * dy: a producer thread owns (window row parity, ha, output channel): four pooled values + four arg-max bytes, split into the
+//     two fp16 pieces, stored as {v, 0} pairs in instruction layout + the 16 index bits; bias gradient sums ride along as before.
+constexpr int SP_STEP = 2 * 2 * 64 * 16 + 2 * 64 * 4;             // one window row: [piece][ha][co] 16-byte fragments + [ha][co] index words
+constexpr int wsp_smem() { return 2 * (2 * 2 * WX_SUB) + 4 * SP_STEP; }
+
+typedef _Float16 f16x16 __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(512) void conv3x3_wgrad_sp_kernel(WgradX3P p) {
+    constexpr int NP = 2;
+    constexpr int WX_BUF = 2 * NP * WX_SUB, WX_BOFF = 2 * WX_BUF;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smx[];
+    const int tid = threadIdx.x;
+    // the channel-block pairs of one pixel-tile sequence (slot) are dispatched 8 workgroups apart, i.e. onto the SAME XCD: the halo and
+    // dy tiles they all read are fetched from HBM once per L2 instead of once per pair (conv7: 4 pairs)
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int pair = jb % p.npairs, slot = (jb / p.npairs) * 8 + xcd, nslots = gridDim.x / p.npairs;
+    const int cib = (pair / p.npj) * 64, cob = (pair % p.npj) * 64;
+    const int my_tiles = (p.tiles - slot + nslots - 1) / nslots;
+    const int T = p.T, F = p.F, Cin = p.Cin, Cout = p.Cout;
+    const int npairs_k = my_tiles * 2;                         // pairs of window rows (2 x 32 pixels): the dy hand-over granule
+    struct TileCache {
+        int j = -1, b = 0, t0 = 0, f0 = 0;
+    };
+    TileCache tc_halo, tc_dy;
+    auto tile_of = [&](TileCache& c, int j, int& b, int& t0, int& f0) {
+        if (j != c.j) {
+            int id = slot + j * nslots;
+            const int fx = id % p.ntf;
+            id /= p.ntf;
+            c.f0 = fx * 16;
+            c.t0 = (id % p.ntt) * 8;
+            c.b = id / p.ntt;
+            c.j = j;
+        }
+        b = c.b;
+        t0 = c.t0;
+        f0 = c.f0;
+    };
+
+    if (tid >= NT) {
+        // ------------------------------------------------------------------ producers: the x halo AND the sparse dy fragments
+        const int ptid = tid - NT;
+        const float sx = pow2_scale(amax_read(p.amax_x)), sdy = pow2_scale(amax_read(p.amax_dy));
+        float4 hv[WX_NVA];
+        unsigned okbits = 0;
+        auto fetch = [&](int j) {
+            int b, t0, f0;
+            tile_of(tc_halo, j, b, t0, f0);
+            okbits = 0;
+#pragma unroll
+            for (int i = 0; i < WX_NVA; ++i) {
+                const int e = ptid + i * NT;
+                const int hp = min(e >> 4, WX_NPIX - 1), c4 = (e & 15) * 4;
+                const int ht = hp / WX_HF, hf = hp - ht * WX_HF;
+                const int ts = t0 + ht - 1, fs = f0 + hf - 1;
+                const bool ok = (unsigned)ts < (unsigned)T && (unsigned)fs < (unsigned)F;
+                const int tc = min(max(ts, 0), T - 1), fc = min(max(fs, 0), F - 1);
+                hv[i] = *reinterpret_cast<const float4*>(p.x + (((long)b * T + tc) * F + fc) * Cin + cib + c4);
+                okbits |= (ok ? 1u : 0u) << i;
+            }
+        };
+        auto commit = [&](int buf) {
+#pragma unroll
+            for (int i = 0; i < WX_NVA; ++i) {
+                const int e = ptid + i * NT;
+                if ((e >> 4) >= WX_NPIX) continue;
+                const int hp = e >> 4, c4 = (e & 15) * 4;
+                const float4 v = mask4(hv[i], ((okbits >> i) & 1u) ? 15u : 0u);
+                uint2 pc[NP];
+                split_x4<NP>(v, sx, pc);
+                unsigned char* dst = smx + buf * WX_BUF + ((c4 >> 5) * WX_NPIX + hp) * 64 + (c4 & 31) * 2;
+#pragma unroll
+                for (int q = 0; q < NP; ++q) *reinterpret_cast<uint2*>(dst + 2 * q * WX_SUB) = pc[q];
+            }
+        };
+        // dy: this thread owns ONE sparse A fragment per pair of window rows -- (window row parity, ha, output channel): the pooled
+        // values of windows {2 ha, 2 ha + 1, 4 + 2 ha, 5 + 2 ha} of that row (the four element pairs of its lane) and their arg-max
+        // codes.  Loaded two pairs ahead.
+        const int bs = ptid >> 7, bha = (ptid >> 6) & 1, bco = ptid & 63;
+        f32x2 bsum2 = {0.f, 0.f};                              // sum of this thread's dy values (bias gradient of channel cob + bco)
+        float bv[2][4];
+        unsigned ba[2], bok[2];
+        auto fetch_b = [&](int pk, float (&v)[4], unsigned& a, unsigned& okm) {
+            const int j = pk >> 1, wr = (pk & 1) * 2 + bs;
+            int b, t0, f0;
+            tile_of(tc_dy, min(j, my_tiles - 1), b, t0, f0);
+            const int tp = (t0 >> 1) + wr, co = cob + bco;
+            const bool rowok = tp < p.Tp && j < my_tiles;
+            okm = 0;
+            a = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int fp = (f0 >> 1) + (k >> 1) * 4 + 2 * bha + (k & 1);
+                const long o = (((long)b * p.Tp + min(tp, p.Tp - 1)) * p.Fp + min(fp, p.Fp - 1)) * Cout + co;
+                v[k] = p.dy[o];
+                a |= ((unsigned)p.am[o] & 3u) << (4 * k);       // element 2 k of the lane: index bits [4 k + 1 : 4 k]
+                okm |= ((rowok && fp < p.Fp) ? 1u : 0u) << k;
+            }
+        };
+        auto commit_b = [&](int pk, const float (&v)[4], unsigned a, unsigned okm) {
+            float val[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) val[k] = ((okm >> k) & 1u) ? v[k] : 0.f;
+            bsum2 += f32x2{val[0], val[1]} + f32x2{val[2], val[3]};
+            unsigned q0[NP], q1[NP];
+            Split<NP>::x2(val[0], val[1], sdy, q0);              // packed pairs [piece]: low half = first value
+            Split<NP>::x2(val[2], val[3], sdy, q1);
+            unsigned char* dst = smx + WX_BOFF + ((pk & 1) * 2 + bs) * SP_STEP;
+#pragma unroll
+            for (int q = 0; q < NP; ++q)                         // {v, 0} pairs: the value is element 2 k, element 2 k + 1 is zero
+                *reinterpret_cast<uint4*>(dst + ((q * 2 + bha) * 64 + bco) * 16) =
+                    make_uint4(q0[q] & 0xffffu, q0[q] >> 16, q1[q] & 0xffffu, q1[q] >> 16);
+            *reinterpret_cast<unsigned*>(dst + 4 * 64 * 16 + (bha * 64 + bco) * 4) = a;
+        };
+        if (my_tiles > 0) {
+            fetch(0);
+            fetch_b(0, bv[0], ba[0], bok[0]);
+            fetch_b(1, bv[1], ba[1], bok[1]);
+            commit(0);
+            commit_b(0, bv[0], ba[0], bok[0]);
+            fetch_b(2, bv[0], ba[0], bok[0]);
+        }
+        if (my_tiles > 1) fetch(1);
+        __syncthreads();                                       // halo 0 and the fragments of pair 0 are visible
+#pragma unroll 1
+        for (int pk = 0; pk < npairs_k; pk += 2) {             // one tile (two pairs of window rows) per iteration
+            commit_b(pk + 1, bv[1], ba[1], bok[1]);
+            fetch_b(pk + 3, bv[1], ba[1], bok[1]);
+            __syncthreads();
+            commit_b(pk + 2, bv[0], ba[0], bok[0]);
+            fetch_b(pk + 4, bv[0], ba[0], bok[0]);
+            const int j = pk >> 1;                             // the consumers are on the tile's last pair: the next halo goes into the other buffer
+            if (j + 1 < my_tiles) {
+                commit((j + 1) & 1);
+                if (j + 2 < my_tiles) fetch(j + 2);
+            }
+            __syncthreads();
+        }
+        if (p.bias_part && cib == 0) {      // the four threads of a channel (window row parity x ha) combine in a fixed order
+            float* sb = reinterpret_cast<float*>(smx);
+            sb[(bs * 2 + bha) * 64 + bco] = bsum2.x + bsum2.y;
+            __syncthreads();
+            if (ptid < 64) p.bias_part[(long)slot * Cout + cob + bco] = (sb[bco] + sb[64 + bco]) + (sb[128 + bco] + sb[192 + bco]);
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- consumers: quadrant (qo: co half, qc: ci half) of the 64 x 64 block
+    const int lane = tid & 63, wave = tid >> 6;
+    const int qc = wave >> 1, qo = wave & 1;
+    const int g = lane >> 4, x16 = lane & 15, l31 = lane & 31, hi = lane >> 5;
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+    // this lane's address inside a 16-lane transpose group: row r = x16 >> 2 of the four it fetches = window position (t & 1 = r & 1,
+    // f & 1 = r >> 1), channels 16 (g & 1) + 4 (x16 & 3) of the wave's ci half; halo columns start at 8 hi
+    const int r = x16 >> 2;
+    const int xbase = ((qc * WX_NPIX) + (r & 1) * WX_HF + 8 * hi + (r >> 1)) * 64 + (16 * (g & 1) + 4 * (x16 & 3)) * 2;
+    const unsigned char* Al = smx + WX_BOFF + (hi * 64 + qo * 32 + l31) * 16;
+    const unsigned char* Il = smx + WX_BOFF + 4 * 64 * 16 + (hi * 64 + qo * 32 + l31) * 4;
+    __syncthreads();
+#pragma unroll 1
+    for (int pk = 0; pk < npairs_k; ++pk) {
+        const int j = pk >> 1;
+        const unsigned char* X = smx + (j & 1) * WX_BUF + xbase;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int slot_b = ((pk & 1) * 2 + s) * SP_STEP;
+            const f16x8 a_h = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(Al + slot_b));
+            const f16x8 a_l = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(Al + slot_b + 2 * 64 * 16));
+            const int idx = (int)*reinterpret_cast<const unsigned*>(Il + slot_b);
+            const int wr = (pk & 1) * 2 + s;                   // window row inside the tile: halo rows 2 wr + kw, + 1
+            // strips are double-buffered by hand: the reads of time offset kw + 1 are issued before the nine instructions of kw (pinned
+            // with sched_barrier: left alone, hipcc hoists all 50 strip reads of a pair above the first instruction and spills the
+            // accumulators: 337 VGPRs spilled)
+            unsigned strip[2][NP][10];                         // [buffer][piece][halo column 8 hi + i]
+            auto load_strip = [&](unsigned (&st)[NP][10], int kw) {
+#pragma unroll
+                for (int pc = 0; pc < NP; ++pc)
+#pragma unroll
+                    for (int c = 0; c < 5; ++c) {
+                        const s16x4 q = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (__attribute__((address_space(3))) s16x4*)(X + 2 * pc * WX_SUB + ((2 * wr + kw) * WX_HF + 2 * c) * 64));
+                        const uint2 u = __builtin_bit_cast(uint2, q);
+                        st[pc][2 * c] = u.x;
+                        st[pc][2 * c + 1] = u.y;
+                    }
+            };
+            load_strip(strip[0], 0);
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                if (kw + 1 < 3) load_strip(strip[(kw + 1) & 1], kw + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) {
+                    union {
+                        unsigned u[8];
+                        f16x16 v;
+                    } bh, bl;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        bh.u[i] = strip[kw & 1][0][kh + i];
+                        bl.u[i] = strip[kw & 1][1][kh + i];
+                    }
+                    f32x16 cc = acc[kh * 3 + kw];
+                    cc = __builtin_amdgcn_smfmac_f32_32x32x32_f16(a_l, bh.v, cc, idx, 0, 0);     // smallest terms first
+                    cc = __builtin_amdgcn_smfmac_f32_32x32x32_f16(a_h, bl.v, cc, idx, 0, 0);
+                    acc[kh * 3 + kw] = __builtin_amdgcn_smfmac_f32_32x32x32_f16(a_h, bh.v, cc, idx, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();
+    }
+    if (p.bias_part && cib == 0) __syncthreads();                  // the producers' bias-gradient hand-over (they use LDS once more)
+    float* slab = p.partial + (long)slot * 9 * Cin * Cout;
+    const float inv = 1.f / (pow2_scale(amax_read(p.amax_x)) * pow2_scale(amax_read(p.amax_dy)));
+    const int ci = cib + qc * 32 + l31;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int v4 = 0; v4 < 4; ++v4) {                           // rows (output channels) 8 v4 + 4 hi + {0..3}: one 16-byte store
+            const int co = cob + qo * 32 + 8 * v4 + 4 * hi;
+            *reinterpret_cast<float4*>(slab + ((long)tap * Cin + ci) * Cout + co) =
+                make_float4(acc[tap][4 * v4] * inv, acc[tap][4 * v4 + 1] * inv, acc[tap][4 * v4 + 2] * inv, acc[tap][4 * v4 + 3] * inv);
+        }
+}
+
 // w_ref (Cout,Cin,3,3) -> w_fwd[tap][cin][cout]  and  w_dgrad[tap'][cout][cin] with tap' the 180-degree flipped tap
 __global__ void conv_wprep_kernel(const float* w, float* wf, float* wd, int Cout, int Cin) {
     const int total = 9 * Cin * Cout;
@@ -2020,6 +2266,20 @@ static int wgrad_pieces(hipStream_t s, const float* x, const float* amax_x, cons
     const int grid = wgrad_x3_grid(Cin, Cout);
     p.bias_part = db ? workspace + (long)(grid / p.npairs) * 9L * Cin * Cout : nullptr;
     constexpr int SMEM = wx_smem(NP);
+    if constexpr (NP == 2) {
+        // pooled layers: the 2:4-sparse form (MTL_WGRAD_SPARSE=0 keeps the dense kernel: A/B measurements)
+        static const bool sparse = !(getenv("MTL_WGRAD_SPARSE") && atoi(getenv("MTL_WGRAD_SPARSE")) == 0);
+        if (pooled && sparse && grid % (8 * p.npairs) == 0) {
+            static int attr_sp = set_smem(conv3x3_wgrad_sp_kernel, wsp_smem());
+            if (attr_sp) return attr_sp;
+            hipLaunchKernelGGL(conv3x3_wgrad_sp_kernel, dim3(grid), dim3(512), wsp_smem(), s, p);
+            MTL_CHECK_LAUNCH();
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((9 * Cin * Cout + (db ? Cout : 0) + 63) / 64), dim3(1024), 0, s, workspace, dw_ref,
+                               grid / p.npairs, Cin, Cout, p.bias_part, db);
+            MTL_CHECK_LAUNCH();
+            return MTL_OK;
+        }
+    }
     if (pooled) {
         static int attr = set_smem(conv3x3_wgrad_x3_kernel<true, NP>, SMEM);
         if (attr) return attr;

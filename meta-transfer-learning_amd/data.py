@@ -157,6 +157,76 @@ class ManifestTaskDataset:
         return self.feature_fn(row[0])[:, :self.args.src_max_len], parse_transcript(self.vocab, row[1])
 
 
+class SpectrogramDataset(ManifestTaskDataset):
+    """utils/data_loader.py:171-236 with the reference's OWN constructor, so that its entry script builds the datasets unchanged
+    (meta_transfer_train.py:159-175):
+
+        SpectrogramDataset(vocab, args, audio_conf, manifest_filepath_list=..., normalize=True, augment=args.augment,
+                           input_type=args.input_type, is_train=True, partitions=args.train_partition_list)
+
+    audio_conf: dict(sample_rate, window_size, window_stride, window, noise_dir, noise_prob, noise_levels) (:141-147).  Features come
+    from the device front-end (SpectrogramFrontEnd = SpectrogramParser.parse_audio, :65-96) unless `feature_fn` is given.  Same
+    attributes as the reference object (max_size, ids_list, proba, part_len, input_type, manifest_filepath_list, is_train) and the
+    same two console lines.  Outside the accelerated path and rejected loudly: augment=True (sox tempo / gain perturbation),
+    noise injection (audio_conf['noise_dir']), input_type other than 'char' (the bpe / ipa branches are commented out in the
+    reference too)."""
+
+    def __init__(self, vocab, args, audio_conf, manifest_filepath_list, normalize=False, augment=False, input_type='char',
+                 is_train=False, partitions=None, feature_fn=None, seed=None):
+        if augment:
+            raise NotImplementedError('augment=True (sox tempo / gain perturbation, utils/data_loader.py:28-38) is outside the accelerated path')
+        if audio_conf.get('noise_dir') is not None:
+            raise NotImplementedError("noise injection (audio_conf['noise_dir']) is outside the accelerated path")
+        if input_type != 'char':
+            raise NotImplementedError("only input_type='char' (utils/data_loader.py:342-361)")
+        self.window_stride, self.window_size = audio_conf['window_stride'], audio_conf['window_size']
+        self.sample_rate, self.window = audio_conf['sample_rate'], audio_conf.get('window', 'hamming')
+        self.normalize, self.augment, self.noise_prob = normalize, augment, audio_conf.get('noise_prob')
+        if feature_fn is None:
+            fe = []       # built at the first utterance: constructing the dataset must not need the device
+
+            def feature_fn(path):
+                if not fe:
+                    fe.append(SpectrogramFrontEnd(self.sample_rate, self.window_size, self.window_stride,
+                                                  self.window if self.window in ('hamming', 'hann', 'blackman', 'bartlett') else 'hamming',
+                                                  self.normalize))
+                return fe[0](load_wav_pcm16(path)).cpu()
+        super().__init__(vocab, args, manifest_filepath_list, feature_fn=feature_fn, partitions=partitions, seed=seed, is_train=is_train)
+        self.manifest_filepath_list, self.input_type = manifest_filepath_list, input_type
+        # (the reference leaves part_len at the LAST manifest's partition size, or max_size without partitions: :211-222)
+        self.part_len = (max(int(len(self.ids_list[-1]) * partitions[len(self.ids_list) - 1]), 1) if partitions is not None
+                         else self.max_size)
+        print('max_size:', self.max_size)
+        print('input_type:', input_type)
+
+    def parse_transcript(self, transcript_path):
+        return parse_transcript(self.vocab, transcript_path)
+
+    def parse_audio(self, audio_path):
+        return self.feature_fn(audio_path)
+
+
+class BucketingSampler(torch.utils.data.Sampler):
+    """utils/data_loader.py:480-500: consecutive bins of `batch_size` indices (the data is assumed sorted by length); iterating
+    shuffles INSIDE each bin, shuffle(epoch) shuffles the ORDER of the bins -- both with the global np.random like the reference."""
+
+    def __init__(self, data_source, batch_size=1):
+        self.data_source = data_source
+        ids = list(range(0, len(data_source)))
+        self.bins = [ids[i:i + batch_size] for i in range(0, len(ids), batch_size)]
+
+    def __iter__(self):
+        for ids in self.bins:
+            np.random.shuffle(ids)
+            yield ids
+
+    def __len__(self):
+        return len(self.bins)
+
+    def shuffle(self, epoch):
+        np.random.shuffle(self.bins)
+
+
 class AudioDataLoader(torch.utils.data.DataLoader):
     """utils/data_loader.py:401-440: a DataLoader over (spectrogram (F,T), transcript ids) items whose batches are sorted by
     descending frame count, zero-padded to the longest utterance / PAD-padded to the longest transcript, and returned as

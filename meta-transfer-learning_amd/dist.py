@@ -81,6 +81,36 @@ def allreduce_sum_(flat):
     return flat
 
 
+def collective_on():
+    """Is the meta-gradient all-reduce issued at all (several ranks, or MTL_DIST_ALWAYS)?"""
+    return is_on() and (world_size() > 1 or _always())
+
+
+def chunked_on():
+    """The all-reduce as one collective per parameter group (decoder, encoder, conv), each started as soon as that group's gradients
+    are final, i.e. under the rest of the validation backward (MTL_CHUNKED_ALLREDUCE=0: ONE collective after the backward)."""
+    return collective_on() and os.environ.get('MTL_CHUNKED_ALLREDUCE', '1') != '0'
+
+
+class ChunkedAllReduce:
+    """SUM all-reduce of a flat buffer as a fixed sequence of slices, each issued asynchronously (`issue`) as soon as the caller
+    knows it is final; `wait()` joins all of them.  Slices are disjoint and always issued in the same order on every rank, so the
+    result is reproducible run to run; with two ranks it is bitwise the single all-reduce (a + b), with more ranks it equals it up
+    to the ring's summation order inside each slice (parity within tolerance, not bitwise)."""
+
+    def __init__(self):
+        self.works = []
+
+    def issue(self, flat_slice):
+        if collective_on():
+            self.works.append(td.all_reduce(flat_slice, op=td.ReduceOp.SUM, async_op=True))
+
+    def wait(self):
+        works, self.works = self.works, []
+        for w in works:
+            w.wait()               # (device tensors: makes the CURRENT stream wait for the collective's stream; host tensors: blocks)
+
+
 def allreduce_scalars(values, device):
     if not (is_on() and world_size() > 1):
         return values

@@ -237,6 +237,10 @@ class PassEngine:
         self._site = 0                # dropout site counter of the current pass (Philox offset = site << 40)
         self.after_conv_hook = None
         self.forward_hook = None      # optional callable(engine) after every forward has been enqueued (tests capture the arena)
+        # optional callable(tag), tag in ('decoder', 'encoder', 'conv'): called by backward() -- at ENQUEUE time, eager run or command-list
+        # replay alike -- right after the last kernel that writes that parameter group's gradients has been enqueued (on the main or
+        # the side stream): the trainer starts the group's share of the meta-gradient all-reduce there (slice_bounds())
+        self.slice_hook = None
         self.deferred = []
         self._wlog = {}
         # weight gradients of all layers of a stack as one strided-batch launch per parameter kind (flush_layer_wgrads)
@@ -315,6 +319,8 @@ class PassEngine:
         self._gen += 1
         if self._pool_bytes <= self.pool_budget:
             return 0
+        if torch.cuda.is_current_stream_capturing():
+            return 0                      # a free inside a hipGraph capture would be baked into the graph: trim at the next eager pass
         freed = 0
         for key in sorted(self.pool, key=lambda k: self._pool_gen.get(k, 0)):
             if self._pool_bytes <= self.pool_budget or self._pool_gen.get(key, 0) >= self._gen - 2:
@@ -540,6 +546,28 @@ class PassEngine:
             ev = self._event()
             check(self.lib.mtl_event_record(ev, self.side.cuda_stream), 'mtl_event_record')
             check(self.lib.mtl_stream_wait_event(self.stream, ev), 'mtl_stream_wait_event')
+
+    def slice_bounds(self):
+        """{'encoder' | 'decoder' | 'conv': (first, end) offsets in floats} of the three parameter groups in the flat buffers --
+        parameters() order of models/asr/transformer.py is encoder, decoder, conv, so each group is one contiguous slice."""
+        L, out, prev = self.L, {}, None
+        for name in L.order:
+            grp = name.split('.')[0]
+            if grp != prev:
+                if grp in out:
+                    raise RuntimeError('parameter group %s is not contiguous in the flat layout' % grp)
+                out[grp] = [L.off(name), L.total]
+                if prev is not None:
+                    out[prev][1] = L.off(name)
+                prev = grp
+        return {k: tuple(v) for k, v in out.items()}
+
+    def _slice_done(self, tag):
+        if self.slice_hook is None:
+            return
+        if isinstance(self.lib, _lib.Recorder):
+            self.lib.segment_break(tag)        # the replay stops here and hands control to the same hook
+        self.slice_hook(tag)
 
     def linear_fwd(self, x, rows, k_in, w, b, y, n_out, relu=False):
         """rows: per task; the rows of task t are x + t * rows * k_in, its weights w + t * sP"""
@@ -1047,7 +1075,20 @@ class PassEngine:
         T4, F4 = T2 // 2, F2 // 2
         if F4 * 128 != hp.d_in:
             raise ValueError('dim_input %d does not match %d frequency bins' % (hp.d_in, F))
+        if nt > 1 and self.group_wgrads:
+            raise RuntimeError('MTL_GROUP_WGRADS=1 addresses the weight-gradient operands per task: it cannot run a task-batched pass')
         self.nt, self.sP = nt, int(sP)
+        try:
+            return self._forward_device(theta, x, meta, smoothing, hyp_out, loss_out, nt, sX, F, T)
+        finally:
+            self.nt, self.sP = 1, 0        # (the backward restores them from `saved`; an exception mid-pass must not leave nt > 1 behind)
+
+    def _forward_device(self, theta, x, meta, smoothing, hyp_out, loss_out, nt, sX, F, T):
+        hp, L, lib, st = self.hp, self.L, self.lib, self.stream
+        sP = self.sP
+        B = meta['B']
+        T2, F2 = T // 2, F // 2
+        T4, F4 = T2 // 2, F2 // 2
         ntw = nt if sP else 1                                       # distinct parameter sets of this pass
         P = theta.data_ptr()
         o = lambda n, t=0: P + 4 * (L.off(n) + t * self.sP)
@@ -1205,7 +1246,6 @@ class PassEngine:
                           enc_inputs=enc_inputs, nt=nt, sP=self.sP, sX=sX)
         if self.forward_hook is not None:
             self.forward_hook(self)
-        self.nt, self.sP = 1, 0            # (the backward restores them from `saved`)
         return dict(pred=pred, gold=ids[1], hyp=hyp, loss=loss, gold_host=meta['gold_host'], n_nonpad=n_nonpad)
 
     # ---------------------------------------------------------------- greedy decoding
@@ -1366,6 +1406,14 @@ class PassEngine:
         self.flush_side(2)
         if not embed_done:
             embed_bwd(dcur)
+        if self.slice_hook is not None:
+            # every decoder-group gradient is enqueued (weights: side stream; LayerNorm partials: main, layer 0's on the side stream):
+            # reduce the decoder's LayerNorm / bias partials now, BEHIND both, instead of with the encoder's at the end of the pass
+            if self.use_side_stream:
+                self.run_on_side(self.flush_ln_reduce)
+            else:
+                self.flush_ln_reduce()
+            self._slice_done('decoder')
 
         # ---- encoder ----
         eA = self.buf('_deA', (nt * Me, d))
@@ -1393,6 +1441,9 @@ class PassEngine:
                   task=(Me * d, Me * hp.d_in, d * hp.d_in, 0, 0))
         for t in range(nt):
             check(lib.mtl_permute_hc(st, dwp[t].data_ptr(), g('encoder.input_linear.weight', t), d, 128, F4, 1, None), 'permute_inv')
+        if self.slice_hook is not None:
+            self.flush_ln_reduce()         # the encoder's LayerNorms (+ the input LayerNorm): their partials were all produced on this stream
+            self._slice_done('encoder')
         h2 = self.conv_h2
         amax = A['amax']
         am_ = (lambda i, t=0: amax.data_ptr() + 4 * _lib.AMAX_SLOTS * (12 * t + i)) if h2 else (lambda i, t=0: None)   # y1, p1, y5 | dp2, dy5, dp1
@@ -1464,4 +1515,5 @@ class PassEngine:
         self.join_side()
         self.flush_ln_reduce()     # the parameter / bias gradients of all 17 LayerNorms of the pass: one launch (after the join: one of
                                    # the 17 backward kernels ran on the side stream)
+        self._slice_done('conv')
         self.nt, self.sP, self.sG = 1, 0, 0

@@ -98,6 +98,7 @@ class RNNModel(nn.Module):
         """-> (decoded (T, B, ntoken), hidden) like lm/model/rnn_model.py:52-60 (no autograd graph: use LMEngine.backward)"""
         eng = self._need_engine()
         out = eng.forward(self._theta, input, None, hidden, self.dropout_rate if self.training else 0.0)
+        eng.check_handoff()          # the caller consumes the logits: a timed-out persistent launch must not pass as a result
         return out['logits'].view(input.shape[0], input.shape[1], self.ntoken), out['hidden']
 
 
@@ -115,10 +116,16 @@ class LMEngine:
         # the whole stack as one wavefront launch per direction (layers one step apart); '0': one launch per layer and direction
         self.stacked = os.environ.get('MTL_LSTM_STACK', '1') != '0'
         self.sync_ws = torch.zeros(int(self.lib.mtl_lstm_layer_workspace()) // 4, dtype=torch.int32, device=device)
+        self._persistent_issued = False
 
     def check_handoff(self):
         """The persistent LSTM kernels bound every grid-wide wait and set a sticky error word instead of hanging the device (e.g.
-        when their workgroups could not all become resident): raise here, where the caller has synchronised anyway."""
+        when their workgroups could not all become resident).  Called wherever results leave the engine: RNNModel.forward
+        (evaluation / inference), LMMetaTrainer.run_iteration, and by direct LMEngine users through results().  One 4-byte
+        read-back (a host sync) -- skipped when no persistent launch has been issued since the last check."""
+        if not self._persistent_issued:
+            return
+        self._persistent_issued = False
         if int(self.sync_ws[1]) != 0:
             self.sync_ws[1] = 0
             raise RuntimeError('mtl_lstm: a grid-wide wait of a persistent LSTM launch timed out; its results are invalid '
@@ -223,6 +230,7 @@ class LMEngine:
             gh = self.buf('gh', (B, 4 * H))
             fused = self.persistent and bool(lib.mtl_lstm_layer_supported(B, H))
             if fused:
+                self._persistent_issued = True
                 check(lib.mtl_lstm_layer_fwd(st, gx.data_ptr(), whh, bhh, hall.data_ptr(), call.data_ptr(), acts.data_ptr(), xout.data_ptr(),
                                              msk.data_ptr() if msk is not None else None, sc, T, B, H, self.sync_ws.data_ptr()),
                       'lstm_layer_fwd')
@@ -236,6 +244,7 @@ class LMEngine:
         if stacked:
             gx = self.buf('gx0', (R, 4 * H))
             self.gemm(0, 1, R, 4 * H, E, emb.data_ptr(), E, o('rnn.weight_ih_l0'), E, gx.data_ptr(), 4 * H, bias=o('rnn.bias_ih_l0'))
+            self._persistent_issued = True
             check(lib.mtl_lstm_stack_fwd(st, ctypes.byref(desc), sc, T, B, H, NL, self.sync_ws.data_ptr()), 'lstm_stack_fwd')
         for l in range(NL):
             hn[l].copy_(layers[l]['hall'][T])
@@ -284,6 +293,7 @@ class LMEngine:
                 desc.dG[l] = dGs[l].data_ptr()
                 desc.mask[l] = Ly['mask'].data_ptr() if Ly['mask'] is not None else None
             scratch = self.buf('stack_scratch', (int(lib.mtl_lstm_stack_scratch(T, B, H, NL)) // 4,))
+            self._persistent_issued = True
             check(lib.mtl_lstm_stack_bwd(st, ctypes.byref(desc), dx.data_ptr(), sc, scratch.data_ptr(), T, B, H, NL, self.sync_ws.data_ptr()),
                   'lstm_stack_bwd')
         for l in reversed(range(NL)):
@@ -295,6 +305,7 @@ class LMEngine:
             msk = Ly['mask']
             fused = stacked or (self.persistent and bool(lib.mtl_lstm_layer_supported(B, H)))
             if fused and not stacked:
+                self._persistent_issued = True
                 check(lib.mtl_lstm_layer_bwd(st, dx.data_ptr(), msk.data_ptr() if msk is not None else None, sc, whh, Ly['acts'].data_ptr(),
                                              Ly['call'].data_ptr(), dG.data_ptr(), T, B, H, self.sync_ws.data_ptr()), 'lstm_layer_bwd')
             for t in reversed(range(0 if fused else T)):

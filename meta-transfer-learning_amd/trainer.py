@@ -302,6 +302,18 @@ def run_validation(forward_one_batch, model, vocab, valid_loader_list, it, args,
 MAX_CONSECUTIVE_FAILURES = 20
 
 
+def _sample_takes_need(ds):
+    """Does ds.sample accept the `need=` keyword (this package's datasets: load only what the rank uses)?  Read from the
+    signature: catching TypeError around the call would also swallow errors raised INSIDE sample() -- after the index stream
+    has advanced -- and the retry would draw a second time, taking this rank out of lock-step with the others."""
+    import inspect
+    try:
+        params = inspect.signature(ds.sample).parameters
+    except (TypeError, ValueError):
+        return False
+    return 'need' in params or any(p.kind is inspect.Parameter.VAR_KEYWORD for p in params.values())
+
+
 class TransientTrainer():
     def __init__(self):
         logging.info('Transient Trainer is initialized')
@@ -401,11 +413,18 @@ class TransientTrainer():
                 key = (lane, tuple(tx.shape), tuple(vx.shape), m_tr['Td'], m_va['Td'], n_tasks, bool(args.clip),
                        float(args.max_norm), smoothing, float(inner.param_groups[0]['lr']), theta0.data_ptr(), eng.dropout_p,
                        tuple(b.data_ptr() for b in bufs[lane]), streams[lane].cuda_stream, eng.use_side_stream)
+                # a rank that holds ONE task (8 tasks on 8 GPUs): G = its g, handed to the all-reduce group by group under the backward
+                chunk = None
+                if n_lanes == 1 and len(task_batches) == 1 and not use_graphs:
+                    g_, G_ = bufs[lane][0], bufs[lane][2]
+                    chunk = self._chunk_hook(model, eng, lambda lo, n, st, g_=g_, G_=G_: check(
+                        _lib.lib().mtl_axpy(st, G_.data_ptr() + 4 * lo, g_.data_ptr() + 4 * lo, 1.0, n), 'mtl_axpy'))
+                    key = key + ('chunked',) if chunk is not None else key
                 body = lambda xa, xb: self._task_body(model, lane, bufs[lane], theta0, xa, m_tr, xb, m_va, n_tasks, inner, args,
-                                                      smoothing, slots)
-                graph = self._graph_for(key, lane, tx, vx, body, streams[lane]) if use_graphs else None
+                                                      smoothing, slots, chunk)
+                graph = self._graph_for(key, lane, tx, vx, body, streams[lane], eng) if use_graphs else None
                 if graph is None and use_cmdlists:
-                    self._run_recorded(key, eng, tx, vx, body)
+                    self._run_recorded(key, eng, tx, vx, body, on_break=chunk)
                 elif graph is None:
                     body(tx, vx)
                 else:
@@ -420,6 +439,7 @@ class TransientTrainer():
                 done.record(streams[lane])
                 main.wait_event(done)
         Gm = model._G
+        self._chunk_join(dev)
         if n_lanes == 1:
             pass                                              # lane 0 accumulated straight into model._G
         else:
@@ -471,6 +491,10 @@ class TransientTrainer():
                      hyp_va=eng.buf('slot.hyp_va', (nt * Bv, m_va['Td']), torch.int64), loss_va=eng.buf('slot.loss_va', (nt,)))
         G = model._G
         lr = float(inner.param_groups[0]['lr'])
+        # several ranks: G's three parameter groups are summed over the local tasks and all-reduced one by one, each as soon as the
+        # validation backward has produced it (decoder first, conv last) -- on a communication stream, under the rest of the backward
+        chunk = self._chunk_hook(model, eng, lambda lo, n, st: check(
+            _lib.lib().mtl_sum_tasks_strided(st, G.data_ptr() + 4 * lo, g.data_ptr() + 4 * lo, n, nt, total, 0), 'mtl_sum_tasks_strided'))
 
         def body(_xa=None, _xb=None):
             eng.zero_(g)                                                         # inner_opt.zero_grad()   (:198), every task
@@ -482,16 +506,22 @@ class TransientTrainer():
             check(eng.lib.mtl_sgd_theta_prime_tasks(eng.stream, theta0.data_ptr(), g.data_ptr(), lr, theta1.data_ptr(), total, nt),
                   'mtl_sgd_theta_prime_tasks')                                   # inner_opt.step()        (:207)
             eng.forward_device(theta1, Xva, m_va, smoothing, hyp_out=slots['hyp_va'], loss_out=slots['loss_va'], sP=total)   # (:215)
-            eng.backward(g, 1.0 / n_tasks, sG=total)                             # (val_loss/n).backward(): g_t += g_val,t/n (Q1)
-            check(eng.lib.mtl_sum_tasks(eng.stream, G.data_ptr(), g.data_ptr(), total, nt, 0), 'mtl_sum_tasks')    # add_copy_grad() (:229)
+            eng.slice_hook = chunk
+            try:
+                eng.backward(g, 1.0 / n_tasks, sG=total)                         # (val_loss/n).backward(): g_t += g_val,t/n (Q1)
+            finally:
+                eng.slice_hook = None
+            if chunk is None:
+                check(eng.lib.mtl_sum_tasks(eng.stream, G.data_ptr(), g.data_ptr(), total, nt, 0), 'mtl_sum_tasks')    # add_copy_grad() (:229)
 
         key = ('batched', nt, (B, F, T), tuple(vx_in.shape), m_tr['Td'], m_va['Td'], n_tasks, bool(args.clip), float(args.max_norm),
                smoothing, lr, theta0.data_ptr(), eng.dropout_p, g.data_ptr(), theta1.data_ptr(), G.data_ptr(),
-               torch.cuda.current_stream(dev).cuda_stream, eng.use_side_stream)
+               torch.cuda.current_stream(dev).cuda_stream, eng.use_side_stream, chunk is not None)
         if use_cmdlists:
-            self._run_recorded(key, eng, Xtr, Xva, body)
+            self._run_recorded(key, eng, Xtr, Xva, body, on_break=chunk)
         else:
             body()
+        self._chunk_join(dev)
         hyp_tr = _pinned(('tb.hyp', 0, self._turn), slots['hyp_tr'].shape, torch.int64)
         hyp_va = _pinned(('tb.hyp', 1, self._turn), slots['hyp_va'].shape, torch.int64)
         loss_tr = _pinned(('tb.loss', 0, self._turn), (nt,), torch.float32)
@@ -500,6 +530,44 @@ class TransientTrainer():
             dst.copy_(src, non_blocking=True)
         return [(_TaskRead(m_tr['gold_hosts'][t], hyp_tr[t * B:(t + 1) * B], loss_tr[t:t + 1]),
                  _TaskRead(m_va['gold_hosts'][t], hyp_va[t * Bv:(t + 1) * Bv], loss_va[t:t + 1])) for t in range(nt)]
+
+    def _chunk_hook(self, model, eng, accumulate_slice):
+        """-> callable(tag) for PassEngine.slice_hook (None when the meta-gradient is not all-reduced in chunks).  At the point where
+        the validation backward has enqueued the last kernel of a parameter group, the hook -- on the communication stream, behind the
+        engine's main AND side stream -- forms that group's slice of G from the local gradients (accumulate_slice(first, count, raw
+        stream)) and starts its all-reduce (dist.ChunkedAllReduce); _chunk_join() makes the main stream wait for all three before the
+        outer step.  Fixed slice order on every rank: decoder, encoder, conv (the order the backward finishes them in)."""
+        if not mdist.chunked_on():
+            self._chunks = None
+            return None
+        dev = model.flat_parameters.device
+        if getattr(self, '_comm_stream', None) is None:
+            self._comm_stream = torch.cuda.Stream(dev)
+        bounds = eng.slice_bounds()
+        if sorted(bounds) != ['conv', 'decoder', 'encoder']:
+            raise RuntimeError('unexpected parameter groups %s' % sorted(bounds))
+        self._chunks = mdist.ChunkedAllReduce()
+        G, comm = model._G, self._comm_stream
+
+        def hook(tag):
+            lo, hi = bounds[tag]
+            comm.wait_stream(torch.cuda.current_stream(dev))
+            if eng.side is not None:
+                comm.wait_stream(eng.side)
+            with torch.cuda.stream(comm):
+                accumulate_slice(lo, hi - lo, comm.cuda_stream)
+                self._chunks.issue(G[lo:hi])
+        return hook
+
+    def _chunk_join(self, dev):
+        """the main stream waits for the chunked collectives (and the slice sums in front of them); marks G as already reduced"""
+        if getattr(self, '_chunks', None) is None:
+            return
+        with torch.cuda.stream(self._comm_stream):
+            self._chunks.wait()                        # comm stream waits for the collectives' stream
+        torch.cuda.current_stream(dev).wait_stream(self._comm_stream)
+        self._chunks = None
+        self._G_reduced = True
 
     def _single_task_split(self, model, task, val_batch, n_tasks, inner, args):
         """A rank that holds ONE task (8 tasks on 8 GPUs) would leave the second lane idle, and the task's own chain
@@ -586,7 +654,7 @@ class TransientTrainer():
             reads.append(_Readback(dict(gold_host=gold, hyp=hyp, loss=loss), ('split', part, self._turn)))
         return [tuple(reads)]
 
-    def _task_body(self, model, lane, bufs, theta0, x_tr, m_tr, x_va, m_va, n_tasks, inner, args, smoothing, slots):
+    def _task_body(self, model, lane, bufs, theta0, x_tr, m_tr, x_va, m_va, n_tasks, inner, args, smoothing, slots, chunk=None):
         """Kernels of ONE task on the current stream (eager, or recorded into a hipGraph): train pass at theta0, fused inner
         SGD into theta', validation pass at theta', accumulation into the lane's copy_grad buffer."""
         eng = model.engines[lane]
@@ -598,15 +666,20 @@ class TransientTrainer():
             clip_flat_grad_(model, g, args.max_norm, lane=lane)          # (:205-206)
         eng.sgd_theta_prime(theta0, g, inner.param_groups[0]['lr'], theta1)     # inner_opt.step() (:207)
         eng.forward_device(theta1, x_va, m_va, smoothing, hyp_out=slots['hyp_va'], loss_out=slots['loss_va'])   # meta-validation forward (:215)
-        eng.backward(g, 1.0 / n_tasks)                                   # (val_loss/n).backward(): g += g_val/n (Q1)
-        eng.axpy_(G, g, 1.0)                                             # add_copy_grad()         (:229)
+        eng.slice_hook = chunk                                           # (several ranks: G's groups leave for their all-reduce as they finish)
+        try:
+            eng.backward(g, 1.0 / n_tasks)                               # (val_loss/n).backward(): g += g_val/n (Q1)
+        finally:
+            eng.slice_hook = None
+        if chunk is None:
+            eng.axpy_(G, g, 1.0)                                         # add_copy_grad()         (:229)
 
     def _slots(self, model, lane, m_tr, m_va):
         eng = model.engines[lane]
         return dict(hyp_tr=eng.buf('slot.hyp_tr', (m_tr['B'], m_tr['Td']), torch.int64), loss_tr=eng.buf('slot.loss_tr', (1,)),
                     hyp_va=eng.buf('slot.hyp_va', (m_va['B'], m_va['Td']), torch.int64), loss_va=eng.buf('slot.loss_va', (1,)))
 
-    def _run_recorded(self, key, eng, tx, vx, body):
+    def _run_recorded(self, key, eng, tx, vx, body, on_break=None):
         """Command-list execution of a task body.  First sighting of a key: plain eager run (it also brings every arena buffer to
         its final size); second sighting: eager run through a Recorder that logs the calls; afterwards: the two input pointers
         are re-pointed to this task's batches and the recorded calls are replayed by mtl_cmdlist_run."""
@@ -639,18 +712,21 @@ class TransientTrainer():
             cl.repoint(ent['x_va'], vx.data_ptr())
             cl.repoint(tmp, tx.data_ptr())
             ent['x_tr'], ent['x_va'] = tx.data_ptr(), vx.data_ptr()
-        cl.run()
+        cl.run(on_break)
 
-    def _graph_for(self, key, lane, tx, vx, body, stream):
+    def _graph_for(self, key, lane, tx, vx, body, stream, model_engine):
         """hipGraph of a task body, keyed by everything baked into it (shapes, scalars, buffer addresses).  First sighting of
         a key -> None (the eager run is the warm-up that allocates every buffer); second sighting -> capture; then replay.
         The per-launch Python/ctypes cost (~7 us x ~1400 launches per task) disappears from the loop."""
+        eng = model_engine
         ent = self._graphs.get(key)
         if ent is None:
             if len(self._graphs) >= 32:
                 return None
             self._graphs[key] = 'warm'
             return None
+        if isinstance(ent, dict) and ent['epoch'] != eng.scratch_epoch:
+            ent = 'warm'            # the engine's pool evicted / re-allocated buffers since the capture: the graph holds dead addresses
         if ent == 'warm':
             try:
                 x_tr, x_va = torch.empty_like(tx), torch.empty_like(vx)
@@ -658,9 +734,13 @@ class TransientTrainer():
                 x_va.copy_(vx)
                 stream.synchronize()
                 g = torch.cuda.CUDAGraph()
+                epoch = eng.scratch_epoch
                 with torch.cuda.graph(g, stream=stream):
                     body(x_tr, x_va)
-                ent = dict(g=g, x_tr=x_tr, x_va=x_va)
+                if eng.scratch_epoch != epoch:      # a buffer moved during the capture: drop it, run eagerly now, capture again next time
+                    self._graphs[key] = 'warm'
+                    return None
+                ent = dict(g=g, x_tr=x_tr, x_va=x_va, epoch=epoch)
             except Exception as exc:                                      # capture unsupported -> stay eager, loudly
                 logging.warning('hipGraph capture failed (%s); task body stays eager', exc)
                 print('WARNING: hipGraph capture failed, running eagerly:', exc, flush=True)
@@ -691,9 +771,11 @@ class TransientTrainer():
         t_host = time.perf_counter()
         self._turn = (self._turn + 1) % (max(getattr(self, 'pipeline_depth', 1), 1) + 1)
         outer_opt.zero_grad()
+        self._G_reduced = False
         reads = self.meta_iteration(model, vocab, task_batches, val_data, n_tasks, inner_opt, outer_opt, args)
         G = model._G
-        mdist.allreduce_sum_(G)                                  # the one collective of the path
+        if not self._G_reduced:                                  # (already summed over the ranks group by group, under the backward: _chunk_hook)
+            mdist.allreduce_sum_(G)                              # the one collective of the path
         if args.clip:
             clip_flat_grad_(model, G, args.max_norm)             # (:253-254) on the summed meta-gradient
         outer_opt.step(G)                                        # from_copy_grad() + outer_opt.step()  (:248-255)
@@ -742,15 +824,17 @@ class TransientTrainer():
         train_data_buffer = [[] for _ in range(n_tasks)]
         my_tasks = mdist.shard_tasks(n_tasks, rank, world)
 
+        takes_need = [_sample_takes_need(ds) for ds in train_data_list]      # decided ONCE from the signature (never by catching)
+
         def fetch_train_batch(buf):
             # every rank DRAWS every task (the index streams stay in lock-step), but only what this rank uses is loaded and
             # featurised: its own tasks' training batches and the last task's validation batch, which all tasks share (:168)
             for manifest_id in range(n_tasks):
                 need = (manifest_id in my_tasks, manifest_id == n_tasks - 1)
                 ds = train_data_list[manifest_id]
-                try:
+                if takes_need[manifest_id]:
                     item = ds.sample(k_train, k_valid, manifest_id, need=need)
-                except TypeError:                                    # a duck-typed dataset with the reference's 3-argument sample()
+                else:                                                # a duck-typed dataset with the reference's 3-argument sample()
                     item = ds.sample(k_train, k_valid, manifest_id)
                 buf[manifest_id].insert(0, item)
 
@@ -889,11 +973,13 @@ class JointTrainer():
         my_tasks = mdist.shard_tasks(n_tasks, rank, world)
         buf = [[] for _ in range(n_tasks)]
 
+        takes_need = [_sample_takes_need(ds) for ds in train_data_list]
+
         def fetch():
             for m in range(n_tasks):                         # all tasks are drawn; only this rank's training batches are loaded
-                try:
+                if takes_need[m]:
                     item = train_data_list[m].sample(args.k_train, 1, m, need=(m in my_tasks, False))
-                except TypeError:
+                else:
                     item = train_data_list[m].sample(args.k_train, 1, m)
                 buf[m].insert(0, item)
         prefetch = threading.Thread(target=fetch)

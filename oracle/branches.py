@@ -1,4 +1,4 @@
-"""Branch-decision comparison between the HIP path and the CPU oracle (test helper).
+"""Branch-decision comparison between the HIP path and the CPU oracle (checker-side helper: imported by tests/ and smoke() only).
 
 The pass contains ~4.6 M (fixture size) to ~250 M (north-star size) ReLU / max-pool branch points.  Two exact-fp32
 implementations with different summation orders differ by ~1e-7 in the pre-activations, so a pre-activation that lies

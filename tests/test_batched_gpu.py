@@ -225,7 +225,7 @@ def test_flat_task_stack_updates(L):
 
 
 def _iteration(mtl_amd, model, vocab, args, tasks, val, n, inner, batched, tr=None, gates=False):
-    from tests import branches
+    from oracle import branches
     if tr is None:
         tr = mtl_amd.TransientTrainer()
     tr.batch_tasks = batched
@@ -263,7 +263,7 @@ def test_task_batched_iteration_equals_per_task_lanes(name, clip, smoothing):
     The two schedules share every per-task kernel but not the tile shapes of the products (a batched launch sees nt x the
     rows), so pre-activations differ by fp32 summation order: when all ReLU / max-pool decisions agree (captured from both
     runs) every tensor of G agrees to 4e-6 (weights 2e-6; the 512-element bias gradients are cancelling column sums, measured 2.3e-6); a differing near-tie decision (rare at this size) widens the bar to the
-    single-flip band of tests/branches.py.  Recorded / replayed command lists reproduce the eager batched step bit for bit."""
+    single-flip band of oracle/branches.py.  Recorded / replayed command lists reproduce the eager batched step bit for bit."""
     z, cfg, spec = gu.load(name)
     mtl_amd, args, vocab, model = make(cfg, spec)
     args.clip, args.max_norm, args.label_smoothing = clip, 0.05, smoothing

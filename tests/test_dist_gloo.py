@@ -102,3 +102,57 @@ def test_replicas_are_synchronised_at_start_and_divergence_is_detected():
     for rank in (0, 1):
         same, step, m0, raised = ret[rank]
         assert same and step == 5 and m0 == 1.0 and raised == [True, True, True], (rank, ret[rank])
+
+
+def _chunk_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    import mtl_amd
+    mdist = mtl_amd.dist
+    mdist.init_from_env(backend='gloo')
+    assert mdist.collective_on() and mdist.chunked_on()
+    g = torch.Generator().manual_seed(100 + rank)
+    total = 4 * 5003
+    local = torch.randn(total, generator=g) * torch.logspace(-6, 3, total)           # wide dynamic range: an order change would show
+    bounds = {'encoder': (0, 4 * 1601), 'decoder': (4 * 1601, 4 * 4900), 'conv': (4 * 4900, total)}   # flat layout: encoder | decoder | conv
+    whole = local.clone()
+    mdist.allreduce_sum_(whole)                                                        # ONE collective after the backward
+    chunked = local.clone()
+    ch = mdist.ChunkedAllReduce()
+    for tag in ('decoder', 'encoder', 'conv'):                                         # the order the validation backward finishes them in
+        lo, hi = bounds[tag]
+        ch.issue(chunked[lo:hi])                                                       # asynchronous: three collectives in flight
+    assert len(ch.works) == 3
+    ch.wait()
+    assert not ch.works
+    other = torch.randn(total, generator=torch.Generator().manual_seed(100 + (1 - rank))) * torch.logspace(-6, 3, total)
+    ret[rank] = (bool(torch.equal(whole, chunked)), bool(torch.equal(whole, local + other) or torch.equal(whole, other + local)))
+    os.environ['MTL_CHUNKED_ALLREDUCE'] = '0'
+    assert mdist.collective_on() and not mdist.chunked_on()
+    mdist.barrier()
+
+
+def test_chunked_allreduce_equals_the_single_collective_bitwise():
+    """The meta-gradient leaves for its all-reduce in three slices (decoder, encoder, conv: dist.ChunkedAllReduce, issued by
+    trainer._chunk_hook under the validation backward).  World 2 over gloo: every element is a + b whichever way it travels, so
+    the three asynchronous collectives must reproduce the single one bit for bit."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_chunk_worker, args=(2, 29617, ret), nprocs=2, join=True)
+    assert ret[0] == (True, True) and ret[1] == (True, True), dict(ret)
+
+
+def test_command_list_breaks_hand_control_back_between_segments():
+    """CommandList.add_break / run(on_break): the replay of a recorded task body stops where the eager run called the engine's
+    slice hook (PassEngine._slice_done) so that the same host code -- the start of a slice's all-reduce -- runs in both (host
+    logic only: the segments here are empty, nothing is dispatched)."""
+    import mtl_amd
+    cl = mtl_amd._lib.CommandList()
+    cl.add_break('decoder')
+    cl.add_break('encoder')
+    cl.add_break('conv')
+    cl.finish()
+    seen = []
+    cl.run(seen.append)
+    assert seen == ['decoder', 'encoder', 'conv'] and cl.n == 0
+    cl.run()                                   # no callback: breaks are ignored

@@ -292,3 +292,78 @@ print('REFERENCE_OK')
     st = o2.state_dict()['state']
     assert len(st) == len(list(m2.parameters())) and float(st[0]['step']) == 2.0
     assert torch.equal(st[0]['exp_avg'], raw['outer_opt'].state_dict()['state'][0]['exp_avg'])
+
+
+def test_spectrogram_dataset_constructed_as_the_reference_entry_script_does(tmp_path, capsys):
+    """meta_transfer_train.py:141-175 builds `SpectrogramDataset(vocab, args, audio_conf, manifest_filepath_list=..., normalize=True,
+    augment=args.augment, input_type=args.input_type, is_train=True, partitions=args.train_partition_list)` once per training manifest and
+    `BucketingSampler(valid_data, batch_size=args.k_train)` per validation manifest (utils/data_loader.py:171-236,480-500): the same
+    calls must work on this package by import swap, with the reference object's attributes, console lines, index stream
+    (np.random.choice over the partition's leading fraction, global RNG) and .sample() layout."""
+    import mtl_amd
+    vocab = mtl_amd.synthetic_vocab(64)
+    manifests = []
+    for m, n in enumerate((7, 4)):
+        rows = []
+        for i in range(n):
+            t = tmp_path / ('m%d_u%d.txt' % (m, i))
+            t.write_text(''.join(chr(0x4e00 + (3 * m + i + j) % 60) for j in range(2 + i)), encoding='utf8')
+            rows.append('%s,%s' % (tmp_path / ('m%d_u%d.wav' % (m, i)), t))
+        mp_ = tmp_path / ('train%d.csv' % m)
+        mp_.write_text('\n'.join(rows) + '\n')
+        manifests.append(str(mp_))
+    args = argparse.Namespace(src_max_len=40, sample_rate=16000, window_size=.02, window_stride=.01, window='hamming', augment=False,
+                              input_type='char', train_manifest_list=manifests, train_partition_list=[0.5, 1.0], k_train=3,
+                              noise_dir=None, noise_prob=0.4, noise_min=0.0, noise_max=0.5)
+    audio_conf = dict(sample_rate=args.sample_rate, window_size=args.window_size, window_stride=args.window_stride, window=args.window,
+                      noise_dir=args.noise_dir, noise_prob=args.noise_prob, noise_levels=(args.noise_min, args.noise_max))
+    feats = lambda wav: torch.full((161, 12 + 3 * int(os.path.basename(wav)[4])), float(os.path.basename(wav)[1]))
+    train_data_list = []
+    for i in range(len(args.train_manifest_list)):      # (the reference builds one dataset object per manifest, each over ALL manifests)
+        train_data_list.append(mtl_amd.SpectrogramDataset(vocab, args, audio_conf, manifest_filepath_list=args.train_manifest_list,
+                                                          normalize=True, augment=args.augment, input_type=args.input_type, is_train=True,
+                                                          partitions=args.train_partition_list, feature_fn=feats))
+    out = capsys.readouterr().out
+    assert out.count('max_size: 30000') == 2 and out.count('input_type: char') == 2          # :198-207 (several manifests, is_train)
+    ds = train_data_list[1]
+    assert len(ds) == 30000 and ds.is_train and ds.input_type == 'char' and ds.manifest_filepath_list == manifests
+    assert [len(ids) for ids in ds.ids_list] == [7, 4] and ds.part_len == 4                   # (:211-216: the LAST manifest's partition size)
+    assert np.allclose(ds.proba[0], [1 / 3] * 3 + [0] * 4) and np.allclose(ds.proba[1], [0.25] * 4)
+    # the index stream of .sample(): np.random.choice(len, k_tr + k_val, p=proba, replace=True) on the global RNG (:247-249)
+    np.random.seed(123456)
+    want = np.random.choice(np.arange(0, 7), 3 + 2, p=ds.proba[0], replace=True)
+    np.random.seed(123456)
+    (x, sizes, pct, tgt, tsz), va = ds.sample(3, 2, 0)
+    assert [int(v) for v in x[:, 0, 0, 0]] == [0, 0, 0] and want.max() <= 2                  # manifest 0, leading half only
+    assert [int(s) for s in sizes] == [12 + 3 * int(j) for j in want[:3]] and [int(s) for s in va[1]] == [12 + 3 * int(j) for j in want[3:]]
+    assert [int(n) for n in tsz] == [2 + int(j) for j in want[:3]] and x.shape[1:3] == (1, 161) and tgt.dtype == torch.int64
+    assert ds.parse_transcript('一丁') == [vocab.label2id['一'], vocab.label2id['丁']]
+    # validation side: one manifest, not training -> max_size = its length; BucketingSampler bins / shuffles like the reference
+    valid = mtl_amd.SpectrogramDataset(vocab, args, audio_conf, manifest_filepath_list=[manifests[0]], normalize=True,
+                                       augment=args.augment, input_type=args.input_type, feature_fn=feats)
+    assert len(valid) == 7 and not valid.is_train and valid.part_len == 7
+    spect, transcript = valid[9]                                                             # index % len (:335-340)
+    assert spect.shape == (161, 12 + 3 * 2) and len(transcript) == 4
+    sampler = mtl_amd.BucketingSampler(valid, batch_size=args.k_train)
+    assert len(sampler) == 3 and [len(b) for b in sampler.bins] == [3, 3, 1]
+    np.random.seed(7)
+    got = [list(b) for b in sampler]
+    np.random.seed(7)
+    ref_bins = [[0, 1, 2], [3, 4, 5], [6]]
+    for b in ref_bins:
+        np.random.shuffle(b)
+    assert got == ref_bins and sorted(sum(got, [])) == list(range(7))
+    np.random.seed(8)
+    sampler.shuffle(0)
+    np.random.seed(8)
+    np.random.shuffle(ref_bins)
+    assert sampler.bins == ref_bins
+    loader = mtl_amd.AudioDataLoader(pad_token_id=vocab.PAD_ID, dataset=valid, batch_sampler=sampler)
+    inputs, targets, percentages, input_sizes, target_sizes = next(iter(loader))
+    assert inputs.shape[1:3] == (1, 161) and inputs.shape[0] == len(ref_bins[0]) and int(input_sizes[0]) == int(input_sizes.max())
+    # outside the accelerated path: rejected loudly, not ignored
+    import pytest
+    with pytest.raises(NotImplementedError):
+        mtl_amd.SpectrogramDataset(vocab, args, audio_conf, manifest_filepath_list=manifests, augment=True, feature_fn=feats)
+    with pytest.raises(NotImplementedError):
+        mtl_amd.SpectrogramDataset(vocab, args, dict(audio_conf, noise_dir='/noise'), manifest_filepath_list=manifests, feature_fn=feats)

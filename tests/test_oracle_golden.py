@@ -138,7 +138,7 @@ def test_gate_replay_of_the_oracles_own_decisions_is_exact():
     """relu_replay / pool_replay (the branch-replay used by the 1e-4 GPU parity tests) fed with the oracle's OWN ReLU / max-pool
     decisions must reproduce the free-running oracle: outputs, loss and every gradient tensor bit for bit (odd F and T so
     the floor-mode pooling tails are exercised)."""
-    from tests import branches
+    from oracle import branches
     z, cfg, spec = gu.load('F0')
     m = R.build_model(cfg)
     x, lens, y = R.synth_batch(11, 3, 70, 6, cfg['vocab_size'], True)
@@ -204,7 +204,7 @@ def test_meta_step_at_north_star_size_matches_reference_golden():
 
 @pytest.mark.slow
 def test_branch_flip_census_between_two_fp32_implementations_of_the_oracle():
-    """The evidence behind the single-flip band of the GPU parity tests (tests/branches.py): the SAME CPU oracle with
+    """The evidence behind the single-flip band of the GPU parity tests (oracle/branches.py): the SAME CPU oracle with
     torch's two exact-fp32 convolution implementations (oneDNN, and the native im2col + GEMM path with oneDNN switched off) --
     same arithmetic, other summation orders, pre-activations <= 6e-7 apart -- takes a handful of the ~250 M ReLU / max-pool
     decisions of one north-star pass the other way, every one a rounding near-tie, and that alone moves individual gradient
@@ -213,7 +213,7 @@ def test_branch_flip_census_between_two_fp32_implementations_of_the_oracle():
     apart, which is why the 1e-4 bar on every tensor is asserted with the branch decisions replayed and the goldens at the
     north-star size only inside the single-flip band."""
     import torch.nn.functional as F
-    from tests import branches
+    from oracle import branches
     z, cfg, spec = gu.load('NS')
     x, lens, y = R.synth_batch(0, spec['k'], spec['T'], spec['L'], cfg['vocab_size'], False)
     torch.set_num_threads(8)

@@ -81,7 +81,7 @@ def test_meta_iterations_match_reference_goldens(name):
         worst = max(worst, max(errs))
         clean = sum(e <= RTOL for e in errs)
         print('%s it %d: %d/%d meta-gradient tensors within 1e-4, worst %.3e' % (name, it, clean, len(errs), max(errs)))
-        # 1e-4 wherever no ReLU/max-pool branch flipped (tests/branches.py); a flip moves single tensors into the band.  Counted
+        # 1e-4 wherever no ReLU/max-pool branch flipped (oracle/branches.py); a flip moves single tensors into the band.  Counted
         # on the iteration that starts from bit-identical theta only: from the second iteration on theta already carries
         # Adam's lr*sign(g) response to the first iteration's rounding noise, and which near-ties flip depends on the
         # summation order of every kernel (fp32-MFMA and split-bf16 convolutions give 54 and 32 of 68 on F0) -- band only.
@@ -115,7 +115,7 @@ def _pass_parity(model, oracle, batch, theta, what, max_flips=8):
         must be a provable rounding near-tie, and there must be few);
     (2) oracle with the HIP pass's own branch decisions replayed (oracle.refimpl gates=): EVERY gradient tensor within 1e-4."""
     from oracle import refimpl as R
-    from tests import branches
+    from oracle import branches
     x, lens, y = batch
     _set_oracle_params(oracle, model, theta)
     out = model.pass_forward(x.cuda(), lens, y, theta=theta)
@@ -188,19 +188,23 @@ def test_single_pass_at_north_star_size_against_live_oracle():
     _pass_parity(model, oracle, batch, model.flat_parameters, 'NS single pass', max_flips=NS_FLIP_BOUND)
 
 
-def test_meta_gradient_at_north_star_size_with_branch_replay():
-    """BASELINE.json configs[1] at full size: the 3-task meta-gradient G of TransientTrainer.meta_iteration (task lanes, side
+@pytest.mark.parametrize('n_tasks,conv', [(3, 'h2'), (8, 'h2'), (3, 'x3')])
+def test_meta_gradient_at_north_star_size_with_branch_replay(n_tasks, conv):
+    """BASELINE.json configs[1] at full size: the meta-gradient G of TransientTrainer.meta_iteration (task-batched passes, side
     stream, fused inner step) against the LIVE oracle's G = sum_m [g_tr,m + g_val,m / n] computed with its own inner steps and
-    the device path's branch decisions of all six passes replayed: 190/190 tensors within 1e-4, losses within 1e-4, labels
-    bit-exact."""
+    the device path's branch decisions of all 2 n passes replayed: 190/190 tensors within 1e-4, losses within 1e-4, labels
+    bit-exact.  (3, h2): configs[1] as the README runs it; (8, h2): the schedule bench.py times (8 tasks in ONE batched pass per
+    phase); (3, x3): the same step with the convolutions on the exact 3-piece bf16 split (MTL_CONV=x3, bench.py's `conv_x3`)."""
     from oracle import refimpl as R
-    from tests import branches
+    from oracle import branches
     z, cfg, spec = gu.load('NS')
     mtl_amd, args, vocab, model = make(cfg, spec)
     model = model.cuda()
+    for e in model.engines:
+        e.conv_mode, e.conv_x3, e.conv_h2 = conv, True, conv == 'h2'
     torch.set_num_threads(min(32, torch.get_num_threads()))
     oracle = R.build_model(cfg)
-    n = spec['n_tasks']
+    n = n_tasks
     tr = [R.synth_batch(10 * m, spec['k'], spec['T'], spec['L'], cfg['vocab_size'], False) for m in range(n)]
     val = R.synth_batch(10 * (n - 1) + 1, spec['k'], spec['T'], spec['L'], cfg['vocab_size'], False)
     inner = mtl_amd.FlatSGD(model, spec['lr'])
@@ -225,8 +229,8 @@ def test_meta_gradient_at_north_star_size_with_branch_replay():
     assert all(c[0] <= 120 and c[1] < branches.NEAR_TIE for c in census), census
     errs = _rel_errs(model, model._G, oracle, G_r)
     worst = max(errs, key=errs.get)
-    print('NS 3-task meta-gradient: %d/%d tensors within 1e-4, worst %.2e (%s)'
-          % (sum(e < RTOL for e in errs.values()), len(errs), errs[worst], worst))
+    print('NS %d-task meta-gradient (conv %s): %d/%d tensors within 1e-4, worst %.2e (%s)'
+          % (n, conv, sum(e < RTOL for e in errs.values()), len(errs), errs[worst], worst))
     assert len(errs) == 190 and errs[worst] < RTOL, (worst, errs[worst])
 
 
@@ -243,7 +247,7 @@ def test_dropin_autograd_api_matches_oracle():
     pred, gold, hyp = model(x.cuda(), lens, y)
     loss, ncorrect = mtl_amd.calculate_metrics(pred, gold, 0, smoothing=0.0, loss_type='ce')
     (loss / 3).backward()
-    from tests import branches
+    from oracle import branches
     pr, gr, hr = oracle(x, lens, y, gates=branches.gates_from_engine(model.engine))
     lref = R.ce_loss(pr, gr)
     (lref / 3).backward()
@@ -327,7 +331,7 @@ def test_clip_and_label_smoothing_meta_step_against_oracle():
     args.clip, args.max_norm = True, 3.0
     oracle = R.build_model(cfg)
     tr, val = gu.batches_for(cfg, spec, 0, z['data_call_index'])
-    from tests import branches
+    from oracle import branches
     inner = mtl_amd.FlatSGD(model, spec['lr'])
     model.zero_copy_grad()
     as5 = lambda b: (b[0], b[1], None, b[2], None)
@@ -401,6 +405,14 @@ def test_two_ranks_sharded_bench_equals_single_rank():
     assert j2['n_gpus'] == 2 and j1['n_gpus'] == 1 and j2['scaling'] == 'strong'
     assert j1['last_step']['chars'] == j2['last_step']['chars'] and j1['last_step']['cer_edits'] == j2['last_step']['cer_edits']
     assert abs(j1['last_step']['val_loss'] - j2['last_step']['val_loss']) < 1e-4 * abs(j1['last_step']['val_loss'])
+    # the default above all-reduced G group by group under the validation backward (dist.ChunkedAllReduce: decoder, encoder, conv);
+    # with two ranks every element is a + b either way, so ONE collective after the backward must give the same bits of theta
+    single = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+                             '127.0.0.1', '--master-port', '29735', os.path.join(root, 'bench.py'), '--gpus', '2'] + common,
+                            capture_output=True, text=True, env=dict(env, MTL_CHUNKED_ALLREDUCE='0'), timeout=240)
+    assert single.returncode == 0, single.stderr[-2000:]
+    j3 = json.loads([l for l in single.stdout.splitlines() if l.startswith('{')][-1])
+    assert j2['theta_checksum'] == j3['theta_checksum'] and j2['last_step'] == j3['last_step'], (j2['theta_checksum'], j3['theta_checksum'])
 
 
 def test_dropout_pass_matches_oracle_with_the_same_masks():
@@ -432,7 +444,7 @@ def test_dropout_pass_matches_oracle_with_the_same_masks():
     assert len(drop) == 3 * cfg['num_enc_layers'] + 5 * cfg['num_dec_layers'] + 1
     keep_rate = float(torch.cat([v.reshape(-1) for v in drop.values()]).gt(0).float().mean())
     assert abs(keep_rate - 0.9) < 0.01
-    from tests import branches
+    from oracle import branches
     pred_r, gold_r, hyp_r = oracle(x, lens, y, drop=drop, gates=branches.gates_from_engine(model.engine))
     loss_r = R.ce_loss(pred_r, gold_r)
     grads = torch.autograd.grad(loss_r, list(oracle.parameters()))

@@ -24,7 +24,7 @@ def test_forward_one_batch_matches_reference_goldens(name):
     batches evaluated at theta0 against what the REAL reference returned (golden `fwd/0/{0,2,4}/{loss,cer}`), the in-place
     scaling of src_percentages (Q6), and loss.backward() against the oracle with the pass's branch decisions replayed."""
     from oracle import refimpl as R
-    from tests import branches
+    from oracle import branches
     z, cfg, spec = gu.load(name)
     mtl_amd, args, vocab, model = make(cfg, spec)
     model = model.cuda()
@@ -52,7 +52,7 @@ def test_forward_one_batch_label_smoothing_matches_reference_formula():
     """--label-smoothing through the compatibility call: loss and gradients vs utils/metrics.py:113-124 restated in torch."""
     import torch.nn.functional as F
     from oracle import refimpl as R
-    from tests import branches
+    from oracle import branches
     z, cfg, spec = gu.load('F0')
     mtl_amd, args, vocab, model = make(cfg, spec)
     model = model.cuda()
@@ -275,7 +275,26 @@ def test_rccl_collective_path_executes():
     j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith('{')][-1])
     j2 = json.loads([l for l in rccl.stdout.splitlines() if l.startswith('{')][-1])
     assert j2['config']['collective'] == 'nccl' and j1['config']['collective'] == 'none'
-    assert j1['last_step'] == j2['last_step']
+    assert j1['last_step'] == j2['last_step'] and j1['theta_checksum'] == j2['theta_checksum']
+    # ... that run issued the all-reduce group by group on a communication stream under the validation backward (the default with a
+    # process group: dist.ChunkedAllReduce); ONE collective after the backward and a single local task (the lane path a rank of the
+    # 8-GPU configuration takes) must leave the same bits
+    whole = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr',
+                            '127.0.0.1', '--master-port', '29743', os.path.join(ROOT, 'bench.py'), '--gpus', '1'] + common,
+                           capture_output=True, text=True, env=dict(env, MTL_DIST_ALWAYS='1', MTL_CHUNKED_ALLREDUCE='0'), timeout=300)
+    assert whole.returncode == 0, whole.stderr[-2000:]
+    j3 = json.loads([l for l in whole.stdout.splitlines() if l.startswith('{')][-1])
+    assert j3['theta_checksum'] == j2['theta_checksum']
+    one_task = common[:]
+    one_task[one_task.index('--tasks') + 1] = '1'
+    ck = []
+    for chunked in ('1', '0'):
+        r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr',
+                            '127.0.0.1', '--master-port', '29745', os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--no-extras'] + one_task,
+                           capture_output=True, text=True, env=dict(env, MTL_DIST_ALWAYS='1', MTL_CHUNKED_ALLREDUCE=chunked), timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        ck.append(json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])['theta_checksum'])
+    assert ck[0] == ck[1], ck
 
 
 def test_host_one_iteration_ahead_is_bitwise_equal(capsys):
