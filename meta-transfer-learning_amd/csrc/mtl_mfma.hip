@@ -1483,7 +1483,19 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_x3_kernel(WgradX3P p) {
     constexpr int WX_BUF = 2 * NP * WX_SUB, WX_BSTEP = NP * 2 * 64 * 16, WX_BOFF = 2 * WX_BUF;
     extern __shared__ __attribute__((aligned(16))) unsigned char smx[];
     const int tid = threadIdx.x;
-    const int pair = blockIdx.x % p.npairs, slot = blockIdx.x / p.npairs, nslots = gridDim.x / p.npairs;
+    // the channel-block pairs of one pixel-tile sequence (slot) sit 8 workgroups apart in dispatch order, i.e. on the SAME XCD, when the
+    // grid allows it: the halo / dy tiles they all read then cross the fabric once per L2 instead of once per pair (PMC, round 3: conv7
+    // 2.8x, conv5 1.7x the algorithmic bytes with the pairs of a slot on neighbouring XCDs)
+    int pair, slot;
+    const int nslots = gridDim.x / p.npairs;
+    if (gridDim.x % (8 * p.npairs) == 0) {
+        const int jb = blockIdx.x >> 3;
+        pair = jb % p.npairs;
+        slot = (jb / p.npairs) * 8 + (blockIdx.x & 7);
+    } else {
+        pair = blockIdx.x % p.npairs;
+        slot = blockIdx.x / p.npairs;
+    }
     const int cib = (pair / p.npj) * 64, cob = (pair % p.npj) * 64;
     const int my_tiles = (p.tiles - slot + nslots - 1) / nslots;
     const int T = p.T, F = p.F, Cin = p.Cin, Cout = p.Cout;

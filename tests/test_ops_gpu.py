@@ -1059,3 +1059,37 @@ def test_bf16_split_engine_k_batching_row_sums_and_tasks(L, x3_forced):
                              tasks, per * M * K, N * K, per * M * N, N, 0) == 0
     want = A.double() @ Bm.double().transpose(1, 2).unsqueeze(1) + bias.double().view(tasks, 1, 1, N)
     assert rel(C, want) < 2e-6
+
+
+@pytest.mark.parametrize('Cin,Cout,B,T,Fq', [(64, 64, 2, 21, 161), (128, 128, 1, 30, 37), (64, 64, 1, 8, 16), (128, 128, 2, 17, 80)])
+def test_conv3x3_pooled_wgrad_on_the_sparse_matrix_cores_matches_fp64(L, Cin, Cout, B, T, Fq):
+    """mtl_conv3x3_wgrad_h2 with an arg-max map runs on v_smfmac_f32_32x32x32_f16 (conv3x3_wgrad_sp_kernel: the un-pooled gradient
+    has one non-zero per 2x2 window and channel, stored as {value, 0} + the arg-max code as the 2:4 index).  ARBITRARY arg-max codes
+    and pooled gradients (not tied to a forward, so every code / window / edge combination occurs), ragged extents (odd T and F:
+    the last row / column has no window; tiles that are cut by the edge), against the fp64 weight gradient of the dense un-pooled
+    gradient; the bias gradient rides along; results accumulate into dw / db."""
+    g = torch.Generator().manual_seed(Cin + 3 * Cout + T + Fq)
+    x = torch.relu(torch.randn(B, Cin, Fq, T, generator=g))
+    Tp, Fp = T // 2, Fq // 2
+    dp = torch.randn(B, Cout, Fp, Tp, generator=g) * 1e-2
+    dp[torch.rand(dp.shape, generator=g) < 0.3] = 0.0                       # ReLU-gated entries
+    am = torch.randint(0, 4, (B, Cout, Fp, Tp), generator=g)                # code = (f & 1) << 1 | (t & 1)
+    dy = torch.zeros(B, Cout, Fq, T, dtype=torch.float64)
+    bi, ci, fi, ti = torch.meshgrid(torch.arange(B), torch.arange(Cout), torch.arange(Fp), torch.arange(Tp), indexing='ij')
+    dy[bi, ci, 2 * fi + (am >> 1), 2 * ti + (am & 1)] = dp.double()
+    want = torch.nn.grad.conv2d_weight(x.double(), (Cout, Cin, 3, 3), dy, padding=1)
+    dxn, dpn, amn = dev(nhwc(x)), dev(nhwc(dp)), dev(nhwc(am.to(torch.uint8)))
+    S = 2048
+    ax, adp = dxn.abs().max().reshape(1).repeat(S), dpn.abs().max().reshape(1).repeat(S)
+    need = L.mtl_conv3x3_wgrad_x3_workspace(B, T, Fq, Cin, Cout, 1)
+    ws = torch.empty(need // 4 + 16).cuda()
+    wg, dbp = torch.zeros(Cout, Cin, 3, 3).cuda(), torch.zeros(Cout).cuda()
+    for rep in (1, 2):                                                       # the second call accumulates
+        assert L.mtl_conv3x3_wgrad_h2(st(), dxn.data_ptr(), ax.data_ptr(), dpn.data_ptr(), adp.data_ptr(), amn.data_ptr(), wg.data_ptr(),
+                                      dbp.data_ptr(), ws.data_ptr(), need, B, T, Fq, Cin, Cout) == 0
+        assert rel(wg.double().cpu(), rep * want) < 1e-6, (rep, rel(wg.double().cpu(), rep * want))
+        assert rel(dbp.double().cpu(), rep * dp.double().sum((0, 2, 3))) < 1e-5
+    # per-tap check (a mis-routed tap or window position would hide in a norm over a random tensor far less than in its own slice)
+    for kh in range(3):
+        for kw in range(3):
+            assert rel(wg[:, :, kh, kw].double().cpu(), 2 * want[:, :, kh, kw]) < 2e-6, (kh, kw)
