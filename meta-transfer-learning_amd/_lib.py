@@ -8,7 +8,7 @@ import os
 from ctypes import c_float, c_int, c_long, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libmtl_hip.so')
+LIB_PATH = os.environ.get('MTL_LIB') or os.path.join(_HERE, 'libmtl_hip.so')     # MTL_LIB: another build of the same ABI (A/B measurements)
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'mtl_hip.h')
 
 

@@ -6,7 +6,8 @@ import torch
 import mtl_amd
 L = mtl_amd._lib.lib()
 dev = torch.device('cuda')
-shapes = [('enc self', 8, 8, 250, 250, 0), ('dec self', 8, 8, 101, 101, 1), ('dec cross', 8, 8, 101, 250, 0), ('T=5000 enc', 8, 8, 1250, 1250, 0)]
+BT = int(os.environ.get("MTL_BENCH_B", "8"))
+shapes = [('enc self', BT, 8, 250, 250, 0), ('dec self', BT, 8, 101, 101, 1), ('dec cross', BT, 8, 101, 250, 0), ('T=5000 enc', 8, 8, 1250, 1250, 0)]
 if len(sys.argv) > 1:
     shapes = shapes[:int(sys.argv[1])]
 dk = dv = 64
