@@ -1,10 +1,10 @@
 #!/bin/bash
-# Runs on the GPU box (via gpurun): collects the round's rocprofv3 summaries into gpurun_out/$ROUND (default r3; copied to profiles/$ROUND afterwards).
+# Runs on the GPU box (via gpurun): collects the round's rocprofv3 summaries into gpurun_out/$ROUND (default r4; copied to profiles/$ROUND afterwards).
 # usage: bash tools/collect_profiles.sh
 set -u
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/${ROUND:-r3}
+O=gpurun_out/${ROUND:-r4}
 mkdir -p $O
 python bench.py > $O/bench.json 2> $O/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/serial -o serial -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --serial > $O/bench_serial_traced.json 2> /dev/null

@@ -16,11 +16,12 @@ _BASE = {  # kernel template instance <BN, sub-tiles, UNPOOL, EPI (0 relu / 1 po
     'conv3x3_x3h_kernel<128, 2, true, 2': 'conv7_dgrad', 'conv3x3_x3h_kernel<64, 2, false, 2': 'conv5_dgrad',
     'conv3x3_wgrad_x3_kernel<false': 'conv5_wgrad',
     'conv3x3_wgrad_x3_kernel<true': ('conv7_wgrad', 'conv2_wgrad'),      # same instance: the backward runs conv7 first, then conv2
+    'conv3x3_wgrad_sp_kernel': ('conv7_wgrad', 'conv2_wgrad'),           # round 4: the pooled layers' 2:4-sparse form
 }
 
 
 def conv_class(kernel_name):
-    m = re.search(r'(conv3x3_x3h_kernel<\d+, \d+, \w+, \d+|conv3x3_wgrad_x3_kernel<\w+)', kernel_name)
+    m = re.search(r'(conv3x3_x3h_kernel<\d+, \d+, \w+, \d+|conv3x3_wgrad_x3_kernel<\w+|conv3x3_wgrad_sp_kernel)', kernel_name)
     return _BASE.get(m.group(1)) if m else None
 
 
