@@ -86,24 +86,6 @@ int mtl_gemm_f32_ex_route(int M, int N, int K, int batch, int kbatch, int has_ro
  * variable), set < 0 only queries; returns the previous value. */
 int mtl_gemm_x3_min_tiles(int set);
 
-/* Fused rank-R projection pair (csrc/mtl_lowrank_x3.hip): for every batch item z (three levels like mtl_gemm_f32_tb: task, outer,
- * inner; item offsets = zt * s?t + zb * s?b + zh * s?h floats)
- *     T_z[M,R] = X_z[M,Kin] . op(W1_z),      Y_z[M,N] (+)= sum_{i < kbatch} T_{z,i} . op(W2_{z,i}) (+ bias_z[N]),
- * weights_out_in = 1: the weights are nn.Linear matrices [out][in] -- W1[R,Kin], W2[N,R]: the forward pair `_linear_a` -> `_linear_b`
- * of FactorizedMultiHeadAttention (modules/common_layers.py:287-289,303); weights_out_in = 0: the products run against the
- * un-transposed weights -- W1[Kin,R], W2[R,N]: the data gradients of such a pair (d -> d . W_b -> . W_a).  kbatch > 1 sums the pairs of
- * several projections that share an input into one Y (item i at + i * s?k: dx = sum_i (d_i W_b,i) W_a,i).  T (nullable) receives the
- * intermediate of every (z, i) -- the weight gradients of the pair need it; it never makes the round trip through HBM in between.
- * flags: MTL_GEMM_ACCUM (Y += ...).  Exact 3-way bf16 split of every operand, fp32 accumulation: results of the class of the
- * two-launch form.  Shapes: mtl_lowrank_pair_supported(Kin, R, N) (R <= 128, R % 4 == 0, N % 512 == 0, Kin % 4 == 0); 16-byte
- * aligned operands, leading dimensions and strides multiples of 4; any M. */
-int mtl_lowrank_pair_supported(int Kin, int R, int N);
-int mtl_lowrank_pair_f32(void* stream, int weights_out_in, int M, int Kin, int R, int N, const float* X, int ldx, const float* W1, int ldw1,
-                         const float* W2, int ldw2, float* T, int ldt, float* Y, int ldy, const float* bias, int flags, int batch, int H,
-                         long sXb, long sXh, long sW1b, long sW1h, long sW2b, long sW2h, long sTb, long sTh, long sYb, long sYh, long sBiasB,
-                         long sBiasH, int kbatch, long sXk, long sW1k, long sW2k, long sTk, int tasks, long sXt, long sW1t, long sW2t, long sTt,
-                         long sYt, long sBiasT);
-
 /* Task-batched two-piece fp16 product on the tile engine of csrc/mtl_gemm_x3.hip (256 x 128 x 32 tiles, 8 waves, split interleaved
  * with the MFMAs; 3 v_mfma_f32_32x32x16_f16 per step): for task t < tasks
  *   C_t[M,N] = A_t[M,K] . op(B_t) (+ bias_t[N]) (gate: C = gate_t[m][n] > 0 ? C : 0),   op(B) = B[N,K]^T (transB = 1) or B[K,N] (transB = 0),

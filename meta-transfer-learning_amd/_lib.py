@@ -35,9 +35,6 @@ SIGNATURES = {
                             I, L, L, L, L, L]),
     'mtl_gemm_f32_ex_route': (I, [I, I, I, I, I, I]),
     'mtl_gemm_x3_min_tiles': (I, [I]),
-    'mtl_lowrank_pair_supported': (I, [I, I, I]),
-    'mtl_lowrank_pair_f32': (I, [P, I, I, I, I, I, P, I, P, I, P, I, P, I, P, I, P, I, I, I, L, L, L, L, L, L, L, L, L, L, L, L, I, L, L, L, L,
-                                 I, L, L, L, L, L, L]),
     'mtl_gemm_wgrad_grouped': (I, [P, P, I, I]),
     'mtl_conv0_relu_fwd': (I, [P, P, P, P, P, I, I, I, P]),
     'mtl_conv0_wgrad_workspace': (L, []),

@@ -1093,53 +1093,3 @@ def test_conv3x3_pooled_wgrad_on_the_sparse_matrix_cores_matches_fp64(L, Cin, Co
     for kh in range(3):
         for kw in range(3):
             assert rel(wg[:, :, kh, kw].double().cpu(), 2 * want[:, :, kh, kw]) < 2e-6, (kh, kw)
-
-
-@pytest.mark.parametrize('M,batch,H,tasks,kb', [(808, 6, 3, 2, 1), (70, 2, 1, 1, 3), (2000, 1, 1, 1, 1), (101, 8, 2, 4, 2)])
-@pytest.mark.parametrize('fwd', [1, 0])
-def test_fused_lowrank_pair_matches_fp64(L, M, batch, H, tasks, kb, fwd):
-    """mtl_lowrank_pair_f32 (csrc/mtl_lowrank_x3.hip): T = X op(W1) (rank 100), Y (+)= sum_i T_i op(W2_i) (+ bias) in one launch, the
-    intermediate written once as a side output -- the `_linear_a` -> `_linear_b` pairs of FactorizedMultiHeadAttention
-    (modules/common_layers.py:287-289,303: weights [out][in]) and the data gradients of such a pair (un-transposed weights, the
-    projections that share an input summed: kbatch), with the three batch levels (task, outer, inner) on every operand, ragged M,
-    accumulation into Y.  Against fp64: fp32-class (the operands are split exactly into three bf16 pieces), bitwise repeatable."""
-    Kin, R, N = 512, 100, 512
-    assert L.mtl_lowrank_pair_supported(Kin, R, N) == 1 and L.mtl_lowrank_pair_supported(Kin, 130, N) == 0 and L.mtl_lowrank_pair_supported(Kin, R, 128) == 0
-    g = torch.Generator().manual_seed(M + batch + 7 * kb + fwd)
-    nb, Zt = batch // H, batch // tasks
-    X = torch.randn(batch, kb, M, Kin, generator=g)
-    W1 = torch.randn(batch, kb, R, Kin, generator=g) / np.sqrt(Kin) if fwd else torch.randn(batch, kb, Kin, R, generator=g) / np.sqrt(Kin)
-    W2 = torch.randn(batch, kb, N, R, generator=g) / np.sqrt(R) if fwd else torch.randn(batch, kb, R, N, generator=g) / np.sqrt(R)
-    bias = torch.randn(batch, N, generator=g)
-    Y0 = torch.randn(batch, M, N, generator=g)
-    Xd, W1d, W2d = X.double(), W1.double(), W2.double()
-    Tref = Xd @ (W1d.transpose(2, 3) if fwd else W1d)
-    Yref = (Tref.float().double() @ (W2d.transpose(2, 3) if fwd else W2d)).sum(1) + bias.double().unsqueeze(1) + Y0.double()
-    dX, dW1, dW2, db = dev(X), dev(W1), dev(W2), dev(bias)
-    # item z = (zt * (Zt / H) + zb) * H + zh: every operand addressed by its three strides (floats)
-    sz = lambda t: t[0].numel()              # floats per batch item
-    def strides(t):
-        return (H * sz(t), sz(t), Zt * sz(t))           # outer, inner, task
-    outs = []
-    for _ in range(2):
-        dT = torch.full((batch, kb, M, R), float('nan')).cuda()
-        dY = dev(Y0)
-        sX, sW1, sW2, sT, sY, sB = strides(dX), strides(dW1), strides(dW2), strides(dT), strides(dY), strides(db)
-        rc = L.mtl_lowrank_pair_f32(st(), fwd, M, Kin, R, N, dX.data_ptr(), Kin, dW1.data_ptr(), Kin if fwd else R, dW2.data_ptr(),
-                                    R if fwd else N, dT.data_ptr(), R, dY.data_ptr(), N, db.data_ptr(), 2, batch, H,
-                                    sX[0], sX[1], sW1[0], sW1[1], sW2[0], sW2[1], sT[0], sT[1], sY[0], sY[1], sB[0], sB[1],
-                                    kb, M * Kin, dW1[0, 0].numel(), dW2[0, 0].numel(), M * R,
-                                    tasks, sX[2], sW1[2], sW2[2], sT[2], sY[2], sB[2])
-        assert rc == 0
-        outs.append((dT.cpu(), dY.cpu()))
-    T, Y = outs[0]
-    assert rel(T.double(), Tref) < 1e-6, rel(T.double(), Tref)
-    assert rel(Y.double(), Yref) < 2e-6, rel(Y.double(), Yref)
-    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
-    # without the side output and without accumulation / bias
-    dY = torch.full((batch, M, N), float('nan')).cuda()
-    sX, sW1, sW2, sY = strides(dX), strides(dW1), strides(dW2), strides(dY)
-    assert L.mtl_lowrank_pair_f32(st(), fwd, M, Kin, R, N, dX.data_ptr(), Kin, dW1.data_ptr(), Kin if fwd else R, dW2.data_ptr(), R if fwd else N,
-                                  None, 0, dY.data_ptr(), N, None, 0, batch, H, sX[0], sX[1], sW1[0], sW1[1], sW2[0], sW2[1], 0, 0, sY[0], sY[1], 0, 0,
-                                  kb, M * Kin, dW1[0, 0].numel(), dW2[0, 0].numel(), 0, tasks, sX[2], sW1[2], sW2[2], 0, sY[2], 0) == 0
-    assert rel(dY.cpu().double(), Yref - bias.double().unsqueeze(1) - Y0.double()) < 2e-6
