@@ -146,6 +146,8 @@ def classify(lib, name, a, conv_mode, wgrad_x3_dense):
         kind = 'wgrad' if 'wgrad' in name else ('dgrad' if 'dgrad' in name else ('fwd_pool' if 'pool' in name else 'fwd'))
         if name.endswith('_x3') or name.endswith('_h2'):
             sym = ('conv3x3_wgrad_x3_kernel<.,%d>' if kind == 'wgrad' else 'conv3x3_x3h_kernel<...,%d>') % (2 if name.endswith('_h2') else 3)
+            if kind == 'wgrad' and name.endswith('_h2') and a[5] and os.environ.get('MTL_WGRAD_SPARSE', '1') != '0':
+                sym = 'conv3x3_wgrad_sp_kernel (pooled layer: 2:4-sparse v_smfmac_f32_32x32x32_f16)'      # the arg-max map is given
         else:
             sym = 'conv3x3_wgrad_kernel' if kind == 'wgrad' else 'conv3x3_kernel'
         return ('conv%d_%s' % (_conv_layer(cin, cout), kind), 2.0 * B * T * F * 9 * cin * cout, 'flop', sym)
@@ -205,7 +207,7 @@ def classify(lib, name, a, conv_mode, wgrad_x3_dense):
 # classes (layer x direction) cannot hide behind one GEMM class that lumps thirteen shapes together
 def family_of(cls, symbols):
     if cls.startswith('conv') and cls.endswith('_wgrad') and not cls.startswith('conv0'):
-        return 'conv3x3_wgrad_x3_kernel' if 'wgrad_x3' in symbols else 'conv3x3_wgrad_kernel'
+        return 'conv3x3_wgrad_sp_kernel' if 'wgrad_sp' in symbols else ('conv3x3_wgrad_x3_kernel' if 'wgrad_x3' in symbols else 'conv3x3_wgrad_kernel')
     if cls.startswith('conv') and not cls.startswith('conv0') and ('_fwd' in cls or '_dgrad' in cls):
         return 'conv3x3_x3h_kernel' if 'x3h' in symbols else 'conv3x3_kernel'
     return {'gemm_x3': 'gemm_x3_kernel<.,.,.,.,3>', 'gemm_h2': 'gemm_x3_kernel<.,.,.,.,2>', 'gemm_small': 'gemm16_kernel', 'gemm_big': 'gemm_kernel',
@@ -591,6 +593,11 @@ def main():
                 peak, unit, bound = peak_of(cls, c['unit'], eng.conv_mode, eng.wgrad_x3_dense)
                 ach = c['work'] / c['time'] / (1e12 if c['unit'] == 'flop' else 1e9)
                 row.update(bound=bound, achieved=ach, peak=peak, unit=unit, frac=ach / peak)
+                if 'wgrad_sp' in c['symbols']:
+                    # `achieved` counts the ALGORITHMIC (dense-equivalent) FLOPs of the reference op; the kernel issues half of them as
+                    # 2:4-sparse instructions, whose peak is twice the dense one
+                    row.update(frac_of_sparse_peak=ach / (2 * peak), note='frac: dense-equivalent FLOPs / dense two-piece-fp16 peak (838.9 TF); '
+                               'frac_of_sparse_peak: the same FLOPs / the 2:4-sparse peak (1677.7 TF) the instructions issue at')
             table[cls] = row
         for cls, row in table.items():
             if cls in pmc:
@@ -621,6 +628,8 @@ def main():
             fam_table[name] = dict(ms_per_pass=f['time'] / passes * 1e3, launches_per_pass=f['launches'] / passes, bound=bound, achieved=ach,
                                    peak=peak, unit=unit, frac=ach / peak, classes=f['classes'],
                                    traffic=(f['traffic'] / f['launches']) if (f['traffic_known'] and f['launches']) else None)
+            if name == 'conv3x3_wgrad_sp_kernel':
+                fam_table[name]['frac_of_sparse_peak'] = ach / (2 * peak)
         dom = next(iter(fam_table))                      # (sorted by accumulated time)
         df, dr = fams[dom], fam_table[dom]
         arith = ('split-bf16 x3: 6 v_mfma_f32_32x32x16_bf16 per fp32-equivalent step, peak = dense bf16 / 6' if dr['peak'] == PEAK_X3_TFLOPS else (

@@ -13,16 +13,21 @@ from tests import golden_util as gu
 
 pytestmark = pytest.mark.gpu
 RTOL = 1e-4          # north_star: fp32 loss and meta-gradients within 1e-4 relative
-# fraction of the 190 (68) gradient tensors that must meet 1e-4 against the reference GOLDENS, whose ReLU / max-pool decisions are
-# frozen in the file: ~20 near-tie branch flips per north-star pass are expected between ANY two fp32 implementations, and WHICH
-# of them flip changes with every change of a kernel's summation order (measured 154/190 and 79/190 at NS with two GEMM tilings --
-# one flipped encoder ReLU moves every encoder tensor by ~2e-4 -- and 186/190 at F1), so this count only guards against gross
-# errors.  The 1e-4 bar on ALL tensors is asserted against the live oracle with the device path's own decisions replayed
-# (test_single_pass_at_north_star_size_against_live_oracle, test_meta_gradient_at_north_star_size_with_branch_replay).
-CLEAN_FRACTION = {'F0': 0.6, 'F1': 0.9, 'NS': 0.25}
-# F0 is zero-padded (variable lengths): its padded region is a constant feature map, so a near-tie there flips a whole
-# region at once (second iteration, after a 1e-3 Adam step); F1 (the real architecture) must stay inside 1e-2.
-GOLDEN_BAND = {'F0': 5e-2, 'F1': 1e-2, 'NS': 1e-2}
+# Against the reference GOLDENS the ReLU / max-pool decisions are frozen in the file: ~20 near-tie branch flips per north-star pass
+# are expected between ANY two fp32 implementations (tests/test_oracle_golden.py: the CPU oracle itself reaches 148 / 176 tensors
+# <= 1e-4 and all <= 1e-3 against NS.npz; two exact-fp32 convolution paths of the SAME oracle differ in 13 decisions and by 2.9e-4).
+# The gates below are what this build MEASURES (deterministic: every kernel is bitwise reproducible), with the stated margins -- they
+# move when a kernel's summation order changes (which near-ties flip), so a change of a kernel is expected to re-measure them:
+#   measured, round 4 (sparse weight gradients, bf16-split attention):  F0 it 0: 67 / 68 clean, worst 1.9e-4; it 1: worst 3.7e-2
+#                                                                       F1 it 0: 184 / 190 clean, worst 3.06e-3
+#                                                                       NS it 0: 154 / 190 clean, worst 3.14e-4
+# CLEAN_MIN: tensors within 1e-4 on the iteration that starts from bit-identical theta (measured minus a margin of ~10 %);
+# GOLDEN_BAND: every tensor, every iteration (<= 2 x the measured worst; F0's second iteration -- zero-padded, variable lengths: a
+# near-tie in the constant padded region flips a whole region after a 1e-3 Adam step -- 1.4 x).
+# The 1e-4 bar on ALL tensors is asserted against the live oracle with the device path's own decisions replayed
+# (test_single_pass_at_north_star_size_against_live_oracle, test_meta_gradient_at_north_star_size_with_branch_replay: 3 and 8 tasks).
+CLEAN_MIN = {'F0': 60, 'F1': 170, 'NS': 135}
+GOLDEN_BAND = {'F0': 5e-2, 'F1': 6.2e-3, 'NS': 6.3e-4}
 NS_FLIP_BOUND = 120   # free-running ReLU / max-pool near-tie disagreements per north-star pass (measured ~25 of ~250 M branch points)
 
 
@@ -86,7 +91,7 @@ def test_meta_iterations_match_reference_goldens(name):
         # Adam's lr*sign(g) response to the first iteration's rounding noise, and which near-ties flip depends on the
         # summation order of every kernel (fp32-MFMA and split-bf16 convolutions give 54 and 32 of 68 on F0) -- band only.
         if it == 0:
-            assert clean >= CLEAN_FRACTION[name] * len(errs), (clean, len(errs))
+            assert clean >= CLEAN_MIN[name], (clean, len(errs))
         for (nm, p), e in zip(model.named_parameters(), errs):
             if float(z['G/%d/%s/l2' % (it, nm)]) < floor * 1e-2:
                 continue        # Adam on an exactly-zero gradient: sign of rounding noise (see tests/test_oracle_golden.py)
@@ -316,8 +321,8 @@ def test_joint_trainer_config0_against_reference_golden():
         floor = 1e-4 * gu.global_l2(z, 'G/%d' % it, names)
         errs = [gu.check_digest(z, 'G/%d' % it, nm, model._layout.view(grads[it], nm), rtol=GOLDEN_BAND['F0'], what='J0', floor=floor)
                 for nm in names]
-        if it == 0:       # see test_meta_iterations_match_reference_goldens
-            assert sum(e <= RTOL for e in errs) >= 0.6 * len(errs)
+        if it == 0:       # see test_meta_iterations_match_reference_goldens (measured: 67 / 68 clean, worst 1.7e-4; it 1: worst 1.7e-2)
+            assert sum(e <= RTOL for e in errs) >= 60
         print('J0 it %d: %d/%d gradient tensors within 1e-4, worst %.2e' % (it, sum(e <= RTOL for e in errs), len(errs), max(errs)))
 
 
