@@ -92,10 +92,11 @@ int mtl_gemm_x3_min_tiles(int set);
  * operands of task t at base + t * s?t (sBt = 0: shared weights), its bounds max|A_t| / max|B_t| at amax_? + t * sAmax? floats
  * (MTL_AMAX_SLOTS slot heads each, as for the *_h2 convolutions; gate shares C's offsets).  The encoder's input Linear (5120 -> 512,
  * models/asr/transformer.py:136-140, modules/encoder.py:72) of all tasks of a pass in one launch, and its data gradient straight from the
- * un-transposed weight (transB = 0).  Any M, N, K; 16-byte aligned operands, lda / ldb / strides multiples of 4. */
+ * un-transposed weight (transB = 0).  Any M, N, K; 16-byte aligned operands, lda / ldb / strides multiples of 4.
+ * workspace (nullable): with ONE task, few output tiles and K >= 2048 the reduction is split over the grid into it (fixed-order sum). */
 int mtl_gemm_h2_tb(void* stream, int transB, int M, int N, int K, const float* A, int lda, const float* amax_a, long sAmaxA,
                    const float* B, int ldb, const float* amax_b, long sAmaxB, float* C, int ldc, const float* bias, const float* gate,
-                   int ldg, int tasks, long sAt, long sBt, long sCt, long sBiasT);
+                   int ldg, int tasks, long sAt, long sBt, long sCt, long sBiasT, float* workspace, long workspace_bytes);
 
 /* Grouped weight gradients: ONE launch computes  C_i += A_i^T . B_i  (and rowsum_i += column sums of A_i, nullable) for a whole
  * table of independent products -- all the small dW = dy^T . x of a backward pass (nn.Linear weight + bias gradients,

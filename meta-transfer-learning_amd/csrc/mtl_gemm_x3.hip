@@ -54,6 +54,7 @@ struct X3P {
     // two-piece fp16 form (NP = 2): bounds of max|A|, max|B| (MTL_AMAX_SLOTS slot heads each, mtl_h2.h) and their task strides in floats
     const float *amax_a, *amax_b;
     long sAmaxA, sAmaxB;
+    int Ksplit;            // split-K launches: the product's full K; item zb (outer batch index) covers k in [zb K, min((zb + 1) K, Ksplit)) -- 0: off
 };
 
 // x0, x1 -> three dwords of packed bf16 pairs, x = h + m + l EXACTLY: h and m are truncations (top 8 significand bits of x and of
@@ -210,6 +211,7 @@ __global__ __launch_bounds__(NT) void gemm_x3_kernel(X3P p) {
     const int m0 = (rem / nx) * BM, n0 = (rem % nx) * BN;
     const int zt = z / p.Zt, zz = z - zt * p.Zt;
     const int zb = zz / p.H, zh = zz - zb * p.H;
+    const int Kz = p.Ksplit ? min(p.K, p.Ksplit - zb * p.K) : p.K;      // this item's reduction length (the last K slice may be shorter)
     float sa = 1.f, sb = 1.f;                     // NP = 2: the power-of-two scales of this task's operands (full waves read the bounds)
     if constexpr (NP == 2) {
         sa = pow2_scale(amax_read(p.amax_a + zt * p.sAmaxA));
@@ -221,7 +223,7 @@ __global__ __launch_bounds__(NT) void gemm_x3_kernel(X3P p) {
     lb.init(p.B + zt * p.sBt + zb * p.sBb + zh * p.sBh, p.ldb, n0, p.N, tid);
     typename OA::Regs ra0, ra1;
     typename OB::Regs rb0, rb1;
-    const int nk = (p.K + BK - 1) / BK, tiles = nk * p.kb;
+    const int nk = (Kz + BK - 1) / BK, tiles = nk * p.kb;
     f32x16 acc[TM][2];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -230,12 +232,12 @@ __global__ __launch_bounds__(NT) void gemm_x3_kernel(X3P p) {
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
     const bool do_rowsum = RS && n0 == 0;     // (every workgroup sums -- 16 adds per tile --, the first column of workgroups stores)
-    const bool kfull = p.K % BK == 0;             // no ragged last K tile
+    const bool kfull = Kz % BK == 0;              // no ragged last K tile
     float rs[4] = {0.f, 0.f, 0.f, 0.f};
     auto fetch = [&](int tile, typename OA::Regs& ra, typename OB::Regs& rb) {
         const int zn = tile / nk, kt = tile - zn * nk;
-        la.fetch(ra, zn * p.sAk, kt * BK, p.K, tid);
-        lb.fetch(rb, zn * p.sBk, kt * BK, p.K, tid);
+        la.fetch(ra, zn * p.sAk, kt * BK, Kz, tid);
+        lb.fetch(rb, zn * p.sBk, kt * BK, Kz, tid);
     };
     auto commit = [&](auto full_tag, const typename OA::Regs& ra, const typename OB::Regs& rb, unsigned char* stage) {
         constexpr bool FULL = decltype(full_tag)::value;
@@ -465,31 +467,42 @@ __global__ __launch_bounds__(256) void x3_splitk_sum_kernel(const float* __restr
     }
 }
 
+// K slices of the split-K form: -> number of slices S (0: not applicable) and the slice length Kc (a multiple of 32: slice starts are
+// tile- and 16-byte aligned; the last slice is shorter when S Kc > K -- X3P::Ksplit).  Enough slices to give every CU a workgroup,
+// each at least `mindepth` deep, all partials inside the workspace.
+static int splitk_plan(long tiles, int M, int N, int K, long ws_bytes, int* Kc_out) {
+    static const int mindepth = getenv("MTL_GEMM_X3_SPLITK_MIN") ? atoi(getenv("MTL_GEMM_X3_SPLITK_MIN")) : 256;
+    int S = (int)((256 + tiles - 1) / tiles);
+    if (S > K / mindepth) S = K / mindepth;
+    while (S >= 2 && (long)S * M * N * 4 > ws_bytes) --S;
+    if (S < 2) return 0;
+    const int Kc = ((K + S - 1) / S + 31) / 32 * 32;
+    S = (K + Kc - 1) / Kc;
+    if (S < 2) return 0;
+    *Kc_out = Kc;
+    return S;
+}
+
 // number of K slices the split-K form would use (0: not applicable)
 int mtl_gemm_x3_splitk_slices(int transA, int transB, int M, int N, int K, int flags, long ws_bytes) {
     const int mt = min_tiles_now();
     const long tiles = x3_tiles(M, N, 1, 128);
-    static const long longk = getenv("MTL_GEMM_X3_SPLITK") ? atol(getenv("MTL_GEMM_X3_SPLITK")) : 4096;
+    // (round 4: from 2048 deep -- the one-task vocabulary-projection data gradient, 808 x 512 x 3765 on 28 tiles: 72 -> 30 us)
+    static const long longk = getenv("MTL_GEMM_X3_SPLITK") ? atol(getenv("MTL_GEMM_X3_SPLITK")) : 2048;
     if (mt <= 0 || longk <= 0 || (transA && transB) || tiles >= mt || K < longk || (N & 3) || (flags & ~MTL_GEMM_ACCUM)) return 0;
-    // S slices of equal length (a multiple of 4 elements: 16-byte aligned slice starts), each >= 512 deep, enough of them to fill the chip
-    auto ok = [&](int c) { return K % c == 0 && (K / c) % 4 == 0 && K / c >= 512 && (long)c * M * N * 4 <= ws_bytes && tiles * c >= mt; };
-    const int want = (int)((256 + tiles - 1) / tiles);
-    for (int c = want; c >= 2; --c)
-        if (ok(c)) return c;
-    for (int c = want + 1; c <= 64; ++c)
-        if (ok(c)) return c;
-    return 0;
+    int Kc;
+    return splitk_plan(tiles, M, N, K, ws_bytes, &Kc);
 }
 
 int mtl_gemm_x3_splitk(void* stream, int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda, const float* B,
                        int ldb, float* C, int ldc, const float* bias, int flags, float* ws, long ws_bytes) {
     if (!ws || (ldc & 3) || !al16(C) || (bias && !al16(bias)) || !al16(A) || !al16(B) || (lda & 3) || (ldb & 3)) return 0;
-    const int S = mtl_gemm_x3_splitk_slices(transA, transB, M, N, K, flags, ws_bytes);
-    if (!S) return 0;
-    const int Kc = K / S;
+    if (!mtl_gemm_x3_splitk_slices(transA, transB, M, N, K, flags, ws_bytes)) return 0;
+    int Kc = 0;
+    const int S = splitk_plan(x3_tiles(M, N, 1, 128), M, N, K, ws_bytes, &Kc);
     const long sA = transA ? (long)Kc * lda : Kc, sB = transB ? Kc : (long)Kc * ldb;
     X3P p{A, B, ws, nullptr, nullptr, nullptr, M, N, Kc, lda, ldb, N, 0, alpha, 0, 1, sA, 0, sB, 0, (long)M * N, 0, 0, 1,
-          0, 0, 0, 0, 0, S, 0, 0, 0, 0, 0, S, nullptr, nullptr, 0, 0};
+          0, 0, 0, 0, 0, S, 0, 0, 0, 0, 0, S, nullptr, nullptr, 0, 0, K};
     hipStream_t s = as_stream(stream);
     const bool big = x3_tiles(M, N, S, 256) >= 224;
     int rc;
@@ -506,12 +519,35 @@ int mtl_gemm_x3_splitk(void* stream, int transA, int transB, int M, int N, int K
 
 extern "C" int mtl_gemm_h2_tb(void* stream, int transB, int M, int N, int K, const float* A, int lda, const float* amax_a, long sAmaxA,
                               const float* B, int ldb, const float* amax_b, long sAmaxB, float* C, int ldc, const float* bias,
-                              const float* gate, int ldg, int tasks, long sAt, long sBt, long sCt, long sBiasT) {
+                              const float* gate, int ldg, int tasks, long sAt, long sBt, long sCt, long sBiasT, float* workspace,
+                              long workspace_bytes) {
     if (M <= 0 || N <= 0 || K <= 0 || tasks <= 0 || !A || !B || !C || !amax_a || !amax_b) return MTL_EINVAL;
     if (!al16(A) || !al16(B) || (lda & 3) || (ldb & 3) || ((sAt | sBt) & 3)) return MTL_EINVAL;
+    hipStream_t s = as_stream(stream);
+    // ONE task, few output tiles, long K (the encoder's input Linear of a rank that holds a single task: 2000 x 512 x 5120 = 64 tiles
+    // on 256 CUs, 115 us): K slices over the grid into the workspace + the fixed-order sum (bias there)
+    static const bool splitk_on = !(getenv("MTL_GEMM_H2_SPLITK") && atoi(getenv("MTL_GEMM_H2_SPLITK")) == 0);
+    const long tiles = x3_tiles(M, N, 1, 128);
+    if (splitk_on && tasks == 1 && !gate && workspace && tiles < 128 && K >= 2048 && !(N & 3) && !(ldc & 3) && al16(C) && (!bias || al16(bias))) {
+        int Kc = 0;
+        const int S = splitk_plan(tiles, M, N, K, workspace_bytes, &Kc);
+        if (S >= 2) {
+            X3P p{A, B, workspace, nullptr, nullptr, nullptr, M, N, Kc, lda, ldb, N, 0, 1.f, 0, 1, (long)Kc, 0, transB ? (long)Kc : (long)Kc * ldb, 0,
+                  (long)M * N, 0, 0, 1, 0, 0, 0, 0, 0, S, 0, 0, 0, 0, 0, S, amax_a, amax_b, 0, 0, K};
+            const bool big = x3_tiles(M, N, S, 256) >= 224;
+            int rc;
+            if (transB) rc = big ? launch_x3<false, true, false, 256, 2>(p, s) : launch_x3<false, true, false, 128, 2>(p, s);
+            else rc = big ? launch_x3<false, false, false, 256, 2>(p, s) : launch_x3<false, false, false, 128, 2>(p, s);
+            if (rc != MTL_OK) return rc;
+            const long total = (long)M * (N / 4);
+            hipLaunchKernelGGL(x3_splitk_sum_kernel, dim3((unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048)), dim3(256), 0, s, workspace, C,
+                               bias, M, N, ldc, S, 0);
+            MTL_CHECK_LAUNCH();
+            return MTL_OK;
+        }
+    }
     X3P p{A, B, C, bias, gate, nullptr, M, N, K, lda, ldb, ldc, ldg, 1.f, 0, 1, 0, 0, 0, 0, 0, 0, 0, 1,
           0, 0, 0, 0, 0, 1, sAt, sBt, sCt, sBiasT, 0, tasks, amax_a, amax_b, sAmaxA, sAmaxB};
-    hipStream_t s = as_stream(stream);
     const bool big = x3_tiles(M, N, tasks, 256) >= 128;
     if (transB) return big ? launch_x3<false, true, false, 256, 2>(p, s) : launch_x3<false, true, false, 128, 2>(p, s);
     return big ? launch_x3<false, false, false, 256, 2>(p, s) : launch_x3<false, false, false, 128, 2>(p, s);

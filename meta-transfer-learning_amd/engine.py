@@ -1193,7 +1193,8 @@ class PassEngine:
             # ONE task-batched launch on the tile engine of mtl_gemm_x3.hip (per-task bounds by stride)
             check(lib.mtl_gemm_h2_tb(st, 1, Me, d, hp.d_in, p2.data_ptr(), hp.d_in, am_(6), am_st, wp.data_ptr(), hp.d_in, am_(7),
                                      am_st if sP else 0, e0.data_ptr(), d, o('encoder.input_linear.bias'), None, 0, nt,
-                                     Me * hp.d_in, d * hp.d_in if sP else 0, Me * d, self.sP), 'mtl_gemm_h2_tb')
+                                     Me * hp.d_in, d * hp.d_in if sP else 0, Me * d, self.sP, self.gemm_ws.data_ptr(), self.gemm_ws.numel() * 4),
+                  'mtl_gemm_h2_tb')
         else:
             self.gemm(0, 1, Me, d, hp.d_in, p2.data_ptr(), hp.d_in, wp.data_ptr(), hp.d_in, e0.data_ptr(), d,
                       bias=o('encoder.input_linear.bias'), task=(Me * hp.d_in, d * hp.d_in if sP else 0, Me * d, self.sP, 0))
@@ -1454,7 +1455,7 @@ class PassEngine:
             am_st = 12 * _lib.AMAX_SLOTS
             check(lib.mtl_gemm_h2_tb(st, 0, Me, hp.d_in, d, de0.data_ptr(), d, am_(8), am_st, A['wp_in'].data_ptr(), hp.d_in, am_(7),
                                      am_st if sP else 0, dp2.data_ptr(), hp.d_in, None, p2.data_ptr(), hp.d_in, nt, Me * d,
-                                     d * hp.d_in if sP else 0, Me * hp.d_in, 0), 'mtl_gemm_h2_tb')
+                                     d * hp.d_in if sP else 0, Me * hp.d_in, 0, None, 0), 'mtl_gemm_h2_tb')
         else:
             self.gemm(0, 0, Me, hp.d_in, d, de0.data_ptr(), d, A['wp_in'].data_ptr(), hp.d_in, dp2.data_ptr(), hp.d_in,
                       gate=p2.data_ptr(), ldg=hp.d_in, task=(Me * d, d * hp.d_in if sP else 0, Me * hp.d_in, 0, 0))

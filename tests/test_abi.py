@@ -106,7 +106,9 @@ def test_product_routing_is_a_pure_host_decision(built):
         assert L.mtl_gemm_f32_ex_route(2000, 512, 512, 8, 1, 0) == 2          # 16 x 4 x 8 tiles of 128 x 128
         assert L.mtl_gemm_f32_ex_route(808, 100, 512, 1, 1, 0) == 1           # 7 tiles: small-tile engine
         assert L.mtl_gemm_f32_ex_route(700, 512, 10000, 1, 1, 0) == 2         # 24 tiles x K = 10000: ten K slices
-        assert L.mtl_gemm_f32_ex_route(700, 512, 10001, 1, 1, 0) != 2         # no equal slicing in multiples of 4
+        assert L.mtl_gemm_f32_ex_route(700, 512, 10001, 1, 1, 0) == 2         # (slices are multiples of 32 deep, the last one ragged)
+        assert L.mtl_gemm_f32_ex_route(808, 512, 3765, 1, 1, 0) == 2          # one-task vocabulary projection dX: 28 tiles, K >= 2048
+        assert L.mtl_gemm_f32_ex_route(808, 512, 1500, 1, 1, 0) != 2          # too shallow to split
         assert L.mtl_gemm_f32_ex_route(700, 512, 10000, 1, 1, 1) == 1         # row sums ride on the small-tile engine
         assert L.mtl_gemm_f32_ex_route(700, 512, 2048, 1, 1, 0) == 1          # K below the split-K threshold
         L.mtl_gemm_x3_min_tiles(0)

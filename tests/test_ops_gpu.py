@@ -913,14 +913,18 @@ def test_spectrogram_front_end_matches_oracle(L, tmp_path):
 
 
 @pytest.mark.parametrize('transB,M,N,K,tasks,shared,gate,bias', [(1, 300, 512, 640, 3, True, False, True), (0, 300, 640, 512, 3, True, True, False),
-                                                                 (1, 2000, 512, 5120, 2, False, False, True), (0, 257, 132, 100, 2, False, True, False)])
+                                                                 (1, 2000, 512, 5120, 2, False, False, True), (0, 257, 132, 100, 2, False, True, False),
+                                                                 (1, 2000, 512, 5120, 1, False, False, True), (0, 300, 512, 2100, 1, True, False, False)])
 def test_gemm_two_piece_fp16_task_batched(L, transB, M, N, K, tasks, shared, gate, bias):
     """mtl_gemm_h2_tb (the tile engine of mtl_gemm_x3.hip with fp16 pairs): per-task operands, bounds and biases by stride, shared or
     per-task weights, both weight orientations, gate, ragged M / N / K; against fp64 no less accurate than 2x the exact-fp32 engine of
-    this library, bitwise reproducible; a quiet task beside a loud one keeps its accuracy (the scale is per task)."""
+    this library, bitwise reproducible; a quiet task beside a loud one keeps its accuracy (the scale is per task).  ONE task with few
+    output tiles and K >= 2048 (the input Linear of a rank that holds a single task): the K range is split over the grid into the
+    workspace (ragged last slice: 5120 = 4 x 1280, 2100 = 2 x 1056 - 12) and summed in a fixed order -- same bars."""
     g = torch.Generator().manual_seed(M + N + K + tasks)
     A = torch.randn(tasks, M, K, generator=g) * 3e-3
-    A[1] *= 2.0 ** -12                                       # a quiet task: its own bound, its own scale
+    if tasks > 1:
+        A[1] *= 2.0 ** -12                                   # a quiet task: its own bound, its own scale
     nb = 1 if shared else tasks
     Bm = torch.randn(nb, N, K, generator=g) * 0.5 if transB else torch.randn(nb, K, N, generator=g) * 0.5
     bv = torch.randn(tasks, N, generator=g) * 1e-4 if bias else None
@@ -940,9 +944,10 @@ def test_gemm_two_piece_fp16_task_batched(L, transB, M, N, K, tasks, shared, gat
         assert L.mtl_absmax_f32(st(), dB[t].data_ptr(), Bm[t].numel(), ab[t].data_ptr()) == 0
     dbv, dgt = (dev(bv) if bias else None), (dev(gt) if gate else None)
     C, C2 = torch.full((tasks, M, N), 7.0).cuda(), torch.empty(tasks, M, N).cuda()
+    wsk = torch.empty(8 << 20).cuda()
     args = lambda out: (st(), transB, M, N, K, dA.data_ptr(), K, aa.data_ptr(), S, dB.data_ptr(), Bm.shape[2], ab.data_ptr(), 0 if shared else S,
                         out.data_ptr(), N, dbv.data_ptr() if bias else None, dgt.data_ptr() if gate else None, N, tasks, M * K,
-                        0 if shared else Bm[0].numel(), M * N, N if bias else 0)
+                        0 if shared else Bm[0].numel(), M * N, N if bias else 0, wsk.data_ptr(), wsk.numel() * 4)
     assert L.mtl_gemm_h2_tb(*args(C)) == 0
     assert L.mtl_gemm_h2_tb(*args(C2)) == 0
     assert torch.equal(C, C2)

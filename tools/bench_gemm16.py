@@ -10,7 +10,9 @@ dev = torch.device('cuda')
 shapes = [('dB enc  dy^T a', 1, 0, 512, 100, 2000, 3, 1), ('dA enc  da^T x', 1, 0, 100, 512, 2000, 3, 0), ('dW ffn enc', 1, 0, 512, 512, 2000, 1, 1),
           ('dB dec', 1, 0, 512, 100, 808, 3, 1), ('dW ffn dec', 1, 0, 512, 512, 808, 1, 1),
           ('a-stage enc', 0, 1, 2000, 100, 512, 3, 0), ('b-stage enc', 0, 1, 2000, 512, 100, 3, 0), ('ffn1 dec', 0, 1, 808, 512, 512, 1, 0),
-          ('dX b-stage dec', 0, 0, 808, 100, 512, 3, 0), ('vocab dX', 0, 0, 808, 512, 3768, 1, 0)]
+          ('dX b-stage dec', 0, 0, 808, 100, 512, 3, 0), ('vocab dX', 0, 0, 808, 512, 3768, 1, 0),
+          ('a-stage dec', 0, 1, 808, 100, 512, 1, 0), ('b-stage dec', 0, 1, 808, 512, 100, 1, 0), ('ffn dX dec', 0, 0, 808, 512, 512, 1, 0),
+          ('ffn1 enc', 0, 1, 2000, 512, 512, 1, 0), ('da dec', 0, 0, 808, 100, 512, 1, 0), ('dx a-stage dec', 0, 0, 808, 512, 100, 1, 0)]
 st = torch.cuda.current_stream().cuda_stream
 for name, ta, tb, M, N, K, nb, rsum in shapes:
     A = torch.randn(nb, K, M, device=dev) if ta else torch.randn(nb, M, K, device=dev)
