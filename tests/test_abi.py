@@ -110,7 +110,7 @@ def test_product_routing_is_a_pure_host_decision(built):
         assert L.mtl_gemm_f32_ex_route(808, 512, 3765, 1, 1, 0) == 2          # one-task vocabulary projection dX: 28 tiles, K >= 2048
         assert L.mtl_gemm_f32_ex_route(808, 512, 1500, 1, 1, 0) != 2          # too shallow to split
         assert L.mtl_gemm_f32_ex_route(700, 512, 10000, 1, 1, 1) == 1         # row sums ride on the small-tile engine
-        assert L.mtl_gemm_f32_ex_route(700, 512, 2048, 1, 1, 0) == 1          # K below the split-K threshold
+        assert L.mtl_gemm_f32_ex_route(700, 512, 2000, 1, 1, 0) == 1          # K below the split-K threshold (2048)
         L.mtl_gemm_x3_min_tiles(0)
         assert L.mtl_gemm_f32_ex_route(2000, 512, 512, 8, 1, 0) != 2          # engine off
     finally:
