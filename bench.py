@@ -139,6 +139,8 @@ def classify(lib, name, a, conv_mode, wgrad_x3_dense):
                 'gemm16_kernel<...>' if small else 'gemm_kernel<...> (+ splitk_reduce_kernel)')
     if name == 'mtl_gemm_h2_tb':
         return 'gemm_h2', 2.0 * a[2] * a[3] * a[4] * a[18], 'flop', 'gemm_x3_kernel<.,.,.,BM,2> (two fp16 pieces)'
+    if name == 'mtl_gemm_h2_tn_tb':
+        return 'gemm_h2', 2.0 * a[1] * a[2] * a[3] * a[14], 'flop', 'gemm_x3_kernel<.,.,.,BM,2> (two fp16 pieces)'
     if name == 'mtl_gemm_wgrad_grouped':
         return 'gemm_wgrad_grouped', GROUP_FLOPS.get(int(a[1] or 0)), 'flop', 'gemm16_kernel<true,false,true,4,1,1> (grouped)'
     if name.startswith('mtl_conv3x3_') and 'wprep' not in name:
@@ -242,6 +244,9 @@ def algorithmic_bytes(name, a, unit, work):
         return 4.0 * batch * (M * K * kb + K * N * kb + M * N)
     if name == 'mtl_gemm_h2_tb':
         M, N, K, nt = a[2], a[3], a[4], a[18]
+        return 4.0 * nt * (M * K + K * N + M * N)
+    if name == 'mtl_gemm_h2_tn_tb':
+        M, N, K, nt = a[1], a[2], a[3], a[14]
         return 4.0 * nt * (M * K + K * N + M * N)
     if name in ('mtl_attn_fwd', 'mtl_attn_bwd'):
         B, H, Tq, Tk, dk = a[10], a[11], a[12], a[13], a[14]

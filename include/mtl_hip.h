@@ -97,6 +97,10 @@ int mtl_gemm_x3_min_tiles(int set);
 int mtl_gemm_h2_tb(void* stream, int transB, int M, int N, int K, const float* A, int lda, const float* amax_a, long sAmaxA,
                    const float* B, int ldb, const float* amax_b, long sAmaxB, float* C, int ldc, const float* bias, const float* gate,
                    int ldg, int tasks, long sAt, long sBt, long sCt, long sBiasT, float* workspace, long workspace_bytes);
+/* the transposed-A form of the same engine: C_t[M,N] = A_t[K,M]^T . B_t[K,N] on two fp16 pieces (bounds as above) -- the weight gradient
+ * of the encoder's input Linear, dW = de0^T . p2 (K = rows of the pass, M = 512, N = 5120), whose operands' bounds the pass has anyway */
+int mtl_gemm_h2_tn_tb(void* stream, int M, int N, int K, const float* A, int lda, const float* amax_a, long sAmaxA, const float* B, int ldb,
+                      const float* amax_b, long sAmaxB, float* C, int ldc, int tasks, long sAt, long sBt, long sCt);
 
 /* Grouped weight gradients: ONE launch computes  C_i += A_i^T . B_i  (and rowsum_i += column sums of A_i, nullable) for a whole
  * table of independent products -- all the small dW = dy^T . x of a backward pass (nn.Linear weight + bias gradients,

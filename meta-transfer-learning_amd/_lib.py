@@ -60,6 +60,7 @@ SIGNATURES = {
     'mtl_conv3x3_wgrad_h2': (I, [P, P, P, P, P, P, P, P, P, L, I, I, I, I, I]),
     'mtl_absmax_f32': (I, [P, P, L, P]),
     'mtl_gemm_h2_tb': (I, [P, I, I, I, I, P, I, P, L, P, I, P, L, P, I, P, P, I, I, L, L, L, L, P, L]),
+    'mtl_gemm_h2_tn_tb': (I, [P, I, I, I, P, I, P, L, P, I, P, L, P, I, I, L, L, L]),
     'mtl_permute_hc': (I, [P, P, P, I, I, I, I, P]),
     'mtl_layernorm_fwd': (I, [P, P, P, P, P, P, P, P, F, P, P, P, I, I, I, F]),
     'mtl_layernorm_fwd_g': (I, [P, P, P, P, P, P, P, P, F, P, P, P, I, I, I, F, I, L]),

@@ -552,3 +552,15 @@ extern "C" int mtl_gemm_h2_tb(void* stream, int transB, int M, int N, int K, con
     if (transB) return big ? launch_x3<false, true, false, 256, 2>(p, s) : launch_x3<false, true, false, 128, 2>(p, s);
     return big ? launch_x3<false, false, false, 256, 2>(p, s) : launch_x3<false, false, false, 128, 2>(p, s);
 }
+
+/* see include/mtl_hip.h */
+extern "C" int mtl_gemm_h2_tn_tb(void* stream, int M, int N, int K, const float* A, int lda, const float* amax_a, long sAmaxA, const float* B,
+                                 int ldb, const float* amax_b, long sAmaxB, float* C, int ldc, int tasks, long sAt, long sBt, long sCt) {
+    if (M <= 0 || N <= 0 || K <= 0 || tasks <= 0 || !A || !B || !C || !amax_a || !amax_b) return MTL_EINVAL;
+    if (!al16(A) || !al16(B) || (lda & 3) || (ldb & 3) || ((sAt | sBt) & 3)) return MTL_EINVAL;
+    X3P p{A, B, C, nullptr, nullptr, nullptr, M, N, K, lda, ldb, ldc, 0, 1.f, 0, 1, 0, 0, 0, 0, 0, 0, 0, 1,
+          0, 0, 0, 0, 0, 1, sAt, sBt, sCt, 0, 0, tasks, amax_a, amax_b, sAmaxA, sAmaxB};
+    const bool big = x3_tiles(M, N, tasks, 256) >= 224;
+    hipStream_t s = as_stream(stream);
+    return big ? launch_x3<true, false, false, 256, 2>(p, s) : launch_x3<true, false, false, 128, 2>(p, s);
+}

@@ -264,6 +264,7 @@ class PassEngine:
         # the K / V projections of ALL decoder layers' encoder-decoder attention read the same encoder output: one batched launch per
         # low-rank stage forward, five launches backward (after the last decoder layer) instead of 2 + 4 per layer
         self.in_linear = os.environ.get('MTL_IN_LINEAR', 'h2')
+        self.in_wgrad_h2 = os.environ.get('MTL_IN_WGRAD', 'h2') == 'h2'      # its weight gradient on fp16 pairs as well ('x3': exact bf16 triples)
         self.hoist_kv = os.environ.get('MTL_HOIST_KV', '1') != '0'
         self.batch_qkv = os.environ.get('MTL_BATCH_QKV', '1') != '0'   # q/k/v projections as strided-batch GEMMs
         self.wgrad_x3_dense = os.environ.get('MTL_WGRAD_X3_DENSE', '1') != '0'    # conv5 (dy not pooled)
@@ -1438,21 +1439,26 @@ class PassEngine:
         p2, y5, p1, y1 = A['p2'], A['y5'], A['p1'], A['y1']
         dwp = self.buf('_dwp', (nt, d, hp.d_in))
         dp2 = self.buf('_dp2', (nt * B, T4, F4, 128))
-        self.gemm(1, 0, d, hp.d_in, Me, de0.data_ptr(), d, p2.data_ptr(), hp.d_in, dwp.data_ptr(), hp.d_in,
-                  task=(Me * d, Me * hp.d_in, d * hp.d_in, 0, 0))
+        h2 = self.conv_h2
+        amax = A['amax']
+        am_ = (lambda i, t=0: amax.data_ptr() + 4 * _lib.AMAX_SLOTS * (12 * t + i)) if h2 else (lambda i, t=0: None)   # y1, p1, y5 | dp2, dy5, dp1
+        am_st = 12 * _lib.AMAX_SLOTS
+        if self.in_h2:
+            for t in range(nt):
+                check(lib.mtl_absmax_f32(st, de0[t * Me:].data_ptr(), Me * d, am_(8, t)), 'mtl_absmax_f32')
+        if self.in_h2 and self.in_wgrad_h2:      # dW = de0^T . p2 on fp16 pairs too: both bounds (slots 8, 6) exist for the data gradient below
+            check(lib.mtl_gemm_h2_tn_tb(st, d, hp.d_in, Me, de0.data_ptr(), d, am_(8), am_st, p2.data_ptr(), hp.d_in, am_(6), am_st,
+                                        dwp.data_ptr(), hp.d_in, nt, Me * d, Me * hp.d_in, d * hp.d_in), 'mtl_gemm_h2_tn_tb')
+        else:
+            self.gemm(1, 0, d, hp.d_in, Me, de0.data_ptr(), d, p2.data_ptr(), hp.d_in, dwp.data_ptr(), hp.d_in,
+                      task=(Me * d, Me * hp.d_in, d * hp.d_in, 0, 0))
         for t in range(nt):
             check(lib.mtl_permute_hc(st, dwp[t].data_ptr(), g('encoder.input_linear.weight', t), d, 128, F4, 1, None), 'permute_inv')
         if self.slice_hook is not None:
             self.flush_ln_reduce()         # the encoder's LayerNorms (+ the input LayerNorm): their partials were all produced on this stream
             self._slice_done('encoder')
-        h2 = self.conv_h2
-        amax = A['amax']
-        am_ = (lambda i, t=0: amax.data_ptr() + 4 * _lib.AMAX_SLOTS * (12 * t + i)) if h2 else (lambda i, t=0: None)   # y1, p1, y5 | dp2, dy5, dp1
         if self.in_h2:
-            for t in range(nt):
-                check(lib.mtl_absmax_f32(st, de0[t * Me:].data_ptr(), Me * d, am_(8, t)), 'mtl_absmax_f32')
             # dp2 = (de0 . wp) gated by p2 > 0, straight from the un-transposed weight, all tasks in one launch
-            am_st = 12 * _lib.AMAX_SLOTS
             check(lib.mtl_gemm_h2_tb(st, 0, Me, hp.d_in, d, de0.data_ptr(), d, am_(8), am_st, A['wp_in'].data_ptr(), hp.d_in, am_(7),
                                      am_st if sP else 0, dp2.data_ptr(), hp.d_in, None, p2.data_ptr(), hp.d_in, nt, Me * d,
                                      d * hp.d_in if sP else 0, Me * hp.d_in, 0, None, 0), 'mtl_gemm_h2_tb')

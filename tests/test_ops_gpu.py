@@ -1098,3 +1098,30 @@ def test_conv3x3_pooled_wgrad_on_the_sparse_matrix_cores_matches_fp64(L, Cin, Co
     for kh in range(3):
         for kw in range(3):
             assert rel(wg[:, :, kh, kw].double().cpu(), 2 * want[:, :, kh, kw]) < 2e-6, (kh, kw)
+
+
+@pytest.mark.parametrize('M,N,K,tasks', [(512, 5120, 2000, 2), (512, 640, 300, 3), (132, 252, 77, 1)])
+def test_gemm_two_piece_fp16_transposed_a(L, M, N, K, tasks):
+    """mtl_gemm_h2_tn_tb: C_t = A_t^T B_t on fp16 pairs (the input Linear's weight gradient dW = de0^T p2, modules/encoder.py:72 backward):
+    per-task operands and bounds, ragged M / N / K; against fp64 fp32-class, bitwise repeatable; a quiet task keeps its accuracy."""
+    g = torch.Generator().manual_seed(M + N + K + tasks)
+    A = torch.randn(tasks, K, M, generator=g) * 2e-3
+    Bm = torch.relu(torch.randn(tasks, K, N, generator=g))
+    if tasks > 1:
+        A[1] *= 2.0 ** -10
+    want = A.double().transpose(1, 2) @ Bm.double()
+    dA, dB = dev(A), dev(Bm)
+    S = 2048
+    aa, ab = torch.zeros(tasks, S).cuda(), torch.zeros(tasks, S).cuda()
+    for t in range(tasks):
+        assert L.mtl_absmax_f32(st(), dA[t].data_ptr(), A[t].numel(), aa[t].data_ptr()) == 0
+        assert L.mtl_absmax_f32(st(), dB[t].data_ptr(), Bm[t].numel(), ab[t].data_ptr()) == 0
+    outs = []
+    for _ in range(2):
+        C = torch.full((tasks, M, N), float('nan')).cuda()
+        assert L.mtl_gemm_h2_tn_tb(st(), M, N, K, dA.data_ptr(), M, aa.data_ptr(), S, dB.data_ptr(), N, ab.data_ptr(), S, C.data_ptr(), N, tasks,
+                                   K * M, K * N, M * N) == 0
+        outs.append(C.cpu())
+    for t in range(tasks):
+        assert rel(outs[0][t].double(), want[t]) < 1e-6, (t, rel(outs[0][t].double(), want[t]))
+    assert torch.equal(outs[0], outs[1])
