@@ -1527,9 +1527,28 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_x3_kernel(WgradX3P p) {
         const float sx = NP == 2 ? pow2_scale(amax_read(p.amax_x)) : 1.f, sdy = NP == 2 ? pow2_scale(amax_read(p.amax_dy)) : 1.f;
         float4 hv[WX_NVA];
         unsigned okbits = 0;
+        // per-thread constants of the halo gather: element i = halo pixel (ht_i, hf_i), channels c4_i; for a tile whose halo lies inside the
+        // image (wave-uniform) the address is base(tile) + woff[i] and every existing element is valid (see conv3x3_x3h_kernel)
+        int woff[WX_NVA];
+        unsigned wexist = 0;
+#pragma unroll
+        for (int i = 0; i < WX_NVA; ++i) {
+            const int e = ptid + i * NT;
+            const int hp = min(e >> 4, WX_NPIX - 1), c4 = (e & 15) * 4;
+            const int ht = hp / WX_HF, hf = hp - ht * WX_HF;
+            woff[i] = ((ht - 1) * F + (hf - 1)) * Cin + c4;
+            wexist |= ((e >> 4) < WX_NPIX ? 1u : 0u) << i;
+        }
         auto fetch = [&](int j) {
             int b, t0, f0;
             tile_of(tc_halo, j, b, t0, f0);
+            if (t0 >= 1 && t0 + 8 < T && f0 >= 1 && f0 + 16 < F) {
+                const float* base = p.x + (((long)b * T + t0) * F + f0) * Cin + cib;
+#pragma unroll
+                for (int i = 0; i < WX_NVA; ++i) hv[i] = *reinterpret_cast<const float4*>(base + woff[i]);
+                okbits = wexist;
+                return;
+            }
             okbits = 0;
 #pragma unroll
             for (int i = 0; i < WX_NVA; ++i) {
@@ -1726,6 +1745,10 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_x3_kernel(WgradX3P p) {
 //     registers [kh, kh + 8) of the strip: 30 LDS reads per 27 instructions instead of 72 per 54.
 //   * dy: a producer thread owns (window row parity, ha, output channel): four pooled values + four arg-max bytes, split into the
 //     two fp16 pieces, stored as {v, 0} pairs in instruction layout + the 16 index bits; bias gradient sums ride along as before.
+#ifndef MTL_SP_DBG
+#define MTL_SP_DBG 0      // ablation builds only (tools/probe): never set in the product build
+#endif
+constexpr int SP_DBG = MTL_SP_DBG;
 constexpr int SP_STEP = 2 * 2 * 64 * 16 + 2 * 64 * 4;             // one window row: [piece][ha][co] 16-byte fragments + [ha][co] index words
 constexpr int wsp_smem() { return 2 * (2 * 2 * WX_SUB) + 4 * SP_STEP; }
 
@@ -1769,12 +1792,37 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_sp_kernel(WgradX3P p) {
         const float sx = pow2_scale(amax_read(p.amax_x)), sdy = pow2_scale(amax_read(p.amax_dy));
         float4 hv[WX_NVA];
         unsigned okbits = 0;
-        auto fetch = [&](int j) {
+        // per-thread constants of the halo gather: element i = halo pixel (ht_i, hf_i), channels c4_i; for a tile whose halo lies inside the
+        // image (wave-uniform) the address is base(tile) + woff[i] and every existing element is valid (see conv3x3_x3h_kernel)
+        int woff[WX_NVA];
+        unsigned wexist = 0;
+#pragma unroll
+        for (int i = 0; i < WX_NVA; ++i) {
+            const int e = ptid + i * NT;
+            const int hp = min(e >> 4, WX_NPIX - 1), c4 = (e & 15) * 4;
+            const int ht = hp / WX_HF, hf = hp - ht * WX_HF;
+            woff[i] = ((ht - 1) * F + (hf - 1)) * Cin + c4;
+            wexist |= ((e >> 4) < WX_NPIX ? 1u : 0u) << i;
+        }
+        // fetch / commit take a HALF of the thread's elements (h = 0: i < WX_NVA / 2, h = 1: the rest): the staging of the next tile's halo
+        // is spread over both barrier intervals of the current tile (all of it in the second one made the consumers wait there)
+        constexpr int HV2 = WX_NVA / 2;
+        auto fetch = [&](int j, int h) {
             int b, t0, f0;
             tile_of(tc_halo, j, b, t0, f0);
-            okbits = 0;
+            const int i0 = h ? HV2 : 0, i1 = h ? WX_NVA : HV2;
+            if (t0 >= 1 && t0 + 8 < T && f0 >= 1 && f0 + 16 < F) {
+                const float* base = p.x + (((long)b * T + t0) * F + f0) * Cin + cib;
+#pragma unroll
+                for (int i = 0; i < WX_NVA; ++i)
+                    if (i >= i0 && i < i1) hv[i] = *reinterpret_cast<const float4*>(base + woff[i]);
+                const unsigned m = ((1u << i1) - 1u) & ~((1u << i0) - 1u);
+                okbits = (okbits & ~m) | (wexist & m);
+                return;
+            }
 #pragma unroll
             for (int i = 0; i < WX_NVA; ++i) {
+                if (i < i0 || i >= i1) continue;
                 const int e = ptid + i * NT;
                 const int hp = min(e >> 4, WX_NPIX - 1), c4 = (e & 15) * 4;
                 const int ht = hp / WX_HF, hf = hp - ht * WX_HF;
@@ -1782,12 +1830,14 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_sp_kernel(WgradX3P p) {
                 const bool ok = (unsigned)ts < (unsigned)T && (unsigned)fs < (unsigned)F;
                 const int tc = min(max(ts, 0), T - 1), fc = min(max(fs, 0), F - 1);
                 hv[i] = *reinterpret_cast<const float4*>(p.x + (((long)b * T + tc) * F + fc) * Cin + cib + c4);
-                okbits |= (ok ? 1u : 0u) << i;
+                okbits = (okbits & ~(1u << i)) | ((ok ? 1u : 0u) << i);
             }
         };
-        auto commit = [&](int buf) {
+        auto commit = [&](int buf, int h) {
+            const int i0 = h ? HV2 : 0, i1 = h ? WX_NVA : HV2;
 #pragma unroll
             for (int i = 0; i < WX_NVA; ++i) {
+                if (i < i0 || i >= i1) continue;
                 const int e = ptid + i * NT;
                 if ((e >> 4) >= WX_NPIX) continue;
                 const int hp = e >> 4, c4 = (e & 15) * 4;
@@ -1838,27 +1888,41 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_sp_kernel(WgradX3P p) {
                     make_uint4(q0[q] & 0xffffu, q0[q] >> 16, q1[q] & 0xffffu, q1[q] >> 16);
             *reinterpret_cast<unsigned*>(dst + 4 * 64 * 16 + (bha * 64 + bco) * 4) = a;
         };
+        constexpr bool dbgF = SP_DBG & 4, dbgC = SP_DBG & 8, dbgB = SP_DBG & 16;      // ablation builds (-DMTL_SP_DBG=..): no halo loads / no halo commit / no dy work
         if (my_tiles > 0) {
-            fetch(0);
+            fetch(0, 0);
+            fetch(0, 1);
             fetch_b(0, bv[0], ba[0], bok[0]);
             fetch_b(1, bv[1], ba[1], bok[1]);
-            commit(0);
+            commit(0, 0);
+            commit(0, 1);
             commit_b(0, bv[0], ba[0], bok[0]);
             fetch_b(2, bv[0], ba[0], bok[0]);
         }
-        if (my_tiles > 1) fetch(1);
+        if (my_tiles > 1) {
+            fetch(1, 0);
+            fetch(1, 1);
+        }
         __syncthreads();                                       // halo 0 and the fragments of pair 0 are visible
 #pragma unroll 1
         for (int pk = 0; pk < npairs_k; pk += 2) {             // one tile (two pairs of window rows) per iteration
-            commit_b(pk + 1, bv[1], ba[1], bok[1]);
-            fetch_b(pk + 3, bv[1], ba[1], bok[1]);
-            __syncthreads();
-            commit_b(pk + 2, bv[0], ba[0], bok[0]);
-            fetch_b(pk + 4, bv[0], ba[0], bok[0]);
-            const int j = pk >> 1;                             // the consumers are on the tile's last pair: the next halo goes into the other buffer
+            const int j = pk >> 1;                             // buffer (j + 1) & 1 was last read during tile j - 1: it is free for all of tile j
+            if (!dbgB) {
+                commit_b(pk + 1, bv[1], ba[1], bok[1]);
+                fetch_b(pk + 3, bv[1], ba[1], bok[1]);
+            }
             if (j + 1 < my_tiles) {
-                commit((j + 1) & 1);
-                if (j + 2 < my_tiles) fetch(j + 2);
+                if (!dbgC) commit((j + 1) & 1, 0);
+                if (j + 2 < my_tiles && !dbgF) fetch(j + 2, 0);
+            }
+            __syncthreads();
+            if (!dbgB) {
+                commit_b(pk + 2, bv[0], ba[0], bok[0]);
+                fetch_b(pk + 4, bv[0], ba[0], bok[0]);
+            }
+            if (j + 1 < my_tiles) {
+                if (!dbgC) commit((j + 1) & 1, 1);
+                if (j + 2 < my_tiles && !dbgF) fetch(j + 2, 1);
             }
             __syncthreads();
         }
@@ -1914,10 +1978,18 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_sp_kernel(WgradX3P p) {
                         st[pc][2 * c + 1] = u.y;
                     }
             };
-            load_strip(strip[0], 0);
+            if (SP_DBG & 2) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int pc = 0; pc < NP; ++pc)
+#pragma unroll
+                        for (int c = 0; c < 10; ++c) strip[q][pc][c] = 0x3c003c00u + c;
+            }
+            if (!(SP_DBG & 2)) load_strip(strip[0], 0);
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
-                if (kw + 1 < 3) load_strip(strip[(kw + 1) & 1], kw + 1);
+                if (kw + 1 < 3 && !(SP_DBG & 2)) load_strip(strip[(kw + 1) & 1], kw + 1);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int kh = 0; kh < 3; ++kh) {
@@ -1931,6 +2003,10 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_sp_kernel(WgradX3P p) {
                         bl.u[i] = strip[kw & 1][1][kh + i];
                     }
                     f32x16 cc = acc[kh * 3 + kw];
+                    if (SP_DBG & 1) {                                  // ablation: no matrix instructions
+                        acc[kh * 3 + kw][0] += __builtin_bit_cast(float, bh.u[0] ^ bl.u[7]);
+                        continue;
+                    }
                     cc = __builtin_amdgcn_smfmac_f32_32x32x32_f16(a_l, bh.v, cc, idx, 0, 0);     // smallest terms first
                     cc = __builtin_amdgcn_smfmac_f32_32x32x32_f16(a_h, bl.v, cc, idx, 0, 0);
                     acc[kh * 3 + kw] = __builtin_amdgcn_smfmac_f32_32x32x32_f16(a_h, bh.v, cc, idx, 0, 0);
