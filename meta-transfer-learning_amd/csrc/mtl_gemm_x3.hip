@@ -32,6 +32,10 @@ namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+#ifndef MTL_X3G_DBG
+#define MTL_X3G_DBG 0      // ablation builds only (tools/probe): 1 no MFMAs, 2 no fragment reads either, 4 operands fetched once, 8 no split / LDS commit
+#endif
+constexpr int X3G_DBG = MTL_X3G_DBG;
 constexpr int BN = 128, BK = 32, NT = 512;               // BM (256 or 128) is a template parameter of the kernel
 constexpr int PLANE_B = BN * 64;                         // one bf16 piece of one operand tile: rows x 64 bytes
 
@@ -55,6 +59,7 @@ struct X3P {
     const float *amax_a, *amax_b;
     long sAmaxA, sAmaxB;
     int Ksplit;            // split-K launches: the product's full K; item zb (outer batch index) covers k in [zb K, min((zb + 1) K, Ksplit)) -- 0: off
+    int pingpong;          // the two waves of a SIMD run a K step's halves in opposite order (MTL_GEMM_X3_PINGPONG=0: lock-step, A/B measurements)
 };
 
 // x0, x1 -> three dwords of packed bf16 pairs, x = h + m + l EXACTLY: h and m are truncations (top 8 significand bits of x and of
@@ -235,12 +240,14 @@ __global__ __launch_bounds__(NT) void gemm_x3_kernel(X3P p) {
     const bool kfull = Kz % BK == 0;              // no ragged last K tile
     float rs[4] = {0.f, 0.f, 0.f, 0.f};
     auto fetch = [&](int tile, typename OA::Regs& ra, typename OB::Regs& rb) {
+        if ((X3G_DBG & 4) && tile > 1) return;
         const int zn = tile / nk, kt = tile - zn * nk;
         la.fetch(ra, zn * p.sAk, kt * BK, Kz, tid);
         lb.fetch(rb, zn * p.sBk, kt * BK, Kz, tid);
     };
     auto commit = [&](auto full_tag, const typename OA::Regs& ra, const typename OB::Regs& rb, unsigned char* stage) {
         constexpr bool FULL = decltype(full_tag)::value;
+        if ((X3G_DBG & 8) && stage != sm) return;
         la.template commit<FULL, RS>(ra, stage, tid, rs, sa);
         lb.template commit<FULL, false>(rb, stage + NP * PLANE_A, tid, rs, sb);
     };
@@ -250,6 +257,7 @@ __global__ __launch_bounds__(NT) void gemm_x3_kernel(X3P p) {
 #pragma unroll
     for (int st = 0; st < 2; ++st) csw[st] = ((st * 2 + hi) ^ ((l31 >> 2) & 3)) << 4;
     auto compute = [&](const unsigned char* stage) {
+        if (X3G_DBG & 2) return;
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
             uint4 a[TM][NP], b[2][NP];
@@ -261,6 +269,13 @@ __global__ __launch_bounds__(NT) void gemm_x3_kernel(X3P p) {
                 for (int j = 0; j < 2; ++j) b[j][pc] = *reinterpret_cast<const uint4*>(stage + pc * PLANE_B + brow + j * 32 * 64 + csw[st]);
             }
             // the cross terms, smallest first, each over all accumulators (dependent MFMAs are 2 TM issues apart)
+            if (X3G_DBG & 1) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j][0] += __builtin_bit_cast(float, a[i][0].x ^ b[j][NP - 1].w);
+                continue;
+            }
             constexpr int NTERM = NP == 3 ? 6 : 3;
             constexpr int PA[6] = {NP == 3 ? 2 : 1, 0, NP == 3 ? 1 : 0, 1, 0, 0}, PB[6] = {0, NP == 3 ? 2 : 1, NP == 3 ? 1 : 0, 0, 1, 0};
 #pragma unroll
@@ -282,12 +297,27 @@ __global__ __launch_bounds__(NT) void gemm_x3_kernel(X3P p) {
     // The main loop's steps are ONE basic block each (no condition between the MFMAs and the split: hipcc interleaves them); it
     // runs unmasked -- it never meets the (possibly ragged) last K tile, except with K-batching, where only K % 32 == 0 qualifies.
     // The last steps go through the general form.
+    // PING-PONG (round 4): the two waves of a SIMD (wave w and w + 4) run the two halves of a step in OPPOSITE order -- waves 0-3
+    // multiply stage kt and then split tile kt + 1, waves 4-7 split first and multiply second -- so that on every SIMD one wave's MFMAs
+    // run beside the other wave's VALU split and LDS stores.  In lock-step (all eight waves: multiply, then split) the phases of a step
+    // simply add up: compile-time ablation builds of this kernel measured barrier + loop 0.19, MFMAs 0.50, fragment reads 0.07, global
+    // fetch 0.18, split + commit 0.25 = 1.19 of the 1.24 us per K step (profiles/r4/gemm_experiments.txt).  Both halves only touch what
+    // the step's single barrier already separates (stage kt is read, stage kt + 1 is written), so no second barrier is needed.
+    // (128-row form only: with 64 x 64 per wave the second code path does not fit the 256-register budget -- 98-173 spilled registers)
+    const bool pong = BM == 128 && __builtin_amdgcn_readfirstlane(tid >> 8) != 0 && p.pingpong;
     auto step_main = [&](auto full_tag, int kt, typename OA::Regs& rac, typename OB::Regs& rbc, const typename OA::Regs& ran,
                          const typename OB::Regs& rbn) {
         fetch(kt + 2, rac, rbc);
         __builtin_amdgcn_sched_barrier(0);           // the loads go out FIRST (hipcc sinks them behind the MFMAs otherwise: a step of flight time lost)
-        compute(sm + (kt & 1) * STAGE);
-        commit(full_tag, ran, rbn, sm + ((kt + 1) & 1) * STAGE);
+        if (pong) {
+            commit(full_tag, ran, rbn, sm + ((kt + 1) & 1) * STAGE);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(sm + (kt & 1) * STAGE);
+        } else {
+            compute(sm + (kt & 1) * STAGE);
+            __builtin_amdgcn_sched_barrier(0);
+            commit(full_tag, ran, rbn, sm + ((kt + 1) & 1) * STAGE);
+        }
         lds_barrier();
     };
     auto step_tail = [&](int kt, typename OA::Regs& rac, typename OB::Regs& rbc, const typename OA::Regs& ran, const typename OB::Regs& rbn) {
@@ -383,6 +413,8 @@ int launch_x3(X3P p, hipStream_t s) {
     static int attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_kernel<TA, TB, RS, BM, NP>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) == hipSuccess ? 0 : MTL_ELAUNCH;
     if (attr) return attr;
+    static const int pp = getenv("MTL_GEMM_X3_PINGPONG") ? atoi(getenv("MTL_GEMM_X3_PINGPONG")) : 1;
+    p.pingpong = pp;
     p.total = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.total;       // (p.total arrives as the number of batch items)
     dim3 grid(((p.total + 7) / 8) * 8);
     hipLaunchKernelGGL((gemm_x3_kernel<TA, TB, RS, BM, NP>), grid, dim3(NT), SMEM, s, p);

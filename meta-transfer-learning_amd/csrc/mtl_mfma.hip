@@ -816,7 +816,28 @@ struct ConvX3P {
     int ntf, ntt, tiles; // halo kernel: pixel tiles along F and T, and tiles in total (F fastest, then T, then output-channel tile, then sample)
     const float* amax_in;   // NP = 2: MTL_AMAX_SLOTS floats whose maximum is >= max|x|
     float* amax_out;        // optional: atomic max of an upper bound of max|y| (the next layer's amax_in)
+#ifdef MTL_X3_PROF
+    unsigned long long* prof;   // probe builds only (tools/probe/conv_prof.py): [workgroup][wave][8] accumulated s_memtime intervals
+#endif
 };
+// In-kernel stall breakdown (probe builds: hipcc -DMTL_X3_PROF, never in the product build where the macros are empty): each role
+// accumulates s_memtime intervals per phase -- real instruction stream, real operands, the production clock / power state.
+#ifdef MTL_X3_PROF
+static unsigned long long* g_x3_prof = nullptr;
+extern "C" void mtl_x3_prof_set(void* buf) { g_x3_prof = (unsigned long long*)buf; }
+#define X3_T(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#define X3_ACC(slot, a, b) prof_acc[slot] += (b) - (a)
+#define X3_PROF_DECL unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define X3_PROF_FLUSH()                                                                                    \
+    if (p.prof && (threadIdx.x & 63) == 0) {                                                               \
+        for (int k_ = 0; k_ < 8; ++k_) p.prof[((long)blockIdx.x * 16 + (threadIdx.x >> 6)) * 8 + k_] = prof_acc[k_]; \
+    }
+#else
+#define X3_T(v)
+#define X3_ACC(slot, a, b)
+#define X3_PROF_DECL
+#define X3_PROF_FLUSH()
+#endif
 
 // ------------------------------------------------------------------ halo-tiled x3 convolution (the one the C ABI dispatches to)
 // What the ablation of conv3x3_x3_kernel showed: the consumer side can run 256 TF-equivalent, the producer
@@ -942,20 +963,34 @@ void conv3x3_x3h_kernel(ConvX3P p) {
             }
         };
         const bool doA = !(p.dbg & 2);
+        X3_PROF_DECL;
+        X3_T(h0);
         if (doA) fetch_halo(0);
         if (doA) commit_halo();
         if (nstage > 1 && doA) fetch_halo(1);
         __syncthreads();                                       // halo of stage 0 (and the weights of step 0) are visible
+        X3_T(h1);
+        X3_ACC(0, h0, h1);                                     // prologue
 #pragma unroll 1
         for (int q = 0; q < nstage; ++q) {
+            X3_T(a0);
 #pragma unroll 1
             for (int tap = 0; tap < 9; ++tap) __syncthreads();
+            X3_T(a1);
+            X3_ACC(1, a0, a1);                                 // nine tap barriers
             if (q + 1 < nstage) {
                 if (doA) commit_halo();                        // nobody reads the halo between these two barriers
+                X3_T(a2);
+                X3_ACC(2, a1, a2);                             // commit (includes the wait for the fetch)
                 if (q + 2 < nstage && doA) fetch_halo(q + 2);  // a whole stage of flight time
+                X3_T(a3);
+                X3_ACC(3, a2, a3);                             // fetch issue
                 __syncthreads();
+                X3_T(a4);
+                X3_ACC(4, a3, a4);                             // closing barrier of the swap
             }
         }
+        X3_PROF_FLUSH();
         return;
     }
     if (tid >= NCONS) {
@@ -989,21 +1024,33 @@ void conv3x3_x3h_kernel(ConvX3P p) {
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         int tap = 0, q = 0;
+        X3_PROF_DECL;
 #pragma unroll 1
         for (int s_ = 0; s_ < nstep; ++s_) {
             // stage (s_ + 2) % 3 was read at step s_ - 1, and every consumer has passed that step's barrier
+            X3_T(w0);
             if (s_ + 2 < nstep) {
                 if (doB) dma(s_ + 2);
+                X3_T(w1);
+                X3_ACC(0, w0, w1);                                                // issue
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");      // tile s_ + 1 is in LDS
+                X3_T(w2);
+                X3_ACC(1, w1, w2);                                                // landing wait
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
+            X3_T(w3);
             __builtin_amdgcn_s_barrier();
+            X3_T(w4);
+            X3_ACC(2, w3, w4);                                                    // step barrier
             if (++tap == 9) {
                 tap = 0;
                 if (++q < nstage) __builtin_amdgcn_s_barrier();                   // the halo swap
+                X3_T(w5);
+                X3_ACC(3, w4, w5);
             }
         }
+        X3_PROF_FLUSH();
         return;
     }
 
@@ -1020,6 +1067,9 @@ void conv3x3_x3h_kernel(ConvX3P p) {
         int t, f;
         tile_row_to_tf(wm * WTM + i * 32 + l31, t, f);
         abase[i] = ((t + grp * 8 + 1) * XH_HF + (f + 1)) * X3_ROWB + hi * 16;
+#ifdef X3_FAKE_A
+        abase[i] = (XH_HF + 1 + l31 + i * 32 + grp * 64) * X3_ROWB + hi * 16;     // probe build: conflict-free (wrong) fragment addresses
+#endif
     }
     const unsigned char* bBase = smB + (wn * WTN + l31) * 64;
     int bsw[BK / 16];                                          // swizzled position of this lane's 16-byte chunk per k-step
@@ -1027,6 +1077,8 @@ void conv3x3_x3h_kernel(ConvX3P p) {
     for (int st = 0; st < BK / 16; ++st) bsw[st] = (((st * 2 + hi) ^ ((l31 >> 2) & 3))) * 16;
     __syncthreads();
     int bst = 0;                                               // weight stage of the current step (step % 3)
+    X3_PROF_DECL;
+    X3_T(k0);
 #pragma unroll 1
     for (int j = 0; j < my_tiles; ++j) {
 #pragma unroll
@@ -1042,6 +1094,7 @@ void conv3x3_x3h_kernel(ConvX3P p) {
                 const int kh = tap / 3, kw = tap - kh * 3;
                 const int toff = ((kw - 1) * XH_HF + (kh - 1)) * X3_ROWB;
                 const unsigned char* bS = bBase + bst * BBUF;
+                X3_T(c0);
 #pragma unroll
                 for (int st = 0; st < BK / 16; ++st) {
                     uint4 a[TM][NP], bb[TN][NP];
@@ -1060,8 +1113,13 @@ void conv3x3_x3h_kernel(ConvX3P p) {
 #pragma unroll
                         for (int jn = 0; jn < TN; ++jn) acc[i][jn] = Split<NP>::mfma(a[i], bb[jn], acc[i][jn]);
                 }
+                X3_T(c1);
+                X3_ACC(0, c0, c1);                             // reads + matrix instructions issued
                 __syncthreads();
+                X3_T(c2);
+                X3_ACC(1, c1, c2);                             // step barrier (drain + wait for the slowest wave)
             }
+            X3_T(e0);
             if (c + 1 == cch && !(p.dbg & 8)) {
                 // epilogue (no LDS): same row -> (pool window, position) walk as Engine::finish with this wave's sub-tile
                 // origin; it runs while the producers commit the next tile's halo
@@ -1117,9 +1175,16 @@ void conv3x3_x3h_kernel(ConvX3P p) {
                             }
                 }
             }
+            X3_T(e1);
+            X3_ACC(2, e0, e1);                                 // epilogue (issue)
             if (j * cch + c + 1 < nstage) __syncthreads();     // the producers replaced the halo between these two barriers
+            X3_T(e2);
+            X3_ACC(3, e1, e2);                                 // swap barrier
         }
     }
+    X3_T(k1);
+    X3_ACC(4, k0, k1);                                         // whole main loop
+    X3_PROF_FLUSH();
     if (p.amax_out) {       // |relu(v + b)| <= |v| + |b| (pooling takes a maximum of those); dgrad: |gate v| <= |v|
         float bmax = 0.f;
         if (EPI != EPI_DGRAD) {
@@ -1141,6 +1206,9 @@ int launch_conv_x3h(ConvX3P p, int Te, int Fe, hipStream_t s) {
     static const int ncu = device_cu_count();
     static const int dbg = getenv("MTL_X3_DBG") ? atoi(getenv("MTL_X3_DBG")) : 0;
     p.dbg = dbg;
+#ifdef MTL_X3_PROF
+    p.prof = g_x3_prof;
+#endif
     p.ntf = (Fe + 15) / 16;
     p.ntt = (Te + 8 * G - 1) / (8 * G);
     p.tiles = p.ntf * p.ntt * p.g.B * p.ntile;
