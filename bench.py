@@ -507,6 +507,51 @@ def main_lm(a, mtl_amd, mdist, dev, rank, world):
     mdist.barrier()
 
 
+def power_limited_ceiling(dev, achieved, peak):
+    """The dense matrix rate the chip SUSTAINS on all CUs under its package power limit, measured live with the probe library
+    (csrc/mtl_probe.hip -> libmtl_probe.so: back-to-back v_mfma_f32_32x32x16_f16, no HBM traffic), for operands that switch
+    like the real ones (pseudo-random fp16, half of one operand zero = activations after a ReLU) and for zeros.  The nominal
+    peak in `roofline.peak` assumes 2.4 GHz; with switching operands the clock is held far below it, so `frac` understates how
+    close a matrix-bound kernel is to what the silicon delivers.  Reported next to it, never instead of it."""
+    import ctypes
+    import torch
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'meta-transfer-learning_amd', 'libmtl_probe.so')
+    if not os.path.exists(path):
+        return None
+    lib = ctypes.CDLL(path)
+    lib.mtl_probe_mfma_f16.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+    sink = torch.zeros(4, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    steps = 3000
+
+    def rate(mode, fill):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        lib.mtl_probe_mfma_f16(st, ncu, steps, mode, fill, sink.data_ptr())          # settle the clocks at this load
+        ev[0].record()
+        rc = lib.mtl_probe_mfma_f16(st, ncu, steps, mode, fill, sink.data_ptr())
+        ev[1].record()
+        torch.cuda.synchronize()
+        if rc:
+            return None
+        return ncu * steps * 8 * 24 * 32768.0 / (ev[0].elapsed_time(ev[1]) * 1e-3) / 1e12      # TFLOP/s of fp16 matrix work
+
+    nominal = PEAK_H2_TFLOPS * 3                        # dense fp16 peak of the guide
+    r = dict(registers_zeros=rate(0, 0), registers_random=rate(0, 1), lds_fed_random=rate(1, 1), lds_fed_post_relu=rate(1, 2))
+    if not all(r.values()):
+        return None
+    out = dict(unit='TFLOP/s of dense fp16 matrix instructions', nominal=nominal,
+               sustained={k: v for k, v in r.items()}, sustained_frac_of_nominal={k: v / nominal for k, v in r.items()},
+               note='sustained = all CUs issuing back-to-back v_mfma_f32_32x32x16_f16 for ~3 ms (registers_*: operands in registers; lds_fed_*: 16 '
+                    'ds_read_b128 per 24 matrix instructions and one s_barrier per step, the fragment traffic of the convolution kernel); '
+                    'the package power limit, not the instruction stream, sets these rates')
+    # the dominant kernel against the ceiling of ITS instruction mix and operand statistics
+    scale = r['lds_fed_post_relu'] / nominal
+    out['frac_of_sustained'] = achieved / (peak * scale)
+    out['frac_note'] = 'roofline.achieved / (roofline.peak x lds_fed_post_relu / nominal)'
+    return out
+
+
 def physical_cores():
     try:
         import psutil
@@ -655,6 +700,8 @@ def main():
                         serial_step=dict(launches_per_pass=n_launch / passes, gpu_ms_per_pass=sum(c['time'] for c in classes.values()) / passes * 1e3,
                                          gpu_span_ms_per_pass=serial_wall / passes * 1e3),
                         per_family=fam_table, per_class=table)
+        if dr['bound'] == 'mfma':
+            roofline['power_limited'] = power_limited_ceiling(dev, dr['achieved'], dr['peak'])
         ms = dt / a.steps * 1e3
         out = dict(metric='meta-steps/sec', value=a.steps / dt, unit='meta-steps/s', n_gpus=world, steps=a.steps, warmup=a.warmup,
                    ms_per_step=ms, higher_is_better=True, scaling='strong', vs_baseline=None, dtype=DTYPE[model.engine.conv_mode],
