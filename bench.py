@@ -197,6 +197,8 @@ def classify(lib, name, a, conv_mode, wgrad_x3_dense):
         return 'adam_step', 28.0 * a[-1], 'byte', 'adam_kernel'
     if name == 'mtl_permute_hc':
         return 'permute_hc', 8.0 * a[3] * a[4] * a[5], 'byte', 'permute_hc_kernel'
+    if name == 'mtl_permute_hc_tb':
+        return 'permute_hc', 8.0 * a[3] * a[4] * a[5] * a[8] + (4.0 * a[3] * a[4] * a[5] * a[8] if a[6] else 0.0), 'byte', 'permute_hc_kernel'
     if name in ('mtl_memcpy_d2d', 'mtl_copy_f32'):
         return 'copy', 2.0 * a[-1] * (4 if name == 'mtl_copy_f32' else 1), 'byte', '__amd_rocclr_copyBuffer'
     if name == 'mtl_memset_zero':

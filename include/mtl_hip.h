@@ -197,6 +197,9 @@ int mtl_conv3x3_wgrad_h2(void* stream, const float* x, const float* amax_x, cons
  * models/asr/transformer.py:136-138 folded into encoder.input_linear's weight instead of an activation copy. */
 int mtl_permute_hc(void* stream, const float* src, float* dst, int rows, int C, int Hh, int inverse_accum,
                    float* amax /* nullable, MTL_AMAX_FLOATS: raised to max|src| (zero it first) */);
+/* the same for `tasks` weight sets at strides sSrc / sDst (floats) and bounds at sAmax (floats) in ONE launch (the theta' stack) */
+int mtl_permute_hc_tb(void* stream, const float* src, float* dst, int rows, int C, int Hh, int inverse_accum, float* amax, int tasks,
+                      long sSrc, long sDst, long sAmax);
 
 /* ---- LayerNorm(x + residual) * gamma + beta (+ pe[row % T]) then * keep[row] -----------------------------
  * nn.LayerNorm eps inside the sqrt, biased variance (modules/common_layers.py:131,304; modules/encoder.py:72-73)

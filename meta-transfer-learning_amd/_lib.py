@@ -62,6 +62,7 @@ SIGNATURES = {
     'mtl_gemm_h2_tb': (I, [P, I, I, I, I, P, I, P, L, P, I, P, L, P, I, P, P, I, I, L, L, L, L, P, L]),
     'mtl_gemm_h2_tn_tb': (I, [P, I, I, I, P, I, P, L, P, I, P, L, P, I, I, L, L, L]),
     'mtl_permute_hc': (I, [P, P, P, I, I, I, I, P]),
+    'mtl_permute_hc_tb': (I, [P, P, P, I, I, I, I, P, I, L, L, L]),
     'mtl_layernorm_fwd': (I, [P, P, P, P, P, P, P, P, F, P, P, P, I, I, I, F]),
     'mtl_layernorm_fwd_g': (I, [P, P, P, P, P, P, P, P, F, P, P, P, I, I, I, F, I, L]),
     'mtl_layernorm_bwd_workspace': (L, [I, I]),

@@ -857,13 +857,48 @@ __global__ __launch_bounds__(256) void conv0_wgrad_final_kernel(const float* __r
 // wp[o][h*C + c] = w[o][c*H + h]   (and the inverse, accumulating, for the gradient)
 // One workgroup per row: the (C, Hh) <-> (Hh, C) transpose goes through LDS so that both the read and the write of HBM are
 // coalesced (the element-wise form below read 4-byte words 4 Hh bytes apart: 28 us for 10 MB).
-__global__ __launch_bounds__(256) void permute_hc_lds_kernel(const float* __restrict__ w, float* __restrict__ wp, int C, int Hh,
-                                                             int inverse_accum, float* __restrict__ amax) {
+// Task-batched (round 4): workgroup (task, row); the per-task launches of the validation pass (8 x 10 MB) were launch-bound.
+template <bool VEC>
+__global__ __launch_bounds__(256) void permute_hc_lds_kernel(const float* __restrict__ w, float* __restrict__ wp, int rows, int C, int Hh,
+                                                             int inverse_accum, float* __restrict__ amax, long sSrc, long sDst, long sAmax) {
     extern __shared__ float tile[];
     const int n = C * Hh;
-    const float* src = w + (long)blockIdx.x * n;
-    float* dst = wp + (long)blockIdx.x * n;
+    const int task = blockIdx.x / rows, row = blockIdx.x - task * rows;
+    const float* src = w + task * sSrc + (long)row * n;
+    float* dst = wp + task * sDst + (long)row * n;
+    if (amax) amax += task * sAmax;
     float mx = 0.f;
+    if (VEC) {        // C % 4 == 0 and Hh % 4 == 0: 16-byte HBM accesses on both sides; the tile is kept in (c, h) order with rows of Hh + 1
+        const int P = Hh + 1;
+        if (inverse_accum) {      // src (h, c) order
+            for (int e = threadIdx.x * 4; e < n; e += 1024) {
+                const float4 v = *reinterpret_cast<const float4*>(src + e);
+                const int h = e / C, c = e - h * C;
+                tile[c * P + h] = v.x, tile[(c + 1) * P + h] = v.y, tile[(c + 2) * P + h] = v.z, tile[(c + 3) * P + h] = v.w;
+            }
+            __syncthreads();
+            for (int e = threadIdx.x * 4; e < n; e += 1024) {
+                const int c = e / Hh, h = e - c * Hh;
+                float4 o = *reinterpret_cast<const float4*>(dst + e);
+                o.x += tile[c * P + h], o.y += tile[c * P + h + 1], o.z += tile[c * P + h + 2], o.w += tile[c * P + h + 3];
+                *reinterpret_cast<float4*>(dst + e) = o;
+            }
+        } else {                  // src (c, h) order
+            for (int e = threadIdx.x * 4; e < n; e += 1024) {
+                const float4 v = *reinterpret_cast<const float4*>(src + e);
+                const int c = e / Hh, h = e - c * Hh;
+                tile[c * P + h] = v.x, tile[c * P + h + 1] = v.y, tile[c * P + h + 2] = v.z, tile[c * P + h + 3] = v.w;
+                mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+            }
+            if (amax) amax_raise(amax, mx);
+            __syncthreads();
+            for (int e = threadIdx.x * 4; e < n; e += 1024) {
+                const int h = e / C, c = e - h * C;
+                *reinterpret_cast<float4*>(dst + e) = make_float4(tile[c * P + h], tile[(c + 1) * P + h], tile[(c + 2) * P + h], tile[(c + 3) * P + h]);
+            }
+        }
+        return;
+    }
     for (int e = threadIdx.x; e < n; e += 256) {
         const float v = src[e];
         tile[e] = v;
@@ -1369,10 +1404,29 @@ int mtl_conv0_wgrad(void* stream, const float* x, const float* dy, float* dw, fl
     return MTL_OK;
 }
 
+int mtl_permute_hc_tb(void* stream, const float* src, float* dst, int rows, int C, int Hh, int inverse_accum, float* amax, int tasks,
+                      long sSrc, long sDst, long sAmax) {
+    if (!src || !dst || rows <= 0 || C <= 0 || Hh <= 0 || tasks <= 0) return MTL_EINVAL;
+    const bool vec = C % 4 == 0 && Hh % 4 == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0 && ((sSrc | sDst) & 3) == 0;
+    const long lds = (long)C * (Hh + (vec ? 1 : 0)) * 4;
+    if (lds > 64 * 1024) {
+        for (int t = 0; t < tasks; ++t) {
+            const int rc = mtl_permute_hc(stream, src + t * sSrc, dst + t * sDst, rows, C, Hh, inverse_accum, amax ? amax + t * sAmax : nullptr);
+            if (rc != MTL_OK) return rc;
+        }
+        return MTL_OK;
+    }
+    if (vec) hipLaunchKernelGGL(permute_hc_lds_kernel<true>, dim3(rows * tasks), dim3(256), lds, as_stream(stream), src, dst, rows, C, Hh,
+                                inverse_accum, amax, sSrc, sDst, sAmax);
+    else hipLaunchKernelGGL(permute_hc_lds_kernel<false>, dim3(rows * tasks), dim3(256), lds, as_stream(stream), src, dst, rows, C, Hh,
+                            inverse_accum, amax, sSrc, sDst, sAmax);
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}
+
 int mtl_permute_hc(void* stream, const float* src, float* dst, int rows, int C, int Hh, int inverse_accum, float* amax) {
     if (!src || !dst) return MTL_EINVAL;
-    if ((long)C * Hh * 4 <= 48 * 1024)
-        hipLaunchKernelGGL(permute_hc_lds_kernel, dim3(rows), dim3(256), C * Hh * 4, as_stream(stream), src, dst, C, Hh, inverse_accum, amax);
+    if ((long)C * (Hh + 1) * 4 <= 64 * 1024) return mtl_permute_hc_tb(stream, src, dst, rows, C, Hh, inverse_accum, amax, 1, 0, 0, 0);
     else {
         if (amax) hipLaunchKernelGGL(absmax_kernel, dim3(grid_for((long)rows * C * Hh / 4 + 1, 256, 1024)), dim3(256), 0, as_stream(stream), src,
                                      (long)rows * C * Hh, amax);

@@ -1166,8 +1166,9 @@ class PassEngine:
 
         # ---- encoder ----
         wp = self.buf('wp_in', (ntw, d, hp.d_in))
-        for t in range(ntw):      # am_(7): max|w| rides along
-            check(lib.mtl_permute_hc(st, o('encoder.input_linear.weight', t), wp[t].data_ptr(), d, 128, F4, 0, am_(7, t)), 'permute')
+        # am_(7): max|w| rides along; the theta' stack in one launch
+        check(lib.mtl_permute_hc_tb(st, o('encoder.input_linear.weight'), wp.data_ptr(), d, 128, F4, 0, am_(7), ntw, self.sP, d * hp.d_in,
+                                    12 * _lib.AMAX_SLOTS), 'permute')
         # decoder prologue: embedding (+ PE, dropout) and layer 0's self-attention block read the labels and theta only
         def dec_prologue():
             d0_ = self.buf('dec_in.y', (nt * Md, d))
@@ -1452,8 +1453,7 @@ class PassEngine:
         else:
             self.gemm(1, 0, d, hp.d_in, Me, de0.data_ptr(), d, p2.data_ptr(), hp.d_in, dwp.data_ptr(), hp.d_in,
                       task=(Me * d, Me * hp.d_in, d * hp.d_in, 0, 0))
-        for t in range(nt):
-            check(lib.mtl_permute_hc(st, dwp[t].data_ptr(), g('encoder.input_linear.weight', t), d, 128, F4, 1, None), 'permute_inv')
+        check(lib.mtl_permute_hc_tb(st, dwp.data_ptr(), g('encoder.input_linear.weight'), d, 128, F4, 1, None, nt, d * hp.d_in, sG, 0), 'permute_inv')
         if self.slice_hook is not None:
             self.flush_ln_reduce()         # the encoder's LayerNorms (+ the input LayerNorm): their partials were all produced on this stream
             self._slice_done('encoder')

@@ -651,6 +651,19 @@ def test_flat_updates_colsum_permute(L):
     back = torch.zeros(rows, C * H).cuda()
     assert L.mtl_permute_hc(st(), wp.data_ptr(), back.data_ptr(), rows, C, H, 1, None) == 0
     assert torch.equal(back.cpu(), wt)
+    # task-batched form (16-byte path: C % 4 == 0 and H % 4 == 0), strided sources / bounds, accumulating inverse
+    tasks, rows, C, H = 3, 5, 128, 40
+    wt = torch.randn(tasks, rows + 2, C * H, generator=g)              # task stride larger than the weight
+    dwt = dev(wt)
+    wp = torch.empty(tasks, rows, C * H).cuda()
+    amx = torch.zeros(tasks, 4096).cuda()
+    assert L.mtl_permute_hc_tb(st(), dwt.data_ptr(), wp.data_ptr(), rows, C, H, 0, amx.data_ptr(), tasks, (rows + 2) * C * H, rows * C * H, 4096) == 0
+    for t in range(tasks):
+        assert float(amx[t].max()) == float(dwt[t, :rows].abs().max())
+        assert torch.equal(wp[t].cpu(), wt[t, :rows].view(rows, C, H).transpose(1, 2).reshape(rows, -1))
+    back = torch.ones(tasks, rows + 2, C * H).cuda()
+    assert L.mtl_permute_hc_tb(st(), wp.data_ptr(), back.data_ptr(), rows, C, H, 1, None, tasks, rows * C * H, (rows + 2) * C * H, 0) == 0
+    assert torch.equal(back[:, :rows].cpu(), wt[:, :rows] + 1) and torch.equal(back[:, rows:].cpu(), torch.ones(tasks, 2, C * H))
 
 
 def test_dropout_mask_statistics_and_determinism(L):
