@@ -703,7 +703,10 @@ def main():
                                          gpu_span_ms_per_pass=serial_wall / passes * 1e3),
                         per_family=fam_table, per_class=table)
         if dr['bound'] == 'mfma':
-            roofline['power_limited'] = power_limited_ceiling(dev, dr['achieved'], dr['peak'])
+            try:
+                roofline['power_limited'] = power_limited_ceiling(dev, dr['achieved'], dr['peak'])
+            except Exception as e:                       # a measurement aid must never cost the bench line
+                roofline['power_limited'] = dict(error=repr(e))
         ms = dt / a.steps * 1e3
         out = dict(metric='meta-steps/sec', value=a.steps / dt, unit='meta-steps/s', n_gpus=world, steps=a.steps, warmup=a.warmup,
                    ms_per_step=ms, higher_is_better=True, scaling='strong', vs_baseline=None, dtype=DTYPE[model.engine.conv_mode],
