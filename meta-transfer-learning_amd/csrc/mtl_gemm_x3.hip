@@ -33,7 +33,7 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #ifndef MTL_X3G_DBG
-#define MTL_X3G_DBG 0      // ablation builds only (tools/probe): 1 no MFMAs, 2 no fragment reads either, 4 operands fetched once, 8 no split / LDS commit
+#define MTL_X3G_DBG 0      // ablation builds only (tools/probe): 1 no MFMAs, 2 no fragment reads either, 4 operands fetched once, 8 no split / LDS commit, 16 B operand fetched / split once
 #endif
 constexpr int X3G_DBG = MTL_X3G_DBG;
 constexpr int BN = 128, BK = 32, NT = 512;               // BM (256 or 128) is a template parameter of the kernel
@@ -243,13 +243,13 @@ __global__ __launch_bounds__(NT) void gemm_x3_kernel(X3P p) {
         if ((X3G_DBG & 4) && tile > 1) return;
         const int zn = tile / nk, kt = tile - zn * nk;
         la.fetch(ra, zn * p.sAk, kt * BK, Kz, tid);
-        lb.fetch(rb, zn * p.sBk, kt * BK, Kz, tid);
+        if (!((X3G_DBG & 16) && tile > 1)) lb.fetch(rb, zn * p.sBk, kt * BK, Kz, tid);
     };
     auto commit = [&](auto full_tag, const typename OA::Regs& ra, const typename OB::Regs& rb, unsigned char* stage) {
         constexpr bool FULL = decltype(full_tag)::value;
         if ((X3G_DBG & 8) && stage != sm) return;
         la.template commit<FULL, RS>(ra, stage, tid, rs, sa);
-        lb.template commit<FULL, false>(rb, stage + NP * PLANE_A, tid, rs, sb);
+        if (!((X3G_DBG & 16) && stage != sm)) lb.template commit<FULL, false>(rb, stage + NP * PLANE_A, tid, rs, sb);
     };
     // fragment addresses: row (wm | wn) * 64 + 32 i + l31, chunk (2 st + hi) ^ ((row >> 2) & 3)
     const int arow = (wm * WTM + l31) * 64, brow = NP * PLANE_A + (wn * 64 + l31) * 64;
