@@ -27,6 +27,10 @@ bash tools/pmc_gemm_x3.sh "ffn fwd (enc)" > /dev/null 2>&1; cp gpurun_out/pmc_x3
 python tools/bench_conv.py 2>/dev/null | grep h2 > $O/conv_random_data.txt
 MTL_BENCH_ZERO=1 python tools/bench_conv.py 2>/dev/null | grep h2 > $O/conv_zero_data.txt
 python tools/clock_probe.py 3 2>/dev/null | grep -v amdgpu.ids > $O/clock_probe.txt
+# in-kernel stall breakdown of the convolutions, the tap-step model with controlled operands, LDS-DMA fill rate (tools/probe/build_probes.sh first)
+if [ -f tools/probe/libmtl_prof.so ]; then MTL_LIB=$PWD/tools/probe/libmtl_prof.so python tools/probe/conv_prof.py 2>/dev/null | grep -v amdgpu.ids > $O/conv_stall_breakdown.txt; fi
+if [ -x tools/probe/conv_step_model ]; then timeout 120 tools/probe/conv_step_model > $O/conv_step_model.txt 2>/dev/null; fi
+if [ -x tools/probe/ldsdma_rate ]; then timeout 120 tools/probe/ldsdma_rate > $O/ldsdma_rate.txt 2>/dev/null; fi
 rm -rf $O/pmc_fetch $O/pmc_write
 find $O -name "*_kernel_trace.csv" -delete
 find $O -name "*agent_info.csv" -delete

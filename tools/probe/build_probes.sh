@@ -1,0 +1,11 @@
+#!/bin/bash
+# Builds the probe artefacts of tools/probe (git-ignored; they travel to the GPU box with gpurun).  Run from the repo root after build().
+#   libmtl_prof.so     the product library with mtl_mfma.hip compiled -DMTL_X3_PROF (in-kernel s_memtime stall breakdown: conv_prof.py)
+#   conv_step_model, ldsdma_rate, ldsdma_contend   stand-alone micro-benchmarks
+set -e
+H=/opt/rocm/bin/hipcc
+C=meta-transfer-learning_amd/csrc
+$H --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DMTL_X3_PROF -c $C/mtl_mfma.hip -o /tmp/mtl_mfma_prof.o
+$H --offload-arch=gfx950 -shared -fPIC $(ls $C/build/*.o | grep -v "/mtl_mfma.o") /tmp/mtl_mfma_prof.o -o tools/probe/libmtl_prof.so
+for p in conv_step_model ldsdma_rate ldsdma_contend; do $H --offload-arch=gfx950 -O3 -Wno-unused-value tools/probe/$p.hip -o tools/probe/$p; done
+ls -la tools/probe/libmtl_prof.so tools/probe/conv_step_model tools/probe/ldsdma_rate tools/probe/ldsdma_contend
