@@ -33,6 +33,14 @@ def test_library_exports_every_declared_symbol(built):
     assert h.mtl_abi_version() == built._lib.ABI_VERSION
 
 
+def test_probe_library_is_separate_from_the_product(built):
+    # bench.py's `roofline.power_limited` aid: its own shared object, one entry point, nothing of it in the product library
+    probe = ctypes.CDLL(os.path.join(ROOT, 'meta-transfer-learning_amd', 'libmtl_probe.so'))
+    assert hasattr(probe, 'mtl_probe_mfma_f16')
+    assert not hasattr(ctypes.CDLL(built._lib.LIB_PATH), 'mtl_probe_mfma_f16')
+    assert 'mtl_probe' not in open(os.path.join(ROOT, 'include', 'mtl_hip.h')).read()
+
+
 def test_argument_validation_without_gpu(built):
     L = built._lib.lib()
     # bad arguments are rejected before any launch (no device needed)
