@@ -219,10 +219,11 @@ def family_of(cls, symbols):
             'layernorm_bwd': 'layernorm_bwd_kernel', 'conv0_fwd': 'conv0_fwd_kernel', 'conv0_wgrad': 'conv0_wgrad_kernel'}.get(cls, cls)
 
 
-DTYPE = {'h2': 'f32 (emulated: 3x3 conv + input Linear on 2 x fp16 pieces "h2" = 22 significand bits, big GEMMs on 3 x bf16 pieces "x3" = exact '
-               'fp32 operands, attention / small products / element-wise on fp32 MFMA + VALU; fp32 accumulation everywhere)',
-         'x3': 'f32 (emulated: 3x3 conv + big GEMMs on 3 x bf16 pieces "x3" = exact fp32 operands, input Linear on 2 x fp16 pieces, rest fp32 '
-               'MFMA + VALU; fp32 accumulation everywhere)',
+DTYPE = {'h2': 'f32 (emulated: 3x3 conv + input Linear on 2 x fp16 pieces "h2" = 22 significand bits, big GEMMs and '
+               'attention (d_k = 64) on 3 x bf16 pieces "x3" = exact fp32 operands, small products on fp32 MFMA, element-wise on VALU; fp32 '
+               'accumulation everywhere)',
+         'x3': 'f32 (emulated: 3x3 conv + big GEMMs + attention (d_k = 64) on 3 x bf16 pieces "x3" = exact fp32 operands, input Linear on 2 x fp16 '
+               'pieces, small products on fp32 MFMA, element-wise on VALU; fp32 accumulation everywhere)',
          'f32': 'f32 (every product on v_mfma_f32_*_f32 / VALU)'}
 
 
