@@ -274,9 +274,10 @@ def check(rc, what):
 
 def levenshtein(a, b):
     """Edit distance between two python strings (host helper, code-point level)."""
-    ua = (ctypes.c_uint32 * max(len(a), 1))(*[ord(c) for c in a])
-    ub = (ctypes.c_uint32 * max(len(b), 1))(*[ord(c) for c in b])
-    d = lib().mtl_levenshtein_u32(ua, len(a), ub, len(b))
+    # code points as little-endian uint32 straight from the codec (a per-character ord() list was 6 ms of host time per meta-step)
+    ua = a.encode('utf-32-le', 'surrogatepass') or b'\0\0\0\0'
+    ub = b.encode('utf-32-le', 'surrogatepass') or b'\0\0\0\0'
+    d = lib().mtl_levenshtein_u32(ctypes.cast(ctypes.c_char_p(ua), c_void_p), len(a), ctypes.cast(ctypes.c_char_p(ub), c_void_p), len(b))
     if d < 0:
         raise RuntimeError('mtl_levenshtein_u32 failed: %d' % d)
     return d
