@@ -1224,7 +1224,8 @@ int dispatch_conv_x3(ConvX3P& p, int Te, int Fe, hipStream_t s) {
     // 8 x 16 tiles (G = 1: 79 KiB of LDS at BN = 64, two workgroups per CU) measured faster only on the 64 -> 64 layer
     // (conv2 fwd 0.52 -> 0.50 ms, dgrad 0.61 -> 0.59); every 128-wide shape and conv5-dgrad is faster with 16 x 16 tiles.
     static const bool g1 = getenv("MTL_X3_G1") != nullptr;          // experiment: 8 x 16 tiles everywhere (LDS room for co-resident kernels)
-    if (p.g.Cout % 128 == 0) {
+    static const bool bn64 = getenv("MTL_X3_BN64") != nullptr;      // experiment: 128 output channels as two 64-channel tiles (two workgroups per CU)
+    if (p.g.Cout % 128 == 0 && !(bn64 && NP == 2 && EPI != EPI_DGRAD)) {
         p.ntile = p.g.Cout / 128;
         return g1 ? launch_conv_x3h<128, 1, UNPOOL, EPI, NP>(p, Te, Fe, s) : launch_conv_x3h<128, 2, UNPOOL, EPI, NP>(p, Te, Fe, s);
     }
