@@ -60,7 +60,19 @@ struct X3P {
     long sAmaxA, sAmaxB;
     int Ksplit;            // split-K launches: the product's full K; item zb (outer batch index) covers k in [zb K, min((zb + 1) K, Ksplit)) -- 0: off
     int pingpong;          // the two waves of a SIMD run a K step's halves in opposite order (MTL_GEMM_X3_PINGPONG=0: lock-step, A/B measurements)
+#ifdef MTL_X3G_PROF
+    unsigned long long* prof;   // probe builds only (tools/probe/gemm_prof.py): [workgroup][wave][8] accumulated s_memtime intervals
+#endif
 };
+#ifdef MTL_X3G_PROF
+static unsigned long long* g_x3g_prof = nullptr;
+extern "C" void mtl_x3g_prof_set(void* buf) { g_x3g_prof = (unsigned long long*)buf; }
+#define XG_T(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#define XG_ACC(slot, a, b) prof_acc[slot] += (b) - (a)
+#else
+#define XG_T(v)
+#define XG_ACC(slot, a, b)
+#endif
 
 // x0, x1 -> three dwords of packed bf16 pairs, x = h + m + l EXACTLY: h and m are truncations (top 8 significand bits of x and of
 // the exact residual x - h), which leaves at most 8 significant bits for l.  Truncation keeps the dependency chain at and -> sub ->
@@ -305,20 +317,38 @@ __global__ __launch_bounds__(NT) void gemm_x3_kernel(X3P p) {
     // the step's single barrier already separates (stage kt is read, stage kt + 1 is written), so no second barrier is needed.
     // (128-row form only: with 64 x 64 per wave the second code path does not fit the 256-register budget -- 98-173 spilled registers)
     const bool pong = BM == 128 && __builtin_amdgcn_readfirstlane(tid >> 8) != 0 && p.pingpong;
+#ifdef MTL_X3G_PROF
+    unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     auto step_main = [&](auto full_tag, int kt, typename OA::Regs& rac, typename OB::Regs& rbc, const typename OA::Regs& ran,
                          const typename OB::Regs& rbn) {
+        XG_T(t0);
         fetch(kt + 2, rac, rbc);
         __builtin_amdgcn_sched_barrier(0);           // the loads go out FIRST (hipcc sinks them behind the MFMAs otherwise: a step of flight time lost)
+        XG_T(t1);
+        XG_ACC(0, t0, t1);                           // operand fetch issued
         if (pong) {
             commit(full_tag, ran, rbn, sm + ((kt + 1) & 1) * STAGE);
             __builtin_amdgcn_sched_barrier(0);
+            XG_T(t2);
+            XG_ACC(2, t1, t2);                       // split + LDS commit (includes the wait for the operands)
             compute(sm + (kt & 1) * STAGE);
+            XG_T(t3);
+            XG_ACC(1, t2, t3);                       // fragment reads + matrix instructions issued
         } else {
             compute(sm + (kt & 1) * STAGE);
             __builtin_amdgcn_sched_barrier(0);
+            XG_T(t2);
+            XG_ACC(1, t1, t2);
             commit(full_tag, ran, rbn, sm + ((kt + 1) & 1) * STAGE);
+            XG_T(t3);
+            XG_ACC(2, t2, t3);
         }
+        XG_T(t4);
         lds_barrier();
+        XG_T(t5);
+        XG_ACC(3, t4, t5);                           // barrier (drain + wait for the slowest wave)
+        XG_ACC(4, t0, t5);                           // whole step
     };
     auto step_tail = [&](int kt, typename OA::Regs& rac, typename OB::Regs& rbc, const typename OA::Regs& ran, const typename OB::Regs& rbn) {
         if (kt + 2 < tiles) fetch(kt + 2, rac, rbc);
@@ -350,6 +380,11 @@ __global__ __launch_bounds__(NT) void gemm_x3_kernel(X3P p) {
         if (kt + 1 < tiles) step_tail(kt + 1, ra1, rb1, ra0, rb0);
     }
 
+#ifdef MTL_X3G_PROF
+    if (p.prof && lane == 0) {
+        for (int k_ = 0; k_ < 8; ++k_) p.prof[((long)blockIdx.x * 8 + wave) * 8 + k_] = prof_acc[k_];
+    }
+#endif
     // epilogue: straight-line per accumulator -- the optional operands (gate, old C) are fetched by wave-uniform branches, all 16
     // of an accumulator in flight together (clamped addresses), the stores are predicated (no load -> wait -> store chains)
     const long co = zt * p.sCt + zb * p.sCb + zh * p.sCh;
@@ -415,6 +450,9 @@ int launch_x3(X3P p, hipStream_t s) {
     if (attr) return attr;
     static const int pp = getenv("MTL_GEMM_X3_PINGPONG") ? atoi(getenv("MTL_GEMM_X3_PINGPONG")) : 1;
     p.pingpong = pp;
+#ifdef MTL_X3G_PROF
+    p.prof = g_x3g_prof;
+#endif
     p.total = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.total;       // (p.total arrives as the number of batch items)
     dim3 grid(((p.total + 7) / 8) * 8);
     hipLaunchKernelGGL((gemm_x3_kernel<TA, TB, RS, BM, NP>), grid, dim3(NT), SMEM, s, p);

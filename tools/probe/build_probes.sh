@@ -9,3 +9,6 @@ $H --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DMTL_X3_PROF -c $C/mtl_mfma.hip -
 $H --offload-arch=gfx950 -shared -fPIC $(ls $C/build/*.o | grep -v "/mtl_mfma.o") /tmp/mtl_mfma_prof.o -o tools/probe/libmtl_prof.so
 for p in conv_step_model ldsdma_rate ldsdma_contend; do $H --offload-arch=gfx950 -O3 -Wno-unused-value tools/probe/$p.hip -o tools/probe/$p; done
 ls -la tools/probe/libmtl_prof.so tools/probe/conv_step_model tools/probe/ldsdma_rate tools/probe/ldsdma_contend
+# per-wave phase breakdown of the bf16-split GEMM engine (tools/probe/gemm_prof.py)
+$H --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DMTL_X3G_PROF -c $C/mtl_gemm_x3.hip -o /tmp/mtl_gemm_x3_prof.o
+$H --offload-arch=gfx950 -shared -fPIC $(ls $C/build/*.o | grep -v "/mtl_gemm_x3.o") /tmp/mtl_gemm_x3_prof.o -o tools/probe/libmtl_gprof.so
