@@ -533,6 +533,8 @@ struct LoadConvA {
     }
 };
 
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+
 struct EpiConvRelu {  // y = relu(acc + bias), dense NHWC
     float* y;
     const float* bias;
@@ -545,6 +547,18 @@ struct EpiConvRelu {  // y = relu(acc + bias), dense NHWC
         for (int j = 0; j < 4; ++j) {
             const int t = t0 + 2 * (w >> 3) + (j & 1), f = f0 + 2 * (w & 7) + (j >> 1);
             if (t < T && f < F) __builtin_nontemporal_store(fmaxf(v[j] + bb, 0.f), y + (((long)b * T + t) * F + f) * Cout + col);
+        }
+    }
+    // two adjacent channels lc, lc + 1 of the same four rows (the 16 x 16 x 32 consumers: a lane owns an even / odd channel pair): 8-byte stores
+    __device__ __forceinline__ void store4x2(int lr, int lc, const float (&v0)[4], const float (&v1)[4]) const {
+        const int col = n0 + lc;
+        const int w = (lr >> 5) * 8 + ((lr >> 2) & 7);
+        const float2 bb = *reinterpret_cast<const float2*>(bias + col);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int t = t0 + 2 * (w >> 3) + (j & 1), f = f0 + 2 * (w & 7) + (j >> 1);
+            const f32x2v o = {fmaxf(v0[j] + bb.x, 0.f), fmaxf(v1[j] + bb.y, 0.f)};
+            if (t < T && f < F) __builtin_nontemporal_store(o, reinterpret_cast<f32x2v*>(y + (((long)b * T + t) * F + f) * Cout + col));
         }
     }
 };
@@ -573,6 +587,24 @@ struct EpiConvPool {  // p = maxpool2x2(relu(acc + bias)), first-max arg index (
         const long o = (((long)b * Tp + tp) * Fp + fp) * Cout + col;
         p[o] = best;
         am[o] = (uint8_t)idx;
+    }
+    __device__ __forceinline__ void store4x2(int lr, int lc, const float (&v0)[4], const float (&v1)[4]) const {
+        const int col = n0 + lc;
+        const int w = (lr >> 5) * 8 + ((lr >> 2) & 7);
+        const int tp = (t0 >> 1) + (w >> 3), fp = (f0 >> 1) + (w & 7);
+        if (tp >= Tp || fp >= Fp) return;
+        const float2 bb = *reinterpret_cast<const float2*>(bias + col);
+        float best0 = fmaxf(v0[0] + bb.x, 0.f), best1 = fmaxf(v1[0] + bb.y, 0.f);
+        int idx0 = 0, idx1 = 0;
+#pragma unroll
+        for (int j = 1; j < 4; ++j) {
+            const float x0 = fmaxf(v0[j] + bb.x, 0.f), x1 = fmaxf(v1[j] + bb.y, 0.f);
+            if (x0 > best0) best0 = x0, idx0 = j;
+            if (x1 > best1) best1 = x1, idx1 = j;
+        }
+        const long o = (((long)b * Tp + tp) * Fp + fp) * Cout + col;
+        *reinterpret_cast<float2*>(p + o) = make_float2(best0, best1);
+        *reinterpret_cast<unsigned short*>(am + o) = (unsigned short)(idx0 | (idx1 << 8));
     }
 };
 
@@ -610,6 +642,25 @@ struct EpiConvDgrad {  // dx = acc masked by the ReLU of the forward activation 
         for (int j = 0; j < 4; ++j) {
             const int t = t0 + 2 * (w >> 3) + (j & 1), f = f0 + 2 * (w & 7) + (j >> 1);
             if (t < T && f < F) __builtin_nontemporal_store(m[j] > 0.f ? v[j] : 0.f, dx + (((long)b * T + t) * F + f) * Cout + col);
+        }
+    }
+    __device__ __forceinline__ void gate4x2(int lr, int lc, f32x2v (&m)[4]) const {
+        const int col = n0 + lc;
+        const int w = (lr >> 5) * 8 + ((lr >> 2) & 7);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int t = min(t0 + 2 * (w >> 3) + (j & 1), T - 1), f = min(f0 + 2 * (w & 7) + (j >> 1), F - 1);
+            m[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x2v*>(act + (((long)b * T + t) * F + f) * Cout + col));
+        }
+    }
+    __device__ __forceinline__ void store4x2g(int lr, int lc, const float (&v0)[4], const float (&v1)[4], const f32x2v (&m)[4]) const {
+        const int col = n0 + lc;
+        const int w = (lr >> 5) * 8 + ((lr >> 2) & 7);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int t = t0 + 2 * (w >> 3) + (j & 1), f = f0 + 2 * (w & 7) + (j >> 1);
+            const f32x2v o = {m[j].x > 0.f ? v0[j] : 0.f, m[j].y > 0.f ? v1[j] : 0.f};
+            if (t < T && f < F) __builtin_nontemporal_store(o, reinterpret_cast<f32x2v*>(dx + (((long)b * T + t) * F + f) * Cout + col));
         }
     }
 };
@@ -717,6 +768,10 @@ __device__ __forceinline__ void split3x4(const float4& v, bf16x4& h, bf16x4& m, 
 
 // two fp16 pieces ("h2"): mtl_h2.h
 // NP 16-bit pieces per fp32 value: 3 = exact bf16 triple (scale ignored), 2 = fp16 pair of the scaled value
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#ifndef X3H_M16
+#define X3H_M16 1          // consumers of conv3x3_x3h_kernel on 16 x 16 x 32 matrix instructions (0: 32 x 32 x 16, A/B builds)
+#endif
 template <int NP>
 struct Split;
 template <>
@@ -732,11 +787,29 @@ struct Split<3> {
         cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, cc, 0, 0, 0);
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, cc, 0, 0, 0);
     }
+    // the same product on 16 x 16 x 32 instructions (one 16-byte fragment per lane covers all 32 k of the chunk)
+    static __device__ __forceinline__ f32x4 mfma16(const uint4 (&a)[3], const uint4 (&b)[3], f32x4 cc) {
+        const bf16x8 a0 = __builtin_bit_cast(bf16x8, a[0]), a1 = __builtin_bit_cast(bf16x8, a[1]), a2 = __builtin_bit_cast(bf16x8, a[2]);
+        const bf16x8 b0 = __builtin_bit_cast(bf16x8, b[0]), b1 = __builtin_bit_cast(bf16x8, b[1]), b2 = __builtin_bit_cast(bf16x8, b[2]);
+        cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b0, cc, 0, 0, 0);
+        cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, cc, 0, 0, 0);
+        cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b2, cc, 0, 0, 0);
+        cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b0, cc, 0, 0, 0);
+        cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b1, cc, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, cc, 0, 0, 0);
+    }
 };
 template <>
 struct Split<2> {
     static __device__ __forceinline__ void x2(float x0, float x1, float s, unsigned (&pc)[2]) { split2x2(x0 * s, x1 * s, pc[0], pc[1]); }
     static __device__ __forceinline__ f32x16 mfma(const uint4 (&a)[2], const uint4 (&b)[2], f32x16 cc) { return h2_mfma(a, b, cc); }
+    static __device__ __forceinline__ f32x4 mfma16(const uint4 (&a)[2], const uint4 (&b)[2], f32x4 cc) {
+        const f16x8 a0 = __builtin_bit_cast(f16x8, a[0]), a1 = __builtin_bit_cast(f16x8, a[1]);
+        const f16x8 b0 = __builtin_bit_cast(f16x8, b[0]), b1 = __builtin_bit_cast(f16x8, b[1]);
+        cc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b0, cc, 0, 0, 0);           // smallest terms first
+        cc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b1, cc, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b0, cc, 0, 0, 0);
+    }
 };
 template <int NP>
 __device__ __forceinline__ void split_x4(const float4& v, float s, uint2 (&pc)[NP]) {
@@ -1058,7 +1131,16 @@ void conv3x3_x3h_kernel(ConvX3P p) {
     const int lane = tid & 63, wave = tid >> 6;
     const int grp = wave / CW, w4 = wave % CW;
     const int wm = w4 / WN, wn = w4 % WN, l31 = lane & 31, hi = lane >> 5;
-    f32x16 acc[TM][TN];
+    // M16 (round 4): the wave's 64 x WTN tile as 4 x (WTN / 16) tiles of v_mfma_f32_16x16x32: the same 64 accumulator registers, one 16-byte
+    // fragment per lane covers all 32 k of a chunk (lane = row (lane & 15), k-quarter (lane >> 4)).  Under the package power limit the chip
+    // sustains 9-12 % more LDS-fed matrix work in this shape than in 32 x 32 x 16 (tools/probe/mfma_shape.py): half the accumulator traffic
+    // per flop.  A tile's 4 registers are 4 consecutive tile rows = one pooling window, like a register group of the 32 x 32 layout.
+    // (conv5's data gradient -- 64 output channels, 16 x 16 pixel tiles, no un-pooling -- measured 4 % slower in this form: it keeps 32 x 32 x 16)
+    constexpr bool M16 = X3H_M16 != 0 && !(BN == 64 && G == 2 && WN == 2 && EPI == EPI_DGRAD && !UNPOOL);
+    constexpr int TM16 = WTM / 16, TN16 = WTN / 16;
+    f32x16 acc[M16 ? 1 : TM][M16 ? 1 : TN];
+    f32x4 acc4[M16 ? TM16 : 1][M16 ? TN16 : 1];
+    const int l15 = lane & 15, q4 = lane >> 4;
     float inv = 1.f, mx = 0.f;                                 // NP = 2: 1 / (activation scale x weight scale); running bound of max|y|
     if (NP == 2) inv = 1.f / (pow2_scale(amax_read(p.amax_in)) * *reinterpret_cast<const float*>(p.w3 + (long)NP * nk * Cout * 64));
     int abase[TM];                                             // byte offset of this lane's pixel (tap centre) in the halo plane
@@ -1071,6 +1153,18 @@ void conv3x3_x3h_kernel(ConvX3P p) {
         abase[i] = (XH_HF + 1 + l31 + i * 32 + grp * 64) * X3_ROWB + hi * 16;     // probe build: conflict-free (wrong) fragment addresses
 #endif
     }
+    int abase16[M16 ? TM16 : 1];
+    if (M16) {
+#pragma unroll
+        for (int i = 0; i < TM16; ++i) {
+            int t, f;
+            tile_row_to_tf(wm * WTM + i * 16 + l15, t, f);
+            abase16[i] = ((t + grp * 8 + 1) * XH_HF + (f + 1)) * X3_ROWB + q4 * 16;
+        }
+    }
+    // tile 2k of a 32-channel block holds its EVEN channels, tile 2k + 1 the odd ones (weight row 32 k + 2 l15 + parity): a lane owns an
+    // adjacent channel pair of each block, so the epilogues move 8 bytes per lane and pixel = 128 contiguous bytes per 16 lanes
+    const unsigned char* bBase16 = smB + (wn * WTN + 2 * l15) * 64 + ((q4 ^ ((l15 >> 1) & 3)) * 16);
     const unsigned char* bBase = smB + (wn * WTN + l31) * 64;
     int bsw[BK / 16];                                          // swizzled position of this lane's 16-byte chunk per k-step
 #pragma unroll
@@ -1081,12 +1175,19 @@ void conv3x3_x3h_kernel(ConvX3P p) {
     X3_T(k0);
 #pragma unroll 1
     for (int j = 0; j < my_tiles; ++j) {
+        if (M16) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM16; ++i)
 #pragma unroll
-            for (int jn = 0; jn < TN; ++jn)
+                for (int jn = 0; jn < TN16; ++jn) acc4[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
+        } else {
 #pragma unroll
-                for (int v = 0; v < 16; ++v) acc[i][jn][v] = 0.f;
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) acc[i][jn][v] = 0.f;
+        }
 #pragma unroll 1
         for (int c = 0; c < cch; ++c) {
 #pragma unroll 1
@@ -1095,6 +1196,28 @@ void conv3x3_x3h_kernel(ConvX3P p) {
                 const int toff = ((kw - 1) * XH_HF + (kh - 1)) * X3_ROWB;
                 const unsigned char* bS = bBase + bst * BBUF;
                 X3_T(c0);
+                if (M16) {
+                    const unsigned char* bS16 = bBase16 + bst * BBUF;
+                    uint4 b16[TN16][NP];
+#pragma unroll
+                    for (int jn = 0; jn < TN16; ++jn)
+#pragma unroll
+                        for (int pc = 0; pc < NP; ++pc)
+                            b16[jn][pc] = *reinterpret_cast<const uint4*>(bS16 + pc * BPLANE + ((jn >> 1) * 32 + (jn & 1)) * 64);
+#pragma unroll
+                    for (int ih = 0; ih < TM16; ih += 2) {          // two row blocks at a time: 2 NP fragments live beside the weights'
+                        uint4 a16[2][NP];
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int pc = 0; pc < NP; ++pc)
+                                a16[i][pc] = *reinterpret_cast<const uint4*>(smA + pc * XH_APLANE + abase16[ih + i] + toff);
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int jn = 0; jn < TN16; ++jn) acc4[ih + i][jn] = Split<NP>::mfma16(a16[i], b16[jn], acc4[ih + i][jn]);
+                    }
+                } else
 #pragma unroll
                 for (int st = 0; st < BK / 16; ++st) {
                     uint4 a[TM][NP], bb[TN][NP];
@@ -1130,6 +1253,22 @@ void conv3x3_x3h_kernel(ConvX3P p) {
                 const X3Tile tl = x3_tile<G>(p, blockIdx.x + jj * gridDim.x);
                 const int ts0 = tl.t0 + grp * 8, n0 = tl.n0 * BN;
                 auto walk = [&](auto&& epi) {
+                    if (M16) {
+#pragma unroll
+                        for (int i = 0; i < TM16; ++i)
+#pragma unroll
+                            for (int jn = 0; jn < TN16; jn += 2) {
+                                float v0[4], v1[4];
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) {
+                                    v0[k] = NP == 2 ? acc4[i][jn][k] * inv : acc4[i][jn][k];
+                                    v1[k] = NP == 2 ? acc4[i][jn + 1][k] * inv : acc4[i][jn + 1][k];
+                                    mx = fmaxf(mx, fmaxf(fabsf(v0[k]), fabsf(v1[k])));
+                                }
+                                epi.store4x2(wm * WTM + i * 16 + 4 * q4, wn * WTN + (jn >> 1) * 32 + 2 * l15, v0, v1);
+                            }
+                        return;
+                    }
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1151,6 +1290,26 @@ void conv3x3_x3h_kernel(ConvX3P p) {
                     walk(EpiConvPool{p.y, p.am_out, p.bias, tl.b, ts0, tl.f0, Tp, Fp, Cout, n0});
                 } else {
                     const EpiConvDgrad epi{p.y, p.act, tl.b, ts0, tl.f0, T, F, Cout, n0};
+                    if (M16) {
+                        f32x2v gate16[TM16][TN16 / 2][4];      // all gate values of the wave in flight together
+#pragma unroll
+                        for (int i = 0; i < TM16; ++i)
+#pragma unroll
+                            for (int jp = 0; jp < TN16 / 2; ++jp) epi.gate4x2(wm * WTM + i * 16 + 4 * q4, wn * WTN + jp * 32 + 2 * l15, gate16[i][jp]);
+#pragma unroll
+                        for (int i = 0; i < TM16; ++i)
+#pragma unroll
+                            for (int jp = 0; jp < TN16 / 2; ++jp) {
+                                float v0[4], v1[4];
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) {
+                                    v0[k] = NP == 2 ? acc4[i][2 * jp][k] * inv : acc4[i][2 * jp][k];
+                                    v1[k] = NP == 2 ? acc4[i][2 * jp + 1][k] * inv : acc4[i][2 * jp + 1][k];
+                                    mx = fmaxf(mx, fmaxf(fabsf(v0[k]), fabsf(v1[k])));
+                                }
+                                epi.store4x2g(wm * WTM + i * 16 + 4 * q4, wn * WTN + jp * 32 + 2 * l15, v0, v1, gate16[i][jp]);
+                            }
+                    } else {
                     float gate[TM][TN][4][4];                  // all gate values of the wave in flight together
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
@@ -1173,6 +1332,7 @@ void conv3x3_x3h_kernel(ConvX3P p) {
                                 mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
                                 epi.store4g(wm * WTM + i * 32 + 8 * g + 4 * hi, wn * WTN + jn * 32 + l31, v, gate[i][jn][g]);
                             }
+                    }
                 }
             }
             X3_T(e1);
@@ -1188,6 +1348,12 @@ void conv3x3_x3h_kernel(ConvX3P p) {
     if (p.amax_out) {       // |relu(v + b)| <= |v| + |b| (pooling takes a maximum of those); dgrad: |gate v| <= |v|
         float bmax = 0.f;
         if (EPI != EPI_DGRAD) {
+            if (M16) {
+#pragma unroll
+                for (int jn = 0; jn < TN16; ++jn)
+                    for (int nt = 0; nt < p.ntile; ++nt)
+                        bmax = fmaxf(bmax, fabsf(p.bias[nt * BN + wn * WTN + (jn >> 1) * 32 + 2 * l15 + (jn & 1)]));
+            } else
 #pragma unroll
             for (int jn = 0; jn < TN; ++jn)
                 for (int nt = 0; nt < p.ntile; ++nt) bmax = fmaxf(bmax, fabsf(p.bias[nt * BN + wn * WTN + jn * 32 + l31]));
