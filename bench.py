@@ -540,18 +540,20 @@ def power_limited_ceiling(dev, achieved, peak):
         return ncu * steps * 8 * 24 * 32768.0 / (ev[0].elapsed_time(ev[1]) * 1e-3) / 1e12      # TFLOP/s of fp16 matrix work
 
     nominal = PEAK_H2_TFLOPS * 3                        # dense fp16 peak of the guide
-    r = dict(registers_zeros=rate(0, 0), registers_random=rate(0, 1), lds_fed_random=rate(1, 1), lds_fed_post_relu=rate(1, 2))
+    r = dict(registers_zeros=rate(0, 0), registers_random=rate(0, 1), lds_fed_random=rate(1, 1), lds_fed_post_relu=rate(1, 2),
+             lds_fed_16x16x32_random=rate(4, 1), lds_fed_16x16x32_post_relu=rate(4, 2))
     if not all(r.values()):
         return None
     out = dict(unit='TFLOP/s of dense fp16 matrix instructions', nominal=nominal,
                sustained={k: v for k, v in r.items()}, sustained_frac_of_nominal={k: v / nominal for k, v in r.items()},
-               note='sustained = all CUs issuing back-to-back v_mfma_f32_32x32x16_f16 for ~3 ms (registers_*: operands in registers; lds_fed_*: 16 '
-                    'ds_read_b128 per 24 matrix instructions and one s_barrier per step, the fragment traffic of the convolution kernel); '
-                    'the package power limit, not the instruction stream, sets these rates')
+               note='sustained = all CUs issuing back-to-back fp16 matrix instructions for ~3 ms (registers_*: v_mfma_f32_32x32x16_f16 on register '
+                    'operands; lds_fed_*: 16 ds_read_b128 per 64 x 64 x 32 wave-tile product and one s_barrier per step, the fragment traffic of '
+                    'the convolution kernel, on 32x32x16 instructions or -- lds_fed_16x16x32_*, what conv3x3_x3h_kernel issues since round 4 -- on '
+                    '16x16x32 ones); the package power limit, not the instruction stream, sets these rates')
     # the dominant kernel against the ceiling of ITS instruction mix and operand statistics
-    scale = r['lds_fed_post_relu'] / nominal
+    scale = r['lds_fed_16x16x32_post_relu'] / nominal
     out['frac_of_sustained'] = achieved / (peak * scale)
-    out['frac_note'] = 'roofline.achieved / (roofline.peak x lds_fed_post_relu / nominal)'
+    out['frac_note'] = 'roofline.achieved / (roofline.peak x lds_fed_16x16x32_post_relu / nominal)'
     return out
 
 

@@ -5,7 +5,7 @@
 // measured ceiling next to the nominal one.
 //   mode 0: one workgroup of 8 waves per CU, each step = 24 matrix instructions per wave on register operands
 //   mode 1: the fragment traffic of conv3x3_x3h_kernel<128, 2, ...> added: 16 ds_read_b128 per wave and step, one s_barrier per step
-//   mode 4: mode 1 on v_mfma_f32_16x16x32_f16 (same flops per step)
+//   mode 4: the step of mode 1 on v_mfma_f32_16x16x32_f16 (4 x 4 tiles of 16 x 16, one 16-byte fragment per lane and tile row / column: same flops, same LDS bytes)
 //   mode 2 / 3: modes 0 / 1 with the instructions that share an operand register issued back to back (an experiment on switching power)
 //   fill 0 zeros | 1 pseudo-random fp16 in [-2, 2) | 2 the same with half of one operand zero (activations after a ReLU)
 #include <hip/hip_runtime.h>
