@@ -769,6 +769,9 @@ __device__ __forceinline__ void split3x4(const float4& v, bf16x4& h, bf16x4& m, 
 // two fp16 pieces ("h2"): mtl_h2.h
 // NP 16-bit pieces per fp32 value: 3 = exact bf16 triple (scale ignored), 2 = fp16 pair of the scaled value
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+#ifndef X3H_IH
+#define X3H_IH 0           // probe builds: row blocks (of 16 pixels) per A-fragment batch of the 16 x 16 x 32 consumers (default 2)
+#endif
 #ifndef X3H_M16
 #define X3H_M16 1          // consumers of conv3x3_x3h_kernel on 16 x 16 x 32 matrix instructions (0: 32 x 32 x 16, A/B builds)
 #endif
@@ -1204,16 +1207,17 @@ void conv3x3_x3h_kernel(ConvX3P p) {
 #pragma unroll
                         for (int pc = 0; pc < NP; ++pc)
                             b16[jn][pc] = *reinterpret_cast<const uint4*>(bS16 + pc * BPLANE + ((jn >> 1) * 32 + (jn & 1)) * 64);
+                    constexpr int IH = X3H_IH ? X3H_IH : 2;         // row blocks per fragment batch: IH NP fragments live beside the weights'
 #pragma unroll
-                    for (int ih = 0; ih < TM16; ih += 2) {          // two row blocks at a time: 2 NP fragments live beside the weights'
-                        uint4 a16[2][NP];
+                    for (int ih = 0; ih < TM16; ih += IH) {
+                        uint4 a16[IH][NP];
 #pragma unroll
-                        for (int i = 0; i < 2; ++i)
+                        for (int i = 0; i < IH; ++i)
 #pragma unroll
                             for (int pc = 0; pc < NP; ++pc)
                                 a16[i][pc] = *reinterpret_cast<const uint4*>(smA + pc * XH_APLANE + abase16[ih + i] + toff);
 #pragma unroll
-                        for (int i = 0; i < 2; ++i)
+                        for (int i = 0; i < IH; ++i)
 #pragma unroll
                             for (int jn = 0; jn < TN16; ++jn) acc4[ih + i][jn] = Split<NP>::mfma16(a16[i], b16[jn], acc4[ih + i][jn]);
                     }
