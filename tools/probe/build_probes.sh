@@ -12,3 +12,6 @@ ls -la tools/probe/libmtl_prof.so tools/probe/conv_step_model tools/probe/ldsdma
 # per-wave phase breakdown of the bf16-split GEMM engine (tools/probe/gemm_prof.py)
 $H --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DMTL_X3G_PROF -c $C/mtl_gemm_x3.hip -o /tmp/mtl_gemm_x3_prof.o
 $H --offload-arch=gfx950 -shared -fPIC $(ls $C/build/*.o | grep -v "/mtl_gemm_x3.o") /tmp/mtl_gemm_x3_prof.o -o tools/probe/libmtl_gprof.so
+# the 3x3 convolution consumers on 32 x 32 x 16 instructions (the round-3 form) for A/B runs: MTL_LIB=tools/probe/libmtl_m32.so
+$H --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DX3H_M16=0 -c $C/mtl_mfma.hip -o /tmp/mtl_mfma_m32.o
+$H --offload-arch=gfx950 -shared -fPIC $(ls $C/build/*.o | grep -v "/mtl_mfma.o") /tmp/mtl_mfma_m32.o -o tools/probe/libmtl_m32.so
