@@ -14,6 +14,10 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- python be
 python tools/pmc_traffic.py $O/pmc_fetch/f_counter_collection.csv $O/pmc_write/w_counter_collection.csv $O/pmc_traffic.json > $O/pmc_traffic.txt 2>&1
 python tools/pmc_summary.py $O/pmc_fetch/f_counter_collection.csv FETCH_SIZE $O/pmc_fetch_size_per_kernel.csv
 python tools/pmc_summary.py $O/pmc_write/w_counter_collection.csv WRITE_SIZE $O/pmc_write_size_per_kernel.csv
+# what ONE rank of the 8-GPU configuration runs (BASELINE.json configs[2]): one task per step
+mkdir -p $O/one_task
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/one_task/trace -o one -- python bench.py --tasks 1 --steps 10 --warmup 3 --no-cpu-baseline --no-extras > $O/one_task/bench_one_task_traced.json 2> /dev/null
+python bench.py --tasks 1 --steps 30 --warmup 3 --no-cpu-baseline --no-extras 2> /dev/null | tail -1 > $O/one_task/bench_one_task.json
 # long-utterance configuration (BASELINE.json configs[3]): T = 5000
 python bench.py --frames 5000 --tasks 2 --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $O/bench_t5000.json 2> /dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/t5000 -o t5000 -- python bench.py --frames 5000 --tasks 1 --steps 1 --warmup 1 --no-cpu-baseline --no-extras --serial > $O/bench_t5000_serial_traced.json 2> /dev/null
