@@ -257,12 +257,17 @@ def algorithmic_bytes(name, a, unit, work):
     return 0.0
 
 
+# classes whose kernels issue SIX bf16 MFMAs per fp32-equivalent multiply-accumulate (operands as exact bf16 triples): the big GEMM
+# engine and -- since round 4 -- the flash attention kernels at the supported head sizes (csrc/mtl_attn.hip, v_mfma_f32_16x16x32_bf16)
+X3_CLASSES = ('gemm_x3', 'attn_fwd', 'attn_bwd')
+
+
 def peak_of(cls, unit, conv_mode, wgrad_x3_dense):
     if unit == 'byte':
         return PEAK_HBM_GBS, 'GB/s', 'hbm'
     if cls == 'gemm_h2':
         return PEAK_H2_TFLOPS, 'TFLOP/s', 'mfma'
-    if cls == 'gemm_x3':
+    if cls in X3_CLASSES:
         return PEAK_X3_TFLOPS, 'TFLOP/s', 'mfma'
     if cls.startswith('conv') and conv_mode != 'f32' and not (cls == 'conv5_wgrad' and not wgrad_x3_dense):
         return (PEAK_H2_TFLOPS if conv_mode == 'h2' else PEAK_X3_TFLOPS), 'TFLOP/s', 'mfma'
@@ -342,9 +347,28 @@ def serial_profile(mtl, trainer, model, vocab, tasks, my_tasks, n_tasks, inner, 
 
 
 HOST_ENQUEUE = {}
+HOST = {}
 
 
 TRACE = [] if os.environ.get('MTL_BENCH_TRACE') else None      # diagnostics: (seconds into the timed span, host enqueue ms) per step, to stderr
+
+
+_SW = []
+
+
+def stall_watch():
+    """diagnostics (MTL_STALL_WATCH=<ms>): tools/probe/libstallwatch.so reports what the host thread is blocked in whenever one
+    enqueue_iteration takes longer than <ms> (kernel-side state + native backtrace, to stderr)"""
+    thr = os.environ.get('MTL_STALL_WATCH')
+    if not thr:
+        return None
+    if not _SW:
+        import ctypes
+        lib = ctypes.CDLL(os.path.join(ROOT, 'tools', 'probe', 'libstallwatch.so'))
+        lib.sw_start.argtypes = [ctypes.c_double, ctypes.c_int]
+        lib.sw_start(float(thr), 2)
+        _SW.append(lib)
+    return _SW[0]
 
 
 def timed_steps(trainer, model, vocab, tasks, my_tasks, n_tasks, inner, outer, args, steps, warmup, mdist, dev):
@@ -358,26 +382,36 @@ def timed_steps(trainer, model, vocab, tasks, my_tasks, n_tasks, inner, outer, a
     mdist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    host = 0.0
+    host = []
     # the loop of TransientTrainer.train: up to `pipeline_depth` iterations are enqueued beyond the one whose read-backs are being
     # resolved (loss, CER strings: host work that would otherwise be GPU idle time); every one of the K iterations is resolved INSIDE
     # the timed span
     pipelined = getattr(trainer, 'pipeline', False) and hasattr(trainer, 'enqueue_iteration')
     depth = max(getattr(trainer, 'pipeline_depth', 1), 1)
     pending = []
+    sw = stall_watch()
     for _ in range(steps):
         if pipelined:
+            if sw is not None:
+                sw.sw_enter()
             pending.append(trainer.enqueue_iteration(model, vocab, local, val, n_tasks, inner, outer, args))
+            if sw is not None:
+                sw.sw_exit()
             while len(pending) > depth:
                 last = pending.pop(0).result()
         else:
             last = one()
-        host += getattr(trainer, 'host_enqueue_s', 0.0)
+        host.append(getattr(trainer, 'host_enqueue_s', 0.0) * 1e3)
         if TRACE is not None:
             TRACE.append((round(time.perf_counter() - t0, 3), round(getattr(trainer, 'host_enqueue_s', 0.0) * 1e3, 1)))
+            ph = sys.modules['mtl_amd']._trace.steps
+            if ph:
+                print('phases step@%.3f: %s' % (time.perf_counter() - t0, json.dumps(ph[-1])), file=sys.stderr)
+                del ph[:]
     while pending:
         last = pending.pop(0).result()
-    HOST_ENQUEUE['ms_per_step'] = host / steps * 1e3     # host time to enqueue a step (the rest of the span it waits for the GPU)
+    # host time to enqueue a step (the rest of the span it waits for the GPU)
+    HOST_ENQUEUE.update(mean=sum(host) / max(len(host), 1), median=sorted(host)[len(host) // 2] if host else 0.0, max=max(host) if host else 0.0)
     if TRACE is not None:
         try:
             age = time.time() - os.stat('/proc/1').st_ctime
@@ -503,7 +537,7 @@ def main_lm(a, mtl_amd, mdist, dev, rank, world):
                    last_step=dict(weighted_val_loss=last[0]))
         if world == 1 and not a.no_cpu_baseline:
             from oracle import lm_refimpl as LR           # checker-side restatement: the cpu_baseline leg only
-            threads = a.cpu_threads or min(32, physical_cores())
+            threads = a.cpu_threads or min(32, physical_cores(), HOST.get("effective_cpus") or 32)
             torch.set_num_threads(threads)
             oracle = LR.RNNModel(c['ntoken'], c['ninp'], c['nhid'], c['nlayers'], 0.0)
             otasks = [LR.batchify(s_, c['batch_size']) for s_ in streams]
@@ -518,7 +552,7 @@ def main_lm(a, mtl_amd, mdist, dev, rank, world):
             out['cpu_baseline'] = dict(value=1.0 / (tc * n / nb), unit='meta-steps/s', cores=threads, kind='port',
                                        sample='%d of %d tasks of one meta-iteration timed after a 1-task warm-up (%.2f s), scaled x%d/%d'
                                               % (nb, n, tc, n, nb))
-        print(json.dumps(out), flush=True)
+        emit(out)
     mdist.barrier()
 
 
@@ -598,6 +632,12 @@ def main():
     with contextlib.redirect_stdout(io.StringIO()):          # the model factory prints; keep stdout to ONE JSON line
         import mtl_amd
     mdist = mtl_amd.dist
+    # torch sizes its CPU pool by the machine (128 threads on the GPU node); the container's CFS quota is 16 CPUs, and a 128-thread
+    # OpenMP region inside it gets the whole process throttled for 50-100 ms at a time (meta-transfer-learning_amd/hostenv.py)
+    HOST['torch_threads_default'] = torch.get_num_threads()
+    HOST['torch_threads'] = mtl_amd.hostenv.bound_torch_threads()
+    HOST['effective_cpus'] = mtl_amd.hostenv.effective_cpus()
+    HOST['cgroup_cpu_quota'] = mtl_amd.hostenv.cgroup_cpu_quota()
     local_rank = mdist.init_from_env()
     world, rank = mdist.world_size(), mdist.rank()
     if world != a.gpus and not (a.gpus == 1 and world == 1):
@@ -641,6 +681,7 @@ def main():
         timed_steps(trainer, model, vocab, tasks, my_tasks, a.tasks, inner, outer, args, n_setup, 0, mdist, dev)
     # ---- the headline number: K meta-steps, inputs resident, nothing else inside the timed region
     dt, last = timed_steps(trainer, model, vocab, tasks, my_tasks, a.tasks, inner, outer, args, a.steps, a.warmup, mdist, dev)
+    host_stats = {k: round(v, 2) for k, v in HOST_ENQUEUE.items()}
 
     # (bit-level fingerprint of theta after the timed steps: tests compare schedules / collectives that must not change a single bit)
     th = model.flat_parameters
@@ -683,7 +724,8 @@ def main():
             if c['unit'] is None or c['work'] <= 0:
                 continue
             f = fams.setdefault(family_of(cls, c['symbols']), dict(time=0.0, work=0.0, launches=0, classes=[], unit=c['unit'], traffic=0.0,
-                                                                   traffic_known=True))
+                                                                   traffic_known=True, abytes=0.0))
+            f['abytes'] += c.get('abytes', 0.0)
             f['time'] += c['time']
             f['work'] += c['work']
             f['launches'] += c['launches']
@@ -707,7 +749,7 @@ def main():
             'two fp16 pieces (h2): 3 v_mfma_f32_32x32x16_f16 per fp32-equivalent step, peak = dense fp16 / 3' if dr['peak'] == PEAK_H2_TFLOPS else (
                 'exact fp32 MFMA' if dr['bound'] == 'mfma' else 'HBM streaming')))
         roofline = dict(bound=dr['bound'], kernel=dom, symbols=dom, achieved=dr['achieved'], peak=dr['peak'], unit=dr['unit'],
-                        frac=dr['frac'], traffic=dr['traffic'],
+                        frac=dr['frac'], traffic=dr['traffic'], algorithmic_bytes=df['abytes'] / max(df['launches'], 1),
                         work_per_launch=df['work'] / df['launches'], avg_launch_ms=df['time'] / df['launches'] * 1e3,
                         launches_timed=df['launches'], ms_per_pass=dr['ms_per_pass'], classes=dr['classes'],
                         selection='rocprofv3 symbol family with the largest accumulated time over ALL library launches of a serial meta-step '
@@ -747,7 +789,7 @@ def main():
                                                 'x3': '3x3 convolutions as exact 3-way bf16 splits of fp32 operands, fp32 accumulate '
                                                       '(fp32-class error, same test tolerances as the fp32-MFMA kernels)',
                                                 'f32': 'fp32 MFMA'}[model.engine.conv_mode]),
-                   roofline=roofline, host_enqueue_ms_per_step=HOST_ENQUEUE.get('ms_per_step'), last_step=dict(val_loss=last[0] / a.tasks, cer_edits=last[1], chars=last[2]), theta_checksum=theta_ck)
+                   roofline=roofline, host_enqueue_ms=host_stats, host=dict(HOST), last_step=dict(val_loss=last[0] / a.tasks, cer_edits=last[1], chars=last[2]), theta_checksum=theta_ck)
 
     extras = world == 1 and not a.no_extras
     if extras:
@@ -805,18 +847,82 @@ def main():
         # torch's CPU kernels do not scale to every core of a large host (measured on the 128-core GPU node: 11.1 s per task at
         # 128 threads, 3.9 s at 32, 4.2 s at 8), so the baseline is timed at the physical core count, at 32 and at 8 threads
         # (SURVEY's 8-core figure) and the FASTEST is reported as `value`, with its thread count in `cores`
-        phys = physical_cores()
+        # (thread counts: the CPUs this container may actually use -- min(physical cores, CFS quota) -- and 8, SURVEY's figure; round 4
+        # timed 128 threads under a 16-CPU quota, which only measured the throttling)
+        phys = min(physical_cores(), HOST.get('effective_cpus') or physical_cores())
         counts = [a.cpu_threads] if a.cpu_threads else sorted({phys, min(32, phys), min(8, phys)}, reverse=True)
         runs = {n: cpu_baseline(a.tasks, a.k, a.frames, a.labels, n, timed_tasks=2)       # two full tasks per thread count
                 for n in counts}
         best = max(runs, key=lambda n: runs[n]['value'])
         out['cpu_baseline'] = dict(runs[best])
-        out['cpu_baseline']['host'] = dict(physical_cores=phys, logical_cpus=os.cpu_count())
+        out['cpu_baseline']['host'] = dict(physical_cores=physical_cores(), logical_cpus=os.cpu_count(), usable_cpus=phys,
+                                           cgroup_cpu_quota=HOST.get('cgroup_cpu_quota'))
+        mtl_amd.hostenv.bound_torch_threads()
         out['cpu_baseline']['by_threads'] = {str(n): dict(value=r['value'], seconds_per_task=r['seconds_per_task'], sample=r['sample'])
                                              for n, r in runs.items()}
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out)
     mdist.barrier()
+
+
+LINE_LIMIT = 4096        # bytes: the driver parses the LAST stdout line; round 4's 20 KB line came back as parsed = null
+
+
+def _r(v, nd=4):
+    return round(v, nd) if isinstance(v, float) else v
+
+
+def compact_line(out):
+    """The ONE stdout line (< LINE_LIMIT bytes): the contract's keys, the `roofline` and `cpu_baseline` objects without their
+    tables, the extra legs as bare numbers.  Everything else (per_class / per_family tables, notes, by-thread CPU runs) goes to
+    gpurun_out/bench_detail.json and stderr."""
+    line = {k: _r(out[k]) for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                                    'vs_baseline', 'dtype', 'data') if k in out}
+    cfg = out.get('config', {})
+    line['config'] = {k: cfg[k] for k in ('workload', 'tasks', 'k_train', 'src_frames', 'tgt_len', 'parallelism', 'collective', 'ranks',
+                                          'inputs', 'schedule', 'bptt', 'batch_size', 'nhid', 'ntoken') if k in cfg}
+    rf = out.get('roofline')
+    if rf:
+        line['roofline'] = {k: _r(rf[k]) for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'algorithmic_bytes',
+                                                   'avg_launch_ms', 'work_per_launch', 'launches_timed', 'ms_per_pass') if k in rf}
+        pl = rf.get('power_limited') or {}
+        if 'frac_of_sustained' in pl:
+            line['roofline']['frac_of_sustained'] = _r(pl['frac_of_sustained'])
+    cb = out.get('cpu_baseline')
+    if cb:
+        line['cpu_baseline'] = {k: _r(cb[k]) for k in ('value', 'unit', 'cores', 'kind', 'sample', 'seconds_per_task') if k in cb}
+    if 'host_enqueue_ms' in out:
+        line['host_enqueue_ms'] = out['host_enqueue_ms']
+    if 'host' in out:
+        line['host'] = out['host']
+    for k in ('with_h2d', 'configs1_3task', 'dropout_0.1', 'conv_x3', 'exact_f32'):
+        if k in out:
+            line[k] = _r(out[k]['value'], 3)
+    if 'one_task_per_gpu' in out:
+        line['one_task_per_gpu_ms'] = _r(out['one_task_per_gpu']['ms_per_step'], 3)
+    for k in ('last_step', 'theta_checksum', 'detail'):
+        if k in out:
+            line[k] = out[k]
+    return line
+
+
+def emit(out):
+    detail_path = os.path.join(ROOT, 'gpurun_out', 'bench_detail.json')
+    try:
+        os.makedirs(os.path.dirname(detail_path), exist_ok=True)
+        with open(detail_path, 'w') as f:
+            json.dump(out, f, indent=1)
+        out['detail'] = 'gpurun_out/bench_detail.json (per_class / per_family tables, notes; also on stderr)'
+    except OSError:
+        out['detail'] = 'stderr'
+    print('bench detail: ' + json.dumps(out), file=sys.stderr, flush=True)
+    text = json.dumps(compact_line(out))
+    if len(text) >= LINE_LIMIT:                       # never let a long note cost the line again: drop the free-text fields
+        line = compact_line(out)
+        line['config'] = {k: v for k, v in line['config'].items() if not isinstance(v, str) or len(v) < 80}
+        line.get('cpu_baseline', {}).pop('sample', None)
+        text = json.dumps(line)
+    print(text, flush=True)
 
 
 if __name__ == '__main__':

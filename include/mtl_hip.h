@@ -423,6 +423,9 @@ typedef struct mtl_cmd {
 } mtl_cmd;
 int mtl_cmdlist_opcode(const char* function_name);     /* -1 if the function cannot be recorded */
 int mtl_cmdlist_run(const mtl_cmd* cmds, int n, int* failed_index);
+/* diagnostics: the same replay, and host_us[i] = HOST time (microseconds) the i-th call took to return (a launch that blocks in
+ * the runtime -- full queue, exhausted kernel-argument pool, a signal still in use -- shows up here, not in any device profile) */
+int mtl_cmdlist_run_timed(const mtl_cmd* cmds, int n, int* failed_index, float* host_us);
 
 /* ---- host helper: Levenshtein distance on code points (utils/metrics.py:38-44 uses python-Levenshtein) ---- */
 int mtl_levenshtein_u32(const unsigned int* a_host, int na, const unsigned int* b_host, int nb);

@@ -11,4 +11,5 @@ from .metrics import calculate_metrics, calculate_cer  # noqa: F401
 from .model import Transformer, Encoder, Decoder  # noqa: F401
 from .trainer import TransientTrainer, JointTrainer, FlatAdam, FlatSGD  # noqa: F401
 from . import dist  # noqa: F401
+from . import hostenv  # noqa: F401
 from . import lm  # noqa: F401

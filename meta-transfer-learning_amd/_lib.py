@@ -113,6 +113,7 @@ SIGNATURES = {
     'mtl_stream_wait_event': (I, [P, P]),
     'mtl_cmdlist_opcode': (I, [ctypes.c_char_p]),
     'mtl_cmdlist_run': (I, [P, I, P]),
+    'mtl_cmdlist_run_timed': (I, [P, I, P, P]),
     'mtl_levenshtein_u32': (I, [P, I, P, I]),
 }
 
@@ -216,6 +217,14 @@ class CommandList:
         self.entries = None
         return self
 
+    def _names(self):
+        names = {}
+        for name in SIGNATURES:
+            op = lib().mtl_cmdlist_opcode(name.encode())
+            if op >= 0:
+                names[op] = name
+        return names
+
     def repoint(self, old, new):
         if old == new:
             return
@@ -227,9 +236,17 @@ class CommandList:
         self._ptr_sites.setdefault(new, []).extend(sites)
 
     def run(self, on_break=None):
+        from . import _trace
         h, start = lib(), 0
         for end, tag in self.breaks + [(self.n, None)]:
-            if end > start:
+            if end > start and _trace.ON:
+                us = (c_float * (end - start))()
+                rc = h.mtl_cmdlist_run_timed(ctypes.byref(self.buf, start * ctypes.sizeof(MtlCmd)), end - start, ctypes.byref(self._failed), us)
+                names = self._names()
+                _trace.calls([names[self.buf[i].op] for i in range(start, end)], list(us), start)
+                if rc != 0:
+                    raise RuntimeError('mtl_cmdlist_run: command %d failed with code %d' % (start + self._failed.value, rc))
+            elif end > start:
                 rc = h.mtl_cmdlist_run(ctypes.byref(self.buf, start * ctypes.sizeof(MtlCmd)), end - start, ctypes.byref(self._failed))
                 if rc != 0:
                     raise RuntimeError('mtl_cmdlist_run: command %d failed with code %d' % (start + self._failed.value, rc))

@@ -7,6 +7,7 @@
 // layer records one eager run and then replays it from here: the host cost per call drops to the hipLaunchKernel itself.
 // Unlike a hipGraph (measured no faster than eager launches on ROCm 7.2) this keeps the two-stream fork / join of the
 // parameter-gradient kernels as plain event calls and needs no capture-safe allocator state.
+#include <chrono>
 #include <cstring>
 
 #include "mtl_common.h"
@@ -55,6 +56,20 @@ int mtl_cmdlist_run(const mtl_cmd* cmds, int n, int* failed_index) {
     if (!cmds || n < 0) return MTL_EINVAL;
     for (int i = 0; i < n; ++i) {
         const int rc = cmd_dispatch(cmds[i]);
+        if (rc != MTL_OK) {
+            if (failed_index) *failed_index = i;
+            return rc;
+        }
+    }
+    return MTL_OK;
+}
+
+int mtl_cmdlist_run_timed(const mtl_cmd* cmds, int n, int* failed_index, float* host_us) {
+    if (!cmds || n < 0 || !host_us) return MTL_EINVAL;
+    for (int i = 0; i < n; ++i) {
+        const auto t0 = std::chrono::steady_clock::now();
+        const int rc = cmd_dispatch(cmds[i]);
+        host_us[i] = std::chrono::duration<float, std::micro>(std::chrono::steady_clock::now() - t0).count();
         if (rc != MTL_OK) {
             if (failed_index) *failed_index = i;
             return rc;

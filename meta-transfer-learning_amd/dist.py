@@ -92,6 +92,10 @@ def chunked_on():
     return collective_on() and os.environ.get('MTL_CHUNKED_ALLREDUCE', '1') != '0'
 
 
+SLICE_ORDER = ('decoder', 'encoder', 'conv')     # the order the validation backward finishes the parameter groups in; EVERY rank posts
+#                                                  its slice collectives in this order, whatever schedule its local tasks take
+
+
 class ChunkedAllReduce:
     """SUM all-reduce of a flat buffer as a fixed sequence of slices, each issued asynchronously (`issue`) as soon as the caller
     knows it is final; `wait()` joins all of them.  Slices are disjoint and always issued in the same order on every rank, so the

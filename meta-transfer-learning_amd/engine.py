@@ -20,7 +20,7 @@ import torch
 
 import re
 
-from . import _lib
+from . import _lib, _trace
 from ._lib import check
 
 PAD_ID, SOS_ID, EOS_ID = 0, 1, 2
@@ -49,6 +49,21 @@ class ParamLayout:
     def view(self, flat, name):
         off, shape, n = self.entries[name]
         return flat[off:off + n].view(shape)
+
+    def group_bounds(self):
+        """{'encoder' | 'decoder' | 'conv': (first, end) offsets in floats} of the three parameter groups in the flat buffers --
+        parameters() order of models/asr/transformer.py is encoder, decoder, conv, so each group is one contiguous slice."""
+        out, prev = {}, None
+        for name in self.order:
+            grp = name.split('.')[0]
+            if grp != prev:
+                if grp in out:
+                    raise RuntimeError('parameter group %s is not contiguous in the flat layout' % grp)
+                out[grp] = [self.off(name), self.total]
+                if prev is not None:
+                    out[prev][1] = self.off(name)
+                prev = grp
+        return {k: tuple(v) for k, v in out.items()}
 
 
 class Hyper:
@@ -198,6 +213,8 @@ class _DecodeSession:
             c[:, :t] = c.index_select(0, idx)[:, :t]
 
 
+STAGE_RING = 6      # pinned staging buffers per slot (prepare_tasks): > pipeline depth (default 2) + 2
+
 _LAYER_BUF = re.compile(r'^([de])(\d+)\.(.+)$')
 
 
@@ -336,7 +353,7 @@ class PassEngine:
             # staging of shapes that are gone: rebuilt on demand
             self._wgrad_tables.clear()
             self._ln_tables.clear()
-            if len(self._stage) > 64:
+            if len(self._stage) > 64 * STAGE_RING:
                 self._stage.clear()
                 self._stage_turn.clear()
             self.arena = {k: v for k, v in self.arena.items() if not isinstance(v, torch.Tensor) or k == '_scratch'}
@@ -549,23 +566,16 @@ class PassEngine:
             check(self.lib.mtl_stream_wait_event(self.stream, ev), 'mtl_stream_wait_event')
 
     def slice_bounds(self):
-        """{'encoder' | 'decoder' | 'conv': (first, end) offsets in floats} of the three parameter groups in the flat buffers --
-        parameters() order of models/asr/transformer.py is encoder, decoder, conv, so each group is one contiguous slice."""
-        L, out, prev = self.L, {}, None
-        for name in L.order:
-            grp = name.split('.')[0]
-            if grp != prev:
-                if grp in out:
-                    raise RuntimeError('parameter group %s is not contiguous in the flat layout' % grp)
-                out[grp] = [L.off(name), L.total]
-                if prev is not None:
-                    out[prev][1] = L.off(name)
-                prev = grp
-        return {k: tuple(v) for k, v in out.items()}
+        """ParamLayout.group_bounds(): the three parameter groups' slices of the flat buffers"""
+        return self.L.group_bounds()
 
     def _slice_done(self, tag):
         if self.slice_hook is None:
             return
+        # every kernel that writes this group's gradients must have been ENQUEUED: nothing collected for a later grouped launch
+        # (the trainer does not hook a backward with group_wgrads / flush_delay: TransientTrainer._chunk_hook)
+        if self.wgrads or self.deferred or self._held is not None:
+            raise RuntimeError('slice %r handed over with weight-gradient launches still pending' % tag)
         if isinstance(self.lib, _lib.Recorder):
             self.lib.segment_break(tag)        # the replay stops here and hands control to the same hook
         self.slice_hook(tag)
@@ -1002,33 +1012,45 @@ class PassEngine:
             firsts.append(first)
             nexts.append(nxt)
         head = 2 + nt + (nt & 1)              # seed (8 bytes) | 1 / n_nonpad per task | padding to an even count
-        meta_i32 = torch.from_numpy(np.concatenate([
+        # (numpy from here to the upload: a torch CPU kernel on > 32768 elements -- the staging copy was one -- starts an OpenMP
+        # region on torch's whole intra-op pool; in a CPU-quota'd container that stalls the enqueueing thread, hostenv.py)
+        meta_np = np.concatenate([
             torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).numpy().view(np.int32),   # dropout seed of this pass (torch CPU RNG), 8-byte aligned
             np.asarray(inv, dtype=np.float32).view(np.int32),                            # 1/n_nonpad (fp32 bits), per task
-            np.zeros(head - 2 - nt, dtype=np.int32)] + klen_e + klen_d + keep_e + keep_d + firsts + nexts))
+            np.zeros(head - 2 - nt, dtype=np.int32)] + klen_e + klen_d + keep_e + keep_d + firsts + nexts)
+        n_meta = int(meta_np.shape[0])
         seq_in = torch.cat([io[0] for io in ios]) if nt > 1 else ios[0][0]
         seq_out = torch.cat([io[1] for io in ios]) if nt > 1 else ios[0][1]
         Bt = nt * B
-        # page-locked staging (two alternating buffers per slot, each guarded by an event): the uploads are truly asynchronous and
-        # the host never rewrites a staging buffer whose copy has not been consumed yet
-        dev_i32 = self.buf('meta_i32.%d' % slot, (meta_i32.numel(),), torch.int32)
+        # page-locked staging (a ring of STAGE_RING buffers per slot, each guarded by an event): the uploads are truly asynchronous
+        # and the host never rewrites a staging buffer whose copy has not been consumed yet.  The ring is deeper than the host may
+        # run ahead (pipeline depth + the iteration being resolved + 1), so the event wait never waits in the steady state.
+        dev_i32 = self.buf('meta_i32.%d' % slot, (n_meta,), torch.int32)
         ids = self.buf('ids.%d' % slot, (2, Bt, Td), torch.int64)
+        _trace.mark('prepare_numpy')
         turn = self._stage_turn.get(slot, 0)
-        self._stage_turn[slot] = turn ^ 1
-        key = (slot, turn, meta_i32.numel(), Bt, Td)
+        self._stage_turn[slot] = (turn + 1) % STAGE_RING
+        key = (slot, turn, n_meta, Bt, Td)
         st = self._stage.get(key)
         if st is None:
-            st = dict(i32=torch.empty(meta_i32.numel(), dtype=torch.int32).pin_memory(),
-                      ids=torch.empty((2, Bt, Td), dtype=torch.int64).pin_memory(), ev=torch.cuda.Event())
-            self._stage[key] = st
+            # first sight of this shape: the WHOLE ring at once (a page-locked allocation serialises against the device; it must
+            # not happen again three iterations later, inside somebody's timed region)
+            for r in range(STAGE_RING):
+                e = dict(i32=torch.empty(n_meta, dtype=torch.int32).pin_memory(),
+                         ids=torch.empty((2, Bt, Td), dtype=torch.int64).pin_memory(), ev=torch.cuda.Event())
+                e['i32_np'], e['ids_np'] = e['i32'].numpy(), e['ids'].numpy()        # views of the pinned memory
+                self._stage.setdefault((slot, r, n_meta, Bt, Td), e)
+            st = self._stage[key]
         else:
             st['ev'].synchronize()
-        st['i32'].copy_(meta_i32)
-        st['ids'][0].copy_(seq_in)
-        st['ids'][1].copy_(seq_out)
+        _trace.mark('stage_wait')
+        np.copyto(st['i32_np'], meta_np)
+        np.copyto(st['ids_np'][0], seq_in.numpy())
+        np.copyto(st['ids_np'][1], seq_out.numpy())
         dev_i32.copy_(st['i32'], non_blocking=True)
         ids.copy_(st['ids'], non_blocking=True)
         st['ev'].record(torch.cuda.current_stream(self.device))
+        _trace.mark('stage_upload')
         seed = dev_i32.data_ptr()
         inv_count = seed + 8
         klen_enc = seed + 4 * head

@@ -20,7 +20,7 @@ from collections import deque
 
 import torch
 
-from . import _lib, dist as mdist
+from . import _lib, _trace, dist as mdist, hostenv
 from .engine import PAD_ID, decoder_io
 from .functions import post_process, save_joint_model, save_meta_model
 from .metrics import calculate_cer, calculate_metrics
@@ -115,14 +115,19 @@ _PINNED = collections.OrderedDict()
 _PINNED_MAX = 512          # variable-length data brings new read-back shapes all the time: least recently used entries go
 
 
-def _pinned(key, shape, dtype):
+def _pinned(key, shape, dtype, turns=1):
     """Page-locked host buffer cached per (call site, shape): pin_memory() costs a host allocation + registration per call, and
-    the read-backs of one iteration are only consumed after that iteration's device sync, so the buffers can be re-used."""
+    the read-backs of one iteration are only consumed after that iteration's device sync, so the buffers can be re-used.
+    `key` ends with the index of the read-back set (`_turn`); on first sight of a (site, shape) the buffers of ALL `turns` sets are
+    allocated, so that no page-locked allocation (it serialises against the device) happens in a later iteration."""
     k = (key, tuple(shape), dtype)
     t = _PINNED.get(k)
     if t is None:
-        t = torch.empty(tuple(shape), dtype=dtype).pin_memory()
-        _PINNED[k] = t
+        for turn in range(turns):
+            kk = (key[:-1] + (turn,), tuple(shape), dtype) if turns > 1 else k
+            if kk not in _PINNED:
+                _PINNED[kk] = torch.empty(tuple(shape), dtype=dtype).pin_memory()
+        t = _PINNED[k]
         while len(_PINNED) > _PINNED_MAX:
             _PINNED.popitem(last=False)
     else:
@@ -156,10 +161,10 @@ class _Readback:
     """Asynchronous D2H of (gold, hyp, loss) of one forward; resolved after the iteration's single sync.  `key` names the
     call site (task index, pass) whose pinned buffers are re-used from iteration to iteration."""
 
-    def __init__(self, out, key):
+    def __init__(self, out, key, turns=1):
         self.gold_host = out['gold_host']
-        self.hyp = _pinned(('hyp', key), out['hyp'].shape, torch.int64)
-        self.loss = _pinned(('loss', key), (1,), torch.float32)
+        self.hyp = _pinned(('hyp',) + tuple(key), out['hyp'].shape, torch.int64, turns)
+        self.loss = _pinned(('loss',) + tuple(key), (1,), torch.float32, turns)
         self.hyp.copy_(out['hyp'], non_blocking=True)
         self.loss.copy_(out['loss'], non_blocking=True)
 
@@ -365,12 +370,16 @@ class TransientTrainer():
     def meta_iteration(self, model, vocab, task_batches, val_batch, n_tasks, inner, outer, args, task_ids=None):
         """task_batches: this rank's [(inputs, input_sizes, percentages, targets, target_sizes)], val_batch: same 5-tuple.
         n_tasks is the GLOBAL task count (the 1/n of the validation loss).  Leaves G in model._G; returns the read-backs.
+        With several ranks and chunking on, the schedules that hook the validation backward leave model._G ALREADY summed over
+        the ranks and set self._G_reduced (reset here on entry); a direct caller must check that flag -- or call
+        reduce_meta_gradient(), which does -- before posting a collective of its own.
 
         Tasks are independent given theta0, so they are dealt round-robin onto the model's task lanes (own stream, buffer
         arena, gradient / theta' / G buffers): one task's many small transformer kernels fill the CUs another task's
         convolutions leave idle.  Lane accumulators are summed in lane order, so G stays run-to-run deterministic."""
         dev = model.flat_parameters.device
         theta0 = model.flat_parameters
+        self._G_reduced = False
         smoothing = float(getattr(args, 'label_smoothing', 0.0) or 0.0)
         hooked = any(e.prof is not None or e.forward_hook is not None or e.after_conv_hook is not None for e in model.engines)
         use_graphs = self.use_graphs and not hooked
@@ -431,8 +440,8 @@ class TransientTrainer():
                     graph['x_tr'].copy_(tx, non_blocking=True)
                     graph['x_va'].copy_(vx, non_blocking=True)
                     graph['g'].replay()
-                reads[idx] = (_Readback(dict(gold_host=m_tr['gold_host'], hyp=slots['hyp_tr'], loss=slots['loss_tr']), (idx, 0, self._turn)),
-                              _Readback(dict(gold_host=m_va['gold_host'], hyp=slots['hyp_va'], loss=slots['loss_va']), (idx, 1, self._turn)))
+                reads[idx] = (_Readback(dict(gold_host=m_tr['gold_host'], hyp=slots['hyp_tr'], loss=slots['loss_tr']), (idx, 0, self._turn), self._turns()),
+                              _Readback(dict(gold_host=m_va['gold_host'], hyp=slots['hyp_va'], loss=slots['loss_va']), (idx, 1, self._turn), self._turns()))
         if streams[0] is not main:
             for lane in range(n_lanes):
                 done = torch.cuda.Event()
@@ -481,11 +490,14 @@ class TransientTrainer():
         g, theta1 = self._stack
         Xtr = eng.buf('tb.x_tr', (nt * B, 1, F, T))
         Xva = eng.buf('tb.x_va', tuple(vx_in.shape))
+        _trace.mark('setup')
         for t, (tx, _tsz, _tp, _ty, _tl) in enumerate(task_batches):
             Xtr[t * B:(t + 1) * B].copy_(tx, non_blocking=True)
         Xva.copy_(vx_in, non_blocking=True)
+        _trace.mark('input_copies')
         m_tr = eng.prepare_tasks([(tsz, ty) for (_tx, tsz, _tp, ty, _tl) in task_batches], B, T, slot=0)
         m_va = eng.prepare_tasks([(val_batch[1], val_batch[3])] * nt, vx_in.shape[0], vx_in.shape[3], slot=1)
+        _trace.mark('prepare_tasks')
         Bv = vx_in.shape[0]
         slots = dict(hyp_tr=eng.buf('slot.hyp_tr', (nt * B, m_tr['Td']), torch.int64), loss_tr=eng.buf('slot.loss_tr', (nt,)),
                      hyp_va=eng.buf('slot.hyp_va', (nt * Bv, m_va['Td']), torch.int64), loss_va=eng.buf('slot.loss_va', (nt,)))
@@ -517,17 +529,20 @@ class TransientTrainer():
         key = ('batched', nt, (B, F, T), tuple(vx_in.shape), m_tr['Td'], m_va['Td'], n_tasks, bool(args.clip), float(args.max_norm),
                smoothing, lr, theta0.data_ptr(), eng.dropout_p, g.data_ptr(), theta1.data_ptr(), G.data_ptr(),
                torch.cuda.current_stream(dev).cuda_stream, eng.use_side_stream, chunk is not None)
+        _trace.mark('keys')
         if use_cmdlists:
             self._run_recorded(key, eng, Xtr, Xva, body, on_break=chunk)
         else:
             body()
+        _trace.mark('launches')
         self._chunk_join(dev)
-        hyp_tr = _pinned(('tb.hyp', 0, self._turn), slots['hyp_tr'].shape, torch.int64)
-        hyp_va = _pinned(('tb.hyp', 1, self._turn), slots['hyp_va'].shape, torch.int64)
-        loss_tr = _pinned(('tb.loss', 0, self._turn), (nt,), torch.float32)
-        loss_va = _pinned(('tb.loss', 1, self._turn), (nt,), torch.float32)
+        hyp_tr = _pinned(('tb.hyp', 0, self._turn), slots['hyp_tr'].shape, torch.int64, self._turns())
+        hyp_va = _pinned(('tb.hyp', 1, self._turn), slots['hyp_va'].shape, torch.int64, self._turns())
+        loss_tr = _pinned(('tb.loss', 0, self._turn), (nt,), torch.float32, self._turns())
+        loss_va = _pinned(('tb.loss', 1, self._turn), (nt,), torch.float32, self._turns())
         for dst, src in ((hyp_tr, slots['hyp_tr']), (hyp_va, slots['hyp_va']), (loss_tr, slots['loss_tr']), (loss_va, slots['loss_va'])):
             dst.copy_(src, non_blocking=True)
+        _trace.mark('readback_copies')
         return [(_TaskRead(m_tr['gold_hosts'][t], hyp_tr[t * B:(t + 1) * B], loss_tr[t:t + 1]),
                  _TaskRead(m_va['gold_hosts'][t], hyp_va[t * Bv:(t + 1) * Bv], loss_va[t:t + 1])) for t in range(nt)]
 
@@ -537,7 +552,9 @@ class TransientTrainer():
         engine's main AND side stream -- forms that group's slice of G from the local gradients (accumulate_slice(first, count, raw
         stream)) and starts its all-reduce (dist.ChunkedAllReduce); _chunk_join() makes the main stream wait for all three before the
         outer step.  Fixed slice order on every rank: decoder, encoder, conv (the order the backward finishes them in)."""
-        if not mdist.chunked_on():
+        if not mdist.chunked_on() or eng.group_wgrads or eng.flush_delay:
+            # (grouped / held weight-gradient launches are issued after the hook points: their groups' slices would leave incomplete;
+            # the iteration then ends with the same three collectives in the same order, see reduce_meta_gradient)
             self._chunks = None
             return None
         dev = model.flat_parameters.device
@@ -651,7 +668,7 @@ class TransientTrainer():
             gold = torch.cat([metas[0][part]['gold_host'], metas[1][part]['gold_host']])
             hyp = torch.cat([slots[0][key_h], slots[1][key_h]])
             loss = slots[0][key_l] + slots[1][key_l]
-            reads.append(_Readback(dict(gold_host=gold, hyp=hyp, loss=loss), ('split', part, self._turn)))
+            reads.append(_Readback(dict(gold_host=gold, hyp=hyp, loss=loss), ('split', part, self._turn), self._turns()))
         return [tuple(reads)]
 
     def _task_body(self, model, lane, bufs, theta0, x_tr, m_tr, x_va, m_va, n_tasks, inner, args, smoothing, slots, chunk=None):
@@ -673,6 +690,10 @@ class TransientTrainer():
             eng.slice_hook = None
         if chunk is None:
             eng.axpy_(G, g, 1.0)                                         # add_copy_grad()         (:229)
+
+    def _turns(self):
+        """read-back buffer sets: one per iteration the host may have in flight (pipeline depth) + the one being resolved"""
+        return max(getattr(self, 'pipeline_depth', 1), 1) + 1
 
     def _slots(self, model, lane, m_tr, m_va):
         eng = model.engines[lane]
@@ -769,20 +790,42 @@ class TransientTrainer():
         single 12 ms task) runs under the next iteration's kernels.  Read-back buffers rotate through pipeline_depth + 1 sets (`_turn`)."""
         dev = model.flat_parameters.device
         t_host = time.perf_counter()
-        self._turn = (self._turn + 1) % (max(getattr(self, 'pipeline_depth', 1), 1) + 1)
+        _trace.begin()
+        self._turn = (self._turn + 1) % self._turns()
         outer_opt.zero_grad()
+        _trace.mark('zero_grad')
         self._G_reduced = False
         reads = self.meta_iteration(model, vocab, task_batches, val_data, n_tasks, inner_opt, outer_opt, args)
+        _trace.mark('meta_iteration_rest')
         G = model._G
         if not self._G_reduced:                                  # (already summed over the ranks group by group, under the backward: _chunk_hook)
-            mdist.allreduce_sum_(G)                              # the one collective of the path
+            self.reduce_meta_gradient(model)
         if args.clip:
             clip_flat_grad_(model, G, args.max_norm)             # (:253-254) on the summed meta-gradient
         outer_opt.step(G)                                        # from_copy_grad() + outer_opt.step()  (:248-255)
+        _trace.mark('allreduce_adam')
         done = torch.cuda.Event()
         done.record(torch.cuda.current_stream(dev))
+        _trace.mark('done_event')
+        _trace.end()
         self.host_enqueue_s = time.perf_counter() - t_host       # host side of the iteration (diagnostics: bench.py reports it)
         return PendingIteration(reads, done, vocab, dev)
+
+    def reduce_meta_gradient(self, model):
+        """The collective of the path for an iteration whose backward did not hand G's groups over as it went (several differently
+        shaped local tasks on lanes, no local task at all, the split-task schedule, hooks off).  Which schedule a rank takes depends
+        on ITS data, so the sequence of collectives must not: with chunking on, every rank always posts the same three all-reduces
+        (decoder, encoder, conv slices, the order _chunk_hook uses) -- here back to back on the current stream; with
+        MTL_CHUNKED_ALLREDUCE=0 every rank posts the single all-reduce of the whole flat buffer."""
+        G = model._G
+        if mdist.chunked_on():
+            bounds = model._layout.group_bounds()
+            for tag in mdist.SLICE_ORDER:
+                lo, hi = bounds[tag]
+                mdist.allreduce_sum_(G[lo:hi])
+        else:
+            mdist.allreduce_sum_(G)
+        self._G_reduced = True
 
     def run_iteration(self, model, vocab, task_batches, val_data, n_tasks, inner_opt, outer_opt, args):
         """The timed body of one meta-iteration, resolved: -> (sum val loss, CER edits, chars), global."""
@@ -799,6 +842,7 @@ class TransientTrainer():
         best_valid_val = 1000000000
         early_stop_criteria, early_stop_val = early_stop.split(',')[0], int(early_stop.split(',')[1])
         count_stop = 0
+        hostenv.bound_torch_threads()        # torch's CPU pool <= the CPUs this container may use (hostenv.py: quota throttling stalls the loop)
         logging.info('name ' + args.name)
         total_time = 0
         logging.info('TRAIN')
@@ -943,7 +987,7 @@ class JointTrainer():
         reads = []
         for (tx, tsz, _tp, ty, _tl) in task_batches:
             out = model.pass_forward(tx.to(dev, non_blocking=True), tsz, ty, smoothing=smoothing)
-            reads.append(_Readback(out, ('joint', len(reads))))
+            reads.append(_Readback(out, ('joint', len(reads), 0)))
             model.pass_backward(g, 1.0 / n_tasks)                       # (tr_loss / n).backward()
         mdist.allreduce_sum_(g)
         if args.clip:
@@ -966,6 +1010,7 @@ class JointTrainer():
         rank, world = mdist.rank(), mdist.world_size()
         if rank == 0:
             print('TRAIN')
+        hostenv.bound_torch_threads()
         model.train()
         opt = FlatAdam(model, args.lr)                                  # the reference builds a fresh Adam per train() call
         self.opt = opt

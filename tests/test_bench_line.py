@@ -1,0 +1,79 @@
+"""bench.py's stdout contract, checked without a GPU: the LAST stdout line is what the driver parses (round 4's 20 KB line came back
+as `parsed: null`), so it must stay small and round-trip through json; and every kernel class must be priced against the roof of the
+matrix instructions it actually issues."""
+import importlib.util
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def load_bench():
+    spec = importlib.util.spec_from_file_location('bench_under_test', os.path.join(ROOT, 'bench.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_bench_line_is_small_and_parseable():
+    bench = load_bench()
+    # a complete round-4 output (20 KB: per_class / per_family tables, notes) stands in for `out`
+    out = json.load(open(os.path.join(ROOT, 'profiles', 'r4', 'bench.json')))
+    assert len(json.dumps(out)) > 15000
+    out['host_enqueue_ms'] = dict(mean=4.61, median=4.6, max=9.87)
+    out['detail'] = 'gpurun_out/bench_detail.json'
+    text = json.dumps(bench.compact_line(out))
+    assert len(text) < bench.LINE_LIMIT, len(text)
+    line = json.loads(text)
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype',
+              'data', 'config', 'roofline', 'cpu_baseline', 'host_enqueue_ms'):
+        assert k in line, k
+    assert 'workload' in line['config'] and 'model' not in line['config']
+    for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
+        assert k in line['roofline'], k
+    assert abs(line['roofline']['frac'] - line['roofline']['achieved'] / line['roofline']['peak']) < 1e-3
+    for k in ('value', 'unit', 'cores', 'kind', 'sample'):
+        assert k in line['cpu_baseline'], k
+    assert 'per_class' not in line['roofline'] and 'per_family' not in line['roofline']
+    assert isinstance(line['with_h2d'], float) and isinstance(line['one_task_per_gpu_ms'], float)
+
+
+def test_emit_prints_one_short_line_last(capsys, tmp_path, monkeypatch):
+    bench = load_bench()
+    monkeypatch.setattr(bench, 'ROOT', str(tmp_path))
+    out = json.load(open(os.path.join(ROOT, 'profiles', 'r4', 'bench.json')))
+    out['roofline']['selection'] = 'x' * 6000           # a runaway note must not cost the line
+    out['config']['schedule'] = 'y' * 5000
+    bench.emit(out)
+    cap = capsys.readouterr()
+    lines = cap.out.strip().splitlines()
+    assert len(lines) == 1 and len(lines[0]) < bench.LINE_LIMIT
+    assert json.loads(lines[0])['value'] == round(out['value'], 4)
+    detail = json.load(open(tmp_path / 'gpurun_out' / 'bench_detail.json'))
+    assert 'per_class' in detail['roofline'] and 'per_family' in detail['roofline']
+    assert 'bench detail: ' in cap.err
+
+
+def test_every_class_is_priced_on_the_roof_of_its_instructions():
+    bench = load_bench()
+    x3, h2, f32 = bench.PEAK_X3_TFLOPS, bench.PEAK_H2_TFLOPS, bench.PEAK_F32_MFMA_TFLOPS
+    assert abs(x3 - 419.4) < 0.1 and abs(h2 - 838.9) < 0.1
+    # entry points on the bf16-triple instructions (six v_mfma_*_bf16 per fp32-equivalent step): the x3 GEMM engine and attention
+    for cls in ('gemm_x3', 'attn_fwd', 'attn_bwd'):
+        for conv_mode in ('h2', 'x3', 'f32'):
+            assert bench.peak_of(cls, 'flop', conv_mode, True)[0] == x3, cls
+    assert bench.peak_of('gemm_h2', 'flop', 'h2', True)[0] == h2
+    for cls in ('conv2_fwd_pool', 'conv5_fwd', 'conv7_dgrad', 'conv2_wgrad'):
+        assert bench.peak_of(cls, 'flop', 'h2', True)[0] == h2
+        assert bench.peak_of(cls, 'flop', 'x3', True)[0] == x3
+        assert bench.peak_of(cls, 'flop', 'f32', True)[0] == f32
+    assert bench.peak_of('conv5_wgrad', 'flop', 'h2', False)[0] == f32      # its dense form off: the fp32-MFMA weight gradient
+    for cls in ('gemm_small', 'gemm_big', 'gemm_wgrad_grouped', 'lstm_stack_fwd'):
+        assert bench.peak_of(cls, 'flop', 'h2', True)[0] == f32
+    for cls in ('layernorm_fwd', 'ce_fwd', 'colsum', 'adam_step', 'conv0_fwd'):
+        assert bench.peak_of(cls, 'byte', 'h2', True) == (bench.PEAK_HBM_GBS, 'GB/s', 'hbm')
+    # the classifier hands attention launches to those classes with the x3 kernel symbols
+    a = [0] * 22
+    a[8], a[10], a[11], a[12], a[13], a[14] = 0, 64, 8, 250, 250, 64
+    cls, flops, unit, sym = bench.classify(None, 'mtl_attn_fwd', a, 'h2', True)
+    assert cls == 'attn_fwd' and unit == 'flop' and flops == 2 * 2.0 * 64 * 8 * 250 * 250 * 64

@@ -156,3 +156,131 @@ def test_command_list_breaks_hand_control_back_between_segments():
     cl.run(seen.append)
     assert seen == ['decoder', 'encoder', 'conv'] and cl.n == 0
     cl.run()                                   # no callback: breaks are ignored
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the collective SEQUENCE must not depend on a rank's data: ranks whose local tasks take different schedules
+# ---------------------------------------------------------------------------------------------------------------------
+def _uneven_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    import types
+    import mtl_amd
+    from mtl_amd.engine import ParamLayout
+    mdist = mtl_amd.dist
+    mdist.init_from_env(backend='gloo')
+    # a flat layout with the three parameter groups in parameters() order (encoder | decoder | conv), odd sizes (16-byte padding)
+    layout = ParamLayout([('encoder.a.weight', (37, 5)), ('encoder.b.bias', (11,)), ('decoder.c.weight', (64, 9)), ('decoder.d.bias', (3,)),
+                          ('conv.0.weight', (8, 1, 3, 3)), ('conv.0.bias', (8,))])
+    bounds = layout.group_bounds()
+    assert sorted(bounds) == ['conv', 'decoder', 'encoder'] and bounds['encoder'][0] == 0 and bounds['conv'][1] == layout.total
+    assert bounds['encoder'][1] == bounds['decoder'][0] and bounds['decoder'][1] == bounds['conv'][0]
+    trainer = mtl_amd.TransientTrainer()
+    n_tasks = 3                                           # 3 tasks on 2 ranks: rank 0 owns {0, 2}, rank 1 owns {1}
+    mine = mdist.shard_tasks(n_tasks, rank, world)
+    gens = {m: torch.randn(layout.total, generator=torch.Generator().manual_seed(50 + m)) for m in range(n_tasks)}
+    for chunked in ('1', '0'):
+        os.environ['MTL_CHUNKED_ALLREDUCE'] = chunked
+        model = types.SimpleNamespace(_G=torch.zeros(layout.total), _layout=layout)
+        for m in mine:
+            model._G += gens[m]
+        trainer._G_reduced = False
+        if rank == 1 and chunked == '1':
+            # this rank's single task ran the hooked schedule: its backward handed the slices over one by one (_chunk_hook)
+            ch = mdist.ChunkedAllReduce()
+            for tag in mdist.SLICE_ORDER:
+                lo, hi = bounds[tag]
+                ch.issue(model._G[lo:hi])
+            ch.wait()
+            trainer._G_reduced = True
+        if not trainer._G_reduced:
+            # rank 0 (two differently shaped tasks -> lanes, no hook) and every rank with chunking off: the end-of-iteration form
+            trainer.reduce_meta_gradient(model)
+        assert trainer._G_reduced
+        want = gens[0] + gens[1] + gens[2]
+        ret[(rank, chunked)] = float((model._G - want).abs().max() / want.abs().max())
+    # a rank with NO local task posts the same sequence (zeros): 1 task on 2 ranks
+    os.environ['MTL_CHUNKED_ALLREDUCE'] = '1'
+    model = types.SimpleNamespace(_G=gens[0].clone() if rank == 0 else torch.zeros(layout.total), _layout=layout)
+    trainer.reduce_meta_gradient(model)
+    ret[(rank, 'idle')] = bool(torch.equal(model._G, gens[0]))
+    mdist.barrier()
+
+
+def test_collective_sequence_is_rank_invariant_with_uneven_shards():
+    """3 tasks on 2 ranks with different schedules per rank (one rank hooked its backward and posted the three slice collectives as it
+    went, the other finished first and reduces at the end): every rank must post the SAME three all-reduces (decoder, encoder, conv),
+    or the single one with MTL_CHUNKED_ALLREDUCE=0.  With round 4's code rank 0 posted one 56 MB collective against rank 1's three
+    slices (size mismatch / deadlock); a hang here fails by the spawn timeout."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    ctx = mp.spawn(_uneven_worker, args=(2, 29621, ret), nprocs=2, join=False)
+    import time
+    t0 = time.time()
+    while not ctx.join(timeout=5):
+        assert time.time() - t0 < 120, 'ranks posted different collective sequences (deadlock)'
+    for rank in (0, 1):
+        assert ret[(rank, '1')] < 1e-6 and ret[(rank, '0')] < 1e-6 and ret[(rank, 'idle')], dict(ret)
+
+
+def _world4_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    import types
+    import mtl_amd
+    from mtl_amd.engine import ParamLayout
+    from oracle import refimpl as R
+    mdist = mtl_amd.dist
+    mdist.init_from_env(backend='gloo')
+    z, cfg, spec = gu.load('F0')
+    n_tasks, k, T, L, alpha = 8, 2, 64, 8, spec['lr']
+    model = R.build_model(cfg)                                   # same seed on every rank: replicas start identical
+    layout = ParamLayout([(nm, p.shape) for nm, p in model.named_parameters()])
+    params = list(model.parameters())
+    adam = R.AdamState(params, 1e-3)
+    mine = mdist.shard_tasks(n_tasks, rank, world)
+    assert len(mine) == 2
+    trainer = mtl_amd.TransientTrainer()
+    worst, same = 0.0, True
+
+    def to_flat(grads):
+        out = torch.zeros(layout.total)
+        for nm, g in zip(layout.order, grads):
+            layout.view(out, nm).copy_(g)
+        return out
+
+    for it in range(3):
+        tr = [R.synth_batch(1000 * it + 10 * m, k, T, L, cfg['vocab_size'], True) for m in range(n_tasks)]
+        val = R.synth_batch(1000 * it + 10 * (n_tasks - 1) + 1, k, T, L, cfg['vocab_size'], True)     # the LAST task's validation batch, shared
+        G = torch.zeros(layout.total)
+        for m in mine:                                           # local part of G with the GLOBAL 1/n (what a GPU rank accumulates)
+            g_m, _, _, _ = R.meta_gradient(model, [tr[m]], val, alpha)                  # (n = 1 inside)
+            pred, gold, _ = model(*tr[m])
+            g_tr = torch.autograd.grad(R.ce_loss(pred, gold), params)
+            G += to_flat([a + (b - a) / n_tasks for a, b in zip(g_tr, g_m)])
+        fake = types.SimpleNamespace(_G=G, _layout=layout)
+        trainer.reduce_meta_gradient(fake)                       # the three slice collectives, SLICE_ORDER
+        if rank == 0:
+            G_ref, _, _, _ = R.meta_gradient(model, tr, val, alpha)                     # sequential accumulation m = 0..7
+            ref = to_flat(G_ref)
+            worst = max(worst, float((G - ref).norm() / ref.norm()))
+        adam.step(params, [layout.view(G, nm) for nm in layout.order])                  # replicated, deterministic outer step
+        bits = to_flat([p.detach() for p in params]).view(torch.int32).to(torch.int64)
+        chk = torch.stack([bits.sum(), (bits * torch.arange(1, bits.numel() + 1)).sum()])
+        lo, hi = chk.clone(), chk.clone()
+        torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
+        torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
+        same = same and bool(torch.equal(lo, hi))
+    ret[rank] = (worst, same)
+    mdist.barrier()
+
+
+def test_world4_two_tasks_per_rank_three_iterations():
+    """BASELINE.json configs[2] partitioning at world 4 (8 tasks, 2 per rank; SURVEY 8(e), transient_trainer.py:168-169,178-237): the
+    sliced all-reduce of the local sums equals the sequential accumulation over m = 0..7 within 1e-6, and after each of three
+    replicated Adam steps every rank holds the same parameter BITS."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_world4_worker, args=(4, 29623, ret), nprocs=4, join=True)
+    assert ret[0][0] < 1e-6, ret[0]
+    assert all(ret[r][1] for r in range(4)), dict(ret)
