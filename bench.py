@@ -348,6 +348,7 @@ def serial_profile(mtl, trainer, model, vocab, tasks, my_tasks, n_tasks, inner, 
 
 HOST_ENQUEUE = {}
 HOST = {}
+PER_RANK = {}
 
 
 TRACE = [] if os.environ.get('MTL_BENCH_TRACE') else None      # diagnostics: (seconds into the timed span, host enqueue ms) per step, to stderr
@@ -423,9 +424,12 @@ def timed_steps(trainer, model, vocab, tasks, my_tasks, n_tasks, inner, outer, a
     mdist.barrier()
     dt = time.perf_counter() - t0
     if mdist.world_size() > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t)
+        # MAX over the ranks is the step time; every rank's own figure (its local tasks + its wait for the collective) is reported too
+        mine = torch.tensor([dt], dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(mine) for _ in range(mdist.world_size())]
+        torch.distributed.all_gather(every, mine)
+        PER_RANK['ms_per_step'] = [round(float(v) / steps * 1e3, 3) for v in every]
+        dt = max(float(v) for v in every)
     return dt, last
 
 
@@ -686,6 +690,17 @@ def main():
     # (bit-level fingerprint of theta after the timed steps: tests compare schedules / collectives that must not change a single bit)
     th = model.flat_parameters
     theta_ck = [float(th.double().sum()), int(th.view(torch.int32).to(torch.int64).sum())]
+    multi = None
+    if world > 1:
+        # self-check of a sharded run (the first SCALE run must be readable without a debugger): the rank count the process group
+        # reports, the backend ("nccl" = RCCL), every rank's own step time, and that the replicas hold the same parameter BITS
+        ck = torch.tensor([theta_ck[1]], dtype=torch.int64, device=dev)
+        lo, hi = ck.clone(), ck.clone()
+        torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
+        torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
+        multi = dict(ranks=torch.distributed.get_world_size(), collective=mdist.backend_name(), chunked_allreduce=mdist.chunked_on(),
+                     allreduce_bytes_per_step=4 * model._layout.total, tasks_per_rank=[len(mdist.shard_tasks(a.tasks, r, world)) for r in range(world)],
+                     per_rank_ms_per_step=PER_RANK.get('ms_per_step'), replicas_bit_identical=bool(int(lo) == int(hi)))
     # ---- serial profiling step (every rank runs it: it contains the collective; only rank 0 reports)
     classes, n_launch, serial_wall = serial_profile(mtl_amd, trainer, model, vocab, tasks, my_tasks, a.tasks, inner, outer, args, dev)
     out = None
@@ -777,7 +792,7 @@ def main():
                                         % (a.tasks, len(my_tasks), a.k, a.frames, a.labels),
                                setup='%d untimed iterations before the warm-up (buffer pool and read-back buffer allocation, command-list recording)' % n_setup,
                                tasks=a.tasks, k_train=a.k, src_frames=a.frames, tgt_len=a.labels, parallelism='task-sharded dp%d' % world,
-                               collective=mdist.backend_name(), inputs='resident in HBM before the timed region',
+                               collective=mdist.backend_name(), ranks=world, inputs='resident in HBM before the timed region',
                                schedule=('serial, ' if a.serial else '') + (
                                    'the %d local tasks as ONE task-batched pass per phase (training passes at theta0, validation passes at the theta\' stack)'
                                    % len(my_tasks) if (trainer.batch_tasks and len(my_tasks) > 1) else '%d task lanes' % model.n_lanes) + (
@@ -789,7 +804,7 @@ def main():
                                                 'x3': '3x3 convolutions as exact 3-way bf16 splits of fp32 operands, fp32 accumulate '
                                                       '(fp32-class error, same test tolerances as the fp32-MFMA kernels)',
                                                 'f32': 'fp32 MFMA'}[model.engine.conv_mode]),
-                   roofline=roofline, host_enqueue_ms=host_stats, host=dict(HOST), last_step=dict(val_loss=last[0] / a.tasks, cer_edits=last[1], chars=last[2]), theta_checksum=theta_ck)
+                   roofline=roofline, host_enqueue_ms=host_stats, host=dict(HOST), **({'multi_gpu': multi} if multi else {}), last_step=dict(val_loss=last[0] / a.tasks, cer_edits=last[1], chars=last[2]), theta_checksum=theta_ck)
 
     extras = world == 1 and not a.no_extras
     if extras:
@@ -807,9 +822,17 @@ def main():
             out['configs1_3task'] = dict(value=k3 / dt3, unit='meta-steps/s', ms_per_step=dt3 / k3 * 1e3,
                                          note='README-faithful: 3 tasks on one GPU, dropout 0 (parity setting)')
         # what ONE rank of the 8-GPU configuration runs per step: a single task, a single lane (no collective on one rank)
-        dt1, _ = timed_steps(trainer, model, vocab, tasks[:1], [0], a.tasks, inner, outer, args, 2 * k3, 3, mdist, dev)
-        out['one_task_per_gpu'] = dict(ms_per_step=dt1 / (2 * k3) * 1e3, note='1 of %d tasks on this GPU (configs[2] per-rank work, '
-                                       'without the all-reduce): its two passes are sequential, only the side stream overlaps' % a.tasks)
+        one = {}
+        for name, lanes in (('unsplit', 0), ('split2', 2), ('split4', 4)):
+            tr1 = mtl_amd.TransientTrainer()
+            tr1.split_single_task, tr1.split_lanes = lanes > 0, max(lanes, 2)
+            dt1, _ = timed_steps(tr1, model, vocab, tasks[:1], [0], a.tasks, inner, outer, args, 2 * k3, 4, mdist, dev)
+            one[name] = dt1 / (2 * k3) * 1e3
+        default = 'split%d' % trainer.split_lanes if trainer.split_single_task else 'unsplit'
+        out['one_task_per_gpu'] = dict(ms_per_step=one.get(default, one['unsplit']), schedule=default, by_schedule=one,
+                                       note='1 of %d tasks on this GPU (configs[2] per-rank work, without the all-reduce); unsplit: the two '
+                                            'passes as one chain + side stream; splitN: every pass split by samples over N lanes, one command '
+                                            'list (TransientTrainer._single_task_split)' % a.tasks)
         # the README trains with --dropout 0.1: same 8-task workload with the Philox dropout active
         model.encoder.dropout_rate = model.decoder.dropout_rate = 0.1
         model.train()
@@ -900,7 +923,7 @@ def compact_line(out):
             line[k] = _r(out[k]['value'], 3)
     if 'one_task_per_gpu' in out:
         line['one_task_per_gpu_ms'] = _r(out['one_task_per_gpu']['ms_per_step'], 3)
-    for k in ('last_step', 'theta_checksum', 'detail'):
+    for k in ('multi_gpu', 'last_step', 'theta_checksum', 'detail'):
         if k in out:
             line[k] = out[k]
     return line

@@ -353,9 +353,6 @@ class PassEngine:
             # staging of shapes that are gone: rebuilt on demand
             self._wgrad_tables.clear()
             self._ln_tables.clear()
-            if len(self._stage) > 64 * STAGE_RING:
-                self._stage.clear()
-                self._stage_turn.clear()
             self.arena = {k: v for k, v in self.arena.items() if not isinstance(v, torch.Tensor) or k == '_scratch'}
             self.scratch_epoch += 1
         return freed
@@ -1028,27 +1025,33 @@ class PassEngine:
         dev_i32 = self.buf('meta_i32.%d' % slot, (n_meta,), torch.int32)
         ids = self.buf('ids.%d' % slot, (2, Bt, Td), torch.int64)
         _trace.mark('prepare_numpy')
+        # the ring holds raw pinned bytes sized for the largest batch seen so far (grown geometrically, the whole ring at once: a
+        # page-locked allocation serialises against the device, so variable-length data must not bring one per new shape, and none
+        # may happen a few iterations later inside somebody's timed region)
+        need = 4 * n_meta + 16 + 16 * Bt * Td
+        ring = self._stage.get(slot)
+        if ring is None or ring[0]['raw'].numel() < need:
+            cap = max(need + need // 2, 1 << 16)
+            ring = [dict(raw=torch.empty(cap, dtype=torch.uint8).pin_memory(), ev=None) for _ in range(STAGE_RING)]
+            self._stage[slot] = ring           # (an old ring's blocks return to torch's pinned allocator once their copies have completed)
+            self._stage_turn[slot] = 0
         turn = self._stage_turn.get(slot, 0)
         self._stage_turn[slot] = (turn + 1) % STAGE_RING
-        key = (slot, turn, n_meta, Bt, Td)
-        st = self._stage.get(key)
-        if st is None:
-            # first sight of this shape: the WHOLE ring at once (a page-locked allocation serialises against the device; it must
-            # not happen again three iterations later, inside somebody's timed region)
-            for r in range(STAGE_RING):
-                e = dict(i32=torch.empty(n_meta, dtype=torch.int32).pin_memory(),
-                         ids=torch.empty((2, Bt, Td), dtype=torch.int64).pin_memory(), ev=torch.cuda.Event())
-                e['i32_np'], e['ids_np'] = e['i32'].numpy(), e['ids'].numpy()        # views of the pinned memory
-                self._stage.setdefault((slot, r, n_meta, Bt, Td), e)
-            st = self._stage[key]
+        st = ring[turn]
+        if st['ev'] is None:
+            st['ev'] = torch.cuda.Event()
         else:
             st['ev'].synchronize()
+        off_ids = (4 * n_meta + 15) // 16 * 16
+        st_i32 = st['raw'][:4 * n_meta].view(torch.int32)
+        st_ids = st['raw'][off_ids:off_ids + 16 * Bt * Td].view(torch.int64).view(2, Bt, Td)
+        i32_np, ids_np = st_i32.numpy(), st_ids.numpy()          # views of the pinned memory
         _trace.mark('stage_wait')
-        np.copyto(st['i32_np'], meta_np)
-        np.copyto(st['ids_np'][0], seq_in.numpy())
-        np.copyto(st['ids_np'][1], seq_out.numpy())
-        dev_i32.copy_(st['i32'], non_blocking=True)
-        ids.copy_(st['ids'], non_blocking=True)
+        np.copyto(i32_np, meta_np)
+        np.copyto(ids_np[0], seq_in.numpy())
+        np.copyto(ids_np[1], seq_out.numpy())
+        dev_i32.copy_(st_i32, non_blocking=True)
+        ids.copy_(st_ids, non_blocking=True)
         st['ev'].record(torch.cuda.current_stream(self.device))
         _trace.mark('stage_upload')
         seed = dev_i32.data_ptr()

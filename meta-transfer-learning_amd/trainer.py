@@ -116,23 +116,26 @@ _PINNED_MAX = 512          # variable-length data brings new read-back shapes al
 
 
 def _pinned(key, shape, dtype, turns=1):
-    """Page-locked host buffer cached per (call site, shape): pin_memory() costs a host allocation + registration per call, and
-    the read-backs of one iteration are only consumed after that iteration's device sync, so the buffers can be re-used.
-    `key` ends with the index of the read-back set (`_turn`); on first sight of a (site, shape) the buffers of ALL `turns` sets are
-    allocated, so that no page-locked allocation (it serialises against the device) happens in a later iteration."""
-    k = (key, tuple(shape), dtype)
-    t = _PINNED.get(k)
-    if t is None:
+    """Page-locked host buffer of a read-back call site: pin_memory() costs a host allocation + registration that serialises against
+    the device, and the read-backs of one iteration are only consumed after that iteration's device sync, so the memory is re-used.
+    `key` ends with the index of the read-back set (`_turn`).  The cache holds RAW bytes per (site, set), sized for the largest shape
+    seen so far and grown geometrically for ALL `turns` sets at once: variable-length data brings a new shape with almost every batch
+    and must not bring a page-locked allocation with it, and none may happen a few iterations later inside a timed region."""
+    shape = tuple(int(v) for v in shape)
+    nbytes = torch.empty((), dtype=dtype).element_size()
+    for v in shape:
+        nbytes *= v
+    raw = _PINNED.get(key)
+    if raw is None or raw.numel() < nbytes:
+        cap = max(nbytes + nbytes // 2, 256)
         for turn in range(turns):
-            kk = (key[:-1] + (turn,), tuple(shape), dtype) if turns > 1 else k
-            if kk not in _PINNED:
-                _PINNED[kk] = torch.empty(tuple(shape), dtype=dtype).pin_memory()
-        t = _PINNED[k]
+            _PINNED[(key[:-1] + (turn,)) if turns > 1 else key] = torch.empty(cap, dtype=torch.uint8).pin_memory()
+        raw = _PINNED[key]
         while len(_PINNED) > _PINNED_MAX:
             _PINNED.popitem(last=False)
     else:
-        _PINNED.move_to_end(k)
-    return t
+        _PINNED.move_to_end(key)
+    return raw[:nbytes].view(dtype).view(shape)
 
 
 class PendingIteration:
@@ -175,6 +178,18 @@ class _TaskRead:
 
     def __init__(self, gold_host, hyp, loss):
         self.gold_host, self.hyp, self.loss = gold_host, hyp, loss
+
+
+class _SplitRead:
+    """Read-backs of a pass that ran in parts on several lanes: the loss of the batch is the sum of the parts' (each normalised by
+    the WHOLE batch's token count)."""
+
+    def __init__(self, gold_host, hyp, part_losses):
+        self.gold_host, self.hyp, self._parts = gold_host, hyp, part_losses
+
+    @property
+    def loss(self):
+        return [float(self._parts.sum())]
 
 
 def _strings(vocab, rows):
@@ -332,6 +347,7 @@ class TransientTrainer():
         # a rank with a single task can split its batch over the two lanes (_single_task_split; exact, tested) -- measured no
         # faster than the unsplit task (18.4 vs 18.7 ms per 1-task step, slower with dropout), so it is opt-in
         self.split_single_task = os.environ.get('MTL_SPLIT_TASK', '0') == '1'
+        self.split_lanes = int(os.environ.get('MTL_SPLIT_LANES', '2'))
         self._graphs = {}
         # the local tasks of a meta-step as ONE task-batched pass per phase (training passes at theta0, validation passes at the
         # theta' stack) instead of one pass chain per task on concurrent lanes; MTL_BATCH_TASKS=0: the lanes
@@ -342,6 +358,8 @@ class TransientTrainer():
         # from the device): 1 hides the host's per-iteration work, 2 also rides out host stalls of up to one iteration's GPU time
         # (shared hosts: measured enqueue times of 5 - 90 ms for the same iteration).  Read-back buffer sets: depth + 1.
         self.pipeline_depth = max(1, int(os.environ.get('MTL_PIPELINE_DEPTH', '2'))) if self.pipeline else 0
+        # batches handed over in host memory are uploaded on a separate stream, one iteration ahead of the kernels (task-batched passes)
+        self.overlap_uploads = os.environ.get('MTL_OVERLAP_UPLOADS', '1') != '0'
         self._turn = 0
 
     # ------------------------------------------------------------------ drop-in single-batch API
@@ -387,7 +405,7 @@ class TransientTrainer():
         if (len(task_batches) == 1 and model.n_lanes >= 2 and self.split_single_task and not use_graphs
                 and task_batches[0][0].shape[0] >= 2 and val_batch[0].shape[0] >= 2
                 and not any(e.prof is not None for e in model.engines)):
-            return self._single_task_split(model, task_batches[0], val_batch, n_tasks, inner, args)
+            return self._single_task_split(model, task_batches[0], val_batch, n_tasks, inner, args, use_cmdlists)
         if self._can_batch(model, task_batches, val_batch, use_graphs):
             return self._batched_iteration(model, task_batches, val_batch, n_tasks, inner, args, smoothing, use_cmdlists)
         n_lanes = min(model.n_lanes, max(len(task_batches), 1))
@@ -488,12 +506,47 @@ class TransientTrainer():
             self._stack = (torch.zeros(nt * total, dtype=torch.float32, device=dev), torch.empty(nt * total, dtype=torch.float32, device=dev))
             self._stack_key = key_b
         g, theta1 = self._stack
+        # The passes read their inputs from two STATIC buffers (recorded command lists hold their addresses, and addresses derived
+        # from them per task).  Inputs that arrive in HOST memory (the reference uploads every batch inside its timed span,
+        # transient_trainer.py:182-184,210-212) go up on their own stream into one of two landing sets, so the copy engine moves
+        # iteration i + 1's batches under iteration i's kernels (the host enqueues ahead); the main stream waits for the set's `ready`
+        # event and moves it into the static buffers with one device copy each (~20 us).  A landing set is rewritten only after that
+        # device copy has run (`_xfree`).  Device-resident inputs are copied straight into the static buffers.
+        main = torch.cuda.current_stream(dev)
         Xtr = eng.buf('tb.x_tr', (nt * B, 1, F, T))
         Xva = eng.buf('tb.x_va', tuple(vx_in.shape))
         _trace.mark('setup')
-        for t, (tx, _tsz, _tp, _ty, _tl) in enumerate(task_batches):
-            Xtr[t * B:(t + 1) * B].copy_(tx, non_blocking=True)
-        Xva.copy_(vx_in, non_blocking=True)
+        on_host = not vx_in.is_cuda or any(not tb[0].is_cuda for tb in task_batches)
+        if on_host and self.overlap_uploads:
+            xs = self._xset = (getattr(self, '_xset', 0) + 1) % 2
+            if getattr(self, '_upload_stream', None) is None:
+                self._upload_stream, self._xfree = torch.cuda.Stream(dev), {}
+            Ltr = eng.buf('tb.land_tr.%d' % xs, (nt * B, 1, F, T))
+            Lva = eng.buf('tb.land_va.%d' % xs, tuple(vx_in.shape))
+            up = self._upload_stream
+            with torch.cuda.stream(up):
+                free = self._xfree.get((xs, Ltr.data_ptr(), Lva.data_ptr()))
+                if free is not None:
+                    up.wait_event(free)
+                else:
+                    up.wait_stream(main)                 # first use of this set: behind whatever produced / last used the memory
+                    Ltr.record_stream(up)                # (the pool may hand the block back to torch's allocator one day)
+                    Lva.record_stream(up)
+                for t, (tx, _tsz, _tp, _ty, _tl) in enumerate(task_batches):
+                    Ltr[t * B:(t + 1) * B].copy_(tx, non_blocking=True)
+                Lva.copy_(vx_in, non_blocking=True)
+                ready = torch.cuda.Event()
+                ready.record(up)
+            main.wait_event(ready)
+            Xtr.copy_(Ltr, non_blocking=True)
+            Xva.copy_(Lva, non_blocking=True)
+            free = torch.cuda.Event()
+            free.record(main)
+            self._xfree = {(xs, Ltr.data_ptr(), Lva.data_ptr()): free, **{k_: v_ for k_, v_ in self._xfree.items() if k_[0] != xs}}
+        else:
+            for t, (tx, _tsz, _tp, _ty, _tl) in enumerate(task_batches):
+                Xtr[t * B:(t + 1) * B].copy_(tx, non_blocking=True)
+            Xva.copy_(vx_in, non_blocking=True)
         _trace.mark('input_copies')
         m_tr = eng.prepare_tasks([(tsz, ty) for (_tx, tsz, _tp, ty, _tl) in task_batches], B, T, slot=0)
         m_va = eng.prepare_tasks([(val_batch[1], val_batch[3])] * nt, vx_in.shape[0], vx_in.shape[3], slot=1)
@@ -546,13 +599,16 @@ class TransientTrainer():
         return [(_TaskRead(m_tr['gold_hosts'][t], hyp_tr[t * B:(t + 1) * B], loss_tr[t:t + 1]),
                  _TaskRead(m_va['gold_hosts'][t], hyp_va[t * Bv:(t + 1) * Bv], loss_va[t:t + 1])) for t in range(nt)]
 
-    def _chunk_hook(self, model, eng, accumulate_slice):
+    def _chunk_hook(self, model, eng, accumulate_slice, lanes=None):
         """-> callable(tag) for PassEngine.slice_hook (None when the meta-gradient is not all-reduced in chunks).  At the point where
         the validation backward has enqueued the last kernel of a parameter group, the hook -- on the communication stream, behind the
         engine's main AND side stream -- forms that group's slice of G from the local gradients (accumulate_slice(first, count, raw
         stream)) and starts its all-reduce (dist.ChunkedAllReduce); _chunk_join() makes the main stream wait for all three before the
-        outer step.  Fixed slice order on every rank: decoder, encoder, conv (the order the backward finishes them in)."""
-        if not mdist.chunked_on() or eng.group_wgrads or eng.flush_delay:
+        outer step.  Fixed slice order on every rank: decoder, encoder, conv (the order the backward finishes them in).
+        lanes: [(stream, engine)] when the pass is split over several lanes (_split_iteration): every lane's backward calls the hook,
+        the slice leaves once ALL of them have (the communication stream then waits for every lane's main and side stream)."""
+        engs = [eng] if lanes is None else [e for _s, e in lanes]
+        if not mdist.chunked_on() or any(e.group_wgrads or e.flush_delay for e in engs):
             # (grouped / held weight-gradient launches are issued after the hook points: their groups' slices would leave incomplete;
             # the iteration then ends with the same three collectives in the same order, see reduce_meta_gradient)
             self._chunks = None
@@ -565,12 +621,23 @@ class TransientTrainer():
             raise RuntimeError('unexpected parameter groups %s' % sorted(bounds))
         self._chunks = mdist.ChunkedAllReduce()
         G, comm = model._G, self._comm_stream
+        seen = {}
 
         def hook(tag):
             lo, hi = bounds[tag]
-            comm.wait_stream(torch.cuda.current_stream(dev))
-            if eng.side is not None:
-                comm.wait_stream(eng.side)
+            if lanes is None:
+                comm.wait_stream(torch.cuda.current_stream(dev))
+                if eng.side is not None:
+                    comm.wait_stream(eng.side)
+            else:
+                seen[tag] = seen.get(tag, 0) + 1
+                if seen[tag] < len(lanes):
+                    return                                   # another lane's backward has not enqueued this group yet
+                seen[tag] = 0
+                for st_, e_ in lanes:
+                    comm.wait_stream(st_)
+                    if e_.side is not None:
+                        comm.wait_stream(e_.side)
             with torch.cuda.stream(comm):
                 accumulate_slice(lo, hi - lo, comm.cuda_stream)
                 self._chunks.issue(G[lo:hi])
@@ -586,89 +653,120 @@ class TransientTrainer():
         self._chunks = None
         self._G_reduced = True
 
-    def _single_task_split(self, model, task, val_batch, n_tasks, inner, args):
-        """A rank that holds ONE task (8 tasks on 8 GPUs) would leave the second lane idle, and the task's own chain
-        (training pass -> theta' -> validation pass) is sequential.  No op of the network couples samples except the loss
-        normaliser, so each pass is split by samples over the two lanes (same 1/n_tokens of the WHOLE batch in both halves):
-        g = g_a + g_b before the clip / inner step, G = G_a + G_b at the end.  Equal to the unsplit step up to fp32 summation
-        order, deterministic run to run."""
+    def _single_task_split(self, model, task, val_batch, n_tasks, inner, args, use_cmdlists=False):
+        """A rank that holds ONE task (8 tasks on 8 GPUs): the task's own chain (training pass -> theta' -> validation pass) is
+        sequential and its ~210 transformer launches per pass are latency-bound at 8 samples.  No op of the network couples samples
+        except the loss normaliser, so each pass is split by samples over `split_lanes` lanes (own stream, engine and side stream; the
+        same 1/n_tokens of the WHOLE batch in every part): g = sum of the parts before the clip / inner step, G = sum of the lanes'
+        accumulators at the end, or -- several ranks -- slice by slice under the validation backward (_chunk_hook(lanes=...)).
+        Equal to the unsplit step up to fp32 summation order, deterministic run to run.  Everything between the input copies and the
+        read-backs is library calls with explicit streams and events, so the whole step is recorded into ONE command list and
+        replayed from C (the eager form needs ~1400 ctypes calls per step and was host-bound)."""
         dev = model.flat_parameters.device
         theta0 = model.flat_parameters
         smoothing = float(getattr(args, 'label_smoothing', 0.0) or 0.0)
-        bufs = self._lane_buffers(model, 2)
-        main = torch.cuda.current_stream(dev)
-        streams = [model.lane_streams[0], model.lane_streams[1]]
+        lib = _lib.lib()
         tx, tsz, _tp, ty, _tl = task
         vx, vsz, _vp, vy, _vl = val_batch
-        tx = tx.to(dev, non_blocking=True)
-        vx = vx.to(dev, non_blocking=True)
-        ready = torch.cuda.Event()
-        ready.record(main)
+        L = max(2, min(int(self.split_lanes), model.n_lanes, tx.shape[0], vx.shape[0]))
+        engs, streams = model.engines[:L], model.lane_streams[:L]
+        main = torch.cuda.current_stream(dev)
+        total = model._layout.total
+        key_b = (id(theta0), L)
+        if getattr(self, '_split_key', None) != key_b:
+            self._split_bufs = (torch.zeros(L * total, dtype=torch.float32, device=dev), torch.empty(total, dtype=torch.float32, device=dev))
+            self._split_key = key_b
+        g_stack, theta1 = self._split_bufs
+        g = [g_stack[l * total:(l + 1) * total] for l in range(L)]
+        e0 = engs[0]
+        # static input buffers (the recorded calls hold their addresses), filled on the main stream
+        Xtr = e0.buf('sp.x_tr', tuple(tx.shape))
+        Xva = e0.buf('sp.x_va', tuple(vx.shape))
+        Xtr.copy_(tx, non_blocking=True)
+        Xva.copy_(vx, non_blocking=True)
 
-        def halves(x, sz, y):
-            h = x.shape[0] // 2
+        def parts(x, sz, y):
+            n = x.shape[0]
+            cuts = [(n * l) // L for l in range(L + 1)]
             seq_out = decoder_io(y)[1]
-            total, width = int((seq_out != PAD_ID).sum()), seq_out.shape[1]  # non-pad targets / decoder width of the WHOLE batch
-            return [(x[sl], sz[sl], y[sl], total, width) for sl in (slice(0, h), slice(h, x.shape[0]))]
-        tr, va = halves(tx, tsz, ty), halves(vx, vsz, vy)
+            tokens, width = int((seq_out != PAD_ID).sum()), seq_out.shape[1]  # non-pad targets / decoder width of the WHOLE batch
+            return [(x[a:b], sz[a:b], y[a:b], tokens, width) for a, b in zip(cuts[:-1], cuts[1:])]
+        tr, va = parts(Xtr, tsz, ty), parts(Xva, vsz, vy)
         metas, slots = [], []
-        for lane in range(2):
-            eng = model.engines[lane]
-            with torch.cuda.stream(streams[lane]):
-                streams[lane].wait_event(ready)
-                bufs[lane][2].zero_()
-                m_tr = eng.prepare(tr[lane][1], tr[lane][2], tr[lane][0].shape[0], tx.shape[3], slot=0, norm_count=tr[lane][3],
-                                   width=tr[lane][4])
-                m_va = eng.prepare(va[lane][1], va[lane][2], va[lane][0].shape[0], vx.shape[3], slot=1, norm_count=va[lane][3],
-                                   width=va[lane][4])
-                metas.append((m_tr, m_va))
-                slots.append(self._slots(model, lane, m_tr, m_va))
-        # ---- training pass, one half per lane
-        for lane in range(2):
-            eng, (g, _t1, _G) = model.engines[lane], bufs[lane]
-            with torch.cuda.stream(streams[lane]):
-                g.zero_()
-                out = eng.forward_device(theta0, tr[lane][0], metas[lane][0], smoothing)
-                slots[lane]['hyp_tr'].copy_(out['hyp'])
-                slots[lane]['loss_tr'].copy_(out['loss'])
-                eng.backward(g, 1.0)
-        # ---- join: g = g_a + g_b on lane 0, clip, theta'; lane 1 restarts its accumulator for the validation half
-        ev = torch.cuda.Event()
-        ev.record(streams[1])
-        g0, theta1, _ = bufs[0]
-        with torch.cuda.stream(streams[0]):
-            streams[0].wait_event(ev)
-            model._axpy(g0, bufs[1][0], 1.0)
-            if args.clip:
-                clip_flat_grad_(model, g0, args.max_norm, lane=0)
-            inner.theta_prime_from(theta0, g0, out=theta1)
-            ev2 = torch.cuda.Event()
-            ev2.record(streams[0])
-        with torch.cuda.stream(streams[1]):
-            streams[1].wait_event(ev2)
-            bufs[1][0].zero_()
-        # ---- validation pass at theta', one half per lane; Q1: the validation gradient accumulates onto g
-        for lane in range(2):
-            eng, (g, _t1, G) = model.engines[lane], bufs[lane]
-            with torch.cuda.stream(streams[lane]):
-                out = eng.forward_device(theta1, va[lane][0], metas[lane][1], smoothing)
-                slots[lane]['hyp_va'].copy_(out['hyp'])
-                slots[lane]['loss_va'].copy_(out['loss'])
-                eng.backward(g, 1.0 / n_tasks)
-                model._axpy(G, g, 1.0)
-        for lane in range(2):
-            done = torch.cuda.Event()
-            done.record(streams[lane])
-            main.wait_event(done)
-        Gm = model._G
-        Gm.copy_(bufs[0][2])
-        model._axpy(Gm, bufs[1][2], 1.0)
+        for l in range(L):              # (uploads of the per-part integers: on the main stream, the lanes start behind `ready`)
+            m_tr = engs[l].prepare(tr[l][1], tr[l][2], tr[l][0].shape[0], tx.shape[3], slot=0, norm_count=tr[l][3], width=tr[l][4])
+            m_va = engs[l].prepare(va[l][1], va[l][2], va[l][0].shape[0], vx.shape[3], slot=1, norm_count=va[l][3], width=va[l][4])
+            metas.append((m_tr, m_va))
+            slots.append(self._slots(model, l, m_tr, m_va))
+        G = model._G
+        lr = float(inner.param_groups[0]['lr'])
+        chunk = self._chunk_hook(model, e0, lambda lo, n, st: check(
+            lib.mtl_sum_tasks_strided(st, G.data_ptr() + 4 * lo, g_stack.data_ptr() + 4 * lo, n, L, total, 0), 'mtl_sum_tasks_strided'),
+            lanes=list(zip(streams, engs)))
+        raw = [s_.cuda_stream for s_ in streams]
+
+        def body(_xa=None, _xb=None):
+            rec, wait = e0.lib.mtl_event_record, e0.lib.mtl_stream_wait_event       # (through the Recorder while recording)
+            ev = e0._event()
+            check(rec(ev, main.cuda_stream), 'mtl_event_record')
+            for l in range(L):
+                check(wait(raw[l], ev), 'mtl_stream_wait_event')
+            for l in range(L):                                                   # ---- training pass, one part per lane
+                with torch.cuda.stream(streams[l]):
+                    engs[l].zero_(g[l])
+                    engs[l].forward_device(theta0, tr[l][0], metas[l][0], smoothing, hyp_out=slots[l]['hyp_tr'], loss_out=slots[l]['loss_tr'])
+                    engs[l].backward(g[l], 1.0)
+            for l in range(1, L):                                                # ---- join on lane 0: g = sum of the parts, clip, theta'
+                ev = engs[l]._event()
+                check(rec(ev, raw[l]), 'mtl_event_record')
+                check(wait(raw[0], ev), 'mtl_stream_wait_event')
+            with torch.cuda.stream(streams[0]):
+                for l in range(1, L):
+                    e0.axpy_(g[0], g[l], 1.0)
+                if args.clip:
+                    clip_flat_grad_(model, g[0], args.max_norm, lane=0)
+                e0.sgd_theta_prime(theta0, g[0], lr, theta1)
+            ev = e0._event()
+            check(rec(ev, raw[0]), 'mtl_event_record')
+            for l in range(1, L):
+                check(wait(raw[l], ev), 'mtl_stream_wait_event')
+                with torch.cuda.stream(streams[l]):
+                    engs[l].zero_(g[l])                                          # the other lanes' accumulators restart (lane 0's holds g_tr: Q1)
+            for l in range(L):                                                   # ---- validation pass at theta', one part per lane
+                with torch.cuda.stream(streams[l]):
+                    engs[l].forward_device(theta1, va[l][0], metas[l][1], smoothing, hyp_out=slots[l]['hyp_va'], loss_out=slots[l]['loss_va'])
+                    engs[l].slice_hook = chunk
+                    try:
+                        engs[l].backward(g[l], 1.0 / n_tasks)
+                    finally:
+                        engs[l].slice_hook = None
+            for l in range(L):                                                   # ---- the main stream continues behind every lane
+                ev = engs[l]._event()
+                check(rec(ev, raw[l]), 'mtl_event_record')
+                check(wait(main.cuda_stream, ev), 'mtl_stream_wait_event')
+            if chunk is None:
+                check(e0.lib.mtl_sum_tasks(main.cuda_stream, G.data_ptr(), g_stack.data_ptr(), total, L, 0), 'mtl_sum_tasks')
+
+        key = ('split', L, tuple(tx.shape), tuple(vx.shape), tuple(m[0]['Td'] for m in metas), tuple(m[1]['Td'] for m in metas), n_tasks,
+               bool(args.clip), float(args.max_norm), smoothing, lr, theta0.data_ptr(), e0.dropout_p, g_stack.data_ptr(), theta1.data_ptr(),
+               G.data_ptr(), main.cuda_stream, tuple(raw), tuple(e.use_side_stream for e in engs), chunk is not None)
+        if use_cmdlists:
+            self._run_recorded(key, engs, None, None, body, on_break=chunk)
+        else:
+            body()
+        self._chunk_join(dev)
         reads = []
         for part, key_h, key_l in ((0, 'hyp_tr', 'loss_tr'), (1, 'hyp_va', 'loss_va')):
-            gold = torch.cat([metas[0][part]['gold_host'], metas[1][part]['gold_host']])
-            hyp = torch.cat([slots[0][key_h], slots[1][key_h]])
-            loss = slots[0][key_l] + slots[1][key_l]
-            reads.append(_Readback(dict(gold_host=gold, hyp=hyp, loss=loss), ('split', part, self._turn), self._turns()))
+            rows = [slots[l][key_h].shape[0] for l in range(L)]
+            hyp = _pinned(('sp.hyp', part, self._turn), (sum(rows), slots[0][key_h].shape[1]), torch.int64, self._turns())
+            loss = _pinned(('sp.loss', part, self._turn), (L,), torch.float32, self._turns())
+            a = 0
+            for l in range(L):
+                hyp[a:a + rows[l]].copy_(slots[l][key_h], non_blocking=True)
+                loss[l:l + 1].copy_(slots[l][key_l], non_blocking=True)
+                a += rows[l]
+            gold = torch.cat([metas[l][part]['gold_host'] for l in range(L)])
+            reads.append(_SplitRead(gold, hyp, loss))
         return [tuple(reads)]
 
     def _task_body(self, model, lane, bufs, theta0, x_tr, m_tr, x_va, m_va, n_tasks, inner, args, smoothing, slots, chunk=None):
@@ -703,7 +801,11 @@ class TransientTrainer():
     def _run_recorded(self, key, eng, tx, vx, body, on_break=None):
         """Command-list execution of a task body.  First sighting of a key: plain eager run (it also brings every arena buffer to
         its final size); second sighting: eager run through a Recorder that logs the calls; afterwards: the two input pointers
-        are re-pointed to this task's batches and the recorded calls are replayed by mtl_cmdlist_run."""
+        are re-pointed to this task's batches and the recorded calls are replayed by mtl_cmdlist_run.
+        eng: one engine, or the list of engines of a body that spans several lanes (ONE list holds all their calls, each with its
+        own stream); tx = vx = None: the body reads static input buffers, nothing is re-pointed."""
+        engs = list(eng) if isinstance(eng, (list, tuple)) else [eng]
+        epoch_now = lambda: tuple(e.scratch_epoch for e in engs)
         ent = self._cmdlists.get(key)
         if ent is None:
             while len(self._cmdlists) >= 64:              # least recently used key goes (variable-length data: keys rarely repeat)
@@ -711,23 +813,27 @@ class TransientTrainer():
             self._cmdlists[key] = 'warm'
             return body(tx, vx)
         self._cmdlists[key] = self._cmdlists.pop(key)     # most recently used: to the end
-        if ent != 'warm' and ent['epoch'] != eng.scratch_epoch:
-            ent = 'warm'                                  # the engine's scratch buffer moved since the recording
+        if ent != 'warm' and ent['epoch'] != epoch_now():
+            ent = 'warm'                                  # an engine's scratch buffer moved since the recording
         if ent == 'warm':
-            if tx.data_ptr() == vx.data_ptr():
+            if tx is not None and tx.data_ptr() == vx.data_ptr():
                 return body(tx, vx)                       # the two inputs must be distinguishable by address to be re-pointed
             cl = _lib.CommandList()
-            real, epoch = eng.lib, eng.scratch_epoch
-            eng.lib = _lib.Recorder(real, cl)
+            reals, epoch = [e.lib for e in engs], epoch_now()
+            recorder = _lib.Recorder(reals[0], cl)
+            for e in engs:
+                e.lib = recorder
             try:
                 body(tx, vx)
             finally:
-                eng.lib = real
-            if eng.scratch_epoch == epoch:                # (a buffer that moved during the run would leave stale addresses)
-                self._cmdlists[key] = dict(cl=cl.finish(), x_tr=tx.data_ptr(), x_va=vx.data_ptr(), epoch=epoch)
+                for e, real in zip(engs, reals):
+                    e.lib = real
+            if epoch_now() == epoch:                      # (a buffer that moved during the run would leave stale addresses)
+                self._cmdlists[key] = dict(cl=cl.finish(), x_tr=tx.data_ptr() if tx is not None else None,
+                                           x_va=vx.data_ptr() if vx is not None else None, epoch=epoch)
             return
         cl = ent['cl']
-        if ent['x_tr'] != tx.data_ptr() or ent['x_va'] != vx.data_ptr():
+        if tx is not None and (ent['x_tr'] != tx.data_ptr() or ent['x_va'] != vx.data_ptr()):
             tmp = 8                                       # two-step re-pointing through a dummy value: the batches may swap addresses
             cl.repoint(ent['x_tr'], tmp)
             cl.repoint(ent['x_va'], vx.data_ptr())

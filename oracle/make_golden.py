@@ -421,11 +421,36 @@ def run_lm_fixture(torch):
     print('L0 written: loss %.6f, %d parameters' % (float(loss), len(names)))
 
 
+def frontend_waveform(seed=7, n=8037):
+    """seeded test waveform of the S0 fixture (two tones, a chirp and noise; 0.5 s + 37 samples at 16 kHz)"""
+    rng = np.random.RandomState(seed)
+    t = np.arange(n) / 16000.0
+    return (0.3 * np.sin(2 * np.pi * 440 * t) + 0.2 * np.sin(2 * np.pi * 3100 * t * (1 + 0.1 * t)) + 0.05 * rng.randn(n)).astype(np.float32)
+
+
+def run_frontend_fixture():
+    """S0: output of oracle/frontend.py (NOT of the reference: librosa is absent here) on a seeded waveform.  It
+    pins the restatement -- and through tests/test_ops_gpu.py the device front-end -- against drift; the row stays "parity unpinned"."""
+    from oracle import frontend
+    y = frontend_waveform()
+    store = {'note': np.array('oracle/frontend.py restating librosa.stft(n_fft=320, hop_length=160, win_length=320, window=scipy.signal.hamming, '
+                              'center=True, pad_mode=reflect) -> abs -> log1p -> (x - mean) / std  (utils/data_loader.py:65-96); generated WITHOUT '
+                              'librosa: parity unpinned'),
+             'seed': np.array([7, 8037]), 'waveform': y,
+             'spect_raw': frontend.parse_audio(y, normalize=False).numpy(), 'spect_norm': frontend.parse_audio(y, normalize=True).numpy()}
+    np.savez_compressed(os.path.join(ROOT, 'tests', 'golden', 'S0.npz'), **store)
+    print('S0 written: spectrogram', store['spect_norm'].shape)
+
+
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--ns', action='store_true')
     ap.add_argument('--only', default='')
     a = ap.parse_args()
+    if a.only == 'S0':
+        sys.path.insert(0, ROOT)
+        run_frontend_fixture()
+        raise SystemExit(0)
     torch = bootstrap_reference()
     todo = [a.only] if a.only else (['F0', 'F1', 'J0', 'B0', 'G0'] + (['NS'] if a.ns else []) + ['L0'])
     for name in todo:

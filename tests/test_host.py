@@ -234,6 +234,21 @@ def test_frontend_oracle_is_the_textbook_stft():
     assert abs(float(sp.mean())) < 1e-5 and abs(float(sp.std()) - 1.0) < 1e-5
 
 
+def test_frontend_oracle_reproduces_its_committed_fixture():
+    """tests/golden/S0.npz (oracle/make_golden.py --only S0): the front-end restatement on a seeded waveform.  Generated without
+    librosa (absent here), so SURVEY 8(f) f1 stays parity-unpinned; the fixture stops the restatement -- and, in the GPU test, the
+    device front-end -- from drifting."""
+    from oracle import frontend
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'S0.npz'))
+    assert 'parity unpinned' in str(z['note']) and 'librosa.stft' in str(z['note'])
+    y = z['waveform']
+    assert y.dtype == np.float32 and y.shape == (int(z['seed'][1]),)
+    for key, norm in (('spect_raw', False), ('spect_norm', True)):
+        got = frontend.parse_audio(y, normalize=norm).numpy()
+        assert got.shape == z[key].shape == (161, 1 + y.size // 160)
+        assert np.abs(got - z[key]).max() <= 2e-6 * np.abs(z[key]).max()
+
+
 REF = '/root/reference'
 
 

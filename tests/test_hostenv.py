@@ -65,7 +65,7 @@ def test_enqueue_path_staging_is_numpy_only():
     enqueue path must fill its pinned staging through numpy views (engine.prepare_tasks); pin the source so it stays that way."""
     src = open(os.path.join(ROOT, 'meta-transfer-learning_amd', 'engine.py')).read()
     body = src[src.index('def prepare_tasks'):src.index('def forward(self, theta')]
-    assert "np.copyto(st['i32_np'], meta_np)" in body and "st['i32'].copy_(" not in body and "st['ids'][0].copy_(" not in body
+    assert "np.copyto(i32_np, meta_np)" in body and "st_i32.copy_(" not in body and "st_ids[0].copy_(" not in body
     # and numpy views of a torch tensor alias its memory (what the staging relies on)
     t = torch.zeros(8, dtype=torch.int32)
     np.copyto(t.numpy(), np.arange(8, dtype=np.int32))

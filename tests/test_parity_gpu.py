@@ -557,9 +557,10 @@ def test_single_task_split_over_lanes_equals_unsplit(B, variable):
     for split in (False, True, True):
         tr = mtl_amd.TransientTrainer()
         tr.split_single_task = split
+        tr.use_cmdlists = False
         reads = tr.meta_iteration(model, vocab, task, val, 3, inner, None, args)
         torch.cuda.synchronize()
-        res.setdefault(split, []).append((model._G.clone(), [(r.loss.clone(), r.hyp.clone(), r.gold_host.clone()) for r in reads[0]]))
+        res.setdefault(split, []).append((model._G.clone(), [(torch.as_tensor(r.loss).clone(), r.hyp.clone(), r.gold_host.clone()) for r in reads[0]]))
     (G0, r0), (G1, r1), (G2, r2) = res[False][0], res[True][0], res[True][1]
     assert torch.equal(G1, G2)                                       # deterministic
     for (l0, h0, g0), (l1, h1, g1) in zip(r0, r1):
@@ -568,6 +569,28 @@ def test_single_task_split_over_lanes_equals_unsplit(B, variable):
     rel = float((G1 - G0).norm() / G0.norm())
     print('split vs unsplit: global rel %.2e' % rel)
     assert rel < 1e-4
+    # the recorded form (what runs by default: ONE command list holds the calls of all lanes, with their streams and the cross-lane
+    # events): eager, recording and two replays reproduce the eager split step bit for bit
+    tr = mtl_amd.TransientTrainer()
+    tr.split_single_task, tr.use_cmdlists = True, True
+    for rep in range(4):
+        reads = tr.meta_iteration(model, vocab, task, val, 3, inner, None, args)
+        torch.cuda.synchronize()
+        assert torch.equal(model._G, G1), rep
+        for r, (l1, h1, g1) in zip(reads[0], r1):
+            assert torch.equal(r.hyp, h1) and float(r.loss[0]) == float(l1)
+    recorded = [v for v in tr._cmdlists.values() if isinstance(v, dict)]
+    assert len(recorded) == 1 and recorded[0]['cl'].n > 200
+    if B >= 4:                                                       # four lanes: same contract
+        tr4 = mtl_amd.TransientTrainer()
+        tr4.split_single_task, tr4.split_lanes = True, 4
+        outs = []
+        for rep in range(3):
+            tr4.meta_iteration(model, vocab, task, val, 3, inner, None, args)
+            torch.cuda.synchronize()
+            outs.append(model._G.clone())
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+        assert float((outs[0] - G0).norm() / G0.norm()) < 1e-4
 
 
 @pytest.mark.parametrize('B,T,L,lens,tlens', [

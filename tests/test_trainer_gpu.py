@@ -320,6 +320,36 @@ def test_host_one_iteration_ahead_is_bitwise_equal(capsys):
         assert torch.equal(out[False][1], out[True][1])
 
 
+def test_uploads_on_their_own_stream_are_bitwise_equal():
+    """Batches handed over in (pinned) host memory go up on a separate stream into alternating input sets, one iteration ahead of
+    the kernels (TransientTrainer._batched_iteration, transient_trainer.py:182-184,210-212 are inside the reference's span): theta and
+    the per-iteration results after 6 pipelined iterations equal those of the in-stream upload (MTL_OVERLAP_UPLOADS=0 behaviour) and
+    those of device-resident inputs, bit for bit -- also across the eager / recording / replay transitions of the command list."""
+    z, cfg, spec = gu.load('F0')
+    out = {}
+    for mode in ('resident', 'in_stream', 'overlapped'):
+        mtl_amd, args, vocab, model = make(cfg, spec, name='upl')
+        model = model.cuda()
+        inner, outer = mtl_amd.FlatSGD(model, spec['lr']), mtl_amd.FlatAdam(model, 1e-3)
+        model.zero_copy_grad()
+        tr = mtl_amd.TransientTrainer()
+        tr.overlap_uploads = mode == 'overlapped'
+        place = (lambda x: x.cuda()) if mode == 'resident' else (lambda x: x.pin_memory())
+        pending, results = [], []
+        for it in range(6):
+            b = [mtl_amd.synth_batch(100 * it + m, 2, 64, 8, cfg['vocab_size'], variable=True) for m in range(4)]
+            as5 = lambda q: (place(q[0]), q[1], None, q[2], None)
+            pending.append(tr.enqueue_iteration(model, vocab, [as5(q) for q in b[:3]], as5(b[3]), 3, inner, outer, args))
+            while len(pending) > tr.pipeline_depth:
+                results.append(pending.pop(0).result())
+        results += [p.result() for p in pending]
+        torch.cuda.synchronize()
+        out[mode] = (results, model.flat_parameters.detach().cpu().clone())
+    for mode in ('in_stream', 'overlapped'):
+        assert out[mode][0] == out['resident'][0], mode
+        assert torch.equal(out[mode][1], out['resident'][1]), mode
+
+
 def test_variable_length_batches_keep_the_buffer_pool_and_the_command_lists_bounded():
     """Real manifests bring a new (frames, label width) with almost every batch (collate pads to the batch maximum).  The engines'
     buffer pool is LRU-trimmed against a byte budget and the trainer's command-list / read-back caches are bounded: twelve
