@@ -483,13 +483,45 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ l
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int row = blockIdx.x;
     const float* x = logits + (long)row * ld;
+    // The row is read ONCE, as 16-byte quads from the 16-byte boundary at or below its first element (rows of V = 3765 floats start at
+    // every alignment), and kept in registers (up to 4 quads per thread: V <= 4093) for the second sweep; quads that straddle the
+    // row's end are read element by element (nothing beyond the caller's buffer is touched; elements before the row belong to the
+    // previous row of the same buffer).  Longer rows take the two-sweep scalar form.
+    const int mis = (int)((reinterpret_cast<uintptr_t>(x) >> 2) & 3);
+    const int nq = (V + mis + 3) >> 2;
+    const bool fast = nq <= 4 * 256 && !(reinterpret_cast<uintptr_t>(logits) & 3);
+    float4 q[4];
     float mx = -INFINITY;
     int arg = 0x7fffffff;
-    for (int j = tid; j < V; j += 256) {
-        const float v = x[j];
-        if (v > mx) {
-            mx = v;
-            arg = j;
+    if (fast) {
+        const float* xa = x - mis;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int v = tid + 256 * i, e0 = 4 * v - mis;       // first element (row index) of quad v
+            float4 t = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+            if (v < nq) {
+                if (e0 >= 0 && e0 + 3 < V) {
+                    t = *reinterpret_cast<const float4*>(xa + 4 * v);
+                } else {
+                    if (e0 >= 0 && e0 < V) t.x = x[e0];
+                    if (e0 + 1 >= 0 && e0 + 1 < V) t.y = x[e0 + 1];
+                    if (e0 + 2 >= 0 && e0 + 2 < V) t.z = x[e0 + 2];
+                    if (e0 + 3 >= 0 && e0 + 3 < V) t.w = x[e0 + 3];
+                }
+            }
+            q[i] = t;
+            if (t.x > mx) { mx = t.x; arg = e0; }                // ascending index within the thread: ties keep the lowest
+            if (t.y > mx) { mx = t.y; arg = e0 + 1; }
+            if (t.z > mx) { mx = t.z; arg = e0 + 2; }
+            if (t.w > mx) { mx = t.w; arg = e0 + 3; }
+        }
+    } else {
+        for (int j = tid; j < V; j += 256) {
+            const float v = x[j];
+            if (v > mx) {
+                mx = v;
+                arg = j;
+            }
         }
     }
 #pragma unroll
@@ -516,10 +548,19 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ l
         }
     }
     float s = 0.f, sx = 0.f;
-    for (int j = tid; j < V; j += 256) {
-        const float v = x[j];
-        s += expf(v - mx);
-        sx += v;
+    if (fast) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                             // (elements outside the row hold -inf: exp -> 0, excluded from sx)
+            const float4 t = q[i];
+            s += (expf(t.x - mx) + expf(t.y - mx)) + (expf(t.z - mx) + expf(t.w - mx));
+            sx += ((t.x > -INFINITY ? t.x : 0.f) + (t.y > -INFINITY ? t.y : 0.f)) + ((t.z > -INFINITY ? t.z : 0.f) + (t.w > -INFINITY ? t.w : 0.f));
+        }
+    } else {
+        for (int j = tid; j < V; j += 256) {
+            const float v = x[j];
+            s += expf(v - mx);
+            sx += v;
+        }
     }
     s = wave_sum(s);
     sx = wave_sum(sx);
@@ -615,6 +656,56 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     __syncthreads();
     if (wv == 0 && c < cols) part[(long)blockIdx.y * cols + c] = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
     if (AMAX && threadIdx.x == 0) pmax[(long)blockIdx.y * gridDim.x + blockIdx.x] = fmaxf(fmaxf(shm[0], shm[1]), fmaxf(shm[2], shm[3]));
+}
+// The same stage 1 for contiguous rows of 4 C4 columns (C4 a power of two <= 64: the conv bias gradients, 64 / 128 channels): a
+// thread owns one 16-byte column quad and every (256 / C4)-th row of the chunk, four rows in flight per thread (the scalar form
+// above keeps two 4-byte loads in flight: 1.9 TB/s on the 41 MB conv7 bias sum).  Fixed assignment and order: deterministic.
+template <bool AMAX>
+__global__ __launch_bounds__(256) void colsum_partial_vec_kernel(const float4* __restrict__ X, long rows, int C4, long rows_per_block,
+                                                                 float* __restrict__ part, float* __restrict__ pmax) {
+    __shared__ float4 sh[256];
+    __shared__ float shm[4];
+    const int tid = threadIdx.x, q = tid & (C4 - 1), ph = tid / C4, nph = 256 / C4;
+    const long r0 = (long)blockIdx.y * rows_per_block;
+    long r1 = r0 + rows_per_block;
+    if (r1 > rows) r1 = rows;
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+    float mx = 0.f;
+    long r = r0 + ph;
+    for (; r + 3L * nph < r1; r += 4L * nph) {
+        const float4 v0 = X[r * C4 + q], v1 = X[(r + nph) * C4 + q], v2 = X[(r + 2L * nph) * C4 + q], v3 = X[(r + 3L * nph) * C4 + q];
+        a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+        a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+        a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
+        a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
+        if (AMAX) {
+            mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(fabsf(v0.x), fabsf(v0.y)), fmaxf(fabsf(v0.z), fabsf(v0.w))),
+                                 fmaxf(fmaxf(fabsf(v1.x), fabsf(v1.y)), fmaxf(fabsf(v1.z), fabsf(v1.w)))));
+            mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(fabsf(v2.x), fabsf(v2.y)), fmaxf(fabsf(v2.z), fabsf(v2.w))),
+                                 fmaxf(fmaxf(fabsf(v3.x), fabsf(v3.y)), fmaxf(fabsf(v3.z), fabsf(v3.w)))));
+        }
+    }
+    for (; r < r1; r += nph) {
+        const float4 v0 = X[r * C4 + q];
+        a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+        if (AMAX) mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v0.x), fabsf(v0.y)), fmaxf(fabsf(v0.z), fabsf(v0.w))));
+    }
+    sh[tid] = make_float4((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y), (a0.z + a1.z) + (a2.z + a3.z), (a0.w + a1.w) + (a2.w + a3.w));
+    if (AMAX) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        if ((tid & 63) == 0) shm[tid >> 6] = mx;
+    }
+    __syncthreads();
+    if (tid < C4) {
+        float4 t = sh[tid];
+        for (int p = 1; p < nph; ++p) {
+            const float4 u = sh[p * C4 + tid];
+            t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+        }
+        reinterpret_cast<float4*>(part + (long)blockIdx.y * (4 * C4))[tid] = t;
+    }
+    if (AMAX && tid == 0) pmax[blockIdx.y] = fmaxf(fmaxf(shm[0], shm[1]), fmaxf(shm[2], shm[3]));
 }
 // 16 waves per column block: the tall conv-bias sums leave ~1000 partial rows, which 4 waves walked in 126 us
 __global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restrict__ part, int nblk, int cols, float* __restrict__ out,
@@ -1369,11 +1460,21 @@ int mtl_colsum_accum(void* stream, const float* X, long rows, int cols, long ld,
     hipStream_t s = as_stream(stream);
     const int cb = (cols + 63) / 64;
     float* pmax = workspace + colsum_chunks(rows, cols) * cols;
-    if (amax)
+    const int c4 = cols / 4;
+    const bool vec = ld == cols && cols % 4 == 0 && c4 <= 64 && (c4 & (c4 - 1)) == 0 && !(reinterpret_cast<uintptr_t>(X) & 15) &&
+                     !(reinterpret_cast<uintptr_t>(workspace) & 15);
+    int npmax = (int)(nblk * cb);
+    if (vec) {
+        npmax = (int)nblk;
+        if (amax)
+            hipLaunchKernelGGL(colsum_partial_vec_kernel<true>, dim3(1, (unsigned)nblk), dim3(256), 0, s, reinterpret_cast<const float4*>(X), rows, c4, rpb, workspace, pmax);
+        else
+            hipLaunchKernelGGL(colsum_partial_vec_kernel<false>, dim3(1, (unsigned)nblk), dim3(256), 0, s, reinterpret_cast<const float4*>(X), rows, c4, rpb, workspace, pmax);
+    } else if (amax)
         hipLaunchKernelGGL(colsum_partial_kernel<true>, dim3(cb, (unsigned)nblk), dim3(256), 0, s, X, rows, cols, ld, rpb, workspace, pmax);
     else
         hipLaunchKernelGGL(colsum_partial_kernel<false>, dim3(cb, (unsigned)nblk), dim3(256), 0, s, X, rows, cols, ld, rpb, workspace, pmax);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(cb), dim3(1024), 0, s, workspace, (int)nblk, cols, out, pmax, (int)(nblk * cb), amax);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cb), dim3(1024), 0, s, workspace, (int)nblk, cols, out, pmax, npmax, amax);
     MTL_CHECK_LAUNCH();
     return MTL_OK;
 }

@@ -607,6 +607,43 @@ def test_embed_and_ce(L):
     assert rel(dlog[:, :V], lr_.grad) < 1e-5
 
 
+@pytest.mark.parametrize('V,ld,rows', [(3765, 3765, 37), (5, 5, 9), (64, 67, 11), (1000, 1000, 13), (4093, 4093, 6), (4094, 4096, 5), (5000, 5003, 7)])
+def test_ce_forward_row_widths_and_alignments(L, V, ld, rows):
+    """ce_fwd_kernel reads a row once, as 16-byte quads from the aligned address below its first element (rows start at every
+    alignment when ld % 4 != 0), up to 4093 logits; longer rows take the two-sweep form.  lse / loss (with label smoothing: the sum
+    over the row) against fp64, arg-max bit-exact with lowest-index ties, at every row alignment, with a buffer that ENDS at the
+    last logit (nothing beyond it may be read)."""
+    g = torch.Generator().manual_seed(V + ld)
+    flat = torch.randn(rows * ld - (ld - V), generator=g)                    # the buffer ends with the last valid logit of the last row
+    pad = torch.cat([flat, torch.zeros(ld - V)]).view(rows, ld)
+    logits = pad[:, :V].clone()
+    logits[1] = 0.0                                                          # a zeroed (padded) row: every logit ties
+    if V > 4:
+        logits[2, V - 1] = logits[2, 3] = logits[2].max() + 1.0              # a tie between the last element and an early one
+    flat[:] = torch.cat([logits, torch.zeros(rows, ld - V)], 1).reshape(-1)[:flat.numel()]
+    gold = torch.randint(1, V, (rows,), generator=g)
+    gold[1] = 0
+    dflat, dgold = dev(flat), gold.cuda()
+    for smoothing in (0.0, 0.1):
+        lse, hyp = torch.empty(rows).cuda(), torch.empty(rows, dtype=torch.int64).cuda()
+        rowloss, loss = torch.empty(rows).cuda(), torch.empty(1).cuda()
+        nn_ = int((gold != 0).sum())
+        assert L.mtl_ce_argmax_fwd(st(), dflat.data_ptr(), dgold.data_ptr(), rows, V, ld, 0, smoothing, nn_, None, lse.data_ptr(),
+                                   hyp.data_ptr(), rowloss.data_ptr(), loss.data_ptr()) == 0
+        l64 = logits.double()
+        lse_ref = torch.logsumexp(l64, 1)
+        assert float((lse.cpu().double() - lse_ref).abs().max()) < 2e-6 * float(lse_ref.abs().max())
+        hyp_ref = torch.stack([(row == row.max()).nonzero()[0, 0] for row in logits])       # lowest index of the maximum
+        assert torch.equal(hyp.cpu(), hyp_ref)
+        assert int(hyp[1]) == 0 and (V <= 4 or int(hyp[2]) == 3)
+        logp = l64 - lse_ref[:, None]
+        nll = -logp.gather(1, gold[:, None]).squeeze(1)
+        ref = ((1 - smoothing) * nll + smoothing / V * (-logp.sum(1) - nll)) if smoothing else nll
+        ref = torch.where(gold != 0, ref, torch.zeros_like(ref))
+        assert float((rowloss.cpu().double() - ref).abs().max()) < 5e-6 * float(ref.abs().max())
+        assert abs(float(loss) - float(ref.sum() / nn_)) < 5e-6 * float(ref.sum() / nn_)
+
+
 def test_flat_updates_colsum_permute(L):
     g = torch.Generator().manual_seed(9)
     n = 100003
@@ -900,6 +937,22 @@ def test_absmax_and_colsum_amax(L):
     assert L.mtl_colsum_accum(st(), dX.data_ptr(), 3000, 128, 128, out.data_ptr(), ws.data_ptr(), slot[2048:].data_ptr()) == 0
     assert float(slot[:2048].max()) == 9.5 and bool((slot[2048::32] == 9.5).all())
     assert rel(out, X.sum(0)) < 1e-5
+    # the 16-byte form (contiguous rows of 4 x 2^k columns: the conv bias gradients) at the north-star extent of conv.7.bias, a ragged
+    # row count, with and without the max|X| by-product, accumulating onto `out`; and shapes that stay on the scalar form
+    for rows, cols, with_amax in ((80000, 128, True), (77777, 64, False), (1003, 256, True), (4999, 16, False), (3000, 100, False), (3000, 192, True)):
+        X = torch.randn(rows, cols, generator=g)
+        X[rows // 3, cols // 2] = 11.25
+        dX = dev(X)
+        out = torch.full((cols,), 2.0).cuda()
+        am = torch.zeros(2048).cuda()
+        ws = torch.empty(L.mtl_colsum_workspace(rows, cols) // 4).cuda()
+        assert L.mtl_colsum_accum(st(), dX.data_ptr(), rows, cols, cols, out.data_ptr(), ws.data_ptr(), am.data_ptr() if with_amax else None) == 0
+        assert rel(out - 2.0, X.double().sum(0).float()) < 2e-5, (rows, cols)
+        if with_amax:
+            assert bool((am[::32] == 11.25).all()), (rows, cols)
+        out2 = torch.full((cols,), 2.0).cuda()
+        assert L.mtl_colsum_accum(st(), dX.data_ptr(), rows, cols, cols, out2.data_ptr(), ws.data_ptr(), None) == 0
+        assert torch.equal(out, out2)                                   # deterministic
 
 
 def test_spectrogram_front_end_matches_oracle(L, tmp_path):
