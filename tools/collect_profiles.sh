@@ -1,12 +1,12 @@
 #!/bin/bash
-# Runs on the GPU box (via gpurun): collects the round's rocprofv3 summaries into gpurun_out/$ROUND (default r4; copied to profiles/$ROUND afterwards).
+# Runs on the GPU box (via gpurun): collects the round's rocprofv3 summaries into gpurun_out/$ROUND (default r5; copied to profiles/$ROUND afterwards).
 # usage: bash tools/collect_profiles.sh
 set -u
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/${ROUND:-r4}
+O=gpurun_out/${ROUND:-r5}
 mkdir -p $O
-python bench.py > $O/bench.json 2> $O/bench.err
+python bench.py > $O/bench.json 2> $O/bench.err; cp gpurun_out/bench_detail.json $O/bench_detail.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/serial -o serial -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --serial > $O/bench_serial_traced.json 2> /dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/lanes -o lanes -- python bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-extras > $O/bench_lanes_traced.json 2> /dev/null
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras --serial > /dev/null 2>&1

@@ -1,9 +1,9 @@
 #!/bin/bash
-# Copies the summaries collect_profiles.sh left in gpurun_out/$ROUND into profiles/$ROUND (default r4) (tracked) and refreshes profiles/pmc_traffic.json.
+# Copies the summaries collect_profiles.sh left in gpurun_out/$ROUND into profiles/$ROUND (default r5) (tracked) and refreshes profiles/pmc_traffic.json.
 set -e
-R=${ROUND:-r4}; S=gpurun_out/$R D=profiles/$R
+R=${ROUND:-r5}; S=gpurun_out/$R D=profiles/$R
 mkdir -p $D/t5000
-cp $S/bench.json $S/bench_lanes_traced.json $S/bench_serial_traced.json $S/pmc_fetch_size_per_kernel.csv $S/pmc_write_size_per_kernel.csv $S/pmc_traffic.json $S/pmc_traffic.txt $D/
+cp $S/bench.json $S/bench_detail.json $S/bench_lanes_traced.json $S/bench_serial_traced.json $S/pmc_fetch_size_per_kernel.csv $S/pmc_write_size_per_kernel.csv $S/pmc_traffic.json $S/pmc_traffic.txt $D/
 cp $S/serial/serial_kernel_stats.csv $D/kernel_stats_serial.csv
 cp $S/lanes/lanes_kernel_stats.csv $D/kernel_stats_lanes.csv
 cp $S/bench_t5000.json $D/t5000/bench_t5000.json
