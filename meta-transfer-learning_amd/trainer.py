@@ -975,6 +975,7 @@ class TransientTrainer():
         my_tasks = mdist.shard_tasks(n_tasks, rank, world)
 
         takes_need = [_sample_takes_need(ds) for ds in train_data_list]      # decided ONCE from the signature (never by catching)
+        pin_batches = bool(getattr(args, 'cuda', True)) and torch.cuda.is_available() and os.environ.get('MTL_PIN_BATCHES', '1') != '0'
 
         def fetch_train_batch(buf):
             # every rank DRAWS every task (the index streams stay in lock-step), but only what this rank uses is loaded and
@@ -986,6 +987,13 @@ class TransientTrainer():
                     item = ds.sample(k_train, k_valid, manifest_id, need=need)
                 else:                                                # a duck-typed dataset with the reference's 3-argument sample()
                     item = ds.sample(k_train, k_valid, manifest_id)
+                if pin_batches:
+                    # the feature tensors this rank will upload are page-locked HERE, on the prefetch thread: a copy from pageable
+                    # memory holds the enqueueing thread for its whole duration (transient_trainer.py:182-184,210-212 upload inside
+                    # the timed span); torch's caching host allocator re-uses the blocks from iteration to iteration
+                    item = tuple(((part[0].pin_memory(),) + tuple(part[1:])) if (want and torch.is_tensor(part[0]) and not part[0].is_cuda
+                                                                                 and not part[0].is_pinned()) else part
+                                 for part, want in zip(item, need))
                 buf[manifest_id].insert(0, item)
 
         prefetch = threading.Thread(target=fetch_train_batch, args=(train_data_buffer,))
