@@ -124,10 +124,23 @@ def _conv_layer(cin, cout):
 GROUP_FLOPS = {}     # table address -> FLOPs of a grouped weight-gradient launch (filled from the engines before classification)
 
 
+def single_task_form(name, a):
+    """mtl_conv3x3_*_h2_tb (the samples of `tasks` meta-tasks in one launch) -> the name and argument tuple of the single-task entry
+    point over tasks x B samples: same leading arguments, (B, T, F, Cin, Cout) last."""
+    if name in ('mtl_conv3x3_relu_fwd_h2_tb', 'mtl_conv3x3_relu_pool_fwd_h2_tb'):
+        B, T, F, cin, cout, tasks = a[-10:-4]
+        return name[:-3], tuple(a[:-10]) + (B * tasks, T, F, cin, cout)
+    if name == 'mtl_conv3x3_dgrad_h2_tb':
+        B, T, F, cin, cout, tasks = a[-9:-3]
+        return name[:-3], tuple(a[:-9]) + (B * tasks, T, F, cin, cout)
+    return name, a
+
+
 def classify(lib, name, a, conv_mode, wgrad_x3_dense):
     """(class, algorithmic work, 'flop' | 'byte' | None, rocprofv3 kernel symbol(s)) of one library call; `a` = its arguments in
     the order of include/mtl_hip.h.  FLOPs are 2 x MACs of the dense extent of the reference op; bytes are the tensors the op
     must read and write once."""
+    name, a = single_task_form(name, a)
     if name in ('mtl_gemm_f32_ex', 'mtl_gemm_f32', 'mtl_gemm_f32_tb'):
         M, N, K, batch = a[3], a[4], a[5], a[17]              # (mtl_gemm_f32_tb: batch counts the items of all tasks)
         kb, rs = (a[26], a[29]) if name != 'mtl_gemm_f32' else (1, None)
@@ -229,6 +242,7 @@ DTYPE = {'h2': 'f32 (emulated: 3x3 conv + input Linear on 2 x fp16 pieces "h2" =
 
 def algorithmic_bytes(name, a, unit, work):
     """Bytes a launch must move once (operands read once, results written once): the yardstick of `traffic`."""
+    name, a = single_task_form(name, a)
     if unit == 'byte':
         return work
     if name.startswith('mtl_conv3x3_') and 'wprep' not in name:

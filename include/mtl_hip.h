@@ -176,6 +176,19 @@ int mtl_conv3x3_relu_pool_fwd_h2(void* stream, const float* x, const float* amax
                                  float* p_out, unsigned char* argmax, float* amax_p, int B, int T, int F, int Cin, int Cout);
 int mtl_conv3x3_dgrad_h2(void* stream, const float* dy, const float* amax_dy, const unsigned char* argmax, const void* w2_dgrad,
                          const float* act, float* dx, float* amax_dx, int B, int T, int F, int Cin, int Cout);
+/* The same three launches for the batches of `tasks` meta-tasks at once (trainer/asr/transient_trainer.py:178-237: the tasks of a
+ * meta-step are independent given theta0): x / y / dy / dx / act / argmax hold tasks * B samples, task k = samples [k B, (k + 1) B);
+ * task k reads its prepared weights at w2 + k * sW BYTES (0: all tasks share theta0's -- the training passes), its bias at
+ * bias + k * sBias floats, its operand bound at amax + k * sAmaxX floats and raises its own output bound at amax_y + k * sAmaxY.
+ * Per task bitwise the single-task launch (same tiles, same scales); one launch of 64 samples costs 2-14 % less than eight of 8. */
+int mtl_conv3x3_relu_fwd_h2_tb(void* stream, const float* x, const float* amax_x, const void* w2_fwd, const float* bias, float* y,
+                               float* amax_y, int B, int T, int F, int Cin, int Cout, int tasks, long sW, long sBias, long sAmaxX, long sAmaxY);
+int mtl_conv3x3_relu_pool_fwd_h2_tb(void* stream, const float* x, const float* amax_x, const void* w2_fwd, const float* bias, float* p_out,
+                                    unsigned char* argmax, float* amax_p, int B, int T, int F, int Cin, int Cout, int tasks, long sW,
+                                    long sBias, long sAmaxX, long sAmaxP);
+int mtl_conv3x3_dgrad_h2_tb(void* stream, const float* dy, const float* amax_dy, const unsigned char* argmax, const void* w2_dgrad,
+                            const float* act, float* dx, float* amax_dx, int B, int T, int F, int Cin, int Cout, int tasks, long sW,
+                            long sAmaxDy, long sAmaxDx);
 /* amax[MTL_AMAX_FLOATS]: slot heads raised so that their maximum is >= max|x[0..n)| (atomic; zero them first) */
 int mtl_absmax_f32(void* stream, const float* x, long n, float* amax);
 long mtl_conv3x3_wgrad_workspace(int B, int T, int F, int Cin, int Cout, int pooled);

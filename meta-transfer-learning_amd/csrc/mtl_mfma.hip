@@ -892,6 +892,12 @@ struct ConvX3P {
     int ntf, ntt, tiles; // halo kernel: pixel tiles along F and T, and tiles in total (F fastest, then T, then output-channel tile, then sample)
     const float* amax_in;   // NP = 2: MTL_AMAX_SLOTS floats whose maximum is >= max|x|
     float* amax_out;        // optional: atomic max of an upper bound of max|y| (the next layer's amax_in)
+    // several tasks in ONE launch (round 5: the samples of task k are b in [k Bt, (k + 1) Bt); g.B counts all of them): task k reads its
+    // prepared weights at w3 + k sW bytes, its bias at bias + k sBias, its input bound at amax_in + k sAmaxIn and raises amax_out + k sAmaxOut
+    // (floats).  Bt = g.B and zero strides: the single-task launch.  Eight launches of 8 samples cost 2-14 % more than one of 64
+    // (prologue, tail and launch boundary of a persistent grid: tools/probe/conv_batch_tasks.py)
+    int Bt;
+    long sW, sBias, sAmaxIn, sAmaxOut;
 #ifdef MTL_X3_PROF
     unsigned long long* prof;   // probe builds only (tools/probe/conv_prof.py): [workgroup][wave][8] accumulated s_memtime intervals
 #endif
@@ -985,7 +991,16 @@ void conv3x3_x3h_kernel(ConvX3P p) {
     if (tid >= NCONS + 64) {
         // ------------------------------------------------------------------ halo waves (3): gather, 3-way split, LDS image
         const int ptid = tid - NCONS - 64;
-        const float sx = NP == 2 ? pow2_scale(amax_read(p.amax_in)) : 1.f;
+        float sx = NP == 2 ? pow2_scale(amax_read(p.amax_in)) : 1.f;
+        int sx_task = 0;
+        auto set_scale = [&](int qc) {          // the operand scale of the task that stage qc's tile belongs to
+            if (NP != 2 || p.Bt >= p.g.B) return;
+            const int tk = x3_tile<G>(p, blockIdx.x + (qc / cch) * gridDim.x).b / p.Bt;
+            if (tk != sx_task) {
+                sx_task = tk;
+                sx = pow2_scale(amax_read(p.amax_in + tk * p.sAmaxIn));
+            }
+        };
         float4 hv[XH_NVA];
         uchar4 ha[XH_NVA];
         unsigned hm[XH_NVA];
@@ -1042,6 +1057,7 @@ void conv3x3_x3h_kernel(ConvX3P p) {
         X3_PROF_DECL;
         X3_T(h0);
         if (doA) fetch_halo(0);
+        set_scale(0);
         if (doA) commit_halo();
         if (nstage > 1 && doA) fetch_halo(1);
         __syncthreads();                                       // halo of stage 0 (and the weights of step 0) are visible
@@ -1055,6 +1071,7 @@ void conv3x3_x3h_kernel(ConvX3P p) {
             X3_T(a1);
             X3_ACC(1, a0, a1);                                 // nine tap barriers
             if (q + 1 < nstage) {
+                set_scale(q + 1);
                 if (doA) commit_halo();                        // nobody reads the halo between these two barriers
                 X3_T(a2);
                 X3_ACC(2, a1, a2);                             // commit (includes the wait for the fetch)
@@ -1078,16 +1095,25 @@ void conv3x3_x3h_kernel(ConvX3P p) {
         // would add vmcnt(0).
         const int lane = tid & 63;
         const bool doB = !(p.dbg & 4);
+        int dma_j = -1, dma_n0 = 0;
+        const unsigned char* dma_w3 = p.w3;
         auto dma = [&](int s_) {
             const int q = s_ / 9, tap = s_ - q * 9;
             const int j = q / cch, c = q - j * cch;
-            const int n0 = p.ntile == 1 ? 0 : x3_tile<G>(p, blockIdx.x + j * gridDim.x).n0 * BN;
+            if (j != dma_j && (p.ntile != 1 || p.Bt < p.g.B)) {      // (once per tile: the tile's channel block and its task's weights)
+                const X3Tile tl = x3_tile<G>(p, blockIdx.x + j * gridDim.x);
+                dma_n0 = tl.n0 * BN;
+                dma_w3 = p.w3 + (tl.b / p.Bt) * p.sW;
+                dma_j = j;
+            }
+            const int n0 = dma_n0;
+            const unsigned char* w3 = dma_w3;
             const int kt = tap * cch + c;
             unsigned char* dst = smB + (s_ % 3) * BBUF;            // scalar ALU
 #pragma unroll
             for (int i = 0; i < NDMA; ++i) {
                 const int piece = i / (BN / 16), r16 = i - piece * (BN / 16);       // 16 rows (1 KiB) per instruction
-                const unsigned char* g = p.w3 + (((long)piece * nk + kt) * Cout + n0 + r16 * 16) * 64 + lane * 16;
+                const unsigned char* g = w3 + (((long)piece * nk + kt) * Cout + n0 + r16 * 16) * 64 + lane * 16;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                                  (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
             }
@@ -1146,6 +1172,26 @@ void conv3x3_x3h_kernel(ConvX3P p) {
     const int l15 = lane & 15, q4 = lane >> 4;
     float inv = 1.f, mx = 0.f;                                 // NP = 2: 1 / (activation scale x weight scale); running bound of max|y|
     if (NP == 2) inv = 1.f / (pow2_scale(amax_read(p.amax_in)) * *reinterpret_cast<const float*>(p.w3 + (long)NP * nk * Cout * 64));
+    int cur_task = 0;                                          // (several tasks per launch: the task of the tile being finished)
+    const float* bias_t = p.bias;
+    // |relu(v + b)| <= |v| + |b| (pooling takes a maximum of those); dgrad: |gate v| <= |v|: the bound of a task's output leaves when
+    // the workgroup's tiles move on to the next task (its tile sequence visits the tasks in order) and at the end
+    auto raise_bound = [&]() {
+        if (!p.amax_out) return;
+        float bmax = 0.f;
+        if (EPI != EPI_DGRAD) {
+            if (M16) {
+#pragma unroll
+                for (int jn = 0; jn < TN16; ++jn)
+                    for (int nt = 0; nt < p.ntile; ++nt)
+                        bmax = fmaxf(bmax, fabsf(bias_t[nt * BN + wn * WTN + (jn >> 1) * 32 + 2 * l15 + (jn & 1)]));
+            } else
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn)
+                for (int nt = 0; nt < p.ntile; ++nt) bmax = fmaxf(bmax, fabsf(bias_t[nt * BN + wn * WTN + jn * 32 + l31]));
+        }
+        amax_raise(p.amax_out + cur_task * p.sAmaxOut, mx + bmax);
+    };
     int abase[TM];                                             // byte offset of this lane's pixel (tap centre) in the halo plane
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -1256,6 +1302,18 @@ void conv3x3_x3h_kernel(ConvX3P p) {
                 asm volatile("" : "+s"(jj));
                 const X3Tile tl = x3_tile<G>(p, blockIdx.x + jj * gridDim.x);
                 const int ts0 = tl.t0 + grp * 8, n0 = tl.n0 * BN;
+                if (p.Bt < p.g.B) {
+                    const int tk = tl.b / p.Bt;
+                    if (tk != cur_task) {
+                        raise_bound();
+                        mx = 0.f;
+                        cur_task = tk;
+                        bias_t = p.bias + tk * p.sBias;
+                        if (NP == 2)
+                            inv = 1.f / (pow2_scale(amax_read(p.amax_in + tk * p.sAmaxIn)) *
+                                         *reinterpret_cast<const float*>(p.w3 + tk * p.sW + (long)NP * nk * Cout * 64));
+                    }
+                }
                 auto walk = [&](auto&& epi) {
                     if (M16) {
 #pragma unroll
@@ -1289,9 +1347,9 @@ void conv3x3_x3h_kernel(ConvX3P p) {
                             }
                 };
                 if (EPI == EPI_RELU) {
-                    walk(EpiConvRelu{p.y, p.bias, tl.b, ts0, tl.f0, T, F, Cout, n0});
+                    walk(EpiConvRelu{p.y, bias_t, tl.b, ts0, tl.f0, T, F, Cout, n0});
                 } else if (EPI == EPI_POOL) {
-                    walk(EpiConvPool{p.y, p.am_out, p.bias, tl.b, ts0, tl.f0, Tp, Fp, Cout, n0});
+                    walk(EpiConvPool{p.y, p.am_out, bias_t, tl.b, ts0, tl.f0, Tp, Fp, Cout, n0});
                 } else {
                     const EpiConvDgrad epi{p.y, p.act, tl.b, ts0, tl.f0, T, F, Cout, n0};
                     if (M16) {
@@ -1349,21 +1407,7 @@ void conv3x3_x3h_kernel(ConvX3P p) {
     X3_T(k1);
     X3_ACC(4, k0, k1);                                         // whole main loop
     X3_PROF_FLUSH();
-    if (p.amax_out) {       // |relu(v + b)| <= |v| + |b| (pooling takes a maximum of those); dgrad: |gate v| <= |v|
-        float bmax = 0.f;
-        if (EPI != EPI_DGRAD) {
-            if (M16) {
-#pragma unroll
-                for (int jn = 0; jn < TN16; ++jn)
-                    for (int nt = 0; nt < p.ntile; ++nt)
-                        bmax = fmaxf(bmax, fabsf(p.bias[nt * BN + wn * WTN + (jn >> 1) * 32 + 2 * l15 + (jn & 1)]));
-            } else
-#pragma unroll
-            for (int jn = 0; jn < TN; ++jn)
-                for (int nt = 0; nt < p.ntile; ++nt) bmax = fmaxf(bmax, fabsf(p.bias[nt * BN + wn * WTN + jn * 32 + l31]));
-        }
-        amax_raise(p.amax_out, mx + bmax);
-    }
+    raise_bound();
 }
 
 template <int BN, int G, bool UNPOOL, int EPI, int NP, int WN = 2>
@@ -2411,24 +2455,41 @@ __global__ void conv_wprep_h2_batch_kernel(WprepBatch b) {
     }
 }
 
+// tasks of one launch: `tasks` groups of B samples, per-task strides of the prepared weights (bytes), the bias, the input / output bounds (floats)
+struct ConvTasks {
+    int tasks;
+    long sW, sBias, sAmaxIn, sAmaxOut;
+};
+static inline void set_tasks(ConvX3P& p, int B, const ConvTasks& tk) {
+    p.Bt = B;
+    p.sW = tk.sW;
+    p.sBias = tk.sBias;
+    p.sAmaxIn = tk.sAmaxIn;
+    p.sAmaxOut = tk.sAmaxOut;
+}
+
 template <int NP>
 static int conv_fwd_pieces(hipStream_t s, const float* x, const float* amax_x, const void* w, const float* bias, float* y,
-                           unsigned char* argmax, float* amax_y, bool pool, int B, int T, int F, int Cin, int Cout) {
-    if (!x || !w || !bias || !y || (pool && !argmax) || (NP == 2 && !amax_x)) return MTL_EINVAL;
-    ConvX3P p{x, nullptr, reinterpret_cast<const unsigned char*>(w), bias, nullptr, y, argmax, {B, T, F, Cin, Cout, T / 2, F / 2}, 1};
+                           unsigned char* argmax, float* amax_y, bool pool, int B, int T, int F, int Cin, int Cout,
+                           ConvTasks tk = ConvTasks{1, 0, 0, 0, 0}) {
+    if (!x || !w || !bias || !y || (pool && !argmax) || (NP == 2 && !amax_x) || tk.tasks < 1 || B < 1) return MTL_EINVAL;
+    ConvX3P p{x, nullptr, reinterpret_cast<const unsigned char*>(w), bias, nullptr, y, argmax, {B * tk.tasks, T, F, Cin, Cout, T / 2, F / 2}, 1};
     p.amax_in = amax_x;
     p.amax_out = amax_y;
+    set_tasks(p, B, tk);
     if (pool) return dispatch_conv_x3<false, EPI_POOL, NP>(p, 2 * (T / 2), 2 * (F / 2), s);
     return dispatch_conv_x3<false, EPI_RELU, NP>(p, T, F, s);
 }
 
 template <int NP>
 static int conv_dgrad_pieces(hipStream_t s, const float* dy, const float* amax_dy, const unsigned char* argmax, const void* w,
-                             const float* act, float* dx, float* amax_dx, int B, int T, int F, int Cin, int Cout) {
-    if (!dy || !w || !act || !dx || (NP == 2 && !amax_dy)) return MTL_EINVAL;
-    ConvX3P p{dy, argmax, reinterpret_cast<const unsigned char*>(w), nullptr, act, dx, nullptr, {B, T, F, Cout, Cin, T / 2, F / 2}, 1};
+                             const float* act, float* dx, float* amax_dx, int B, int T, int F, int Cin, int Cout,
+                             ConvTasks tk = ConvTasks{1, 0, 0, 0, 0}) {
+    if (!dy || !w || !act || !dx || (NP == 2 && !amax_dy) || tk.tasks < 1 || B < 1) return MTL_EINVAL;
+    ConvX3P p{dy, argmax, reinterpret_cast<const unsigned char*>(w), nullptr, act, dx, nullptr, {B * tk.tasks, T, F, Cout, Cin, T / 2, F / 2}, 1};
     p.amax_in = amax_dy;
     p.amax_out = amax_dx;
+    set_tasks(p, B, tk);
     if (argmax) return dispatch_conv_x3<true, EPI_DGRAD, NP>(p, T, F, s);
     return dispatch_conv_x3<false, EPI_DGRAD, NP>(p, T, F, s);
 }
@@ -2494,6 +2555,26 @@ int mtl_conv3x3_relu_pool_fwd_h2(void* stream, const float* x, const float* amax
 int mtl_conv3x3_dgrad_h2(void* stream, const float* dy, const float* amax_dy, const unsigned char* argmax, const void* w2_dgrad,
                          const float* act, float* dx, float* amax_dx, int B, int T, int F, int Cin, int Cout) {
     return conv_dgrad_pieces<2>(as_stream(stream), dy, amax_dy, argmax, w2_dgrad, act, dx, amax_dx, B, T, F, Cin, Cout);
+}
+
+int mtl_conv3x3_relu_fwd_h2_tb(void* stream, const float* x, const float* amax_x, const void* w2_fwd, const float* bias, float* y,
+                               float* amax_y, int B, int T, int F, int Cin, int Cout, int tasks, long sW, long sBias, long sAmaxX, long sAmaxY) {
+    return conv_fwd_pieces<2>(as_stream(stream), x, amax_x, w2_fwd, bias, y, nullptr, amax_y, false, B, T, F, Cin, Cout,
+                              ConvTasks{tasks, sW, sBias, sAmaxX, sAmaxY});
+}
+
+int mtl_conv3x3_relu_pool_fwd_h2_tb(void* stream, const float* x, const float* amax_x, const void* w2_fwd, const float* bias, float* p_out,
+                                    unsigned char* argmax, float* amax_p, int B, int T, int F, int Cin, int Cout, int tasks, long sW,
+                                    long sBias, long sAmaxX, long sAmaxP) {
+    return conv_fwd_pieces<2>(as_stream(stream), x, amax_x, w2_fwd, bias, p_out, argmax, amax_p, true, B, T, F, Cin, Cout,
+                              ConvTasks{tasks, sW, sBias, sAmaxX, sAmaxP});
+}
+
+int mtl_conv3x3_dgrad_h2_tb(void* stream, const float* dy, const float* amax_dy, const unsigned char* argmax, const void* w2_dgrad,
+                            const float* act, float* dx, float* amax_dx, int B, int T, int F, int Cin, int Cout, int tasks, long sW,
+                            long sAmaxDy, long sAmaxDx) {
+    return conv_dgrad_pieces<2>(as_stream(stream), dy, amax_dy, argmax, w2_dgrad, act, dx, amax_dx, B, T, F, Cin, Cout,
+                                ConvTasks{tasks, sW, 0, sAmaxDy, sAmaxDx});
 }
 
 long mtl_conv3x3_wgrad_workspace(int B, int T, int F, int Cin, int Cout, int pooled) {

@@ -285,6 +285,8 @@ class PassEngine:
         self.hoist_kv = os.environ.get('MTL_HOIST_KV', '1') != '0'
         self.batch_qkv = os.environ.get('MTL_BATCH_QKV', '1') != '0'   # q/k/v projections as strided-batch GEMMs
         self.wgrad_x3_dense = os.environ.get('MTL_WGRAD_X3_DENSE', '1') != '0'    # conv5 (dy not pooled)
+        # task-batched passes: the 3x3 forward kernels and the data gradients of conv7 / conv5 as ONE launch over all tasks' samples
+        self.conv_tb = os.environ.get('MTL_CONV_TB', '1') != '0'
         # scaled-dot-product attention as ONE flash-style kernel forward and two backward (no score tensor in HBM); head sizes
         # outside mtl_attn_supported() take the batched-GEMM + softmax path ('0' forces it, for A/B measurements)
         self.fused_attn = (os.environ.get('MTL_FUSED_ATTN', '1') != '0' and device.type == 'cuda'
@@ -1176,7 +1178,20 @@ class PassEngine:
         y5 = self.buf('y5', (Bt, T2, F2, 128))
         p2 = self.buf('p2', (Bt, T4, F4, 128))
         am2 = self.buf('am2', (Bt, T4, F4, 128), torch.uint8)
-        for t in range(nt):
+        if h2 and nt > 1 and self.conv_tb:
+            # the samples of all tasks in ONE launch per layer (per-task bounds, weights and biases by stride): a persistent grid's
+            # prologue, tail and launch boundary are paid once instead of nt times (2-14 % of a layer: tools/probe/conv_batch_tasks.py);
+            # per task bitwise the per-task launches (tests/test_ops_gpu.py)
+            AS = 12 * _lib.AMAX_SLOTS
+            sw = lambda idx: wf[idx].stride(0) if ntw > 1 else 0
+            check(lib.mtl_conv3x3_relu_pool_fwd_h2_tb(st, y1.data_ptr(), am_(0), wf[2].data_ptr(), o('conv.2.bias'), p1.data_ptr(), am1.data_ptr(),
+                                                      am_(1), B, T, F, 64, 64, nt, sw(2), sP, AS, AS), 'conv2')
+            check(lib.mtl_conv3x3_relu_fwd_h2_tb(st, p1.data_ptr(), am_(1), wf[5].data_ptr(), o('conv.5.bias'), y5.data_ptr(), am_(2),
+                                                 B, T2, F2, 64, 128, nt, sw(5), sP, AS, AS), 'conv5')
+            check(lib.mtl_conv3x3_relu_pool_fwd_h2_tb(st, y5.data_ptr(), am_(2), wf[7].data_ptr(), o('conv.7.bias'), p2.data_ptr(), am2.data_ptr(),
+                                                      am_(6), B, T2, F2, 128, 128, nt, sw(7), sP, AS, AS), 'conv7')
+        else:
+          for t in range(nt):
             tw, sl = (t if sP else 0), slice(t * B, (t + 1) * B)
             check(conv_fwd_pool(st, y1[sl].data_ptr(), wf[2][tw].data_ptr(), o('conv.2.bias', t), p1[sl].data_ptr(), am1[sl].data_ptr(),
                                 am_(0, t), am_(1, t), B, T, F, 64, 64), 'conv2')
@@ -1524,26 +1539,57 @@ class PassEngine:
         dy1 = self.buf('_dy1', (nt * B, T, F, 64))
         f5, f2 = fold(None), fold(A['am1'])
         xin = S['x']
-        for t in range(nt):
+        merged = h2 and nt > 1 and self.conv_tb     # data gradients of conv7 / conv5: ONE launch over the samples of all tasks (see forward)
+        AS = 12 * _lib.AMAX_SLOTS
+        swd = lambda name: A[name].stride(0) if (sP and nt > 1) else 0
+
+        def layer7(t, dgrad):
             tw, sl = (t if sP else 0), slice(t * B, (t + 1) * B)
-            am1_t, am2_t = A['am1'][sl].data_ptr(), A['am2'][sl].data_ptr()
+            am2_t = A['am2'][sl].data_ptr()
             self.colsum(dp2[sl].data_ptr(), B * T4 * F4, 128, g('conv.7.bias', t), am_(3, t))
             wgrad(t, y5[sl].data_ptr(), 2, dp2[sl].data_ptr(), 3, am2_t, 7, B, T2, F2, 128, 128)
-            check(conv_dgrad(t, dp2[sl].data_ptr(), 3, am2_t, A['wd7'][tw].data_ptr(), y5[sl].data_ptr(), dy5[sl].data_ptr(),
-                             B, T2, F2, 128, 128, ao=4 if f5 else None), 'dgrad7')
+            if dgrad:
+                check(conv_dgrad(t, dp2[sl].data_ptr(), 3, am2_t, A['wd7'][tw].data_ptr(), y5[sl].data_ptr(), dy5[sl].data_ptr(),
+                                 B, T2, F2, 128, 128, ao=4 if f5 else None), 'dgrad7')
+
+        def layer5(t, dgrad):
+            tw, sl = (t if sP else 0), slice(t * B, (t + 1) * B)
             if not f5:
                 self.colsum(dy5[sl].data_ptr(), B * T2 * F2, 128, g('conv.5.bias', t), am_(4, t))
             wgrad(t, p1[sl].data_ptr(), 1, dy5[sl].data_ptr(), 4, None, 5, B, T2, F2, 64, 128, db=g('conv.5.bias', t) if f5 else None)
-            check(conv_dgrad(t, dy5[sl].data_ptr(), 4, None, A['wd5'][tw].data_ptr(), p1[sl].data_ptr(), dp1[sl].data_ptr(),
-                             B, T2, F2, 64, 128, ao=5 if f2 else None), 'dgrad5')
+            if dgrad:
+                check(conv_dgrad(t, dy5[sl].data_ptr(), 4, None, A['wd5'][tw].data_ptr(), p1[sl].data_ptr(), dp1[sl].data_ptr(),
+                                 B, T2, F2, 64, 128, ao=5 if f2 else None), 'dgrad5')
+
+        def layer2(t):
+            tw, sl = (t if sP else 0), slice(t * B, (t + 1) * B)
+            am1_t = A['am1'][sl].data_ptr()
             if not f2:
                 self.colsum(dp1[sl].data_ptr(), B * T2 * F2, 64, g('conv.2.bias', t), am_(5, t))
             wgrad(t, y1[sl].data_ptr(), 0, dp1[sl].data_ptr(), 5, am1_t, 2, B, T, F, 64, 64, db=g('conv.2.bias', t) if f2 else None)
+            # (conv2's data gradient stays one launch per task: 8 x 16 tiles, measured no faster merged)
             check(conv_dgrad(t, dp1[sl].data_ptr(), 5, am1_t, A['wd2'][tw].data_ptr(), y1[sl].data_ptr(), dy1[sl].data_ptr(),
                              B, T, F, 64, 64), 'dgrad2')
             ws = self.scratch(lib.mtl_conv0_wgrad_workspace())
             check(lib.mtl_conv0_wgrad(st, xin.data_ptr() + 4 * t * sX, dy1[sl].data_ptr(), g('conv.0.weight', t), g('conv.0.bias', t),
                                       ws, B, T, F), 'wgrad0')
+
+        if merged:
+            for t in range(nt):
+                layer7(t, False)
+            check(lib.mtl_conv3x3_dgrad_h2_tb(st, dp2.data_ptr(), am_(3), A['am2'].data_ptr(), A['wd7'].data_ptr(), y5.data_ptr(), dy5.data_ptr(),
+                                              am_(4) if f5 else None, B, T2, F2, 128, 128, nt, swd('wd7'), AS, AS), 'dgrad7')
+            for t in range(nt):
+                layer5(t, False)
+            check(lib.mtl_conv3x3_dgrad_h2_tb(st, dy5.data_ptr(), am_(4), None, A['wd5'].data_ptr(), p1.data_ptr(), dp1.data_ptr(),
+                                              am_(5) if f2 else None, B, T2, F2, 64, 128, nt, swd('wd5'), AS, AS), 'dgrad5')
+            for t in range(nt):
+                layer2(t)
+        else:
+            for t in range(nt):
+                layer7(t, True)
+                layer5(t, True)
+                layer2(t)
         self.join_side()
         self.flush_ln_reduce()     # the parameter / bias gradients of all 17 LayerNorms of the pass: one launch (after the join: one of
                                    # the 17 backward kernels ran on the side stream)

@@ -806,6 +806,69 @@ def test_conv3x3_two_piece_fp16_dynamic_range_inside_one_tensor(L, k):
     assert loud < 1e-6 and quiet < bound, (k, loud, quiet, bound)
 
 
+@pytest.mark.parametrize('Cin,Cout,B,T,Fq,nt', [(64, 64, 2, 37, 161, 3), (64, 128, 3, 34, 80, 4), (128, 128, 2, 50, 40, 5), (64, 64, 8, 96, 161, 8)])
+@pytest.mark.parametrize('shared_w', [True, False])
+def test_conv3x3_two_piece_fp16_several_tasks_in_one_launch(L, Cin, Cout, B, T, Fq, nt, shared_w):
+    """mtl_conv3x3_*_h2_tb: the samples of nt meta-tasks in ONE launch (per-task operand bounds, weights shared -- training passes at
+    theta0 -- or per task -- validation passes at the theta' stack --, per-task bias and output bounds) against nt single-task launches:
+    forward, fused pool (+ arg-max), both data gradients and every output bound must agree BIT FOR BIT (same tiles, same scales; a
+    workgroup's tile sequence crosses task boundaries, also inside the multi-stage pipeline of the halo / weight waves)."""
+    g = torch.Generator().manual_seed(Cin + Cout + T + nt)
+    S = 2048
+    mags = [10.0 ** (t - 1) for t in range(nt)]                                  # the tasks' tensors differ by orders of magnitude: a shared scale would show
+    x = torch.cat([torch.relu(torch.randn(B, T, Fq, Cin, generator=g)) * m for m in mags]).cuda()
+    nw = 1 if shared_w else nt
+    w = torch.randn(nw, Cout, Cin, 3, 3, generator=g) * (1.0 / np.sqrt(9 * Cin))
+    w = (w * torch.tensor([3.0 ** k for k in range(nw)]).view(-1, 1, 1, 1, 1)).cuda()
+    bias = (torch.randn(nw, Cout, generator=g) * 0.1).cuda()
+    nb = (L.mtl_conv3x3_wprep_h2_bytes(Cout, Cin) + 15) // 16 * 16
+    w2f, w2d = torch.empty(nw, nb, dtype=torch.uint8).cuda(), torch.empty(nw, nb, dtype=torch.uint8).cuda()
+    for k in range(nw):
+        assert L.mtl_conv3x3_wprep_h2(st(), w[k].data_ptr(), w2f[k].data_ptr(), w2d[k].data_ptr(), Cout, Cin) == 0
+    ax = torch.stack([x[t * B:(t + 1) * B].abs().max().reshape(1).repeat(S) for t in range(nt)]).contiguous()
+    sW, sB = (0, 0) if shared_w else (nb, Cout)
+    wk = lambda t: 0 if shared_w else t
+    Tp, Fp = T // 2, Fq // 2
+    for pooled in (False, True):
+        shp = (nt * B, Tp, Fp, Cout) if pooled else (nt * B, T, Fq, Cout)
+        y1, yn = torch.zeros(shp).cuda(), torch.zeros(shp).cuda()
+        am1, amn = torch.zeros(shp, dtype=torch.uint8).cuda(), torch.zeros(shp, dtype=torch.uint8).cuda()
+        ay1, ayn = torch.zeros(nt, S).cuda(), torch.zeros(nt, S).cuda()
+        for t in range(nt):
+            sl = slice(t * B, (t + 1) * B)
+            if pooled:
+                assert L.mtl_conv3x3_relu_pool_fwd_h2(st(), x[sl].data_ptr(), ax[t].data_ptr(), w2f[wk(t)].data_ptr(), bias[wk(t)].data_ptr(), yn[sl].data_ptr(),
+                                                      amn[sl].data_ptr(), ayn[t].data_ptr(), B, T, Fq, Cin, Cout) == 0
+            else:
+                assert L.mtl_conv3x3_relu_fwd_h2(st(), x[sl].data_ptr(), ax[t].data_ptr(), w2f[wk(t)].data_ptr(), bias[wk(t)].data_ptr(), yn[sl].data_ptr(),
+                                                 ayn[t].data_ptr(), B, T, Fq, Cin, Cout) == 0
+        if pooled:
+            assert L.mtl_conv3x3_relu_pool_fwd_h2_tb(st(), x.data_ptr(), ax.data_ptr(), w2f.data_ptr(), bias.data_ptr(), y1.data_ptr(), am1.data_ptr(),
+                                                     ay1.data_ptr(), B, T, Fq, Cin, Cout, nt, sW, sB, S, S) == 0
+        else:
+            assert L.mtl_conv3x3_relu_fwd_h2_tb(st(), x.data_ptr(), ax.data_ptr(), w2f.data_ptr(), bias.data_ptr(), y1.data_ptr(), ay1.data_ptr(),
+                                                B, T, Fq, Cin, Cout, nt, sW, sB, S, S) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(y1, yn) and float(yn.abs().max()) > 0, ('forward', pooled)
+        assert torch.equal(ay1.view(nt, -1, 32)[:, :, 0].max(1)[0], ayn.view(nt, -1, 32)[:, :, 0].max(1)[0]), ('output bound', pooled)
+        if pooled:
+            assert torch.equal(am1, amn)
+        # data gradient of the same layer (pooled: the gradient lives on the pooled grid + arg-max)
+        dy = torch.cat([torch.randn((B,) + shp[1:], generator=g) * m for m in reversed(mags)]).cuda()
+        ady = torch.stack([dy[t * B:(t + 1) * B].abs().max().reshape(1).repeat(S) for t in range(nt)]).contiguous()
+        dx1, dxn = torch.zeros_like(x), torch.zeros_like(x)
+        ad1, adn = torch.zeros(nt, S).cuda(), torch.zeros(nt, S).cuda()
+        for t in range(nt):
+            sl = slice(t * B, (t + 1) * B)
+            assert L.mtl_conv3x3_dgrad_h2(st(), dy[sl].data_ptr(), ady[t].data_ptr(), amn[sl].data_ptr() if pooled else None, w2d[wk(t)].data_ptr(),
+                                          x[sl].data_ptr(), dxn[sl].data_ptr(), adn[t].data_ptr(), B, T, Fq, Cin, Cout) == 0
+        assert L.mtl_conv3x3_dgrad_h2_tb(st(), dy.data_ptr(), ady.data_ptr(), amn.data_ptr() if pooled else None, w2d.data_ptr(), x.data_ptr(),
+                                         dx1.data_ptr(), ad1.data_ptr(), B, T, Fq, Cin, Cout, nt, sW, S, S) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(dx1, dxn) and float(dxn.abs().max()) > 0, ('data gradient', pooled)
+        assert torch.equal(ad1.view(nt, -1, 32)[:, :, 0].max(1)[0], adn.view(nt, -1, 32)[:, :, 0].max(1)[0]), ('dx bound', pooled)
+
+
 @pytest.mark.parametrize('Cin,Cout,B,T,Fq', [(64, 64, 2, 21, 161), (64, 128, 2, 18, 80), (128, 128, 1, 9, 19)])
 @pytest.mark.parametrize('mag', [1.0, 3e-7, 4e5])
 def test_conv3x3_two_piece_fp16_is_fp32_class(L, Cin, Cout, B, T, Fq, mag):
