@@ -133,6 +133,9 @@ def single_task_form(name, a):
     if name == 'mtl_conv3x3_dgrad_h2_tb':
         B, T, F, cin, cout, tasks = a[-9:-3]
         return name[:-3], tuple(a[:-9]) + (B * tasks, T, F, cin, cout)
+    if name == 'mtl_conv3x3_wgrad_h2_tb':
+        B, T, F, cin, cout, tasks = a[-10:-4]
+        return name[:-3], tuple(a[:-10]) + (B * tasks, T, F, cin, cout)
     return name, a
 
 

@@ -189,6 +189,14 @@ int mtl_conv3x3_relu_pool_fwd_h2_tb(void* stream, const float* x, const float* a
 int mtl_conv3x3_dgrad_h2_tb(void* stream, const float* dy, const float* amax_dy, const unsigned char* argmax, const void* w2_dgrad,
                             const float* act, float* dx, float* amax_dx, int B, int T, int F, int Cin, int Cout, int tasks, long sW,
                             long sAmaxDy, long sAmaxDx);
+/* weight (+ bias) gradients of `tasks` meta-tasks in one launch: x / dy / argmax hold tasks * B samples; task k reads its bounds at
+ * amax_x + k sAmaxX, amax_dy + k sAmaxDy floats and accumulates onto dw_ref + k sDw, db + k sDb floats (the per-task gradient stack).
+ * The launch's partial slabs (workspace: mtl_conv3x3_wgrad_x3_workspace, unchanged) are dealt to the tasks in equal contiguous ranges,
+ * so one launch writes / reduces as many slabs as ONE single-task launch; tasks <= slabs.  Fixed-order sums: deterministic; the
+ * partition of a task's pixels over slabs differs from the single-task launch (same class of rounding, not the same bits). */
+int mtl_conv3x3_wgrad_h2_tb(void* stream, const float* x, const float* amax_x, const float* dy, const float* amax_dy,
+                            const unsigned char* argmax, float* dw_ref, float* db, float* workspace, long workspace_bytes, int B, int T,
+                            int F, int Cin, int Cout, int tasks, long sAmaxX, long sAmaxDy, long sDw, long sDb);
 /* amax[MTL_AMAX_FLOATS]: slot heads raised so that their maximum is >= max|x[0..n)| (atomic; zero them first) */
 int mtl_absmax_f32(void* stream, const float* x, long n, float* amax);
 long mtl_conv3x3_wgrad_workspace(int B, int T, int F, int Cin, int Cout, int pooled);

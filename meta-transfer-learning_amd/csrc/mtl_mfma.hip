@@ -1657,10 +1657,17 @@ __global__ __launch_bounds__(NT) void conv3x3_wgrad_kernel(WgradP p) {
 // A workgroup owns 64 consecutive elements; its 16 waves split the slabs (wave w: slabs w, w + 16, ...; every load of a thread is
 // independent of the others) and combine through LDS in wave order.  The bias gradient (per-slot sums of dy) rides along as Cout
 // extra elements behind the weights.  (One thread per element walking all 256 slabs was a latency chain: 69 us for conv2's 37 MB.)
+// blockIdx.y = task (several tasks per weight-gradient launch): its nsplit slabs start at slab task * nsplit, its gradients at + task * sDw / sDb
 __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int nsplit,
                                                             int Cin, int Cout, const float* __restrict__ bias_part,
-                                                            float* __restrict__ db) {
+                                                            float* __restrict__ db, long sDw = 0, long sDb = 0) {
     __shared__ float sh[16][64];
+    if (blockIdx.y) {
+        partial += (long)blockIdx.y * nsplit * 9 * Cin * Cout;
+        dw += blockIdx.y * sDw;
+        if (bias_part) bias_part += (long)blockIdx.y * nsplit * Cout;
+        if (db) db += blockIdx.y * sDb;
+    }
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int total = 9 * Cin * Cout;
     const int e = blockIdx.x * 64 + lane;
@@ -1738,6 +1745,11 @@ struct WgradX3P {
     const float* amax_dy;
     float* bias_part;     // optional [slot][Cout]: per-slot sums of dy over the slot's pixels (the bias gradient rides along: the
                           // producers see every dy element exactly once per input-channel block; block 0 keeps the sums)
+    // several tasks in one launch (round 5): B / tiles count ONE task; the slots are dealt to the tasks in equal contiguous ranges
+    // (slot / (nslots / tasks)), a slot walks the pixel tiles of its task only, task k reads its bounds at amax_* + k sAmax* floats.
+    // One launch writes nslots partial slabs in total instead of nslots per task (conv7 at 8 tasks: 38 MB instead of 300 MB).
+    int tasks;
+    long sAmaxX, sAmaxDy;
 };
 
 constexpr int WX_HF = 18, WX_NPIX = 10 * WX_HF;          // halo of an 8 x 16 tile
@@ -1780,7 +1792,11 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_x3_kernel(WgradX3P p) {
         slot = blockIdx.x / p.npairs;
     }
     const int cib = (pair / p.npj) * 64, cob = (pair % p.npj) * 64;
-    const int my_tiles = (p.tiles - slot + nslots - 1) / nslots;
+    const int spt = nslots / p.tasks, task = slot / spt, ls = slot - task * spt;      // slots per task, this slot's task and rank in it
+    if (task >= p.tasks) return;                               // (nslots % tasks left-over slots: the whole workgroup, before any barrier)
+    const int my_tiles = (p.tiles - ls + spt - 1) / spt;
+    const float* amax_x = p.amax_x ? p.amax_x + task * p.sAmaxX : nullptr;
+    const float* amax_dy = p.amax_dy ? p.amax_dy + task * p.sAmaxDy : nullptr;
     const int T = p.T, F = p.F, Cin = p.Cin, Cout = p.Cout;
     const int npairs_k = my_tiles * 4;                         // pairs of k-steps (2 x 16 pixels): the B hand-over granule
     // (sample, t0, f0) of this workgroup's j-th tile; each caller keeps its last answer: the producers ask five times per tile, and
@@ -1791,12 +1807,12 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_x3_kernel(WgradX3P p) {
     TileCache tc_halo, tc_dy;
     auto tile_of = [&](TileCache& c, int j, int& b, int& t0, int& f0) {
         if (j != c.j) {
-            int id = slot + j * nslots;
+            int id = ls + j * spt;
             const int fx = id % p.ntf;
             id /= p.ntf;
             c.f0 = fx * 16;
             c.t0 = (id % p.ntt) * 8;
-            c.b = id / p.ntt;
+            c.b = id / p.ntt + task * p.B;                     // (sample index over all tasks: the tensors are contiguous over the tasks)
             c.j = j;
         }
         b = c.b;
@@ -1807,7 +1823,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_x3_kernel(WgradX3P p) {
     if (tid >= NT) {
         // ------------------------------------------------------------------ producers: the x halo AND the dy fragments
         const int ptid = tid - NT;
-        const float sx = NP == 2 ? pow2_scale(amax_read(p.amax_x)) : 1.f, sdy = NP == 2 ? pow2_scale(amax_read(p.amax_dy)) : 1.f;
+        const float sx = NP == 2 ? pow2_scale(amax_read(amax_x)) : 1.f, sdy = NP == 2 ? pow2_scale(amax_read(amax_dy)) : 1.f;
         float4 hv[WX_NVA];
         unsigned okbits = 0;
         // per-thread constants of the halo gather: element i = halo pixel (ht_i, hf_i), channels c4_i; for a tile whose halo lies inside the
@@ -2000,7 +2016,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_x3_kernel(WgradX3P p) {
     }
     if (p.bias_part && cib == 0) __syncthreads();                  // the producers' bias-gradient hand-over (they use LDS once more)
     float* slab = p.partial + (long)slot * 9 * Cin * Cout;
-    const float inv = NP == 2 ? 1.f / (pow2_scale(amax_read(p.amax_x)) * pow2_scale(amax_read(p.amax_dy))) : 1.f;
+    const float inv = NP == 2 ? 1.f / (pow2_scale(amax_read(amax_x)) * pow2_scale(amax_read(amax_dy))) : 1.f;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
@@ -2047,7 +2063,11 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_sp_kernel(WgradX3P p) {
     const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
     const int pair = jb % p.npairs, slot = (jb / p.npairs) * 8 + xcd, nslots = gridDim.x / p.npairs;
     const int cib = (pair / p.npj) * 64, cob = (pair % p.npj) * 64;
-    const int my_tiles = (p.tiles - slot + nslots - 1) / nslots;
+    const int spt = nslots / p.tasks, task = slot / spt, ls = slot - task * spt;      // slots per task, this slot's task and rank in it
+    if (task >= p.tasks) return;
+    const int my_tiles = (p.tiles - ls + spt - 1) / spt;
+    const float* amax_x = p.amax_x + task * p.sAmaxX;
+    const float* amax_dy = p.amax_dy + task * p.sAmaxDy;
     const int T = p.T, F = p.F, Cin = p.Cin, Cout = p.Cout;
     const int npairs_k = my_tiles * 2;                         // pairs of window rows (2 x 32 pixels): the dy hand-over granule
     struct TileCache {
@@ -2056,12 +2076,12 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_sp_kernel(WgradX3P p) {
     TileCache tc_halo, tc_dy;
     auto tile_of = [&](TileCache& c, int j, int& b, int& t0, int& f0) {
         if (j != c.j) {
-            int id = slot + j * nslots;
+            int id = ls + j * spt;
             const int fx = id % p.ntf;
             id /= p.ntf;
             c.f0 = fx * 16;
             c.t0 = (id % p.ntt) * 8;
-            c.b = id / p.ntt;
+            c.b = id / p.ntt + task * p.B;                     // (sample index over all tasks: the tensors are contiguous over the tasks)
             c.j = j;
         }
         b = c.b;
@@ -2072,7 +2092,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_sp_kernel(WgradX3P p) {
     if (tid >= NT) {
         // ------------------------------------------------------------------ producers: the x halo AND the sparse dy fragments
         const int ptid = tid - NT;
-        const float sx = pow2_scale(amax_read(p.amax_x)), sdy = pow2_scale(amax_read(p.amax_dy));
+        const float sx = pow2_scale(amax_read(amax_x)), sdy = pow2_scale(amax_read(amax_dy));
         float4 hv[WX_NVA];
         unsigned okbits = 0;
         // per-thread constants of the halo gather: element i = halo pixel (ht_i, hf_i), channels c4_i; for a tile whose halo lies inside the
@@ -2301,7 +2321,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_sp_kernel(WgradX3P p) {
     }
     if (p.bias_part && cib == 0) __syncthreads();                  // the producers' bias-gradient hand-over (they use LDS once more)
     float* slab = p.partial + (long)slot * 9 * Cin * Cout;
-    const float inv = 1.f / (pow2_scale(amax_read(p.amax_x)) * pow2_scale(amax_read(p.amax_dy)));
+    const float inv = 1.f / (pow2_scale(amax_read(amax_x)) * pow2_scale(amax_read(amax_dy)));
     const int ci = cib + qc * 32 + l31;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
@@ -2642,11 +2662,17 @@ long mtl_conv3x3_wgrad_x3_workspace(int B, int T, int F, int Cin, int Cout, int 
 
 }  // extern "C"
 
+struct WgradTasks {
+    int tasks;
+    long sAmaxX, sAmaxDy, sDw, sDb;
+};
+
 template <int NP>
 static int wgrad_pieces(hipStream_t s, const float* x, const float* amax_x, const float* dy, const float* amax_dy,
                         const unsigned char* argmax, float* dw_ref, float* db, float* workspace, long workspace_bytes, int B, int T,
-                        int F, int Cin, int Cout) {
+                        int F, int Cin, int Cout, WgradTasks tk = WgradTasks{1, 0, 0, 0, 0}) {
     if (!x || !dy || !dw_ref || !workspace || Cin % 64 || Cout % 64 || (NP == 2 && (!amax_x || !amax_dy))) return MTL_EINVAL;
+    if (tk.tasks < 1 || tk.tasks > wgrad_x3_grid(Cin, Cout) / ((Cin / 64) * (Cout / 64))) return MTL_EINVAL;
     const int pooled = argmax != nullptr;
     if (workspace_bytes < mtl_conv3x3_wgrad_x3_workspace(B, T, F, Cin, Cout, pooled)) return MTL_EINVAL;
     WgradX3P p;
@@ -2671,7 +2697,12 @@ static int wgrad_pieces(hipStream_t s, const float* x, const float* amax_x, cons
     p.dbg = 0;
     p.amax_x = amax_x;
     p.amax_dy = amax_dy;
+    p.tasks = tk.tasks;
+    p.sAmaxX = tk.sAmaxX;
+    p.sAmaxDy = tk.sAmaxDy;
     const int grid = wgrad_x3_grid(Cin, Cout);
+    const int spt = grid / p.npairs / tk.tasks;                 // slabs per task
+    const dim3 rgrid((9 * Cin * Cout + (db ? Cout : 0) + 63) / 64, tk.tasks);
     p.bias_part = db ? workspace + (long)(grid / p.npairs) * 9L * Cin * Cout : nullptr;
     constexpr int SMEM = wx_smem(NP);
     if constexpr (NP == 2) {
@@ -2682,8 +2713,7 @@ static int wgrad_pieces(hipStream_t s, const float* x, const float* amax_x, cons
             if (attr_sp) return attr_sp;
             hipLaunchKernelGGL(conv3x3_wgrad_sp_kernel, dim3(grid), dim3(512), wsp_smem(), s, p);
             MTL_CHECK_LAUNCH();
-            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((9 * Cin * Cout + (db ? Cout : 0) + 63) / 64), dim3(1024), 0, s, workspace, dw_ref,
-                               grid / p.npairs, Cin, Cout, p.bias_part, db);
+            hipLaunchKernelGGL(wgrad_reduce_kernel, rgrid, dim3(1024), 0, s, workspace, dw_ref, spt, Cin, Cout, p.bias_part, db, tk.sDw, tk.sDb);
             MTL_CHECK_LAUNCH();
             return MTL_OK;
         }
@@ -2698,13 +2728,19 @@ static int wgrad_pieces(hipStream_t s, const float* x, const float* amax_x, cons
         hipLaunchKernelGGL((conv3x3_wgrad_x3_kernel<false, NP>), dim3(grid), dim3(512), SMEM, s, p);
     }
     MTL_CHECK_LAUNCH();
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((9 * Cin * Cout + (db ? Cout : 0) + 63) / 64), dim3(1024), 0, s, workspace, dw_ref,
-                       grid / p.npairs, Cin, Cout, p.bias_part, db);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, rgrid, dim3(1024), 0, s, workspace, dw_ref, spt, Cin, Cout, p.bias_part, db, tk.sDw, tk.sDb);
     MTL_CHECK_LAUNCH();
     return MTL_OK;
 }
 
 extern "C" {
+
+int mtl_conv3x3_wgrad_h2_tb(void* stream, const float* x, const float* amax_x, const float* dy, const float* amax_dy,
+                            const unsigned char* argmax, float* dw_ref, float* db, float* workspace, long workspace_bytes, int B, int T,
+                            int F, int Cin, int Cout, int tasks, long sAmaxX, long sAmaxDy, long sDw, long sDb) {
+    return wgrad_pieces<2>(as_stream(stream), x, amax_x, dy, amax_dy, argmax, dw_ref, db, workspace, workspace_bytes, B, T, F, Cin, Cout,
+                           WgradTasks{tasks, sAmaxX, sAmaxDy, sDw, sDb});
+}
 
 int mtl_conv3x3_wgrad_x3(void* stream, const float* x, const float* dy, const unsigned char* argmax, float* dw_ref,
                          float* workspace, long workspace_bytes, int B, int T, int F, int Cin, int Cout) {

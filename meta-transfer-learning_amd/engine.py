@@ -287,6 +287,7 @@ class PassEngine:
         self.wgrad_x3_dense = os.environ.get('MTL_WGRAD_X3_DENSE', '1') != '0'    # conv5 (dy not pooled)
         # task-batched passes: the 3x3 forward kernels and the data gradients of conv7 / conv5 as ONE launch over all tasks' samples
         self.conv_tb = os.environ.get('MTL_CONV_TB', '1') != '0'
+        self.conv_tb_wgrad = os.environ.get('MTL_CONV_TB_WGRAD', '1') != '0'      # ... and the weight gradients
         # scaled-dot-product attention as ONE flash-style kernel forward and two backward (no score tensor in HBM); head sizes
         # outside mtl_attn_supported() take the batched-GEMM + softmax path ('0' forces it, for A/B measurements)
         self.fused_attn = (os.environ.get('MTL_FUSED_ATTN', '1') != '0' and device.type == 'cuda'
@@ -1561,12 +1562,13 @@ class PassEngine:
                 check(conv_dgrad(t, dy5[sl].data_ptr(), 4, None, A['wd5'][tw].data_ptr(), p1[sl].data_ptr(), dp1[sl].data_ptr(),
                                  B, T2, F2, 64, 128, ao=5 if f2 else None), 'dgrad5')
 
-        def layer2(t):
+        def layer2(t, wg=True):
             tw, sl = (t if sP else 0), slice(t * B, (t + 1) * B)
             am1_t = A['am1'][sl].data_ptr()
             if not f2:
                 self.colsum(dp1[sl].data_ptr(), B * T2 * F2, 64, g('conv.2.bias', t), am_(5, t))
-            wgrad(t, y1[sl].data_ptr(), 0, dp1[sl].data_ptr(), 5, am1_t, 2, B, T, F, 64, 64, db=g('conv.2.bias', t) if f2 else None)
+            if wg:
+                wgrad(t, y1[sl].data_ptr(), 0, dp1[sl].data_ptr(), 5, am1_t, 2, B, T, F, 64, 64, db=g('conv.2.bias', t) if f2 else None)
             # (conv2's data gradient stays one launch per task: 8 x 16 tiles, measured no faster merged)
             check(conv_dgrad(t, dp1[sl].data_ptr(), 5, am1_t, A['wd2'][tw].data_ptr(), y1[sl].data_ptr(), dy1[sl].data_ptr(),
                              B, T, F, 64, 64), 'dgrad2')
@@ -1574,22 +1576,44 @@ class PassEngine:
             check(lib.mtl_conv0_wgrad(st, xin.data_ptr() + 4 * t * sX, dy1[sl].data_ptr(), g('conv.0.weight', t), g('conv.0.bias', t),
                                       ws, B, T, F), 'wgrad0')
 
+        def wgrad_tb(xa, axi, dy, adi, am, idx, Tq, Fq, cin, cout, db):
+            """the weight (+ bias) gradients of all tasks of one layer in ONE launch (its partial slabs are dealt to the tasks: as many
+            slabs written and reduced as by one single-task launch)"""
+            need = lib.mtl_conv3x3_wgrad_x3_workspace(B, Tq, Fq, cin, cout, 1 if am else 0)
+            ws = self.scratch(need)
+            check(lib.mtl_conv3x3_wgrad_h2_tb(st, xa, am_(axi), dy, am_(adi), am, g('conv.%d.weight' % idx), db, ws, need, B, Tq, Fq, cin, cout,
+                                              nt, AS, AS, sG, sG), 'wgrad_tb')
+
         if merged:
+            w5_h2 = self.conv_x3 and self.wgrad_x3_dense          # (conv5's dy is not pooled: the dense h2 kernel unless switched off)
             for t in range(nt):
-                layer7(t, False)
+                sl = slice(t * B, (t + 1) * B)
+                self.colsum(dp2[sl].data_ptr(), B * T4 * F4, 128, g('conv.7.bias', t), am_(3, t))
+            if self.conv_tb_wgrad:
+                wgrad_tb(y5.data_ptr(), 2, dp2.data_ptr(), 3, A['am2'].data_ptr(), 7, T2, F2, 128, 128, None)
+            else:
+                for t in range(nt):
+                    sl = slice(t * B, (t + 1) * B)
+                    wgrad(t, y5[sl].data_ptr(), 2, dp2[sl].data_ptr(), 3, A['am2'][sl].data_ptr(), 7, B, T2, F2, 128, 128)
             check(lib.mtl_conv3x3_dgrad_h2_tb(st, dp2.data_ptr(), am_(3), A['am2'].data_ptr(), A['wd7'].data_ptr(), y5.data_ptr(), dy5.data_ptr(),
                                               am_(4) if f5 else None, B, T2, F2, 128, 128, nt, swd('wd7'), AS, AS), 'dgrad7')
-            for t in range(nt):
-                layer5(t, False)
+            if w5_h2 and f5 and self.conv_tb_wgrad:
+                wgrad_tb(p1.data_ptr(), 1, dy5.data_ptr(), 4, None, 5, T2, F2, 64, 128, g('conv.5.bias'))
+            else:
+                for t in range(nt):
+                    layer5(t, False)
             check(lib.mtl_conv3x3_dgrad_h2_tb(st, dy5.data_ptr(), am_(4), None, A['wd5'].data_ptr(), p1.data_ptr(), dp1.data_ptr(),
                                               am_(5) if f2 else None, B, T2, F2, 64, 128, nt, swd('wd5'), AS, AS), 'dgrad5')
+            if f2 and self.conv_tb_wgrad:
+                wgrad_tb(y1.data_ptr(), 0, dp1.data_ptr(), 5, A['am1'].data_ptr(), 2, T, F, 64, 64, g('conv.2.bias'))
             for t in range(nt):
-                layer2(t)
+                layer2(t, wg=not (f2 and self.conv_tb_wgrad))
         else:
             for t in range(nt):
                 layer7(t, True)
                 layer5(t, True)
                 layer2(t)
+        # (merged: f2 false -- MTL_WGRAD folding off -- keeps layer 2's weight gradient per task inside layer2)
         self.join_side()
         self.flush_ln_reduce()     # the parameter / bias gradients of all 17 LayerNorms of the pass: one launch (after the join: one of
                                    # the 17 backward kernels ran on the side stream)

@@ -867,6 +867,30 @@ def test_conv3x3_two_piece_fp16_several_tasks_in_one_launch(L, Cin, Cout, B, T, 
         torch.cuda.synchronize()
         assert torch.equal(dx1, dxn) and float(dxn.abs().max()) > 0, ('data gradient', pooled)
         assert torch.equal(ad1.view(nt, -1, 32)[:, :, 0].max(1)[0], adn.view(nt, -1, 32)[:, :, 0].max(1)[0]), ('dx bound', pooled)
+        # weight + bias gradients of all tasks in one launch (mtl_conv3x3_wgrad_h2_tb): the launch's partial slabs are dealt to the tasks,
+        # so a task's pixels are partitioned over fewer slabs than in its own launch -- same arithmetic, another summation tree: equal to
+        # the per-task launches within fp32 rounding (and to fp64 like them), accumulating onto the stack, deterministic
+        if shared_w:
+            need = L.mtl_conv3x3_wgrad_x3_workspace(B, T, Fq, Cin, Cout, 1 if pooled else 0)
+            ws = torch.empty(need // 4 + 64).cuda()
+            dwn, dbn = torch.full((nt, Cout, Cin, 3, 3), 0.5).cuda(), torch.full((nt, Cout), 0.25).cuda()
+            dw1, db1 = dwn.clone(), dbn.clone()
+            for t in range(nt):
+                sl = slice(t * B, (t + 1) * B)
+                assert L.mtl_conv3x3_wgrad_h2(st(), x[sl].data_ptr(), ax[t].data_ptr(), dy[sl].data_ptr(), ady[t].data_ptr(),
+                                              amn[sl].data_ptr() if pooled else None, dwn[t].data_ptr(), dbn[t].data_ptr(), ws.data_ptr(), need,
+                                              B, T, Fq, Cin, Cout) == 0
+            for rep in range(2):
+                dw_, db_ = (dw1, db1) if rep == 0 else (torch.full_like(dw1, 0.5), torch.full_like(db1, 0.25))
+                assert L.mtl_conv3x3_wgrad_h2_tb(st(), x.data_ptr(), ax.data_ptr(), dy.data_ptr(), ady.data_ptr(), amn.data_ptr() if pooled else None,
+                                                 dw_.data_ptr(), db_.data_ptr(), ws.data_ptr(), need, B, T, Fq, Cin, Cout, nt, S, S,
+                                                 dw_[0].numel(), Cout) == 0
+                torch.cuda.synchronize()
+                if rep:
+                    assert torch.equal(dw_, dw1) and torch.equal(db_, db1)          # deterministic
+            for t in range(nt):
+                assert rel(dw1[t] - 0.5, dwn[t] - 0.5) < 3e-6, ('dW', pooled, t, rel(dw1[t] - 0.5, dwn[t] - 0.5))
+                assert rel(db1[t] - 0.25, dbn[t] - 0.25) < 3e-6, ('db', pooled, t)
 
 
 @pytest.mark.parametrize('Cin,Cout,B,T,Fq', [(64, 64, 2, 21, 161), (64, 128, 2, 18, 80), (128, 128, 1, 9, 19)])

@@ -66,3 +66,31 @@ def case(name, T_, F_, cin, cout, pooled, nt=8, B=8):
 case('conv2', 1000, 161, 64, 64, True)
 case('conv5', 500, 80, 64, 128, False)
 case('conv7', 500, 80, 128, 128, True)
+
+
+def wcase(name, T_, F_, cin, cout, pooled, nt=8, B=8):
+    """weight gradients: nt launches over B samples against ONE over nt B samples (same work, one dW instead of nt: the bound of what
+    merging the tasks of a pass into one launch could save)"""
+    x = torch.relu(torch.randn(nt * B, T_, F_, cin, device=dev))
+    Tp, Fp = T_ // 2, F_ // 2
+    shp = (nt * B, Tp, Fp, cout) if pooled else (nt * B, T_, F_, cout)
+    dy = torch.randn(shp, device=dev)
+    am = torch.randint(0, 4, shp, dtype=torch.uint8, device=dev)
+    ax, ady = x.abs().max().reshape(1).repeat(2048), dy.abs().max().reshape(1).repeat(2048)
+    dw = torch.zeros(cout, cin, 3, 3, device=dev); db = torch.zeros(cout, device=dev)
+    def run(b, xs, dys, ams):
+        need = L.mtl_conv3x3_wgrad_x3_workspace(b, T_, F_, cin, cout, 1 if pooled else 0)
+        ws = torch.empty(need // 4 + 64, device=dev)
+        return lambda: L.mtl_conv3x3_wgrad_h2(st(), xs.data_ptr(), ax.data_ptr(), dys.data_ptr(), ady.data_ptr(), ams.data_ptr() if pooled else None, dw.data_ptr(), db.data_ptr(), ws.data_ptr(), need, b, T_, F_, cin, cout)
+    fns = [run(B, x[t * B:], dy[t * B:], am[t * B:]) for t in range(nt)]
+    def per_task():
+        for f in fns:
+            assert f() == 0
+    one = run(nt * B, x, dy, am)
+    a, b = timeit(per_task), timeit(lambda: one())
+    print('%-6s weight gradient: %d launches of B=%d %.3f ms | one launch of B=%d %.3f ms (%+.1f %%)' % (name, nt, B, a, nt * B, b, 100 * (b - a) / a))
+
+
+wcase('conv2', 1000, 161, 64, 64, True)
+wcase('conv5', 500, 80, 64, 128, False)
+wcase('conv7', 500, 80, 128, 128, True)
