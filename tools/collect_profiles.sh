@@ -6,14 +6,16 @@ cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/${ROUND:-r5}
 mkdir -p $O
-python bench.py > $O/bench.json 2> $O/bench.err; cp gpurun_out/bench_detail.json $O/bench_detail.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/serial -o serial -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --serial > $O/bench_serial_traced.json 2> /dev/null
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/lanes -o lanes -- python bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-extras > $O/bench_lanes_traced.json 2> /dev/null
+# counter passes FIRST: bench.py reads profiles/pmc_traffic.json for `roofline.traffic` (per launch, so it must come from the same launch structure)
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras --serial > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras --serial > /dev/null 2>&1
 python tools/pmc_traffic.py $O/pmc_fetch/f_counter_collection.csv $O/pmc_write/w_counter_collection.csv $O/pmc_traffic.json > $O/pmc_traffic.txt 2>&1
 python tools/pmc_summary.py $O/pmc_fetch/f_counter_collection.csv FETCH_SIZE $O/pmc_fetch_size_per_kernel.csv
 python tools/pmc_summary.py $O/pmc_write/w_counter_collection.csv WRITE_SIZE $O/pmc_write_size_per_kernel.csv
+cp $O/pmc_traffic.json profiles/pmc_traffic.json
+python bench.py > $O/bench.json 2> $O/bench.err; cp gpurun_out/bench_detail.json $O/bench_detail.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/serial -o serial -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --serial > $O/bench_serial_traced.json 2> /dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/lanes -o lanes -- python bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-extras > $O/bench_lanes_traced.json 2> /dev/null
 # what ONE rank of the 8-GPU configuration runs (BASELINE.json configs[2]): one task per step
 mkdir -p $O/one_task
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/one_task/trace -o one -- python bench.py --tasks 1 --steps 10 --warmup 3 --no-cpu-baseline --no-extras > $O/one_task/bench_one_task_traced.json 2> /dev/null
