@@ -172,9 +172,17 @@ def classify(lib, name, a, conv_mode, wgrad_x3_dense):
     if name == 'mtl_conv0_relu_fwd':
         B, T, F = a[-4:-1]
         return 'conv0_fwd', 4.0 * B * T * F * (1 + 64), 'byte', 'conv0_fwd_kernel'
+    if name == 'mtl_conv0_relu_fwd_tb':                        # (..., B, T, F, amax_y, tasks, sX, sW, sBias, sAmax)
+        B, T, F, tasks = a[5], a[6], a[7], a[9]
+        return 'conv0_fwd', 4.0 * B * tasks * T * F * (1 + 64), 'byte', 'conv0_fwd_kernel'
     if name == 'mtl_conv0_wgrad':
         B, T, F = a[-3:]
         return 'conv0_wgrad', 4.0 * B * T * F * (1 + 64), 'byte', 'conv0_wgrad_kernel (+ final)'
+    if name == 'mtl_conv0_wgrad_tb':                           # (..., B, T, F, tasks, sX, sDw, sDb)
+        B, T, F, tasks = a[6], a[7], a[8], a[9]
+        return 'conv0_wgrad', 4.0 * B * tasks * T * F * (1 + 64), 'byte', 'conv0_wgrad_kernel (+ final)'
+    if name == 'mtl_colsum_accum_tb':                          # (stream, X, rows, cols, out, ws, amax, tasks, sOut, sAmax)
+        return 'colsum', 4.0 * a[2] * a[3] * a[7], 'byte', 'colsum_partial_vec_kernel + colsum_final_kernel'
     if name in ('mtl_attn_fwd', 'mtl_attn_bwd'):
         causal, B, H, Tq, Tk, dk = a[8], a[10], a[11], a[12], a[13], a[14]
         prods = 2 if name == 'mtl_attn_fwd' else 7            # backward recomputes S: 2 x QK^T, dP, dV, dQ, dK (+ the second S)

@@ -126,6 +126,19 @@ int mtl_conv0_relu_fwd(void* stream, const float* x_ref, const float* w /*(64,1,
 long mtl_conv0_wgrad_workspace(void);
 int mtl_conv0_wgrad(void* stream, const float* x_ref, const float* dy, float* dw /*accum*/, float* db /*accum*/,
                     float* workspace, int B, int T, int F);
+/* conv0 and the conv bias column sums for the batches of `tasks` meta-tasks in one launch (pair) each -- the task-batched passes issue
+ * them once per phase instead of once per task (8 launches of 8 samples: 593 / 527 / 132 us, one launch: 523 / 424 / 55 us).  Task k reads
+ * its input batch at x + k sX floats (0: all tasks see the same batch, the shared validation batch), its weights / bias / output bound at
+ * + k sW / sBias / sAmax floats; y and dy hold tasks * B samples; gradients accumulate onto dw + k sDw, db + k sDb.  Per task bitwise the
+ * single-task calls for the forward; the weight gradient shares the 1024 partial rows of its workspace among the tasks. */
+int mtl_conv0_relu_fwd_tb(void* stream, const float* x, const float* w, const float* bias, float* y, int B, int T, int F, float* amax_y,
+                          int tasks, long sX, long sW, long sBias, long sAmax);
+int mtl_conv0_wgrad_tb(void* stream, const float* x, const float* dy, float* dw, float* db, float* workspace, int B, int T, int F, int tasks,
+                       long sX, long sDw, long sDb);
+/* column sums of `tasks` contiguous row blocks (rows x cols each) in one launch pair; workspace: tasks x mtl_colsum_workspace(rows, cols)
+ * bytes (+ 16 per task); cols = 4 x 2^j <= 256, 16-byte aligned X */
+int mtl_colsum_accum_tb(void* stream, const float* X, long rows, int cols, float* out, float* workspace, float* amax, int tasks, long sOut,
+                        long sAmax);
 /* (Cout,Cin,3,3) -> w_fwd [9][Cin][Cout] and w_dgrad [9][Cout][Cin] (taps rotated 180 degrees) */
 int mtl_conv3x3_wprep(void* stream, const float* w_ref, float* w_fwd, float* w_dgrad, int Cout, int Cin);
 int mtl_conv3x3_relu_fwd(void* stream, const float* x, const float* w_fwd, const float* bias, float* y, int B, int T,

@@ -39,6 +39,9 @@ SIGNATURES = {
     'mtl_conv0_relu_fwd': (I, [P, P, P, P, P, I, I, I, P]),
     'mtl_conv0_wgrad_workspace': (L, []),
     'mtl_conv0_wgrad': (I, [P, P, P, P, P, P, I, I, I]),
+    'mtl_conv0_relu_fwd_tb': (I, [P, P, P, P, P, I, I, I, P, I, L, L, L, L]),
+    'mtl_conv0_wgrad_tb': (I, [P, P, P, P, P, P, I, I, I, I, L, L, L]),
+    'mtl_colsum_accum_tb': (I, [P, P, L, I, P, P, P, I, L, L]),
     'mtl_conv3x3_wprep': (I, [P, P, P, P, I, I]),
     'mtl_conv3x3_relu_fwd': (I, [P, P, P, P, P, I, I, I, I, I]),
     'mtl_conv3x3_relu_pool_fwd': (I, [P, P, P, P, P, P, I, I, I, I, I]),

@@ -662,9 +662,14 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
 // above keeps two 4-byte loads in flight: 1.9 TB/s on the 41 MB conv7 bias sum).  Fixed assignment and order: deterministic.
 template <bool AMAX>
 __global__ __launch_bounds__(256) void colsum_partial_vec_kernel(const float4* __restrict__ X, long rows, int C4, long rows_per_block,
-                                                                 float* __restrict__ part, float* __restrict__ pmax) {
+                                                                 float* __restrict__ part, float* __restrict__ pmax, long sWs = 0) {
     __shared__ float4 sh[256];
     __shared__ float shm[4];
+    if (blockIdx.z) {                                    // task blockIdx.z: its rows behind the previous tasks', its own workspace region
+        X += (long)blockIdx.z * rows * C4;
+        part += blockIdx.z * sWs;
+        pmax += blockIdx.z * sWs;
+    }
     const int tid = threadIdx.x, q = tid & (C4 - 1), ph = tid / C4, nph = 256 / C4;
     const long r0 = (long)blockIdx.y * rows_per_block;
     long r1 = r0 + rows_per_block;
@@ -709,8 +714,15 @@ __global__ __launch_bounds__(256) void colsum_partial_vec_kernel(const float4* _
 }
 // 16 waves per column block: the tall conv-bias sums leave ~1000 partial rows, which 4 waves walked in 126 us
 __global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restrict__ part, int nblk, int cols, float* __restrict__ out,
-                                                            const float* __restrict__ pmax, int npmax, float* __restrict__ amax) {
+                                                            const float* __restrict__ pmax, int npmax, float* __restrict__ amax,
+                                                            long sWs = 0, long sOut = 0, long sAmax = 0) {
     __shared__ float sh[16][64];
+    if (blockIdx.y) {                                    // task blockIdx.y
+        part += blockIdx.y * sWs;
+        pmax += blockIdx.y * sWs;
+        out += blockIdx.y * sOut;
+        if (amax) amax += blockIdx.y * sAmax;
+    }
     if (amax && blockIdx.x == 0) {             // block 0 also reduces the per-block maxima and WRITES the result (no atomics, no reset)
         __shared__ float shm[16];
         float mx = 0.f;
@@ -797,11 +809,21 @@ __device__ __forceinline__ void conv0_stage(const float* __restrict__ x, float* 
     }
 }
 
+// blockIdx.y = task of a task-batched pass (round 5): its B samples of x at + task sX floats (0: every task reads the same batch), of y
+// at + task B T F 64, its weights / bias / bound at + task sW / sBias / sAmax floats
 __global__ __launch_bounds__(256) void conv0_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, float* __restrict__ y, int B, int T,
-                                                        int F, float* __restrict__ amax_y) {
+                                                        int F, float* __restrict__ amax_y, long sX = 0, long sW = 0, long sBias = 0,
+                                                        long sAmax = 0) {
     extern __shared__ __attribute__((aligned(16))) float c0_lds[];          // [C0_NB][F + 2][8]
     const int cg = threadIdx.x & 15, sl = threadIdx.x >> 4;  // channels 4cg..4cg+3, bin slot
+    if (blockIdx.y) {
+        x += blockIdx.y * sX;
+        y += (long)blockIdx.y * B * T * F * 64;
+        w += blockIdx.y * sW;
+        bias += blockIdx.y * sBias;
+        if (amax_y) amax_y += blockIdx.y * sAmax;
+    }
     // this workgroup's slot of the bound, read NOW (a stale value only costs a redundant atomic): read at the end, the round trip
     // sat on the tail of every short-lived workgroup (+24 us per launch)
     float* slot = amax_y ? amax_y + (blockIdx.x & (MTL_AMAX_SLOTS - 1)) * MTL_AMAX_STRIDE : nullptr;
@@ -864,10 +886,16 @@ __global__ __launch_bounds__(256) void conv0_fwd_kernel(const float* __restrict_
 }
 // dw0[c][tap] = sum_pix x[pix+tap]*dy[pix][c], db0[c] = sum_pix dy[pix][c]: per-block partials [blk][64][10].  Same tiling as the
 // forward kernel; a thread keeps the 4 channels x (9 taps + bias) sums of its bin slot as v_pk_fma_f32 pairs.
+// blockIdx.y = task (see conv0_fwd_kernel): x at + task sX, dy at + task B T F 64, its partial rows behind the previous tasks'
 __global__ __launch_bounds__(256) void conv0_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                          float* __restrict__ part, int B, int T, int F) {
+                                                          float* __restrict__ part, int B, int T, int F, long sX = 0) {
     extern __shared__ __attribute__((aligned(16))) float c0_lds[];          // [C0_NB][F + 2][8], re-used for the final [16][64][10]
     const int cg = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    if (blockIdx.y) {
+        x += blockIdx.y * sX;
+        dy += (long)blockIdx.y * B * T * F * 64;
+        part += (long)blockIdx.y * gridDim.x * 640;
+    }
     f32x2 a01[10], a23[10];
 #pragma unroll
     for (int k = 0; k < 10; ++k) a01[k] = a23[k] = f32x2{0.f, 0.f};
@@ -927,7 +955,12 @@ __global__ __launch_bounds__(256) void conv0_wgrad_kernel(const float* __restric
 }
 // one wave per output element: lanes stride the per-block partials, fixed-order shuffle tree
 __global__ __launch_bounds__(256) void conv0_wgrad_final_kernel(const float* __restrict__ part, int nblk, float* __restrict__ dw,
-                                                                float* __restrict__ db) {
+                                                                float* __restrict__ db, long sDw = 0, long sDb = 0) {
+    if (blockIdx.y) {
+        part += (long)blockIdx.y * nblk * 640;
+        dw += blockIdx.y * sDw;
+        db += blockIdx.y * sDb;
+    }
     const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (e >= 640) return;
@@ -1479,6 +1512,29 @@ int mtl_colsum_accum(void* stream, const float* X, long rows, int cols, long ld,
     return MTL_OK;
 }
 
+/* column sums of `tasks` row blocks (rows x cols each, contiguous, ld = cols) in one launch pair: task k accumulates onto out + k sOut and
+ * writes its max|X| to amax + k sAmax; workspace: tasks x mtl_colsum_workspace(rows, cols) bytes.  Needs the 16-byte form (cols = 4 x 2^j <= 256) */
+int mtl_colsum_accum_tb(void* stream, const float* X, long rows, int cols, float* out, float* workspace, float* amax, int tasks, long sOut,
+                        long sAmax) {
+    if (!X || !out || !workspace || rows <= 0 || cols <= 0 || tasks < 1 || tasks > 65535) return MTL_EINVAL;
+    const int c4 = cols / 4;
+    if (cols % 4 || c4 > 64 || (c4 & (c4 - 1)) || (reinterpret_cast<uintptr_t>(X) & 15) || (reinterpret_cast<uintptr_t>(workspace) & 15)) return MTL_EINVAL;
+    long nblk = colsum_chunks(rows, cols);
+    const long rpb = (rows + nblk - 1) / nblk;
+    nblk = (rows + rpb - 1) / rpb;
+    hipStream_t s = as_stream(stream);
+    const int cb = (cols + 63) / 64;
+    const long sWs = (mtl_colsum_workspace(rows, cols) / 4 + 3) / 4 * 4;          // floats per task, 16-byte aligned
+    float* pmax = workspace + colsum_chunks(rows, cols) * cols;
+    if (amax)
+        hipLaunchKernelGGL(colsum_partial_vec_kernel<true>, dim3(1, (unsigned)nblk, tasks), dim3(256), 0, s, reinterpret_cast<const float4*>(X), rows, c4, rpb, workspace, pmax, sWs);
+    else
+        hipLaunchKernelGGL(colsum_partial_vec_kernel<false>, dim3(1, (unsigned)nblk, tasks), dim3(256), 0, s, reinterpret_cast<const float4*>(X), rows, c4, rpb, workspace, pmax, sWs);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cb, tasks), dim3(1024), 0, s, workspace, (int)nblk, cols, out, pmax, (int)nblk, amax, sWs, sOut, sAmax);
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}
+
 int mtl_conv0_relu_fwd(void* stream, const float* x, const float* w, const float* bias, float* y, int B, int T, int F, float* amax_y) {
     if (!x || !w || !bias || !y) return MTL_EINVAL;
     const long lds = (long)C0_NB * (F + 2) * C0_ROW * 4;
@@ -1490,7 +1546,33 @@ int mtl_conv0_relu_fwd(void* stream, const float* x, const float* w, const float
     return MTL_OK;
 }
 
+int mtl_conv0_relu_fwd_tb(void* stream, const float* x, const float* w, const float* bias, float* y, int B, int T, int F, float* amax_y,
+                          int tasks, long sX, long sW, long sBias, long sAmax) {
+    if (!x || !w || !bias || !y || tasks < 1 || tasks > 65535) return MTL_EINVAL;
+    const long lds = (long)C0_NB * (F + 2) * C0_ROW * 4;
+    if (B <= 0 || T <= 0 || F <= 0 || lds > 64 * 1024) return MTL_EINVAL;
+    const long tiles = (long)B * ((T + C0_TB - 1) / C0_TB);
+    hipLaunchKernelGGL(conv0_fwd_kernel, dim3((unsigned)std::min<long>((tiles + C0_NB - 1) / C0_NB, 4096), tasks), dim3(256), (size_t)lds,
+                       as_stream(stream), x, w, bias, y, B, T, F, amax_y, sX, sW, sBias, sAmax);
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}
+
 long mtl_conv0_wgrad_workspace(void) { return 1024L * 640 * 4; }
+
+int mtl_conv0_wgrad_tb(void* stream, const float* x, const float* dy, float* dw, float* db, float* workspace, int B, int T, int F, int tasks,
+                       long sX, long sDw, long sDb) {
+    if (!x || !dy || !dw || !db || !workspace || tasks < 1 || tasks > 256) return MTL_EINVAL;
+    const long lds = std::max<long>((long)C0_NB * (F + 2) * C0_ROW * 4, 16L * 640 * 4);
+    if (B <= 0 || T <= 0 || F <= 0 || lds > 64 * 1024) return MTL_EINVAL;
+    const long tiles = (long)B * ((T + C0_TB - 1) / C0_TB);
+    const int nb = (int)std::min<long>((tiles + C0_NB - 1) / C0_NB, 1024 / tasks);      // the tasks share the 1024 partial rows of the workspace
+    hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL(conv0_wgrad_kernel, dim3(nb, tasks), dim3(256), (size_t)lds, s, x, dy, workspace, B, T, F, sX);
+    hipLaunchKernelGGL(conv0_wgrad_final_kernel, dim3(160, tasks), dim3(256), 0, s, workspace, nb, dw, db, sDw, sDb);
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}
 
 int mtl_conv0_wgrad(void* stream, const float* x, const float* dy, float* dw, float* db, float* workspace, int B, int T, int F) {
     if (!x || !dy || !dw || !db || !workspace) return MTL_EINVAL;

@@ -1139,9 +1139,13 @@ class PassEngine:
         if h2:
             check(lib.mtl_memset_zero(st, amax.data_ptr(), nt * 12 * 4 * _lib.AMAX_SLOTS), 'mtl_memset_zero')
         xp = lambda t: x.data_ptr() + 4 * t * sX
-        for t in range(nt):
-            check(lib.mtl_conv0_relu_fwd(st, xp(t), o('conv.0.weight', t), o('conv.0.bias', t), y1[t * B:].data_ptr(), B, T, F,
-                                         am_(0, t)), 'conv0')
+        if nt > 1 and self.conv_tb:      # every task's samples in one launch (task = grid dimension; sX = 0: the shared validation batch)
+            check(lib.mtl_conv0_relu_fwd_tb(st, x.data_ptr(), o('conv.0.weight'), o('conv.0.bias'), y1.data_ptr(), B, T, F, am_(0), nt, sX,
+                                            sP, sP, 12 * _lib.AMAX_SLOTS), 'conv0')
+        else:
+            for t in range(nt):
+                check(lib.mtl_conv0_relu_fwd(st, xp(t), o('conv.0.weight', t), o('conv.0.bias', t), y1[t * B:].data_ptr(), B, T, F,
+                                             am_(0, t)), 'conv0')
         wf, wd = {}, {}
         wprep = lib.mtl_conv3x3_wprep_h2 if h2 else (lib.mtl_conv3x3_wprep_x3 if x3 else lib.mtl_conv3x3_wprep)
         if h2:
@@ -1562,7 +1566,7 @@ class PassEngine:
                 check(conv_dgrad(t, dy5[sl].data_ptr(), 4, None, A['wd5'][tw].data_ptr(), p1[sl].data_ptr(), dp1[sl].data_ptr(),
                                  B, T2, F2, 64, 128, ao=5 if f2 else None), 'dgrad5')
 
-        def layer2(t, wg=True):
+        def layer2(t, wg=True, w0=True):
             tw, sl = (t if sP else 0), slice(t * B, (t + 1) * B)
             am1_t = A['am1'][sl].data_ptr()
             if not f2:
@@ -1572,9 +1576,10 @@ class PassEngine:
             # (conv2's data gradient stays one launch per task: 8 x 16 tiles, measured no faster merged)
             check(conv_dgrad(t, dp1[sl].data_ptr(), 5, am1_t, A['wd2'][tw].data_ptr(), y1[sl].data_ptr(), dy1[sl].data_ptr(),
                              B, T, F, 64, 64), 'dgrad2')
-            ws = self.scratch(lib.mtl_conv0_wgrad_workspace())
-            check(lib.mtl_conv0_wgrad(st, xin.data_ptr() + 4 * t * sX, dy1[sl].data_ptr(), g('conv.0.weight', t), g('conv.0.bias', t),
-                                      ws, B, T, F), 'wgrad0')
+            if w0:
+                ws = self.scratch(lib.mtl_conv0_wgrad_workspace())
+                check(lib.mtl_conv0_wgrad(st, xin.data_ptr() + 4 * t * sX, dy1[sl].data_ptr(), g('conv.0.weight', t), g('conv.0.bias', t),
+                                          ws, B, T, F), 'wgrad0')
 
         def wgrad_tb(xa, axi, dy, adi, am, idx, Tq, Fq, cin, cout, db):
             """the weight (+ bias) gradients of all tasks of one layer in ONE launch (its partial slabs are dealt to the tasks: as many
@@ -1586,9 +1591,9 @@ class PassEngine:
 
         if merged:
             w5_h2 = self.conv_x3 and self.wgrad_x3_dense          # (conv5's dy is not pooled: the dense h2 kernel unless switched off)
-            for t in range(nt):
-                sl = slice(t * B, (t + 1) * B)
-                self.colsum(dp2[sl].data_ptr(), B * T4 * F4, 128, g('conv.7.bias', t), am_(3, t))
+            per = ((lib.mtl_colsum_workspace(B * T4 * F4, 128) // 4 + 3) // 4 * 4) * 4
+            check(lib.mtl_colsum_accum_tb(st, dp2.data_ptr(), B * T4 * F4, 128, g('conv.7.bias'), self.scratch(nt * per + 64), am_(3), nt, sG, AS),
+                  'colsum_tb')
             if self.conv_tb_wgrad:
                 wgrad_tb(y5.data_ptr(), 2, dp2.data_ptr(), 3, A['am2'].data_ptr(), 7, T2, F2, 128, 128, None)
             else:
@@ -1607,7 +1612,10 @@ class PassEngine:
             if f2 and self.conv_tb_wgrad:
                 wgrad_tb(y1.data_ptr(), 0, dp1.data_ptr(), 5, A['am1'].data_ptr(), 2, T, F, 64, 64, g('conv.2.bias'))
             for t in range(nt):
-                layer2(t, wg=not (f2 and self.conv_tb_wgrad))
+                layer2(t, wg=not (f2 and self.conv_tb_wgrad), w0=False)
+            ws = self.scratch(lib.mtl_conv0_wgrad_workspace())
+            check(lib.mtl_conv0_wgrad_tb(st, xin.data_ptr(), dy1.data_ptr(), g('conv.0.weight'), g('conv.0.bias'), ws, B, T, F, nt, sX, sG, sG),
+                  'wgrad0_tb')
         else:
             for t in range(nt):
                 layer7(t, True)

@@ -806,6 +806,57 @@ def test_conv3x3_two_piece_fp16_dynamic_range_inside_one_tensor(L, k):
     assert loud < 1e-6 and quiet < bound, (k, loud, quiet, bound)
 
 
+@pytest.mark.parametrize('nt,B,T,Fq,shared_x,shared_w', [(3, 2, 37, 161, False, True), (8, 2, 50, 40, True, False), (5, 3, 21, 80, False, False)])
+def test_conv0_and_bias_sums_for_several_tasks_in_one_launch(L, nt, B, T, Fq, shared_x, shared_w):
+    """mtl_conv0_relu_fwd_tb / mtl_conv0_wgrad_tb / mtl_colsum_accum_tb (task = a grid dimension; the shared validation batch is a zero
+    input stride, theta0 a zero weight stride) against the per-task calls: forward, output bounds and column sums bit for bit; the
+    weight gradient within fp32 rounding (the tasks share the workspace's partial rows) and deterministic."""
+    g = torch.Generator().manual_seed(nt + B + T)
+    S = 2048
+    nx, nw = (1 if shared_x else nt), (1 if shared_w else nt)
+    x = (torch.randn(nx, B, 1, Fq, T, generator=g) * torch.tensor([2.0 ** k for k in range(nx)]).view(-1, 1, 1, 1, 1)).cuda()
+    w = (torch.randn(nw, 64, 1, 3, 3, generator=g) * 0.3).cuda()
+    b = (torch.randn(nw, 64, generator=g) * 0.1).cuda()
+    xi, wi = (lambda t: 0 if shared_x else t), (lambda t: 0 if shared_w else t)
+    yn, y1 = torch.zeros(nt * B, T, Fq, 64).cuda(), torch.zeros(nt * B, T, Fq, 64).cuda()
+    an, a1 = torch.zeros(nt, S).cuda(), torch.zeros(nt, S).cuda()
+    for t in range(nt):
+        assert L.mtl_conv0_relu_fwd(st(), x[xi(t)].data_ptr(), w[wi(t)].data_ptr(), b[wi(t)].data_ptr(), yn[t * B:].data_ptr(), B, T, Fq, an[t].data_ptr()) == 0
+    assert L.mtl_conv0_relu_fwd_tb(st(), x.data_ptr(), w.data_ptr(), b.data_ptr(), y1.data_ptr(), B, T, Fq, a1.data_ptr(), nt,
+                                   0 if shared_x else x[0].numel(), 0 if shared_w else 576, 0 if shared_w else 64, S) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(y1, yn) and float(yn.abs().max()) > 0
+    assert torch.equal(a1.view(nt, -1, 32)[:, :, 0].max(1)[0], an.view(nt, -1, 32)[:, :, 0].max(1)[0])
+    dy = torch.randn(nt * B, T, Fq, 64, generator=g).cuda()
+    ws = torch.empty(L.mtl_conv0_wgrad_workspace() // 4).cuda()
+    dwn, dbn = torch.full((nt, 64, 9), 0.5).cuda(), torch.full((nt, 64), 0.25).cuda()
+    for t in range(nt):
+        assert L.mtl_conv0_wgrad(st(), x[xi(t)].data_ptr(), dy[t * B:].data_ptr(), dwn[t].data_ptr(), dbn[t].data_ptr(), ws.data_ptr(), B, T, Fq) == 0
+    outs = []
+    for rep in range(2):
+        dw1, db1 = torch.full((nt, 64, 9), 0.5).cuda(), torch.full((nt, 64), 0.25).cuda()
+        assert L.mtl_conv0_wgrad_tb(st(), x.data_ptr(), dy.data_ptr(), dw1.data_ptr(), db1.data_ptr(), ws.data_ptr(), B, T, Fq, nt,
+                                    0 if shared_x else x[0].numel(), 576, 64) == 0
+        torch.cuda.synchronize()
+        outs.append((dw1, db1))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    for t in range(nt):
+        assert rel(outs[0][0][t] - 0.5, dwn[t] - 0.5) < 3e-6 and rel(outs[0][1][t] - 0.25, dbn[t] - 0.25) < 3e-6, t
+    # bias column sums of nt row blocks (+ their max|X|)
+    rows, cols = B * (T // 4) * (Fq // 4) + 3, 128
+    X = torch.randn(nt, rows, cols, generator=g).cuda()
+    per = ((L.mtl_colsum_workspace(rows, cols) // 4 + 3) // 4 * 4) * 4
+    cws = torch.empty(nt * per // 4 + 16).cuda()
+    on, o1 = torch.full((nt, 700), 1.5).cuda(), torch.full((nt, 700), 1.5).cuda()
+    mn, m1 = torch.zeros(nt, S).cuda(), torch.zeros(nt, S).cuda()
+    for t in range(nt):
+        assert L.mtl_colsum_accum(st(), X[t].data_ptr(), rows, cols, cols, on[t].data_ptr(), cws.data_ptr(), mn[t].data_ptr()) == 0
+    assert L.mtl_colsum_accum_tb(st(), X.data_ptr(), rows, cols, o1.data_ptr(), cws.data_ptr(), m1.data_ptr(), nt, 700, S) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(o1, on) and torch.equal(m1, mn) and rel(o1[:, :cols] - 1.5, X.sum(1)) < 2e-5
+    assert bool((o1[:, cols:] == 1.5).all())
+
+
 @pytest.mark.parametrize('Cin,Cout,B,T,Fq,nt', [(64, 64, 2, 37, 161, 3), (64, 128, 3, 34, 80, 4), (128, 128, 2, 50, 40, 5), (64, 64, 8, 96, 161, 8)])
 @pytest.mark.parametrize('shared_w', [True, False])
 def test_conv3x3_two_piece_fp16_several_tasks_in_one_launch(L, Cin, Cout, B, T, Fq, nt, shared_w):
