@@ -183,6 +183,11 @@ int mtl_conv3x3_wprep_h2(void* stream, const float* w_ref, void* w2_fwd, void* w
 /* the same for n <= 3 layers with one call (the pass prepares conv2 / conv5 / conv7 together); unused triples are ignored */
 int mtl_conv3x3_wprep_h2_batch(void* stream, int n, const float* w0, void* f0, void* d0, int Cout0, int Cin0, const float* w1, void* f1,
                                void* d1, int Cout1, int Cin1, const float* w2, void* f2, void* d2, int Cout2, int Cin2);
+/* ... and for `sets` parameter sets (the theta' stack of a task-batched validation pass) with the same two launches: set z reads its
+ * weights at w_i + z sSrc floats and writes its prepared blocks at f_i / d_i + z sDst_i BYTES (multiples of 4) */
+int mtl_conv3x3_wprep_h2_batch_tb(void* stream, int n, const float* w0, void* f0, void* d0, int Cout0, int Cin0, const float* w1, void* f1,
+                                  void* d1, int Cout1, int Cin1, const float* w2, void* f2, void* d2, int Cout2, int Cin2, int sets,
+                                  long sSrc, long sDst0, long sDst1, long sDst2);
 int mtl_conv3x3_relu_fwd_h2(void* stream, const float* x, const float* amax_x, const void* w2_fwd, const float* bias, float* y,
                             float* amax_y, int B, int T, int F, int Cin, int Cout);
 int mtl_conv3x3_relu_pool_fwd_h2(void* stream, const float* x, const float* amax_x, const void* w2_fwd, const float* bias,
@@ -212,6 +217,8 @@ int mtl_conv3x3_wgrad_h2_tb(void* stream, const float* x, const float* amax_x, c
                             int F, int Cin, int Cout, int tasks, long sAmaxX, long sAmaxDy, long sDw, long sDb);
 /* amax[MTL_AMAX_FLOATS]: slot heads raised so that their maximum is >= max|x[0..n)| (atomic; zero them first) */
 int mtl_absmax_f32(void* stream, const float* x, long n, float* amax);
+/* the same for `tasks` tensors of n floats at x + k sX, bound k at amax + k sAmax floats, one launch */
+int mtl_absmax_f32_tb(void* stream, const float* x, long n, float* amax, int tasks, long sX, long sAmax);
 long mtl_conv3x3_wgrad_workspace(int B, int T, int F, int Cin, int Cout, int pooled);
 /* dw_ref (Cout,Cin,3,3) += sum_pixels x (x) dy ; dy dense (B,T,F,Cout) or pooled + argmax as above. */
 int mtl_conv3x3_wgrad(void* stream, const float* x, const float* dy, const unsigned char* argmax, float* dw_ref,

@@ -1449,7 +1449,12 @@ int mtl_ce_bwd(void* stream, const float* logits, const float* lse, const long* 
     return mtl_ce_bwd_g(stream, logits, lse, gold, rows, V, ld, pad_id, smoothing, gscale, gscale_dev, dlogits, ldd, rows > 0 ? rows : 1);
 }
 
-__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long n, float* __restrict__ amax) {
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long n, float* __restrict__ amax, long sX = 0,
+                                                     long sAmax = 0) {
+    if (blockIdx.y) {                           // tensor blockIdx.y of a strided batch (the tasks of a task-batched pass)
+        x += blockIdx.y * sX;
+        amax += blockIdx.y * sAmax;
+    }
     float mx = 0.f;
     const long n4 = n >> 2;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
@@ -1476,6 +1481,14 @@ int mtl_absmax_f32(void* stream, const float* x, long n, float* amax) {
     if (!x || !amax || n <= 0) return MTL_EINVAL;
     if (reinterpret_cast<uintptr_t>(x) & 15) return MTL_EINVAL;
     hipLaunchKernelGGL(absmax_kernel, dim3(grid_for(n / 4 + 1, 256, 1024)), dim3(256), 0, as_stream(stream), x, n, amax);
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}
+
+int mtl_absmax_f32_tb(void* stream, const float* x, long n, float* amax, int tasks, long sX, long sAmax) {
+    if (!x || !amax || n <= 0 || tasks < 1 || tasks > 65535 || (sX & 3)) return MTL_EINVAL;
+    if (reinterpret_cast<uintptr_t>(x) & 15) return MTL_EINVAL;
+    hipLaunchKernelGGL(absmax_kernel, dim3(grid_for(n / 4 + 1, 256, 1024), tasks), dim3(256), 0, as_stream(stream), x, n, amax, sX, sAmax);
     MTL_CHECK_LAUNCH();
     return MTL_OK;
 }

@@ -2429,10 +2429,13 @@ struct WprepBatch {
     unsigned short* wf[3];
     unsigned short* wd[3];
     int Cout[3], Cin[3];
+    long sSrc, sDst[3];      // parameter set blockIdx.z (the theta' stack): weights at + z sSrc floats, prepared blocks at + z sDst[L] BYTES
 };
 __global__ __launch_bounds__(256) void conv_wscale_batch_kernel(WprepBatch b) {
     __shared__ float sh[4];
     const int L = blockIdx.y, total = 9 * b.Cin[L] * b.Cout[L];
+    b.w[L] += blockIdx.z * b.sSrc;
+    b.wf[L] = reinterpret_cast<unsigned short*>(reinterpret_cast<unsigned char*>(b.wf[L]) + blockIdx.z * b.sDst[L]);
     const float* w = b.w[L];
     float mx = 0.f;
     for (int e = (blockIdx.x * 256 + threadIdx.x) * 4; e < total; e += WSCALE_PARTS * 1024) {
@@ -2446,9 +2449,9 @@ __global__ __launch_bounds__(256) void conv_wscale_batch_kernel(WprepBatch b) {
 }
 __global__ void conv_wprep_h2_batch_kernel(WprepBatch b) {
     const int L = blockIdx.y, Cin = b.Cin[L], Cout = b.Cout[L];
-    const float* w = b.w[L];
-    unsigned short* wf = b.wf[L];
-    unsigned short* wd = b.wd[L];
+    const float* w = b.w[L] + blockIdx.z * b.sSrc;
+    unsigned short* wf = reinterpret_cast<unsigned short*>(reinterpret_cast<unsigned char*>(b.wf[L]) + blockIdx.z * b.sDst[L]);
+    unsigned short* wd = reinterpret_cast<unsigned short*>(reinterpret_cast<unsigned char*>(b.wd[L]) + blockIdx.z * b.sDst[L]);
     const int total = 9 * Cin * Cout;
     const int nkf = 9 * (Cin / 32), nkd = 9 * (Cout / 32);
     float* hf = reinterpret_cast<float*>(wf + 2L * total);
@@ -2535,25 +2538,41 @@ int mtl_conv3x3_dgrad_x3(void* stream, const float* dy, const unsigned char* arg
     return conv_dgrad_pieces<3>(as_stream(stream), dy, nullptr, argmax, w3_dgrad, act, dx, nullptr, B, T, F, Cin, Cout);
 }
 
-int mtl_conv3x3_wprep_h2_batch(void* stream, int n, const float* w0, void* f0, void* d0, int Cout0, int Cin0, const float* w1, void* f1,
-                               void* d1, int Cout1, int Cin1, const float* w2, void* f2, void* d2, int Cout2, int Cin2) {
-    if (n < 1 || n > 3) return MTL_EINVAL;
+static int wprep_h2_batch_sets(void* stream, int n, const float* w0, void* f0, void* d0, int Cout0, int Cin0, const float* w1, void* f1,
+                               void* d1, int Cout1, int Cin1, const float* w2, void* f2, void* d2, int Cout2, int Cin2, int sets, long sSrc,
+                               long sDst0, long sDst1, long sDst2) {
+    if (n < 1 || n > 3 || sets < 1 || sets > 65535) return MTL_EINVAL;
     WprepBatch b{{w0, w1, w2},
                  {reinterpret_cast<unsigned short*>(f0), reinterpret_cast<unsigned short*>(f1), reinterpret_cast<unsigned short*>(f2)},
                  {reinterpret_cast<unsigned short*>(d0), reinterpret_cast<unsigned short*>(d1), reinterpret_cast<unsigned short*>(d2)},
                  {Cout0, Cout1, Cout2},
-                 {Cin0, Cin1, Cin2}};
+                 {Cin0, Cin1, Cin2},
+                 sSrc,
+                 {sDst0, sDst1, sDst2}};
     long tmax = 0;
     for (int i = 0; i < n; ++i) {
         if (!b.w[i] || !b.wf[i] || !b.wd[i] || b.Cin[i] % 32 || b.Cout[i] % 32 || b.Cin[i] <= 0 || b.Cout[i] <= 0) return MTL_EINVAL;
+        if (sets > 1 && ((b.sDst[i] & 3) || (sSrc & 3))) return MTL_EINVAL;
         const long t = 9L * b.Cin[i] * b.Cout[i];
         tmax = t > tmax ? t : tmax;
     }
     hipStream_t s = as_stream(stream);
-    hipLaunchKernelGGL(conv_wscale_batch_kernel, dim3(WSCALE_PARTS, n), dim3(256), 0, s, b);
-    hipLaunchKernelGGL(conv_wprep_h2_batch_kernel, dim3(grid_for(tmax, 256, 256), n), dim3(256), 0, s, b);
+    hipLaunchKernelGGL(conv_wscale_batch_kernel, dim3(WSCALE_PARTS, n, sets), dim3(256), 0, s, b);
+    hipLaunchKernelGGL(conv_wprep_h2_batch_kernel, dim3(grid_for(tmax, 256, 256), n, sets), dim3(256), 0, s, b);
     MTL_CHECK_LAUNCH();
     return MTL_OK;
+}
+
+int mtl_conv3x3_wprep_h2_batch(void* stream, int n, const float* w0, void* f0, void* d0, int Cout0, int Cin0, const float* w1, void* f1,
+                               void* d1, int Cout1, int Cin1, const float* w2, void* f2, void* d2, int Cout2, int Cin2) {
+    return wprep_h2_batch_sets(stream, n, w0, f0, d0, Cout0, Cin0, w1, f1, d1, Cout1, Cin1, w2, f2, d2, Cout2, Cin2, 1, 0, 0, 0, 0);
+}
+
+int mtl_conv3x3_wprep_h2_batch_tb(void* stream, int n, const float* w0, void* f0, void* d0, int Cout0, int Cin0, const float* w1, void* f1,
+                                  void* d1, int Cout1, int Cin1, const float* w2, void* f2, void* d2, int Cout2, int Cin2, int sets,
+                                  long sSrc, long sDst0, long sDst1, long sDst2) {
+    return wprep_h2_batch_sets(stream, n, w0, f0, d0, Cout0, Cin0, w1, f1, d1, Cout1, Cin1, w2, f2, d2, Cout2, Cin2, sets, sSrc, sDst0, sDst1,
+                               sDst2);
 }
 
 long mtl_conv3x3_wprep_h2_bytes(int Cout, int Cin) { return 2L * 9 * Cin * Cout * 2 + 4 * (1 + WSCALE_PARTS) + 12; }

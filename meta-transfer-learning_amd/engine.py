@@ -1172,7 +1172,12 @@ class PassEngine:
             if not h2:
                 for t in range(ntw):
                     check(wprep(st, o('conv.%d.weight' % idx, t), wf[idx][t].data_ptr(), wd[idx][t].data_ptr(), cout, cin), 'wprep')
-        if h2:          # all three layers: one call (two launches) per parameter set
+        if h2 and ntw > 1 and self.conv_tb:      # all three layers of ALL parameter sets (the theta' stack): one call (two launches)
+            spec = []
+            for idx, cin, cout in ((2, 64, 64), (5, 64, 128), (7, 128, 128)):
+                spec += [o('conv.%d.weight' % idx), wf[idx].data_ptr(), wd[idx].data_ptr(), cout, cin]
+            check(lib.mtl_conv3x3_wprep_h2_batch_tb(st, 3, *spec, ntw, sP, wf[2].stride(0), wf[5].stride(0), wf[7].stride(0)), 'wprep')
+        elif h2:        # all three layers: one call (two launches) per parameter set
             for t in range(ntw):
                 spec = []
                 for idx, cin, cout in ((2, 64, 64), (5, 64, 128), (7, 128, 128)):
@@ -1489,7 +1494,9 @@ class PassEngine:
         amax = A['amax']
         am_ = (lambda i, t=0: amax.data_ptr() + 4 * _lib.AMAX_SLOTS * (12 * t + i)) if h2 else (lambda i, t=0: None)   # y1, p1, y5 | dp2, dy5, dp1
         am_st = 12 * _lib.AMAX_SLOTS
-        if self.in_h2:
+        if self.in_h2 and nt > 1 and self.conv_tb:
+            check(lib.mtl_absmax_f32_tb(st, de0.data_ptr(), Me * d, am_(8), nt, Me * d, am_st), 'mtl_absmax_f32')
+        elif self.in_h2:
             for t in range(nt):
                 check(lib.mtl_absmax_f32(st, de0[t * Me:].data_ptr(), Me * d, am_(8, t)), 'mtl_absmax_f32')
         if self.in_h2 and self.in_wgrad_h2:      # dW = de0^T . p2 on fp16 pairs too: both bounds (slots 8, 6) exist for the data gradient below

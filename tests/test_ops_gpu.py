@@ -806,6 +806,40 @@ def test_conv3x3_two_piece_fp16_dynamic_range_inside_one_tensor(L, k):
     assert loud < 1e-6 and quiet < bound, (k, loud, quiet, bound)
 
 
+def test_weight_preparation_and_bounds_for_several_parameter_sets(L):
+    """mtl_conv3x3_wprep_h2_batch_tb (all three layers of the theta' stack in two launches) and mtl_absmax_f32_tb (the bounds of nt
+    tensors in one launch) against the per-set calls: bit for bit."""
+    g = torch.Generator().manual_seed(77)
+    nt, total = 5, 4 * 30001
+    theta = (torch.randn(nt, total, generator=g) * torch.tensor([3.0 ** k for k in range(nt)]).view(-1, 1)).cuda()
+    layers = ((64, 64, 0), (128, 64, 36864 + 16), (128, 128, 36864 + 16 + 73728 + 32))        # (Cout, Cin, offset of the weight in theta)
+    nbs = [(L.mtl_conv3x3_wprep_h2_bytes(co, ci) + 255) // 256 * 256 for co, ci, _ in layers]
+    fn = [torch.zeros(nt, nb, dtype=torch.uint8).cuda() for nb in nbs]; dn = [torch.zeros(nt, nb, dtype=torch.uint8).cuda() for nb in nbs]
+    f1 = [torch.zeros(nt, nb, dtype=torch.uint8).cuda() for nb in nbs]; d1 = [torch.zeros(nt, nb, dtype=torch.uint8).cuda() for nb in nbs]
+    for t in range(nt):
+        spec = []
+        for i, (co, ci, off) in enumerate(layers):
+            spec += [theta[t, off:].data_ptr(), fn[i][t].data_ptr(), dn[i][t].data_ptr(), co, ci]
+        assert L.mtl_conv3x3_wprep_h2_batch(st(), 3, *spec) == 0
+    spec = []
+    for i, (co, ci, off) in enumerate(layers):
+        spec += [theta[0, off:].data_ptr(), f1[i].data_ptr(), d1[i].data_ptr(), co, ci]
+    assert L.mtl_conv3x3_wprep_h2_batch_tb(st(), 3, *spec, nt, total, nbs[0], nbs[1], nbs[2]) == 0
+    torch.cuda.synchronize()
+    for i, (co, ci, _) in enumerate(layers):
+        used = L.mtl_conv3x3_wprep_h2_bytes(co, ci) - 12
+        assert torch.equal(f1[i][:, :used], fn[i][:, :used]) and torch.equal(d1[i][:, :used], dn[i][:, :used]), i
+        assert int(f1[i][:, :used].sum()) != 0
+    S = 2048
+    an, a1 = torch.zeros(nt, S).cuda(), torch.zeros(nt, S).cuda()
+    for t in range(nt):
+        assert L.mtl_absmax_f32(st(), theta[t].data_ptr(), total - 1, an[t].data_ptr()) == 0
+    assert L.mtl_absmax_f32_tb(st(), theta.data_ptr(), total - 1, a1.data_ptr(), nt, total, S) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(a1.view(nt, -1, 32)[:, :, 0].max(1)[0], an.view(nt, -1, 32)[:, :, 0].max(1)[0])
+    assert torch.equal(a1.view(nt, -1, 32)[:, :, 0].max(1)[0].cpu(), theta[:, :total - 1].abs().max(1)[0].cpu())
+
+
 @pytest.mark.parametrize('nt,B,T,Fq,shared_x,shared_w', [(3, 2, 37, 161, False, True), (8, 2, 50, 40, True, False), (5, 3, 21, 80, False, False)])
 def test_conv0_and_bias_sums_for_several_tasks_in_one_launch(L, nt, B, T, Fq, shared_x, shared_w):
     """mtl_conv0_relu_fwd_tb / mtl_conv0_wgrad_tb / mtl_colsum_accum_tb (task = a grid dimension; the shared validation batch is a zero
