@@ -655,6 +655,7 @@ def main():
     ap.add_argument('--dropout', type=float, default=0.0, help='diagnostics: run the headline region and the serial profile with this dropout rate (the extras always report 0.1)')
     ap.add_argument('--lanes', action='store_true', help='per-task pass chains on concurrent lanes instead of task-batched passes (MTL_BATCH_TASKS=0)')
     ap.add_argument('--serial', action='store_true', help='no task lanes / side stream / replay (for rocprofv3 per-kernel durations)')
+    ap.add_argument('--host-inputs', action='store_true', help='diagnostics: the headline region with every batch uploaded from pinned host memory per step (what the `with_h2d` leg measures)')
     ap.add_argument('--workload', default='asr', choices=['asr', 'lm'], help="'lm': the LSTM-LM meta loop (BASELINE.json configs[4], SURVEY 8(f) f3)")
     a = ap.parse_args()
 
@@ -698,6 +699,8 @@ def main():
     inner, outer = mtl_amd.FlatSGD(model, args.lr), mtl_amd.FlatAdam(model, args.meta_lr)
     model.zero_copy_grad()
     tasks = [ResidentTask(mtl_amd, m, a.k, a.frames, a.labels, CFG['vocab_size'], dev) for m in range(a.tasks)]
+    if a.host_inputs:
+        tasks = [PinnedHostTask(mtl_amd, m, a.k, a.frames, a.labels, CFG['vocab_size']) for m in range(a.tasks)]
     my_tasks = mdist.shard_tasks(a.tasks, rank, world)
 
     # ---- setup: two iterations that allocate the buffer pool and record the command list (what a graph capture is elsewhere), so that
@@ -817,7 +820,8 @@ def main():
                                         % (a.tasks, len(my_tasks), a.k, a.frames, a.labels),
                                setup='%d untimed iterations before the warm-up (buffer pool and read-back buffer allocation, command-list recording)' % n_setup,
                                tasks=a.tasks, k_train=a.k, src_frames=a.frames, tgt_len=a.labels, parallelism='task-sharded dp%d' % world,
-                               collective=mdist.backend_name(), ranks=world, inputs='resident in HBM before the timed region',
+                               collective=mdist.backend_name(), ranks=world,
+                               inputs='uploaded from pinned host memory inside the timed span (--host-inputs)' if a.host_inputs else 'resident in HBM before the timed region',
                                schedule=('serial, ' if a.serial else '') + (
                                    'the %d local tasks as ONE task-batched pass per phase (training passes at theta0, validation passes at the theta\' stack)'
                                    % len(my_tasks) if (trainer.batch_tasks and len(my_tasks) > 1) else '%d task lanes' % model.n_lanes) + (
