@@ -1,4 +1,5 @@
-"""x3 engine, wave-specialised form: K-step anatomy by runtime ablation (MTL_GEMM_X3_WSDBG bits: 2 no fetch after the prologue, 4 no
+"""(Needs tools/probe/gemm_x3_wave_specialised.patch applied to csrc/mtl_gemm_x3.hip: the production library has no MTL_GEMM_X3_WS switch.)
+x3 engine, wave-specialised form: K-step anatomy by runtime ablation (MTL_GEMM_X3_WSDBG bits: 2 no fetch after the prologue, 4 no
 split / commit, 8 no fragment reads / MFMAs) on a few shapes of the batched pass.  usage: python tools/probe/bench_x3_ws.py"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
