@@ -1618,7 +1618,7 @@ class PassEngine:
                                               am_(5) if f2 else None, B, T2, F2, 64, 128, nt, swd('wd5'), AS, AS), 'dgrad5')
             if f2 and self.conv_tb_wgrad:
                 wgrad_tb(y1.data_ptr(), 0, dp1.data_ptr(), 5, A['am1'].data_ptr(), 2, T, F, 64, 64, g('conv.2.bias'))
-            for t in range(nt):
+            for t in range(nt):       # (conv2's data gradient merged as well: 52.23 / 52.63 / 52.83 against 52.03 / 52.18 / 52.92 ms per step: no gain)
                 layer2(t, wg=not (f2 and self.conv_tb_wgrad), w0=False)
             ws = self.scratch(lib.mtl_conv0_wgrad_workspace())
             check(lib.mtl_conv0_wgrad_tb(st, xin.data_ptr(), dy1.data_ptr(), g('conv.0.weight'), g('conv.0.bias'), ws, B, T, F, nt, sX, sG, sG),
