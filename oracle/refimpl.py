@@ -370,7 +370,7 @@ def clip_(grads, max_norm):
     return grads
 
 
-def meta_gradient(model, task_batches, val_batch, alpha, max_norm=None, gates=None):
+def meta_gradient(model, task_batches, val_batch, alpha, max_norm=None, gates=None, n_tasks=None):
     """G = sum_m [ grad L_tr,m(theta0) + (1/n) grad L_val(theta0 - alpha grad L_tr,m(theta0)) ]  (SURVEY Q1).
 
     task_batches: list of (x, lengths, y); val_batch: (x, lengths, y).  Restores theta0 before returning.
@@ -378,11 +378,13 @@ def meta_gradient(model, task_batches, val_batch, alpha, max_norm=None, gates=No
     clipped tensor is what stays in .grad.
     gates: optional list of 2n gate dicts (SpeechTransformer.conv_stack), one per forward in execution order (task 0 train,
     task 0 valid, task 1 train, ...): replays the device path's ReLU / max-pool decisions.
+    n_tasks: the GLOBAL task count when task_batches are only one rank's share of a sharded meta-step (the 1/n of :226 is global:
+    n = len(train_data_list)); default: len(task_batches).
     Returns (G list per parameter, [tr losses], [val losses], [(gold, hyp) of every forward]).
     """
     params = list(model.parameters())
     theta0 = [p.detach().clone() for p in params]
-    n = len(task_batches)
+    n = n_tasks or len(task_batches)
     G = [torch.zeros_like(p) for p in params]
     tr_losses, val_losses, labels = [], [], []
     for m_, (x, lens, y) in enumerate(task_batches):

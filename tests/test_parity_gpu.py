@@ -279,6 +279,39 @@ def test_meta_gradient_at_north_star_size_with_branch_replay(n_tasks, conv):
     assert len(errs) == 190 and errs[worst] < RTOL, (worst, errs[worst])
 
 
+def test_one_local_task_of_eight_at_north_star_size_against_live_oracle():
+    """What ONE rank of BASELINE.json configs[2] computes (8 tasks sharded one per GPU, SURVEY 8(e), transient_trainer.py:178-237): its
+    single local task with the GLOBAL n = 8 in the validation term -- the lane schedule (no task batching), its local share
+    G_r = g_tr + g_val / 8 against the live oracle with the device's branch decisions replayed: 190/190 tensors within 1e-4, labels
+    bit-exact.  (The sum over ranks is the all-reduce: tests/test_dist_gloo.py.)"""
+    from oracle import refimpl as R
+    from oracle import branches
+    z, cfg, spec = gu.load('NS')
+    mtl_amd, args, vocab, model = make(cfg, spec)
+    model = model.cuda()
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    oracle = R.build_model(cfg)
+    m = 5                                                        # the task rank 5 owns
+    tr = R.synth_batch(10 * m, spec['k'], spec['T'], spec['L'], cfg['vocab_size'], False)
+    val = R.synth_batch(10 * 7 + 1, spec['k'], spec['T'], spec['L'], cfg['vocab_size'], False)      # the LAST task's validation batch
+    inner = mtl_amd.FlatSGD(model, spec['lr'])
+    model.zero_copy_grad()
+    as5 = lambda b: (b[0], b[1], None, b[2], None)
+    trainer = mtl_amd.TransientTrainer()
+    with branches.capture_gates(model) as log:
+        reads = trainer.meta_iteration(model, vocab, [as5(tr)], as5(val), 8, inner, None, args)
+        torch.cuda.synchronize()
+    assert len(log) == 2 and len(reads) == 1
+    G_r, trl, val_l, labels = R.meta_gradient(oracle, [tr], val, spec['lr'], gates=log, n_tasks=8)
+    for rd, (gold, hyp), loss in ((reads[0][0], labels[0], trl[0]), (reads[0][1], labels[1], val_l[0])):
+        assert torch.equal(rd.hyp, hyp) and torch.equal(rd.gold_host, gold)
+        assert abs(float(rd.loss[0]) - loss) < RTOL * loss
+    errs = _rel_errs(model, model._G, oracle, G_r)
+    worst = max(errs, key=errs.get)
+    print('NS one local task of 8: %d/%d tensors within 1e-4, worst %.2e (%s)' % (sum(e < RTOL for e in errs.values()), len(errs), errs[worst], worst))
+    assert len(errs) == 190 and errs[worst] < RTOL, (worst, errs[worst])
+
+
 def test_dropin_autograd_api_matches_oracle():
     """pred,gold,hyp = model(...); loss,_ = calculate_metrics(...); loss.backward() -- the reference's own call pattern."""
     from oracle import refimpl as R
