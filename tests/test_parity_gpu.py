@@ -493,6 +493,37 @@ def test_two_ranks_sharded_bench_equals_single_rank():
     assert j2['theta_checksum'] == j3['theta_checksum'] and j2['last_step'] == j3['last_step'], (j2['theta_checksum'], j3['theta_checksum'])
 
 
+@pytest.mark.parametrize('world,tasks', [(4, 8), (8, 8)])
+def test_sharded_bench_at_four_and_eight_ranks_on_one_gpu(world, tasks):
+    """BASELINE.json configs[2]'s partitioning with the ranks sharing this box's single GPU over gloo: 8 tasks on 4 ranks (2 per rank: the
+    task-batched schedule with the slice hooks) and on 8 ranks (ONE task per rank: the lane schedule a rank of the 8-GPU node runs) must
+    reproduce the single-process step (labels / CER counts equal, loss within 1e-4), report the rank count and the per-rank step times
+    in the `multi_gpu` block, and leave bit-identical replicas."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ['--steps', '2', '--warmup', '1', '--tasks', str(tasks), '--k', '2', '--frames', '120', '--labels', '12', '--no-cpu-baseline']
+    env = dict(os.environ, MTL_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0', MTL_POOL_GB='2')
+    one = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--no-extras'] + common, capture_output=True, text=True,
+                         env=env, timeout=300)
+    assert one.returncode == 0, one.stderr[-2000:]
+    many = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world), '--master-addr',
+                           '127.0.0.1', '--master-port', str(29750 + world), os.path.join(root, 'bench.py'), '--gpus', str(world)] + common,
+                          capture_output=True, text=True, env=env, timeout=600)
+    assert many.returncode == 0, many.stderr[-3000:]
+    j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith('{')][-1])
+    jn = json.loads([l for l in many.stdout.splitlines() if l.startswith('{')][-1])
+    assert jn['n_gpus'] == world and jn['scaling'] == 'strong' and jn['config']['collective'] == 'gloo'
+    mg = jn['multi_gpu']
+    assert mg['ranks'] == world and mg['replicas_bit_identical'] is True and mg['tasks_per_rank'] == [tasks // world] * world
+    assert len(mg['per_rank_ms_per_step']) == world and all(t > 0 for t in mg['per_rank_ms_per_step'])
+    assert j1['last_step']['chars'] == jn['last_step']['chars'] and j1['last_step']['cer_edits'] == jn['last_step']['cer_edits']
+    assert abs(j1['last_step']['val_loss'] - jn['last_step']['val_loss']) < 1e-4 * abs(j1['last_step']['val_loss'])
+    assert len(many.stdout.strip().splitlines()[-1]) < 4096
+
+
 def test_dropout_pass_matches_oracle_with_the_same_masks():
     """--dropout 0.1 (README config): the keep-masks the HIP pass drew are replayed inside the oracle, so
     forward and backward must agree exactly like the dropout-free pass (the masks themselves come from Philox, not from
