@@ -219,6 +219,12 @@ int mtl_conv3x3_wgrad_h2_tb(void* stream, const float* x, const float* amax_x, c
 int mtl_absmax_f32(void* stream, const float* x, long n, float* amax);
 /* the same for `tasks` tensors of n floats at x + k sX, bound k at amax + k sAmax floats, one launch */
 int mtl_absmax_f32_tb(void* stream, const float* x, long n, float* amax, int tasks, long sX, long sAmax);
+/* Several tasks' batches of different frame counts in ONE pass, padded to the widest (data.py collate pads every task's batch to its OWN
+ * longest utterance, transient_trainer.py:178-237 runs them one by one): y is (n, T, row) floats, sample s belongs to task s / per_task and
+ * its frames [widths[task] >> shift, T) are cleared, so that the next convolution meets the zero border of the task's own image and the
+ * ReLU gates of the backward hold every gradient out of them.  widths: `n / per_task` ints on the device (full-resolution frame counts;
+ * shift = 1 after the first pooling).  row % 4 == 0, y 16-byte aligned. */
+int mtl_zero_tails(void* stream, float* y, int n, int T, int row, const int* widths, int shift, int per_task);
 long mtl_conv3x3_wgrad_workspace(int B, int T, int F, int Cin, int Cout, int pooled);
 /* dw_ref (Cout,Cin,3,3) += sum_pixels x (x) dy ; dy dense (B,T,F,Cout) or pooled + argmax as above. */
 int mtl_conv3x3_wgrad(void* stream, const float* x, const float* dy, const unsigned char* argmax, float* dw_ref,

@@ -1493,6 +1493,27 @@ int mtl_absmax_f32_tb(void* stream, const float* x, long n, float* amax, int tas
     return MTL_OK;
 }
 
+// Tasks of different widths in one batch padded to the widest: y is (n, T, row) floats, sample s belongs to task s / per_task, and its
+// frames [widths[task] >> shift, T) are cleared -- the next 3x3 convolution then sees the zero border the task's own (narrower) image
+// ends in, and the ReLU gates of the backward (act > 0) keep every gradient out of those frames.
+__global__ void __launch_bounds__(256) zero_tails_kernel(float* __restrict__ y, long T, long row, const int* __restrict__ widths, int shift,
+                                                         int per_task) {
+    const long s = blockIdx.y;
+    long t0 = widths[s / per_task] >> shift;
+    t0 = t0 < T ? t0 : T;
+    const long n4 = (T - t0) * row / 4;
+    float4* p = reinterpret_cast<float4*>(y + (s * T + t0) * row);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+int mtl_zero_tails(void* stream, float* y, int n, int T, int row, const int* widths, int shift, int per_task) {
+    if (!y || !widths || n < 1 || n > 65535 || T < 1 || row < 4 || (row & 3) || shift < 0 || shift > 8 || per_task < 1) return MTL_EINVAL;
+    if (reinterpret_cast<uintptr_t>(y) & 15) return MTL_EINVAL;
+    hipLaunchKernelGGL(zero_tails_kernel, dim3(32, n), dim3(256), 0, as_stream(stream), y, (long)T, (long)row, widths, shift, per_task);
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}
+
 long mtl_colsum_workspace(long rows, int cols) {
     const long chunks = colsum_chunks(rows, cols);
     return chunks * cols * 4 + chunks * ((cols + 63) / 64) * 4;       // partial sums + per-block maxima

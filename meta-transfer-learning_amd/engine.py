@@ -218,6 +218,25 @@ STAGE_RING = 6      # pinned staging buffers per slot (prepare_tasks): > pipelin
 _LAYER_BUF = re.compile(r'^([de])(\d+)\.(.+)$')
 
 
+_POOL_ACCOUNTS = {}
+
+
+def _pool_account(device):
+    """Bytes held by the buffer pools of every engine on one device, and the budget they share (MTL_POOL_GB)."""
+    key = (device.type, device.index)
+    acc = _POOL_ACCOUNTS.get(key)
+    if acc is None:
+        gb = os.environ.get('MTL_POOL_GB')
+        if gb is not None:
+            budget = int(float(gb) * (1 << 30))
+        elif device.type == 'cuda':
+            budget = max(torch.cuda.get_device_properties(device).total_memory // 4, 4 << 30)
+        else:
+            budget = 4 << 30
+        acc = _POOL_ACCOUNTS[key] = dict(bytes=0, budget=budget)
+    return acc
+
+
 class PassEngine:
     def __init__(self, layout, hp, device, pe_enc, pe_dec):
         self.pe_enc, self.pe_dec = pe_enc, pe_dec   # (max_len, d) fp32 device tables (non-trainable buffers)
@@ -229,10 +248,13 @@ class PassEngine:
         self.pool = {}      # (name, shape, dtype) -> allocation, so alternating batch shapes do not re-allocate
         # Real manifests bring a new (T, Td) with almost every batch (collate pads to the batch maximum; padding further would change
         # results: the reference masks with RAW frame counts).  The pool is therefore bounded: entries carry the number
-        # of the last pass that touched them, and trim_pool() -- start of every forward -- drops the least recently used ones
-        # beyond MTL_POOL_GB (default 48 GiB of the 288) that neither this pass nor the previous one uses.  An eviction bumps
+        # of the last pass that touched them, and trim_pool() -- start of every forward -- drops the least recently used ones that
+        # neither this pass nor the previous one uses while the pools of ALL engines on this device (a model has one per task lane)
+        # together hold more than MTL_POOL_GB (default: a quarter of the device's memory, 72 GiB of the 288; a budget per engine let
+        # eight lanes keep 8 x 48 GiB of stale shapes and ran a north-star run on ragged batches out of memory).  An eviction bumps
         # scratch_epoch, which makes the trainer re-record its command lists (they hold raw addresses).
-        self.pool_budget = int(float(os.environ.get('MTL_POOL_GB', '48')) * (1 << 30))
+        self.account = _pool_account(device)
+        self.pool_budget = self.account['budget']           # (an engine may be given a tighter one of its own: tests)
         self._pool_gen, self._pool_bytes, self._gen = {}, 0, 0
         self.saved = None
         self.gemm_ws = torch.empty(8 << 20, dtype=torch.float32, device=device) if device.type == 'cuda' else None  # split-K slabs
@@ -301,6 +323,16 @@ class PassEngine:
             raise RuntimeError('PassEngine needs an MI355X device (got %s); there is no CPU product path' % device)
 
     # ---------------------------------------------------------------- plumbing
+    def _took(self, nbytes):
+        self._pool_bytes += nbytes
+        self.account['bytes'] += nbytes
+
+    def __del__(self):
+        try:
+            self.account['bytes'] -= self._pool_bytes     # the device-wide account outlives the engine
+        except Exception:
+            pass
+
     def buf(self, name, shape, dtype=torch.float32):
         """Named buffer of the current pass.  Per-layer buffers ('d<i>.<what>', 'e<i>.<what>') are slices of ONE allocation per
         <what> with the layers at a constant stride -- 'dec_in.y' / 'enc_in.y' are slot 0 of the '<x>.ff.y' group, so that every
@@ -318,7 +350,7 @@ class PassEngine:
                 if grp is None:
                     grp = torch.empty(key[1], dtype=dtype, device=self.device)
                     self.pool[key] = grp
-                    self._pool_bytes += grp.numel() * grp.element_size()
+                    self._took(grp.numel() * grp.element_size())
                 self._pool_gen[key] = self._gen
                 t = grp[slot]
                 self.arena[name] = t
@@ -328,7 +360,7 @@ class PassEngine:
         if t is None:
             t = torch.empty(key[1], dtype=dtype, device=self.device)
             self.pool[key] = t
-            self._pool_bytes += t.numel() * t.element_size()
+            self._took(t.numel() * t.element_size())
         self._pool_gen[key] = self._gen
         self.arena[name] = t
         return t
@@ -338,18 +370,26 @@ class PassEngine:
         passes did not touch (a forward and its backward, and the pass a pipelined host has already enqueued, keep theirs).
         Frees go back to torch's caching allocator in stream order: the side stream was joined at the end of the backward."""
         self._gen += 1
-        if self._pool_bytes <= self.pool_budget:
+        if len(self._wgrad_tables) + len(self._ln_tables) > 512:
+            # descriptor tables are keyed by addresses AND extents: ragged batches bring new ones with every pass.  Recorded command
+            # lists hold the tables' addresses, hence the epoch.
+            self._wgrad_tables.clear()
+            self._ln_tables.clear()
+            self.wgrad_flops.clear()
+            self.scratch_epoch += 1
+        over = lambda: self._pool_bytes > self.pool_budget or self.account['bytes'] > self.account['budget']
+        if not over():
             return 0
         if torch.cuda.is_current_stream_capturing():
             return 0                      # a free inside a hipGraph capture would be baked into the graph: trim at the next eager pass
         freed = 0
         for key in sorted(self.pool, key=lambda k: self._pool_gen.get(k, 0)):
-            if self._pool_bytes <= self.pool_budget or self._pool_gen.get(key, 0) >= self._gen - 2:
+            if not over() or self._pool_gen.get(key, 0) >= self._gen - 2:
                 break
             t = self.pool.pop(key)
             self._pool_gen.pop(key, None)
             nb = t.numel() * t.element_size()
-            self._pool_bytes -= nb
+            self._took(-nb)
             freed += nb
         if freed:
             # device tables keyed by buffer addresses (weight-gradient groups, LayerNorm reductions, transposes) and the pinned
@@ -962,14 +1002,24 @@ class PassEngine:
         a captured hipGraph of the pass can be replayed for any batch of the same shape."""
         return self.prepare_tasks([(lengths, target)], B, T, slot, norm_count, width)
 
-    def prepare_tasks(self, batches, B, T, slot=0, norm_count=None, width=None):
+    def prepare_tasks(self, batches, B, T, slot=0, norm_count=None, width=None, frames=None):
         """prepare() for the batches [(lengths, target)] of several tasks that one task-batched pass carries (all B samples x T
         frames; the decoder width is the largest of the tasks' -- positions beyond a task's own width are padding like any other:
         masked as keys, zeroed as rows, ignored by the loss).  Everything per-sample is concatenated in task order; the loss
-        normaliser 1 / n_nonpad and the embedding occurrence chains are per task."""
+        normaliser 1 / n_nonpad and the embedding occurrence chains are per task.
+        frames: the tasks' OWN frame counts when their batches were padded to different widths (data.py:77 pads a batch to its
+        longest utterance) and stacked at the widest, T.  A task's encoder then has (frames // 2) // 2 positions as in its own
+        pass: the positions beyond are padding (the reference compares RAW lengths with the positions it has, SURVEY Q2, so a wider
+        pad would otherwise turn into live positions), and forward_device clears the convolution outputs beyond each task's frames."""
         hp = self.hp
         nt = len(batches)
         T4 = (T // 2) // 2
+        if frames is not None:
+            frames = [int(f) for f in frames]
+            if len(frames) != nt or max(frames) > T or min(frames) < 4:
+                raise ValueError('frames: one count per task, none above the padded width')
+            if all(f == T for f in frames):
+                frames = None
         ios = [decoder_io(target, width=width) for _lengths, target in batches]
         Td = max(io[0].shape[1] for io in ios)
         if nt > 1 and any(io[0].shape[1] != Td for io in ios):
@@ -984,6 +1034,8 @@ class PassEngine:
             if seq_in.shape[0] != B:
                 raise ValueError('every task of a batched pass must bring %d samples' % B)
             lens = lengths.detach().to('cpu', torch.int64).numpy()
+            if frames is not None:
+                lens = np.minimum(lens, (frames[ti] // 2) // 2)     # a position the task's own pass does not have is padding
             is_pad = seq_in == EOS_ID
             dec_len = (~is_pad).sum(1)
             if not bool((is_pad == (dpos >= dec_len[:, None])).all()):
@@ -1017,7 +1069,8 @@ class PassEngine:
         meta_np = np.concatenate([
             torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).numpy().view(np.int32),   # dropout seed of this pass (torch CPU RNG), 8-byte aligned
             np.asarray(inv, dtype=np.float32).view(np.int32),                            # 1/n_nonpad (fp32 bits), per task
-            np.zeros(head - 2 - nt, dtype=np.int32)] + klen_e + klen_d + keep_e + keep_d + firsts + nexts)
+            np.zeros(head - 2 - nt, dtype=np.int32)] + klen_e + klen_d + keep_e + keep_d + firsts + nexts
+            + ([np.asarray(frames, dtype=np.int32)] if frames is not None else []))
         n_meta = int(meta_np.shape[0])
         seq_in = torch.cat([io[0] for io in ios]) if nt > 1 else ios[0][0]
         seq_out = torch.cat([io[1] for io in ios]) if nt > 1 else ios[0][1]
@@ -1065,7 +1118,8 @@ class PassEngine:
         keep_dec = keep_enc + 4 * Bt * T4
         embed_first = keep_dec + 4 * Bt * Td
         embed_next = embed_first + 4 * Bt * Td
-        return dict(seed=seed, B=B, T=T, Td=Td, nt=nt, n_nonpad=n_nonpads[0], n_nonpads=n_nonpads, gold_host=seq_out,
+        widths = embed_next + 4 * Bt * Td if frames is not None else None
+        return dict(frames=frames, widths=widths, seed=seed, B=B, T=T, Td=Td, nt=nt, n_nonpad=n_nonpads[0], n_nonpads=n_nonpads, gold_host=seq_out,
                     gold_hosts=[io[1] for io in ios], ids=ids, klen_enc=klen_enc, klen_dec=klen_dec,
                     keep_enc=keep_enc, keep_dec=keep_dec, embed_first=embed_first, embed_next=embed_next, inv_count=inv_count)
 
@@ -1146,6 +1200,13 @@ class PassEngine:
             for t in range(nt):
                 check(lib.mtl_conv0_relu_fwd(st, xp(t), o('conv.0.weight', t), o('conv.0.bias', t), y1[t * B:].data_ptr(), B, T, F,
                                              am_(0, t)), 'conv0')
+        # tasks of different frame counts stacked at the widest (prepare_tasks(frames=...)): every convolution output that another
+        # convolution reads is cleared beyond its task's own frames, which is the zero border the task's own pass has there; p2's tail
+        # rows are encoder padding (keep_enc = 0: nothing reads them, no gradient reaches them)
+        widths = meta.get('widths')
+        tails = (lambda buf_, T_, row_, shift_: check(lib.mtl_zero_tails(st, buf_.data_ptr(), Bt, T_, row_, widths, shift_, B), 'mtl_zero_tails')) \
+            if widths is not None else (lambda *a_: None)
+        tails(y1, T, F * 64, 0)
         wf, wd = {}, {}
         wprep = lib.mtl_conv3x3_wprep_h2 if h2 else (lib.mtl_conv3x3_wprep_x3 if x3 else lib.mtl_conv3x3_wprep)
         if h2:
@@ -1196,10 +1257,14 @@ class PassEngine:
             sw = lambda idx: wf[idx].stride(0) if ntw > 1 else 0
             check(lib.mtl_conv3x3_relu_pool_fwd_h2_tb(st, y1.data_ptr(), am_(0), wf[2].data_ptr(), o('conv.2.bias'), p1.data_ptr(), am1.data_ptr(),
                                                       am_(1), B, T, F, 64, 64, nt, sw(2), sP, AS, AS), 'conv2')
+            tails(p1, T2, F2 * 64, 1)
             check(lib.mtl_conv3x3_relu_fwd_h2_tb(st, p1.data_ptr(), am_(1), wf[5].data_ptr(), o('conv.5.bias'), y5.data_ptr(), am_(2),
                                                  B, T2, F2, 64, 128, nt, sw(5), sP, AS, AS), 'conv5')
+            tails(y5, T2, F2 * 128, 1)
             check(lib.mtl_conv3x3_relu_pool_fwd_h2_tb(st, y5.data_ptr(), am_(2), wf[7].data_ptr(), o('conv.7.bias'), p2.data_ptr(), am2.data_ptr(),
                                                       am_(6), B, T2, F2, 128, 128, nt, sw(7), sP, AS, AS), 'conv7')
+        elif widths is not None:
+            raise RuntimeError('per-task frame counts in one pass need the merged two-piece-fp16 convolution launches (MTL_CONV_TB=1, h2)')
         else:
           for t in range(nt):
             tw, sl = (t if sP else 0), slice(t * B, (t + 1) * B)

@@ -352,6 +352,14 @@ class TransientTrainer():
         # the local tasks of a meta-step as ONE task-batched pass per phase (training passes at theta0, validation passes at the
         # theta' stack) instead of one pass chain per task on concurrent lanes; MTL_BATCH_TASKS=0: the lanes
         self.batch_tasks = os.environ.get('MTL_BATCH_TASKS', '1') != '0'
+        # tasks whose batches have different frame counts in one pass, stacked at the widest (0: one lane per task), as long as the
+        # tasks' frames fill at least this share of the stack
+        self.batch_ragged = os.environ.get('MTL_BATCH_RAGGED', '1') != '0'
+        self.ragged_fill = float(os.environ.get('MTL_RAGGED_FILL', '0.6'))
+        # ... and the stack's width (training and validation) rounded up to a multiple of this many frames: any width at or above the
+        # widest task is exact (every task keeps its own border), and widths that repeat keep the buffer pool's allocations -- 11 GB
+        # per width at the north-star size, otherwise re-allocated for every new widest utterance -- and the recorded command lists
+        self.ragged_quantum = int(os.environ.get('MTL_RAGGED_QUANTUM', '64'))
         # train() enqueues iteration i + 1 before it resolves (logs) iteration i (enqueue_iteration); MTL_PIPELINE=0: resolve at once
         self.pipeline = os.environ.get('MTL_PIPELINE', '1') != '0'
         # how many iterations may be enqueued beyond the one being resolved (nothing the host needs to enqueue an iteration comes
@@ -405,8 +413,12 @@ class TransientTrainer():
         if (len(task_batches) == 1 and model.n_lanes >= 2 and self.split_single_task and not use_graphs
                 and task_batches[0][0].shape[0] >= 2 and val_batch[0].shape[0] >= 2
                 and not any(e.prof is not None for e in model.engines)):
+            self.last_schedule = 'split'
             return self._single_task_split(model, task_batches[0], val_batch, n_tasks, inner, args, use_cmdlists)
+        self.last_schedule = 'lanes'                         # (diagnostics / tests: which schedule the last iteration took)
         if self._can_batch(model, task_batches, val_batch, use_graphs):
+            frames = [int(tb[0].shape[3]) for tb in task_batches]
+            self.last_schedule = 'batched' if min(frames) == max(frames) else 'batched-ragged'
             return self._batched_iteration(model, task_batches, val_batch, n_tasks, inner, args, smoothing, use_cmdlists)
         n_lanes = min(model.n_lanes, max(len(task_batches), 1))
         if len(task_batches) > n_lanes:                      # several rounds: equal rounds (8 tasks on 6 lanes measured slower than on 3)
@@ -484,8 +496,21 @@ class TransientTrainer():
         eng = model.engines[0]
         if not eng.fused_attn or eng.group_wgrads or eng.after_conv_hook is not None:
             return False
+        if val_batch[0].dim() != 4 or any(tb[0].dim() != 4 for tb in task_batches):
+            return False
         shape = tuple(task_batches[0][0].shape)
-        return all(tuple(tb[0].shape) == shape and tb[0].dim() == 4 for tb in task_batches) and val_batch[0].dim() == 4
+        if all(tuple(tb[0].shape) == shape for tb in task_batches):
+            return True
+        # manifest-fed batches: every task's batch is padded to its OWN longest utterance (data.py:77), so the frame counts differ.
+        # They are stacked at the widest (engine.prepare_tasks(frames=...) keeps each task's own image border and encoder length) as
+        # long as the padding does not outweigh what one pass for all tasks saves over a lane per task (which, on shapes that never
+        # repeat, is enqueued call by call: ~88 ms of host time per 8-task north-star step against ~55 ms of kernels).
+        if not self.batch_ragged or not (eng.conv_h2 and eng.conv_tb):
+            return False
+        if any(tuple(tb[0].shape[:3]) != shape[:3] for tb in task_batches):
+            return False
+        frames = [int(tb[0].shape[3]) for tb in task_batches]
+        return min(frames) >= 4 and sum(frames) >= self.ragged_fill * len(frames) * max(frames)
 
     def _batched_iteration(self, model, task_batches, val_batch, n_tasks, inner, args, smoothing, use_cmdlists):
         """trainer/asr/transient_trainer.py:178-237 for all local tasks at once.  The tasks of a meta-step are independent given
@@ -500,7 +525,15 @@ class TransientTrainer():
         nt = len(task_batches)
         total = model._layout.total
         B, _, F, T = task_batches[0][0].shape
+        frames = [int(tb[0].shape[3]) for tb in task_batches]
+        T = max(frames)
+        ragged = min(frames) != T
         vx_in = val_batch[0]
+        Tv = Tv_own = int(vx_in.shape[3])
+        if ragged and self.ragged_quantum > 1:
+            q, most = self.ragged_quantum, 4 * eng.hp.src_max_len            # (the positional table bounds the encoder length)
+            T = max(min(-(-T // q) * q, most), T)
+            Tv = max(min(-(-Tv // q) * q, most), Tv)
         key_b = (id(theta0), nt)
         if getattr(self, '_stack_key', None) != key_b:
             self._stack = (torch.zeros(nt * total, dtype=torch.float32, device=dev), torch.empty(nt * total, dtype=torch.float32, device=dev))
@@ -514,10 +547,19 @@ class TransientTrainer():
         # device copy has run (`_xfree`).  Device-resident inputs are copied straight into the static buffers.
         main = torch.cuda.current_stream(dev)
         Xtr = eng.buf('tb.x_tr', (nt * B, 1, F, T))
-        Xva = eng.buf('tb.x_va', tuple(vx_in.shape))
+        Xva = eng.buf('tb.x_va', tuple(vx_in.shape[:3]) + (Tv,))
         _trace.mark('setup')
         on_host = not vx_in.is_cuda or any(not tb[0].is_cuda for tb in task_batches)
-        if on_host and self.overlap_uploads:
+        if ragged:
+            # every task's frames at the front of its slab, zeros behind them (the border its own, narrower image ends in)
+            Xtr.zero_()
+            X5 = Xtr.view(nt, B, 1, F, T)
+            for t, (tx, _tsz, _tp, _ty, _tl) in enumerate(task_batches):
+                X5[t, :, :, :, :frames[t]].copy_(tx if tx.is_cuda else tx.to(dev, non_blocking=True), non_blocking=True)
+            if Tv != Tv_own:
+                Xva.zero_()
+            Xva[:, :, :, :Tv_own].copy_(vx_in if vx_in.is_cuda else vx_in.to(dev, non_blocking=True), non_blocking=True)
+        elif on_host and self.overlap_uploads:
             xs = self._xset = (getattr(self, '_xset', 0) + 1) % 2
             if getattr(self, '_upload_stream', None) is None:
                 self._upload_stream, self._xfree = torch.cuda.Stream(dev), {}
@@ -548,8 +590,8 @@ class TransientTrainer():
                 Xtr[t * B:(t + 1) * B].copy_(tx, non_blocking=True)
             Xva.copy_(vx_in, non_blocking=True)
         _trace.mark('input_copies')
-        m_tr = eng.prepare_tasks([(tsz, ty) for (_tx, tsz, _tp, ty, _tl) in task_batches], B, T, slot=0)
-        m_va = eng.prepare_tasks([(val_batch[1], val_batch[3])] * nt, vx_in.shape[0], vx_in.shape[3], slot=1)
+        m_tr = eng.prepare_tasks([(tsz, ty) for (_tx, tsz, _tp, ty, _tl) in task_batches], B, T, slot=0, frames=frames if ragged else None)
+        m_va = eng.prepare_tasks([(val_batch[1], val_batch[3])] * nt, vx_in.shape[0], Tv, slot=1, frames=[Tv_own] * nt if Tv != Tv_own else None)
         _trace.mark('prepare_tasks')
         Bv = vx_in.shape[0]
         slots = dict(hyp_tr=eng.buf('slot.hyp_tr', (nt * B, m_tr['Td']), torch.int64), loss_tr=eng.buf('slot.loss_tr', (nt,)),
@@ -579,7 +621,7 @@ class TransientTrainer():
             if chunk is None:
                 check(eng.lib.mtl_sum_tasks(eng.stream, G.data_ptr(), g.data_ptr(), total, nt, 0), 'mtl_sum_tasks')    # add_copy_grad() (:229)
 
-        key = ('batched', nt, (B, F, T), tuple(vx_in.shape), m_tr['Td'], m_va['Td'], n_tasks, bool(args.clip), float(args.max_norm),
+        key = ('batched', nt, (B, F, T), ragged, tuple(Xva.shape), Tv != Tv_own, m_tr['Td'], m_va['Td'], n_tasks, bool(args.clip), float(args.max_norm),
                smoothing, lr, theta0.data_ptr(), eng.dropout_p, g.data_ptr(), theta1.data_ptr(), G.data_ptr(),
                torch.cuda.current_stream(dev).cuda_stream, eng.use_side_stream, chunk is not None)
         _trace.mark('keys')

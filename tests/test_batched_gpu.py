@@ -382,3 +382,148 @@ def test_eight_tasks_at_north_star_shapes_three_schedules():
     tight = sum(e < 2e-6 for e in errs.values())
     print('8 tasks at NS shapes: batched vs 1 lane: global %.2e, %d/%d tensors < 2e-6, worst %.2e (%s)' % (glob, tight, len(errs), errs[worst], worst))
     assert glob < 1e-3 and errs[worst] < 1e-2
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# tasks of DIFFERENT frame counts in one pass (manifest-fed batches: data.py:77 pads every task's batch to its own longest utterance)
+# ------------------------------------------------------------------------------------------------------------------
+def test_zero_tails_clears_every_tasks_own_tail(L):
+    """mtl_zero_tails: (n, T, row) activations of tasks stacked at the widest; frames [width >> shift, T) of every sample of a task are
+    cleared, everything in front stays bit for bit (odd widths, a task as wide as the stack, a width beyond T)."""
+    per_task, T, row = 3, 21, 161 * 64
+    widths = [21, 13, 40, 4]
+    n = per_task * len(widths)
+    w = torch.tensor(widths, dtype=torch.int32).cuda()
+    for shift in (0, 1):
+        y = torch.randn(n, T, row).cuda()
+        ref = y.clone()
+        for s in range(n):
+            ref[s, min(widths[s // per_task] >> shift, T):] = 0
+        assert L.mtl_zero_tails(st(), y.data_ptr(), n, T, row, w.data_ptr(), shift, per_task) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(y, ref)
+    assert L.mtl_zero_tails(st(), y.data_ptr(), n, T, 6, w.data_ptr(), 0, per_task) != 0          # row % 4
+
+
+def _ragged_tasks(mtl_amd, k, frames, widths, V, seed):
+    as5 = lambda b: (b[0].cuda(), b[1], None, b[2], None)
+    return [as5(mtl_amd.synth_batch(seed + m, k, T_m, L_m, V, variable=True)) for m, (T_m, L_m) in enumerate(zip(frames, widths))]
+
+
+def _crop_gates(g, k, frames, dec_width):
+    """ReLU / max-pool decisions of one task of a pass stacked at the widest -> the extent of the task's OWN pass (frames, frames // 2,
+    (frames // 2) // 2 columns; its own encoder / decoder rows); also returns how many decisions beyond that extent are set in the maps
+    a later convolution reads (must be none: those frames are cleared)."""
+    out, beyond = {}, 0
+    T2 = frames // 2
+    T4 = T2 // 2
+    for key, v in g.items():
+        if v.dim() == 4:
+            w = {'conv0': frames, 'conv5': T2, 'am1': T2, 'pool1': T2}.get(key, T4)
+            if key in ('conv0', 'conv5', 'pool1'):
+                beyond += int((v[..., w:] != 0).sum())
+            out[key] = v[..., :w].contiguous()
+        else:
+            rows = T4 if key.startswith('e') else dec_width
+            out[key] = v.view(k, -1, v.shape[-1])[:, :rows].reshape(-1, v.shape[-1])
+    return out, beyond
+
+
+def _decisions_differ(ga, gb):
+    return sum(int((ga[key] != gb[key]).sum()) for key in ga)
+
+
+@pytest.mark.parametrize('name,frames,val_frames,quantum', [('F0', (64, 53, 46), 60, 64), ('F0', (41, 64, 64, 58), 64, 1), ('F1', (64, 50, 39), 47, 64),
+                                                            ('F1', (64, 47, 36), 47, 1), ('F0', (41, 50, 39), 45, 16), ('F1', (30, 57, 44), 33, 32)])
+def test_tasks_of_different_frame_counts_in_one_pass_equal_a_lane_per_task(name, frames, val_frames, quantum):
+    """Every task's batch padded to its OWN longest utterance (odd frame counts, counts that are not multiples of four), stacked at the
+    widest and run as ONE pass per phase -- against one lane per task, each at its own width, which is the reference's schedule
+    (transient_trainer.py:178-237).  A task's own image border (zeros beyond its frames at every convolution), its encoder length
+    ((frames // 2) // 2 positions) and its loss are those of its own pass -- also when the stack is WIDER than its widest task (widths
+    rounded up to a quantum, so that they repeat: the validation batch then carries a border of its own too): labels bit-exact, losses to 2e-6, no decision set beyond a
+    task's frames, and -- when the two schedules took every ReLU / max-pool decision alike (captured from both and compared on each
+    task's own extent) -- every tensor of G to the summation-order bar of the fixed-shape comparison above; a differing near-tie (the
+    F1 case with 47 frames has ONE, in a validation pass) widens it to the single-flip band."""
+    z, cfg, spec = gu.load(name)
+    mtl_amd, args, vocab, model = make(cfg, spec)
+    model = model.cuda()
+    k, V = spec['k'], cfg['vocab_size']
+    widths = (8, 5, 11, 8)
+    tasks = _ragged_tasks(mtl_amd, k, frames, widths, V, 340 if 47 in frames else 140)
+    val = _ragged_tasks(mtl_amd, k, (val_frames,), (6,), V, 199)[0]
+    n = len(tasks)
+    inner = mtl_amd.FlatSGD(model, spec['lr'])
+    model.zero_copy_grad()
+    G0, r0, _, log0 = _iteration(mtl_amd, model, vocab, args, tasks, val, n, inner, False, gates=True)
+    tr = mtl_amd.TransientTrainer()
+    tr.ragged_quantum = quantum
+    G1, r1, tr, log1 = _iteration(mtl_amd, model, vocab, args, tasks, val, n, inner, True, tr=tr, gates=True)
+    assert tr.last_schedule == 'batched-ragged', 'the ragged tasks did not take the task-batched pass'
+    assert len(log0) == len(log1) == 2 * n
+    flips = 0
+    for i, (ga, gb) in enumerate(zip(log0, log1)):
+        t, is_val = i // 2, i % 2
+        crop, beyond = _crop_gates(gb, k, val_frames if is_val else frames[t], 7 if is_val else widths[t] + 1)
+        assert beyond == 0 or is_val, (i, beyond)
+        flips += _decisions_differ(ga, crop)
+    for (l0, h0, g0), (l1, h1, g1) in zip(r0, r1):
+        w = g0.shape[1]
+        assert torch.equal(g0, g1[:, :w]) and bool((g1[:, w:] == 0).all())
+        assert torch.equal(h0, h1[:, :w]) and bool((h1[:, w:] == 0).all())
+        assert abs(l0 - l1) <= 2e-6 * abs(l0), (l0, l1)
+    errs = _tensor_errs(model, G1, G0)
+    strict = {nm: e for nm, e in errs.items() if not nm.endswith('key_linear_b.bias')}
+    ws_, worst = max(strict, key=strict.get), max(errs, key=errs.get)
+    print('%s frames %s: stacked vs lanes: %d differing decisions, worst tensor %.2e (%s), global %.2e'
+          % (name, frames, flips, errs[worst], worst, float((G1 - G0).norm() / G0.norm())))
+    assert flips <= 2
+    assert strict[ws_] < (1.5e-5 if flips == 0 else 1e-2) and errs[worst] < (1e-4 if flips == 0 else 1e-2), (ws_, strict[ws_], worst, errs[worst], flips)
+    for rnd in range(3):                                  # first sighting of the key (eager), recording, replay
+        G2, r2, _, _ = _iteration(mtl_amd, model, vocab, args, tasks, val, n, inner, True, tr=tr)
+        assert torch.equal(G2, G1)
+    assert any(isinstance(v, dict) and k_[0] == 'batched' for k_, v in tr._cmdlists.items()), 'no command list was recorded'
+    # the recorded list holds no frame count: other per-task counts under the same widest replay it -- bit for bit what a fresh trainer
+    # enqueues call by call
+    other = tuple(max(frames) if f == max(frames) else f - 3 for f in frames)
+    tasks_b = _ragged_tasks(mtl_amd, k, other, widths, V, 540)
+    G3, _, _, _ = _iteration(mtl_amd, model, vocab, args, tasks_b, val, n, inner, True, tr=tr)
+    fresh = mtl_amd.TransientTrainer()
+    fresh.ragged_quantum = quantum
+    G4, _, _, _ = _iteration(mtl_amd, model, vocab, args, tasks_b, val, n, inner, True, tr=fresh)
+    assert torch.equal(G3, G4)
+
+
+def test_tasks_of_different_frame_counts_in_one_pass_against_live_oracle():
+    """The stacked pass against the CPU oracle run task by task at each task's own width (oracle/refimpl.py meta_gradient: the reference's
+    loop), the device's branch decisions -- cropped to each task's own extent -- replayed: labels bit-exact, losses and every tensor of
+    G within 1e-4."""
+    from oracle import refimpl as R
+    from oracle import branches
+    from tests.test_parity_gpu import _rel_errs, RTOL
+    z, cfg, spec = gu.load('F0')
+    mtl_amd, args, vocab, model = make(cfg, spec)
+    model = model.cuda()
+    oracle = R.build_model(cfg)
+    k, V = spec['k'], cfg['vocab_size']
+    frames, widths, val_frames = (64, 51, 45), (8, 5, 11), 58
+    cpu = [mtl_amd.synth_batch(240 + m, k, T_m, L_m, V, variable=True) for m, (T_m, L_m) in enumerate(zip(frames, widths))]
+    val = mtl_amd.synth_batch(299, k, val_frames, 6, V, variable=True)
+    as5 = lambda b: (b[0].cuda(), b[1], None, b[2], None)
+    inner = mtl_amd.FlatSGD(model, spec['lr'])
+    model.zero_copy_grad()
+    tr = mtl_amd.TransientTrainer()
+    with branches.capture_gates(model) as log:
+        reads = tr.meta_iteration(model, vocab, [as5(b) for b in cpu], as5(val), 3, inner, None, args)
+        torch.cuda.synchronize()
+    assert tr.last_schedule == 'batched-ragged' and len(log) == 6
+    gates = [_crop_gates(g, k, val_frames if i % 2 else frames[i // 2], 7 if i % 2 else widths[i // 2] + 1)[0] for i, g in enumerate(log)]
+    G, trl, val_l, labels = R.meta_gradient(oracle, cpu, val, spec['lr'], gates=gates)
+    for t in range(3):
+        for rd, (gold, hyp), loss in ((reads[t][0], labels[2 * t], trl[t]), (reads[t][1], labels[2 * t + 1], val_l[t])):
+            w = gold.shape[1]
+            assert torch.equal(rd.hyp[:, :w], hyp) and torch.equal(rd.gold_host[:, :w], gold)
+            assert abs(float(rd.loss[0]) - loss) < RTOL * loss
+    errs = _rel_errs(model, model._G, oracle, G)
+    worst = max(errs, key=errs.get)
+    print('ragged stack vs oracle: %d/%d tensors within 1e-4, worst %.2e (%s)' % (sum(e < RTOL for e in errs.values()), len(errs), errs[worst], worst))
+    assert errs[worst] < RTOL, (worst, errs[worst])
