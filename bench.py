@@ -70,6 +70,57 @@ class PinnedHostTask:
         return self.batches
 
 
+class RaggedTask:
+    """What a manifest-fed run hands over: every call a NEW batch padded to its own longest utterance (data.py:77) -- frame counts
+    drawn per sample from [lo, hi], so the width differs from task to task and from step to step.  Resident in HBM."""
+
+    def __init__(self, task_id, k, lo, hi, L, V, device, mode='ragged'):
+        self.g = torch.Generator().manual_seed(77 + task_id)
+        self.k, self.lo, self.hi, self.L, self.V, self.dev, self.mode = k, lo, hi, L, V, device, mode
+
+    def batch(self):
+        if self.mode == 'fixed':
+            T = (self.lo + self.hi) // 2
+            lens = torch.full((self.k,), T, dtype=torch.int32)
+        else:
+            lens = torch.randint(self.lo, self.hi + 1, (self.k,), generator=self.g).to(torch.int32)
+            T = int(lens.max()) if self.mode == 'ragged' else self.hi
+        x = torch.randn(self.k, 1, 161, T, device=self.dev)
+        for i in range(self.k):
+            x[i, :, :, int(lens[i]):] = 0
+        y = torch.randint(4, self.V, (self.k, self.L), generator=self.g)
+        return (x, lens, lens.float() / T, y, (y != 0).sum(1).to(torch.int32))
+
+    def sample(self, k_train, k_valid, manifest_id):
+        return self.batch(), self.batch()
+
+
+def ragged_steps(trainer, model, vocab, tasks, n_tasks, inner, outer, args, steps, warmup, dev):
+    """The production loop (pipelined enqueue, every iteration resolved inside the span) on batches that change shape every step.
+    -> (seconds, frames processed, host enqueue ms per step)"""
+    pending, host, frames, dt = [], [], 0, 0.0
+    depth = max(getattr(trainer, 'pipeline_depth', 1), 1)
+    for timed, n in ((False, warmup), (True, steps)):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            local = [t.batch() for t in tasks]
+            val = tasks[-1].batch()
+            if timed:
+                frames += sum(int(b[0].shape[0] * b[0].shape[3]) for b in local) + len(local) * int(val[0].shape[0] * val[0].shape[3])
+            h0 = time.perf_counter()
+            pending.append(trainer.enqueue_iteration(model, vocab, local, val, n_tasks, inner, outer, args))
+            if timed:
+                host.append((time.perf_counter() - h0) * 1e3)
+            while len(pending) > depth:
+                pending.pop(0).result()
+        while pending:
+            pending.pop(0).result()
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+    return dt, frames, host
+
+
 def make_args(k, lr=1e-4, meta_lr=1e-4):
     return argparse.Namespace(feat_extractor='vgg_cnn', sample_rate=16000, window_size=.02, feat='spectrogram', dim_input=161,
                               dropout=0.0, emb_trg_sharing=False, label_smoothing=0.0, name='bench', lr=lr, meta_lr=meta_lr,
@@ -852,6 +903,18 @@ def main():
             dt3, _ = timed_steps(trainer, model, vocab, tasks[:3], [0, 1, 2], 3, inner, outer, args, k3, 3, mdist, dev)
             out['configs1_3task'] = dict(value=k3 / dt3, unit='meta-steps/s', ms_per_step=dt3 / k3 * 1e3,
                                          note='README-faithful: 3 tasks on one GPU, dropout 0 (parity setting)')
+        # manifest-like batches: every task's batch padded to its OWN longest utterance, new frame counts every step (0.6 ... 1.0 of
+        # --frames per utterance); the tasks run stacked at the widest in one pass per phase, each with its own border and length
+        if a.tasks >= 2:
+            rag = [RaggedTask(m, a.k, int(0.6 * a.frames), a.frames, a.labels, CFG['vocab_size'], dev) for m in range(a.tasks)]
+            trr = mtl_amd.TransientTrainer()
+            dtr, fr, hostr = ragged_steps(trr, model, vocab, rag, a.tasks, inner, outer, args, k3, 6, dev)
+            out['ragged_frames'] = dict(value=k3 / dtr, unit='meta-steps/s', ms_per_step=dtr / k3 * 1e3, frames_per_step=fr // k3,
+                                        schedule=trr.last_schedule, host_enqueue_ms=round(sum(hostr) / len(hostr), 2),
+                                        note='every utterance %d ... %d frames, every batch padded to its own longest (data.py:77): '
+                                             'new shapes every step; headline: %d frames per step' % (int(0.6 * a.frames), a.frames,
+                                                                                                    2 * a.tasks * a.k * a.frames))
+            del rag, trr
         # what ONE rank of the 8-GPU configuration runs per step: a single task, a single lane (no collective on one rank)
         one = {}
         for name, lanes in (('unsplit', 0), ('split2', 2), ('split4', 4)):
@@ -949,7 +1012,7 @@ def compact_line(out):
         line['host_enqueue_ms'] = out['host_enqueue_ms']
     if 'host' in out:
         line['host'] = out['host']
-    for k in ('with_h2d', 'configs1_3task', 'dropout_0.1', 'conv_x3', 'exact_f32'):
+    for k in ('with_h2d', 'configs1_3task', 'ragged_frames', 'dropout_0.1', 'conv_x3', 'exact_f32'):
         if k in out:
             line[k] = _r(out[k]['value'], 3)
     if 'one_task_per_gpu' in out:

@@ -996,11 +996,11 @@ class PassEngine:
         self.flush_side(0)
 
     # ---------------------------------------------------------------- the pass
-    def prepare(self, lengths, target, B, T, slot=0, norm_count=None, width=None):
+    def prepare(self, lengths, target, B, T, slot=0, norm_count=None, width=None, frames=None):
         """Host-side integer prep of one batch (modules/decoder.py:55-69 target shifting; every mask is derived inside the
         kernels from these few integers) + asynchronous H2D into STATIC per-slot buffers.  Kept separate from the kernels so
         a captured hipGraph of the pass can be replayed for any batch of the same shape."""
-        return self.prepare_tasks([(lengths, target)], B, T, slot, norm_count, width)
+        return self.prepare_tasks([(lengths, target)], B, T, slot, norm_count, width, frames=None if frames is None else [frames])
 
     def prepare_tasks(self, batches, B, T, slot=0, norm_count=None, width=None, frames=None):
         """prepare() for the batches [(lengths, target)] of several tasks that one task-batched pass carries (all B samples x T
@@ -1263,17 +1263,33 @@ class PassEngine:
             tails(y5, T2, F2 * 128, 1)
             check(lib.mtl_conv3x3_relu_pool_fwd_h2_tb(st, y5.data_ptr(), am_(2), wf[7].data_ptr(), o('conv.7.bias'), p2.data_ptr(), am2.data_ptr(),
                                                       am_(6), B, T2, F2, 128, 128, nt, sw(7), sP, AS, AS), 'conv7')
-        elif widths is not None:
-            raise RuntimeError('per-task frame counts in one pass need the merged two-piece-fp16 convolution launches (MTL_CONV_TB=1, h2)')
         else:
-          for t in range(nt):
-            tw, sl = (t if sP else 0), slice(t * B, (t + 1) * B)
-            check(conv_fwd_pool(st, y1[sl].data_ptr(), wf[2][tw].data_ptr(), o('conv.2.bias', t), p1[sl].data_ptr(), am1[sl].data_ptr(),
-                                am_(0, t), am_(1, t), B, T, F, 64, 64), 'conv2')
-            check(conv_fwd(st, p1[sl].data_ptr(), wf[5][tw].data_ptr(), o('conv.5.bias', t), y5[sl].data_ptr(), am_(1, t), am_(2, t),
-                           B, T2, F2, 64, 128), 'conv5')
-            check(conv_fwd_pool(st, y5[sl].data_ptr(), wf[7][tw].data_ptr(), o('conv.7.bias', t), p2[sl].data_ptr(), am2[sl].data_ptr(),
-                                am_(2, t), am_(6, t), B, T2, F2, 128, 128), 'conv7')
+            def c2(t, tw, sl):
+                check(conv_fwd_pool(st, y1[sl].data_ptr(), wf[2][tw].data_ptr(), o('conv.2.bias', t), p1[sl].data_ptr(), am1[sl].data_ptr(),
+                                    am_(0, t), am_(1, t), B, T, F, 64, 64), 'conv2')
+
+            def c5(t, tw, sl):
+                check(conv_fwd(st, p1[sl].data_ptr(), wf[5][tw].data_ptr(), o('conv.5.bias', t), y5[sl].data_ptr(), am_(1, t), am_(2, t),
+                               B, T2, F2, 64, 128), 'conv5')
+
+            def c7(t, tw, sl):
+                check(conv_fwd_pool(st, y5[sl].data_ptr(), wf[7][tw].data_ptr(), o('conv.7.bias', t), p2[sl].data_ptr(), am2[sl].data_ptr(),
+                                    am_(2, t), am_(6, t), B, T2, F2, 128, 128), 'conv7')
+            per_task = [(t, (t if sP else 0), slice(t * B, (t + 1) * B)) for t in range(nt)]
+            if widths is None:
+                for a_ in per_task:          # task by task
+                    c2(*a_)
+                    c5(*a_)
+                    c7(*a_)
+            else:                            # layer by layer: a layer's tails are cleared (all tasks at once) before the next layer reads them
+                for a_ in per_task:
+                    c2(*a_)
+                tails(p1, T2, F2 * 64, 1)
+                for a_ in per_task:
+                    c5(*a_)
+                tails(y5, T2, F2 * 128, 1)
+                for a_ in per_task:
+                    c7(*a_)
 
         if self.after_conv_hook is not None:      # lets the trainer de-phase concurrent task lanes (see trainer.meta_iteration)
             hook, self.after_conv_hook = self.after_conv_hook, None

@@ -360,6 +360,10 @@ class TransientTrainer():
         # widest task is exact (every task keeps its own border), and widths that repeat keep the buffer pool's allocations -- 11 GB
         # per width at the north-star size, otherwise re-allocated for every new widest utterance -- and the recorded command lists
         self.ragged_quantum = int(os.environ.get('MTL_RAGGED_QUANTUM', '64'))
+        # the same rounding for a task that runs on a lane of its own (one task per rank; tasks too unequal to stack): 'auto' = from the
+        # moment the lanes have seen two different widths (fixed-shape workloads are never padded), '1' always, '0' never
+        self.pad_lanes = os.environ.get('MTL_PAD_LANES', 'auto')
+        self._lane_widths = set()
         # train() enqueues iteration i + 1 before it resolves (logs) iteration i (enqueue_iteration); MTL_PIPELINE=0: resolve at once
         self.pipeline = os.environ.get('MTL_PIPELINE', '1') != '0'
         # how many iterations may be enqueued beyond the one being resolved (nothing the host needs to enqueue an iteration comes
@@ -427,6 +431,26 @@ class TransientTrainer():
         bufs = self._lane_buffers(model, n_lanes)
         main = torch.cuda.current_stream(dev)
         vx = val_batch[0].to(dev, non_blocking=True)
+        # widths that change from batch to batch (manifest-fed) would be enqueued call by call for ever: rounded up to a quantum they
+        # repeat (recorded lists replay, the pool keeps its buffers); the batch keeps its own border and encoder length (prepare(frames))
+        if self.pad_lanes == 'auto' and len(self._lane_widths) < 2:
+            self._lane_widths.update(int(tb[0].shape[3]) for tb in task_batches)
+            self._lane_widths.add(int(vx.shape[3]))
+            self._lane_widths = set(sorted(self._lane_widths)[:2])
+        q = self.ragged_quantum if (self.pad_lanes == '1' or (self.pad_lanes == 'auto' and len(self._lane_widths) > 1)) and not use_graphs else 0
+        most = 4 * model.engines[0].hp.src_max_len
+
+        def widened(x, eng_, name):
+            """-> (x or its copy in a zero-filled buffer of the rounded width, own frame count or None)"""
+            T_own = int(x.shape[3])
+            Tq = max(min(-(-T_own // q) * q, most), T_own) if q > 1 else T_own
+            if Tq == T_own:
+                return x, None
+            xp = eng_.buf(name, tuple(x.shape[:3]) + (Tq,))
+            xp.zero_()
+            xp[:, :, :, :T_own].copy_(x, non_blocking=True)
+            return xp, T_own
+        vx, v_own = widened(vx, model.engines[0], 'lane.x_va')
         ready = torch.cuda.Event()
         ready.record(main)
         reads = [None] * len(task_batches)
@@ -445,11 +469,11 @@ class TransientTrainer():
                     eng.after_conv_hook = lambda: phase_ev.record(torch.cuda.current_stream(dev))
                 if stagger and 0 < idx < n_lanes:
                     streams[lane].wait_event(phase_ev)        # start this lane half a phase behind lane 0
-                tx = tx.to(dev, non_blocking=True)
-                m_tr = eng.prepare(tsz, ty, tx.shape[0], tx.shape[3], slot=0)             # host ints -> static device buffers
-                m_va = eng.prepare(val_batch[1], val_batch[3], vx.shape[0], vx.shape[3], slot=1)
+                tx, t_own = widened(tx.to(dev, non_blocking=True), eng, 'lane.x_tr')
+                m_tr = eng.prepare(tsz, ty, tx.shape[0], tx.shape[3], slot=0, frames=t_own)   # host ints -> static device buffers
+                m_va = eng.prepare(val_batch[1], val_batch[3], vx.shape[0], vx.shape[3], slot=1, frames=v_own)
                 slots = self._slots(model, lane, m_tr, m_va)
-                key = (lane, tuple(tx.shape), tuple(vx.shape), m_tr['Td'], m_va['Td'], n_tasks, bool(args.clip),
+                key = (lane, tuple(tx.shape), tuple(vx.shape), t_own is not None, v_own is not None, m_tr['Td'], m_va['Td'], n_tasks, bool(args.clip),
                        float(args.max_norm), smoothing, float(inner.param_groups[0]['lr']), theta0.data_ptr(), eng.dropout_p,
                        tuple(b.data_ptr() for b in bufs[lane]), streams[lane].cuda_stream, eng.use_side_stream)
                 # a rank that holds ONE task (8 tasks on 8 GPUs): G = its g, handed to the all-reduce group by group under the backward
@@ -505,7 +529,7 @@ class TransientTrainer():
         # They are stacked at the widest (engine.prepare_tasks(frames=...) keeps each task's own image border and encoder length) as
         # long as the padding does not outweigh what one pass for all tasks saves over a lane per task (which, on shapes that never
         # repeat, is enqueued call by call: ~88 ms of host time per 8-task north-star step against ~55 ms of kernels).
-        if not self.batch_ragged or not (eng.conv_h2 and eng.conv_tb):
+        if not self.batch_ragged:
             return False
         if any(tuple(tb[0].shape[:3]) != shape[:3] for tb in task_batches):
             return False

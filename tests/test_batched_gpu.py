@@ -454,7 +454,9 @@ def test_tasks_of_different_frame_counts_in_one_pass_equal_a_lane_per_task(name,
     n = len(tasks)
     inner = mtl_amd.FlatSGD(model, spec['lr'])
     model.zero_copy_grad()
-    G0, r0, _, log0 = _iteration(mtl_amd, model, vocab, args, tasks, val, n, inner, False, gates=True)
+    own = mtl_amd.TransientTrainer()
+    own.pad_lanes = '0'                                   # the reference's schedule: every task at its own width
+    G0, r0, _, log0 = _iteration(mtl_amd, model, vocab, args, tasks, val, n, inner, False, tr=own, gates=True)
     tr = mtl_amd.TransientTrainer()
     tr.ragged_quantum = quantum
     G1, r1, tr, log1 = _iteration(mtl_amd, model, vocab, args, tasks, val, n, inner, True, tr=tr, gates=True)
@@ -527,3 +529,52 @@ def test_tasks_of_different_frame_counts_in_one_pass_against_live_oracle():
     worst = max(errs, key=errs.get)
     print('ragged stack vs oracle: %d/%d tensors within 1e-4, worst %.2e (%s)' % (sum(e < RTOL for e in errs.values()), len(errs), errs[worst], worst))
     assert errs[worst] < RTOL, (worst, errs[worst])
+
+
+@pytest.mark.parametrize('name,frames,val_frames,conv', [('F0', (41, 50, 39), 45, 'h2'), ('F1', (57,), 33, 'h2'), ('F0', (41, 50, 39), 45, 'x3')])
+def test_a_lane_per_task_at_rounded_widths_equals_its_own_widths(name, frames, val_frames, conv):
+    """The lane schedule (one task per rank; tasks too unequal to stack) on manifest-like batches: every batch widened to a multiple of
+    the quantum -- so that widths repeat, recorded lists replay and the pool keeps its buffers -- with its own border and encoder
+    length, against the same lanes at the batches' own widths: labels bit-exact, losses to 2e-6, G to the summation-order bar when all
+    decisions agree.  Also with the convolutions on the exact 3 x bf16 split (per-task launches, tails cleared layer by layer)."""
+    z, cfg, spec = gu.load(name)
+    mtl_amd, args, vocab, model = make(cfg, spec)
+    model = model.cuda()
+    if conv == 'x3':
+        for e in model.engines:
+            e.conv_mode, e.conv_x3, e.conv_h2 = 'x3', True, False
+    k, V = spec['k'], cfg['vocab_size']
+    widths = (8, 5, 11)
+    tasks = _ragged_tasks(mtl_amd, k, frames, widths, V, 740)
+    val = _ragged_tasks(mtl_amd, k, (val_frames,), (6,), V, 799)[0]
+    n = 8 if len(tasks) == 1 else len(tasks)
+    inner = mtl_amd.FlatSGD(model, spec['lr'])
+    model.zero_copy_grad()
+    own, wide = mtl_amd.TransientTrainer(), mtl_amd.TransientTrainer()
+    own.pad_lanes, wide.pad_lanes, wide.ragged_quantum = '0', '1', 16
+    G0, r0, _, log0 = _iteration(mtl_amd, model, vocab, args, tasks, val, n, inner, False, tr=own, gates=True)
+    G1, r1, _, log1 = _iteration(mtl_amd, model, vocab, args, tasks, val, n, inner, False, tr=wide, gates=True)
+    assert own.last_schedule == wide.last_schedule == 'lanes'
+    assert log1[0]['conv0'].shape[3] == -(-frames[0] // 16) * 16 and log0[0]['conv0'].shape[3] == frames[0]
+    flips = 0
+    for i, (ga, gb) in enumerate(zip(log0, log1)):
+        crop, beyond = _crop_gates(gb, k, val_frames if i % 2 else frames[i // 2], 7 if i % 2 else widths[i // 2] + 1)
+        assert beyond == 0, (i, beyond)
+        flips += _decisions_differ(ga, crop)
+    for (l0, h0, g0), (l1, h1, g1) in zip(r0, r1):
+        assert torch.equal(g0, g1) and torch.equal(h0, h1) and abs(l0 - l1) <= 2e-6 * abs(l0)
+    errs = _tensor_errs(model, G1, G0)
+    worst = max(errs, key=errs.get)
+    print('%s %s frames %s: lanes at rounded vs own widths: %d differing decisions, worst tensor %.2e (%s)' % (name, conv, frames, flips, errs[worst], worst))
+    assert flips <= 2 and errs[worst] < (1e-4 if flips == 0 else 1e-2), (worst, errs[worst], flips)
+    for rnd in range(3):                                  # eager, recording, replay
+        G2, _, _, _ = _iteration(mtl_amd, model, vocab, args, tasks, val, n, inner, False, tr=wide)
+        assert torch.equal(G2, G1)
+    # other own widths under the same rounded ones replay the recorded lists
+    tasks_b = _ragged_tasks(mtl_amd, k, tuple(f - 2 for f in frames), widths, V, 840)
+    G3, _, _, _ = _iteration(mtl_amd, model, vocab, args, tasks_b, val, n, inner, False, tr=wide)
+    fresh = mtl_amd.TransientTrainer()
+    fresh.pad_lanes, fresh.ragged_quantum = '1', 16
+    G4, _, _, _ = _iteration(mtl_amd, model, vocab, args, tasks_b, val, n, inner, False, tr=fresh)
+    assert torch.equal(G3, G4)
+    assert any(isinstance(v, dict) for v in wide._cmdlists.values()), 'no command list was recorded'

@@ -16,29 +16,7 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
 
-class RaggedTask:
-    def __init__(self, task_id, k, lo, hi, L, V, dev, mode):
-        self.g = torch.Generator().manual_seed(77 + task_id)
-        self.k, self.lo, self.hi, self.L, self.V, self.dev, self.mode, self.id = k, lo, hi, L, V, dev, mode, task_id
-        self.calls = 0
-
-    def _batch(self, seed):
-        g = self.g
-        if self.mode == 'fixed':
-            T = (self.lo + self.hi) // 2
-            lens = torch.full((self.k,), T, dtype=torch.int32)
-        else:
-            lens = torch.randint(self.lo, self.hi + 1, (self.k,), generator=g).to(torch.int32)
-            T = int(lens.max()) if self.mode == 'ragged' else self.hi
-        x = torch.randn(self.k, 1, 161, T, device=self.dev)
-        for i in range(self.k):
-            x[i, :, :, int(lens[i]):] = 0
-        y = torch.randint(4, self.V, (self.k, self.L), generator=g)
-        return (x, lens, lens.float() / T, y, (y != 0).sum(1).to(torch.int32))
-
-    def sample(self, k_train, k_valid, manifest_id):
-        self.calls += 1
-        return self._batch(0), self._batch(1)
+RaggedTask = bench.RaggedTask
 
 
 def main():
@@ -66,8 +44,7 @@ def main():
     tasks = [RaggedTask(m, a.k, a.lo, a.hi, a.labels, bench.CFG['vocab_size'], dev, a.mode) for m in range(a.tasks)]
 
     def batches():
-        local = [t.sample(0, 0, 0)[0] for t in tasks]
-        return local, tasks[-1].sample(0, 0, 0)[1]
+        return [t.batch() for t in tasks], tasks[-1].batch()
     pending, host, frames = [], [], 0
     depth = max(getattr(trainer, 'pipeline_depth', 1), 1)
     for phase, n in (('setup', 4), ('timed', a.steps)):
