@@ -1071,6 +1071,7 @@ class TransientTrainer():
         failures = 0
         pending = deque()                                 # enqueued, not yet resolved: (it, step), oldest first
         clock = [time.time()]
+        self.loss_trace = []                              # (validation loss / n, CER edits, characters) of every resolved iteration
 
         def resolve(it_, step):
             nonlocal total_time
@@ -1078,6 +1079,7 @@ class TransientTrainer():
             last_sum_cer.append(total_cer)
             last_sum_char.append(total_char)
             last_sum_loss.append(total_loss / n_tasks)
+            self.loss_trace.append((total_loss / n_tasks, total_cer, total_char))
             now = time.time()
             diff_time, clock[0] = now - clock[0], now    # iterations overlap: the time between two resolutions is one iteration
             total_time += diff_time

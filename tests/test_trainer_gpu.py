@@ -385,3 +385,53 @@ def test_variable_length_batches_keep_the_buffer_pool_and_the_command_lists_boun
     assert len(tr._cmdlists) <= 64 and len(eng._stage) <= 64 + 4
     again = iteration(64, 8, 500)
     assert torch.equal(first, again)
+
+
+class _CollatedTask:
+    """The dataset contract of TransientTrainer.train over a list of utterances, batches formed like the reference's loader: k random
+    utterances collated to the batch's OWN longest one (utils/data_loader.py:284-297 = mtl_amd.data.collate)."""
+
+    def __init__(self, seed, n, V, pad_id):
+        self.items, self.pad_id = _ListDataset(seed, n, V).items, pad_id
+        self.g = torch.Generator().manual_seed(seed + 1)
+
+    def _draw(self, k):
+        pick = torch.randperm(len(self.items), generator=self.g)[:k].tolist()
+        import mtl_amd
+        return mtl_amd.data.collate([self.items[i][0] for i in pick], [self.items[i][1] for i in pick], self.pad_id)
+
+    def sample(self, k_train, k_valid, manifest_id):
+        return self._draw(k_train), self._draw(k_valid)
+
+
+def test_train_loop_on_collated_batches_of_different_widths_equals_the_reference_schedule(tmp_path):
+    """TransientTrainer.train fed like the reference (every task's batch collated to its own longest utterance: the frame counts
+    differ from task to task and from iteration to iteration).  The default schedule stacks the tasks at the widest in one pass per
+    phase; the reference's schedule is a pass per task at its own width (batch_ragged off, no widening): the same losses / CER counts
+    per iteration (iterations 2-4 run at parameters the earlier outer steps have moved)."""
+    z, cfg, spec = gu.load('F0')
+    V = cfg['vocab_size']
+    out = {}
+    for mode in ('stacked', 'own'):
+        mtl_amd, args, vocab, model = make(cfg, spec, name='ragged_' + mode)
+        args.save_folder, args.k_train, args.k_valid = str(tmp_path), 3, 3
+        model = model.cuda()
+        tasks = [_CollatedTask(300 + 7 * m, 12, V, vocab.PAD_ID) for m in range(3)]
+        trainer = mtl_amd.TransientTrainer()
+        if mode == 'own':
+            trainer.batch_ragged, trainer.pad_lanes = False, '0'
+        else:
+            trainer.ragged_quantum = 8
+        trainer.train(model, vocab, tasks, [], 'ce', 0, 4, args, evaluate_every=10 ** 9, early_stop='cer,10', is_copy_grad=True)
+        torch.cuda.synchronize()
+        out[mode] = (list(trainer.loss_trace), model.flat_parameters.detach().clone(), trainer.last_schedule)
+    assert out['stacked'][2] == 'batched-ragged' and out['own'][2] == 'lanes'
+    assert len(out['own'][0]) == 4
+    for (la, ca, na), (lb, cb, nb) in zip(out['stacked'][0], out['own'][0]):
+        assert abs(la - lb) <= 5e-6 * abs(lb) and (ca, na) == (cb, nb), ((la, ca, na), (lb, cb, nb))
+    d = float((out['stacked'][1] - out['own'][1]).norm() / out['own'][1].norm())
+    print('train() on collated batches: theta after 4 steps, stacked vs own widths: %.2e' % d)
+    # (Adam's first steps move every element by ~meta_lr x sign(g): elements whose exact gradient is zero -- the key-projection biases --
+    # follow the sign of rounding noise, which the two schedules do not share; the losses of iterations 2-4 above, computed at the moved
+    # parameters, are what shows that the steps agree)
+    assert d < 5e-4
