@@ -138,6 +138,14 @@ def _pinned(key, shape, dtype, turns=1):
     return raw[:nbytes].view(dtype).view(shape)
 
 
+def _round_width(T, quantum):
+    """Frame count rounded up to a repeating width: a multiple of `quantum`, coarser for long batches (at most 1/16 of the width, so the
+    padding stays below ~6 % while a 5000-frame workload -- 55 GB of buffers per width -- sees a handful of widths, not dozens)."""
+    q = max(int(quantum), 1)
+    q = max(q, (T // 16) // q * q)
+    return -(-T // q) * q
+
+
 class PendingIteration:
     """An enqueued meta-iteration: result() waits for ITS end-of-iteration event (not for the device, which may already be
     running the next iteration), then computes the reference's log quantities from the read-backs."""
@@ -443,7 +451,7 @@ class TransientTrainer():
         def widened(x, eng_, name):
             """-> (x or its copy in a zero-filled buffer of the rounded width, own frame count or None)"""
             T_own = int(x.shape[3])
-            Tq = max(min(-(-T_own // q) * q, most), T_own) if q > 1 else T_own
+            Tq = max(min(_round_width(T_own, q), most), T_own) if q > 1 else T_own
             if Tq == T_own:
                 return x, None
             xp = eng_.buf(name, tuple(x.shape[:3]) + (Tq,))
@@ -555,9 +563,9 @@ class TransientTrainer():
         vx_in = val_batch[0]
         Tv = Tv_own = int(vx_in.shape[3])
         if ragged and self.ragged_quantum > 1:
-            q, most = self.ragged_quantum, 4 * eng.hp.src_max_len            # (the positional table bounds the encoder length)
-            T = max(min(-(-T // q) * q, most), T)
-            Tv = max(min(-(-Tv // q) * q, most), Tv)
+            most = 4 * eng.hp.src_max_len                                    # (the positional table bounds the encoder length)
+            T = max(min(_round_width(T, self.ragged_quantum), most), T)
+            Tv = max(min(_round_width(Tv, self.ragged_quantum), most), Tv)
         key_b = (id(theta0), nt)
         if getattr(self, '_stack_key', None) != key_b:
             self._stack = (torch.zeros(nt * total, dtype=torch.float32, device=dev), torch.empty(nt * total, dtype=torch.float32, device=dev))
