@@ -371,7 +371,7 @@ class TransientTrainer():
         # the same rounding for a task that runs on a lane of its own (one task per rank; tasks too unequal to stack): 'auto' = from the
         # moment the lanes have seen two different widths (fixed-shape workloads are never padded), '1' always, '0' never
         self.pad_lanes = os.environ.get('MTL_PAD_LANES', 'auto')
-        self._lane_widths = set()
+        self._lane_widths, self._lane_widths_vary = {}, False
         # train() enqueues iteration i + 1 before it resolves (logs) iteration i (enqueue_iteration); MTL_PIPELINE=0: resolve at once
         self.pipeline = os.environ.get('MTL_PIPELINE', '1') != '0'
         # how many iterations may be enqueued beyond the one being resolved (nothing the host needs to enqueue an iteration comes
@@ -441,11 +441,8 @@ class TransientTrainer():
         vx = val_batch[0].to(dev, non_blocking=True)
         # widths that change from batch to batch (manifest-fed) would be enqueued call by call for ever: rounded up to a quantum they
         # repeat (recorded lists replay, the pool keeps its buffers); the batch keeps its own border and encoder length (prepare(frames))
-        if self.pad_lanes == 'auto' and len(self._lane_widths) < 2:
-            self._lane_widths.update(int(tb[0].shape[3]) for tb in task_batches)
-            self._lane_widths.add(int(vx.shape[3]))
-            self._lane_widths = set(sorted(self._lane_widths)[:2])
-        q = self.ragged_quantum if (self.pad_lanes == '1' or (self.pad_lanes == 'auto' and len(self._lane_widths) > 1)) and not use_graphs else 0
+        varies = self._widths_vary([('lane', i, int(tb[0].shape[3])) for i, tb in enumerate(task_batches)] + [('lane', 'val', int(vx.shape[3]))])
+        q = self.ragged_quantum if varies and not use_graphs else 0
         most = 4 * model.engines[0].hp.src_max_len
 
         def widened(x, eng_, name):
@@ -520,6 +517,19 @@ class TransientTrainer():
         return reads
 
     # ------------------------------------------------------------------ task-batched passes
+    def _widths_vary(self, sightings):
+        """sightings: [(schedule, slot, frames)] of this iteration's batches.  -> whether batches are to be widened to repeating widths:
+        pad_lanes '1' always, '0' never, 'auto' from the moment any slot (a task's position, the validation batch) has brought two
+        different widths -- a fixed-shape workload is never padded, a manifest-fed one from its second iteration on."""
+        if self.pad_lanes != 'auto':
+            return self.pad_lanes == '1'
+        if not self._lane_widths_vary:
+            for sched, slot, frames in sightings:
+                if self._lane_widths.setdefault((sched, slot), frames) != frames:
+                    self._lane_widths_vary = True
+                    break
+        return self._lane_widths_vary
+
     def _can_batch(self, model, task_batches, val_batch, use_graphs):
         """All local tasks in one pass per phase: needs >= 2 tasks with identical batch shapes (samples x frames; label widths may
         differ), the fused attention kernel and plain launches (no hipGraph capture, no profiling proxy)."""
@@ -562,7 +572,10 @@ class TransientTrainer():
         ragged = min(frames) != T
         vx_in = val_batch[0]
         Tv = Tv_own = int(vx_in.shape[3])
-        if ragged and self.ragged_quantum > 1:
+        # (uniform across the tasks but changing from step to step -- a loader that pads all tasks alike -- is rounded as well, from the
+        # second width on: `_widths_vary`)
+        varies = self._widths_vary([('batched', 'train', T), ('batched', 'val', Tv)]) and self.batch_ragged
+        if (ragged or varies) and self.ragged_quantum > 1:
             most = 4 * eng.hp.src_max_len                                    # (the positional table bounds the encoder length)
             T = max(min(_round_width(T, self.ragged_quantum), most), T)
             Tv = max(min(_round_width(Tv, self.ragged_quantum), most), Tv)
@@ -582,7 +595,8 @@ class TransientTrainer():
         Xva = eng.buf('tb.x_va', tuple(vx_in.shape[:3]) + (Tv,))
         _trace.mark('setup')
         on_host = not vx_in.is_cuda or any(not tb[0].is_cuda for tb in task_batches)
-        if ragged:
+        own_tr = min(frames) != T                            # some task is narrower than the stack: borders / lengths of their own
+        if own_tr or Tv != Tv_own:
             # every task's frames at the front of its slab, zeros behind them (the border its own, narrower image ends in)
             Xtr.zero_()
             X5 = Xtr.view(nt, B, 1, F, T)
@@ -622,7 +636,7 @@ class TransientTrainer():
                 Xtr[t * B:(t + 1) * B].copy_(tx, non_blocking=True)
             Xva.copy_(vx_in, non_blocking=True)
         _trace.mark('input_copies')
-        m_tr = eng.prepare_tasks([(tsz, ty) for (_tx, tsz, _tp, ty, _tl) in task_batches], B, T, slot=0, frames=frames if ragged else None)
+        m_tr = eng.prepare_tasks([(tsz, ty) for (_tx, tsz, _tp, ty, _tl) in task_batches], B, T, slot=0, frames=frames if own_tr else None)
         m_va = eng.prepare_tasks([(val_batch[1], val_batch[3])] * nt, vx_in.shape[0], Tv, slot=1, frames=[Tv_own] * nt if Tv != Tv_own else None)
         _trace.mark('prepare_tasks')
         Bv = vx_in.shape[0]
@@ -653,7 +667,7 @@ class TransientTrainer():
             if chunk is None:
                 check(eng.lib.mtl_sum_tasks(eng.stream, G.data_ptr(), g.data_ptr(), total, nt, 0), 'mtl_sum_tasks')    # add_copy_grad() (:229)
 
-        key = ('batched', nt, (B, F, T), ragged, tuple(Xva.shape), Tv != Tv_own, m_tr['Td'], m_va['Td'], n_tasks, bool(args.clip), float(args.max_norm),
+        key = ('batched', nt, (B, F, T), own_tr, tuple(Xva.shape), Tv != Tv_own, m_tr['Td'], m_va['Td'], n_tasks, bool(args.clip), float(args.max_norm),
                smoothing, lr, theta0.data_ptr(), eng.dropout_p, g.data_ptr(), theta1.data_ptr(), G.data_ptr(),
                torch.cuda.current_stream(dev).cuda_stream, eng.use_side_stream, chunk is not None)
         _trace.mark('keys')

@@ -20,6 +20,12 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/lanes -o lanes -- pyt
 mkdir -p $O/one_task
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/one_task/trace -o one -- python bench.py --tasks 1 --steps 10 --warmup 3 --no-cpu-baseline --no-extras > $O/one_task/bench_one_task_traced.json 2> /dev/null
 python bench.py --tasks 1 --steps 30 --warmup 3 --no-cpu-baseline --no-extras 2> /dev/null | tail -1 > $O/one_task/bench_one_task.json
+# manifest-like batches (every batch padded to its own longest utterance, new shapes every step): probe line + kernel stats
+mkdir -p $O/ragged
+python tools/probe/ragged_steps.py --mode ragged --steps 40 2> /dev/null | tail -1 > $O/ragged/ragged_stacked.json
+MTL_BATCH_RAGGED=0 MTL_PAD_LANES=0 python tools/probe/ragged_steps.py --mode ragged --steps 20 2> /dev/null | tail -1 > $O/ragged/ragged_lane_per_task_own_widths.json
+MTL_BATCH_RAGGED=0 python tools/probe/ragged_steps.py --mode ragged --steps 40 2> /dev/null | tail -1 > $O/ragged/ragged_lane_per_task_rounded_widths.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/ragged/trace -o ragged -- python tools/probe/ragged_steps.py --mode ragged --steps 6 > /dev/null 2>&1
 # long-utterance configuration (BASELINE.json configs[3]): T = 5000
 python bench.py --frames 5000 --tasks 2 --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $O/bench_t5000.json 2> /dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/t5000 -o t5000 -- python bench.py --frames 5000 --tasks 1 --steps 1 --warmup 1 --no-cpu-baseline --no-extras --serial > $O/bench_t5000_serial_traced.json 2> /dev/null

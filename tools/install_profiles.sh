@@ -16,3 +16,4 @@ cp $S/lm/trace/lm_kernel_stats.csv $D/lm/kernel_stats.csv
 cp $S/gemm_x3_vs_fp32.txt $S/pmc_gemm_x3_ffn_fwd.txt $S/conv_random_data.txt $S/conv_zero_data.txt $S/clock_probe.txt $D/
 for f in conv_stall_breakdown.txt conv_step_model.txt ldsdma_rate.txt; do [ -f $S/$f ] && cp $S/$f $D/; done
 if [ -d $S/one_task ]; then mkdir -p $D/one_task; cp $S/one_task/bench_one_task.json $S/one_task/bench_one_task_traced.json $D/one_task/; cp $S/one_task/trace/one_kernel_stats.csv $D/one_task/kernel_stats.csv; fi
+if [ -d $S/ragged ]; then mkdir -p $D/ragged; cp $S/ragged/*.json $D/ragged/; cp $S/ragged/trace/ragged_kernel_stats.csv $D/ragged/kernel_stats.csv; fi
