@@ -218,6 +218,14 @@ STAGE_RING = 6      # pinned staging buffers per slot (prepare_tasks): > pipelin
 _LAYER_BUF = re.compile(r'^([de])(\d+)\.(.+)$')
 
 
+def round_width(T, quantum):
+    """Frame count rounded up to a repeating width: a multiple of `quantum`, coarser for long batches (at most 1/16 of the width, so the
+    padding stays below ~6 % while a 5000-frame workload -- 55 GB of buffers per width -- sees a handful of widths, not dozens)."""
+    q = max(int(quantum), 1)
+    q = max(q, (T // 16) // q * q)
+    return -(-T // q) * q
+
+
 _POOL_ACCOUNTS = {}
 
 
@@ -254,6 +262,8 @@ class PassEngine:
         # eight lanes keep 8 x 48 GiB of stale shapes and ran a north-star run on ragged batches out of memory).  An eviction bumps
         # scratch_epoch, which makes the trainer re-record its command lists (they hold raw addresses).
         self.account = _pool_account(device)
+        self.widen, self.widen_quantum = os.environ.get('MTL_PAD_LANES', 'auto'), int(os.environ.get('MTL_RAGGED_QUANTUM', '64'))
+        self._first_width, self._widths_vary = {}, False
         self.pool_budget = self.account['budget']           # (an engine may be given a tighter one of its own: tests)
         self._pool_gen, self._pool_bytes, self._gen = {}, 0, 0
         self.saved = None
@@ -1128,7 +1138,20 @@ class PassEngine:
         tensors pred (B,Td,V), gold, hyp (B,Td) int64 and `loss` (1,) fp32; keeps what the backward needs."""
         if x.dim() != 4 or x.shape[1] != 1:
             raise ValueError('expected (B,1,F,T) input')
-        meta = self.prepare(lengths, target, x.shape[0], x.shape[3], slot)
+        # stand-alone passes (validation loops, the joint trainer, the drop-in autograd call) on batches whose width changes from call
+        # to call: widened to a repeating width like the trainer's lanes (own border and encoder length kept), from the second width on
+        # (not while a test's forward hook reads the activations in the pass's own extent)
+        T_own, frames = int(x.shape[3]), None
+        if self.widen == 'auto' and not self._widths_vary:
+            self._widths_vary = self._first_width.setdefault(slot, T_own) != T_own
+        if self.widen_quantum > 1 and (self.widen == '1' or (self.widen == 'auto' and self._widths_vary and self.forward_hook is None)):
+            Tq = max(min(round_width(T_own, self.widen_quantum), 4 * self.hp.src_max_len), T_own)
+            if Tq != T_own:
+                xp = self.buf('fwd.x.%d' % slot, tuple(x.shape[:3]) + (Tq,))
+                xp.zero_()
+                xp[:, :, :, :T_own].copy_(x, non_blocking=True)
+                x, frames = xp, T_own
+        meta = self.prepare(lengths, target, x.shape[0], x.shape[3], slot, frames=frames)
         return self.forward_device(theta, x, meta, smoothing)
 
     def forward_device(self, theta, x, meta, smoothing=0.0, hyp_out=None, loss_out=None, sP=0):

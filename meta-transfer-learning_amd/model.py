@@ -323,7 +323,11 @@ class Transformer(nn.Module):
         self.eval()
         ids_nbest = None
         try:
-            out = self.pass_forward(padded_input, input_lengths, padded_target)
+            widen, eng.widen = eng.widen, '0'          # the decoders read the encoder output in the batch's own extent (T4 positions per utterance)
+            try:
+                out = self.pass_forward(padded_input, input_lengths, padded_target)
+            finally:
+                eng.widen = widen
             B, T = padded_input.shape[0], padded_input.shape[3]
             T4 = (T // 2) // 2
             mem = eng.arena['e%d.ff.y' % (eng.hp.n_enc - 1)] if eng.hp.n_enc else eng.arena['enc_in.y']

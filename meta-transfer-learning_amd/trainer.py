@@ -21,7 +21,7 @@ from collections import deque
 import torch
 
 from . import _lib, _trace, dist as mdist, hostenv
-from .engine import PAD_ID, decoder_io
+from .engine import PAD_ID, decoder_io, round_width
 from .functions import post_process, save_joint_model, save_meta_model
 from .metrics import calculate_cer, calculate_metrics
 
@@ -136,14 +136,6 @@ def _pinned(key, shape, dtype, turns=1):
     else:
         _PINNED.move_to_end(key)
     return raw[:nbytes].view(dtype).view(shape)
-
-
-def _round_width(T, quantum):
-    """Frame count rounded up to a repeating width: a multiple of `quantum`, coarser for long batches (at most 1/16 of the width, so the
-    padding stays below ~6 % while a 5000-frame workload -- 55 GB of buffers per width -- sees a handful of widths, not dozens)."""
-    q = max(int(quantum), 1)
-    q = max(q, (T // 16) // q * q)
-    return -(-T // q) * q
 
 
 class PendingIteration:
@@ -448,7 +440,7 @@ class TransientTrainer():
         def widened(x, eng_, name):
             """-> (x or its copy in a zero-filled buffer of the rounded width, own frame count or None)"""
             T_own = int(x.shape[3])
-            Tq = max(min(_round_width(T_own, q), most), T_own) if q > 1 else T_own
+            Tq = max(min(round_width(T_own, q), most), T_own) if q > 1 else T_own
             if Tq == T_own:
                 return x, None
             xp = eng_.buf(name, tuple(x.shape[:3]) + (Tq,))
@@ -577,8 +569,8 @@ class TransientTrainer():
         varies = self._widths_vary([('batched', 'train', T), ('batched', 'val', Tv)]) and self.batch_ragged
         if (ragged or varies) and self.ragged_quantum > 1:
             most = 4 * eng.hp.src_max_len                                    # (the positional table bounds the encoder length)
-            T = max(min(_round_width(T, self.ragged_quantum), most), T)
-            Tv = max(min(_round_width(Tv, self.ragged_quantum), most), Tv)
+            T = max(min(round_width(T, self.ragged_quantum), most), T)
+            Tv = max(min(round_width(Tv, self.ragged_quantum), most), Tv)
         key_b = (id(theta0), nt)
         if getattr(self, '_stack_key', None) != key_b:
             self._stack = (torch.zeros(nt * total, dtype=torch.float32, device=dev), torch.empty(nt * total, dtype=torch.float32, device=dev))

@@ -578,3 +578,38 @@ def test_a_lane_per_task_at_rounded_widths_equals_its_own_widths(name, frames, v
     G4, _, _, _ = _iteration(mtl_amd, model, vocab, args, tasks_b, val, n, inner, False, tr=fresh)
     assert torch.equal(G3, G4)
     assert any(isinstance(v, dict) for v in wide._cmdlists.values()), 'no command list was recorded'
+
+
+def test_stand_alone_passes_at_rounded_widths_match_the_oracle_at_their_own():
+    """model(...) / loss.backward() -- the drop-in call pattern, what validation loops and the joint trainer run -- on batches whose width
+    changes from call to call: from the second width on the engine widens a batch to a repeating width (own border and encoder length
+    kept).  Predictions, labels and every parameter gradient against the CPU oracle at the batch's OWN width."""
+    from oracle import refimpl as R
+    from tests.test_parity_gpu import RTOL
+    z, cfg, spec = gu.load('F0')
+    mtl_amd, args, vocab, model = make(cfg, spec)
+    model = model.cuda()
+    model.engine.widen_quantum = 16
+    oracle = R.build_model(cfg)
+    k, V = spec['k'], cfg['vocab_size']
+    for i, T in enumerate((50, 41, 57)):
+        x, lens, y = mtl_amd.synth_batch(900 + i, k, T, 8, V, variable=True)
+        model.zero_grad()
+        oracle.zero_grad()
+        pred, gold, hyp = model(x.cuda(), lens, y)
+        assert model.engine._widths_vary == (i > 0)
+        widened = model.engine.arena['y1'].shape[1]
+        assert widened == (T if i == 0 else -(-T // 16) * 16)
+        loss, _ = mtl_amd.calculate_metrics(pred, gold, 0, smoothing=0.0, loss_type='ce')
+        loss.backward()
+        pr, gr, hr = oracle(x, lens, y)
+        lref = R.ce_loss(pr, gr)
+        lref.backward()
+        assert torch.equal(hyp.cpu(), hr) and torch.equal(gold.cpu(), gr)
+        assert abs(float(loss) - float(lref)) < RTOL * float(lref)
+        assert float((pred.cpu() - pr).abs().max()) < 1e-4 * float(pr.abs().max())
+        gn = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in oracle.parameters())))
+        worst = max(float((p.grad.cpu() - q.grad).norm() / max(float(q.grad.norm()), 1e-4 * gn))
+                    for (_, p), (_, q) in zip(model.named_parameters(), oracle.named_parameters()))
+        print('T = %d (run at %d): worst parameter gradient %.2e' % (T, widened, worst))
+        assert worst < RTOL
