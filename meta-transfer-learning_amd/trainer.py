@@ -355,7 +355,7 @@ class TransientTrainer():
         # tasks whose batches have different frame counts in one pass, stacked at the widest (0: one lane per task), as long as the
         # tasks' frames fill at least this share of the stack
         self.batch_ragged = os.environ.get('MTL_BATCH_RAGGED', '1') != '0'
-        self.ragged_fill = float(os.environ.get('MTL_RAGGED_FILL', '0.6'))
+        self.ragged_fill = float(os.environ.get('MTL_RAGGED_FILL', '0.4'))
         # ... and the stack's width (training and validation) rounded up to a multiple of this many frames: any width at or above the
         # widest task is exact (every task keeps its own border), and widths that repeat keep the buffer pool's allocations -- 11 GB
         # per width at the north-star size, otherwise re-allocated for every new widest utterance -- and the recorded command lists

@@ -28,6 +28,7 @@ def main():
     ap.add_argument('--hi', type=int, default=1000)
     ap.add_argument('--labels', type=int, default=100)
     ap.add_argument('--mode', default='ragged')
+    ap.add_argument('--hetero', type=float, default=1.0, help='task m draws its utterances from [lo, hi] scaled by hetero + (1 - hetero) m / (n - 1): corpora of different utterance lengths')
     a = ap.parse_args()
     with contextlib.redirect_stdout(io.StringIO()):
         import mtl_amd
@@ -41,7 +42,8 @@ def main():
     trainer = mtl_amd.TransientTrainer()
     inner, outer = mtl_amd.FlatSGD(model, args.lr), mtl_amd.FlatAdam(model, args.meta_lr)
     model.zero_copy_grad()
-    tasks = [RaggedTask(m, a.k, a.lo, a.hi, a.labels, bench.CFG['vocab_size'], dev, a.mode) for m in range(a.tasks)]
+    sc = [a.hetero + (1 - a.hetero) * m / max(a.tasks - 1, 1) for m in range(a.tasks)]
+    tasks = [RaggedTask(m, a.k, int(a.lo * sc[m]), int(a.hi * sc[m]), a.labels, bench.CFG['vocab_size'], dev, a.mode) for m in range(a.tasks)]
 
     def batches():
         return [t.batch() for t in tasks], tasks[-1].batch()
