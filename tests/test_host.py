@@ -382,3 +382,38 @@ def test_spectrogram_dataset_constructed_as_the_reference_entry_script_does(tmp_
         mtl_amd.SpectrogramDataset(vocab, args, audio_conf, manifest_filepath_list=manifests, augment=True, feature_fn=feats)
     with pytest.raises(NotImplementedError):
         mtl_amd.SpectrogramDataset(vocab, args, dict(audio_conf, noise_dir='/noise'), manifest_filepath_list=manifests, feature_fn=feats)
+
+
+def test_schedule_choice_for_batches_of_different_widths():
+    """Host logic of the manifest-fed case (data.py:77 pads every batch to its own longest utterance): rounded widths repeat and never
+    shrink a batch; a fixed-shape workload is never widened; tasks of different frame counts are stacked while they fill the stack."""
+    import types
+    import mtl_amd
+    from mtl_amd.engine import round_width
+    for T in (4, 41, 64, 65, 600, 995, 1000, 1025, 2000, 4999, 5000):
+        for q in (16, 64):
+            w = round_width(T, q)
+            assert w >= T and w % q == 0 and w - T < max(q, T // 16 + q)
+    assert len({round_width(T, 64) for T in range(600, 1001)}) <= 8 and len({round_width(T, 64) for T in range(3000, 5001)}) <= 16
+    tr = mtl_amd.TransientTrainer()
+    assert tr.pad_lanes == 'auto' and tr.batch_ragged and tr.ragged_quantum == 64
+    fixed = [('lane', 0, 1000), ('lane', 1, 1000), ('lane', 'val', 800)]
+    assert not tr._widths_vary(fixed) and not tr._widths_vary(fixed)                 # training and validation widths may differ: still fixed
+    assert tr._widths_vary([('lane', 0, 1000), ('lane', 1, 990), ('lane', 'val', 800)])      # a slot brought a second width
+    assert tr._widths_vary(fixed)                                                    # ... and it stays on
+    tr.pad_lanes = '0'
+    assert not tr._widths_vary([('lane', 0, 7)])
+    eng = types.SimpleNamespace(fused_attn=True, group_wgrads=False, after_conv_hook=None)
+    model = types.SimpleNamespace(engines=[eng])
+    batch = lambda k, T: (torch.zeros(k, 1, 161, T),)
+    tr = mtl_amd.TransientTrainer()
+    val = batch(2, 50)
+    assert tr._can_batch(model, [batch(2, 64), batch(2, 64)], val, False)
+    assert tr._can_batch(model, [batch(2, 64), batch(2, 40)], val, False)            # fill 0.81
+    assert tr._can_batch(model, [batch(2, 64), batch(2, 8), batch(2, 8)], val, False)           # fill 80 / 192 = 0.42
+    assert not tr._can_batch(model, [batch(2, 64), batch(2, 4), batch(2, 4), batch(2, 4)], val, False)      # fill 76 / 256 = 0.30: lanes
+    assert not tr._can_batch(model, [batch(2, 64), batch(3, 64)], val, False)        # different sample counts
+    assert not tr._can_batch(model, [batch(2, 64), batch(2, 3)], val, False)         # a batch too short for two poolings
+    assert not tr._can_batch(model, [batch(2, 64)], val, False)                      # one task: a lane
+    tr.batch_ragged = False
+    assert tr._can_batch(model, [batch(2, 64), batch(2, 64)], val, False) and not tr._can_batch(model, [batch(2, 64), batch(2, 40)], val, False)
