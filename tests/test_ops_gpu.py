@@ -810,7 +810,7 @@ def test_weight_preparation_and_bounds_for_several_parameter_sets(L):
     """mtl_conv3x3_wprep_h2_batch_tb (all three layers of the theta' stack in two launches) and mtl_absmax_f32_tb (the bounds of nt
     tensors in one launch) against the per-set calls: bit for bit."""
     g = torch.Generator().manual_seed(77)
-    nt, total = 5, 4 * 30001
+    nt, total = 5, 4 * 70001          # (a set must hold its last layer: 110640 + 128 * 128 * 9 = 258096 floats; a shorter one read past the allocation)
     theta = (torch.randn(nt, total, generator=g) * torch.tensor([3.0 ** k for k in range(nt)]).view(-1, 1)).cuda()
     layers = ((64, 64, 0), (128, 64, 36864 + 16), (128, 128, 36864 + 16 + 73728 + 32))        # (Cout, Cin, offset of the weight in theta)
     nbs = [(L.mtl_conv3x3_wprep_h2_bytes(co, ci) + 255) // 256 * 256 for co, ci, _ in layers]
