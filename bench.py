@@ -449,10 +449,21 @@ def stall_watch():
 
 
 def timed_steps(trainer, model, vocab, tasks, my_tasks, n_tasks, inner, outer, args, steps, warmup, mdist, dev):
-    val = tasks[-1].sample(0, 0, 0)[1]
-    local = [tasks[m].sample(0, 0, m)[0] for m in my_tasks]
+    fresh = hasattr(tasks[0], 'batch')            # --ragged: new batches (new shapes) every step
+    state = {}
+
+    def draw():
+        if fresh:       # every rank draws EVERY task's batch (the generators stay in lock-step across the ranks, like the reference's loop)
+            every = [t.batch() for t in tasks]
+            state['val'] = tasks[-1].batch()
+            state['local'] = [every[m] for m in my_tasks]
+        elif not state:
+            state['val'] = tasks[-1].sample(0, 0, 0)[1]
+            state['local'] = [tasks[m].sample(0, 0, m)[0] for m in my_tasks]
+        return state['local'], state['val']
 
     def one():
+        local, val = draw()
         return trainer.run_iteration(model, vocab, local, val, n_tasks, inner, outer, args)
     for _ in range(warmup):
         one()
@@ -469,6 +480,7 @@ def timed_steps(trainer, model, vocab, tasks, my_tasks, n_tasks, inner, outer, a
     sw = stall_watch()
     for _ in range(steps):
         if pipelined:
+            local, val = draw()
             if sw is not None:
                 sw.sw_enter()
             pending.append(trainer.enqueue_iteration(model, vocab, local, val, n_tasks, inner, outer, args))
@@ -707,6 +719,7 @@ def main():
     ap.add_argument('--lanes', action='store_true', help='per-task pass chains on concurrent lanes instead of task-batched passes (MTL_BATCH_TASKS=0)')
     ap.add_argument('--serial', action='store_true', help='no task lanes / side stream / replay (for rocprofv3 per-kernel durations)')
     ap.add_argument('--host-inputs', action='store_true', help='diagnostics: the headline region with every batch uploaded from pinned host memory per step (what the `with_h2d` leg measures)')
+    ap.add_argument('--ragged', action='store_true', help='diagnostics: the headline region on manifest-like batches (every batch padded to its own longest utterance of 0.6 ... 1.0 x --frames, new shapes every step)')
     ap.add_argument('--workload', default='asr', choices=['asr', 'lm'], help="'lm': the LSTM-LM meta loop (BASELINE.json configs[4], SURVEY 8(f) f3)")
     a = ap.parse_args()
 
@@ -750,6 +763,8 @@ def main():
     inner, outer = mtl_amd.FlatSGD(model, args.lr), mtl_amd.FlatAdam(model, args.meta_lr)
     model.zero_copy_grad()
     tasks = [ResidentTask(mtl_amd, m, a.k, a.frames, a.labels, CFG['vocab_size'], dev) for m in range(a.tasks)]
+    if a.ragged:
+        tasks = [RaggedTask(m, a.k, int(0.6 * a.frames), a.frames, a.labels, CFG['vocab_size'], dev) for m in range(a.tasks)]
     if a.host_inputs:
         tasks = [PinnedHostTask(mtl_amd, m, a.k, a.frames, a.labels, CFG['vocab_size']) for m in range(a.tasks)]
     my_tasks = mdist.shard_tasks(a.tasks, rank, world)

@@ -524,6 +524,32 @@ def test_sharded_bench_at_four_and_eight_ranks_on_one_gpu(world, tasks):
     assert len(many.stdout.strip().splitlines()[-1]) < 4096
 
 
+def test_sharded_bench_on_manifest_like_batches_equals_single_rank():
+    """Two gloo ranks sharing this box's GPU, two tasks each, on batches padded to their OWN longest utterance with new shapes every step
+    (`bench.py --ragged`): every rank stacks its tasks at its own widest (a different width per rank and step), the three slice
+    all-reduces leave under the validation backward as in the fixed-shape case; the step must reproduce the single-process run
+    (4 tasks in one stack) and leave bit-identical replicas."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ['--steps', '3', '--warmup', '1', '--tasks', '4', '--k', '2', '--frames', '150', '--labels', '12', '--no-cpu-baseline', '--no-extras', '--ragged']
+    env = dict(os.environ, MTL_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0', MTL_POOL_GB='2', MTL_RAGGED_QUANTUM='16')
+    one = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1'] + common, capture_output=True, text=True, env=env, timeout=300)
+    assert one.returncode == 0, one.stderr[-2000:]
+    two = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                          '--master-port', '29761', os.path.join(root, 'bench.py'), '--gpus', '2'] + common, capture_output=True, text=True,
+                         env=env, timeout=600)
+    assert two.returncode == 0, two.stderr[-3000:]
+    j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith('{')][-1])
+    j2 = json.loads([l for l in two.stdout.splitlines() if l.startswith('{')][-1])
+    assert j2['multi_gpu']['ranks'] == 2 and j2['multi_gpu']['replicas_bit_identical'] is True
+    assert j1['last_step']['chars'] == j2['last_step']['chars'] and j1['last_step']['cer_edits'] == j2['last_step']['cer_edits']
+    assert abs(j1['last_step']['val_loss'] - j2['last_step']['val_loss']) < 1e-4 * abs(j1['last_step']['val_loss'])
+    assert abs(j1['theta_checksum'][0] - j2['theta_checksum'][0]) < 1e-5 * abs(j1['theta_checksum'][0])
+
+
 def test_dropout_pass_matches_oracle_with_the_same_masks():
     """--dropout 0.1 (README config): the keep-masks the HIP pass drew are replayed inside the oracle, so
     forward and backward must agree exactly like the dropout-free pass (the masks themselves come from Philox, not from
