@@ -36,6 +36,11 @@ def test_bench_line_is_small_and_parseable():
         assert k in line['cpu_baseline'], k
     assert 'per_class' not in line['roofline'] and 'per_family' not in line['roofline']
     assert isinstance(line['with_h2d'], float) and isinstance(line['one_task_per_gpu_ms'], float)
+    # this round's complete output (bench_detail.json): the manifest-like leg rides in the line as a bare number
+    full = json.load(open(os.path.join(ROOT, 'profiles', 'r5', 'bench_detail.json')))
+    text5 = json.dumps(bench.compact_line(full))
+    assert len(text5) < bench.LINE_LIMIT and isinstance(json.loads(text5)['ragged_frames'], float)
+    assert full['ragged_frames']['schedule'] == 'batched-ragged' and full['ragged_frames']['value'] > 0.9 * full['value']
 
 
 def test_emit_prints_one_short_line_last(capsys, tmp_path, monkeypatch):
