@@ -613,3 +613,47 @@ def test_stand_alone_passes_at_rounded_widths_match_the_oracle_at_their_own():
                     for (_, p), (_, q) in zip(model.named_parameters(), oracle.named_parameters()))
         print('T = %d (run at %d): worst parameter gradient %.2e' % (T, widened, worst))
         assert worst < RTOL
+
+
+def test_ragged_stack_with_clipping_smoothing_and_another_validation_batch_size():
+    """The stacked schedule on tasks of different frame counts with per-task gradient clipping, label smoothing and a validation batch
+    of another sample count (k_valid != k_train), against a lane per task at its own width; then with dropout 0.1: two runs of the
+    same iteration give the same bits (Philox streams are per site and position, the stack's padding does not move them)."""
+    z, cfg, spec = gu.load('F0')
+    mtl_amd, args, vocab, model = make(cfg, spec)
+    args.clip, args.max_norm, args.label_smoothing = True, 0.05, 0.1
+    model = model.cuda()
+    V = cfg['vocab_size']
+    frames, widths = (61, 38, 47, 52), (8, 5, 11, 7)
+    tasks = _ragged_tasks(mtl_amd, 3, frames, widths, V, 1140)
+    val = _ragged_tasks(mtl_amd, 2, (55,), (6,), V, 1199)[0]
+    inner = mtl_amd.FlatSGD(model, spec['lr'])
+    model.zero_copy_grad()
+    own, stacked = mtl_amd.TransientTrainer(), mtl_amd.TransientTrainer()
+    own.pad_lanes, stacked.ragged_quantum = '0', 16
+    G0, r0, _, log0 = _iteration(mtl_amd, model, vocab, args, tasks, val, 4, inner, False, tr=own, gates=True)
+    G1, r1, _, log1 = _iteration(mtl_amd, model, vocab, args, tasks, val, 4, inner, True, tr=stacked, gates=True)
+    assert stacked.last_schedule == 'batched-ragged' and own.last_schedule == 'lanes'
+    flips = 0
+    for i, (ga, gb) in enumerate(zip(log0, log1)):
+        crop, beyond = _crop_gates(gb, 2 if i % 2 else 3, 55 if i % 2 else frames[i // 2], 7 if i % 2 else widths[i // 2] + 1)
+        assert beyond == 0 or i % 2, (i, beyond)
+        flips += _decisions_differ(ga, crop)
+    for (l0, h0, g0), (l1, h1, g1) in zip(r0, r1):
+        w = g0.shape[1]
+        assert torch.equal(g0, g1[:, :w]) and torch.equal(h0, h1[:, :w]) and abs(l0 - l1) <= 2e-6 * abs(l0)
+    errs = _tensor_errs(model, G1, G0)
+    worst = max(errs, key=errs.get)
+    print('clip + smoothing, k_valid 2 / k_train 3: stacked vs lanes: %d differing decisions, worst tensor %.2e (%s)' % (flips, errs[worst], worst))
+    assert flips <= 2 and errs[worst] < (1e-4 if flips == 0 else 1e-2), (worst, errs[worst], flips)
+    model.encoder.dropout_rate = model.decoder.dropout_rate = 0.1
+    model.train()
+    runs = []
+    for rep in range(2):
+        torch.manual_seed(4242)                              # the pass seeds come from torch's CPU generator
+        tr = mtl_amd.TransientTrainer()
+        tr.ragged_quantum = 16
+        G, r, _, _ = _iteration(mtl_amd, model, vocab, args, tasks, val, 4, inner, True, tr=tr)
+        runs.append((G, [x[0] for x in r]))
+    assert torch.equal(runs[0][0], runs[1][0]) and runs[0][1] == runs[1][1]
+    assert not torch.equal(runs[0][0], G1)                   # (dropout did act)
