@@ -198,15 +198,20 @@ int mtl_conv3x3_dgrad_h2(void* stream, const float* dy, const float* amax_dy, co
  * meta-step are independent given theta0): x / y / dy / dx / act / argmax hold tasks * B samples, task k = samples [k B, (k + 1) B);
  * task k reads its prepared weights at w2 + k * sW BYTES (0: all tasks share theta0's -- the training passes), its bias at
  * bias + k * sBias floats, its operand bound at amax + k * sAmaxX floats and raises its own output bound at amax_y + k * sAmaxY.
- * Per task bitwise the single-task launch (same tiles, same scales); one launch of 64 samples costs 2-14 % less than eight of 8. */
+ * Per task bitwise the single-task launch (same tiles, same scales); one launch of 64 samples costs 2-14 % less than eight of 8.
+ * widths (optional, `tasks` ints on the device, with mtl_zero_tails): the tasks' own frame counts when their batches were stacked at a
+ * common T; rows t >= widths[k] >> wshift of task k's samples (t = the row index of this launch's convolution: before its pooling, the
+ * data gradient's output rows) are then NOT computed -- whole pixel-tile rows beyond them are left out of the launch and their outputs
+ * stay untouched: the caller clears them (mtl_zero_tails) before anything reads them.  NULL: every row. */
 int mtl_conv3x3_relu_fwd_h2_tb(void* stream, const float* x, const float* amax_x, const void* w2_fwd, const float* bias, float* y,
-                               float* amax_y, int B, int T, int F, int Cin, int Cout, int tasks, long sW, long sBias, long sAmaxX, long sAmaxY);
+                               float* amax_y, int B, int T, int F, int Cin, int Cout, int tasks, long sW, long sBias, long sAmaxX, long sAmaxY,
+                               const int* widths, int wshift);
 int mtl_conv3x3_relu_pool_fwd_h2_tb(void* stream, const float* x, const float* amax_x, const void* w2_fwd, const float* bias, float* p_out,
                                     unsigned char* argmax, float* amax_p, int B, int T, int F, int Cin, int Cout, int tasks, long sW,
-                                    long sBias, long sAmaxX, long sAmaxP);
+                                    long sBias, long sAmaxX, long sAmaxP, const int* widths, int wshift);
 int mtl_conv3x3_dgrad_h2_tb(void* stream, const float* dy, const float* amax_dy, const unsigned char* argmax, const void* w2_dgrad,
                             const float* act, float* dx, float* amax_dx, int B, int T, int F, int Cin, int Cout, int tasks, long sW,
-                            long sAmaxDy, long sAmaxDx);
+                            long sAmaxDy, long sAmaxDx, const int* widths, int wshift);
 /* weight (+ bias) gradients of `tasks` meta-tasks in one launch: x / dy / argmax hold tasks * B samples; task k reads its bounds at
  * amax_x + k sAmaxX, amax_dy + k sAmaxDy floats and accumulates onto dw_ref + k sDw, db + k sDb floats (the per-task gradient stack).
  * The launch's partial slabs (workspace: mtl_conv3x3_wgrad_x3_workspace, unchanged) are dealt to the tasks in equal contiguous ranges,

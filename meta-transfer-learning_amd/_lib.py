@@ -61,9 +61,9 @@ SIGNATURES = {
     'mtl_conv3x3_relu_fwd_h2': (I, [P, P, P, P, P, P, P, I, I, I, I, I]),
     'mtl_conv3x3_relu_pool_fwd_h2': (I, [P, P, P, P, P, P, P, P, I, I, I, I, I]),
     'mtl_conv3x3_dgrad_h2': (I, [P, P, P, P, P, P, P, P, I, I, I, I, I]),
-    'mtl_conv3x3_relu_fwd_h2_tb': (I, [P, P, P, P, P, P, P, I, I, I, I, I, I, L, L, L, L]),
-    'mtl_conv3x3_relu_pool_fwd_h2_tb': (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, I, L, L, L, L]),
-    'mtl_conv3x3_dgrad_h2_tb': (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, I, L, L, L]),
+    'mtl_conv3x3_relu_fwd_h2_tb': (I, [P, P, P, P, P, P, P, I, I, I, I, I, I, L, L, L, L, P, I]),
+    'mtl_conv3x3_relu_pool_fwd_h2_tb': (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, I, L, L, L, L, P, I]),
+    'mtl_conv3x3_dgrad_h2_tb': (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, I, L, L, L, P, I]),
     'mtl_conv3x3_wgrad_h2': (I, [P, P, P, P, P, P, P, P, P, L, I, I, I, I, I]),
     'mtl_conv3x3_wgrad_h2_tb': (I, [P, P, P, P, P, P, P, P, P, L, I, I, I, I, I, I, L, L, L, L]),
     'mtl_absmax_f32': (I, [P, P, L, P]),

@@ -898,6 +898,11 @@ struct ConvX3P {
     // (prologue, tail and launch boundary of a persistent grid: tools/probe/conv_batch_tasks.py)
     int Bt;
     long sW, sBias, sAmaxIn, sAmaxOut;
+    // tasks of different frame counts stacked at a common T (mtl_zero_tails): task k's rows t >= widths[k] >> wshift are not computed at
+    // all -- the tile index space holds only the ceil(rows / tile rows) leading tile rows of every task (their outputs are left untouched:
+    // the caller clears them).  nullptr: every tile of the T x F extent.
+    const int* widths;
+    int wshift;
 #ifdef MTL_X3_PROF
     unsigned long long* prof;   // probe builds only (tools/probe/conv_prof.py): [workgroup][wave][8] accumulated s_memtime intervals
 #endif
@@ -950,16 +955,56 @@ inline int device_cu_count() {
 }
 
 template <int G>
-__device__ inline X3Tile x3_tile(const ConvX3P& p, int id) {
+__device__ inline int x3_task_rows(const ConvX3P& p, int task) {      // tile rows of a task that has frames of its own
+    const int r = ((p.widths[task] >> p.wshift) + 8 * G - 1) / (8 * G);
+    return r < p.ntt ? (r < 1 ? 1 : r) : p.ntt;
+}
+
+template <int G>
+__device__ inline int x3_total_tiles(const ConvX3P& p) {
+    if (!p.widths) return p.tiles;
+    const int nt = p.g.B / p.Bt;
+    int total = 0;
+    for (int k = 0; k < nt; ++k) total += p.Bt * p.ntile * x3_task_rows<G>(p, k) * p.ntf;
+    return total;
+}
+
+// A role's position in the compacted index space (per-task tile rows): a role asks for tiles in rising order, so the walk over the
+// tasks -- one load of a frame count each -- advances a few times per kernel, not once per tile.
+struct X3Cur {
+    int k = 0, lo = 0, hi = -1, ntt = 0;
+};
+
+template <int G>
+__device__ inline X3Tile x3_tile(const ConvX3P& p, int id, X3Cur& c) {
     X3Tile t;
+    int ntt = p.ntt, b0 = 0;
+    if (p.widths) {                // compacted index space: task by task, each with its own number of tile rows
+        const int per_row = p.Bt * p.ntile * p.ntf, nt = p.g.B / p.Bt;
+        if (c.hi < 0 || id < c.lo) {
+            c.k = 0;
+            c.lo = 0;
+            c.ntt = x3_task_rows<G>(p, 0);
+            c.hi = per_row * c.ntt;
+        }
+        while (id >= c.hi && c.k < nt - 1) {
+            ++c.k;
+            c.lo = c.hi;
+            c.ntt = x3_task_rows<G>(p, c.k);
+            c.hi = c.lo + per_row * c.ntt;
+        }
+        id -= c.lo;
+        ntt = c.ntt;
+        b0 = c.k * p.Bt;
+    }
     const int fx = id % p.ntf;
     id /= p.ntf;
-    const int ty = id % p.ntt;
-    id /= p.ntt;
+    const int ty = id % ntt;
+    id /= ntt;
     t.f0 = fx * 16;
     t.t0 = ty * (8 * G);
     t.n0 = id % p.ntile;           // output-channel tile index (x BN at the use site)
-    t.b = id / p.ntile;
+    t.b = b0 + id / p.ntile;
     return t;
 }
 
@@ -984,7 +1029,8 @@ void conv3x3_x3h_kernel(ConvX3P p) {
     const int tid = threadIdx.x;
     const int Cin = p.g.Cin, Cout = p.g.Cout, cch = Cin / BK, nk = 9 * cch;
     const int T = p.g.T, F = p.g.F, Tp = p.g.Tp, Fp = p.g.Fp;
-    const int my_tiles = (p.tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int my_tiles = (x3_total_tiles<G>(p) - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    if (my_tiles <= 0) return;                                     // (fewer tiles than workgroups: only with per-task rows)
     const int nstage = my_tiles * cch;                             // stage q = (tile q / cch of this workgroup, chunk q % cch)
     const int nstep = nstage * 9;                                  // step s = stage * 9 + tap; weight stage s % 3
 
@@ -993,9 +1039,10 @@ void conv3x3_x3h_kernel(ConvX3P p) {
         const int ptid = tid - NCONS - 64;
         float sx = NP == 2 ? pow2_scale(amax_read(p.amax_in)) : 1.f;
         int sx_task = 0;
+        X3Cur cur_scale, cur_halo;
         auto set_scale = [&](int qc) {          // the operand scale of the task that stage qc's tile belongs to
             if (NP != 2 || p.Bt >= p.g.B) return;
-            const int tk = x3_tile<G>(p, blockIdx.x + (qc / cch) * gridDim.x).b / p.Bt;
+            const int tk = x3_tile<G>(p, blockIdx.x + (qc / cch) * gridDim.x, cur_scale).b / p.Bt;
             if (tk != sx_task) {
                 sx_task = tk;
                 sx = pow2_scale(amax_read(p.amax_in + tk * p.sAmaxIn));
@@ -1006,7 +1053,7 @@ void conv3x3_x3h_kernel(ConvX3P p) {
         unsigned hm[XH_NVA];
         auto fetch_halo = [&](int q) {          // stage q: channels c*32 .. +31 of the halo pixels of its tile
             const int j = q / cch, c = q - j * cch;
-            const X3Tile tl = x3_tile<G>(p, blockIdx.x + j * gridDim.x);
+            const X3Tile tl = x3_tile<G>(p, blockIdx.x + j * gridDim.x, cur_halo);
 #pragma unroll
             for (int i = 0; i < XH_NVA; ++i) {
                 const int e = ptid + i * NHALO;
@@ -1096,12 +1143,13 @@ void conv3x3_x3h_kernel(ConvX3P p) {
         const int lane = tid & 63;
         const bool doB = !(p.dbg & 4);
         int dma_j = -1, dma_n0 = 0;
+        X3Cur cur_dma;
         const unsigned char* dma_w3 = p.w3;
         auto dma = [&](int s_) {
             const int q = s_ / 9, tap = s_ - q * 9;
             const int j = q / cch, c = q - j * cch;
             if (j != dma_j && (p.ntile != 1 || p.Bt < p.g.B)) {      // (once per tile: the tile's channel block and its task's weights)
-                const X3Tile tl = x3_tile<G>(p, blockIdx.x + j * gridDim.x);
+                const X3Tile tl = x3_tile<G>(p, blockIdx.x + j * gridDim.x, cur_dma);
                 dma_n0 = tl.n0 * BN;
                 dma_w3 = p.w3 + (tl.b / p.Bt) * p.sW;
                 dma_j = j;
@@ -1173,6 +1221,7 @@ void conv3x3_x3h_kernel(ConvX3P p) {
     float inv = 1.f, mx = 0.f;                                 // NP = 2: 1 / (activation scale x weight scale); running bound of max|y|
     if (NP == 2) inv = 1.f / (pow2_scale(amax_read(p.amax_in)) * *reinterpret_cast<const float*>(p.w3 + (long)NP * nk * Cout * 64));
     int cur_task = 0;                                          // (several tasks per launch: the task of the tile being finished)
+    X3Cur cur_epi;
     const float* bias_t = p.bias;
     // |relu(v + b)| <= |v| + |b| (pooling takes a maximum of those); dgrad: |gate v| <= |v|: the bound of a task's output leaves when
     // the workgroup's tiles move on to the next task (its tile sequence visits the tasks in order) and at the end
@@ -1300,7 +1349,7 @@ void conv3x3_x3h_kernel(ConvX3P p) {
                 // above the MFMA loops they were spilled per tile, and the scratch traffic doubled the dgrad kernels' HBM writes)
                 int jj = j;
                 asm volatile("" : "+s"(jj));
-                const X3Tile tl = x3_tile<G>(p, blockIdx.x + jj * gridDim.x);
+                const X3Tile tl = x3_tile<G>(p, blockIdx.x + jj * gridDim.x, cur_epi);
                 const int ts0 = tl.t0 + grp * 8, n0 = tl.n0 * BN;
                 if (p.Bt < p.g.B) {
                     const int tk = tl.b / p.Bt;
@@ -2482,9 +2531,13 @@ __global__ void conv_wprep_h2_batch_kernel(WprepBatch b) {
 struct ConvTasks {
     int tasks;
     long sW, sBias, sAmaxIn, sAmaxOut;
+    const int* widths = nullptr;
+    int wshift = 0;
 };
 static inline void set_tasks(ConvX3P& p, int B, const ConvTasks& tk) {
     p.Bt = B;
+    p.widths = tk.widths;
+    p.wshift = tk.wshift;
     p.sW = tk.sW;
     p.sBias = tk.sBias;
     p.sAmaxIn = tk.sAmaxIn;
@@ -2597,23 +2650,27 @@ int mtl_conv3x3_dgrad_h2(void* stream, const float* dy, const float* amax_dy, co
 }
 
 int mtl_conv3x3_relu_fwd_h2_tb(void* stream, const float* x, const float* amax_x, const void* w2_fwd, const float* bias, float* y,
-                               float* amax_y, int B, int T, int F, int Cin, int Cout, int tasks, long sW, long sBias, long sAmaxX, long sAmaxY) {
+                               float* amax_y, int B, int T, int F, int Cin, int Cout, int tasks, long sW, long sBias, long sAmaxX, long sAmaxY,
+                               const int* widths, int wshift) {
+    if (wshift < 0 || wshift > 8) return MTL_EINVAL;
     return conv_fwd_pieces<2>(as_stream(stream), x, amax_x, w2_fwd, bias, y, nullptr, amax_y, false, B, T, F, Cin, Cout,
-                              ConvTasks{tasks, sW, sBias, sAmaxX, sAmaxY});
+                              ConvTasks{tasks, sW, sBias, sAmaxX, sAmaxY, widths, wshift});
 }
 
 int mtl_conv3x3_relu_pool_fwd_h2_tb(void* stream, const float* x, const float* amax_x, const void* w2_fwd, const float* bias, float* p_out,
                                     unsigned char* argmax, float* amax_p, int B, int T, int F, int Cin, int Cout, int tasks, long sW,
-                                    long sBias, long sAmaxX, long sAmaxP) {
+                                    long sBias, long sAmaxX, long sAmaxP, const int* widths, int wshift) {
+    if (wshift < 0 || wshift > 8) return MTL_EINVAL;
     return conv_fwd_pieces<2>(as_stream(stream), x, amax_x, w2_fwd, bias, p_out, argmax, amax_p, true, B, T, F, Cin, Cout,
-                              ConvTasks{tasks, sW, sBias, sAmaxX, sAmaxP});
+                              ConvTasks{tasks, sW, sBias, sAmaxX, sAmaxP, widths, wshift});
 }
 
 int mtl_conv3x3_dgrad_h2_tb(void* stream, const float* dy, const float* amax_dy, const unsigned char* argmax, const void* w2_dgrad,
                             const float* act, float* dx, float* amax_dx, int B, int T, int F, int Cin, int Cout, int tasks, long sW,
-                            long sAmaxDy, long sAmaxDx) {
+                            long sAmaxDy, long sAmaxDx, const int* widths, int wshift) {
+    if (wshift < 0 || wshift > 8) return MTL_EINVAL;
     return conv_dgrad_pieces<2>(as_stream(stream), dy, amax_dy, argmax, w2_dgrad, act, dx, amax_dx, B, T, F, Cin, Cout,
-                                ConvTasks{tasks, sW, 0, sAmaxDy, sAmaxDx});
+                                ConvTasks{tasks, sW, 0, sAmaxDy, sAmaxDx, widths, wshift});
 }
 
 long mtl_conv3x3_wgrad_workspace(int B, int T, int F, int Cin, int Cout, int pooled) {

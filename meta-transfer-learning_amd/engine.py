@@ -262,6 +262,7 @@ class PassEngine:
         # eight lanes keep 8 x 48 GiB of stale shapes and ran a north-star run on ragged batches out of memory).  An eviction bumps
         # scratch_epoch, which makes the trainer re-record its command lists (they hold raw addresses).
         self.account = _pool_account(device)
+        self.conv_skip_tails = os.environ.get('MTL_CONV_SKIP_TAILS', '1') != '0'     # ragged stacks: no convolution tiles beyond a task's frames
         self.widen, self.widen_quantum = os.environ.get('MTL_PAD_LANES', 'auto'), int(os.environ.get('MTL_RAGGED_QUANTUM', '64'))
         self._first_width, self._widths_vary = {}, False
         self.pool_budget = self.account['budget']           # (an engine may be given a tighter one of its own: tests)
@@ -1278,14 +1279,21 @@ class PassEngine:
             # per task bitwise the per-task launches (tests/test_ops_gpu.py)
             AS = 12 * _lib.AMAX_SLOTS
             sw = lambda idx: wf[idx].stride(0) if ntw > 1 else 0
+            # (tasks with frame counts of their own: the launches leave out the pixel-tile rows beyond a task's frames -- `skip` -- and
+            # everything a later kernel reads there is cleared: activations, pooled maps and their arg-max bytes)
+            skip = widths if self.conv_skip_tails else None
             check(lib.mtl_conv3x3_relu_pool_fwd_h2_tb(st, y1.data_ptr(), am_(0), wf[2].data_ptr(), o('conv.2.bias'), p1.data_ptr(), am1.data_ptr(),
-                                                      am_(1), B, T, F, 64, 64, nt, sw(2), sP, AS, AS), 'conv2')
+                                                      am_(1), B, T, F, 64, 64, nt, sw(2), sP, AS, AS, skip, 0), 'conv2')
             tails(p1, T2, F2 * 64, 1)
             check(lib.mtl_conv3x3_relu_fwd_h2_tb(st, p1.data_ptr(), am_(1), wf[5].data_ptr(), o('conv.5.bias'), y5.data_ptr(), am_(2),
-                                                 B, T2, F2, 64, 128, nt, sw(5), sP, AS, AS), 'conv5')
+                                                 B, T2, F2, 64, 128, nt, sw(5), sP, AS, AS, skip, 1), 'conv5')
             tails(y5, T2, F2 * 128, 1)
             check(lib.mtl_conv3x3_relu_pool_fwd_h2_tb(st, y5.data_ptr(), am_(2), wf[7].data_ptr(), o('conv.7.bias'), p2.data_ptr(), am2.data_ptr(),
-                                                      am_(6), B, T2, F2, 128, 128, nt, sw(7), sP, AS, AS), 'conv7')
+                                                      am_(6), B, T2, F2, 128, 128, nt, sw(7), sP, AS, AS, skip, 1), 'conv7')
+            if skip is not None:
+                tails(p2, T4, F4 * 128, 2)
+                tails(am1, T2, F2 * 64 // 4, 1)          # (bytes, four to a float)
+                tails(am2, T4, F4 * 128 // 4, 2)
         else:
             def c2(t, tw, sl):
                 check(conv_fwd_pool(st, y1[sl].data_ptr(), wf[2][tw].data_ptr(), o('conv.2.bias', t), p1[sl].data_ptr(), am1[sl].data_ptr(),
@@ -1656,6 +1664,12 @@ class PassEngine:
         f5, f2 = fold(None), fold(A['am1'])
         xin = S['x']
         merged = h2 and nt > 1 and self.conv_tb     # data gradients of conv7 / conv5: ONE launch over the samples of all tasks (see forward)
+        # tasks with frame counts of their own (forward): the data gradients leave out the tile rows beyond a task's frames and those
+        # rows of their outputs are cleared right behind them -- bias sums, bounds and weight gradients read whole tensors
+        widths_b = S['meta'].get('widths')
+        skip = widths_b if (merged and self.conv_skip_tails) else None
+        tails_b = (lambda buf_, T_, row_, shift_: check(lib.mtl_zero_tails(st, buf_.data_ptr(), nt * B, T_, row_, skip, shift_, B), 'mtl_zero_tails')) \
+            if skip is not None else (lambda *a_: None)
         AS = 12 * _lib.AMAX_SLOTS
         swd = lambda name: A[name].stride(0) if (sP and nt > 1) else 0
 
@@ -1685,8 +1699,12 @@ class PassEngine:
             if wg:
                 wgrad(t, y1[sl].data_ptr(), 0, dp1[sl].data_ptr(), 5, am1_t, 2, B, T, F, 64, 64, db=g('conv.2.bias', t) if f2 else None)
             # (conv2's data gradient stays one launch per task: 8 x 16 tiles, measured no faster merged)
-            check(conv_dgrad(t, dp1[sl].data_ptr(), 5, am1_t, A['wd2'][tw].data_ptr(), y1[sl].data_ptr(), dy1[sl].data_ptr(),
-                             B, T, F, 64, 64), 'dgrad2')
+            if skip is not None:      # ... through the several-task entry point with ONE task: it takes the task's own frame count
+                check(lib.mtl_conv3x3_dgrad_h2_tb(st, dp1[sl].data_ptr(), am_(5, t), am1_t, A['wd2'][tw].data_ptr(), y1[sl].data_ptr(),
+                                                  dy1[sl].data_ptr(), None, B, T, F, 64, 64, 1, 0, 0, 0, skip + 4 * t, 0), 'dgrad2')
+            else:
+                check(conv_dgrad(t, dp1[sl].data_ptr(), 5, am1_t, A['wd2'][tw].data_ptr(), y1[sl].data_ptr(), dy1[sl].data_ptr(),
+                                 B, T, F, 64, 64), 'dgrad2')
             if w0:
                 ws = self.scratch(lib.mtl_conv0_wgrad_workspace())
                 check(lib.mtl_conv0_wgrad(st, xin.data_ptr() + 4 * t * sX, dy1[sl].data_ptr(), g('conv.0.weight', t), g('conv.0.bias', t),
@@ -1712,18 +1730,21 @@ class PassEngine:
                     sl = slice(t * B, (t + 1) * B)
                     wgrad(t, y5[sl].data_ptr(), 2, dp2[sl].data_ptr(), 3, A['am2'][sl].data_ptr(), 7, B, T2, F2, 128, 128)
             check(lib.mtl_conv3x3_dgrad_h2_tb(st, dp2.data_ptr(), am_(3), A['am2'].data_ptr(), A['wd7'].data_ptr(), y5.data_ptr(), dy5.data_ptr(),
-                                              am_(4) if f5 else None, B, T2, F2, 128, 128, nt, swd('wd7'), AS, AS), 'dgrad7')
+                                              am_(4) if f5 else None, B, T2, F2, 128, 128, nt, swd('wd7'), AS, AS, skip, 1), 'dgrad7')
+            tails_b(dy5, T2, F2 * 128, 1)
             if w5_h2 and f5 and self.conv_tb_wgrad:
                 wgrad_tb(p1.data_ptr(), 1, dy5.data_ptr(), 4, None, 5, T2, F2, 64, 128, g('conv.5.bias'))
             else:
                 for t in range(nt):
                     layer5(t, False)
             check(lib.mtl_conv3x3_dgrad_h2_tb(st, dy5.data_ptr(), am_(4), None, A['wd5'].data_ptr(), p1.data_ptr(), dp1.data_ptr(),
-                                              am_(5) if f2 else None, B, T2, F2, 64, 128, nt, swd('wd5'), AS, AS), 'dgrad5')
+                                              am_(5) if f2 else None, B, T2, F2, 64, 128, nt, swd('wd5'), AS, AS, skip, 1), 'dgrad5')
+            tails_b(dp1, T2, F2 * 64, 1)
             if f2 and self.conv_tb_wgrad:
                 wgrad_tb(y1.data_ptr(), 0, dp1.data_ptr(), 5, A['am1'].data_ptr(), 2, T, F, 64, 64, g('conv.2.bias'))
             for t in range(nt):       # (conv2's data gradient merged as well: 52.23 / 52.63 / 52.83 against 52.03 / 52.18 / 52.92 ms per step: no gain)
                 layer2(t, wg=not (f2 and self.conv_tb_wgrad), w0=False)
+            tails_b(dy1, T, F * 64, 0)
             ws = self.scratch(lib.mtl_conv0_wgrad_workspace())
             check(lib.mtl_conv0_wgrad_tb(st, xin.data_ptr(), dy1.data_ptr(), g('conv.0.weight'), g('conv.0.bias'), ws, B, T, F, nt, sX, sG, sG),
                   'wgrad0_tb')

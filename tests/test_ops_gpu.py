@@ -929,10 +929,10 @@ def test_conv3x3_two_piece_fp16_several_tasks_in_one_launch(L, Cin, Cout, B, T, 
                                                  ayn[t].data_ptr(), B, T, Fq, Cin, Cout) == 0
         if pooled:
             assert L.mtl_conv3x3_relu_pool_fwd_h2_tb(st(), x.data_ptr(), ax.data_ptr(), w2f.data_ptr(), bias.data_ptr(), y1.data_ptr(), am1.data_ptr(),
-                                                     ay1.data_ptr(), B, T, Fq, Cin, Cout, nt, sW, sB, S, S) == 0
+                                                     ay1.data_ptr(), B, T, Fq, Cin, Cout, nt, sW, sB, S, S, None, 0) == 0
         else:
             assert L.mtl_conv3x3_relu_fwd_h2_tb(st(), x.data_ptr(), ax.data_ptr(), w2f.data_ptr(), bias.data_ptr(), y1.data_ptr(), ay1.data_ptr(),
-                                                B, T, Fq, Cin, Cout, nt, sW, sB, S, S) == 0
+                                                B, T, Fq, Cin, Cout, nt, sW, sB, S, S, None, 0) == 0
         torch.cuda.synchronize()
         assert torch.equal(y1, yn) and float(yn.abs().max()) > 0, ('forward', pooled)
         assert torch.equal(ay1.view(nt, -1, 32)[:, :, 0].max(1)[0], ayn.view(nt, -1, 32)[:, :, 0].max(1)[0]), ('output bound', pooled)
@@ -948,10 +948,38 @@ def test_conv3x3_two_piece_fp16_several_tasks_in_one_launch(L, Cin, Cout, B, T, 
             assert L.mtl_conv3x3_dgrad_h2(st(), dy[sl].data_ptr(), ady[t].data_ptr(), amn[sl].data_ptr() if pooled else None, w2d[wk(t)].data_ptr(),
                                           x[sl].data_ptr(), dxn[sl].data_ptr(), adn[t].data_ptr(), B, T, Fq, Cin, Cout) == 0
         assert L.mtl_conv3x3_dgrad_h2_tb(st(), dy.data_ptr(), ady.data_ptr(), amn.data_ptr() if pooled else None, w2d.data_ptr(), x.data_ptr(),
-                                         dx1.data_ptr(), ad1.data_ptr(), B, T, Fq, Cin, Cout, nt, sW, S, S) == 0
+                                         dx1.data_ptr(), ad1.data_ptr(), B, T, Fq, Cin, Cout, nt, sW, S, S, None, 0) == 0
         torch.cuda.synchronize()
         assert torch.equal(dx1, dxn) and float(dxn.abs().max()) > 0, ('data gradient', pooled)
         assert torch.equal(ad1.view(nt, -1, 32)[:, :, 0].max(1)[0], adn.view(nt, -1, 32)[:, :, 0].max(1)[0]), ('dx bound', pooled)
+        # tasks with frame counts of their own (`widths`): pixel-tile rows wholly beyond a task's frames are left out of the launch --
+        # what is computed is bit for bit the full launch, what is left out keeps the buffer's previous content (the caller clears it)
+        wd_host = [max(T - 7 * t - (3 if t else 0), 4) for t in range(nt)]
+        wd = torch.tensor(wd_host, dtype=torch.int32).cuda()
+        yw = torch.full(shp, -7.0).cuda()
+        amw = torch.full(shp, 9, dtype=torch.uint8).cuda()
+        ayw = torch.zeros(nt, S).cuda()
+        if pooled:
+            assert L.mtl_conv3x3_relu_pool_fwd_h2_tb(st(), x.data_ptr(), ax.data_ptr(), w2f.data_ptr(), bias.data_ptr(), yw.data_ptr(), amw.data_ptr(),
+                                                     ayw.data_ptr(), B, T, Fq, Cin, Cout, nt, sW, sB, S, S, wd.data_ptr(), 0) == 0
+        else:
+            assert L.mtl_conv3x3_relu_fwd_h2_tb(st(), x.data_ptr(), ax.data_ptr(), w2f.data_ptr(), bias.data_ptr(), yw.data_ptr(), ayw.data_ptr(),
+                                                B, T, Fq, Cin, Cout, nt, sW, sB, S, S, wd.data_ptr(), 0) == 0
+        dxw = torch.full(x.shape, -7.0).cuda()
+        assert L.mtl_conv3x3_dgrad_h2_tb(st(), dy.data_ptr(), ady.data_ptr(), amn.data_ptr() if pooled else None, w2d.data_ptr(), x.data_ptr(),
+                                         dxw.data_ptr(), None, B, T, Fq, Cin, Cout, nt, sW, S, 0, wd.data_ptr(), 0) == 0
+        torch.cuda.synchronize()
+        left_out = 0
+        for t in range(nt):
+            sl = slice(t * B, (t + 1) * B)
+            own = wd_host[t] // 2 if pooled else wd_host[t]                      # output rows of the task's own extent
+            assert torch.equal(yw[sl, :own], yn[sl, :own]) and torch.equal(dxw[sl, :wd_host[t]], dxn[sl, :wd_host[t]]), (t, pooled)
+            if pooled:
+                assert torch.equal(amw[sl, :own], amn[sl, :own])
+            edge = -(-wd_host[t] // 16) * 16                                     # (tile rows are 8 or 16 pixel rows)
+            assert bool((dxw[sl, edge:] == -7.0).all()) and bool((yw[sl, (edge // 2 if pooled else edge):] == -7.0).all()), (t, pooled)
+            left_out += int((dxw[sl] == -7.0).sum())
+        assert left_out > 0 or T < 24
         # weight + bias gradients of all tasks in one launch (mtl_conv3x3_wgrad_h2_tb): the launch's partial slabs are dealt to the tasks,
         # so a task's pixels are partitioned over fewer slabs than in its own launch -- same arithmetic, another summation tree: equal to
         # the per-task launches within fp32 rounding (and to fp64 like them), accumulating onto the stack, deterministic

@@ -53,11 +53,11 @@ def case(name, T_, F_, cin, cout, pooled, nt=8, B=8):
     axs = ax.repeat(nt, 1).contiguous(); adys = ady.repeat(nt, 1).contiguous(); slots = torch.zeros(nt, 2048, device=dev)
     def tb():
         if pooled:
-            assert L.mtl_conv3x3_relu_pool_fwd_h2_tb(st(), x.data_ptr(), axs.data_ptr(), w2f.data_ptr(), bias.data_ptr(), y.data_ptr(), am.data_ptr(), slots.data_ptr(), B, T_, F_, cin, cout, nt, 0, 0, 2048, 2048) == 0
+            assert L.mtl_conv3x3_relu_pool_fwd_h2_tb(st(), x.data_ptr(), axs.data_ptr(), w2f.data_ptr(), bias.data_ptr(), y.data_ptr(), am.data_ptr(), slots.data_ptr(), B, T_, F_, cin, cout, nt, 0, 0, 2048, 2048, None, 0) == 0
         else:
-            assert L.mtl_conv3x3_relu_fwd_h2_tb(st(), x.data_ptr(), axs.data_ptr(), w2f.data_ptr(), bias.data_ptr(), y.data_ptr(), slots.data_ptr(), B, T_, F_, cin, cout, nt, 0, 0, 2048, 2048) == 0
+            assert L.mtl_conv3x3_relu_fwd_h2_tb(st(), x.data_ptr(), axs.data_ptr(), w2f.data_ptr(), bias.data_ptr(), y.data_ptr(), slots.data_ptr(), B, T_, F_, cin, cout, nt, 0, 0, 2048, 2048, None, 0) == 0
     def d_tb():
-        assert L.mtl_conv3x3_dgrad_h2_tb(st(), dy.data_ptr(), adys.data_ptr(), amp(0), w2d.data_ptr(), x.data_ptr(), dx.data_ptr(), slots.data_ptr(), B, T_, F_, cin, cout, nt, 0, 2048, 2048) == 0
+        assert L.mtl_conv3x3_dgrad_h2_tb(st(), dy.data_ptr(), adys.data_ptr(), amp(0), w2d.data_ptr(), x.data_ptr(), dx.data_ptr(), slots.data_ptr(), B, T_, F_, cin, cout, nt, 0, 2048, 2048, None, 0) == 0
     a, b, c, d, e, f2 = timeit(per_task), timeit(one), timeit(d_per_task), timeit(d_one), timeit(tb), timeit(d_tb)
     print('%-6s forward: %d launches of B=%d %.3f ms | one launch of B=%d %.3f ms (%+.1f %%) | %d tasks in one launch %.3f ms    data gradient: %.3f | %.3f ms (%+.1f %%) | %.3f ms'
           % (name, nt, B, a, nt * B, b, 100 * (b - a) / a, nt, e, c, d, 100 * (d - c) / c, f2))
