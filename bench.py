@@ -178,12 +178,17 @@ GROUP_FLOPS = {}     # table address -> FLOPs of a grouped weight-gradient launc
 def single_task_form(name, a):
     """mtl_conv3x3_*_h2_tb (the samples of `tasks` meta-tasks in one launch) -> the name and argument tuple of the single-task entry
     point over tasks x B samples: same leading arguments, (B, T, F, Cin, Cout) last."""
+    # (argument counts as in include/mtl_hip.h: a prototype that grows must fail HERE, not shift the dimensions silently -- round 5's
+    # `widths, wshift` once turned the convolutions into zero-work launches and the roofline object into the GEMM family)
+    arity = {'mtl_conv3x3_relu_fwd_h2_tb': 19, 'mtl_conv3x3_relu_pool_fwd_h2_tb': 20, 'mtl_conv3x3_dgrad_h2_tb': 19, 'mtl_conv3x3_wgrad_h2_tb': 20}
+    if name in arity and len(a) != arity[name]:
+        raise RuntimeError('%s called with %d arguments, classify() expects %d' % (name, len(a), arity[name]))
     if name in ('mtl_conv3x3_relu_fwd_h2_tb', 'mtl_conv3x3_relu_pool_fwd_h2_tb'):
-        B, T, F, cin, cout, tasks = a[-10:-4]
-        return name[:-3], tuple(a[:-10]) + (B * tasks, T, F, cin, cout)
+        B, T, F, cin, cout, tasks = a[-12:-6]
+        return name[:-3], tuple(a[:-12]) + (B * tasks, T, F, cin, cout)
     if name == 'mtl_conv3x3_dgrad_h2_tb':
-        B, T, F, cin, cout, tasks = a[-9:-3]
-        return name[:-3], tuple(a[:-9]) + (B * tasks, T, F, cin, cout)
+        B, T, F, cin, cout, tasks = a[-11:-5]
+        return name[:-3], tuple(a[:-11]) + (B * tasks, T, F, cin, cout)
     if name == 'mtl_conv3x3_wgrad_h2_tb':
         B, T, F, cin, cout, tasks = a[-10:-4]
         return name[:-3], tuple(a[:-10]) + (B * tasks, T, F, cin, cout)

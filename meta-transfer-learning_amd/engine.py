@@ -1273,7 +1273,8 @@ class PassEngine:
         y5 = self.buf('y5', (Bt, T2, F2, 128))
         p2 = self.buf('p2', (Bt, T4, F4, 128))
         am2 = self.buf('am2', (Bt, T4, F4, 128), torch.uint8)
-        if h2 and nt > 1 and self.conv_tb:
+        # (a single task with frames of its own -- a widened batch on a lane -- takes the several-task launches too: they skip its tail rows)
+        if h2 and self.conv_tb and (nt > 1 or (widths is not None and self.conv_skip_tails)):
             # the samples of all tasks in ONE launch per layer (per-task bounds, weights and biases by stride): a persistent grid's
             # prologue, tail and launch boundary are paid once instead of nt times (2-14 % of a layer: tools/probe/conv_batch_tasks.py);
             # per task bitwise the per-task launches (tests/test_ops_gpu.py)
@@ -1663,7 +1664,7 @@ class PassEngine:
         dy1 = self.buf('_dy1', (nt * B, T, F, 64))
         f5, f2 = fold(None), fold(A['am1'])
         xin = S['x']
-        merged = h2 and nt > 1 and self.conv_tb     # data gradients of conv7 / conv5: ONE launch over the samples of all tasks (see forward)
+        merged = h2 and self.conv_tb and (nt > 1 or (S['meta'].get('widths') is not None and self.conv_skip_tails))     # data gradients of conv7 / conv5: ONE launch over the samples of all tasks (see forward)
         # tasks with frame counts of their own (forward): the data gradients leave out the tile rows beyond a task's frames and those
         # rows of their outputs are cleared right behind them -- bias sums, bounds and weight gradients read whole tensors
         widths_b = S['meta'].get('widths')

@@ -4,6 +4,7 @@ matrix instructions it actually issues."""
 import importlib.util
 import json
 import os
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -84,11 +85,20 @@ def test_every_class_is_priced_on_the_roof_of_its_instructions():
     assert cls == 'attn_fwd' and unit == 'flop' and flops == 2 * 2.0 * 64 * 8 * 250 * 250 * 64
     # the task-batched convolution launches are counted as the tasks x B samples they process
     one = (0, 1, 2, 3, 4, 5, 6, 7, 8, 500, 80, 128, 128)                       # relu_pool_fwd_h2: ..., B, T, F, Cin, Cout
-    tb = one[:8] + (8, 500, 80, 128, 128, 8, 1024, 128, 2048, 2048)             # ..._tb: ..., B, T, F, Cin, Cout, tasks, strides
+    tb = one[:8] + (8, 500, 80, 128, 128, 8, 1024, 128, 2048, 2048, None, 0)    # ..._tb: ..., B, T, F, Cin, Cout, tasks, strides, widths, wshift
     c1 = bench.classify(None, 'mtl_conv3x3_relu_pool_fwd_h2', one, 'h2', True)
     c8 = bench.classify(None, 'mtl_conv3x3_relu_pool_fwd_h2_tb', tb, 'h2', True)
     assert c1[0] == c8[0] == 'conv7_fwd_pool' and c8[1] == 8 * c1[1] and c8[3] == c1[3]
     d1 = (0, 1, 2, 3, 4, 5, 6, 7, 8, 500, 80, 64, 128)
-    d8 = d1[:8] + (8, 500, 80, 64, 128, 8, 4096, 2048, 2048)
+    d8 = d1[:8] + (8, 500, 80, 64, 128, 8, 4096, 2048, 2048, None, 0)
+    # the hand-built tuples above have the arity of the REAL prototypes (a prototype that grows must not shift the dimensions silently)
+    import ctypes
+    sys.path.insert(0, ROOT)
+    import mtl_amd
+    for nm, args_ in (('mtl_conv3x3_relu_pool_fwd_h2_tb', tb), ('mtl_conv3x3_dgrad_h2_tb', d8)):
+        assert len(mtl_amd._lib.SIGNATURES[nm][1]) == len(args_), nm
+    import pytest
+    with pytest.raises(RuntimeError):
+        bench.classify(None, 'mtl_conv3x3_dgrad_h2_tb', d8[:-2], 'h2', True)
     assert bench.classify(None, 'mtl_conv3x3_dgrad_h2_tb', d8, 'h2', True)[1] == 8 * bench.classify(None, 'mtl_conv3x3_dgrad_h2', d1, 'h2', True)[1]
     assert bench.algorithmic_bytes('mtl_conv3x3_dgrad_h2_tb', d8, 'flop', 1.0) == 8 * bench.algorithmic_bytes('mtl_conv3x3_dgrad_h2', d1, 'flop', 1.0)
