@@ -588,21 +588,26 @@ class TransientTrainer():
         _trace.mark('setup')
         on_host = not vx_in.is_cuda or any(not tb[0].is_cuda for tb in task_batches)
         own_tr = min(frames) != T                            # some task is narrower than the stack: borders / lengths of their own
-        if own_tr or Tv != Tv_own:
-            # every task's frames at the front of its slab, zeros behind them (the border its own, narrower image ends in)
+        wide = own_tr or Tv != Tv_own
+        nv = vx_in.numel()
+
+        def place(src_tr, src_va):
+            """every task's frames at the front of its slab, zeros behind them (the border its own, narrower image ends in);
+            src_tr(t) / src_va: device tensors of the batches' own shapes"""
             Xtr.zero_()
             X5 = Xtr.view(nt, B, 1, F, T)
-            for t, (tx, _tsz, _tp, _ty, _tl) in enumerate(task_batches):
-                X5[t, :, :, :, :frames[t]].copy_(tx if tx.is_cuda else tx.to(dev, non_blocking=True), non_blocking=True)
+            for t in range(nt):
+                X5[t, :, :, :, :frames[t]].copy_(src_tr(t), non_blocking=True)
             if Tv != Tv_own:
                 Xva.zero_()
-            Xva[:, :, :, :Tv_own].copy_(vx_in if vx_in.is_cuda else vx_in.to(dev, non_blocking=True), non_blocking=True)
-        elif on_host and self.overlap_uploads:
+            Xva[:, :, :, :Tv_own].copy_(src_va, non_blocking=True)
+        if on_host and self.overlap_uploads:
             xs = self._xset = (getattr(self, '_xset', 0) + 1) % 2
             if getattr(self, '_upload_stream', None) is None:
                 self._upload_stream, self._xfree = torch.cuda.Stream(dev), {}
             Ltr = eng.buf('tb.land_tr.%d' % xs, (nt * B, 1, F, T))
-            Lva = eng.buf('tb.land_va.%d' % xs, tuple(vx_in.shape))
+            Lva = eng.buf('tb.land_va.%d' % xs, tuple(Xva.shape))
+            L2 = Ltr.view(nt, -1)                            # a task's batch lands CONTIGUOUSLY at the front of its slab (its own shape)
             up = self._upload_stream
             with torch.cuda.stream(up):
                 free = self._xfree.get((xs, Ltr.data_ptr(), Lva.data_ptr()))
@@ -613,16 +618,22 @@ class TransientTrainer():
                     Ltr.record_stream(up)                # (the pool may hand the block back to torch's allocator one day)
                     Lva.record_stream(up)
                 for t, (tx, _tsz, _tp, _ty, _tl) in enumerate(task_batches):
-                    Ltr[t * B:(t + 1) * B].copy_(tx, non_blocking=True)
-                Lva.copy_(vx_in, non_blocking=True)
+                    L2[t, :tx.numel()].copy_(tx.reshape(-1), non_blocking=True)
+                Lva.view(-1)[:nv].copy_(vx_in.reshape(-1), non_blocking=True)
                 ready = torch.cuda.Event()
                 ready.record(up)
             main.wait_event(ready)
-            Xtr.copy_(Ltr, non_blocking=True)
-            Xva.copy_(Lva, non_blocking=True)
+            if wide:
+                place(lambda t: L2[t, :B * F * frames[t]].view(B, 1, F, frames[t]), Lva.view(-1)[:nv].view(vx_in.shape))
+            else:
+                Xtr.copy_(Ltr, non_blocking=True)
+                Xva.copy_(Lva, non_blocking=True)
             free = torch.cuda.Event()
             free.record(main)
             self._xfree = {(xs, Ltr.data_ptr(), Lva.data_ptr()): free, **{k_: v_ for k_, v_ in self._xfree.items() if k_[0] != xs}}
+        elif wide:
+            place(lambda t: task_batches[t][0] if task_batches[t][0].is_cuda else task_batches[t][0].to(dev, non_blocking=True),
+                  vx_in if vx_in.is_cuda else vx_in.to(dev, non_blocking=True))
         else:
             for t, (tx, _tsz, _tp, _ty, _tl) in enumerate(task_batches):
                 Xtr[t * B:(t + 1) * B].copy_(tx, non_blocking=True)

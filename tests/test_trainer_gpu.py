@@ -320,11 +320,14 @@ def test_host_one_iteration_ahead_is_bitwise_equal(capsys):
         assert torch.equal(out[False][1], out[True][1])
 
 
-def test_uploads_on_their_own_stream_are_bitwise_equal():
+@pytest.mark.parametrize('ragged', [False, True])
+def test_uploads_on_their_own_stream_are_bitwise_equal(ragged):
     """Batches handed over in (pinned) host memory go up on a separate stream into alternating input sets, one iteration ahead of
     the kernels (TransientTrainer._batched_iteration, transient_trainer.py:182-184,210-212 are inside the reference's span): theta and
     the per-iteration results after 6 pipelined iterations equal those of the in-stream upload (MTL_OVERLAP_UPLOADS=0 behaviour) and
-    those of device-resident inputs, bit for bit -- also across the eager / recording / replay transitions of the command list."""
+    those of device-resident inputs, bit for bit -- also across the eager / recording / replay transitions of the command list.
+    ragged: every batch at a width of its own, new ones every iteration (a batch lands contiguously at the front of its slab of the
+    landing set and is spread into the zero-filled stack on the main stream)."""
     z, cfg, spec = gu.load('F0')
     out = {}
     for mode in ('resident', 'in_stream', 'overlapped'):
@@ -334,10 +337,12 @@ def test_uploads_on_their_own_stream_are_bitwise_equal():
         model.zero_copy_grad()
         tr = mtl_amd.TransientTrainer()
         tr.overlap_uploads = mode == 'overlapped'
+        tr.ragged_quantum = 16
         place = (lambda x: x.cuda()) if mode == 'resident' else (lambda x: x.pin_memory())
         pending, results = [], []
         for it in range(6):
-            b = [mtl_amd.synth_batch(100 * it + m, 2, 64, 8, cfg['vocab_size'], variable=True) for m in range(4)]
+            widths = [64 - ((5 * it + 7 * m) % 23) for m in range(4)] if ragged else [64] * 4
+            b = [mtl_amd.synth_batch(100 * it + m, 2, widths[m], 8, cfg['vocab_size'], variable=True) for m in range(4)]
             as5 = lambda q: (place(q[0]), q[1], None, q[2], None)
             pending.append(tr.enqueue_iteration(model, vocab, [as5(q) for q in b[:3]], as5(b[3]), 3, inner, outer, args))
             while len(pending) > tr.pipeline_depth:
