@@ -77,6 +77,7 @@ class RaggedTask:
     def __init__(self, task_id, k, lo, hi, L, V, device, mode='ragged'):
         self.g = torch.Generator().manual_seed(77 + task_id)
         self.k, self.lo, self.hi, self.L, self.V, self.dev, self.mode = k, lo, hi, L, V, device, mode
+        self.vary_labels = False          # (probe: label widths of L / 2 ... L, a new one per batch)
 
     def batch(self):
         if self.mode == 'fixed':
@@ -88,7 +89,8 @@ class RaggedTask:
         x = torch.randn(self.k, 1, 161, T, device=self.dev)
         for i in range(self.k):
             x[i, :, :, int(lens[i]):] = 0
-        y = torch.randint(4, self.V, (self.k, self.L), generator=self.g)
+        L = self.L if not self.vary_labels else int(torch.randint(max(self.L // 2, 1), self.L + 1, (1,), generator=self.g))
+        y = torch.randint(4, self.V, (self.k, L), generator=self.g)
         return (x, lens, lens.float() / T, y, (y != 0).sum(1).to(torch.int32))
 
     def sample(self, k_train, k_valid, manifest_id):

@@ -138,6 +138,15 @@ def _pinned(key, shape, dtype, turns=1):
     return raw[:nbytes].view(dtype).view(shape)
 
 
+def _label_width(targets, quantum, most):
+    """decoder positions of a pass on these padded targets (longest label sequence + 1), rounded up to a multiple of `quantum`: label
+    widths change from batch to batch like the frame counts, and a wider decoder is exact (positions beyond a sequence are padding:
+    masked as keys, zeroed as rows, outside the loss; their PAD labels leave the CER strings)"""
+    own = max(int((t != PAD_ID).sum(1).max()) for t in targets) + 1
+    q = max(int(quantum), 1)
+    return max(min(-(-own // q) * q, most), own)
+
+
 class PendingIteration:
     """An enqueued meta-iteration: result() waits for ITS end-of-iteration event (not for the device, which may already be
     running the next iteration), then computes the reference's log quantities from the read-backs."""
@@ -363,6 +372,7 @@ class TransientTrainer():
         # the same rounding for a task that runs on a lane of its own (one task per rank; tasks too unequal to stack): 'auto' = from the
         # moment the lanes have seen two different widths (fixed-shape workloads are never padded), '1' always, '0' never
         self.pad_lanes = os.environ.get('MTL_PAD_LANES', 'auto')
+        self.label_quantum = int(os.environ.get('MTL_LABEL_QUANTUM', '8'))      # ... and the decoder width to a multiple of this many positions
         self._lane_widths, self._lane_widths_vary = {}, False
         # train() enqueues iteration i + 1 before it resolves (logs) iteration i (enqueue_iteration); MTL_PIPELINE=0: resolve at once
         self.pipeline = os.environ.get('MTL_PIPELINE', '1') != '0'
@@ -467,8 +477,9 @@ class TransientTrainer():
                 if stagger and 0 < idx < n_lanes:
                     streams[lane].wait_event(phase_ev)        # start this lane half a phase behind lane 0
                 tx, t_own = widened(tx.to(dev, non_blocking=True), eng, 'lane.x_tr')
-                m_tr = eng.prepare(tsz, ty, tx.shape[0], tx.shape[3], slot=0, frames=t_own)   # host ints -> static device buffers
-                m_va = eng.prepare(val_batch[1], val_batch[3], vx.shape[0], vx.shape[3], slot=1, frames=v_own)
+                lw = (lambda y_: _label_width([y_], self.label_quantum, eng.hp.tgt_max_len)) if (q > 1 and self.label_quantum > 1) else (lambda y_: None)
+                m_tr = eng.prepare(tsz, ty, tx.shape[0], tx.shape[3], slot=0, frames=t_own, width=lw(ty))   # host ints -> static device buffers
+                m_va = eng.prepare(val_batch[1], val_batch[3], vx.shape[0], vx.shape[3], slot=1, frames=v_own, width=lw(val_batch[3]))
                 slots = self._slots(model, lane, m_tr, m_va)
                 key = (lane, tuple(tx.shape), tuple(vx.shape), t_own is not None, v_own is not None, m_tr['Td'], m_va['Td'], n_tasks, bool(args.clip),
                        float(args.max_norm), smoothing, float(inner.param_groups[0]['lr']), theta0.data_ptr(), eng.dropout_p,
@@ -639,8 +650,12 @@ class TransientTrainer():
                 Xtr[t * B:(t + 1) * B].copy_(tx, non_blocking=True)
             Xva.copy_(vx_in, non_blocking=True)
         _trace.mark('input_copies')
-        m_tr = eng.prepare_tasks([(tsz, ty) for (_tx, tsz, _tp, ty, _tl) in task_batches], B, T, slot=0, frames=frames if own_tr else None)
-        m_va = eng.prepare_tasks([(val_batch[1], val_batch[3])] * nt, vx_in.shape[0], Tv, slot=1, frames=[Tv_own] * nt if Tv != Tv_own else None)
+        wq = (ragged or varies) and self.ragged_quantum > 1 and self.label_quantum > 1      # label widths repeat like the frame counts
+        lw = (lambda ys: _label_width(ys, self.label_quantum, eng.hp.tgt_max_len)) if wq else (lambda ys: None)
+        m_tr = eng.prepare_tasks([(tsz, ty) for (_tx, tsz, _tp, ty, _tl) in task_batches], B, T, slot=0, frames=frames if own_tr else None,
+                                 width=lw([tb[3] for tb in task_batches]))
+        m_va = eng.prepare_tasks([(val_batch[1], val_batch[3])] * nt, vx_in.shape[0], Tv, slot=1, frames=[Tv_own] * nt if Tv != Tv_own else None,
+                                 width=lw([val_batch[3]]))
         _trace.mark('prepare_tasks')
         Bv = vx_in.shape[0]
         slots = dict(hyp_tr=eng.buf('slot.hyp_tr', (nt * B, m_tr['Td']), torch.int64), loss_tr=eng.buf('slot.loss_tr', (nt,)),

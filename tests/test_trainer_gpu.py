@@ -368,6 +368,7 @@ def test_variable_length_batches_keep_the_buffer_pool_and_the_command_lists_boun
     inner = mtl_amd.FlatSGD(model, spec['lr'])
     model.zero_copy_grad()
     tr = mtl_amd.TransientTrainer()
+    tr.pad_lanes = '0'           # (no rounding to repeating widths here: every iteration is to bring shapes of its own)
 
     def iteration(T, Lw, seed):
         tasks = [as5(mtl_amd.synth_batch(seed + m, 2, T, Lw, cfg['vocab_size'], variable=True)) for m in range(2)]

@@ -28,6 +28,7 @@ def main():
     ap.add_argument('--hi', type=int, default=1000)
     ap.add_argument('--labels', type=int, default=100)
     ap.add_argument('--mode', default='ragged')
+    ap.add_argument('--vary-labels', action='store_true', help='label width of every batch drawn from labels / 2 ... labels')
     ap.add_argument('--hetero', type=float, default=1.0, help='task m draws its utterances from [lo, hi] scaled by hetero + (1 - hetero) m / (n - 1): corpora of different utterance lengths')
     a = ap.parse_args()
     with contextlib.redirect_stdout(io.StringIO()):
@@ -44,6 +45,9 @@ def main():
     model.zero_copy_grad()
     sc = [a.hetero + (1 - a.hetero) * m / max(a.tasks - 1, 1) for m in range(a.tasks)]
     tasks = [RaggedTask(m, a.k, int(a.lo * sc[m]), int(a.hi * sc[m]), a.labels, bench.CFG['vocab_size'], dev, a.mode) for m in range(a.tasks)]
+
+    for t in tasks:
+        t.vary_labels = a.vary_labels
 
     def batches():
         return [t.batch() for t in tasks], tasks[-1].batch()
