@@ -1,7 +1,8 @@
 """bench.py -- meta-steps/sec of the `--copy-grad` meta-transfer step on MI355X (BASELINE.json metric).
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+    (N > 1: either launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`, or started plainly --
+    without RANK / WORLD_SIZE in the environment the script starts its own N ranks under torch.distributed.run: `self_launch_command`)
 
 One "step" = one meta-iteration of `TransientTrainer` (the reference's timed span, trainer/asr/transient_trainer.py:152-264):
 every task does {train forward+backward at theta0, fused inner SGD, validation forward+backward at theta'}, copy_grad
@@ -710,6 +711,20 @@ def physical_cores():
         return os.cpu_count() or 8
 
 
+def self_launch_command(gpus, argv, env):
+    """`python bench.py --gpus N` started WITHOUT a launcher (no RANK / WORLD_SIZE in the environment) and N > 1: the command that
+    starts the N ranks (one process per GPU, torch.distributed.run on the loopback address, a free rendezvous port), else None.
+    Under torchrun (RANK set), with N = 1, or when WORLD_SIZE already says N the script runs as it is."""
+    if gpus <= 1 or 'RANK' in env or int(env.get('WORLD_SIZE', '1')) > 1:
+        return None
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(gpus), '--master-addr', '127.0.0.1',
+            '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -730,7 +745,25 @@ def main():
     ap.add_argument('--workload', default='asr', choices=['asr', 'lm'], help="'lm': the LSTM-LM meta loop (BASELINE.json configs[4], SURVEY 8(f) f3)")
     a = ap.parse_args()
 
-    with contextlib.redirect_stdout(io.StringIO()):          # the model factory prints; keep stdout to ONE JSON line
+    cmd = self_launch_command(a.gpus, sys.argv[1:], os.environ)
+    if cmd is not None:
+        # the ranks inherit stdout: rank 0 prints the ONE line, the others print nothing there (their notes go to stderr)
+        import subprocess
+        if torch.cuda.is_available() and torch.cuda.device_count() < a.gpus and os.environ.get('MTL_DIST_BACKEND', 'nccl') == 'nccl':
+            raise SystemExit('--gpus %d but this node shows %d device(s): RCCL needs one device per rank (MTL_DIST_BACKEND=gloo lets '
+                             'ranks share a device for functional tests)' % (a.gpus, torch.cuda.device_count()))
+        env = dict(os.environ)
+        env.setdefault('OMP_NUM_THREADS', '1')           # (torchrun would set it, with a warning on stderr)
+        env['MTL_BENCH_LAUNCHER'] = 'self'
+        raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+    # stdout carries ONE line, rank 0's JSON: everything else any library writes to file descriptor 1 (gloo's C++ "[Gloo] Rank 0 is
+    # connected to ..." at process-group creation, the model factory's prints) is sent to stderr; emit() writes to the saved descriptor
+    global _STDOUT_FD
+    sys.stdout.flush()
+    _STDOUT_FD = os.dup(1)
+    os.dup2(2, 1)
+    with contextlib.redirect_stdout(io.StringIO()):
         import mtl_amd
     mdist = mtl_amd.dist
     # torch sizes its CPU pool by the machine (128 threads on the GPU node); the container's CFS quota is 16 CPUs, and a 128-thread
@@ -791,17 +824,21 @@ def main():
     # (bit-level fingerprint of theta after the timed steps: tests compare schedules / collectives that must not change a single bit)
     th = model.flat_parameters
     theta_ck = [float(th.double().sum()), int(th.view(torch.int32).to(torch.int64).sum())]
-    multi = None
+    # self-check block, same keys at every N (the first SCALE run must be readable without a debugger, and its N = 1 line comparable
+    # with the plain bench line): the rank count the process group reports, the backend ("nccl" = RCCL; "none" = no process group),
+    # every rank's own step time, and that the replicas hold the same parameter BITS
+    lo = hi = theta_ck[1]
     if world > 1:
-        # self-check of a sharded run (the first SCALE run must be readable without a debugger): the rank count the process group
-        # reports, the backend ("nccl" = RCCL), every rank's own step time, and that the replicas hold the same parameter BITS
         ck = torch.tensor([theta_ck[1]], dtype=torch.int64, device=dev)
-        lo, hi = ck.clone(), ck.clone()
-        torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
-        torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
-        multi = dict(ranks=torch.distributed.get_world_size(), collective=mdist.backend_name(), chunked_allreduce=mdist.chunked_on(),
-                     allreduce_bytes_per_step=4 * model._layout.total, tasks_per_rank=[len(mdist.shard_tasks(a.tasks, r, world)) for r in range(world)],
-                     per_rank_ms_per_step=PER_RANK.get('ms_per_step'), replicas_bit_identical=bool(int(lo) == int(hi)))
+        lo_t, hi_t = ck.clone(), ck.clone()
+        torch.distributed.all_reduce(lo_t, op=torch.distributed.ReduceOp.MIN)
+        torch.distributed.all_reduce(hi_t, op=torch.distributed.ReduceOp.MAX)
+        lo, hi = int(lo_t), int(hi_t)
+    multi = dict(ranks=world, collective=mdist.backend_name(), chunked_allreduce=mdist.chunked_on(),
+                 allreduce_bytes_per_step=4 * model._layout.total if mdist.collective_on() else 0,
+                 tasks_per_rank=[len(mdist.shard_tasks(a.tasks, r, world)) for r in range(world)],
+                 per_rank_ms_per_step=PER_RANK.get('ms_per_step') or [round(dt / a.steps * 1e3, 3)], replicas_bit_identical=bool(lo == hi),
+                 launcher=os.environ.get('MTL_BENCH_LAUNCHER', 'external' if 'RANK' in os.environ else 'none'))
     # ---- serial profiling step (every rank runs it: it contains the collective; only rank 0 reports)
     classes, n_launch, serial_wall = serial_profile(mtl_amd, trainer, model, vocab, tasks, my_tasks, a.tasks, inner, outer, args, dev)
     out = None
@@ -906,7 +943,7 @@ def main():
                                                 'x3': '3x3 convolutions as exact 3-way bf16 splits of fp32 operands, fp32 accumulate '
                                                       '(fp32-class error, same test tolerances as the fp32-MFMA kernels)',
                                                 'f32': 'fp32 MFMA'}[model.engine.conv_mode]),
-                   roofline=roofline, host_enqueue_ms=host_stats, host=dict(HOST), **({'multi_gpu': multi} if multi else {}), last_step=dict(val_loss=last[0] / a.tasks, cer_edits=last[1], chars=last[2]), theta_checksum=theta_ck)
+                   roofline=roofline, host_enqueue_ms=host_stats, host=dict(HOST), multi_gpu=multi, last_step=dict(val_loss=last[0] / a.tasks, cer_edits=last[1], chars=last[2]), theta_checksum=theta_ck)
 
     extras = world == 1 and not a.no_extras
     if extras:
@@ -1004,6 +1041,7 @@ def main():
     mdist.barrier()
 
 
+_STDOUT_FD = None       # main(): the process's real stdout (fd 1 itself is pointed at stderr for the run)
 LINE_LIMIT = 4096        # bytes: the driver parses the LAST stdout line; round 4's 20 KB line came back as parsed = null
 
 
@@ -1061,7 +1099,11 @@ def emit(out):
         line['config'] = {k: v for k, v in line['config'].items() if not isinstance(v, str) or len(v) < 80}
         line.get('cpu_baseline', {}).pop('sample', None)
         text = json.dumps(line)
-    print(text, flush=True)
+    if _STDOUT_FD is not None:
+        sys.stdout.flush()
+        os.write(_STDOUT_FD, (text + '\n').encode())
+    else:
+        print(text, flush=True)
 
 
 if __name__ == '__main__':

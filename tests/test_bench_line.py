@@ -102,3 +102,41 @@ def test_every_class_is_priced_on_the_roof_of_its_instructions():
         bench.classify(None, 'mtl_conv3x3_dgrad_h2_tb', d8[:-2], 'h2', True)
     assert bench.classify(None, 'mtl_conv3x3_dgrad_h2_tb', d8, 'h2', True)[1] == 8 * bench.classify(None, 'mtl_conv3x3_dgrad_h2', d1, 'h2', True)[1]
     assert bench.algorithmic_bytes('mtl_conv3x3_dgrad_h2_tb', d8, 'flop', 1.0) == 8 * bench.algorithmic_bytes('mtl_conv3x3_dgrad_h2', d1, 'flop', 1.0)
+
+
+def test_self_launch_only_when_started_without_a_launcher():
+    """`python3 bench.py --gpus N` with N > 1 and no RANK / WORLD_SIZE starts its own N ranks (the driver's N = 1 command is the plain
+    form; a SCALE run in the same form must yield a line, not `--gpus N but WORLD_SIZE 1`).  N = 1, or a run under torchrun, is left
+    exactly as it is: no re-exec, same process, same line."""
+    bench = load_bench()
+    argv = ['--gpus', '4', '--steps', '5', '--warmup', '2']
+    assert bench.self_launch_command(1, ['--gpus', '1'], {}) is None
+    assert bench.self_launch_command(1, [], {'WORLD_SIZE': '1'}) is None
+    assert bench.self_launch_command(4, argv, {'RANK': '0', 'WORLD_SIZE': '4', 'LOCAL_RANK': '0'}) is None
+    assert bench.self_launch_command(4, argv, {'WORLD_SIZE': '4'}) is None
+    cmd = bench.self_launch_command(4, argv, {'HOME': '/root'})
+    assert cmd[0] == sys.executable and cmd[1:3] == ['-m', 'torch.distributed.run']
+    assert cmd[cmd.index('--nproc-per-node') + 1] == '4' and cmd[cmd.index('--master-addr') + 1] == '127.0.0.1'
+    assert 0 < int(cmd[cmd.index('--master-port') + 1]) < 65536
+    script = cmd.index(os.path.join(ROOT, 'bench.py'))
+    assert cmd[script + 1:] == argv                       # the ranks see the caller's own flags, `--gpus N` included
+    # the plain N = 1 invocation does not reach the launcher at all (main() consults self_launch_command before anything else)
+    src = open(os.path.join(ROOT, 'bench.py')).read()
+    assert src.index('self_launch_command(a.gpus') < src.index('import mtl_amd\n    mdist')
+
+
+def test_self_launch_starts_the_ranks_for_real(tmp_path):
+    """The launcher end to end on CPU: two ranks come up under torch.distributed.run, each sees RANK / WORLD_SIZE = 2, and fails at the
+    first thing bench.py needs that this container lacks (a GPU) with the product's own message -- not with `--gpus 2 but WORLD_SIZE 1`."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    env['MTL_DIST_BACKEND'] = 'gloo'
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip('CPU-side check of the launcher; the GPU suite runs bench.py --gpus 2 for real')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0', '--no-extras'],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0
+    assert 'WORLD_SIZE 1' not in r.stderr and 'bench.py needs an MI355X' in r.stderr, r.stderr[-2000:]
+    assert r.stdout.strip() == ''

@@ -493,6 +493,39 @@ def test_two_ranks_sharded_bench_equals_single_rank():
     assert j2['theta_checksum'] == j3['theta_checksum'] and j2['last_step'] == j3['last_step'], (j2['theta_checksum'], j3['theta_checksum'])
 
 
+def test_plain_bench_invocation_starts_its_own_ranks():
+    """`python3 bench.py --gpus 2 ...` with NO launcher around it (the form the driver uses for N = 1): bench.py starts its two ranks
+    itself (`self_launch_command`), stdout carries exactly ONE line -- rank 0's JSON -- and that line says n_gpus 2, two ranks, bit-identical
+    replicas.  The N = 1 line carries the same `multi_gpu` keys, so a SCALE run's N = 1 entry can be held against the BENCH line."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ['--steps', '2', '--warmup', '1', '--tasks', '4', '--k', '2', '--frames', '200', '--labels', '20', '--no-cpu-baseline']
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(MTL_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0', MTL_POOL_GB='2')
+    two = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2'] + common, capture_output=True, text=True,
+                         env=env, timeout=400)
+    assert two.returncode == 0, two.stderr[-3000:]
+    lines = [l for l in two.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    j2 = json.loads(lines[0])
+    mg = j2['multi_gpu']
+    assert j2['n_gpus'] == 2 and mg['ranks'] == 2 and mg['replicas_bit_identical'] is True and mg['launcher'] == 'self'
+    assert mg['tasks_per_rank'] == [2, 2] and len(mg['per_rank_ms_per_step']) == 2 and mg['allreduce_bytes_per_step'] > 0
+    one = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--no-extras'] + common, capture_output=True,
+                         text=True, env=env, timeout=300)
+    assert one.returncode == 0, one.stderr[-2000:]
+    lines1 = [l for l in one.stdout.splitlines() if l.strip()]
+    assert len(lines1) == 1
+    j1 = json.loads(lines1[0])
+    assert set(j1) - {'cpu_baseline'} <= set(j2) | {'cpu_baseline'} and set(j1['multi_gpu']) == set(mg)
+    assert j1['multi_gpu']['ranks'] == 1 and j1['multi_gpu']['launcher'] == 'none' and j1['multi_gpu']['collective'] == 'none'
+    assert j1['last_step']['chars'] == j2['last_step']['chars'] and j1['last_step']['cer_edits'] == j2['last_step']['cer_edits']
+    assert abs(j1['last_step']['val_loss'] - j2['last_step']['val_loss']) < 1e-4 * abs(j1['last_step']['val_loss'])
+
+
 @pytest.mark.parametrize('world,tasks', [(4, 8), (8, 8)])
 def test_sharded_bench_at_four_and_eight_ranks_on_one_gpu(world, tasks):
     """BASELINE.json configs[2]'s partitioning with the ranks sharing this box's single GPU over gloo: 8 tasks on 4 ranks (2 per rank: the
