@@ -82,6 +82,11 @@ FIXTURES = {
     'NS': dict(cfg=dict(num_enc_layers=2, num_dec_layers=4, num_heads=8, dim_model=512, dim_key=64, dim_value=64,
                         dim_inner=512, dim_emb=512, src_max_len=5000, tgt_max_len=2500, r=100, vocab_size=3765),
                k=8, T=1000, L=100, n_tasks=3, lr=1e-4, meta_lr=1e-4, iters=1, variable=False),
+    # BASELINE.json configs[3] at its FULL batch (src-max-len 5000, 8 utterances), checksum-only: one task = one training pass at theta0 and
+    # one validation pass at theta' (`--t5000`; ~10 GB of autograd state per pass on the CPU, a few minutes)
+    'T5': dict(cfg=dict(num_enc_layers=2, num_dec_layers=4, num_heads=8, dim_model=512, dim_key=64, dim_value=64,
+                        dim_inner=512, dim_emb=512, src_max_len=5000, tgt_max_len=2500, r=100, vocab_size=3765),
+               k=8, T=5000, L=100, n_tasks=1, lr=1e-4, meta_lr=1e-4, iters=1, variable=True),
 }
 
 
@@ -446,7 +451,10 @@ if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--ns', action='store_true')
     ap.add_argument('--only', default='')
+    ap.add_argument('--t5000', action='store_true', help='only the T = 5000, B = 8 checksum record (tests/golden/T5.npz)')
     a = ap.parse_args()
+    if a.t5000:
+        a.only = 'T5'
     if a.only == 'S0':
         sys.path.insert(0, ROOT)
         run_frontend_fixture()
@@ -463,5 +471,5 @@ if __name__ == '__main__':
         elif name == 'J0':
             run_joint_fixture(torch)
         else:
-            NSAMPLE['n'] = 4096 if name == 'NS' else 256
+            NSAMPLE['n'] = 4096 if name in ('NS', 'T5') else 256
             run_fixture(name, FIXTURES[name], torch)

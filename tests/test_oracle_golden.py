@@ -203,6 +203,36 @@ def test_meta_step_at_north_star_size_matches_reference_golden():
 
 
 @pytest.mark.slow
+def test_long_utterance_full_batch_matches_reference_golden():
+    """BASELINE.json configs[3] at its FULL batch (8 utterances of up to 5000 frames, variable lengths: Q2 masks on a 1250-wide pooled
+    axis): the restated oracle against T5.npz, written by the real reference (`oracle/make_golden.py --t5000`).  One task = a training
+    pass at theta0 and a validation pass at theta'.  Labels bit-exact, losses 2e-6, gradients as for NS (every tensor inside 1e-3, three
+    quarters inside 1e-4).  ~10 GB of autograd state, about a minute on 8 cores."""
+    torch.set_num_threads(8)
+    z, cfg, spec = gu.load('T5')
+    assert (spec['k'], spec['T'], spec['variable']) == (8, 5000, True)
+    m = R.build_model(cfg)
+    names = [n for n, _ in m.named_parameters()]
+    assert _theta_hash(m) == bytes(z['theta0_sha256']).decode()
+    tr, val = gu.batches_for(cfg, spec, 0, z['data_call_index'])
+    G, trl, val_l, labels = R.meta_gradient(m, tr, val, spec['lr'])
+    for j, (gold, hyp) in enumerate(labels):
+        assert np.array_equal(gold.numpy(), z['fwd/0/%d/gold' % j]) and np.array_equal(hyp.numpy(), z['fwd/0/%d/hyp' % j]), j
+    for j, v in enumerate(v for pair in zip(trl, val_l) for v in pair):
+        assert abs(v - float(z['fwd/0/%d/loss' % j])) <= 2e-6 * abs(v)
+    floor = 1e-4 * gu.global_l2(z, 'G/0', names)
+    errs = {}
+    for nm, g in zip(names, G):
+        if float(z['G/0/%s/l2' % nm]) < floor:
+            continue
+        errs[nm] = gu.check_digest(z, 'G/0', nm, g, rtol=1e-3, what='T5', floor=floor)
+    tight = sum(e <= 1e-4 for e in errs.values())
+    worst = max(errs, key=errs.get)
+    print('oracle vs reference golden at T = 5000, B = 8: %d / %d tensors <= 1e-4, worst %.2e (%s)' % (tight, len(errs), errs[worst], worst))
+    assert tight >= 0.75 * len(errs)
+
+
+@pytest.mark.slow
 def test_branch_flip_census_between_two_fp32_implementations_of_the_oracle():
     """The evidence behind the single-flip band of the GPU parity tests (oracle/branches.py): the SAME CPU oracle with
     torch's two exact-fp32 convolution implementations (oneDNN, and the native im2col + GEMM path with oneDNN switched off) --

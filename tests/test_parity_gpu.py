@@ -26,8 +26,8 @@ RTOL = 1e-4          # north_star: fp32 loss and meta-gradients within 1e-4 rela
 # near-tie in the constant padded region flips a whole region after a 1e-3 Adam step -- 1.4 x).
 # The 1e-4 bar on ALL tensors is asserted against the live oracle with the device path's own decisions replayed
 # (test_single_pass_at_north_star_size_against_live_oracle, test_meta_gradient_at_north_star_size_with_branch_replay: 3 and 8 tasks).
-CLEAN_MIN = {'F0': 60, 'F1': 170, 'NS': 135}
-GOLDEN_BAND = {'F0': 5e-2, 'F1': 6.2e-3, 'NS': 6.3e-4}
+CLEAN_MIN = {'F0': 60, 'F1': 170, 'NS': 135, 'T5': 100}
+GOLDEN_BAND = {'F0': 5e-2, 'F1': 6.2e-3, 'NS': 6.3e-4, 'T5': 2e-3}
 NS_FLIP_BOUND = 120   # free-running ReLU / max-pool near-tie disagreements per north-star pass (measured ~25 of ~250 M branch points)
 
 
@@ -44,8 +44,10 @@ def make(cfg, spec, name='parity'):
     return mtl_amd, args, vocab, model
 
 
-@pytest.mark.parametrize('name', ['F0', 'F1', 'NS'])
+@pytest.mark.parametrize('name', ['F0', 'F1', 'NS', 'T5'])
 def test_meta_iterations_match_reference_goldens(name):
+    # (T5: BASELINE.json configs[3] at its FULL batch -- 8 utterances of up to 5000 frames, one task -- against the record the real
+    # reference wrote, oracle/make_golden.py --t5000)
     z, cfg, spec = gu.load(name)
     mtl_amd, args, vocab, model = make(cfg, spec)
     names = [str(s) for s in z['param_names']]
