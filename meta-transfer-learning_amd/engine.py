@@ -241,7 +241,7 @@ def _pool_account(device):
             budget = max(torch.cuda.get_device_properties(device).total_memory // 4, 4 << 30)
         else:
             budget = 4 << 30
-        acc = _POOL_ACCOUNTS[key] = dict(bytes=0, budget=budget)
+        acc = _POOL_ACCOUNTS[key] = dict(bytes=0, budget=budget, gen=0, engines=[])
     return acc
 
 
@@ -262,8 +262,12 @@ class PassEngine:
         # eight lanes keep 8 x 48 GiB of stale shapes and ran a north-star run on ragged batches out of memory).  An eviction bumps
         # scratch_epoch, which makes the trainer re-record its command lists (they hold raw addresses).
         self.account = _pool_account(device)
-        self.conv_skip_tails = os.environ.get('MTL_CONV_SKIP_TAILS', '1') != '0'     # ragged stacks: no convolution tiles beyond a task's frames
-        self.widen, self.widen_quantum = os.environ.get('MTL_PAD_LANES', 'auto'), int(os.environ.get('MTL_RAGGED_QUANTUM', '64'))
+        import weakref
+        self.account['engines'] = [w for w in self.account['engines'] if w() is not None] + [weakref.ref(self)]
+        self._last_pass = self.account['gen']       # the device-wide pass count at this engine's latest pass (trim_pool)
+        # stand-alone passes on batches whose width changes from call to call are widened to repeating widths ('auto': from the second
+        # width on; '0' never -- Transformer.evaluate; '1' always), to a multiple of MTL_RAGGED_QUANTUM frames
+        self.widen, self.widen_quantum = 'auto', int(os.environ.get('MTL_RAGGED_QUANTUM', '64'))
         self._first_width, self._widths_vary = {}, False
         self.pool_budget = self.account['budget']           # (an engine may be given a tighter one of its own: tests)
         self._pool_gen, self._pool_bytes, self._gen = {}, 0, 0
@@ -276,16 +280,10 @@ class PassEngine:
         self.scratch_side = torch.empty(4 << 20, dtype=torch.float32, device=device) if device.type == 'cuda' else None
         self.on_side = False
         self.scratch_epoch = 0
-        # small weight-gradient products of a backward are collected and issued as ONE grouped launch (mtl_gemm_wgrad_grouped)
-        self.wgrads, self._wgrad_tables, self.wgrad_flops = [], {}, {}
-        # opt-in: measured SLOWER than per-block launches on the side stream (8.57 vs 9.36 meta-steps/s; one task per GPU 18.1 vs
-        # 16.0 ms): the grouped launch is as L2-bound as the single ones (19 TF, 32 x 32 tiles) and lands on top of the VGG backward
-        self.group_wgrads = os.environ.get('MTL_GROUP_WGRADS', '0') == '1'
         self._stage, self._stage_turn = {}, {}   # pinned host staging of prepare()
         self._events, self._ev_next = [], 0    # fork / join events of the side stream (raw handles: recordable library calls)
         self.dropout_p = 0.0          # set by the model: hp.dropout when model.training else 0
         self._site = 0                # dropout site counter of the current pass (Philox offset = site << 40)
-        self.after_conv_hook = None
         self.forward_hook = None      # optional callable(engine) after every forward has been enqueued (tests capture the arena)
         # optional callable(tag), tag in ('decoder', 'encoder', 'conv'): called by backward() -- at ENQUEUE time, eager run or command-list
         # replay alike -- right after the last kernel that writes that parameter group's gradients has been enqueued (on the main or
@@ -293,38 +291,25 @@ class PassEngine:
         self.slice_hook = None
         self.deferred = []
         self._wlog = {}
-        # weight gradients of all layers of a stack as one strided-batch launch per parameter kind (flush_layer_wgrads)
-        self.layer_wgrads = os.environ.get('MTL_LAYER_WGRADS', '1') != '0'
-        self.use_side_stream = True
-        # the decoder's prologue (embedding + layer 0's self-attention block) depends on the labels and theta only: it runs on the side
+        # the weight gradients of all layers of a stack run as one strided-batch launch per parameter kind (flush_layer_wgrads); the
+        # decoder's prologue (embedding + layer 0's self-attention block) depends on the labels and theta only: it runs on the side
         # stream under the encoder, and its backward (which feeds parameter gradients only) under the encoder's backward
-        self.overlap_dec0 = os.environ.get('MTL_OVERLAP_DEC0', '1') != '0'
-        self.flush_level = int(os.environ.get('MTL_FLUSH_LEVEL', '0'))      # see flush_side
-        self.flush_delay = os.environ.get('MTL_FLUSH_DELAY', '0') == '1'
-        self._held = None
+        self.use_side_stream = True
         # 3x3 convolutions (forward, data gradient, weight gradient), MTL_CONV: 'h2' (default) two fp16 pieces per fp32 operand
         # (3 MFMAs per step, per-tensor power-of-two scaling from device scalars the producers deliver; csrc/mtl_h2.h), 'x3' three
         # exact bf16 pieces (6 MFMAs), 'f32' the fp32-MFMA engine
-        self.conv_mode = os.environ.get('MTL_CONV', 'h2' if os.environ.get('MTL_CONV_X3', '1') != '0' else 'f32')
+        self.conv_mode = os.environ.get('MTL_CONV', 'h2')
         if self.conv_mode not in ('h2', 'x3', 'f32'):
             raise ValueError('MTL_CONV must be h2, x3 or f32')
         self.conv_x3 = self.conv_mode != 'f32'
         self.conv_h2 = self.conv_mode == 'h2'
         self._ln_pending, self._ln_tables = [], {}
-        # the K / V projections of ALL decoder layers' encoder-decoder attention read the same encoder output: one batched launch per
-        # low-rank stage forward, five launches backward (after the last decoder layer) instead of 2 + 4 per layer
-        self.in_linear = os.environ.get('MTL_IN_LINEAR', 'h2')
-        self.in_wgrad_h2 = os.environ.get('MTL_IN_WGRAD', 'h2') == 'h2'      # its weight gradient on fp16 pairs as well ('x3': exact bf16 triples)
-        self.hoist_kv = os.environ.get('MTL_HOIST_KV', '1') != '0'
-        self.batch_qkv = os.environ.get('MTL_BATCH_QKV', '1') != '0'   # q/k/v projections as strided-batch GEMMs
-        self.wgrad_x3_dense = os.environ.get('MTL_WGRAD_X3_DENSE', '1') != '0'    # conv5 (dy not pooled)
-        # task-batched passes: the 3x3 forward kernels and the data gradients of conv7 / conv5 as ONE launch over all tasks' samples
-        self.conv_tb = os.environ.get('MTL_CONV_TB', '1') != '0'
-        self.conv_tb_wgrad = os.environ.get('MTL_CONV_TB_WGRAD', '1') != '0'      # ... and the weight gradients
+        # the encoder's input Linear (5120 -> 512) with its data / weight gradient: 'h2' with the h2 convolutions (two fp16 pieces, the
+        # bounds ride along), else the product engines' own routing (x3 / fp32); bench.py's exact-fp32 leg sets 'f32'
+        self.in_linear = 'h2'
         # scaled-dot-product attention as ONE flash-style kernel forward and two backward (no score tensor in HBM); head sizes
-        # outside mtl_attn_supported() take the batched-GEMM + softmax path ('0' forces it, for A/B measurements)
-        self.fused_attn = (os.environ.get('MTL_FUSED_ATTN', '1') != '0' and device.type == 'cuda'
-                           and bool(self.lib.mtl_attn_supported(hp.dk, hp.dv)))
+        # outside mtl_attn_supported() take the batched-GEMM + softmax path
+        self.fused_attn = device.type == 'cuda' and bool(self.lib.mtl_attn_supported(hp.dk, hp.dv))
         # task batching: a pass may carry the batches of `nt` tasks of a meta-step (rows of task t follow those of task t - 1); task t
         # reads its parameters at theta + t * sP floats (0: all tasks share theta0 -- the training passes) and accumulates its
         # gradients at grad + t * sG (see forward_device / backward)
@@ -376,26 +361,13 @@ class PassEngine:
         self.arena[name] = t
         return t
 
-    def trim_pool(self):
-        """Start of a pass: count it, and while the pool is over its budget drop least-recently-used buffers that the last two
-        passes did not touch (a forward and its backward, and the pass a pipelined host has already enqueued, keep theirs).
-        Frees go back to torch's caching allocator in stream order: the side stream was joined at the end of the backward."""
-        self._gen += 1
-        if len(self._wgrad_tables) + len(self._ln_tables) > 512:
-            # descriptor tables are keyed by addresses AND extents: ragged batches bring new ones with every pass.  Recorded command
-            # lists hold the tables' addresses, hence the epoch.
-            self._wgrad_tables.clear()
-            self._ln_tables.clear()
-            self.wgrad_flops.clear()
-            self.scratch_epoch += 1
+    def _evict(self, evictable):
+        """drop the least recently used pool entries `evictable(key)` accepts while the pool / the device-wide account is over its
+        budget; -> bytes freed.  An eviction invalidates everything that holds addresses (tables, arena, recorded command lists)."""
         over = lambda: self._pool_bytes > self.pool_budget or self.account['bytes'] > self.account['budget']
-        if not over():
-            return 0
-        if torch.cuda.is_current_stream_capturing():
-            return 0                      # a free inside a hipGraph capture would be baked into the graph: trim at the next eager pass
         freed = 0
         for key in sorted(self.pool, key=lambda k: self._pool_gen.get(k, 0)):
-            if not over() or self._pool_gen.get(key, 0) >= self._gen - 2:
+            if not over() or not evictable(key):
                 break
             t = self.pool.pop(key)
             self._pool_gen.pop(key, None)
@@ -403,12 +375,47 @@ class PassEngine:
             self._took(-nb)
             freed += nb
         if freed:
-            # device tables keyed by buffer addresses (weight-gradient groups, LayerNorm reductions, transposes) and the pinned
-            # staging of shapes that are gone: rebuilt on demand
-            self._wgrad_tables.clear()
+            # device tables keyed by buffer addresses (LayerNorm reductions) and the pinned staging of shapes that are gone: rebuilt on
+            # demand
             self._ln_tables.clear()
             self.arena = {k: v for k, v in self.arena.items() if not isinstance(v, torch.Tensor) or k == '_scratch'}
             self.scratch_epoch += 1
+        return freed
+
+    def trim_pool(self):
+        """Start of a pass: count it, and while the pool is over its budget drop least-recently-used buffers that the last two
+        passes did not touch (a forward and its backward, and the pass a pipelined host has already enqueued, keep theirs).
+        The budget is shared by all engines of the device (a model has one per task lane), and an engine can only give up its OWN
+        buffers during its own pass: when the shared account is over, the engines that have been IDLE for a while (no pass among the
+        device's last max(8, 4 x engines) passes: lanes a changed schedule no longer uses) are emptied first -- otherwise the one
+        engine doing the work would stay over budget for ever, dropping and re-allocating its own shapes (and re-recording the
+        trainer's command lists) on every pass.
+        Frees go back to torch's caching allocator in stream order: the side stream was joined at the end of the backward, and a
+        block returns to the free list of the stream it was allocated on."""
+        self._gen += 1
+        acc = self.account
+        acc['gen'] += 1
+        self._last_pass = acc['gen']
+        if len(self._ln_tables) > 512:
+            # descriptor tables are keyed by addresses AND extents: ragged batches bring new ones with every pass.  Recorded command
+            # lists hold the tables' addresses, hence the epoch.
+            self._ln_tables.clear()
+            self.scratch_epoch += 1
+        over = lambda: self._pool_bytes > self.pool_budget or acc['bytes'] > acc['budget']
+        if not over():
+            return 0
+        if torch.cuda.is_current_stream_capturing():
+            return 0                      # a free inside a hipGraph capture would be baked into the graph: trim at the next eager pass
+        freed = 0
+        if acc['bytes'] > acc['budget']:
+            others = [e for e in (w() for w in acc['engines']) if e is not None and e is not self]
+            idle_after = max(8, 4 * (len(others) + 1))
+            for e in sorted(others, key=lambda e_: e_._last_pass):
+                if acc['bytes'] <= acc['budget'] or acc['gen'] - e._last_pass < idle_after:
+                    break
+                freed += e._evict(lambda key: True)
+        if over():
+            freed += self._evict(lambda key: self._pool_gen.get(key, 0) < self._gen - 2)
         return freed
 
     def scratch(self, nbytes):
@@ -474,47 +481,16 @@ class PassEngine:
         self._ev_next = (self._ev_next + 1) % len(self._events)
         return ev.cuda_event
 
-    # ---- grouped weight gradients
+    # ---- weight gradients
     def wgrad(self, dy, x, rows, n_out, k_in, dw, db=None, kind=None):
         """dw (n_out x k_in) += dy^T x ; db += colsum(dy).  With `kind` (the parameter's name without its layer index) the product is
         only LOGGED: flush_layer_wgrads() issues the products of all layers of a stack as one strided-batch launch per kind.
-        Otherwise: MTL_GROUP_WGRADS registers small products for one grouped launch (flush_wgrads); the rest goes to the side stream
-        as single calls."""
-        if kind is not None and self.layer_wgrads:
+        Otherwise it goes to the side stream as a single call."""
+        if kind is not None:
             self.wgrad_job(kind, n_out, k_in, rows, dy, n_out, x, k_in, dw, k_in, rowsum=db)
             return
-        if self.group_wgrads and self.nt == 1 and self.lib.mtl_gemm_f32_ex_route(n_out, k_in, rows, 1, 1, 1 if db else 0):
-            self.wgrads.append((int(dy), int(x), int(dw), int(db or 0), n_out, k_in, rows, n_out, k_in, k_in))
-        else:
-            self.defer(lambda: self.gemm(1, 0, n_out, k_in, rows, dy, n_out, x, k_in, dw, k_in, flags=ACCUM, rowsum=db,
-                                         task=(rows * n_out, rows * k_in, self.sG, 0, self.sG)))
-
-    def flush_wgrads(self):
-        """issue the registered products (their operands are per-block buffers that stay intact until the end of the backward):
-        on the side stream behind everything the main stream has enqueued so far, so that they overlap the rest of the backward"""
-        if not self.wgrads:
-            return
-        descs, self.wgrads = tuple(self.wgrads), []
-        ent = self._wgrad_tables.get(descs)
-        if ent is None:
-            import numpy as np
-            dt = np.dtype([('A', 'u8'), ('B', 'u8'), ('C', 'u8'), ('rowsum', 'u8'), ('M', 'i4'), ('N', 'i4'), ('K', 'i4'), ('lda', 'i4'),
-                           ('ldb', 'i4'), ('ldc', 'i4'), ('tile0', 'i4'), ('reserved', 'i4')])
-            arr = np.zeros(len(descs), dtype=dt)
-            tiles = 0
-            for i, d in enumerate(descs):
-                arr[i] = d + (tiles, 0)
-                tiles += ((d[4] + 31) // 32) * ((d[5] + 31) // 32)
-            table = torch.from_numpy(arr.view(np.uint8).copy()).to(self.device)
-            ent = (table, tiles)
-            self._wgrad_tables[descs] = ent            # kept alive: recorded command lists hold the table's address
-            self.wgrad_flops[table.data_ptr()] = sum(2.0 * d[4] * d[5] * d[6] for d in descs)
-        table, tiles = ent
-
-        def launch():
-            check(self.lib.mtl_gemm_wgrad_grouped(self.stream, table.data_ptr(), len(descs), tiles), 'mtl_gemm_wgrad_grouped')
-        self.defer(launch)
-        self.flush_side()
+        self.defer(lambda: self.gemm(1, 0, n_out, k_in, rows, dy, n_out, x, k_in, dw, k_in, flags=ACCUM, rowsum=db,
+                                     task=(rows * n_out, rows * k_in, self.sG, 0, self.sG)))
 
     def wgrad_job(self, kind, M, N, K, A, lda, B, ldb, C, ldc, n=1, sA=0, sB=0, sC=0, rowsum=None, srow=0):
         """log C_z (M x N) += A_z^T B_z (z < n, strides in floats), rowsum_z += row sums of A_z^T"""
@@ -555,26 +531,15 @@ class PassEngine:
         else:
             fn()
 
-    def flush_side(self, level=3):
+    def flush_side(self):
         """Everything enqueued on the main stream so far is visible to the deferred jobs, which are now issued on the side
-        stream.  Their inputs are per-block buffers that the main stream never rewrites within this backward, so a fork may be
-        postponed: `level` names the call site (0 end of a sub-layer block, 1 end of a layer, 2 end of the decoder / encoder
-        backward, 3 unconditional) and sites below self.flush_level only let the jobs pile up for the next fork."""
-        if not self.deferred or level < self.flush_level:
+        stream.  Their inputs are per-block buffers that the main stream never rewrites within this backward."""
+        if not self.deferred:
             return
         ev = self._event()
         check(self.lib.mtl_event_record(ev, self.stream), 'mtl_event_record')
         jobs, self.deferred = self.deferred, []
-        held, self._held = self._held, None
-        if self.flush_delay and level < 3:
-            self._held = (ev, jobs)          # issued at the NEXT fork (or the join): by then the main stream has more work queued
-        else:
-            if held is not None:
-                self._issue_side(*held)
-                held = None
-            self._issue_side(ev, jobs)
-        if held is not None:
-            self._issue_side(*held)
+        self._issue_side(ev, jobs)
 
     def _issue_side(self, ev, jobs):
         check(self.lib.mtl_stream_wait_event(self.side.cuda_stream, ev), 'mtl_stream_wait_event')
@@ -606,11 +571,7 @@ class PassEngine:
         check(self.lib.mtl_stream_wait_event(self.stream, ev), 'mtl_stream_wait_event')
 
     def join_side(self):
-        self.flush_wgrads()
         self.flush_side()
-        if self._held is not None:
-            held, self._held = self._held, None
-            self._issue_side(*held)
         if self.use_side_stream:
             ev = self._event()
             check(self.lib.mtl_event_record(ev, self.side.cuda_stream), 'mtl_event_record')
@@ -623,9 +584,8 @@ class PassEngine:
     def _slice_done(self, tag):
         if self.slice_hook is None:
             return
-        # every kernel that writes this group's gradients must have been ENQUEUED: nothing collected for a later grouped launch
-        # (the trainer does not hook a backward with group_wgrads / flush_delay: TransientTrainer._chunk_hook)
-        if self.wgrads or self.deferred or self._held is not None:
+        # every kernel that writes this group's gradients must have been ENQUEUED
+        if self.deferred:
             raise RuntimeError('slice %r handed over with weight-gradient launches still pending' % tag)
         if isinstance(self.lib, _lib.Recorder):
             self.lib.segment_break(tag)        # the replay stops here and hands control to the same hook
@@ -847,32 +807,14 @@ class PassEngine:
             a_ptr, d_ptr, da_ptr = a_all.data_ptr(), d_all.data_ptr(), da_all.data_ptr()
 
             # dW_b[i] += d[i]^T a[i]  and  db_b[i] += colsum(d[i])
-            if self.group_wgrads:
-                for i, nm in enumerate(names):
-                    self.wgrad(d_ptr + 4 * i * rows * wd, a_ptr + 4 * i * rows * r, rows, wd, r, g(_FULL[nm] + '_linear_b.weight'),
-                               g(_FULL[nm] + '_linear_b.bias'))
-            elif self.layer_wgrads and not (dkv_hoisted is not None and names == 'kv'):
-                self.wgrad_job(kd + names + '.b', wd, r, rows, d_ptr, wd, a_ptr, r, g(f0 + '_linear_b.weight'), r, n=n, sA=R * wd,
-                               sB=R * r, sC=sb, rowsum=g(f0 + '_linear_b.bias'), srow=sbias)
-            else:       # one strided-batch call on the side stream (outputs strided into G)
-                self.defer(lambda n=n, f0=f0, rows=rows, R=R, a_ptr=a_ptr, d_ptr=d_ptr, sb=sb, sbias=sbias, wd=wd: self.gemm(
-                    1, 0, wd, r, rows, d_ptr, wd, a_ptr, r, g(f0 + '_linear_b.weight'), r, flags=ACCUM, batch=n, sA=(R * wd, 0),
-                    sB=(R * r, 0), sC=(sb, 0), rowsum=g(f0 + '_linear_b.bias'), srow=sbias, task=(rows * wd, rows * r, sG, 0, sG)))
+            self.wgrad_job(kd + names + '.b', wd, r, rows, d_ptr, wd, a_ptr, r, g(f0 + '_linear_b.weight'), r, n=n, sA=R * wd,
+                           sB=R * r, sC=sb, rowsum=g(f0 + '_linear_b.bias'), srow=sbias)
             # da[i] = d[i] . W_b[i]
             self.gemm(0, 0, rows, r, wd, d_ptr, wd, o(f0 + '_linear_b.weight'), r, da_ptr, r, batch=n, sA=(R * wd, 0),
                       sB=(sb, 0), sC=(R * r, 0), task=(rows * wd, sP, rows * r, 0, 0))
 
             # dW_a[i] += da[i]^T x
-            if self.group_wgrads:
-                for i, nm in enumerate(names):
-                    self.wgrad(da_ptr + 4 * i * rows * r, src, rows, r, d, g(_FULL[nm] + '_linear_a.weight'))
-            elif self.layer_wgrads:
-                self.wgrad_job(kd + names + '.a', r, d, rows, da_ptr, r, src, d, g(f0 + '_linear_a.weight'), d, n=n, sA=R * r, sB=0,
-                               sC=sa)
-            else:
-                self.defer(lambda n=n, f0=f0, rows=rows, R=R, da_ptr=da_ptr, src=src, sa=sa: self.gemm(
-                    1, 0, r, d, rows, da_ptr, r, src, d, g(f0 + '_linear_a.weight'), d, flags=ACCUM, batch=n, sA=(R * r, 0), sC=(sa, 0),
-                    task=(rows * r, rows * d, sG, 0, 0)))
+            self.wgrad_job(kd + names + '.a', r, d, rows, da_ptr, r, src, d, g(f0 + '_linear_a.weight'), d, n=n, sA=R * r, sB=0, sC=sa)
             # dx (+)= sum_i da[i] . W_a[i]: the items of a group accumulate into ONE tensor -> one K-batched launch
             if names[0] == 'q':
                 dst, accum = dxq, True
@@ -881,14 +823,14 @@ class PassEngine:
                 kv_written = True
             self.gemm(0, 0, rows, d, r, da_ptr, r, o(f0 + '_linear_a.weight'), d, dst, d, flags=ACCUM if accum else 0,
                       kbatch=n, sAk=R * r, sBk=sa, task=(rows * r, sP, rows * d, 0, 0))
-        self.flush_side(0)
+        self.flush_side()
 
     # ---- encoder-decoder attention: K / V projections of all decoder layers in one go
     def _cross_kv_plan(self, Mk):
         """(layer stride, projection stride) in floats when the K / V low-rank parameters of the decoder layers' encoder_attn blocks
         sit at constant strides in the flat buffer (they do for the reference's module tree), else None."""
         hp, L = self.hp, self.L
-        if not (self.hoist_kv and self.batch_qkv and hp.n_dec >= 2 and not self.group_wgrads) or hp.dk != hp.dv:
+        if hp.n_dec < 2 or hp.dk != hp.dv:
             return None
         plan = None
         for sfx in ('_linear_a.weight', '_linear_b.weight', '_linear_b.bias'):
@@ -945,7 +887,7 @@ class PassEngine:
         for pj, name in enumerate(('key', 'value')):      # dmem (=|+=) sum_l da[l, pj] . W_a[l, pj]
             self.gemm(0, 0, Mk, d, r, da_ptr + 4 * pj * Rk * r, r, o0(name + '_linear_a.weight'), d, dmem, d, flags=ACCUM if pj else 0,
                       kbatch=NL, sAk=2 * Rk * r, sBk=Ls, task=(Mk * r, sP, Mk * d, 0, 0))
-        self.flush_side(0)
+        self.flush_side()
 
     def _pstride(self, pre, names, suffix):
         """Distance (floats) between consecutive projections' parameters `suffix` in the flat buffer (0 for a single one)."""
@@ -963,9 +905,9 @@ class PassEngine:
                 if len(steps) != 1 or min(steps) <= 0 or min(steps) % 4:
                     return False
             return hk == hv
-        if self.batch_qkv and xq == xkv and Mq == Mk and uniform('qkv'):
+        if xq == xkv and Mq == Mk and uniform('qkv'):
             return [('qkv', xq, Mq)]
-        if self.batch_qkv and uniform('kv'):
+        if uniform('kv'):
             return [('q', xq, Mq), ('kv', xkv, Mk)]
         return [('q', xq, Mq), ('k', xkv, Mk), ('v', xkv, Mk)]
 
@@ -1004,7 +946,7 @@ class PassEngine:
                         None, dh1.data_ptr(), False, gate=h1.data_ptr(), kind=kd + 'w2')
         self.linear_bwd(x, dh1.data_ptr(), rows, hp.d, hp.inner, o('linear_1.weight'), g('linear_1.weight'),
                         g('linear_1.bias'), dx, True, kind=kd + 'w1')
-        self.flush_side(0)
+        self.flush_side()
 
     # ---------------------------------------------------------------- the pass
     def prepare(self, lengths, target, B, T, slot=0, norm_count=None, width=None, frames=None):
@@ -1182,8 +1124,6 @@ class PassEngine:
         T4, F4 = T2 // 2, F2 // 2
         if F4 * 128 != hp.d_in:
             raise ValueError('dim_input %d does not match %d frequency bins' % (hp.d_in, F))
-        if nt > 1 and self.group_wgrads:
-            raise RuntimeError('MTL_GROUP_WGRADS=1 addresses the weight-gradient operands per task: it cannot run a task-batched pass')
         self.nt, self.sP = nt, int(sP)
         try:
             return self._forward_device(theta, x, meta, smoothing, hyp_out, loss_out, nt, sX, F, T)
@@ -1217,7 +1157,7 @@ class PassEngine:
         if h2:
             check(lib.mtl_memset_zero(st, amax.data_ptr(), nt * 12 * 4 * _lib.AMAX_SLOTS), 'mtl_memset_zero')
         xp = lambda t: x.data_ptr() + 4 * t * sX
-        if nt > 1 and self.conv_tb:      # every task's samples in one launch (task = grid dimension; sX = 0: the shared validation batch)
+        if nt > 1:      # every task's samples in one launch (task = grid dimension; sX = 0: the shared validation batch)
             check(lib.mtl_conv0_relu_fwd_tb(st, x.data_ptr(), o('conv.0.weight'), o('conv.0.bias'), y1.data_ptr(), B, T, F, am_(0), nt, sX,
                                             sP, sP, 12 * _lib.AMAX_SLOTS), 'conv0')
         else:
@@ -1257,7 +1197,7 @@ class PassEngine:
             if not h2:
                 for t in range(ntw):
                     check(wprep(st, o('conv.%d.weight' % idx, t), wf[idx][t].data_ptr(), wd[idx][t].data_ptr(), cout, cin), 'wprep')
-        if h2 and ntw > 1 and self.conv_tb:      # all three layers of ALL parameter sets (the theta' stack): one call (two launches)
+        if h2 and ntw > 1:      # all three layers of ALL parameter sets (the theta' stack): one call (two launches)
             spec = []
             for idx, cin, cout in ((2, 64, 64), (5, 64, 128), (7, 128, 128)):
                 spec += [o('conv.%d.weight' % idx), wf[idx].data_ptr(), wd[idx].data_ptr(), cout, cin]
@@ -1274,7 +1214,7 @@ class PassEngine:
         p2 = self.buf('p2', (Bt, T4, F4, 128))
         am2 = self.buf('am2', (Bt, T4, F4, 128), torch.uint8)
         # (a single task with frames of its own -- a widened batch on a lane -- takes the several-task launches too: they skip its tail rows)
-        if h2 and self.conv_tb and (nt > 1 or (widths is not None and self.conv_skip_tails)):
+        if h2 and (nt > 1 or widths is not None):
             # the samples of all tasks in ONE launch per layer (per-task bounds, weights and biases by stride): a persistent grid's
             # prologue, tail and launch boundary are paid once instead of nt times (2-14 % of a layer: tools/probe/conv_batch_tasks.py);
             # per task bitwise the per-task launches (tests/test_ops_gpu.py)
@@ -1282,7 +1222,7 @@ class PassEngine:
             sw = lambda idx: wf[idx].stride(0) if ntw > 1 else 0
             # (tasks with frame counts of their own: the launches leave out the pixel-tile rows beyond a task's frames -- `skip` -- and
             # everything a later kernel reads there is cleared: activations, pooled maps and their arg-max bytes)
-            skip = widths if self.conv_skip_tails else None
+            skip = widths
             check(lib.mtl_conv3x3_relu_pool_fwd_h2_tb(st, y1.data_ptr(), am_(0), wf[2].data_ptr(), o('conv.2.bias'), p1.data_ptr(), am1.data_ptr(),
                                                       am_(1), B, T, F, 64, 64, nt, sw(2), sP, AS, AS, skip, 0), 'conv2')
             tails(p1, T2, F2 * 64, 1)
@@ -1323,10 +1263,6 @@ class PassEngine:
                 for a_ in per_task:
                     c7(*a_)
 
-        if self.after_conv_hook is not None:      # lets the trainer de-phase concurrent task lanes (see trainer.meta_iteration)
-            hook, self.after_conv_hook = self.after_conv_hook, None
-            hook()
-
         # ---- encoder ----
         wp = self.buf('wp_in', (ntw, d, hp.d_in))
         # am_(7): max|w| rides along; the theta' stack in one launch
@@ -1344,8 +1280,7 @@ class PassEngine:
             return d0_, self.mha_fwd('d0.sa.', P, 'decoder.layers.0.self_attn.', d0_.data_ptr(), B, Td, d0_.data_ptr(), Td, klen_dec, 1,
                                      keep_dec)
         pro_done = None
-        self.dec0_on_side = bool(self.use_side_stream and self.overlap_dec0 and self.layer_wgrads and not self.group_wgrads
-                                 and hp.n_dec > 0)
+        self.dec0_on_side = bool(self.use_side_stream and hp.n_dec > 0)
         if self.dec0_on_side:
             (d0, a0), pro_done = self.run_on_side(dec_prologue)      # under the input Linear and the encoder
         e0 = self.buf('e0', (nt * Me, d))
@@ -1565,11 +1500,9 @@ class PassEngine:
             self.mha_bwd('d%d.sa.' % i, P, G, pre + 'self_attn.', dcur.data_ptr(), x_in.data_ptr(), B, Td, x_in.data_ptr(), Td,
                          keep_dec, dnext.data_ptr(), dnext.data_ptr(), True)
             dcur, dnext = dnext, dcur
-            self.flush_side(1)
         if hoisted:
             self.cross_kv_bwd(P, G, mem_ptr, Me, dmem.data_ptr())
         self.flush_layer_wgrads()       # the decoder stack's weight gradients: one launch per parameter kind
-        self.flush_side(2)
         if not embed_done:
             embed_bwd(dcur)
         if self.slice_hook is not None:
@@ -1593,7 +1526,6 @@ class PassEngine:
             self.mha_bwd('e%d.sa.' % i, P, G, pre + 'self_attn.', dcur.data_ptr(), x_in.data_ptr(), B, T4, x_in.data_ptr(), T4,
                          keep_enc, dnext.data_ptr(), dnext.data_ptr(), True)
             dcur, dnext = dnext, dcur
-            self.flush_side(1)
         # input LayerNorm (+PE: no grad) and input_linear
         de0 = dnext
         self.ln_bwd(dcur.data_ptr(), A['enc_in.xhat'].data_ptr(), A['enc_in.rstd'].data_ptr(), o('encoder.layer_norm_input.weight'),
@@ -1607,12 +1539,12 @@ class PassEngine:
         amax = A['amax']
         am_ = (lambda i, t=0: amax.data_ptr() + 4 * _lib.AMAX_SLOTS * (12 * t + i)) if h2 else (lambda i, t=0: None)   # y1, p1, y5 | dp2, dy5, dp1
         am_st = 12 * _lib.AMAX_SLOTS
-        if self.in_h2 and nt > 1 and self.conv_tb:
+        if self.in_h2 and nt > 1:
             check(lib.mtl_absmax_f32_tb(st, de0.data_ptr(), Me * d, am_(8), nt, Me * d, am_st), 'mtl_absmax_f32')
         elif self.in_h2:
             for t in range(nt):
                 check(lib.mtl_absmax_f32(st, de0[t * Me:].data_ptr(), Me * d, am_(8, t)), 'mtl_absmax_f32')
-        if self.in_h2 and self.in_wgrad_h2:      # dW = de0^T . p2 on fp16 pairs too: both bounds (slots 8, 6) exist for the data gradient below
+        if self.in_h2:      # dW = de0^T . p2 on fp16 pairs too: both bounds (slots 8, 6) exist for the data gradient below
             check(lib.mtl_gemm_h2_tn_tb(st, d, hp.d_in, Me, de0.data_ptr(), d, am_(8), am_st, p2.data_ptr(), hp.d_in, am_(6), am_st,
                                         dwp.data_ptr(), hp.d_in, nt, Me * d, Me * hp.d_in, d * hp.d_in), 'mtl_gemm_h2_tn_tb')
         else:
@@ -1631,8 +1563,7 @@ class PassEngine:
             self.gemm(0, 0, Me, hp.d_in, d, de0.data_ptr(), d, A['wp_in'].data_ptr(), hp.d_in, dp2.data_ptr(), hp.d_in,
                       gate=p2.data_ptr(), ldg=hp.d_in, task=(Me * d, d * hp.d_in if sP else 0, Me * hp.d_in, 0, 0))
 
-        self.flush_wgrads()        # every small dW of the transformer half: one grouped launch, overlapping the VGG backward
-        self.flush_side(2)
+        self.flush_side()
         # ---- VGG front-end (per task) ----
         dgrad_fn = lib.mtl_conv3x3_dgrad_x3 if self.conv_x3 else lib.mtl_conv3x3_dgrad
 
@@ -1644,10 +1575,10 @@ class PassEngine:
         # h2: the weight-gradient kernel's dy loaders also sum dy (bias gradient) and the data-gradient epilogue delivers the bound of
         # its output, so the column-sum passes over dy5 (164 MB) and dp1 (82 MB) are not needed; dp2 keeps its pass (its bound has no
         # other producer)
-        fold = lambda am: h2 and (am is not None or self.wgrad_x3_dense)
+        fold = lambda am: h2
 
         def wgrad(t, xa, axi, dy, adi, am, idx, Bq, Tq, Fq, cin, cout, db=None):
-            x3 = self.conv_x3 and (am is not None or self.wgrad_x3_dense)
+            x3 = self.conv_x3
             wsfn = lib.mtl_conv3x3_wgrad_x3_workspace if x3 else lib.mtl_conv3x3_wgrad_workspace
             need = wsfn(Bq, Tq, Fq, cin, cout, 1 if am else 0)
             ws = self.scratch(need)
@@ -1664,11 +1595,11 @@ class PassEngine:
         dy1 = self.buf('_dy1', (nt * B, T, F, 64))
         f5, f2 = fold(None), fold(A['am1'])
         xin = S['x']
-        merged = h2 and self.conv_tb and (nt > 1 or (S['meta'].get('widths') is not None and self.conv_skip_tails))     # data gradients of conv7 / conv5: ONE launch over the samples of all tasks (see forward)
+        merged = h2 and (nt > 1 or S['meta'].get('widths') is not None)     # data gradients of conv7 / conv5: ONE launch over the samples of all tasks (see forward)
         # tasks with frame counts of their own (forward): the data gradients leave out the tile rows beyond a task's frames and those
         # rows of their outputs are cleared right behind them -- bias sums, bounds and weight gradients read whole tensors
         widths_b = S['meta'].get('widths')
-        skip = widths_b if (merged and self.conv_skip_tails) else None
+        skip = widths_b if merged else None
         tails_b = (lambda buf_, T_, row_, shift_: check(lib.mtl_zero_tails(st, buf_.data_ptr(), nt * B, T_, row_, skip, shift_, B), 'mtl_zero_tails')) \
             if skip is not None else (lambda *a_: None)
         AS = 12 * _lib.AMAX_SLOTS
@@ -1720,31 +1651,20 @@ class PassEngine:
                                               nt, AS, AS, sG, sG), 'wgrad_tb')
 
         if merged:
-            w5_h2 = self.conv_x3 and self.wgrad_x3_dense          # (conv5's dy is not pooled: the dense h2 kernel unless switched off)
             per = ((lib.mtl_colsum_workspace(B * T4 * F4, 128) // 4 + 3) // 4 * 4) * 4
             check(lib.mtl_colsum_accum_tb(st, dp2.data_ptr(), B * T4 * F4, 128, g('conv.7.bias'), self.scratch(nt * per + 64), am_(3), nt, sG, AS),
                   'colsum_tb')
-            if self.conv_tb_wgrad:
-                wgrad_tb(y5.data_ptr(), 2, dp2.data_ptr(), 3, A['am2'].data_ptr(), 7, T2, F2, 128, 128, None)
-            else:
-                for t in range(nt):
-                    sl = slice(t * B, (t + 1) * B)
-                    wgrad(t, y5[sl].data_ptr(), 2, dp2[sl].data_ptr(), 3, A['am2'][sl].data_ptr(), 7, B, T2, F2, 128, 128)
+            wgrad_tb(y5.data_ptr(), 2, dp2.data_ptr(), 3, A['am2'].data_ptr(), 7, T2, F2, 128, 128, None)
             check(lib.mtl_conv3x3_dgrad_h2_tb(st, dp2.data_ptr(), am_(3), A['am2'].data_ptr(), A['wd7'].data_ptr(), y5.data_ptr(), dy5.data_ptr(),
                                               am_(4) if f5 else None, B, T2, F2, 128, 128, nt, swd('wd7'), AS, AS, skip, 1), 'dgrad7')
             tails_b(dy5, T2, F2 * 128, 1)
-            if w5_h2 and f5 and self.conv_tb_wgrad:
-                wgrad_tb(p1.data_ptr(), 1, dy5.data_ptr(), 4, None, 5, T2, F2, 64, 128, g('conv.5.bias'))
-            else:
-                for t in range(nt):
-                    layer5(t, False)
+            wgrad_tb(p1.data_ptr(), 1, dy5.data_ptr(), 4, None, 5, T2, F2, 64, 128, g('conv.5.bias'))
             check(lib.mtl_conv3x3_dgrad_h2_tb(st, dy5.data_ptr(), am_(4), None, A['wd5'].data_ptr(), p1.data_ptr(), dp1.data_ptr(),
                                               am_(5) if f2 else None, B, T2, F2, 64, 128, nt, swd('wd5'), AS, AS, skip, 1), 'dgrad5')
             tails_b(dp1, T2, F2 * 64, 1)
-            if f2 and self.conv_tb_wgrad:
-                wgrad_tb(y1.data_ptr(), 0, dp1.data_ptr(), 5, A['am1'].data_ptr(), 2, T, F, 64, 64, g('conv.2.bias'))
+            wgrad_tb(y1.data_ptr(), 0, dp1.data_ptr(), 5, A['am1'].data_ptr(), 2, T, F, 64, 64, g('conv.2.bias'))
             for t in range(nt):       # (conv2's data gradient merged as well: 52.23 / 52.63 / 52.83 against 52.03 / 52.18 / 52.92 ms per step: no gain)
-                layer2(t, wg=not (f2 and self.conv_tb_wgrad), w0=False)
+                layer2(t, wg=False, w0=False)
             tails_b(dy1, T, F * 64, 0)
             ws = self.scratch(lib.mtl_conv0_wgrad_workspace())
             check(lib.mtl_conv0_wgrad_tb(st, xin.data_ptr(), dy1.data_ptr(), g('conv.0.weight'), g('conv.0.bias'), ws, B, T, F, nt, sX, sG, sG),
@@ -1754,7 +1674,6 @@ class PassEngine:
                 layer7(t, True)
                 layer5(t, True)
                 layer2(t)
-        # (merged: f2 false -- MTL_WGRAD folding off -- keeps layer 2's weight gradient per task inside layer2)
         self.join_side()
         self.flush_ln_reduce()     # the parameter / bias gradients of all 17 LayerNorms of the pass: one launch (after the join: one of
                                    # the 17 backward kernels ran on the side stream)

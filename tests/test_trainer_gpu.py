@@ -393,6 +393,49 @@ def test_variable_length_batches_keep_the_buffer_pool_and_the_command_lists_boun
     assert torch.equal(first, again)
 
 
+def test_shared_pool_budget_empties_idle_lane_engines_before_the_working_one():
+    """The pool budget is shared by all engines of a device, and an engine only gives up buffers during its OWN pass.  A few iterations
+    on the lane-per-task schedule leave buffers on every lane engine; when the schedule then changes to the stacked one (engine 0 only)
+    and the shared account is over its budget, the idle lanes' buffers must go first -- not engine 0's own shapes on every pass,
+    which would bump its scratch epoch (= re-record the command lists) for ever."""
+    z, cfg, spec = gu.load('F0')
+    mtl_amd, args, vocab, model = make(cfg, spec)
+    model = model.cuda()
+    as5 = lambda b: (b[0].cuda(), b[1], None, b[2], None)
+    inner = mtl_amd.FlatSGD(model, spec['lr'])
+    model.zero_copy_grad()
+    tr = mtl_amd.TransientTrainer()
+    tasks = [as5(mtl_amd.synth_batch(700 + m, 2, 64, 8, cfg['vocab_size'], variable=True)) for m in range(3)]
+    val = as5(mtl_amd.synth_batch(709, 2, 64, 8, cfg['vocab_size'], variable=True))
+    tr.batch_tasks = False
+    for _ in range(2):
+        tr.meta_iteration(model, vocab, tasks, val, 3, inner, None, args)
+    torch.cuda.synchronize()
+    lanes = [e for e in model.engines[1:] if e._pool_bytes > 0]
+    assert lanes, 'the lane schedule did not use a second engine'
+    eng = model.engines[0]
+    acc = eng.account
+    tr.batch_tasks = True
+    for _ in range(2):                                          # the stacked schedule allocates its own shapes on engine 0
+        tr.meta_iteration(model, vocab, tasks, val, 3, inner, None, args)
+    torch.cuda.synchronize()
+    idle_bytes = sum(e._pool_bytes for e in lanes)
+    saved = acc['budget']
+    try:
+        acc['budget'] = acc['bytes'] - idle_bytes // 2          # over budget by half of what the idle lanes hold
+        epochs = []
+        for _ in range(3 * max(8, 4 * len(model.engines))):
+            tr.meta_iteration(model, vocab, tasks, val, 3, inner, None, args)
+            epochs.append(eng.scratch_epoch)
+        torch.cuda.synchronize()
+        assert acc['bytes'] <= acc['budget']
+        assert sum(e._pool_bytes for e in lanes) < idle_bytes   # the idle lanes paid ...
+        assert epochs[-1] == epochs[-8]                         # ... and the working engine's buffers (and command lists) are stable
+        assert tr.last_schedule == 'batched'
+    finally:
+        acc['budget'] = saved
+
+
 class _CollatedTask:
     """The dataset contract of TransientTrainer.train over a list of utterances, batches formed like the reference's loader: k random
     utterances collated to the batch's OWN longest one (utils/data_loader.py:284-297 = mtl_amd.data.collate)."""
