@@ -175,7 +175,6 @@ def _conv_layer(cin, cout):
     return {(64, 64): 2, (64, 128): 5, (128, 128): 7}.get((cin, cout), 0)
 
 
-GROUP_FLOPS = {}     # table address -> FLOPs of a grouped weight-gradient launch (filled from the engines before classification)
 
 
 def single_task_form(name, a):
@@ -198,7 +197,7 @@ def single_task_form(name, a):
     return name, a
 
 
-def classify(lib, name, a, conv_mode, wgrad_x3_dense):
+def classify(lib, name, a, conv_mode):
     """(class, algorithmic work, 'flop' | 'byte' | None, rocprofv3 kernel symbol(s)) of one library call; `a` = its arguments in
     the order of include/mtl_hip.h.  FLOPs are 2 x MACs of the dense extent of the reference op; bytes are the tensors the op
     must read and write once."""
@@ -216,8 +215,6 @@ def classify(lib, name, a, conv_mode, wgrad_x3_dense):
         return 'gemm_h2', 2.0 * a[2] * a[3] * a[4] * a[18], 'flop', 'gemm_x3_kernel<.,.,.,BM,2> (two fp16 pieces)'
     if name == 'mtl_gemm_h2_tn_tb':
         return 'gemm_h2', 2.0 * a[1] * a[2] * a[3] * a[14], 'flop', 'gemm_x3_kernel<.,.,.,BM,2> (two fp16 pieces)'
-    if name == 'mtl_gemm_wgrad_grouped':
-        return 'gemm_wgrad_grouped', GROUP_FLOPS.get(int(a[1] or 0)), 'flop', 'gemm16_kernel<true,false,true,4,1,1> (grouped)'
     if name.startswith('mtl_conv3x3_') and 'wprep' not in name:
         B, T, F, cin, cout = a[-5:]
         kind = 'wgrad' if 'wgrad' in name else ('dgrad' if 'dgrad' in name else ('fwd_pool' if 'pool' in name else 'fwd'))
@@ -346,14 +343,14 @@ def algorithmic_bytes(name, a, unit, work):
 X3_CLASSES = ('gemm_x3', 'attn_fwd', 'attn_bwd')
 
 
-def peak_of(cls, unit, conv_mode, wgrad_x3_dense):
+def peak_of(cls, unit, conv_mode):
     if unit == 'byte':
         return PEAK_HBM_GBS, 'GB/s', 'hbm'
     if cls == 'gemm_h2':
         return PEAK_H2_TFLOPS, 'TFLOP/s', 'mfma'
     if cls in X3_CLASSES:
         return PEAK_X3_TFLOPS, 'TFLOP/s', 'mfma'
-    if cls.startswith('conv') and conv_mode != 'f32' and not (cls == 'conv5_wgrad' and not wgrad_x3_dense):
+    if cls.startswith('conv') and conv_mode != 'f32':
         return (PEAK_H2_TFLOPS if conv_mode == 'h2' else PEAK_X3_TFLOPS), 'TFLOP/s', 'mfma'
     return PEAK_F32_MFMA_TFLOPS, 'TFLOP/s', 'mfma'
 
@@ -416,11 +413,9 @@ def serial_profile(mtl, trainer, model, vocab, tasks, my_tasks, n_tasks, inner, 
         e.lib, e.use_side_stream, e.prof = lib_, side, None
     model.n_lanes = lanes
     eng = model.engine
-    for e in model.engines:
-        GROUP_FLOPS.update(e.wgrad_flops)
     classes = {}
     for name, a, e0, e1 in prof.records:
-        cls, work, unit, sym = classify(mtl._lib.lib(), name, a, eng.conv_mode, eng.wgrad_x3_dense)
+        cls, work, unit, sym = classify(mtl._lib.lib(), name, a, eng.conv_mode)
         c = classes.setdefault(cls, dict(time=0.0, work=0.0, unit=unit, launches=0, symbols=sym, abytes=0.0))
         c['time'] += e0.elapsed_time(e1) * 1e-3
         c['work'] += work or 0.0
@@ -855,7 +850,7 @@ def main():
             # "pass" = forward + backward of ONE task's batch (a task-batched pass of nt tasks counts nt)
             row = dict(ms_per_pass=c['time'] / passes * 1e3, launches_per_pass=c['launches'] / passes, symbols=c['symbols'])
             if c['unit'] is not None and c['work'] > 0:
-                peak, unit, bound = peak_of(cls, c['unit'], eng.conv_mode, eng.wgrad_x3_dense)
+                peak, unit, bound = peak_of(cls, c['unit'], eng.conv_mode)
                 ach = c['work'] / c['time'] / (1e12 if c['unit'] == 'flop' else 1e9)
                 row.update(bound=bound, achieved=ach, peak=peak, unit=unit, frac=ach / peak)
                 if 'wgrad_sp' in c['symbols']:
@@ -889,7 +884,7 @@ def main():
                 f['traffic_known'] = False
         fam_table = {}
         for name, f in sorted(fams.items(), key=lambda kv: -kv[1]['time']):
-            peak, unit, bound = peak_of(f['classes'][0], f['unit'], eng.conv_mode, eng.wgrad_x3_dense)
+            peak, unit, bound = peak_of(f['classes'][0], f['unit'], eng.conv_mode)
             ach = f['work'] / f['time'] / (1e12 if f['unit'] == 'flop' else 1e9)
             fam_table[name] = dict(ms_per_pass=f['time'] / passes * 1e3, launches_per_pass=f['launches'] / passes, bound=bound, achieved=ach,
                                    peak=peak, unit=unit, frac=ach / peak, classes=f['classes'],
@@ -975,17 +970,12 @@ def main():
                                                                                                     2 * a.tasks * a.k * a.frames))
             del rag, trr
         # what ONE rank of the 8-GPU configuration runs per step: a single task, a single lane (no collective on one rank)
-        one = {}
-        for name, lanes in (('unsplit', 0), ('split2', 2), ('split4', 4)):
-            tr1 = mtl_amd.TransientTrainer()
-            tr1.split_single_task, tr1.split_lanes = lanes > 0, max(lanes, 2)
-            dt1, _ = timed_steps(tr1, model, vocab, tasks[:1], [0], a.tasks, inner, outer, args, 2 * k3, 4, mdist, dev)
-            one[name] = dt1 / (2 * k3) * 1e3
-        default = 'split%d' % trainer.split_lanes if trainer.split_single_task else 'unsplit'
-        out['one_task_per_gpu'] = dict(ms_per_step=one.get(default, one['unsplit']), schedule=default, by_schedule=one,
-                                       note='1 of %d tasks on this GPU (configs[2] per-rank work, without the all-reduce); unsplit: the two '
-                                            'passes as one chain + side stream; splitN: every pass split by samples over N lanes, one command '
-                                            'list (TransientTrainer._single_task_split)' % a.tasks)
+        tr1 = mtl_amd.TransientTrainer()
+        dt1, _ = timed_steps(tr1, model, vocab, tasks[:1], [0], a.tasks, inner, outer, args, 2 * k3, 4, mdist, dev)
+        out['one_task_per_gpu'] = dict(ms_per_step=dt1 / (2 * k3) * 1e3, schedule=tr1.last_schedule,
+                                       note='1 of %d tasks on this GPU (configs[2] per-rank work, without the all-reduce): the two '
+                                            'passes as one chain + side stream, one recorded command list' % a.tasks)
+        del tr1
         # the README trains with --dropout 0.1: same 8-task workload with the Philox dropout active
         model.encoder.dropout_rate = model.decoder.dropout_rate = 0.1
         model.train()

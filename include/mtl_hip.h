@@ -102,22 +102,6 @@ int mtl_gemm_h2_tb(void* stream, int transB, int M, int N, int K, const float* A
 int mtl_gemm_h2_tn_tb(void* stream, int M, int N, int K, const float* A, int lda, const float* amax_a, long sAmaxA, const float* B, int ldb,
                       const float* amax_b, long sAmaxB, float* C, int ldc, int tasks, long sAt, long sBt, long sCt);
 
-/* Grouped weight gradients: ONE launch computes  C_i += A_i^T . B_i  (and rowsum_i += column sums of A_i, nullable) for a whole
- * table of independent products -- all the small dW = dy^T . x of a backward pass (nn.Linear weight + bias gradients,
- * modules/common_layers.py:130,287-289,303), which are otherwise ~60 launches of 64..256 workgroups each.  A_i is K x M (lda), B_i is
- * K x N (ldb), C_i is M x N (ldc); operands 16-byte aligned with leading dimensions that are multiples of 4.  tile0 = number of
- * 32 x 32 output tiles of the products before i (prefix sum); total_tiles = sum.  The table lives in DEVICE memory. */
-typedef struct mtl_wgrad_desc {
-    const float* A;
-    const float* B;
-    float* C;
-    float* rowsum;
-    int M, N, K, lda, ldb, ldc;
-    int tile0;
-    int reserved;
-} mtl_wgrad_desc;
-int mtl_gemm_wgrad_grouped(void* stream, const mtl_wgrad_desc* table_dev, int n_products, int total_tiles);
-
 /* ---- VGG front-end: models/asr/transformer.py:48-59 (Conv2d 3x3 s1 p1 + ReLU [+ MaxPool2d(2,2)]) ------
  * x_ref is the reference's (B,1,F,T) input; everything downstream is (B,T,F,C). */
 /* amax_y (optional): MTL_AMAX_FLOATS floats, slot heads atomically raised to max(y) -- the `amax_x` of a following *_h2 convolution; zero them first. */

@@ -35,7 +35,6 @@ SIGNATURES = {
                             I, L, L, L, L, L]),
     'mtl_gemm_f32_ex_route': (I, [I, I, I, I, I, I]),
     'mtl_gemm_x3_min_tiles': (I, [I]),
-    'mtl_gemm_wgrad_grouped': (I, [P, P, I, I]),
     'mtl_conv0_relu_fwd': (I, [P, P, P, P, P, I, I, I, P]),
     'mtl_conv0_wgrad_workspace': (L, []),
     'mtl_conv0_wgrad': (I, [P, P, P, P, P, P, I, I, I]),
@@ -158,12 +157,6 @@ def lib():
 # ---------------------------------------------------------------------------------------------------------------------
 # command lists (include/mtl_hip.h "command lists"): record the C calls of one eager run, replay them with ONE ctypes call
 # ---------------------------------------------------------------------------------------------------------------------
-class WgradDesc(ctypes.Structure):
-    """mtl_wgrad_desc of include/mtl_hip.h (64 bytes)"""
-    _fields_ = [('A', c_void_p), ('B', c_void_p), ('C', c_void_p), ('rowsum', c_void_p), ('M', c_int), ('N', c_int), ('K', c_int),
-                ('lda', c_int), ('ldb', c_int), ('ldc', c_int), ('tile0', c_int), ('reserved', c_int)]
-
-
 AMAX_SLOTS = 64 * 32    # MTL_AMAX_FLOATS of include/mtl_hip.h: floats per max|tensor| bound of the h2 kernels (64 slot heads, 128 B apart)
 
 

@@ -49,8 +49,6 @@ struct G16P {
     int Zt;                       // batch items per TASK (third, outermost batch level: z = (zt * Zt/H + zb) * H + zh)
     long sAt, sBt, sCt, sBiasT, sRowT;
     int total;       // workgroups = tiles in N x tiles in M x batch
-    const mtl_wgrad_desc* groups;   // grouped mode: one launch covers `ngroups` independent products (descriptor table in HBM)
-    int ngroups;
 };
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
@@ -132,22 +130,9 @@ __global__ __launch_bounds__(256 * KG) void gemm16_kernel(G16P p0) {
     const int per = (p0.total + 7) >> 3;
     const int t = (blockIdx.x & 7) * per + (blockIdx.x >> 3);       // XCD-aware order (see the header)
     if (t >= p0.total) return;
-    G16P p = p0;
-    int rem = t, z = 0;
-    if (p0.groups) {
-        // grouped mode (mtl_gemm_wgrad_grouped): find the product this tile belongs to (uniform scalar scan of the table)
-        int gi = 0;
-        while (gi + 1 < p0.ngroups && p0.groups[gi + 1].tile0 <= t) ++gi;
-        const mtl_wgrad_desc d = p0.groups[gi];
-        p.A = d.A, p.B = d.B, p.C = d.C, p.rowsum = d.rowsum;
-        p.M = d.M, p.N = d.N, p.K = d.K, p.lda = d.lda, p.ldb = d.ldb, p.ldc = d.ldc;
-        rem = t - d.tile0;
-    }
+    const G16P& p = p0;
     const int nx = (p.N + TN - 1) / TN, ny = (p.M + TM - 1) / TM;
-    if (!p0.groups) {
-        z = t / (nx * ny);
-        rem = t - z * (nx * ny);
-    }
+    const int z = t / (nx * ny), rem = t - z * (nx * ny);
     const int m0 = (rem / nx) * TM, n0 = (rem % nx) * TN;
     const int zt = z / p.Zt, zz = z - zt * p.Zt;
     const int zb = zz / p.H, zh = zz - zb * p.H;
@@ -333,20 +318,16 @@ int launch16(const G16P& p, int batch, hipStream_t s) {
                      ((p.sAb | p.sAh | p.sBb | p.sBh | p.sAk | p.sBk | p.sAt | p.sBt) & 3) == 0;
     if (!vec) return launch_cfg<TA, TB, false, 1, 1, 1>(p, batch, s);     // dword loads: unaligned operands (rare)
     auto wgs = [&](int wm, int wn) { return (long)((p.M + 32 * wm - 1) / (32 * wm)) * ((p.N + 32 * wn - 1) / (32 * wn)) * batch; };
-    // grow the tile while the grid still holds about one chip-full of workgroups (256 CUs); tuning knobs for tools/bench_gemm16.py
-    static const int f_kg = getenv("MTL_G16_KG") ? atoi(getenv("MTL_G16_KG")) : 0;
-    static const int f_tile = getenv("MTL_G16_TILE") ? atoi(getenv("MTL_G16_TILE")) : 0;
+    // grow the tile while the grid still holds about one chip-full of workgroups (256 CUs)
     // measured (tools/bench_gemm16.py): 32 x 32 tiles win or tie up to ~1000 workgroups; beyond that the larger tiles' operand
     // re-use pays (vocabulary-projection dX: 64 -> 57 us with 64 x 32)
     int tile = wgs(1, 1) <= 1024 ? 1 : (wgs(2, 1) <= 1024 ? 2 : 3);
-    if (f_tile) tile = f_tile;
     const long n_wg = tile == 3 ? wgs(2, 2) : (tile == 2 ? wgs(2, 1) : wgs(1, 1));
     // K groups: only while the chip is not already full of workgroups, and each group keeps >= 2 K tiles
     const long ktiles = (long)((p.K + TK - 1) / TK) * p.kb;
     int kg = 1;
     if (n_wg <= 320 && ktiles >= 8) kg = 4;
     else if (n_wg <= 640 && ktiles >= 4) kg = 2;
-    if (f_kg) kg = f_kg;
     if (tile == 3) return launch_kg<TA, TB, 2, 2>(p, batch, s, kg == 4 ? 2 : kg);    // 64 x 64 x 4 groups would exceed 160 KiB of LDS
     if (tile == 2) return launch_kg<TA, TB, 2, 1>(p, batch, s, kg);
     return launch_kg<TA, TB, 1, 1>(p, batch, s, kg);
@@ -357,14 +338,11 @@ int launch16(const G16P& p, int batch, hipStream_t s) {
 static bool route_small(int M, int N, int K, int batch, int kbatch, bool rowsum) {
     const long tiles64 = (long)((M + 63) / 64) * ((N + 63) / 64) * batch;
     const long tiles32 = (long)((M + 31) / 32) * ((N + 31) / 32) * batch;
-    static const int f_small = getenv("MTL_G16_FORCE") ? atoi(getenv("MTL_G16_FORCE")) : 0;      // tuning knob
     // the big engine (64 x 64 / 128 x 128 tiles of v_mfma_f32_32x32x2_f32, split-K through the workspace) keeps every product
     // that fills the chip with its own tiles, and the few-tile / very-long-K ones (the 5120-deep input projection)
     // ... and long-K products with few tiles (the LM decoder's dX: 700 x 512 x 10000 on 88 tiles): split-K over the chip instead of
     // K groups inside 88 workgroups (176 -> 60 us)
-    static const long longk = getenv("MTL_G16_LONGK") ? atol(getenv("MTL_G16_LONGK")) : 4096;
-    const bool small = f_small ? f_small > 0
-                               : (tiles64 <= 320 && !(tiles32 < 48 && (long)K * kbatch >= 4096) && !(tiles64 <= 128 && (long)K * kbatch >= longk));
+    const bool small = tiles64 <= 320 && !(tiles32 < 48 && (long)K * kbatch >= 4096) && !(tiles64 <= 128 && (long)K * kbatch >= 4096);
     return kbatch > 1 || rowsum || small;
 }
 
@@ -376,18 +354,6 @@ int mtl_gemm_f32_ex_route(int M, int N, int K, int batch, int kbatch, int has_ro
     // (split-K form of the same engine: assumes an NN / NT / TN call with 16-byte aligned operands and a workspace that holds the slices)
     if (batch == 1 && kbatch == 1 && !has_rowsum && mtl_gemm_x3_splitk_slices(0, 0, M, N, K, 0, 1L << 40)) return 2;
     return route_small(M, N, K, batch, kbatch, has_rowsum != 0) ? 1 : 0;
-}
-
-/* see include/mtl_hip.h */
-int mtl_gemm_wgrad_grouped(void* stream, const mtl_wgrad_desc* table_dev, int n_products, int total_tiles) {
-    if (!table_dev || n_products <= 0 || total_tiles <= 0) return MTL_EINVAL;
-    G16P p{};
-    p.alpha = 1.f, p.flags = MTL_GEMM_ACCUM, p.H = 1, p.kb = 1, p.total = total_tiles, p.groups = table_dev, p.ngroups = n_products;
-    p.Zt = 1 << 30;
-    dim3 grid(((total_tiles + 7) / 8) * 8);
-    hipLaunchKernelGGL((gemm16_kernel<true, false, true, 4, 1, 1>), grid, dim3(1024), 0, as_stream(stream), p);
-    MTL_CHECK_LAUNCH();
-    return MTL_OK;
 }
 
 int mtl_gemm_f32_tb(void* stream, int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
@@ -412,7 +378,7 @@ int mtl_gemm_f32_tb(void* stream, int transA, int transB, int M, int N, int K, f
         return mtl_gemm_f32_3l(stream, transA, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, bias, gate, ldg, flags, batch, H, sAb,
                                sAh, sBb, sBh, sCb, sCh, sBias, sBiasH, workspace, workspace_bytes, tasks, sAt, sBt, sCt, sBiasT);
     G16P p{A, B, C, bias, gate, rowsum, M, N, K, lda, ldb, ldc, ldg, alpha, flags, H, sAb, sAh, sBb, sBh, sCb, sCh, sBias, kbatch,
-           sAk, sBk, sRowsum, sBiasH, sRowsumH, batch / tasks, sAt, sBt, sCt, sBiasT, sRowsumT, 0, nullptr, 0};
+           sAk, sBk, sRowsum, sBiasH, sRowsumH, batch / tasks, sAt, sBt, sCt, sBiasT, sRowsumT, 0};
     hipStream_t s = as_stream(stream);
     if (!transA && transB) return launch16<false, true>(p, batch, s);
     if (!transA && !transB) return launch16<false, false>(p, batch, s);

@@ -59,7 +59,7 @@ struct X3P {
     const float *amax_a, *amax_b;
     long sAmaxA, sAmaxB;
     int Ksplit;            // split-K launches: the product's full K; item zb (outer batch index) covers k in [zb K, min((zb + 1) K, Ksplit)) -- 0: off
-    int pingpong;          // the two waves of a SIMD run a K step's halves in opposite order (MTL_GEMM_X3_PINGPONG=0: lock-step, A/B measurements)
+    int pingpong;          // the two waves of a SIMD run a K step's halves in opposite order (0: lock-step, A/B measurements with a probe build)
 #ifdef MTL_X3G_PROF
     unsigned long long* prof;   // probe builds only (tools/probe/gemm_prof.py): [workgroup][wave][8] accumulated s_memtime intervals
 #endif
@@ -448,8 +448,7 @@ int launch_x3(X3P p, hipStream_t s) {
     static int attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_kernel<TA, TB, RS, BM, NP>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) == hipSuccess ? 0 : MTL_ELAUNCH;
     if (attr) return attr;
-    static const int pp = getenv("MTL_GEMM_X3_PINGPONG") ? atoi(getenv("MTL_GEMM_X3_PINGPONG")) : 1;
-    p.pingpong = pp;
+    p.pingpong = 1;
 #ifdef MTL_X3G_PROF
     p.prof = g_x3g_prof;
 #endif
@@ -471,7 +470,7 @@ inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) =
 
 static int g_min_tiles = -1;
 static int min_tiles_now() {
-    if (g_min_tiles < 0) g_min_tiles = getenv("MTL_GEMM_X3") ? atoi(getenv("MTL_GEMM_X3")) : 128;
+    if (g_min_tiles < 0) g_min_tiles = 128;       // (mtl_gemm_x3_min_tiles() changes it: bench.py's exact-fp32 leg sets 0 = engine off)
     return g_min_tiles;
 }
 
@@ -500,7 +499,7 @@ int mtl_gemm_x3_route(void* stream, int transA, int transB, int M, int N, int K,
     X3P p{A, B, C, bias, gate, rowsum, M, N, K, lda, ldb, ldc, ldg, alpha, flags, H, sAb, sAh, sBb, sBh, sCb, sCh, sBias, kbatch,
           sAk, sBk, sRowsum, sBiasH, sRowsumH, batch / tasks, sAt, sBt, sCt, sBiasT, sRowsumT, batch, nullptr, nullptr, 0, 0};
     // 256-row tiles (less operand traffic and split work per MFMA) once they give every CU a workgroup; 128-row tiles otherwise
-    static const int big_from = getenv("MTL_GEMM_X3_BIG") ? atoi(getenv("MTL_GEMM_X3_BIG")) : 224;
+    constexpr int big_from = 224;
     const bool big = x3_tiles(M, N, batch, 256) >= big_from;
     hipStream_t s = as_stream(stream);
     int rc;
@@ -541,7 +540,7 @@ __global__ __launch_bounds__(256) void x3_splitk_sum_kernel(const float* __restr
 // tile- and 16-byte aligned; the last slice is shorter when S Kc > K -- X3P::Ksplit).  Enough slices to give every CU a workgroup,
 // each at least `mindepth` deep, all partials inside the workspace.
 static int splitk_plan(long tiles, int M, int N, int K, long ws_bytes, int* Kc_out) {
-    static const int mindepth = getenv("MTL_GEMM_X3_SPLITK_MIN") ? atoi(getenv("MTL_GEMM_X3_SPLITK_MIN")) : 256;
+    constexpr int mindepth = 256;
     int S = (int)((256 + tiles - 1) / tiles);
     if (S > K / mindepth) S = K / mindepth;
     while (S >= 2 && (long)S * M * N * 4 > ws_bytes) --S;
@@ -558,8 +557,8 @@ int mtl_gemm_x3_splitk_slices(int transA, int transB, int M, int N, int K, int f
     const int mt = min_tiles_now();
     const long tiles = x3_tiles(M, N, 1, 128);
     // (round 4: from 2048 deep -- the one-task vocabulary-projection data gradient, 808 x 512 x 3765 on 28 tiles: 72 -> 30 us)
-    static const long longk = getenv("MTL_GEMM_X3_SPLITK") ? atol(getenv("MTL_GEMM_X3_SPLITK")) : 2048;
-    if (mt <= 0 || longk <= 0 || (transA && transB) || tiles >= mt || K < longk || (N & 3) || (flags & ~MTL_GEMM_ACCUM)) return 0;
+    constexpr long longk = 2048;
+    if (mt <= 0 || (transA && transB) || tiles >= mt || K < longk || (N & 3) || (flags & ~MTL_GEMM_ACCUM)) return 0;
     int Kc;
     return splitk_plan(tiles, M, N, K, ws_bytes, &Kc);
 }
@@ -596,9 +595,8 @@ extern "C" int mtl_gemm_h2_tb(void* stream, int transB, int M, int N, int K, con
     hipStream_t s = as_stream(stream);
     // ONE task, few output tiles, long K (the encoder's input Linear of a rank that holds a single task: 2000 x 512 x 5120 = 64 tiles
     // on 256 CUs, 115 us): K slices over the grid into the workspace + the fixed-order sum (bias there)
-    static const bool splitk_on = !(getenv("MTL_GEMM_H2_SPLITK") && atoi(getenv("MTL_GEMM_H2_SPLITK")) == 0);
     const long tiles = x3_tiles(M, N, 1, 128);
-    if (splitk_on && tasks == 1 && !gate && workspace && tiles < 128 && K >= 2048 && !(N & 3) && !(ldc & 3) && al16(C) && (!bias || al16(bias))) {
+    if (tasks == 1 && !gate && workspace && tiles < 128 && K >= 2048 && !(N & 3) && !(ldc & 3) && al16(C) && (!bias || al16(bias))) {
         int Kc = 0;
         const int S = splitk_plan(tiles, M, N, K, workspace_bytes, &Kc);
         if (S >= 2) {

@@ -888,7 +888,7 @@ struct ConvX3P {
     uint8_t* am_out;
     ConvGeom g;          // Cin = reduction channels, Cout = output channels of THIS conv (dgrad: swapped by the caller)
     int ntile;
-    int dbg;             // ablation switches (MTL_X3_DBG), 0 in production
+    int dbg;             // ablation switches of probe builds, 0 in production
     int ntf, ntt, tiles; // halo kernel: pixel tiles along F and T, and tiles in total (F fastest, then T, then output-channel tile, then sample)
     const float* amax_in;   // NP = 2: MTL_AMAX_SLOTS floats whose maximum is >= max|x|
     float* amax_out;        // optional: atomic max of an upper bound of max|y| (the next layer's amax_in)
@@ -946,11 +946,6 @@ inline int device_cu_count() {
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
         n = 256;
-    // experiment (MTL_X3_CUS): persistent convolution grids that leave some CUs to the other task lane's small kernels
-    if (const char* e = getenv("MTL_X3_CUS")) {
-        const int lim = atoi(e);
-        if (lim >= 8 && lim < n) n = lim / 8 * 8;
-    }
     return n;
 }
 
@@ -1467,8 +1462,7 @@ int launch_conv_x3h(ConvX3P p, int Te, int Fe, hipStream_t s) {
     if (attr) return attr;
     static const int per_cu = (THREADS <= 512 && SMEM <= 80 * 1024) ? 2 : 1;     // 12-wave workgroups never share a CU
     static const int ncu = device_cu_count();
-    static const int dbg = getenv("MTL_X3_DBG") ? atoi(getenv("MTL_X3_DBG")) : 0;
-    p.dbg = dbg;
+    p.dbg = 0;
 #ifdef MTL_X3_PROF
     p.prof = g_x3_prof;
 #endif
@@ -1486,21 +1480,16 @@ int dispatch_conv_x3(ConvX3P& p, int Te, int Fe, hipStream_t s) {
     if (p.g.Cin % 64 || p.g.Cout % 64) return MTL_EINVAL;     // C_in % 64: even number of K-tiles (producer loop is unrolled by 2)
     // 8 x 16 tiles (G = 1: 79 KiB of LDS at BN = 64, two workgroups per CU) measured faster only on the 64 -> 64 layer
     // (conv2 fwd 0.52 -> 0.50 ms, dgrad 0.61 -> 0.59); every 128-wide shape and conv5-dgrad is faster with 16 x 16 tiles.
-    static const bool g1 = getenv("MTL_X3_G1") != nullptr;          // experiment: 8 x 16 tiles everywhere (LDS room for co-resident kernels)
-    static const bool bn64 = getenv("MTL_X3_BN64") != nullptr;      // experiment: 128 output channels as two 64-channel tiles (two workgroups per CU)
-    if (p.g.Cout % 128 == 0 && !(bn64 && NP == 2 && EPI != EPI_DGRAD)) {
+    if (p.g.Cout % 128 == 0) {
         p.ntile = p.g.Cout / 128;
-        return g1 ? launch_conv_x3h<128, 1, UNPOOL, EPI, NP>(p, Te, Fe, s) : launch_conv_x3h<128, 2, UNPOOL, EPI, NP>(p, Te, Fe, s);
+        return launch_conv_x3h<128, 2, UNPOOL, EPI, NP>(p, Te, Fe, s);
     }
     p.ntile = p.g.Cout / 64;
     // two-piece fp16 forward, 64 output channels: 16 x 16 tiles with FOUR consumer waves of 64 px x 64 ch, two workgroups per CU
     // (LDS-bound with 32-channel waves, see the kernel's header: conv2 forward 0.385 -> 0.341 ms); the data-gradient epilogue does not
-    // fit the 128-VGPR budget of that shape (spills: 0.45 -> 0.71 ms).  MTL_X3_WN2 keeps the older shape for A/B measurements
-    static const bool wn2 = getenv("MTL_X3_WN2") != nullptr;
-    if constexpr (NP == 2 && EPI != EPI_DGRAD) {
-        if (!wn2 && !g1) return launch_conv_x3h<64, 2, UNPOOL, EPI, NP, 1>(p, Te, Fe, s);
-    }
-    if (p.g.Cin == 64 || g1) return launch_conv_x3h<64, 1, UNPOOL, EPI, NP>(p, Te, Fe, s);
+    // fit the 128-VGPR budget of that shape (spills: 0.45 -> 0.71 ms)
+    if constexpr (NP == 2 && EPI != EPI_DGRAD) return launch_conv_x3h<64, 2, UNPOOL, EPI, NP, 1>(p, Te, Fe, s);
+    if (p.g.Cin == 64) return launch_conv_x3h<64, 1, UNPOOL, EPI, NP>(p, Te, Fe, s);
     return launch_conv_x3h<64, 2, UNPOOL, EPI, NP>(p, Te, Fe, s);
 }
 
@@ -1789,7 +1778,7 @@ struct WgradX3P {
     int B, T, F, Ty, Fy, Tp, Fp, Cin, Cout;
     int npairs, npj;      // channel-block pairs, and pairs along Cout
     int ntf, ntt, tiles;  // pixel tiles along F, along T, in total (F fastest)
-    int dbg;              // ablation switches (MTL_X3_DBG): 1 no halo staging, 2 no dy loads / splits; 0 in production
+    int dbg;              // ablation switches of probe builds: 1 no halo staging, 2 no dy loads / splits; 0 in production
     const float* amax_x;  // NP = 2: device scalars >= max|x|, >= max|dy|
     const float* amax_dy;
     float* bias_part;     // optional [slot][Cout]: per-slot sums of dy over the slot's pixels (the bias gradient rides along: the
@@ -2782,9 +2771,8 @@ static int wgrad_pieces(hipStream_t s, const float* x, const float* amax_x, cons
     p.bias_part = db ? workspace + (long)(grid / p.npairs) * 9L * Cin * Cout : nullptr;
     constexpr int SMEM = wx_smem(NP);
     if constexpr (NP == 2) {
-        // pooled layers: the 2:4-sparse form (MTL_WGRAD_SPARSE=0 keeps the dense kernel: A/B measurements)
-        static const bool sparse = !(getenv("MTL_WGRAD_SPARSE") && atoi(getenv("MTL_WGRAD_SPARSE")) == 0);
-        if (pooled && sparse && grid % (8 * p.npairs) == 0) {
+        // pooled layers: the 2:4-sparse form
+        if (pooled && grid % (8 * p.npairs) == 0) {
             static int attr_sp = set_smem(conv3x3_wgrad_sp_kernel, wsp_smem());
             if (attr_sp) return attr_sp;
             hipLaunchKernelGGL(conv3x3_wgrad_sp_kernel, dim3(grid), dim3(512), wsp_smem(), s, p);

@@ -109,12 +109,11 @@ class LMEngine:
         self.m, self.device, self.lib, self.L = model, device, _lib.lib(), model._layout
         self.pool, self.saved = {}, None
         self.ws = torch.empty(4 << 20, dtype=torch.float32, device=device)
-        # all T steps of a layer in ONE launch per direction (csrc/mtl_lstm.hip) where the shape is supported; '0' keeps the per-step
-        # recurrent product + cell kernel (A/B measurements, unsupported shapes take it anyway)
-        import os
-        self.persistent = os.environ.get('MTL_LSTM_PERSISTENT', '1') != '0'
-        # the whole stack as one wavefront launch per direction (layers one step apart); '0': one launch per layer and direction
-        self.stacked = os.environ.get('MTL_LSTM_STACK', '1') != '0'
+        # all T steps of a layer in ONE launch per direction (csrc/mtl_lstm.hip) where the shape is supported; False keeps the per-step
+        # recurrent product + cell kernel (tests compare the two; unsupported shapes take it anyway)
+        self.persistent = True
+        # the whole stack as one wavefront launch per direction (layers one step apart); False: one launch per layer and direction
+        self.stacked = True
         self.sync_ws = torch.zeros(int(self.lib.mtl_lstm_layer_workspace()) // 4, dtype=torch.int32, device=device)
         self._persistent_issued = False
 

@@ -21,7 +21,7 @@ from collections import deque
 import torch
 
 from . import _lib, _trace, dist as mdist, hostenv
-from .engine import PAD_ID, decoder_io, round_width
+from .engine import PAD_ID, round_width
 from .functions import post_process, save_joint_model, save_meta_model
 from .metrics import calculate_cer, calculate_metrics
 
@@ -189,18 +189,6 @@ class _TaskRead:
         self.gold_host, self.hyp, self.loss = gold_host, hyp, loss
 
 
-class _SplitRead:
-    """Read-backs of a pass that ran in parts on several lanes: the loss of the batch is the sum of the parts' (each normalised by
-    the WHOLE batch's token count)."""
-
-    def __init__(self, gold_host, hyp, part_losses):
-        self.gold_host, self.hyp, self._parts = gold_host, hyp, part_losses
-
-    @property
-    def loss(self):
-        return [float(self._parts.sum())]
-
-
 def _strings(vocab, rows):
     return [''.join(vocab.id2label[int(t)] for t in row) for row in rows.tolist()]
 
@@ -346,24 +334,18 @@ def _sample_takes_need(ds):
 class TransientTrainer():
     def __init__(self):
         logging.info('Transient Trainer is initialized')
-        # hipGraph replay of a task body (per-task lanes only) is validated but opt-in: the loop is GPU-throughput-bound and replay
-        # measured equal (8 tasks) or slower (3 tasks, dropout) than the command lists below on ROCm 7.2
-        self.use_graphs = os.environ.get('MTL_GRAPHS', '0') == '1'
-        # command lists (default on): the library calls of a task body are recorded once per (lane, shapes, scalars) and then
-        # replayed from C with one ctypes call per task (include/mtl_hip.h "command lists"): host cost per pass 4.4 -> ~1 ms
-        self.use_cmdlists = os.environ.get('MTL_CMDLISTS', '1') != '0'
+        # Runtime switches read from the environment (INTEGRATION.md "Environment"): MTL_BATCH_TASKS, MTL_RAGGED_FILL,
+        # MTL_RAGGED_QUANTUM, MTL_PIPELINE_DEPTH.  Everything else below is a plain attribute (tests and bench.py set them).
+        # command lists: the library calls of a task body are recorded once per (lane, shapes, scalars) and then replayed from C with
+        # one ctypes call per task (include/mtl_hip.h "command lists"): host cost per pass 4.4 -> ~1 ms
+        self.use_cmdlists = True
         self._cmdlists = {}
-        # a rank with a single task can split its batch over the two lanes (_single_task_split; exact, tested) -- measured no
-        # faster than the unsplit task (18.4 vs 18.7 ms per 1-task step, slower with dropout), so it is opt-in
-        self.split_single_task = os.environ.get('MTL_SPLIT_TASK', '0') == '1'
-        self.split_lanes = int(os.environ.get('MTL_SPLIT_LANES', '2'))
-        self._graphs = {}
         # the local tasks of a meta-step as ONE task-batched pass per phase (training passes at theta0, validation passes at the
         # theta' stack) instead of one pass chain per task on concurrent lanes; MTL_BATCH_TASKS=0: the lanes
         self.batch_tasks = os.environ.get('MTL_BATCH_TASKS', '1') != '0'
-        # tasks whose batches have different frame counts in one pass, stacked at the widest (0: one lane per task), as long as the
+        # tasks whose batches have different frame counts in one pass, stacked at the widest (False: one lane per task), as long as the
         # tasks' frames fill at least this share of the stack
-        self.batch_ragged = os.environ.get('MTL_BATCH_RAGGED', '1') != '0'
+        self.batch_ragged = True
         self.ragged_fill = float(os.environ.get('MTL_RAGGED_FILL', '0.4'))
         # ... and the stack's width (training and validation) rounded up to a multiple of this many frames: any width at or above the
         # widest task is exact (every task keeps its own border), and widths that repeat keep the buffer pool's allocations -- 11 GB
@@ -371,17 +353,20 @@ class TransientTrainer():
         self.ragged_quantum = int(os.environ.get('MTL_RAGGED_QUANTUM', '64'))
         # the same rounding for a task that runs on a lane of its own (one task per rank; tasks too unequal to stack): 'auto' = from the
         # moment the lanes have seen two different widths (fixed-shape workloads are never padded), '1' always, '0' never
-        self.pad_lanes = os.environ.get('MTL_PAD_LANES', 'auto')
-        self.label_quantum = int(os.environ.get('MTL_LABEL_QUANTUM', '8'))      # ... and the decoder width to a multiple of this many positions
+        self.pad_lanes = 'auto'
+        self.label_quantum = 8      # ... and the decoder width to a multiple of this many positions
         self._lane_widths, self._lane_widths_vary = {}, False
-        # train() enqueues iteration i + 1 before it resolves (logs) iteration i (enqueue_iteration); MTL_PIPELINE=0: resolve at once
-        self.pipeline = os.environ.get('MTL_PIPELINE', '1') != '0'
-        # how many iterations may be enqueued beyond the one being resolved (nothing the host needs to enqueue an iteration comes
-        # from the device): 1 hides the host's per-iteration work, 2 also rides out host stalls of up to one iteration's GPU time
-        # (shared hosts: measured enqueue times of 5 - 90 ms for the same iteration).  Read-back buffer sets: depth + 1.
-        self.pipeline_depth = max(1, int(os.environ.get('MTL_PIPELINE_DEPTH', '2'))) if self.pipeline else 0
+        # train() enqueues iteration i + 1 before it resolves (logs) iteration i (enqueue_iteration).  MTL_PIPELINE_DEPTH: how many
+        # iterations may be enqueued beyond the one being resolved (nothing the host needs to enqueue an iteration comes from the
+        # device): 0 resolves at once, 1 hides the host's per-iteration work, 2 (default) also rides out host stalls of up to one
+        # iteration's GPU time (shared hosts: measured enqueue times of 5 - 90 ms for the same iteration).  Read-back buffer sets:
+        # depth + 1.
+        self.pipeline_depth = max(0, int(os.environ.get('MTL_PIPELINE_DEPTH', '2')))
+        self.pipeline = self.pipeline_depth > 0
         # batches handed over in host memory are uploaded on a separate stream, one iteration ahead of the kernels (task-batched passes)
-        self.overlap_uploads = os.environ.get('MTL_OVERLAP_UPLOADS', '1') != '0'
+        self.overlap_uploads = True
+        self.pin_batches = True             # train(): batches drawn on the host are page-locked by the prefetch thread
+        self.replica_check_every = 100      # several ranks: iterations between two bit-level divergence checks of the replicas
         self._turn = 0
 
     # ------------------------------------------------------------------ drop-in single-batch API
@@ -421,16 +406,10 @@ class TransientTrainer():
         theta0 = model.flat_parameters
         self._G_reduced = False
         smoothing = float(getattr(args, 'label_smoothing', 0.0) or 0.0)
-        hooked = any(e.prof is not None or e.forward_hook is not None or e.after_conv_hook is not None for e in model.engines)
-        use_graphs = self.use_graphs and not hooked
-        use_cmdlists = self.use_cmdlists and not use_graphs and not hooked and os.environ.get('MTL_STAGGER', '0') != '1'
-        if (len(task_batches) == 1 and model.n_lanes >= 2 and self.split_single_task and not use_graphs
-                and task_batches[0][0].shape[0] >= 2 and val_batch[0].shape[0] >= 2
-                and not any(e.prof is not None for e in model.engines)):
-            self.last_schedule = 'split'
-            return self._single_task_split(model, task_batches[0], val_batch, n_tasks, inner, args, use_cmdlists)
+        hooked = any(e.prof is not None or e.forward_hook is not None for e in model.engines)
+        use_cmdlists = self.use_cmdlists and not hooked
         self.last_schedule = 'lanes'                         # (diagnostics / tests: which schedule the last iteration took)
-        if self._can_batch(model, task_batches, val_batch, use_graphs):
+        if self._can_batch(model, task_batches, val_batch):
             frames = [int(tb[0].shape[3]) for tb in task_batches]
             self.last_schedule = 'batched' if min(frames) == max(frames) else 'batched-ragged'
             return self._batched_iteration(model, task_batches, val_batch, n_tasks, inner, args, smoothing, use_cmdlists)
@@ -444,7 +423,7 @@ class TransientTrainer():
         # widths that change from batch to batch (manifest-fed) would be enqueued call by call for ever: rounded up to a quantum they
         # repeat (recorded lists replay, the pool keeps its buffers); the batch keeps its own border and encoder length (prepare(frames))
         varies = self._widths_vary([('lane', i, int(tb[0].shape[3])) for i, tb in enumerate(task_batches)] + [('lane', 'val', int(vx.shape[3]))])
-        q = self.ragged_quantum if varies and not use_graphs else 0
+        q = self.ragged_quantum if varies else 0
         most = 4 * model.engines[0].hp.src_max_len
 
         def widened(x, eng_, name):
@@ -461,21 +440,15 @@ class TransientTrainer():
         ready = torch.cuda.Event()
         ready.record(main)
         reads = [None] * len(task_batches)
-        streams = [model.lane_streams[lane] if (n_lanes > 1 or use_graphs) else main for lane in range(n_lanes)]
+        streams = [model.lane_streams[lane] if n_lanes > 1 else main for lane in range(n_lanes)]
         for lane in range(n_lanes):
             with torch.cuda.stream(streams[lane]):
                 streams[lane].wait_event(ready)
                 bufs[lane][2].zero_()
-        stagger = os.environ.get('MTL_STAGGER', '0') == '1' and n_lanes > 1
-        phase_ev = torch.cuda.Event() if stagger else None
         for idx, (tx, tsz, _tp, ty, _tl) in enumerate(task_batches):      # enqueue task by task, alternating lanes
             lane = idx % n_lanes
             eng = model.engines[lane]
             with torch.cuda.stream(streams[lane]):
-                if stagger and idx == 0:
-                    eng.after_conv_hook = lambda: phase_ev.record(torch.cuda.current_stream(dev))
-                if stagger and 0 < idx < n_lanes:
-                    streams[lane].wait_event(phase_ev)        # start this lane half a phase behind lane 0
                 tx, t_own = widened(tx.to(dev, non_blocking=True), eng, 'lane.x_tr')
                 lw = (lambda y_: _label_width([y_], self.label_quantum, eng.hp.tgt_max_len)) if (q > 1 and self.label_quantum > 1) else (lambda y_: None)
                 m_tr = eng.prepare(tsz, ty, tx.shape[0], tx.shape[3], slot=0, frames=t_own, width=lw(ty))   # host ints -> static device buffers
@@ -486,22 +459,17 @@ class TransientTrainer():
                        tuple(b.data_ptr() for b in bufs[lane]), streams[lane].cuda_stream, eng.use_side_stream)
                 # a rank that holds ONE task (8 tasks on 8 GPUs): G = its g, handed to the all-reduce group by group under the backward
                 chunk = None
-                if n_lanes == 1 and len(task_batches) == 1 and not use_graphs:
+                if n_lanes == 1 and len(task_batches) == 1:
                     g_, G_ = bufs[lane][0], bufs[lane][2]
                     chunk = self._chunk_hook(model, eng, lambda lo, n, st, g_=g_, G_=G_: check(
                         _lib.lib().mtl_axpy(st, G_.data_ptr() + 4 * lo, g_.data_ptr() + 4 * lo, 1.0, n), 'mtl_axpy'))
                     key = key + ('chunked',) if chunk is not None else key
                 body = lambda xa, xb: self._task_body(model, lane, bufs[lane], theta0, xa, m_tr, xb, m_va, n_tasks, inner, args,
                                                       smoothing, slots, chunk)
-                graph = self._graph_for(key, lane, tx, vx, body, streams[lane], eng) if use_graphs else None
-                if graph is None and use_cmdlists:
+                if use_cmdlists:
                     self._run_recorded(key, eng, tx, vx, body, on_break=chunk)
-                elif graph is None:
-                    body(tx, vx)
                 else:
-                    graph['x_tr'].copy_(tx, non_blocking=True)
-                    graph['x_va'].copy_(vx, non_blocking=True)
-                    graph['g'].replay()
+                    body(tx, vx)
                 reads[idx] = (_Readback(dict(gold_host=m_tr['gold_host'], hyp=slots['hyp_tr'], loss=slots['loss_tr']), (idx, 0, self._turn), self._turns()),
                               _Readback(dict(gold_host=m_va['gold_host'], hyp=slots['hyp_va'], loss=slots['loss_va']), (idx, 1, self._turn), self._turns()))
         if streams[0] is not main:
@@ -533,13 +501,13 @@ class TransientTrainer():
                     break
         return self._lane_widths_vary
 
-    def _can_batch(self, model, task_batches, val_batch, use_graphs):
+    def _can_batch(self, model, task_batches, val_batch):
         """All local tasks in one pass per phase: needs >= 2 tasks with identical batch shapes (samples x frames; label widths may
-        differ), the fused attention kernel and plain launches (no hipGraph capture, no profiling proxy)."""
-        if not self.batch_tasks or len(task_batches) < 2 or use_graphs:
+        differ) and the fused attention kernel."""
+        if not self.batch_tasks or len(task_batches) < 2:
             return False
         eng = model.engines[0]
-        if not eng.fused_attn or eng.group_wgrads or eng.after_conv_hook is not None:
+        if not eng.fused_attn:
             return False
         if val_batch[0].dim() != 4 or any(tb[0].dim() != 4 for tb in task_batches):
             return False
@@ -705,18 +673,13 @@ class TransientTrainer():
         return [(_TaskRead(m_tr['gold_hosts'][t], hyp_tr[t * B:(t + 1) * B], loss_tr[t:t + 1]),
                  _TaskRead(m_va['gold_hosts'][t], hyp_va[t * Bv:(t + 1) * Bv], loss_va[t:t + 1])) for t in range(nt)]
 
-    def _chunk_hook(self, model, eng, accumulate_slice, lanes=None):
+    def _chunk_hook(self, model, eng, accumulate_slice):
         """-> callable(tag) for PassEngine.slice_hook (None when the meta-gradient is not all-reduced in chunks).  At the point where
         the validation backward has enqueued the last kernel of a parameter group, the hook -- on the communication stream, behind the
         engine's main AND side stream -- forms that group's slice of G from the local gradients (accumulate_slice(first, count, raw
         stream)) and starts its all-reduce (dist.ChunkedAllReduce); _chunk_join() makes the main stream wait for all three before the
-        outer step.  Fixed slice order on every rank: decoder, encoder, conv (the order the backward finishes them in).
-        lanes: [(stream, engine)] when the pass is split over several lanes (_split_iteration): every lane's backward calls the hook,
-        the slice leaves once ALL of them have (the communication stream then waits for every lane's main and side stream)."""
-        engs = [eng] if lanes is None else [e for _s, e in lanes]
-        if not mdist.chunked_on() or any(e.group_wgrads or e.flush_delay for e in engs):
-            # (grouped / held weight-gradient launches are issued after the hook points: their groups' slices would leave incomplete;
-            # the iteration then ends with the same three collectives in the same order, see reduce_meta_gradient)
+        outer step.  Fixed slice order on every rank: decoder, encoder, conv (the order the backward finishes them in)."""
+        if not mdist.chunked_on():
             self._chunks = None
             return None
         dev = model.flat_parameters.device
@@ -727,23 +690,12 @@ class TransientTrainer():
             raise RuntimeError('unexpected parameter groups %s' % sorted(bounds))
         self._chunks = mdist.ChunkedAllReduce()
         G, comm = model._G, self._comm_stream
-        seen = {}
 
         def hook(tag):
             lo, hi = bounds[tag]
-            if lanes is None:
-                comm.wait_stream(torch.cuda.current_stream(dev))
-                if eng.side is not None:
-                    comm.wait_stream(eng.side)
-            else:
-                seen[tag] = seen.get(tag, 0) + 1
-                if seen[tag] < len(lanes):
-                    return                                   # another lane's backward has not enqueued this group yet
-                seen[tag] = 0
-                for st_, e_ in lanes:
-                    comm.wait_stream(st_)
-                    if e_.side is not None:
-                        comm.wait_stream(e_.side)
+            comm.wait_stream(torch.cuda.current_stream(dev))
+            if eng.side is not None:
+                comm.wait_stream(eng.side)
             with torch.cuda.stream(comm):
                 accumulate_slice(lo, hi - lo, comm.cuda_stream)
                 self._chunks.issue(G[lo:hi])
@@ -759,124 +711,8 @@ class TransientTrainer():
         self._chunks = None
         self._G_reduced = True
 
-    def _single_task_split(self, model, task, val_batch, n_tasks, inner, args, use_cmdlists=False):
-        """A rank that holds ONE task (8 tasks on 8 GPUs): the task's own chain (training pass -> theta' -> validation pass) is
-        sequential and its ~210 transformer launches per pass are latency-bound at 8 samples.  No op of the network couples samples
-        except the loss normaliser, so each pass is split by samples over `split_lanes` lanes (own stream, engine and side stream; the
-        same 1/n_tokens of the WHOLE batch in every part): g = sum of the parts before the clip / inner step, G = sum of the lanes'
-        accumulators at the end, or -- several ranks -- slice by slice under the validation backward (_chunk_hook(lanes=...)).
-        Equal to the unsplit step up to fp32 summation order, deterministic run to run.  Everything between the input copies and the
-        read-backs is library calls with explicit streams and events, so the whole step is recorded into ONE command list and
-        replayed from C (the eager form needs ~1400 ctypes calls per step and was host-bound)."""
-        dev = model.flat_parameters.device
-        theta0 = model.flat_parameters
-        smoothing = float(getattr(args, 'label_smoothing', 0.0) or 0.0)
-        lib = _lib.lib()
-        tx, tsz, _tp, ty, _tl = task
-        vx, vsz, _vp, vy, _vl = val_batch
-        L = max(2, min(int(self.split_lanes), model.n_lanes, tx.shape[0], vx.shape[0]))
-        engs, streams = model.engines[:L], model.lane_streams[:L]
-        main = torch.cuda.current_stream(dev)
-        total = model._layout.total
-        key_b = (id(theta0), L)
-        if getattr(self, '_split_key', None) != key_b:
-            self._split_bufs = (torch.zeros(L * total, dtype=torch.float32, device=dev), torch.empty(total, dtype=torch.float32, device=dev))
-            self._split_key = key_b
-        g_stack, theta1 = self._split_bufs
-        g = [g_stack[l * total:(l + 1) * total] for l in range(L)]
-        e0 = engs[0]
-        # static input buffers (the recorded calls hold their addresses), filled on the main stream
-        Xtr = e0.buf('sp.x_tr', tuple(tx.shape))
-        Xva = e0.buf('sp.x_va', tuple(vx.shape))
-        Xtr.copy_(tx, non_blocking=True)
-        Xva.copy_(vx, non_blocking=True)
-
-        def parts(x, sz, y):
-            n = x.shape[0]
-            cuts = [(n * l) // L for l in range(L + 1)]
-            seq_out = decoder_io(y)[1]
-            tokens, width = int((seq_out != PAD_ID).sum()), seq_out.shape[1]  # non-pad targets / decoder width of the WHOLE batch
-            return [(x[a:b], sz[a:b], y[a:b], tokens, width) for a, b in zip(cuts[:-1], cuts[1:])]
-        tr, va = parts(Xtr, tsz, ty), parts(Xva, vsz, vy)
-        metas, slots = [], []
-        for l in range(L):              # (uploads of the per-part integers: on the main stream, the lanes start behind `ready`)
-            m_tr = engs[l].prepare(tr[l][1], tr[l][2], tr[l][0].shape[0], tx.shape[3], slot=0, norm_count=tr[l][3], width=tr[l][4])
-            m_va = engs[l].prepare(va[l][1], va[l][2], va[l][0].shape[0], vx.shape[3], slot=1, norm_count=va[l][3], width=va[l][4])
-            metas.append((m_tr, m_va))
-            slots.append(self._slots(model, l, m_tr, m_va))
-        G = model._G
-        lr = float(inner.param_groups[0]['lr'])
-        chunk = self._chunk_hook(model, e0, lambda lo, n, st: check(
-            lib.mtl_sum_tasks_strided(st, G.data_ptr() + 4 * lo, g_stack.data_ptr() + 4 * lo, n, L, total, 0), 'mtl_sum_tasks_strided'),
-            lanes=list(zip(streams, engs)))
-        raw = [s_.cuda_stream for s_ in streams]
-
-        def body(_xa=None, _xb=None):
-            rec, wait = e0.lib.mtl_event_record, e0.lib.mtl_stream_wait_event       # (through the Recorder while recording)
-            ev = e0._event()
-            check(rec(ev, main.cuda_stream), 'mtl_event_record')
-            for l in range(L):
-                check(wait(raw[l], ev), 'mtl_stream_wait_event')
-            for l in range(L):                                                   # ---- training pass, one part per lane
-                with torch.cuda.stream(streams[l]):
-                    engs[l].zero_(g[l])
-                    engs[l].forward_device(theta0, tr[l][0], metas[l][0], smoothing, hyp_out=slots[l]['hyp_tr'], loss_out=slots[l]['loss_tr'])
-                    engs[l].backward(g[l], 1.0)
-            for l in range(1, L):                                                # ---- join on lane 0: g = sum of the parts, clip, theta'
-                ev = engs[l]._event()
-                check(rec(ev, raw[l]), 'mtl_event_record')
-                check(wait(raw[0], ev), 'mtl_stream_wait_event')
-            with torch.cuda.stream(streams[0]):
-                for l in range(1, L):
-                    e0.axpy_(g[0], g[l], 1.0)
-                if args.clip:
-                    clip_flat_grad_(model, g[0], args.max_norm, lane=0)
-                e0.sgd_theta_prime(theta0, g[0], lr, theta1)
-            ev = e0._event()
-            check(rec(ev, raw[0]), 'mtl_event_record')
-            for l in range(1, L):
-                check(wait(raw[l], ev), 'mtl_stream_wait_event')
-                with torch.cuda.stream(streams[l]):
-                    engs[l].zero_(g[l])                                          # the other lanes' accumulators restart (lane 0's holds g_tr: Q1)
-            for l in range(L):                                                   # ---- validation pass at theta', one part per lane
-                with torch.cuda.stream(streams[l]):
-                    engs[l].forward_device(theta1, va[l][0], metas[l][1], smoothing, hyp_out=slots[l]['hyp_va'], loss_out=slots[l]['loss_va'])
-                    engs[l].slice_hook = chunk
-                    try:
-                        engs[l].backward(g[l], 1.0 / n_tasks)
-                    finally:
-                        engs[l].slice_hook = None
-            for l in range(L):                                                   # ---- the main stream continues behind every lane
-                ev = engs[l]._event()
-                check(rec(ev, raw[l]), 'mtl_event_record')
-                check(wait(main.cuda_stream, ev), 'mtl_stream_wait_event')
-            if chunk is None:
-                check(e0.lib.mtl_sum_tasks(main.cuda_stream, G.data_ptr(), g_stack.data_ptr(), total, L, 0), 'mtl_sum_tasks')
-
-        key = ('split', L, tuple(tx.shape), tuple(vx.shape), tuple(m[0]['Td'] for m in metas), tuple(m[1]['Td'] for m in metas), n_tasks,
-               bool(args.clip), float(args.max_norm), smoothing, lr, theta0.data_ptr(), e0.dropout_p, g_stack.data_ptr(), theta1.data_ptr(),
-               G.data_ptr(), main.cuda_stream, tuple(raw), tuple(e.use_side_stream for e in engs), chunk is not None)
-        if use_cmdlists:
-            self._run_recorded(key, engs, None, None, body, on_break=chunk)
-        else:
-            body()
-        self._chunk_join(dev)
-        reads = []
-        for part, key_h, key_l in ((0, 'hyp_tr', 'loss_tr'), (1, 'hyp_va', 'loss_va')):
-            rows = [slots[l][key_h].shape[0] for l in range(L)]
-            hyp = _pinned(('sp.hyp', part, self._turn), (sum(rows), slots[0][key_h].shape[1]), torch.int64, self._turns())
-            loss = _pinned(('sp.loss', part, self._turn), (L,), torch.float32, self._turns())
-            a = 0
-            for l in range(L):
-                hyp[a:a + rows[l]].copy_(slots[l][key_h], non_blocking=True)
-                loss[l:l + 1].copy_(slots[l][key_l], non_blocking=True)
-                a += rows[l]
-            gold = torch.cat([metas[l][part]['gold_host'] for l in range(L)])
-            reads.append(_SplitRead(gold, hyp, loss))
-        return [tuple(reads)]
-
     def _task_body(self, model, lane, bufs, theta0, x_tr, m_tr, x_va, m_va, n_tasks, inner, args, smoothing, slots, chunk=None):
-        """Kernels of ONE task on the current stream (eager, or recorded into a hipGraph): train pass at theta0, fused inner
+        """Kernels of ONE task on the current stream (eager, or recorded into a command list): train pass at theta0, fused inner
         SGD into theta', validation pass at theta', accumulation into the lane's copy_grad buffer."""
         eng = model.engines[lane]
         g, theta1, G = bufs
@@ -946,41 +782,6 @@ class TransientTrainer():
             cl.repoint(tmp, tx.data_ptr())
             ent['x_tr'], ent['x_va'] = tx.data_ptr(), vx.data_ptr()
         cl.run(on_break)
-
-    def _graph_for(self, key, lane, tx, vx, body, stream, model_engine):
-        """hipGraph of a task body, keyed by everything baked into it (shapes, scalars, buffer addresses).  First sighting of
-        a key -> None (the eager run is the warm-up that allocates every buffer); second sighting -> capture; then replay.
-        The per-launch Python/ctypes cost (~7 us x ~1400 launches per task) disappears from the loop."""
-        eng = model_engine
-        ent = self._graphs.get(key)
-        if ent is None:
-            if len(self._graphs) >= 32:
-                return None
-            self._graphs[key] = 'warm'
-            return None
-        if isinstance(ent, dict) and ent['epoch'] != eng.scratch_epoch:
-            ent = 'warm'            # the engine's pool evicted / re-allocated buffers since the capture: the graph holds dead addresses
-        if ent == 'warm':
-            try:
-                x_tr, x_va = torch.empty_like(tx), torch.empty_like(vx)
-                x_tr.copy_(tx)
-                x_va.copy_(vx)
-                stream.synchronize()
-                g = torch.cuda.CUDAGraph()
-                epoch = eng.scratch_epoch
-                with torch.cuda.graph(g, stream=stream):
-                    body(x_tr, x_va)
-                if eng.scratch_epoch != epoch:      # a buffer moved during the capture: drop it, run eagerly now, capture again next time
-                    self._graphs[key] = 'warm'
-                    return None
-                ent = dict(g=g, x_tr=x_tr, x_va=x_va, epoch=epoch)
-            except Exception as exc:                                      # capture unsupported -> stay eager, loudly
-                logging.warning('hipGraph capture failed (%s); task body stays eager', exc)
-                print('WARNING: hipGraph capture failed, running eagerly:', exc, flush=True)
-                torch.cuda.synchronize()
-                ent = 'eager'
-            self._graphs[key] = ent
-        return ent if isinstance(ent, dict) else None
 
     def _lane_buffers(self, model, n_lanes):
         """(grad, theta', G) per lane; lane 0 uses the model's own flat_grad / copy_grad buffers when it is the only lane."""
@@ -1081,7 +882,7 @@ class TransientTrainer():
         my_tasks = mdist.shard_tasks(n_tasks, rank, world)
 
         takes_need = [_sample_takes_need(ds) for ds in train_data_list]      # decided ONCE from the signature (never by catching)
-        pin_batches = bool(getattr(args, 'cuda', True)) and torch.cuda.is_available() and os.environ.get('MTL_PIN_BATCHES', '1') != '0'
+        pin_batches = bool(getattr(args, 'cuda', True)) and torch.cuda.is_available() and self.pin_batches
 
         def fetch_train_batch(buf):
             # every rank DRAWS every task (the index streams stay in lock-step), but only what this rank uses is loaded and
@@ -1106,7 +907,7 @@ class TransientTrainer():
         prefetch.start()
         dev = model.flat_parameters.device
         sync_replicas_from_rank0(model, [outer_opt])
-        check_every = int(os.environ.get('MTL_REPLICA_CHECK_EVERY', '100'))
+        check_every = int(self.replica_check_every)
         it = start_it
         failures = 0
         pending = deque()                                 # enqueued, not yet resolved: (it, step), oldest first

@@ -67,27 +67,26 @@ def test_every_class_is_priced_on_the_roof_of_its_instructions():
     # entry points on the bf16-triple instructions (six v_mfma_*_bf16 per fp32-equivalent step): the x3 GEMM engine and attention
     for cls in ('gemm_x3', 'attn_fwd', 'attn_bwd'):
         for conv_mode in ('h2', 'x3', 'f32'):
-            assert bench.peak_of(cls, 'flop', conv_mode, True)[0] == x3, cls
-    assert bench.peak_of('gemm_h2', 'flop', 'h2', True)[0] == h2
+            assert bench.peak_of(cls, 'flop', conv_mode)[0] == x3, cls
+    assert bench.peak_of('gemm_h2', 'flop', 'h2')[0] == h2
     for cls in ('conv2_fwd_pool', 'conv5_fwd', 'conv7_dgrad', 'conv2_wgrad'):
-        assert bench.peak_of(cls, 'flop', 'h2', True)[0] == h2
-        assert bench.peak_of(cls, 'flop', 'x3', True)[0] == x3
-        assert bench.peak_of(cls, 'flop', 'f32', True)[0] == f32
-    assert bench.peak_of('conv5_wgrad', 'flop', 'h2', False)[0] == f32      # its dense form off: the fp32-MFMA weight gradient
-    for cls in ('gemm_small', 'gemm_big', 'gemm_wgrad_grouped', 'lstm_stack_fwd'):
-        assert bench.peak_of(cls, 'flop', 'h2', True)[0] == f32
+        assert bench.peak_of(cls, 'flop', 'h2')[0] == h2
+        assert bench.peak_of(cls, 'flop', 'x3')[0] == x3
+        assert bench.peak_of(cls, 'flop', 'f32')[0] == f32
+    for cls in ('gemm_small', 'gemm_big', 'lstm_stack_fwd'):
+        assert bench.peak_of(cls, 'flop', 'h2')[0] == f32
     for cls in ('layernorm_fwd', 'ce_fwd', 'colsum', 'adam_step', 'conv0_fwd'):
-        assert bench.peak_of(cls, 'byte', 'h2', True) == (bench.PEAK_HBM_GBS, 'GB/s', 'hbm')
+        assert bench.peak_of(cls, 'byte', 'h2') == (bench.PEAK_HBM_GBS, 'GB/s', 'hbm')
     # the classifier hands attention launches to those classes with the x3 kernel symbols
     a = [0] * 22
     a[8], a[10], a[11], a[12], a[13], a[14] = 0, 64, 8, 250, 250, 64
-    cls, flops, unit, sym = bench.classify(None, 'mtl_attn_fwd', a, 'h2', True)
+    cls, flops, unit, sym = bench.classify(None, 'mtl_attn_fwd', a, 'h2')
     assert cls == 'attn_fwd' and unit == 'flop' and flops == 2 * 2.0 * 64 * 8 * 250 * 250 * 64
     # the task-batched convolution launches are counted as the tasks x B samples they process
     one = (0, 1, 2, 3, 4, 5, 6, 7, 8, 500, 80, 128, 128)                       # relu_pool_fwd_h2: ..., B, T, F, Cin, Cout
     tb = one[:8] + (8, 500, 80, 128, 128, 8, 1024, 128, 2048, 2048, None, 0)    # ..._tb: ..., B, T, F, Cin, Cout, tasks, strides, widths, wshift
-    c1 = bench.classify(None, 'mtl_conv3x3_relu_pool_fwd_h2', one, 'h2', True)
-    c8 = bench.classify(None, 'mtl_conv3x3_relu_pool_fwd_h2_tb', tb, 'h2', True)
+    c1 = bench.classify(None, 'mtl_conv3x3_relu_pool_fwd_h2', one, 'h2')
+    c8 = bench.classify(None, 'mtl_conv3x3_relu_pool_fwd_h2_tb', tb, 'h2')
     assert c1[0] == c8[0] == 'conv7_fwd_pool' and c8[1] == 8 * c1[1] and c8[3] == c1[3]
     d1 = (0, 1, 2, 3, 4, 5, 6, 7, 8, 500, 80, 64, 128)
     d8 = d1[:8] + (8, 500, 80, 64, 128, 8, 4096, 2048, 2048, None, 0)
@@ -99,8 +98,8 @@ def test_every_class_is_priced_on_the_roof_of_its_instructions():
         assert len(mtl_amd._lib.SIGNATURES[nm][1]) == len(args_), nm
     import pytest
     with pytest.raises(RuntimeError):
-        bench.classify(None, 'mtl_conv3x3_dgrad_h2_tb', d8[:-2], 'h2', True)
-    assert bench.classify(None, 'mtl_conv3x3_dgrad_h2_tb', d8, 'h2', True)[1] == 8 * bench.classify(None, 'mtl_conv3x3_dgrad_h2', d1, 'h2', True)[1]
+        bench.classify(None, 'mtl_conv3x3_dgrad_h2_tb', d8[:-2], 'h2')
+    assert bench.classify(None, 'mtl_conv3x3_dgrad_h2_tb', d8, 'h2')[1] == 8 * bench.classify(None, 'mtl_conv3x3_dgrad_h2', d1, 'h2')[1]
     assert bench.algorithmic_bytes('mtl_conv3x3_dgrad_h2_tb', d8, 'flop', 1.0) == 8 * bench.algorithmic_bytes('mtl_conv3x3_dgrad_h2', d1, 'flop', 1.0)
 
 

@@ -403,17 +403,17 @@ def test_schedule_choice_for_batches_of_different_widths():
     assert tr._widths_vary(fixed)                                                    # ... and it stays on
     tr.pad_lanes = '0'
     assert not tr._widths_vary([('lane', 0, 7)])
-    eng = types.SimpleNamespace(fused_attn=True, group_wgrads=False, after_conv_hook=None)
+    eng = types.SimpleNamespace(fused_attn=True)
     model = types.SimpleNamespace(engines=[eng])
     batch = lambda k, T: (torch.zeros(k, 1, 161, T),)
     tr = mtl_amd.TransientTrainer()
     val = batch(2, 50)
-    assert tr._can_batch(model, [batch(2, 64), batch(2, 64)], val, False)
-    assert tr._can_batch(model, [batch(2, 64), batch(2, 40)], val, False)            # fill 0.81
-    assert tr._can_batch(model, [batch(2, 64), batch(2, 8), batch(2, 8)], val, False)           # fill 80 / 192 = 0.42
-    assert not tr._can_batch(model, [batch(2, 64), batch(2, 4), batch(2, 4), batch(2, 4)], val, False)      # fill 76 / 256 = 0.30: lanes
-    assert not tr._can_batch(model, [batch(2, 64), batch(3, 64)], val, False)        # different sample counts
-    assert not tr._can_batch(model, [batch(2, 64), batch(2, 3)], val, False)         # a batch too short for two poolings
-    assert not tr._can_batch(model, [batch(2, 64)], val, False)                      # one task: a lane
+    assert tr._can_batch(model, [batch(2, 64), batch(2, 64)], val)
+    assert tr._can_batch(model, [batch(2, 64), batch(2, 40)], val)            # fill 0.81
+    assert tr._can_batch(model, [batch(2, 64), batch(2, 8), batch(2, 8)], val)           # fill 80 / 192 = 0.42
+    assert not tr._can_batch(model, [batch(2, 64), batch(2, 4), batch(2, 4), batch(2, 4)], val)      # fill 76 / 256 = 0.30: lanes
+    assert not tr._can_batch(model, [batch(2, 64), batch(3, 64)], val)        # different sample counts
+    assert not tr._can_batch(model, [batch(2, 64), batch(2, 3)], val)         # a batch too short for two poolings
+    assert not tr._can_batch(model, [batch(2, 64)], val)                      # one task: a lane
     tr.batch_ragged = False
-    assert tr._can_batch(model, [batch(2, 64), batch(2, 64)], val, False) and not tr._can_batch(model, [batch(2, 64), batch(2, 40)], val, False)
+    assert tr._can_batch(model, [batch(2, 64), batch(2, 64)], val) and not tr._can_batch(model, [batch(2, 64), batch(2, 40)], val)

@@ -174,39 +174,6 @@ def test_gemm_k_batching_and_row_sums(L):
                              1, 1, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, Wview, 0, None, 0, 0, 0) == -22      # row sums need transA
 
 
-def test_grouped_weight_gradients(L):
-    """mtl_gemm_wgrad_grouped: ONE launch for a table of independent dW_i += dy_i^T x_i (+ db_i += colsum(dy_i)) products of
-    different shapes -- every small weight gradient of a backward pass -- against torch, bitwise repeatable"""
-    import mtl_amd
-    g = torch.Generator().manual_seed(31)
-    shapes = [(808, 512, 100, True), (808, 100, 512, False), (2000, 512, 100, True), (2000, 100, 512, False), (808, 512, 512, True),
-              (37, 36, 8, True), (2000, 128, 100, False)]             # (tile tails in M, N and K; operands stay 16-byte aligned)
-    dys = [torch.randn(r, m, generator=g) for r, m, n, b in shapes]
-    xs = [torch.randn(r, n, generator=g) for r, m, n, b in shapes]
-    W0 = [torch.randn(m, n, generator=g) for r, m, n, b in shapes]
-    b0 = [torch.randn(m, generator=g) for r, m, n, b in shapes]
-    ddy, dx = [dev(t) for t in dys], [dev(t) for t in xs]
-    outs = []
-    for _ in range(2):
-        dW, db = [dev(t.clone()) for t in W0], [dev(t.clone()) for t in b0]
-        table = (mtl_amd._lib.WgradDesc * len(shapes))()
-        tiles = 0
-        for i, (r, m, n, hasb) in enumerate(shapes):
-            d = table[i]
-            d.A, d.B, d.C, d.rowsum = ddy[i].data_ptr(), dx[i].data_ptr(), dW[i].data_ptr(), db[i].data_ptr() if hasb else None
-            d.M, d.N, d.K, d.lda, d.ldb, d.ldc, d.tile0 = m, n, r, m, n, n, tiles
-            tiles += ((m + 31) // 32) * ((n + 31) // 32)
-        tdev = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8).cuda()
-        assert L.mtl_gemm_wgrad_grouped(st(), tdev.data_ptr(), len(shapes), tiles) == 0
-        outs.append(([t.cpu() for t in dW], [t.cpu() for t in db]))
-    for i, (r, m, n, hasb) in enumerate(shapes):
-        assert rel(outs[0][0][i], W0[i].double() + dys[i].double().t() @ xs[i].double()) < 2e-6, i
-        ref_b = b0[i].double() + (dys[i].double().sum(0) if hasb else 0)
-        assert rel(outs[0][1][i], ref_b) < 3e-6, i
-        assert torch.equal(outs[0][0][i], outs[1][0][i]) and torch.equal(outs[0][1][i], outs[1][1][i])
-    assert L.mtl_gemm_wgrad_grouped(st(), None, 1, 1) == -22
-
-
 def test_gemm_gate_and_batched_heads(L):
     g = torch.Generator().manual_seed(5)
     Bn, H, Tq, Tk, dk = 3, 8, 101, 250, 16

@@ -634,33 +634,6 @@ def test_dropout_pass_matches_oracle_with_the_same_masks():
     assert float((out_e['pred'].cpu() - pr0).norm() / pr0.norm()) < 1e-5
 
 
-def test_hipgraph_replay_is_bitwise_equal_to_eager():
-    """The per-task body captured into a hipGraph (trainer._graph_for, opt-in via MTL_GRAPHS=1) must reproduce the eager
-    meta-gradient bit for bit, also for a batch it was not captured on."""
-    z, cfg, spec = gu.load('F0')
-    mtl_amd, args, vocab, model = make(cfg, spec)
-    model = model.cuda()
-    as5 = lambda b: (b[0].cuda(), b[1], None, b[2], None)
-    mk = lambda s0: [as5(mtl_amd.synth_batch(s0 + i, 2, 64, 8, cfg['vocab_size'])) for i in range(6)]
-    val = as5(mtl_amd.synth_batch(77, 2, 64, 8, cfg['vocab_size']))
-    inner = mtl_amd.FlatSGD(model, spec['lr'])
-    model.zero_copy_grad()
-    res = {}
-    for mode in (False, True):
-        tr = mtl_amd.TransientTrainer()
-        tr.batch_tasks = False                     # (hipGraph capture is a feature of the per-task lanes)
-        tr.use_graphs = mode
-        outs = []
-        for s0 in (100, 200):                      # second batch set runs purely on replays when graphs are on
-            tr.meta_iteration(model, vocab, mk(s0), val, 6, inner, None, args)
-            torch.cuda.synchronize()
-            outs.append(model._G.clone())
-        res[mode] = outs
-        if mode:
-            assert any(isinstance(v, dict) for v in tr._graphs.values()), 'no graph was captured'
-    assert torch.equal(res[False][0], res[True][0]) and torch.equal(res[False][1], res[True][1])
-
-
 @pytest.mark.parametrize('dropout', [0.0, 0.1])
 def test_command_list_replay_is_bitwise_equal_to_eager(dropout):
     """The per-task body recorded into a command list and replayed by mtl_cmdlist_run (trainer._run_recorded, default on) must
@@ -695,60 +668,6 @@ def test_command_list_replay_is_bitwise_equal_to_eager(dropout):
         assert torch.equal(G0, G1)
         for (l0, h0), (l1, h1) in zip(r0, r1):
             assert torch.equal(l0, l1) and torch.equal(h0, h1)
-
-
-@pytest.mark.parametrize('B,variable', [(4, False), (5, True)])
-def test_single_task_split_over_lanes_equals_unsplit(B, variable):
-    """a rank that holds ONE task splits each pass by samples over the two lanes (trainer._single_task_split: what 8 tasks on 8
-    GPUs runs): same losses, labels and meta-gradient as the unsplit step up to fp32 summation order; bitwise repeatable;
-    with gradient clipping on (the clip acts on the joined gradient)"""
-    z, cfg, spec = gu.load('F0')
-    mtl_amd, args, vocab, model = make(cfg, spec)
-    args.clip, args.max_norm = True, 0.5
-    model = model.cuda()
-    as5 = lambda b: (b[0].cuda(), b[1], None, b[2], None)
-    task = [as5(mtl_amd.synth_batch(31, B, 64, 8, cfg['vocab_size'], variable=variable))]
-    val = as5(mtl_amd.synth_batch(32, B, 64, 8, cfg['vocab_size'], variable=variable))
-    inner = mtl_amd.FlatSGD(model, spec['lr'])
-    model.zero_copy_grad()
-    res = {}
-    for split in (False, True, True):
-        tr = mtl_amd.TransientTrainer()
-        tr.split_single_task = split
-        tr.use_cmdlists = False
-        reads = tr.meta_iteration(model, vocab, task, val, 3, inner, None, args)
-        torch.cuda.synchronize()
-        res.setdefault(split, []).append((model._G.clone(), [(torch.as_tensor(r.loss).clone(), r.hyp.clone(), r.gold_host.clone()) for r in reads[0]]))
-    (G0, r0), (G1, r1), (G2, r2) = res[False][0], res[True][0], res[True][1]
-    assert torch.equal(G1, G2)                                       # deterministic
-    for (l0, h0, g0), (l1, h1, g1) in zip(r0, r1):
-        assert torch.equal(g0, g1) and torch.equal(h0, h1)          # labels: bit-exact, in batch order
-        assert abs(float(l0) - float(l1)) <= 2e-6 * abs(float(l0))
-    rel = float((G1 - G0).norm() / G0.norm())
-    print('split vs unsplit: global rel %.2e' % rel)
-    assert rel < 1e-4
-    # the recorded form (what runs by default: ONE command list holds the calls of all lanes, with their streams and the cross-lane
-    # events): eager, recording and two replays reproduce the eager split step bit for bit
-    tr = mtl_amd.TransientTrainer()
-    tr.split_single_task, tr.use_cmdlists = True, True
-    for rep in range(4):
-        reads = tr.meta_iteration(model, vocab, task, val, 3, inner, None, args)
-        torch.cuda.synchronize()
-        assert torch.equal(model._G, G1), rep
-        for r, (l1, h1, g1) in zip(reads[0], r1):
-            assert torch.equal(r.hyp, h1) and float(r.loss[0]) == float(l1)
-    recorded = [v for v in tr._cmdlists.values() if isinstance(v, dict)]
-    assert len(recorded) == 1 and recorded[0]['cl'].n > 200
-    if B >= 4:                                                       # four lanes: same contract
-        tr4 = mtl_amd.TransientTrainer()
-        tr4.split_single_task, tr4.split_lanes = True, 4
-        outs = []
-        for rep in range(3):
-            tr4.meta_iteration(model, vocab, task, val, 3, inner, None, args)
-            torch.cuda.synchronize()
-            outs.append(model._G.clone())
-        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
-        assert float((outs[0] - G0).norm() / G0.norm()) < 1e-4
 
 
 @pytest.mark.parametrize('B,T,L,lens,tlens', [
