@@ -220,7 +220,7 @@ def classify(lib, name, a, conv_mode):
         kind = 'wgrad' if 'wgrad' in name else ('dgrad' if 'dgrad' in name else ('fwd_pool' if 'pool' in name else 'fwd'))
         if name.endswith('_x3') or name.endswith('_h2'):
             sym = ('conv3x3_wgrad_x3_kernel<.,%d>' if kind == 'wgrad' else 'conv3x3_x3h_kernel<...,%d>') % (2 if name.endswith('_h2') else 3)
-            if kind == 'wgrad' and name.endswith('_h2') and a[5] and os.environ.get('MTL_WGRAD_SPARSE', '1') != '0':
+            if kind == 'wgrad' and name.endswith('_h2') and a[5]:
                 sym = 'conv3x3_wgrad_sp_kernel (pooled layer: 2:4-sparse v_smfmac_f32_32x32x32_f16)'      # the arg-max map is given
         else:
             sym = 'conv3x3_wgrad_kernel' if kind == 'wgrad' else 'conv3x3_kernel'
@@ -549,6 +549,90 @@ def cpu_baseline(n_tasks, k, T, L, threads, timed_tasks):
                        'every task has the same shapes, scaled x%d/%d' % (timed_tasks, n_tasks, ', '.join('%.2f' % t for t in times),
                                                                           t_outer, n_tasks, timed_tasks),
                 seconds_per_task=t_task)
+
+
+def eval_leg(mtl, trainer, model, vocab, args, k, frames, labels, dev, reps=3, decode_steps=300):
+    """SURVEY 8(f) f2, measured: (a) what the in-loop validation runs per batch (transient_trainer.py:280-331: eval mode, no autograd,
+    `forward_one_batch` = teacher-forced pass + loss + CER strings) and (b) test-time greedy decoding (Transformer.evaluate ->
+    Decoder.greedy_search, modules/decoder.py:131-185: the reference's 300 fixed steps, here K/V-cached with the token fed back
+    through device memory) at the north-star model, batch = k_valid utterances of `frames` frames resident in HBM.
+    The decode steps are GEMV-shaped (8 rows): every step streams the decoder's weights once, so the step is priced against HBM."""
+    V = CFG['vocab_size']
+    x, lens, y = mtl.synth_batch(99001, k, frames, labels, V)
+    x = x.to(dev)
+    pct = lens.float() / frames
+    tl = (y != 0).sum(1).to(torch.int32)
+    model.eval()
+    out = {}
+    try:
+        with torch.no_grad():
+            for _ in range(2):
+                trainer.forward_one_batch(model, vocab, x, y.to(dev), pct.clone(), lens, tl, 0.0, 'ce')
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            n = 10
+            for _ in range(n):
+                loss, cer, nchar = trainer.forward_one_batch(model, vocab, x, y.to(dev), pct.clone(), lens, tl, 0.0, 'ce')
+                float(loss.item())
+            torch.cuda.synchronize(dev)
+            dt = (time.perf_counter() - t0) / n
+        out['valid_loop'] = dict(utt_per_s=k / dt, ms_per_batch=dt * 1e3, batch=k,
+                                 note='forward_one_batch in eval mode (teacher-forced pass + loss + host CER strings), the body of the '
+                                      'in-loop validation, transient_trainer.py:280-331')
+        model.evaluate(x, lens, y, args, start_token=vocab.SOS_ID, max_steps=8)                    # buffers
+        torch.cuda.synchronize(dev)
+        times = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            model.evaluate(x, lens, y, args, start_token=vocab.SOS_ID, max_steps=decode_steps)
+            torch.cuda.synchronize(dev)
+            times.append(time.perf_counter() - t0)
+        dt = min(times)
+        # one profiled decode: HIP events around every launch of the decode session (the encoder pass before it is not the subject)
+        eng = model.engine
+        prof = LaunchProfiler(mtl._lib.lib(), dev)
+        real_greedy = eng.greedy_decode
+
+        def profiled(*a_, **kw_):
+            lib_, eng.lib, eng.prof = eng.lib, prof, prof
+            try:
+                return real_greedy(*a_, **kw_)
+            finally:
+                eng.lib, eng.prof = lib_, None
+        eng.greedy_decode = profiled
+        try:
+            psteps = 32
+            model.evaluate(x, lens, y, args, start_token=vocab.SOS_ID, max_steps=psteps)
+            torch.cuda.synchronize(dev)
+        finally:
+            del eng.greedy_decode
+        classes = {}
+        for name, a_, e0, e1 in prof.records:
+            cls, work, unit, sym = classify(mtl._lib.lib(), name, a_, eng.conv_mode)
+            c = classes.setdefault(cls, dict(time=0.0, launches=0, symbols=sym))
+            c['time'] += e0.elapsed_time(e1) * 1e-3
+            c['launches'] += 1
+        kt = sum(c['time'] for c in classes.values())
+        dom = max(classes, key=lambda c_: classes[c_]['time'])
+        lay = model._layout
+        dec_bytes = 4 * sum(lay.entries[nm][2] for nm in lay.order if nm.startswith('decoder.'))
+        step_ms = dt / decode_steps * 1e3
+        out['greedy_decode'] = dict(utt_per_s=k / dt, ms_per_decode=dt * 1e3, ms_per_step=step_ms, steps=decode_steps, batch=k,
+                                    launches_per_step=len(prof.records) / psteps, kernel_ms_per_step=kt / psteps * 1e3,
+                                    dominant=dict(kernel=classes[dom]['symbols'], cls=dom, share=classes[dom]['time'] / kt,
+                                                  us_per_launch=classes[dom]['time'] / classes[dom]['launches'] * 1e6),
+                                    per_class={c_: dict(ms_per_step=v['time'] / psteps * 1e3, launches_per_step=v['launches'] / psteps)
+                                               for c_, v in sorted(classes.items(), key=lambda kv: -kv[1]['time'])},
+                                    roofline=dict(bound='hbm', achieved=dec_bytes / (step_ms * 1e-3) / 1e9, peak=PEAK_HBM_GBS, unit='GB/s',
+                                                  frac=dec_bytes / (step_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                                                  algorithmic_bytes_per_step=dec_bytes,
+                                                  note='a step multiplies %d hypothesis rows with every decoder weight once: the decoder '
+                                                       'parameters (%.1f MB) are the algorithmic traffic of a step' % (k, dec_bytes / 1e6)),
+                                    note='Transformer.evaluate greedy: encoder pass + %d K/V-cached decoder steps, token feedback on the '
+                                         'device, one read-back (models/asr/transformer.py:162-202, modules/decoder.py:131-185)' % decode_steps)
+    finally:
+        model.train()
+    return out
 
 
 LM_CFG = dict(ntoken=10000, ninp=512, nhid=512, nlayers=2, bptt=35, batch_size=20, dropout=0.2, lr=1.0, meta_lr_factor=3.0, clip=0.25,
@@ -976,6 +1060,11 @@ def main():
                                        note='1 of %d tasks on this GPU (configs[2] per-rank work, without the all-reduce): the two '
                                             'passes as one chain + side stream, one recorded command list' % a.tasks)
         del tr1
+        # f2: the validation loop's forward and test-time greedy decoding at this model (after the training legs: own buffers)
+        try:
+            out['eval'] = eval_leg(mtl_amd, trainer, model, vocab, args, a.k, a.frames, a.labels, dev)
+        except Exception as e:                           # a side leg must never cost the bench line
+            out['eval'] = dict(error=repr(e))
         # the README trains with --dropout 0.1: same 8-task workload with the Philox dropout active
         model.encoder.dropout_rate = model.decoder.dropout_rate = 0.1
         model.train()
@@ -1067,6 +1156,10 @@ def compact_line(out):
             line[k] = _r(out[k]['value'], 3)
     if 'one_task_per_gpu' in out:
         line['one_task_per_gpu_ms'] = _r(out['one_task_per_gpu']['ms_per_step'], 3)
+    ev = out.get('eval') or {}
+    if 'greedy_decode' in ev:
+        line['eval_utt_per_s'] = _r(ev['greedy_decode']['utt_per_s'], 2)
+        line['valid_loop_utt_per_s'] = _r(ev['valid_loop']['utt_per_s'], 1)
     for k in ('multi_gpu', 'last_step', 'theta_checksum', 'detail'):
         if k in out:
             line[k] = out[k]

@@ -275,7 +275,7 @@ class PassEngine:
         self.gemm_ws = torch.empty(8 << 20, dtype=torch.float32, device=device) if device.type == 'cuda' else None  # split-K slabs
         # weight/bias-gradient kernels are off the critical path (nothing downstream in the backward reads them): they run
         # on a second HIP stream with their own workspaces, forked once per block and joined at the end of the backward
-        self.side = torch.cuda.Stream(device) if device.type == 'cuda' else None
+        self.side = torch.cuda.Stream(device, priority=int(os.environ.get('MTL_EXP_SIDE_PRIO', '0'))) if device.type == 'cuda' else None
         self.gemm_ws_side = torch.empty(8 << 20, dtype=torch.float32, device=device) if device.type == 'cuda' else None
         self.scratch_side = torch.empty(4 << 20, dtype=torch.float32, device=device) if device.type == 'cuda' else None
         self.on_side = False

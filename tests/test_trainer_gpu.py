@@ -258,6 +258,22 @@ def test_long_utterance_config_against_live_oracle(B, lens):
                  max_flips=120)
 
 
+def test_long_utterance_full_batch_against_live_oracle():
+    """BASELINE.json configs[3] at its FULL batch: the training batch of the T5 record (8 utterances, up to 5000 frames, variable lengths:
+    raw-length masks on the 1250-wide pooled axis, zero tails) against the live oracle -- labels bit-exact, loss, and with the device's
+    ReLU / max-pool decisions replayed EVERY gradient tensor within 1e-4 (measured: 62 near-ties decided differently, margin 1.9e-6,
+    worst tensor 2.5e-5).  The oracle pass takes ~40 s of CPU time and ~10 GB of host memory."""
+    from oracle import refimpl as R
+    z, cfg, spec = gu.load('T5')
+    mtl_amd, args, vocab, model = make(cfg, spec)
+    model = model.cuda()
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    oracle = R.build_model(cfg)
+    tr, _val = gu.batches_for(cfg, spec, 0, z['data_call_index'])
+    assert tuple(tr[0][0].shape) == (8, 1, 161, 5000) and int(tr[0][1].min()) < 1250
+    _pass_parity(model, oracle, tr[0], model.flat_parameters, 'T=5000 B=8', max_flips=400)
+
+
 def test_rccl_collective_path_executes():
     """The `nccl` (= RCCL) branch of dist.init_from_env and the flat-G all-reduce on this box's GPU: one rank under torchrun with
     MTL_DIST_ALWAYS=1 (the collective is issued even at world size 1).  Multi-rank arithmetic is covered by the gloo tests; this
