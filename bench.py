@@ -182,7 +182,8 @@ def single_task_form(name, a):
     point over tasks x B samples: same leading arguments, (B, T, F, Cin, Cout) last."""
     # (argument counts as in include/mtl_hip.h: a prototype that grows must fail HERE, not shift the dimensions silently -- round 5's
     # `widths, wshift` once turned the convolutions into zero-work launches and the roofline object into the GEMM family)
-    arity = {'mtl_conv3x3_relu_fwd_h2_tb': 19, 'mtl_conv3x3_relu_pool_fwd_h2_tb': 20, 'mtl_conv3x3_dgrad_h2_tb': 19, 'mtl_conv3x3_wgrad_h2_tb': 20}
+    arity = {'mtl_conv3x3_relu_fwd_h2_tb': 19, 'mtl_conv3x3_relu_pool_fwd_h2_tb': 20, 'mtl_conv3x3_dgrad_h2_tb': 19, 'mtl_conv3x3_wgrad_h2_tb': 20,
+             'mtl_conv3x3_relu_fwd_x3_tb': 15, 'mtl_conv3x3_relu_pool_fwd_x3_tb': 16, 'mtl_conv3x3_dgrad_x3_tb': 15, 'mtl_conv3x3_wgrad_x3_tb': 16}
     if name in arity and len(a) != arity[name]:
         raise RuntimeError('%s called with %d arguments, classify() expects %d' % (name, len(a), arity[name]))
     if name in ('mtl_conv3x3_relu_fwd_h2_tb', 'mtl_conv3x3_relu_pool_fwd_h2_tb'):
@@ -194,6 +195,15 @@ def single_task_form(name, a):
     if name == 'mtl_conv3x3_wgrad_h2_tb':
         B, T, F, cin, cout, tasks = a[-10:-4]
         return name[:-3], tuple(a[:-10]) + (B * tasks, T, F, cin, cout)
+    if name in ('mtl_conv3x3_relu_fwd_x3_tb', 'mtl_conv3x3_relu_pool_fwd_x3_tb'):      # (..., B, T, F, Cin, Cout, tasks, sW, sBias, widths, wshift)
+        B, T, F, cin, cout, tasks = a[-10:-4]
+        return name[:-3], tuple(a[:-10]) + (B * tasks, T, F, cin, cout)
+    if name == 'mtl_conv3x3_dgrad_x3_tb':                                               # (..., B, T, F, Cin, Cout, tasks, sW, widths, wshift)
+        B, T, F, cin, cout, tasks = a[-9:-3]
+        return name[:-3], tuple(a[:-9]) + (B * tasks, T, F, cin, cout)
+    if name == 'mtl_conv3x3_wgrad_x3_tb':                                               # (stream, x, dy, argmax, dw, db, ws, bytes, B, ..., tasks, sDw, sDb)
+        B, T, F, cin, cout, tasks = a[-8:-2]
+        return name[:-3], tuple(a[:4]) + (a[4],) + tuple(a[6:8]) + (B * tasks, T, F, cin, cout)
     return name, a
 
 
@@ -549,6 +559,16 @@ def cpu_baseline(n_tasks, k, T, L, threads, timed_tasks):
                        'every task has the same shapes, scaled x%d/%d' % (timed_tasks, n_tasks, ', '.join('%.2f' % t for t in times),
                                                                           t_outer, n_tasks, timed_tasks),
                 seconds_per_task=t_task)
+
+
+def h2_frac(trainer):
+    """the trainer's latest census of the h2 operands (TransientTrainer.h2_check_every: sampled on the first iteration and every 100th):
+    the largest share, over the operands, of non-zero elements that keep fewer than 22 / fewer than 16 significand bits"""
+    cen = getattr(trainer, 'h2_census', None)
+    if not cen:
+        return None
+    return dict(lt22_bits=max(v[0] for v in cen.values()), lt16_bits=max(v[1] for v in cen.values()),
+                worst_operand=max(cen, key=lambda k_: cen[k_][0]), limit_lt16=trainer.h2_limit, sampled_every=trainer.h2_check_every)
 
 
 def eval_leg(mtl, trainer, model, vocab, args, k, frames, labels, dev, reps=3, decode_steps=300):
@@ -1022,7 +1042,7 @@ def main():
                                                 'x3': '3x3 convolutions as exact 3-way bf16 splits of fp32 operands, fp32 accumulate '
                                                       '(fp32-class error, same test tolerances as the fp32-MFMA kernels)',
                                                 'f32': 'fp32 MFMA'}[model.engine.conv_mode]),
-                   roofline=roofline, host_enqueue_ms=host_stats, host=dict(HOST), multi_gpu=multi, last_step=dict(val_loss=last[0] / a.tasks, cer_edits=last[1], chars=last[2]), theta_checksum=theta_ck)
+                   h2_subnormal_frac=h2_frac(trainer), roofline=roofline, host_enqueue_ms=host_stats, host=dict(HOST), multi_gpu=multi, last_step=dict(val_loss=last[0] / a.tasks, cer_edits=last[1], chars=last[2]), theta_checksum=theta_ck)
 
     extras = world == 1 and not a.no_extras
     if extras:
@@ -1060,6 +1080,15 @@ def main():
                                        note='1 of %d tasks on this GPU (configs[2] per-rank work, without the all-reduce): the two '
                                             'passes as one chain + side stream, one recorded command list' % a.tasks)
         del tr1
+        # what the h2 guard costs: the same steps with the census taken on EVERY iteration (it is taken on one in `h2_check_every`)
+        trc = mtl_amd.TransientTrainer()
+        trc.h2_check_every = 1
+        dtc, _ = timed_steps(trc, model, vocab, tasks, my_tasks, a.tasks, inner, outer, args, k3, 4, mdist, dev)
+        if out.get('h2_subnormal_frac'):
+            extra = dtc / k3 * 1e3 - ms
+            out['h2_subnormal_frac'].update(census_step_extra_ms=extra, amortised_cost=max(extra, 0.0) / ms / max(trainer.h2_check_every, 1),
+                                            per_operand={k_: dict(lt22_bits=v[0], lt16_bits=v[1]) for k_, v in (trc.h2_census or {}).items()})
+        del trc
         # f2: the validation loop's forward and test-time greedy decoding at this model (after the training legs: own buffers)
         try:
             out['eval'] = eval_leg(mtl_amd, trainer, model, vocab, args, a.k, a.frames, a.labels, dev)
@@ -1147,6 +1176,10 @@ def compact_line(out):
     cb = out.get('cpu_baseline')
     if cb:
         line['cpu_baseline'] = {k: _r(cb[k]) for k in ('value', 'unit', 'cores', 'kind', 'sample', 'seconds_per_task') if k in cb}
+    hf = out.get('h2_subnormal_frac')
+    if hf:
+        line['h2_subnormal_frac'] = {k: (float('%.3g' % hf[k]) if isinstance(hf[k], float) else hf[k])
+                                     for k in ('lt22_bits', 'lt16_bits', 'amortised_cost') if k in hf}
     if 'host_enqueue_ms' in out:
         line['host_enqueue_ms'] = out['host_enqueue_ms']
     if 'host' in out:

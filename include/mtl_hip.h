@@ -204,10 +204,29 @@ int mtl_conv3x3_dgrad_h2_tb(void* stream, const float* dy, const float* amax_dy,
 int mtl_conv3x3_wgrad_h2_tb(void* stream, const float* x, const float* amax_x, const float* dy, const float* amax_dy,
                             const unsigned char* argmax, float* dw_ref, float* db, float* workspace, long workspace_bytes, int B, int T,
                             int F, int Cin, int Cout, int tasks, long sAmaxX, long sAmaxDy, long sDw, long sDb);
+/* The same four several-task launches on the EXACT 3 x bf16 split (MTL_CONV=x3: every fp32 operand bit kept, models/asr/transformer.py:48-59
+ * is fp32): no bounds; w3 + k * sW bytes, bias + k * sBias floats, dw_ref + k sDw / db + k sDb floats as above (db nullable: the bias
+ * gradient = per-channel sums of dy rides on the weight-gradient launch). */
+int mtl_conv3x3_relu_fwd_x3_tb(void* stream, const float* x, const void* w3_fwd, const float* bias, float* y, int B, int T, int F, int Cin,
+                               int Cout, int tasks, long sW, long sBias, const int* widths, int wshift);
+int mtl_conv3x3_relu_pool_fwd_x3_tb(void* stream, const float* x, const void* w3_fwd, const float* bias, float* p_out, unsigned char* argmax,
+                                    int B, int T, int F, int Cin, int Cout, int tasks, long sW, long sBias, const int* widths, int wshift);
+int mtl_conv3x3_dgrad_x3_tb(void* stream, const float* dy, const unsigned char* argmax, const void* w3_dgrad, const float* act, float* dx,
+                            int B, int T, int F, int Cin, int Cout, int tasks, long sW, const int* widths, int wshift);
+int mtl_conv3x3_wgrad_x3_tb(void* stream, const float* x, const float* dy, const unsigned char* argmax, float* dw_ref, float* db,
+                            float* workspace, long workspace_bytes, int B, int T, int F, int Cin, int Cout, int tasks, long sDw, long sDb);
 /* amax[MTL_AMAX_FLOATS]: slot heads raised so that their maximum is >= max|x[0..n)| (atomic; zero them first) */
 int mtl_absmax_f32(void* stream, const float* x, long n, float* amax);
 /* the same for `tasks` tensors of n floats at x + k sX, bound k at amax + k sAmax floats, one launch */
 int mtl_absmax_f32_tb(void* stream, const float* x, long n, float* amax, int tasks, long sX, long sAmax);
+/* Census of an h2 operand against its bound -- the runtime guard of the two-piece fp16 arithmetic (csrc/mtl_h2.h: one power-of-two scale per
+ * tensor; an element more than ~2^17.5 below max|tensor| keeps fewer than 22 significand bits).  For `tasks` tensors of n floats at
+ * x + k sX with bounds at amax + k sAmax floats, ADDS to counts + k sCounts (three 64-bit counters each; zero them first):
+ * [0] non-zero elements, [1] of those, elements that keep fewer than 22 bits, [2] fewer than 16 bits.  Exact (integer atomics).
+ * The reference's inputs are normalised per utterance (utils/data_loader.py:84-94), which is why its activations stay in the
+ * full-precision regime; TransientTrainer samples this census periodically and leaves h2 when they do not. */
+int mtl_h2_census(void* stream, const float* x, long n, const float* amax, unsigned long long* counts, int tasks, long sX, long sAmax,
+                  long sCounts);
 /* Several tasks' batches of different frame counts in ONE pass, padded to the widest (data.py collate pads every task's batch to its OWN
  * longest utterance, transient_trainer.py:178-237 runs them one by one): y is (n, T, row) floats, sample s belongs to task s / per_task and
  * its frames [widths[task] >> shift, T) are cleared, so that the next convolution meets the zero border of the task's own image and the

@@ -65,8 +65,13 @@ SIGNATURES = {
     'mtl_conv3x3_dgrad_h2_tb': (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, I, L, L, L, P, I]),
     'mtl_conv3x3_wgrad_h2': (I, [P, P, P, P, P, P, P, P, P, L, I, I, I, I, I]),
     'mtl_conv3x3_wgrad_h2_tb': (I, [P, P, P, P, P, P, P, P, P, L, I, I, I, I, I, I, L, L, L, L]),
+    'mtl_conv3x3_relu_fwd_x3_tb': (I, [P, P, P, P, P, I, I, I, I, I, I, L, L, P, I]),
+    'mtl_conv3x3_relu_pool_fwd_x3_tb': (I, [P, P, P, P, P, P, I, I, I, I, I, I, L, L, P, I]),
+    'mtl_conv3x3_dgrad_x3_tb': (I, [P, P, P, P, P, P, I, I, I, I, I, I, L, P, I]),
+    'mtl_conv3x3_wgrad_x3_tb': (I, [P, P, P, P, P, P, P, L, I, I, I, I, I, I, L, L]),
     'mtl_absmax_f32': (I, [P, P, L, P]),
     'mtl_absmax_f32_tb': (I, [P, P, L, P, I, L, L]),
+    'mtl_h2_census': (I, [P, P, L, P, P, I, L, L, L]),
     'mtl_zero_tails': (I, [P, P, I, I, I, P, I, I]),
     'mtl_gemm_h2_tb': (I, [P, I, I, I, I, P, I, P, L, P, I, P, L, P, I, P, P, I, I, L, L, L, L, P, L]),
     'mtl_gemm_h2_tn_tb': (I, [P, I, I, I, P, I, P, L, P, I, P, L, P, I, I, L, L, L]),

@@ -12,6 +12,7 @@
 #include <algorithm>
 
 #include "mtl_common.h"
+#include "mtl_h2.h"
 #include "../../include/mtl_hip.h"
 
 namespace {
@@ -1489,6 +1490,55 @@ int mtl_absmax_f32_tb(void* stream, const float* x, long n, float* amax, int tas
     if (!x || !amax || n <= 0 || tasks < 1 || tasks > 65535 || (sX & 3)) return MTL_EINVAL;
     if (reinterpret_cast<uintptr_t>(x) & 15) return MTL_EINVAL;
     hipLaunchKernelGGL(absmax_kernel, dim3(grid_for(n / 4 + 1, 256, 1024), tasks), dim3(256), 0, as_stream(stream), x, n, amax, sX, sAmax);
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}
+
+// Census of an h2 operand against its bound (csrc/mtl_h2.h): with s = pow2_scale(bound) an element keeps both fp16 pieces' 22 bits
+// while |x| s >= 2^-3 (the low piece is a normal fp16); below, it keeps 22 - (its distance below that line) bits.  Counted per tensor:
+// [0] non-zero elements, [1] those with |x| s < 2^-3 (fewer than 22 bits), [2] those with |x| s < 2^-9 (fewer than 16 bits).
+// Integer atomics: exact and order-independent (one per workgroup and counter).
+__global__ __launch_bounds__(256) void h2_census_kernel(const float* __restrict__ x, long n, const float* __restrict__ amax,
+                                                        unsigned long long* __restrict__ counts, long sX, long sAmax, long sCounts) {
+    x += blockIdx.y * sX;
+    amax += blockIdx.y * sAmax;
+    counts += blockIdx.y * sCounts;
+    const float s = pow2_scale(amax_read(amax));
+    const float lim22 = 0.125f / s, lim16 = 0.001953125f / s;          // exact: powers of two
+    unsigned nz = 0, b22 = 0, b16 = 0;
+    auto see = [&](float v) {
+        const float a = fabsf(v);
+        nz += a > 0.f;
+        b22 += a > 0.f && a < lim22;
+        b16 += a > 0.f && a < lim16;
+    };
+    const long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        see(v.x), see(v.y), see(v.z), see(v.w);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) see(x[(n4 << 2) + threadIdx.x]);
+    __shared__ unsigned shm[3][4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        nz += __shfl_xor(nz, o, 64);
+        b22 += __shfl_xor(b22, o, 64);
+        b16 += __shfl_xor(b16, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) shm[0][threadIdx.x >> 6] = nz, shm[1][threadIdx.x >> 6] = b22, shm[2][threadIdx.x >> 6] = b16;
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const unsigned long long t = (unsigned long long)shm[threadIdx.x][0] + shm[threadIdx.x][1] + shm[threadIdx.x][2] + shm[threadIdx.x][3];
+        if (t) atomicAdd(counts + threadIdx.x, t);
+    }
+}
+
+int mtl_h2_census(void* stream, const float* x, long n, const float* amax, unsigned long long* counts, int tasks, long sX, long sAmax,
+                  long sCounts) {
+    if (!x || !amax || !counts || n <= 0 || tasks < 1 || tasks > 65535 || (sX & 3)) return MTL_EINVAL;
+    if (reinterpret_cast<uintptr_t>(x) & 15) return MTL_EINVAL;
+    hipLaunchKernelGGL(h2_census_kernel, dim3(grid_for(n / 4 + 1, 1024, 2048), tasks), dim3(256), 0, as_stream(stream), x, n, amax, counts, sX,
+                       sAmax, sCounts);
     MTL_CHECK_LAUNCH();
     return MTL_OK;
 }

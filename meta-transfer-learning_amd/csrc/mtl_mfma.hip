@@ -2662,6 +2662,28 @@ int mtl_conv3x3_dgrad_h2_tb(void* stream, const float* dy, const float* amax_dy,
                                 ConvTasks{tasks, sW, 0, sAmaxDy, sAmaxDx, widths, wshift});
 }
 
+/* the samples of `tasks` meta-tasks in one launch on the exact 3 x bf16 split: no bounds, otherwise as the *_h2_tb entry points */
+int mtl_conv3x3_relu_fwd_x3_tb(void* stream, const float* x, const void* w3_fwd, const float* bias, float* y, int B, int T, int F, int Cin,
+                               int Cout, int tasks, long sW, long sBias, const int* widths, int wshift) {
+    if (wshift < 0 || wshift > 8) return MTL_EINVAL;
+    return conv_fwd_pieces<3>(as_stream(stream), x, nullptr, w3_fwd, bias, y, nullptr, nullptr, false, B, T, F, Cin, Cout,
+                              ConvTasks{tasks, sW, sBias, 0, 0, widths, wshift});
+}
+
+int mtl_conv3x3_relu_pool_fwd_x3_tb(void* stream, const float* x, const void* w3_fwd, const float* bias, float* p_out, unsigned char* argmax,
+                                    int B, int T, int F, int Cin, int Cout, int tasks, long sW, long sBias, const int* widths, int wshift) {
+    if (wshift < 0 || wshift > 8) return MTL_EINVAL;
+    return conv_fwd_pieces<3>(as_stream(stream), x, nullptr, w3_fwd, bias, p_out, argmax, nullptr, true, B, T, F, Cin, Cout,
+                              ConvTasks{tasks, sW, sBias, 0, 0, widths, wshift});
+}
+
+int mtl_conv3x3_dgrad_x3_tb(void* stream, const float* dy, const unsigned char* argmax, const void* w3_dgrad, const float* act, float* dx,
+                            int B, int T, int F, int Cin, int Cout, int tasks, long sW, const int* widths, int wshift) {
+    if (wshift < 0 || wshift > 8) return MTL_EINVAL;
+    return conv_dgrad_pieces<3>(as_stream(stream), dy, nullptr, argmax, w3_dgrad, act, dx, nullptr, B, T, F, Cin, Cout,
+                                ConvTasks{tasks, sW, 0, 0, 0, widths, wshift});
+}
+
 long mtl_conv3x3_wgrad_workspace(int B, int T, int F, int Cin, int Cout, int pooled) {
     const int Ty = pooled ? 2 * (T / 2) : T, Fy = pooled ? 2 * (F / 2) : F;
     const long npix = (long)B * Ty * Fy;
@@ -2804,6 +2826,12 @@ int mtl_conv3x3_wgrad_h2_tb(void* stream, const float* x, const float* amax_x, c
                             int F, int Cin, int Cout, int tasks, long sAmaxX, long sAmaxDy, long sDw, long sDb) {
     return wgrad_pieces<2>(as_stream(stream), x, amax_x, dy, amax_dy, argmax, dw_ref, db, workspace, workspace_bytes, B, T, F, Cin, Cout,
                            WgradTasks{tasks, sAmaxX, sAmaxDy, sDw, sDb});
+}
+
+int mtl_conv3x3_wgrad_x3_tb(void* stream, const float* x, const float* dy, const unsigned char* argmax, float* dw_ref, float* db,
+                            float* workspace, long workspace_bytes, int B, int T, int F, int Cin, int Cout, int tasks, long sDw, long sDb) {
+    return wgrad_pieces<3>(as_stream(stream), x, nullptr, dy, nullptr, argmax, dw_ref, db, workspace, workspace_bytes, B, T, F, Cin, Cout,
+                           WgradTasks{tasks, 0, 0, sDw, sDb});
 }
 
 int mtl_conv3x3_wgrad_x3(void* stream, const float* x, const float* dy, const unsigned char* argmax, float* dw_ref,

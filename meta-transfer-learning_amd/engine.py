@@ -213,6 +213,8 @@ class _DecodeSession:
             c[:, :t] = c.index_select(0, idx)[:, :t]
 
 
+CENSUS_SLOTS = 9    # bound slots of the h2 operands: 0 y1, 1 p1, 2 y5, 3 dp2, 4 dy5, 5 dp1, 6 p2, (7: weights, not counted) 8 de0
+CENSUS_NAMES = {0: 'conv0 out', 1: 'pool1', 2: 'conv5 out', 3: 'd pool2', 4: 'd conv5 out', 5: 'd pool1', 6: 'pool2', 8: 'd input-linear out'}
 STAGE_RING = 6      # pinned staging buffers per slot (prepare_tasks): > pipeline depth (default 2) + 2
 
 _LAYER_BUF = re.compile(r'^([de])(\d+)\.(.+)$')
@@ -275,7 +277,7 @@ class PassEngine:
         self.gemm_ws = torch.empty(8 << 20, dtype=torch.float32, device=device) if device.type == 'cuda' else None  # split-K slabs
         # weight/bias-gradient kernels are off the critical path (nothing downstream in the backward reads them): they run
         # on a second HIP stream with their own workspaces, forked once per block and joined at the end of the backward
-        self.side = torch.cuda.Stream(device, priority=int(os.environ.get('MTL_EXP_SIDE_PRIO', '0'))) if device.type == 'cuda' else None
+        self.side = torch.cuda.Stream(device) if device.type == 'cuda' else None
         self.gemm_ws_side = torch.empty(8 << 20, dtype=torch.float32, device=device) if device.type == 'cuda' else None
         self.scratch_side = torch.empty(4 << 20, dtype=torch.float32, device=device) if device.type == 'cuda' else None
         self.on_side = False
@@ -289,6 +291,9 @@ class PassEngine:
         # replay alike -- right after the last kernel that writes that parameter group's gradients has been enqueued (on the main or
         # the side stream): the trainer starts the group's share of the meta-gradient all-reduce there (slice_bounds())
         self.slice_hook = None
+        # h2 guard: a (tasks, CENSUS_SLOTS, 4) int64 device tensor while the trainer samples the census of the h2 operands against their
+        # bounds (mtl_h2_census: non-zero elements / fewer than 22 bits / fewer than 16 bits; TransientTrainer.h2_check_every), else None
+        self.census = None
         self.deferred = []
         self._wlog = {}
         # the weight gradients of all layers of a stack run as one strided-batch launch per parameter kind (flush_layer_wgrads); the
@@ -603,6 +608,14 @@ class PassEngine:
         if dx is not None:
             self.gemm(0, 0, rows, k_in, n_out, dy, n_out, w, k_in, dx, k_in, gate=gate, ldg=k_in,
                       flags=ACCUM if dx_accum else 0, task=(rows * n_out, self.sP, rows * k_in, 0, 0))
+
+    def _census(self, slot, t, amax_ptr):
+        """add the census of the stacked h2 operand `t` (tasks x equal shares) against bound slot `slot` of every task"""
+        if self.census is None or amax_ptr is None:
+            return
+        n = t.numel() // self.nt
+        check(self.lib.mtl_h2_census(self.stream, t.data_ptr(), n, amax_ptr, self.census.data_ptr() + 32 * slot, self.nt, n,
+                                     12 * _lib.AMAX_SLOTS, 4 * CENSUS_SLOTS), 'mtl_h2_census')
 
     def colsum(self, x, rows, cols, out, amax=None):
         ws = self.scratch(self.lib.mtl_colsum_workspace(rows, cols))
@@ -1214,7 +1227,24 @@ class PassEngine:
         p2 = self.buf('p2', (Bt, T4, F4, 128))
         am2 = self.buf('am2', (Bt, T4, F4, 128), torch.uint8)
         # (a single task with frames of its own -- a widened batch on a lane -- takes the several-task launches too: they skip its tail rows)
-        if h2 and (nt > 1 or widths is not None):
+        x3_only = x3 and not h2
+        if x3_only and (nt > 1 or widths is not None):
+            # the exact 3 x bf16 split, same structure as the h2 branch below: ONE launch per layer for the samples of all tasks
+            swb = lambda idx: wf[idx].stride(0) * wf[idx].element_size() if ntw > 1 else 0
+            skip = widths
+            check(lib.mtl_conv3x3_relu_pool_fwd_x3_tb(st, y1.data_ptr(), wf[2].data_ptr(), o('conv.2.bias'), p1.data_ptr(), am1.data_ptr(),
+                                                      B, T, F, 64, 64, nt, swb(2), sP, skip, 0), 'conv2')
+            tails(p1, T2, F2 * 64, 1)
+            check(lib.mtl_conv3x3_relu_fwd_x3_tb(st, p1.data_ptr(), wf[5].data_ptr(), o('conv.5.bias'), y5.data_ptr(), B, T2, F2, 64, 128,
+                                                 nt, swb(5), sP, skip, 1), 'conv5')
+            tails(y5, T2, F2 * 128, 1)
+            check(lib.mtl_conv3x3_relu_pool_fwd_x3_tb(st, y5.data_ptr(), wf[7].data_ptr(), o('conv.7.bias'), p2.data_ptr(), am2.data_ptr(),
+                                                      B, T2, F2, 128, 128, nt, swb(7), sP, skip, 1), 'conv7')
+            if skip is not None:
+                tails(p2, T4, F4 * 128, 2)
+                tails(am1, T2, F2 * 64 // 4, 1)
+                tails(am2, T4, F4 * 128 // 4, 2)
+        elif h2 and (nt > 1 or widths is not None):
             # the samples of all tasks in ONE launch per layer (per-task bounds, weights and biases by stride): a persistent grid's
             # prologue, tail and launch boundary are paid once instead of nt times (2-14 % of a layer: tools/probe/conv_batch_tasks.py);
             # per task bitwise the per-task launches (tests/test_ops_gpu.py)
@@ -1262,6 +1292,10 @@ class PassEngine:
                 tails(y5, T2, F2 * 128, 1)
                 for a_ in per_task:
                     c7(*a_)
+
+        if h2 and self.census is not None:          # (stream order: every producer epilogue has raised its bound by now)
+            for slot, t_ in ((0, y1), (1, p1), (2, y5), (6, p2)):
+                self._census(slot, t_, am_(slot))
 
         # ---- encoder ----
         wp = self.buf('wp_in', (ntw, d, hp.d_in))
@@ -1544,6 +1578,8 @@ class PassEngine:
         elif self.in_h2:
             for t in range(nt):
                 check(lib.mtl_absmax_f32(st, de0[t * Me:].data_ptr(), Me * d, am_(8, t)), 'mtl_absmax_f32')
+        if self.in_h2:
+            self._census(8, de0, am_(8))
         if self.in_h2:      # dW = de0^T . p2 on fp16 pairs too: both bounds (slots 8, 6) exist for the data gradient below
             check(lib.mtl_gemm_h2_tn_tb(st, d, hp.d_in, Me, de0.data_ptr(), d, am_(8), am_st, p2.data_ptr(), hp.d_in, am_(6), am_st,
                                         dwp.data_ptr(), hp.d_in, nt, Me * d, Me * hp.d_in, d * hp.d_in), 'mtl_gemm_h2_tn_tb')
@@ -1575,7 +1611,6 @@ class PassEngine:
         # h2: the weight-gradient kernel's dy loaders also sum dy (bias gradient) and the data-gradient epilogue delivers the bound of
         # its output, so the column-sum passes over dy5 (164 MB) and dp1 (82 MB) are not needed; dp2 keeps its pass (its bound has no
         # other producer)
-        fold = lambda am: h2
 
         def wgrad(t, xa, axi, dy, adi, am, idx, Bq, Tq, Fq, cin, cout, db=None):
             x3 = self.conv_x3
@@ -1593,9 +1628,12 @@ class PassEngine:
         dy5 = self.buf('_dy5', (nt * B, T2, F2, 128))
         dp1 = self.buf('_dp1', (nt * B, T2, F2, 64))
         dy1 = self.buf('_dy1', (nt * B, T, F, 64))
-        f5, f2 = fold(None), fold(A['am1'])
+        x3_only = self.conv_x3 and not h2
+        merged = (h2 or x3_only) and (nt > 1 or S['meta'].get('widths') is not None)     # data gradients of conv7 / conv5: ONE launch over the samples of all tasks (see forward)
+        # the bias gradients of conv5 / conv2 ride on their weight-gradient launches (sums of dy in the loaders): always with h2 (the
+        # data-gradient epilogues also deliver the next bound), with the exact split in the several-task launches
+        f5 = f2 = h2 or (x3_only and merged)
         xin = S['x']
-        merged = h2 and (nt > 1 or S['meta'].get('widths') is not None)     # data gradients of conv7 / conv5: ONE launch over the samples of all tasks (see forward)
         # tasks with frame counts of their own (forward): the data gradients leave out the tile rows beyond a task's frames and those
         # rows of their outputs are cleared right behind them -- bias sums, bounds and weight gradients read whole tensors
         widths_b = S['meta'].get('widths')
@@ -1603,7 +1641,7 @@ class PassEngine:
         tails_b = (lambda buf_, T_, row_, shift_: check(lib.mtl_zero_tails(st, buf_.data_ptr(), nt * B, T_, row_, skip, shift_, B), 'mtl_zero_tails')) \
             if skip is not None else (lambda *a_: None)
         AS = 12 * _lib.AMAX_SLOTS
-        swd = lambda name: A[name].stride(0) if (sP and nt > 1) else 0
+        swd = lambda name: A[name].stride(0) * A[name].element_size() if (sP and nt > 1) else 0      # (bytes)
 
         def layer7(t, dgrad):
             tw, sl = (t if sP else 0), slice(t * B, (t + 1) * B)
@@ -1631,7 +1669,10 @@ class PassEngine:
             if wg:
                 wgrad(t, y1[sl].data_ptr(), 0, dp1[sl].data_ptr(), 5, am1_t, 2, B, T, F, 64, 64, db=g('conv.2.bias', t) if f2 else None)
             # (conv2's data gradient stays one launch per task: 8 x 16 tiles, measured no faster merged)
-            if skip is not None:      # ... through the several-task entry point with ONE task: it takes the task's own frame count
+            if skip is not None and x3_only:
+                check(lib.mtl_conv3x3_dgrad_x3_tb(st, dp1[sl].data_ptr(), am1_t, A['wd2'][tw].data_ptr(), y1[sl].data_ptr(),
+                                                  dy1[sl].data_ptr(), B, T, F, 64, 64, 1, 0, skip + 4 * t, 0), 'dgrad2')
+            elif skip is not None:      # ... through the several-task entry point with ONE task: it takes the task's own frame count
                 check(lib.mtl_conv3x3_dgrad_h2_tb(st, dp1[sl].data_ptr(), am_(5, t), am1_t, A['wd2'][tw].data_ptr(), y1[sl].data_ptr(),
                                                   dy1[sl].data_ptr(), None, B, T, F, 64, 64, 1, 0, 0, 0, skip + 4 * t, 0), 'dgrad2')
             else:
@@ -1647,6 +1688,10 @@ class PassEngine:
             slabs written and reduced as by one single-task launch)"""
             need = lib.mtl_conv3x3_wgrad_x3_workspace(B, Tq, Fq, cin, cout, 1 if am else 0)
             ws = self.scratch(need)
+            if x3_only:
+                check(lib.mtl_conv3x3_wgrad_x3_tb(st, xa, dy, am, g('conv.%d.weight' % idx), db, ws, need, B, Tq, Fq, cin, cout, nt, sG, sG),
+                      'wgrad_tb')
+                return
             check(lib.mtl_conv3x3_wgrad_h2_tb(st, xa, am_(axi), dy, am_(adi), am, g('conv.%d.weight' % idx), db, ws, need, B, Tq, Fq, cin, cout,
                                               nt, AS, AS, sG, sG), 'wgrad_tb')
 
@@ -1655,12 +1700,21 @@ class PassEngine:
             check(lib.mtl_colsum_accum_tb(st, dp2.data_ptr(), B * T4 * F4, 128, g('conv.7.bias'), self.scratch(nt * per + 64), am_(3), nt, sG, AS),
                   'colsum_tb')
             wgrad_tb(y5.data_ptr(), 2, dp2.data_ptr(), 3, A['am2'].data_ptr(), 7, T2, F2, 128, 128, None)
-            check(lib.mtl_conv3x3_dgrad_h2_tb(st, dp2.data_ptr(), am_(3), A['am2'].data_ptr(), A['wd7'].data_ptr(), y5.data_ptr(), dy5.data_ptr(),
-                                              am_(4) if f5 else None, B, T2, F2, 128, 128, nt, swd('wd7'), AS, AS, skip, 1), 'dgrad7')
+            if x3_only:
+                check(lib.mtl_conv3x3_dgrad_x3_tb(st, dp2.data_ptr(), A['am2'].data_ptr(), A['wd7'].data_ptr(), y5.data_ptr(), dy5.data_ptr(),
+                                                  B, T2, F2, 128, 128, nt, swd('wd7'), skip, 1), 'dgrad7')
+            else:
+                check(lib.mtl_conv3x3_dgrad_h2_tb(st, dp2.data_ptr(), am_(3), A['am2'].data_ptr(), A['wd7'].data_ptr(), y5.data_ptr(),
+                                                  dy5.data_ptr(), am_(4) if f5 else None, B, T2, F2, 128, 128, nt, swd('wd7'), AS, AS, skip, 1),
+                      'dgrad7')
             tails_b(dy5, T2, F2 * 128, 1)
             wgrad_tb(p1.data_ptr(), 1, dy5.data_ptr(), 4, None, 5, T2, F2, 64, 128, g('conv.5.bias'))
-            check(lib.mtl_conv3x3_dgrad_h2_tb(st, dy5.data_ptr(), am_(4), None, A['wd5'].data_ptr(), p1.data_ptr(), dp1.data_ptr(),
-                                              am_(5) if f2 else None, B, T2, F2, 64, 128, nt, swd('wd5'), AS, AS, skip, 1), 'dgrad5')
+            if x3_only:
+                check(lib.mtl_conv3x3_dgrad_x3_tb(st, dy5.data_ptr(), None, A['wd5'].data_ptr(), p1.data_ptr(), dp1.data_ptr(),
+                                                  B, T2, F2, 64, 128, nt, swd('wd5'), skip, 1), 'dgrad5')
+            else:
+                check(lib.mtl_conv3x3_dgrad_h2_tb(st, dy5.data_ptr(), am_(4), None, A['wd5'].data_ptr(), p1.data_ptr(), dp1.data_ptr(),
+                                                  am_(5) if f2 else None, B, T2, F2, 64, 128, nt, swd('wd5'), AS, AS, skip, 1), 'dgrad5')
             tails_b(dp1, T2, F2 * 64, 1)
             wgrad_tb(y1.data_ptr(), 0, dp1.data_ptr(), 5, A['am1'].data_ptr(), 2, T, F, 64, 64, g('conv.2.bias'))
             for t in range(nt):       # (conv2's data gradient merged as well: 52.23 / 52.63 / 52.83 against 52.03 / 52.18 / 52.92 ms per step: no gain)
@@ -1674,6 +1728,9 @@ class PassEngine:
                 layer7(t, True)
                 layer5(t, True)
                 layer2(t)
+        if h2 and self.census is not None:
+            for slot, t_ in ((3, dp2), (4, dy5), (5, dp1)):
+                self._census(slot, t_, am_(slot))
         self.join_side()
         self.flush_ln_reduce()     # the parameter / bias gradients of all 17 LayerNorms of the pass: one launch (after the join: one of
                                    # the 17 backward kernels ran on the side stream)

@@ -21,7 +21,7 @@ from collections import deque
 import torch
 
 from . import _lib, _trace, dist as mdist, hostenv
-from .engine import PAD_ID, round_width
+from .engine import CENSUS_NAMES, CENSUS_SLOTS, PAD_ID, round_width
 from .functions import post_process, save_joint_model, save_meta_model
 from .metrics import calculate_cer, calculate_metrics
 
@@ -151,8 +151,9 @@ class PendingIteration:
     """An enqueued meta-iteration: result() waits for ITS end-of-iteration event (not for the device, which may already be
     running the next iteration), then computes the reference's log quantities from the read-backs."""
 
-    def __init__(self, reads, done, vocab, dev):
+    def __init__(self, reads, done, vocab, dev, census=None):
         self.reads, self.done, self.vocab, self.dev = reads, done, vocab, dev
+        self.census = census          # (pinned counters, callback) of an iteration that sampled the h2 census
         self._result = None
 
     def result(self):
@@ -166,6 +167,10 @@ class PendingIteration:
                 total_loss += float(va_read.loss[0])
             self._result = mdist.allreduce_scalars([total_loss, total_cer, total_char], self.dev)
             self.reads = None
+            if self.census is not None:
+                counters, report = self.census
+                self.census = None
+                report(counters)
         return self._result
 
 
@@ -367,6 +372,16 @@ class TransientTrainer():
         self.overlap_uploads = True
         self.pin_batches = True             # train(): batches drawn on the host are page-locked by the prefetch thread
         self.replica_check_every = 100      # several ranks: iterations between two bit-level divergence checks of the replicas
+        # Guard of the two-piece fp16 ("h2") convolution arithmetic (csrc/mtl_h2.h: ONE power-of-two scale per tensor, so an element more
+        # than ~2^17.5 below its tensor's maximum keeps fewer than 22 significand bits).  The reference's features are normalised per
+        # utterance (utils/data_loader.py:84-94), which keeps every operand of the path in the full-precision regime -- this checks it
+        # instead of assuming it: every `h2_check_every` iterations (the first included) the iteration also counts, for every h2 operand
+        # of every pass (activations forward, gradients backward), the non-zero elements that keep fewer than 22 / fewer than 16 bits
+        # (mtl_h2_census; ~5 % on that one iteration).  `h2_census` holds the latest fractions; when the share below 16 bits of any
+        # operand exceeds `h2_limit`, `h2_guard` acts: 'x3' (default) moves the convolutions to the exact 3 x bf16 split for the rest of
+        # the run, 'raise' stops, 'warn' only reports.  0 = never sample.
+        self.h2_check_every, self.h2_limit, self.h2_guard = 100, 1e-3, 'x3'
+        self.h2_census, self._h2_iter, self._h2_buf, self._census_on = None, 0, None, None
         self._turn = 0
 
     # ------------------------------------------------------------------ drop-in single-batch API
@@ -451,12 +466,13 @@ class TransientTrainer():
             with torch.cuda.stream(streams[lane]):
                 tx, t_own = widened(tx.to(dev, non_blocking=True), eng, 'lane.x_tr')
                 lw = (lambda y_: _label_width([y_], self.label_quantum, eng.hp.tgt_max_len)) if (q > 1 and self.label_quantum > 1) else (lambda y_: None)
+                eng.census = self._census_on[lane:lane + 1] if self._census_on is not None else None
                 m_tr = eng.prepare(tsz, ty, tx.shape[0], tx.shape[3], slot=0, frames=t_own, width=lw(ty))   # host ints -> static device buffers
                 m_va = eng.prepare(val_batch[1], val_batch[3], vx.shape[0], vx.shape[3], slot=1, frames=v_own, width=lw(val_batch[3]))
                 slots = self._slots(model, lane, m_tr, m_va)
                 key = (lane, tuple(tx.shape), tuple(vx.shape), t_own is not None, v_own is not None, m_tr['Td'], m_va['Td'], n_tasks, bool(args.clip),
                        float(args.max_norm), smoothing, float(inner.param_groups[0]['lr']), theta0.data_ptr(), eng.dropout_p,
-                       tuple(b.data_ptr() for b in bufs[lane]), streams[lane].cuda_stream, eng.use_side_stream)
+                       tuple(b.data_ptr() for b in bufs[lane]), streams[lane].cuda_stream, eng.use_side_stream, eng.census is not None)
                 # a rank that holds ONE task (8 tasks on 8 GPUs): G = its g, handed to the all-reduce group by group under the backward
                 chunk = None
                 if n_lanes == 1 and len(task_batches) == 1:
@@ -635,6 +651,8 @@ class TransientTrainer():
         chunk = self._chunk_hook(model, eng, lambda lo, n, st: check(
             _lib.lib().mtl_sum_tasks_strided(st, G.data_ptr() + 4 * lo, g.data_ptr() + 4 * lo, n, nt, total, 0), 'mtl_sum_tasks_strided'))
 
+        eng.census = self._census_on[:nt] if self._census_on is not None else None
+
         def body(_xa=None, _xb=None):
             eng.zero_(g)                                                         # inner_opt.zero_grad()   (:198), every task
             eng.forward_device(theta0, Xtr, m_tr, smoothing, hyp_out=slots['hyp_tr'], loss_out=slots['loss_tr'])      # (:188)
@@ -655,7 +673,7 @@ class TransientTrainer():
 
         key = ('batched', nt, (B, F, T), own_tr, tuple(Xva.shape), Tv != Tv_own, m_tr['Td'], m_va['Td'], n_tasks, bool(args.clip), float(args.max_norm),
                smoothing, lr, theta0.data_ptr(), eng.dropout_p, g.data_ptr(), theta1.data_ptr(), G.data_ptr(),
-               torch.cuda.current_stream(dev).cuda_stream, eng.use_side_stream, chunk is not None)
+               torch.cuda.current_stream(dev).cuda_stream, eng.use_side_stream, chunk is not None, eng.census is not None)
         _trace.mark('keys')
         if use_cmdlists:
             self._run_recorded(key, eng, Xtr, Xva, body, on_break=chunk)
@@ -808,7 +826,13 @@ class TransientTrainer():
         outer_opt.zero_grad()
         _trace.mark('zero_grad')
         self._G_reduced = False
-        reads = self.meta_iteration(model, vocab, task_batches, val_data, n_tasks, inner_opt, outer_opt, args)
+        census = self._census_begin(model, len(task_batches))
+        try:
+            reads = self.meta_iteration(model, vocab, task_batches, val_data, n_tasks, inner_opt, outer_opt, args)
+        finally:
+            self._census_on = None
+            for e in model.engines:
+                e.census = None
         _trace.mark('meta_iteration_rest')
         G = model._G
         if not self._G_reduced:                                  # (already summed over the ranks group by group, under the backward: _chunk_hook)
@@ -821,8 +845,57 @@ class TransientTrainer():
         done.record(torch.cuda.current_stream(dev))
         _trace.mark('done_event')
         _trace.end()
+        pend = None
+        if census is not None:
+            host = _pinned(('h2census', self._turn), census.shape, torch.int64, self._turns())
+            host.copy_(census, non_blocking=True)
+            done.record(torch.cuda.current_stream(dev))
+            pend = (host, lambda counters, model=model: self._census_report(model, counters))
         self.host_enqueue_s = time.perf_counter() - t_host       # host side of the iteration (diagnostics: bench.py reports it)
-        return PendingIteration(reads, done, vocab, dev)
+        return PendingIteration(reads, done, vocab, dev, census=pend)
+
+    def _census_begin(self, model, n_local):
+        """-> the zeroed counter buffer when this iteration samples the h2 census (see __init__), else None.  Row t belongs to local
+        task t of a task-batched pass, or to lane t of the lane schedule."""
+        self._census_on = None
+        engs = getattr(model, 'engines', None)
+        if not engs or self.h2_check_every <= 0 or not all(e.conv_h2 for e in engs) or any(e.prof is not None for e in engs):
+            return None
+        self._h2_iter += 1
+        if (self._h2_iter - 1) % self.h2_check_every:
+            return None
+        rows = max(len(engs), n_local, 1)
+        dev = model.flat_parameters.device
+        if self._h2_buf is None or self._h2_buf.shape[0] < rows or self._h2_buf.device != dev:
+            self._h2_buf = torch.zeros(rows, CENSUS_SLOTS, 4, dtype=torch.int64, device=dev)
+        engs[0].zero_(self._h2_buf)
+        self._census_on = self._h2_buf
+        return self._h2_buf
+
+    def _census_report(self, model, counters):
+        """the read-back counters of a census iteration -> self.h2_census {operand: (share below 22 bits, share below 16 bits)} of
+        the non-zero elements; acts per `h2_guard` when an operand's share below 16 bits exceeds `h2_limit`"""
+        c = counters.numpy().reshape(-1, CENSUS_SLOTS, 4).sum(0)
+        self.h2_census = {CENSUS_NAMES[i]: (float(c[i, 1]) / max(int(c[i, 0]), 1), float(c[i, 2]) / max(int(c[i, 0]), 1))
+                          for i in sorted(CENSUS_NAMES) if int(c[i, 0]) > 0}
+        worst = max(self.h2_census, key=lambda k_: self.h2_census[k_][1], default=None)
+        msg = 'H2 CENSUS share of non-zero elements below 22 / 16 significand bits: ' + ', '.join(
+            '%s %.2e / %.2e' % (k_, v[0], v[1]) for k_, v in self.h2_census.items())
+        logging.info(msg)
+        if worst is None or self.h2_census[worst][1] <= self.h2_limit:
+            return
+        what = ('%.2e of the non-zero elements of "%s" keep fewer than 16 significand bits under one scale per tensor (limit %.1e): '
+                'the batch mixes magnitudes more than 2^22 apart (features not normalised per utterance?)' %
+                (self.h2_census[worst][1], worst, self.h2_limit))
+        if self.h2_guard == 'raise':
+            raise RuntimeError('h2 range guard: ' + what)
+        if self.h2_guard == 'x3' and all(e.conv_h2 for e in model.engines):
+            for e in model.engines:
+                e.conv_mode, e.conv_x3, e.conv_h2 = 'x3', True, False
+            self._cmdlists.clear()                           # (the recorded lists hold the h2 entry points)
+            what += '; the 3x3 convolutions and the input Linear run on the exact 3 x bf16 split from the next enqueued iteration on'
+        logging.warning('h2 range guard: ' + what)
+        print('WARNING: h2 range guard: ' + what, flush=True)
 
     def reduce_meta_gradient(self, model):
         """The collective of the path for an iteration whose backward did not hand G's groups over as it went (several differently

@@ -973,6 +973,94 @@ def test_conv3x3_two_piece_fp16_several_tasks_in_one_launch(L, Cin, Cout, B, T, 
                 assert rel(db1[t] - 0.25, dbn[t] - 0.25) < 3e-6, ('db', pooled, t)
 
 
+@pytest.mark.parametrize('Cin,Cout,B,T,Fq,nt', [(64, 64, 2, 37, 161, 3), (64, 128, 3, 34, 80, 4), (128, 128, 2, 50, 40, 5)])
+@pytest.mark.parametrize('shared_w', [True, False])
+def test_conv3x3_exact_split_several_tasks_in_one_launch(L, Cin, Cout, B, T, Fq, nt, shared_w):
+    """mtl_conv3x3_*_x3_tb (the exact 3 x bf16 split, MTL_CONV=x3): the samples of nt meta-tasks in ONE launch against nt single-task
+    launches -- forward, fused pool (+ arg-max) and both data gradients BIT FOR BIT (weights shared or per task, per-task bias), rows
+    beyond a task's own frames left out; weight + bias gradients of all tasks in one launch equal to the per-task launches within fp32
+    rounding (other slab partition), accumulating onto the stack, deterministic."""
+    g = torch.Generator().manual_seed(Cin + Cout + T + nt + 1)
+    x = torch.cat([torch.relu(torch.randn(B, T, Fq, Cin, generator=g)) * 10.0 ** (t - 1) for t in range(nt)]).cuda()
+    nw = 1 if shared_w else nt
+    w = (torch.randn(nw, Cout, Cin, 3, 3, generator=g) * (1.0 / np.sqrt(9 * Cin))).cuda()
+    bias = (torch.randn(nw, Cout, generator=g) * 0.1).cuda()
+    w3f = torch.empty(nw, 3, 9, Cin, Cout, dtype=torch.bfloat16).cuda()
+    w3d = torch.empty(nw, 3, 9, Cout, Cin, dtype=torch.bfloat16).cuda()
+    for k in range(nw):
+        assert L.mtl_conv3x3_wprep_x3(st(), w[k].data_ptr(), w3f[k].data_ptr(), w3d[k].data_ptr(), Cout, Cin) == 0
+    sW, sB = (0, 0) if shared_w else (w3f[0].numel() * 2, Cout)
+    wk = lambda t: 0 if shared_w else t
+    Tp, Fp = T // 2, Fq // 2
+    for pooled in (False, True):
+        shp = (nt * B, Tp, Fp, Cout) if pooled else (nt * B, T, Fq, Cout)
+        y1, yn = torch.zeros(shp).cuda(), torch.zeros(shp).cuda()
+        am1, amn = torch.zeros(shp, dtype=torch.uint8).cuda(), torch.zeros(shp, dtype=torch.uint8).cuda()
+        for t in range(nt):
+            sl = slice(t * B, (t + 1) * B)
+            if pooled:
+                assert L.mtl_conv3x3_relu_pool_fwd_x3(st(), x[sl].data_ptr(), w3f[wk(t)].data_ptr(), bias[wk(t)].data_ptr(), yn[sl].data_ptr(),
+                                                      amn[sl].data_ptr(), B, T, Fq, Cin, Cout) == 0
+            else:
+                assert L.mtl_conv3x3_relu_fwd_x3(st(), x[sl].data_ptr(), w3f[wk(t)].data_ptr(), bias[wk(t)].data_ptr(), yn[sl].data_ptr(),
+                                                 B, T, Fq, Cin, Cout) == 0
+        wd_host = [max(T - 7 * t - (3 if t else 0), 4) for t in range(nt)]
+        wd = torch.tensor(wd_host, dtype=torch.int32).cuda()
+        yw, amw = torch.full(shp, -7.0).cuda(), torch.full(shp, 9, dtype=torch.uint8).cuda()
+        for widths, yo, ao in ((None, y1, am1), (wd.data_ptr(), yw, amw)):
+            if pooled:
+                assert L.mtl_conv3x3_relu_pool_fwd_x3_tb(st(), x.data_ptr(), w3f.data_ptr(), bias.data_ptr(), yo.data_ptr(), ao.data_ptr(),
+                                                         B, T, Fq, Cin, Cout, nt, sW, sB, widths, 0) == 0
+            else:
+                assert L.mtl_conv3x3_relu_fwd_x3_tb(st(), x.data_ptr(), w3f.data_ptr(), bias.data_ptr(), yo.data_ptr(), B, T, Fq, Cin, Cout,
+                                                    nt, sW, sB, widths, 0) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(y1, yn) and float(yn.abs().max()) > 0, ('forward', pooled)
+        if pooled:
+            assert torch.equal(am1, amn)
+        dy = torch.cat([torch.randn((B,) + shp[1:], generator=g) * 10.0 ** (1 - t) for t in range(nt)]).cuda()
+        dx1, dxn, dxw = torch.zeros_like(x), torch.zeros_like(x), torch.full(x.shape, -7.0).cuda()
+        for t in range(nt):
+            sl = slice(t * B, (t + 1) * B)
+            assert L.mtl_conv3x3_dgrad_x3(st(), dy[sl].data_ptr(), amn[sl].data_ptr() if pooled else None, w3d[wk(t)].data_ptr(), x[sl].data_ptr(),
+                                          dxn[sl].data_ptr(), B, T, Fq, Cin, Cout) == 0
+        for widths, dxo in ((None, dx1), (wd.data_ptr(), dxw)):
+            assert L.mtl_conv3x3_dgrad_x3_tb(st(), dy.data_ptr(), amn.data_ptr() if pooled else None, w3d.data_ptr(), x.data_ptr(), dxo.data_ptr(),
+                                             B, T, Fq, Cin, Cout, nt, sW, widths, 0) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(dx1, dxn) and float(dxn.abs().max()) > 0, ('data gradient', pooled)
+        for t in range(nt):
+            sl = slice(t * B, (t + 1) * B)
+            own = wd_host[t] // 2 if pooled else wd_host[t]
+            assert torch.equal(yw[sl, :own], yn[sl, :own]) and torch.equal(dxw[sl, :wd_host[t]], dxn[sl, :wd_host[t]]), (t, pooled)
+            edge = -(-wd_host[t] // 16) * 16
+            assert bool((dxw[sl, edge:] == -7.0).all()) and bool((yw[sl, (edge // 2 if pooled else edge):] == -7.0).all()), (t, pooled)
+        if shared_w:
+            need = L.mtl_conv3x3_wgrad_x3_workspace(B, T, Fq, Cin, Cout, 1 if pooled else 0)
+            ws = torch.empty(need // 4 + 64).cuda()
+            dwn, dw1, db1 = torch.full((nt, Cout, Cin, 3, 3), 0.5).cuda(), torch.full((nt, Cout, Cin, 3, 3), 0.5).cuda(), torch.full((nt, Cout), 0.25).cuda()
+            for t in range(nt):
+                sl = slice(t * B, (t + 1) * B)
+                assert L.mtl_conv3x3_wgrad_x3(st(), x[sl].data_ptr(), dy[sl].data_ptr(), amn[sl].data_ptr() if pooled else None, dwn[t].data_ptr(),
+                                              ws.data_ptr(), need, B, T, Fq, Cin, Cout) == 0
+            outs = []
+            for rep in range(2):
+                dw_, db_ = (dw1, db1) if rep == 0 else (torch.full_like(dw1, 0.5), torch.full_like(db1, 0.25))
+                assert L.mtl_conv3x3_wgrad_x3_tb(st(), x.data_ptr(), dy.data_ptr(), amn.data_ptr() if pooled else None, dw_.data_ptr(), db_.data_ptr(),
+                                                 ws.data_ptr(), need, B, T, Fq, Cin, Cout, nt, dw_[0].numel(), Cout) == 0
+                torch.cuda.synchronize()
+                if rep:
+                    assert torch.equal(dw_, dw1) and torch.equal(db_, db1)
+            for t in range(nt):
+                sl = slice(t * B, (t + 1) * B)
+                assert rel(dw1[t] - 0.5, dwn[t] - 0.5) < 3e-6, ('dW', pooled, t)
+                if pooled:      # the bias gradient = sums of the un-pooled dy = sums of dy on the pooled grid
+                    ref_b = dy[sl].double().sum((0, 1, 2))
+                else:
+                    ref_b = dy[sl].double().sum((0, 1, 2))
+                assert rel(db1[t] - 0.25, ref_b) < 3e-6, ('db', pooled, t)
+
+
 @pytest.mark.parametrize('Cin,Cout,B,T,Fq', [(64, 64, 2, 21, 161), (64, 128, 2, 18, 80), (128, 128, 1, 9, 19)])
 @pytest.mark.parametrize('mag', [1.0, 3e-7, 4e5])
 def test_conv3x3_two_piece_fp16_is_fp32_class(L, Cin, Cout, B, T, Fq, mag):

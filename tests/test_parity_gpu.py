@@ -239,13 +239,14 @@ def test_single_pass_at_north_star_size_against_live_oracle():
     _pass_parity(model, oracle, batch, model.flat_parameters, 'NS single pass', max_flips=NS_FLIP_BOUND)
 
 
-@pytest.mark.parametrize('n_tasks,conv', [(3, 'h2'), (8, 'h2'), (3, 'x3')])
+@pytest.mark.parametrize('n_tasks,conv', [(3, 'h2'), (8, 'h2'), (3, 'x3'), (8, 'x3')])
 def test_meta_gradient_at_north_star_size_with_branch_replay(n_tasks, conv):
     """BASELINE.json configs[1] at full size: the meta-gradient G of TransientTrainer.meta_iteration (task-batched passes, side
     stream, fused inner step) against the LIVE oracle's G = sum_m [g_tr,m + g_val,m / n] computed with its own inner steps and
     the device path's branch decisions of all 2 n passes replayed: 190/190 tensors within 1e-4, losses within 1e-4, labels
     bit-exact.  (3, h2): configs[1] as the README runs it; (8, h2): the schedule bench.py times (8 tasks in ONE batched pass per
-    phase); (3, x3): the same step with the convolutions on the exact 3-piece bf16 split (MTL_CONV=x3, bench.py's `conv_x3`)."""
+    phase); (3, x3) / (8, x3): the same steps with the convolutions on the exact 3-piece bf16 split (MTL_CONV=x3, bench.py's `conv_x3`: one
+    launch per layer for all tasks as with h2)."""
     from oracle import refimpl as R
     from oracle import branches
     z, cfg, spec = gu.load('NS')

@@ -274,6 +274,101 @@ def test_long_utterance_full_batch_against_live_oracle():
     _pass_parity(model, oracle, tr[0], model.flat_parameters, 'T=5000 B=8', max_flips=400)
 
 
+def _norm_per_utterance(x, lens):
+    """utils/data_loader.py:84-94 on a synthetic batch: every utterance to zero mean / unit std over its OWN frames, zero tail beyond"""
+    x = x.clone()
+    for i, n in enumerate(lens.tolist()):
+        v = x[i, :, :, :n]
+        x[i, :, :, :n] = (v - v.mean()) / v.std()
+        x[i, :, :, n:] = 0
+    return x
+
+
+def test_h2_range_guard_census_is_clean_on_normalised_utterances_of_very_different_lengths():
+    """The guard of the two-piece fp16 convolutions (TransientTrainer.h2_check_every): on features normalised per utterance
+    (utils/data_loader.py:84-94) with zero tails of very different lengths -- what the real collate hands over -- every h2 operand of
+    every pass (activations forward, gradients backward) stays in the full-precision regime: no non-zero element below 16 bits, the
+    trainer stays on h2, and the pass meets the oracle at 1e-4 on every tensor."""
+    from oracle import refimpl as R
+    z, cfg, spec = gu.load('F1')
+    mtl_amd, args, vocab, model = make(cfg, spec)
+    model = model.cuda()
+    assert model._need_engine().conv_h2
+    g = torch.Generator().manual_seed(4242)
+    lens = torch.tensor([240, 30, 111, 8], dtype=torch.int32)
+    mk = lambda: (_norm_per_utterance(torch.randn(4, 1, 161, 240, generator=g) * 3.0 + 1.5, lens), lens,
+                  torch.randint(4, cfg['vocab_size'], (4, 9), generator=g))
+    tasks = [mk() for _ in range(2)]
+    val = mk()
+    as5 = lambda b: (b[0].cuda(), b[1], None, b[2], None)
+    inner, outer = mtl_amd.FlatSGD(model, spec['lr']), mtl_amd.FlatAdam(model, spec['meta_lr'])
+    model.zero_copy_grad()
+    for batch_tasks in (True, False):                    # one stacked pass per phase / a lane per task
+        tr = mtl_amd.TransientTrainer()
+        tr.h2_check_every, tr.batch_tasks = 1, batch_tasks
+        tr.run_iteration(model, vocab, [as5(b) for b in tasks], as5(val), 2, inner, outer, args)
+        cen = tr.h2_census
+        assert cen is not None and set(cen) == {'conv0 out', 'pool1', 'conv5 out', 'pool2', 'd pool2', 'd conv5 out', 'd pool1', 'd input-linear out'}
+        print('census (%s):' % tr.last_schedule, {k: ('%.1e' % v[0], '%.1e' % v[1]) for k, v in cen.items()})
+        assert max(v[1] for v in cen.values()) <= 1e-6 and all(e.conv_h2 for e in model.engines)
+        assert max(cen[k][0] for k in ('conv0 out', 'pool1', 'conv5 out', 'pool2')) <= 1e-3
+    oracle = R.build_model(cfg)
+    _pass_parity(model, oracle, tasks[0], model.flat_parameters, 'normalised utterances, lengths 240 / 30 / 111 / 8')
+
+
+def test_h2_range_guard_fires_on_a_loud_and_a_quiet_sample_and_moves_to_the_exact_split():
+    """One scale per tensor: a sample 2^24 quieter than its batch-mate keeps ~15 bits in the two fp16 pieces.  (With the reference's
+    biases the convolutions' outputs of a quiet INPUT are bias-dominated -- not quiet; the spread is produced here the way it can arise
+    inside the stack: bias-free convolutions.)  The census counts the quiet sample's elements, the guard moves the engines to the exact
+    3 x bf16 split, and against the oracle the quiet sample's logits are then ~100 x closer than under h2."""
+    from oracle import refimpl as R
+    from oracle import branches
+    z, cfg, spec = gu.load('F0')
+    mtl_amd, args, vocab, model = make(cfg, spec)
+    with torch.no_grad():
+        for i in (0, 2, 5, 7):
+            getattr(model.conv, str(i)).bias.zero_()
+    model = model.cuda()
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(2, 1, 161, 64, generator=g)
+    x[1] *= 2.0 ** -24
+    lens = torch.tensor([64, 64], dtype=torch.int32)
+    y = torch.randint(4, cfg['vocab_size'], (2, 8), generator=g)
+    batch = (x, lens, y)
+    as5 = lambda b: (b[0].cuda(), b[1], None, b[2], None)
+    oracle = R.build_model(cfg)
+    _set_oracle_params(oracle, model, model.flat_parameters)
+    with torch.no_grad():
+        pred_ref = oracle(x, lens, y)[0]
+    err = {}
+    out = model.pass_forward(x.cuda(), lens, y)
+    err['h2'] = float((out['pred'][1].cpu() - pred_ref[1]).norm() / pred_ref[1].norm())
+    inner, outer = mtl_amd.FlatSGD(model, 0.0), mtl_amd.FlatAdam(model, 0.0)       # (no parameter motion: the same theta afterwards)
+    model.zero_copy_grad()
+    tr = mtl_amd.TransientTrainer()
+    tr.h2_check_every = 1
+    assert tr.h2_guard == 'x3' and all(e.conv_h2 for e in model.engines)
+    tr.run_iteration(model, vocab, [as5(batch)], as5(batch), 1, inner, outer, args)
+    cen = tr.h2_census
+    print('census:', {k: ('%.2f' % v[0], '%.2f' % v[1]) for k, v in cen.items()})
+    assert cen['conv0 out'][1] > 0.3 and cen['pool2'][1] > 0.3           # the quiet sample's half of the non-zero elements
+    assert all(e.conv_mode == 'x3' and not e.conv_h2 for e in model.engines) and not tr._cmdlists
+    out = model.pass_forward(x.cuda(), lens, y)
+    err['x3'] = float((out['pred'][1].cpu() - pred_ref[1]).norm() / pred_ref[1].norm())
+    print('quiet sample, logits vs oracle: h2 %.2e, x3 after the guard %.2e' % (err['h2'], err['x3']))
+    assert err['x3'] < 2e-6 and err['x3'] < err['h2'] / 20
+    tr2 = mtl_amd.TransientTrainer()                         # 'raise' stops instead
+    for e in model.engines:
+        e.conv_mode, e.conv_x3, e.conv_h2 = 'h2', True, True
+    tr2.h2_check_every, tr2.h2_guard = 1, 'raise'
+    with pytest.raises(RuntimeError, match='h2 range guard'):
+        tr2.run_iteration(model, vocab, [as5(batch)], as5(batch), 1, inner, outer, args)
+    # the whole pass on the exact split against the oracle: labels, loss, every gradient tensor (decisions replayed)
+    for e in model.engines:
+        e.conv_mode, e.conv_x3, e.conv_h2 = 'x3', True, False
+    _pass_parity(model, oracle, batch, model.flat_parameters, 'loud / quiet pair on the exact split')
+
+
 def test_rccl_collective_path_executes():
     """The `nccl` (= RCCL) branch of dist.init_from_env and the flat-G all-reduce on this box's GPU: one rank under torchrun with
     MTL_DIST_ALWAYS=1 (the collective is issued even at world size 1).  Multi-rank arithmetic is covered by the gloo tests; this
