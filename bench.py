@@ -373,7 +373,10 @@ def dump_shapes(records):
     shapes = {}
     for name, a, e0, e1 in records:
         if name in ('mtl_gemm_f32_ex', 'mtl_gemm_f32_tb'):
-            key = 'gemm ta%d tb%d M%d N%d K%d b%d kb%d rs%d' % (a[1], a[2], a[3], a[4], a[5], a[17], a[26], 1 if a[29] else 0)
+            route = sys.modules['mtl_amd']._lib.lib().mtl_gemm_f32_ex_route(a[3], a[4], a[5], a[17], a[26], 1 if a[29] else 0)
+            key = 'gemm %-5s ta%d tb%d M%d N%d K%d b%d kb%d rs%d gflop %.2f' % (
+                {0: 'big', 1: 'small', 2: 'x3'}.get(route, '?'), a[1], a[2], a[3], a[4], a[5], a[17], a[26], 1 if a[29] else 0,
+                2e-9 * a[3] * a[4] * a[5] * a[17] * a[26])
         elif name in ('mtl_attn_fwd', 'mtl_attn_bwd', 'mtl_layernorm_fwd', 'mtl_layernorm_bwd', 'mtl_layernorm_fwd_g', 'mtl_layernorm_bwd_g'):
             key = name + ' ' + ' '.join(str(v) for v in a if isinstance(v, int) and 0 <= v < 100000)
         else:

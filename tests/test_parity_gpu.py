@@ -102,7 +102,10 @@ def test_meta_iterations_match_reference_goldens(name):
             if float(z['G/%d/%s/l2' % (it, nm)]) < floor * 1e-2:
                 continue        # Adam on an exactly-zero gradient: sign of rounding noise (see tests/test_oracle_golden.py)
             # Adam's first steps are ~ lr*sign(g): elements with |g| ~ eps inherit g's relative error one-for-one
-            gu.check_digest(z, 'theta/%d' % (it + 1), nm, p, rtol=RTOL if e <= RTOL / 10 else GOLDEN_BAND[name], what=name)
+            # (T5: zero-initialised LayerNorm / bias tensors move by -lr g / (|g| + eps) with |g| ~ eps = 1e-8: an element of g inside its
+            # error band may change sign, which moves theta by 2 lr -- normwise ~ 2 sqrt(share of such elements) <= 3 sqrt(e))
+            band = GOLDEN_BAND[name] if name != 'T5' else max(GOLDEN_BAND[name], 3.0 * float(np.sqrt(e)))
+            gu.check_digest(z, 'theta/%d' % (it + 1), nm, p, rtol=RTOL if e <= RTOL / 10 else band, what=name)
     print('%s worst per-tensor meta-gradient rel err: %.3e' % (name, worst))
 
 
