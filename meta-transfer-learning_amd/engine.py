@@ -1096,7 +1096,8 @@ class PassEngine:
             raise ValueError('expected (B,1,F,T) input')
         # stand-alone passes (validation loops, the joint trainer, the drop-in autograd call) on batches whose width changes from call
         # to call: widened to a repeating width like the trainer's lanes (own border and encoder length kept), from the second width on
-        # (not while a test's forward hook reads the activations in the pass's own extent)
+        # (not while a test's forward hook reads the activations in the pass's own extent).  Exact with dropout off; with dropout on, the
+        # keep-masks of a widened pass differ from the own-width pass's (the Philox element indices follow the buffer extents).
         T_own, frames = int(x.shape[3]), None
         if self.widen == 'auto' and not self._widths_vary:
             self._widths_vary = self._first_width.setdefault(slot, T_own) != T_own
@@ -1381,7 +1382,10 @@ class PassEngine:
                           enc_inputs=enc_inputs, nt=nt, sP=self.sP, sX=sX)
         if self.forward_hook is not None:
             self.forward_hook(self)
-        return dict(pred=pred, gold=ids[1], hyp=hyp, loss=loss, gold_host=meta['gold_host'], n_nonpad=n_nonpad)
+        # T4 / frames: the extent of the arena's encoder-side activations (a widened stand-alone pass, PassEngine.forward, carries
+        # T // 4 >= own frames // 4 positions per utterance: readers of eng.arena index with T4, the batch's own extent is frames)
+        return dict(pred=pred, gold=ids[1], hyp=hyp, loss=loss, gold_host=meta['gold_host'], n_nonpad=n_nonpad, T4=T4,
+                    frames=meta.get('frames'))
 
     # ---------------------------------------------------------------- greedy decoding
     def decode_session(self, theta, mem, B, T4, S, shared_memory=False):

@@ -612,6 +612,10 @@ class TransientTrainer():
                     up.wait_stream(main)                 # first use of this set: behind whatever produced / last used the memory
                     Ltr.record_stream(up)                # (the pool may hand the block back to torch's allocator one day)
                     Lva.record_stream(up)
+                if vx_in.is_cuda or any(tb[0].is_cuda for tb in task_batches):
+                    # mixed residency (e.g. a cached device-resident validation batch beside host training batches): a device tensor
+                    # may have been produced on the main stream in this very iteration
+                    up.wait_stream(main)
                 for t, (tx, _tsz, _tp, _ty, _tl) in enumerate(task_batches):
                     L2[t, :tx.numel()].copy_(tx.reshape(-1), non_blocking=True)
                 Lva.view(-1)[:nv].copy_(vx_in.reshape(-1), non_blocking=True)
