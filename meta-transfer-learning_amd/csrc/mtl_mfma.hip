@@ -2546,6 +2546,68 @@ static int conv_fwd_pieces(hipStream_t s, const float* x, const float* amax_x, c
     return dispatch_conv_x3<false, EPI_RELU, NP>(p, T, F, s);
 }
 
+// Edge column of a data gradient whose source lives on the pooled grid of an ODD dense width (F = 2 Fp + 1: conv2 at 161 frequency bins).
+// The un-pooled gradient is zero in column F - 1 (floor-mode pooling never selects it), so dx[:, :, F - 1, :] receives only the three taps
+// that read column F - 2 -- 1 / 16 of a 16-wide pixel-tile column of the matrix kernel, which would spend a whole tile column on it (one of
+// eleven at F = 161).  This kernel computes that column on the vector pipe: dx[b, t, F-1, n] = gate . sum_{kw, k} dyU[b, t+kw-1, F-2, k]
+// W[tap kw][k][n] with dy in exact fp32 and W re-assembled from its prepared pieces (two fp16 pieces / scale, or three bf16 pieces: the same
+// weight values the matrix kernel multiplies with).  A workgroup: EDGE_PIX rows t of one sample, all n.
+constexpr int EDGE_PIX = 8;
+template <int NP>
+__global__ __launch_bounds__(256) void conv_dgrad_edge_kernel(ConvX3P p) {
+    const int N = p.g.Cout, K = p.g.Cin, T = p.g.T, F = p.g.F, Tp = p.g.Tp, Fp = p.g.Fp;
+    const int b = blockIdx.y, t0 = blockIdx.x * EDGE_PIX, tid = threadIdx.x;
+    const int task = b / p.Bt;
+    int rows = T;
+    if (p.widths) rows = min(T, ((p.widths[task] >> p.wshift) + 7) / 8 * 8);       // as the matrix kernel: whole 8-row tile rows of the task's frames
+    if (t0 >= rows) return;
+    extern __shared__ float src[];                                                // [EDGE_PIX + 2][K]: un-pooled dy at column F - 2
+    const int fs = F - 2, fp = fs >> 1;
+    for (int e = tid; e < (EDGE_PIX + 2) * K; e += 256) {
+        const int r = e / K, k = e - r * K, ts = t0 + r - 1, tp = ts >> 1;
+        float v = 0.f;
+        if (ts >= 0 && ts < T && tp < Tp && fp < Fp) {
+            const long o = (((long)b * Tp + tp) * Fp + fp) * K + k;
+            const unsigned sub = (unsigned)(((fs & 1) << 1) | (ts & 1));
+            v = p.am_in[o] == sub ? p.x[o] : 0.f;
+        }
+        src[e] = v;
+    }
+    __syncthreads();
+    const unsigned short* w = reinterpret_cast<const unsigned short*>(p.w3 + task * p.sW);
+    const int nk = 9 * (K / 32);
+    const float inv_sw = NP == 2 ? 1.f / *reinterpret_cast<const float*>(p.w3 + task * p.sW + (long)NP * nk * N * 64) : 1.f;
+    const int groups = 256 / N, n = tid % N, grp = tid / N, ppg = EDGE_PIX / groups;          // N = 64: 4 groups x 2 rows; N = 128: 2 x 4
+    float acc[EDGE_PIX] = {};
+    for (int kw = 0; kw < 3; ++kw)                                                 // taps kh = 0 (source column f - 1), kw = 0 .. 2 (rows t - 1 .. t + 1)
+        for (int kc = 0; kc < K / 32; ++kc) {
+            const unsigned short* row = w + (((long)kw * (K / 32) + kc) * N + n) * 32;
+            for (int kk = 0; kk < 32; ++kk) {
+                const int o = x3_swz(kk, n);
+                float wv = 0.f;
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    const unsigned short bits = row[(long)q * nk * N * 32 + o];
+                    wv += NP == 2 ? (float)__builtin_bit_cast(_Float16, bits) : __builtin_bit_cast(float, (unsigned)bits << 16);
+                }
+                const int k = kc * 32 + kk;
+#pragma unroll
+                for (int i = 0; i < EDGE_PIX; ++i)
+                    if (i < ppg) acc[i] += src[(grp * ppg + i + kw) * K + k] * wv;
+            }
+        }
+    float mx = 0.f;
+    for (int i = 0; i < ppg; ++i) {
+        const int t = t0 + grp * ppg + i;
+        if (t >= T) break;
+        const long o = (((long)b * T + t) * F + (F - 1)) * N + n;
+        const float v = p.act[o] > 0.f ? acc[i] * inv_sw : 0.f;
+        p.y[o] = v;
+        mx = fmaxf(mx, fabsf(v));
+    }
+    if (p.amax_out) amax_raise(p.amax_out + task * p.sAmaxOut, mx);
+}
+
 template <int NP>
 static int conv_dgrad_pieces(hipStream_t s, const float* dy, const float* amax_dy, const unsigned char* argmax, const void* w,
                              const float* act, float* dx, float* amax_dx, int B, int T, int F, int Cin, int Cout,
@@ -2555,8 +2617,18 @@ static int conv_dgrad_pieces(hipStream_t s, const float* dy, const float* amax_d
     p.amax_in = amax_dy;
     p.amax_out = amax_dx;
     set_tasks(p, B, tk);
-    if (argmax) return dispatch_conv_x3<true, EPI_DGRAD, NP>(p, T, F, s);
-    return dispatch_conv_x3<false, EPI_DGRAD, NP>(p, T, F, s);
+    if (!argmax) return dispatch_conv_x3<false, EPI_DGRAD, NP>(p, T, F, s);
+    // odd width under a pooled source: the matrix kernel covers columns [0, F - 1), the last column goes to the edge kernel
+#ifndef MTL_DGRAD_EDGE
+#define MTL_DGRAD_EDGE 1     // (0: probe builds for A/B runs -- the matrix kernel spends a tile column on the last frequency bin)
+#endif
+    const bool edge = MTL_DGRAD_EDGE && (F & 1) && F >= 3 && (Cin == 64 || Cin == 128) && Cout % 32 == 0 && B * tk.tasks <= 65535;
+    const int rc = dispatch_conv_x3<true, EPI_DGRAD, NP>(p, T, edge ? F - 1 : F, s);
+    if (rc != MTL_OK || !edge) return rc;
+    hipLaunchKernelGGL(conv_dgrad_edge_kernel<NP>, dim3((T + EDGE_PIX - 1) / EDGE_PIX, B * tk.tasks), dim3(256), (EDGE_PIX + 2) * Cout * sizeof(float),
+                       s, p);
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
 }
 
 extern "C" {

@@ -1672,16 +1672,8 @@ class PassEngine:
                 self.colsum(dp1[sl].data_ptr(), B * T2 * F2, 64, g('conv.2.bias', t), am_(5, t))
             if wg:
                 wgrad(t, y1[sl].data_ptr(), 0, dp1[sl].data_ptr(), 5, am1_t, 2, B, T, F, 64, 64, db=g('conv.2.bias', t) if f2 else None)
-            # (conv2's data gradient stays one launch per task: 8 x 16 tiles, measured no faster merged)
-            if skip is not None and x3_only:
-                check(lib.mtl_conv3x3_dgrad_x3_tb(st, dp1[sl].data_ptr(), am1_t, A['wd2'][tw].data_ptr(), y1[sl].data_ptr(),
-                                                  dy1[sl].data_ptr(), B, T, F, 64, 64, 1, 0, skip + 4 * t, 0), 'dgrad2')
-            elif skip is not None:      # ... through the several-task entry point with ONE task: it takes the task's own frame count
-                check(lib.mtl_conv3x3_dgrad_h2_tb(st, dp1[sl].data_ptr(), am_(5, t), am1_t, A['wd2'][tw].data_ptr(), y1[sl].data_ptr(),
-                                                  dy1[sl].data_ptr(), None, B, T, F, 64, 64, 1, 0, 0, 0, skip + 4 * t, 0), 'dgrad2')
-            else:
-                check(conv_dgrad(t, dp1[sl].data_ptr(), 5, am1_t, A['wd2'][tw].data_ptr(), y1[sl].data_ptr(), dy1[sl].data_ptr(),
-                                 B, T, F, 64, 64), 'dgrad2')
+            check(conv_dgrad(t, dp1[sl].data_ptr(), 5, am1_t, A['wd2'][tw].data_ptr(), y1[sl].data_ptr(), dy1[sl].data_ptr(),
+                             B, T, F, 64, 64), 'dgrad2')
             if w0:
                 ws = self.scratch(lib.mtl_conv0_wgrad_workspace())
                 check(lib.mtl_conv0_wgrad(st, xin.data_ptr() + 4 * t * sX, dy1[sl].data_ptr(), g('conv.0.weight', t), g('conv.0.bias', t),
@@ -1721,8 +1713,14 @@ class PassEngine:
                                                   am_(5) if f2 else None, B, T2, F2, 64, 128, nt, swd('wd5'), AS, AS, skip, 1), 'dgrad5')
             tails_b(dp1, T2, F2 * 64, 1)
             wgrad_tb(y1.data_ptr(), 0, dp1.data_ptr(), 5, A['am1'].data_ptr(), 2, T, F, 64, 64, g('conv.2.bias'))
-            for t in range(nt):       # (conv2's data gradient merged as well: 52.23 / 52.63 / 52.83 against 52.03 / 52.18 / 52.92 ms per step: no gain)
-                layer2(t, wg=False, w0=False)
+            # conv2's data gradient: one launch for all tasks too (its matrix kernel covers the even part of the 161-bin axis, the last
+            # column goes to the edge kernel: csrc/mtl_mfma.hip conv_dgrad_edge_kernel)
+            if x3_only:
+                check(lib.mtl_conv3x3_dgrad_x3_tb(st, dp1.data_ptr(), A['am1'].data_ptr(), A['wd2'].data_ptr(), y1.data_ptr(), dy1.data_ptr(),
+                                                  B, T, F, 64, 64, nt, swd('wd2'), skip, 0), 'dgrad2')
+            else:
+                check(lib.mtl_conv3x3_dgrad_h2_tb(st, dp1.data_ptr(), am_(5), A['am1'].data_ptr(), A['wd2'].data_ptr(), y1.data_ptr(),
+                                                  dy1.data_ptr(), None, B, T, F, 64, 64, nt, swd('wd2'), AS, 0, skip, 0), 'dgrad2')
             tails_b(dy1, T, F * 64, 0)
             ws = self.scratch(lib.mtl_conv0_wgrad_workspace())
             check(lib.mtl_conv0_wgrad_tb(st, xin.data_ptr(), dy1.data_ptr(), g('conv.0.weight'), g('conv.0.bias'), ws, B, T, F, nt, sX, sG, sG),

@@ -15,3 +15,6 @@ $H --offload-arch=gfx950 -shared -fPIC $(ls $C/build/*.o | grep -v "/mtl_gemm_x3
 # the 3x3 convolution consumers on 32 x 32 x 16 instructions (the round-3 form) for A/B runs: MTL_LIB=tools/probe/libmtl_m32.so
 $H --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DX3H_M16=0 -c $C/mtl_mfma.hip -o /tmp/mtl_mfma_m32.o
 $H --offload-arch=gfx950 -shared -fPIC $(ls $C/build/*.o | grep -v "/mtl_mfma.o") /tmp/mtl_mfma_m32.o -o tools/probe/libmtl_m32.so
+# conv2's data gradient without the edge-column kernel (the matrix kernel covers all 161 bins) for A/B runs: MTL_LIB=tools/probe/libmtl_noedge.so
+$H --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DMTL_DGRAD_EDGE=0 -c $C/mtl_mfma.hip -o /tmp/mtl_mfma_noedge.o
+$H --offload-arch=gfx950 -shared -fPIC $(ls $C/build/*.o | grep -v "/mtl_mfma.o") /tmp/mtl_mfma_noedge.o -o tools/probe/libmtl_noedge.so
