@@ -857,6 +857,7 @@ def main():
         env = dict(os.environ)
         env.setdefault('OMP_NUM_THREADS', '1')           # (torchrun would set it, with a warning on stderr)
         env['MTL_BENCH_LAUNCHER'] = 'self'
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # (the host driver only supports dmabuf IPC: RCCL across processes needs it)
         raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
     # stdout carries ONE line, rank 0's JSON: everything else any library writes to file descriptor 1 (gloo's C++ "[Gloo] Rank 0 is

@@ -110,8 +110,26 @@ class _DecodeSession:
         self.P = theta.data_ptr()
         buf = eng.buf
         self.x = buf('g.x', (B, d))
-        self.kc = [buf('g.kc%d' % i, (B, S, hk)) for i in range(hp.n_dec)]
-        self.vc = [buf('g.vc%d' % i, (B, S, hv)) for i in range(hp.n_dec)]
+        # fast path (head sizes of the fused attention kernel, h d_k = h d_v): q / k / v of a layer's self-attention live in ONE (3, B, S, h d_k)
+        # block -- row t of [0] is the current query, [1] / [2] are the K / V caches -- so that the three low-rank projections are two
+        # strided-batch launches writing row t, and the attention over the cache is ONE flash-attention launch (keys beyond the current
+        # position masked by a per-step length: row t of `klen_self`) instead of product + softmax + product
+        self.fast = bool(eng.fused_attn and hk == hv and hp.n_dec > 0 and
+                         eng._qkv_groups('decoder.layers.0.self_attn.', 1, 1, 1, 1, hk, hv)[0][0] == 'qkv')
+        if self.fast:
+            self.qkv = [buf('g.qkv%d' % i, (3, B, S, hk)) for i in range(hp.n_dec)]
+            for c in self.qkv:
+                eng.zero_(c)                                        # (masked keys are multiplied by probability 0: they must be finite)
+            self.kc, self.vc = [c[1] for c in self.qkv], [c[2] for c in self.qkv]
+            self.ta3 = buf('g.ta3', (3, B, r))
+            self.klen_self = buf('g.klen', (S, B), torch.int32)
+            self.klen_self.copy_(torch.arange(1, S + 1, dtype=torch.int32).view(S, 1).expand(S, B))
+            self.klen_cross = buf('g.klenx', (B,), torch.int32)
+            self.klen_cross.fill_(T4)
+            self.lse = buf('g.lse', (B, h, 1))
+        else:
+            self.kc = [buf('g.kc%d' % i, (B, S, hk)) for i in range(hp.n_dec)]
+            self.vc = [buf('g.vc%d' % i, (B, S, hv)) for i in range(hp.n_dec)]
         Bm = 1 if shared_memory else B
         self.cross_stride = 0 if shared_memory else T4
         self.ck = [buf('g.ck%d' % i, (Bm * T4, hk)) for i in range(hp.n_dec)]
@@ -168,26 +186,42 @@ class _DecodeSession:
             pre = 'decoder.layers.%d.' % i
             o = lambda n: P + 4 * L.off(pre + n)
             sa = pre + 'self_attn.'
-            self._lowrank(sa, 'query', cur.data_ptr(), B, self.tq.data_ptr())
-            self._lowrank(sa, 'key', cur.data_ptr(), B, self.kc[i].data_ptr() + 4 * t * hk, ldc=S * hk)      # row t of the cache
-            self._lowrank(sa, 'value', cur.data_ptr(), B, self.vc[i].data_ptr() + 4 * t * hv, ldc=S * hv, width=hv)
-            self._attend(self.tq.data_ptr(), self.kc[i].data_ptr(), self.vc[i].data_ptr(), t + 1, S * hk, self.to.data_ptr())
+            if self.fast:
+                sA_, sB_, sb_ = (eng._pstride(sa, 'qkv', sfx) for sfx in ('_linear_a.weight', '_linear_b.weight', '_linear_b.bias'))
+                qkv = self.qkv[i].data_ptr()
+                eng.gemm(0, 1, B, hp.r, d, cur.data_ptr(), d, o('self_attn.query_linear_a.weight'), d, self.ta3.data_ptr(), hp.r, batch=3,
+                         sB=(sA_, 0), sC=(B * hp.r, 0))
+                eng.gemm(0, 1, B, hk, hp.r, self.ta3.data_ptr(), hp.r, o('self_attn.query_linear_b.weight'), hp.r, qkv + 4 * t * hk, S * hk,
+                         bias=o('self_attn.query_linear_b.bias'), batch=3, sA=(B * hp.r, 0), sB=(sB_, 0), sC=(B * S * hk, 0), sbias=sb_)
+                check(lib.mtl_attn_fwd(eng.stream, qkv + 4 * t * hk, self.kc[i].data_ptr(), self.vc[i].data_ptr(), S * hk, hk, hv,
+                                       self.klen_self.data_ptr() + 4 * t * B, 0, 1.0 / float(hp.temperature), B, hp.h, 1, S, hp.dk, hp.dv, None, 0,
+                                       1.0, self.to.data_ptr(), hv, self.lse.data_ptr()), 'mtl_attn_fwd')
+            else:
+                self._lowrank(sa, 'query', cur.data_ptr(), B, self.tq.data_ptr())
+                self._lowrank(sa, 'key', cur.data_ptr(), B, self.kc[i].data_ptr() + 4 * t * hk, ldc=S * hk)      # row t of the cache
+                self._lowrank(sa, 'value', cur.data_ptr(), B, self.vc[i].data_ptr() + 4 * t * hv, ldc=S * hv, width=hv)
+                self._attend(self.tq.data_ptr(), self.kc[i].data_ptr(), self.vc[i].data_ptr(), t + 1, S * hk, self.to.data_ptr())
             self._lowrank(sa, 'output', self.to.data_ptr(), B, self.tob.data_ptr(), width=d)
             eng.ln_fwd(self.tob.data_ptr(), cur.data_ptr(), o('self_attn.layer_norm.weight'), o('self_attn.layer_norm.bias'), None, None,
                        self.y1.data_ptr(), self.xhat.data_ptr(), self.rstd.data_ptr(), B, 1)
             ca = pre + 'encoder_attn.'
             self._lowrank(ca, 'query', self.y1.data_ptr(), B, self.tq.data_ptr())
-            self._attend(self.tq.data_ptr(), self.ck[i].data_ptr(), self.cv[i].data_ptr(), T4, self.cross_stride * hk, self.to.data_ptr())
+            if self.fast and self.cross_stride:      # (every row has its own memory: greedy search; beam search shares one with stride 0)
+                check(lib.mtl_attn_fwd(eng.stream, self.tq.data_ptr(), self.ck[i].data_ptr(), self.cv[i].data_ptr(), hk, hk, hv,
+                                       self.klen_cross.data_ptr(), 0, 1.0 / float(hp.temperature), B, hp.h, 1, T4, hp.dk, hp.dv, None, 0, 1.0,
+                                       self.to.data_ptr(), hv, self.lse.data_ptr()), 'mtl_attn_fwd')
+            else:
+                self._attend(self.tq.data_ptr(), self.ck[i].data_ptr(), self.cv[i].data_ptr(), T4, self.cross_stride * hk, self.to.data_ptr())
             self._lowrank(ca, 'output', self.to.data_ptr(), B, self.tob.data_ptr(), width=d)
             eng.ln_fwd(self.tob.data_ptr(), self.y1.data_ptr(), o('encoder_attn.layer_norm.weight'), o('encoder_attn.layer_norm.bias'), None,
                        None, self.y2.data_ptr(), self.xhat.data_ptr(), self.rstd.data_ptr(), B, 1)
             eng.linear_fwd(self.y2.data_ptr(), B, d, o('pos_ffn.linear_1.weight'), o('pos_ffn.linear_1.bias'), self.h1.data_ptr(), hp.inner,
                            relu=True)
             eng.linear_fwd(self.h1.data_ptr(), B, hp.inner, o('pos_ffn.linear_2.weight'), o('pos_ffn.linear_2.bias'), self.h2.data_ptr(), d)
+            nxt = self.cur[i & 1]                  # (the layer's output lands where the next layer reads it: no copy)
             eng.ln_fwd(self.h2.data_ptr(), self.y2.data_ptr(), o('pos_ffn.layer_norm.weight'), o('pos_ffn.layer_norm.bias'), None, None,
-                       self.y3.data_ptr(), self.xhat.data_ptr(), self.rstd.data_ptr(), B, 1)
-            cur = self.cur[i & 1]
-            check(lib.mtl_copy_f32(eng.stream, cur.data_ptr(), self.y3.data_ptr(), B * d), 'copy')
+                       nxt.data_ptr(), self.xhat.data_ptr(), self.rstd.data_ptr(), B, 1)
+            cur = nxt
         eng.gemm(0, 1, B, V, d, cur.data_ptr(), d, P + 4 * L.off('decoder.output_linear.weight'), d, self.logits.data_ptr(), V)
         return self.logits
 

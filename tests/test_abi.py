@@ -128,3 +128,21 @@ def test_product_routing_is_a_pure_host_decision(built):
     assert L.mtl_lstm_stack_supported(20, 256, 3) == 1 and L.mtl_lstm_stack_supported(20, 128, 5) == 0
     assert L.mtl_lstm_stack_scratch(35, 20, 512, 2) == 35 * 64 * 20 * 512 * 4 and L.mtl_lstm_stack_scratch(35, 20, 512, 1) == 0
     assert L.mtl_lstm_layer_workspace() >= 4096
+
+
+def test_mtl_lib_selects_another_build_of_the_same_abi(tmp_path):
+    """MTL_LIB: the package loads the library at that path (A/B runs against the probe builds) and still checks its ABI hash"""
+    import shutil
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    built = os.path.join(root, 'meta-transfer-learning_amd', 'libmtl_hip.so')
+    other = str(tmp_path / 'libmtl_other.so')
+    shutil.copy(built, other)
+    code = ("import sys; sys.path.insert(0, %r); import mtl_amd; L = mtl_amd._lib.lib(); "
+            "assert mtl_amd._lib.LIB_PATH == %r and L.mtl_abi_version() == mtl_amd._lib.ABI_VERSION; "
+            "print(open('/proc/self/maps').read().count('libmtl_other.so') > 0)" % (root, other))
+    r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, MTL_LIB=other), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith('True'), r.stderr[-2000:]
+    r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, MTL_LIB=str(tmp_path / 'missing.so')), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0                              # a missing library fails loudly: no fallback

@@ -417,3 +417,76 @@ def test_schedule_choice_for_batches_of_different_widths():
     assert not tr._can_batch(model, [batch(2, 64)], val)                      # one task: a lane
     tr.batch_ragged = False
     assert tr._can_batch(model, [batch(2, 64), batch(2, 64)], val) and not tr._can_batch(model, [batch(2, 64), batch(2, 40)], val)
+
+
+def test_environment_switches_are_the_documented_ones():
+    """Every MTL_* variable the package reads is in INTEGRATION.md's table and is flipped by a test; nothing else is read (round 5 had
+    58 of them, most left over from experiments that lost -- every one an untested configuration of a loop people run for days)."""
+    import glob
+    import re
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(ROOT, 'meta-transfer-learning_amd')
+    read = set()
+    for path in glob.glob(os.path.join(pkg, '*.py')):
+        src = open(path).read()
+        read |= set(re.findall(r"environ\.get\(\s*'(MTL_[A-Z0-9_]+)'", src)) | set(re.findall(r"environ\[\s*'(MTL_[A-Z0-9_]+)'", src))
+    for path in glob.glob(os.path.join(pkg, 'csrc', '*')):
+        if path.endswith(('.hip', '.h', '.inc')):
+            assert 'getenv' not in open(path).read(), path          # the library reads no environment at all
+    doc = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    table = set(re.findall(r"^\| `(MTL_[A-Z0-9_]+)` \|", doc, flags=re.M))
+    assert read == table, (sorted(read - table), sorted(table - read))
+    assert len(read) <= 15
+    # where each one is flipped (file: a test that sets it, by the environment or through the attribute it initialises)
+    flipped_in = {
+        'MTL_CONV': 'tests/test_parity_gpu.py', 'MTL_BATCH_TASKS': 'tests/test_batched_gpu.py', 'MTL_TASK_LANES': 'tests/test_host.py',
+        'MTL_PIPELINE_DEPTH': 'tests/test_trainer_gpu.py', 'MTL_POOL_GB': 'tests/test_parity_gpu.py', 'MTL_RAGGED_FILL': 'tests/test_host.py',
+        'MTL_RAGGED_QUANTUM': 'tests/test_batched_gpu.py', 'MTL_CHUNKED_ALLREDUCE': 'tests/test_dist_gloo.py', 'MTL_DIST_BACKEND': 'tests/test_parity_gpu.py',
+        'MTL_DIST_ALWAYS': 'tests/test_trainer_gpu.py', 'MTL_HOST_THREADS': 'tests/test_hostenv.py', 'MTL_LIB': 'tests/test_abi.py',
+        'MTL_TRACE_PHASES': 'tests/test_host.py'}
+    attr = {'MTL_CONV': 'conv_mode', 'MTL_BATCH_TASKS': 'batch_tasks', 'MTL_TASK_LANES': 'n_lanes', 'MTL_PIPELINE_DEPTH': 'pipeline',
+            'MTL_RAGGED_FILL': 'ragged_fill', 'MTL_RAGGED_QUANTUM': 'ragged_quantum'}
+    assert set(flipped_in) == read
+    for var, path in flipped_in.items():
+        text = open(os.path.join(ROOT, path)).read()
+        assert var in text or attr.get(var, '\0') in text, (var, path)
+
+
+def test_switches_read_at_construction(monkeypatch):
+    """the trainer-side switches: environment -> attribute, and MTL_TRACE_PHASES / MTL_RAGGED_FILL change behaviour"""
+    import importlib
+    import types
+    import mtl_amd
+    monkeypatch.setenv('MTL_BATCH_TASKS', '0')
+    monkeypatch.setenv('MTL_PIPELINE_DEPTH', '0')
+    monkeypatch.setenv('MTL_RAGGED_FILL', '0.9')
+    monkeypatch.setenv('MTL_RAGGED_QUANTUM', '16')
+    tr = mtl_amd.TransientTrainer()
+    assert tr.batch_tasks is False and tr.pipeline is False and tr.pipeline_depth == 0 and tr.ragged_fill == 0.9 and tr.ragged_quantum == 16
+    assert tr._turns() == 2
+    model = types.SimpleNamespace(engines=[types.SimpleNamespace(fused_attn=True)])
+    batch = lambda k, T: (torch.zeros(k, 1, 161, T),)
+    tr.batch_tasks = True
+    assert not tr._can_batch(model, [batch(2, 64), batch(2, 40)], batch(2, 50))       # fill 0.81 < 0.9: lanes
+    monkeypatch.delenv('MTL_PIPELINE_DEPTH')
+    assert mtl_amd.TransientTrainer().pipeline_depth == 2
+    # MTL_TASK_LANES: engines (stream + buffers) a model keeps for the lane schedule
+    z, cfg, spec = gu.load('F0')
+    from tests.test_parity_gpu import make
+    monkeypatch.setenv('MTL_TASK_LANES', '3')
+    assert make(cfg, spec)[3].n_lanes == 3
+    monkeypatch.delenv('MTL_TASK_LANES')
+    assert make(cfg, spec)[3].n_lanes == 8
+    from mtl_amd import _trace
+    monkeypatch.setenv('MTL_TRACE_PHASES', '1')
+    try:
+        importlib.reload(_trace)
+        assert _trace.ON
+        _trace.begin()
+        _trace.mark('x')
+        _trace.end()
+        assert _trace.steps and 'x' in _trace.steps[-1]
+    finally:
+        monkeypatch.delenv('MTL_TRACE_PHASES')
+        importlib.reload(_trace)
+    assert not _trace.ON
