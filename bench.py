@@ -844,6 +844,7 @@ def main():
     ap.add_argument('--serial', action='store_true', help='no task lanes / side stream / replay (for rocprofv3 per-kernel durations)')
     ap.add_argument('--host-inputs', action='store_true', help='diagnostics: the headline region with every batch uploaded from pinned host memory per step (what the `with_h2d` leg measures)')
     ap.add_argument('--ragged', action='store_true', help='diagnostics: the headline region on manifest-like batches (every batch padded to its own longest utterance of 0.6 ... 1.0 x --frames, new shapes every step)')
+    ap.add_argument('--eval-only', action='store_true', help='only the `eval` leg (validation-loop forward + greedy decoding), for rocprofv3')
     ap.add_argument('--workload', default='asr', choices=['asr', 'lm'], help="'lm': the LSTM-LM meta loop (BASELINE.json configs[4], SURVEY 8(f) f3)")
     a = ap.parse_args()
 
@@ -903,6 +904,10 @@ def main():
         trainer.pipeline = False
         for e in model.engines:
             e.use_side_stream = False
+    if a.eval_only:
+        ev = eval_leg(mtl_amd, trainer, model, vocab, args, a.k, a.frames, a.labels, dev)
+        emit(dict(metric='eval utterances/sec (greedy decode)', value=ev['greedy_decode']['utt_per_s'], unit='utt/s', n_gpus=1, data='synthetic', eval=ev))
+        return
     inner, outer = mtl_amd.FlatSGD(model, args.lr), mtl_amd.FlatAdam(model, args.meta_lr)
     model.zero_copy_grad()
     tasks = [ResidentTask(mtl_amd, m, a.k, a.frames, a.labels, CFG['vocab_size'], dev) for m in range(a.tasks)]

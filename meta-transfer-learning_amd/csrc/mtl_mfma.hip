@@ -2552,16 +2552,44 @@ static int conv_fwd_pieces(hipStream_t s, const float* x, const float* amax_x, c
 // eleven at F = 161).  This kernel computes that column on the vector pipe: dx[b, t, F-1, n] = gate . sum_{kw, k} dyU[b, t+kw-1, F-2, k]
 // W[tap kw][k][n] with dy in exact fp32 and W re-assembled from its prepared pieces (two fp16 pieces / scale, or three bf16 pieces: the same
 // weight values the matrix kernel multiplies with).  A workgroup: EDGE_PIX rows t of one sample, all n.
-constexpr int EDGE_PIX = 8;
+constexpr int EDGE_PIX = 32;                   // rows t per workgroup (the re-assembled weights are staged once per workgroup)
+constexpr int EDGE_C = 64;                     // channels on both sides (conv2: 64 -> 64, the only odd-width pooled layer of the path)
+constexpr int EDGE_SMEM = (3 * EDGE_C * EDGE_C + (EDGE_PIX + 2) * EDGE_C) * 4;
 template <int NP>
 __global__ __launch_bounds__(256) void conv_dgrad_edge_kernel(ConvX3P p) {
-    const int N = p.g.Cout, K = p.g.Cin, T = p.g.T, F = p.g.F, Tp = p.g.Tp, Fp = p.g.Fp;
+    constexpr int N = EDGE_C, K = EDGE_C;
+    const int T = p.g.T, F = p.g.F, Tp = p.g.Tp, Fp = p.g.Fp;
     const int b = blockIdx.y, t0 = blockIdx.x * EDGE_PIX, tid = threadIdx.x;
     const int task = b / p.Bt;
     int rows = T;
     if (p.widths) rows = min(T, ((p.widths[task] >> p.wshift) + 7) / 8 * 8);       // as the matrix kernel: whole 8-row tile rows of the task's frames
     if (t0 >= rows) return;
-    extern __shared__ float src[];                                                // [EDGE_PIX + 2][K]: un-pooled dy at column F - 2
+    extern __shared__ __attribute__((aligned(16))) float edge_lds[];
+    float* Ws = edge_lds;                                                          // [3 taps][K][N] fp32, re-assembled from the prepared pieces
+    float* src = edge_lds + 3 * K * N;                                             // [EDGE_PIX + 2][K]: un-pooled dy at column F - 2
+    const unsigned short* w = reinterpret_cast<const unsigned short*>(p.w3 + task * p.sW);
+    constexpr int nk = 9 * (K / 32);
+    const float inv_sw = NP == 2 ? 1.f / *reinterpret_cast<const float*>(p.w3 + task * p.sW + (long)NP * nk * N * 64) : 1.f;
+    // taps kh = 0 (source column f - 1), kw = 0 .. 2 (rows t - 1 .. t + 1): K-tiles kw * (K / 32) + kc; a K-tile row n holds 32 k (16-byte chunks, swizzled)
+#pragma unroll 1
+    for (int e = tid; e < 3 * (K / 32) * N * 4; e += 256) {
+        const int chunk = e & 3, n = (e >> 2) % N, kt = e / (4 * N);                // kt = kw * (K / 32) + kc
+        float v[8] = {};
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            const uint4 raw = *reinterpret_cast<const uint4*>(w + ((long)q * nk + kt) * N * 32 + n * 32 + chunk * 8);
+            const unsigned u[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const unsigned short bits = (unsigned short)(u[j >> 1] >> (16 * (j & 1)));
+                v[j] += NP == 2 ? (float)__builtin_bit_cast(_Float16, bits) : __builtin_bit_cast(float, (unsigned)bits << 16);
+            }
+        }
+        const int kk0 = ((chunk ^ ((n >> 2) & 3)) << 3);                            // x3_swz: chunk c of row n holds k = 8 (c ^ ((n >> 2) & 3)) ..
+        const int kw = kt / (K / 32), kc = kt - kw * (K / 32);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) Ws[(kw * K + kc * 32 + kk0 + j) * N + n] = v[j] * inv_sw;
+    }
     const int fs = F - 2, fp = fs >> 1;
     for (int e = tid; e < (EDGE_PIX + 2) * K; e += 256) {
         const int r = e / K, k = e - r * K, ts = t0 + r - 1, tp = ts >> 1;
@@ -2574,36 +2602,31 @@ __global__ __launch_bounds__(256) void conv_dgrad_edge_kernel(ConvX3P p) {
         src[e] = v;
     }
     __syncthreads();
-    const unsigned short* w = reinterpret_cast<const unsigned short*>(p.w3 + task * p.sW);
-    const int nk = 9 * (K / 32);
-    const float inv_sw = NP == 2 ? 1.f / *reinterpret_cast<const float*>(p.w3 + task * p.sW + (long)NP * nk * N * 64) : 1.f;
-    const int groups = 256 / N, n = tid % N, grp = tid / N, ppg = EDGE_PIX / groups;          // N = 64: 4 groups x 2 rows; N = 128: 2 x 4
-    float acc[EDGE_PIX] = {};
-    for (int kw = 0; kw < 3; ++kw)                                                 // taps kh = 0 (source column f - 1), kw = 0 .. 2 (rows t - 1 .. t + 1)
-        for (int kc = 0; kc < K / 32; ++kc) {
-            const unsigned short* row = w + (((long)kw * (K / 32) + kc) * N + n) * 32;
-            for (int kk = 0; kk < 32; ++kk) {
-                const int o = x3_swz(kk, n);
-                float wv = 0.f;
+    constexpr int PPG = EDGE_PIX / 4;                                              // 4 waves: wave g owns rows [g PPG, (g + 1) PPG), lane = n
+    const int n = tid & 63, grp = tid >> 6;
+    float acc[PPG] = {};
+#pragma unroll 1
+    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll 2
+        for (int k = 0; k < K; k += 4) {
+            const float w0 = Ws[(kw * K + k) * N + n], w1 = Ws[(kw * K + k + 1) * N + n], w2 = Ws[(kw * K + k + 2) * N + n],
+                        w3 = Ws[(kw * K + k + 3) * N + n];
 #pragma unroll
-                for (int q = 0; q < NP; ++q) {
-                    const unsigned short bits = row[(long)q * nk * N * 32 + o];
-                    wv += NP == 2 ? (float)__builtin_bit_cast(_Float16, bits) : __builtin_bit_cast(float, (unsigned)bits << 16);
-                }
-                const int k = kc * 32 + kk;
-#pragma unroll
-                for (int i = 0; i < EDGE_PIX; ++i)
-                    if (i < ppg) acc[i] += src[(grp * ppg + i + kw) * K + k] * wv;
+            for (int i = 0; i < PPG; ++i) {
+                const float4 sv = *reinterpret_cast<const float4*>(src + (grp * PPG + i + kw) * K + k);      // (wave-uniform address: broadcast)
+                acc[i] += sv.x * w0 + sv.y * w1 + sv.z * w2 + sv.w * w3;
             }
         }
     float mx = 0.f;
-    for (int i = 0; i < ppg; ++i) {
-        const int t = t0 + grp * ppg + i;
-        if (t >= T) break;
-        const long o = (((long)b * T + t) * F + (F - 1)) * N + n;
-        const float v = p.act[o] > 0.f ? acc[i] * inv_sw : 0.f;
-        p.y[o] = v;
-        mx = fmaxf(mx, fabsf(v));
+#pragma unroll
+    for (int i = 0; i < PPG; ++i) {
+        const int t = t0 + grp * PPG + i;
+        if (t < rows) {
+            const long o = (((long)b * T + t) * F + (F - 1)) * N + n;
+            const float v = p.act[o] > 0.f ? acc[i] : 0.f;
+            p.y[o] = v;
+            mx = fmaxf(mx, fabsf(v));
+        }
     }
     if (p.amax_out) amax_raise(p.amax_out + task * p.sAmaxOut, mx);
 }
@@ -2622,11 +2645,12 @@ static int conv_dgrad_pieces(hipStream_t s, const float* dy, const float* amax_d
 #ifndef MTL_DGRAD_EDGE
 #define MTL_DGRAD_EDGE 1     // (0: probe builds for A/B runs -- the matrix kernel spends a tile column on the last frequency bin)
 #endif
-    const bool edge = MTL_DGRAD_EDGE && (F & 1) && F >= 3 && (Cin == 64 || Cin == 128) && Cout % 32 == 0 && B * tk.tasks <= 65535;
+    const bool edge = MTL_DGRAD_EDGE && (F & 1) && F >= 3 && Cin == EDGE_C && Cout == EDGE_C && B * tk.tasks <= 65535;
     const int rc = dispatch_conv_x3<true, EPI_DGRAD, NP>(p, T, edge ? F - 1 : F, s);
     if (rc != MTL_OK || !edge) return rc;
-    hipLaunchKernelGGL(conv_dgrad_edge_kernel<NP>, dim3((T + EDGE_PIX - 1) / EDGE_PIX, B * tk.tasks), dim3(256), (EDGE_PIX + 2) * Cout * sizeof(float),
-                       s, p);
+    static int attr = set_smem(conv_dgrad_edge_kernel<NP>, EDGE_SMEM);
+    if (attr) return attr;
+    hipLaunchKernelGGL(conv_dgrad_edge_kernel<NP>, dim3((T + EDGE_PIX - 1) / EDGE_PIX, B * tk.tasks), dim3(256), EDGE_SMEM, s, p);
     MTL_CHECK_LAUNCH();
     return MTL_OK;
 }

@@ -1,10 +1,10 @@
 #!/bin/bash
-# Runs on the GPU box (via gpurun): collects the round's rocprofv3 summaries into gpurun_out/$ROUND (default r5; copied to profiles/$ROUND afterwards).
+# Runs on the GPU box (via gpurun): collects the round's rocprofv3 summaries into gpurun_out/$ROUND (default r6; copied to profiles/$ROUND afterwards).
 # usage: bash tools/collect_profiles.sh
 set -u
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/${ROUND:-r5}
+O=gpurun_out/${ROUND:-r6}
 mkdir -p $O
 # counter passes FIRST: bench.py reads profiles/pmc_traffic.json for `roofline.traffic` (per launch, so it must come from the same launch structure)
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras --serial > /dev/null 2>&1
@@ -23,9 +23,13 @@ python bench.py --tasks 1 --steps 30 --warmup 3 --no-cpu-baseline --no-extras 2>
 # manifest-like batches (every batch padded to its own longest utterance, new shapes every step): probe line + kernel stats
 mkdir -p $O/ragged
 python tools/probe/ragged_steps.py --mode ragged --steps 40 2> /dev/null | tail -1 > $O/ragged/ragged_stacked.json
-MTL_BATCH_RAGGED=0 MTL_PAD_LANES=0 python tools/probe/ragged_steps.py --mode ragged --steps 20 2> /dev/null | tail -1 > $O/ragged/ragged_lane_per_task_own_widths.json
-MTL_BATCH_RAGGED=0 python tools/probe/ragged_steps.py --mode ragged --steps 40 2> /dev/null | tail -1 > $O/ragged/ragged_lane_per_task_rounded_widths.json
+python tools/probe/ragged_steps.py --mode ragged --steps 20 --lanes --own-widths 2> /dev/null | tail -1 > $O/ragged/ragged_lane_per_task_own_widths.json
+python tools/probe/ragged_steps.py --mode ragged --steps 40 --lanes 2> /dev/null | tail -1 > $O/ragged/ragged_lane_per_task_rounded_widths.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ragged/trace -o ragged -- python tools/probe/ragged_steps.py --mode ragged --steps 6 > /dev/null 2>&1
+# f2: the validation loop's forward and greedy decoding (bench.py's `eval` leg) under the profiler
+mkdir -p $O/eval
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/eval/trace -o eval -- python bench.py --eval-only > $O/eval/bench_eval_traced.json 2> /dev/null
+python bench.py --eval-only 2> /dev/null | tail -1 > $O/eval/bench_eval.json
 # long-utterance configuration (BASELINE.json configs[3]): T = 5000
 python bench.py --frames 5000 --tasks 2 --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $O/bench_t5000.json 2> /dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/t5000 -o t5000 -- python bench.py --frames 5000 --tasks 1 --steps 1 --warmup 1 --no-cpu-baseline --no-extras --serial > $O/bench_t5000_serial_traced.json 2> /dev/null

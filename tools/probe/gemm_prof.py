@@ -1,6 +1,6 @@
 """Per-wave phase breakdown of the bf16-split tile engine's K step from s_memtime stamps inside the kernel (probe build only:
 hipcc -DMTL_X3G_PROF mtl_gemm_x3.hip, linked as tools/probe/libmtl_gprof.so; tools/probe/build_probes.sh).
-usage: MTL_LIB=tools/probe/libmtl_gprof.so [MTL_GEMM_X3_PINGPONG=0] python tools/probe/gemm_prof.py"""
+usage: MTL_LIB=tools/probe/libmtl_gprof.so python tools/probe/gemm_prof.py"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch

@@ -28,6 +28,8 @@ def main():
     ap.add_argument('--hi', type=int, default=1000)
     ap.add_argument('--labels', type=int, default=100)
     ap.add_argument('--mode', default='ragged')
+    ap.add_argument('--lanes', action='store_true', help='a lane per task instead of the stacked pass (trainer.batch_ragged = False)')
+    ap.add_argument('--own-widths', action='store_true', help='... at every batch\'s own width (trainer.pad_lanes = \'0\'): the reference\'s schedule')
     ap.add_argument('--vary-labels', action='store_true', help='label width of every batch drawn from labels / 2 ... labels')
     ap.add_argument('--hetero', type=float, default=1.0, help='task m draws its utterances from [lo, hi] scaled by hetero + (1 - hetero) m / (n - 1): corpora of different utterance lengths')
     a = ap.parse_args()
@@ -41,6 +43,10 @@ def main():
     with contextlib.redirect_stdout(io.StringIO()):
         model = mtl_amd.init_transformer_model(args, vocab, r=bench.CFG['r']).to(dev)
     trainer = mtl_amd.TransientTrainer()
+    if a.lanes:
+        trainer.batch_ragged = False
+    if a.own_widths:
+        trainer.pad_lanes = '0'
     inner, outer = mtl_amd.FlatSGD(model, args.lr), mtl_amd.FlatAdam(model, args.meta_lr)
     model.zero_copy_grad()
     sc = [a.hetero + (1 - a.hetero) * m / max(a.tasks - 1, 1) for m in range(a.tasks)]
