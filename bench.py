@@ -218,7 +218,9 @@ def classify(lib, name, a, conv_mode):
         route = lib.mtl_gemm_f32_ex_route(M, N, K, batch, kb, 1 if rs else 0) if name != 'mtl_gemm_f32' else 0
         if route == 2 and not (a[1] and a[2]):                # the bf16-split engine (the pass has no doubly transposed product)
             return 'gemm_x3', 2.0 * M * N * K * batch * kb, 'flop', 'gemm_x3_kernel<TA,TB,RS>'
-        small = route == 1
+        if route == 3 and not a[1] and a[2]:                  # few rows x every weight once (the decode session's products): weight streaming
+            return 'gemm_rows', 4.0 * batch * (N * K + M * K + M * N), 'byte', 'gemm_rows_kernel<8|16>'
+        small = route in (1, 3)
         return ('gemm_small' if small else 'gemm_big', 2.0 * M * N * K * batch * kb, 'flop',
                 'gemm16_kernel<...>' if small else 'gemm_kernel<...> (+ splitk_reduce_kernel)')
     if name == 'mtl_gemm_h2_tb':
@@ -375,7 +377,7 @@ def dump_shapes(records):
         if name in ('mtl_gemm_f32_ex', 'mtl_gemm_f32_tb'):
             route = sys.modules['mtl_amd']._lib.lib().mtl_gemm_f32_ex_route(a[3], a[4], a[5], a[17], a[26], 1 if a[29] else 0)
             key = 'gemm %-5s ta%d tb%d M%d N%d K%d b%d kb%d rs%d gflop %.2f' % (
-                {0: 'big', 1: 'small', 2: 'x3'}.get(route, '?'), a[1], a[2], a[3], a[4], a[5], a[17], a[26], 1 if a[29] else 0,
+                {0: 'big', 1: 'small', 2: 'x3', 3: 'rows'}.get(route, '?'), a[1], a[2], a[3], a[4], a[5], a[17], a[26], 1 if a[29] else 0,
                 2e-9 * a[3] * a[4] * a[5] * a[17] * a[26])
         elif name in ('mtl_attn_fwd', 'mtl_attn_bwd', 'mtl_layernorm_fwd', 'mtl_layernorm_bwd', 'mtl_layernorm_fwd_g', 'mtl_layernorm_bwd_g'):
             key = name + ' ' + ' '.join(str(v) for v in a if isinstance(v, int) and 0 <= v < 100000)

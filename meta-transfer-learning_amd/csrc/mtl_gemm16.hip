@@ -295,6 +295,95 @@ __global__ __launch_bounds__(256 * KG) void gemm16_kernel(G16P p0) {
 
 inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
+// ---- few-row products (incremental decoding: one new position of B hypotheses against every decoder weight, M = B rows) ----
+// C[M <= 16, N] (=|+=) alpha A[M, K] . W[N, K]^T (+ bias, ReLU): a weight-streaming product -- every weight is read once and multiplied
+// with all M rows.  The tile engine above pays a 32 x 32 MFMA tile and its K-group combine for it (~10 us); here a workgroup owns 16
+// output columns: a wave streams 4 weight rows with 16 lanes x 16 bytes each (256 contiguous bytes per row and step), A sits in LDS,
+// the 16 partial sums of a column meet by DPP shuffles.  Exact fp32 FMAs in a fixed order.
+constexpr int RW_COLS = 16, RW_KC = 1024;      // columns per workgroup; K chunk staged in LDS (16 rows x 1024 floats = 64 KiB)
+struct RowsP {
+    const float *A, *W;
+    float* C;
+    const float* bias;
+    int M, N, K, lda, ldw, ldc;
+    float alpha;
+    int flags;
+    long sA, sW, sC, sBias;
+};
+template <int MB>
+__global__ __launch_bounds__(256) void gemm_rows_kernel(RowsP p) {
+    extern __shared__ __attribute__((aligned(16))) float rows_lds[];              // [MB][min(K, RW_KC)] (row stride kc)
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, col = lane >> 4, j = lane & 15;
+    const int z = blockIdx.y;
+    const float* A = p.A + z * p.sA;
+    const float* W = p.W + z * p.sW;
+    const int n = blockIdx.x * RW_COLS + wv * 4 + col;
+    const float* wrow = W + (long)min(n, p.N - 1) * p.ldw;
+    float acc[MB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) acc[m] = 0.f;
+    for (int k0 = 0; k0 < p.K; k0 += RW_KC) {
+        const int kc = min(RW_KC, p.K - k0);                                      // (a multiple of 4)
+        if (k0) __syncthreads();
+        for (int e = tid * 4; e < MB * kc; e += 1024) {
+            const int m = e / kc, k = e - m * kc;
+            *reinterpret_cast<float4*>(rows_lds + e) =
+                m < p.M ? *reinterpret_cast<const float4*>(A + (long)m * p.lda + k0 + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int k = 4 * j; k < kc; k += 64) {
+            const float4 w4 = *reinterpret_cast<const float4*>(wrow + k0 + k);
+#pragma unroll
+            for (int m = 0; m < MB; ++m) {
+                const float4 a4 = *reinterpret_cast<const float4*>(rows_lds + m * kc + k);
+                acc[m] = fmaf(a4.w, w4.w, fmaf(a4.z, w4.z, fmaf(a4.y, w4.y, fmaf(a4.x, w4.x, acc[m]))));
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) acc[m] += __shfl_xor(acc[m], o, 64);      // the 16 lanes of a column: fixed tree
+    }
+    if (n < p.N) {
+        const float bb = p.bias ? p.bias[z * p.sBias + n] : 0.f;
+        float* C = p.C + z * p.sC;
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+            if (m == j && m < p.M) {                                              // lane j of a column writes row j
+                float x = p.alpha * acc[m] + bb;
+                if (p.flags & MTL_GEMM_RELU) x = fmaxf(x, 0.f);
+                float* c = C + (long)m * p.ldc + n;
+                *c = (p.flags & MTL_GEMM_ACCUM) ? *c + x : x;
+            }
+    }
+}
+
+static bool rows_ok(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb, const float* gate, int H,
+                    long sAb, long sBb, int kbatch, const float* rowsum, int tasks) {
+    return !transA && transB && M <= 16 && N >= 1 && kbatch == 1 && !rowsum && !gate && H == 1 && tasks == 1 && (K & 3) == 0 && (lda & 3) == 0 &&
+           (ldb & 3) == 0 && ((sAb | sBb) & 3) == 0 && al16(A) && al16(B);
+}
+
+static int launch_rows(hipStream_t s, const RowsP& p, int batch) {
+    const int kc = p.K < RW_KC ? p.K : RW_KC;
+    const dim3 grid((p.N + RW_COLS - 1) / RW_COLS, batch);
+    if (p.M <= 8) {
+        static int attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_rows_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              8 * RW_KC * 4) == hipSuccess ? 0 : MTL_ELAUNCH;
+        if (attr) return attr;
+        hipLaunchKernelGGL(gemm_rows_kernel<8>, grid, dim3(256), 8 * kc * 4, s, p);
+    } else {
+        static int attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_rows_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              16 * RW_KC * 4) == hipSuccess ? 0 : MTL_ELAUNCH;
+        if (attr) return attr;
+        hipLaunchKernelGGL(gemm_rows_kernel<16>, grid, dim3(256), 16 * kc * 4, s, p);
+    }
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}
+
 template <bool TA, bool TB, bool VEC, int KG, int WM, int WN>
 int launch_cfg(const G16P& p, int batch, hipStream_t s) {
     G16P q = p;
@@ -350,6 +439,8 @@ extern "C" {
 
 /* 1: this product runs on the small-tile engine (gemm16_kernel<...>), 0: it is forwarded to mtl_gemm_f32 (gemm_kernel<...>) */
 int mtl_gemm_f32_ex_route(int M, int N, int K, int batch, int kbatch, int has_rowsum) {
+    // (3: the few-row kernel, for an NT call with aligned operands, no gate and one batch level -- what the decode session issues)
+    if (M <= 16 && kbatch == 1 && !has_rowsum && (K & 3) == 0) return 3;
     if (mtl_gemm_x3_eligible(M, N, batch)) return 2;
     // (split-K form of the same engine: assumes an NN / NT / TN call with 16-byte aligned operands and a workspace that holds the slices)
     if (batch == 1 && kbatch == 1 && !has_rowsum && mtl_gemm_x3_splitk_slices(0, 0, M, N, K, 0, 1L << 40)) return 2;
@@ -364,6 +455,10 @@ int mtl_gemm_f32_tb(void* stream, int transA, int transB, int M, int N, int K, f
     if (M <= 0 || N <= 0 || K <= 0 || batch <= 0 || H <= 0 || kbatch <= 0 || tasks <= 0 || !A || !B || !C) return MTL_EINVAL;
     if (rowsum && !transA) return MTL_EINVAL;
     if (batch % tasks != 0 || (batch / tasks) % H != 0) return MTL_EINVAL;
+    if (rows_ok(transA, transB, M, N, K, A, lda, B, ldb, gate, H, sAb, sBb, kbatch, rowsum, tasks)) {
+        const RowsP rp{A, B, C, bias, M, N, K, lda, ldb, ldc, alpha, flags, sAb, sBb, sCb, sBias};
+        return launch_rows(as_stream(stream), rp, batch);
+    }
     {   // large products: the bf16-split engine (mtl_gemm_x3.hip)
         const int rc = mtl_gemm_x3_route(stream, transA, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, bias, gate, ldg, flags, batch, H,
                                          sAb, sAh, sBb, sBh, sCb, sCh, sBias, kbatch, sAk, sBk, rowsum, sRowsum, sBiasH, sRowsumH, tasks,

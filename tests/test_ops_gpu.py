@@ -195,6 +195,37 @@ def test_gemm_gate_and_batched_heads(L):
     assert rel(C, (A @ Bm) * (gate > 0)) < 2e-6
 
 
+@pytest.mark.parametrize('M,N,K,batch', [(8, 512, 512, 1), (8, 100, 512, 3), (8, 512, 100, 3), (8, 3765, 512, 1), (1, 64, 128, 1), (16, 37, 2052, 2),
+                                         (3, 16, 4, 1)])
+def test_gemm_few_rows_weight_streaming_kernel(L, M, N, K, batch):
+    """mtl_gemm_f32_ex with M <= 16 rows, NT (what a decode step issues against every decoder weight: gemm_rows_kernel): against fp64,
+    with bias + ReLU, accumulate, a strided batch with a leading dimension larger than N (rows of a K/V cache), bitwise repeatable; and the
+    route report says 3."""
+    g = torch.Generator().manual_seed(M * 1000 + N + K)
+    A = torch.randn(batch, M, K, generator=g)
+    W = torch.randn(batch, N, K, generator=g) / np.sqrt(K)
+    bias = torch.randn(batch, N, generator=g)
+    ldc = N + 12
+    C0 = torch.randn(batch, M, ldc, generator=g)
+    dA, dW, db = dev(A), dev(W), dev(bias)
+    assert L.mtl_gemm_f32_ex_route(M, N, K, batch, 1, 0) == 3
+    for flags in (0, 1, 2, 3):                            # RELU = 1, ACCUM = 2
+        outs = []
+        for _ in range(2):
+            C = dev(C0.clone())
+            assert L.mtl_gemm_f32_ex(st(), 0, 1, M, N, K, 0.5, dA.data_ptr(), K, dW.data_ptr(), K, C.data_ptr(), ldc, db.data_ptr(), None, 0, flags,
+                                     batch, 1, M * K, 0, N * K, 0, M * ldc, 0, N, 1, 0, 0, None, 0, None, 0, 0, 0) == 0
+            outs.append(C.cpu())
+        assert torch.equal(outs[0], outs[1])
+        ref = 0.5 * torch.einsum('zmk,znk->zmn', A.double(), W.double()) + bias.double()[:, None, :]
+        if flags & 1:
+            ref = ref.clamp_min(0)
+        if flags & 2:
+            ref = ref + C0[:, :, :N].double()
+        assert rel(outs[0][:, :, :N], ref) < 2e-6, flags
+        assert torch.equal(outs[0][:, :, N:], C0[:, :, N:])          # the columns beyond N (other rows' cache entries) are untouched
+
+
 @pytest.mark.parametrize('M,N,K,ta,tb', [(333, 100, 512, 0, 1), (512, 100, 700, 1, 0), (100, 512, 1999, 1, 0), (2000, 512, 100, 0, 1)])
 def test_gemm_strided_parameter_batch(L, M, N, K, ta, tb):
     """three products in one call (the Q/K/V projections: operands at a constant stride inside one flat buffer, per-item
