@@ -576,7 +576,7 @@ def h2_frac(trainer):
                 worst_operand=max(cen, key=lambda k_: cen[k_][0]), limit_lt16=trainer.h2_limit, sampled_every=trainer.h2_check_every)
 
 
-def eval_leg(mtl, trainer, model, vocab, args, k, frames, labels, dev, reps=3, decode_steps=300):
+def eval_leg(mtl, trainer, model, vocab, args, k, frames, labels, dev, reps=4, decode_steps=300):
     """SURVEY 8(f) f2, measured: (a) what the in-loop validation runs per batch (transient_trainer.py:280-331: eval mode, no autograd,
     `forward_one_batch` = teacher-forced pass + loss + CER strings) and (b) test-time greedy decoding (Transformer.evaluate ->
     Decoder.greedy_search, modules/decoder.py:131-185: the reference's 300 fixed steps, here K/V-cached with the token fed back

@@ -1436,12 +1436,39 @@ class PassEngine:
         memory, so the 300 steps run without a single host synchronisation.  Returns the (max_steps, B) int64 token ids."""
         if max_steps + 1 > self.hp.tgt_max_len:
             raise ValueError('tgt_max_len too small for %d decoding steps' % max_steps)
-        ses = self.decode_session(theta, mem, B, T4, max_steps + 1)
+        ses = self.decode_session(theta, mem, B, T4, max_steps + 1)          # (eager: cache zeroing, cross-attention keys / values)
         ys = self.buf('g.ys', (max_steps + 1, B), torch.int64)
         ys[0].fill_(int(start_token))
-        for t in range(max_steps):
-            ses.step(t, ys.data_ptr() + 8 * t * B)
-            ses.argmax_into(ys.data_ptr() + 8 * (t + 1) * B)
+
+        def steps():
+            for t in range(max_steps):
+                ses.step(t, ys.data_ptr() + 8 * t * B)
+                ses.argmax_into(ys.data_ptr() + 8 * (t + 1) * B)
+        # The ~64 launches of a step cost the host more (8 us each through ctypes) than the device (a decode was host-bound at 0.53 ms
+        # per step): the calls of all steps are recorded once per (parameters, shapes, buffers) into ONE command list -- every address is
+        # fixed: the session's buffers come from the pool by name and shape -- and replayed from C (first sighting: plain eager run,
+        # second: recorded, like TransientTrainer._run_recorded).
+        key = (theta.data_ptr(), int(mem), B, T4, max_steps, ys.data_ptr(), self.stream, self.scratch_epoch, ses.fast)
+        lists = self.__dict__.setdefault('_decode_lists', {})
+        ent = lists.get(key)
+        if self.prof is not None or isinstance(self.lib, _lib.Recorder):
+            steps()
+        elif ent is None:
+            while len(lists) >= 4:
+                lists.pop(next(iter(lists)))
+            lists[key] = 'warm'
+            steps()
+        elif ent == 'warm':
+            cl, real = _lib.CommandList(), self.lib
+            self.lib = _lib.Recorder(real, cl)
+            try:
+                steps()
+            finally:
+                self.lib = real
+            if key[7] == self.scratch_epoch:
+                lists[key] = cl.finish()
+        else:
+            ent.run()
         return ys[1:]
 
     def beam_decode(self, theta, mem_row, T4, start_token, beam_width, nbest, tgt_max_len, num_words, eos_id=EOS_ID, c_weight=1.0):

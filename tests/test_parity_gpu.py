@@ -712,6 +712,16 @@ def test_greedy_decoding_matches_oracle():
     _, hyps, golds = model.evaluate(x.cuda(), lens, y, args, start_token=vocab.SOS_ID, max_steps=steps)
     ref = R.greedy_search(oracle, x, lens, vocab.SOS_ID, steps)             # (B, steps)
     assert torch.equal(model.last_greedy_ids.t().contiguous(), ref)
+    # the steps of a decode are recorded into one command list at its second sighting and replayed from C afterwards: eager, recording and
+    # two replays give the same tokens; a decode of another length in between does not disturb the recorded one
+    for rep in range(3):
+        _, hyps_r, _ = model.evaluate(x.cuda(), lens, y, args, start_token=vocab.SOS_ID, max_steps=steps)
+        assert torch.equal(model.last_greedy_ids.t().contiguous(), ref) and hyps_r == hyps, rep
+        if rep == 1:
+            model.evaluate(x.cuda(), lens, y, args, start_token=vocab.SOS_ID, max_steps=steps - 5)
+            assert torch.equal(model.last_greedy_ids.t().contiguous(), ref[:, :steps - 5])
+    recorded = [v for v in model.engine._decode_lists.values() if not isinstance(v, str)]
+    assert len(recorded) == 1 and recorded[0].n > 20 * steps
     for b in range(3):
         exp = ''
         for t in ref[b].tolist():
