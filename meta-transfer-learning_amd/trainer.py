@@ -880,6 +880,11 @@ class TransientTrainer():
         """the read-back counters of a census iteration -> self.h2_census {operand: (share below 22 bits, share below 16 bits)} of
         the non-zero elements; acts per `h2_guard` when an operand's share below 16 bits exceeds `h2_limit`"""
         c = counters.numpy().reshape(-1, CENSUS_SLOTS, 4).sum(0)
+        if mdist.world_size() > 1:
+            # every rank samples on the same iterations: the counters are summed over the ranks (host collective), so that all of them
+            # see the same shares and take the same decision
+            flat = mdist.allreduce_scalars([float(v) for v in c.reshape(-1)], counters.device)
+            c = torch.tensor(flat, dtype=torch.float64).view(CENSUS_SLOTS, 4).numpy()
         self.h2_census = {CENSUS_NAMES[i]: (float(c[i, 1]) / max(int(c[i, 0]), 1), float(c[i, 2]) / max(int(c[i, 0]), 1))
                           for i in sorted(CENSUS_NAMES) if int(c[i, 0]) > 0}
         worst = max(self.h2_census, key=lambda k_: self.h2_census[k_][1], default=None)
