@@ -710,7 +710,7 @@ def main_lm(a, mtl_amd, mdist, dev, rank, world):
     dump_shapes(prof.records)
     classes = {}
     for name, args_, e0, e1 in prof.records:
-        cls, work, unit, sym = classify(mtl_amd._lib.lib(), name, args_, False, False)
+        cls, work, unit, sym = classify(mtl_amd._lib.lib(), name, args_, 'f32')
         cc = classes.setdefault(cls, dict(time=0.0, work=0.0, unit=unit, launches=0, symbols=sym))
         cc['time'] += e0.elapsed_time(e1) * 1e-3
         cc['work'] += work or 0.0
@@ -722,7 +722,7 @@ def main_lm(a, mtl_amd, mdist, dev, rank, world):
         for cls, cc in sorted(classes.items(), key=lambda kv: -kv[1]['time']):
             row = dict(ms_per_pass=cc['time'] / passes * 1e3, launches_per_pass=cc['launches'] / passes, symbols=cc['symbols'])
             if cc['unit'] is not None and cc['work'] > 0:
-                peak, unit, bound = peak_of(cls, cc['unit'], False, False)
+                peak, unit, bound = peak_of(cls, cc['unit'], 'f32')
                 ach = cc['work'] / cc['time'] / (1e12 if cc['unit'] == 'flop' else 1e9)
                 row.update(bound=bound, achieved=ach, peak=peak, unit=unit, frac=ach / peak)
             table[cls] = row

@@ -139,3 +139,21 @@ def test_self_launch_starts_the_ranks_for_real(tmp_path):
     assert r.returncode != 0
     assert 'WORLD_SIZE 1' not in r.stderr and 'bench.py needs an MI355X' in r.stderr, r.stderr[-2000:]
     assert r.stdout.strip() == ''
+
+
+def test_bench_helpers_are_called_with_their_current_signatures():
+    """bench.py's LM leg runs on the GPU only; a stale call of classify / peak_of there (round 6: two arguments too many after a switch was
+    removed) would only show up as an empty bench line on the GPU box -- checked here on the source"""
+    import ast
+    import inspect
+    bench = load_bench()
+    tree = ast.parse(open(os.path.join(ROOT, 'bench.py')).read())
+    want = {name: len(inspect.signature(getattr(bench, name)).parameters) for name in ('classify', 'peak_of', 'algorithmic_bytes', 'family_of', 'eval_leg', 'h2_frac')}
+    seen = {k: 0 for k in want}
+    for node in ast.walk(tree):
+        if isinstance(node, ast.Call) and isinstance(node.func, ast.Name) and node.func.id in want:
+            n = len(node.args) + len(node.keywords)
+            required = sum(p.default is inspect.Parameter.empty for p in inspect.signature(getattr(bench, node.func.id)).parameters.values())
+            assert required <= n <= want[node.func.id], (node.func.id, node.lineno, n)
+            seen[node.func.id] += 1
+    assert all(v > 0 for v in seen.values()), seen
