@@ -1091,6 +1091,17 @@ def main():
                                        note='1 of %d tasks on this GPU (configs[2] per-rank work, without the all-reduce): the two '
                                             'passes as one chain + side stream, one recorded command list' % a.tasks)
         del tr1
+        # ... and what one rank of the 2- and 4-GPU configurations runs (4 / 2 of the 8 tasks, global n = 8, no collective): with the
+        # headline (8 local tasks) and the one-task leg, the per-rank work of every N of the scaling curve, measured on ONE device
+        per_rank = {str(a.tasks): ms, '1': out['one_task_per_gpu']['ms_per_step']}
+        for local in (4, 2):
+            if a.tasks % local == 0 and a.tasks > local:
+                trl = mtl_amd.TransientTrainer()
+                dtl, _ = timed_steps(trl, model, vocab, tasks[:local], list(range(local)), a.tasks, inner, outer, args, k3, 4, mdist, dev)
+                per_rank[str(local)] = dtl / k3 * 1e3
+                del trl
+        out['per_rank_work_ms'] = dict(local_tasks=per_rank, note='step time of ONE rank holding this many of the %d tasks (global n = %d, no '
+                                       'all-reduce): the compute side of the 1 / 2 / 4 / 8-GPU points; not a scaling measurement' % (a.tasks, a.tasks))
         # what the h2 guard costs: the same steps with the census taken on EVERY iteration (it is taken on one in `h2_check_every`)
         trc = mtl_amd.TransientTrainer()
         trc.h2_check_every = 1
@@ -1200,6 +1211,8 @@ def compact_line(out):
             line[k] = _r(out[k]['value'], 3)
     if 'one_task_per_gpu' in out:
         line['one_task_per_gpu_ms'] = _r(out['one_task_per_gpu']['ms_per_step'], 3)
+    if 'per_rank_work_ms' in out:
+        line['per_rank_work_ms'] = {k_: _r(v_, 2) for k_, v_ in out['per_rank_work_ms']['local_tasks'].items()}
     ev = out.get('eval') or {}
     if 'greedy_decode' in ev:
         line['eval_utt_per_s'] = _r(ev['greedy_decode']['utt_per_s'], 2)

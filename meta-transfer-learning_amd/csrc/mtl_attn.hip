@@ -763,6 +763,73 @@ void launch_attn_bwd(const AttnP& p, int nqb, int nkb, hipStream_t s) {
 
 inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
+// ------------------------------------------------------------------ one query row per (batch, head): incremental decoding
+// A decoding step attends ONE new position of every hypothesis over the K / V cache (modules/decoder.py:131-185 re-runs the whole
+// decoder on the growing prefix; PassEngine's decode session keeps a cache): the 64-row flash tile above spends 63 of its rows on
+// nothing and 12.9 us per launch.  Here a workgroup owns one (batch, head): a thread scores one key (D fused multiply-adds on its own
+// cache row), the softmax statistics are two block reductions, and the weighted sum of the value rows is taken by D / 4 lanes per row
+// (16-byte loads, 256 / (D / 4) key groups, combined through LDS in a fixed order).  Exact fp32; the forward kernel's contract (klen
+// masks keys, lse = log-sum-exp of the scaled scores); no dropout, no causal flag (a single query sees its whole prefix through klen).
+constexpr int AD_MAXK = 4096;         // keys per (batch, head) the probabilities of which fit the workgroup's LDS
+template <int D>
+__global__ __launch_bounds__(256) void attn_decode_kernel(AttnP p) {
+    constexpr int LPR = D / 4, G = 256 / LPR;                       // lanes per value row, key groups
+    __shared__ float prob[AD_MAXK];
+    __shared__ float red[8];
+    __shared__ __attribute__((aligned(16))) float part[G][D];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
+    const int klim = p.klen ? min(p.klen[b], p.Tk) : p.Tk;
+    const float* kbase = p.k + (long)b * p.Tk * p.ldk + h * D;
+    const float* vbase = p.v + (long)b * p.Tk * p.ldv + h * D;
+    float4 q[LPR];
+#pragma unroll
+    for (int i = 0; i < LPR; ++i) q[i] = *reinterpret_cast<const float4*>(p.q + (long)b * p.ldq + h * D + 4 * i);
+    float mx = -INFINITY;
+    for (int j = tid; j < klim; j += 256) {
+        const float4* kr = reinterpret_cast<const float4*>(kbase + (long)j * p.ldk);
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < LPR; ++i) {
+            const float4 kv = kr[i];
+            s = fmaf(q[i].w, kv.w, fmaf(q[i].z, kv.z, fmaf(q[i].y, kv.y, fmaf(q[i].x, kv.x, s))));
+        }
+        s *= p.scale;
+        prob[j] = s;
+        mx = fmaxf(mx, s);
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red[w] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+    for (int j = tid; j < klim; j += 256) {
+        const float e = expf(prob[j] - mx);
+        prob[j] = e;
+        sum += e;
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) red[4 + w] = sum;
+    __syncthreads();
+    sum = (red[4] + red[5]) + (red[6] + red[7]);
+    const int l4 = tid % LPR, g = tid / LPR;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+    for (int j = g; j < klim; j += G) {
+        const float pj = prob[j];
+        const float4 vv = *reinterpret_cast<const float4*>(vbase + (long)j * p.ldv + 4 * l4);
+        acc.x = fmaf(pj, vv.x, acc.x), acc.y = fmaf(pj, vv.y, acc.y), acc.z = fmaf(pj, vv.z, acc.z), acc.w = fmaf(pj, vv.w, acc.w);
+    }
+    *reinterpret_cast<float4*>(&part[g][4 * l4]) = acc;
+    __syncthreads();
+    if (tid < D) {
+        float o = 0.f;
+        for (int gg = 0; gg < G; ++gg) o += part[gg][tid];
+        p.O[(long)b * p.ldo + h * D + tid] = klim > 0 ? o / sum : 0.f;
+    }
+    if (tid == 0) p.lse[bh] = klim > 0 ? mx + logf(sum) : -INFINITY;
+}
+
 bool attn_args_ok(const AttnP& p, int dk, int dv) {
     if (!p.q || !p.k || !p.v || p.B <= 0 || p.H <= 0 || p.Tq <= 0 || p.Tk <= 0) return false;
     if (!((dk == 64 && dv == 64) || (dk == 16 && dv == 16))) return false;
@@ -785,6 +852,14 @@ int mtl_attn_fwd(void* stream, const float* q, const float* k, const float* v, i
     p.q = q, p.k = k, p.v = v, p.ldq = ldq, p.ldk = ldk, p.ldv = ldv, p.klen = klen, p.causal = causal, p.scale = scale;
     p.B = B, p.H = H, p.Tq = Tq, p.Tk = Tk, p.pmask = pmask, p.ldm = ldm, p.pscale = pscale, p.O = O, p.ldo = ldo, p.lse = lse;
     if (!attn_args_ok(p, dk, dv) || !O || !lse || ldo < H * dv) return MTL_EINVAL;
+    if (Tq == 1 && !pmask && Tk <= AD_MAXK && (!causal || Tk == 1)) {      // one query row per (batch, head): the decode kernel
+        if (dk == 64)
+            hipLaunchKernelGGL(attn_decode_kernel<64>, dim3(B * H), dim3(256), 0, as_stream(stream), p);
+        else
+            hipLaunchKernelGGL(attn_decode_kernel<16>, dim3(B * H), dim3(256), 0, as_stream(stream), p);
+        MTL_CHECK_LAUNCH();
+        return MTL_OK;
+    }
     dim3 grid((Tq + AT_ROWS - 1) / AT_ROWS, B * H);
     if (dk == 64)
         hipLaunchKernelGGL((attn_fwd_kernel<64, 64>), grid, dim3(256), 0, as_stream(stream), p);

@@ -442,6 +442,9 @@ def test_layernorm(L, d):
     (3, 8, 9, 16, 16, 0, [16, 10, 3], 0.0),           # fixture head size (d_k = 16)
     (2, 8, 70, 70, 16, 1, [70, 9], 0.3),
     (2, 8, 2100, 2100, 64, 1, [2100, 900], 0.0),      # > 1024 workgroups: the backward's two-launch form (query side, then key side)
+    (8, 8, 1, 301, 64, 0, [1, 2, 64, 65, 150, 256, 257, 301], 0.0),     # ONE query row per (batch, head): the decode kernel over a K/V cache
+    (3, 8, 1, 250, 64, 0, None, 0.0),                 # ... cross-attention of a decoding step: every key
+    (2, 8, 1, 40, 16, 0, [40, 7], 0.0),               # ... fixture head size
 ])
 def test_fused_attention_forward_and_backward(L, B, H, Tq, Tk, dk, causal, klens, drop):
     """mtl_attn_fwd / mtl_attn_bwd against ScaledDotProductAttention written out in torch (modules/common_layers.py:317-331:
