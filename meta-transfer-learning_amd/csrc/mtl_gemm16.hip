@@ -26,6 +26,12 @@
 #include "mtl_common.h"
 #include "../../include/mtl_hip.h"
 
+#ifdef MTL_G16_PROBE
+// probe builds only (tools/probe/scan_g16.py, tools/probe/build_probes.sh): forced tile / K-group choice of the small-product engine
+static int g_g16_tile = 0, g_g16_kg = 0;
+extern "C" void mtl_probe_g16_force(int tile, int kg) { g_g16_tile = tile, g_g16_kg = kg; }
+#endif
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -410,13 +416,21 @@ int launch16(const G16P& p, int batch, hipStream_t s) {
     // grow the tile while the grid still holds about one chip-full of workgroups (256 CUs)
     // measured (tools/bench_gemm16.py): 32 x 32 tiles win or tie up to ~1000 workgroups; beyond that the larger tiles' operand
     // re-use pays (vocabulary-projection dX: 64 -> 57 us with 64 x 32)
-    int tile = wgs(1, 1) <= 1024 ? 1 : (wgs(2, 1) <= 1024 ? 2 : 3);
+    // (round 6 scan, tools/probe/scan_g16.py: 2000 x 512 x 512 and its K-batched rank-100 sibling -- 1008 tiles of 32 x 32 -- run 13 %
+    // faster on 64 x 32 tiles with two K groups; everything up to ~770 tiles stays on 32 x 32)
+    int tile = wgs(1, 1) <= 768 ? 1 : (wgs(2, 1) <= 1024 ? 2 : 3);
+#ifdef MTL_G16_PROBE
+    if (g_g16_tile) tile = g_g16_tile;
+#endif
     const long n_wg = tile == 3 ? wgs(2, 2) : (tile == 2 ? wgs(2, 1) : wgs(1, 1));
     // K groups: only while the chip is not already full of workgroups, and each group keeps >= 2 K tiles
     const long ktiles = (long)((p.K + TK - 1) / TK) * p.kb;
     int kg = 1;
     if (n_wg <= 320 && ktiles >= 8) kg = 4;
     else if (n_wg <= 640 && ktiles >= 4) kg = 2;
+#ifdef MTL_G16_PROBE
+    if (g_g16_kg) kg = g_g16_kg;
+#endif
     if (tile == 3) return launch_kg<TA, TB, 2, 2>(p, batch, s, kg == 4 ? 2 : kg);    // 64 x 64 x 4 groups would exceed 160 KiB of LDS
     if (tile == 2) return launch_kg<TA, TB, 2, 1>(p, batch, s, kg);
     return launch_kg<TA, TB, 1, 1>(p, batch, s, kg);

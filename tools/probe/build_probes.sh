@@ -18,3 +18,6 @@ $H --offload-arch=gfx950 -shared -fPIC $(ls $C/build/*.o | grep -v "/mtl_mfma.o"
 # conv2's data gradient without the edge-column kernel (the matrix kernel covers all 161 bins) for A/B runs: MTL_LIB=tools/probe/libmtl_noedge.so
 $H --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DMTL_DGRAD_EDGE=0 -c $C/mtl_mfma.hip -o /tmp/mtl_mfma_noedge.o
 $H --offload-arch=gfx950 -shared -fPIC $(ls $C/build/*.o | grep -v "/mtl_mfma.o") /tmp/mtl_mfma_noedge.o -o tools/probe/libmtl_noedge.so
+# the small-product engine with a forced tile / K-group choice (tools/probe/scan_g16.py): MTL_LIB=tools/probe/libmtl_g16probe.so
+$H --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DMTL_G16_PROBE -c $C/mtl_gemm16.hip -o /tmp/mtl_gemm16_probe.o
+$H --offload-arch=gfx950 -shared -fPIC $(ls $C/build/*.o | grep -v "/mtl_gemm16.o") /tmp/mtl_gemm16_probe.o -o tools/probe/libmtl_g16probe.so
