@@ -121,12 +121,28 @@ class _DecodeSession:
             for c in self.qkv:
                 eng.zero_(c)                                        # (masked keys are multiplied by probability 0: they must be finite)
             self.kc, self.vc = [c[1] for c in self.qkv], [c[2] for c in self.qkv]
-            self.ta3 = buf('g.ta3', (3, B, r))
             self.klen_self = buf('g.klen', (S, B), torch.int32)
             self.klen_self.copy_(torch.arange(1, S + 1, dtype=torch.int32).view(S, 1).expand(S, B))
             self.klen_cross = buf('g.klenx', (B,), torch.int32)
             self.klen_cross.fill_(T4)
             self.lse = buf('g.lse', (B, h, 1))
+            # the weights do not move during a decode: every rank-r pair  y = (x W_a^T) W_b^T  is applied as ONE product with
+            # W_b W_a (h d_k x d: 1 MB instead of 0.4 MB streamed per step, but one dependent launch instead of two -- a step is a
+            # chain of launches, not a bandwidth problem); merged once per session from the current theta (6 small products per layer)
+            self.Wqkv = [buf('g.wqkv%d' % i, (3, hk, d)) for i in range(hp.n_dec)]
+            self.Wso = [buf('g.wso%d' % i, (d, hv)) for i in range(hp.n_dec)]
+            self.Wcq = [buf('g.wcq%d' % i, (hk, d)) for i in range(hp.n_dec)]
+            self.Wco = [buf('g.wco%d' % i, (d, hv)) for i in range(hp.n_dec)]
+            for i in range(hp.n_dec):
+                pre = 'decoder.layers.%d.' % i
+                o = lambda n, pre=pre: self.P + 4 * eng.L.off(pre + n)
+                sA_, sB_ = (eng._pstride(pre + 'self_attn.', 'qkv', sfx) for sfx in ('_linear_a.weight', '_linear_b.weight'))
+                eng.gemm(0, 0, hk, d, r, o('self_attn.query_linear_b.weight'), r, o('self_attn.query_linear_a.weight'), d, self.Wqkv[i].data_ptr(), d,
+                         batch=3, sA=(sB_, 0), sB=(sA_, 0), sC=(hk * d, 0))
+                for att, dst in (('self_attn.', self.Wso[i]), ('encoder_attn.', self.Wco[i])):
+                    eng.gemm(0, 0, d, hv, r, o(att + 'output_linear_b.weight'), r, o(att + 'output_linear_a.weight'), hv, dst.data_ptr(), hv)
+                eng.gemm(0, 0, hk, d, r, o('encoder_attn.query_linear_b.weight'), r, o('encoder_attn.query_linear_a.weight'), d,
+                         self.Wcq[i].data_ptr(), d)
         else:
             self.kc = [buf('g.kc%d' % i, (B, S, hk)) for i in range(hp.n_dec)]
             self.vc = [buf('g.vc%d' % i, (B, S, hv)) for i in range(hp.n_dec)]
@@ -187,12 +203,10 @@ class _DecodeSession:
             o = lambda n: P + 4 * L.off(pre + n)
             sa = pre + 'self_attn.'
             if self.fast:
-                sA_, sB_, sb_ = (eng._pstride(sa, 'qkv', sfx) for sfx in ('_linear_a.weight', '_linear_b.weight', '_linear_b.bias'))
+                sb_ = eng._pstride(sa, 'qkv', '_linear_b.bias')
                 qkv = self.qkv[i].data_ptr()
-                eng.gemm(0, 1, B, hp.r, d, cur.data_ptr(), d, o('self_attn.query_linear_a.weight'), d, self.ta3.data_ptr(), hp.r, batch=3,
-                         sB=(sA_, 0), sC=(B * hp.r, 0))
-                eng.gemm(0, 1, B, hk, hp.r, self.ta3.data_ptr(), hp.r, o('self_attn.query_linear_b.weight'), hp.r, qkv + 4 * t * hk, S * hk,
-                         bias=o('self_attn.query_linear_b.bias'), batch=3, sA=(B * hp.r, 0), sB=(sB_, 0), sC=(B * S * hk, 0), sbias=sb_)
+                eng.gemm(0, 1, B, hk, d, cur.data_ptr(), d, self.Wqkv[i].data_ptr(), d, qkv + 4 * t * hk, S * hk,
+                         bias=o('self_attn.query_linear_b.bias'), batch=3, sB=(hk * d, 0), sC=(B * S * hk, 0), sbias=sb_)
                 check(lib.mtl_attn_fwd(eng.stream, qkv + 4 * t * hk, self.kc[i].data_ptr(), self.vc[i].data_ptr(), S * hk, hk, hv,
                                        self.klen_self.data_ptr() + 4 * t * B, 0, 1.0 / float(hp.temperature), B, hp.h, 1, S, hp.dk, hp.dv, None, 0,
                                        1.0, self.to.data_ptr(), hv, self.lse.data_ptr()), 'mtl_attn_fwd')
@@ -201,18 +215,30 @@ class _DecodeSession:
                 self._lowrank(sa, 'key', cur.data_ptr(), B, self.kc[i].data_ptr() + 4 * t * hk, ldc=S * hk)      # row t of the cache
                 self._lowrank(sa, 'value', cur.data_ptr(), B, self.vc[i].data_ptr() + 4 * t * hv, ldc=S * hv, width=hv)
                 self._attend(self.tq.data_ptr(), self.kc[i].data_ptr(), self.vc[i].data_ptr(), t + 1, S * hk, self.to.data_ptr())
-            self._lowrank(sa, 'output', self.to.data_ptr(), B, self.tob.data_ptr(), width=d)
+            if self.fast:
+                eng.gemm(0, 1, B, d, hv, self.to.data_ptr(), hv, self.Wso[i].data_ptr(), hv, self.tob.data_ptr(), d,
+                         bias=o('self_attn.output_linear_b.bias'))
+            else:
+                self._lowrank(sa, 'output', self.to.data_ptr(), B, self.tob.data_ptr(), width=d)
             eng.ln_fwd(self.tob.data_ptr(), cur.data_ptr(), o('self_attn.layer_norm.weight'), o('self_attn.layer_norm.bias'), None, None,
                        self.y1.data_ptr(), self.xhat.data_ptr(), self.rstd.data_ptr(), B, 1)
             ca = pre + 'encoder_attn.'
-            self._lowrank(ca, 'query', self.y1.data_ptr(), B, self.tq.data_ptr())
+            if self.fast:
+                eng.gemm(0, 1, B, hk, d, self.y1.data_ptr(), d, self.Wcq[i].data_ptr(), d, self.tq.data_ptr(), hk,
+                         bias=o('encoder_attn.query_linear_b.bias'))
+            else:
+                self._lowrank(ca, 'query', self.y1.data_ptr(), B, self.tq.data_ptr())
             if self.fast and self.cross_stride:      # (every row has its own memory: greedy search; beam search shares one with stride 0)
                 check(lib.mtl_attn_fwd(eng.stream, self.tq.data_ptr(), self.ck[i].data_ptr(), self.cv[i].data_ptr(), hk, hk, hv,
                                        self.klen_cross.data_ptr(), 0, 1.0 / float(hp.temperature), B, hp.h, 1, T4, hp.dk, hp.dv, None, 0, 1.0,
                                        self.to.data_ptr(), hv, self.lse.data_ptr()), 'mtl_attn_fwd')
             else:
                 self._attend(self.tq.data_ptr(), self.ck[i].data_ptr(), self.cv[i].data_ptr(), T4, self.cross_stride * hk, self.to.data_ptr())
-            self._lowrank(ca, 'output', self.to.data_ptr(), B, self.tob.data_ptr(), width=d)
+            if self.fast:
+                eng.gemm(0, 1, B, d, hv, self.to.data_ptr(), hv, self.Wco[i].data_ptr(), hv, self.tob.data_ptr(), d,
+                         bias=o('encoder_attn.output_linear_b.bias'))
+            else:
+                self._lowrank(ca, 'output', self.to.data_ptr(), B, self.tob.data_ptr(), width=d)
             eng.ln_fwd(self.tob.data_ptr(), self.y1.data_ptr(), o('encoder_attn.layer_norm.weight'), o('encoder_attn.layer_norm.bias'), None,
                        None, self.y2.data_ptr(), self.xhat.data_ptr(), self.rstd.data_ptr(), B, 1)
             eng.linear_fwd(self.y2.data_ptr(), B, d, o('pos_ffn.linear_1.weight'), o('pos_ffn.linear_1.bias'), self.h1.data_ptr(), hp.inner,
