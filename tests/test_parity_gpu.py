@@ -721,7 +721,7 @@ def test_greedy_decoding_matches_oracle():
             model.evaluate(x.cuda(), lens, y, args, start_token=vocab.SOS_ID, max_steps=steps - 5)
             assert torch.equal(model.last_greedy_ids.t().contiguous(), ref[:, :steps - 5])
     recorded = [v for v in model.engine._decode_lists.values() if not isinstance(v, str)]
-    assert len(recorded) == 1 and recorded[0].n >= 15 * steps
+    assert len(recorded) == 1 and recorded[0].n >= 12 * steps
     for b in range(3):
         exp = ''
         for t in ref[b].tolist():
