@@ -303,10 +303,10 @@ inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) =
 
 // ---- few-row products (incremental decoding: one new position of B hypotheses against every decoder weight, M = B rows) ----
 // C[M <= 16, N] (=|+=) alpha A[M, K] . W[N, K]^T (+ bias, ReLU): a weight-streaming product -- every weight is read once and multiplied
-// with all M rows.  The tile engine above pays a 32 x 32 MFMA tile and its K-group combine for it (~10 us); here a workgroup owns 16
-// output columns: a wave streams 4 weight rows with 16 lanes x 16 bytes each (256 contiguous bytes per row and step), A sits in LDS,
-// the 16 partial sums of a column meet by DPP shuffles.  Exact fp32 FMAs in a fixed order.
-constexpr int RW_COLS = 16, RW_KC = 1024;      // columns per workgroup; K chunk staged in LDS (16 rows x 1024 floats = 64 KiB)
+// with all M rows.  The tile engine above pays a 32 x 32 MFMA tile and its K-group combine for it (~10 us); here a workgroup owns 8
+// output columns: a wave streams 2 weight rows with 32 lanes x 16 bytes each (512 contiguous bytes per row and step: K = 512 in four
+// steps, all requested up front), A sits in LDS, the 32 partial sums of a column meet by shuffles.  Exact fp32 FMAs in a fixed order.
+constexpr int RW_COLS = 8, RW_KC = 1024;       // columns per workgroup (two per wave, 32 lanes each); K chunk staged in LDS (16 rows x 1024 floats = 64 KiB)
 struct RowsP {
     const float *A, *W;
     float* C;
@@ -319,17 +319,26 @@ struct RowsP {
 template <int MB>
 __global__ __launch_bounds__(256) void gemm_rows_kernel(RowsP p) {
     extern __shared__ __attribute__((aligned(16))) float rows_lds[];              // [MB][min(K, RW_KC)] (row stride kc)
-    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, col = lane >> 4, j = lane & 15;
+    constexpr int NW = RW_KC / 128;                                                // weight quads of a lane per chunk: k = 4 j + 128 i
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, col = lane >> 5, j = lane & 31;
     const int z = blockIdx.y;
     const float* A = p.A + z * p.sA;
     const float* W = p.W + z * p.sW;
-    const int n = blockIdx.x * RW_COLS + wv * 4 + col;
+    const int n = blockIdx.x * RW_COLS + wv * 2 + col;
     const float* wrow = W + (long)min(n, p.N - 1) * p.ldw;
     float acc[MB];
 #pragma unroll
     for (int m = 0; m < MB; ++m) acc[m] = 0.f;
     for (int k0 = 0; k0 < p.K; k0 += RW_KC) {
         const int kc = min(RW_KC, p.K - k0);                                      // (a multiple of 4)
+        // the chunk's weights of this lane are requested FIRST: they fly while the rows are staged (a step of a decode is a chain of
+        // such launches: what counts is the latency of one workgroup, not the bandwidth of the launch)
+        float4 w4[NW];
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int k = 4 * j + 128 * i;
+            w4[i] = k < kc ? *reinterpret_cast<const float4*>(wrow + k0 + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
         if (k0) __syncthreads();
         for (int e = tid * 4; e < MB * kc; e += 1024) {
             const int m = e / kc, k = e - m * kc;
@@ -337,20 +346,22 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(RowsP p) {
                 m < p.M ? *reinterpret_cast<const float4*>(A + (long)m * p.lda + k0 + k) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         __syncthreads();
-#pragma unroll 4
-        for (int k = 4 * j; k < kc; k += 64) {
-            const float4 w4 = *reinterpret_cast<const float4*>(wrow + k0 + k);
 #pragma unroll
-            for (int m = 0; m < MB; ++m) {
-                const float4 a4 = *reinterpret_cast<const float4*>(rows_lds + m * kc + k);
-                acc[m] = fmaf(a4.w, w4.w, fmaf(a4.z, w4.z, fmaf(a4.y, w4.y, fmaf(a4.x, w4.x, acc[m]))));
+        for (int i = 0; i < NW; ++i) {
+            const int k = 4 * j + 128 * i;
+            if (k < kc) {
+#pragma unroll
+                for (int m = 0; m < MB; ++m) {
+                    const float4 a4 = *reinterpret_cast<const float4*>(rows_lds + m * kc + k);
+                    acc[m] = fmaf(a4.w, w4[i].w, fmaf(a4.z, w4[i].z, fmaf(a4.y, w4[i].y, fmaf(a4.x, w4[i].x, acc[m]))));
+                }
             }
         }
     }
 #pragma unroll
     for (int m = 0; m < MB; ++m) {
 #pragma unroll
-        for (int o = 8; o > 0; o >>= 1) acc[m] += __shfl_xor(acc[m], o, 64);      // the 16 lanes of a column: fixed tree
+        for (int o = 16; o > 0; o >>= 1) acc[m] += __shfl_xor(acc[m], o, 64);     // the 32 lanes of a column: fixed tree
     }
     if (n < p.N) {
         const float bb = p.bias ? p.bias[z * p.sBias + n] : 0.f;
