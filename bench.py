@@ -655,6 +655,21 @@ def eval_leg(mtl, trainer, model, vocab, args, k, frames, labels, dev, reps=4, d
                                                        'parameters (%.1f MB) are the algorithmic traffic of a step' % (k, dec_bytes / 1e6)),
                                     note='Transformer.evaluate greedy: encoder pass + %d K/V-cached decoder steps, token feedback on the '
                                          'device, one read-back (models/asr/transformer.py:162-202, modules/decoder.py:131-185)' % decode_steps)
+        # beam search (modules/decoder.py:187-291, the reference's test-time default: width 3, 5 best): one utterance at a time, the
+        # hypothesis bookkeeping on the host as in the reference, one K/V-cached device step per position for all live hypotheses
+        bargs = argparse.Namespace(**vars(args))
+        bargs.beam_width, bargs.beam_nbest = 3, 5
+        nb = min(2, k)
+        model.evaluate(x[:nb], lens[:nb], y[:nb], bargs, beam_search=True, start_token=vocab.SOS_ID)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        model.evaluate(x[:nb], lens[:nb], y[:nb], bargs, beam_search=True, start_token=vocab.SOS_ID)
+        torch.cuda.synchronize(dev)
+        dtb = time.perf_counter() - t0
+        steps_b = max(len(h_) for h_ in model.last_beam_ids) - 1 if getattr(model, 'last_beam_ids', None) else 0
+        out['beam_search'] = dict(utt_per_s=nb / dtb, ms_per_utterance=dtb / nb * 1e3, beam_width=3, nbest=5, utterances=nb, longest_hypothesis=steps_b,
+                                  note='Transformer.evaluate(beam_search=True): per utterance up to T\' = %d positions, one device step + one '
+                                       'read-back of the logits per position (the host ranks the hypotheses as the reference does)' % ((frames // 2) // 2))
     finally:
         model.train()
     return out
@@ -1225,6 +1240,8 @@ def compact_line(out):
     if 'greedy_decode' in ev:
         line['eval_utt_per_s'] = _r(ev['greedy_decode']['utt_per_s'], 2)
         line['valid_loop_utt_per_s'] = _r(ev['valid_loop']['utt_per_s'], 1)
+    if 'beam_search' in ev:
+        line['beam_utt_per_s'] = _r(ev['beam_search']['utt_per_s'], 2)
     for k in ('multi_gpu', 'last_step', 'theta_checksum', 'extras_error', 'detail'):
         if k in out:
             line[k] = out[k]
