@@ -1511,6 +1511,40 @@ class PassEngine:
             raise ValueError('bad beam search arguments')
         ses = self.decode_session(theta, mem_row, W, T4, steps, shared_memory=True)
         toks = self.buf('b.tok', (W,), torch.int64)
+        hyp_buf = self.buf('g.hyp', (W,), torch.int64)
+        # the device side of position i (one decoder step for the W rows + log-sum-exp) is the same call sequence for every utterance:
+        # eager at its first sighting, recorded into a command list at the second, replayed from C afterwards (as greedy_decode does for
+        # all its steps at once; here the host ranks the hypotheses between two positions, so there is one list per position)
+        key = ('beam', theta.data_ptr(), W, T4, steps, toks.data_ptr(), self.stream, ses.fast)
+        store = self.__dict__.setdefault('_beam_lists', {})
+        ent = store.get(key)
+        if ent is None or ent['epoch'] != self.scratch_epoch:
+            while len(store) >= 2:
+                store.pop(next(iter(store)))
+            ent = store[key] = dict(epoch=self.scratch_epoch, seen=set(), lists={})
+
+        def body(i):
+            ses.step(i, toks.data_ptr())
+            ses.argmax_into(hyp_buf.data_ptr())                   # (leaves the log-sum-exp of the W rows in ses.junk[:W])
+
+        def device_step(i):
+            cl = ent['lists'].get(i)
+            if self.prof is not None or isinstance(self.lib, _lib.Recorder) or ent['epoch'] != self.scratch_epoch:
+                body(i)
+            elif cl is not None:
+                cl.run()
+            elif i in ent['seen']:
+                cl, real = _lib.CommandList(), self.lib
+                self.lib = _lib.Recorder(real, cl)
+                try:
+                    body(i)
+                finally:
+                    self.lib = real
+                if ent['epoch'] == self.scratch_epoch:
+                    ent['lists'][i] = cl.finish()
+            else:
+                ent['seen'].add(i)
+                body(i)
         hyps = [dict(score=np.float32(0.0), yseq=[int(start_token)], row=0)]
         ended = []
         for i in range(steps):
@@ -1519,8 +1553,8 @@ class PassEngine:
             if i > 0:
                 ses.reorder(rows, i)                              # row r of the caches <- its parent's rows 0..i-1
             toks.copy_(torch.tensor([h['yseq'][-1] for h in hyps] + [int(eos_id)] * (W - n), dtype=torch.int64))
-            ses.step(i, toks.data_ptr())
-            logits, lse = ses.logits_and_lse()
+            device_step(i)
+            logits, lse = ses.logits.cpu(), ses.junk[:W].cpu()
             local = (logits[:n] - lse[:n].unsqueeze(1))           # F.log_softmax of the last position, fp32
             kept = []
             for r, h in enumerate(hyps):
